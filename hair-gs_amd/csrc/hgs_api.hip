@@ -1,0 +1,161 @@
+// hgs_api.hip -- the extern "C" surface declared in include/hgs.h (host code only).
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "hgs_common.h"
+
+static thread_local char g_err[512] = "";
+
+void hgs_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+static int check_aligned(const void* p, const char* what) {
+  if (!p || ((size_t)p & (HGS_ALIGN - 1))) {
+    hgs_set_error("%s must be a non-null %d-byte aligned device pointer", what, HGS_ALIGN);
+    return 1;
+  }
+  return 0;
+}
+
+extern "C" {
+
+int hgs_abi_version(void) { return HGS_ABI_VERSION; }
+const char* hgs_last_error(void) { return g_err; }
+
+size_t hgs_geom_bytes(int P) { HgsGeom g; return hgs_geom_carve(nullptr, (size_t)(P > 0 ? P : 0), g, nullptr); }
+size_t hgs_image_bytes(int W, int H) { HgsImage im; return hgs_image_carve(nullptr, (size_t)W, (size_t)H, im, nullptr); }
+size_t hgs_binning_bytes(int R) { HgsBinning b; return hgs_binning_carve(nullptr, (size_t)(R > 0 ? R : 0), b, nullptr); }
+size_t hgs_backward_scratch_bytes(int P, int R) {
+  (void)P;
+  return hgs_align_up((size_t)(R > 0 ? R : 0) * HGS_INST_GRAD_FLOATS * sizeof(float)) + HGS_ALIGN;
+}
+int hgs_geom_layout(int P, size_t* offsets) { HgsGeom g; hgs_geom_carve(nullptr, (size_t)P, g, offsets); return 0; }
+int hgs_image_layout(int W, int H, size_t* offsets) { HgsImage im; hgs_image_carve(nullptr, (size_t)W, (size_t)H, im, offsets); return 0; }
+int hgs_binning_layout(int R, size_t* offsets) { HgsBinning b; hgs_binning_carve(nullptr, (size_t)R, b, offsets); return 0; }
+
+int hgs_forward_preprocess(void* stream, int P, int D, int M, int W, int H, const float* means3D, const float* shs,
+                           const float* colors_precomp, const float* opacities, const float* scales,
+                           float scale_modifier, const float* rotations, const float* cov3D_precomp,
+                           const float* viewmatrix, const float* projmatrix, const float* campos, float tan_fovx,
+                           float tan_fovy, int prefiltered, void* geom_buf, void* image_buf, int* radii,
+                           int* num_rendered_host) {
+  hipStream_t s = (hipStream_t)stream;
+  if (P < 0 || W <= 0 || H <= 0) { hgs_set_error("bad sizes P=%d W=%d H=%d", P, W, H); return 1; }
+  if (D < 0 || D > 3) { hgs_set_error("sh degree %d unsupported (0..3)", D); return 1; }
+  if (check_aligned(image_buf, "image_buf")) return 1;
+  HgsImage im;
+  hgs_image_carve((char*)image_buf, (size_t)W, (size_t)H, im, nullptr);
+  const int T = ((W + HGS_TILE - 1) / HGS_TILE) * ((H + HGS_TILE - 1) / HGS_TILE);
+  HGS_CHECK_HIP(hipMemsetAsync(im.tile_count, 0, ((size_t)3 * T + HGS_STATUS_WORDS) * sizeof(uint32_t), s));
+  if (P == 0) {  // reference short-circuits P == 0 (rasterize_points.cu:81)
+    HGS_CHECK_HIP(hipMemsetAsync(im.ranges, 0, (size_t)T * sizeof(uint2), s));
+    if (num_rendered_host) { HGS_CHECK_HIP(hipStreamSynchronize(s)); *num_rendered_host = 0; }
+    return 0;
+  }
+  if (check_aligned(geom_buf, "geom_buf")) return 1;
+  if (!means3D || !opacities || !viewmatrix || !projmatrix || !campos || !radii) { hgs_set_error("null required input"); return 1; }
+  if ((shs == nullptr) == (colors_precomp == nullptr)) { hgs_set_error("provide exactly one of shs / colors_precomp"); return 1; }
+  if (((scales == nullptr) || (rotations == nullptr)) == (cov3D_precomp == nullptr)) {
+    hgs_set_error("provide exactly one of (scales, rotations) / cov3D_precomp"); return 1;
+  }
+  if (shs && M < (D + 1) * (D + 1)) { hgs_set_error("M=%d SH coefficients < (D+1)^2 for D=%d", M, D); return 1; }
+  HgsGeom g;
+  hgs_geom_carve((char*)geom_buf, (size_t)P, g, nullptr);
+  HgsFwdArgs a;
+  a.P = P; a.D = D; a.M = M; a.W = W; a.H = H;
+  a.means3D = means3D; a.shs = shs; a.colors_precomp = colors_precomp; a.opacities = opacities; a.scales = scales;
+  a.rotations = rotations; a.cov3D_precomp = cov3D_precomp; a.viewmatrix = viewmatrix; a.projmatrix = projmatrix;
+  a.campos = campos; a.scale_modifier = scale_modifier; a.tan_fovx = tan_fovx; a.tan_fovy = tan_fovy;
+  a.prefiltered = prefiltered;
+  if (hgs_launch_preprocess_fwd(s, a, g, im, radii)) return 1;
+  if (hgs_launch_scan(s, P, T, g, im)) return 1;
+  if (num_rendered_host) {
+    uint32_t r = 0;
+    HGS_CHECK_HIP(hipMemcpyAsync(&r, im.status, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    HGS_CHECK_HIP(hipStreamSynchronize(s));
+    *num_rendered_host = (int)r;
+  }
+  return 0;
+}
+
+int hgs_forward_render(void* stream, int P, int W, int H, int R_capacity, const float* bg, const float* colors_precomp,
+                       void* geom_buf, void* binning_buf, void* image_buf, float* out_color) {
+  hipStream_t s = (hipStream_t)stream;
+  if (check_aligned(image_buf, "image_buf")) return 1;
+  if (!bg || !out_color) { hgs_set_error("null bg/out_color"); return 1; }
+  HgsImage im;
+  hgs_image_carve((char*)image_buf, (size_t)W, (size_t)H, im, nullptr);
+  HgsGeom g = {};
+  HgsBinning b = {};
+  if (P > 0) {
+    if (check_aligned(geom_buf, "geom_buf")) return 1;
+    hgs_geom_carve((char*)geom_buf, (size_t)P, g, nullptr);
+    if (R_capacity > 0) {
+      if (check_aligned(binning_buf, "binning_buf")) return 1;
+      hgs_binning_carve((char*)binning_buf, (size_t)R_capacity, b, nullptr);
+      const float* feat = colors_precomp ? colors_precomp : g.rgb;
+      if (hgs_launch_scatter(s, P, W, H, R_capacity, nullptr, g, im, b)) return 1;
+      if (hgs_launch_sort_tiles(s, W, H, R_capacity, feat, g, im, b)) return 1;
+    }
+  }
+  return hgs_launch_blend_fwd(s, W, H, bg, im, b, out_color);
+}
+
+int hgs_backward(void* stream, int P, int D, int M, int R, int W, int H, const float* bg, const float* means3D,
+                 const float* shs, const float* colors_precomp, const float* scales, float scale_modifier,
+                 const float* rotations, const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix,
+                 const float* campos, float tan_fovx, float tan_fovy, const int* radii, const void* geom_buf,
+                 const void* binning_buf, const void* image_buf, const float* dL_dpix, void* scratch,
+                 float* dL_dmeans2D, float* dL_dconic, float* dL_dopacity, float* dL_dcolors, float* dL_dmeans3D,
+                 float* dL_dcov3D, float* dL_dsh, float* dL_dscales, float* dL_drotations) {
+  hipStream_t s = (hipStream_t)stream;
+  if (P == 0) return 0;  // rasterize_points.cu:161
+  if (check_aligned(geom_buf, "geom_buf") || check_aligned(image_buf, "image_buf")) return 1;
+  if (!dL_dpix || !radii || !means3D) { hgs_set_error("null required input"); return 1; }
+  if (!dL_dmeans2D || !dL_dconic || !dL_dopacity || !dL_dcolors || !dL_dmeans3D || !dL_dcov3D || !dL_dscales ||
+      !dL_drotations || (shs && !dL_dsh)) { hgs_set_error("null gradient output"); return 1; }
+  HgsGeom g;
+  HgsImage im;
+  HgsBinning b = {};
+  hgs_geom_carve((char*)geom_buf, (size_t)P, g, nullptr);
+  hgs_image_carve((char*)image_buf, (size_t)W, (size_t)H, im, nullptr);
+  float* inst_grad = nullptr;
+  if (R > 0) {
+    if (check_aligned(binning_buf, "binning_buf") || check_aligned(scratch, "scratch")) return 1;
+    hgs_binning_carve((char*)binning_buf, (size_t)R, b, nullptr);
+    inst_grad = (float*)scratch;
+    HGS_CHECK_HIP(hipMemsetAsync(inst_grad, 0, (size_t)R * HGS_INST_GRAD_FLOATS * sizeof(float), s));
+    if (hgs_launch_blend_bwd(s, W, H, bg, im, b, dL_dpix, inst_grad)) return 1;
+  }
+  HgsBwdArgs a;
+  a.P = P; a.D = D; a.M = M; a.W = W; a.H = H;
+  a.means3D = means3D; a.shs = shs; a.colors_precomp = colors_precomp; a.scales = scales; a.rotations = rotations;
+  a.cov3D_precomp = cov3D_precomp; a.viewmatrix = viewmatrix; a.projmatrix = projmatrix; a.campos = campos;
+  a.scale_modifier = scale_modifier; a.tan_fovx = tan_fovx; a.tan_fovy = tan_fovy; a.radii = radii;
+  a.dL_dmeans2D = dL_dmeans2D; a.dL_dconic = dL_dconic; a.dL_dopacity = dL_dopacity; a.dL_dcolors = dL_dcolors;
+  a.dL_dmeans3D = dL_dmeans3D; a.dL_dcov3D = dL_dcov3D; a.dL_dsh = dL_dsh; a.dL_dscales = dL_dscales;
+  a.dL_drotations = dL_drotations;
+  return hgs_launch_preprocess_bwd(s, a, g, b, inst_grad);
+}
+
+int hgs_mark_visible(void* stream, int P, const float* means3D, const float* viewmatrix, const float* projmatrix,
+                     uint8_t* present) {
+  (void)projmatrix;  // the reference computes p_proj but only tests view-space z (auxiliary.h:149-154)
+  if (P == 0) return 0;
+  if (!means3D || !viewmatrix || !present) { hgs_set_error("null input"); return 1; }
+  return hgs_launch_mark_visible((hipStream_t)stream, P, means3D, viewmatrix, present);
+}
+
+size_t hgs_dist2_scratch_bytes(int P) { return hgs_dist2_scratch(P > 0 ? P : 0); }
+int hgs_dist2(void* stream, int P, const float* points, float* out, void* scratch, size_t scratch_bytes) {
+  if (P == 0) return 0;
+  if (!points || !out) { hgs_set_error("null input"); return 1; }
+  return hgs_launch_dist2((hipStream_t)stream, P, points, out, scratch, scratch_bytes);
+}
+
+}  // extern "C"

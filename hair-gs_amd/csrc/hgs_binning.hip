@@ -1,0 +1,152 @@
+// hgs_binning.hip -- tile binning without a global sort.
+//
+// The reference sorts R (tile<<32|depth, id) pairs with one 44/45-bit stable CUB radix sort
+// (cuda_rasterizer/rasterizer_impl.cu:300-308) after emitting them in Gaussian order (:70-111), then finds
+// tile boundaries (:116-138).  Because a Gaussian appears at most once per tile, that stable order is the
+// total order (tile, depth_bits, gaussian_id).  Here:
+//   scan_kernel        exclusive prefix over the per-tile counts -> `ranges` directly (no boundary search),
+//                      and over the per-block instance sums -> per-Gaussian offsets (replaces DeviceScan :277)
+//   sort_tiles_kernel  one workgroup per tile sorts its segment by the unique 64-bit key
+//                      depth_bits<<32|id in LDS (bitonic), emits point_list in final order, the packed
+//                      per-instance records the blend kernels stream, and the inverse index the
+//                      deterministic backward gather uses.
+// Result: identical point_list/ranges, ~10x less sort traffic than 144 B/instance, no stability needed.
+#include "hgs_common.h"
+
+namespace {
+
+#define SCAN_THREADS 1024
+#define SORT_CAP 2048  // keys per LDS chunk (16 KB)
+
+// generic helper: scans `n` uint32 values with one 1024-thread block; calls emit(i, exclusive, value)
+template <typename F>
+__device__ __forceinline__ uint32_t block_scan(const uint32_t* in, int n, uint32_t* wtot, F emit) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  uint32_t carry = 0;
+  for (int base = 0; base < n; base += SCAN_THREADS) {
+    const int i = base + tid;
+    const uint32_t v = i < n ? in[i] : 0u;
+    const uint32_t incl = hgs_wave_incl_scan(v, lane);
+    if (lane == 63) wtot[wave] = incl;
+    __syncthreads();
+    uint32_t woff = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < SCAN_THREADS / 64; w++) {
+      const uint32_t t = wtot[w];
+      if (w < wave) woff += t;
+      total += t;
+    }
+    if (i < n) emit(i, carry + woff + incl - v, v);
+    carry += total;
+    __syncthreads();
+  }
+  return carry;
+}
+
+__global__ __launch_bounds__(SCAN_THREADS) void scan_kernel(int nblk, int T, HgsGeom g, HgsImage im) {
+  __shared__ uint32_t wtot[SCAN_THREADS / 64];
+  uint32_t* bs = g.block_sums;
+  block_scan(bs, nblk, wtot, [&](int i, uint32_t excl, uint32_t) { bs[i] = excl; });
+  uint2* ranges = im.ranges;
+  const uint32_t R = block_scan(im.tile_count, T, wtot, [&](int i, uint32_t excl, uint32_t v) {
+    ranges[i] = v ? make_uint2(excl, excl + v) : make_uint2(0u, 0u);  // empty tiles stay (0,0): memset at :310
+  });
+  if (threadIdx.x == 0) im.status[0] = R;
+}
+
+__device__ __forceinline__ void emit_instance(uint64_t key, uint32_t pos, int tx, int ty, const float* __restrict__ feat,
+                                              const HgsGeom& g, const HgsBinning& b) {
+  const uint32_t id = (uint32_t)key;
+  b.point_list[pos] = id;
+  b.keys_sorted[pos] = key;
+  const float2 xy = g.means2D[id];
+  const float4 co = g.conic_opacity[id];
+  const float f0 = feat[3 * (size_t)id], f1 = feat[3 * (size_t)id + 1], f2 = feat[3 * (size_t)id + 2];
+  float4* rec = b.packed + (size_t)pos * (HGS_PACKED_FLOATS / 4);
+  rec[0] = make_float4(xy.x, xy.y, co.x, co.y);
+  rec[1] = make_float4(co.z, co.w, f0, f1);
+  rec[2] = make_float4(f2, __uint_as_float(id), 0.f, 0.f);
+  const HgsRect rc = g.rect[id];
+  const uint32_t k = (uint32_t)(ty - rc.y0) * (uint32_t)(rc.x1 - rc.x0) + (uint32_t)(tx - rc.x0);
+  b.inv[rc.off + k] = pos;
+}
+
+__device__ __forceinline__ void bitonic_lds(uint64_t* sk, int m) {
+  for (int k = 2; k <= m; k <<= 1) {
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int t = threadIdx.x; t < (m >> 1); t += HGS_BLOCK) {
+        const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+        const int l = i | j;
+        const bool asc = (i & k) == 0;
+        const uint64_t x = sk[i], y = sk[l];
+        if ((x > y) == asc) { sk[i] = y; sk[l] = x; }
+      }
+      __syncthreads();
+    }
+  }
+}
+
+__global__ __launch_bounds__(HGS_BLOCK) void sort_tiles_kernel(int gx, uint32_t Rcap, const float* __restrict__ feat,
+                                                               HgsGeom g, HgsImage im, HgsBinning b) {
+  __shared__ uint64_t sk[SORT_CAP];
+  const int tile = blockIdx.x;
+  const uint2 range = im.ranges[tile];
+  if (range.y <= range.x || range.y > Rcap) return;  // empty, or binning buffer overflow (status[1] already set)
+  const uint32_t start = range.x, n = range.y - range.x;
+  const int tx = tile % gx, ty = tile / gx;
+  const uint32_t nchunks = (n + SORT_CAP - 1) / SORT_CAP;
+  for (uint32_t c = 0; c < nchunks; c++) {
+    const uint32_t cbase = start + c * SORT_CAP;
+    const uint32_t cn = min((uint32_t)SORT_CAP, n - c * SORT_CAP);
+    int m = 2;
+    while ((uint32_t)m < cn) m <<= 1;
+    for (int i = threadIdx.x; i < m; i += HGS_BLOCK) sk[i] = (uint32_t)i < cn ? b.keys[cbase + i] : ~0ull;
+    __syncthreads();
+    bitonic_lds(sk, m);
+    if (nchunks == 1) {
+      for (uint32_t i = threadIdx.x; i < cn; i += HGS_BLOCK) emit_instance(sk[i], cbase + i, tx, ty, feat, g, b);
+    } else {
+      for (uint32_t i = threadIdx.x; i < cn; i += HGS_BLOCK) b.keys[cbase + i] = sk[i];
+    }
+    __syncthreads();
+  }
+  if (nchunks > 1) {
+    // long list: chunks are sorted; the final rank of a key = its index in its chunk + the number of smaller keys
+    // in every other chunk (keys are unique).  O(n * nchunks * log CAP), only for tiles with > SORT_CAP entries.
+    __threadfence_block();
+    __syncthreads();
+    for (uint32_t e = threadIdx.x; e < n; e += HGS_BLOCK) {
+      const uint64_t key = b.keys[start + e];
+      const uint32_t c = e / SORT_CAP;
+      uint32_t rank = e - c * SORT_CAP;
+      for (uint32_t c2 = 0; c2 < nchunks; c2++) {
+        if (c2 == c) continue;
+        const uint64_t* ck = b.keys + start + c2 * SORT_CAP;
+        uint32_t lo = 0, hi = min((uint32_t)SORT_CAP, n - c2 * SORT_CAP);
+        while (lo < hi) {
+          const uint32_t mid = (lo + hi) >> 1;
+          if (ck[mid] < key) lo = mid + 1; else hi = mid;
+        }
+        rank += lo;
+      }
+      emit_instance(key, start + rank, tx, ty, feat, g, b);
+    }
+  }
+}
+
+}  // namespace
+
+int hgs_launch_scan(hipStream_t s, int P, int T, const HgsGeom& g, const HgsImage& im) {
+  const int nblk = (P + HGS_BLOCK - 1) / HGS_BLOCK;
+  hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(SCAN_THREADS), 0, s, nblk, T, g, im);
+  HGS_CHECK_LAUNCH();
+  return 0;
+}
+
+int hgs_launch_sort_tiles(hipStream_t s, int W, int H, int Rcap, const float* features, const HgsGeom& g,
+                          const HgsImage& im, const HgsBinning& b) {
+  const int gx = (W + HGS_TILE - 1) / HGS_TILE, gy = (H + HGS_TILE - 1) / HGS_TILE;
+  hipLaunchKernelGGL(sort_tiles_kernel, dim3(gx * gy), dim3(HGS_BLOCK), 0, s, gx, (uint32_t)Rcap, features, g, im, b);
+  HGS_CHECK_LAUNCH();
+  return 0;
+}

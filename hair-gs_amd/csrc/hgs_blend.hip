@@ -1,0 +1,194 @@
+// hgs_blend.hip -- per-tile alpha compositing, forward and backward, for wave64.
+//
+// replaces renderCUDA (cuda_rasterizer/forward.cu:261-374) and renderCUDABW_* (backward_distwar.cu:400-1014).
+//
+// CDNA4 mapping (not the reference's 256-entry shared-memory staging):
+//   * a 16x16 tile = one 256-thread workgroup = 4 wavefronts; wavefront w owns the 8x8 pixel quadrant
+//     (w&1, w>>1): compact footprints make whole-wave rejection of thin strand Gaussians likely;
+//   * the tile's depth-sorted instance records (48 B: xy, conic, opacity, rgb, id; written by
+//     sort_tiles_kernel) are wave-uniform data: they are streamed with SCALAR loads (s_load_dwordx4) straight
+//     into SGPRs and used as SGPR operands of the per-pixel VALU math -- no LDS staging, no barriers in the
+//     forward, each wavefront leaves its loop on its own when its 64 pixels are saturated;
+//   * backward: per (wave, entry) the 9 partial sums are reduced across the 64 lanes, the 4 wavefronts'
+//     results are combined through LDS in fixed order and written ONCE per (tile, entry) with plain stores
+//     into an instance-indexed scratch; preprocess_bwd gathers them per Gaussian through the inverse index.
+//     No float atomics anywhere -> gradients are bitwise reproducible run to run (the reference's are not).
+#include "hgs_common.h"
+
+namespace {
+
+#define BWD_BATCH 64   // entries combined per LDS flush in the backward
+#define NPART 9        // dmean2D.xy, dconic.x/.y/.w, dopacity, dcolor.rgb
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+  return v;
+}
+
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(HGS_BLOCK) void blend_fwd_kernel(const uint2* __restrict__ ranges,
+                                                              const float4* __restrict__ packed, int W, int H, int gx,
+                                                              const float* __restrict__ bg, float* __restrict__ final_T,
+                                                              uint32_t* __restrict__ n_contrib,
+                                                              uint32_t* __restrict__ tile_maxc,
+                                                              float* __restrict__ out_color) {
+  const int tile = blockIdx.x;
+  const int tx = tile % gx, ty = tile / gx;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int px = tx * HGS_TILE + (wave & 1) * 8 + (lane & 7);
+  const int py = ty * HGS_TILE + (wave >> 1) * 8 + (lane >> 3);
+  const bool inside = px < W && py < H;
+  const float pxf = (float)px, pyf = (float)py;
+  const uint2 range = ranges[tile];
+  float T = 1.f, C0 = 0.f, C1 = 0.f, C2 = 0.f;
+  uint32_t last = 0;
+  bool done = !inside;
+  for (uint32_t j = range.x; j < range.y; ++j) {
+    if (__ballot(!done) == 0) break;  // forward.cu:309-311, per wavefront instead of per block
+    const float4 r0 = packed[3 * (size_t)j], r1 = packed[3 * (size_t)j + 1];
+    const float dx = r0.x - pxf, dy = r0.y - pyf;
+    const float power = -0.5f * (r0.z * dx * dx + r1.x * dy * dy) - r0.w * dx * dy;  // forward.cu:335
+    const float alpha = fminf(0.99f, r1.y * __expf(power));                           // :343
+    bool ok = !done && power <= 0.f && alpha >= (1.0f / 255.0f);                      // :336, :344
+    if (__ballot(ok) == 0) continue;
+    const float test_T = T * (1.f - alpha);
+    if (ok && test_T < 0.0001f) { done = true; ok = false; }                          // :346-351
+    if (ok) {
+      const float b2 = packed[3 * (size_t)j + 2].x;
+      const float w = alpha * T;
+      C0 += r1.z * w; C1 += r1.w * w; C2 += b2 * w;                                   // :354-355
+      T = test_T;
+      last = j - range.x + 1;                                                         // :328, :361
+    }
+  }
+  uint32_t wmax = last;
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) wmax = max(wmax, (uint32_t)__shfl_xor((int)wmax, d, 64));
+  if (lane == 0 && wmax) atomicMax(&tile_maxc[tile], wmax);
+  if (inside) {
+    const size_t pix = (size_t)py * W + px, HW = (size_t)H * W;
+    final_T[pix] = T;
+    n_contrib[pix] = last;
+    out_color[pix] = C0 + T * bg[0];                                                  // :372
+    out_color[HW + pix] = C1 + T * bg[1];
+    out_color[2 * HW + pix] = C2 + T * bg[2];
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(HGS_BLOCK) void blend_bwd_kernel(const uint2* __restrict__ ranges,
+                                                              const float4* __restrict__ packed, int W, int H, int gx,
+                                                              const float* __restrict__ bg,
+                                                              const float* __restrict__ final_Ts,
+                                                              const uint32_t* __restrict__ n_contrib,
+                                                              const uint32_t* __restrict__ tile_maxc,
+                                                              const float* __restrict__ dL_dpix,
+                                                              float* __restrict__ inst_grad) {
+  __shared__ float part[4][BWD_BATCH][NPART];
+  const int tile = blockIdx.x;
+  const uint2 range = ranges[tile];
+  const uint32_t maxc = tile_maxc[tile];
+  if (maxc == 0) return;  // nothing in this tile contributed to any pixel (inst_grad rows stay zero)
+  const int tx = tile % gx, ty = tile / gx;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int px = tx * HGS_TILE + (wave & 1) * 8 + (lane & 7);
+  const int py = ty * HGS_TILE + (wave >> 1) * 8 + (lane >> 3);
+  const bool inside = px < W && py < H;
+  const float pxf = (float)px, pyf = (float)py;
+  const size_t pix = (size_t)py * W + px, HW = (size_t)H * W;
+
+  const float T_final = inside ? final_Ts[pix] : 0.f;
+  float T = T_final;
+  const uint32_t last = inside ? n_contrib[pix] : 0u;
+  float dpx0 = 0.f, dpx1 = 0.f, dpx2 = 0.f;
+  if (inside) { dpx0 = dL_dpix[pix]; dpx1 = dL_dpix[HW + pix]; dpx2 = dL_dpix[2 * HW + pix]; }
+  const float bg_dot_dpixel = bg[0] * dpx0 + bg[1] * dpx1 + bg[2] * dpx2;   // backward_distwar.cu:988-990
+  float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, lc0 = 0.f, lc1 = 0.f, lc2 = 0.f, last_alpha = 0.f;
+  const float ddelx_dx = 0.5f * W, ddely_dy = 0.5f * H;                       // :917-918
+
+  for (int i = threadIdx.x; i < 4 * BWD_BATCH * NPART; i += HGS_BLOCK) (&part[0][0][0])[i] = 0.f;
+  __syncthreads();
+
+  // walk the list back to front in batches of BWD_BATCH positions; position p (0-based) is valid for a pixel
+  // iff p < n_contrib (backward_distwar.cu:943-945)
+  for (int hi = (int)maxc; hi > 0; hi -= BWD_BATCH) {
+    const int lo = max(0, hi - BWD_BATCH);
+    for (int p = hi - 1; p >= lo; --p) {
+      const uint32_t j = range.x + (uint32_t)p;
+      const float4 r0 = packed[3 * (size_t)j], r1 = packed[3 * (size_t)j + 1];
+      const float dx = r0.x - pxf, dy = r0.y - pyf;
+      const float power = -0.5f * (r0.z * dx * dx + r1.x * dy * dy) - r0.w * dx * dy;
+      const float G = __expf(power);
+      const float alpha = fminf(0.99f, r1.y * G);
+      const bool ok = (uint32_t)p < last && power <= 0.f && alpha >= (1.0f / 255.0f);
+      if (__ballot(ok) == 0) continue;
+      float v[NPART];
+#pragma unroll
+      for (int k = 0; k < NPART; k++) v[k] = 0.f;
+      if (ok) {
+        const float c0 = r1.z, c1 = r1.w, c2 = packed[3 * (size_t)j + 2].x;
+        const float one_m_a = 1.f - alpha;
+        T = T / one_m_a;                                                      // :960
+        const float dchannel_dcolor = alpha * T;
+        acc0 = last_alpha * lc0 + (1.f - last_alpha) * acc0;                  // :972
+        acc1 = last_alpha * lc1 + (1.f - last_alpha) * acc1;
+        acc2 = last_alpha * lc2 + (1.f - last_alpha) * acc2;
+        lc0 = c0; lc1 = c1; lc2 = c2;
+        float dL_dalpha = (c0 - acc0) * dpx0 + (c1 - acc1) * dpx1 + (c2 - acc2) * dpx2;
+        v[6] = dchannel_dcolor * dpx0; v[7] = dchannel_dcolor * dpx1; v[8] = dchannel_dcolor * dpx2;
+        dL_dalpha *= T;
+        last_alpha = alpha;
+        dL_dalpha += (-T_final / one_m_a) * bg_dot_dpixel;                    // :991
+        const float dL_dG = r1.y * dL_dalpha;
+        const float gdx = G * dx, gdy = G * dy;
+        const float dG_ddelx = -gdx * r0.z - gdy * r0.w;
+        const float dG_ddely = -gdy * r1.x - gdx * r0.w;
+        v[0] = dL_dG * dG_ddelx * ddelx_dx;                                   // :1002-1003
+        v[1] = dL_dG * dG_ddely * ddely_dy;
+        v[2] = -0.5f * gdx * dx * dL_dG;                                      // :1006-1008
+        v[3] = -0.5f * gdx * dy * dL_dG;
+        v[4] = -0.5f * gdy * dy * dL_dG;
+        v[5] = G * dL_dalpha;                                                 // :1011
+      }
+#pragma unroll
+      for (int k = 0; k < NPART; k++) v[k] = wave_sum(v[k]);
+      if (lane < NPART) {
+        float mine = v[0];
+#pragma unroll
+        for (int k = 1; k < NPART; k++) mine = (lane == k) ? v[k] : mine;
+        part[wave][p - lo][lane] = mine;
+      }
+    }
+    __syncthreads();
+    // combine the 4 wavefronts in fixed order and store one row per (tile, entry)
+    const int cnt = hi - lo;
+    for (int i = threadIdx.x; i < cnt * NPART; i += HGS_BLOCK) {
+      const int e = i / NPART, k = i - e * NPART;
+      const float s = ((part[0][e][k] + part[1][e][k]) + part[2][e][k]) + part[3][e][k];
+      inst_grad[(size_t)(range.x + lo + e) * HGS_INST_GRAD_FLOATS + k] = s;
+      part[0][e][k] = 0.f; part[1][e][k] = 0.f; part[2][e][k] = 0.f; part[3][e][k] = 0.f;
+    }
+    __syncthreads();
+  }
+}
+
+}  // namespace
+
+int hgs_launch_blend_fwd(hipStream_t s, int W, int H, const float* bg, const HgsImage& im, const HgsBinning& b,
+                         float* out_color) {
+  const int gx = (W + HGS_TILE - 1) / HGS_TILE, gy = (H + HGS_TILE - 1) / HGS_TILE;
+  hipLaunchKernelGGL(blend_fwd_kernel, dim3(gx * gy), dim3(HGS_BLOCK), 0, s, im.ranges, b.packed, W, H, gx, bg,
+                     im.final_T, im.n_contrib, im.tile_maxc, out_color);
+  HGS_CHECK_LAUNCH();
+  return 0;
+}
+
+int hgs_launch_blend_bwd(hipStream_t s, int W, int H, const float* bg, const HgsImage& im, const HgsBinning& b,
+                         const float* dL_dpix, float* inst_grad) {
+  const int gx = (W + HGS_TILE - 1) / HGS_TILE, gy = (H + HGS_TILE - 1) / HGS_TILE;
+  hipLaunchKernelGGL(blend_bwd_kernel, dim3(gx * gy), dim3(HGS_BLOCK), 0, s, im.ranges, b.packed, W, H, gx, bg,
+                     im.final_T, im.n_contrib, im.tile_maxc, dL_dpix, inst_grad);
+  HGS_CHECK_LAUNCH();
+  return 0;
+}

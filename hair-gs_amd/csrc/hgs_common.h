@@ -1,0 +1,149 @@
+// hgs_common.h -- shared declarations of libhgs.so (gfx950 only; wave64 is assumed everywhere).
+//
+// Workspace layout (all sub-arrays 256-B aligned inside caller-owned byte buffers):
+//   geom    (per Gaussian)  depths, clamped, means2D, cov3D, conic_opacity, rgb, tiles_touched,
+//                           point_offsets, rect(+exclusive instance offset), block_sums
+//   image   (per pixel/tile) final_T, n_contrib, ranges, tile_count, tile_cursor, tile_maxc, status
+//   binning (per instance)  keys (depth<<32|id), point_list, packed records, inverse index, sorted keys
+// They play the roles of GeometryState / ImageState / BinningState of the reference
+// (cuda_rasterizer/rasterizer_impl.h:23-71) but the layout is this library's own.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+
+#include "../../include/hgs.h"
+
+#define HGS_BLOCK 256   // threads per workgroup for per-Gaussian kernels and per-tile kernels (4 waves)
+#define HGS_WAVE 64
+#define HGS_ALIGN 256
+
+struct HgsRect {        // 16 B per Gaussian: tile rectangle + exclusive instance offset
+  uint16_t x0, y0, x1, y1;
+  uint32_t off;         // exclusive prefix of tiles_touched (filled by the scatter kernel)
+  uint32_t pad;
+};
+
+struct HgsGeom {
+  float* depths; uint8_t* clamped; float2* means2D; float* cov3D; float4* conic_opacity; float* rgb;
+  uint32_t* tiles_touched; uint32_t* point_offsets; HgsRect* rect; uint32_t* block_sums;
+};
+struct HgsImage {
+  float* final_T; uint32_t* n_contrib; uint2* ranges; uint32_t* tile_count; uint32_t* tile_cursor;
+  uint32_t* tile_maxc; uint32_t* status;
+};
+struct HgsBinning {
+  uint64_t* keys; uint32_t* point_list; float4* packed; uint32_t* inv; uint64_t* keys_sorted;
+};
+
+static inline size_t hgs_align_up(size_t v) { return (v + HGS_ALIGN - 1) & ~(size_t)(HGS_ALIGN - 1); }
+
+template <typename T>
+static inline void hgs_carve(char*& cur, T*& ptr, size_t count) {
+  cur = (char*)hgs_align_up((size_t)cur);
+  ptr = (T*)cur;
+  cur += count * sizeof(T);
+}
+
+static inline size_t hgs_geom_carve(char* base, size_t P, HgsGeom& g, size_t* offs) {
+  char* cur = base;
+  size_t nblk = (P + HGS_BLOCK - 1) / HGS_BLOCK;
+  hgs_carve(cur, g.depths, P);              if (offs) offs[HGS_GEOM_DEPTHS] = (char*)g.depths - base;
+  hgs_carve(cur, g.clamped, 3 * P);         if (offs) offs[HGS_GEOM_CLAMPED] = (char*)g.clamped - base;
+  hgs_carve(cur, g.means2D, P);             if (offs) offs[HGS_GEOM_MEANS2D] = (char*)g.means2D - base;
+  hgs_carve(cur, g.cov3D, 6 * P);           if (offs) offs[HGS_GEOM_COV3D] = (char*)g.cov3D - base;
+  hgs_carve(cur, g.conic_opacity, P);       if (offs) offs[HGS_GEOM_CONIC_OPACITY] = (char*)g.conic_opacity - base;
+  hgs_carve(cur, g.rgb, 3 * P);             if (offs) offs[HGS_GEOM_RGB] = (char*)g.rgb - base;
+  hgs_carve(cur, g.tiles_touched, P);       if (offs) offs[HGS_GEOM_TILES_TOUCHED] = (char*)g.tiles_touched - base;
+  hgs_carve(cur, g.point_offsets, P);       if (offs) offs[HGS_GEOM_POINT_OFFSETS] = (char*)g.point_offsets - base;
+  hgs_carve(cur, g.rect, P);                if (offs) offs[HGS_GEOM_RECT] = (char*)g.rect - base;
+  hgs_carve(cur, g.block_sums, nblk + 1);   if (offs) offs[HGS_GEOM_BLOCK_SUMS] = (char*)g.block_sums - base;
+  return hgs_align_up((size_t)(cur - base)) + HGS_ALIGN;
+}
+static inline size_t hgs_image_carve(char* base, size_t W, size_t H, HgsImage& im, size_t* offs) {
+  char* cur = base;
+  size_t N = W * H, T = ((W + HGS_TILE - 1) / HGS_TILE) * ((H + HGS_TILE - 1) / HGS_TILE);
+  hgs_carve(cur, im.final_T, N);            if (offs) offs[HGS_IMG_FINAL_T] = (char*)im.final_T - base;
+  hgs_carve(cur, im.n_contrib, N);          if (offs) offs[HGS_IMG_N_CONTRIB] = (char*)im.n_contrib - base;
+  hgs_carve(cur, im.ranges, T);             if (offs) offs[HGS_IMG_RANGES] = (char*)im.ranges - base;
+  // the next four are zeroed together by one memset in hgs_forward_preprocess
+  hgs_carve(cur, im.tile_count, T);         if (offs) offs[HGS_IMG_TILE_COUNT] = (char*)im.tile_count - base;
+  im.tile_cursor = im.tile_count + T;       if (offs) offs[HGS_IMG_TILE_CURSOR] = (char*)im.tile_cursor - base;
+  im.tile_maxc = im.tile_cursor + T;        if (offs) offs[HGS_IMG_TILE_MAXC] = (char*)im.tile_maxc - base;
+  im.status = im.tile_maxc + T;             if (offs) offs[HGS_IMG_STATUS] = (char*)im.status - base;
+  cur += (3 * T + HGS_STATUS_WORDS) * sizeof(uint32_t);
+  return hgs_align_up((size_t)(cur - base)) + HGS_ALIGN;
+}
+static inline size_t hgs_binning_carve(char* base, size_t R, HgsBinning& b, size_t* offs) {
+  char* cur = base;
+  hgs_carve(cur, b.keys, R);                                  if (offs) offs[HGS_BIN_KEYS] = (char*)b.keys - base;
+  hgs_carve(cur, b.point_list, R);                            if (offs) offs[HGS_BIN_POINT_LIST] = (char*)b.point_list - base;
+  hgs_carve(cur, b.packed, R * (HGS_PACKED_FLOATS / 4) + 4);  if (offs) offs[HGS_BIN_PACKED] = (char*)b.packed - base;
+  hgs_carve(cur, b.inv, R);                                   if (offs) offs[HGS_BIN_INV] = (char*)b.inv - base;
+  hgs_carve(cur, b.keys_sorted, R);                           if (offs) offs[HGS_BIN_KEYS_TMP] = (char*)b.keys_sorted - base;
+  return hgs_align_up((size_t)(cur - base)) + HGS_ALIGN;
+}
+
+// ---- error plumbing -------------------------------------------------------------------------
+void hgs_set_error(const char* fmt, ...);
+#define HGS_CHECK_HIP(expr)                                                                       \
+  do {                                                                                            \
+    hipError_t _e = (expr);                                                                       \
+    if (_e != hipSuccess) {                                                                       \
+      hgs_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__);   \
+      return 1;                                                                                   \
+    }                                                                                             \
+  } while (0)
+#define HGS_CHECK_LAUNCH() HGS_CHECK_HIP(hipGetLastError())
+
+// ---- launchers implemented in the kernel translation units -------------------------------------
+struct HgsFwdArgs {
+  int P, D, M, W, H;
+  const float *means3D, *shs, *colors_precomp, *opacities, *scales, *rotations, *cov3D_precomp;
+  const float *viewmatrix, *projmatrix, *campos;
+  float scale_modifier, tan_fovx, tan_fovy;
+  int prefiltered;
+};
+int hgs_launch_preprocess_fwd(hipStream_t s, const HgsFwdArgs& a, const HgsGeom& g, const HgsImage& im, int* radii);
+int hgs_launch_scan(hipStream_t s, int P, int T, const HgsGeom& g, const HgsImage& im);
+int hgs_launch_scatter(hipStream_t s, int P, int W, int H, int Rcap, const int* radii, const HgsGeom& g,
+                       const HgsImage& im, const HgsBinning& b);
+int hgs_launch_sort_tiles(hipStream_t s, int W, int H, int Rcap, const float* features, const HgsGeom& g,
+                          const HgsImage& im, const HgsBinning& b);
+int hgs_launch_blend_fwd(hipStream_t s, int W, int H, const float* bg, const HgsImage& im, const HgsBinning& b,
+                         float* out_color);
+int hgs_launch_blend_bwd(hipStream_t s, int W, int H, const float* bg, const HgsImage& im, const HgsBinning& b,
+                         const float* dL_dpix, float* inst_grad);
+struct HgsBwdArgs {
+  int P, D, M, W, H;
+  const float *means3D, *shs, *colors_precomp, *scales, *rotations, *cov3D_precomp;
+  const float *viewmatrix, *projmatrix, *campos;
+  float scale_modifier, tan_fovx, tan_fovy;
+  const int* radii;
+  float *dL_dmeans2D, *dL_dconic, *dL_dopacity, *dL_dcolors, *dL_dmeans3D, *dL_dcov3D, *dL_dsh, *dL_dscales,
+      *dL_drotations;
+};
+int hgs_launch_preprocess_bwd(hipStream_t s, const HgsBwdArgs& a, const HgsGeom& g, const HgsBinning& b,
+                              const float* inst_grad);
+int hgs_launch_mark_visible(hipStream_t s, int P, const float* means3D, const float* viewmatrix, uint8_t* present);
+int hgs_launch_dist2(hipStream_t s, int P, const float* points, float* out, void* scratch, size_t scratch_bytes);
+size_t hgs_dist2_scratch(int P);
+
+// ---- device helpers ----------------------------------------------------------------------------
+#ifdef __HIPCC__
+// float -> int with the hardware's saturating semantics made explicit (NaN -> 0).
+__device__ __forceinline__ int hgs_f2i(float v) {
+  if (v != v) return 0;
+  v = fminf(fmaxf(v, -2147483648.f), 2147483520.f);
+  return (int)v;
+}
+// wave64 inclusive scan / reductions on 32-bit values through ds_bpermute-free DPP-less shuffles.
+__device__ __forceinline__ uint32_t hgs_wave_incl_scan(uint32_t v, int lane) {
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    uint32_t o = __shfl_up(v, d, 64);
+    if (lane >= d) v += o;
+  }
+  return v;
+}
+#endif

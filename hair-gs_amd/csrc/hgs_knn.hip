@@ -1,0 +1,239 @@
+// hgs_knn.hip -- distCUDA2: mean squared distance to the 3 nearest neighbours (simple-knn/simple_knn.cu).
+//
+// Same plan as the reference (origin-including bounding box :192-201, 30-bit Morton codes :46-71, stable sort
+// by code :207-214, 1024-point boxes :79-118, box-pruned exact search :148-184) with these CDNA4 choices:
+//   * no host round trips: min/max stay on the device (the reference does two blocking D2H copies);
+//   * the stable (code, index) sort is a sort by the unique 64-bit key code<<32|index -> plain bitonic network
+//     (LDS for strides < 4096, global otherwise); called once per run, P <= a few million;
+//   * points are gathered once into Morton order; the search runs one lane per point with WAVE-level box
+//     pruning: a box is visited if any lane of the wavefront needs it, and then its points are wave-uniform
+//     -> scalar loads.  Visiting extra boxes cannot change the 3 smallest distances, so the result is exactly
+//     the reference's (it is the exact 3-NN; only traversal differs).
+#include <float.h>
+
+#include "hgs_common.h"
+
+namespace {
+
+#define BOX_SIZE 1024
+#define KNN_LDS_KEYS 4096
+
+struct KnnScratch { float* minmax; uint64_t* keys; float4* sorted; float* boxes; };
+
+__device__ __forceinline__ uint32_t prep_morton(uint32_t x) {
+  x = (x | (x << 16)) & 0x030000FF;
+  x = (x | (x << 8)) & 0x0300F00F;
+  x = (x | (x << 4)) & 0x030C30C3;
+  x = (x | (x << 2)) & 0x09249249;
+  return x;
+}
+__device__ __forceinline__ uint32_t f2u_sat(float v) {
+  if (!(v > 0.f)) return 0u;
+  if (v >= 4294967040.f) return 0xFFFFFFFFu;
+  return (uint32_t)v;
+}
+
+// one block: component-wise min/max with init (0,0,0) (simple_knn.cu:192)
+__global__ __launch_bounds__(1024) void minmax_kernel(int P, const float* __restrict__ pts, float* __restrict__ mm) {
+  __shared__ float red[16][6];
+  float mn[3] = {0.f, 0.f, 0.f}, mx[3] = {0.f, 0.f, 0.f};
+  for (int i = threadIdx.x; i < P; i += 1024)
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      const float v = pts[3 * (size_t)i + k];
+      mn[k] = fminf(mn[k], v);
+      mx[k] = fmaxf(mx[k], v);
+    }
+#pragma unroll
+  for (int k = 0; k < 3; k++)
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+      mn[k] = fminf(mn[k], __shfl_xor(mn[k], d, 64));
+      mx[k] = fmaxf(mx[k], __shfl_xor(mx[k], d, 64));
+    }
+  const int wave = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0)
+    for (int k = 0; k < 3; k++) { red[wave][k] = mn[k]; red[wave][3 + k] = mx[k]; }
+  __syncthreads();
+  if (threadIdx.x < 6) {
+    float v = red[0][threadIdx.x];
+    for (int w = 1; w < 16; w++) v = threadIdx.x < 3 ? fminf(v, red[w][threadIdx.x]) : fmaxf(v, red[w][threadIdx.x]);
+    mm[threadIdx.x] = v;
+  }
+}
+
+__global__ __launch_bounds__(256) void morton_kernel(int P, int Npad, const float* __restrict__ pts,
+                                                     const float* __restrict__ mm, uint64_t* __restrict__ keys) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= Npad) return;
+  if (i >= P) { keys[i] = ~0ull; return; }
+  const float mnx = mm[0], mny = mm[1], mnz = mm[2], mxx = mm[3], mxy = mm[4], mxz = mm[5];
+  const float x = pts[3 * (size_t)i], y = pts[3 * (size_t)i + 1], z = pts[3 * (size_t)i + 2];
+  const uint32_t cx = prep_morton(f2u_sat(((x - mnx) / (mxx - mnx)) * 1023));
+  const uint32_t cy = prep_morton(f2u_sat(((y - mny) / (mxy - mny)) * 1023));
+  const uint32_t cz = prep_morton(f2u_sat(((z - mnz) / (mxz - mnz)) * 1023));
+  keys[i] = ((uint64_t)(cx | (cy << 1) | (cz << 2)) << 32) | (uint32_t)i;
+}
+
+// bitonic steps j = jstart .. 1 of stage k inside LDS chunks of KNN_LDS_KEYS keys (jstart < KNN_LDS_KEYS);
+// with full=true runs every stage k = 2..KNN_LDS_KEYS (initial chunk sort)
+__global__ __launch_bounds__(1024) void bitonic_lds_kernel(uint64_t* __restrict__ keys, int k_stage, int jstart, bool full) {
+  __shared__ uint64_t sk[KNN_LDS_KEYS];
+  const size_t base = (size_t)blockIdx.x * KNN_LDS_KEYS;
+  for (int i = threadIdx.x; i < KNN_LDS_KEYS; i += 1024) sk[i] = keys[base + i];
+  __syncthreads();
+  const int k0 = full ? 2 : k_stage, k1 = full ? KNN_LDS_KEYS : k_stage;
+  for (int k = k0; k <= k1; k <<= 1) {
+    for (int j = full ? (k >> 1) : jstart; j > 0; j >>= 1) {
+      for (int t = threadIdx.x; t < KNN_LDS_KEYS / 2; t += 1024) {
+        const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+        const int l = i | j;
+        const bool asc = (((base + i) & (size_t)k) == 0);
+        const uint64_t x = sk[i], y = sk[l];
+        if ((x > y) == asc) { sk[i] = y; sk[l] = x; }
+      }
+      __syncthreads();
+    }
+    if (!full) break;
+  }
+  for (int i = threadIdx.x; i < KNN_LDS_KEYS; i += 1024) keys[base + i] = sk[i];
+}
+
+__global__ __launch_bounds__(256) void bitonic_global_kernel(uint64_t* __restrict__ keys, size_t half, int k, int j) {
+  const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (t >= half) return;
+  const size_t i = ((t & ~((size_t)j - 1)) << 1) | (t & ((size_t)j - 1));
+  const size_t l = i | (size_t)j;
+  const bool asc = (i & (size_t)k) == 0;
+  const uint64_t x = keys[i], y = keys[l];
+  if ((x > y) == asc) { keys[i] = y; keys[l] = x; }
+}
+
+__global__ __launch_bounds__(256) void gather_kernel(int P, const float* __restrict__ pts, const uint64_t* __restrict__ keys,
+                                                     float4* __restrict__ sorted) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= P) return;
+  const uint32_t id = (uint32_t)keys[i];
+  sorted[i] = make_float4(pts[3 * (size_t)id], pts[3 * (size_t)id + 1], pts[3 * (size_t)id + 2], __uint_as_float(id));
+}
+
+// one 1024-thread block per box (simple_knn.cu:79-118): AABB of 1024 Morton-consecutive points
+__global__ __launch_bounds__(BOX_SIZE) void box_minmax_kernel(int P, const float4* __restrict__ sorted, float* __restrict__ boxes) {
+  __shared__ float red[16][6];
+  const int i = blockIdx.x * BOX_SIZE + threadIdx.x;
+  float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+  if (i < P) {
+    const float4 p = sorted[i];
+    mn[0] = mx[0] = p.x; mn[1] = mx[1] = p.y; mn[2] = mx[2] = p.z;
+  }
+#pragma unroll
+  for (int k = 0; k < 3; k++)
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+      mn[k] = fminf(mn[k], __shfl_xor(mn[k], d, 64));
+      mx[k] = fmaxf(mx[k], __shfl_xor(mx[k], d, 64));
+    }
+  const int wave = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0)
+    for (int k = 0; k < 3; k++) { red[wave][k] = mn[k]; red[wave][3 + k] = mx[k]; }
+  __syncthreads();
+  if (threadIdx.x < 6) {
+    float v = red[0][threadIdx.x];
+    for (int w = 1; w < 16; w++) v = threadIdx.x < 3 ? fminf(v, red[w][threadIdx.x]) : fmaxf(v, red[w][threadIdx.x]);
+    boxes[8 * (size_t)blockIdx.x + threadIdx.x] = v;
+  }
+}
+
+__device__ __forceinline__ void kbest3(float px, float py, float pz, float qx, float qy, float qz, float* knn) {
+  const float dx = qx - px, dy = qy - py, dz = qz - pz;
+  float dist = dx * dx + dy * dy + dz * dz;  // simple_knn.cu:135-136 (no contraction: built with -ffp-contract=off)
+#pragma unroll
+  for (int j = 0; j < 3; j++) {
+    const float t = knn[j];
+    const bool sw = t > dist;
+    knn[j] = sw ? dist : t;
+    dist = sw ? t : dist;
+  }
+}
+
+__global__ __launch_bounds__(256) void mean_dist_kernel(int P, const float4* __restrict__ sorted,
+                                                        const float* __restrict__ boxes, float* __restrict__ out) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  const bool active = idx < P;
+  const float4 me = sorted[active ? idx : P - 1];
+  float best[3] = {FLT_MAX, FLT_MAX, FLT_MAX};
+  if (active) {
+    const int lo = max(0, idx - 3), hi = min(P - 1, idx + 3);
+    for (int i = lo; i <= hi; i++) {
+      if (i == idx) continue;
+      const float4 q = sorted[i];
+      kbest3(me.x, me.y, me.z, q.x, q.y, q.z, best);
+    }
+  }
+  const float reject = best[2];
+  best[0] = best[1] = best[2] = FLT_MAX;
+  const int nb = (P + BOX_SIZE - 1) / BOX_SIZE;
+  for (int b = 0; b < nb; b++) {
+    const float* bx = boxes + 8 * (size_t)b;
+    float d0 = 0.f, d1 = 0.f, d2 = 0.f;  // distBoxPoint, simple_knn.cu:120-130
+    if (me.x < bx[0] || me.x > bx[3]) d0 = fminf(fabsf(me.x - bx[0]), fabsf(me.x - bx[3]));
+    if (me.y < bx[1] || me.y > bx[4]) d1 = fminf(fabsf(me.y - bx[1]), fabsf(me.y - bx[4]));
+    if (me.z < bx[2] || me.z > bx[5]) d2 = fminf(fabsf(me.z - bx[2]), fabsf(me.z - bx[5]));
+    const float dist = d0 * d0 + d1 * d1 + d2 * d2;
+    const bool need = active && !(dist > reject || dist > best[2]);
+    if (__ballot(need) == 0) continue;  // wave-uniform
+    const int i0 = b * BOX_SIZE, i1 = min(P, (b + 1) * BOX_SIZE);
+    for (int i = i0; i < i1; i++) {
+      const float4 q = sorted[i];  // wave-uniform address -> scalar load
+      if (i != idx) kbest3(me.x, me.y, me.z, q.x, q.y, q.z, best);
+    }
+  }
+  if (active) out[__float_as_uint(me.w)] = (best[0] + best[1] + best[2]) / 3.0f;
+}
+
+size_t knn_carve(char* base, size_t P, size_t Npad, KnnScratch& s) {
+  char* cur = base;
+  hgs_carve(cur, s.minmax, 8);
+  hgs_carve(cur, s.keys, Npad);
+  hgs_carve(cur, s.sorted, P + 1);
+  hgs_carve(cur, s.boxes, 8 * ((P + BOX_SIZE - 1) / BOX_SIZE + 1));
+  return hgs_align_up((size_t)(cur - base)) + HGS_ALIGN;
+}
+size_t pad_pow2(size_t P) {
+  size_t n = KNN_LDS_KEYS;
+  while (n < P) n <<= 1;
+  return n;
+}
+
+}  // namespace
+
+size_t hgs_dist2_scratch(int P) {
+  KnnScratch s;
+  return knn_carve(nullptr, (size_t)P, pad_pow2((size_t)P), s);
+}
+
+int hgs_launch_dist2(hipStream_t st, int P, const float* points, float* out, void* scratch, size_t scratch_bytes) {
+  const size_t Npad = pad_pow2((size_t)P);
+  KnnScratch s;
+  knn_carve((char*)scratch, (size_t)P, Npad, s);
+  if (hgs_dist2_scratch(P) > scratch_bytes || ((size_t)scratch & (HGS_ALIGN - 1))) {
+    hgs_set_error("hgs_dist2: scratch must be %d-byte aligned and >= %zu bytes (got %zu)", HGS_ALIGN, hgs_dist2_scratch(P), scratch_bytes);
+    return 1;
+  }
+  hipLaunchKernelGGL(minmax_kernel, dim3(1), dim3(1024), 0, st, P, points, s.minmax);
+  hipLaunchKernelGGL(morton_kernel, dim3((unsigned)((Npad + 255) / 256)), dim3(256), 0, st, P, (int)Npad, points, s.minmax, s.keys);
+  const unsigned nchunks = (unsigned)(Npad / KNN_LDS_KEYS);
+  hipLaunchKernelGGL(bitonic_lds_kernel, dim3(nchunks), dim3(1024), 0, st, s.keys, 0, 0, true);
+  for (size_t k = 2 * KNN_LDS_KEYS; k <= Npad; k <<= 1) {
+    size_t j = k >> 1;
+    for (; j >= KNN_LDS_KEYS; j >>= 1)
+      hipLaunchKernelGGL(bitonic_global_kernel, dim3((unsigned)((Npad / 2 + 255) / 256)), dim3(256), 0, st, s.keys, Npad / 2, (int)k, (int)j);
+    hipLaunchKernelGGL(bitonic_lds_kernel, dim3(nchunks), dim3(1024), 0, st, s.keys, (int)k, (int)j, false);
+  }
+  const unsigned nb = (unsigned)((P + BOX_SIZE - 1) / BOX_SIZE);
+  hipLaunchKernelGGL(gather_kernel, dim3((P + 255) / 256), dim3(256), 0, st, P, points, s.keys, s.sorted);
+  hipLaunchKernelGGL(box_minmax_kernel, dim3(nb), dim3(BOX_SIZE), 0, st, P, s.sorted, s.boxes);
+  hipLaunchKernelGGL(mean_dist_kernel, dim3((P + 255) / 256), dim3(256), 0, st, P, s.sorted, s.boxes, out);
+  HGS_CHECK_LAUNCH();
+  return 0;
+}

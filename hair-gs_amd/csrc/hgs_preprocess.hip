@@ -1,0 +1,495 @@
+// hgs_preprocess.hip -- per-Gaussian kernels (one lane per Gaussian, 256-thread workgroups):
+//   preprocess_fwd   cull, cov3D, EWA cov2D, conic, radius, tile rect, SH->RGB, per-tile instance counts
+//                    replaces preprocessCUDA (cuda_rasterizer/forward.cu:155-256)
+//   scatter          instance emission into per-tile segments (replaces duplicateWithKeys,
+//                    cuda_rasterizer/rasterizer_impl.cu:70-111, and the P-wide InclusiveSum :277)
+//   preprocess_bwd   per-instance gradient gather + computeCov2DCUDA + preprocessCUDA(bwd)
+//                    (cuda_rasterizer/backward_distwar.cu:145-275, 347-397) in one pass
+//   mark_visible     checkFrustum (cuda_rasterizer/rasterizer_impl.cu:54-66)
+//
+// Built with -ffp-contract=off: every fp32 expression that decides a radius, a tile rectangle or a
+// depth key is evaluated operation by operation in the reference's order (glm column-major products,
+// type_mat3x3.inl:486-520), so keys/rects are bit-identical to the CPU oracle.
+#include "hgs_common.h"
+
+namespace {
+
+__device__ const float kSH_C0 = 0.28209479177387814f;
+__device__ const float kSH_C1 = 0.4886025119029199f;
+__device__ const float kSH_C2[5] = {1.0925484305920792f, -1.0925484305920792f, 0.31539156525252005f,
+                                    -1.0925484305920792f, 0.5462742152960396f};
+__device__ const float kSH_C3[7] = {-0.5900435899266435f, 2.890611442640554f, -0.4570457994644658f,
+                                    0.3731763325901154f,  -0.4570457994644658f, 1.445305721320277f,
+                                    -0.5900435899266435f};
+
+struct V3 { float x, y, z; };
+struct M3 { float m[3][3]; };  // m[col][row], glm convention
+
+__device__ __forceinline__ M3 m3mul(const M3& A, const M3& B) {
+  M3 r;
+#pragma unroll
+  for (int c = 0; c < 3; c++)
+#pragma unroll
+    for (int w = 0; w < 3; w++) r.m[c][w] = A.m[0][w] * B.m[c][0] + A.m[1][w] * B.m[c][1] + A.m[2][w] * B.m[c][2];
+  return r;
+}
+__device__ __forceinline__ M3 m3tr(const M3& A) {
+  M3 r;
+#pragma unroll
+  for (int c = 0; c < 3; c++)
+#pragma unroll
+    for (int w = 0; w < 3; w++) r.m[c][w] = A.m[w][c];
+  return r;
+}
+__device__ __forceinline__ V3 xform4x3(V3 p, const float* M) {
+  return {M[0] * p.x + M[4] * p.y + M[8] * p.z + M[12], M[1] * p.x + M[5] * p.y + M[9] * p.z + M[13],
+          M[2] * p.x + M[6] * p.y + M[10] * p.z + M[14]};
+}
+__device__ __forceinline__ float ndc2pix(float v, int S) { return (float)(((v + 1.0) * S - 1.0) * 0.5); }
+
+// rotation matrix exactly as written at forward.cu:134-138 (columns), quaternion taken as given
+__device__ __forceinline__ M3 quat_R(float r, float x, float y, float z) {
+  M3 R;
+  R.m[0][0] = 1.f - 2.f * (y * y + z * z); R.m[0][1] = 2.f * (x * y - r * z); R.m[0][2] = 2.f * (x * z + r * y);
+  R.m[1][0] = 2.f * (x * y + r * z); R.m[1][1] = 1.f - 2.f * (x * x + z * z); R.m[1][2] = 2.f * (y * z - r * x);
+  R.m[2][0] = 2.f * (x * z - r * y); R.m[2][1] = 2.f * (y * z + r * x); R.m[2][2] = 1.f - 2.f * (x * x + y * y);
+  return R;
+}
+
+struct Cov2D {
+  V3 t; float txtz, tytz, limx, limy;
+  M3 W, T, Vrk;
+  float a, b, c;  // cov2D (+0.3 low-pass on the diagonal)
+};
+// shared by forward (forward.cu:74-113) and backward (backward_distwar.cu:167-200)
+__device__ __forceinline__ void cov2d(V3 mean, float fx, float fy, float tan_fovx, float tan_fovy, const float* cov3D,
+                                      const float* V, Cov2D& o) {
+  o.t = xform4x3(mean, V);
+  o.limx = 1.3f * tan_fovx;
+  o.limy = 1.3f * tan_fovy;
+  o.txtz = o.t.x / o.t.z;
+  o.tytz = o.t.y / o.t.z;
+  o.t.x = fminf(o.limx, fmaxf(-o.limx, o.txtz)) * o.t.z;
+  o.t.y = fminf(o.limy, fmaxf(-o.limy, o.tytz)) * o.t.z;
+  const float tz = o.t.z;
+  M3 J;
+  J.m[0][0] = fx / tz; J.m[0][1] = 0.f; J.m[0][2] = -(fx * o.t.x) / (tz * tz);
+  J.m[1][0] = 0.f; J.m[1][1] = fy / tz; J.m[1][2] = -(fy * o.t.y) / (tz * tz);
+  J.m[2][0] = 0.f; J.m[2][1] = 0.f; J.m[2][2] = 0.f;
+  o.W.m[0][0] = V[0]; o.W.m[0][1] = V[4]; o.W.m[0][2] = V[8];
+  o.W.m[1][0] = V[1]; o.W.m[1][1] = V[5]; o.W.m[1][2] = V[9];
+  o.W.m[2][0] = V[2]; o.W.m[2][1] = V[6]; o.W.m[2][2] = V[10];
+  o.T = m3mul(o.W, J);
+  o.Vrk.m[0][0] = cov3D[0]; o.Vrk.m[0][1] = cov3D[1]; o.Vrk.m[0][2] = cov3D[2];
+  o.Vrk.m[1][0] = cov3D[1]; o.Vrk.m[1][1] = cov3D[3]; o.Vrk.m[1][2] = cov3D[4];
+  o.Vrk.m[2][0] = cov3D[2]; o.Vrk.m[2][1] = cov3D[4]; o.Vrk.m[2][2] = cov3D[5];
+  const M3 cov = m3mul(m3mul(m3tr(o.T), m3tr(o.Vrk)), o.T);
+  o.a = cov.m[0][0] + 0.3f;
+  o.b = cov.m[0][1];
+  o.c = cov.m[1][1] + 0.3f;
+}
+
+__device__ __forceinline__ uint32_t block_sum_256(uint32_t v, uint32_t* lds4) {
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+  if ((threadIdx.x & 63) == 0) lds4[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return lds4[0] + lds4[1] + lds4[2] + lds4[3];
+}
+
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(HGS_BLOCK) void preprocess_fwd_kernel(HgsFwdArgs a, HgsGeom g, HgsImage im, int* radii) {
+  __shared__ uint32_t red[4];
+  const int idx = blockIdx.x * HGS_BLOCK + threadIdx.x;
+  const int gx = (a.W + HGS_TILE - 1) / HGS_TILE, gy = (a.H + HGS_TILE - 1) / HGS_TILE;
+  uint32_t ntiles = 0;
+  if (idx < a.P) {
+    int my_radius_i = 0;
+    HgsRect rc = {0, 0, 0, 0, 0, 0};
+    do {
+      const V3 p = {a.means3D[3 * idx], a.means3D[3 * idx + 1], a.means3D[3 * idx + 2]};
+      const V3 pv = xform4x3(p, a.viewmatrix);
+      if (pv.z <= 0.2f) {  // auxiliary.h:154 (the `prefiltered` trap of :156-160 is not reproduced: it aborts the GPU)
+        break;
+      }
+      const float* Pm = a.projmatrix;
+      const float hx = Pm[0] * p.x + Pm[4] * p.y + Pm[8] * p.z + Pm[12];
+      const float hy = Pm[1] * p.x + Pm[5] * p.y + Pm[9] * p.z + Pm[13];
+      const float hw = Pm[3] * p.x + Pm[7] * p.y + Pm[11] * p.z + Pm[15];
+      const float p_w = 1.0f / (hw + 0.0000001f);
+      const float projx = hx * p_w, projy = hy * p_w;
+      float cov3[6];
+      if (a.cov3D_precomp) {
+#pragma unroll
+        for (int k = 0; k < 6; k++) cov3[k] = a.cov3D_precomp[6 * (size_t)idx + k];
+      } else {
+        const float mod = a.scale_modifier;
+        const float s0 = mod * a.scales[3 * idx], s1 = mod * a.scales[3 * idx + 1], s2 = mod * a.scales[3 * idx + 2];
+        const float4 q = ((const float4*)a.rotations)[idx];
+        const M3 R = quat_R(q.x, q.y, q.z, q.w);
+        M3 Mm;  // M = S * R  (S diagonal: M[c][r] = s_r * R[c][r]; the zero terms of the full product add exact zeros)
+#pragma unroll
+        for (int c = 0; c < 3; c++) { Mm.m[c][0] = s0 * R.m[c][0]; Mm.m[c][1] = s1 * R.m[c][1]; Mm.m[c][2] = s2 * R.m[c][2]; }
+        const M3 Sg = m3mul(m3tr(Mm), Mm);
+        cov3[0] = Sg.m[0][0]; cov3[1] = Sg.m[0][1]; cov3[2] = Sg.m[0][2];
+        cov3[3] = Sg.m[1][1]; cov3[4] = Sg.m[1][2]; cov3[5] = Sg.m[2][2];
+#pragma unroll
+        for (int k = 0; k < 6; k++) g.cov3D[6 * (size_t)idx + k] = cov3[k];
+      }
+      const float focal_y = a.H / (2.0f * a.tan_fovy), focal_x = a.W / (2.0f * a.tan_fovx);
+      Cov2D c2;
+      cov2d(p, focal_x, focal_y, a.tan_fovx, a.tan_fovy, cov3, a.viewmatrix, c2);
+      const float det = c2.a * c2.c - c2.b * c2.b;
+      if (det == 0.0f) break;
+      const float det_inv = 1.f / det;
+      const float4 conic_o = {c2.c * det_inv, -c2.b * det_inv, c2.a * det_inv, a.opacities[idx]};
+      const float mid = 0.5f * (c2.a + c2.c);
+      const float lambda1 = mid + sqrtf(fmaxf(0.1f, mid * mid - det));
+      const float lambda2 = mid - sqrtf(fmaxf(0.1f, mid * mid - det));
+      const float my_radius = ceilf(3.f * sqrtf(fmaxf(lambda1, lambda2)));
+      const float pixx = ndc2pix(projx, a.W), pixy = ndc2pix(projy, a.H);
+      const int ri = hgs_f2i(my_radius);
+      int x0 = hgs_f2i((pixx - ri) / HGS_TILE), y0 = hgs_f2i((pixy - ri) / HGS_TILE);
+      int x1 = hgs_f2i((pixx + ri + HGS_TILE - 1) / HGS_TILE), y1 = hgs_f2i((pixy + ri + HGS_TILE - 1) / HGS_TILE);
+      x0 = min(gx, max(0, x0)); y0 = min(gy, max(0, y0));
+      x1 = min(gx, max(0, x1)); y1 = min(gy, max(0, y1));
+      const uint32_t area = (uint32_t)(x1 - x0) * (uint32_t)(y1 - y0);
+      if (area == 0) break;
+      if (!a.colors_precomp) {
+        // computeColorFromSH, forward.cu:20-71
+        V3 d = {p.x - a.campos[0], p.y - a.campos[1], p.z - a.campos[2]};
+        const float len = sqrtf(d.x * d.x + d.y * d.y + d.z * d.z);
+        const float x = d.x / len, y = d.y / len, z = d.z / len;
+        const float* sh = a.shs + (size_t)idx * a.M * 3;
+#pragma unroll
+        for (int ch = 0; ch < 3; ch++) {
+          float res = kSH_C0 * sh[ch];
+          if (a.D > 0) {
+            res = res - kSH_C1 * y * sh[3 + ch] + kSH_C1 * z * sh[6 + ch] - kSH_C1 * x * sh[9 + ch];
+            if (a.D > 1) {
+              const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+              res = res + kSH_C2[0] * xy * sh[12 + ch] + kSH_C2[1] * yz * sh[15 + ch] +
+                    kSH_C2[2] * (2.0f * zz - xx - yy) * sh[18 + ch] + kSH_C2[3] * xz * sh[21 + ch] +
+                    kSH_C2[4] * (xx - yy) * sh[24 + ch];
+              if (a.D > 2) {
+                res = res + kSH_C3[0] * y * (3.0f * xx - yy) * sh[27 + ch] + kSH_C3[1] * xy * z * sh[30 + ch] +
+                      kSH_C3[2] * y * (4.0f * zz - xx - yy) * sh[33 + ch] +
+                      kSH_C3[3] * z * (2.0f * zz - 3.0f * xx - 3.0f * yy) * sh[36 + ch] +
+                      kSH_C3[4] * x * (4.0f * zz - xx - yy) * sh[39 + ch] + kSH_C3[5] * z * (xx - yy) * sh[42 + ch] +
+                      kSH_C3[6] * x * (xx - 3.0f * yy) * sh[45 + ch];
+              }
+            }
+          }
+          res += 0.5f;
+          g.clamped[3 * (size_t)idx + ch] = (res < 0.f);
+          g.rgb[3 * (size_t)idx + ch] = fmaxf(res, 0.0f);
+        }
+      }
+      g.depths[idx] = pv.z;
+      g.means2D[idx] = make_float2(pixx, pixy);
+      g.conic_opacity[idx] = conic_o;
+      my_radius_i = ri;
+      ntiles = area;
+      rc.x0 = (uint16_t)x0; rc.y0 = (uint16_t)y0; rc.x1 = (uint16_t)x1; rc.y1 = (uint16_t)y1;
+      // per-tile instance counts: integer atomics, order-independent
+      for (int ty = y0; ty < y1; ty++)
+        for (int tx = x0; tx < x1; tx++) atomicAdd(&im.tile_count[ty * gx + tx], 1u);
+    } while (0);
+    radii[idx] = my_radius_i;
+    g.tiles_touched[idx] = ntiles;
+    g.rect[idx] = rc;
+  }
+  const uint32_t bs = block_sum_256(ntiles, red);
+  if (threadIdx.x == 0) g.block_sums[blockIdx.x] = bs;
+}
+
+// ------------------------------------------------------------------------------------------------
+// scatter: one lane per Gaussian.  Exclusive instance offset = block prefix (scan kernel) + in-block scan;
+// every touched tile gets key = depth_bits<<32 | gaussian_id appended to the tile's segment (order inside the
+// segment is irrelevant: the per-tile sort key is unique).
+__global__ __launch_bounds__(HGS_BLOCK) void scatter_kernel(int P, int gx, uint32_t Rcap, const int* radii, HgsGeom g,
+                                                            HgsImage im, HgsBinning b) {
+  __shared__ uint32_t wsum[4];
+  const int idx = blockIdx.x * HGS_BLOCK + threadIdx.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const uint32_t n = idx < P ? g.tiles_touched[idx] : 0;
+  const uint32_t incl = hgs_wave_incl_scan(n, lane);
+  if (lane == 63) wsum[wave] = incl;
+  __syncthreads();
+  uint32_t base = g.block_sums[blockIdx.x];  // exclusive block prefix
+  for (int w = 0; w < wave; w++) base += wsum[w];
+  if (idx >= P) return;
+  const uint32_t off_incl = base + incl;
+  g.point_offsets[idx] = off_incl;
+  if (n == 0) return;
+  HgsRect rc = g.rect[idx];
+  rc.off = off_incl - n;
+  g.rect[idx] = rc;
+  const uint64_t key = ((uint64_t)__float_as_uint(g.depths[idx]) << 32) | (uint32_t)idx;
+  for (int ty = rc.y0; ty < rc.y1; ty++)
+    for (int tx = rc.x0; tx < rc.x1; tx++) {
+      const int t = ty * gx + tx;
+      const uint32_t pos = im.ranges[t].x + atomicAdd(&im.tile_cursor[t], 1u);
+      if (pos < Rcap) b.keys[pos] = key;
+      else im.status[1] = 1;  // overflow: caller under-sized the binning buffer
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ V3 dnormvdv(V3 v, V3 dv) {  // auxiliary.h:107-117
+  const float sum2 = v.x * v.x + v.y * v.y + v.z * v.z;
+  const float invsum32 = 1.0f / sqrtf(sum2 * sum2 * sum2);
+  V3 r;
+  r.x = ((+sum2 - v.x * v.x) * dv.x - v.y * v.x * dv.y - v.z * v.x * dv.z) * invsum32;
+  r.y = (-v.x * v.y * dv.x + (sum2 - v.y * v.y) * dv.y - v.z * v.y * dv.z) * invsum32;
+  r.z = (-v.x * v.z * dv.x - v.y * v.z * dv.y + (sum2 - v.z * v.z) * dv.z) * invsum32;
+  return r;
+}
+
+__global__ __launch_bounds__(HGS_BLOCK) void preprocess_bwd_kernel(HgsBwdArgs a, HgsGeom g, HgsBinning b,
+                                                                   const float* __restrict__ inst_grad) {
+  const int idx = blockIdx.x * HGS_BLOCK + threadIdx.x;
+  if (idx >= a.P) return;
+  const int M = a.M;
+  float dmx = 0.f, dmy = 0.f, dcx = 0.f, dcy = 0.f, dcw = 0.f, dop = 0.f, dcol[3] = {0.f, 0.f, 0.f};
+  float dmean[3] = {0.f, 0.f, 0.f}, dcov[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  float dscale[3] = {0.f, 0.f, 0.f}, drot[4] = {0.f, 0.f, 0.f, 0.f};
+  const bool vis = a.radii[idx] > 0;
+  if (vis) {
+    // ---- deterministic gather of this Gaussian's per-instance partial sums (instance order = tile rect order)
+    const HgsRect rc = g.rect[idx];
+    const uint32_t n = g.tiles_touched[idx];
+    for (uint32_t k = 0; k < n; k++) {
+      const uint32_t pos = b.inv[rc.off + k];
+      const float4* r = (const float4*)(inst_grad + (size_t)pos * HGS_INST_GRAD_FLOATS);
+      const float4 r0 = r[0], r1 = r[1];
+      const float r2 = r[2].x;
+      dmx += r0.x; dmy += r0.y; dcx += r0.z; dcy += r0.w;
+      dcw += r1.x; dop += r1.y; dcol[0] += r1.z; dcol[1] += r1.w; dcol[2] += r2;
+    }
+    // ---- computeCov2DCUDA, backward_distwar.cu:145-275
+    const V3 mean = {a.means3D[3 * idx], a.means3D[3 * idx + 1], a.means3D[3 * idx + 2]};
+    const float* cov3D = (a.cov3D_precomp ? a.cov3D_precomp : g.cov3D) + 6 * (size_t)idx;
+    float cov3[6];
+#pragma unroll
+    for (int k = 0; k < 6; k++) cov3[k] = cov3D[k];
+    const float h_y = a.H / (2.0f * a.tan_fovy), h_x = a.W / (2.0f * a.tan_fovx);
+    Cov2D c;
+    cov2d(mean, h_x, h_y, a.tan_fovx, a.tan_fovy, cov3, a.viewmatrix, c);
+    const float x_grad_mul = (c.txtz < -c.limx || c.txtz > c.limx) ? 0.f : 1.f;
+    const float y_grad_mul = (c.tytz < -c.limy || c.tytz > c.limy) ? 0.f : 1.f;
+    const float A = c.a, B = c.b, Cc = c.c;
+    const float denom = A * Cc - B * B;
+    float dL_da = 0, dL_db = 0, dL_dc = 0;
+    const float denom2inv = 1.0f / ((denom * denom) + 0.0000001f);
+#define T_(i, j) c.T.m[i][j]
+#define V_(i, j) c.Vrk.m[i][j]
+#define W_(i, j) c.W.m[i][j]
+    if (denom2inv != 0) {
+      dL_da = denom2inv * (-Cc * Cc * dcx + 2 * B * Cc * dcy + (denom - A * Cc) * dcw);
+      dL_dc = denom2inv * (-A * A * dcw + 2 * A * B * dcy + (denom - A * Cc) * dcx);
+      dL_db = denom2inv * 2 * (B * Cc * dcx - (denom + 2 * B * B) * dcy + A * B * dcw);
+      dcov[0] = (T_(0, 0) * T_(0, 0) * dL_da + T_(0, 0) * T_(1, 0) * dL_db + T_(1, 0) * T_(1, 0) * dL_dc);
+      dcov[3] = (T_(0, 1) * T_(0, 1) * dL_da + T_(0, 1) * T_(1, 1) * dL_db + T_(1, 1) * T_(1, 1) * dL_dc);
+      dcov[5] = (T_(0, 2) * T_(0, 2) * dL_da + T_(0, 2) * T_(1, 2) * dL_db + T_(1, 2) * T_(1, 2) * dL_dc);
+      dcov[1] = 2 * T_(0, 0) * T_(0, 1) * dL_da + (T_(0, 0) * T_(1, 1) + T_(0, 1) * T_(1, 0)) * dL_db +
+                2 * T_(1, 0) * T_(1, 1) * dL_dc;
+      dcov[2] = 2 * T_(0, 0) * T_(0, 2) * dL_da + (T_(0, 0) * T_(1, 2) + T_(0, 2) * T_(1, 0)) * dL_db +
+                2 * T_(1, 0) * T_(1, 2) * dL_dc;
+      dcov[4] = 2 * T_(0, 2) * T_(0, 1) * dL_da + (T_(0, 1) * T_(1, 2) + T_(0, 2) * T_(1, 1)) * dL_db +
+                2 * T_(1, 1) * T_(1, 2) * dL_dc;
+    }
+    const float dL_dT00 = 2 * (T_(0, 0) * V_(0, 0) + T_(0, 1) * V_(0, 1) + T_(0, 2) * V_(0, 2)) * dL_da +
+                          (T_(1, 0) * V_(0, 0) + T_(1, 1) * V_(0, 1) + T_(1, 2) * V_(0, 2)) * dL_db;
+    const float dL_dT01 = 2 * (T_(0, 0) * V_(1, 0) + T_(0, 1) * V_(1, 1) + T_(0, 2) * V_(1, 2)) * dL_da +
+                          (T_(1, 0) * V_(1, 0) + T_(1, 1) * V_(1, 1) + T_(1, 2) * V_(1, 2)) * dL_db;
+    const float dL_dT02 = 2 * (T_(0, 0) * V_(2, 0) + T_(0, 1) * V_(2, 1) + T_(0, 2) * V_(2, 2)) * dL_da +
+                          (T_(1, 0) * V_(2, 0) + T_(1, 1) * V_(2, 1) + T_(1, 2) * V_(2, 2)) * dL_db;
+    const float dL_dT10 = 2 * (T_(1, 0) * V_(0, 0) + T_(1, 1) * V_(0, 1) + T_(1, 2) * V_(0, 2)) * dL_dc +
+                          (T_(0, 0) * V_(0, 0) + T_(0, 1) * V_(0, 1) + T_(0, 2) * V_(0, 2)) * dL_db;
+    const float dL_dT11 = 2 * (T_(1, 0) * V_(1, 0) + T_(1, 1) * V_(1, 1) + T_(1, 2) * V_(1, 2)) * dL_dc +
+                          (T_(0, 0) * V_(1, 0) + T_(0, 1) * V_(1, 1) + T_(0, 2) * V_(1, 2)) * dL_db;
+    const float dL_dT12 = 2 * (T_(1, 0) * V_(2, 0) + T_(1, 1) * V_(2, 1) + T_(1, 2) * V_(2, 2)) * dL_dc +
+                          (T_(0, 0) * V_(2, 0) + T_(0, 1) * V_(2, 1) + T_(0, 2) * V_(2, 2)) * dL_db;
+    const float dL_dJ00 = W_(0, 0) * dL_dT00 + W_(0, 1) * dL_dT01 + W_(0, 2) * dL_dT02;
+    const float dL_dJ02 = W_(2, 0) * dL_dT00 + W_(2, 1) * dL_dT01 + W_(2, 2) * dL_dT02;
+    const float dL_dJ11 = W_(1, 0) * dL_dT10 + W_(1, 1) * dL_dT11 + W_(1, 2) * dL_dT12;
+    const float dL_dJ12 = W_(2, 0) * dL_dT10 + W_(2, 1) * dL_dT11 + W_(2, 2) * dL_dT12;
+#undef T_
+#undef V_
+#undef W_
+    const float tz = 1.f / c.t.z, tz2 = tz * tz, tz3 = tz2 * tz;
+    const float dL_dtx = x_grad_mul * -h_x * tz2 * dL_dJ02;
+    const float dL_dty = y_grad_mul * -h_y * tz2 * dL_dJ12;
+    const float dL_dtz = -h_x * tz2 * dL_dJ00 - h_y * tz2 * dL_dJ11 + (2 * h_x * c.t.x) * tz3 * dL_dJ02 +
+                         (2 * h_y * c.t.y) * tz3 * dL_dJ12;
+    const float* Vm = a.viewmatrix;
+    dmean[0] = Vm[0] * dL_dtx + Vm[1] * dL_dty + Vm[2] * dL_dtz;  // transformVec4x3Transpose, auxiliary.h:89-97
+    dmean[1] = Vm[4] * dL_dtx + Vm[5] * dL_dty + Vm[6] * dL_dtz;
+    dmean[2] = Vm[8] * dL_dtx + Vm[9] * dL_dty + Vm[10] * dL_dtz;
+
+    // ---- preprocessCUDA (backward), backward_distwar.cu:347-397
+    const float* pj = a.projmatrix;
+    const float m_hw = pj[3] * mean.x + pj[7] * mean.y + pj[11] * mean.z + pj[15];
+    const float m_w = 1.0f / (m_hw + 0.0000001f);
+    const float mul1 = (pj[0] * mean.x + pj[4] * mean.y + pj[8] * mean.z + pj[12]) * m_w * m_w;
+    const float mul2 = (pj[1] * mean.x + pj[5] * mean.y + pj[9] * mean.z + pj[13]) * m_w * m_w;
+    dmean[0] += (pj[0] * m_w - pj[3] * mul1) * dmx + (pj[1] * m_w - pj[3] * mul2) * dmy;
+    dmean[1] += (pj[4] * m_w - pj[7] * mul1) * dmx + (pj[5] * m_w - pj[7] * mul2) * dmy;
+    dmean[2] += (pj[8] * m_w - pj[11] * mul1) * dmx + (pj[9] * m_w - pj[11] * mul2) * dmy;
+
+    if (a.shs) {
+      // computeColorFromSH (backward), backward_distwar.cu:21-140
+      const V3 dir_orig = {mean.x - a.campos[0], mean.y - a.campos[1], mean.z - a.campos[2]};
+      const float len = sqrtf(dir_orig.x * dir_orig.x + dir_orig.y * dir_orig.y + dir_orig.z * dir_orig.z);
+      const float x = dir_orig.x / len, y = dir_orig.y / len, z = dir_orig.z / len;
+      const float* sh = a.shs + (size_t)idx * M * 3;
+      float* dsh = a.dL_dsh + (size_t)idx * M * 3;
+      float dRGB[3];
+#pragma unroll
+      for (int ch = 0; ch < 3; ch++) dRGB[ch] = dcol[ch] * (g.clamped[3 * (size_t)idx + ch] ? 0.f : 1.f);
+      float ddx[3] = {0, 0, 0}, ddy[3] = {0, 0, 0}, ddz[3] = {0, 0, 0};
+#define SHC(k, ch) sh[3 * (k) + (ch)]
+#define DSH(k, coef) { const float cf_ = (coef); dsh[3 * (k)] = cf_ * dRGB[0]; dsh[3 * (k) + 1] = cf_ * dRGB[1]; dsh[3 * (k) + 2] = cf_ * dRGB[2]; }
+      DSH(0, kSH_C0);
+      if (a.D > 0) {
+        DSH(1, -kSH_C1 * y); DSH(2, kSH_C1 * z); DSH(3, -kSH_C1 * x);
+#pragma unroll
+        for (int ch = 0; ch < 3; ch++) {
+          ddx[ch] = -kSH_C1 * SHC(3, ch);
+          ddy[ch] = -kSH_C1 * SHC(1, ch);
+          ddz[ch] = kSH_C1 * SHC(2, ch);
+        }
+        if (a.D > 1) {
+          const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+          DSH(4, kSH_C2[0] * xy); DSH(5, kSH_C2[1] * yz); DSH(6, kSH_C2[2] * (2.f * zz - xx - yy));
+          DSH(7, kSH_C2[3] * xz); DSH(8, kSH_C2[4] * (xx - yy));
+#pragma unroll
+          for (int ch = 0; ch < 3; ch++) {
+            ddx[ch] += kSH_C2[0] * y * SHC(4, ch) + kSH_C2[2] * 2.f * -x * SHC(6, ch) + kSH_C2[3] * z * SHC(7, ch) +
+                       kSH_C2[4] * 2.f * x * SHC(8, ch);
+            ddy[ch] += kSH_C2[0] * x * SHC(4, ch) + kSH_C2[1] * z * SHC(5, ch) + kSH_C2[2] * 2.f * -y * SHC(6, ch) +
+                       kSH_C2[4] * 2.f * -y * SHC(8, ch);
+            ddz[ch] += kSH_C2[1] * y * SHC(5, ch) + kSH_C2[2] * 2.f * 2.f * z * SHC(6, ch) + kSH_C2[3] * x * SHC(7, ch);
+          }
+          if (a.D > 2) {
+            DSH(9, kSH_C3[0] * y * (3.f * xx - yy)); DSH(10, kSH_C3[1] * xy * z);
+            DSH(11, kSH_C3[2] * y * (4.f * zz - xx - yy)); DSH(12, kSH_C3[3] * z * (2.f * zz - 3.f * xx - 3.f * yy));
+            DSH(13, kSH_C3[4] * x * (4.f * zz - xx - yy)); DSH(14, kSH_C3[5] * z * (xx - yy));
+            DSH(15, kSH_C3[6] * x * (xx - 3.f * yy));
+#pragma unroll
+            for (int ch = 0; ch < 3; ch++) {
+              ddx[ch] += (kSH_C3[0] * SHC(9, ch) * 3.f * 2.f * xy + kSH_C3[1] * SHC(10, ch) * yz +
+                          kSH_C3[2] * SHC(11, ch) * -2.f * xy + kSH_C3[3] * SHC(12, ch) * -3.f * 2.f * xz +
+                          kSH_C3[4] * SHC(13, ch) * (-3.f * xx + 4.f * zz - yy) + kSH_C3[5] * SHC(14, ch) * 2.f * xz +
+                          kSH_C3[6] * SHC(15, ch) * 3.f * (xx - yy));
+              ddy[ch] += (kSH_C3[0] * SHC(9, ch) * 3.f * (xx - yy) + kSH_C3[1] * SHC(10, ch) * xz +
+                          kSH_C3[2] * SHC(11, ch) * (-3.f * yy + 4.f * zz - xx) + kSH_C3[3] * SHC(12, ch) * -3.f * 2.f * yz +
+                          kSH_C3[4] * SHC(13, ch) * -2.f * xy + kSH_C3[5] * SHC(14, ch) * -2.f * yz +
+                          kSH_C3[6] * SHC(15, ch) * -3.f * 2.f * xy);
+              ddz[ch] += (kSH_C3[1] * SHC(10, ch) * xy + kSH_C3[2] * SHC(11, ch) * 4.f * 2.f * yz +
+                          kSH_C3[3] * SHC(12, ch) * 3.f * (2.f * zz - xx - yy) + kSH_C3[4] * SHC(13, ch) * 4.f * 2.f * xz +
+                          kSH_C3[5] * SHC(14, ch) * (xx - yy));
+            }
+          }
+        }
+      }
+      // coefficients above the active degree receive zero gradient
+      for (int k = (a.D + 1) * (a.D + 1); k < M; k++) { dsh[3 * k] = 0.f; dsh[3 * k + 1] = 0.f; dsh[3 * k + 2] = 0.f; }
+#undef SHC
+#undef DSH
+      const V3 dL_ddir = {ddx[0] * dRGB[0] + ddx[1] * dRGB[1] + ddx[2] * dRGB[2],
+                          ddy[0] * dRGB[0] + ddy[1] * dRGB[1] + ddy[2] * dRGB[2],
+                          ddz[0] * dRGB[0] + ddz[1] * dRGB[1] + ddz[2] * dRGB[2]};
+      const V3 dm = dnormvdv(dir_orig, dL_ddir);
+      dmean[0] += dm.x; dmean[1] += dm.y; dmean[2] += dm.z;
+    }
+    if (a.scales) {
+      // computeCov3D (backward), backward_distwar.cu:279-342
+      const float4 q = ((const float4*)a.rotations)[idx];
+      const float r = q.x, x = q.y, y = q.z, z = q.w;
+      const M3 R = quat_R(r, x, y, z);
+      const float s[3] = {a.scale_modifier * a.scales[3 * idx], a.scale_modifier * a.scales[3 * idx + 1],
+                          a.scale_modifier * a.scales[3 * idx + 2]};
+      M3 M2;  // 2 * (S * R)
+#pragma unroll
+      for (int cc = 0; cc < 3; cc++)
+#pragma unroll
+        for (int w = 0; w < 3; w++) M2.m[cc][w] = (s[w] * R.m[cc][w]) * 2.0f;
+      M3 dSig;
+      dSig.m[0][0] = dcov[0]; dSig.m[0][1] = 0.5f * dcov[1]; dSig.m[0][2] = 0.5f * dcov[2];
+      dSig.m[1][0] = 0.5f * dcov[1]; dSig.m[1][1] = dcov[3]; dSig.m[1][2] = 0.5f * dcov[4];
+      dSig.m[2][0] = 0.5f * dcov[2]; dSig.m[2][1] = 0.5f * dcov[4]; dSig.m[2][2] = dcov[5];
+      const M3 dM = m3mul(M2, dSig);
+      const M3 Rt = m3tr(R);
+      M3 dMt = m3tr(dM);
+#pragma unroll
+      for (int k = 0; k < 3; k++)
+        dscale[k] = Rt.m[k][0] * dMt.m[k][0] + Rt.m[k][1] * dMt.m[k][1] + Rt.m[k][2] * dMt.m[k][2];
+#pragma unroll
+      for (int k = 0; k < 3; k++)
+#pragma unroll
+        for (int w = 0; w < 3; w++) dMt.m[k][w] *= s[k];
+#define D_(i, j) dMt.m[i][j]
+      drot[0] = 2 * z * (D_(0, 1) - D_(1, 0)) + 2 * y * (D_(2, 0) - D_(0, 2)) + 2 * x * (D_(1, 2) - D_(2, 1));
+      drot[1] = 2 * y * (D_(1, 0) + D_(0, 1)) + 2 * z * (D_(2, 0) + D_(0, 2)) + 2 * r * (D_(1, 2) - D_(2, 1)) -
+                4 * x * (D_(2, 2) + D_(1, 1));
+      drot[2] = 2 * x * (D_(1, 0) + D_(0, 1)) + 2 * r * (D_(2, 0) - D_(0, 2)) + 2 * z * (D_(1, 2) + D_(2, 1)) -
+                4 * y * (D_(2, 2) + D_(0, 0));
+      drot[3] = 2 * r * (D_(0, 1) - D_(1, 0)) + 2 * x * (D_(2, 0) + D_(0, 2)) + 2 * y * (D_(1, 2) + D_(2, 1)) -
+                4 * z * (D_(1, 1) + D_(0, 0));
+#undef D_
+    }
+  } else if (a.shs) {
+    float* dsh = a.dL_dsh + (size_t)idx * M * 3;
+    for (int k = 0; k < 3 * M; k++) dsh[k] = 0.f;
+  }
+  // every output is written (zeros for culled Gaussians): no separate zero-fill pass
+  a.dL_dmeans2D[3 * idx] = dmx; a.dL_dmeans2D[3 * idx + 1] = dmy; a.dL_dmeans2D[3 * idx + 2] = 0.f;
+  ((float4*)a.dL_dconic)[idx] = make_float4(dcx, dcy, 0.f, dcw);
+  a.dL_dopacity[idx] = dop;
+  a.dL_dcolors[3 * idx] = dcol[0]; a.dL_dcolors[3 * idx + 1] = dcol[1]; a.dL_dcolors[3 * idx + 2] = dcol[2];
+  a.dL_dmeans3D[3 * idx] = dmean[0]; a.dL_dmeans3D[3 * idx + 1] = dmean[1]; a.dL_dmeans3D[3 * idx + 2] = dmean[2];
+#pragma unroll
+  for (int k = 0; k < 6; k++) a.dL_dcov3D[6 * (size_t)idx + k] = dcov[k];
+  a.dL_dscales[3 * idx] = dscale[0]; a.dL_dscales[3 * idx + 1] = dscale[1]; a.dL_dscales[3 * idx + 2] = dscale[2];
+  ((float4*)a.dL_drotations)[idx] = make_float4(drot[0], drot[1], drot[2], drot[3]);
+}
+
+__global__ __launch_bounds__(HGS_BLOCK) void mark_visible_kernel(int P, const float* means3D, const float* V, uint8_t* present) {
+  const int idx = blockIdx.x * HGS_BLOCK + threadIdx.x;
+  if (idx >= P) return;
+  const V3 p = {means3D[3 * idx], means3D[3 * idx + 1], means3D[3 * idx + 2]};
+  present[idx] = !(xform4x3(p, V).z <= 0.2f);
+}
+
+}  // namespace
+
+int hgs_launch_preprocess_fwd(hipStream_t s, const HgsFwdArgs& a, const HgsGeom& g, const HgsImage& im, int* radii) {
+  const int nblk = (a.P + HGS_BLOCK - 1) / HGS_BLOCK;
+  hipLaunchKernelGGL(preprocess_fwd_kernel, dim3(nblk), dim3(HGS_BLOCK), 0, s, a, g, im, radii);
+  HGS_CHECK_LAUNCH();
+  return 0;
+}
+int hgs_launch_scatter(hipStream_t s, int P, int W, int H, int Rcap, const int* radii, const HgsGeom& g,
+                       const HgsImage& im, const HgsBinning& b) {
+  (void)H;
+  const int nblk = (P + HGS_BLOCK - 1) / HGS_BLOCK;
+  const int gx = (W + HGS_TILE - 1) / HGS_TILE;
+  hipLaunchKernelGGL(scatter_kernel, dim3(nblk), dim3(HGS_BLOCK), 0, s, P, gx, (uint32_t)Rcap, radii, g, im, b);
+  HGS_CHECK_LAUNCH();
+  return 0;
+}
+int hgs_launch_preprocess_bwd(hipStream_t s, const HgsBwdArgs& a, const HgsGeom& g, const HgsBinning& b,
+                              const float* inst_grad) {
+  const int nblk = (a.P + HGS_BLOCK - 1) / HGS_BLOCK;
+  hipLaunchKernelGGL(preprocess_bwd_kernel, dim3(nblk), dim3(HGS_BLOCK), 0, s, a, g, b, inst_grad);
+  HGS_CHECK_LAUNCH();
+  return 0;
+}
+int hgs_launch_mark_visible(hipStream_t s, int P, const float* means3D, const float* viewmatrix, uint8_t* present) {
+  const int nblk = (P + HGS_BLOCK - 1) / HGS_BLOCK;
+  hipLaunchKernelGGL(mark_visible_kernel, dim3(nblk), dim3(HGS_BLOCK), 0, s, P, means3D, viewmatrix, present);
+  HGS_CHECK_LAUNCH();
+  return 0;
+}

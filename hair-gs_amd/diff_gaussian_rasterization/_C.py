@@ -1,0 +1,105 @@
+"""Drop-in for the reference's pybind11 module `diff_gaussian_rasterization._C`
+(submodules/diff-gaussian-rasterization/ext.cpp:15-19): same three functions, same argument order, same
+return tuples -- implemented over the C ABI of libhgs.so (include/hgs.h) with ctypes."""
+import ctypes as C
+
+import torch
+
+import hgs_runtime as rt
+
+# set False to skip the blocking read of num_rendered (binning buffer is then sized from `capacity_hint`)
+_state = {"last_R": 0}
+
+
+def _f32(t, name):
+    if t is None or t.numel() == 0:
+        return None
+    return rt.require_gpu_tensor(t, name, torch.float32)
+
+
+def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp,
+                        viewmatrix, projmatrix, tan_fovx, tan_fovy, image_height, image_width, sh, degree, campos,
+                        prefiltered, debug):
+    """RasterizeGaussiansCUDA (rasterize_points.cu:35-115).
+    Returns (num_rendered, out_color[3,H,W], radii[P], geomBuffer, binningBuffer, imgBuffer)."""
+    if means3D.ndim != 2 or means3D.shape[1] != 3:
+        raise RuntimeError("means3D must have dimensions (num_points, 3)")  # rasterize_points.cu:57-59
+    L = rt.lib()
+    means3D = rt.require_gpu_tensor(means3D, "means3D", torch.float32)
+    dev = means3D.device
+    P, H, W = means3D.shape[0], int(image_height), int(image_width)
+    M = sh.shape[1] if (sh is not None and sh.numel() != 0) else 0
+    out_color = torch.empty((3, H, W), dtype=torch.float32, device=dev)
+    radii = torch.empty((P,), dtype=torch.int32, device=dev)
+    u8 = dict(dtype=torch.uint8, device=dev)
+    geom = torch.empty((L.hgs_geom_bytes(P),), **u8)
+    img = torch.empty((L.hgs_image_bytes(W, H),), **u8)
+    bg = _f32(background, "bg")
+    colors_, opacity_, scales_, rots_, cov_, sh_ = (_f32(colors, "colors_precomp"), _f32(opacity, "opacities"),
+                                                     _f32(scales, "scales"), _f32(rotations, "rotations"),
+                                                     _f32(cov3D_precomp, "cov3D_precomp"), _f32(sh, "sh"))
+    view, proj, cam = _f32(viewmatrix, "viewmatrix"), _f32(projmatrix, "projmatrix"), _f32(campos, "campos")
+    stream = rt.current_stream()
+    with torch.cuda.device(dev):
+        n_host = C.c_int(0)
+        rt.check(L.hgs_forward_preprocess(stream, P, int(degree), M, W, H, rt.ptr(means3D), rt.ptr(sh_), rt.ptr(colors_),
+                                          rt.ptr(opacity_), rt.ptr(scales_), float(scale_modifier), rt.ptr(rots_),
+                                          rt.ptr(cov_), rt.ptr(view), rt.ptr(proj), rt.ptr(cam), float(tan_fovx),
+                                          float(tan_fovy), int(bool(prefiltered)), rt.ptr(geom), rt.ptr(img),
+                                          rt.ptr(radii), C.addressof(n_host)))
+        R = int(n_host.value)
+        binning = torch.empty((L.hgs_binning_bytes(R),), **u8)
+        rt.check(L.hgs_forward_render(stream, P, W, H, R, rt.ptr(bg), rt.ptr(colors_), rt.ptr(geom), rt.ptr(binning),
+                                      rt.ptr(img), rt.ptr(out_color)))
+        if debug:
+            torch.cuda.synchronize(dev)  # surface asynchronous faults here, like CHECK_CUDA (auxiliary.h:166-173)
+    _state["last_R"] = R
+    return R, out_color, radii, geom, binning, img
+
+
+def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rotations, scale_modifier, cov3D_precomp,
+                                 viewmatrix, projmatrix, tan_fovx, tan_fovy, dL_dout_color, sh, degree, campos,
+                                 geomBuffer, R, binningBuffer, imageBuffer, debug):
+    """RasterizeGaussiansBackwardCUDA (rasterize_points.cu:117-196).
+    Returns (dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations)."""
+    L = rt.lib()
+    means3D = rt.require_gpu_tensor(means3D, "means3D", torch.float32)
+    dev = means3D.device
+    P = means3D.shape[0]
+    H, W = int(dL_dout_color.shape[1]), int(dL_dout_color.shape[2])
+    M = sh.shape[1] if (sh is not None and sh.numel() != 0) else 0
+    f32 = dict(dtype=torch.float32, device=dev)
+    new = torch.empty if P > 0 else torch.zeros  # the kernel writes every element when P > 0
+    dL_dmeans3D, dL_dmeans2D, dL_dcolors = new((P, 3), **f32), new((P, 3), **f32), new((P, 3), **f32)
+    dL_dconic, dL_dopacity, dL_dcov3D = new((P, 2, 2), **f32), new((P, 1), **f32), new((P, 6), **f32)
+    dL_dsh, dL_dscales, dL_drotations = new((P, M, 3), **f32), new((P, 3), **f32), new((P, 4), **f32)
+    if P == 0:
+        return dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations
+    scratch = torch.empty((L.hgs_backward_scratch_bytes(P, int(R)),), dtype=torch.uint8, device=dev)
+    dpix = rt.require_gpu_tensor(dL_dout_color, "dL_dout_color", torch.float32)
+    with torch.cuda.device(dev):
+        rt.check(L.hgs_backward(rt.current_stream(), P, int(degree), M, int(R), W, H, rt.ptr(_f32(background, "bg")),
+                                rt.ptr(means3D), rt.ptr(_f32(sh, "sh")), rt.ptr(_f32(colors, "colors_precomp")),
+                                rt.ptr(_f32(scales, "scales")), float(scale_modifier), rt.ptr(_f32(rotations, "rotations")),
+                                rt.ptr(_f32(cov3D_precomp, "cov3D_precomp")), rt.ptr(_f32(viewmatrix, "viewmatrix")),
+                                rt.ptr(_f32(projmatrix, "projmatrix")), rt.ptr(_f32(campos, "campos")), float(tan_fovx),
+                                float(tan_fovy), rt.ptr(radii), rt.ptr(geomBuffer), rt.ptr(binningBuffer),
+                                rt.ptr(imageBuffer), rt.ptr(dpix), rt.ptr(scratch), rt.ptr(dL_dmeans2D),
+                                rt.ptr(dL_dconic), rt.ptr(dL_dopacity), rt.ptr(dL_dcolors), rt.ptr(dL_dmeans3D),
+                                rt.ptr(dL_dcov3D), rt.ptr(dL_dsh), rt.ptr(dL_dscales), rt.ptr(dL_drotations)))
+        if debug:
+            torch.cuda.synchronize(dev)
+    rasterize_gaussians_backward.last_dL_dconic = dL_dconic  # kept for the parity tests
+    return dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations
+
+
+def mark_visible(means3D, viewmatrix, projmatrix):
+    """markVisible (rasterize_points.cu:198-217) -> bool[P]."""
+    means3D = rt.require_gpu_tensor(means3D, "means3D", torch.float32)
+    P = means3D.shape[0]
+    present = torch.zeros((P,), dtype=torch.bool, device=means3D.device)
+    if P:
+        with torch.cuda.device(means3D.device):
+            rt.check(rt.lib().hgs_mark_visible(rt.current_stream(), P, rt.ptr(means3D), rt.ptr(_f32(viewmatrix, "viewmatrix")),
+                                               rt.ptr(_f32(projmatrix, "projmatrix")), rt.ptr(present)))
+    return present

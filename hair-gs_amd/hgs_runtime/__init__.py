@@ -1,0 +1,104 @@
+"""Loader of libhgs.so (the hand-written HIP kernels behind a C ABI, include/hgs.h).
+
+There is NO fallback: if the library is missing or fails to load, every op raises.  The library is built
+in-tree by `hgs_runtime.build()` (hipcc --offload-arch=gfx950, cross-compiles without a GPU) and travels
+with the source tree.
+"""
+import ctypes as C
+import os
+import subprocess
+
+_PKG_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB_PATH = os.path.join(_PKG_ROOT, "libhgs.so")
+CSRC = os.path.join(_PKG_ROOT, "csrc")
+_lib = None
+
+vp, ci, cf, sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t
+
+# name -> (restype, argtypes); mirrors include/hgs.h one to one (tests/test_abi.py checks the header against this)
+SIGNATURES = {
+    "hgs_abi_version": (ci, []),
+    "hgs_last_error": (C.c_char_p, []),
+    "hgs_geom_bytes": (sz, [ci]),
+    "hgs_image_bytes": (sz, [ci, ci]),
+    "hgs_binning_bytes": (sz, [ci]),
+    "hgs_backward_scratch_bytes": (sz, [ci, ci]),
+    "hgs_forward_preprocess": (ci, [vp, ci, ci, ci, ci, ci, vp, vp, vp, vp, vp, cf, vp, vp, vp, vp, vp, cf, cf, ci,
+                                    vp, vp, vp, vp]),
+    "hgs_forward_render": (ci, [vp, ci, ci, ci, ci, vp, vp, vp, vp, vp, vp]),
+    "hgs_backward": (ci, [vp, ci, ci, ci, ci, ci, ci, vp, vp, vp, vp, vp, cf, vp, vp, vp, vp, vp, cf, cf, vp, vp, vp,
+                          vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
+    "hgs_mark_visible": (ci, [vp, ci, vp, vp, vp, vp]),
+    "hgs_dist2_scratch_bytes": (sz, [ci]),
+    "hgs_dist2": (ci, [vp, ci, vp, vp, vp, sz]),
+    "hgs_geom_layout": (ci, [ci, vp]),
+    "hgs_image_layout": (ci, [ci, ci, vp]),
+    "hgs_binning_layout": (ci, [ci, vp]),
+}
+GEOM_FIELDS = ["depths", "clamped", "means2D", "cov3D", "conic_opacity", "rgb", "tiles_touched", "point_offsets", "rect",
+               "block_sums"]
+IMG_FIELDS = ["final_T", "n_contrib", "ranges", "tile_count", "tile_cursor", "tile_maxc", "status"]
+BIN_FIELDS = ["keys", "point_list", "packed", "inv", "keys_sorted"]
+PACKED_FLOATS = 12
+INST_GRAD_FLOATS = 12
+
+
+class HgsError(RuntimeError):
+    pass
+
+
+def build(verbose=False):
+    """Compile csrc/*.hip into libhgs.so for gfx950 (no GPU needed)."""
+    subprocess.check_call(["make", "-s", "-j8", "-C", CSRC], stdout=None if verbose else subprocess.DEVNULL)
+    return LIB_PATH
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise HgsError(f"{LIB_PATH} not found: run hgs_runtime.build() (hipcc --offload-arch=gfx950). "
+                           "There is no CPU fallback.")
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        if L.hgs_abi_version() != 1:
+            raise HgsError("libhgs.so ABI version mismatch")
+        _lib = L
+    return _lib
+
+
+def check(status):
+    if status != 0:
+        raise HgsError(lib().hgs_last_error().decode())
+
+
+def ptr(t):
+    """Device pointer of a tensor; None / empty tensors map to NULL (the reference passes 0-element tensors)."""
+    if t is None or t.numel() == 0:
+        return None
+    return t.data_ptr()
+
+
+def current_stream():
+    import torch
+    return torch.cuda.current_stream().cuda_stream
+
+
+def require_gpu_tensor(t, name, dtype=None):
+    import torch
+    if not t.is_cuda:
+        raise HgsError(f"{name} must be a CUDA(HIP) tensor: libhgs.so only runs on the GPU, there is no CPU path")
+    if dtype is not None and t.dtype != dtype:
+        raise HgsError(f"{name} must be {dtype}, got {t.dtype}")
+    return t.contiguous()
+
+
+def layout(kind, *dims):
+    n = {"geom": len(GEOM_FIELDS), "image": len(IMG_FIELDS), "binning": len(BIN_FIELDS)}[kind]
+    arr = (C.c_size_t * n)()
+    getattr(lib(), f"hgs_{kind}_layout")(*dims, arr)
+    names = {"geom": GEOM_FIELDS, "image": IMG_FIELDS, "binning": BIN_FIELDS}[kind]
+    return dict(zip(names, list(arr)))

@@ -1,0 +1,1 @@
+"""MI355X drop-in for the reference's `simple_knn` package (submodules/simple-knn)."""

@@ -1,0 +1,120 @@
+/*
+ * hgs.h -- C ABI of libhgs.so, the MI355X (gfx950) rasterizer + distCUDA2 library.
+ *
+ * This is the drop-in boundary for the reference's native layer.  Every entry point names the
+ * reference interface it replaces (paths relative to /root/reference/submodules/):
+ *
+ *   hgs_forward_preprocess + hgs_forward_render
+ *        <-> RasterizeGaussiansCUDA            diff-gaussian-rasterization/rasterize_points.cu:35-115
+ *            CudaRasterizer::Rasterizer::forward  .../cuda_rasterizer/rasterizer_impl.cu:198-336
+ *            (split at the one point where the reference needs `num_rendered` on the host, :280-285)
+ *   hgs_backward
+ *        <-> RasterizeGaussiansBackwardCUDA    diff-gaussian-rasterization/rasterize_points.cu:117-196
+ *            CudaRasterizer::Rasterizer::backward .../cuda_rasterizer/rasterizer_impl.cu:340-434
+ *   hgs_mark_visible
+ *        <-> markVisible                       diff-gaussian-rasterization/rasterize_points.cu:198-217
+ *   hgs_dist2
+ *        <-> distCUDA2 / SimpleKNN::knn        simple-knn/spatial.cu:15-26, simple-knn/simple_knn.cu:186-222
+ *   hgs_geom_bytes / hgs_image_bytes / hgs_binning_bytes
+ *        <-> required<GeometryState|ImageState|BinningState>()  .../cuda_rasterizer/rasterizer_impl.h:67-71
+ *            (the reference grows torch byte tensors through resize callbacks, rasterize_points.cu:27-33;
+ *             here the caller asks for the size and allocates)
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer owned by the caller (torch), fp32/int32 contiguous, unless
+ *     the name ends in _host;  "absent" optional inputs are NULL (the reference passes 0-element tensors);
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream); calls only enqueue work,
+ *     except hgs_forward_preprocess which waits for the instance count when num_rendered_host != NULL;
+ *   - return value 0 = ok, non-zero = error, message in hgs_last_error() (thread-local);
+ *   - matrices are the reference's row-vector (transposed) 4x4s, read as m[0],m[4],m[8],m[12] per row
+ *     (cuda_rasterizer/auxiliary.h:58-77);
+ *   - the three opaque buffers play the roles of geomBuffer / imgBuffer / binningBuffer
+ *     (rasterize_points.cu:72-78): written by forward, handed back unchanged to backward.
+ *   - not re-entrant on the same buffers; distinct buffers + distinct streams may overlap.
+ */
+#ifndef HGS_H_INCLUDED
+#define HGS_H_INCLUDED
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HGS_ABI_VERSION 1
+#define HGS_TILE 16 /* cuda_rasterizer/config.h:16-17 */
+
+int hgs_abi_version(void);
+const char* hgs_last_error(void);
+
+/* ---- workspace sizes (bytes).  Layout is private; hgs_*_layout() exposes it for tests. ---- */
+size_t hgs_geom_bytes(int P);
+size_t hgs_image_bytes(int W, int H);
+size_t hgs_binning_bytes(int R);
+size_t hgs_backward_scratch_bytes(int P, int R);
+
+/* Forward, part 1: per-Gaussian preprocess (cull, cov3D, EWA cov2D, conic, radius, tile rect, SH->RGB)
+ * + per-tile instance counts + scans.  Writes radii[P].  If num_rendered_host != NULL the call blocks
+ * until R = num_rendered is known and stores it there (reference: rasterizer_impl.cu:280-281);
+ * with NULL nothing blocks and R stays on the device (pass a capacity to hgs_forward_render). */
+int hgs_forward_preprocess(void* stream, int P, int D, int M, int W, int H,
+                           const float* means3D, const float* shs, const float* colors_precomp,
+                           const float* opacities, const float* scales, float scale_modifier,
+                           const float* rotations, const float* cov3D_precomp,
+                           const float* viewmatrix, const float* projmatrix, const float* campos,
+                           float tan_fovx, float tan_fovy, int prefiltered,
+                           void* geom_buf, void* image_buf, int* radii, int* num_rendered_host);
+
+/* Forward, part 2: instance scatter (tile binning), per-tile depth sort, front-to-back blend.
+ * `R_capacity` = number of instances binning_buf was sized for (== num_rendered in the blocking mode).
+ * out_color is [3,H,W].  Fails (status in hgs_read_status) if the scene needs more than R_capacity. */
+int hgs_forward_render(void* stream, int P, int W, int H, int R_capacity, const float* bg,
+                       const float* colors_precomp, void* geom_buf, void* binning_buf, void* image_buf,
+                       float* out_color);
+
+/* Backward.  All nine gradient outputs are fully written by the call (zeros for culled Gaussians):
+ * the caller does not need to zero-fill them (reference zero-allocates, rasterize_points.cu:151-159).
+ * dL_dconic is [P,2,2] (element [1,0] is written as 0), dL_dmeans2D is [P,3] (z = 0).
+ * `scratch` >= hgs_backward_scratch_bytes(P, R) bytes. */
+int hgs_backward(void* stream, int P, int D, int M, int R, int W, int H, const float* bg,
+                 const float* means3D, const float* shs, const float* colors_precomp,
+                 const float* scales, float scale_modifier, const float* rotations,
+                 const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix,
+                 const float* campos, float tan_fovx, float tan_fovy, const int* radii,
+                 const void* geom_buf, const void* binning_buf, const void* image_buf,
+                 const float* dL_dpix, void* scratch,
+                 float* dL_dmeans2D, float* dL_dconic, float* dL_dopacity, float* dL_dcolors,
+                 float* dL_dmeans3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscales,
+                 float* dL_drotations);
+
+/* present[i] = (view-space z > 0.2)   (cuda_rasterizer/rasterizer_impl.cu:54-66) */
+int hgs_mark_visible(void* stream, int P, const float* means3D, const float* viewmatrix,
+                     const float* projmatrix, uint8_t* present);
+
+/* distCUDA2: out[i] = mean of the 3 smallest squared distances from point i to the other points. */
+size_t hgs_dist2_scratch_bytes(int P);
+int hgs_dist2(void* stream, int P, const float* points, float* out, void* scratch, size_t scratch_bytes);
+
+/* ---- introspection used by the parity tests (byte offsets of the sub-arrays of each buffer) ---- */
+enum { HGS_GEOM_DEPTHS = 0, HGS_GEOM_CLAMPED, HGS_GEOM_MEANS2D, HGS_GEOM_COV3D, HGS_GEOM_CONIC_OPACITY,
+       HGS_GEOM_RGB, HGS_GEOM_TILES_TOUCHED, HGS_GEOM_POINT_OFFSETS, HGS_GEOM_RECT, HGS_GEOM_BLOCK_SUMS,
+       HGS_GEOM_NFIELDS };
+enum { HGS_IMG_FINAL_T = 0, HGS_IMG_N_CONTRIB, HGS_IMG_RANGES, HGS_IMG_TILE_COUNT, HGS_IMG_TILE_CURSOR,
+       HGS_IMG_TILE_MAXC, HGS_IMG_STATUS, HGS_IMG_NFIELDS };
+enum { HGS_BIN_KEYS = 0, HGS_BIN_POINT_LIST, HGS_BIN_PACKED, HGS_BIN_INV, HGS_BIN_KEYS_TMP, HGS_BIN_NFIELDS };
+int hgs_geom_layout(int P, size_t* offsets /* [HGS_GEOM_NFIELDS] */);
+int hgs_image_layout(int W, int H, size_t* offsets /* [HGS_IMG_NFIELDS] */);
+int hgs_binning_layout(int R, size_t* offsets /* [HGS_BIN_NFIELDS] */);
+
+/* status words written by the kernels into image_buf (HGS_IMG_STATUS): [0]=num_rendered, [1]=overflow flag */
+#define HGS_STATUS_WORDS 4
+/* bytes per packed instance record in HGS_BIN_PACKED (12 floats: x,y, conic a,b,c, opacity, r,g,b, id, pad, pad) */
+#define HGS_PACKED_FLOATS 12
+/* floats per instance in the backward scratch (dmean2D.xy, dconic.xyw, dopacity, dcolor.rgb, pad...) */
+#define HGS_INST_GRAD_FLOATS 12
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HGS_H_INCLUDED */

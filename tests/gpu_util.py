@@ -1,0 +1,85 @@
+"""Helpers for the GPU parity tests: run the HIP path through the drop-in `_C` module (ctypes -> C ABI) and view
+the opaque workspace buffers as typed arrays for comparison with the oracle."""
+import numpy as np
+import torch
+
+import hgs_runtime as rt
+from diff_gaussian_rasterization import _C
+
+
+def to_dev(x, dev="cuda"):
+    if x is None:
+        return torch.empty(0, device=dev)
+    return torch.as_tensor(np.ascontiguousarray(x), device=dev)
+
+
+def run_forward(scene, dev="cuda", debug=False):
+    s = scene
+    args = (to_dev(s["bg"]), to_dev(s["means3D"]), to_dev(s["colors_precomp"]), to_dev(s["opacities"]).reshape(-1, 1),
+            to_dev(s["scales"]), to_dev(s["rotations"]), float(s["scale_modifier"]), to_dev(s["cov3D_precomp"]),
+            to_dev(s["viewmatrix"]), to_dev(s["projmatrix"]), float(s["tanfovx"]), float(s["tanfovy"]), int(s["H"]),
+            int(s["W"]), to_dev(s["shs"]), int(s["sh_degree"]), to_dev(s["campos"]), False, debug)
+    R, color, radii, geom, binning, img = _C.rasterize_gaussians(*args)
+    torch.cuda.synchronize()
+    return dict(args=args, R=R, color=color, radii=radii, geom=geom, binning=binning, img=img)
+
+
+def _view(buf, off, count, dtype):
+    nbytes = count * np.dtype(dtype).itemsize
+    return np.frombuffer(buf[off:off + nbytes].cpu().numpy().tobytes(), dtype=dtype, count=count)
+
+
+def intermediates(scene, fw):
+    P, W, H, R = scene["means3D"].shape[0], scene["W"], scene["H"], fw["R"]
+    T = ((W + 15) // 16) * ((H + 15) // 16)
+    g = rt.layout("geom", P)
+    im = rt.layout("image", W, H)
+    o = {}
+    gb, ib, bb = fw["geom"], fw["img"], fw["binning"]
+    if P:
+        o["depths"] = _view(gb, g["depths"], P, np.float32)
+        o["clamped"] = _view(gb, g["clamped"], 3 * P, np.uint8).reshape(P, 3)
+        o["means2D"] = _view(gb, g["means2D"], 2 * P, np.float32).reshape(P, 2)
+        o["cov3D"] = _view(gb, g["cov3D"], 6 * P, np.float32).reshape(P, 6)
+        o["conic_opacity"] = _view(gb, g["conic_opacity"], 4 * P, np.float32).reshape(P, 4)
+        o["rgb"] = _view(gb, g["rgb"], 3 * P, np.float32).reshape(P, 3)
+        o["tiles_touched"] = _view(gb, g["tiles_touched"], P, np.uint32)
+        o["point_offsets"] = _view(gb, g["point_offsets"], P, np.uint32)
+    o["final_T"] = _view(ib, im["final_T"], W * H, np.float32).reshape(H, W)
+    o["n_contrib"] = _view(ib, im["n_contrib"], W * H, np.uint32).reshape(H, W)
+    o["ranges"] = _view(ib, im["ranges"], 2 * T, np.uint32).reshape(T, 2)
+    o["status"] = _view(ib, im["status"], 4, np.uint32)
+    o["tile_maxc"] = _view(ib, im["tile_maxc"], T, np.uint32)
+    if R:
+        b = rt.layout("binning", R)
+        o["point_list"] = _view(bb, b["point_list"], R, np.uint32)
+        ks = _view(bb, b["keys_sorted"], R, np.uint64)  # depth_bits<<32 | id, per tile
+        # rebuild the reference's key format tile<<32|depth_bits (rasterizer_impl.cu:102-104) from ranges
+        tile_of = np.zeros(R, np.uint64)
+        for t in range(T):
+            a, e = o["ranges"][t]
+            tile_of[a:e] = t
+        o["keys_sorted"] = (tile_of << np.uint64(32)) | (ks >> np.uint64(32))
+        o["inv"] = _view(bb, b["inv"], R, np.uint32)
+    else:
+        o["point_list"] = np.zeros(0, np.uint32)
+        o["keys_sorted"] = np.zeros(0, np.uint64)
+    o["out_color"] = fw["color"].cpu().numpy()
+    o["radii"] = fw["radii"].cpu().numpy()
+    o["num_rendered"] = R
+    return o
+
+
+def run_backward(scene, fw, dL_dpix):
+    a = fw["args"]
+    (bg, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D, view, proj, tfx, tfy, H, W, sh, degree,
+     campos, _, debug) = a
+    out = _C.rasterize_gaussians_backward(bg, means3D, fw["radii"], colors, scales, rotations, scale_modifier, cov3D, view,
+                                          proj, tfx, tfy, to_dev(dL_dpix), sh, degree, campos, fw["geom"], fw["R"],
+                                          fw["binning"], fw["img"], debug)
+    torch.cuda.synchronize()
+    names = ["dL_dmeans2D", "dL_dcolors", "dL_dopacity", "dL_dmeans3D", "dL_dcov3D", "dL_dsh", "dL_dscales",
+             "dL_drotations"]
+    g = {n: t.cpu().numpy() for n, t in zip(names, out)}
+    g["dL_dconic"] = _C.rasterize_gaussians_backward.last_dL_dconic.cpu().numpy().reshape(-1, 4)
+    return g
