@@ -98,8 +98,11 @@ int hgs_forward_render(void* stream, int P, int W, int H, int R_capacity, const 
     if (R_capacity > 0) {
       if (check_aligned(binning_buf, "binning_buf")) return 1;
       hgs_binning_carve((char*)binning_buf, (size_t)R_capacity, b, nullptr);
+    }
+    // the scatter also finishes the per-Gaussian instance offsets, so it runs even when nothing is visible
+    if (hgs_launch_scatter(s, P, W, H, R_capacity > 0 ? R_capacity : 0, nullptr, g, im, b)) return 1;
+    if (R_capacity > 0) {
       const float* feat = colors_precomp ? colors_precomp : g.rgb;
-      if (hgs_launch_scatter(s, P, W, H, R_capacity, nullptr, g, im, b)) return 1;
       if (hgs_launch_sort_tiles(s, W, H, R_capacity, feat, g, im, b)) return 1;
     }
   }
