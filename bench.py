@@ -1,0 +1,209 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark: strand-Gaussian training iterations per second (+ forward render ms/view).
+
+  python bench.py --gpus N --steps K --warmup W [--workload north_star|c2|c3|c4|c5|tiny]
+
+One *train iteration* is the reference's (train.py:133-204): lr update, ONE camera view, render + 2 more raster
+passes inside the losses (mask, orientation), backward through all three, densification statistics, Adam step.
+With N GPUs (one process per GPU, launched by torch.distributed.run) every rank trains a different view of the same
+optimizer step; gradients are all-reduced over RCCL before Adam (hair-gs_amd/train.py).  `value` = whole-job train
+iterations (views) per second = N x optimizer steps / s; per-GPU work is fixed, so scaling is "weak".
+
+Default workload = BASELINE.json north_star: synthetic 100k strand-Gaussians (1000 strands x 100 segments), 1080p,
+32 views.  Data is synthetic (SURVEY.md 8d generators), parameters random-init: there is no dataset offline.
+
+The JSON line also carries
+  roofline      blend_bwd_kernel (the dominant kernel): algorithmic bytes (76 B x sum_tiles L_t +
+                20 B x W*H + 8 B x T per launch) / mean launch duration measured with HIP events on the launch
+                stream inside the timed region; peak = 8 TB/s HBM3E.
+  cpu_baseline  the CPU oracle (oracle/, OpenMP C restatement of the reference rasterizer) doing the 3 raster
+                fwd+bwd passes of one iteration on the host cores (rank 0, N=1 only, bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "hair-gs_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); measured copy BW is ~6.3 TB/s
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--workload", default="north_star")
+    ap.add_argument("--views", type=int, default=None, help="override the number of camera views")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timing", action="store_true", help="disable per-kernel HIP-event timing")
+    return ap.parse_args()
+
+
+def cpu_baseline(model, cam, threads):
+    """Oracle timing of the raster work of ONE iteration (3 fwd+bwd passes) on the host."""
+    import numpy as np
+    import torch
+    from oracle import hgs_oracle as O
+    O.set_threads(threads)
+    with torch.no_grad():
+        base = dict(means3D=model.get_xyz.cpu().numpy(), opacities=model.get_opacity.cpu().numpy().reshape(-1),
+                    scales=model.get_scaling.cpu().numpy(), rotations=model.get_rotation.cpu().numpy(),
+                    cov3D_precomp=None, viewmatrix=cam.world_view_transform.cpu().numpy(),
+                    projmatrix=cam.full_proj_transform.cpu().numpy(), campos=cam.camera_center.cpu().numpy(),
+                    bg=np.zeros(3, np.float32), tanfovx=float(np.tan(cam.FoVx * 0.5)), tanfovy=float(np.tan(cam.FoVy * 0.5)),
+                    W=cam.image_width, H=cam.image_height, sh_degree=model.active_sh_degree, scale_modifier=1.0)
+        passes = [dict(base, shs=model.get_features.cpu().numpy(), colors_precomp=None),
+                  dict(base, shs=None, colors_precomp=model.get_mask.repeat(1, 3).cpu().numpy()),
+                  dict(base, shs=None, colors_precomp=model.get_orientation.cpu().numpy())]
+    dpix = np.ones((3, cam.image_height, cam.image_width), np.float32)
+    t0 = time.perf_counter()
+    for s in passes:
+        f = O.forward(s)
+        O.backward(s, f, dpix)
+    dt = time.perf_counter() - t0
+    return dt
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+
+    import hgs_runtime as rt
+    from arguments import OptimizationParams
+    from gaussian_renderer import render
+    from synthetic import WORKLOADS, build_workload
+    from train import ViewParallel, ViewSampler, training_step
+    from utils.general import safe_state
+
+    rt.lib()  # fail loudly if the HIP library is missing
+    safe_state(True)
+    model, cams, extent = build_workload(args.workload, device=dev, seed=0, n_views=args.views)
+    opt = OptimizationParams()
+    opt.enable_topology = False  # densify/merge intervals (every 100 it) are reported separately, not in the timed loop
+    model.training_setup(opt)
+    bg = torch.zeros(3, dtype=torch.float32, device=dev)
+    vp = ViewParallel()
+    sampler = ViewSampler(cams, seed=0, rank=vp.rank, world=vp.world)
+
+    def sync_all():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    it = 0
+    for _ in range(args.warmup):
+        it += 1
+        training_step(model, sampler.next(), opt, bg, it, extent=extent, vp=vp)
+    if not args.no_kernel_timing:
+        sync_all()
+        rt.prof_collect()
+        rt.prof_enable(True)
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        it += 1
+        training_step(model, sampler.next(), opt, bg, it, extent=extent, vp=vp)
+    sync_all()
+    dt = time.perf_counter() - t0
+    kern = {}
+    if not args.no_kernel_timing:
+        kern = rt.prof_collect()
+        rt.prof_enable(False)
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+
+    # ---- forward-only render ms/view, all views, after 3 warm-ups
+    with torch.no_grad():
+        for c in cams[:3]:
+            render(c, model, bg)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        sumL = 0
+        for c in cams:
+            render(c, model, bg)
+        torch.cuda.synchronize()
+        render_ms = (time.perf_counter() - t1) * 1e3 / len(cams)
+        # sum over tiles of L_t (= tile_maxc) per view, for the algorithmic-byte model
+        from diff_gaussian_rasterization import _C as C_
+        W, H = cams[0].image_width, cams[0].image_height
+        T = ((W + 15) // 16) * ((H + 15) // 16)
+        lay = rt.layout("image", W, H)
+        Ls, Rs = [], []
+        for c in cams:
+            import math
+            out = C_.rasterize_gaussians(bg, model.get_xyz, torch.empty(0, device=dev), model.get_opacity, model.get_scaling,
+                                         model.get_rotation, 1.0, torch.empty(0, device=dev), c.world_view_transform,
+                                         c.full_proj_transform, math.tan(c.FoVx * 0.5), math.tan(c.FoVy * 0.5), H, W,
+                                         model.get_features, model.active_sh_degree, c.camera_center, False, False)
+            img = out[5]
+            maxc = img[lay["tile_maxc"]:lay["tile_maxc"] + 4 * T].view(torch.int32)
+            Ls.append(int(maxc.sum().item()))
+            Rs.append(out[0])
+        meanL, meanR = sum(Ls) / len(Ls), sum(Rs) / len(Rs)
+
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+    kind, kw, views, W, H = WORKLOADS[args.workload]
+    T = ((W + 15) // 16) * ((H + 15) // 16)
+    P = model.get_xyz.shape[0]
+    result = {
+        "metric": "train_iters_per_sec", "value": world * args.steps / dt, "unit": "iters/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt * 1e3 / args.steps, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"{args.workload}: {P} strand-Gaussians, {len(cams)} views @ {W}x{H}, 1 view/GPU/step, "
+                               "3 raster fwd+bwd passes + L1/DSSIM/mask/orientation/smoothness losses + Adam",
+                   "gaussians": P, "views": len(cams), "width": W, "height": H, "parallelism": f"view-parallel x{world}",
+                   "mean_num_rendered": meanR, "mean_sum_tile_list_len": meanL},
+        "render_ms_per_view": render_ms,
+    }
+    if kern:
+        bwd_ms, bwd_n = kern["blend_bwd_kernel"]
+        fwd_ms, fwd_n = kern["blend_fwd_kernel"]
+        bytes_bwd = 76.0 * meanL + 20.0 * W * H + 8.0 * T
+        bytes_fwd = 40.0 * meanL + 20.0 * W * H + 8.0 * T
+        ach = bytes_bwd / (bwd_ms / max(bwd_n, 1) * 1e-3) / 1e9 if bwd_ms > 0 else 0.0
+        result["roofline"] = {"kernel": "blend_bwd_kernel", "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS,
+                              "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                              "algorithmic_bytes_per_launch": bytes_bwd, "mean_launch_us": bwd_ms / max(bwd_n, 1) * 1e3,
+                              "launches": bwd_n}
+        result["roofline_blend_fwd"] = {"achieved": bytes_fwd / (fwd_ms / max(fwd_n, 1) * 1e-3) / 1e9 if fwd_ms else 0.0,
+                                        "unit": "GB/s", "mean_launch_us": fwd_ms / max(fwd_n, 1) * 1e3}
+        result["kernel_us_per_launch"] = {k: (v[0] / v[1] * 1e3 if v[1] else 0.0) for k, v in kern.items()}
+        result["kernel_ms_per_iter"] = {k: v[0] / args.steps for k, v in kern.items()}
+    if world == 1 and not args.no_cpu_baseline:
+        threads = min(os.cpu_count() or 1, 64)
+        try:
+            sec = cpu_baseline(model, cams[0], threads)
+            result["cpu_baseline"] = {"value": 1.0 / sec, "unit": "iters/s", "cores": threads, "kind": "port",
+                                      "sample": "1 view of the same workload: the 3 raster fwd+bwd passes of one "
+                                                "iteration through oracle/ (OpenMP C restatement of the reference "
+                                                "rasterizer); losses and Adam excluded"}
+        except Exception as e:  # the baseline must never break the headline number
+            result["cpu_baseline"] = {"value": None, "error": str(e)}
+    print(json.dumps(result))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -14,6 +14,38 @@ void hgs_set_error(const char* fmt, ...) {
   va_end(ap);
 }
 
+// ---- per-kernel timing -------------------------------------------------------------------------
+#include <vector>
+namespace {
+struct ProfRec { hipEvent_t a, b; int id; };
+bool g_prof_on = false;
+std::vector<ProfRec> g_prof_log;
+std::vector<hipEvent_t> g_prof_pool;
+hipEvent_t g_prof_open = nullptr;
+int g_prof_open_id = -1;
+const char* kKernelNames[HGS_K_COUNT] = {"preprocess_fwd_kernel", "scan_kernel", "scatter_kernel", "sort_tiles_kernel",
+                                         "blend_fwd_kernel", "blend_bwd_kernel", "preprocess_bwd_kernel", "dist2_kernels"};
+hipEvent_t prof_event() {
+  if (!g_prof_pool.empty()) { hipEvent_t e = g_prof_pool.back(); g_prof_pool.pop_back(); return e; }
+  hipEvent_t e = nullptr;
+  (void)hipEventCreate(&e);
+  return e;
+}
+}  // namespace
+void hgs_prof_begin(hipStream_t s, int kernel_id) {
+  if (!g_prof_on) return;
+  g_prof_open = prof_event();
+  g_prof_open_id = kernel_id;
+  (void)hipEventRecord(g_prof_open, s);
+}
+void hgs_prof_end(hipStream_t s) {
+  if (!g_prof_on || !g_prof_open) return;
+  hipEvent_t b = prof_event();
+  (void)hipEventRecord(b, s);
+  g_prof_log.push_back({g_prof_open, b, g_prof_open_id});
+  g_prof_open = nullptr;
+}
+
 static int check_aligned(const void* p, const char* what) {
   if (!p || ((size_t)p & (HGS_ALIGN - 1))) {
     hgs_set_error("%s must be a non-null %d-byte aligned device pointer", what, HGS_ALIGN);
@@ -152,6 +184,22 @@ int hgs_mark_visible(void* stream, int P, const float* means3D, const float* vie
   if (P == 0) return 0;
   if (!means3D || !viewmatrix || !present) { hgs_set_error("null input"); return 1; }
   return hgs_launch_mark_visible((hipStream_t)stream, P, means3D, viewmatrix, present);
+}
+
+int hgs_prof_enable(int on) { g_prof_on = on != 0; return 0; }
+const char* hgs_prof_kernel_name(int id) { return (id >= 0 && id < HGS_K_COUNT) ? kKernelNames[id] : ""; }
+int hgs_prof_collect(double* total_ms, long long* launches) {
+  for (auto& r : g_prof_log) {
+    HGS_CHECK_HIP(hipEventSynchronize(r.b));
+    float ms = 0.f;
+    HGS_CHECK_HIP(hipEventElapsedTime(&ms, r.a, r.b));
+    if (total_ms) total_ms[r.id] += ms;
+    if (launches) launches[r.id] += 1;
+    g_prof_pool.push_back(r.a);
+    g_prof_pool.push_back(r.b);
+  }
+  g_prof_log.clear();
+  return 0;
 }
 
 size_t hgs_dist2_scratch_bytes(int P) { return hgs_dist2_scratch(P > 0 ? P : 0); }

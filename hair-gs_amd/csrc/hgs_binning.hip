@@ -138,7 +138,10 @@ __global__ __launch_bounds__(HGS_BLOCK) void sort_tiles_kernel(int gx, uint32_t 
 
 int hgs_launch_scan(hipStream_t s, int P, int T, const HgsGeom& g, const HgsImage& im) {
   const int nblk = (P + HGS_BLOCK - 1) / HGS_BLOCK;
-  hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(SCAN_THREADS), 0, s, nblk, T, g, im);
+  {
+    HgsProfScope _prof(s, HGS_K_SCAN);
+    hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(SCAN_THREADS), 0, s, nblk, T, g, im);
+  }
   HGS_CHECK_LAUNCH();
   return 0;
 }
@@ -146,7 +149,10 @@ int hgs_launch_scan(hipStream_t s, int P, int T, const HgsGeom& g, const HgsImag
 int hgs_launch_sort_tiles(hipStream_t s, int W, int H, int Rcap, const float* features, const HgsGeom& g,
                           const HgsImage& im, const HgsBinning& b) {
   const int gx = (W + HGS_TILE - 1) / HGS_TILE, gy = (H + HGS_TILE - 1) / HGS_TILE;
-  hipLaunchKernelGGL(sort_tiles_kernel, dim3(gx * gy), dim3(HGS_BLOCK), 0, s, gx, (uint32_t)Rcap, features, g, im, b);
+  {
+    HgsProfScope _prof(s, HGS_K_SORT_TILES);
+    hipLaunchKernelGGL(sort_tiles_kernel, dim3(gx * gy), dim3(HGS_BLOCK), 0, s, gx, (uint32_t)Rcap, features, g, im, b);
+  }
   HGS_CHECK_LAUNCH();
   return 0;
 }

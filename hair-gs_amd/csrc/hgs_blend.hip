@@ -178,8 +178,11 @@ __global__ __launch_bounds__(HGS_BLOCK) void blend_bwd_kernel(const uint2* __res
 int hgs_launch_blend_fwd(hipStream_t s, int W, int H, const float* bg, const HgsImage& im, const HgsBinning& b,
                          float* out_color) {
   const int gx = (W + HGS_TILE - 1) / HGS_TILE, gy = (H + HGS_TILE - 1) / HGS_TILE;
-  hipLaunchKernelGGL(blend_fwd_kernel, dim3(gx * gy), dim3(HGS_BLOCK), 0, s, im.ranges, b.packed, W, H, gx, bg,
+  {
+    HgsProfScope _prof(s, HGS_K_BLEND_FWD);
+    hipLaunchKernelGGL(blend_fwd_kernel, dim3(gx * gy), dim3(HGS_BLOCK), 0, s, im.ranges, b.packed, W, H, gx, bg,
                      im.final_T, im.n_contrib, im.tile_maxc, out_color);
+  }
   HGS_CHECK_LAUNCH();
   return 0;
 }
@@ -187,8 +190,11 @@ int hgs_launch_blend_fwd(hipStream_t s, int W, int H, const float* bg, const Hgs
 int hgs_launch_blend_bwd(hipStream_t s, int W, int H, const float* bg, const HgsImage& im, const HgsBinning& b,
                          const float* dL_dpix, float* inst_grad) {
   const int gx = (W + HGS_TILE - 1) / HGS_TILE, gy = (H + HGS_TILE - 1) / HGS_TILE;
-  hipLaunchKernelGGL(blend_bwd_kernel, dim3(gx * gy), dim3(HGS_BLOCK), 0, s, im.ranges, b.packed, W, H, gx, bg,
+  {
+    HgsProfScope _prof(s, HGS_K_BLEND_BWD);
+    hipLaunchKernelGGL(blend_bwd_kernel, dim3(gx * gy), dim3(HGS_BLOCK), 0, s, im.ranges, b.packed, W, H, gx, bg,
                      im.final_T, im.n_contrib, im.tile_maxc, dL_dpix, inst_grad);
+  }
   HGS_CHECK_LAUNCH();
   return 0;
 }

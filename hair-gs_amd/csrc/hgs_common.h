@@ -96,6 +96,15 @@ void hgs_set_error(const char* fmt, ...);
   } while (0)
 #define HGS_CHECK_LAUNCH() HGS_CHECK_HIP(hipGetLastError())
 
+// ---- optional per-kernel timing (hgs_api.hip) ---------------------------------------------------
+void hgs_prof_begin(hipStream_t s, int kernel_id);
+void hgs_prof_end(hipStream_t s);
+struct HgsProfScope {
+  hipStream_t s;
+  HgsProfScope(hipStream_t st, int id) : s(st) { hgs_prof_begin(st, id); }
+  ~HgsProfScope() { hgs_prof_end(s); }
+};
+
 // ---- launchers implemented in the kernel translation units -------------------------------------
 struct HgsFwdArgs {
   int P, D, M, W, H;

@@ -220,6 +220,7 @@ int hgs_launch_dist2(hipStream_t st, int P, const float* points, float* out, voi
     hgs_set_error("hgs_dist2: scratch must be %d-byte aligned and >= %zu bytes (got %zu)", HGS_ALIGN, hgs_dist2_scratch(P), scratch_bytes);
     return 1;
   }
+  HgsProfScope _prof(st, HGS_K_KNN);
   hipLaunchKernelGGL(minmax_kernel, dim3(1), dim3(1024), 0, st, P, points, s.minmax);
   hipLaunchKernelGGL(morton_kernel, dim3((unsigned)((Npad + 255) / 256)), dim3(256), 0, st, P, (int)Npad, points, s.minmax, s.keys);
   const unsigned nchunks = (unsigned)(Npad / KNN_LDS_KEYS);

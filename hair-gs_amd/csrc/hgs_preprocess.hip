@@ -467,7 +467,10 @@ __global__ __launch_bounds__(HGS_BLOCK) void mark_visible_kernel(int P, const fl
 
 int hgs_launch_preprocess_fwd(hipStream_t s, const HgsFwdArgs& a, const HgsGeom& g, const HgsImage& im, int* radii) {
   const int nblk = (a.P + HGS_BLOCK - 1) / HGS_BLOCK;
-  hipLaunchKernelGGL(preprocess_fwd_kernel, dim3(nblk), dim3(HGS_BLOCK), 0, s, a, g, im, radii);
+  {
+    HgsProfScope _prof(s, HGS_K_PREPROCESS_FWD);
+    hipLaunchKernelGGL(preprocess_fwd_kernel, dim3(nblk), dim3(HGS_BLOCK), 0, s, a, g, im, radii);
+  }
   HGS_CHECK_LAUNCH();
   return 0;
 }
@@ -476,14 +479,20 @@ int hgs_launch_scatter(hipStream_t s, int P, int W, int H, int Rcap, const int* 
   (void)H;
   const int nblk = (P + HGS_BLOCK - 1) / HGS_BLOCK;
   const int gx = (W + HGS_TILE - 1) / HGS_TILE;
-  hipLaunchKernelGGL(scatter_kernel, dim3(nblk), dim3(HGS_BLOCK), 0, s, P, gx, (uint32_t)Rcap, radii, g, im, b);
+  {
+    HgsProfScope _prof(s, HGS_K_SCATTER);
+    hipLaunchKernelGGL(scatter_kernel, dim3(nblk), dim3(HGS_BLOCK), 0, s, P, gx, (uint32_t)Rcap, radii, g, im, b);
+  }
   HGS_CHECK_LAUNCH();
   return 0;
 }
 int hgs_launch_preprocess_bwd(hipStream_t s, const HgsBwdArgs& a, const HgsGeom& g, const HgsBinning& b,
                               const float* inst_grad) {
   const int nblk = (a.P + HGS_BLOCK - 1) / HGS_BLOCK;
-  hipLaunchKernelGGL(preprocess_bwd_kernel, dim3(nblk), dim3(HGS_BLOCK), 0, s, a, g, b, inst_grad);
+  {
+    HgsProfScope _prof(s, HGS_K_PREPROCESS_BWD);
+    hipLaunchKernelGGL(preprocess_bwd_kernel, dim3(nblk), dim3(HGS_BLOCK), 0, s, a, g, b, inst_grad);
+  }
   HGS_CHECK_LAUNCH();
   return 0;
 }

@@ -31,6 +31,9 @@ SIGNATURES = {
     "hgs_mark_visible": (ci, [vp, ci, vp, vp, vp, vp]),
     "hgs_dist2_scratch_bytes": (sz, [ci]),
     "hgs_dist2": (ci, [vp, ci, vp, vp, vp, sz]),
+    "hgs_prof_enable": (ci, [ci]),
+    "hgs_prof_collect": (ci, [vp, vp]),
+    "hgs_prof_kernel_name": (C.c_char_p, [ci]),
     "hgs_geom_layout": (ci, [ci, vp]),
     "hgs_image_layout": (ci, [ci, ci, vp]),
     "hgs_binning_layout": (ci, [ci, vp]),
@@ -94,6 +97,21 @@ def require_gpu_tensor(t, name, dtype=None):
     if dtype is not None and t.dtype != dtype:
         raise HgsError(f"{name} must be {dtype}, got {t.dtype}")
     return t.contiguous()
+
+
+KERNEL_COUNT = 8
+
+
+def prof_enable(on=True):
+    lib().hgs_prof_enable(int(bool(on)))
+
+
+def prof_collect():
+    """{kernel name: (total_ms, launches)} since the last collect (synchronises the recorded events)."""
+    ms = (C.c_double * KERNEL_COUNT)()
+    n = (C.c_longlong * KERNEL_COUNT)()
+    check(lib().hgs_prof_collect(ms, n))
+    return {lib().hgs_prof_kernel_name(i).decode(): (ms[i], n[i]) for i in range(KERNEL_COUNT)}
 
 
 def layout(kind, *dims):

@@ -1,0 +1,134 @@
+"""Training losses (counterparts of the reference's loss/losses.py:16-355).  The loss math is stock PyTorch; what
+matters for the hot path is that mask_loss_rast and orientation_loss_rast each run one more rasterizer
+forward+backward through render(override_color=...), so one training iteration = 3 raster passes."""
+import math
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from gaussian_renderer import render
+from scene.hair_gaussian_model import HairGaussianModel
+
+_WINDOWS = {}
+
+
+def l1_loss(network_output, gt):
+    return torch.abs(network_output - gt).mean()
+
+
+def l2_loss(network_output, gt):
+    return ((network_output - gt) ** 2).mean()
+
+
+def gaussian(window_size, sigma):
+    g = torch.tensor([math.exp(-((x - window_size // 2) ** 2) / float(2 * sigma ** 2)) for x in range(window_size)])
+    return g / g.sum()
+
+
+def create_window(window_size, channel):
+    w1 = gaussian(window_size, 1.5).unsqueeze(1)
+    return (w1 @ w1.t()).float()[None, None].expand(channel, 1, window_size, window_size).contiguous()
+
+
+def _window(window_size, channel, like):
+    key = (window_size, channel, like.device, like.dtype)
+    if key not in _WINDOWS:  # the reference rebuilds + uploads the 11x11 window every call (losses.py:78-82)
+        _WINDOWS[key] = create_window(window_size, channel).to(device=like.device, dtype=like.dtype)
+    return _WINDOWS[key]
+
+
+def ssim(img1, img2, window_size=11, size_average=True):
+    """Gaussian-window SSIM exactly as losses.py:43-84 (5 grouped 11x11 convolutions, C1=0.01^2, C2=0.03^2)."""
+    channel = img1.size(-3)
+    window = _window(window_size, channel, img1)
+    pad = window_size // 2
+    mu1 = F.conv2d(img1, window, padding=pad, groups=channel)
+    mu2 = F.conv2d(img2, window, padding=pad, groups=channel)
+    mu1_sq, mu2_sq, mu1_mu2 = mu1.pow(2), mu2.pow(2), mu1 * mu2
+    sigma1_sq = F.conv2d(img1 * img1, window, padding=pad, groups=channel) - mu1_sq
+    sigma2_sq = F.conv2d(img2 * img2, window, padding=pad, groups=channel) - mu2_sq
+    sigma12 = F.conv2d(img1 * img2, window, padding=pad, groups=channel) - mu1_mu2
+    C1, C2 = 0.01 ** 2, 0.03 ** 2
+    ssim_map = ((2 * mu1_mu2 + C1) * (2 * sigma12 + C2)) / ((mu1_sq + mu2_sq + C1) * (sigma1_sq + sigma2_sq + C2))
+    return ssim_map.mean() if size_average else ssim_map.mean(1).mean(1).mean(1)
+
+
+def bidirectional_angle_difference(angle1, angle2):
+    """min(|a1-a2|, pi-|a1-a2|) for line orientations in [0, pi)."""
+    half_pi = np.pi / 2
+    ab = torch.abs if isinstance(angle1, torch.Tensor) else np.abs
+    return half_pi - ab(ab(angle1 - angle2) - half_pi)
+
+
+def angle_smoothness_loss(gaussians: HairGaussianModel, threshold: float = 30, eps: float = 1e-6):
+    """Mean squared bending angle over consecutive strand segments whose angle exceeds `threshold` degrees
+    (losses.py:175-221).  The index table comes from the model's cache instead of a per-step CPU rebuild."""
+    cos_th = np.cos(threshold * np.pi / 180)
+    idx = gaussians.smoothness_index_pairs()
+    if idx.shape[0] == 0:
+        return 0
+    pos = gaussians._endpoints[idx]                      # (N, 2, 2, 3)
+    d = pos[:, :, 1] - pos[:, :, 0]
+    d = d / torch.norm(d, dim=2, keepdim=True)
+    dot = torch.sum(d[:, 0] * d[:, 1], dim=1)
+    dot = dot[dot <= cos_th]
+    if dot.shape[0] == 0:
+        return 0
+    return torch.mean(torch.acos(torch.clamp(dot, -1 + eps, 1 - eps)) ** 2)
+
+
+def strand_joints_magnet_loss(gaussians: HairGaussianModel):
+    raise NotImplementedError("lambda_magnet is 0 (disabled) in the reference defaults (arguments/__init__.py:93)")
+
+
+def _black(device):
+    return torch.zeros(3, dtype=torch.float32, device=device)
+
+
+def orientation_loss_rast(gaussians, camera, args, bg=None):
+    """Render world-space segment directions, rotate to view space, convert to an angle in [0, pi) w.r.t. the image
+    y axis and compare bidirectionally with the GT orientation field, confidence-weighted (losses.py:224-289)."""
+    bg = _black(gaussians.get_xyz.device) if bg is None else bg
+    omap = render(camera, gaussians, bg, override_color=gaussians.get_orientation)["render"].permute(1, 2, 0)  # H,W,3
+    h, w = omap.shape[:2]
+    flat = omap.flatten(0, 1)
+    pix = (flat @ camera.world_view_transform[:3, :3])[:, :2]
+    pix = pix / (torch.norm(pix, dim=1, keepdim=True) + gaussians.min_val)
+    x, y = pix[:, 0], pix[:, 1]
+    y = torch.where(y < gaussians.min_val, y + gaussians.min_val, y)
+    theta = torch.atan2(x, y)
+    theta = torch.where(theta < 0, theta + np.pi, theta).reshape(h, w)
+    mask = torch.any(omap != bg, dim=2) if camera.mask is None else camera.mask
+    diff = bidirectional_angle_difference(theta[mask], camera.orientation_field[mask])
+    return (diff * camera.orientation_confidence[mask]).mean()
+
+
+def mask_loss_rast(gaussians, camera, args, bg=None):
+    """BCE-with-logits between the rasterized per-Gaussian mask value and the GT mask (losses.py:292-316)."""
+    bg = _black(gaussians.get_xyz.device) if bg is None else bg
+    rendered = render(camera, gaussians, bg, override_color=gaussians.get_mask.repeat(1, 3))["render"][0]
+    return F.binary_cross_entropy_with_logits(rendered, camera.float_mask)
+
+
+def loss_function(gaussians, image, viewpoint_cam, args):
+    """(1-l)L1 + l(1-SSIM) + l_mask BCE + l_orient orientation [+ l_smooth smoothness] (losses.py:319-355)."""
+    gt = viewpoint_cam.original_image
+    terms = {"l1": l1_loss(image, gt)}
+    loss = max(0, 1.0 - args.lambda_dssim) * terms["l1"]
+    terms["dssim"] = 1.0 - ssim(image, gt)
+    loss = loss + args.lambda_dssim * terms["dssim"]
+    if args.lambda_mask > 0 and viewpoint_cam.mask is not None:
+        terms["mask"] = mask_loss_rast(gaussians, viewpoint_cam, args)
+        loss = loss + args.lambda_mask * terms["mask"]
+    if args.lambda_orientation > 0:
+        terms["orientation"] = orientation_loss_rast(gaussians, viewpoint_cam, args)
+        loss = loss + args.lambda_orientation * terms["orientation"]
+    if isinstance(gaussians, HairGaussianModel):
+        if args.lambda_smooth > 0:
+            terms["smooth"] = angle_smoothness_loss(gaussians)
+            loss = loss + args.lambda_smooth * terms["smooth"]
+        if args.lambda_magnet > 0:
+            terms["magnet"] = strand_joints_magnet_loss(gaussians)
+            loss = loss + args.lambda_magnet * terms["magnet"]
+    return loss, terms

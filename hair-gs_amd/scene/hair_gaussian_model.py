@@ -1,0 +1,308 @@
+"""Stage-III strand model (counterpart of the reference's scene/hair_gaussian_model.py:44-1515).
+
+A Gaussian k is a line segment between two SHARED endpoints (e0, e1) = _endpoints[endpoint_pairs[k]] plus a width:
+    mean     = (e0 + e1) / 2                                                    (reference :167-172)
+    scale    = (max(|e1-e0|/2 * dist_to_scale_factor, 1e-7), exp(w), exp(w))    (:134-145)
+    rotation = quaternion of the rotation x_hat -> (e1-e0), identity if collapsed (:147-165)
+Gradients flow through all three back to the shared endpoints (scatter-add of per-segment gradients).
+
+This file holds the rasterizer-facing surface + optimizer plumbing + strand bookkeeping; the topology
+operators (split / clone / merge / grow) live in scene/hair_topology.py.
+"""
+from typing import NamedTuple
+
+import numpy as np
+import torch
+from torch import nn
+
+from scene.gaussian_model import GaussianModel
+from utils.general import get_expon_lr_func, inverse_sigmoid
+from utils.transform import calculate_rotation_from_vectors
+
+
+class StrandsInfo(NamedTuple):
+    list_strands: np.ndarray              # object array; each [n_seg, 2] endpoint ids, root -> tip
+    list_strands_segments_id: np.ndarray  # object array; each [n_seg] rows of endpoint_pairs
+    id_to_strand_id: np.ndarray           # endpoint id -> strand id (-1 if none)
+    strand_endpoint_id_to_complementary: np.ndarray  # strand end id -> the other end of its strand
+
+
+class HairGaussianModel(GaussianModel):
+    _PARAM_ATTRS = (("endpoints", "_endpoints"), ("f_dc", "_features_dc"), ("f_rest", "_features_rest"),
+                    ("opacity", "_opacity"), ("mask", "_mask"), ("width", "_width"))
+    _POSITION_GROUP = "endpoints"
+
+    def __init__(self, sh_degree: int = 3, spatial_lr_scale: float = 1.0, device: str = "cuda"):
+        self.active_sh_degree = 0
+        self.max_sh_degree = sh_degree
+        self.ref_strand_root = np.empty(0)
+        self.strand_root_endpoint_idx = torch.empty(0)
+        self.endpoint_pairs = torch.empty(0)
+        for _, attr in self._PARAM_ATTRS:
+            setattr(self, attr, torch.empty(0))
+        self.max_radii2D = torch.empty(0)
+        self.xyz_gradient_accum = torch.empty(0)
+        self.denom = torch.empty(0)
+        self.optimizer = None
+        self.spatial_lr_scale = spatial_lr_scale
+        self.device = device
+        self.setup_functions()
+        self.strands_info = None  # must be refreshed before topology operators run
+        self._smooth_pairs = None  # cached index tensor for the smoothness loss (depends on strands_info only)
+
+    def _capture_attrs(self):
+        return [(None, a) for a in ("ref_strand_root", "strand_root_endpoint_idx", "endpoint_pairs", "_endpoints",
+                                    "_features_dc", "_features_rest", "_opacity", "_mask", "_width")]
+
+    # ---- derived Gaussian parameters -------------------------------------------------------
+    def _segment_delta(self):
+        pairs = self._endpoints[self.endpoint_pairs]
+        return pairs, pairs[:, 1] - pairs[:, 0]
+
+    @property
+    def get_scaling(self):
+        _, diff = self._segment_delta()
+        half_len = torch.norm(diff, p=2, dim=1, keepdim=True) / 2
+        scale_x = torch.clamp(half_len * self.dist_to_scale_factor, min=self.min_val)
+        scale_yz = self.scaling_activation(self._width.repeat(1, 2))
+        return torch.cat((scale_x, scale_yz), dim=1)
+
+    @property
+    def get_rotation(self):
+        _, v2 = self._segment_delta()
+        rotation = torch.zeros((v2.shape[0], 4), dtype=torch.float, device=v2.device)
+        rotation[:, 0] = 1.0
+        valid = torch.norm(v2, p=2, dim=1) > self.min_val  # collapsed segments keep the identity
+        x_hat = torch.zeros_like(v2[valid])
+        x_hat[:, 0] = 1.0
+        rotation[valid] = calculate_rotation_from_vectors(x_hat, v2[valid], representation="quat")
+        return rotation
+
+    @property
+    def get_xyz(self):
+        return torch.mean(self._endpoints[self.endpoint_pairs], dim=1)
+
+    @property
+    def get_orientation(self):
+        """World-space unit direction of every segment; x_hat for collapsed ones (reference :188-201)."""
+        _, d = self._segment_delta()
+        norm = torch.norm(d, p=2, dim=1, keepdim=True)
+        ok = (norm >= self.min_val).squeeze(1)
+        out = torch.zeros_like(d)
+        out[:, 0] = 1.0
+        out[ok] = d[ok] / norm[ok]
+        return out
+
+    def get_covariance(self, scaling_modifier=0.5):
+        return self.covariance_activation(self.get_scaling, scaling_modifier, self.get_rotation)
+
+    def _num_primitives(self):
+        return self.endpoint_pairs.shape[0]
+
+    def create_from_pcd(self, pcd):
+        raise NotImplementedError("This method is only intended for Gaussian Model")
+
+    # ---- optimizer ---------------------------------------------------------------------------
+    def _group_lrs(self, ta):
+        return {"endpoints": ta.position_lr_init * self.spatial_lr_scale, "f_dc": ta.feature_lr,
+                "f_rest": ta.feature_lr / 20.0, "opacity": ta.opacity_lr, "mask": ta.mask_lr, "width": ta.scaling_lr}
+
+    def training_setup(self, training_args):
+        """6 Adam groups + endpoint lr schedule + merge distance/angle schedules + max segment length
+        (reference :212-283)."""
+        n = self._num_primitives()
+        self.max_radii2D = torch.zeros((n,), device=self.device)
+        self.xyz_gradient_accum = torch.zeros((n, 1), device=self.device)
+        self.denom = torch.zeros((n, 1), device=self.device)
+        lrs = self._group_lrs(training_args)
+        groups = [{"params": [getattr(self, attr)], "lr": lrs[name], "name": name} for name, attr in self._PARAM_ATTRS]
+        self.optimizer = torch.optim.Adam(groups, lr=0.0, eps=1e-15)
+        ta = training_args
+
+        def sched(a, b):
+            return get_expon_lr_func(lr_init=a, lr_final=b, lr_delay_mult=ta.position_lr_delay_mult,
+                                     max_steps=ta.position_lr_max_steps)
+        self.endpoints_scheduler = sched(ta.position_lr_init * self.spatial_lr_scale,
+                                         ta.position_lr_final * self.spatial_lr_scale)
+        self.xyz_scheduler_args = self.endpoints_scheduler
+        self.merge_dist_th, self.merge_dist_th_scheduler = ta.merge_dist_th_init, sched(ta.merge_dist_th_init,
+                                                                                         ta.merge_dist_th_final)
+        self.merge_angle_th, self.merge_angle_th_scheduler = ta.merge_angle_th_init, sched(ta.merge_angle_th_init,
+                                                                                            ta.merge_angle_th_final)
+        self.set_pval(ta.pval)
+        self.training_args = ta
+        # longest allowed segment = foreground bounding-box diagonal / num_points_strand
+        fg = (self.get_mask >= self.foreground_binarization_th).squeeze(1)
+        used = torch.zeros(self._endpoints.shape[0], dtype=torch.bool, device=self.device)
+        used[self.endpoint_pairs[fg].flatten()] = True
+        pts = self._endpoints[used]
+        self.max_segment_length = torch.norm(pts.max(dim=0).values - pts.min(dim=0).values) / ta.num_points_strand
+
+    def update_learning_rate(self, iteration):
+        for group in self.optimizer.param_groups:
+            if group["name"] == "endpoints":
+                group["lr"] = self.endpoints_scheduler(iteration)
+        self.merge_dist_th = self.merge_dist_th_scheduler(iteration)
+        self.merge_angle_th = self.merge_angle_th_scheduler(iteration)
+
+    def update_densification_stats(self, viewspace_point_tensor, radii, update_filter):
+        self.max_radii2D[update_filter] = torch.max(self.max_radii2D[update_filter], radii[update_filter])
+        self.xyz_gradient_accum[update_filter] += torch.norm(viewspace_point_tensor.grad[update_filter, :2], dim=-1,
+                                                             keepdim=True)
+        self.denom[update_filter] += 1
+
+    def reset_opacity(self):
+        new = inverse_sigmoid(torch.min(self.get_opacity, torch.ones_like(self.get_opacity) * 0.01))
+        self._rebind(self.replace_tensor_to_optimizer(new, "opacity"))
+
+    # ---- segment-level surgery (reference :469-622) ------------------------------------------
+    def _replace_tensor_in_optimizer(self, tensor, name):
+        return self.replace_tensor_to_optimizer(tensor, name)
+
+    def cat_segments(self, new_endpoint_pairs, new_endpoints, new_features_dc, new_features_rest, new_opacities,
+                     new_masks, new_widths):
+        self.endpoint_pairs = torch.cat([self.endpoint_pairs, new_endpoint_pairs], dim=0)
+        self._rebind(self.cat_tensors_to_optimizer({
+            "endpoints": new_endpoints, "f_dc": new_features_dc, "f_rest": new_features_rest, "opacity": new_opacities,
+            "mask": new_masks, "width": new_widths}))
+        self._reset_stats()
+        self._smooth_pairs = None
+
+    def prune_segments(self, segments_prune_mask):
+        """Drop segments; endpoints no segment references any more are dropped too and ids are compacted."""
+        seg_keep = ~segments_prune_mask
+        self.endpoint_pairs = self.endpoint_pairs[seg_keep]
+        ep_keep = torch.zeros(self._endpoints.shape[0], dtype=torch.bool, device=self.device)
+        ep_keep[self.endpoint_pairs.flatten()] = True
+        remap = torch.cumsum(ep_keep.to(torch.long), dim=0) - 1  # old id -> new id for kept endpoints
+        self.endpoint_pairs = remap[self.endpoint_pairs]
+        if torch.is_tensor(self.strand_root_endpoint_idx) and self.strand_root_endpoint_idx.numel():
+            self.strand_root_endpoint_idx = remap[self.strand_root_endpoint_idx]
+        out = {}
+        for g in self.optimizer.param_groups:
+            keep = ep_keep if g["name"] == "endpoints" else seg_keep
+            out[g["name"]] = self._swap_param(g, g["params"][0][keep], lambda m, k=keep: m[k])
+        self._rebind(out)
+        self.xyz_gradient_accum = self.xyz_gradient_accum[seg_keep]
+        self.denom = self.denom[seg_keep]
+        self.max_radii2D = self.max_radii2D[seg_keep]
+        self._smooth_pairs = None
+
+    # ---- strand bookkeeping ----------------------------------------------------------------------
+    def update_strand_root(self, dist_th: float = 1e-2):
+        """Endpoints that are the nearest neighbour of a reference root within sqrt(dist_th) become strand roots
+        (reference :1373-1399 uses pytorch3d.knn_points whose `dist` is the SQUARED distance)."""
+        if self.ref_strand_root is None or self.ref_strand_root.shape[0] == 0:
+            return
+        roots = torch.from_numpy(np.asarray(self.ref_strand_root)).to(self.device).to(self._endpoints.dtype)
+        ep = self._endpoints.detach()
+        sel = torch.zeros(ep.shape[0], dtype=torch.bool, device=self.device)
+        for s in range(0, roots.shape[0], 4096):
+            d2 = torch.cdist(roots[s:s + 4096], ep).pow(2)
+            best, arg = d2.min(dim=1)
+            sel[arg[best <= dist_th]] = True
+        self.strand_root_endpoint_idx = torch.nonzero(sel).squeeze(1)
+        print(f"Identified {int(sel.sum())} endpoints as strand roots")
+
+    def compute_strands_info(self, only_foreground: bool = True):
+        """Walk every open polyline of `endpoint_pairs` from one end to the other and orient it root -> tip by the
+        distance of its two ends to the nearest reference root (reference :1410-1498).  Assumes well-formed
+        chains (every endpoint id appears once or twice, no cycles)."""
+        if self.ref_strand_root is None or np.asarray(self.ref_strand_root).shape[0] == 0:
+            raise ValueError("ref_strand_root is not set")
+        from scipy.spatial import cKDTree
+        tree = cKDTree(np.asarray(self.ref_strand_root))
+        endpoints = self._endpoints.detach().cpu().numpy()
+        pairs = self.endpoint_pairs.cpu().numpy()
+        if only_foreground:
+            m = self.compute_foreground_mask().cpu().numpy()
+            pairs = pairs[m]
+        n_ep = endpoints.shape[0]
+        id_to_strand = -np.ones(n_ep, np.int32)
+        complementary = -np.ones(n_ep, np.int32)
+        if pairs.shape[0] == 0:
+            e = np.empty(0, dtype=object)
+            self.strands_info = StrandsInfo(e, e.copy(), id_to_strand, complementary)
+            self._smooth_pairs = None
+            return
+        # incidence table: endpoint id -> up to two rows (order of appearance, like the reference's id_to_row_id)
+        flat = pairs.reshape(-1)
+        order = np.argsort(flat, kind="stable")
+        ids_sorted = flat[order]
+        first = np.r_[True, ids_sorted[1:] != ids_sorted[:-1]]
+        inc = -np.ones((n_ep, 2), np.int64)
+        inc[ids_sorted[first], 0] = order[first] // 2
+        second = ~first
+        inc[ids_sorted[second], 1] = order[second] // 2
+        counts = np.bincount(flat, minlength=n_ep)
+        strand_ends = np.nonzero(counts == 1)[0]
+        visited = np.zeros(n_ep, bool)
+        strands, strands_rows = [], []
+        for start in strand_ends:
+            if visited[start]:
+                continue
+            cur, row = start, inc[start, 0]
+            seq, seq_rows = [], []
+            sid = len(strands)
+            while row != -1:
+                id_to_strand[cur] = sid
+                a, b = pairs[row]
+                nxt = a if a != cur else b
+                seq.append((cur, nxt))
+                seq_rows.append(row)
+                cur = nxt
+                r0, r1 = inc[cur]
+                row = r0 if r0 != row else r1
+            id_to_strand[cur] = sid
+            visited[start] = visited[cur] = True
+            complementary[start], complementary[cur] = cur, start
+            seq, seq_rows = np.asarray(seq, np.int64), np.asarray(seq_rows, np.int64)
+            dist, _ = tree.query(np.stack([endpoints[start], endpoints[cur]]), k=1)
+            if dist[0] > dist[1]:  # the far end was first: reverse direction and order
+                seq, seq_rows = seq[::-1, ::-1].copy(), seq_rows[::-1].copy()
+            strands.append(seq)
+            strands_rows.append(seq_rows)  # row ids index the (foreground-filtered) pair table, like the reference
+        ls, lr = np.empty(len(strands), dtype=object), np.empty(len(strands), dtype=object)
+        for i, (a, b) in enumerate(zip(strands, strands_rows)):
+            ls[i], lr[i] = a, b
+        self.strands_info = StrandsInfo(ls, lr, id_to_strand, complementary)
+        self._smooth_pairs = None
+
+    def smoothness_index_pairs(self):
+        """[pairs, 2, 2] endpoint-id tensor of consecutive segments of every strand, cached on the device until the
+        topology changes.  (The reference rebuilds it on the CPU through Cython every iteration, losses.py:193-199.)"""
+        if self._smooth_pairs is None:
+            from c_utils import filter_strand_list_segments
+            idx = filter_strand_list_segments(self.strands_info.list_strands)
+            self._smooth_pairs = torch.as_tensor(np.asarray(idx), device=self.device, dtype=torch.long)
+        return self._smooth_pairs
+
+    # ---- construction from explicit polylines (synthetic scenes; the reference builds strands through merge.py) --
+    @classmethod
+    def from_strands(cls, strand_points, width=1e-4, opacity=None, mask_prob=0.9, colors=None, sh_degree=0,
+                     spatial_lr_scale=1.0, device="cuda", ref_strand_root=None):
+        """strand_points: [S, V, 3] polylines; consecutive vertices share an endpoint (E = S*V, P = S*(V-1))."""
+        sp = torch.as_tensor(strand_points, dtype=torch.float32)
+        S, V, _ = sp.shape
+        m = cls(sh_degree=sh_degree, spatial_lr_scale=spatial_lr_scale, device=device)
+        ids = torch.arange(S * V).reshape(S, V)
+        pairs = torch.stack((ids[:, :-1].reshape(-1), ids[:, 1:].reshape(-1)), dim=1)
+        P = pairs.shape[0]
+        n_coef = (sh_degree + 1) ** 2
+        if colors is None:
+            colors = torch.full((P, 3), 0.5)
+        from utils.sh import RGB2SH
+        f_dc = RGB2SH(torch.as_tensor(colors, dtype=torch.float32)).reshape(P, 1, 3)
+        if opacity is None:
+            opacity = torch.full((P, 1), 0.8)
+        opacity = torch.as_tensor(opacity, dtype=torch.float32).reshape(P, 1)
+        m._endpoints = nn.Parameter(sp.reshape(-1, 3).to(device).contiguous().requires_grad_(True))
+        m.endpoint_pairs = pairs.to(device)
+        m._features_dc = nn.Parameter(f_dc.to(device).contiguous().requires_grad_(True))
+        m._features_rest = nn.Parameter(torch.zeros((P, n_coef - 1, 3), device=device).requires_grad_(True))
+        m._opacity = nn.Parameter(inverse_sigmoid(opacity).to(device).requires_grad_(True))
+        m._mask = nn.Parameter(inverse_sigmoid(torch.full((P, 1), float(mask_prob))).to(device).requires_grad_(True))
+        m._width = nn.Parameter(torch.full((P, 1), float(np.log(width)), device=device).requires_grad_(True))
+        m.ref_strand_root = (sp[:, 0].numpy() if ref_strand_root is None else np.asarray(ref_strand_root))
+        m.strand_root_endpoint_idx = ids[:, 0].to(device)
+        return m

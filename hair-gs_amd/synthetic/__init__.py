@@ -1,0 +1,129 @@
+"""Deterministic synthetic scenes for tests and benchmarks: camera rigs as the reference's
+dataset scripts build them (utils/camera.py generate_cameras; 90 degree FoV: focal = W/2), random Gaussian
+clouds (Stage I) and random-walk strand sets (Stage III), plus self-rendered training targets."""
+import math
+
+import numpy as np
+import torch
+
+from scene.cameras import Camera
+from utils.camera import generate_cameras
+from utils.graphics import focal2fov
+
+WORKLOADS = {
+    # name: (kind, primitives, views, W, H)   -- BASELINE.json configs
+    "north_star": ("strands", dict(n_strands=1000, n_seg=100), 32, 1920, 1080),   # 100k strand-Gaussians / 1080p / 32 views
+    "c2": ("cloud", dict(P=50000), 16, 800, 800),
+    "c3": ("strands", dict(n_strands=2000, n_seg=100), 32, 1920, 1080),
+    "c4": ("strands", dict(n_strands=10000, n_seg=100, curly=True), 48, 1920, 1080),
+    "c5": ("strands", dict(n_strands=5000, n_seg=100), 64, 1920, 1080),
+    "tiny": ("strands", dict(n_strands=40, n_seg=30), 4, 256, 144),
+}
+
+
+def make_cameras(n_views, W, H, device="cuda", dist=0.5, anchor=(0.0, 0.0, 0.0)):
+    """n_views-1 cameras on a circle of radius `dist` about the y axis + one top view; f = W/2 px."""
+    pose = np.eye(4)
+    pose[:3, 3] = np.asarray(anchor) + np.array([0.0, 0.0, -dist])  # looks along +z at the anchor
+    focal = W / 2.0
+    _, Es = generate_cameras(n_views, H, W, cam_pose=pose, anchor_pos=np.asarray(anchor, float), offset=dist,
+                             focal_length_px=focal)
+    cams = []
+    for uid, cid in enumerate(sorted(Es)):
+        w2c = Es[cid]
+        R = w2c[:3, :3].T  # camera-to-world rotation, as the COLMAP reader stores it
+        T = w2c[:3, 3]
+        cams.append(Camera(colmap_id=cid, R=R, T=T, FoVx=focal2fov(focal, W), FoVy=focal2fov(focal, H), image=None,
+                           gt_alpha_mask=None, image_name=f"view_{cid:03d}", uid=uid, data_device=device,
+                           image_width=W, image_height=H))
+    return cams
+
+
+def cameras_extent(cams):
+    """1.1 x max distance of a camera centre from their mean (data/dataset_readers.py:57-78) = spatial_lr_scale."""
+    c = torch.stack([cam.camera_center for cam in cams]).double()
+    return float(1.1 * (c - c.mean(0, keepdim=True)).norm(dim=1).max())
+
+
+def strand_polylines(n_strands, n_seg, seed=0, radius=0.10, step=0.0025, jitter_deg=5.0, curly=False):
+    """[S, n_seg+1, 3] random-walk strands rooted on a sphere (USC-HairSalon-like: 100 vertices, mm-scale steps)."""
+    rng = np.random.default_rng(seed)
+    roots = rng.normal(size=(n_strands, 3))
+    roots = radius * roots / np.linalg.norm(roots, axis=1, keepdims=True)
+    d = roots / np.linalg.norm(roots, axis=1, keepdims=True)
+    pts = [roots]
+    phase = rng.uniform(0, 2 * np.pi, n_strands)
+    for k in range(n_seg):
+        d = d + rng.normal(size=d.shape) * math.radians(jitter_deg) + np.array([0.0, 0.02, 0.0])  # +y = down (gravity)
+        d /= np.linalg.norm(d, axis=1, keepdims=True)
+        p = pts[-1] + step * d
+        pts.append(p)
+    pts = np.stack(pts, 1)
+    if curly:  # helical offset, radius 5 mm, period 20 segments
+        t = np.arange(n_seg + 1)[None, :] * (2 * np.pi / 20.0) + phase[:, None]
+        pts = pts + 0.005 * np.stack([np.cos(t), np.zeros_like(t), np.sin(t)], -1) * np.minimum(1.0, np.arange(n_seg + 1) / 10.0)[None, :, None]
+    return pts.astype(np.float32)
+
+
+def make_strand_model(n_strands, n_seg, seed=0, device="cuda", spatial_lr_scale=1.0, curly=False, sh_degree=0):
+    from scene.hair_gaussian_model import HairGaussianModel
+    pts = strand_polylines(n_strands, n_seg, seed=seed, curly=curly)
+    rng = np.random.default_rng(seed + 1)
+    P = n_strands * n_seg
+    hue = rng.uniform(0, 1, n_strands)
+    col = np.stack([0.5 + 0.4 * np.cos(2 * np.pi * (hue + s)) for s in (0.0, 1 / 3, 2 / 3)], 1)
+    col = np.repeat(col, n_seg, axis=0).astype(np.float32)
+    opacity = rng.uniform(0.3, 0.95, (P, 1)).astype(np.float32)
+    return HairGaussianModel.from_strands(pts, width=1e-4, opacity=opacity, mask_prob=0.9, colors=col,
+                                          sh_degree=sh_degree, spatial_lr_scale=spatial_lr_scale, device=device)
+
+
+def make_cloud_model(P, seed=0, device="cuda", spatial_lr_scale=1.0, radius=0.12, sh_degree=0):
+    """Stage-I initial state exactly as create_from_pcd builds it (distCUDA2 scales, opacity 0.1, mask 0.5)."""
+    from scene.gaussian_model import GaussianModel
+    from utils.graphics import BasicPointCloud
+    rng = np.random.default_rng(seed)
+    v = rng.normal(size=(P, 3))
+    v = v / np.linalg.norm(v, axis=1, keepdims=True) * radius * rng.uniform(0, 1, (P, 1)) ** (1 / 3)
+    m = GaussianModel(sh_degree=sh_degree, spatial_lr_scale=spatial_lr_scale, device=device)
+    m.create_from_pcd(BasicPointCloud(points=v.astype(np.float32), colors=rng.uniform(0, 1, (P, 3)).astype(np.float32),
+                                      normals=np.zeros((P, 3), np.float32)))
+    return m
+
+
+@torch.no_grad()
+def attach_targets(cams, model, seed=0, perturb=0.001):
+    """GT image = render of a perturbed copy of the model, GT mask = (alpha > 0), orientation ~ U[0,pi),
+    confidence ~ U[0,1] (SURVEY.md 8d 'Targets for the training step')."""
+    from gaussian_renderer import render
+    dev = model.get_xyz.device
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    pos_attr = "_endpoints" if hasattr(model, "_endpoints") and model._endpoints.numel() else "_xyz"
+    saved = getattr(model, pos_attr).data.clone()
+    getattr(model, pos_attr).data.add_(torch.randn(saved.shape, generator=g).to(dev) * perturb)
+    bg = torch.zeros(3, device=dev)
+    ones = torch.ones((model.get_xyz.shape[0], 3), device=dev)
+    for cam in cams:
+        H, W = cam.image_height, cam.image_width
+        cam.original_image = render(cam, model, bg)["render"].clamp(0, 1).detach()
+        alpha = render(cam, model, bg, override_color=ones)["render"][0]
+        cam.mask = alpha > 0
+        cam.float_mask = cam.mask.to(torch.float32)
+        cam.orientation_field = (torch.rand((H, W), generator=g) * math.pi).to(dev)
+        cam.orientation_confidence = torch.rand((H, W), generator=g).to(dev)
+    getattr(model, pos_attr).data.copy_(saved)
+
+
+def build_workload(name, device="cuda", seed=0, with_targets=True, n_views=None):
+    kind, kw, views, W, H = WORKLOADS[name]
+    views = views if n_views is None else n_views
+    cams = make_cameras(views, W, H, device=device)
+    extent = cameras_extent(cams)
+    if kind == "strands":
+        model = make_strand_model(seed=seed, device=device, spatial_lr_scale=extent, **kw)
+        model.compute_strands_info(only_foreground=True)
+    else:
+        model = make_cloud_model(seed=seed, device=device, spatial_lr_scale=extent, **kw)
+    if with_targets:
+        attach_targets(cams, model, seed=seed)
+    return model, cams, extent

@@ -1,0 +1,129 @@
+"""Training step + loop (counterpart of the reference's train.py:38-265), single GPU or view-parallel.
+
+One iteration (`training_step`) reproduces train.py:133-204: lr update, SH-degree bump every 1000 it, one view,
+render -> loss_function (which renders twice more) -> backward, densification statistics / densification /
+opacity reset / merging at their intervals, Adam step, zero_grad.
+
+View-parallel extension (not in the reference, which is single-process): every rank draws a DIFFERENT view of the
+same global step, gradients of all parameter groups are summed with ONE RCCL all-reduce over a flat fp32 buffer and
+averaged, densification statistics are reduced the same way (SUM / MAX), then every rank applies the identical
+Adam update, so parameters stay replicated bit for bit.  Topology operators run on identical replicated state with
+identical seeds.
+"""
+import random
+
+import torch
+import torch.distributed as dist
+
+from gaussian_renderer import render
+from loss.losses import loss_function
+from scene.hair_gaussian_model import HairGaussianModel
+
+
+class ViewParallel:
+    """Gradient + statistics exchange for view-parallel training (one process per GPU, torch.distributed;
+    backend "nccl" is RCCL over xGMI on ROCm, "gloo" on CPU for tests)."""
+
+    def __init__(self, enabled=None):
+        self.enabled = dist.is_available() and dist.is_initialized() if enabled is None else enabled
+        self.world = dist.get_world_size() if self.enabled else 1
+        self.rank = dist.get_rank() if self.enabled else 0
+        self._flat = None
+
+    def params(self, gaussians):
+        return [g["params"][0] for g in gaussians.optimizer.param_groups]
+
+    def reduce_gradients(self, gaussians):
+        """One all-reduce(SUM) over [endpoints|f_dc|f_rest|opacity|mask|width] (Stage I: xyz|...|rotation), / world."""
+        if self.world == 1:
+            return
+        ps = [p for p in self.params(gaussians) if p.grad is not None]
+        n = sum(p.grad.numel() for p in ps)
+        if self._flat is None or self._flat.numel() != n or self._flat.device != ps[0].device:
+            self._flat = torch.empty(n, dtype=torch.float32, device=ps[0].device)
+        off = 0
+        for p in ps:
+            k = p.grad.numel()
+            self._flat[off:off + k].copy_(p.grad.reshape(-1))
+            off += k
+        dist.all_reduce(self._flat, op=dist.ReduceOp.SUM)
+        self._flat.div_(self.world)
+        off = 0
+        for p in ps:
+            k = p.grad.numel()
+            p.grad.copy_(self._flat[off:off + k].view_as(p.grad))
+            off += k
+
+    def reduce_stats(self, gaussians):
+        if self.world == 1:
+            return
+        both = torch.cat([gaussians.xyz_gradient_accum.reshape(-1), gaussians.denom.reshape(-1)])
+        dist.all_reduce(both, op=dist.ReduceOp.SUM)
+        n = gaussians.xyz_gradient_accum.numel()
+        gaussians.xyz_gradient_accum.copy_(both[:n].view_as(gaussians.xyz_gradient_accum))
+        gaussians.denom.copy_(both[n:].view_as(gaussians.denom))
+        dist.all_reduce(gaussians.max_radii2D, op=dist.ReduceOp.MAX)
+
+
+class ViewSampler:
+    """Pops random cameras without replacement, refilling when empty (train.py:139-143).  With `world` ranks the
+    same shuffled order is generated on every rank and rank r takes entries r, r+world, ..."""
+
+    def __init__(self, cameras, seed=0, rank=0, world=1):
+        self.cameras, self.rank, self.world = cameras, rank, world
+        self.rng = random.Random(seed)
+        self.stack = []
+
+    def next(self):
+        picks = []
+        for _ in range(self.world):
+            if not self.stack:
+                self.stack = list(range(len(self.cameras)))
+            picks.append(self.stack.pop(self.rng.randint(0, len(self.stack) - 1)))
+        return self.cameras[picks[self.rank]]
+
+
+def training_step(gaussians, viewpoint_cam, opt, bg, iteration, extent=1.0, vp=None, stats_local=None):
+    """One optimizer step.  Returns (loss tensor (detached, on device), loss_dict, render_pkg)."""
+    gaussians.update_learning_rate(iteration)
+    if iteration % 1000 == 0:
+        gaussians.oneupSHdegree()
+    render_pkg = render(viewpoint_cam, gaussians, bg)
+    loss, loss_dict = loss_function(gaussians, render_pkg["render"], viewpoint_cam, opt)
+    loss.backward()
+    with torch.no_grad():
+        if iteration < opt.densify_until_iter:
+            gaussians.update_densification_stats(render_pkg["viewspace_points"], render_pkg["radii"],
+                                                 render_pkg["visibility_filter"])
+            if iteration > opt.densify_from_iter and iteration % opt.densification_interval == 0 \
+                    and hasattr(gaussians, "densification") and getattr(opt, "enable_topology", True):
+                if vp is not None:
+                    vp.reduce_stats(gaussians)
+                size_threshold = opt.prune_max_radii_2d if iteration > opt.opacity_reset_interval else None
+                gaussians.densification(extent, size_threshold, None)
+            if iteration % opt.opacity_reset_interval == 0:
+                gaussians.reset_opacity()
+        if isinstance(gaussians, HairGaussianModel) and getattr(opt, "enable_topology", True):
+            if iteration % opt.merge_interval == 0 and hasattr(gaussians, "merging"):
+                gaussians.merging(training_info=None)
+        if vp is not None:
+            vp.reduce_gradients(gaussians)
+        gaussians.optimizer.step()
+        gaussians.optimizer.zero_grad(set_to_none=True)
+    return loss.detach(), loss_dict, render_pkg
+
+
+def training(gaussians, cameras, opt, iterations=None, extent=1.0, seed=0, log_every=0, vp=None, start_iteration=0):
+    """Plain loop over training_step (no logger / viewer / dataset IO: those are outside the accelerated path)."""
+    vp = ViewParallel() if vp is None else vp
+    dev = gaussians.get_xyz.device
+    bg = torch.zeros(3, dtype=torch.float32, device=dev)
+    sampler = ViewSampler(cameras, seed=seed, rank=vp.rank, world=vp.world)
+    ema = None
+    n = opt.iterations if iterations is None else iterations
+    for it in range(start_iteration + 1, start_iteration + n + 1):
+        loss, _, _ = training_step(gaussians, sampler.next(), opt, bg, it, extent=extent, vp=vp)
+        ema = loss if ema is None else 0.4 * loss + 0.6 * ema  # stays on the device: no per-iteration host sync
+        if log_every and it % log_every == 0 and vp.rank == 0:
+            print(f"[it {it}] loss(ema) {float(ema):.6f}")
+    return ema

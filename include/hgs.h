@@ -96,6 +96,16 @@ int hgs_mark_visible(void* stream, int P, const float* means3D, const float* vie
 size_t hgs_dist2_scratch_bytes(int P);
 int hgs_dist2(void* stream, int P, const float* points, float* out, void* scratch, size_t scratch_bytes);
 
+/* ---- per-kernel device timing (bench.py roofline): when enabled every kernel launch of the library is bracketed
+ * by hipEvents recorded on the launch stream.  hgs_prof_collect() synchronises those events, ADDS elapsed
+ * milliseconds / launch counts per kernel id into the caller's arrays (length HGS_K_COUNT) and clears the log.
+ * No reference counterpart (the reference only times whole iterations, train.py:81-82,133,156). ---- */
+enum { HGS_K_PREPROCESS_FWD = 0, HGS_K_SCAN, HGS_K_SCATTER, HGS_K_SORT_TILES, HGS_K_BLEND_FWD, HGS_K_BLEND_BWD,
+       HGS_K_PREPROCESS_BWD, HGS_K_KNN, HGS_K_COUNT };
+int hgs_prof_enable(int on);
+int hgs_prof_collect(double* total_ms, long long* launches);
+const char* hgs_prof_kernel_name(int kernel_id);
+
 /* ---- introspection used by the parity tests (byte offsets of the sub-arrays of each buffer) ---- */
 enum { HGS_GEOM_DEPTHS = 0, HGS_GEOM_CLAMPED, HGS_GEOM_MEANS2D, HGS_GEOM_COV3D, HGS_GEOM_CONIC_OPACITY,
        HGS_GEOM_RGB, HGS_GEOM_TILES_TOUCHED, HGS_GEOM_POINT_OFFSETS, HGS_GEOM_RECT, HGS_GEOM_BLOCK_SUMS,

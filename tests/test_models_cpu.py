@@ -1,0 +1,171 @@
+"""Model containers on CPU tensors (the rasterizer itself needs the GPU; see tests/test_gpu_train.py)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from arguments import OptimizationParams
+
+
+def _cloud(n=50, seed=0):
+    from scene.gaussian_model import GaussianModel
+    from torch import nn
+    g = torch.Generator().manual_seed(seed)
+    m = GaussianModel(sh_degree=1, spatial_lr_scale=2.0, device="cpu")
+    m._xyz = nn.Parameter(torch.randn(n, 3, generator=g))
+    m._features_dc = nn.Parameter(torch.randn(n, 1, 3, generator=g))
+    m._features_rest = nn.Parameter(torch.zeros(n, 3, 3))
+    m._scaling = nn.Parameter(torch.log(torch.rand(n, 3, generator=g) * 0.1 + 0.01))
+    m._rotation = nn.Parameter(torch.randn(n, 4, generator=g))
+    m._opacity = nn.Parameter(torch.randn(n, 1, generator=g))
+    m._mask = nn.Parameter(torch.randn(n, 1, generator=g))
+    m.max_radii2D = torch.zeros(n)
+    return m
+
+
+def test_gaussian_model_getters_and_covariance():
+    m = _cloud()
+    assert torch.allclose(m.get_scaling, torch.exp(m._scaling))
+    assert torch.allclose(m.get_rotation.norm(dim=1), torch.ones(50), atol=1e-6)
+    assert m.get_features.shape == (50, 4, 3)
+    cov = m.get_covariance(1.0)
+    from utils.transform import build_rotation
+    R = build_rotation(m._rotation)
+    S = torch.diag_embed(m.get_scaling)
+    full = R @ S @ S @ R.transpose(1, 2)
+    ref = torch.stack([full[:, 0, 0], full[:, 0, 1], full[:, 0, 2], full[:, 1, 1], full[:, 1, 2], full[:, 2, 2]], 1)
+    assert torch.allclose(cov, ref, atol=1e-6)
+    ori = m.get_orientation
+    idx = m.get_scaling.argmax(1)
+    assert torch.allclose(ori, R[torch.arange(50), :, idx], atol=1e-6)
+
+
+def test_training_setup_groups_and_lr_schedule():
+    m = _cloud()
+    opt = OptimizationParams()
+    m.training_setup(opt)
+    names = [g["name"] for g in m.optimizer.param_groups]
+    assert names == ["xyz", "f_dc", "f_rest", "opacity", "scaling", "mask", "rotation"]
+    lrs = {g["name"]: g["lr"] for g in m.optimizer.param_groups}
+    assert lrs["xyz"] == pytest.approx(0.00016 * 2.0) and lrs["f_rest"] == pytest.approx(0.025 / 20)
+    assert m.optimizer.defaults["eps"] == 1e-15
+    assert m.update_learning_rate(0) == pytest.approx(0.00016 * 2.0)
+    assert m.update_learning_rate(30000) == pytest.approx(0.0000016 * 2.0)
+    mid = m.update_learning_rate(15000)
+    assert mid == pytest.approx(math.sqrt(0.00016 * 0.0000016) * 2.0, rel=1e-6)
+    assert float(m.dist_to_scale_factor) == pytest.approx(0.5102133812190369, rel=1e-6)
+
+
+def test_densify_prune_keeps_optimizer_state_consistent():
+    torch.manual_seed(0)
+    m = _cloud(n=40)
+    opt = OptimizationParams()
+    m.training_setup(opt)
+    loss = (m._xyz ** 2).sum() + (m._opacity ** 2).sum() + (m._scaling ** 2).sum() + (m._rotation ** 2).sum() + \
+        (m._features_dc ** 2).sum() + (m._features_rest ** 2).sum() + (m._mask ** 2).sum()
+    loss.backward()
+    m.optimizer.step()
+    m.xyz_gradient_accum[:] = 1.0
+    m.denom[:] = 1.0
+    m.densification(extent=1.0, max_screen_size=None)
+    n = m.get_xyz.shape[0]
+    for g in m.optimizer.param_groups:
+        p = g["params"][0]
+        assert p.shape[0] == n and p.requires_grad
+        st = m.optimizer.state[p]
+        assert st["exp_avg"].shape == p.shape and st["exp_avg_sq"].shape == p.shape
+    assert m.xyz_gradient_accum.shape == (n, 1) and m.max_radii2D.shape == (n,)
+    m.reset_opacity()
+    assert float(m.get_opacity.max()) <= 0.01 + 1e-6
+    st = m.optimizer.state[m._opacity]
+    assert float(st["exp_avg"].abs().max()) == 0.0
+
+
+def _strands(S=6, V=9, seed=0):
+    from synthetic import strand_polylines
+    from scene.hair_gaussian_model import HairGaussianModel
+    pts = strand_polylines(S, V - 1, seed=seed)
+    return HairGaussianModel.from_strands(pts, device="cpu", sh_degree=0), pts
+
+
+def test_hair_model_closed_forms():
+    m, pts = _strands()
+    m.set_pval(0.05)
+    e0 = torch.from_numpy(pts[:, :-1].reshape(-1, 3))
+    e1 = torch.from_numpy(pts[:, 1:].reshape(-1, 3))
+    assert torch.allclose(m.get_xyz, 0.5 * (e0 + e1), atol=1e-7)
+    d = e1 - e0
+    ln = d.norm(dim=1)
+    sc = m.get_scaling
+    assert torch.allclose(sc[:, 0], ln / 2 * float(m.dist_to_scale_factor), rtol=1e-6)
+    assert torch.allclose(sc[:, 1:], torch.full_like(sc[:, 1:], 1e-4), rtol=1e-5)
+    q = m.get_rotation
+    from utils.transform import build_rotation, xaxis_to_direction_quaternion
+    assert torch.allclose(q, xaxis_to_direction_quaternion(d / ln[:, None]), atol=1e-5)
+    assert torch.allclose(build_rotation(q)[:, :, 0], d / ln[:, None], atol=1e-5)
+    assert torch.allclose(m.get_orientation, d / ln[:, None], atol=1e-6)
+    # collapsed segment -> identity rotation, x_hat orientation, clamped scale
+    with torch.no_grad():
+        m._endpoints[1] = m._endpoints[0]
+    assert torch.equal(m.get_rotation[0], torch.tensor([1.0, 0, 0, 0]))
+    assert torch.equal(m.get_orientation[0], torch.tensor([1.0, 0, 0]))
+    assert float(m.get_scaling[0, 0]) == pytest.approx(1e-7)
+
+
+def test_hair_gradients_reach_shared_endpoints():
+    m, _ = _strands()
+    (m.get_xyz.sum() + m.get_scaling.sum() + (m.get_rotation ** 2).sum()).backward()
+    g = m._endpoints.grad
+    assert g is not None and torch.isfinite(g).all() and (g.abs().sum(dim=1) > 0).all()
+
+
+def test_strands_info_and_smoothness_pairs():
+    m, pts = _strands(S=5, V=7)
+    m.compute_strands_info(only_foreground=True)
+    info = m.strands_info
+    assert len(info.list_strands) == 5
+    for s, strand in enumerate(info.list_strands):
+        assert strand.shape == (6, 2)
+        assert (strand[1:, 0] == strand[:-1, 1]).all()          # consecutive segments share an endpoint
+        assert strand[0, 0] == s * 7                             # oriented root -> tip
+        assert info.strand_endpoint_id_to_complementary[s * 7] == s * 7 + 6
+    pairs = m.smoothness_index_pairs()
+    assert pairs.shape == (5 * 5, 2, 2)
+    from loss.losses import angle_smoothness_loss
+    v = angle_smoothness_loss(m, threshold=0.0)
+    assert torch.is_tensor(v) and float(v) > 0
+    # reversed storage order of one strand must still come out root -> tip
+    m.endpoint_pairs = m.endpoint_pairs.flip(0)
+    m.compute_strands_info(only_foreground=True)
+    assert sorted(int(s[0, 0]) for s in m.strands_info.list_strands) == [0, 7, 14, 21, 28]
+
+
+def test_hair_prune_and_cat_segments():
+    m, _ = _strands(S=4, V=6)
+    m.training_setup(OptimizationParams())
+    P0, E0 = m.endpoint_pairs.shape[0], m._endpoints.shape[0]
+    prune = torch.zeros(P0, dtype=torch.bool)
+    prune[:5] = True  # the whole first strand
+    m.prune_segments(prune)
+    assert m.endpoint_pairs.shape[0] == P0 - 5 and m._endpoints.shape[0] == E0 - 6
+    assert int(m.endpoint_pairs.max()) == m._endpoints.shape[0] - 1
+    n_new = 3
+    m.cat_segments(torch.tensor([[0, 1]] * n_new), torch.zeros(0, 3), torch.zeros(n_new, 1, 3), torch.zeros(n_new, 0, 3),
+                   torch.zeros(n_new, 1), torch.zeros(n_new, 1), torch.zeros(n_new, 1))
+    assert m.endpoint_pairs.shape[0] == P0 - 5 + n_new == m._opacity.shape[0] == m.denom.shape[0]
+
+
+def test_generate_cameras_rig():
+    from utils.camera import generate_cameras
+    pose = np.eye(4)
+    pose[:3, 3] = [0, 0, -0.5]
+    cams, Es = generate_cameras(8, 100, 200, cam_pose=pose, offset=0.5, focal_length_px=100)
+    assert len(cams) == len(Es) == 8 and cams[1].params == [100, 100.0, 50.0]
+    for i in range(1, 8):
+        c2w = np.linalg.inv(Es[i])
+        assert np.linalg.norm(c2w[:3, 3]) == pytest.approx(0.5)
+        fwd = c2w[:3, 2]
+        assert np.allclose(fwd, -c2w[:3, 3] / 0.5, atol=1e-6)   # every ring camera looks at the anchor
+    top = np.linalg.inv(Es[8])
+    assert np.allclose(top[:3, 3], [0, 0.5, 0])
