@@ -76,17 +76,22 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
     if P == 0:
         return dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations
     scratch = torch.empty((L.hgs_backward_scratch_bytes(P, int(R)),), dtype=torch.uint8, device=dev)
+    # keep every (possibly freshly made contiguous) input alive in a local until the launch has been enqueued:
+    # a temporary released early would hand its block to the next temporary of the same size
     dpix = rt.require_gpu_tensor(dL_dout_color, "dL_dout_color", torch.float32)
+    bg_, sh_, colors_, scales_, rots_, cov_ = (_f32(background, "bg"), _f32(sh, "sh"), _f32(colors, "colors_precomp"),
+                                               _f32(scales, "scales"), _f32(rotations, "rotations"),
+                                               _f32(cov3D_precomp, "cov3D_precomp"))
+    view_, proj_, cam_ = _f32(viewmatrix, "viewmatrix"), _f32(projmatrix, "projmatrix"), _f32(campos, "campos")
+    radii_ = rt.require_gpu_tensor(radii, "radii", torch.int32)
     with torch.cuda.device(dev):
-        rt.check(L.hgs_backward(rt.current_stream(), P, int(degree), M, int(R), W, H, rt.ptr(_f32(background, "bg")),
-                                rt.ptr(means3D), rt.ptr(_f32(sh, "sh")), rt.ptr(_f32(colors, "colors_precomp")),
-                                rt.ptr(_f32(scales, "scales")), float(scale_modifier), rt.ptr(_f32(rotations, "rotations")),
-                                rt.ptr(_f32(cov3D_precomp, "cov3D_precomp")), rt.ptr(_f32(viewmatrix, "viewmatrix")),
-                                rt.ptr(_f32(projmatrix, "projmatrix")), rt.ptr(_f32(campos, "campos")), float(tan_fovx),
-                                float(tan_fovy), rt.ptr(radii), rt.ptr(geomBuffer), rt.ptr(binningBuffer),
-                                rt.ptr(imageBuffer), rt.ptr(dpix), rt.ptr(scratch), rt.ptr(dL_dmeans2D),
-                                rt.ptr(dL_dconic), rt.ptr(dL_dopacity), rt.ptr(dL_dcolors), rt.ptr(dL_dmeans3D),
-                                rt.ptr(dL_dcov3D), rt.ptr(dL_dsh), rt.ptr(dL_dscales), rt.ptr(dL_drotations)))
+        rt.check(L.hgs_backward(rt.current_stream(), P, int(degree), M, int(R), W, H, rt.ptr(bg_), rt.ptr(means3D),
+                                rt.ptr(sh_), rt.ptr(colors_), rt.ptr(scales_), float(scale_modifier), rt.ptr(rots_),
+                                rt.ptr(cov_), rt.ptr(view_), rt.ptr(proj_), rt.ptr(cam_), float(tan_fovx), float(tan_fovy),
+                                rt.ptr(radii_), rt.ptr(geomBuffer), rt.ptr(binningBuffer), rt.ptr(imageBuffer),
+                                rt.ptr(dpix), rt.ptr(scratch), rt.ptr(dL_dmeans2D), rt.ptr(dL_dconic), rt.ptr(dL_dopacity),
+                                rt.ptr(dL_dcolors), rt.ptr(dL_dmeans3D), rt.ptr(dL_dcov3D), rt.ptr(dL_dsh),
+                                rt.ptr(dL_dscales), rt.ptr(dL_drotations)))
         if debug:
             torch.cuda.synchronize(dev)
     rasterize_gaussians_backward.last_dL_dconic = dL_dconic  # kept for the parity tests
@@ -99,7 +104,8 @@ def mark_visible(means3D, viewmatrix, projmatrix):
     P = means3D.shape[0]
     present = torch.zeros((P,), dtype=torch.bool, device=means3D.device)
     if P:
+        view_, proj_ = _f32(viewmatrix, "viewmatrix"), _f32(projmatrix, "projmatrix")
         with torch.cuda.device(means3D.device):
-            rt.check(rt.lib().hgs_mark_visible(rt.current_stream(), P, rt.ptr(means3D), rt.ptr(_f32(viewmatrix, "viewmatrix")),
-                                               rt.ptr(_f32(projmatrix, "projmatrix")), rt.ptr(present)))
+            rt.check(rt.lib().hgs_mark_visible(rt.current_stream(), P, rt.ptr(means3D), rt.ptr(view_), rt.ptr(proj_),
+                                               rt.ptr(present)))
     return present

@@ -38,9 +38,9 @@ class Camera(nn.Module):
         self.orientation_confidence = None if orientation_confidence is None else orientation_confidence.to(dev)
         self.zfar, self.znear = 100.0, 0.01
         self.trans, self.scale = trans, scale
-        self.world_view_transform = torch.tensor(getWorld2View2(R, T, trans, scale)).transpose(0, 1).to(dev)
+        self.world_view_transform = torch.tensor(getWorld2View2(R, T, trans, scale)).transpose(0, 1).contiguous().to(dev)
         self.projection_matrix = getProjectionMatrix(znear=self.znear, zfar=self.zfar, fovX=FoVx, fovY=FoVy) \
-            .transpose(0, 1).to(dev)
+            .transpose(0, 1).contiguous().to(dev)
         self.full_proj_transform = self.world_view_transform @ self.projection_matrix
         self.camera_center = self.world_view_transform.inverse()[3, :3]
 

@@ -57,10 +57,10 @@ def make_camera(eye, target, W, H, fovx_deg=60.0, up=(0.0, -1.0, 0.0), znear=0.0
 
 def random_scene(P=500, W=96, H=64, seed=0, sh_degree=0, M=None, use_colors_precomp=False, use_cov3D_precomp=False,
                  bg=(0.0, 0.0, 0.0), spread=0.35, scale_lo=0.005, scale_hi=0.05, depth=1.2, behind_frac=0.05,
-                 neg_colors=False, fovx_deg=60.0, opacity_lo=0.05, opacity_hi=0.95, depth_levels=0):
+                 neg_colors=False, fovx_deg=60.0, opacity_lo=0.05, opacity_hi=0.95, depth_levels=0, eye=None):
     """Random blob scene in front of one camera.  Some Gaussians sit behind the near plane / off-screen."""
     rng = np.random.default_rng(seed)
-    cam = make_camera(eye=(0.1, -0.05, -depth), target=(0, 0, 0), W=W, H=H, fovx_deg=fovx_deg)
+    cam = make_camera(eye=(0.1, -0.05, -depth) if eye is None else eye, target=(0, 0, 0), W=W, H=H, fovx_deg=fovx_deg)
     xyz = rng.uniform(-spread, spread, (P, 3)).astype(np.float32)
     xyz[:, 0] *= 1.6 * W / max(W, H) * 1.5
     nb = int(P * behind_frac)

@@ -25,6 +25,8 @@ VARIANTS = {
     "opaque_early_stop": dict(P=3000, W=96, H=64, seed=7, sh_degree=0, scale_lo=0.05, scale_hi=0.2,
                               opacity_lo=0.9, opacity_hi=0.99),                              # saturation / early exit
     "depth_ties": dict(P=3000, W=200, H=120, seed=11, depth_levels=6, scale_lo=0.01, scale_hi=0.06),
+    # camera far off the +z axis: view rotation of ~120 degrees about y and ~35 degrees of pitch
+    "rotated_cam": dict(P=1500, W=160, H=96, seed=12, sh_degree=2, eye=(1.0, -0.7, 0.55), behind_frac=0.0, fovx_deg=90.0),
     "all_culled": dict(P=300, W=64, H=64, seed=8, behind_frac=1.0),
     "tiny_image": dict(P=200, W=7, H=5, seed=9),
 }
