@@ -23,8 +23,11 @@ WORKLOADS = {
 
 def make_cameras(n_views, W, H, device="cuda", dist=0.5, anchor=(0.0, 0.0, 0.0)):
     """n_views-1 cameras on a circle of radius `dist` about the y axis + one top view; f = W/2 px."""
+    # camera 1 as the reference's dataset scripts place it (scripts/parse_usc_hairsalon.py:172-177): y-up world,
+    # camera at +z looking back at the anchor, OpenCV axes (y and z flipped)
     pose = np.eye(4)
-    pose[:3, 3] = np.asarray(anchor) + np.array([0.0, 0.0, -dist])  # looks along +z at the anchor
+    pose[:3, 3] = np.asarray(anchor) + np.array([0.0, 0.0, dist])
+    pose[:3, 1:3] *= -1
     focal = W / 2.0
     _, Es = generate_cameras(n_views, H, W, cam_pose=pose, anchor_pos=np.asarray(anchor, float), offset=dist,
                              focal_length_px=focal)
@@ -54,7 +57,7 @@ def strand_polylines(n_strands, n_seg, seed=0, radius=0.10, step=0.0025, jitter_
     pts = [roots]
     phase = rng.uniform(0, 2 * np.pi, n_strands)
     for k in range(n_seg):
-        d = d + rng.normal(size=d.shape) * math.radians(jitter_deg) + np.array([0.0, 0.02, 0.0])  # +y = down (gravity)
+        d = d + rng.normal(size=d.shape) * math.radians(jitter_deg) + np.array([0.0, -0.02, 0.0])  # y-up world: gravity pulls towards -y
         d /= np.linalg.norm(d, axis=1, keepdims=True)
         p = pts[-1] + step * d
         pts.append(p)

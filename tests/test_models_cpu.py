@@ -156,6 +156,17 @@ def test_hair_prune_and_cat_segments():
     assert m.endpoint_pairs.shape[0] == P0 - 5 + n_new == m._opacity.shape[0] == m.denom.shape[0]
 
 
+def test_synthetic_rig_sees_the_anchor():
+    from synthetic import make_cameras
+    cams = make_cameras(5, 64, 48, device="cpu", dist=0.5)
+    for cam in cams:
+        c = cam.camera_center
+        assert abs(float(c.norm()) - 0.5) < 1e-5
+        fwd = cam.world_view_transform[:3, 2]          # world-space viewing direction (third column of W2C^T)
+        assert torch.allclose(fwd, -c / c.norm(), atol=1e-5)
+    assert float(cams[-1].camera_center[1]) > 0.49      # the extra camera looks down from above (y-up world)
+
+
 def test_generate_cameras_rig():
     from utils.camera import generate_cameras
     pose = np.eye(4)
