@@ -1,0 +1,132 @@
+// hgs_strands.hip -- fused strand geometry: shared segment endpoints -> per-Gaussian (mean, scale, quaternion,
+// direction), forward and backward, one lane per segment.
+//
+// Replaces, for the Stage-III model, the ~30 small PyTorch kernels (x3 per iteration, plus their autograd) behind
+// HairGaussianModel.get_xyz / get_scaling / get_rotation / get_orientation (reference scene/hair_gaussian_model.py
+// :134-201 and utils/transform.py:69-86), computed ONCE per optimizer step and shared by the three raster passes.
+//   mean   = (e0 + e1) / 2
+//   scale  = (max(|e1-e0|/2 * f, 1e-7), exp(w), exp(w))          f = dist_to_scale_factor
+//   quat   = rotation x_hat -> d = (e1-e0)/|e1-e0| :  normalize(1 + d.x, 0, -d.z, d.y)   (w,x,y,z; w >= 0)
+//            -- the closed form of matrix_to_quaternion(I + K + K^2/(1+c)), K = skew(x_hat x d), c = x_hat.d;
+//            identity for collapsed segments (|e1-e0| <= 1e-7)
+//   dir    = d (x_hat for collapsed segments)
+// Backward scatters into the shared endpoints with fp32 atomics (an endpoint of a strand has <= 2 segments:
+// two-term sums commute, so the result is order-independent for chains).
+#include "hgs_common.h"
+
+namespace {
+
+#define MINV 1e-7f
+
+__global__ __launch_bounds__(256) void strand_fwd_kernel(int P, const float* __restrict__ ep, const long long* __restrict__ pairs,
+                                                         const float* __restrict__ width, float f, float* __restrict__ xyz,
+                                                         float* __restrict__ scale, float* __restrict__ quat,
+                                                         float* __restrict__ dir) {
+  const int k = blockIdx.x * 256 + threadIdx.x;
+  if (k >= P) return;
+  const long long i0 = pairs[2 * (size_t)k], i1 = pairs[2 * (size_t)k + 1];
+  const float ax = ep[3 * i0], ay = ep[3 * i0 + 1], az = ep[3 * i0 + 2];
+  const float bx = ep[3 * i1], by = ep[3 * i1 + 1], bz = ep[3 * i1 + 2];
+  xyz[3 * (size_t)k] = (ax + bx) / 2.f; xyz[3 * (size_t)k + 1] = (ay + by) / 2.f; xyz[3 * (size_t)k + 2] = (az + bz) / 2.f;
+  const float dx = bx - ax, dy = by - ay, dz = bz - az;
+  const float L = sqrtf(dx * dx + dy * dy + dz * dz);
+  const float ew = expf(width[k]);
+  scale[3 * (size_t)k] = fmaxf(L / 2.f * f, MINV);
+  scale[3 * (size_t)k + 1] = ew;
+  scale[3 * (size_t)k + 2] = ew;
+  float q0 = 1.f, q1 = 0.f, q2 = 0.f, q3 = 0.f, ux = 1.f, uy = 0.f, uz = 0.f;
+  if (L > MINV) {
+    const float il = 1.f / L;
+    const float vx = dx * il, vy = dy * il, vz = dz * il;
+    const float n0 = 1.f + vx;
+    if (n0 > MINV) {
+      const float in = 1.f / sqrtf(n0 * n0 + vz * vz + vy * vy);
+      q0 = n0 * in; q1 = 0.f; q2 = -vz * in; q3 = vy * in;
+    } else {  // d = -x_hat: half turn about z
+      q0 = 0.f; q3 = 1.f;
+    }
+    if (L >= MINV) { ux = vx; uy = vy; uz = vz; }
+  }
+  ((float4*)quat)[k] = make_float4(q0, q1, q2, q3);
+  dir[3 * (size_t)k] = ux; dir[3 * (size_t)k + 1] = uy; dir[3 * (size_t)k + 2] = uz;
+}
+
+__global__ __launch_bounds__(256) void strand_bwd_kernel(int P, const float* __restrict__ ep, const long long* __restrict__ pairs,
+                                                         const float* __restrict__ width, float f,
+                                                         const float* __restrict__ g_xyz, const float* __restrict__ g_scale,
+                                                         const float* __restrict__ g_quat, const float* __restrict__ g_dir,
+                                                         float* __restrict__ d_ep, float* __restrict__ d_width) {
+  const int k = blockIdx.x * 256 + threadIdx.x;
+  if (k >= P) return;
+  const long long i0 = pairs[2 * (size_t)k], i1 = pairs[2 * (size_t)k + 1];
+  const float dx = ep[3 * i1] - ep[3 * i0], dy = ep[3 * i1 + 1] - ep[3 * i0 + 1], dz = ep[3 * i1 + 2] - ep[3 * i0 + 2];
+  const float L = sqrtf(dx * dx + dy * dy + dz * dz);
+  float hx = 0.f, hy = 0.f, hz = 0.f;  // gradient w.r.t. the midpoint, split evenly
+  if (g_xyz) { hx = 0.5f * g_xyz[3 * (size_t)k]; hy = 0.5f * g_xyz[3 * (size_t)k + 1]; hz = 0.5f * g_xyz[3 * (size_t)k + 2]; }
+  float gDx = 0.f, gDy = 0.f, gDz = 0.f;  // gradient w.r.t. delta = e1 - e0
+  float gw = 0.f;
+  if (g_scale) {
+    gw = (g_scale[3 * (size_t)k + 1] + g_scale[3 * (size_t)k + 2]) * expf(width[k]);
+  }
+  if (L > MINV) {
+    const float il = 1.f / L;
+    const float vx = dx * il, vy = dy * il, vz = dz * il;
+    float gvx = 0.f, gvy = 0.f, gvz = 0.f;  // gradient w.r.t. the unit direction
+    if (g_dir && L >= MINV) { gvx = g_dir[3 * (size_t)k]; gvy = g_dir[3 * (size_t)k + 1]; gvz = g_dir[3 * (size_t)k + 2]; }
+    const float n0 = 1.f + vx;
+    if (g_quat && n0 > MINV) {
+      const float4 gq = ((const float4*)g_quat)[k];
+      const float in = 1.f / sqrtf(n0 * n0 + vz * vz + vy * vy);
+      const float q0 = n0 * in, q2 = -vz * in, q3 = vy * in;
+      const float dot = q0 * gq.x + q2 * gq.z + q3 * gq.w;  // q1 = 0
+      const float gn0 = (gq.x - q0 * dot) * in, gn2 = (gq.z - q2 * dot) * in, gn3 = (gq.w - q3 * dot) * in;
+      gvx += gn0; gvy += gn3; gvz -= gn2;
+    }
+    const float vd = vx * gvx + vy * gvy + vz * gvz;
+    gDx = (gvx - vx * vd) * il; gDy = (gvy - vy * vd) * il; gDz = (gvz - vz * vd) * il;
+    if (g_scale && L / 2.f * f > MINV) {
+      const float gs = g_scale[3 * (size_t)k] * (0.5f * f);
+      gDx += gs * vx; gDy += gs * vy; gDz += gs * vz;
+    }
+  }
+  atomicAdd(&d_ep[3 * i0], hx - gDx); atomicAdd(&d_ep[3 * i0 + 1], hy - gDy); atomicAdd(&d_ep[3 * i0 + 2], hz - gDz);
+  atomicAdd(&d_ep[3 * i1], hx + gDx); atomicAdd(&d_ep[3 * i1 + 1], hy + gDy); atomicAdd(&d_ep[3 * i1 + 2], hz + gDz);
+  d_width[k] = gw;
+}
+
+}  // namespace
+
+extern "C" {
+
+int hgs_strand_geometry_forward(void* stream, int P, const float* endpoints, const long long* endpoint_pairs,
+                                const float* width, float dist_to_scale_factor, float* xyz, float* scale, float* quat,
+                                float* dir) {
+  if (P == 0) return 0;
+  if (!endpoints || !endpoint_pairs || !width || !xyz || !scale || !quat || !dir) { hgs_set_error("hgs_strand_geometry_forward: null argument"); return 1; }
+  hipStream_t s = (hipStream_t)stream;
+  {
+    HgsProfScope _prof(s, HGS_K_STRAND_FWD);
+    hipLaunchKernelGGL(strand_fwd_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, endpoints, endpoint_pairs, width,
+                       dist_to_scale_factor, xyz, scale, quat, dir);
+  }
+  HGS_CHECK_LAUNCH();
+  return 0;
+}
+
+int hgs_strand_geometry_backward(void* stream, int P, int E, const float* endpoints, const long long* endpoint_pairs,
+                                 const float* width, float dist_to_scale_factor, const float* g_xyz, const float* g_scale,
+                                 const float* g_quat, const float* g_dir, float* d_endpoints, float* d_width) {
+  if (!d_endpoints || !d_width) { hgs_set_error("hgs_strand_geometry_backward: null output"); return 1; }
+  hipStream_t s = (hipStream_t)stream;
+  HGS_CHECK_HIP(hipMemsetAsync(d_endpoints, 0, (size_t)E * 3 * sizeof(float), s));
+  if (P == 0) return 0;
+  {
+    HgsProfScope _prof(s, HGS_K_STRAND_BWD);
+    hipLaunchKernelGGL(strand_bwd_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, endpoints, endpoint_pairs, width,
+                       dist_to_scale_factor, g_xyz, g_scale, g_quat, g_dir, d_endpoints, d_width);
+  }
+  HGS_CHECK_LAUNCH();
+  return 0;
+}
+
+}  // extern "C"

@@ -31,6 +31,15 @@ SIGNATURES = {
     "hgs_mark_visible": (ci, [vp, ci, vp, vp, vp, vp]),
     "hgs_dist2_scratch_bytes": (sz, [ci]),
     "hgs_dist2": (ci, [vp, ci, vp, vp, vp, sz]),
+    "hgs_ssim_l1_scratch_floats": (sz, [ci, ci, ci]),
+    "hgs_ssim_l1_num_blocks": (ci, [ci, ci, ci]),
+    "hgs_ssim_l1_forward": (ci, [vp, ci, ci, ci, vp, vp, vp, vp, vp]),
+    "hgs_ssim_l1_backward": (ci, [vp, ci, ci, ci, vp, vp, vp, vp, vp, vp, vp]),
+    "hgs_orientation_loss_num_blocks": (ci, [ci, ci]),
+    "hgs_orientation_loss_forward": (ci, [vp, ci, ci, vp, vp, vp, cf, vp, vp, vp, vp]),
+    "hgs_orientation_loss_backward": (ci, [vp, ci, ci, vp, vp, vp, cf, vp, vp, vp, vp, vp, vp]),
+    "hgs_strand_geometry_forward": (ci, [vp, ci, vp, vp, vp, cf, vp, vp, vp, vp]),
+    "hgs_strand_geometry_backward": (ci, [vp, ci, ci, vp, vp, vp, cf, vp, vp, vp, vp, vp, vp]),
     "hgs_prof_enable": (ci, [ci]),
     "hgs_prof_collect": (ci, [vp, vp]),
     "hgs_prof_kernel_name": (C.c_char_p, [ci]),
@@ -99,7 +108,7 @@ def require_gpu_tensor(t, name, dtype=None):
     return t.contiguous()
 
 
-KERNEL_COUNT = 8
+KERNEL_COUNT = 14
 
 
 def prof_enable(on=True):

@@ -11,6 +11,7 @@ from gaussian_renderer import render
 from scene.hair_gaussian_model import HairGaussianModel
 
 _WINDOWS = {}
+fused_losses = True  # GPU: fused HIP kernels for L1+SSIM and the orientation loss (hgs_runtime.fused); False: torch ops
 
 
 def l1_loss(network_output, gt):
@@ -88,20 +89,34 @@ def _black(device):
 
 def orientation_loss_rast(gaussians, camera, args, bg=None):
     """Render world-space segment directions, rotate to view space, convert to an angle in [0, pi) w.r.t. the image
-    y axis and compare bidirectionally with the GT orientation field, confidence-weighted (losses.py:224-289)."""
+    y axis and compare bidirectionally with the GT orientation field, confidence-weighted (losses.py:224-289).
+    On the GPU everything after the render is one fused kernel pair (hgs_orientation_loss_*); `fused_losses=False`
+    or CPU tensors run the op-by-op restatement below (masked mean written as sum/count: no host sync)."""
     bg = _black(gaussians.get_xyz.device) if bg is None else bg
-    omap = render(camera, gaussians, bg, override_color=gaussians.get_orientation)["render"].permute(1, 2, 0)  # H,W,3
+    omap = render(camera, gaussians, bg, override_color=gaussians.get_orientation)["render"]      # [3,H,W]
+    if fused_losses and omap.is_cuda:
+        from hgs_runtime.fused import orientation_loss
+        key = "_hgs_rot6"
+        if not hasattr(camera, key):  # view rotation is constant per camera: read it back once
+            setattr(camera, key, [float(v) for v in camera.world_view_transform[:3, :2].reshape(-1).cpu()])
+        bg3 = getattr(orientation_loss_rast, "_bg_cache", {}).get(id(bg))
+        if bg3 is None:
+            bg3 = [float(v) for v in bg.cpu()]
+            orientation_loss_rast._bg_cache = {id(bg): bg3}
+        return orientation_loss(omap, getattr(camera, key), bg3, gaussians.min_val, camera.orientation_field,
+                                camera.orientation_confidence, camera.mask)
+    omap = omap.permute(1, 2, 0)
     h, w = omap.shape[:2]
-    flat = omap.flatten(0, 1)
-    pix = (flat @ camera.world_view_transform[:3, :3])[:, :2]
+    pix = (omap.flatten(0, 1) @ camera.world_view_transform[:3, :3])[:, :2]
     pix = pix / (torch.norm(pix, dim=1, keepdim=True) + gaussians.min_val)
     x, y = pix[:, 0], pix[:, 1]
     y = torch.where(y < gaussians.min_val, y + gaussians.min_val, y)
     theta = torch.atan2(x, y)
     theta = torch.where(theta < 0, theta + np.pi, theta).reshape(h, w)
     mask = torch.any(omap != bg, dim=2) if camera.mask is None else camera.mask
-    diff = bidirectional_angle_difference(theta[mask], camera.orientation_field[mask])
-    return (diff * camera.orientation_confidence[mask]).mean()
+    diff = bidirectional_angle_difference(theta, camera.orientation_field) * camera.orientation_confidence
+    m = mask.to(diff.dtype)
+    return (diff * m).sum() / m.sum()
 
 
 def mask_loss_rast(gaussians, camera, args, bg=None):
@@ -114,10 +129,13 @@ def mask_loss_rast(gaussians, camera, args, bg=None):
 def loss_function(gaussians, image, viewpoint_cam, args):
     """(1-l)L1 + l(1-SSIM) + l_mask BCE + l_orient orientation [+ l_smooth smoothness] (losses.py:319-355)."""
     gt = viewpoint_cam.original_image
-    terms = {"l1": l1_loss(image, gt)}
-    loss = max(0, 1.0 - args.lambda_dssim) * terms["l1"]
-    terms["dssim"] = 1.0 - ssim(image, gt)
-    loss = loss + args.lambda_dssim * terms["dssim"]
+    if fused_losses and image.is_cuda:
+        from hgs_runtime.fused import ssim_l1
+        ssim_mean, l1_mean = ssim_l1(image, gt)
+        terms = {"l1": l1_mean, "dssim": 1.0 - ssim_mean}
+    else:
+        terms = {"l1": l1_loss(image, gt), "dssim": 1.0 - ssim(image, gt)}
+    loss = max(0, 1.0 - args.lambda_dssim) * terms["l1"] + args.lambda_dssim * terms["dssim"]
     if args.lambda_mask > 0 and viewpoint_cam.mask is not None:
         terms["mask"] = mask_loss_rast(gaussians, viewpoint_cam, args)
         loss = loss + args.lambda_mask * terms["mask"]

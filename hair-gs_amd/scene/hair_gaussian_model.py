@@ -55,12 +55,39 @@ class HairGaussianModel(GaussianModel):
                                     "_features_dc", "_features_rest", "_opacity", "_mask", "_width")]
 
     # ---- derived Gaussian parameters -------------------------------------------------------
+    # On the GPU the four derived tensors come from ONE fused HIP kernel (hgs_strand_geometry_*), evaluated once per
+    # parameter state and shared by every getter call of the step (3 render passes + orientation colours); the
+    # cache is dropped when the parameters change (tensor version counters) or after its graph was back-propagated.
+    # `fused_geometry = False` (or CPU tensors) selects the op-by-op PyTorch formulas below, which restate the
+    # reference getters and are what the fused kernel is tested against.
+    fused_geometry = True
+
     def _segment_delta(self):
         pairs = self._endpoints[self.endpoint_pairs]
         return pairs, pairs[:, 1] - pairs[:, 0]
 
+    def _derived_key(self):
+        return (id(self._endpoints), self._endpoints._version, id(self._width), self._width._version,
+                id(self.endpoint_pairs), float(self.dist_to_scale_factor), torch.is_grad_enabled())
+
+    def _fused(self):
+        if not (self.fused_geometry and self._endpoints.is_cuda):
+            return None
+        key = self._derived_key()
+        cached = getattr(self, "_derived", None)
+        if cached is None or cached[0] != key:
+            from hgs_runtime.fused import strand_geometry
+            out = strand_geometry(self._endpoints, self._width, self.endpoint_pairs, float(self.dist_to_scale_factor),
+                                  owner=self if torch.is_grad_enabled() else None)
+            cached = (key, out)
+            self._derived = cached
+        return cached[1]
+
     @property
     def get_scaling(self):
+        f = self._fused()
+        if f is not None:
+            return f[1]
         _, diff = self._segment_delta()
         half_len = torch.norm(diff, p=2, dim=1, keepdim=True) / 2
         scale_x = torch.clamp(half_len * self.dist_to_scale_factor, min=self.min_val)
@@ -69,6 +96,9 @@ class HairGaussianModel(GaussianModel):
 
     @property
     def get_rotation(self):
+        f = self._fused()
+        if f is not None:
+            return f[2]
         _, v2 = self._segment_delta()
         rotation = torch.zeros((v2.shape[0], 4), dtype=torch.float, device=v2.device)
         rotation[:, 0] = 1.0
@@ -80,11 +110,17 @@ class HairGaussianModel(GaussianModel):
 
     @property
     def get_xyz(self):
+        f = self._fused()
+        if f is not None:
+            return f[0]
         return torch.mean(self._endpoints[self.endpoint_pairs], dim=1)
 
     @property
     def get_orientation(self):
         """World-space unit direction of every segment; x_hat for collapsed ones (reference :188-201)."""
+        f = self._fused()
+        if f is not None:
+            return f[3]
         _, d = self._segment_delta()
         norm = torch.norm(d, p=2, dim=1, keepdim=True)
         ok = (norm >= self.min_val).squeeze(1)

@@ -96,12 +96,51 @@ int hgs_mark_visible(void* stream, int P, const float* means3D, const float* vie
 size_t hgs_dist2_scratch_bytes(int P);
 int hgs_dist2(void* stream, int P, const float* points, float* out, void* scratch, size_t scratch_bytes);
 
+/* ---- MI355X-native fusions of PyTorch-side work ON the training-step path.  The reference has
+ * no native counterpart: it runs these as chains of small torch kernels.  Every pointer is a device pointer except
+ * `window11_host` (the 11 normalised fp32 taps of the Gaussian window, host memory).
+ *
+ * hgs_ssim_l1_forward/backward <-> loss/losses.py:16-17 (l1_loss) + :43-84 (ssim: five grouped 11x11 conv2d) and
+ *   their autograd.  forward writes 3*C*H*W floats of derivative maps + 2 floats per 16x16 block and channel
+ *   (partial sums of the SSIM map and of |img1-img2|; the caller sums them and divides by C*H*W).
+ *   backward: dL_dimg1 = g_ssim_mean/(CHW) * dSSIM/dimg1 + g_l1_mean/(CHW) * sign(img1-img2), g_* device scalars.
+ * hgs_strand_geometry_forward/backward <-> scene/hair_gaussian_model.py:134-201 getters (get_xyz, get_scaling,
+ *   get_rotation, get_orientation) + utils/transform.py:69-86, and their autograd (gather / Rodrigues /
+ *   matrix_to_quaternion / scatter-add into shared endpoints).  endpoint_pairs is int64 [P,2] as torch stores it.
+ *   backward: any of g_xyz/g_scale/g_quat/g_dir may be NULL (output unused); d_endpoints [E,3] is zeroed inside. ---- */
+size_t hgs_ssim_l1_scratch_floats(int C, int H, int W);
+int hgs_ssim_l1_num_blocks(int C, int H, int W);
+int hgs_ssim_l1_forward(void* stream, int C, int H, int W, const float* window11_host, const float* img1,
+                        const float* img2, float* dmaps, float* partials);
+int hgs_ssim_l1_backward(void* stream, int C, int H, int W, const float* window11_host, const float* img1,
+                         const float* img2, const float* dmaps, const float* g_ssim_mean, const float* g_l1_mean,
+                         float* dL_dimg1);
+/* hgs_orientation_loss_forward/backward <-> loss/losses.py:250-288 (everything after the orientation render):
+ *   omap [3,H,W] rendered world-space directions; rot6_host = world_view_transform[:3,:2] row-major (6 floats, host);
+ *   mask uint8 [H,W] or NULL (then mask = any(omap != bg3_host)); partials: 2 floats per 256-pixel block
+ *   (sum of diff*confidence over the mask, mask count); loss = sum0 / sum1.  backward: g_loss, mask_count are
+ *   device scalars; d_omap [3,H,W] fully written. */
+int hgs_orientation_loss_num_blocks(int H, int W);
+int hgs_orientation_loss_forward(void* stream, int H, int W, const float* omap, const float* rot6_host,
+                                 const float* bg3_host, float min_val, const float* gt_theta, const float* confidence,
+                                 const uint8_t* mask, float* partials);
+int hgs_orientation_loss_backward(void* stream, int H, int W, const float* omap, const float* rot6_host,
+                                  const float* bg3_host, float min_val, const float* gt_theta, const float* confidence,
+                                  const uint8_t* mask, const float* g_loss, const float* mask_count, float* d_omap);
+int hgs_strand_geometry_forward(void* stream, int P, const float* endpoints, const long long* endpoint_pairs,
+                                const float* width, float dist_to_scale_factor, float* xyz, float* scale, float* quat,
+                                float* dir);
+int hgs_strand_geometry_backward(void* stream, int P, int E, const float* endpoints, const long long* endpoint_pairs,
+                                 const float* width, float dist_to_scale_factor, const float* g_xyz, const float* g_scale,
+                                 const float* g_quat, const float* g_dir, float* d_endpoints, float* d_width);
+
 /* ---- per-kernel device timing (bench.py roofline): when enabled every kernel launch of the library is bracketed
  * by hipEvents recorded on the launch stream.  hgs_prof_collect() synchronises those events, ADDS elapsed
  * milliseconds / launch counts per kernel id into the caller's arrays (length HGS_K_COUNT) and clears the log.
  * No reference counterpart (the reference only times whole iterations, train.py:81-82,133,156). ---- */
 enum { HGS_K_PREPROCESS_FWD = 0, HGS_K_SCAN, HGS_K_SCATTER, HGS_K_SORT_TILES, HGS_K_BLEND_FWD, HGS_K_BLEND_BWD,
-       HGS_K_PREPROCESS_BWD, HGS_K_KNN, HGS_K_COUNT };
+       HGS_K_PREPROCESS_BWD, HGS_K_KNN, HGS_K_SSIM_FWD, HGS_K_SSIM_BWD, HGS_K_STRAND_FWD, HGS_K_STRAND_BWD,
+       HGS_K_ORI_FWD, HGS_K_ORI_BWD, HGS_K_COUNT };
 int hgs_prof_enable(int on);
 int hgs_prof_collect(double* total_ms, long long* launches);
 const char* hgs_prof_kernel_name(int kernel_id);

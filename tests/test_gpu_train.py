@@ -97,3 +97,74 @@ def test_stage1_cloud_model_step():
         loss, terms, _ = training_step(model, cams[it % 3], opt, bg, it)
         assert torch.isfinite(loss)
     assert "smooth" not in terms
+
+
+def test_fused_strand_geometry_matches_torch_formulas():
+    """hgs_strand_geometry_* vs the op-by-op getters (which restate the reference's), forward and backward."""
+    from synthetic import make_strand_model
+    m = make_strand_model(50, 20, device="cuda")
+    with torch.no_grad():  # include one collapsed segment and one anti-parallel-to-x segment
+        m._endpoints[1] = m._endpoints[0]
+        m._endpoints[5] = m._endpoints[4] + torch.tensor([-0.002, 0.0, 0.0], device="cuda")
+    w = [torch.randn(s, device="cuda", generator=torch.Generator(device="cuda").manual_seed(i)) for i, s in
+         enumerate([(1000, 3), (1000, 3), (1000, 4), (1000, 3)])]
+    outs, grads = {}, {}
+    for fused in (False, True):
+        m.fused_geometry = fused
+        m._derived = None
+        m._endpoints.grad = None
+        m._width.grad = None
+        o = (m.get_xyz, m.get_scaling, m.get_rotation, m.get_orientation)
+        sum((a * b).sum() for a, b in zip(o, w)).backward()
+        outs[fused] = [t.detach().clone() for t in o]
+        grads[fused] = (m._endpoints.grad.clone(), m._width.grad.clone())
+    skip = torch.zeros(1000, dtype=torch.bool, device="cuda")
+    skip[4] = True  # d = -x_hat: the reference formula itself degenerates there (1/(1+c) with c clamped at -1+1e-7)
+    for a, b, name in zip(outs[True], outs[False], ("xyz", "scale", "quat", "dir")):
+        assert (a - b)[~skip].abs().max() <= 2e-6 * max(1.0, float(b.abs().max())), name
+    ge_t, gw_t = grads[False]
+    ge_f, gw_f = grads[True]
+    touched = torch.zeros(ge_t.shape[0], dtype=torch.bool, device="cuda")
+    touched[m.endpoint_pairs[4]] = True
+    assert (ge_f - ge_t)[~touched].abs().max() <= 1e-4 * ge_t.abs().max()
+    assert (gw_f - gw_t).abs().max() <= 1e-5 * max(1e-12, float(gw_t.abs().max()))
+    assert torch.isfinite(ge_f).all()
+
+
+def test_fused_losses_match_torch_ops():
+    """hgs_ssim_l1_* and hgs_orientation_loss_* vs the PyTorch implementations (which restate loss/losses.py)."""
+    from arguments import OptimizationParams
+    from loss import losses as Ls
+    from synthetic import build_workload
+    model, cams, _ = build_workload("tiny", device="cuda", with_targets=True)
+    cam = cams[2]
+    opt = OptimizationParams()
+    g = torch.Generator(device="cuda").manual_seed(3)
+    img = (cam.original_image + 0.1 * torch.randn(cam.original_image.shape, device="cuda", generator=g)).clamp(0, 1)
+    res = {}
+    for fused in (False, True):
+        Ls.fused_losses = fused
+        x = img.clone().requires_grad_(True)
+        if fused:
+            from hgs_runtime.fused import ssim_l1
+            s, l = ssim_l1(x, cam.original_image)
+        else:
+            s, l = Ls.ssim(x, cam.original_image), Ls.l1_loss(x, cam.original_image)
+        (0.3 * (1 - s) + 0.7 * l).backward()
+        res[fused] = (float(s), float(l), x.grad.clone())
+    Ls.fused_losses = True
+    assert abs(res[True][0] - res[False][0]) < 2e-5 and abs(res[True][1] - res[False][1]) < 1e-6
+    gt_, gf_ = res[False][2], res[True][2]
+    assert (gf_ - gt_).abs().max() <= 2e-4 * gt_.abs().max()
+    # orientation loss through the full render, both implementations, gradients w.r.t. the endpoints
+    out = {}
+    for fused in (False, True):
+        Ls.fused_losses = fused
+        model._derived = None
+        model._endpoints.grad = None
+        v = Ls.orientation_loss_rast(model, cam, opt)
+        v.backward()
+        out[fused] = (float(v), model._endpoints.grad.clone())
+    Ls.fused_losses = True
+    assert abs(out[True][0] - out[False][0]) <= 1e-5 * abs(out[False][0])
+    assert (out[True][1] - out[False][1]).abs().max() <= 5e-4 * out[False][1].abs().max()
