@@ -19,11 +19,44 @@ namespace {
 
 #define BWD_BATCH 64   // entries combined per LDS flush in the backward
 #define NPART 9        // dmean2D.xy, dconic.x/.y/.w, dopacity, dcolor.rgb
+#define REC_CHUNK 4     // instance records fetched per scalar-load burst
 
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+// ---- wavefront-wide reduction of 9 per-lane values (CDNA4: v_permlane32_swap / v_permlane16_swap + DPP) ----------
+// Transposing butterfly: a swap of the upper half-wave of `a` with the lower half-wave of `b` followed by one add
+// folds TWO values by a factor 2 into ONE register; the same with 16-lane rows folds four values into one register
+// with one value per row; four DPP adds (quad xor 1, quad xor 2, row_ror 4, row_ror 8) finish each row.  28 VALU
+// instructions for 9 values instead of 54 ds_bpermute round trips.
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0u, __builtin_bit_cast(unsigned, v), CTRL, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float row_sum16(float v) {   // every lane of a 16-lane row ends with the row's sum
+  v += dpp_mov<0xB1>(v);    // quad_perm [1,0,3,2]
+  v += dpp_mov<0x4E>(v);    // quad_perm [2,3,0,1]
+  v += dpp_mov<0x124>(v);   // row_ror:4
+  v += dpp_mov<0x128>(v);   // row_ror:8
   return v;
+}
+__device__ __forceinline__ float fold32(float a, float b) {  // lanes 0-31: a[l]+a[l+32]; lanes 32-63: b[l-32]+b[l]
+  auto r = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, a), __builtin_bit_cast(unsigned, b), false, false);
+  unsigned lo = r[0], hi = r[1];
+  asm volatile("" : "+v"(hi));  // ROCm 7.2 hipcc folds r[0] + r[1] of the swap builtin into r[0] + r[0] without this
+  return __builtin_bit_cast(float, lo) + __builtin_bit_cast(float, hi);
+}
+__device__ __forceinline__ float fold16(float a, float b) {  // rows: (a.r0+a.r1, b.r0+b.r1, a.r2+a.r3, b.r2+b.r3)
+  auto r = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, a), __builtin_bit_cast(unsigned, b), false, false);
+  unsigned lo = r[0], hi = r[1];
+  asm volatile("" : "+v"(hi));  // same miscompile guard as fold32
+  return __builtin_bit_cast(float, lo) + __builtin_bit_cast(float, hi);
+}
+// in : v[0..8] per lane.   out: x0123 rows (0,1,2,3) hold the totals of v0, v2, v1, v3; x4567 rows hold v4, v6, v5, v7;
+//      x8 holds the total of v8 in every lane.
+__device__ __forceinline__ void wave_reduce9(const float* v, float& x0123, float& x4567, float& x8) {
+  const float w01 = fold32(v[0], v[1]), w23 = fold32(v[2], v[3]), w45 = fold32(v[4], v[5]), w67 = fold32(v[6], v[7]);
+  const float w88 = fold32(v[8], v[8]);
+  x0123 = row_sum16(fold16(w01, w23));
+  x4567 = row_sum16(fold16(w45, w67));
+  x8 = row_sum16(fold16(w88, w88));
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -44,22 +77,37 @@ __global__ __launch_bounds__(HGS_BLOCK) void blend_fwd_kernel(const uint2* __res
   float T = 1.f, C0 = 0.f, C1 = 0.f, C2 = 0.f;
   uint32_t last = 0;
   bool done = !inside;
-  for (uint32_t j = range.x; j < range.y; ++j) {
+  // The instance records are streamed in chunks of REC_CHUNK: all scalar loads of a chunk are issued back to back
+  // (indices clamped to the list end, so no branch sits between them), one wait, then the entries are evaluated.
+  // The critical path of the kernel is the longest tile list x per-entry latency; this divides the load latency
+  // per entry by REC_CHUNK.
+  for (uint32_t j0 = range.x; j0 < range.y; j0 += REC_CHUNK) {
     if (__ballot(!done) == 0) break;  // forward.cu:309-311, per wavefront instead of per block
-    const float4 r0 = packed[3 * (size_t)j], r1 = packed[3 * (size_t)j + 1];
-    const float dx = r0.x - pxf, dy = r0.y - pyf;
-    const float power = -0.5f * (r0.z * dx * dx + r1.x * dy * dy) - r0.w * dx * dy;  // forward.cu:335
-    const float alpha = fminf(0.99f, r1.y * __expf(power));                           // :343
-    bool ok = !done && power <= 0.f && alpha >= (1.0f / 255.0f);                      // :336, :344
-    if (__ballot(ok) == 0) continue;
-    const float test_T = T * (1.f - alpha);
-    if (ok && test_T < 0.0001f) { done = true; ok = false; }                          // :346-351
-    if (ok) {
-      const float b2 = packed[3 * (size_t)j + 2].x;
-      const float w = alpha * T;
-      C0 += r1.z * w; C1 += r1.w * w; C2 += b2 * w;                                   // :354-355
-      T = test_T;
-      last = j - range.x + 1;                                                         // :328, :361
+    float4 q0[REC_CHUNK], q1[REC_CHUNK];
+    float qb[REC_CHUNK];
+#pragma unroll
+    for (int u = 0; u < REC_CHUNK; u++) {
+      const size_t jj = min(j0 + (uint32_t)u, range.y - 1u);
+      q0[u] = packed[3 * jj]; q1[u] = packed[3 * jj + 1]; qb[u] = packed[3 * jj + 2].x;
+    }
+#pragma unroll
+    for (int u = 0; u < REC_CHUNK; u++) {
+      const uint32_t j = j0 + (uint32_t)u;
+      if (j >= range.y) break;
+      const float4 r0 = q0[u], r1 = q1[u];
+      const float dx = r0.x - pxf, dy = r0.y - pyf;
+      const float power = -0.5f * (r0.z * dx * dx + r1.x * dy * dy) - r0.w * dx * dy;  // forward.cu:335
+      const float alpha = fminf(0.99f, r1.y * __expf(power));                           // :343
+      bool ok = !done && power <= 0.f && alpha >= (1.0f / 255.0f);                      // :336, :344
+      if (__ballot(ok) == 0) continue;
+      const float test_T = T * (1.f - alpha);
+      if (ok && test_T < 0.0001f) { done = true; ok = false; }                          // :346-351
+      if (ok) {
+        const float w = alpha * T;
+        C0 += r1.z * w; C1 += r1.w * w; C2 += qb[u] * w;                                // :354-355
+        T = test_T;
+        last = j - range.x + 1;                                                         // :328, :361
+      }
     }
   }
   uint32_t wmax = last;
@@ -114,9 +162,20 @@ __global__ __launch_bounds__(HGS_BLOCK) void blend_bwd_kernel(const uint2* __res
   // iff p < n_contrib (backward_distwar.cu:943-945)
   for (int hi = (int)maxc; hi > 0; hi -= BWD_BATCH) {
     const int lo = max(0, hi - BWD_BATCH);
-    for (int p = hi - 1; p >= lo; --p) {
-      const uint32_t j = range.x + (uint32_t)p;
-      const float4 r0 = packed[3 * (size_t)j], r1 = packed[3 * (size_t)j + 1];
+    for (int p0 = hi - 1; p0 >= lo; p0 -= REC_CHUNK) {
+    float4 q0[REC_CHUNK], q1[REC_CHUNK];
+    float qb[REC_CHUNK];
+#pragma unroll
+    for (int u = 0; u < REC_CHUNK; u++) {
+      const size_t jj = (size_t)range.x + (size_t)max(p0 - u, lo);
+      q0[u] = packed[3 * jj]; q1[u] = packed[3 * jj + 1]; qb[u] = packed[3 * jj + 2].x;
+    }
+#pragma unroll
+    for (int u = 0; u < REC_CHUNK; u++) {
+      const int p = p0 - u;
+      if (p < lo) break;
+      const float4 r0 = q0[u], r1 = q1[u];
+      const float c2 = qb[u];
       const float dx = r0.x - pxf, dy = r0.y - pyf;
       const float power = -0.5f * (r0.z * dx * dx + r1.x * dy * dy) - r0.w * dx * dy;
       const float G = __expf(power);
@@ -127,11 +186,11 @@ __global__ __launch_bounds__(HGS_BLOCK) void blend_bwd_kernel(const uint2* __res
 #pragma unroll
       for (int k = 0; k < NPART; k++) v[k] = 0.f;
       if (ok) {
-        const float c0 = r1.z, c1 = r1.w, c2 = packed[3 * (size_t)j + 2].x;
-        const float one_m_a = 1.f - alpha;
-        T = T / one_m_a;                                                      // :960
+        const float c0 = r1.z, c1 = r1.w;
+        const float inv_one_m_a = __builtin_amdgcn_rcpf(1.f - alpha);             // 1 ulp; alpha <= 0.99
+        T = T * inv_one_m_a;                                                       // :960
         const float dchannel_dcolor = alpha * T;
-        acc0 = last_alpha * lc0 + (1.f - last_alpha) * acc0;                  // :972
+        acc0 = last_alpha * lc0 + (1.f - last_alpha) * acc0;                       // :972
         acc1 = last_alpha * lc1 + (1.f - last_alpha) * acc1;
         acc2 = last_alpha * lc2 + (1.f - last_alpha) * acc2;
         lc0 = c0; lc1 = c1; lc2 = c2;
@@ -139,26 +198,29 @@ __global__ __launch_bounds__(HGS_BLOCK) void blend_bwd_kernel(const uint2* __res
         v[6] = dchannel_dcolor * dpx0; v[7] = dchannel_dcolor * dpx1; v[8] = dchannel_dcolor * dpx2;
         dL_dalpha *= T;
         last_alpha = alpha;
-        dL_dalpha += (-T_final / one_m_a) * bg_dot_dpixel;                    // :991
+        dL_dalpha += (-T_final * inv_one_m_a) * bg_dot_dpixel;                     // :991
         const float dL_dG = r1.y * dL_dalpha;
         const float gdx = G * dx, gdy = G * dy;
         const float dG_ddelx = -gdx * r0.z - gdy * r0.w;
         const float dG_ddely = -gdy * r1.x - gdx * r0.w;
-        v[0] = dL_dG * dG_ddelx * ddelx_dx;                                   // :1002-1003
+        v[0] = dL_dG * dG_ddelx * ddelx_dx;                                        // :1002-1003
         v[1] = dL_dG * dG_ddely * ddely_dy;
-        v[2] = -0.5f * gdx * dx * dL_dG;                                      // :1006-1008
+        v[2] = -0.5f * gdx * dx * dL_dG;                                           // :1006-1008
         v[3] = -0.5f * gdx * dy * dL_dG;
         v[4] = -0.5f * gdy * dy * dL_dG;
-        v[5] = G * dL_dalpha;                                                 // :1011
+        v[5] = G * dL_dalpha;                                                      // :1011
       }
-#pragma unroll
-      for (int k = 0; k < NPART; k++) v[k] = wave_sum(v[k]);
-      if (lane < NPART) {
-        float mine = v[0];
-#pragma unroll
-        for (int k = 1; k < NPART; k++) mine = (lane == k) ? v[k] : mine;
-        part[wave][p - lo][lane] = mine;
+      float x0123, x4567, x8;
+      wave_reduce9(v, x0123, x4567, x8);
+      if ((lane & 15) == 0) {
+        const int row = lane >> 4;
+        const int k = ((row & 1) << 1) | (row >> 1);   // rows hold values (0,2,1,3)
+        float* dst = &part[wave][p - lo][0];
+        dst[k] = x0123;
+        dst[4 + k] = x4567;
+        if (lane == 0) dst[8] = x8;
       }
+    }
     }
     __syncthreads();
     // combine the 4 wavefronts in fixed order and store one row per (tile, entry)
