@@ -42,6 +42,8 @@ def parse():
     ap.add_argument("--views", type=int, default=None, help="override the number of camera views")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true", help="disable per-kernel HIP-event timing")
+    ap.add_argument("--blocking", action="store_true",
+                    help="reference-style forward (host reads num_rendered in every pass) instead of the async capacity mode")
     return ap.parse_args()
 
 
@@ -92,6 +94,8 @@ def main():
     from utils.general import safe_state
 
     rt.lib()  # fail loudly if the HIP library is missing
+    from diff_gaussian_rasterization import _C as raster
+    raster.set_async(not args.blocking)
     safe_state(True)
     model, cams, extent = build_workload(args.workload, device=dev, seed=0, n_views=args.views)
     opt = OptimizationParams()
@@ -131,6 +135,7 @@ def main():
     dt = float(tmax.item())
 
     # ---- forward-only render ms/view, all views, after 3 warm-ups
+    raster.check_async()
     with torch.no_grad():
         for c in cams[:3]:
             render(c, model, bg)
@@ -141,6 +146,8 @@ def main():
             render(c, model, bg)
         torch.cuda.synchronize()
         render_ms = (time.perf_counter() - t1) * 1e3 / len(cams)
+        raster.check_async()
+        raster.set_async(False)
         # sum over tiles of L_t (= tile_maxc) per view, for the algorithmic-byte model
         from diff_gaussian_rasterization import _C as C_
         W, H = cams[0].image_width, cams[0].image_height
@@ -173,7 +180,8 @@ def main():
         "config": {"workload": f"{args.workload}: {P} strand-Gaussians, {len(cams)} views @ {W}x{H}, 1 view/GPU/step, "
                                "3 raster fwd+bwd passes + L1/DSSIM/mask/orientation/smoothness losses + Adam",
                    "gaussians": P, "views": len(cams), "width": W, "height": H, "parallelism": f"view-parallel x{world}",
-                   "mean_num_rendered": meanR, "mean_sum_tile_list_len": meanL},
+                   "mean_num_rendered": meanR, "mean_sum_tile_list_len": meanL,
+                   "forward_mode": "blocking" if args.blocking else "async-capacity"},
         "render_ms_per_view": render_ms,
     }
     if kern:

@@ -7,8 +7,42 @@ import torch
 
 import hgs_runtime as rt
 
-# set False to skip the blocking read of num_rendered (binning buffer is then sized from `capacity_hint`)
-_state = {"last_R": 0}
+# ---- optional asynchronous mode -----------------------------------------------------------------------------------
+# Default (async_mode False) = the reference's behaviour: every forward blocks once on `num_rendered`
+# (cuda_rasterizer/rasterizer_impl.cu:280-281) to size the binning buffer exactly.
+# With set_async(True) the forward never blocks: the binning buffer is sized from a CAPACITY (slack x the largest
+# instance count seen so far), the true count and the overflow flag of every pass are copied to pinned host memory
+# asynchronously, and the caller validates them ONCE per training step with check_async() (one synchronisation
+# instead of three).  If a pass needed more than its capacity, check_async() raises HgsCapacityOverflow after growing
+# the capacity: the caller discards the step's gradients and repeats it.  `num_rendered` returned by
+# rasterize_gaussians is then the capacity (it only sizes/carves buffers downstream).
+_state = {"last_R": 0, "async": False, "cap": 0, "slack": 1.5, "pending": []}
+
+
+class HgsCapacityOverflow(RuntimeError):
+    pass
+
+
+def set_async(enabled=True, slack=1.5):
+    _state["async"], _state["slack"] = bool(enabled), float(slack)
+    _state["pending"].clear()
+
+
+def check_async():
+    """Synchronise once, validate every pass issued since the last check; returns the list of true num_rendered."""
+    if not _state["pending"]:
+        return []
+    torch.cuda.current_stream().synchronize()
+    counts, overflow = [], False
+    for host, cap in _state["pending"]:
+        r, flag = int(host[0]), int(host[1])
+        counts.append(r)
+        overflow |= (flag != 0) or (r > cap)
+    _state["pending"].clear()
+    _state["cap"] = max(_state["cap"], int(max(counts) * _state["slack"]) + 4096)
+    if overflow:
+        raise HgsCapacityOverflow(f"a raster pass needed {max(counts)} instances: capacity raised to {_state['cap']}, repeat the step")
+    return counts
 
 
 def _f32(t, name):
@@ -41,16 +75,27 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
     view, proj, cam = _f32(viewmatrix, "viewmatrix"), _f32(projmatrix, "projmatrix"), _f32(campos, "campos")
     stream = rt.current_stream()
     with torch.cuda.device(dev):
+        use_async = _state["async"] and _state["cap"] > 0 and P > 0
         n_host = C.c_int(0)
         rt.check(L.hgs_forward_preprocess(stream, P, int(degree), M, W, H, rt.ptr(means3D), rt.ptr(sh_), rt.ptr(colors_),
                                           rt.ptr(opacity_), rt.ptr(scales_), float(scale_modifier), rt.ptr(rots_),
                                           rt.ptr(cov_), rt.ptr(view), rt.ptr(proj), rt.ptr(cam), float(tan_fovx),
                                           float(tan_fovy), int(bool(prefiltered)), rt.ptr(geom), rt.ptr(img),
-                                          rt.ptr(radii), C.addressof(n_host)))
-        R = int(n_host.value)
+                                          rt.ptr(radii), None if use_async else C.addressof(n_host)))
+        if use_async:
+            R = _state["cap"]
+        else:
+            R = int(n_host.value)
+            if _state["async"]:  # first call: learn the scale of the scene with one blocking read
+                _state["cap"] = max(_state["cap"], int(R * _state["slack"]) + 4096)
         binning = torch.empty((L.hgs_binning_bytes(R),), **u8)
         rt.check(L.hgs_forward_render(stream, P, W, H, R, rt.ptr(bg), rt.ptr(colors_), rt.ptr(geom), rt.ptr(binning),
                                       rt.ptr(img), rt.ptr(out_color)))
+        if use_async:
+            off = rt.layout("image", W, H)["status"]
+            host = torch.empty(2, dtype=torch.int32, pin_memory=True)
+            host.copy_(img[off:off + 8].view(torch.int32), non_blocking=True)
+            _state["pending"].append((host, R))
         if debug:
             torch.cuda.synchronize(dev)  # surface asynchronous faults here, like CHECK_CUDA (auxiliary.h:166-173)
     _state["last_R"] = R

@@ -73,10 +73,12 @@ def angle_smoothness_loss(gaussians: HairGaussianModel, threshold: float = 30, e
     d = pos[:, :, 1] - pos[:, :, 0]
     d = d / torch.norm(d, dim=2, keepdim=True)
     dot = torch.sum(d[:, 0] * d[:, 1], dim=1)
-    dot = dot[dot <= cos_th]
-    if dot.shape[0] == 0:
-        return 0
-    return torch.mean(torch.acos(torch.clamp(dot, -1 + eps, 1 - eps)) ** 2)
+    sel = dot <= cos_th                                  # only bends sharper than the threshold are penalised
+    ang2 = torch.acos(torch.clamp(dot, -1 + eps, 1 - eps)) ** 2
+    # mean over the selected pairs as sum/count (the reference indexes with the boolean mask: same value, but that
+    # form synchronises with the host every iteration); no selected pair -> 0
+    cnt = sel.sum()
+    return torch.where(sel, ang2, torch.zeros_like(ang2)).sum() / torch.clamp(cnt, min=1).to(ang2.dtype)
 
 
 def strand_joints_magnet_loss(gaussians: HairGaussianModel):

@@ -147,6 +147,11 @@ class GaussianModel:
 
     _POSITION_GROUP = "xyz"
 
+    def _adam_kwargs(self):
+        """Same Adam as the reference (lr=0, eps=1e-15, per-tensor groups); on the GPU the update of each group runs as
+        ONE fused multi-tensor kernel instead of ~5 foreach kernels (identical update rule)."""
+        return {"fused": True} if str(self.device).startswith("cuda") or getattr(self.device, "type", "") == "cuda" else {}
+
     def _num_primitives(self):
         return self.get_xyz.shape[0]
 
@@ -162,7 +167,7 @@ class GaussianModel:
         self.denom = torch.zeros((n, 1), device=self.device)
         lrs = self._group_lrs(training_args)
         groups = [{"params": [getattr(self, attr)], "lr": lrs[name], "name": name} for name, attr in self._PARAM_ATTRS]
-        self.optimizer = torch.optim.Adam(groups, lr=0.0, eps=1e-15)
+        self.optimizer = torch.optim.Adam(groups, lr=0.0, eps=1e-15, **self._adam_kwargs())
         self.xyz_scheduler_args = get_expon_lr_func(
             lr_init=training_args.position_lr_init * self.spatial_lr_scale,
             lr_final=training_args.position_lr_final * self.spatial_lr_scale,
@@ -278,11 +283,14 @@ class GaussianModel:
             self.prune_points(prune)
 
     def update_densification_stats(self, viewspace_point_tensor, radii, update_filter):
-        """max screen radius + accumulated |dL/dmean2D| (pixel grad x (0.5W, 0.5H)) per visible Gaussian (:675-682)."""
-        self.max_radii2D[update_filter] = torch.max(self.max_radii2D[update_filter], radii[update_filter])
-        self.xyz_gradient_accum[update_filter] += torch.norm(viewspace_point_tensor.grad[update_filter, :2], dim=-1,
-                                                             keepdim=True)
-        self.denom[update_filter] += 1
+        """max screen radius + accumulated |dL/dmean2D| (pixel grad x (0.5W, 0.5H)) per visible primitive
+        (reference gaussian_model.py:675-682 / hair_gaussian_model.py:1401-1408).  Written with torch.where instead
+        of boolean-mask assignment: same values, but no nonzero() -> no host synchronisation per iteration."""
+        f = update_filter
+        self.max_radii2D = torch.where(f, torch.max(self.max_radii2D, radii.to(self.max_radii2D.dtype)), self.max_radii2D)
+        g = torch.norm(viewspace_point_tensor.grad[:, :2], dim=-1, keepdim=True)
+        self.xyz_gradient_accum = self.xyz_gradient_accum + torch.where(f[:, None], g, torch.zeros_like(g))
+        self.denom = self.denom + f[:, None].to(self.denom.dtype)
 
     # ---- segment view of a Gaussian (reference :686-725) ----
     def set_dist_to_scale_factor(self, dist_to_scale_factor):

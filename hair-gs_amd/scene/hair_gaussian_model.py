@@ -152,7 +152,7 @@ class HairGaussianModel(GaussianModel):
         self.denom = torch.zeros((n, 1), device=self.device)
         lrs = self._group_lrs(training_args)
         groups = [{"params": [getattr(self, attr)], "lr": lrs[name], "name": name} for name, attr in self._PARAM_ATTRS]
-        self.optimizer = torch.optim.Adam(groups, lr=0.0, eps=1e-15)
+        self.optimizer = torch.optim.Adam(groups, lr=0.0, eps=1e-15, **self._adam_kwargs())
         ta = training_args
 
         def sched(a, b):
@@ -182,10 +182,14 @@ class HairGaussianModel(GaussianModel):
         self.merge_angle_th = self.merge_angle_th_scheduler(iteration)
 
     def update_densification_stats(self, viewspace_point_tensor, radii, update_filter):
-        self.max_radii2D[update_filter] = torch.max(self.max_radii2D[update_filter], radii[update_filter])
-        self.xyz_gradient_accum[update_filter] += torch.norm(viewspace_point_tensor.grad[update_filter, :2], dim=-1,
-                                                             keepdim=True)
-        self.denom[update_filter] += 1
+        """max screen radius + accumulated |dL/dmean2D| (pixel grad x (0.5W, 0.5H)) per visible primitive
+        (reference gaussian_model.py:675-682 / hair_gaussian_model.py:1401-1408).  Written with torch.where instead
+        of boolean-mask assignment: same values, but no nonzero() -> no host synchronisation per iteration."""
+        f = update_filter
+        self.max_radii2D = torch.where(f, torch.max(self.max_radii2D, radii.to(self.max_radii2D.dtype)), self.max_radii2D)
+        g = torch.norm(viewspace_point_tensor.grad[:, :2], dim=-1, keepdim=True)
+        self.xyz_gradient_accum = self.xyz_gradient_accum + torch.where(f[:, None], g, torch.zeros_like(g))
+        self.denom = self.denom + f[:, None].to(self.denom.dtype)
 
     def reset_opacity(self):
         new = inverse_sigmoid(torch.min(self.get_opacity, torch.ones_like(self.get_opacity) * 0.01))

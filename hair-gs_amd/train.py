@@ -84,13 +84,26 @@ class ViewSampler:
 
 
 def training_step(gaussians, viewpoint_cam, opt, bg, iteration, extent=1.0, vp=None, stats_local=None):
-    """One optimizer step.  Returns (loss tensor (detached, on device), loss_dict, render_pkg)."""
+    """One optimizer step.  Returns (loss tensor (detached, on device), loss_dict, render_pkg).
+    In the rasterizer's asynchronous mode (diff_gaussian_rasterization._C.set_async) the three passes never block;
+    their instance counts are validated once here, before Adam, and the step is repeated if a pass overflowed."""
+    from diff_gaussian_rasterization import _C as raster
+    for _attempt in range(4):
+        try:
+            return _training_step(gaussians, viewpoint_cam, opt, bg, iteration, extent, vp, raster)
+        except raster.HgsCapacityOverflow:
+            gaussians.optimizer.zero_grad(set_to_none=True)
+    raise RuntimeError("rasterizer capacity kept overflowing")
+
+
+def _training_step(gaussians, viewpoint_cam, opt, bg, iteration, extent, vp, raster):
     gaussians.update_learning_rate(iteration)
     if iteration % 1000 == 0:
         gaussians.oneupSHdegree()
     render_pkg = render(viewpoint_cam, gaussians, bg)
     loss, loss_dict = loss_function(gaussians, render_pkg["render"], viewpoint_cam, opt)
     loss.backward()
+    raster.check_async()  # async mode: the step's single synchronisation (raises -> step repeated); no-op otherwise
     with torch.no_grad():
         if iteration < opt.densify_until_iter:
             gaussians.update_densification_stats(render_pkg["viewspace_points"], render_pkg["radii"],

@@ -175,3 +175,42 @@ def test_fused_losses_match_torch_ops():
     Ls.fused_losses = True
     assert abs(out[True][0] - out[False][0]) <= 1e-5 * abs(out[False][0])
     assert (out[True][1] - out[False][1]).abs().max() <= 5e-4 * out[False][1].abs().max()
+
+
+def test_async_capacity_mode_matches_blocking_and_recovers_from_overflow():
+    """set_async: no per-pass host sync; results identical to the blocking mode; an under-sized capacity is detected
+    by check_async() and the step is repeated by training_step."""
+    from arguments import OptimizationParams
+    from diff_gaussian_rasterization import _C as raster
+    from gaussian_renderer import render
+    from synthetic import build_workload
+    from train import training_step
+    model, cams, extent = build_workload("tiny", device="cuda", with_targets=True)
+    bg = torch.zeros(3, device="cuda")
+    with torch.no_grad():
+        ref = [render(c, model, bg)["render"].clone() for c in cams]
+    try:
+        raster.set_async(True)
+        with torch.no_grad():
+            got = [render(c, model, bg)["render"].clone() for c in cams]   # first call learns the capacity (blocking)
+            counts = raster.check_async()
+        assert len(counts) == len(cams) - 1 and all(c > 0 for c in counts)
+        for a, b in zip(got, ref):
+            assert torch.equal(a, b)
+        # force an overflow: shrink the capacity below what the scene needs
+        raster._state["cap"] = 64
+        with torch.no_grad():
+            render(cams[0], model, bg)
+        with pytest.raises(raster.HgsCapacityOverflow):
+            raster.check_async()
+        assert raster._state["cap"] > 64
+        # training_step repeats the step transparently
+        opt = OptimizationParams()
+        opt.enable_topology = False
+        model.training_setup(opt)
+        raster._state["cap"] = 64
+        before = model._endpoints.detach().clone()
+        loss, _, _ = training_step(model, cams[1], opt, bg, 1, extent=extent)
+        assert torch.isfinite(loss) and not torch.equal(before, model._endpoints.detach())
+    finally:
+        raster.set_async(False)
