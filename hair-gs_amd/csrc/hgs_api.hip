@@ -140,7 +140,7 @@ int hgs_forward_render(void* stream, int P, int W, int H, int R_capacity, const 
       if (hgs_launch_sort_tiles(s, W, H, R_capacity, feat, g, im, b)) return 1;
     }
   }
-  return hgs_launch_blend_fwd(s, W, H, bg, im, b, out_color);
+  return hgs_launch_blend_fwd(s, W, H, R_capacity > 0 ? R_capacity : 0, bg, im, b, out_color);
 }
 
 int hgs_backward(void* stream, int P, int D, int M, int R, int W, int H, const float* bg, const float* means3D,
@@ -167,7 +167,7 @@ int hgs_backward(void* stream, int P, int D, int M, int R, int W, int H, const f
     hgs_binning_carve((char*)binning_buf, (size_t)R, b, nullptr);
     inst_grad = (float*)scratch;
     HGS_CHECK_HIP(hipMemsetAsync(inst_grad, 0, (size_t)R * HGS_INST_GRAD_FLOATS * sizeof(float), s));
-    if (hgs_launch_blend_bwd(s, W, H, bg, im, b, dL_dpix, inst_grad)) return 1;
+    if (hgs_launch_blend_bwd(s, W, H, R, bg, im, b, dL_dpix, inst_grad)) return 1;
   }
   HgsBwdArgs a;
   a.P = P; a.D = D; a.M = M; a.W = W; a.H = H;
@@ -177,7 +177,7 @@ int hgs_backward(void* stream, int P, int D, int M, int R, int W, int H, const f
   a.dL_dmeans2D = dL_dmeans2D; a.dL_dconic = dL_dconic; a.dL_dopacity = dL_dopacity; a.dL_dcolors = dL_dcolors;
   a.dL_dmeans3D = dL_dmeans3D; a.dL_dcov3D = dL_dcov3D; a.dL_dsh = dL_dsh; a.dL_dscales = dL_dscales;
   a.dL_drotations = dL_drotations;
-  return hgs_launch_preprocess_bwd(s, a, g, b, inst_grad);
+  return hgs_launch_preprocess_bwd(s, a, g, b, inst_grad, R);
 }
 
 int hgs_mark_visible(void* stream, int P, const float* means3D, const float* viewmatrix, const float* projmatrix,

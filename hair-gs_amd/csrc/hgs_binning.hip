@@ -55,7 +55,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_kernel(int nblk, int T, Hgs
 }
 
 __device__ __forceinline__ void emit_instance(uint64_t key, uint32_t pos, int tx, int ty, const float* __restrict__ feat,
-                                              const HgsGeom& g, const HgsBinning& b) {
+                                              const HgsGeom& g, const HgsBinning& b, uint32_t Rcap) {
   const uint32_t id = (uint32_t)key;
   b.point_list[pos] = id;
   b.keys_sorted[pos] = key;
@@ -68,7 +68,7 @@ __device__ __forceinline__ void emit_instance(uint64_t key, uint32_t pos, int tx
   rec[2] = make_float4(f2, __uint_as_float(id), 0.f, 0.f);
   const HgsRect rc = g.rect[id];
   const uint32_t k = (uint32_t)(ty - rc.y0) * (uint32_t)(rc.x1 - rc.x0) + (uint32_t)(tx - rc.x0);
-  b.inv[rc.off + k] = pos;
+  if (rc.off + k < Rcap) b.inv[rc.off + k] = pos;
 }
 
 __device__ __forceinline__ void bitonic_lds(uint64_t* sk, int m) {
@@ -104,7 +104,7 @@ __global__ __launch_bounds__(HGS_BLOCK) void sort_tiles_kernel(int gx, uint32_t 
     __syncthreads();
     bitonic_lds(sk, m);
     if (nchunks == 1) {
-      for (uint32_t i = threadIdx.x; i < cn; i += HGS_BLOCK) emit_instance(sk[i], cbase + i, tx, ty, feat, g, b);
+      for (uint32_t i = threadIdx.x; i < cn; i += HGS_BLOCK) emit_instance(sk[i], cbase + i, tx, ty, feat, g, b, Rcap);
     } else {
       for (uint32_t i = threadIdx.x; i < cn; i += HGS_BLOCK) b.keys[cbase + i] = sk[i];
     }
@@ -129,7 +129,7 @@ __global__ __launch_bounds__(HGS_BLOCK) void sort_tiles_kernel(int gx, uint32_t 
         }
         rank += lo;
       }
-      emit_instance(key, start + rank, tx, ty, feat, g, b);
+      emit_instance(key, start + rank, tx, ty, feat, g, b, Rcap);
     }
   }
 }

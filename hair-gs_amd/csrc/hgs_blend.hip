@@ -62,7 +62,8 @@ __device__ __forceinline__ void wave_reduce9(const float* v, float& x0123, float
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(HGS_BLOCK) void blend_fwd_kernel(const uint2* __restrict__ ranges,
                                                               const float4* __restrict__ packed, int W, int H, int gx,
-                                                              const float* __restrict__ bg, float* __restrict__ final_T,
+                                                              uint32_t Rcap, const float* __restrict__ bg,
+                                                              float* __restrict__ final_T,
                                                               uint32_t* __restrict__ n_contrib,
                                                               uint32_t* __restrict__ tile_maxc,
                                                               float* __restrict__ out_color) {
@@ -73,7 +74,8 @@ __global__ __launch_bounds__(HGS_BLOCK) void blend_fwd_kernel(const uint2* __res
   const int py = ty * HGS_TILE + (wave >> 1) * 8 + (lane >> 3);
   const bool inside = px < W && py < H;
   const float pxf = (float)px, pyf = (float)py;
-  const uint2 range = ranges[tile];
+  uint2 range = ranges[tile];
+  if (range.y > Rcap) range = make_uint2(0u, 0u);  // binning buffer under-sized (flagged by the scatter kernel)
   float T = 1.f, C0 = 0.f, C1 = 0.f, C2 = 0.f;
   uint32_t last = 0;
   bool done = !inside;
@@ -127,7 +129,7 @@ __global__ __launch_bounds__(HGS_BLOCK) void blend_fwd_kernel(const uint2* __res
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(HGS_BLOCK) void blend_bwd_kernel(const uint2* __restrict__ ranges,
                                                               const float4* __restrict__ packed, int W, int H, int gx,
-                                                              const float* __restrict__ bg,
+                                                              uint32_t Rcap, const float* __restrict__ bg,
                                                               const float* __restrict__ final_Ts,
                                                               const uint32_t* __restrict__ n_contrib,
                                                               const uint32_t* __restrict__ tile_maxc,
@@ -137,7 +139,7 @@ __global__ __launch_bounds__(HGS_BLOCK) void blend_bwd_kernel(const uint2* __res
   const int tile = blockIdx.x;
   const uint2 range = ranges[tile];
   const uint32_t maxc = tile_maxc[tile];
-  if (maxc == 0) return;  // nothing in this tile contributed to any pixel (inst_grad rows stay zero)
+  if (maxc == 0 || range.y > Rcap) return;  // nothing in this tile contributed to any pixel (inst_grad rows stay zero)
   const int tx = tile % gx, ty = tile / gx;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int px = tx * HGS_TILE + (wave & 1) * 8 + (lane & 7);
@@ -237,24 +239,24 @@ __global__ __launch_bounds__(HGS_BLOCK) void blend_bwd_kernel(const uint2* __res
 
 }  // namespace
 
-int hgs_launch_blend_fwd(hipStream_t s, int W, int H, const float* bg, const HgsImage& im, const HgsBinning& b,
+int hgs_launch_blend_fwd(hipStream_t s, int W, int H, int Rcap, const float* bg, const HgsImage& im, const HgsBinning& b,
                          float* out_color) {
   const int gx = (W + HGS_TILE - 1) / HGS_TILE, gy = (H + HGS_TILE - 1) / HGS_TILE;
   {
     HgsProfScope _prof(s, HGS_K_BLEND_FWD);
-    hipLaunchKernelGGL(blend_fwd_kernel, dim3(gx * gy), dim3(HGS_BLOCK), 0, s, im.ranges, b.packed, W, H, gx, bg,
+    hipLaunchKernelGGL(blend_fwd_kernel, dim3(gx * gy), dim3(HGS_BLOCK), 0, s, im.ranges, b.packed, W, H, gx, (uint32_t)Rcap, bg,
                      im.final_T, im.n_contrib, im.tile_maxc, out_color);
   }
   HGS_CHECK_LAUNCH();
   return 0;
 }
 
-int hgs_launch_blend_bwd(hipStream_t s, int W, int H, const float* bg, const HgsImage& im, const HgsBinning& b,
+int hgs_launch_blend_bwd(hipStream_t s, int W, int H, int Rcap, const float* bg, const HgsImage& im, const HgsBinning& b,
                          const float* dL_dpix, float* inst_grad) {
   const int gx = (W + HGS_TILE - 1) / HGS_TILE, gy = (H + HGS_TILE - 1) / HGS_TILE;
   {
     HgsProfScope _prof(s, HGS_K_BLEND_BWD);
-    hipLaunchKernelGGL(blend_bwd_kernel, dim3(gx * gy), dim3(HGS_BLOCK), 0, s, im.ranges, b.packed, W, H, gx, bg,
+    hipLaunchKernelGGL(blend_bwd_kernel, dim3(gx * gy), dim3(HGS_BLOCK), 0, s, im.ranges, b.packed, W, H, gx, (uint32_t)Rcap, bg,
                      im.final_T, im.n_contrib, im.tile_maxc, dL_dpix, inst_grad);
   }
   HGS_CHECK_LAUNCH();

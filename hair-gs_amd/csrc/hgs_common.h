@@ -119,9 +119,9 @@ int hgs_launch_scatter(hipStream_t s, int P, int W, int H, int Rcap, const int* 
                        const HgsImage& im, const HgsBinning& b);
 int hgs_launch_sort_tiles(hipStream_t s, int W, int H, int Rcap, const float* features, const HgsGeom& g,
                           const HgsImage& im, const HgsBinning& b);
-int hgs_launch_blend_fwd(hipStream_t s, int W, int H, const float* bg, const HgsImage& im, const HgsBinning& b,
+int hgs_launch_blend_fwd(hipStream_t s, int W, int H, int Rcap, const float* bg, const HgsImage& im, const HgsBinning& b,
                          float* out_color);
-int hgs_launch_blend_bwd(hipStream_t s, int W, int H, const float* bg, const HgsImage& im, const HgsBinning& b,
+int hgs_launch_blend_bwd(hipStream_t s, int W, int H, int Rcap, const float* bg, const HgsImage& im, const HgsBinning& b,
                          const float* dL_dpix, float* inst_grad);
 struct HgsBwdArgs {
   int P, D, M, W, H;
@@ -133,7 +133,7 @@ struct HgsBwdArgs {
       *dL_drotations;
 };
 int hgs_launch_preprocess_bwd(hipStream_t s, const HgsBwdArgs& a, const HgsGeom& g, const HgsBinning& b,
-                              const float* inst_grad);
+                              const float* inst_grad, int Rcap);
 int hgs_launch_mark_visible(hipStream_t s, int P, const float* means3D, const float* viewmatrix, uint8_t* present);
 int hgs_launch_dist2(hipStream_t s, int P, const float* points, float* out, void* scratch, size_t scratch_bytes);
 size_t hgs_dist2_scratch(int P);

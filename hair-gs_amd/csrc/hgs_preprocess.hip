@@ -247,7 +247,7 @@ __device__ __forceinline__ V3 dnormvdv(V3 v, V3 dv) {  // auxiliary.h:107-117
 }
 
 __global__ __launch_bounds__(HGS_BLOCK) void preprocess_bwd_kernel(HgsBwdArgs a, HgsGeom g, HgsBinning b,
-                                                                   const float* __restrict__ inst_grad) {
+                                                                   const float* __restrict__ inst_grad, uint32_t Rcap) {
   const int idx = blockIdx.x * HGS_BLOCK + threadIdx.x;
   if (idx >= a.P) return;
   const int M = a.M;
@@ -260,7 +260,9 @@ __global__ __launch_bounds__(HGS_BLOCK) void preprocess_bwd_kernel(HgsBwdArgs a,
     const HgsRect rc = g.rect[idx];
     const uint32_t n = g.tiles_touched[idx];
     for (uint32_t k = 0; k < n; k++) {
+      if (rc.off + k >= Rcap) break;  // under-sized binning buffer (forward already flagged the overflow)
       const uint32_t pos = b.inv[rc.off + k];
+      if (pos >= Rcap) continue;
       const float4* r = (const float4*)(inst_grad + (size_t)pos * HGS_INST_GRAD_FLOATS);
       const float4 r0 = r[0], r1 = r[1];
       const float r2 = r[2].x;
@@ -487,11 +489,11 @@ int hgs_launch_scatter(hipStream_t s, int P, int W, int H, int Rcap, const int* 
   return 0;
 }
 int hgs_launch_preprocess_bwd(hipStream_t s, const HgsBwdArgs& a, const HgsGeom& g, const HgsBinning& b,
-                              const float* inst_grad) {
+                              const float* inst_grad, int Rcap) {
   const int nblk = (a.P + HGS_BLOCK - 1) / HGS_BLOCK;
   {
     HgsProfScope _prof(s, HGS_K_PREPROCESS_BWD);
-    hipLaunchKernelGGL(preprocess_bwd_kernel, dim3(nblk), dim3(HGS_BLOCK), 0, s, a, g, b, inst_grad);
+    hipLaunchKernelGGL(preprocess_bwd_kernel, dim3(nblk), dim3(HGS_BLOCK), 0, s, a, g, b, inst_grad, (uint32_t)Rcap);
   }
   HGS_CHECK_LAUNCH();
   return 0;

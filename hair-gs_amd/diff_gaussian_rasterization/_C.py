@@ -16,7 +16,7 @@ import hgs_runtime as rt
 # instead of three).  If a pass needed more than its capacity, check_async() raises HgsCapacityOverflow after growing
 # the capacity: the caller discards the step's gradients and repeats it.  `num_rendered` returned by
 # rasterize_gaussians is then the capacity (it only sizes/carves buffers downstream).
-_state = {"last_R": 0, "async": False, "cap": 0, "slack": 1.5, "pending": []}
+_state = {"last_R": 0, "async": False, "cap": 0, "slack": 1.5, "pending": [], "pool": []}
 
 
 class HgsCapacityOverflow(RuntimeError):
@@ -38,6 +38,7 @@ def check_async():
         r, flag = int(host[0]), int(host[1])
         counts.append(r)
         overflow |= (flag != 0) or (r > cap)
+        _state["pool"].append(host)  # pinned buffers are recycled: allocating one per pass costs more than the sync
     _state["pending"].clear()
     _state["cap"] = max(_state["cap"], int(max(counts) * _state["slack"]) + 4096)
     if overflow:
@@ -93,7 +94,7 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
                                       rt.ptr(img), rt.ptr(out_color)))
         if use_async:
             off = rt.layout("image", W, H)["status"]
-            host = torch.empty(2, dtype=torch.int32, pin_memory=True)
+            host = _state["pool"].pop() if _state["pool"] else torch.empty(2, dtype=torch.int32, pin_memory=True)
             host.copy_(img[off:off + 8].view(torch.int32), non_blocking=True)
             _state["pending"].append((host, R))
         if debug:
