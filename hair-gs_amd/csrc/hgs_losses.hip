@@ -145,12 +145,13 @@ __global__ __launch_bounds__(256) void ssim_l1_bwd_kernel(int H, int W, SsimWin 
 // ---- orientation loss (reference loss/losses.py:224-289) ---------------------------------------------------------
 // per pixel: world-space direction image -> view space (x,y) -> unit 2-vector -> angle in [0,pi) w.r.t. the image
 // y axis -> bidirectional difference to the GT angle, confidence-weighted, averaged over the mask.
-struct OriParams { float r00, r01, r10, r11, r20, r21; float bg0, bg1, bg2; float min_val; int has_mask; };
+struct OriParams { const float* view; float bg0, bg1, bg2; float min_val; int has_mask; };
 
 __device__ __forceinline__ bool ori_pixel(const OriParams& p, float o0, float o1, float o2, float& px, float& py, float& r,
                                           float& n, float& x, float& y, float& yq, float& theta) {
-  px = o0 * p.r00 + o1 * p.r10 + o2 * p.r20;   // (flat @ world_view[:3,:3])[:, :2]
-  py = o0 * p.r01 + o1 * p.r11 + o2 * p.r21;
+  const float* v = p.view;                      // world_view_transform, row-major 4x4 (device, wave-uniform)
+  px = o0 * v[0] + o1 * v[4] + o2 * v[8];      // (flat @ world_view[:3,:3])[:, :2]
+  py = o0 * v[1] + o1 * v[5] + o2 * v[9];
   r = sqrtf(px * px + py * py);
   n = r + p.min_val;
   x = px / n;
@@ -208,7 +209,8 @@ __global__ __launch_bounds__(256) void ori_bwd_kernel(int N, OriParams p, const 
       const float inv_n = 1.f / n, inv_n2 = inv_n * inv_n, ir = 1.f / r;
       const float dn = -(dx * px + dy * py) * inv_n2;
       const float dpx = dx * inv_n + dn * px * ir, dpy = dy * inv_n + dn * py * ir;
-      g0 = dpx * p.r00 + dpy * p.r01; g1 = dpx * p.r10 + dpy * p.r11; g2 = dpx * p.r20 + dpy * p.r21;
+      const float* v = p.view;
+      g0 = dpx * v[0] + dpy * v[1]; g1 = dpx * v[4] + dpy * v[5]; g2 = dpx * v[8] + dpy * v[9];
     }
   }
   d_omap[i] = g0; d_omap[(size_t)N + i] = g1; d_omap[2 * (size_t)N + i] = g2;
@@ -260,9 +262,9 @@ int hgs_ssim_l1_backward(void* stream, int C, int H, int W, const float* window1
   return 0;
 }
 
-static OriParams ori_params(const float* rot6_host, const float* bg3_host, float min_val, const uint8_t* mask) {
+static OriParams ori_params(const float* viewmatrix, const float* bg3_host, float min_val, const uint8_t* mask) {
   OriParams p;
-  p.r00 = rot6_host[0]; p.r01 = rot6_host[1]; p.r10 = rot6_host[2]; p.r11 = rot6_host[3]; p.r20 = rot6_host[4]; p.r21 = rot6_host[5];
+  p.view = viewmatrix;
   p.bg0 = bg3_host[0]; p.bg1 = bg3_host[1]; p.bg2 = bg3_host[2];
   p.min_val = min_val;
   p.has_mask = mask != nullptr;
@@ -271,30 +273,30 @@ static OriParams ori_params(const float* rot6_host, const float* bg3_host, float
 
 int hgs_orientation_loss_num_blocks(int H, int W) { return (int)(((size_t)H * W + 255) / 256); }
 
-int hgs_orientation_loss_forward(void* stream, int H, int W, const float* omap, const float* rot6_host,
+int hgs_orientation_loss_forward(void* stream, int H, int W, const float* omap, const float* viewmatrix,
                                  const float* bg3_host, float min_val, const float* gt_theta, const float* confidence,
                                  const uint8_t* mask, float* partials) {
-  if (!omap || !rot6_host || !bg3_host || !gt_theta || !confidence || !partials) { hgs_set_error("hgs_orientation_loss_forward: null argument"); return 1; }
+  if (!omap || !viewmatrix || !bg3_host || !gt_theta || !confidence || !partials) { hgs_set_error("hgs_orientation_loss_forward: null argument"); return 1; }
   const int N = H * W;
   hipStream_t s = (hipStream_t)stream;
   {
     HgsProfScope _prof(s, HGS_K_ORI_FWD);
-    hipLaunchKernelGGL(ori_fwd_kernel, dim3((N + 255) / 256), dim3(256), 0, s, N, ori_params(rot6_host, bg3_host, min_val, mask),
+    hipLaunchKernelGGL(ori_fwd_kernel, dim3((N + 255) / 256), dim3(256), 0, s, N, ori_params(viewmatrix, bg3_host, min_val, mask),
                        omap, gt_theta, confidence, mask, partials);
   }
   HGS_CHECK_LAUNCH();
   return 0;
 }
 
-int hgs_orientation_loss_backward(void* stream, int H, int W, const float* omap, const float* rot6_host,
+int hgs_orientation_loss_backward(void* stream, int H, int W, const float* omap, const float* viewmatrix,
                                   const float* bg3_host, float min_val, const float* gt_theta, const float* confidence,
                                   const uint8_t* mask, const float* g_loss, const float* mask_count, float* d_omap) {
-  if (!omap || !rot6_host || !bg3_host || !gt_theta || !confidence || !g_loss || !mask_count || !d_omap) { hgs_set_error("hgs_orientation_loss_backward: null argument"); return 1; }
+  if (!omap || !viewmatrix || !bg3_host || !gt_theta || !confidence || !g_loss || !mask_count || !d_omap) { hgs_set_error("hgs_orientation_loss_backward: null argument"); return 1; }
   const int N = H * W;
   hipStream_t s = (hipStream_t)stream;
   {
     HgsProfScope _prof(s, HGS_K_ORI_BWD);
-    hipLaunchKernelGGL(ori_bwd_kernel, dim3((N + 255) / 256), dim3(256), 0, s, N, ori_params(rot6_host, bg3_host, min_val, mask),
+    hipLaunchKernelGGL(ori_bwd_kernel, dim3((N + 255) / 256), dim3(256), 0, s, N, ori_params(viewmatrix, bg3_host, min_val, mask),
                        omap, gt_theta, confidence, mask, g_loss, mask_count, d_omap);
   }
   HGS_CHECK_LAUNCH();

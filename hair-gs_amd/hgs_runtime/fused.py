@@ -97,40 +97,43 @@ def ssim_l1(img, gt):
 
 class _OrientationLoss(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, omap, rot, bg, min_val, gt_theta, confidence, mask):
+    def forward(ctx, omap, viewmatrix, bg, min_val, gt_theta, confidence, mask):
         omap = rt.require_gpu_tensor(omap, "orientation map", torch.float32)
+        view = rt.require_gpu_tensor(viewmatrix, "world_view_transform", torch.float32)
         gt_theta = rt.require_gpu_tensor(gt_theta, "orientation_field", torch.float32)
         confidence = rt.require_gpu_tensor(confidence, "orientation_confidence", torch.float32)
         H, W, dev, L = omap.shape[1], omap.shape[2], omap.device, rt.lib()
-        mask_u8 = None if mask is None else rt.require_gpu_tensor(mask, "mask").to(torch.uint8)
+        mask_u8 = None
+        if mask is not None:
+            mask = rt.require_gpu_tensor(mask, "mask")
+            mask_u8 = mask.view(torch.uint8) if mask.dtype == torch.bool else mask.to(torch.uint8)
         nb = L.hgs_orientation_loss_num_blocks(H, W)
         partials = torch.empty((nb, 2), dtype=torch.float32, device=dev)
-        rot6 = (C.c_float * 6)(*rot)
         bg3 = (C.c_float * 3)(*bg)
         with torch.cuda.device(dev):
-            rt.check(L.hgs_orientation_loss_forward(rt.current_stream(), H, W, rt.ptr(omap), rot6, bg3, float(min_val),
+            rt.check(L.hgs_orientation_loss_forward(rt.current_stream(), H, W, rt.ptr(omap), rt.ptr(view), bg3, float(min_val),
                                                     rt.ptr(gt_theta), rt.ptr(confidence), rt.ptr(mask_u8), rt.ptr(partials)))
         sums = partials.sum(dim=0)
-        ctx.save_for_backward(omap, gt_theta, confidence, mask_u8 if mask_u8 is not None else torch.empty(0, device=dev),
-                              sums)
-        ctx.consts = (rot6, bg3, float(min_val), mask_u8 is not None)
+        ctx.save_for_backward(omap, view, gt_theta, confidence,
+                              mask_u8 if mask_u8 is not None else torch.empty(0, device=dev), sums)
+        ctx.consts = (bg3, float(min_val), mask_u8 is not None)
         return sums[0] / sums[1]
 
     @staticmethod
     def backward(ctx, g):
-        omap, gt_theta, confidence, mask_u8, sums = ctx.saved_tensors
-        rot6, bg3, min_val, has_mask = ctx.consts
+        omap, view, gt_theta, confidence, mask_u8, sums = ctx.saved_tensors
+        bg3, min_val, has_mask = ctx.consts
         H, W = omap.shape[1], omap.shape[2]
         g = g.contiguous().to(torch.float32)
         count = sums[1:2].contiguous()
         d = torch.empty_like(omap)
         with torch.cuda.device(omap.device):
-            rt.check(rt.lib().hgs_orientation_loss_backward(rt.current_stream(), H, W, rt.ptr(omap), rot6, bg3, min_val,
-                                                            rt.ptr(gt_theta), rt.ptr(confidence),
+            rt.check(rt.lib().hgs_orientation_loss_backward(rt.current_stream(), H, W, rt.ptr(omap), rt.ptr(view), bg3,
+                                                            min_val, rt.ptr(gt_theta), rt.ptr(confidence),
                                                             rt.ptr(mask_u8) if has_mask else None, rt.ptr(g), rt.ptr(count),
                                                             rt.ptr(d)))
         return d, None, None, None, None, None, None
 
 
-def orientation_loss(omap, rot6, bg3, min_val, gt_theta, confidence, mask):
-    return _OrientationLoss.apply(omap, rot6, bg3, min_val, gt_theta, confidence, mask)
+def orientation_loss(omap, viewmatrix, bg3, min_val, gt_theta, confidence, mask):
+    return _OrientationLoss.apply(omap, viewmatrix, bg3, min_val, gt_theta, confidence, mask)

@@ -98,14 +98,11 @@ def orientation_loss_rast(gaussians, camera, args, bg=None):
     omap = render(camera, gaussians, bg, override_color=gaussians.get_orientation)["render"]      # [3,H,W]
     if fused_losses and omap.is_cuda:
         from hgs_runtime.fused import orientation_loss
-        key = "_hgs_rot6"
-        if not hasattr(camera, key):  # view rotation is constant per camera: read it back once
-            setattr(camera, key, [float(v) for v in camera.world_view_transform[:3, :2].reshape(-1).cpu()])
-        bg3 = getattr(orientation_loss_rast, "_bg_cache", {}).get(id(bg))
-        if bg3 is None:
-            bg3 = [float(v) for v in bg.cpu()]
-            orientation_loss_rast._bg_cache = {id(bg): bg3}
-        return orientation_loss(omap, getattr(camera, key), bg3, gaussians.min_val, camera.orientation_field,
+        cache = orientation_loss_rast.__dict__.setdefault("_bg_cache", {})
+        bg3 = cache.get(id(bg))
+        if bg3 is None:  # the background colour is a per-run constant: read it back once
+            bg3 = cache[id(bg)] = [float(v) for v in bg.cpu()]
+        return orientation_loss(omap, camera.world_view_transform, bg3, gaussians.min_val, camera.orientation_field,
                                 camera.orientation_confidence, camera.mask)
     omap = omap.permute(1, 2, 0)
     h, w = omap.shape[:2]

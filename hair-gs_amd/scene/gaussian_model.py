@@ -287,10 +287,11 @@ class GaussianModel:
         (reference gaussian_model.py:675-682 / hair_gaussian_model.py:1401-1408).  Written with torch.where instead
         of boolean-mask assignment: same values, but no nonzero() -> no host synchronisation per iteration."""
         f = update_filter
-        self.max_radii2D = torch.where(f, torch.max(self.max_radii2D, radii.to(self.max_radii2D.dtype)), self.max_radii2D)
+        # in-place on the persistent statistics tensors (also what makes the step capturable in a HIP graph)
+        self.max_radii2D.copy_(torch.where(f, torch.max(self.max_radii2D, radii.to(self.max_radii2D.dtype)), self.max_radii2D))
         g = torch.norm(viewspace_point_tensor.grad[:, :2], dim=-1, keepdim=True)
-        self.xyz_gradient_accum = self.xyz_gradient_accum + torch.where(f[:, None], g, torch.zeros_like(g))
-        self.denom = self.denom + f[:, None].to(self.denom.dtype)
+        self.xyz_gradient_accum.add_(torch.where(f[:, None], g, torch.zeros_like(g)))
+        self.denom.add_(f[:, None].to(self.denom.dtype))
 
     # ---- segment view of a Gaussian (reference :686-725) ----
     def set_dist_to_scale_factor(self, dist_to_scale_factor):

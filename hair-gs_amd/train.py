@@ -126,6 +126,131 @@ def _training_step(gaussians, viewpoint_cam, opt, bg, iteration, extent, vp, ras
     return loss.detach(), loss_dict, render_pkg
 
 
+class GraphedStep:
+    """The whole training iteration (3 raster fwd+bwd, losses, statistics, Adam) captured ONCE into a HIP graph and
+    replayed per step: ~100 kernel launches cost one graph launch on the host, so the step runs at GPU speed instead
+    of Python-dispatch speed.  Requirements, all met by the library: no host synchronisation inside the step (the
+    rasterizer's async capacity mode), every per-step input in device memory (the camera is a static slot that
+    `step()` refreshes with device-to-device copies; learning rates are device tensors), in-place statistics.
+    Re-capture (`capture()`) after anything that changes shapes: densification, SH-degree bump, opacity reset.
+    Multi-GPU: gradients are exchanged between two graphs (fwd/bwd | eager RCCL all-reduce | Adam)."""
+
+    CAMERA_FIELDS = ("world_view_transform", "full_proj_transform", "camera_center", "original_image", "mask",
+                     "float_mask", "orientation_field", "orientation_confidence")
+
+    def __init__(self, gaussians, cameras, opt, bg, extent=1.0, vp=None, slack=2.0):
+        import copy
+        from diff_gaussian_rasterization import _C as raster
+        self.g, self.opt, self.bg, self.extent, self.raster = gaussians, opt, bg, extent, raster
+        self.vp = vp if vp is not None else ViewParallel()
+        c0 = cameras[0]
+        for c in cameras:  # by-value kernel arguments are frozen into the graph
+            assert (c.image_width, c.image_height, c.FoVx, c.FoVy) == (c0.image_width, c0.image_height, c0.FoVx, c0.FoVy)
+        self.slot = copy.copy(c0)
+        for f in self.CAMERA_FIELDS:
+            v = getattr(c0, f, None)
+            if torch.is_tensor(v):
+                setattr(self.slot, f, v.clone())
+        raster.set_async(True, slack=slack)
+        self._graphs = None
+        self._pending = []
+        self._make_capturable()
+
+    def _make_capturable(self):
+        opt_ = self.g.optimizer
+        dev = self.g.get_xyz.device
+        for group in opt_.param_groups:
+            group["capturable"] = True
+            if not torch.is_tensor(group["lr"]):
+                group["lr"] = torch.tensor(float(group["lr"]), dtype=torch.float32, device=dev)
+        for st in opt_.state.values():
+            if "step" in st and torch.is_tensor(st["step"]) and not st["step"].is_cuda:
+                st["step"] = st["step"].to(dev)
+
+    def _set_lr(self, iteration):
+        g = self.g
+        lr = g.xyz_scheduler_args(iteration)
+        for group in g.optimizer.param_groups:
+            if group["name"] == g._POSITION_GROUP:
+                group["lr"].fill_(float(lr))
+        if hasattr(g, "merge_dist_th_scheduler"):
+            g.merge_dist_th = g.merge_dist_th_scheduler(iteration)
+            g.merge_angle_th = g.merge_angle_th_scheduler(iteration)
+
+    def load_camera(self, cam):
+        for f in self.CAMERA_FIELDS:
+            dst, src = getattr(self.slot, f, None), getattr(cam, f, None)
+            if torch.is_tensor(dst) and torch.is_tensor(src):
+                dst.copy_(src, non_blocking=True)
+        self.slot.uid = cam.uid
+
+    def _forward_backward(self):
+        pkg = render(self.slot, self.g, self.bg)
+        loss, _ = loss_function(self.g, pkg["render"], self.slot, self.opt)
+        loss.backward()
+        with torch.no_grad():
+            self.g.update_densification_stats(pkg["viewspace_points"], pkg["radii"], pkg["visibility_filter"])
+        return loss.detach()
+
+    def capture(self, warmup_cams, iteration=1):
+        """Warm up eagerly on a side stream (allocator, lazy module loads, capacity), then capture."""
+        g, raster = self.g, self.raster
+        self._make_capturable()
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            for cam in warmup_cams:  # every view once: the capacity must cover the busiest camera
+                self.load_camera(cam)
+                self._set_lr(iteration)
+                self._forward_backward()
+                g.optimizer.zero_grad(set_to_none=True)
+                g._derived = None
+                raster.check_async()
+        torch.cuda.current_stream().wait_stream(s)
+        torch.cuda.synchronize()
+        raster._state["pending"].clear()
+        g.optimizer.zero_grad(set_to_none=True)
+        self.loss_buf = None
+        if self.vp.world == 1:
+            ga = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(ga):
+                self.loss_buf = self._forward_backward()
+                g.optimizer.step()
+            self._graphs = (ga, None)
+        else:
+            ga, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+            with torch.cuda.graph(ga):
+                self.loss_buf = self._forward_backward()
+            with torch.cuda.graph(gb, pool=ga.pool()):
+                g.optimizer.step()
+            self._graphs = (ga, gb)
+        self._pending = list(raster._state["pending"])  # pinned status buffers the captured copies write into
+        raster._state["pending"].clear()
+        g._derived = None
+
+    def step(self, cam, iteration):
+        """One optimizer step on `cam`; returns the (device) loss of this step."""
+        self._set_lr(iteration)
+        self.load_camera(cam)
+        ga, gb = self._graphs
+        ga.replay()
+        if gb is not None:
+            self.vp.reduce_stats_and_grads = None
+            self.vp.reduce_gradients(self.g)
+            gb.replay()
+        self.g._derived = None  # cached derived tensors now hold pre-update values
+        return self.loss_buf
+
+    def check(self):
+        """Synchronise and validate the instance counts of the last replay (raises on capacity overflow)."""
+        torch.cuda.current_stream().synchronize()
+        for host, cap in self._pending:
+            if int(host[1]) != 0 or int(host[0]) > cap:
+                raise self.raster.HgsCapacityOverflow(
+                    f"captured step needed {int(host[0])} instances > capacity {cap}: re-capture with a larger slack")
+        return [int(h[0]) for h, _ in self._pending]
+
+
 def training(gaussians, cameras, opt, iterations=None, extent=1.0, seed=0, log_every=0, vp=None, start_iteration=0):
     """Plain loop over training_step (no logger / viewer / dataset IO: those are outside the accelerated path)."""
     vp = ViewParallel() if vp is None else vp

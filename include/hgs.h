@@ -116,15 +116,15 @@ int hgs_ssim_l1_backward(void* stream, int C, int H, int W, const float* window1
                          const float* img2, const float* dmaps, const float* g_ssim_mean, const float* g_l1_mean,
                          float* dL_dimg1);
 /* hgs_orientation_loss_forward/backward <-> loss/losses.py:250-288 (everything after the orientation render):
- *   omap [3,H,W] rendered world-space directions; rot6_host = world_view_transform[:3,:2] row-major (6 floats, host);
+ *   omap [3,H,W] rendered world-space directions; viewmatrix = world_view_transform [4,4] (device; rows 0-2, cols 0-1 used);
  *   mask uint8 [H,W] or NULL (then mask = any(omap != bg3_host)); partials: 2 floats per 256-pixel block
  *   (sum of diff*confidence over the mask, mask count); loss = sum0 / sum1.  backward: g_loss, mask_count are
  *   device scalars; d_omap [3,H,W] fully written. */
 int hgs_orientation_loss_num_blocks(int H, int W);
-int hgs_orientation_loss_forward(void* stream, int H, int W, const float* omap, const float* rot6_host,
+int hgs_orientation_loss_forward(void* stream, int H, int W, const float* omap, const float* viewmatrix,
                                  const float* bg3_host, float min_val, const float* gt_theta, const float* confidence,
                                  const uint8_t* mask, float* partials);
-int hgs_orientation_loss_backward(void* stream, int H, int W, const float* omap, const float* rot6_host,
+int hgs_orientation_loss_backward(void* stream, int H, int W, const float* omap, const float* viewmatrix,
                                   const float* bg3_host, float min_val, const float* gt_theta, const float* confidence,
                                   const uint8_t* mask, const float* g_loss, const float* mask_count, float* d_omap);
 int hgs_strand_geometry_forward(void* stream, int P, const float* endpoints, const long long* endpoint_pairs,

@@ -214,3 +214,44 @@ def test_async_capacity_mode_matches_blocking_and_recovers_from_overflow():
         assert torch.isfinite(loss) and not torch.equal(before, model._endpoints.detach())
     finally:
         raster.set_async(False)
+
+
+def test_graphed_step_matches_eager_steps():
+    """HIP-graph replay of the whole iteration == the eager training_step sequence (same views, same updates)."""
+    from arguments import OptimizationParams
+    from diff_gaussian_rasterization import _C as raster
+    from synthetic import build_workload
+    from train import GraphedStep, training_step
+    from utils.general import safe_state
+    results = {}
+    order = [1, 3, 0, 2, 1, 0, 3, 2]
+    try:
+        for mode in ("eager", "graph"):
+            safe_state(True)
+            model, cams, extent = build_workload("tiny", device="cuda", with_targets=True)
+            opt = OptimizationParams()
+            opt.enable_topology = False
+            model.training_setup(opt)
+            bg = torch.zeros(3, device="cuda")
+            losses = []
+            if mode == "eager":
+                for it, ci in enumerate(order, 1):
+                    loss, _, _ = training_step(model, cams[ci], opt, bg, it, extent=extent)
+                    losses.append(float(loss))
+            else:
+                gs = GraphedStep(model, cams, opt, bg, extent=extent)
+                gs.capture(cams)
+                for it, ci in enumerate(order, 1):
+                    losses.append(float(gs.step(cams[ci], it)))
+                counts = gs.check()
+                assert len(counts) == 3 and min(counts) > 0
+                raster.set_async(False)
+            results[mode] = (losses, model._endpoints.detach().clone(), model._opacity.detach().clone(),
+                             model.denom.clone(), model.xyz_gradient_accum.clone())
+    finally:
+        raster.set_async(False)
+    le, lg = results["eager"][0], results["graph"][0]
+    assert np.allclose(le, lg, rtol=1e-4, atol=1e-6), (le, lg)
+    for a, b in zip(results["eager"][1:], results["graph"][1:]):
+        assert (a - b).abs().max() <= 1e-4 * max(1e-6, float(a.abs().max()))
+    assert float(results["graph"][3].sum()) > 0
