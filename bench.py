@@ -42,6 +42,7 @@ def parse():
     ap.add_argument("--views", type=int, default=None, help="override the number of camera views")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true", help="disable per-kernel HIP-event timing")
+    ap.add_argument("--eager", action="store_true", help="eager dispatch of every kernel instead of replaying the captured HIP graph")
     ap.add_argument("--blocking", action="store_true",
                     help="reference-style forward (host reads num_rendered in every pass) instead of the async capacity mode")
     return ap.parse_args()
@@ -110,25 +111,48 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    from train import GraphedStep
+    use_graph = not (args.eager or args.blocking)
     it = 0
+    if use_graph:
+        # the whole iteration is captured once into a HIP graph and replayed (train.GraphedStep); the W warm-up steps
+        # and the K timed steps are real optimizer steps on successive random views, exactly like the eager loop
+        gs = GraphedStep(model, cams, opt, bg, extent=extent, vp=vp)
+        gs.capture(cams, iteration=1)
+
+        def one_step():
+            nonlocal it
+            it += 1
+            gs.step(sampler.next(), it)
+    else:
+        def one_step():
+            nonlocal it
+            it += 1
+            training_step(model, sampler.next(), opt, bg, it, extent=extent, vp=vp)
     for _ in range(args.warmup):
-        it += 1
-        training_step(model, sampler.next(), opt, bg, it, extent=extent, vp=vp)
+        one_step()
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        one_step()
+    sync_all()
+    dt = time.perf_counter() - t0
+    if use_graph:
+        gs.check()  # instance counts of the captured passes stayed within capacity
+    # per-kernel device time: HIP events cannot bracket individual nodes of a replayed graph, so the same K steps are
+    # continued with eager dispatch and every library launch bracketed by events on its stream (hgs_prof_*)
+    kern = {}
     if not args.no_kernel_timing:
         sync_all()
         rt.prof_collect()
         rt.prof_enable(True)
-    sync_all()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        it += 1
-        training_step(model, sampler.next(), opt, bg, it, extent=extent, vp=vp)
-    sync_all()
-    dt = time.perf_counter() - t0
-    kern = {}
-    if not args.no_kernel_timing:
+        for _ in range(min(args.steps, 50)):
+            it += 1
+            training_step(model, sampler.next(), opt, bg, it, extent=extent, vp=vp)
+        sync_all()
         kern = rt.prof_collect()
         rt.prof_enable(False)
+        kern_steps = min(args.steps, 50)
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -181,7 +205,8 @@ def main():
                                "3 raster fwd+bwd passes + L1/DSSIM/mask/orientation/smoothness losses + Adam",
                    "gaussians": P, "views": len(cams), "width": W, "height": H, "parallelism": f"view-parallel x{world}",
                    "mean_num_rendered": meanR, "mean_sum_tile_list_len": meanL,
-                   "forward_mode": "blocking" if args.blocking else "async-capacity"},
+                   "forward_mode": "blocking" if args.blocking else "async-capacity",
+                   "dispatch": "hip-graph replay" if use_graph else "eager"},
         "render_ms_per_view": render_ms,
     }
     if kern:
@@ -197,7 +222,7 @@ def main():
         result["roofline_blend_fwd"] = {"achieved": bytes_fwd / (fwd_ms / max(fwd_n, 1) * 1e-3) / 1e9 if fwd_ms else 0.0,
                                         "unit": "GB/s", "mean_launch_us": fwd_ms / max(fwd_n, 1) * 1e3}
         result["kernel_us_per_launch"] = {k: (v[0] / v[1] * 1e3 if v[1] else 0.0) for k, v in kern.items()}
-        result["kernel_ms_per_iter"] = {k: v[0] / args.steps for k, v in kern.items()}
+        result["kernel_ms_per_iter"] = {k: v[0] / kern_steps for k, v in kern.items()}
     if world == 1 and not args.no_cpu_baseline:
         threads = min(os.cpu_count() or 1, 64)
         try:

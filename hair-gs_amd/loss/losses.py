@@ -85,8 +85,25 @@ def strand_joints_magnet_loss(gaussians: HairGaussianModel):
     raise NotImplementedError("lambda_magnet is 0 (disabled) in the reference defaults (arguments/__init__.py:93)")
 
 
+_BLACK = {}
+_BG_HOST = {}
+
+
 def _black(device):
-    return torch.zeros(3, dtype=torch.float32, device=device)
+    """Black background tensor, one per device (the reference allocates a fresh one per call, losses.py:228,296)."""
+    key = str(device)
+    if key not in _BLACK:
+        _BLACK[key] = torch.zeros(3, dtype=torch.float32, device=device)
+        _BG_HOST[id(_BLACK[key])] = [0.0, 0.0, 0.0]
+    return _BLACK[key]
+
+
+def _bg_host(bg):
+    """Host copy of a background colour (a per-run constant), read back at most once per tensor."""
+    v = _BG_HOST.get(id(bg))
+    if v is None:
+        v = _BG_HOST[id(bg)] = [float(x) for x in bg.cpu()]
+    return v
 
 
 def orientation_loss_rast(gaussians, camera, args, bg=None):
@@ -98,10 +115,7 @@ def orientation_loss_rast(gaussians, camera, args, bg=None):
     omap = render(camera, gaussians, bg, override_color=gaussians.get_orientation)["render"]      # [3,H,W]
     if fused_losses and omap.is_cuda:
         from hgs_runtime.fused import orientation_loss
-        cache = orientation_loss_rast.__dict__.setdefault("_bg_cache", {})
-        bg3 = cache.get(id(bg))
-        if bg3 is None:  # the background colour is a per-run constant: read it back once
-            bg3 = cache[id(bg)] = [float(v) for v in bg.cpu()]
+        bg3 = _bg_host(bg)
         return orientation_loss(omap, camera.world_view_transform, bg3, gaussians.min_val, camera.orientation_field,
                                 camera.orientation_confidence, camera.mask)
     omap = omap.permute(1, 2, 0)

@@ -167,12 +167,15 @@ class HairGaussianModel(GaussianModel):
                                                                                             ta.merge_angle_th_final)
         self.set_pval(ta.pval)
         self.training_args = ta
-        # longest allowed segment = foreground bounding-box diagonal / num_points_strand
-        fg = (self.get_mask >= self.foreground_binarization_th).squeeze(1)
-        used = torch.zeros(self._endpoints.shape[0], dtype=torch.bool, device=self.device)
-        used[self.endpoint_pairs[fg].flatten()] = True
-        pts = self._endpoints[used]
-        self.max_segment_length = torch.norm(pts.max(dim=0).values - pts.min(dim=0).values) / ta.num_points_strand
+        # longest allowed segment = foreground bounding-box diagonal / num_points_strand.  Evaluated without autograd:
+        # the reference leaves a graph hanging off this tensor (it indexes the parameter with grad enabled), which
+        # keeps the parameter's AccumulateGrad node alive on the creating stream and breaks later graph capture.
+        with torch.no_grad():
+            fg = (self.get_mask >= self.foreground_binarization_th).squeeze(1)
+            used = torch.zeros(self._endpoints.shape[0], dtype=torch.bool, device=self.device)
+            used[self.endpoint_pairs[fg].flatten()] = True
+            pts = self._endpoints[used]
+            self.max_segment_length = torch.norm(pts.max(dim=0).values - pts.min(dim=0).values) / ta.num_points_strand
 
     def update_learning_rate(self, iteration):
         for group in self.optimizer.param_groups:

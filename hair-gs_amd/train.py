@@ -163,9 +163,16 @@ class GraphedStep:
             group["capturable"] = True
             if not torch.is_tensor(group["lr"]):
                 group["lr"] = torch.tensor(float(group["lr"]), dtype=torch.float32, device=dev)
-        for st in opt_.state.values():
-            if "step" in st and torch.is_tensor(st["step"]) and not st["step"].is_cuda:
-                st["step"] = st["step"].to(dev)
+            for p in group["params"]:
+                st = opt_.state[p]
+                if len(st) == 0:
+                    # create the Adam state NOW (exactly what the first optimizer.step() would create): state created
+                    # lazily inside the capture would be re-zeroed by every replay
+                    st["step"] = torch.zeros((), dtype=torch.float32, device=p.device)
+                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                elif torch.is_tensor(st.get("step")) and not st["step"].is_cuda:
+                    st["step"] = st["step"].to(dev)
 
     def _set_lr(self, iteration):
         g = self.g
@@ -196,7 +203,8 @@ class GraphedStep:
         """Warm up eagerly on a side stream (allocator, lazy module loads, capacity), then capture."""
         g, raster = self.g, self.raster
         self._make_capturable()
-        s = torch.cuda.Stream()
+        saved_stats = (g.max_radii2D.clone(), g.xyz_gradient_accum.clone(), g.denom.clone())  # warm-up must not count
+        s = self._stream = torch.cuda.Stream()  # warm-up AND capture run on this stream (AccumulateGrad nodes are per stream)
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):
             for cam in warmup_cams:  # every view once: the capacity must cover the busiest camera
@@ -210,18 +218,20 @@ class GraphedStep:
         torch.cuda.synchronize()
         raster._state["pending"].clear()
         g.optimizer.zero_grad(set_to_none=True)
+        for dst, src in zip((g.max_radii2D, g.xyz_gradient_accum, g.denom), saved_stats):
+            dst.copy_(src)
         self.loss_buf = None
         if self.vp.world == 1:
             ga = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(ga):
+            with torch.cuda.graph(ga, stream=s):
                 self.loss_buf = self._forward_backward()
                 g.optimizer.step()
             self._graphs = (ga, None)
         else:
             ga, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-            with torch.cuda.graph(ga):
+            with torch.cuda.graph(ga, stream=s):
                 self.loss_buf = self._forward_backward()
-            with torch.cuda.graph(gb, pool=ga.pool()):
+            with torch.cuda.graph(gb, pool=ga.pool(), stream=s):
                 g.optimizer.step()
             self._graphs = (ga, gb)
         self._pending = list(raster._state["pending"])  # pinned status buffers the captured copies write into
