@@ -48,6 +48,20 @@ void hgs_prof_end(hipStream_t s) {
   g_prof_open = nullptr;
 }
 
+__global__ __launch_bounds__(256) void hgs_zero_kernel(uint32_t* __restrict__ p, size_t n_words) {
+  const size_t stride = (size_t)gridDim.x * 256;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n_words; i += stride) p[i] = 0u;
+}
+int hgs_zero_async(hipStream_t s, void* ptr, size_t bytes) {
+  if (bytes == 0) return 0;
+  if (((size_t)ptr & 3) || (bytes & 3)) { hgs_set_error("hgs_zero_async: pointer/size must be 4-byte multiples"); return 1; }
+  const size_t n = bytes / 4;
+  const unsigned blocks = (unsigned)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
+  hipLaunchKernelGGL(hgs_zero_kernel, dim3(blocks), dim3(256), 0, s, (uint32_t*)ptr, n);
+  HGS_CHECK_LAUNCH();
+  return 0;
+}
+
 static int check_aligned(const void* p, const char* what) {
   if (!p || ((size_t)p & (HGS_ALIGN - 1))) {
     hgs_set_error("%s must be a non-null %d-byte aligned device pointer", what, HGS_ALIGN);
@@ -85,9 +99,9 @@ int hgs_forward_preprocess(void* stream, int P, int D, int M, int W, int H, cons
   HgsImage im;
   hgs_image_carve((char*)image_buf, (size_t)W, (size_t)H, im, nullptr);
   const int T = ((W + HGS_TILE - 1) / HGS_TILE) * ((H + HGS_TILE - 1) / HGS_TILE);
-  HGS_CHECK_HIP(hipMemsetAsync(im.tile_count, 0, ((size_t)3 * T + HGS_STATUS_WORDS) * sizeof(uint32_t), s));
+  if (hgs_zero_async(s, im.tile_count, ((size_t)3 * T + HGS_STATUS_WORDS) * sizeof(uint32_t))) return 1;
   if (P == 0) {  // reference short-circuits P == 0 (rasterize_points.cu:81)
-    HGS_CHECK_HIP(hipMemsetAsync(im.ranges, 0, (size_t)T * sizeof(uint2), s));
+    if (hgs_zero_async(s, im.ranges, (size_t)T * sizeof(uint2))) return 1;
     if (num_rendered_host) { HGS_CHECK_HIP(hipStreamSynchronize(s)); *num_rendered_host = 0; }
     return 0;
   }
@@ -166,7 +180,7 @@ int hgs_backward(void* stream, int P, int D, int M, int R, int W, int H, const f
     if (check_aligned(binning_buf, "binning_buf") || check_aligned(scratch, "scratch")) return 1;
     hgs_binning_carve((char*)binning_buf, (size_t)R, b, nullptr);
     inst_grad = (float*)scratch;
-    HGS_CHECK_HIP(hipMemsetAsync(inst_grad, 0, (size_t)R * HGS_INST_GRAD_FLOATS * sizeof(float), s));
+    if (hgs_zero_async(s, inst_grad, (size_t)R * HGS_INST_GRAD_FLOATS * sizeof(float))) return 1;
     if (hgs_launch_blend_bwd(s, W, H, R, bg, im, b, dL_dpix, inst_grad)) return 1;
   }
   HgsBwdArgs a;

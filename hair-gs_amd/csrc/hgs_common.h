@@ -96,6 +96,10 @@ void hgs_set_error(const char* fmt, ...);
   } while (0)
 #define HGS_CHECK_LAUNCH() HGS_CHECK_HIP(hipGetLastError())
 
+// Zero-fill by a kernel instead of hipMemsetAsync: memset NODES of a captured HIP graph did not re-execute reliably
+// on replay (ROCm 7.2: stale tile counters on the second replay -> out-of-bounds); kernel nodes do.
+int hgs_zero_async(hipStream_t s, void* ptr, size_t bytes);
+
 // ---- optional per-kernel timing (hgs_api.hip) ---------------------------------------------------
 void hgs_prof_begin(hipStream_t s, int kernel_id);
 void hgs_prof_end(hipStream_t s);

@@ -118,7 +118,7 @@ int hgs_strand_geometry_backward(void* stream, int P, int E, const float* endpoi
                                  const float* g_quat, const float* g_dir, float* d_endpoints, float* d_width) {
   if (!d_endpoints || !d_width) { hgs_set_error("hgs_strand_geometry_backward: null output"); return 1; }
   hipStream_t s = (hipStream_t)stream;
-  HGS_CHECK_HIP(hipMemsetAsync(d_endpoints, 0, (size_t)E * 3 * sizeof(float), s));
+  if (hgs_zero_async(s, d_endpoints, (size_t)E * 3 * sizeof(float))) return 1;
   if (P == 0) return 0;
   {
     HgsProfScope _prof(s, HGS_K_STRAND_BWD);
