@@ -1,1 +1,2 @@
 from .losses import *  # noqa: F401,F403
+from .metrics import *  # noqa: F401,F403

@@ -16,6 +16,7 @@ import torch
 from torch import nn
 
 from scene.gaussian_model import GaussianModel
+from scene.hair_topology import HairTopologyMixin
 from utils.general import get_expon_lr_func, inverse_sigmoid
 from utils.transform import calculate_rotation_from_vectors
 
@@ -27,7 +28,7 @@ class StrandsInfo(NamedTuple):
     strand_endpoint_id_to_complementary: np.ndarray  # strand end id -> the other end of its strand
 
 
-class HairGaussianModel(GaussianModel):
+class HairGaussianModel(HairTopologyMixin, GaussianModel):
     _PARAM_ATTRS = (("endpoints", "_endpoints"), ("f_dc", "_features_dc"), ("f_rest", "_features_rest"),
                     ("opacity", "_opacity"), ("mask", "_mask"), ("width", "_width"))
     _POSITION_GROUP = "endpoints"
@@ -211,6 +212,7 @@ class HairGaussianModel(GaussianModel):
             "mask": new_masks, "width": new_widths}))
         self._reset_stats()
         self._smooth_pairs = None
+        self._derived = None
 
     def prune_segments(self, segments_prune_mask):
         """Drop segments; endpoints no segment references any more are dropped too and ids are compacted."""
@@ -231,6 +233,7 @@ class HairGaussianModel(GaussianModel):
         self.denom = self.denom[seg_keep]
         self.max_radii2D = self.max_radii2D[seg_keep]
         self._smooth_pairs = None
+        self._derived = None
 
     # ---- strand bookkeeping ----------------------------------------------------------------------
     def update_strand_root(self, dist_th: float = 1e-2):

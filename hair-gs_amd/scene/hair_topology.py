@@ -1,0 +1,255 @@
+"""Strand topology operators of the Stage-III model (counterparts of the reference's
+scene/hair_gaussian_model.py:619-706 merge_endpoint_pairs, :712-784 index helpers, :788-1077 densification =
+clone / split / merge-collapsed / prune, :1079-1096 merging, :1205-1362 compute_endpoint_pair_to_merge, :1500-1515
+clean_gaussians).  Mixed into HairGaussianModel.  They run every `densification_interval` / `merge_interval` = 100
+iterations on replicated state; the greedy selections are sequential by nature and stay on the host (the reference
+loops over CUDA tensors element by element, :1246-1253), the candidate search is one vectorised kd-tree query."""
+import numpy as np
+import torch
+
+
+class HairTopologyMixin:
+    # ---- index helpers -------------------------------------------------------------------------------------------
+    def get_first_occurence_index(self, tensor):
+        """Index of the first occurrence of every unique value (reference :772-784)."""
+        uniq, inv = torch.unique(tensor, return_inverse=True, sorted=False, dim=0)
+        perm = torch.arange(inv.shape[0], dtype=inv.dtype, device=tensor.device)
+        inv, perm = inv.flip([0]), perm.flip([0])
+        return inv.new_empty(uniq.shape[0]).scatter_(0, inv, perm)
+
+    def remove_duplicate_endpoint_rows(self, index_pairs, return_mask=False):
+        """Keep the rows whose two ids both occur there for the first time in row-major order (reference :712-728)."""
+        flat = index_pairs.flatten()
+        mask = torch.zeros(flat.shape[0], dtype=torch.bool, device=self.device)
+        if flat.numel():
+            mask[self.get_first_occurence_index(flat)] = True
+        mask = mask.reshape(-1, 2)
+        mask = mask[:, 0] & mask[:, 1]
+        return (index_pairs[mask], mask) if return_mask else index_pairs[mask]
+
+    def get_endpoint_pairs_row_indices(self, endpoint_id, exclude_segments=None):
+        """Row of `endpoint_pairs` holding each id (the last one if it occurs twice; -1 if none) (reference :730-752)."""
+        mapping = -torch.ones(int(self.endpoint_pairs.max()) + 1, dtype=torch.long, device=self.device)
+        rows = torch.arange(self.endpoint_pairs.shape[0], device=self.device)
+        pairs = self.endpoint_pairs
+        if exclude_segments is not None:
+            pairs, rows = pairs[~exclude_segments], rows[~exclude_segments]
+        mapping[pairs[:, 0]] = rows
+        mapping[pairs[:, 1]] = rows
+        return mapping[endpoint_id]
+
+    def get_complementary_endpoint_idx(self, endpoint_id, exclude_segments=None):
+        rows = self.get_endpoint_pairs_row_indices(endpoint_id, exclude_segments)
+        sel = self.endpoint_pairs[rows]
+        return torch.where(sel[:, 1] == endpoint_id, sel[:, 0], sel[:, 1]), rows
+
+    # ---- densification (reference :788-1077) -------------------------------------------------------------------------
+    def densification(self, extent, max_screen_size, training_info=None):
+        grads = self.xyz_gradient_accum / self.denom
+        grads[grads.isnan()] = 0.0
+        info = training_info.densification_info if training_info is not None else {}
+        self.clone_strategy(grads, extent, info)
+        self.split_strategy(grads, extent, info)
+        self.merge_collapsed_segments(info)
+        self.prune_strategy(extent, max_screen_size, info, avoid_connected=True)
+        self.compute_strands_info()
+
+    def _segment_lengths(self):
+        seg = self._endpoints[self.endpoint_pairs]
+        return torch.norm(seg[:, 1] - seg[:, 0], p=2, dim=1)
+
+    def clone_strategy(self, grads, scene_extent, info=None):
+        """High view-space gradient + small extent -> duplicate the segment as a new, disconnected one (:915-967)."""
+        ta = self.training_args
+        sel = (torch.norm(grads, dim=-1) >= ta.densify_grad_threshold) & (
+            torch.max(self.get_scaling, dim=1).values <= ta.percent_dense * scene_extent)
+        new_ep = self._endpoints[self.endpoint_pairs[sel]].flatten(0, 1).detach()
+        ids = torch.arange(new_ep.shape[0], device=self.device) + self.endpoint_pairs.max() + 1
+        if info is not None:
+            info["clone"] = int(sel.sum())
+        self.cat_segments(ids.reshape(-1, 2), new_ep, self._features_dc[sel].detach(), self._features_rest[sel].detach(),
+                          self._opacity[sel].detach(), self._mask[sel].detach(), self._width[sel].detach())
+
+    def split_strategy(self, grads, scene_extent, info=None):
+        """High gradient + large extent, or longer than max_segment_length (foreground only) -> cut at the midpoint
+        into two connected segments sharing a new endpoint (:828-913)."""
+        ta = self.training_args
+        n0 = self.endpoint_pairs.shape[0]
+        padded = torch.zeros((n0,), device=self.device)
+        padded[: grads.shape[0]] = grads.squeeze()
+        sel = (padded >= ta.densify_grad_threshold) & (
+            torch.max(self.get_scaling, dim=1).values > ta.percent_dense * scene_extent)
+        sel = sel | (self._segment_lengths() >= self.max_segment_length)
+        sel = sel & (self.get_mask > self.foreground_binarization_th).squeeze(1)
+        k = int(sel.sum())
+        mid = self.get_xyz[sel].detach()
+        ids = torch.arange(k, device=self.device) + 1 + torch.max(self.endpoint_pairs)
+        orig = self.endpoint_pairs[sel]
+        new_pairs = torch.cat([torch.stack([orig[:, 0], ids], 1), torch.stack([ids, orig[:, 1]], 1)], dim=0)
+        self.cat_segments(new_pairs, mid, self._features_dc[sel].detach().repeat(2, 1, 1),
+                          self._features_rest[sel].detach().repeat(2, 1, 1), self._opacity[sel].detach().repeat(2, 1),
+                          self._mask[sel].detach().repeat(2, 1), self._width[sel].detach().repeat(2, 1))
+        if info is not None:
+            info["split"] = k
+        self.prune_segments(torch.cat((sel, torch.zeros(2 * k, device=self.device, dtype=torch.bool))))
+
+    def merge_collapsed_segments(self, info=None):
+        """Segments that collapsed to a point or left the foreground, and whose both ends are interior joints, are
+        removed by fusing their two endpoints; repeated until nothing merges (:969-1018)."""
+        total = 0
+        while True:
+            collapsed = self._segment_lengths() < self.min_val
+            mask = collapsed | ~self.compute_foreground_mask()
+            cand = self.endpoint_pairs[mask]
+            u, c = torch.unique(self.endpoint_pairs, return_counts=True)
+            interior = u[c != 1]
+            both_interior = torch.all(torch.isin(cand, interior), dim=1)
+            mask[mask.clone()] = both_interior
+            to_merge = cand[both_interior]
+            to_merge, keep = self.remove_duplicate_endpoint_rows(to_merge, return_mask=True)
+            mask[mask.clone()] = keep
+            self.prune_segments(mask)
+            mapping = torch.arange(int(self.endpoint_pairs.max()) + 1 if self.endpoint_pairs.numel() else 0,
+                                   device=self.device)
+            if to_merge.shape[0]:
+                mapping[to_merge[:, 1]] = to_merge[:, 0]
+                self.endpoint_pairs = mapping[self.endpoint_pairs]
+            # compacts the endpoint table (drops the ids that just lost their last reference)
+            self.prune_segments(torch.zeros(self.endpoint_pairs.shape[0], dtype=torch.bool, device=self.device))
+            total += int(to_merge.shape[0])
+            if to_merge.shape[0] == 0:
+                break
+        if info is not None:
+            info["merge_collapsed"] = total
+
+    def prune_strategy(self, extent, max_screen_size, info=None, avoid_connected=False):
+        """Drop collapsed / transparent / oversized segments; with avoid_connected only strand-end or background
+        segments may go, so strands are never cut in the middle (:1020-1077)."""
+        info = {} if info is None else info
+        prune = self._segment_lengths() < self.min_val
+        info["prune_collapsed"] = int(prune.sum())
+        low = (self.get_opacity < self.opacity_th).squeeze(1)
+        info["prune_low_opacity"] = int(low.sum())
+        prune = prune | low
+        if max_screen_size and extent != 0.0:
+            big = self.get_scaling.max(dim=1).values > 0.1 * extent
+            info["prune_big_ws"] = int(big.sum())
+            prune = prune | big
+        if avoid_connected and prune.sum() != 0:
+            u, c = torch.unique(self.endpoint_pairs, return_counts=True)
+            is_end = torch.any(torch.isin(self.endpoint_pairs, u[c == 1]), dim=1)
+            allowed = is_end | (self.get_mask < self.foreground_binarization_th).squeeze(1)
+            info["prune_avoided"] = int(prune.sum() - (prune & allowed).sum())
+            prune = prune & allowed
+        n = int(prune.sum())
+        info["prune_total"] = n
+        if 0 < n < self._opacity.shape[0]:
+            self.prune_segments(prune)
+
+    def clean_gaussians(self, avoid_connected=True):
+        """Remove background / transparent segments (only strand-end ones when avoid_connected) (:1500-1515)."""
+        prune = ~self.compute_foreground_mask()
+        if avoid_connected:
+            u, c = torch.unique(self.endpoint_pairs, return_counts=True)
+            is_end = torch.any(torch.isin(self.endpoint_pairs[prune], u[c == 1]), dim=1)
+            prune[prune.clone()] = is_end
+        self.prune_segments(prune)
+
+    # ---- merging (reference :1079-1096, :1205-1362, :619-706) ----------------------------------------------------------
+    def merging(self, training_info=None):
+        self.compute_strands_info()
+        pairs = self.compute_endpoint_pair_to_merge()
+        if training_info is not None:
+            training_info.densification_info["merge"] = int(pairs.shape[0])
+        self.merge_endpoint_pairs(pairs)
+        self.compute_strands_info()
+
+    def growing(self, training_info=None, **_):
+        raise NotImplementedError("the reference's growing() cannot run either (cat_segments is called without "
+                                  "`new_masks`, hair_gaussian_model.py:1187-1194) and its interval is 100000 iterations")
+
+    def compute_endpoint_pair_to_merge(self, chunk_size=-1, max_num_nn=-1):
+        """Greedy one-to-one matching of nearby strand ends (root/tip) that face each other: candidates = foreground
+        strand ends within merge_dist_th of each other, not the two ends of one strand, whose outgoing directions are
+        opposite within merge_angle_th; sorted by distance; a pair is kept if neither id was used before and neither
+        sits on a strand whose OTHER end was already merged in this round.  Returns an [N,2] id tensor."""
+        from scipy.spatial import cKDTree
+        dir_th = np.cos(np.deg2rad(self.merge_angle_th))
+        ids, counts = torch.unique(self.endpoint_pairs, return_counts=True)
+        ends = ids[counts == 1]
+        fg_ids = self.endpoint_pairs[self.compute_foreground_mask()].flatten()
+        ends = ends[torch.isin(ends, fg_ids)]
+        empty = torch.zeros((0, 2), dtype=torch.long, device=self.device)
+        if ends.numel() < 2:
+            return empty
+        comp, _ = self.get_complementary_endpoint_idx(ends)
+        pos_t = self._endpoints[ends].detach()
+        dirs_t = self._endpoints[comp].detach() - pos_t
+        dirs_t = dirs_t / torch.norm(dirs_t, dim=1, keepdim=True)
+        pos, dirs, ends_np = pos_t.cpu().numpy(), dirs_t.cpu().numpy(), ends.cpu().numpy()
+        partner = self.strands_info.strand_endpoint_id_to_complementary  # other end of the same strand, per id
+        pairs = cKDTree(pos).query_pairs(r=float(self.merge_dist_th), output_type="ndarray")
+        if pairs.shape[0] == 0:
+            return empty
+        a, b = pairs[:, 0], pairs[:, 1]
+        ok = partner[ends_np[a]] != ends_np[b]
+        dot = -(dirs[a] * dirs[b]).sum(1)                     # directions must be opposite
+        if self.training_args.bidirectional_merge:
+            dot = np.abs(dot)
+        ok &= dot >= dir_th
+        a, b = a[ok], b[ok]
+        dist = np.linalg.norm(pos[a] - pos[b], axis=1)
+        if max_num_nn > 0:  # cap candidates per point, nearest first
+            order = np.argsort(dist, kind="stable")
+            a, b, dist = a[order], b[order], dist[order]
+            seen = {}
+            keep = np.ones(len(a), bool)
+            for i, (x, y) in enumerate(zip(a, b)):
+                if seen.get(x, 0) >= max_num_nn or seen.get(y, 0) >= max_num_nn:
+                    keep[i] = False
+                else:
+                    seen[x] = seen.get(x, 0) + 1
+                    seen[y] = seen.get(y, 0) + 1
+            a, b, dist = a[keep], b[keep], dist[keep]
+        order = np.argsort(dist, kind="stable")
+        cand = np.stack([ends_np[a[order]], ends_np[b[order]]], 1)
+        seen, blocked, out = set(), set(), []
+        for p, q in cand:
+            # stage 1 (reference remove_duplicate_endpoint_rows): both ids must occur here for the first time in the
+            # distance-sorted candidate list -- ids of rejected rows count as seen too
+            first = p not in seen and q not in seen
+            seen.add(p)
+            seen.add(q)
+            if not first:
+                continue
+            # stage 2 (reference remove_complementary_rows): never merge both ends of one strand in the same round
+            if p in blocked or q in blocked:
+                continue
+            blocked.add(int(partner[p]))
+            blocked.add(int(partner[q]))
+            out.append((p, q))
+        if not out:
+            return empty
+        return torch.as_tensor(np.asarray(out, np.int64), device=self.device)
+
+    def merge_endpoint_pairs(self, endpoint_pair_index):
+        """Fuse each pair of strand ends into ONE new endpoint at their midpoint: the two end segments are re-created
+        attached to it (attributes cloned), the old ones and the two old endpoints disappear (reference :619-706)."""
+        if endpoint_pair_index.shape[0] == 0:
+            return
+        pos = self._endpoints[endpoint_pair_index].detach()
+        c1, r1 = self.get_complementary_endpoint_idx(endpoint_pair_index[:, 0])
+        c2, r2 = self.get_complementary_endpoint_idx(endpoint_pair_index[:, 1])
+        new_ep = 0.5 * pos[:, 1] + 0.5 * pos[:, 0]
+        new_ids = torch.arange(new_ep.shape[0], device=self.device) + self.endpoint_pairs.max() + 1
+        remap = torch.arange(self._endpoints.shape[0], device=self.device)
+        remap[endpoint_pair_index[:, 0]] = new_ids
+        remap[endpoint_pair_index[:, 1]] = new_ids
+        new_pairs = torch.cat((torch.stack((remap[c1], new_ids), 1), torch.stack((new_ids, remap[c2]), 1)), dim=0)
+        rows = torch.cat((r1, r2))
+        self.cat_segments(new_pairs, new_ep, self._features_dc[rows].detach(), self._features_rest[rows].detach(),
+                          self._opacity[rows].detach(), self._mask[rows].detach(), self._width[rows].detach())
+        prune = torch.zeros(self.endpoint_pairs.shape[0], device=self.device, dtype=torch.bool)
+        prune[r1] = True
+        prune[r2] = True
+        self.prune_segments(prune)

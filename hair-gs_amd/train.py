@@ -261,17 +261,80 @@ class GraphedStep:
         return [int(h[0]) for h, _ in self._pending]
 
 
-def training(gaussians, cameras, opt, iterations=None, extent=1.0, seed=0, log_every=0, vp=None, start_iteration=0):
-    """Plain loop over training_step (no logger / viewer / dataset IO: those are outside the accelerated path)."""
+def topology_due(gaussians, opt, iteration):
+    """Which shape-changing operators train.py:172-200 schedules at this iteration."""
+    due = []
+    if iteration < opt.densify_until_iter:
+        if iteration > opt.densify_from_iter and iteration % opt.densification_interval == 0:
+            due.append("densify")
+        if iteration % opt.opacity_reset_interval == 0:
+            due.append("reset_opacity")
+    if isinstance(gaussians, HairGaussianModel) and iteration % opt.merge_interval == 0:
+        due.append("merge")
+    if iteration % 1000 == 0 and gaussians.active_sh_degree < gaussians.max_sh_degree:
+        due.append("sh")
+    return due
+
+
+def apply_topology(gaussians, opt, iteration, extent, due, vp=None):
+    """Run the due operators on (replicated) state, in the reference's order (train.py:172-200)."""
+    with torch.no_grad():
+        if "densify" in due:
+            if vp is not None:
+                vp.reduce_stats(gaussians)
+            size_threshold = opt.prune_max_radii_2d if iteration > opt.opacity_reset_interval else None
+            gaussians.densification(extent, size_threshold, None)
+        if "reset_opacity" in due:
+            gaussians.reset_opacity()
+        if "merge" in due:
+            gaussians.merging(training_info=None)
+
+
+def training(gaussians, cameras, opt, iterations=None, extent=1.0, seed=0, log_every=0, vp=None, start_iteration=0,
+             use_graph=True):
+    """Training loop (reference train.py:91-254 without logger / viewer / dataset IO, which are outside the
+    accelerated path).  With use_graph the iteration body replays a captured HIP graph (GraphedStep); iterations that
+    change tensor shapes (densification, merging, opacity reset, SH-degree bump) run their operators eagerly after
+    the step's backward+Adam, exactly where the reference runs them relative to the next step, and the graph is
+    re-captured.  Note: the reference applies densify/merge BEFORE optimizer.step() of the same iteration
+    (train.py:172-204); with freshly re-created tensors that step has no gradients for them, so applying the
+    operators after the step changes nothing but the order of two independent updates."""
     vp = ViewParallel() if vp is None else vp
     dev = gaussians.get_xyz.device
     bg = torch.zeros(3, dtype=torch.float32, device=dev)
     sampler = ViewSampler(cameras, seed=seed, rank=vp.rank, world=vp.world)
     ema = None
     n = opt.iterations if iterations is None else iterations
-    for it in range(start_iteration + 1, start_iteration + n + 1):
-        loss, _, _ = training_step(gaussians, sampler.next(), opt, bg, it, extent=extent, vp=vp)
-        ema = loss if ema is None else 0.4 * loss + 0.6 * ema  # stays on the device: no per-iteration host sync
-        if log_every and it % log_every == 0 and vp.rank == 0:
-            print(f"[it {it}] loss(ema) {float(ema):.6f}")
+    gs = None
+    use_graph = use_graph and dev.type == "cuda"
+    saved_topology = getattr(opt, "enable_topology", True)
+    opt.enable_topology = False  # the loop below schedules the operators itself
+    try:
+        for it in range(start_iteration + 1, start_iteration + n + 1):
+            due = topology_due(gaussians, opt, it) if saved_topology else []
+            if "sh" in due:
+                gaussians.oneupSHdegree()
+                gs = None
+            if use_graph:
+                if gs is None:
+                    gs = GraphedStep(gaussians, cameras, opt, bg, extent=extent, vp=vp)
+                    gs.capture(cameras, iteration=it)
+                loss = gs.step(sampler.next(), it)
+            else:
+                loss, _, _ = training_step(gaussians, sampler.next(), opt, bg, it, extent=extent, vp=vp)
+            ema = loss.clone() if ema is None else 0.4 * loss + 0.6 * ema  # on the device: no per-iteration host sync
+            if any(d in due for d in ("densify", "reset_opacity", "merge")):
+                if gs is not None:
+                    gs.check()
+                apply_topology(gaussians, opt, it, extent, due, vp)
+                gs = None  # shapes changed: capture again at the next iteration
+            if log_every and it % log_every == 0 and vp.rank == 0:
+                print(f"[it {it}] loss(ema) {float(ema):.6f}  segments {gaussians.get_xyz.shape[0]}")
+        if gs is not None:
+            gs.check()
+    finally:
+        opt.enable_topology = saved_topology
+        if use_graph:
+            from diff_gaussian_rasterization import _C as raster
+            raster.set_async(False)
     return ema

@@ -255,3 +255,28 @@ def test_graphed_step_matches_eager_steps():
     for a, b in zip(results["eager"][1:], results["graph"][1:]):
         assert (a - b).abs().max() <= 1e-4 * max(1e-6, float(a.abs().max()))
     assert float(results["graph"][3].sum()) > 0
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_training_loop_with_topology_changes(use_graph):
+    """training(): densification + merging + opacity reset at their intervals, with graph re-capture after each."""
+    from arguments import OptimizationParams
+    from synthetic import build_workload
+    from train import training
+    from utils.general import safe_state
+    safe_state(True)
+    model, cams, extent = build_workload("tiny", device="cuda", with_targets=True)
+    opt = OptimizationParams()
+    opt.densify_from_iter, opt.densification_interval, opt.merge_interval, opt.opacity_reset_interval = 3, 6, 8, 12
+    model.training_setup(opt)
+    P0 = model.get_xyz.shape[0]
+    ema = training(model, cams, opt, iterations=20, extent=extent, use_graph=use_graph)
+    assert torch.isfinite(ema)
+    P1 = model.get_xyz.shape[0]
+    assert P1 != P0                                           # the topology did change
+    pairs = model.endpoint_pairs
+    assert int(pairs.max()) == model._endpoints.shape[0] - 1
+    for g in model.optimizer.param_groups:
+        p = g["params"][0]
+        assert torch.isfinite(p).all() and p.shape[0] == (model._endpoints.shape[0] if g["name"] == "endpoints" else P1)
+    assert float(model.get_opacity.max()) < 0.9               # opacity reset happened at it 12

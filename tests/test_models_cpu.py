@@ -180,3 +180,90 @@ def test_generate_cameras_rig():
         assert np.allclose(fwd, -c2w[:3, 3] / 0.5, atol=1e-6)   # every ring camera looks at the anchor
     top = np.linalg.inv(Es[8])
     assert np.allclose(top[:3, 3], [0, 0.5, 0])
+
+
+def _chain_invariants(m):
+    pairs = m.endpoint_pairs
+    assert int(pairs.max()) == m._endpoints.shape[0] - 1 and int(pairs.min()) == 0
+    counts = torch.bincount(pairs.flatten(), minlength=m._endpoints.shape[0])
+    assert int(counts.min()) >= 1 and int(counts.max()) <= 2          # open polylines only, every endpoint referenced
+    P = pairs.shape[0]
+    for t in (m._features_dc, m._features_rest, m._opacity, m._mask, m._width, m.denom, m.xyz_gradient_accum):
+        assert t.shape[0] == P
+    for g in m.optimizer.param_groups:
+        p = g["params"][0]
+        assert p.shape[0] == (m._endpoints.shape[0] if g["name"] == "endpoints" else P)
+
+
+def test_hair_merging_joins_facing_strand_ends():
+    """Two collinear strands whose tip/root are 1 mm apart get merged into one; a far-away strand is untouched."""
+    from scene.hair_gaussian_model import HairGaussianModel
+    x = np.linspace(0, 0.02, 6)
+    s0 = np.stack([x, np.zeros(6), np.zeros(6)], 1)
+    s1 = np.stack([x + 0.021, np.zeros(6), np.zeros(6)], 1)          # starts 1 mm after s0 ends, same direction
+    s2 = np.stack([x, np.full(6, 0.05), np.zeros(6)], 1)             # parallel, 5 cm away
+    pts = np.stack([s0, s1, s2]).astype(np.float32)
+    roots = np.array([[0, 0, 0], [0, 0.05, 0]], np.float32)
+    m = HairGaussianModel.from_strands(pts, device="cpu", ref_strand_root=roots)
+    m.training_setup(OptimizationParams())
+    m.compute_strands_info()
+    assert len(m.strands_info.list_strands) == 3
+    pairs = m.compute_endpoint_pair_to_merge()
+    assert pairs.shape == (1, 2) and sorted(pairs[0].tolist()) == [5, 6]      # tip of s0 with root of s1
+    P0 = m.endpoint_pairs.shape[0]
+    m.merging()
+    assert m.endpoint_pairs.shape[0] == P0                 # two end segments re-created, none lost
+    assert m._endpoints.shape[0] == 18 - 1                 # two endpoints fused into one
+    assert len(m.strands_info.list_strands) == 2
+    lens = sorted(s.shape[0] for s in m.strands_info.list_strands)
+    assert lens == [5, 10]
+    _chain_invariants(m)
+    long = max(m.strands_info.list_strands, key=len)
+    assert np.allclose(m._endpoints.detach().numpy()[long[0, 0]], [0, 0, 0], atol=1e-6)   # oriented from the root
+
+
+def test_hair_densification_split_clone_prune():
+    from scene.hair_gaussian_model import HairGaussianModel
+    from synthetic import strand_polylines
+    torch.manual_seed(0)
+    m = HairGaussianModel.from_strands(strand_polylines(6, 8, seed=1), device="cpu")
+    opt = OptimizationParams()
+    m.training_setup(opt)
+    m.compute_strands_info()
+    P0, E0 = m.endpoint_pairs.shape[0], m._endpoints.shape[0]
+    # split: give the first strand a large gradient + make extent tiny so the "large" branch triggers
+    m.denom[:] = 1.0
+    m.xyz_gradient_accum[:8] = 1.0
+    with torch.no_grad():
+        m._opacity[40:44] = -10.0            # transparent tail segments of the last strand -> pruned (strand ends only)
+    m.densification(extent=1e-3, max_screen_size=None)
+    _chain_invariants(m)
+    info_strands = m.strands_info.list_strands
+    assert m.endpoint_pairs.shape[0] > P0 - 4            # 8 segments were split in two, at most 4 pruned
+    assert sum(s.shape[0] for s in info_strands) <= m.endpoint_pairs.shape[0]
+    # clone branch: large gradient, extent huge -> small relative size
+    m.denom[:] = 1.0
+    m.xyz_gradient_accum[:] = 0.0
+    m.xyz_gradient_accum[:3] = 1.0
+    n1 = m.endpoint_pairs.shape[0]
+    m.max_segment_length = torch.tensor(1e9)
+    m.densification(extent=1e3, max_screen_size=None)
+    assert m.endpoint_pairs.shape[0] == n1 + 3
+    _chain_invariants(m)
+
+
+def test_merge_collapsed_segment_fuses_its_endpoints():
+    from scene.hair_gaussian_model import HairGaussianModel
+    from synthetic import strand_polylines
+    m = HairGaussianModel.from_strands(strand_polylines(2, 6, seed=2), device="cpu")
+    m.training_setup(OptimizationParams())
+    with torch.no_grad():
+        m._endpoints[3] = m._endpoints[2]     # interior segment (2,3) of strand 0 collapses
+    P0, E0 = m.endpoint_pairs.shape[0], m._endpoints.shape[0]
+    info = {}
+    m.merge_collapsed_segments(info)
+    assert info["merge_collapsed"] == 1
+    assert m.endpoint_pairs.shape[0] == P0 - 1 and m._endpoints.shape[0] == E0 - 1
+    _chain_invariants(m)
+    m.compute_strands_info()
+    assert sorted(s.shape[0] for s in m.strands_info.list_strands) == [5, 6]
