@@ -131,11 +131,15 @@ int hgs_forward_preprocess(void* stream, int P, int D, int M, int W, int H, cons
   return 0;
 }
 
-int hgs_forward_render(void* stream, int P, int W, int H, int R_capacity, const float* bg, const float* colors_precomp,
-                       void* geom_buf, void* binning_buf, void* image_buf, float* out_color) {
+static int forward_render_impl(void* stream, int P, int W, int H, int R_capacity, const float* bg,
+                               const float* colors_precomp, const float* extra, int n_extra, void* geom_buf,
+                               void* binning_buf, void* image_buf, float* out_color) {
   hipStream_t s = (hipStream_t)stream;
   if (check_aligned(image_buf, "image_buf")) return 1;
   if (!bg || !out_color) { hgs_set_error("null bg/out_color"); return 1; }
+  if (n_extra != 0 && n_extra != 4) { hgs_set_error("n_extra must be 0 or 4 (got %d)", n_extra); return 1; }
+  if (n_extra && P > 0 && (!extra || ((size_t)extra & 15))) { hgs_set_error("extra colours must be a 16-byte aligned [P,4] array"); return 1; }
+  const int channels = 3 + n_extra;
   HgsImage im;
   hgs_image_carve((char*)image_buf, (size_t)W, (size_t)H, im, nullptr);
   HgsGeom g = {};
@@ -145,31 +149,52 @@ int hgs_forward_render(void* stream, int P, int W, int H, int R_capacity, const 
     hgs_geom_carve((char*)geom_buf, (size_t)P, g, nullptr);
     if (R_capacity > 0) {
       if (check_aligned(binning_buf, "binning_buf")) return 1;
-      hgs_binning_carve((char*)binning_buf, (size_t)R_capacity, b, nullptr);
+      hgs_binning_carve((char*)binning_buf, (size_t)R_capacity, b, nullptr, channels);
     }
     // the scatter also finishes the per-Gaussian instance offsets, so it runs even when nothing is visible
     if (hgs_launch_scatter(s, P, W, H, R_capacity > 0 ? R_capacity : 0, nullptr, g, im, b)) return 1;
     if (R_capacity > 0) {
       const float* feat = colors_precomp ? colors_precomp : g.rgb;
-      if (hgs_launch_sort_tiles(s, W, H, R_capacity, feat, g, im, b)) return 1;
+      if (hgs_launch_sort_tiles(s, W, H, R_capacity, feat, extra, n_extra, g, im, b)) return 1;
     }
   }
-  return hgs_launch_blend_fwd(s, W, H, R_capacity > 0 ? R_capacity : 0, bg, im, b, out_color);
+  return hgs_launch_blend_fwd(s, W, H, R_capacity > 0 ? R_capacity : 0, channels, bg, im, b, out_color);
 }
 
-int hgs_backward(void* stream, int P, int D, int M, int R, int W, int H, const float* bg, const float* means3D,
-                 const float* shs, const float* colors_precomp, const float* scales, float scale_modifier,
-                 const float* rotations, const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix,
-                 const float* campos, float tan_fovx, float tan_fovy, const int* radii, const void* geom_buf,
-                 const void* binning_buf, const void* image_buf, const float* dL_dpix, void* scratch,
-                 float* dL_dmeans2D, float* dL_dconic, float* dL_dopacity, float* dL_dcolors, float* dL_dmeans3D,
-                 float* dL_dcov3D, float* dL_dsh, float* dL_dscales, float* dL_drotations) {
+int hgs_forward_render(void* stream, int P, int W, int H, int R_capacity, const float* bg, const float* colors_precomp,
+                       void* geom_buf, void* binning_buf, void* image_buf, float* out_color) {
+  return forward_render_impl(stream, P, W, H, R_capacity, bg, colors_precomp, nullptr, 0, geom_buf, binning_buf,
+                             image_buf, out_color);
+}
+
+int hgs_forward_render_multi(void* stream, int P, int W, int H, int R_capacity, const float* bg7,
+                             const float* colors_precomp, const float* extra4, void* geom_buf, void* binning_buf,
+                             void* image_buf, float* out_color7) {
+  return forward_render_impl(stream, P, W, H, R_capacity, bg7, colors_precomp, extra4, 4, geom_buf, binning_buf,
+                             image_buf, out_color7);
+}
+
+size_t hgs_binning_bytes_multi(int R) { HgsBinning b; return hgs_binning_carve(nullptr, (size_t)(R > 0 ? R : 0), b, nullptr, 7); }
+size_t hgs_backward_scratch_bytes_multi(int P, int R) {
+  (void)P;
+  return hgs_align_up((size_t)(R > 0 ? R : 0) * 16 * sizeof(float)) + HGS_ALIGN;
+}
+
+static int backward_impl(void* stream, int P, int D, int M, int R, int W, int H, const float* bg, const float* means3D,
+                         const float* shs, const float* colors_precomp, const float* scales, float scale_modifier,
+                         const float* rotations, const float* cov3D_precomp, const float* viewmatrix,
+                         const float* projmatrix, const float* campos, float tan_fovx, float tan_fovy, const int* radii,
+                         const void* geom_buf, const void* binning_buf, const void* image_buf, const float* dL_dpix,
+                         void* scratch, int n_extra, float* dL_dextra, float* dL_dmeans2D, float* dL_dconic,
+                         float* dL_dopacity, float* dL_dcolors, float* dL_dmeans3D, float* dL_dcov3D, float* dL_dsh,
+                         float* dL_dscales, float* dL_drotations) {
   hipStream_t s = (hipStream_t)stream;
   if (P == 0) return 0;  // rasterize_points.cu:161
   if (check_aligned(geom_buf, "geom_buf") || check_aligned(image_buf, "image_buf")) return 1;
   if (!dL_dpix || !radii || !means3D) { hgs_set_error("null required input"); return 1; }
   if (!dL_dmeans2D || !dL_dconic || !dL_dopacity || !dL_dcolors || !dL_dmeans3D || !dL_dcov3D || !dL_dscales ||
-      !dL_drotations || (shs && !dL_dsh)) { hgs_set_error("null gradient output"); return 1; }
+      !dL_drotations || (shs && !dL_dsh) || (n_extra && !dL_dextra)) { hgs_set_error("null gradient output"); return 1; }
+  const int channels = 3 + n_extra, row = n_extra ? 16 : HGS_INST_GRAD_FLOATS;
   HgsGeom g;
   HgsImage im;
   HgsBinning b = {};
@@ -178,10 +203,10 @@ int hgs_backward(void* stream, int P, int D, int M, int R, int W, int H, const f
   float* inst_grad = nullptr;
   if (R > 0) {
     if (check_aligned(binning_buf, "binning_buf") || check_aligned(scratch, "scratch")) return 1;
-    hgs_binning_carve((char*)binning_buf, (size_t)R, b, nullptr);
+    hgs_binning_carve((char*)binning_buf, (size_t)R, b, nullptr, channels);
     inst_grad = (float*)scratch;
-    if (hgs_zero_async(s, inst_grad, (size_t)R * HGS_INST_GRAD_FLOATS * sizeof(float))) return 1;
-    if (hgs_launch_blend_bwd(s, W, H, R, bg, im, b, dL_dpix, inst_grad)) return 1;
+    if (hgs_zero_async(s, inst_grad, (size_t)R * row * sizeof(float))) return 1;
+    if (hgs_launch_blend_bwd(s, W, H, R, channels, bg, im, b, dL_dpix, inst_grad)) return 1;
   }
   HgsBwdArgs a;
   a.P = P; a.D = D; a.M = M; a.W = W; a.H = H;
@@ -191,7 +216,35 @@ int hgs_backward(void* stream, int P, int D, int M, int R, int W, int H, const f
   a.dL_dmeans2D = dL_dmeans2D; a.dL_dconic = dL_dconic; a.dL_dopacity = dL_dopacity; a.dL_dcolors = dL_dcolors;
   a.dL_dmeans3D = dL_dmeans3D; a.dL_dcov3D = dL_dcov3D; a.dL_dsh = dL_dsh; a.dL_dscales = dL_dscales;
   a.dL_drotations = dL_drotations;
+  a.n_extra = n_extra; a.dL_dextra = dL_dextra;
   return hgs_launch_preprocess_bwd(s, a, g, b, inst_grad, R);
+}
+
+int hgs_backward(void* stream, int P, int D, int M, int R, int W, int H, const float* bg, const float* means3D,
+                 const float* shs, const float* colors_precomp, const float* scales, float scale_modifier,
+                 const float* rotations, const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix,
+                 const float* campos, float tan_fovx, float tan_fovy, const int* radii, const void* geom_buf,
+                 const void* binning_buf, const void* image_buf, const float* dL_dpix, void* scratch,
+                 float* dL_dmeans2D, float* dL_dconic, float* dL_dopacity, float* dL_dcolors, float* dL_dmeans3D,
+                 float* dL_dcov3D, float* dL_dsh, float* dL_dscales, float* dL_drotations) {
+  return backward_impl(stream, P, D, M, R, W, H, bg, means3D, shs, colors_precomp, scales, scale_modifier, rotations,
+                       cov3D_precomp, viewmatrix, projmatrix, campos, tan_fovx, tan_fovy, radii, geom_buf, binning_buf,
+                       image_buf, dL_dpix, scratch, 0, nullptr, dL_dmeans2D, dL_dconic, dL_dopacity, dL_dcolors,
+                       dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations);
+}
+
+int hgs_backward_multi(void* stream, int P, int D, int M, int R, int W, int H, const float* bg7, const float* means3D,
+                       const float* shs, const float* colors_precomp, const float* scales, float scale_modifier,
+                       const float* rotations, const float* cov3D_precomp, const float* viewmatrix,
+                       const float* projmatrix, const float* campos, float tan_fovx, float tan_fovy, const int* radii,
+                       const void* geom_buf, const void* binning_buf, const void* image_buf, const float* dL_dpix7,
+                       void* scratch, float* dL_dextra4, float* dL_dmeans2D_rgb, float* dL_dconic, float* dL_dopacity,
+                       float* dL_dcolors, float* dL_dmeans3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscales,
+                       float* dL_drotations) {
+  return backward_impl(stream, P, D, M, R, W, H, bg7, means3D, shs, colors_precomp, scales, scale_modifier, rotations,
+                       cov3D_precomp, viewmatrix, projmatrix, campos, tan_fovx, tan_fovy, radii, geom_buf, binning_buf,
+                       image_buf, dL_dpix7, scratch, 4, dL_dextra4, dL_dmeans2D_rgb, dL_dconic, dL_dopacity, dL_dcolors,
+                       dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations);
 }
 
 int hgs_mark_visible(void* stream, int P, const float* means3D, const float* viewmatrix, const float* projmatrix,

@@ -54,21 +54,32 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_kernel(int nblk, int T, Hgs
   if (threadIdx.x == 0) im.status[0] = R;
 }
 
-__device__ __forceinline__ void emit_instance(uint64_t key, uint32_t pos, int tx, int ty, const float* __restrict__ feat,
-                                              const HgsGeom& g, const HgsBinning& b, uint32_t Rcap) {
+struct EmitCtx { const float* feat; const float* extra; int n_extra; uint32_t Rcap; };
+
+__device__ __forceinline__ void emit_instance(uint64_t key, uint32_t pos, int tx, int ty, const EmitCtx& e,
+                                              const HgsGeom& g, const HgsBinning& b) {
   const uint32_t id = (uint32_t)key;
   b.point_list[pos] = id;
   b.keys_sorted[pos] = key;
   const float2 xy = g.means2D[id];
   const float4 co = g.conic_opacity[id];
-  const float f0 = feat[3 * (size_t)id], f1 = feat[3 * (size_t)id + 1], f2 = feat[3 * (size_t)id + 2];
-  float4* rec = b.packed + (size_t)pos * (HGS_PACKED_FLOATS / 4);
-  rec[0] = make_float4(xy.x, xy.y, co.x, co.y);
-  rec[1] = make_float4(co.z, co.w, f0, f1);
-  rec[2] = make_float4(f2, __uint_as_float(id), 0.f, 0.f);
+  const float f0 = e.feat[3 * (size_t)id], f1 = e.feat[3 * (size_t)id + 1], f2 = e.feat[3 * (size_t)id + 2];
+  if (e.n_extra == 0) {  // 48-B record: xy, conic, opacity, rgb, id
+    float4* rec = b.packed + (size_t)pos * 3;
+    rec[0] = make_float4(xy.x, xy.y, co.x, co.y);
+    rec[1] = make_float4(co.z, co.w, f0, f1);
+    rec[2] = make_float4(f2, __uint_as_float(id), 0.f, 0.f);
+  } else {               // 64-B record: ... rgb, 4 extra channels, id
+    const float4 ex = ((const float4*)e.extra)[id];
+    float4* rec = b.packed + (size_t)pos * 4;
+    rec[0] = make_float4(xy.x, xy.y, co.x, co.y);
+    rec[1] = make_float4(co.z, co.w, f0, f1);
+    rec[2] = make_float4(f2, ex.x, ex.y, ex.z);
+    rec[3] = make_float4(ex.w, __uint_as_float(id), 0.f, 0.f);
+  }
   const HgsRect rc = g.rect[id];
   const uint32_t k = (uint32_t)(ty - rc.y0) * (uint32_t)(rc.x1 - rc.x0) + (uint32_t)(tx - rc.x0);
-  if (rc.off + k < Rcap) b.inv[rc.off + k] = pos;
+  if (rc.off + k < e.Rcap) b.inv[rc.off + k] = pos;
 }
 
 __device__ __forceinline__ void bitonic_lds(uint64_t* sk, int m) {
@@ -86,8 +97,8 @@ __device__ __forceinline__ void bitonic_lds(uint64_t* sk, int m) {
   }
 }
 
-__global__ __launch_bounds__(HGS_BLOCK) void sort_tiles_kernel(int gx, uint32_t Rcap, const float* __restrict__ feat,
-                                                               HgsGeom g, HgsImage im, HgsBinning b) {
+__global__ __launch_bounds__(HGS_BLOCK) void sort_tiles_kernel(int gx, uint32_t Rcap, EmitCtx ec, HgsGeom g, HgsImage im,
+                                                               HgsBinning b) {
   __shared__ uint64_t sk[SORT_CAP];
   const int tile = blockIdx.x;
   const uint2 range = im.ranges[tile];
@@ -104,7 +115,7 @@ __global__ __launch_bounds__(HGS_BLOCK) void sort_tiles_kernel(int gx, uint32_t 
     __syncthreads();
     bitonic_lds(sk, m);
     if (nchunks == 1) {
-      for (uint32_t i = threadIdx.x; i < cn; i += HGS_BLOCK) emit_instance(sk[i], cbase + i, tx, ty, feat, g, b, Rcap);
+      for (uint32_t i = threadIdx.x; i < cn; i += HGS_BLOCK) emit_instance(sk[i], cbase + i, tx, ty, ec, g, b);
     } else {
       for (uint32_t i = threadIdx.x; i < cn; i += HGS_BLOCK) b.keys[cbase + i] = sk[i];
     }
@@ -129,7 +140,7 @@ __global__ __launch_bounds__(HGS_BLOCK) void sort_tiles_kernel(int gx, uint32_t 
         }
         rank += lo;
       }
-      emit_instance(key, start + rank, tx, ty, feat, g, b, Rcap);
+      emit_instance(key, start + rank, tx, ty, ec, g, b);
     }
   }
 }
@@ -146,12 +157,13 @@ int hgs_launch_scan(hipStream_t s, int P, int T, const HgsGeom& g, const HgsImag
   return 0;
 }
 
-int hgs_launch_sort_tiles(hipStream_t s, int W, int H, int Rcap, const float* features, const HgsGeom& g,
-                          const HgsImage& im, const HgsBinning& b) {
+int hgs_launch_sort_tiles(hipStream_t s, int W, int H, int Rcap, const float* features, const float* extra, int n_extra,
+                          const HgsGeom& g, const HgsImage& im, const HgsBinning& b) {
   const int gx = (W + HGS_TILE - 1) / HGS_TILE, gy = (H + HGS_TILE - 1) / HGS_TILE;
   {
     HgsProfScope _prof(s, HGS_K_SORT_TILES);
-    hipLaunchKernelGGL(sort_tiles_kernel, dim3(gx * gy), dim3(HGS_BLOCK), 0, s, gx, (uint32_t)Rcap, features, g, im, b);
+    EmitCtx ec = {features, extra, n_extra, (uint32_t)Rcap};
+    hipLaunchKernelGGL(sort_tiles_kernel, dim3(gx * gy), dim3(HGS_BLOCK), 0, s, gx, (uint32_t)Rcap, ec, g, im, b);
   }
   HGS_CHECK_LAUNCH();
   return 0;

@@ -5,8 +5,8 @@
 // CDNA4 mapping (not the reference's 256-entry shared-memory staging):
 //   * a 16x16 tile = one 256-thread workgroup = 4 wavefronts; wavefront w owns the 8x8 pixel quadrant
 //     (w&1, w>>1): compact footprints make whole-wave rejection of thin strand Gaussians likely;
-//   * the tile's depth-sorted instance records (48 B: xy, conic, opacity, rgb, id; written by
-//     sort_tiles_kernel) are wave-uniform data: they are streamed with SCALAR loads (s_load_dwordx4) straight
+//   * the tile's depth-sorted instance records (48 B: xy, conic, opacity, rgb, id -- 64 B with the 4 extra channels of
+//     the single-pass mode; written by sort_tiles_kernel) are wave-uniform data: they are streamed with SCALAR loads (s_load_dwordx4) straight
 //     into SGPRs and used as SGPR operands of the per-pixel VALU math -- no LDS staging, no barriers in the
 //     forward, each wavefront leaves its loop on its own when its 64 pixels are saturated;
 //   * backward: per (wave, entry) the 9 partial sums are reduced across the 64 lanes, the 4 wavefronts'
@@ -18,7 +18,6 @@
 namespace {
 
 #define BWD_BATCH 64   // entries combined per LDS flush in the backward
-#define NPART 9        // dmean2D.xy, dconic.x/.y/.w, dopacity, dcolor.rgb
 #define REC_CHUNK 4     // instance records fetched per scalar-load burst
 
 // ---- wavefront-wide reduction of 9 per-lane values (CDNA4: v_permlane32_swap / v_permlane16_swap + DPP) ----------
@@ -49,17 +48,30 @@ __device__ __forceinline__ float fold16(float a, float b) {  // rows: (a.r0+a.r1
   asm volatile("" : "+v"(hi));  // same miscompile guard as fold32
   return __builtin_bit_cast(float, lo) + __builtin_bit_cast(float, hi);
 }
-// in : v[0..8] per lane.   out: x0123 rows (0,1,2,3) hold the totals of v0, v2, v1, v3; x4567 rows hold v4, v6, v5, v7;
-//      x8 holds the total of v8 in every lane.
-__device__ __forceinline__ void wave_reduce9(const float* v, float& x0123, float& x4567, float& x8) {
-  const float w01 = fold32(v[0], v[1]), w23 = fold32(v[2], v[3]), w45 = fold32(v[4], v[5]), w67 = fold32(v[6], v[7]);
-  const float w88 = fold32(v[8], v[8]);
-  x0123 = row_sum16(fold16(w01, w23));
-  x4567 = row_sum16(fold16(w45, w67));
-  x8 = row_sum16(fold16(w88, w88));
+// Channel layouts.  C = 3: the reference's RGB pass.  C = 7 (single-pass mode): RGB + 4 extra
+// unclamped channels (mask, world-space direction xyz) blended with the SAME weights in one traversal, which is what
+// the reference's three render() calls per iteration compute separately (train.py:146, loss/losses.py:247,312).
+//   record  : [x, y, conic a, b, c, opacity, f0 .. f(C-1), id, pad]          REC4(C) float4 per instance
+//   partials: [dmean2D.x, .y, dconic.x, .y, .w, dopacity, dcolor 0..C-1, (C>3: RGB-only dmean2D.x, .y)]
+// The RGB-only screen-space gradient is what the reference's densification statistics see (the mask / orientation
+// passes use their own throw-away screenspace tensors), so it is accumulated separately from the total.
+template <int C> struct Chan {
+  static constexpr int REC4 = (C <= 3) ? 3 : 4;                    // float4 per packed record
+  static constexpr int NPART = (C <= 3) ? 9 : 6 + C + 2;           // partial sums per (tile, entry)
+  static constexpr int NREG = (NPART + 3) / 4;                     // registers after the transposing fold
+  static constexpr int ROW = (C <= 3) ? HGS_INST_GRAD_FLOATS : 16; // floats per instance row in the scratch
+};
+
+// in : v[0 .. 4*NREG) per lane.  out: x[r] rows (0,1,2,3) hold the wave totals of v[4r], v[4r+2], v[4r+1], v[4r+3].
+template <int NREG>
+__device__ __forceinline__ void wave_reduce(const float* v, float* x) {
+#pragma unroll
+  for (int r = 0; r < NREG; r++)
+    x[r] = row_sum16(fold16(fold32(v[4 * r], v[4 * r + 1]), fold32(v[4 * r + 2], v[4 * r + 3])));
 }
 
 // ------------------------------------------------------------------------------------------------
+template <int C>
 __global__ __launch_bounds__(HGS_BLOCK) void blend_fwd_kernel(const uint2* __restrict__ ranges,
                                                               const float4* __restrict__ packed, int W, int H, int gx,
                                                               uint32_t Rcap, const float* __restrict__ bg,
@@ -67,6 +79,7 @@ __global__ __launch_bounds__(HGS_BLOCK) void blend_fwd_kernel(const uint2* __res
                                                               uint32_t* __restrict__ n_contrib,
                                                               uint32_t* __restrict__ tile_maxc,
                                                               float* __restrict__ out_color) {
+  constexpr int REC4 = Chan<C>::REC4;
   const int tile = blockIdx.x;
   const int tx = tile % gx, ty = tile / gx;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -76,7 +89,9 @@ __global__ __launch_bounds__(HGS_BLOCK) void blend_fwd_kernel(const uint2* __res
   const float pxf = (float)px, pyf = (float)py;
   uint2 range = ranges[tile];
   if (range.y > Rcap) range = make_uint2(0u, 0u);  // binning buffer under-sized (flagged by the scatter kernel)
-  float T = 1.f, C0 = 0.f, C1 = 0.f, C2 = 0.f;
+  float T = 1.f, acc[C];
+#pragma unroll
+  for (int k = 0; k < C; k++) acc[k] = 0.f;
   uint32_t last = 0;
   bool done = !inside;
   // The instance records are streamed in chunks of REC_CHUNK: all scalar loads of a chunk are issued back to back
@@ -85,18 +100,18 @@ __global__ __launch_bounds__(HGS_BLOCK) void blend_fwd_kernel(const uint2* __res
   // per entry by REC_CHUNK.
   for (uint32_t j0 = range.x; j0 < range.y; j0 += REC_CHUNK) {
     if (__ballot(!done) == 0) break;  // forward.cu:309-311, per wavefront instead of per block
-    float4 q0[REC_CHUNK], q1[REC_CHUNK];
-    float qb[REC_CHUNK];
+    float4 q[REC_CHUNK][REC4];
 #pragma unroll
     for (int u = 0; u < REC_CHUNK; u++) {
       const size_t jj = min(j0 + (uint32_t)u, range.y - 1u);
-      q0[u] = packed[3 * jj]; q1[u] = packed[3 * jj + 1]; qb[u] = packed[3 * jj + 2].x;
+#pragma unroll
+      for (int w = 0; w < REC4; w++) q[u][w] = packed[REC4 * jj + w];
     }
 #pragma unroll
     for (int u = 0; u < REC_CHUNK; u++) {
       const uint32_t j = j0 + (uint32_t)u;
       if (j >= range.y) break;
-      const float4 r0 = q0[u], r1 = q1[u];
+      const float4 r0 = q[u][0], r1 = q[u][1];
       const float dx = r0.x - pxf, dy = r0.y - pyf;
       const float power = -0.5f * (r0.z * dx * dx + r1.x * dy * dy) - r0.w * dx * dy;  // forward.cu:335
       const float alpha = fminf(0.99f, r1.y * __expf(power));                           // :343
@@ -106,7 +121,9 @@ __global__ __launch_bounds__(HGS_BLOCK) void blend_fwd_kernel(const uint2* __res
       if (ok && test_T < 0.0001f) { done = true; ok = false; }                          // :346-351
       if (ok) {
         const float w = alpha * T;
-        C0 += r1.z * w; C1 += r1.w * w; C2 += qb[u] * w;                                // :354-355
+        const float* f = (const float*)&q[u][0];                                        // features start at float 6
+#pragma unroll
+        for (int k = 0; k < C; k++) acc[k] += f[6 + k] * w;                             // :354-355
         T = test_T;
         last = j - range.x + 1;                                                         // :328, :361
       }
@@ -120,13 +137,13 @@ __global__ __launch_bounds__(HGS_BLOCK) void blend_fwd_kernel(const uint2* __res
     const size_t pix = (size_t)py * W + px, HW = (size_t)H * W;
     final_T[pix] = T;
     n_contrib[pix] = last;
-    out_color[pix] = C0 + T * bg[0];                                                  // :372
-    out_color[HW + pix] = C1 + T * bg[1];
-    out_color[2 * HW + pix] = C2 + T * bg[2];
+#pragma unroll
+    for (int k = 0; k < C; k++) out_color[k * HW + pix] = acc[k] + T * bg[k];           // :372
   }
 }
 
 // ------------------------------------------------------------------------------------------------
+template <int C>
 __global__ __launch_bounds__(HGS_BLOCK) void blend_bwd_kernel(const uint2* __restrict__ ranges,
                                                               const float4* __restrict__ packed, int W, int H, int gx,
                                                               uint32_t Rcap, const float* __restrict__ bg,
@@ -135,11 +152,12 @@ __global__ __launch_bounds__(HGS_BLOCK) void blend_bwd_kernel(const uint2* __res
                                                               const uint32_t* __restrict__ tile_maxc,
                                                               const float* __restrict__ dL_dpix,
                                                               float* __restrict__ inst_grad) {
-  __shared__ float part[4][BWD_BATCH][NPART];
+  constexpr int REC4 = Chan<C>::REC4, NPART = Chan<C>::NPART, NREG = Chan<C>::NREG, NV = 4 * NREG, ROW = Chan<C>::ROW;
+  __shared__ float part[4][BWD_BATCH][NV];
   const int tile = blockIdx.x;
   const uint2 range = ranges[tile];
   const uint32_t maxc = tile_maxc[tile];
-  if (maxc == 0 || range.y > Rcap) return;  // nothing in this tile contributed to any pixel (inst_grad rows stay zero)
+  if (maxc == 0 || range.y > Rcap) return;  // nothing in this tile contributed to any pixel (rows stay zero)
   const int tx = tile % gx, ty = tile / gx;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int px = tx * HGS_TILE + (wave & 1) * 8 + (lane & 7);
@@ -151,13 +169,19 @@ __global__ __launch_bounds__(HGS_BLOCK) void blend_bwd_kernel(const uint2* __res
   const float T_final = inside ? final_Ts[pix] : 0.f;
   float T = T_final;
   const uint32_t last = inside ? n_contrib[pix] : 0u;
-  float dpx0 = 0.f, dpx1 = 0.f, dpx2 = 0.f;
-  if (inside) { dpx0 = dL_dpix[pix]; dpx1 = dL_dpix[HW + pix]; dpx2 = dL_dpix[2 * HW + pix]; }
-  const float bg_dot_dpixel = bg[0] * dpx0 + bg[1] * dpx1 + bg[2] * dpx2;   // backward_distwar.cu:988-990
-  float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, lc0 = 0.f, lc1 = 0.f, lc2 = 0.f, last_alpha = 0.f;
+  float dpx[C], acc[C], lc[C];
+  float bg_dot = 0.f, bg_dot_rgb = 0.f;                                       // backward_distwar.cu:988-990
+#pragma unroll
+  for (int k = 0; k < C; k++) {
+    dpx[k] = inside ? dL_dpix[k * HW + pix] : 0.f;
+    acc[k] = 0.f; lc[k] = 0.f;
+    bg_dot += bg[k] * dpx[k];
+    if (k < 3) bg_dot_rgb += bg[k] * dpx[k];
+  }
+  float last_alpha = 0.f;
   const float ddelx_dx = 0.5f * W, ddely_dy = 0.5f * H;                       // :917-918
 
-  for (int i = threadIdx.x; i < 4 * BWD_BATCH * NPART; i += HGS_BLOCK) (&part[0][0][0])[i] = 0.f;
+  for (int i = threadIdx.x; i < 4 * BWD_BATCH * NV; i += HGS_BLOCK) (&part[0][0][0])[i] = 0.f;
   __syncthreads();
 
   // walk the list back to front in batches of BWD_BATCH positions; position p (0-based) is valid for a pixel
@@ -165,64 +189,73 @@ __global__ __launch_bounds__(HGS_BLOCK) void blend_bwd_kernel(const uint2* __res
   for (int hi = (int)maxc; hi > 0; hi -= BWD_BATCH) {
     const int lo = max(0, hi - BWD_BATCH);
     for (int p0 = hi - 1; p0 >= lo; p0 -= REC_CHUNK) {
-    float4 q0[REC_CHUNK], q1[REC_CHUNK];
-    float qb[REC_CHUNK];
+      float4 q[REC_CHUNK][REC4];
 #pragma unroll
-    for (int u = 0; u < REC_CHUNK; u++) {
-      const size_t jj = (size_t)range.x + (size_t)max(p0 - u, lo);
-      q0[u] = packed[3 * jj]; q1[u] = packed[3 * jj + 1]; qb[u] = packed[3 * jj + 2].x;
-    }
+      for (int u = 0; u < REC_CHUNK; u++) {
+        const size_t jj = (size_t)range.x + (size_t)max(p0 - u, lo);
 #pragma unroll
-    for (int u = 0; u < REC_CHUNK; u++) {
-      const int p = p0 - u;
-      if (p < lo) break;
-      const float4 r0 = q0[u], r1 = q1[u];
-      const float c2 = qb[u];
-      const float dx = r0.x - pxf, dy = r0.y - pyf;
-      const float power = -0.5f * (r0.z * dx * dx + r1.x * dy * dy) - r0.w * dx * dy;
-      const float G = __expf(power);
-      const float alpha = fminf(0.99f, r1.y * G);
-      const bool ok = (uint32_t)p < last && power <= 0.f && alpha >= (1.0f / 255.0f);
-      if (__ballot(ok) == 0) continue;
-      float v[NPART];
-#pragma unroll
-      for (int k = 0; k < NPART; k++) v[k] = 0.f;
-      if (ok) {
-        const float c0 = r1.z, c1 = r1.w;
-        const float inv_one_m_a = __builtin_amdgcn_rcpf(1.f - alpha);             // 1 ulp; alpha <= 0.99
-        T = T * inv_one_m_a;                                                       // :960
-        const float dchannel_dcolor = alpha * T;
-        acc0 = last_alpha * lc0 + (1.f - last_alpha) * acc0;                       // :972
-        acc1 = last_alpha * lc1 + (1.f - last_alpha) * acc1;
-        acc2 = last_alpha * lc2 + (1.f - last_alpha) * acc2;
-        lc0 = c0; lc1 = c1; lc2 = c2;
-        float dL_dalpha = (c0 - acc0) * dpx0 + (c1 - acc1) * dpx1 + (c2 - acc2) * dpx2;
-        v[6] = dchannel_dcolor * dpx0; v[7] = dchannel_dcolor * dpx1; v[8] = dchannel_dcolor * dpx2;
-        dL_dalpha *= T;
-        last_alpha = alpha;
-        dL_dalpha += (-T_final * inv_one_m_a) * bg_dot_dpixel;                     // :991
-        const float dL_dG = r1.y * dL_dalpha;
-        const float gdx = G * dx, gdy = G * dy;
-        const float dG_ddelx = -gdx * r0.z - gdy * r0.w;
-        const float dG_ddely = -gdy * r1.x - gdx * r0.w;
-        v[0] = dL_dG * dG_ddelx * ddelx_dx;                                        // :1002-1003
-        v[1] = dL_dG * dG_ddely * ddely_dy;
-        v[2] = -0.5f * gdx * dx * dL_dG;                                           // :1006-1008
-        v[3] = -0.5f * gdx * dy * dL_dG;
-        v[4] = -0.5f * gdy * dy * dL_dG;
-        v[5] = G * dL_dalpha;                                                      // :1011
+        for (int w = 0; w < REC4; w++) q[u][w] = packed[REC4 * jj + w];
       }
-      float x0123, x4567, x8;
-      wave_reduce9(v, x0123, x4567, x8);
-      if ((lane & 15) == 0) {
-        const int row = lane >> 4;
-        const int k = ((row & 1) << 1) | (row >> 1);   // rows hold values (0,2,1,3)
-        float* dst = &part[wave][p - lo][0];
-        dst[k] = x0123;
-        dst[4 + k] = x4567;
-        if (lane == 0) dst[8] = x8;
+#pragma unroll
+      for (int u = 0; u < REC_CHUNK; u++) {
+        const int p = p0 - u;
+        if (p < lo) break;
+        const float4 r0 = q[u][0], r1 = q[u][1];
+        const float* f = (const float*)&q[u][0];
+        const float dx = r0.x - pxf, dy = r0.y - pyf;
+        const float power = -0.5f * (r0.z * dx * dx + r1.x * dy * dy) - r0.w * dx * dy;
+        const float G = __expf(power);
+        const float alpha = fminf(0.99f, r1.y * G);
+        const bool ok = (uint32_t)p < last && power <= 0.f && alpha >= (1.0f / 255.0f);
+        if (__ballot(ok) == 0) continue;
+        float v[NV];
+#pragma unroll
+        for (int k = 0; k < NV; k++) v[k] = 0.f;
+        if (ok) {
+          const float inv_one_m_a = __builtin_amdgcn_rcpf(1.f - alpha);             // 1 ulp; alpha <= 0.99
+          T = T * inv_one_m_a;                                                       // :960
+          const float dchannel_dcolor = alpha * T;
+          float dL_dalpha = 0.f, dL_dalpha_rgb = 0.f;
+#pragma unroll
+          for (int k = 0; k < C; k++) {
+            const float c = f[6 + k];
+            acc[k] = last_alpha * lc[k] + (1.f - last_alpha) * acc[k];               // :972
+            lc[k] = c;
+            const float t = (c - acc[k]) * dpx[k];
+            dL_dalpha += t;
+            if (k < 3) dL_dalpha_rgb += t;
+            v[6 + k] = dchannel_dcolor * dpx[k];                                     // :980
+          }
+          dL_dalpha *= T;
+          last_alpha = alpha;
+          const float bgw = -T_final * inv_one_m_a;
+          dL_dalpha += bgw * bg_dot;                                                 // :991
+          const float dL_dG = r1.y * dL_dalpha;
+          const float gdx = G * dx, gdy = G * dy;
+          const float dG_ddelx = -gdx * r0.z - gdy * r0.w;
+          const float dG_ddely = -gdy * r1.x - gdx * r0.w;
+          v[0] = dL_dG * dG_ddelx * ddelx_dx;                                        // :1002-1003
+          v[1] = dL_dG * dG_ddely * ddely_dy;
+          v[2] = -0.5f * gdx * dx * dL_dG;                                           // :1006-1008
+          v[3] = -0.5f * gdx * dy * dL_dG;
+          v[4] = -0.5f * gdy * dy * dL_dG;
+          v[5] = G * dL_dalpha;                                                      // :1011
+          if (C > 3) {  // screen-space gradient of the RGB channels alone (densification statistics)
+            const float dL_dG_rgb = r1.y * (dL_dalpha_rgb * T + bgw * bg_dot_rgb);
+            v[6 + C] = dL_dG_rgb * dG_ddelx * ddelx_dx;
+            v[7 + C] = dL_dG_rgb * dG_ddely * ddely_dy;
+          }
+        }
+        float x[NREG];
+        wave_reduce<NREG>(v, x);
+        if ((lane & 15) == 0) {
+          const int row = lane >> 4;
+          const int k = ((row & 1) << 1) | (row >> 1);   // rows hold values (0,2,1,3) of each group of four
+          float* dst = &part[wave][p - lo][0];
+#pragma unroll
+          for (int r = 0; r < NREG; r++) dst[4 * r + k] = x[r];
+        }
       }
-    }
     }
     __syncthreads();
     // combine the 4 wavefronts in fixed order and store one row per (tile, entry)
@@ -230,7 +263,7 @@ __global__ __launch_bounds__(HGS_BLOCK) void blend_bwd_kernel(const uint2* __res
     for (int i = threadIdx.x; i < cnt * NPART; i += HGS_BLOCK) {
       const int e = i / NPART, k = i - e * NPART;
       const float s = ((part[0][e][k] + part[1][e][k]) + part[2][e][k]) + part[3][e][k];
-      inst_grad[(size_t)(range.x + lo + e) * HGS_INST_GRAD_FLOATS + k] = s;
+      inst_grad[(size_t)(range.x + lo + e) * ROW + k] = s;
       part[0][e][k] = 0.f; part[1][e][k] = 0.f; part[2][e][k] = 0.f; part[3][e][k] = 0.f;
     }
     __syncthreads();
@@ -239,25 +272,33 @@ __global__ __launch_bounds__(HGS_BLOCK) void blend_bwd_kernel(const uint2* __res
 
 }  // namespace
 
-int hgs_launch_blend_fwd(hipStream_t s, int W, int H, int Rcap, const float* bg, const HgsImage& im, const HgsBinning& b,
-                         float* out_color) {
+int hgs_launch_blend_fwd(hipStream_t s, int W, int H, int Rcap, int channels, const float* bg, const HgsImage& im,
+                         const HgsBinning& b, float* out_color) {
   const int gx = (W + HGS_TILE - 1) / HGS_TILE, gy = (H + HGS_TILE - 1) / HGS_TILE;
   {
     HgsProfScope _prof(s, HGS_K_BLEND_FWD);
-    hipLaunchKernelGGL(blend_fwd_kernel, dim3(gx * gy), dim3(HGS_BLOCK), 0, s, im.ranges, b.packed, W, H, gx, (uint32_t)Rcap, bg,
-                     im.final_T, im.n_contrib, im.tile_maxc, out_color);
+    if (channels == 3)
+      hipLaunchKernelGGL(blend_fwd_kernel<3>, dim3(gx * gy), dim3(HGS_BLOCK), 0, s, im.ranges, b.packed, W, H, gx,
+                         (uint32_t)Rcap, bg, im.final_T, im.n_contrib, im.tile_maxc, out_color);
+    else
+      hipLaunchKernelGGL(blend_fwd_kernel<7>, dim3(gx * gy), dim3(HGS_BLOCK), 0, s, im.ranges, b.packed, W, H, gx,
+                         (uint32_t)Rcap, bg, im.final_T, im.n_contrib, im.tile_maxc, out_color);
   }
   HGS_CHECK_LAUNCH();
   return 0;
 }
 
-int hgs_launch_blend_bwd(hipStream_t s, int W, int H, int Rcap, const float* bg, const HgsImage& im, const HgsBinning& b,
-                         const float* dL_dpix, float* inst_grad) {
+int hgs_launch_blend_bwd(hipStream_t s, int W, int H, int Rcap, int channels, const float* bg, const HgsImage& im,
+                         const HgsBinning& b, const float* dL_dpix, float* inst_grad) {
   const int gx = (W + HGS_TILE - 1) / HGS_TILE, gy = (H + HGS_TILE - 1) / HGS_TILE;
   {
     HgsProfScope _prof(s, HGS_K_BLEND_BWD);
-    hipLaunchKernelGGL(blend_bwd_kernel, dim3(gx * gy), dim3(HGS_BLOCK), 0, s, im.ranges, b.packed, W, H, gx, (uint32_t)Rcap, bg,
-                     im.final_T, im.n_contrib, im.tile_maxc, dL_dpix, inst_grad);
+    if (channels == 3)
+      hipLaunchKernelGGL(blend_bwd_kernel<3>, dim3(gx * gy), dim3(HGS_BLOCK), 0, s, im.ranges, b.packed, W, H, gx,
+                         (uint32_t)Rcap, bg, im.final_T, im.n_contrib, im.tile_maxc, dL_dpix, inst_grad);
+    else
+      hipLaunchKernelGGL(blend_bwd_kernel<7>, dim3(gx * gy), dim3(HGS_BLOCK), 0, s, im.ranges, b.packed, W, H, gx,
+                         (uint32_t)Rcap, bg, im.final_T, im.n_contrib, im.tile_maxc, dL_dpix, inst_grad);
   }
   HGS_CHECK_LAUNCH();
   return 0;

@@ -74,11 +74,11 @@ static inline size_t hgs_image_carve(char* base, size_t W, size_t H, HgsImage& i
   cur += (3 * T + HGS_STATUS_WORDS) * sizeof(uint32_t);
   return hgs_align_up((size_t)(cur - base)) + HGS_ALIGN;
 }
-static inline size_t hgs_binning_carve(char* base, size_t R, HgsBinning& b, size_t* offs) {
+static inline size_t hgs_binning_carve(char* base, size_t R, HgsBinning& b, size_t* offs, int channels = 3) {
   char* cur = base;
   hgs_carve(cur, b.keys, R);                                  if (offs) offs[HGS_BIN_KEYS] = (char*)b.keys - base;
   hgs_carve(cur, b.point_list, R);                            if (offs) offs[HGS_BIN_POINT_LIST] = (char*)b.point_list - base;
-  hgs_carve(cur, b.packed, R * (HGS_PACKED_FLOATS / 4) + 4);  if (offs) offs[HGS_BIN_PACKED] = (char*)b.packed - base;
+  hgs_carve(cur, b.packed, R * (channels <= 3 ? HGS_PACKED_FLOATS / 4 : 4) + 4);  if (offs) offs[HGS_BIN_PACKED] = (char*)b.packed - base;
   hgs_carve(cur, b.inv, R);                                   if (offs) offs[HGS_BIN_INV] = (char*)b.inv - base;
   hgs_carve(cur, b.keys_sorted, R);                           if (offs) offs[HGS_BIN_KEYS_TMP] = (char*)b.keys_sorted - base;
   return hgs_align_up((size_t)(cur - base)) + HGS_ALIGN;
@@ -121,12 +121,12 @@ int hgs_launch_preprocess_fwd(hipStream_t s, const HgsFwdArgs& a, const HgsGeom&
 int hgs_launch_scan(hipStream_t s, int P, int T, const HgsGeom& g, const HgsImage& im);
 int hgs_launch_scatter(hipStream_t s, int P, int W, int H, int Rcap, const int* radii, const HgsGeom& g,
                        const HgsImage& im, const HgsBinning& b);
-int hgs_launch_sort_tiles(hipStream_t s, int W, int H, int Rcap, const float* features, const HgsGeom& g,
-                          const HgsImage& im, const HgsBinning& b);
-int hgs_launch_blend_fwd(hipStream_t s, int W, int H, int Rcap, const float* bg, const HgsImage& im, const HgsBinning& b,
-                         float* out_color);
-int hgs_launch_blend_bwd(hipStream_t s, int W, int H, int Rcap, const float* bg, const HgsImage& im, const HgsBinning& b,
-                         const float* dL_dpix, float* inst_grad);
+int hgs_launch_sort_tiles(hipStream_t s, int W, int H, int Rcap, const float* features, const float* extra, int n_extra,
+                          const HgsGeom& g, const HgsImage& im, const HgsBinning& b);
+int hgs_launch_blend_fwd(hipStream_t s, int W, int H, int Rcap, int channels, const float* bg, const HgsImage& im,
+                         const HgsBinning& b, float* out_color);
+int hgs_launch_blend_bwd(hipStream_t s, int W, int H, int Rcap, int channels, const float* bg, const HgsImage& im,
+                         const HgsBinning& b, const float* dL_dpix, float* inst_grad);
 struct HgsBwdArgs {
   int P, D, M, W, H;
   const float *means3D, *shs, *colors_precomp, *scales, *rotations, *cov3D_precomp;
@@ -135,6 +135,8 @@ struct HgsBwdArgs {
   const int* radii;
   float *dL_dmeans2D, *dL_dconic, *dL_dopacity, *dL_dcolors, *dL_dmeans3D, *dL_dcov3D, *dL_dsh, *dL_dscales,
       *dL_drotations;
+  int n_extra;         // 0, or 4 in the single-pass mode
+  float* dL_dextra;    // [P, n_extra]
 };
 int hgs_launch_preprocess_bwd(hipStream_t s, const HgsBwdArgs& a, const HgsGeom& g, const HgsBinning& b,
                               const float* inst_grad, int Rcap);

@@ -252,6 +252,7 @@ __global__ __launch_bounds__(HGS_BLOCK) void preprocess_bwd_kernel(HgsBwdArgs a,
   if (idx >= a.P) return;
   const int M = a.M;
   float dmx = 0.f, dmy = 0.f, dcx = 0.f, dcy = 0.f, dcw = 0.f, dop = 0.f, dcol[3] = {0.f, 0.f, 0.f};
+  float dex[4] = {0.f, 0.f, 0.f, 0.f}, dmx_rgb = 0.f, dmy_rgb = 0.f;
   float dmean[3] = {0.f, 0.f, 0.f}, dcov[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   float dscale[3] = {0.f, 0.f, 0.f}, drot[4] = {0.f, 0.f, 0.f, 0.f};
   const bool vis = a.radii[idx] > 0;
@@ -259,15 +260,20 @@ __global__ __launch_bounds__(HGS_BLOCK) void preprocess_bwd_kernel(HgsBwdArgs a,
     // ---- deterministic gather of this Gaussian's per-instance partial sums (instance order = tile rect order)
     const HgsRect rc = g.rect[idx];
     const uint32_t n = g.tiles_touched[idx];
+    const int row_floats = a.n_extra ? 16 : HGS_INST_GRAD_FLOATS;
     for (uint32_t k = 0; k < n; k++) {
       if (rc.off + k >= Rcap) break;  // under-sized binning buffer (forward already flagged the overflow)
       const uint32_t pos = b.inv[rc.off + k];
       if (pos >= Rcap) continue;
-      const float4* r = (const float4*)(inst_grad + (size_t)pos * HGS_INST_GRAD_FLOATS);
-      const float4 r0 = r[0], r1 = r[1];
-      const float r2 = r[2].x;
+      const float4* r = (const float4*)(inst_grad + (size_t)pos * row_floats);
+      const float4 r0 = r[0], r1 = r[1], r2 = r[2];
       dmx += r0.x; dmy += r0.y; dcx += r0.z; dcy += r0.w;
-      dcw += r1.x; dop += r1.y; dcol[0] += r1.z; dcol[1] += r1.w; dcol[2] += r2;
+      dcw += r1.x; dop += r1.y; dcol[0] += r1.z; dcol[1] += r1.w; dcol[2] += r2.x;
+      if (a.n_extra) {  // row = [.., dcolor 0..6, rgb-only dmean2D.xy]
+        const float4 r3 = r[3];
+        dex[0] += r2.y; dex[1] += r2.z; dex[2] += r2.w; dex[3] += r3.x;
+        dmx_rgb += r3.y; dmy_rgb += r3.z;
+      }
     }
     // ---- computeCov2DCUDA, backward_distwar.cu:145-275
     const V3 mean = {a.means3D[3 * idx], a.means3D[3 * idx + 1], a.means3D[3 * idx + 2]};
@@ -447,7 +453,12 @@ __global__ __launch_bounds__(HGS_BLOCK) void preprocess_bwd_kernel(HgsBwdArgs a,
     for (int k = 0; k < 3 * M; k++) dsh[k] = 0.f;
   }
   // every output is written (zeros for culled Gaussians): no separate zero-fill pass
-  a.dL_dmeans2D[3 * idx] = dmx; a.dL_dmeans2D[3 * idx + 1] = dmy; a.dL_dmeans2D[3 * idx + 2] = 0.f;
+  // returned screen-space gradient: in the single-pass mode the RGB channels' share only (what the reference's
+  // densification statistics read from the RGB pass); dL_dmeans3D above used the total
+  a.dL_dmeans2D[3 * idx] = a.n_extra ? dmx_rgb : dmx;
+  a.dL_dmeans2D[3 * idx + 1] = a.n_extra ? dmy_rgb : dmy;
+  a.dL_dmeans2D[3 * idx + 2] = 0.f;
+  if (a.n_extra) ((float4*)a.dL_dextra)[idx] = make_float4(dex[0], dex[1], dex[2], dex[3]);
   ((float4*)a.dL_dconic)[idx] = make_float4(dcx, dcy, 0.f, dcw);
   a.dL_dopacity[idx] = dop;
   a.dL_dcolors[3 * idx] = dcol[0]; a.dL_dcolors[3 * idx + 1] = dcol[1]; a.dL_dcolors[3 * idx + 2] = dcol[2];

@@ -57,6 +57,23 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
                         prefiltered, debug):
     """RasterizeGaussiansCUDA (rasterize_points.cu:35-115).
     Returns (num_rendered, out_color[3,H,W], radii[P], geomBuffer, binningBuffer, imgBuffer)."""
+    return _forward(background, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp, viewmatrix,
+                    projmatrix, tan_fovx, tan_fovy, image_height, image_width, sh, degree, campos, prefiltered, debug,
+                    None)
+
+
+def rasterize_gaussians_multi(background7, means3D, colors, extra4, opacity, scales, rotations, scale_modifier,
+                              cov3D_precomp, viewmatrix, projmatrix, tan_fovx, tan_fovy, image_height, image_width, sh,
+                              degree, campos, prefiltered, debug):
+    """Single-pass 7-channel forward (hgs_forward_render_multi): RGB + `extra4` [P,4] unclamped channels blended with
+    the same weights.  Returns (num_rendered, out_color[7,H,W], radii, geomBuffer, binningBuffer, imgBuffer)."""
+    return _forward(background7, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp, viewmatrix,
+                    projmatrix, tan_fovx, tan_fovy, image_height, image_width, sh, degree, campos, prefiltered, debug,
+                    extra4)
+
+
+def _forward(background, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp, viewmatrix,
+             projmatrix, tan_fovx, tan_fovy, image_height, image_width, sh, degree, campos, prefiltered, debug, extra4):
     if means3D.ndim != 2 or means3D.shape[1] != 3:
         raise RuntimeError("means3D must have dimensions (num_points, 3)")  # rasterize_points.cu:57-59
     L = rt.lib()
@@ -64,7 +81,9 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
     dev = means3D.device
     P, H, W = means3D.shape[0], int(image_height), int(image_width)
     M = sh.shape[1] if (sh is not None and sh.numel() != 0) else 0
-    out_color = torch.empty((3, H, W), dtype=torch.float32, device=dev)
+    n_ch = 3 if extra4 is None else 7
+    extra_ = None if extra4 is None else rt.require_gpu_tensor(extra4, "extra4", torch.float32)
+    out_color = torch.empty((n_ch, H, W), dtype=torch.float32, device=dev)
     radii = torch.empty((P,), dtype=torch.int32, device=dev)
     u8 = dict(dtype=torch.uint8, device=dev)
     geom = torch.empty((L.hgs_geom_bytes(P),), **u8)
@@ -89,9 +108,14 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
             R = int(n_host.value)
             if _state["async"]:  # first call: learn the scale of the scene with one blocking read
                 _state["cap"] = max(_state["cap"], int(R * _state["slack"]) + 4096)
-        binning = torch.empty((L.hgs_binning_bytes(R),), **u8)
-        rt.check(L.hgs_forward_render(stream, P, W, H, R, rt.ptr(bg), rt.ptr(colors_), rt.ptr(geom), rt.ptr(binning),
-                                      rt.ptr(img), rt.ptr(out_color)))
+        if extra_ is None:
+            binning = torch.empty((L.hgs_binning_bytes(R),), **u8)
+            rt.check(L.hgs_forward_render(stream, P, W, H, R, rt.ptr(bg), rt.ptr(colors_), rt.ptr(geom), rt.ptr(binning),
+                                          rt.ptr(img), rt.ptr(out_color)))
+        else:
+            binning = torch.empty((L.hgs_binning_bytes_multi(R),), **u8)
+            rt.check(L.hgs_forward_render_multi(stream, P, W, H, R, rt.ptr(bg), rt.ptr(colors_), rt.ptr(extra_),
+                                                rt.ptr(geom), rt.ptr(binning), rt.ptr(img), rt.ptr(out_color)))
         if use_async:
             off = rt.layout("image", W, H)["status"]
             host = _state["pool"].pop() if _state["pool"] else torch.empty(2, dtype=torch.int32, pin_memory=True)
@@ -142,6 +166,45 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
             torch.cuda.synchronize(dev)
     rasterize_gaussians_backward.last_dL_dconic = dL_dconic  # kept for the parity tests
     return dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations
+
+
+def rasterize_gaussians_multi_backward(background7, means3D, radii, colors, scales, rotations, scale_modifier,
+                                       cov3D_precomp, viewmatrix, projmatrix, tan_fovx, tan_fovy, dL_dout_color7, sh,
+                                       degree, campos, geomBuffer, R, binningBuffer, imageBuffer, debug):
+    """Backward of the single-pass mode (hgs_backward_multi).  Returns (dL_dmeans2D_rgb, dL_dcolors, dL_dextra4,
+    dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations)."""
+    L = rt.lib()
+    means3D = rt.require_gpu_tensor(means3D, "means3D", torch.float32)
+    dev, P = means3D.device, means3D.shape[0]
+    H, W = int(dL_dout_color7.shape[1]), int(dL_dout_color7.shape[2])
+    M = sh.shape[1] if (sh is not None and sh.numel() != 0) else 0
+    f32 = dict(dtype=torch.float32, device=dev)
+    new = torch.empty if P > 0 else torch.zeros
+    dL_dmeans3D, dL_dmeans2D, dL_dcolors = new((P, 3), **f32), new((P, 3), **f32), new((P, 3), **f32)
+    dL_dconic, dL_dopacity, dL_dcov3D = new((P, 2, 2), **f32), new((P, 1), **f32), new((P, 6), **f32)
+    dL_dsh, dL_dscales, dL_drotations = new((P, M, 3), **f32), new((P, 3), **f32), new((P, 4), **f32)
+    dL_dextra = new((P, 4), **f32)
+    if P == 0:
+        return dL_dmeans2D, dL_dcolors, dL_dextra, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations
+    scratch = torch.empty((L.hgs_backward_scratch_bytes_multi(P, int(R)),), dtype=torch.uint8, device=dev)
+    dpix = rt.require_gpu_tensor(dL_dout_color7, "dL_dout_color", torch.float32)
+    bg_, sh_, colors_, scales_, rots_, cov_ = (_f32(background7, "bg"), _f32(sh, "sh"), _f32(colors, "colors_precomp"),
+                                               _f32(scales, "scales"), _f32(rotations, "rotations"),
+                                               _f32(cov3D_precomp, "cov3D_precomp"))
+    view_, proj_, cam_ = _f32(viewmatrix, "viewmatrix"), _f32(projmatrix, "projmatrix"), _f32(campos, "campos")
+    radii_ = rt.require_gpu_tensor(radii, "radii", torch.int32)
+    with torch.cuda.device(dev):
+        rt.check(L.hgs_backward_multi(rt.current_stream(), P, int(degree), M, int(R), W, H, rt.ptr(bg_), rt.ptr(means3D),
+                                      rt.ptr(sh_), rt.ptr(colors_), rt.ptr(scales_), float(scale_modifier), rt.ptr(rots_),
+                                      rt.ptr(cov_), rt.ptr(view_), rt.ptr(proj_), rt.ptr(cam_), float(tan_fovx),
+                                      float(tan_fovy), rt.ptr(radii_), rt.ptr(geomBuffer), rt.ptr(binningBuffer),
+                                      rt.ptr(imageBuffer), rt.ptr(dpix), rt.ptr(scratch), rt.ptr(dL_dextra),
+                                      rt.ptr(dL_dmeans2D), rt.ptr(dL_dconic), rt.ptr(dL_dopacity), rt.ptr(dL_dcolors),
+                                      rt.ptr(dL_dmeans3D), rt.ptr(dL_dcov3D), rt.ptr(dL_dsh), rt.ptr(dL_dscales),
+                                      rt.ptr(dL_drotations)))
+        if debug:
+            torch.cuda.synchronize(dev)
+    return dL_dmeans2D, dL_dcolors, dL_dextra, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations
 
 
 def mark_visible(means3D, viewmatrix, projmatrix):

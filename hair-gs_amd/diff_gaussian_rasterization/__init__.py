@@ -81,6 +81,41 @@ class _RasterizeGaussians(torch.autograd.Function):
                 _m(grad_scales, scales), _m(grad_rotations, rotations), _m(grad_cov3Ds_precomp, cov3Ds_precomp), None)
 
 
+class _RasterizeGaussiansMulti(torch.autograd.Function):
+    """Single-pass mode: RGB (from SH or precomputed colours) + 4 extra unclamped channels in one forward/backward.
+    `raster_settings.bg` must have 7 entries.  means2D's gradient is the RGB channels' screen-space gradient."""
+
+    @staticmethod
+    def forward(ctx, means3D, means2D, sh, colors_precomp, extra4, opacities, scales, rotations, cov3Ds_precomp,
+                raster_settings):
+        rs = raster_settings
+        num_rendered, color, radii, geomBuffer, binningBuffer, imgBuffer = _C.rasterize_gaussians_multi(
+            rs.bg, means3D, colors_precomp, extra4, opacities, scales, rotations, rs.scale_modifier, cov3Ds_precomp,
+            rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy, rs.image_height, rs.image_width, sh, rs.sh_degree,
+            rs.campos, rs.prefiltered, rs.debug)
+        ctx.raster_settings, ctx.num_rendered = rs, num_rendered
+        ctx.save_for_backward(colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geomBuffer,
+                              binningBuffer, imgBuffer)
+        ctx.mark_non_differentiable(radii)
+        return color, radii
+
+    @staticmethod
+    def backward(ctx, grad_out_color, _):
+        rs = ctx.raster_settings
+        colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geomBuffer, binningBuffer, imgBuffer = \
+            ctx.saved_tensors
+        (g_means2D, g_colors, g_extra, g_opac, g_means3D, g_cov, g_sh, g_scales, g_rot) = \
+            _C.rasterize_gaussians_multi_backward(rs.bg, means3D, radii, colors_precomp, scales, rotations,
+                                                  rs.scale_modifier, cov3Ds_precomp, rs.viewmatrix, rs.projmatrix,
+                                                  rs.tanfovx, rs.tanfovy, grad_out_color, sh, rs.sh_degree, rs.campos,
+                                                  geomBuffer, ctx.num_rendered, binningBuffer, imgBuffer, rs.debug)
+
+        def _m(g, ref):
+            return g if ref.numel() != 0 else None
+        return (g_means3D, g_means2D, _m(g_sh, sh), _m(g_colors, colors_precomp), g_extra, g_opac, _m(g_scales, scales),
+                _m(g_rot, rotations), _m(g_cov, cov3Ds_precomp), None)
+
+
 def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
                         raster_settings):
     return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
@@ -112,3 +147,17 @@ class GaussianRasterizer(nn.Module):
         rotations = empty if rotations is None else rotations
         cov3D_precomp = empty if cov3D_precomp is None else cov3D_precomp
         return rasterize_gaussians(means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, rs)
+
+    def forward_multi(self, means3D, means2D, opacities, extra4, shs=None, colors_precomp=None, scales=None,
+                      rotations=None, cov3D_precomp=None):
+        """Single-pass mode: returns (image[7,H,W], radii); channels 0-2 = RGB, 3-6 = the blended `extra4` [P,4]."""
+        if (shs is None) == (colors_precomp is None):
+            raise Exception("Please provide excatly one of either SHs or precomputed colors!")
+        if ((scales is None or rotations is None) and cov3D_precomp is None) or \
+                ((scales is not None or rotations is not None) and cov3D_precomp is not None):
+            raise Exception("Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!")
+        empty = torch.Tensor([])
+        return _RasterizeGaussiansMulti.apply(
+            means3D, means2D, empty if shs is None else shs, empty if colors_precomp is None else colors_precomp, extra4,
+            opacities, empty if scales is None else scales, empty if rotations is None else rotations,
+            empty if cov3D_precomp is None else cov3D_precomp, self.raster_settings)

@@ -51,3 +51,33 @@ def render(viewpoint_camera, pc, bg_color, scaling_modifier=1.0, override_color=
                                        cov3D_precomp=cov3D_precomp)
     return {"render": rendered_image, "viewspace_points": screenspace_points, "visibility_filter": radii > 0,
             "radii": radii}
+
+
+_BG7 = {}
+
+
+def render_multi(viewpoint_camera, pc, bg_color, extra4, scaling_modifier=1.0, debug=False):
+    """One traversal for RGB + 4 extra per-Gaussian channels.  Equivalent to render(...) plus
+    render(..., override_color=extra) on a black background, which is how the reference's mask and orientation losses
+    obtain their images (loss/losses.py:247,312).  Returns render()'s dict + "extra" [4,H,W]."""
+    xyz = pc.get_xyz
+    screenspace_points = torch.zeros_like(xyz, dtype=xyz.dtype, requires_grad=True, device=xyz.device) + 0
+    try:
+        screenspace_points.retain_grad()
+    except Exception:
+        pass
+    key = id(bg_color)
+    if key not in _BG7:  # RGB background + black for the extra channels (the reference's default bg of those passes)
+        _BG7[key] = (bg_color, torch.cat([bg_color.to(torch.float32), torch.zeros(4, device=bg_color.device)]))
+    bg7 = _BG7[key][1]
+    raster_settings = GaussianRasterizationSettings(
+        image_height=int(viewpoint_camera.image_height), image_width=int(viewpoint_camera.image_width),
+        tanfovx=math.tan(viewpoint_camera.FoVx * 0.5), tanfovy=math.tan(viewpoint_camera.FoVy * 0.5), bg=bg7,
+        scale_modifier=scaling_modifier, viewmatrix=viewpoint_camera.world_view_transform,
+        projmatrix=viewpoint_camera.full_proj_transform, sh_degree=pc.active_sh_degree,
+        campos=viewpoint_camera.camera_center, prefiltered=False, debug=debug)
+    image7, radii = GaussianRasterizer(raster_settings=raster_settings).forward_multi(
+        means3D=xyz, means2D=screenspace_points, opacities=pc.get_opacity, extra4=extra4, shs=pc.get_features,
+        scales=pc.get_scaling, rotations=pc.get_rotation)
+    return {"render": image7[:3], "extra": image7[3:], "viewspace_points": screenspace_points,
+            "visibility_filter": radii > 0, "radii": radii}

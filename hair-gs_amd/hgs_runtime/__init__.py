@@ -28,6 +28,11 @@ SIGNATURES = {
     "hgs_forward_render": (ci, [vp, ci, ci, ci, ci, vp, vp, vp, vp, vp, vp]),
     "hgs_backward": (ci, [vp, ci, ci, ci, ci, ci, ci, vp, vp, vp, vp, vp, cf, vp, vp, vp, vp, vp, cf, cf, vp, vp, vp,
                           vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
+    "hgs_binning_bytes_multi": (sz, [ci]),
+    "hgs_backward_scratch_bytes_multi": (sz, [ci, ci]),
+    "hgs_forward_render_multi": (ci, [vp, ci, ci, ci, ci, vp, vp, vp, vp, vp, vp, vp]),
+    "hgs_backward_multi": (ci, [vp, ci, ci, ci, ci, ci, ci, vp, vp, vp, vp, vp, cf, vp, vp, vp, vp, vp, cf, cf, vp, vp, vp,
+                                vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "hgs_mark_visible": (ci, [vp, ci, vp, vp, vp, vp]),
     "hgs_dist2_scratch_bytes": (sz, [ci]),
     "hgs_dist2": (ci, [vp, ci, vp, vp, vp, sz]),

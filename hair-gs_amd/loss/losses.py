@@ -139,6 +139,59 @@ def mask_loss_rast(gaussians, camera, args, bg=None):
     return F.binary_cross_entropy_with_logits(rendered, camera.float_mask)
 
 
+def _orientation_term(omap, gaussians, camera, bg):
+    """Everything of orientation_loss_rast after the render, on a [3,H,W] direction image."""
+    if fused_losses and omap.is_cuda:
+        from hgs_runtime.fused import orientation_loss
+        return orientation_loss(omap, camera.world_view_transform, _bg_host(bg), gaussians.min_val,
+                                camera.orientation_field, camera.orientation_confidence, camera.mask)
+    o = omap.permute(1, 2, 0)
+    h, w = o.shape[:2]
+    pix = (o.flatten(0, 1) @ camera.world_view_transform[:3, :3])[:, :2]
+    pix = pix / (torch.norm(pix, dim=1, keepdim=True) + gaussians.min_val)
+    x, y = pix[:, 0], pix[:, 1]
+    y = torch.where(y < gaussians.min_val, y + gaussians.min_val, y)
+    theta = torch.atan2(x, y)
+    theta = torch.where(theta < 0, theta + np.pi, theta).reshape(h, w)
+    mask = torch.any(o != bg, dim=2) if camera.mask is None else camera.mask
+    diff = bidirectional_angle_difference(theta, camera.orientation_field) * camera.orientation_confidence
+    m = mask.to(diff.dtype)
+    return (diff * m).sum() / m.sum()
+
+
+def loss_function_single_pass(gaussians, viewpoint_cam, args, bg):
+    """loss_function with ONE rasterizer traversal: RGB, the mask value and the world-space direction are blended
+    together (gaussian_renderer.render_multi) instead of three render() calls.  Same terms, same weights; returns
+    (loss, terms, render_pkg) where render_pkg is what render() would have returned for the RGB pass."""
+    from gaussian_renderer import render_multi
+    extra = torch.cat((gaussians.get_mask, gaussians.get_orientation), dim=1)      # [P, 1 + 3]
+    pkg = render_multi(viewpoint_cam, gaussians, bg, extra)
+    image, ex = pkg["render"], pkg["extra"]
+    gt = viewpoint_cam.original_image
+    if fused_losses and image.is_cuda:
+        from hgs_runtime.fused import ssim_l1
+        ssim_mean, l1_mean = ssim_l1(image, gt)
+        terms = {"l1": l1_mean, "dssim": 1.0 - ssim_mean}
+    else:
+        terms = {"l1": l1_loss(image, gt), "dssim": 1.0 - ssim(image, gt)}
+    loss = max(0, 1.0 - args.lambda_dssim) * terms["l1"] + args.lambda_dssim * terms["dssim"]
+    black = _black(image.device)
+    if args.lambda_mask > 0 and viewpoint_cam.mask is not None:
+        terms["mask"] = F.binary_cross_entropy_with_logits(ex[0], viewpoint_cam.float_mask)
+        loss = loss + args.lambda_mask * terms["mask"]
+    if args.lambda_orientation > 0:
+        terms["orientation"] = _orientation_term(ex[1:4], gaussians, viewpoint_cam, black)
+        loss = loss + args.lambda_orientation * terms["orientation"]
+    if isinstance(gaussians, HairGaussianModel):
+        if args.lambda_smooth > 0:
+            terms["smooth"] = angle_smoothness_loss(gaussians)
+            loss = loss + args.lambda_smooth * terms["smooth"]
+        if args.lambda_magnet > 0:
+            terms["magnet"] = strand_joints_magnet_loss(gaussians)
+            loss = loss + args.lambda_magnet * terms["magnet"]
+    return loss, terms, pkg
+
+
 def loss_function(gaussians, image, viewpoint_cam, args):
     """(1-l)L1 + l(1-SSIM) + l_mask BCE + l_orient orientation [+ l_smooth smoothness] (losses.py:319-355)."""
     gt = viewpoint_cam.original_image

@@ -16,7 +16,7 @@ import torch
 import torch.distributed as dist
 
 from gaussian_renderer import render
-from loss.losses import loss_function
+from loss.losses import loss_function, loss_function_single_pass
 from scene.hair_gaussian_model import HairGaussianModel
 
 
@@ -100,8 +100,12 @@ def _training_step(gaussians, viewpoint_cam, opt, bg, iteration, extent, vp, ras
     gaussians.update_learning_rate(iteration)
     if iteration % 1000 == 0:
         gaussians.oneupSHdegree()
-    render_pkg = render(viewpoint_cam, gaussians, bg)
-    loss, loss_dict = loss_function(gaussians, render_pkg["render"], viewpoint_cam, opt)
+    if getattr(opt, "single_pass", True) and gaussians.get_xyz.is_cuda:
+        # RGB + mask + orientation in one rasterizer traversal (same loss, 3x fewer raster passes)
+        loss, loss_dict, render_pkg = loss_function_single_pass(gaussians, viewpoint_cam, opt, bg)
+    else:
+        render_pkg = render(viewpoint_cam, gaussians, bg)
+        loss, loss_dict = loss_function(gaussians, render_pkg["render"], viewpoint_cam, opt)
     loss.backward()
     raster.check_async()  # async mode: the step's single synchronisation (raises -> step repeated); no-op otherwise
     with torch.no_grad():
@@ -192,8 +196,11 @@ class GraphedStep:
         self.slot.uid = cam.uid
 
     def _forward_backward(self):
-        pkg = render(self.slot, self.g, self.bg)
-        loss, _ = loss_function(self.g, pkg["render"], self.slot, self.opt)
+        if getattr(self.opt, "single_pass", True):
+            loss, _, pkg = loss_function_single_pass(self.g, self.slot, self.opt, self.bg)
+        else:
+            pkg = render(self.slot, self.g, self.bg)
+            loss, _ = loss_function(self.g, pkg["render"], self.slot, self.opt)
         loss.backward()
         with torch.no_grad():
             self.g.update_densification_stats(pkg["viewspace_points"], pkg["radii"], pkg["visibility_filter"])

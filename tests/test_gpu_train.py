@@ -280,3 +280,45 @@ def test_training_loop_with_topology_changes(use_graph):
         p = g["params"][0]
         assert torch.isfinite(p).all() and p.shape[0] == (model._endpoints.shape[0] if g["name"] == "endpoints" else P1)
     assert float(model.get_opacity.max()) < 0.9               # opacity reset happened at it 12
+
+
+def test_single_pass_equals_three_passes():
+    """render_multi (7 channels, one traversal) vs the reference's three render() calls: identical images, gradients
+    equal up to fp32 summation order, RGB-only screen-space gradient for the densification statistics."""
+    from arguments import OptimizationParams
+    from gaussian_renderer import render, render_multi
+    from loss import losses as Ls
+    from synthetic import build_workload
+    model, cams, _ = build_workload("tiny", device="cuda", with_targets=True)
+    cam = cams[1]
+    bg = torch.zeros(3, device="cuda")
+    extra = torch.cat((model.get_mask, model.get_orientation), dim=1)
+    with torch.no_grad():
+        a = render(cam, model, bg)["render"]
+        m = render(cam, model, bg, override_color=model.get_mask.repeat(1, 3))["render"][0]
+        o = render(cam, model, bg, override_color=model.get_orientation)["render"]
+        pk = render_multi(cam, model, bg, extra)
+    assert torch.equal(pk["render"], a) and torch.equal(pk["extra"][0], m) and torch.equal(pk["extra"][1:4], o)
+    opt = OptimizationParams()
+    res = {}
+    for single in (False, True):
+        model._derived = None
+        for g in model.optimizer.param_groups if model.optimizer else []:
+            pass
+        for p in (model._endpoints, model._features_dc, model._opacity, model._mask, model._width):
+            p.grad = None
+        if single:
+            loss, terms, pkg = Ls.loss_function_single_pass(model, cam, opt, bg)
+        else:
+            pkg = render(cam, model, bg)
+            loss, terms = Ls.loss_function(model, pkg["render"], cam, opt)
+        loss.backward()
+        res[single] = (float(loss), {k: float(v) for k, v in terms.items()}, pkg["viewspace_points"].grad.clone(),
+                       [p.grad.clone() for p in (model._endpoints, model._features_dc, model._opacity, model._mask, model._width)])
+    assert abs(res[True][0] - res[False][0]) <= 1e-5 * abs(res[False][0])
+    for k in res[False][1]:
+        assert abs(res[True][1][k] - res[False][1][k]) <= 1e-5 * max(1e-6, abs(res[False][1][k])), k
+    vs_t, vs_f = res[True][2], res[False][2]
+    assert (vs_t - vs_f).abs().max() <= 2e-4 * vs_f.abs().max()          # RGB-only dL/dmean2D
+    for gt_, gf_ in zip(res[True][3], res[False][3]):
+        assert (gt_ - gf_).abs().max() <= 2e-4 * gf_.abs().max()
