@@ -42,6 +42,8 @@ def parse():
     ap.add_argument("--views", type=int, default=None, help="override the number of camera views")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true", help="disable per-kernel HIP-event timing")
+    ap.add_argument("--three-pass", action="store_true",
+                    help="three separate raster passes per iteration like the reference instead of the single 7-channel pass")
     ap.add_argument("--eager", action="store_true", help="eager dispatch of every kernel instead of replaying the captured HIP graph")
     ap.add_argument("--blocking", action="store_true",
                     help="reference-style forward (host reads num_rendered in every pass) instead of the async capacity mode")
@@ -100,6 +102,7 @@ def main():
     safe_state(True)
     model, cams, extent = build_workload(args.workload, device=dev, seed=0, n_views=args.views)
     opt = OptimizationParams()
+    opt.single_pass = not args.three_pass
     opt.enable_topology = False  # densify/merge intervals (every 100 it) are reported separately, not in the timed loop
     model.training_setup(opt)
     bg = torch.zeros(3, dtype=torch.float32, device=dev)
@@ -202,18 +205,23 @@ def main():
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt * 1e3 / args.steps, "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"{args.workload}: {P} strand-Gaussians, {len(cams)} views @ {W}x{H}, 1 view/GPU/step, "
-                               "3 raster fwd+bwd passes + L1/DSSIM/mask/orientation/smoothness losses + Adam",
+                               "RGB+mask+orientation raster fwd+bwd + L1/DSSIM/mask/orientation/smoothness losses + Adam",
                    "gaussians": P, "views": len(cams), "width": W, "height": H, "parallelism": f"view-parallel x{world}",
                    "mean_num_rendered": meanR, "mean_sum_tile_list_len": meanL,
                    "forward_mode": "blocking" if args.blocking else "async-capacity",
-                   "dispatch": "hip-graph replay" if use_graph else "eager"},
+                   "dispatch": "hip-graph replay" if use_graph else "eager",
+                   "raster_passes_per_iter": 1 if getattr(opt, "single_pass", True) else 3},
         "render_ms_per_view": render_ms,
     }
     if kern:
         bwd_ms, bwd_n = kern["blend_bwd_kernel"]
         fwd_ms, fwd_n = kern["blend_fwd_kernel"]
-        bytes_bwd = 76.0 * meanL + 20.0 * W * H + 8.0 * T
-        bytes_fwd = 40.0 * meanL + 20.0 * W * H + 8.0 * T
+        # algorithmic bytes per launch: per needed tile entry the packed record is read once and one row of
+        # partial sums is written; per pixel the upstream gradient (4 B x channels) + final_T + n_contrib are read
+        ch = 7 if getattr(opt, "single_pass", True) else 3
+        rec_b, part_b = (64.0, 60.0) if ch == 7 else (48.0, 36.0)
+        bytes_bwd = (rec_b + part_b) * meanL + (4.0 * ch + 8.0) * W * H + 8.0 * T
+        bytes_fwd = rec_b * meanL + (4.0 * ch + 8.0) * W * H + 8.0 * T
         ach = bytes_bwd / (bwd_ms / max(bwd_n, 1) * 1e-3) / 1e9 if bwd_ms > 0 else 0.0
         result["roofline"] = {"kernel": "blend_bwd_kernel", "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS,
                               "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
