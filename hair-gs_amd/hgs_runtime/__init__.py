@@ -43,6 +43,10 @@ SIGNATURES = {
     "hgs_orientation_loss_num_blocks": (ci, [ci, ci]),
     "hgs_orientation_loss_forward": (ci, [vp, ci, ci, vp, vp, vp, cf, vp, vp, vp, vp]),
     "hgs_orientation_loss_backward": (ci, [vp, ci, ci, vp, vp, vp, cf, vp, vp, vp, vp, vp, vp]),
+    "hgs_adam_step": (ci, [vp, ci, vp, vp, vp, vp, vp, vp, vp, cf, cf, cf]),
+    "hgs_smoothness_num_blocks": (ci, [ci]),
+    "hgs_smoothness_forward": (ci, [vp, ci, vp, vp, cf, cf, vp]),
+    "hgs_smoothness_backward": (ci, [vp, ci, ci, vp, vp, cf, cf, vp, vp, vp]),
     "hgs_strand_geometry_forward": (ci, [vp, ci, vp, vp, vp, cf, vp, vp, vp, vp]),
     "hgs_strand_geometry_backward": (ci, [vp, ci, ci, vp, vp, vp, cf, vp, vp, vp, vp, vp, vp]),
     "hgs_prof_enable": (ci, [ci]),
@@ -113,7 +117,7 @@ def require_gpu_tensor(t, name, dtype=None):
     return t.contiguous()
 
 
-KERNEL_COUNT = 14
+KERNEL_COUNT = 16
 
 
 def prof_enable(on=True):

@@ -137,3 +137,97 @@ class _OrientationLoss(torch.autograd.Function):
 
 def orientation_loss(omap, viewmatrix, bg3, min_val, gt_theta, confidence, mask):
     return _OrientationLoss.apply(omap, viewmatrix, bg3, min_val, gt_theta, confidence, mask)
+
+
+class _SmoothnessLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, endpoints, index_pairs, cos_th, eps):
+        endpoints = rt.require_gpu_tensor(endpoints, "endpoints", torch.float32)
+        idx = rt.require_gpu_tensor(index_pairs, "index_pairs", torch.int64)
+        N, dev, L = idx.shape[0], endpoints.device, rt.lib()
+        partials = torch.empty((max(L.hgs_smoothness_num_blocks(N), 1), 2), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            rt.check(L.hgs_smoothness_forward(rt.current_stream(), N, rt.ptr(endpoints), rt.ptr(idx), float(cos_th),
+                                              float(eps), rt.ptr(partials)))
+        sums = partials.sum(dim=0)
+        ctx.save_for_backward(endpoints, idx, sums)
+        ctx.consts = (float(cos_th), float(eps))
+        return sums[0] / torch.clamp(sums[1], min=1.0)
+
+    @staticmethod
+    def backward(ctx, g):
+        endpoints, idx, sums = ctx.saved_tensors
+        cos_th, eps = ctx.consts
+        g = g.contiguous().to(torch.float32)
+        count = sums[1:2].contiguous()
+        d = torch.empty_like(endpoints)
+        with torch.cuda.device(endpoints.device):
+            rt.check(rt.lib().hgs_smoothness_backward(rt.current_stream(), idx.shape[0], endpoints.shape[0],
+                                                      rt.ptr(endpoints), rt.ptr(idx), cos_th, eps, rt.ptr(g),
+                                                      rt.ptr(count), rt.ptr(d)))
+        return d, None, None, None
+
+
+def smoothness_loss(endpoints, index_pairs, cos_th, eps):
+    """Mean squared bending angle over the consecutive-segment pairs bent beyond the threshold (0 if none)."""
+    return _SmoothnessLoss.apply(endpoints, index_pairs, cos_th, eps)
+
+
+class FusedAdam(torch.optim.Optimizer):
+    """Adam with the reference's settings (eps 1e-15, betas (0.9, 0.999), no weight decay, one group per tensor, per-group
+    lr) whose whole update is ONE kernel launch (hgs_adam_step).  State layout (`exp_avg`, `exp_avg_sq`, `step` per
+    parameter) is torch.optim.Adam's, so the models' optimizer-state surgery works unchanged.  `lr` of a group may be a
+    Python float or a device scalar tensor (the latter is what graph capture needs)."""
+
+    def __init__(self, params, lr=0.0, betas=(0.9, 0.999), eps=1e-15):
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
+        self._lr_dev = {}
+        self._call = None
+
+    def _state_for(self, p):
+        st = self.state[p]
+        if len(st) == 0:
+            st["step"] = torch.zeros((), dtype=torch.float32, device=p.device)
+            st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+            st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+        return st
+
+    def _lr_tensor(self, gi, group, dev):
+        lr = group["lr"]
+        if torch.is_tensor(lr):
+            return lr
+        cached = self._lr_dev.get(gi)
+        if cached is None or cached[0] != float(lr) or cached[1].device != dev:
+            t = cached[1] if cached is not None and cached[1].device == dev else torch.empty((), dtype=torch.float32, device=dev)
+            t.fill_(float(lr))
+            cached = (float(lr), t)
+            self._lr_dev[gi] = cached
+        return cached[1]
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        rows = []
+        for gi, group in enumerate(self.param_groups):
+            for p in group["params"]:
+                if p.grad is None or p.numel() == 0:
+                    continue
+                if not p.is_cuda:
+                    raise rt.HgsError("FusedAdam runs on the GPU only")
+                st = self._state_for(p)
+                rows.append((p, p.grad.contiguous(), st["exp_avg"], st["exp_avg_sq"], self._lr_tensor(gi, group, p.device),
+                             st["step"], group))
+        if not rows:
+            return None
+        beta1, beta2 = rows[0][6]["betas"]
+        eps = rows[0][6]["eps"]
+        key = tuple(t.data_ptr() for r in rows for t in r[:6])
+        if self._call is None or self._call[0] != key:
+            n = len(rows)
+            arrs = [(C.c_void_p * n)(*[r[j].data_ptr() for r in rows]) for j in range(6)]
+            numel = (C.c_longlong * n)(*[r[0].numel() for r in rows])
+            self._call = (key, n, arrs, numel)
+        _, n, arrs, numel = self._call
+        with torch.cuda.device(rows[0][0].device):
+            rt.check(rt.lib().hgs_adam_step(rt.current_stream(), n, arrs[0], arrs[1], arrs[2], arrs[3], arrs[4], arrs[5],
+                                            numel, float(beta1), float(beta2), float(eps)))
+        return None

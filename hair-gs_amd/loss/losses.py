@@ -69,6 +69,9 @@ def angle_smoothness_loss(gaussians: HairGaussianModel, threshold: float = 30, e
     idx = gaussians.smoothness_index_pairs()
     if idx.shape[0] == 0:
         return 0
+    if fused_losses and gaussians._endpoints.is_cuda:
+        from hgs_runtime.fused import smoothness_loss
+        return smoothness_loss(gaussians._endpoints, idx, float(cos_th), float(eps))
     pos = gaussians._endpoints[idx]                      # (N, 2, 2, 3)
     d = pos[:, :, 1] - pos[:, :, 0]
     d = d / torch.norm(d, dim=2, keepdim=True)

@@ -147,10 +147,17 @@ class GaussianModel:
 
     _POSITION_GROUP = "xyz"
 
-    def _adam_kwargs(self):
-        """Same Adam as the reference (lr=0, eps=1e-15, per-tensor groups); on the GPU the update of each group runs as
-        ONE fused multi-tensor kernel instead of ~5 foreach kernels (identical update rule)."""
-        return {"fused": True} if str(self.device).startswith("cuda") or getattr(self.device, "type", "") == "cuda" else {}
+    fused_adam = True
+
+    def _make_optimizer(self, groups):
+        """Adam exactly as the reference configures it (lr=0 default, eps=1e-15, one group per tensor).  On the GPU the
+        update of all groups is one fused launch (hgs_runtime.fused.FusedAdam, same update rule, same state layout);
+        `fused_adam = False` or CPU tensors use torch.optim.Adam."""
+        on_gpu = str(self.device).startswith("cuda") or getattr(self.device, "type", "") == "cuda"
+        if self.fused_adam and on_gpu:
+            from hgs_runtime.fused import FusedAdam
+            return FusedAdam(groups, lr=0.0, eps=1e-15)
+        return torch.optim.Adam(groups, lr=0.0, eps=1e-15)
 
     def _num_primitives(self):
         return self.get_xyz.shape[0]
@@ -167,7 +174,7 @@ class GaussianModel:
         self.denom = torch.zeros((n, 1), device=self.device)
         lrs = self._group_lrs(training_args)
         groups = [{"params": [getattr(self, attr)], "lr": lrs[name], "name": name} for name, attr in self._PARAM_ATTRS]
-        self.optimizer = torch.optim.Adam(groups, lr=0.0, eps=1e-15, **self._adam_kwargs())
+        self.optimizer = self._make_optimizer(groups)
         self.xyz_scheduler_args = get_expon_lr_func(
             lr_init=training_args.position_lr_init * self.spatial_lr_scale,
             lr_final=training_args.position_lr_final * self.spatial_lr_scale,

@@ -153,7 +153,7 @@ class HairGaussianModel(HairTopologyMixin, GaussianModel):
         self.denom = torch.zeros((n, 1), device=self.device)
         lrs = self._group_lrs(training_args)
         groups = [{"params": [getattr(self, attr)], "lr": lrs[name], "name": name} for name, attr in self._PARAM_ATTRS]
-        self.optimizer = torch.optim.Adam(groups, lr=0.0, eps=1e-15, **self._adam_kwargs())
+        self.optimizer = self._make_optimizer(groups)
         ta = training_args
 
         def sched(a, b):

@@ -164,7 +164,8 @@ class GraphedStep:
         opt_ = self.g.optimizer
         dev = self.g.get_xyz.device
         for group in opt_.param_groups:
-            group["capturable"] = True
+            if isinstance(opt_, torch.optim.Adam):
+                group["capturable"] = True
             if not torch.is_tensor(group["lr"]):
                 group["lr"] = torch.tensor(float(group["lr"]), dtype=torch.float32, device=dev)
             for p in group["params"]:

@@ -148,6 +148,21 @@ int hgs_orientation_loss_forward(void* stream, int H, int W, const float* omap, 
 int hgs_orientation_loss_backward(void* stream, int H, int W, const float* omap, const float* viewmatrix,
                                   const float* bg3_host, float min_val, const float* gt_theta, const float* confidence,
                                   const uint8_t* mask, const float* g_loss, const float* mask_count, float* d_omap);
+/* hgs_adam_step <-> torch.optim.Adam(lr=0, eps=1e-15) as built at scene/gaussian_model.py:250 and
+ *   scene/hair_gaussian_model.py:246: all parameter tensors (<= 8) updated by ONE launch.  The six arrays are HOST arrays
+ *   of n_tensors DEVICE pointers; lr[k] and step[k] point to fp32 device scalars (step is incremented by the call).
+ * hgs_smoothness_forward/backward <-> loss/losses.py:175-221 angle_smoothness_loss: index_pairs is the int64 [N,2,2]
+ *   table of consecutive strand segments (endpoint ids); partials: 2 floats per 256 pairs (sum of squared angles of the
+ *   pairs bent more than the threshold, their count); loss = sum0 / max(sum1, 1).  backward zeroes d_endpoints [E,3]
+ *   and scatters with fp32 atomics (order-dependent in the last bits). */
+int hgs_adam_step(void* stream, int n_tensors, float* const* params, const float* const* grads, float* const* exp_avg,
+                  float* const* exp_avg_sq, const float* const* lr, float* const* step, const long long* numel,
+                  float beta1, float beta2, float eps);
+int hgs_smoothness_num_blocks(int N);
+int hgs_smoothness_forward(void* stream, int N, const float* endpoints, const long long* index_pairs,
+                           float cos_threshold, float eps, float* partials);
+int hgs_smoothness_backward(void* stream, int N, int E, const float* endpoints, const long long* index_pairs,
+                            float cos_threshold, float eps, const float* g_loss, const float* count, float* d_endpoints);
 int hgs_strand_geometry_forward(void* stream, int P, const float* endpoints, const long long* endpoint_pairs,
                                 const float* width, float dist_to_scale_factor, float* xyz, float* scale, float* quat,
                                 float* dir);
@@ -161,7 +176,7 @@ int hgs_strand_geometry_backward(void* stream, int P, int E, const float* endpoi
  * No reference counterpart (the reference only times whole iterations, train.py:81-82,133,156). ---- */
 enum { HGS_K_PREPROCESS_FWD = 0, HGS_K_SCAN, HGS_K_SCATTER, HGS_K_SORT_TILES, HGS_K_BLEND_FWD, HGS_K_BLEND_BWD,
        HGS_K_PREPROCESS_BWD, HGS_K_KNN, HGS_K_SSIM_FWD, HGS_K_SSIM_BWD, HGS_K_STRAND_FWD, HGS_K_STRAND_BWD,
-       HGS_K_ORI_FWD, HGS_K_ORI_BWD, HGS_K_COUNT };
+       HGS_K_ORI_FWD, HGS_K_ORI_BWD, HGS_K_ADAM, HGS_K_SMOOTH, HGS_K_COUNT };
 int hgs_prof_enable(int on);
 int hgs_prof_collect(double* total_ms, long long* launches);
 const char* hgs_prof_kernel_name(int kernel_id);

@@ -322,3 +322,44 @@ def test_single_pass_equals_three_passes():
     assert (vs_t - vs_f).abs().max() <= 2e-4 * vs_f.abs().max()          # RGB-only dL/dmean2D
     for gt_, gf_ in zip(res[True][3], res[False][3]):
         assert (gt_ - gf_).abs().max() <= 2e-4 * gf_.abs().max()
+
+
+def test_fused_adam_matches_torch_adam():
+    from hgs_runtime.fused import FusedAdam
+    g = torch.Generator(device="cuda").manual_seed(0)
+    shapes = [(1000, 3), (777, 1, 3), (777, 1), (5,), (64, 4)]
+    ref_p = [torch.randn(s, device="cuda", generator=g).requires_grad_(True) for s in shapes]
+    my_p = [p.detach().clone().requires_grad_(True) for p in ref_p]
+    lrs = [1.6e-4, 0.025, 0.05, 0.01, 0.005]
+    ref = torch.optim.Adam([{"params": [p], "lr": lr} for p, lr in zip(ref_p, lrs)], lr=0.0, eps=1e-15)
+    mine = FusedAdam([{"params": [p], "lr": lr} for p, lr in zip(my_p, lrs)], lr=0.0, eps=1e-15)
+    for it in range(25):
+        for a, b in zip(ref_p, my_p):
+            gr = torch.randn(a.shape, device="cuda", generator=g) * (10.0 ** ((it % 5) - 3))
+            a.grad, b.grad = gr.clone(), gr.clone()
+        if it == 10:
+            ref.param_groups[0]["lr"] = mine.param_groups[0]["lr"] = 3e-5     # lr schedule change
+        ref.step()
+        mine.step()
+    for a, b in zip(ref_p, my_p):
+        assert (a - b).abs().max() <= 2e-6 * max(1.0, float(a.abs().max()))
+    assert float(mine.state[my_p[0]]["step"]) == 25.0
+
+
+def test_fused_smoothness_matches_torch_ops():
+    from loss import losses as Ls
+    from synthetic import make_strand_model
+    m = make_strand_model(60, 25, device="cuda")
+    m.compute_strands_info()
+    out = {}
+    for fused in (False, True):
+        Ls.fused_losses = fused
+        m._endpoints.grad = None
+        v = Ls.angle_smoothness_loss(m, threshold=3.0)
+        v.backward()
+        out[fused] = (float(v), m._endpoints.grad.clone())
+    Ls.fused_losses = True
+    assert out[False][0] > 0 and abs(out[True][0] - out[False][0]) <= 2e-5 * out[False][0]
+    assert (out[True][1] - out[False][1]).abs().max() <= 2e-4 * out[False][1].abs().max()
+    Ls.fused_losses = True
+    assert float(Ls.angle_smoothness_loss(m, threshold=179.0)) == 0.0      # nothing selected -> 0
