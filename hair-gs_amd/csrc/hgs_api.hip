@@ -185,14 +185,16 @@ static int backward_impl(void* stream, int P, int D, int M, int R, int W, int H,
                          const float* shs, const float* colors_precomp, const float* scales, float scale_modifier,
                          const float* rotations, const float* cov3D_precomp, const float* viewmatrix,
                          const float* projmatrix, const float* campos, float tan_fovx, float tan_fovy, const int* radii,
-                         const void* geom_buf, const void* binning_buf, const void* image_buf, const float* dL_dpix,
-                         void* scratch, int n_extra, float* dL_dextra, float* dL_dmeans2D, float* dL_dconic,
+                         const void* geom_buf, const void* binning_buf, const void* image_buf,
+                         const float* const* dL_dpix_planes, void* scratch, int n_extra, float* dL_dextra, float* dL_dmeans2D, float* dL_dconic,
                          float* dL_dopacity, float* dL_dcolors, float* dL_dmeans3D, float* dL_dcov3D, float* dL_dsh,
                          float* dL_dscales, float* dL_drotations) {
   hipStream_t s = (hipStream_t)stream;
   if (P == 0) return 0;  // rasterize_points.cu:161
   if (check_aligned(geom_buf, "geom_buf") || check_aligned(image_buf, "image_buf")) return 1;
-  if (!dL_dpix || !radii || !means3D) { hgs_set_error("null required input"); return 1; }
+  if (!dL_dpix_planes || !radii || !means3D) { hgs_set_error("null required input"); return 1; }
+  for (int k = 0; k < 3 + n_extra; k++)
+    if (!dL_dpix_planes[k]) { hgs_set_error("null dL_dpix plane %d", k); return 1; }
   if (!dL_dmeans2D || !dL_dconic || !dL_dopacity || !dL_dcolors || !dL_dmeans3D || !dL_dcov3D || !dL_dscales ||
       !dL_drotations || (shs && !dL_dsh) || (n_extra && !dL_dextra)) { hgs_set_error("null gradient output"); return 1; }
   const int channels = 3 + n_extra, row = n_extra ? 16 : HGS_INST_GRAD_FLOATS;
@@ -207,7 +209,7 @@ static int backward_impl(void* stream, int P, int D, int M, int R, int W, int H,
     hgs_binning_carve((char*)binning_buf, (size_t)R, b, nullptr, channels);
     inst_grad = (float*)scratch;
     if (hgs_zero_async(s, inst_grad, (size_t)R * row * sizeof(float))) return 1;
-    if (hgs_launch_blend_bwd(s, W, H, R, channels, bg, im, b, dL_dpix, inst_grad)) return 1;
+    if (hgs_launch_blend_bwd(s, W, H, R, channels, bg, im, b, dL_dpix_planes, inst_grad)) return 1;
   }
   HgsBwdArgs a;
   a.P = P; a.D = D; a.M = M; a.W = W; a.H = H;
@@ -228,9 +230,12 @@ int hgs_backward(void* stream, int P, int D, int M, int R, int W, int H, const f
                  const void* binning_buf, const void* image_buf, const float* dL_dpix, void* scratch,
                  float* dL_dmeans2D, float* dL_dconic, float* dL_dopacity, float* dL_dcolors, float* dL_dmeans3D,
                  float* dL_dcov3D, float* dL_dsh, float* dL_dscales, float* dL_drotations) {
+  if (!dL_dpix && P > 0) { hgs_set_error("null dL_dpix"); return 1; }
+  const size_t HW = (size_t)H * W;
+  const float* planes[3] = {dL_dpix, dL_dpix + HW, dL_dpix + 2 * HW};
   return backward_impl(stream, P, D, M, R, W, H, bg, means3D, shs, colors_precomp, scales, scale_modifier, rotations,
                        cov3D_precomp, viewmatrix, projmatrix, campos, tan_fovx, tan_fovy, radii, geom_buf, binning_buf,
-                       image_buf, dL_dpix, scratch, 0, nullptr, dL_dmeans2D, dL_dconic, dL_dopacity, dL_dcolors,
+                       image_buf, planes, scratch, 0, nullptr, dL_dmeans2D, dL_dconic, dL_dopacity, dL_dcolors,
                        dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations);
 }
 
@@ -238,13 +243,13 @@ int hgs_backward_multi(void* stream, int P, int D, int M, int R, int W, int H, c
                        const float* shs, const float* colors_precomp, const float* scales, float scale_modifier,
                        const float* rotations, const float* cov3D_precomp, const float* viewmatrix,
                        const float* projmatrix, const float* campos, float tan_fovx, float tan_fovy, const int* radii,
-                       const void* geom_buf, const void* binning_buf, const void* image_buf, const float* dL_dpix7,
-                       void* scratch, float* dL_dextra4, float* dL_dmeans2D_rgb, float* dL_dconic, float* dL_dopacity,
+                       const void* geom_buf, const void* binning_buf, const void* image_buf,
+                       const float* const* dL_dpix_planes7, void* scratch, float* dL_dextra4, float* dL_dmeans2D_rgb, float* dL_dconic, float* dL_dopacity,
                        float* dL_dcolors, float* dL_dmeans3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscales,
                        float* dL_drotations) {
   return backward_impl(stream, P, D, M, R, W, H, bg7, means3D, shs, colors_precomp, scales, scale_modifier, rotations,
                        cov3D_precomp, viewmatrix, projmatrix, campos, tan_fovx, tan_fovy, radii, geom_buf, binning_buf,
-                       image_buf, dL_dpix7, scratch, 4, dL_dextra4, dL_dmeans2D_rgb, dL_dconic, dL_dopacity, dL_dcolors,
+                       image_buf, dL_dpix_planes7, scratch, 4, dL_dextra4, dL_dmeans2D_rgb, dL_dconic, dL_dopacity, dL_dcolors,
                        dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations);
 }
 

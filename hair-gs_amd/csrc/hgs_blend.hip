@@ -143,6 +143,8 @@ __global__ __launch_bounds__(HGS_BLOCK) void blend_fwd_kernel(const uint2* __res
 }
 
 // ------------------------------------------------------------------------------------------------
+template <int C> struct PixGrad { const float* plane[C]; };  // dL/d(output channel k) as [H,W] planes (need not be adjacent)
+
 template <int C>
 __global__ __launch_bounds__(HGS_BLOCK) void blend_bwd_kernel(const uint2* __restrict__ ranges,
                                                               const float4* __restrict__ packed, int W, int H, int gx,
@@ -150,7 +152,7 @@ __global__ __launch_bounds__(HGS_BLOCK) void blend_bwd_kernel(const uint2* __res
                                                               const float* __restrict__ final_Ts,
                                                               const uint32_t* __restrict__ n_contrib,
                                                               const uint32_t* __restrict__ tile_maxc,
-                                                              const float* __restrict__ dL_dpix,
+                                                              PixGrad<C> dL_dpix,
                                                               float* __restrict__ inst_grad) {
   constexpr int REC4 = Chan<C>::REC4, NPART = Chan<C>::NPART, NREG = Chan<C>::NREG, NV = 4 * NREG, ROW = Chan<C>::ROW;
   __shared__ float part[4][BWD_BATCH][NV];
@@ -164,7 +166,7 @@ __global__ __launch_bounds__(HGS_BLOCK) void blend_bwd_kernel(const uint2* __res
   const int py = ty * HGS_TILE + (wave >> 1) * 8 + (lane >> 3);
   const bool inside = px < W && py < H;
   const float pxf = (float)px, pyf = (float)py;
-  const size_t pix = (size_t)py * W + px, HW = (size_t)H * W;
+  const size_t pix = (size_t)py * W + px;
 
   const float T_final = inside ? final_Ts[pix] : 0.f;
   float T = T_final;
@@ -173,7 +175,7 @@ __global__ __launch_bounds__(HGS_BLOCK) void blend_bwd_kernel(const uint2* __res
   float bg_dot = 0.f, bg_dot_rgb = 0.f;                                       // backward_distwar.cu:988-990
 #pragma unroll
   for (int k = 0; k < C; k++) {
-    dpx[k] = inside ? dL_dpix[k * HW + pix] : 0.f;
+    dpx[k] = inside ? dL_dpix.plane[k][pix] : 0.f;
     acc[k] = 0.f; lc[k] = 0.f;
     bg_dot += bg[k] * dpx[k];
     if (k < 3) bg_dot_rgb += bg[k] * dpx[k];
@@ -289,16 +291,21 @@ int hgs_launch_blend_fwd(hipStream_t s, int W, int H, int Rcap, int channels, co
 }
 
 int hgs_launch_blend_bwd(hipStream_t s, int W, int H, int Rcap, int channels, const float* bg, const HgsImage& im,
-                         const HgsBinning& b, const float* dL_dpix, float* inst_grad) {
+                         const HgsBinning& b, const float* const* dL_dpix_planes, float* inst_grad) {
   const int gx = (W + HGS_TILE - 1) / HGS_TILE, gy = (H + HGS_TILE - 1) / HGS_TILE;
   {
     HgsProfScope _prof(s, HGS_K_BLEND_BWD);
-    if (channels == 3)
+    if (channels == 3) {
+      PixGrad<3> pg;
+      for (int k = 0; k < 3; k++) pg.plane[k] = dL_dpix_planes[k];
       hipLaunchKernelGGL(blend_bwd_kernel<3>, dim3(gx * gy), dim3(HGS_BLOCK), 0, s, im.ranges, b.packed, W, H, gx,
-                         (uint32_t)Rcap, bg, im.final_T, im.n_contrib, im.tile_maxc, dL_dpix, inst_grad);
-    else
+                         (uint32_t)Rcap, bg, im.final_T, im.n_contrib, im.tile_maxc, pg, inst_grad);
+    } else {
+      PixGrad<7> pg;
+      for (int k = 0; k < 7; k++) pg.plane[k] = dL_dpix_planes[k];
       hipLaunchKernelGGL(blend_bwd_kernel<7>, dim3(gx * gy), dim3(HGS_BLOCK), 0, s, im.ranges, b.packed, W, H, gx,
-                         (uint32_t)Rcap, bg, im.final_T, im.n_contrib, im.tile_maxc, dL_dpix, inst_grad);
+                         (uint32_t)Rcap, bg, im.final_T, im.n_contrib, im.tile_maxc, pg, inst_grad);
+    }
   }
   HGS_CHECK_LAUNCH();
   return 0;

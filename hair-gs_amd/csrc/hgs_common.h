@@ -126,7 +126,7 @@ int hgs_launch_sort_tiles(hipStream_t s, int W, int H, int Rcap, const float* fe
 int hgs_launch_blend_fwd(hipStream_t s, int W, int H, int Rcap, int channels, const float* bg, const HgsImage& im,
                          const HgsBinning& b, float* out_color);
 int hgs_launch_blend_bwd(hipStream_t s, int W, int H, int Rcap, int channels, const float* bg, const HgsImage& im,
-                         const HgsBinning& b, const float* dL_dpix, float* inst_grad);
+                         const HgsBinning& b, const float* const* dL_dpix_planes, float* inst_grad);
 struct HgsBwdArgs {
   int P, D, M, W, H;
   const float *means3D, *shs, *colors_precomp, *scales, *rotations, *cov3D_precomp;

@@ -169,14 +169,15 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
 
 
 def rasterize_gaussians_multi_backward(background7, means3D, radii, colors, scales, rotations, scale_modifier,
-                                       cov3D_precomp, viewmatrix, projmatrix, tan_fovx, tan_fovy, dL_dout_color7, sh,
+                                       cov3D_precomp, viewmatrix, projmatrix, tan_fovx, tan_fovy, grad_planes, sh,
                                        degree, campos, geomBuffer, R, binningBuffer, imageBuffer, debug):
-    """Backward of the single-pass mode (hgs_backward_multi).  Returns (dL_dmeans2D_rgb, dL_dcolors, dL_dextra4,
-    dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations)."""
+    """Backward of the single-pass mode (hgs_backward_multi).  `grad_planes`: list of 7 contiguous [H,W] tensors (views
+    into larger gradient tensors are fine).  Returns (dL_dmeans2D_rgb, dL_dcolors, dL_dextra4, dL_dopacity,
+    dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations)."""
     L = rt.lib()
     means3D = rt.require_gpu_tensor(means3D, "means3D", torch.float32)
     dev, P = means3D.device, means3D.shape[0]
-    H, W = int(dL_dout_color7.shape[1]), int(dL_dout_color7.shape[2])
+    H, W = int(grad_planes[0].shape[-2]), int(grad_planes[0].shape[-1])
     M = sh.shape[1] if (sh is not None and sh.numel() != 0) else 0
     f32 = dict(dtype=torch.float32, device=dev)
     new = torch.empty if P > 0 else torch.zeros
@@ -187,7 +188,8 @@ def rasterize_gaussians_multi_backward(background7, means3D, radii, colors, scal
     if P == 0:
         return dL_dmeans2D, dL_dcolors, dL_dextra, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations
     scratch = torch.empty((L.hgs_backward_scratch_bytes_multi(P, int(R)),), dtype=torch.uint8, device=dev)
-    dpix = rt.require_gpu_tensor(dL_dout_color7, "dL_dout_color", torch.float32)
+    planes = [rt.require_gpu_tensor(g, "grad plane", torch.float32) for g in grad_planes]
+    plane_ptrs = (C.c_void_p * 7)(*[g.data_ptr() for g in planes])
     bg_, sh_, colors_, scales_, rots_, cov_ = (_f32(background7, "bg"), _f32(sh, "sh"), _f32(colors, "colors_precomp"),
                                                _f32(scales, "scales"), _f32(rotations, "rotations"),
                                                _f32(cov3D_precomp, "cov3D_precomp"))
@@ -198,7 +200,7 @@ def rasterize_gaussians_multi_backward(background7, means3D, radii, colors, scal
                                       rt.ptr(sh_), rt.ptr(colors_), rt.ptr(scales_), float(scale_modifier), rt.ptr(rots_),
                                       rt.ptr(cov_), rt.ptr(view_), rt.ptr(proj_), rt.ptr(cam_), float(tan_fovx),
                                       float(tan_fovy), rt.ptr(radii_), rt.ptr(geomBuffer), rt.ptr(binningBuffer),
-                                      rt.ptr(imageBuffer), rt.ptr(dpix), rt.ptr(scratch), rt.ptr(dL_dextra),
+                                      rt.ptr(imageBuffer), plane_ptrs, rt.ptr(scratch), rt.ptr(dL_dextra),
                                       rt.ptr(dL_dmeans2D), rt.ptr(dL_dconic), rt.ptr(dL_dopacity), rt.ptr(dL_dcolors),
                                       rt.ptr(dL_dmeans3D), rt.ptr(dL_dcov3D), rt.ptr(dL_dsh), rt.ptr(dL_dscales),
                                       rt.ptr(dL_drotations)))

@@ -83,11 +83,13 @@ class _RasterizeGaussians(torch.autograd.Function):
 
 class _RasterizeGaussiansMulti(torch.autograd.Function):
     """Single-pass mode: RGB (from SH or precomputed colours) + 4 extra unclamped channels in one forward/backward.
-    `raster_settings.bg` must have 7 entries.  means2D's gradient is the RGB channels' screen-space gradient."""
+    `raster_settings.bg` must have 7 entries.  Returns (rgb[3,H,W], extra[4,H,W], radii): two views of one 7-channel
+    buffer, so the losses' gradients arrive as separate tensors and are handed to the kernel plane by plane (no
+    zero-filled 7-channel gradient is ever assembled).  means2D's gradient is the RGB channels' screen-space gradient."""
 
     @staticmethod
     def forward(ctx, means3D, means2D, sh, colors_precomp, extra4, opacities, scales, rotations, cov3Ds_precomp,
-                raster_settings):
+                raster_settings, splits):
         rs = raster_settings
         num_rendered, color, radii, geomBuffer, binningBuffer, imgBuffer = _C.rasterize_gaussians_multi(
             rs.bg, means3D, colors_precomp, extra4, opacities, scales, rotations, rs.scale_modifier, cov3Ds_precomp,
@@ -97,23 +99,37 @@ class _RasterizeGaussiansMulti(torch.autograd.Function):
         ctx.save_for_backward(colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geomBuffer,
                               binningBuffer, imgBuffer)
         ctx.mark_non_differentiable(radii)
-        return color, radii
+        ctx.hw = (color.shape[1], color.shape[2])
+        ctx.splits = tuple(splits)
+        assert sum(ctx.splits) == 4
+        outs, c0 = [], 3
+        for n in ctx.splits:  # the extra channels as separate (contiguous) views: their gradients arrive separately
+            outs.append(color[c0] if n == 1 else color[c0:c0 + n])
+            c0 += n
+        return (color[:3], radii) + tuple(outs)
 
     @staticmethod
-    def backward(ctx, grad_out_color, _):
+    def backward(ctx, g_rgb, _, *g_splits):
         rs = ctx.raster_settings
         colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geomBuffer, binningBuffer, imgBuffer = \
             ctx.saved_tensors
-        (g_means2D, g_colors, g_extra, g_opac, g_means3D, g_cov, g_sh, g_scales, g_rot) = \
+        H, W = ctx.hw
+        dev = means3D.device
+        g_rgb = torch.zeros((3, H, W), device=dev) if g_rgb is None else g_rgb.contiguous()
+        planes = [g_rgb[0], g_rgb[1], g_rgb[2]]
+        for n, g in zip(ctx.splits, g_splits):
+            g = torch.zeros((n, H, W), device=dev) if g is None else g.contiguous().reshape(n, H, W)
+            planes += [g[k] for k in range(n)]
+        (g_means2D, g_colors, g_ex, g_opac, g_means3D, g_cov, g_sh, g_scales, g_rot) = \
             _C.rasterize_gaussians_multi_backward(rs.bg, means3D, radii, colors_precomp, scales, rotations,
                                                   rs.scale_modifier, cov3Ds_precomp, rs.viewmatrix, rs.projmatrix,
-                                                  rs.tanfovx, rs.tanfovy, grad_out_color, sh, rs.sh_degree, rs.campos,
+                                                  rs.tanfovx, rs.tanfovy, planes, sh, rs.sh_degree, rs.campos,
                                                   geomBuffer, ctx.num_rendered, binningBuffer, imgBuffer, rs.debug)
 
         def _m(g, ref):
             return g if ref.numel() != 0 else None
-        return (g_means3D, g_means2D, _m(g_sh, sh), _m(g_colors, colors_precomp), g_extra, g_opac, _m(g_scales, scales),
-                _m(g_rot, rotations), _m(g_cov, cov3Ds_precomp), None)
+        return (g_means3D, g_means2D, _m(g_sh, sh), _m(g_colors, colors_precomp), g_ex, g_opac, _m(g_scales, scales),
+                _m(g_rot, rotations), _m(g_cov, cov3Ds_precomp), None, None)
 
 
 def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
@@ -149,8 +165,9 @@ class GaussianRasterizer(nn.Module):
         return rasterize_gaussians(means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, rs)
 
     def forward_multi(self, means3D, means2D, opacities, extra4, shs=None, colors_precomp=None, scales=None,
-                      rotations=None, cov3D_precomp=None):
-        """Single-pass mode: returns (image[7,H,W], radii); channels 0-2 = RGB, 3-6 = the blended `extra4` [P,4]."""
+                      rotations=None, cov3D_precomp=None, splits=(4,)):
+        """Single-pass mode: returns (rgb[3,H,W], radii, *extras) where the blended `extra4` [P,4] channels are handed
+        back in groups of `splits` channels ((4,) -> one [4,H,W] tensor; (1,3) -> [H,W] and [3,H,W])."""
         if (shs is None) == (colors_precomp is None):
             raise Exception("Please provide excatly one of either SHs or precomputed colors!")
         if ((scales is None or rotations is None) and cov3D_precomp is None) or \
@@ -160,4 +177,4 @@ class GaussianRasterizer(nn.Module):
         return _RasterizeGaussiansMulti.apply(
             means3D, means2D, empty if shs is None else shs, empty if colors_precomp is None else colors_precomp, extra4,
             opacities, empty if scales is None else scales, empty if rotations is None else rotations,
-            empty if cov3D_precomp is None else cov3D_precomp, self.raster_settings)
+            empty if cov3D_precomp is None else cov3D_precomp, self.raster_settings, tuple(splits))

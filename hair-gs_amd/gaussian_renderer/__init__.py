@@ -56,10 +56,11 @@ def render(viewpoint_camera, pc, bg_color, scaling_modifier=1.0, override_color=
 _BG7 = {}
 
 
-def render_multi(viewpoint_camera, pc, bg_color, extra4, scaling_modifier=1.0, debug=False):
+def render_multi(viewpoint_camera, pc, bg_color, extra4, scaling_modifier=1.0, debug=False, splits=(4,)):
     """One traversal for RGB + 4 extra per-Gaussian channels.  Equivalent to render(...) plus
     render(..., override_color=extra) on a black background, which is how the reference's mask and orientation losses
-    obtain their images (loss/losses.py:247,312).  Returns render()'s dict + "extra" [4,H,W]."""
+    obtain their images (loss/losses.py:247,312).  Returns render()'s dict + "extra": one tensor per entry of `splits`
+    ((4,) -> a single [4,H,W] tensor; (1,3) -> ([H,W], [3,H,W]))."""
     xyz = pc.get_xyz
     screenspace_points = torch.zeros_like(xyz, dtype=xyz.dtype, requires_grad=True, device=xyz.device) + 0
     try:
@@ -76,8 +77,9 @@ def render_multi(viewpoint_camera, pc, bg_color, extra4, scaling_modifier=1.0, d
         scale_modifier=scaling_modifier, viewmatrix=viewpoint_camera.world_view_transform,
         projmatrix=viewpoint_camera.full_proj_transform, sh_degree=pc.active_sh_degree,
         campos=viewpoint_camera.camera_center, prefiltered=False, debug=debug)
-    image7, radii = GaussianRasterizer(raster_settings=raster_settings).forward_multi(
+    out = GaussianRasterizer(raster_settings=raster_settings).forward_multi(
         means3D=xyz, means2D=screenspace_points, opacities=pc.get_opacity, extra4=extra4, shs=pc.get_features,
-        scales=pc.get_scaling, rotations=pc.get_rotation)
-    return {"render": image7[:3], "extra": image7[3:], "viewspace_points": screenspace_points,
+        scales=pc.get_scaling, rotations=pc.get_rotation, splits=splits)
+    rgb, radii, extras = out[0], out[1], out[2:]
+    return {"render": rgb, "extra": extras[0] if len(extras) == 1 else extras, "viewspace_points": screenspace_points,
             "visibility_filter": radii > 0, "radii": radii}

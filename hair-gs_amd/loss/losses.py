@@ -168,8 +168,8 @@ def loss_function_single_pass(gaussians, viewpoint_cam, args, bg):
     (loss, terms, render_pkg) where render_pkg is what render() would have returned for the RGB pass."""
     from gaussian_renderer import render_multi
     extra = torch.cat((gaussians.get_mask, gaussians.get_orientation), dim=1)      # [P, 1 + 3]
-    pkg = render_multi(viewpoint_cam, gaussians, bg, extra)
-    image, ex = pkg["render"], pkg["extra"]
+    pkg = render_multi(viewpoint_cam, gaussians, bg, extra, splits=(1, 3))
+    image, (mask_img, omap) = pkg["render"], pkg["extra"]
     gt = viewpoint_cam.original_image
     if fused_losses and image.is_cuda:
         from hgs_runtime.fused import ssim_l1
@@ -180,10 +180,10 @@ def loss_function_single_pass(gaussians, viewpoint_cam, args, bg):
     loss = max(0, 1.0 - args.lambda_dssim) * terms["l1"] + args.lambda_dssim * terms["dssim"]
     black = _black(image.device)
     if args.lambda_mask > 0 and viewpoint_cam.mask is not None:
-        terms["mask"] = F.binary_cross_entropy_with_logits(ex[0], viewpoint_cam.float_mask)
+        terms["mask"] = F.binary_cross_entropy_with_logits(mask_img, viewpoint_cam.float_mask)
         loss = loss + args.lambda_mask * terms["mask"]
     if args.lambda_orientation > 0:
-        terms["orientation"] = _orientation_term(ex[1:4], gaussians, viewpoint_cam, black)
+        terms["orientation"] = _orientation_term(omap, gaussians, viewpoint_cam, black)
         loss = loss + args.lambda_orientation * terms["orientation"]
     if isinstance(gaussians, HairGaussianModel):
         if args.lambda_smooth > 0:

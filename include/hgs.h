@@ -91,7 +91,8 @@ int hgs_backward(void* stream, int P, int D, int M, int R, int W, int H, const f
 /* Single-pass mode: RGB + 4 extra unclamped per-Gaussian channels (the reference's mask value and
  * world-space direction) composited with the same weights in ONE traversal -- what the reference obtains from three
  * separate render() calls per iteration (train.py:146, loss/losses.py:247 and :312).  hgs_forward_preprocess is
- * shared; bg7 / out_color7 / dL_dpix7 have 7 channels; extra4 is [P,4] (16-byte aligned); workspace sizes from the
+ * shared; bg7 / out_color7 have 7 channels; dL_dpix_planes7 is a HOST array of 7 device pointers, one [H,W] gradient
+ * plane per output channel (the planes need not be adjacent: the losses produce them separately); extra4 is [P,4] (16-byte aligned); workspace sizes from the
  * *_multi size functions.  dL_dmeans2D_rgb is the screen-space gradient of the RGB channels alone (the only one
  * the reference's densification statistics see); dL_dmeans3D uses the total. */
 size_t hgs_binning_bytes_multi(int R);
@@ -105,7 +106,7 @@ int hgs_backward_multi(void* stream, int P, int D, int M, int R, int W, int H, c
                        const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix,
                        const float* campos, float tan_fovx, float tan_fovy, const int* radii,
                        const void* geom_buf, const void* binning_buf, const void* image_buf,
-                       const float* dL_dpix7, void* scratch, float* dL_dextra4, float* dL_dmeans2D_rgb,
+                       const float* const* dL_dpix_planes7, void* scratch, float* dL_dextra4, float* dL_dmeans2D_rgb,
                        float* dL_dconic, float* dL_dopacity, float* dL_dcolors, float* dL_dmeans3D,
                        float* dL_dcov3D, float* dL_dsh, float* dL_dscales, float* dL_drotations);
 

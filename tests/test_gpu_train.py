@@ -299,6 +299,9 @@ def test_single_pass_equals_three_passes():
         o = render(cam, model, bg, override_color=model.get_orientation)["render"]
         pk = render_multi(cam, model, bg, extra)
     assert torch.equal(pk["render"], a) and torch.equal(pk["extra"][0], m) and torch.equal(pk["extra"][1:4], o)
+    with torch.no_grad():
+        pk2 = render_multi(cam, model, bg, extra, splits=(1, 3))
+    assert pk2["extra"][0].shape == m.shape and torch.equal(pk2["extra"][0], m) and torch.equal(pk2["extra"][1], o)
     opt = OptimizationParams()
     res = {}
     for single in (False, True):
