@@ -13,9 +13,11 @@
 
 namespace {
 
-#define LT 16              // pixels per block side
+#define LT 32              // output pixels per block side (256 threads, 4 pixels per thread and pass)
 #define HALO 5             // window radius
 #define TILE (LT + 2 * HALO)
+#define TP (TILE + 1)      // padded LDS row strides (bank-conflict-free for both passes)
+#define HP (LT + 1)
 
 struct SsimWin { float w[11]; };
 
@@ -28,11 +30,62 @@ __device__ __forceinline__ float block_sum(float v, float* red4) {
   return (red4[0] + red4[1]) + (red4[2] + red4[3]);
 }
 
+// Register-blocked separable filter.  Row pass: one work item = 4 consecutive outputs of one tile row (14 LDS reads
+// per input image feed 4 x 11 taps); column pass: one thread = 4 consecutive output rows of one column (14 reads per
+// filtered quantity).  ~29 LDS reads per output pixel instead of ~100 for the one-pixel-per-thread form.
+template <int NQ, typename F>
+__device__ __forceinline__ void row_pass(const SsimWin& win, float (*hz)[TILE][HP], F load) {
+  for (int it = threadIdx.x; it < TILE * (LT / 4); it += 256) {
+    const int r = it / (LT / 4), x0 = (it - r * (LT / 4)) * 4;
+    float acc[NQ][4];
+#pragma unroll
+    for (int q = 0; q < NQ; q++)
+#pragma unroll
+      for (int o = 0; o < 4; o++) acc[q][o] = 0.f;
+#pragma unroll
+    for (int k = 0; k < 14; k++) {
+      float val[NQ];
+      load(r, x0 + k, val);
+#pragma unroll
+      for (int o = 0; o < 4; o++) {
+        const int tap = k - o;
+        if (tap >= 0 && tap < 11) {
+#pragma unroll
+          for (int q = 0; q < NQ; q++) acc[q][o] += win.w[tap] * val[q];
+        }
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < NQ; q++)
+#pragma unroll
+      for (int o = 0; o < 4; o++) hz[q][r][x0 + o] = acc[q][o];
+  }
+}
+template <int NQ>
+__device__ __forceinline__ void col_pass(const SsimWin& win, float (*hz)[TILE][HP], int lx, int y0, float (*out)[4]) {
+#pragma unroll
+  for (int q = 0; q < NQ; q++)
+#pragma unroll
+    for (int o = 0; o < 4; o++) out[q][o] = 0.f;
+#pragma unroll
+  for (int k = 0; k < 14; k++) {
+#pragma unroll
+    for (int q = 0; q < NQ; q++) {
+      const float v = hz[q][y0 + k][lx];
+#pragma unroll
+      for (int o = 0; o < 4; o++) {
+        const int tap = k - o;
+        if (tap >= 0 && tap < 11) out[q][o] += win.w[tap] * v;
+      }
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void ssim_l1_fwd_kernel(int H, int W, SsimWin win, const float* __restrict__ img1,
                                                           const float* __restrict__ img2, float* __restrict__ dmap,
                                                           float* __restrict__ partials) {
-  __shared__ float t1[TILE][TILE + 1], t2[TILE][TILE + 1];
-  __shared__ float hz[5][TILE][LT + 1];
+  __shared__ float t1[TILE][TP], t2[TILE][TP];
+  __shared__ float hz[5][TILE][HP];
   __shared__ float red[4];
   const int c = blockIdx.z, bx0 = blockIdx.x * LT, by0 = blockIdx.y * LT;
   const size_t plane = (size_t)H * W;
@@ -46,45 +99,35 @@ __global__ __launch_bounds__(256) void ssim_l1_fwd_kernel(int H, int W, SsimWin 
     t2[r][q] = in ? p2[(size_t)y * W + x] : 0.f;
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < TILE * LT; i += 256) {
-    const int r = i / LT, x = i - r * LT;
-    float s1 = 0.f, s2 = 0.f, s11 = 0.f, s22 = 0.f, s12 = 0.f;
-#pragma unroll
-    for (int k = 0; k < 11; k++) {
-      const float a = t1[r][x + k], b = t2[r][x + k], w = win.w[k];
-      s1 += w * a; s2 += w * b; s11 += w * (a * a); s22 += w * (b * b); s12 += w * (a * b);
-    }
-    hz[0][r][x] = s1; hz[1][r][x] = s2; hz[2][r][x] = s11; hz[3][r][x] = s22; hz[4][r][x] = s12;
-  }
+  row_pass<5>(win, hz, [&](int r, int x, float* v) {
+    const float a = t1[r][x], b = t2[r][x];
+    v[0] = a; v[1] = b; v[2] = a * a; v[3] = b * b; v[4] = a * b;
+  });
   __syncthreads();
-  const int lx = threadIdx.x & (LT - 1), ly = threadIdx.x >> 4;
-  const int px = bx0 + lx, py = by0 + ly;
-  const bool inside = px < W && py < H;
-  float mu1 = 0.f, mu2 = 0.f, e11 = 0.f, e22 = 0.f, e12 = 0.f;
-#pragma unroll
-  for (int k = 0; k < 11; k++) {
-    const float w = win.w[k];
-    mu1 += w * hz[0][ly + k][lx]; mu2 += w * hz[1][ly + k][lx];
-    e11 += w * hz[2][ly + k][lx]; e22 += w * hz[3][ly + k][lx]; e12 += w * hz[4][ly + k][lx];
-  }
+  const int lx = threadIdx.x & (LT - 1), y0 = (threadIdx.x >> 5) * 4;
+  float f[5][4];
+  col_pass<5>(win, hz, lx, y0, f);
   const float C1 = 0.01f * 0.01f, C2 = 0.03f * 0.03f;
-  const float mu1_sq = mu1 * mu1, mu2_sq = mu2 * mu2, mu12 = mu1 * mu2;
-  const float s1 = e11 - mu1_sq, s2 = e22 - mu2_sq, s12 = e12 - mu12;
-  const float A1 = 2.f * mu12 + C1, A2 = 2.f * s12 + C2, B1 = mu1_sq + mu2_sq + C1, B2 = s1 + s2 + C2;
-  const float inv = 1.f / (B1 * B2);
-  const float S = (A1 * A2) * inv;                                   // losses.py:71-73
+  const size_t cp = (size_t)gridDim.z * plane;
+  const int px = bx0 + lx;
   float ssim_v = 0.f, l1_v = 0.f;
-  if (inside) {
-    const size_t o = (size_t)py * W + px;
-    ssim_v = S;
-    l1_v = fabsf(t1[ly + HALO][lx + HALO] - t2[ly + HALO][lx + HALO]);
-    const float dS_dmu1 = 2.f * mu2 * (A2 - A1) * inv - S * (2.f * mu1 / B1 - 2.f * mu1 / B2);
-    const float dS_dE11 = -S / B2;
-    const float dS_dE12 = 2.f * A1 * inv;
-    const size_t cp = (size_t)gridDim.z * plane;
-    dmap[c * plane + o] = dS_dmu1;
-    dmap[cp + c * plane + o] = dS_dE11;
-    dmap[2 * cp + c * plane + o] = dS_dE12;
+#pragma unroll
+  for (int o = 0; o < 4; o++) {
+    const int py = by0 + y0 + o;
+    if (px < W && py < H) {
+      const float mu1 = f[0][o], mu2 = f[1][o];
+      const float mu1_sq = mu1 * mu1, mu2_sq = mu2 * mu2, mu12 = mu1 * mu2;
+      const float s1 = f[2][o] - mu1_sq, s2 = f[3][o] - mu2_sq, s12 = f[4][o] - mu12;
+      const float A1 = 2.f * mu12 + C1, A2 = 2.f * s12 + C2, B1 = mu1_sq + mu2_sq + C1, B2 = s1 + s2 + C2;
+      const float inv = 1.f / (B1 * B2);
+      const float S = (A1 * A2) * inv;                                 // losses.py:71-73
+      ssim_v += S;
+      l1_v += fabsf(t1[y0 + o + HALO][lx + HALO] - t2[y0 + o + HALO][lx + HALO]);
+      const size_t oo = c * plane + (size_t)py * W + px;
+      dmap[oo] = 2.f * mu2 * (A2 - A1) * inv - S * (2.f * mu1 / B1 - 2.f * mu1 / B2);   // dS/dmu1 at fixed E11, E12
+      dmap[cp + oo] = -S / B2;                                                           // dS/dE11
+      dmap[2 * cp + oo] = 2.f * A1 * inv;                                                // dS/dE12
+    }
   }
   const float bs = block_sum(ssim_v, red);
   const float bl = block_sum(l1_v, red);
@@ -99,8 +142,8 @@ __global__ __launch_bounds__(256) void ssim_l1_bwd_kernel(int H, int W, SsimWin 
                                                           const float* __restrict__ img2, const float* __restrict__ dmap,
                                                           const float* __restrict__ g_ssim_mean,
                                                           const float* __restrict__ g_l1_mean, float* __restrict__ dimg1) {
-  __shared__ float t[3][TILE][TILE + 1];
-  __shared__ float hz[3][TILE][LT + 1];
+  __shared__ float t[3][TILE][TP];
+  __shared__ float hz[3][TILE][HP];
   const int c = blockIdx.z, bx0 = blockIdx.x * LT, by0 = blockIdx.y * LT;
   const size_t plane = (size_t)H * W, cp = (size_t)gridDim.z * plane;
   for (int i = threadIdx.x; i < TILE * TILE; i += 256) {
@@ -113,34 +156,26 @@ __global__ __launch_bounds__(256) void ssim_l1_bwd_kernel(int H, int W, SsimWin 
     t[2][r][q] = in ? dmap[2 * cp + o] : 0.f;
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < TILE * LT; i += 256) {
-    const int r = i / LT, x = i - r * LT;
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f;
-#pragma unroll
-    for (int k = 0; k < 11; k++) {
-      const float w = win.w[k];
-      s0 += w * t[0][r][x + k]; s1 += w * t[1][r][x + k]; s2 += w * t[2][r][x + k];
-    }
-    hz[0][r][x] = s0; hz[1][r][x] = s1; hz[2][r][x] = s2;
-  }
+  row_pass<3>(win, hz, [&](int r, int x, float* v) { v[0] = t[0][r][x]; v[1] = t[1][r][x]; v[2] = t[2][r][x]; });
   __syncthreads();
-  const int lx = threadIdx.x & (LT - 1), ly = threadIdx.x >> 4;
-  const int px = bx0 + lx, py = by0 + ly;
-  if (px >= W || py >= H) return;
-  float ca = 0.f, cb = 0.f, cc = 0.f;
-#pragma unroll
-  for (int k = 0; k < 11; k++) {
-    const float w = win.w[k];
-    ca += w * hz[0][ly + k][lx]; cb += w * hz[1][ly + k][lx]; cc += w * hz[2][ly + k][lx];
-  }
-  const size_t o = c * plane + (size_t)py * W + px;
-  const float x1 = img1[o], x2 = img2[o];
+  const int lx = threadIdx.x & (LT - 1), y0 = (threadIdx.x >> 5) * 4;
+  float f[3][4];
+  col_pass<3>(win, hz, lx, y0, f);
+  const int px = bx0 + lx;
   const float n = 1.f / (float)((size_t)gridDim.z * plane);
-  const float d = x1 - x2;
-  const float sgn = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
-  dimg1[o] = (*g_ssim_mean * n) * (ca + 2.f * x1 * cb + x2 * cc) + (*g_l1_mean * n) * sgn;
+  const float gs = *g_ssim_mean * n, gl = *g_l1_mean * n;
+#pragma unroll
+  for (int o = 0; o < 4; o++) {
+    const int py = by0 + y0 + o;
+    if (px < W && py < H) {
+      const size_t oo = c * plane + (size_t)py * W + px;
+      const float x1 = img1[oo], x2 = img2[oo];
+      const float d = x1 - x2;
+      const float sgn = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
+      dimg1[oo] = gs * (f[0][o] + 2.f * x1 * f[1][o] + x2 * f[2][o]) + gl * sgn;
+    }
+  }
 }
-
 
 // ---- orientation loss (reference loss/losses.py:224-289) ---------------------------------------------------------
 // per pixel: world-space direction image -> view space (x,y) -> unit 2-vector -> angle in [0,pi) w.r.t. the image
