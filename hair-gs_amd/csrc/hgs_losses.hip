@@ -16,7 +16,6 @@ namespace {
 #define LT 32              // output pixels per block side (256 threads, 4 pixels per thread and pass)
 #define HALO 5             // window radius
 #define TILE (LT + 2 * HALO)
-#define TP (TILE + 1)      // padded LDS row strides (bank-conflict-free for both passes)
 #define HP (LT + 1)
 
 struct SsimWin { float w[11]; };
@@ -28,6 +27,37 @@ __device__ __forceinline__ float block_sum(float v, float* red4) {
   if ((threadIdx.x & 63) == 0) red4[threadIdx.x >> 6] = v;
   __syncthreads();
   return (red4[0] + red4[1]) + (red4[2] + red4[3]);
+}
+
+// Halo tile load.  Fast path (W % 4 == 0): the tile is widened to x in [bx0-8, bx0+LT+8) so that every row is 12
+// aligned float4 chunks, each wholly inside or wholly outside the image -> 504 independent 16-B loads per plane, all in
+// flight at once (the scalar form exposed ~7 dependent load latencies per block).  LDS column c <-> image x = bx0-8+c.
+#define XOFF 8
+#define TW (LT + 2 * XOFF)          // 48 columns staged
+#define TPW (TW + 1)
+template <int NP, typename PtrOf>
+__device__ __forceinline__ void load_tiles(float (*t)[TILE][TPW], int H, int W, int bx0, int by0, PtrOf plane_ptr) {
+  if ((W & 3) == 0) {
+    for (int i = threadIdx.x; i < TILE * (TW / 4); i += 256) {
+      const int r = i / (TW / 4), c4 = (i - r * (TW / 4)) * 4;
+      const int y = by0 + r - HALO, x = bx0 - XOFF + c4;
+      const bool in = (unsigned)y < (unsigned)H && x >= 0 && x < W;
+#pragma unroll
+      for (int p = 0; p < NP; p++) {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (in) v = *(const float4*)(plane_ptr(p) + (size_t)y * W + x);
+        t[p][r][c4] = v.x; t[p][r][c4 + 1] = v.y; t[p][r][c4 + 2] = v.z; t[p][r][c4 + 3] = v.w;
+      }
+    }
+  } else {
+    for (int i = threadIdx.x; i < TILE * TW; i += 256) {
+      const int r = i / TW, c = i - r * TW;
+      const int y = by0 + r - HALO, x = bx0 - XOFF + c;
+      const bool in = (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W;
+#pragma unroll
+      for (int p = 0; p < NP; p++) t[p][r][c] = in ? plane_ptr(p)[(size_t)y * W + x] : 0.f;
+    }
+  }
 }
 
 // Register-blocked separable filter.  Row pass: one work item = 4 consecutive outputs of one tile row (14 LDS reads
@@ -84,23 +114,17 @@ __device__ __forceinline__ void col_pass(const SsimWin& win, float (*hz)[TILE][H
 __global__ __launch_bounds__(256) void ssim_l1_fwd_kernel(int H, int W, SsimWin win, const float* __restrict__ img1,
                                                           const float* __restrict__ img2, float* __restrict__ dmap,
                                                           float* __restrict__ partials) {
-  __shared__ float t1[TILE][TP], t2[TILE][TP];
+  __shared__ float t[2][TILE][TPW];
   __shared__ float hz[5][TILE][HP];
   __shared__ float red[4];
   const int c = blockIdx.z, bx0 = blockIdx.x * LT, by0 = blockIdx.y * LT;
   const size_t plane = (size_t)H * W;
   const float* p1 = img1 + c * plane;
   const float* p2 = img2 + c * plane;
-  for (int i = threadIdx.x; i < TILE * TILE; i += 256) {
-    const int r = i / TILE, q = i - r * TILE;
-    const int y = by0 + r - HALO, x = bx0 + q - HALO;
-    const bool in = (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W;
-    t1[r][q] = in ? p1[(size_t)y * W + x] : 0.f;
-    t2[r][q] = in ? p2[(size_t)y * W + x] : 0.f;
-  }
+  load_tiles<2>(t, H, W, bx0, by0, [&](int p) { return p == 0 ? p1 : p2; });
   __syncthreads();
-  row_pass<5>(win, hz, [&](int r, int x, float* v) {
-    const float a = t1[r][x], b = t2[r][x];
+  row_pass<5>(win, hz, [&](int r, int x, float* v) {   // x = tile column of the tap: image x = bx0 - HALO + x
+    const float a = t[0][r][x + XOFF - HALO], b = t[1][r][x + XOFF - HALO];
     v[0] = a; v[1] = b; v[2] = a * a; v[3] = b * b; v[4] = a * b;
   });
   __syncthreads();
@@ -122,7 +146,7 @@ __global__ __launch_bounds__(256) void ssim_l1_fwd_kernel(int H, int W, SsimWin 
       const float inv = 1.f / (B1 * B2);
       const float S = (A1 * A2) * inv;                                 // losses.py:71-73
       ssim_v += S;
-      l1_v += fabsf(t1[y0 + o + HALO][lx + HALO] - t2[y0 + o + HALO][lx + HALO]);
+      l1_v += fabsf(t[0][y0 + o + HALO][lx + XOFF] - t[1][y0 + o + HALO][lx + XOFF]);
       const size_t oo = c * plane + (size_t)py * W + px;
       dmap[oo] = 2.f * mu2 * (A2 - A1) * inv - S * (2.f * mu1 / B1 - 2.f * mu1 / B2);   // dS/dmu1 at fixed E11, E12
       dmap[cp + oo] = -S / B2;                                                           // dS/dE11
@@ -142,21 +166,15 @@ __global__ __launch_bounds__(256) void ssim_l1_bwd_kernel(int H, int W, SsimWin 
                                                           const float* __restrict__ img2, const float* __restrict__ dmap,
                                                           const float* __restrict__ g_ssim_mean,
                                                           const float* __restrict__ g_l1_mean, float* __restrict__ dimg1) {
-  __shared__ float t[3][TILE][TP];
+  __shared__ float t[3][TILE][TPW];
   __shared__ float hz[3][TILE][HP];
   const int c = blockIdx.z, bx0 = blockIdx.x * LT, by0 = blockIdx.y * LT;
   const size_t plane = (size_t)H * W, cp = (size_t)gridDim.z * plane;
-  for (int i = threadIdx.x; i < TILE * TILE; i += 256) {
-    const int r = i / TILE, q = i - r * TILE;
-    const int y = by0 + r - HALO, x = bx0 + q - HALO;
-    const bool in = (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W;
-    const size_t o = c * plane + (size_t)y * W + x;
-    t[0][r][q] = in ? dmap[o] : 0.f;
-    t[1][r][q] = in ? dmap[cp + o] : 0.f;
-    t[2][r][q] = in ? dmap[2 * cp + o] : 0.f;
-  }
+  load_tiles<3>(t, H, W, bx0, by0, [&](int p) { return dmap + p * cp + c * plane; });
   __syncthreads();
-  row_pass<3>(win, hz, [&](int r, int x, float* v) { v[0] = t[0][r][x]; v[1] = t[1][r][x]; v[2] = t[2][r][x]; });
+  row_pass<3>(win, hz, [&](int r, int x, float* v) {
+    v[0] = t[0][r][x + XOFF - HALO]; v[1] = t[1][r][x + XOFF - HALO]; v[2] = t[2][r][x + XOFF - HALO];
+  });
   __syncthreads();
   const int lx = threadIdx.x & (LT - 1), y0 = (threadIdx.x >> 5) * 4;
   float f[3][4];

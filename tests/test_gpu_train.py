@@ -366,3 +366,22 @@ def test_fused_smoothness_matches_torch_ops():
     assert (out[True][1] - out[False][1]).abs().max() <= 2e-4 * out[False][1].abs().max()
     Ls.fused_losses = True
     assert float(Ls.angle_smoothness_loss(m, threshold=179.0)) == 0.0      # nothing selected -> 0
+
+
+@pytest.mark.parametrize("hw", [(61, 97), (64, 100), (33, 17)])
+def test_fused_ssim_odd_sizes(hw):
+    """Image sizes that are not multiples of the 32-px block / of 4 (scalar halo-load path)."""
+    from hgs_runtime.fused import ssim_l1
+    from loss import losses as Ls
+    H, W = hw
+    g = torch.Generator(device="cuda").manual_seed(H * 1000 + W)
+    a = torch.rand(3, H, W, device="cuda", generator=g).requires_grad_(True)
+    b = torch.rand(3, H, W, device="cuda", generator=g)
+    s, l = ssim_l1(a, b)
+    (s + 2 * l).backward()
+    ga = a.grad.clone()
+    a.grad = None
+    s2, l2 = Ls.ssim(a, b), Ls.l1_loss(a, b)
+    (s2 + 2 * l2).backward()
+    assert abs(float(s) - float(s2)) < 2e-5 and abs(float(l) - float(l2)) < 1e-6
+    assert (ga - a.grad).abs().max() <= 2e-4 * a.grad.abs().max()

@@ -1,0 +1,24 @@
+"""Runs only the single-pass rasterizer forward+backward on the north_star workload (for rocprofv3 --pmc passes)."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "hair-gs_amd")]
+import torch
+from gaussian_renderer import render_multi
+from synthetic import build_workload
+wl = sys.argv[1] if len(sys.argv) > 1 else "north_star"
+n = int(sys.argv[2]) if len(sys.argv) > 2 else 10
+model, cams, _ = build_workload(wl, device="cuda", with_targets=False, n_views=4)
+bg = torch.zeros(3, device="cuda")
+H, W = cams[0].image_height, cams[0].image_width
+w3 = torch.randn(3, H, W, device="cuda"); w1 = torch.randn(H, W, device="cuda"); wo = torch.randn(3, H, W, device="cuda")
+for i in range(n):
+    cam = cams[i % len(cams)]
+    extra = torch.cat((model.get_mask, model.get_orientation), dim=1)
+    pkg = render_multi(cam, model, bg, extra, splits=(1, 3))
+    loss = (pkg["render"] * w3).sum() + (pkg["extra"][0] * w1).sum() + (pkg["extra"][1] * wo).sum()
+    loss.backward()
+    model._derived = None
+    for p in (model._endpoints, model._features_dc, model._opacity, model._mask, model._width):
+        p.grad = None
+torch.cuda.synchronize()
+print("done")
