@@ -18,7 +18,7 @@
 namespace {
 
 #define BWD_BATCH 64   // entries combined per LDS flush in the backward
-#define REC_CHUNK 4     // instance records fetched per scalar-load burst
+#define REC_BATCH 64   // instance records staged in LDS per batch (<= one float4 per thread)
 
 // ---- wavefront-wide reduction of 9 per-lane values (CDNA4: v_permlane32_swap / v_permlane16_swap + DPP) ----------
 // Transposing butterfly: a swap of the upper half-wave of `a` with the lower half-wave of `b` followed by one add
@@ -51,7 +51,7 @@ __device__ __forceinline__ float fold16(float a, float b) {  // rows: (a.r0+a.r1
 // Channel layouts.  C = 3: the reference's RGB pass.  C = 7 (single-pass mode): RGB + 4 extra
 // unclamped channels (mask, world-space direction xyz) blended with the SAME weights in one traversal, which is what
 // the reference's three render() calls per iteration compute separately (train.py:146, loss/losses.py:247,312).
-//   record  : [x, y, conic a, b, c, opacity, f0 .. f(C-1), id, pad]          REC4(C) float4 per instance
+//   record  : [x, y, conic a, b, c, opacity, f0 .. f(C-1), id, quadrant mask, pad]   REC4(C) float4 per instance
 //   partials: [dmean2D.x, .y, dconic.x, .y, .w, dopacity, dcolor 0..C-1, (C>3: RGB-only dmean2D.x, .y)]
 // The RGB-only screen-space gradient is what the reference's densification statistics see (the mask / orientation
 // passes use their own throw-away screenspace tensors), so it is accumulated separately from the total.
@@ -70,6 +70,27 @@ __device__ __forceinline__ void wave_reduce(const float* v, float* x) {
     x[r] = row_sum16(fold16(fold32(v[4 * r], v[4 * r + 1]), fold32(v[4 * r + 2], v[4 * r + 3])));
 }
 
+// ---- record staging ------------------------------------------------------------------------------------------
+// A tile's list is consumed in batches of REC_BATCH entries.  One batch is REC_BATCH * REC4 float4 = at most one float4
+// per thread, fetched with a single fully coalesced global load per thread; the NEXT batch's load is issued before the
+// current batch is evaluated, so the HBM / Infinity-Cache round trip (about 1 us on this part, and the whole critical
+// path of a long tile when it is paid per handful of entries) overlaps the math.  Double-buffered LDS, one barrier per
+// batch in the forward.
+//
+// Each wavefront then builds, with one ballot over the records' quadrant masks (sort_tiles_kernel), the 64-bit set of
+// batch entries whose alpha >= 1/255 footprint can touch ITS 8x8 pixels, and walks only those bits on the scalar unit
+// (s_ff1 / s_flbit); for thin strand Gaussians that is about 30% of the tile's entries.  The selected record is read
+// from LDS with wave-uniform (broadcast) ds_read_b128, one entry ahead of the one being evaluated.
+template <int C> struct Rec { float4 q[Chan<C>::REC4]; };
+
+template <int C>
+__device__ __forceinline__ Rec<C> lds_record(const float4* recs, int e) {
+  Rec<C> r;
+#pragma unroll
+  for (int w = 0; w < Chan<C>::REC4; w++) r.q[w] = recs[e * Chan<C>::REC4 + w];
+  return r;
+}
+
 // ------------------------------------------------------------------------------------------------
 template <int C>
 __global__ __launch_bounds__(HGS_BLOCK) void blend_fwd_kernel(const uint2* __restrict__ ranges,
@@ -80,6 +101,8 @@ __global__ __launch_bounds__(HGS_BLOCK) void blend_fwd_kernel(const uint2* __res
                                                               uint32_t* __restrict__ tile_maxc,
                                                               float* __restrict__ out_color) {
   constexpr int REC4 = Chan<C>::REC4;
+  __shared__ float4 recs[2][REC_BATCH * REC4];
+  __shared__ uint32_t alive[2][4];
   const int tile = blockIdx.x;
   const int tx = tile % gx, ty = tile / gx;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -89,44 +112,71 @@ __global__ __launch_bounds__(HGS_BLOCK) void blend_fwd_kernel(const uint2* __res
   const float pxf = (float)px, pyf = (float)py;
   uint2 range = ranges[tile];
   if (range.y > Rcap) range = make_uint2(0u, 0u);  // binning buffer under-sized (flagged by the scatter kernel)
+  const uint32_t L = range.y - range.x;
+  const int nb = (int)((L + REC_BATCH - 1) / REC_BATCH);
   float T = 1.f, acc[C];
 #pragma unroll
   for (int k = 0; k < C; k++) acc[k] = 0.f;
   uint32_t last = 0;
   bool done = !inside;
-  // The instance records are streamed in chunks of REC_CHUNK: all scalar loads of a chunk are issued back to back
-  // (indices clamped to the list end, so no branch sits between them), one wait, then the entries are evaluated.
-  // The critical path of the kernel is the longest tile list x per-entry latency; this divides the load latency
-  // per entry by REC_CHUNK.
-  for (uint32_t j0 = range.x; j0 < range.y; j0 += REC_CHUNK) {
-    if (__ballot(!done) == 0) break;  // forward.cu:309-311, per wavefront instead of per block
-    float4 q[REC_CHUNK][REC4];
-#pragma unroll
-    for (int u = 0; u < REC_CHUNK; u++) {
-      const size_t jj = min(j0 + (uint32_t)u, range.y - 1u);
-#pragma unroll
-      for (int w = 0; w < REC4; w++) q[u][w] = packed[REC4 * jj + w];
+
+  const float4* src = packed + (size_t)range.x * REC4;
+  const uint32_t nf4 = L * REC4;
+  float4 stage = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (nb > 0) {
+    if (threadIdx.x < REC_BATCH * REC4 && threadIdx.x < nf4) stage = src[threadIdx.x];
+    if (threadIdx.x < REC_BATCH * REC4) recs[0][threadIdx.x] = stage;
+    if (threadIdx.x < 4) alive[0][threadIdx.x] = 1u;
+  }
+  for (int b = 0; b < nb; b++) {
+    const int cur = b & 1;
+    if (b + 1 < nb) {
+      const uint32_t i = (uint32_t)(b + 1) * (REC_BATCH * REC4) + threadIdx.x;
+      if (threadIdx.x < REC_BATCH * REC4 && i < nf4) stage = src[i];
     }
+    __syncthreads();
+    // forward.cu:309-311: the tile stops when every pixel is saturated (flags written before the barrier above)
+    if ((alive[cur][0] | alive[cur][1] | alive[cur][2] | alive[cur][3]) == 0u) break;
+    const int cnt = min(REC_BATCH, (int)L - b * REC_BATCH);
+    const float* rf = (const float*)&recs[cur][0];
+    const uint32_t mk = lane < cnt ? __float_as_uint(rf[lane * 4 * REC4 + 7 + C]) : 0u;
+    uint64_t m = __ballot(((mk >> wave) & 1u) != 0u);
+    if (__ballot(!done) == 0) m = 0;
+    if (m) {
+      int e = __builtin_ctzll(m);
+      Rec<C> r = lds_record<C>(recs[cur], e);
+      while (true) {
+        m &= m - 1;
+        const int en = m ? __builtin_ctzll(m) : e;
+        const Rec<C> rn = lds_record<C>(recs[cur], en);      // one entry ahead: hides the LDS latency
+        const float4 r0 = r.q[0], r1 = r.q[1];
+        const float dx = r0.x - pxf, dy = r0.y - pyf;
+        const float power = -0.5f * (r0.z * dx * dx + r1.x * dy * dy) - r0.w * dx * dy;  // forward.cu:335
+        const float alpha = fminf(0.99f, r1.y * __expf(power));                           // :343
+        bool ok = !done && power <= 0.f && alpha >= (1.0f / 255.0f);                      // :336, :344
+        if (__ballot(ok) != 0) {
+          const float test_T = T * (1.f - alpha);
+          const bool sat = ok && test_T < 0.0001f;                                        // :346-351
+          if (sat) { done = true; ok = false; }
+          if (ok) {
+            const float w = alpha * T;
+            const float* f = (const float*)&r.q[0];                                       // features start at float 6
 #pragma unroll
-    for (int u = 0; u < REC_CHUNK; u++) {
-      const uint32_t j = j0 + (uint32_t)u;
-      if (j >= range.y) break;
-      const float4 r0 = q[u][0], r1 = q[u][1];
-      const float dx = r0.x - pxf, dy = r0.y - pyf;
-      const float power = -0.5f * (r0.z * dx * dx + r1.x * dy * dy) - r0.w * dx * dy;  // forward.cu:335
-      const float alpha = fminf(0.99f, r1.y * __expf(power));                           // :343
-      bool ok = !done && power <= 0.f && alpha >= (1.0f / 255.0f);                      // :336, :344
-      if (__ballot(ok) == 0) continue;
-      const float test_T = T * (1.f - alpha);
-      if (ok && test_T < 0.0001f) { done = true; ok = false; }                          // :346-351
-      if (ok) {
-        const float w = alpha * T;
-        const float* f = (const float*)&q[u][0];                                        // features start at float 6
-#pragma unroll
-        for (int k = 0; k < C; k++) acc[k] += f[6 + k] * w;                             // :354-355
-        T = test_T;
-        last = j - range.x + 1;                                                         // :328, :361
+            for (int k = 0; k < C; k++) acc[k] += f[6 + k] * w;                           // :354-355
+            T = test_T;
+            last = (uint32_t)(b * REC_BATCH + e + 1);                                     // :328, :361
+          }
+          if (__ballot(sat) != 0 && __ballot(!done) == 0) break;
+        }
+        if (m == 0) break;
+        e = en;
+        r = rn;
       }
+    }
+    if (b + 1 < nb) {
+      if (threadIdx.x < REC_BATCH * REC4) recs[cur ^ 1][threadIdx.x] = stage;
+      const uint32_t wave_alive = __ballot(!done) != 0 ? 1u : 0u;   // all lanes vote: taken outside the lane-0 branch
+      if (lane == 0) alive[cur ^ 1][wave] = wave_alive;
     }
   }
   uint32_t wmax = last;
@@ -155,7 +205,9 @@ __global__ __launch_bounds__(HGS_BLOCK) void blend_bwd_kernel(const uint2* __res
                                                               PixGrad<C> dL_dpix,
                                                               float* __restrict__ inst_grad) {
   constexpr int REC4 = Chan<C>::REC4, NPART = Chan<C>::NPART, NREG = Chan<C>::NREG, NV = 4 * NREG, ROW = Chan<C>::ROW;
+  static_assert(BWD_BATCH == REC_BATCH, "one record batch per partial-sum flush");
   __shared__ float part[4][BWD_BATCH][NV];
+  __shared__ float4 recs[2][REC_BATCH * REC4];
   const int tile = blockIdx.x;
   const uint2 range = ranges[tile];
   const uint32_t maxc = tile_maxc[tile];
@@ -168,9 +220,21 @@ __global__ __launch_bounds__(HGS_BLOCK) void blend_bwd_kernel(const uint2* __res
   const float pxf = (float)px, pyf = (float)py;
   const size_t pix = (size_t)py * W + px;
 
+  // first batch (the END of the list: the walk is back to front) is in flight while the per-pixel state is set up
+  const float4* src = packed + (size_t)range.x * REC4;
+  float4 stage = make_float4(0.f, 0.f, 0.f, 0.f);
+  {
+    const int lo = max(0, (int)maxc - BWD_BATCH), cnt = (int)maxc - lo;
+    if (threadIdx.x < cnt * REC4) stage = src[(size_t)lo * REC4 + threadIdx.x];
+  }
+
   const float T_final = inside ? final_Ts[pix] : 0.f;
   float T = T_final;
   const uint32_t last = inside ? n_contrib[pix] : 0u;
+  uint32_t wlast = last;                                                       // wave-wide last contributor
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) wlast = max(wlast, (uint32_t)__shfl_xor((int)wlast, d, 64));
+  wlast = __builtin_amdgcn_readfirstlane(wlast);
   float dpx[C], acc[C], lc[C];
   float bg_dot = 0.f, bg_dot_rgb = 0.f;                                       // backward_distwar.cu:988-990
 #pragma unroll
@@ -184,90 +248,103 @@ __global__ __launch_bounds__(HGS_BLOCK) void blend_bwd_kernel(const uint2* __res
   const float ddelx_dx = 0.5f * W, ddely_dy = 0.5f * H;                       // :917-918
 
   for (int i = threadIdx.x; i < 4 * BWD_BATCH * NV; i += HGS_BLOCK) (&part[0][0][0])[i] = 0.f;
+  if (threadIdx.x < REC_BATCH * REC4) recs[0][threadIdx.x] = stage;
   __syncthreads();
 
   // walk the list back to front in batches of BWD_BATCH positions; position p (0-based) is valid for a pixel
   // iff p < n_contrib (backward_distwar.cu:943-945)
-  for (int hi = (int)maxc; hi > 0; hi -= BWD_BATCH) {
+  int cur = 0;
+  for (int hi = (int)maxc; hi > 0; hi -= BWD_BATCH, cur ^= 1) {
     const int lo = max(0, hi - BWD_BATCH);
-    for (int p0 = hi - 1; p0 >= lo; p0 -= REC_CHUNK) {
-      float4 q[REC_CHUNK][REC4];
-#pragma unroll
-      for (int u = 0; u < REC_CHUNK; u++) {
-        const size_t jj = (size_t)range.x + (size_t)max(p0 - u, lo);
-#pragma unroll
-        for (int w = 0; w < REC4; w++) q[u][w] = packed[REC4 * jj + w];
-      }
-#pragma unroll
-      for (int u = 0; u < REC_CHUNK; u++) {
-        const int p = p0 - u;
-        if (p < lo) break;
-        const float4 r0 = q[u][0], r1 = q[u][1];
-        const float* f = (const float*)&q[u][0];
+    const int cnt = hi - lo;
+    if (lo > 0) {  // next batch's records: in flight during this batch's math
+      const int nlo = max(0, lo - BWD_BATCH), ncnt = lo - nlo;
+      if (threadIdx.x < ncnt * REC4) stage = src[(size_t)nlo * REC4 + threadIdx.x];
+    }
+    const float* rf = (const float*)&recs[cur][0];
+    const uint32_t mk = lane < cnt ? __float_as_uint(rf[lane * 4 * REC4 + 7 + C]) : 0u;
+    uint64_t m = __ballot(((mk >> wave) & 1u) != 0u);
+    // positions at or past this wavefront's last contributor cannot be valid for any of its pixels
+    if ((int)wlast <= lo) m = 0;
+    else if ((int)wlast - lo < 64) m &= (1ull << ((int)wlast - lo)) - 1ull;
+    if (m) {
+      int e = 63 - __builtin_clzll(m);
+      Rec<C> r = lds_record<C>(recs[cur], e);
+      while (true) {
+        m &= ~(1ull << e);
+        const int en = m ? 63 - __builtin_clzll(m) : e;
+        const Rec<C> rn = lds_record<C>(recs[cur], en);
+        const int p = lo + e;
+        const float* f = (const float*)&r.q[0];
+        const float4 r0 = r.q[0], r1 = r.q[1];
         const float dx = r0.x - pxf, dy = r0.y - pyf;
         const float power = -0.5f * (r0.z * dx * dx + r1.x * dy * dy) - r0.w * dx * dy;
         const float G = __expf(power);
         const float alpha = fminf(0.99f, r1.y * G);
         const bool ok = (uint32_t)p < last && power <= 0.f && alpha >= (1.0f / 255.0f);
-        if (__ballot(ok) == 0) continue;
-        float v[NV];
+        if (__ballot(ok) != 0) {
+          float v[NV];
 #pragma unroll
-        for (int k = 0; k < NV; k++) v[k] = 0.f;
-        if (ok) {
-          const float inv_one_m_a = __builtin_amdgcn_rcpf(1.f - alpha);             // 1 ulp; alpha <= 0.99
-          T = T * inv_one_m_a;                                                       // :960
-          const float dchannel_dcolor = alpha * T;
-          float dL_dalpha = 0.f, dL_dalpha_rgb = 0.f;
+          for (int k = 0; k < NV; k++) v[k] = 0.f;
+          if (ok) {
+            const float inv_one_m_a = __builtin_amdgcn_rcpf(1.f - alpha);             // 1 ulp; alpha <= 0.99
+            T = T * inv_one_m_a;                                                       // :960
+            const float dchannel_dcolor = alpha * T;
+            float dL_dalpha = 0.f, dL_dalpha_rgb = 0.f;
 #pragma unroll
-          for (int k = 0; k < C; k++) {
-            const float c = f[6 + k];
-            acc[k] = last_alpha * lc[k] + (1.f - last_alpha) * acc[k];               // :972
-            lc[k] = c;
-            const float t = (c - acc[k]) * dpx[k];
-            dL_dalpha += t;
-            if (k < 3) dL_dalpha_rgb += t;
-            v[6 + k] = dchannel_dcolor * dpx[k];                                     // :980
+            for (int k = 0; k < C; k++) {
+              const float c = f[6 + k];
+              acc[k] = last_alpha * lc[k] + (1.f - last_alpha) * acc[k];               // :972
+              lc[k] = c;
+              const float t = (c - acc[k]) * dpx[k];
+              dL_dalpha += t;
+              if (k < 3) dL_dalpha_rgb += t;
+              v[6 + k] = dchannel_dcolor * dpx[k];                                     // :980
+            }
+            dL_dalpha *= T;
+            last_alpha = alpha;
+            const float bgw = -T_final * inv_one_m_a;
+            dL_dalpha += bgw * bg_dot;                                                 // :991
+            const float dL_dG = r1.y * dL_dalpha;
+            const float gdx = G * dx, gdy = G * dy;
+            const float dG_ddelx = -gdx * r0.z - gdy * r0.w;
+            const float dG_ddely = -gdy * r1.x - gdx * r0.w;
+            v[0] = dL_dG * dG_ddelx * ddelx_dx;                                        // :1002-1003
+            v[1] = dL_dG * dG_ddely * ddely_dy;
+            v[2] = -0.5f * gdx * dx * dL_dG;                                           // :1006-1008
+            v[3] = -0.5f * gdx * dy * dL_dG;
+            v[4] = -0.5f * gdy * dy * dL_dG;
+            v[5] = G * dL_dalpha;                                                      // :1011
+            if (C > 3) {  // screen-space gradient of the RGB channels alone (densification statistics)
+              const float dL_dG_rgb = r1.y * (dL_dalpha_rgb * T + bgw * bg_dot_rgb);
+              v[6 + C] = dL_dG_rgb * dG_ddelx * ddelx_dx;
+              v[7 + C] = dL_dG_rgb * dG_ddely * ddely_dy;
+            }
           }
-          dL_dalpha *= T;
-          last_alpha = alpha;
-          const float bgw = -T_final * inv_one_m_a;
-          dL_dalpha += bgw * bg_dot;                                                 // :991
-          const float dL_dG = r1.y * dL_dalpha;
-          const float gdx = G * dx, gdy = G * dy;
-          const float dG_ddelx = -gdx * r0.z - gdy * r0.w;
-          const float dG_ddely = -gdy * r1.x - gdx * r0.w;
-          v[0] = dL_dG * dG_ddelx * ddelx_dx;                                        // :1002-1003
-          v[1] = dL_dG * dG_ddely * ddely_dy;
-          v[2] = -0.5f * gdx * dx * dL_dG;                                           // :1006-1008
-          v[3] = -0.5f * gdx * dy * dL_dG;
-          v[4] = -0.5f * gdy * dy * dL_dG;
-          v[5] = G * dL_dalpha;                                                      // :1011
-          if (C > 3) {  // screen-space gradient of the RGB channels alone (densification statistics)
-            const float dL_dG_rgb = r1.y * (dL_dalpha_rgb * T + bgw * bg_dot_rgb);
-            v[6 + C] = dL_dG_rgb * dG_ddelx * ddelx_dx;
-            v[7 + C] = dL_dG_rgb * dG_ddely * ddely_dy;
+          float x[NREG];
+          wave_reduce<NREG>(v, x);
+          if ((lane & 15) == 0) {
+            const int row = lane >> 4;
+            const int k = ((row & 1) << 1) | (row >> 1);   // rows hold values (0,2,1,3) of each group of four
+            float* dst = &part[wave][e][0];
+#pragma unroll
+            for (int rr = 0; rr < NREG; rr++) dst[4 * rr + k] = x[rr];
           }
         }
-        float x[NREG];
-        wave_reduce<NREG>(v, x);
-        if ((lane & 15) == 0) {
-          const int row = lane >> 4;
-          const int k = ((row & 1) << 1) | (row >> 1);   // rows hold values (0,2,1,3) of each group of four
-          float* dst = &part[wave][p - lo][0];
-#pragma unroll
-          for (int r = 0; r < NREG; r++) dst[4 * r + k] = x[r];
-        }
+        if (m == 0) break;
+        e = en;
+        r = rn;
       }
     }
     __syncthreads();
     // combine the 4 wavefronts in fixed order and store one row per (tile, entry)
-    const int cnt = hi - lo;
     for (int i = threadIdx.x; i < cnt * NPART; i += HGS_BLOCK) {
       const int e = i / NPART, k = i - e * NPART;
       const float s = ((part[0][e][k] + part[1][e][k]) + part[2][e][k]) + part[3][e][k];
       inst_grad[(size_t)(range.x + lo + e) * ROW + k] = s;
       part[0][e][k] = 0.f; part[1][e][k] = 0.f; part[2][e][k] = 0.f; part[3][e][k] = 0.f;
     }
+    if (lo > 0 && threadIdx.x < REC_BATCH * REC4) recs[cur ^ 1][threadIdx.x] = stage;
     __syncthreads();
   }
 }

@@ -1,0 +1,45 @@
+"""Tile-list statistics of a synthetic workload: list-length distribution, quadrant-cull rate, critical path.
+Runs the 3-channel forward through the C-ABI and reads the binning / image scratch back (diagnostics only)."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "hair-gs_amd"), os.path.join(ROOT, "tests")]
+import numpy as np, torch
+import hgs_runtime as rt
+from diff_gaussian_rasterization import _C
+from synthetic import build_workload
+from utils.sh import RGB2SH  # noqa: F401
+
+wl = sys.argv[1] if len(sys.argv) > 1 else "north_star"
+model, cams, _ = build_workload(wl, device="cuda", with_targets=False, n_views=4)
+cam = cams[0]
+H, W = cam.image_height, cam.image_width
+with torch.no_grad():
+    import math
+    tfx, tfy = math.tan(cam.FoVx * 0.5), math.tan(cam.FoVy * 0.5)
+    R, color, radii, geom, binning, img = _C.rasterize_gaussians(
+        torch.zeros(3, device="cuda"), model.get_xyz, torch.empty(0, device="cuda"), model.get_opacity, model.get_scaling,
+        model.get_rotation, 1.0, torch.empty(0, device="cuda"), cam.world_view_transform, cam.full_proj_transform, tfx, tfy,
+        H, W, model.get_features, model.active_sh_degree, cam.camera_center, False, False)
+torch.cuda.synchronize()
+im = rt.layout("image", W, H)
+ib = img.cpu().numpy()
+T = ((W + 15) // 16) * ((H + 15) // 16)
+ranges = ib[im["ranges"]:im["ranges"] + 8 * T].view(np.uint32).reshape(T, 2)
+L = (ranges[:, 1] - ranges[:, 0]).astype(np.int64)
+print("R", R, "tiles", T, "nonempty", int((L > 0).sum()), "mean L (nonempty)", L[L > 0].mean(), "max", L.max())
+print("percentiles 50/90/99/99.9:", np.percentile(L[L > 0], [50, 90, 99, 99.9]))
+hist = np.bincount(np.minimum(L // 64, 40))
+print("L//64 histogram:", hist.tolist())
+n_contrib = ib[im["n_contrib"]:im["n_contrib"] + 4 * W * H].view(np.uint32).reshape(H, W)
+print("mean last contributor", n_contrib.mean(), "max", n_contrib.max())
+b = rt.layout("binning", R)
+bb = binning.cpu().numpy()
+rec = bb[b["packed"]:b["packed"] + 48 * R].view(np.uint32).reshape(R, 12)
+qm = rec[:, 10]
+pop = np.array([bin(int(x)).count("1") for x in range(16)])[qm & 15]
+print("quadrant mask popcount histogram:", np.bincount(pop, minlength=5).tolist(), "kept fraction", pop.sum() / (4.0 * R))
+# entries a wave actually visits before its pixels are all done: per tile max n_contrib
+ty, tx = (H + 15) // 16, (W + 15) // 16
+pad = np.zeros((ty * 16, tx * 16), np.uint32); pad[:H, :W] = n_contrib
+last = pad.reshape(ty, 16, tx, 16).max(axis=(1, 3)).reshape(-1)
+print("sum L", L.sum(), "sum tile-max last contributor", last.sum())
