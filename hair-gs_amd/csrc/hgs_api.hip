@@ -27,7 +27,7 @@ const char* kKernelNames[HGS_K_COUNT] = {"preprocess_fwd_kernel", "scan_kernel",
                                          "blend_fwd_kernel", "blend_bwd_kernel", "preprocess_bwd_kernel", "dist2_kernels",
                                          "ssim_l1_fwd_kernel", "ssim_l1_bwd_kernel", "strand_fwd_kernel",
                                          "strand_bwd_kernel", "ori_fwd_kernel", "ori_bwd_kernel", "adam_kernel",
-                                         "smooth_kernels"};
+                                         "smooth_kernels", "head_finalize_kernel", "misc_kernels"};
 hipEvent_t prof_event() {
   if (!g_prof_pool.empty()) { hipEvent_t e = g_prof_pool.back(); g_prof_pool.pop_back(); return e; }
   hipEvent_t e = nullptr;
@@ -61,6 +61,29 @@ int hgs_zero_async(hipStream_t s, void* ptr, size_t bytes) {
   hipLaunchKernelGGL(hgs_zero_kernel, dim3(blocks), dim3(256), 0, s, (uint32_t*)ptr, n);
   HGS_CHECK_LAUNCH();
   return 0;
+}
+
+// ---- small per-iteration bookkeeping kernels --------------------------------------------------------------------
+__global__ void select_view_kernel(const HgsViewTargets* __restrict__ table, int view, HgsViewTargets* __restrict__ slot,
+                                   float lr, float* __restrict__ lr_dst) {
+  const uint32_t* src = (const uint32_t*)(table + view);
+  uint32_t* dst = (uint32_t*)slot;
+  for (int i = threadIdx.x; i < (int)(sizeof(HgsViewTargets) / 4); i += 64) dst[i] = src[i];
+  if (threadIdx.x == 0 && lr_dst) *lr_dst = lr;
+}
+
+__global__ __launch_bounds__(256) void densify_stats_kernel(int P, const int* __restrict__ radii,
+                                                            const float* __restrict__ g, int stride,
+                                                            float* __restrict__ max_radii, float* __restrict__ accum,
+                                                            float* __restrict__ denom) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= P) return;
+  const int r = radii[i];
+  if (r <= 0) return;                                           // visibility_filter = radii > 0 (train.py:170)
+  max_radii[i] = fmaxf(max_radii[i], (float)r);
+  const float gx = g[(size_t)i * stride], gy = g[(size_t)i * stride + 1];
+  accum[i] += sqrtf(gx * gx + gy * gy);                         // torch.norm(grad[:, :2], dim=-1)
+  denom[i] += 1.f;
 }
 
 static int check_aligned(const void* p, const char* what) {
@@ -282,6 +305,37 @@ int hgs_dist2(void* stream, int P, const float* points, float* out, void* scratc
   if (P == 0) return 0;
   if (!points || !out) { hgs_set_error("null input"); return 1; }
   return hgs_launch_dist2((hipStream_t)stream, P, points, out, scratch, scratch_bytes);
+}
+
+size_t hgs_view_targets_bytes(void) { return sizeof(HgsViewTargets); }
+size_t hgs_head_params_bytes(void) { return sizeof(HgsHeadParams); }
+
+int hgs_select_view(void* stream, const HgsViewTargets* table, int view, HgsViewTargets* slot, float lr, float* lr_dst) {
+  if (!table || !slot || view < 0) { hgs_set_error("hgs_select_view: bad arguments"); return 1; }
+  hipStream_t s = (hipStream_t)stream;
+  {
+    HgsProfScope _prof(s, HGS_K_MISC);
+    hipLaunchKernelGGL(select_view_kernel, dim3(1), dim3(64), 0, s, table, view, slot, lr, lr_dst);
+  }
+  HGS_CHECK_LAUNCH();
+  return 0;
+}
+
+int hgs_densify_stats(void* stream, int P, const int* radii, const float* dL_dmean2D, int stride, float* max_radii2D,
+                      float* xyz_gradient_accum, float* denom) {
+  if (P <= 0) return 0;
+  if (!radii || !dL_dmean2D || stride < 2 || !max_radii2D || !xyz_gradient_accum || !denom) {
+    hgs_set_error("hgs_densify_stats: bad arguments");
+    return 1;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  {
+    HgsProfScope _prof(s, HGS_K_MISC);
+    hipLaunchKernelGGL(densify_stats_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, radii, dL_dmean2D, stride, max_radii2D,
+                       xyz_gradient_accum, denom);
+  }
+  HGS_CHECK_LAUNCH();
+  return 0;
 }
 
 }  // extern "C"

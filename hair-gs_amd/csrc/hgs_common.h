@@ -110,6 +110,10 @@ struct HgsProfScope {
 };
 
 // ---- launchers implemented in the kernel translation units -------------------------------------
+int hgs_launch_smooth_fwd(hipStream_t s, int N, const float* endpoints, const long long* index_pairs, float cos_th, float eps,
+                          float* partials);
+int hgs_launch_smooth_bwd(hipStream_t s, int N, const float* endpoints, const long long* index_pairs, float cos_th, float eps,
+                          const float* g_loss, const float* count, const float* go, float* d_endpoints);
 struct HgsFwdArgs {
   int P, D, M, W, H;
   const float *means3D, *shs, *colors_precomp, *opacities, *scales, *rotations, *cov3D_precomp;

@@ -112,13 +112,14 @@ __device__ __forceinline__ void col_pass(const SsimWin& win, float (*hz)[TILE][H
 }
 
 __global__ __launch_bounds__(256) void ssim_l1_fwd_kernel(int H, int W, SsimWin win, const float* __restrict__ img1,
-                                                          const float* __restrict__ img2, float* __restrict__ dmap,
-                                                          float* __restrict__ partials) {
+                                                          const float* __restrict__ img2_, const HgsViewTargets* __restrict__ tgt,
+                                                          float* __restrict__ dmap, float* __restrict__ partials) {
   __shared__ float t[2][TILE][TPW];
   __shared__ float hz[5][TILE][HP];
   __shared__ float red[4];
   const int c = blockIdx.z, bx0 = blockIdx.x * LT, by0 = blockIdx.y * LT;
   const size_t plane = (size_t)H * W;
+  const float* img2 = tgt ? tgt->image : img2_;   // per-view target read through the device-resident slot
   const float* p1 = img1 + c * plane;
   const float* p2 = img2 + c * plane;
   load_tiles<2>(t, H, W, bx0, by0, [&](int p) { return p == 0 ? p1 : p2; });
@@ -163,11 +164,14 @@ __global__ __launch_bounds__(256) void ssim_l1_fwd_kernel(int H, int W, SsimWin 
 }
 
 __global__ __launch_bounds__(256) void ssim_l1_bwd_kernel(int H, int W, SsimWin win, const float* __restrict__ img1,
-                                                          const float* __restrict__ img2, const float* __restrict__ dmap,
+                                                          const float* __restrict__ img2_, const HgsViewTargets* __restrict__ tgt,
+                                                          const float* __restrict__ dmap,
                                                           const float* __restrict__ g_ssim_mean,
-                                                          const float* __restrict__ g_l1_mean, float* __restrict__ dimg1) {
+                                                          const float* __restrict__ g_l1_mean, const float* __restrict__ go,
+                                                          float* __restrict__ dimg1) {
   __shared__ float t[3][TILE][TPW];
   __shared__ float hz[3][TILE][HP];
+  const float* img2 = tgt ? tgt->image : img2_;
   const int c = blockIdx.z, bx0 = blockIdx.x * LT, by0 = blockIdx.y * LT;
   const size_t plane = (size_t)H * W, cp = (size_t)gridDim.z * plane;
   load_tiles<3>(t, H, W, bx0, by0, [&](int p) { return dmap + p * cp + c * plane; });
@@ -181,7 +185,8 @@ __global__ __launch_bounds__(256) void ssim_l1_bwd_kernel(int H, int W, SsimWin 
   col_pass<3>(win, hz, lx, y0, f);
   const int px = bx0 + lx;
   const float n = 1.f / (float)((size_t)gridDim.z * plane);
-  const float gs = *g_ssim_mean * n, gl = *g_l1_mean * n;
+  const float up = go ? *go : 1.f;                 // upstream dL/dtotal of the loss head (NULL: 1)
+  const float gs = *g_ssim_mean * up * n, gl = *g_l1_mean * up * n;
 #pragma unroll
   for (int o = 0; o < 4; o++) {
     const int py = by0 + y0 + o;
@@ -269,6 +274,121 @@ __global__ __launch_bounds__(256) void ori_bwd_kernel(int N, OriParams p, const 
   d_omap[i] = g0; d_omap[(size_t)N + i] = g1; d_omap[2 * (size_t)N + i] = g2;
 }
 
+
+// ---- loss head (hgs_loss_head_*): the per-pixel terms that are not SSIM/L1, and the final reduction ---------------
+// pix kernels: binary cross-entropy with logits of the blended mask channel against the view's float mask
+// (loss/losses.py:240-248, F.binary_cross_entropy_with_logits, mean over H*W) and the orientation term above, in
+// one pass over the pixels; targets come from the device-resident HgsViewTargets.
+struct HeadFlags { int bce, ori; };
+
+__global__ __launch_bounds__(256) void pix_fwd_kernel(int N, HeadFlags fl, float bg0, float bg1, float bg2, float min_val,
+                                                      const float* __restrict__ mask_img, const float* __restrict__ omap,
+                                                      const HgsViewTargets* __restrict__ tgt, float* __restrict__ partials) {
+  __shared__ float red[4];
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  float s = 0.f, cnt = 0.f, b = 0.f;
+  if (i < N) {
+    if (fl.bce) {
+      const float x = mask_img[i], y = tgt->float_mask[i];
+      b = fmaxf(x, 0.f) - x * y + log1pf(expf(-fabsf(x)));
+    }
+    if (fl.ori) {
+      OriParams p;
+      p.view = tgt->viewmatrix; p.bg0 = bg0; p.bg1 = bg1; p.bg2 = bg2; p.min_val = min_val; p.has_mask = tgt->mask != nullptr;
+      const float o0 = omap[i], o1 = omap[(size_t)N + i], o2 = omap[2 * (size_t)N + i];
+      const bool m = p.has_mask ? tgt->mask[i] != 0 : (o0 != p.bg0 || o1 != p.bg1 || o2 != p.bg2);
+      if (m) {
+        float px, py, r, n, x, y, yq, th;
+        ori_pixel(p, o0, o1, o2, px, py, r, n, x, y, yq, th);
+        const float hp = 1.57079632679489661923f;
+        s = (hp - fabsf(fabsf(th - tgt->orientation[i]) - hp)) * tgt->confidence[i];
+        cnt = 1.f;
+      }
+    }
+  }
+  const float bs = block_sum(s, red);
+  const float bc = block_sum(cnt, red);
+  const float bb = block_sum(b, red);
+  if (threadIdx.x == 0) { partials[3 * blockIdx.x] = bs; partials[3 * blockIdx.x + 1] = bc; partials[3 * blockIdx.x + 2] = bb; }
+}
+
+__global__ __launch_bounds__(256) void pix_bwd_kernel(int N, HeadFlags fl, float bg0, float bg1, float bg2, float min_val,
+                                                      const float* __restrict__ mask_img, const float* __restrict__ omap,
+                                                      const HgsViewTargets* __restrict__ tgt, const float* __restrict__ out,
+                                                      const float* __restrict__ go, float* __restrict__ d_mask_img,
+                                                      float* __restrict__ d_omap) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= N) return;
+  const float up = *go;
+  float gm = 0.f;
+  if (fl.bce) {
+    const float x = mask_img[i], y = tgt->float_mask[i];
+    gm = out[HGS_HEAD_G_MASK] * up * (1.f / (1.f + expf(-x)) - y);
+  }
+  d_mask_img[i] = gm;
+  float g0 = 0.f, g1 = 0.f, g2 = 0.f;
+  if (fl.ori) {
+    OriParams p;
+    p.view = tgt->viewmatrix; p.bg0 = bg0; p.bg1 = bg1; p.bg2 = bg2; p.min_val = min_val; p.has_mask = tgt->mask != nullptr;
+    const float o0 = omap[i], o1 = omap[(size_t)N + i], o2 = omap[2 * (size_t)N + i];
+    const bool m = p.has_mask ? tgt->mask[i] != 0 : (o0 != p.bg0 || o1 != p.bg1 || o2 != p.bg2);
+    if (m) {
+      float px, py, r, n, x, y, yq, th;
+      ori_pixel(p, o0, o1, o2, px, py, r, n, x, y, yq, th);
+      if (r > 0.f) {
+        const float hp = 1.57079632679489661923f;
+        const float e = th - tgt->orientation[i];
+        const float u = fabsf(e) - hp;
+        const float sg = (u > 0.f ? 1.f : (u < 0.f ? -1.f : 0.f)) * (e > 0.f ? 1.f : (e < 0.f ? -1.f : 0.f));
+        const float dth = -sg * tgt->confidence[i] * (out[HGS_HEAD_G_ORI] * up) / out[HGS_HEAD_ORI_COUNT];
+        const float den = x * x + yq * yq;
+        const float dx = dth * (yq / den), dy = dth * (-x / den);
+        const float inv_n = 1.f / n, inv_n2 = inv_n * inv_n, ir = 1.f / r;
+        const float dn = -(dx * px + dy * py) * inv_n2;
+        const float dpx = dx * inv_n + dn * px * ir, dpy = dy * inv_n + dn * py * ir;
+        const float* v = p.view;
+        g0 = dpx * v[0] + dpy * v[1]; g1 = dpx * v[4] + dpy * v[5]; g2 = dpx * v[8] + dpy * v[9];
+      }
+    }
+  }
+  d_omap[i] = g0; d_omap[(size_t)N + i] = g1; d_omap[2 * (size_t)N + i] = g2;
+}
+
+// One block: fixed-order sums of the three partial arrays (bitwise reproducible), the loss terms, the total, and the
+// derivative of the total w.r.t. each term (what the backward kernels scale by).
+struct HeadReduce { int nb_ssim, nb_pix, nb_smooth; float inv_chw, inv_hw; float l_dssim, l_mask, l_ori, l_smooth; int bce, ori; };
+
+__device__ __forceinline__ float strided_sum(const float* __restrict__ a, int n, int stride, int off, float* red) {
+  float v = 0.f;
+  for (int i = threadIdx.x; i < n; i += 256) v += a[(size_t)i * stride + off];
+  return block_sum(v, red);
+}
+
+__global__ __launch_bounds__(256) void head_finalize_kernel(HeadReduce h, const float* __restrict__ p_ssim,
+                                                            const float* __restrict__ p_pix, const float* __restrict__ p_smooth,
+                                                            float* __restrict__ out) {
+  __shared__ float red[4];
+  const float ssim_s = strided_sum(p_ssim, h.nb_ssim, 2, 0, red), l1_s = strided_sum(p_ssim, h.nb_ssim, 2, 1, red);
+  const float ori_s = strided_sum(p_pix, h.nb_pix, 3, 0, red), ori_c = strided_sum(p_pix, h.nb_pix, 3, 1, red);
+  const float bce_s = strided_sum(p_pix, h.nb_pix, 3, 2, red);
+  const float sm_s = strided_sum(p_smooth, h.nb_smooth, 2, 0, red), sm_c = strided_sum(p_smooth, h.nb_smooth, 2, 1, red);
+  if (threadIdx.x != 0) return;
+  const float l1 = l1_s * h.inv_chw, dssim = 1.f - ssim_s * h.inv_chw;
+  const float w_l1 = fmaxf(0.f, 1.f - h.l_dssim);
+  float total = w_l1 * l1 + h.l_dssim * dssim;
+  float mask = 0.f, ori = 0.f, smooth = 0.f;
+  if (h.bce) { mask = bce_s * h.inv_hw; total += h.l_mask * mask; }
+  if (h.ori) { ori = ori_s / ori_c; total += h.l_ori * ori; }                        // empty mask -> NaN, as the reference
+  if (h.nb_smooth > 0) { smooth = sm_s / fmaxf(sm_c, 1.f); total += h.l_smooth * smooth; }
+  out[HGS_HEAD_TOTAL] = total; out[HGS_HEAD_L1] = l1; out[HGS_HEAD_DSSIM] = dssim; out[HGS_HEAD_MASK] = mask;
+  out[HGS_HEAD_ORIENTATION] = ori; out[HGS_HEAD_SMOOTH] = smooth;
+  out[HGS_HEAD_ORI_COUNT] = ori_c; out[HGS_HEAD_SMOOTH_COUNT] = sm_c;
+  out[HGS_HEAD_G_SSIM] = -h.l_dssim; out[HGS_HEAD_G_L1] = w_l1;
+  out[HGS_HEAD_G_MASK] = h.bce ? h.l_mask * h.inv_hw : 0.f;
+  out[HGS_HEAD_G_ORI] = h.ori ? h.l_ori : 0.f;
+  out[HGS_HEAD_G_SMOOTH] = h.nb_smooth > 0 ? h.l_smooth : 0.f;
+}
+
 }  // namespace
 
 extern "C" {
@@ -291,7 +411,7 @@ int hgs_ssim_l1_forward(void* stream, int C, int H, int W, const float* window11
   {
     HgsProfScope _prof(s, HGS_K_SSIM_FWD);
     hipLaunchKernelGGL(ssim_l1_fwd_kernel, dim3((W + LT - 1) / LT, (H + LT - 1) / LT, C), dim3(256), 0, s, H, W, win, img1,
-                       img2, dmaps, partials);
+                       img2, (const HgsViewTargets*)nullptr, dmaps, partials);
   }
   HGS_CHECK_LAUNCH();
   return 0;
@@ -309,7 +429,7 @@ int hgs_ssim_l1_backward(void* stream, int C, int H, int W, const float* window1
   {
     HgsProfScope _prof(s, HGS_K_SSIM_BWD);
     hipLaunchKernelGGL(ssim_l1_bwd_kernel, dim3((W + LT - 1) / LT, (H + LT - 1) / LT, C), dim3(256), 0, s, H, W, win, img1,
-                       img2, dmaps, g_ssim_mean, g_l1_mean, dL_dimg1);
+                       img2, (const HgsViewTargets*)nullptr, dmaps, g_ssim_mean, g_l1_mean, (const float*)nullptr, dL_dimg1);
   }
   HGS_CHECK_LAUNCH();
   return 0;
@@ -351,6 +471,94 @@ int hgs_orientation_loss_backward(void* stream, int H, int W, const float* omap,
     HgsProfScope _prof(s, HGS_K_ORI_BWD);
     hipLaunchKernelGGL(ori_bwd_kernel, dim3((N + 255) / 256), dim3(256), 0, s, N, ori_params(viewmatrix, bg3_host, min_val, mask),
                        omap, gt_theta, confidence, mask, g_loss, mask_count, d_omap);
+  }
+  HGS_CHECK_LAUNCH();
+  return 0;
+}
+
+// ---- loss head ------------------------------------------------------------------------------------------------------
+static inline int head_nb_ssim(const HgsHeadParams* p) { return ((p->W + LT - 1) / LT) * ((p->H + LT - 1) / LT) * 3; }
+static inline int head_nb_pix(const HgsHeadParams* p) { return (int)(((size_t)p->H * p->W + 255) / 256); }
+static inline int head_nb_smooth(const HgsHeadParams* p) { return p->lambda_smooth > 0.f ? (p->n_smooth + 255) / 256 : 0; }
+// scratch: [dmaps 9*H*W][ssim partials 2*nb][pix partials 3*nb][smooth partials 2*nb]
+size_t hgs_loss_head_scratch_floats(const HgsHeadParams* p) {
+  return 9 * (size_t)p->H * p->W + 2 * (size_t)head_nb_ssim(p) + 3 * (size_t)head_nb_pix(p) + 2 * (size_t)head_nb_smooth(p) + 8;
+}
+
+int hgs_loss_head_forward(void* stream, const HgsHeadParams* p, const float* image, const float* mask_img,
+                          const float* omap, const HgsViewTargets* targets, const float* endpoints,
+                          const long long* smooth_pairs, float* scratch, float* out) {
+  if (!p || !image || !mask_img || !omap || !targets || !scratch || !out || p->H <= 0 || p->W <= 0) {
+    hgs_set_error("hgs_loss_head_forward: bad arguments");
+    return 1;
+  }
+  const int H = p->H, W = p->W, N = H * W;
+  const int nbs = head_nb_ssim(p), nbp = head_nb_pix(p), nbm = head_nb_smooth(p);
+  if (nbm > 0 && (!endpoints || !smooth_pairs)) { hgs_set_error("hgs_loss_head_forward: smoothness term without endpoints"); return 1; }
+  float* dmaps = scratch;
+  float* p_ssim = dmaps + 9 * (size_t)N;
+  float* p_pix = p_ssim + 2 * (size_t)nbs;
+  float* p_smooth = p_pix + 3 * (size_t)nbp;
+  SsimWin win;
+  for (int k = 0; k < 11; k++) win.w[k] = p->window[k];
+  hipStream_t s = (hipStream_t)stream;
+  {
+    HgsProfScope _prof(s, HGS_K_SSIM_FWD);
+    hipLaunchKernelGGL(ssim_l1_fwd_kernel, dim3((W + LT - 1) / LT, (H + LT - 1) / LT, 3), dim3(256), 0, s, H, W, win, image,
+                       (const float*)nullptr, targets, dmaps, p_ssim);
+  }
+  HeadFlags fl;
+  fl.bce = p->lambda_mask > 0.f; fl.ori = p->lambda_orientation > 0.f;   // a NULL float_mask with lambda_mask > 0 is the caller's error
+  {
+    HgsProfScope _prof(s, HGS_K_ORI_FWD);
+    hipLaunchKernelGGL(pix_fwd_kernel, dim3(nbp), dim3(256), 0, s, N, fl, p->bg[0], p->bg[1], p->bg[2], p->min_val, mask_img,
+                       omap, targets, p_pix);
+  }
+  if (nbm > 0 && hgs_launch_smooth_fwd(s, p->n_smooth, endpoints, smooth_pairs, p->cos_threshold, p->eps, p_smooth)) return 1;
+  HeadReduce h;
+  h.nb_ssim = nbs; h.nb_pix = nbp; h.nb_smooth = nbm;
+  h.inv_chw = 1.f / (3.f * (float)N); h.inv_hw = 1.f / (float)N;
+  h.l_dssim = p->lambda_dssim; h.l_mask = p->lambda_mask; h.l_ori = p->lambda_orientation; h.l_smooth = p->lambda_smooth;
+  h.bce = fl.bce; h.ori = fl.ori;
+  {
+    HgsProfScope _prof(s, HGS_K_HEAD);
+    hipLaunchKernelGGL(head_finalize_kernel, dim3(1), dim3(256), 0, s, h, p_ssim, p_pix, p_smooth, out);
+  }
+  HGS_CHECK_LAUNCH();
+  return 0;
+}
+
+int hgs_loss_head_backward(void* stream, const HgsHeadParams* p, const float* image, const float* mask_img,
+                           const float* omap, const HgsViewTargets* targets, const float* endpoints,
+                           const long long* smooth_pairs, const float* scratch, const float* out,
+                           const float* grad_out, float* d_image, float* d_mask_img, float* d_omap,
+                           float* d_endpoints) {
+  if (!p || !image || !mask_img || !omap || !targets || !scratch || !out || !grad_out || !d_image || !d_mask_img || !d_omap) {
+    hgs_set_error("hgs_loss_head_backward: bad arguments");
+    return 1;
+  }
+  const int H = p->H, W = p->W, N = H * W;
+  const int nbp = head_nb_pix(p), nbm = head_nb_smooth(p);
+  const float* dmaps = scratch;
+  SsimWin win;
+  for (int k = 0; k < 11; k++) win.w[k] = p->window[k];
+  hipStream_t s = (hipStream_t)stream;
+  {
+    HgsProfScope _prof(s, HGS_K_SSIM_BWD);
+    hipLaunchKernelGGL(ssim_l1_bwd_kernel, dim3((W + LT - 1) / LT, (H + LT - 1) / LT, 3), dim3(256), 0, s, H, W, win, image,
+                       (const float*)nullptr, targets, dmaps, out + HGS_HEAD_G_SSIM, out + HGS_HEAD_G_L1, grad_out, d_image);
+  }
+  HeadFlags fl;
+  fl.bce = p->lambda_mask > 0.f; fl.ori = p->lambda_orientation > 0.f;
+  {
+    HgsProfScope _prof(s, HGS_K_ORI_BWD);
+    hipLaunchKernelGGL(pix_bwd_kernel, dim3(nbp), dim3(256), 0, s, N, fl, p->bg[0], p->bg[1], p->bg[2], p->min_val, mask_img,
+                       omap, targets, out, grad_out, d_mask_img, d_omap);
+  }
+  if (d_endpoints) {
+    if (hgs_zero_async(s, d_endpoints, (size_t)p->n_endpoints * 3 * sizeof(float))) return 1;
+    if (nbm > 0 && hgs_launch_smooth_bwd(s, p->n_smooth, endpoints, smooth_pairs, p->cos_threshold, p->eps,
+                                         out + HGS_HEAD_G_SMOOTH, out + HGS_HEAD_SMOOTH_COUNT, grad_out, d_endpoints)) return 1;
   }
   HGS_CHECK_LAUNCH();
   return 0;

@@ -91,7 +91,8 @@ __global__ __launch_bounds__(256) void smooth_fwd_kernel(int N, const float* __r
 
 __global__ __launch_bounds__(256) void smooth_bwd_kernel(int N, const float* __restrict__ ep, const long long* __restrict__ idx,
                                                          float cos_th, float eps, const float* __restrict__ g_loss,
-                                                         const float* __restrict__ count, float* __restrict__ d_ep) {
+                                                         const float* __restrict__ count, const float* __restrict__ go,
+                                                         float* __restrict__ d_ep) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= N) return;
   const long long* q = idx + 4 * (size_t)i;
@@ -100,7 +101,7 @@ __global__ __launch_bounds__(256) void smooth_bwd_kernel(int N, const float* __r
   if (!(e.dot > -1.f + eps && e.dot < 1.f - eps)) return;      // clamp saturated: zero gradient
   const float cnt = fmaxf(*count, 1.f);
   // d(ang^2)/d(dot) = 2 ang * (-1/sqrt(1-dot^2))
-  const float gdot = (*g_loss / cnt) * 2.f * e.ang * (-1.f / sqrtf(1.f - e.dot * e.dot));
+  const float gdot = (*g_loss * (go ? *go : 1.f) / cnt) * 2.f * e.ang * (-1.f / sqrtf(1.f - e.dot * e.dot));
   float g0[3], g1[3];                                           // gradients w.r.t. the two segment deltas
 #pragma unroll
   for (int c = 0; c < 3; c++) {
@@ -115,6 +116,21 @@ __global__ __launch_bounds__(256) void smooth_bwd_kernel(int N, const float* __r
 }
 
 }  // namespace
+
+// launchers shared with the loss head (hgs_losses.hip)
+int hgs_launch_smooth_fwd(hipStream_t s, int N, const float* endpoints, const long long* index_pairs, float cos_th, float eps,
+                          float* partials) {
+  HgsProfScope _prof(s, HGS_K_SMOOTH);
+  hipLaunchKernelGGL(smooth_fwd_kernel, dim3((N + 255) / 256), dim3(256), 0, s, N, endpoints, index_pairs, cos_th, eps, partials);
+  return 0;
+}
+int hgs_launch_smooth_bwd(hipStream_t s, int N, const float* endpoints, const long long* index_pairs, float cos_th, float eps,
+                          const float* g_loss, const float* count, const float* go, float* d_endpoints) {
+  HgsProfScope _prof(s, HGS_K_SMOOTH);
+  hipLaunchKernelGGL(smooth_bwd_kernel, dim3((N + 255) / 256), dim3(256), 0, s, N, endpoints, index_pairs, cos_th, eps, g_loss,
+                     count, go, d_endpoints);
+  return 0;
+}
 
 extern "C" {
 
@@ -170,7 +186,7 @@ int hgs_smoothness_backward(void* stream, int N, int E, const float* endpoints, 
   if (N <= 0) return 0;
   {
     HgsProfScope _prof(s, HGS_K_SMOOTH);
-    hipLaunchKernelGGL(smooth_bwd_kernel, dim3((N + 255) / 256), dim3(256), 0, s, N, endpoints, index_pairs, cos_threshold, eps, g_loss, count, d_endpoints);
+    hipLaunchKernelGGL(smooth_bwd_kernel, dim3((N + 255) / 256), dim3(256), 0, s, N, endpoints, index_pairs, cos_threshold, eps, g_loss, count, (const float*)nullptr, d_endpoints);
   }
   HGS_CHECK_LAUNCH();
   return 0;

@@ -21,7 +21,9 @@ namespace {
 __global__ __launch_bounds__(256) void strand_fwd_kernel(int P, const float* __restrict__ ep, const long long* __restrict__ pairs,
                                                          const float* __restrict__ width, float f, float* __restrict__ xyz,
                                                          float* __restrict__ scale, float* __restrict__ quat,
-                                                         float* __restrict__ dir) {
+                                                         float* __restrict__ dir, const float* __restrict__ opacity_raw,
+                                                         const float* __restrict__ mask_raw, float* __restrict__ opacity,
+                                                         float* __restrict__ extra4) {
   const int k = blockIdx.x * 256 + threadIdx.x;
   if (k >= P) return;
   const long long i0 = pairs[2 * (size_t)k], i1 = pairs[2 * (size_t)k + 1];
@@ -48,16 +50,25 @@ __global__ __launch_bounds__(256) void strand_fwd_kernel(int P, const float* __r
     if (L >= MINV) { ux = vx; uy = vy; uz = vz; }
   }
   ((float4*)quat)[k] = make_float4(q0, q1, q2, q3);
-  dir[3 * (size_t)k] = ux; dir[3 * (size_t)k + 1] = uy; dir[3 * (size_t)k + 2] = uz;
+  if (dir) { dir[3 * (size_t)k] = ux; dir[3 * (size_t)k + 1] = uy; dir[3 * (size_t)k + 2] = uz; }
+  if (opacity) opacity[k] = 1.f / (1.f + expf(-opacity_raw[k]));              // gaussian_model.py:93-95
+  if (extra4) ((float4*)extra4)[k] = make_float4(1.f / (1.f + expf(-mask_raw[k])), ux, uy, uz);  // :97-99 + direction
 }
 
 __global__ __launch_bounds__(256) void strand_bwd_kernel(int P, const float* __restrict__ ep, const long long* __restrict__ pairs,
                                                          const float* __restrict__ width, float f,
                                                          const float* __restrict__ g_xyz, const float* __restrict__ g_scale,
                                                          const float* __restrict__ g_quat, const float* __restrict__ g_dir,
-                                                         float* __restrict__ d_ep, float* __restrict__ d_width) {
+                                                         float* __restrict__ d_ep, float* __restrict__ d_width,
+                                                         const float* __restrict__ opacity, const float* __restrict__ extra4,
+                                                         const float* __restrict__ g_opacity, const float* __restrict__ g_extra4,
+                                                         float* __restrict__ d_opacity_raw, float* __restrict__ d_mask_raw) {
   const int k = blockIdx.x * 256 + threadIdx.x;
   if (k >= P) return;
+  float4 ge = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (g_extra4) ge = ((const float4*)g_extra4)[k];
+  if (d_opacity_raw) { const float o = opacity[k]; d_opacity_raw[k] = g_opacity[k] * o * (1.f - o); }   // sigmoid'
+  if (d_mask_raw) { const float m = extra4[4 * (size_t)k]; d_mask_raw[k] = ge.x * m * (1.f - m); }
   const long long i0 = pairs[2 * (size_t)k], i1 = pairs[2 * (size_t)k + 1];
   const float dx = ep[3 * i1] - ep[3 * i0], dy = ep[3 * i1 + 1] - ep[3 * i0 + 1], dz = ep[3 * i1 + 2] - ep[3 * i0 + 2];
   const float L = sqrtf(dx * dx + dy * dy + dz * dz);
@@ -73,6 +84,7 @@ __global__ __launch_bounds__(256) void strand_bwd_kernel(int P, const float* __r
     const float vx = dx * il, vy = dy * il, vz = dz * il;
     float gvx = 0.f, gvy = 0.f, gvz = 0.f;  // gradient w.r.t. the unit direction
     if (g_dir && L >= MINV) { gvx = g_dir[3 * (size_t)k]; gvy = g_dir[3 * (size_t)k + 1]; gvz = g_dir[3 * (size_t)k + 2]; }
+    if (g_extra4 && L >= MINV) { gvx += ge.y; gvy += ge.z; gvz += ge.w; }
     const float n0 = 1.f + vx;
     if (g_quat && n0 > MINV) {
       const float4 gq = ((const float4*)g_quat)[k];
@@ -107,7 +119,8 @@ int hgs_strand_geometry_forward(void* stream, int P, const float* endpoints, con
   {
     HgsProfScope _prof(s, HGS_K_STRAND_FWD);
     hipLaunchKernelGGL(strand_fwd_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, endpoints, endpoint_pairs, width,
-                       dist_to_scale_factor, xyz, scale, quat, dir);
+                       dist_to_scale_factor, xyz, scale, quat, dir, (const float*)nullptr, (const float*)nullptr,
+                       (float*)nullptr, (float*)nullptr);
   }
   HGS_CHECK_LAUNCH();
   return 0;
@@ -123,7 +136,49 @@ int hgs_strand_geometry_backward(void* stream, int P, int E, const float* endpoi
   {
     HgsProfScope _prof(s, HGS_K_STRAND_BWD);
     hipLaunchKernelGGL(strand_bwd_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, endpoints, endpoint_pairs, width,
-                       dist_to_scale_factor, g_xyz, g_scale, g_quat, g_dir, d_endpoints, d_width);
+                       dist_to_scale_factor, g_xyz, g_scale, g_quat, g_dir, d_endpoints, d_width, (const float*)nullptr,
+                       (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (float*)nullptr, (float*)nullptr);
+  }
+  HGS_CHECK_LAUNCH();
+  return 0;
+}
+
+int hgs_hair_params_forward(void* stream, int P, const float* endpoints, const long long* endpoint_pairs,
+                            const float* width, float dist_to_scale_factor, const float* opacity_raw,
+                            const float* mask_raw, float* xyz, float* scale, float* quat, float* dir, float* opacity,
+                            float* extra4) {
+  if (P == 0) return 0;
+  if (!endpoints || !endpoint_pairs || !width || !opacity_raw || !mask_raw || !xyz || !scale || !quat || !opacity || !extra4) {
+    hgs_set_error("hgs_hair_params_forward: null argument");
+    return 1;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  {
+    HgsProfScope _prof(s, HGS_K_STRAND_FWD);
+    hipLaunchKernelGGL(strand_fwd_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, endpoints, endpoint_pairs, width,
+                       dist_to_scale_factor, xyz, scale, quat, dir, opacity_raw, mask_raw, opacity, extra4);
+  }
+  HGS_CHECK_LAUNCH();
+  return 0;
+}
+
+int hgs_hair_params_backward(void* stream, int P, int E, const float* endpoints, const long long* endpoint_pairs,
+                             const float* width, float dist_to_scale_factor, const float* opacity, const float* extra4,
+                             const float* g_xyz, const float* g_scale, const float* g_quat, const float* g_dir,
+                             const float* g_opacity, const float* g_extra4, int accumulate_endpoints,
+                             float* d_endpoints, float* d_width, float* d_opacity_raw, float* d_mask_raw) {
+  if (!d_endpoints || !d_width || !d_opacity_raw || !d_mask_raw || !opacity || !extra4 || !g_opacity || !g_extra4) {
+    hgs_set_error("hgs_hair_params_backward: null argument");
+    return 1;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  if (!accumulate_endpoints && hgs_zero_async(s, d_endpoints, (size_t)E * 3 * sizeof(float))) return 1;
+  if (P == 0) return 0;
+  {
+    HgsProfScope _prof(s, HGS_K_STRAND_BWD);
+    hipLaunchKernelGGL(strand_bwd_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, endpoints, endpoint_pairs, width,
+                       dist_to_scale_factor, g_xyz, g_scale, g_quat, g_dir, d_endpoints, d_width, opacity, extra4,
+                       g_opacity, g_extra4, d_opacity_raw, d_mask_raw);
   }
   HGS_CHECK_LAUNCH();
   return 0;

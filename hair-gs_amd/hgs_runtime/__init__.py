@@ -49,6 +49,15 @@ SIGNATURES = {
     "hgs_smoothness_backward": (ci, [vp, ci, ci, vp, vp, cf, cf, vp, vp, vp]),
     "hgs_strand_geometry_forward": (ci, [vp, ci, vp, vp, vp, cf, vp, vp, vp, vp]),
     "hgs_strand_geometry_backward": (ci, [vp, ci, ci, vp, vp, vp, cf, vp, vp, vp, vp, vp, vp]),
+    "hgs_view_targets_bytes": (sz, []),
+    "hgs_head_params_bytes": (sz, []),
+    "hgs_select_view": (ci, [vp, vp, ci, vp, cf, vp]),
+    "hgs_hair_params_forward": (ci, [vp, ci, vp, vp, vp, cf, vp, vp, vp, vp, vp, vp, vp, vp]),
+    "hgs_hair_params_backward": (ci, [vp, ci, ci, vp, vp, vp, cf, vp, vp, vp, vp, vp, vp, vp, vp, ci, vp, vp, vp, vp]),
+    "hgs_loss_head_scratch_floats": (sz, [vp]),
+    "hgs_loss_head_forward": (ci, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
+    "hgs_loss_head_backward": (ci, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
+    "hgs_densify_stats": (ci, [vp, ci, vp, vp, ci, vp, vp, vp]),
     "hgs_prof_enable": (ci, [ci]),
     "hgs_prof_collect": (ci, [vp, vp]),
     "hgs_prof_kernel_name": (C.c_char_p, [ci]),
@@ -66,6 +75,24 @@ INST_GRAD_FLOATS = 12
 
 class HgsError(RuntimeError):
     pass
+
+
+class ViewTargets(C.Structure):
+    """include/hgs.h HgsViewTargets (184 bytes)."""
+    _fields_ = [("image", vp), ("float_mask", vp), ("orientation", vp), ("confidence", vp), ("mask", vp),
+                ("viewmatrix", cf * 16), ("projmatrix", cf * 16), ("campos", cf * 3), ("pad", cf)]
+
+
+class HeadParams(C.Structure):
+    """include/hgs.h HgsHeadParams."""
+    _fields_ = [("H", ci), ("W", ci), ("lambda_dssim", cf), ("lambda_mask", cf), ("lambda_orientation", cf),
+                ("lambda_smooth", cf), ("bg", cf * 3), ("min_val", cf), ("window", cf * 11), ("n_smooth", ci),
+                ("cos_threshold", cf), ("eps", cf), ("n_endpoints", ci)]
+
+
+HEAD_OUT = ["total", "l1", "dssim", "mask", "orientation", "smooth", "ori_count", "smooth_count", "g_ssim", "g_l1", "g_mask",
+            "g_ori", "g_smooth"]
+HEAD_NOUT = 16
 
 
 def build(verbose=False):
@@ -117,7 +144,7 @@ def require_gpu_tensor(t, name, dtype=None):
     return t.contiguous()
 
 
-KERNEL_COUNT = 16
+KERNEL_COUNT = 18
 
 
 def prof_enable(on=True):

@@ -1,0 +1,224 @@
+"""The strand-Gaussian training iteration as ONE autograd node over the C ABI (include/hgs.h: hgs_select_view,
+hgs_hair_params_*, hgs_forward_render_multi / hgs_backward_multi, hgs_loss_head_*, hgs_densify_stats).
+
+What the reference does between `gaussians` and `loss.backward()` in train.py:135-171 for a HairGaussianModel --
+getters (scene/hair_gaussian_model.py:134-201), three render() calls, loss_function (loss/losses.py:319-355) and the
+densification statistics (hair_gaussian_model.py:1401-1408) -- is ~60 small PyTorch kernels per iteration around the
+rasterizer.  Here the same arithmetic is ~20 launches: parameters -> Gaussians (1), rasterizer forward (6), loss head
+(4), loss head backward (4), rasterizer backward (4), Gaussians -> parameters (1), statistics (1).  Nothing is
+approximated; tests/test_gpu_train.py checks loss, gradients and statistics against the op-by-op path.
+
+Views live in a device-resident table (ViewTable); the iteration reads the current view through a 184-byte slot, so a
+captured HIP graph switches views with one tiny launch (hgs_select_view) and no image copies."""
+import ctypes as C
+import math
+
+import numpy as np
+import torch
+
+import hgs_runtime as rt
+from hgs_runtime.fused import gaussian_window11
+
+_SLOT_BYTES = C.sizeof(rt.ViewTargets)
+_F_VIEW, _F_PROJ, _F_CAM = (rt.ViewTargets.viewmatrix.offset // 4, rt.ViewTargets.projmatrix.offset // 4,
+                            rt.ViewTargets.campos.offset // 4)
+
+
+class ViewTable:
+    """HgsViewTargets rows of a list of cameras in device memory + the slot the kernels read.  The cameras' tensors are
+    referenced, not copied (they must stay alive and unchanged)."""
+
+    def __init__(self, cameras, device=None):
+        if len(cameras) == 0:
+            raise rt.HgsError("ViewTable needs at least one camera")
+        c0 = cameras[0]
+        self.device = torch.device(device) if device is not None else c0.original_image.device
+        self.H, self.W = int(c0.image_height), int(c0.image_width)
+        self.tanfovx, self.tanfovy = math.tan(c0.FoVx * 0.5), math.tan(c0.FoVy * 0.5)
+        self.has_float_mask = getattr(c0, "float_mask", None) is not None
+        self.has_mask = getattr(c0, "mask", None) is not None
+        rows = (rt.ViewTargets * len(cameras))()
+        self._keep = []
+        for i, c in enumerate(cameras):
+            if (int(c.image_height), int(c.image_width), c.FoVx, c.FoVy) != (self.H, self.W, c0.FoVx, c0.FoVy):
+                raise rt.HgsError("all views of a ViewTable must share resolution and field of view")
+            if (getattr(c, "float_mask", None) is not None) != self.has_float_mask or \
+                    (getattr(c, "mask", None) is not None) != self.has_mask:
+                raise rt.HgsError("either every view has a mask or none")
+            r = rows[i]
+            img = rt.require_gpu_tensor(c.original_image, "original_image", torch.float32)
+            ori = rt.require_gpu_tensor(c.orientation_field, "orientation_field", torch.float32)
+            conf = rt.require_gpu_tensor(c.orientation_confidence, "orientation_confidence", torch.float32)
+            keep = [img, ori, conf]
+            r.image, r.orientation, r.confidence = img.data_ptr(), ori.data_ptr(), conf.data_ptr()
+            if self.has_float_mask:
+                fm = rt.require_gpu_tensor(c.float_mask, "float_mask", torch.float32)
+                keep.append(fm)
+                r.float_mask = fm.data_ptr()
+            if self.has_mask:
+                m = rt.require_gpu_tensor(c.mask, "mask")
+                m = m.view(torch.uint8) if m.dtype == torch.bool else m.to(torch.uint8)
+                keep.append(m)
+                r.mask = m.data_ptr()
+            for k, v in enumerate(c.world_view_transform.detach().float().cpu().reshape(-1).tolist()):
+                r.viewmatrix[k] = v
+            for k, v in enumerate(c.full_proj_transform.detach().float().cpu().reshape(-1).tolist()):
+                r.projmatrix[k] = v
+            for k, v in enumerate(c.camera_center.detach().float().cpu().reshape(-1).tolist()):
+                r.campos[k] = v
+            self._keep.append(keep)
+        host = torch.from_numpy(np.frombuffer(bytes(rows), dtype=np.uint8).copy())
+        self.table = host.to(self.device)
+        self.slot = torch.zeros(_SLOT_BYTES, dtype=torch.uint8, device=self.device)
+        f = self.slot.view(torch.float32)
+        self.viewmatrix, self.projmatrix, self.campos = f[_F_VIEW:_F_VIEW + 16], f[_F_PROJ:_F_PROJ + 16], f[_F_CAM:_F_CAM + 3]
+        self.index = {id(c): i for i, c in enumerate(cameras)}
+        self.n = len(cameras)
+        self.current = -1
+
+    def select(self, view, lr=0.0, lr_dst=None):
+        """slot <- table[view] (and *lr_dst <- lr): one launch on the current stream."""
+        if not 0 <= int(view) < self.n:
+            raise rt.HgsError(f"view {view} outside the table (0..{self.n - 1})")
+        with torch.cuda.device(self.device):
+            rt.check(rt.lib().hgs_select_view(rt.current_stream(), self.table.data_ptr(), int(view), self.slot.data_ptr(),
+                                              float(lr), None if lr_dst is None else lr_dst.data_ptr()))
+        self.current = int(view)
+
+
+def head_params(H, W, opt, n_smooth, n_endpoints, min_val, has_float_mask, threshold_deg=30.0, eps=1e-6):
+    p = rt.HeadParams()
+    p.H, p.W = int(H), int(W)
+    p.lambda_dssim = float(opt.lambda_dssim)
+    p.lambda_mask = float(opt.lambda_mask) if has_float_mask else 0.0
+    p.lambda_orientation = float(opt.lambda_orientation)
+    p.lambda_smooth = float(getattr(opt, "lambda_smooth", 0.0)) if n_smooth > 0 else 0.0
+    p.bg[0] = p.bg[1] = p.bg[2] = 0.0          # the orientation / mask renders use a black background (losses.py:247,312)
+    p.min_val = float(min_val)
+    win = gaussian_window11()
+    for k in range(11):
+        p.window[k] = win[k]
+    p.n_smooth = int(n_smooth)
+    p.cos_threshold = float(np.cos(threshold_deg * np.pi / 180))
+    p.eps = float(eps)
+    p.n_endpoints = int(n_endpoints)
+    return p
+
+
+class _StrandIteration(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, endpoints, width, opacity_raw, mask_raw, f_dc, f_rest, step):
+        from diff_gaussian_rasterization import _C as raster
+        g, vt, L = step.gaussians, step.views, rt.lib()
+        endpoints = rt.require_gpu_tensor(endpoints, "endpoints", torch.float32)
+        width = rt.require_gpu_tensor(width, "width", torch.float32)
+        opacity_raw = rt.require_gpu_tensor(opacity_raw, "opacity", torch.float32)
+        mask_raw = rt.require_gpu_tensor(mask_raw, "mask", torch.float32)
+        pairs = rt.require_gpu_tensor(g.endpoint_pairs, "endpoint_pairs", torch.int64)
+        dev, P, E = endpoints.device, pairs.shape[0], endpoints.shape[0]
+        f32 = dict(dtype=torch.float32, device=dev)
+        xyz, scale, quat = torch.empty((P, 3), **f32), torch.empty((P, 3), **f32), torch.empty((P, 4), **f32)
+        opacity, extra4 = torch.empty((P, 1), **f32), torch.empty((P, 4), **f32)
+        factor = float(g.dist_to_scale_factor)
+        stream = rt.current_stream()
+        with torch.cuda.device(dev):
+            rt.check(L.hgs_hair_params_forward(stream, P, rt.ptr(endpoints), rt.ptr(pairs), rt.ptr(width), factor,
+                                               rt.ptr(opacity_raw), rt.ptr(mask_raw), rt.ptr(xyz), rt.ptr(scale), rt.ptr(quat),
+                                               None, rt.ptr(opacity), rt.ptr(extra4)))
+        shs = f_dc if f_rest.numel() == 0 else torch.cat((f_dc, f_rest), dim=1)
+        empty = step.empty
+        R, planes, radii, geom, binning, img = raster.rasterize_gaussians_multi(
+            step.bg7, xyz, empty, extra4, opacity, scale, quat, 1.0, empty, vt.viewmatrix, vt.projmatrix, vt.tanfovx,
+            vt.tanfovy, vt.H, vt.W, shs, g.active_sh_degree, vt.campos, False, False)
+        idx = step.smooth_pairs
+        hp = step.head
+        hp.n_endpoints = E
+        scratch = torch.empty((L.hgs_loss_head_scratch_floats(C.byref(hp)),), **f32)
+        out = torch.empty((rt.HEAD_NOUT,), **f32)
+        with torch.cuda.device(dev):
+            rt.check(L.hgs_loss_head_forward(stream, C.byref(hp), planes[0:3].data_ptr(), planes[3].data_ptr(),
+                                             planes[4:7].data_ptr(), vt.slot.data_ptr(), rt.ptr(endpoints), rt.ptr(idx),
+                                             rt.ptr(scratch), rt.ptr(out)))
+        ctx.step, ctx.R, ctx.f_rest_k = step, R, f_rest.shape[1]
+        ctx.save_for_backward(endpoints, width, pairs, xyz, scale, quat, opacity, extra4, shs, planes, radii, geom, binning,
+                              img, scratch, out)
+        step.last = {"planes": planes, "radii": radii, "terms": out}
+        terms = out.detach()
+        ctx.mark_non_differentiable(terms)
+        return out[0], terms
+
+    @staticmethod
+    def backward(ctx, go, _):
+        from diff_gaussian_rasterization import _C as raster
+        step, L = ctx.step, rt.lib()
+        g, vt, hp = step.gaussians, step.views, step.head
+        (endpoints, width, pairs, xyz, scale, quat, opacity, extra4, shs, planes, radii, geom, binning, img, scratch,
+         out) = ctx.saved_tensors
+        dev, P, E = endpoints.device, pairs.shape[0], endpoints.shape[0]
+        f32 = dict(dtype=torch.float32, device=dev)
+        go = go.contiguous().to(torch.float32)
+        dplanes = torch.empty_like(planes)
+        d_ep = torch.empty((E, 3), **f32)
+        stream = rt.current_stream()
+        hp.n_endpoints = E
+        with torch.cuda.device(dev):
+            rt.check(L.hgs_loss_head_backward(stream, C.byref(hp), planes[0:3].data_ptr(), planes[3].data_ptr(),
+                                              planes[4:7].data_ptr(), vt.slot.data_ptr(), rt.ptr(endpoints),
+                                              rt.ptr(step.smooth_pairs), rt.ptr(scratch), rt.ptr(out), rt.ptr(go),
+                                              dplanes[0:3].data_ptr(), dplanes[3].data_ptr(), dplanes[4:7].data_ptr(),
+                                              rt.ptr(d_ep)))
+        empty = step.empty
+        (g_means2D, _gc, g_ex, g_opac, g_means3D, _gcov, g_sh, g_scales, g_rot) = raster.rasterize_gaussians_multi_backward(
+            step.bg7, xyz, radii, empty, scale, quat, 1.0, empty, vt.viewmatrix, vt.projmatrix, vt.tanfovx, vt.tanfovy,
+            [dplanes[k] for k in range(7)], shs, g.active_sh_degree, vt.campos, geom, ctx.R, binning, img, False)
+        d_w, d_o, d_m = torch.empty((P, 1), **f32), torch.empty((P, 1), **f32), torch.empty((P, 1), **f32)
+        with torch.cuda.device(dev):
+            rt.check(L.hgs_hair_params_backward(stream, P, E, rt.ptr(endpoints), rt.ptr(pairs), rt.ptr(width),
+                                                float(g.dist_to_scale_factor), rt.ptr(opacity), rt.ptr(extra4),
+                                                rt.ptr(g_means3D), rt.ptr(g_scales), rt.ptr(g_rot), None, rt.ptr(g_opac),
+                                                rt.ptr(g_ex), 1, rt.ptr(d_ep), rt.ptr(d_w), rt.ptr(d_o), rt.ptr(d_m)))
+        step.last["dmean2D"] = g_means2D      # RGB-only screen-space gradient: what the densification statistics see
+        if ctx.f_rest_k == 0:
+            d_dc, d_rest = g_sh, None
+        else:
+            d_dc, d_rest = g_sh[:, :1], g_sh[:, 1:]
+        return d_ep, d_w, d_o, d_m, d_dc, d_rest, None
+
+
+class FusedStrandStep:
+    """Host side of the fused iteration for one HairGaussianModel and one set of views."""
+
+    def __init__(self, gaussians, cameras, opt, bg):
+        self.gaussians, self.opt = gaussians, opt
+        self.views = cameras if isinstance(cameras, ViewTable) else ViewTable(cameras)
+        dev = self.views.device
+        self.bg7 = torch.cat([bg.to(dev, torch.float32), torch.zeros(4, device=dev)]).contiguous()
+        self.empty = torch.empty(0, device=dev)
+        self.last = {}
+        self.refresh()
+
+    def refresh(self):
+        """Call after anything that changes the strands' topology (the smoothness index table and sizes)."""
+        g = self.gaussians
+        idx = g.smoothness_index_pairs() if float(getattr(self.opt, "lambda_smooth", 0.0)) > 0 else None
+        n = 0 if idx is None else int(idx.shape[0])
+        self.smooth_pairs = rt.require_gpu_tensor(idx, "index_pairs", torch.int64) if n > 0 else None
+        self.head = head_params(self.views.H, self.views.W, self.opt, n, g._endpoints.shape[0], g.min_val,
+                                self.views.has_float_mask)
+
+    def loss(self):
+        """(total loss, terms tensor) of the CURRENT slot view; differentiable w.r.t. the model parameters."""
+        g = self.gaussians
+        return _StrandIteration.apply(g._endpoints, g._width, g._opacity, g._mask, g._features_dc, g._features_rest, self)
+
+    def terms(self):
+        t = self.last["terms"]
+        return {k: t[i] for i, k in enumerate(rt.HEAD_OUT[1:6], start=1)}
+
+    def update_densification_stats(self):
+        """add_densification_stats + max_radii2D of the iteration just back-propagated (one launch)."""
+        g, last = self.gaussians, self.last
+        gm, radii = last["dmean2D"], last["radii"]
+        with torch.cuda.device(gm.device):
+            rt.check(rt.lib().hgs_densify_stats(rt.current_stream(), gm.shape[0], rt.ptr(radii), rt.ptr(gm), gm.shape[1],
+                                                rt.ptr(g.max_radii2D), rt.ptr(g.xyz_gradient_accum), rt.ptr(g.denom)))

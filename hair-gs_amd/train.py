@@ -83,24 +83,40 @@ class ViewSampler:
         return self.cameras[picks[self.rank]]
 
 
-def training_step(gaussians, viewpoint_cam, opt, bg, iteration, extent=1.0, vp=None, stats_local=None):
+def fused_step_applicable(gaussians, opt):
+    """The fused iteration (hgs_runtime.strand_step) covers the Stage-III model with the single-pass rasterizer on the
+    GPU and the reference's default loss terms (no magnet loss)."""
+    return (getattr(opt, "fused_step", True) and getattr(opt, "single_pass", True)
+            and isinstance(gaussians, HairGaussianModel) and gaussians._endpoints.is_cuda
+            and float(getattr(opt, "lambda_magnet", 0.0)) == 0.0)
+
+
+def training_step(gaussians, viewpoint_cam, opt, bg, iteration, extent=1.0, vp=None, stats_local=None, fused=None):
     """One optimizer step.  Returns (loss tensor (detached, on device), loss_dict, render_pkg).
     In the rasterizer's asynchronous mode (diff_gaussian_rasterization._C.set_async) the three passes never block;
-    their instance counts are validated once here, before Adam, and the step is repeated if a pass overflowed."""
+    their instance counts are validated once here, before Adam, and the step is repeated if a pass overflowed.
+    `fused`: a hgs_runtime.strand_step.FusedStrandStep whose view table holds `viewpoint_cam` -> the iteration runs as
+    one autograd node over the fused kernels (same loss, gradients and statistics)."""
     from diff_gaussian_rasterization import _C as raster
     for _attempt in range(4):
         try:
-            return _training_step(gaussians, viewpoint_cam, opt, bg, iteration, extent, vp, raster)
+            return _training_step(gaussians, viewpoint_cam, opt, bg, iteration, extent, vp, raster, fused)
         except raster.HgsCapacityOverflow:
             gaussians.optimizer.zero_grad(set_to_none=True)
     raise RuntimeError("rasterizer capacity kept overflowing")
 
 
-def _training_step(gaussians, viewpoint_cam, opt, bg, iteration, extent, vp, raster):
+def _training_step(gaussians, viewpoint_cam, opt, bg, iteration, extent, vp, raster, fused=None):
     gaussians.update_learning_rate(iteration)
     if iteration % 1000 == 0:
         gaussians.oneupSHdegree()
-    if getattr(opt, "single_pass", True) and gaussians.get_xyz.is_cuda:
+    if fused is not None:
+        fused.views.select(fused.views.index[id(viewpoint_cam)])
+        loss, _ = fused.loss()
+        loss_dict = fused.terms()
+        render_pkg = {"render": fused.last["planes"][:3], "radii": fused.last["radii"], "viewspace_points": None,
+                      "visibility_filter": None}
+    elif getattr(opt, "single_pass", True) and gaussians.get_xyz.is_cuda:
         # RGB + mask + orientation in one rasterizer traversal (same loss, 3x fewer raster passes)
         loss, loss_dict, render_pkg = loss_function_single_pass(gaussians, viewpoint_cam, opt, bg)
     else:
@@ -110,8 +126,11 @@ def _training_step(gaussians, viewpoint_cam, opt, bg, iteration, extent, vp, ras
     raster.check_async()  # async mode: the step's single synchronisation (raises -> step repeated); no-op otherwise
     with torch.no_grad():
         if iteration < opt.densify_until_iter:
-            gaussians.update_densification_stats(render_pkg["viewspace_points"], render_pkg["radii"],
-                                                 render_pkg["visibility_filter"])
+            if fused is not None:
+                fused.update_densification_stats()
+            else:
+                gaussians.update_densification_stats(render_pkg["viewspace_points"], render_pkg["radii"],
+                                                     render_pkg["visibility_filter"])
             if iteration > opt.densify_from_iter and iteration % opt.densification_interval == 0 \
                     and hasattr(gaussians, "densification") and getattr(opt, "enable_topology", True):
                 if vp is not None:
@@ -142,11 +161,16 @@ class GraphedStep:
     CAMERA_FIELDS = ("world_view_transform", "full_proj_transform", "camera_center", "original_image", "mask",
                      "float_mask", "orientation_field", "orientation_confidence")
 
-    def __init__(self, gaussians, cameras, opt, bg, extent=1.0, vp=None, slack=2.0):
+    def __init__(self, gaussians, cameras, opt, bg, extent=1.0, vp=None, slack=2.0, views=None):
         import copy
         from diff_gaussian_rasterization import _C as raster
         self.g, self.opt, self.bg, self.extent, self.raster = gaussians, opt, bg, extent, raster
         self.vp = vp if vp is not None else ViewParallel()
+        self.fused = None
+        if fused_step_applicable(gaussians, opt):
+            # device-resident view table: a view switch is one tiny launch, not eight tensor copies
+            from hgs_runtime.strand_step import FusedStrandStep, ViewTable
+            self.fused = FusedStrandStep(gaussians, views if views is not None else ViewTable(cameras), opt, bg)
         c0 = cameras[0]
         for c in cameras:  # by-value kernel arguments are frozen into the graph
             assert (c.image_width, c.image_height, c.FoVx, c.FoVy) == (c0.image_width, c0.image_height, c0.FoVx, c0.FoVy)
@@ -179,17 +203,27 @@ class GraphedStep:
                 elif torch.is_tensor(st.get("step")) and not st["step"].is_cuda:
                     st["step"] = st["step"].to(dev)
 
+    def _position_lr(self):
+        for group in self.g.optimizer.param_groups:
+            if group["name"] == self.g._POSITION_GROUP:
+                return group["lr"]
+        return None
+
     def _set_lr(self, iteration):
         g = self.g
         lr = g.xyz_scheduler_args(iteration)
-        for group in g.optimizer.param_groups:
-            if group["name"] == g._POSITION_GROUP:
-                group["lr"].fill_(float(lr))
+        self._lr_now = float(lr)
+        if self.fused is None:  # the fused path writes the position lr with the view-select launch
+            self._position_lr().fill_(float(lr))
         if hasattr(g, "merge_dist_th_scheduler"):
             g.merge_dist_th = g.merge_dist_th_scheduler(iteration)
             g.merge_angle_th = g.merge_angle_th_scheduler(iteration)
 
     def load_camera(self, cam):
+        if self.fused is not None:
+            v = self.fused.views
+            v.select(v.index[id(cam)], lr=self._lr_now, lr_dst=self._position_lr())
+            return
         for f in self.CAMERA_FIELDS:
             dst, src = getattr(self.slot, f, None), getattr(cam, f, None)
             if torch.is_tensor(dst) and torch.is_tensor(src):
@@ -197,6 +231,11 @@ class GraphedStep:
         self.slot.uid = cam.uid
 
     def _forward_backward(self):
+        if self.fused is not None:
+            loss, _ = self.fused.loss()
+            loss.backward()
+            self.fused.update_densification_stats()
+            return loss.detach()
         if getattr(self.opt, "single_pass", True):
             loss, _, pkg = loss_function_single_pass(self.g, self.slot, self.opt, self.bg)
         else:
@@ -216,8 +255,8 @@ class GraphedStep:
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):
             for cam in warmup_cams:  # every view once: the capacity must cover the busiest camera
-                self.load_camera(cam)
                 self._set_lr(iteration)
+                self.load_camera(cam)
                 self._forward_backward()
                 g.optimizer.zero_grad(set_to_none=True)
                 g._derived = None
@@ -253,7 +292,6 @@ class GraphedStep:
         ga, gb = self._graphs
         ga.replay()
         if gb is not None:
-            self.vp.reduce_stats_and_grads = None
             self.vp.reduce_gradients(self.g)
             gb.replay()
         self.g._derived = None  # cached derived tensors now hold pre-update values
@@ -315,6 +353,12 @@ def training(gaussians, cameras, opt, iterations=None, extent=1.0, seed=0, log_e
     n = opt.iterations if iterations is None else iterations
     gs = None
     use_graph = use_graph and dev.type == "cuda"
+    views = fused = None
+    if dev.type == "cuda" and fused_step_applicable(gaussians, opt):
+        from hgs_runtime.strand_step import FusedStrandStep, ViewTable
+        views = ViewTable(cameras)             # built once; survives topology changes
+        if not use_graph:
+            fused = FusedStrandStep(gaussians, views, opt, bg)
     saved_topology = getattr(opt, "enable_topology", True)
     opt.enable_topology = False  # the loop below schedules the operators itself
     try:
@@ -325,17 +369,19 @@ def training(gaussians, cameras, opt, iterations=None, extent=1.0, seed=0, log_e
                 gs = None
             if use_graph:
                 if gs is None:
-                    gs = GraphedStep(gaussians, cameras, opt, bg, extent=extent, vp=vp)
+                    gs = GraphedStep(gaussians, cameras, opt, bg, extent=extent, vp=vp, views=views)
                     gs.capture(cameras, iteration=it)
                 loss = gs.step(sampler.next(), it)
             else:
-                loss, _, _ = training_step(gaussians, sampler.next(), opt, bg, it, extent=extent, vp=vp)
+                loss, _, _ = training_step(gaussians, sampler.next(), opt, bg, it, extent=extent, vp=vp, fused=fused)
             ema = loss.clone() if ema is None else 0.4 * loss + 0.6 * ema  # on the device: no per-iteration host sync
             if any(d in due for d in ("densify", "reset_opacity", "merge")):
                 if gs is not None:
                     gs.check()
                 apply_topology(gaussians, opt, it, extent, due, vp)
                 gs = None  # shapes changed: capture again at the next iteration
+                if fused is not None:
+                    fused.refresh()
             if log_every and it % log_every == 0 and vp.rank == 0:
                 print(f"[it {it}] loss(ema) {float(ema):.6f}  segments {gaussians.get_xyz.shape[0]}")
         if gs is not None:

@@ -171,13 +171,94 @@ int hgs_strand_geometry_backward(void* stream, int P, int E, const float* endpoi
                                  const float* width, float dist_to_scale_factor, const float* g_xyz, const float* g_scale,
                                  const float* g_quat, const float* g_dir, float* d_endpoints, float* d_width);
 
+/* ---- the strand-Gaussian training iteration as a handful of launches -------------------------
+ * The reference runs everything between the model parameters and the rasterizer, and between the rendered images and
+ * the scalar loss, as ~60 small PyTorch kernels per iteration (train.py:135-168, loss/losses.py:224-355,
+ * scene/hair_gaussian_model.py:134-201,1401-1408).  On MI355X those launches, not the math, bound the step; the
+ * entry points below do the same arithmetic in one kernel per stage.
+ *
+ * HgsViewTargets: one training view's targets, resident in HBM for the whole run (288 GB holds every view of a capture
+ *   session).  The loss-head kernels read it from DEVICE memory, so a captured HIP graph switches views by rewriting
+ *   this one struct (hgs_select_view) instead of copying ~50 MB of images into a staging slot.  viewmatrix /
+ *   projmatrix / campos are stored by value in the layout the reference's Camera holds them (world_view_transform,
+ *   full_proj_transform: row-major, transposed; scene/cameras.py:59-62), so `&slot->viewmatrix[0]` is a valid
+ *   `viewmatrix` argument of the rasterizer entry points. */
+typedef struct HgsViewTargets {
+  const float* image;           /* [3,H,W] ground-truth RGB (Camera.original_image) */
+  const float* float_mask;      /* [H,W] mask as floats, BCE target (Camera.float_mask); NULL: no mask term */
+  const float* orientation;     /* [H,W] ground-truth strand angle in [0,pi) (Camera.orientation_field) */
+  const float* confidence;      /* [H,W] (Camera.orientation_confidence) */
+  const unsigned char* mask;    /* [H,W] bool mask of the orientation term (Camera.mask); NULL: any(omap != bg) */
+  float viewmatrix[16];
+  float projmatrix[16];
+  float campos[3];
+  float pad;
+} HgsViewTargets;
+size_t hgs_view_targets_bytes(void);   /* sizeof(HgsViewTargets), for bindings that mirror the struct */
+size_t hgs_head_params_bytes(void);    /* sizeof(HgsHeadParams) */
+/* slot[0] = table[view]; if lr_dst != NULL also *lr_dst = lr (the position learning rate of this iteration, a by-value
+ * kernel argument, so the host may run ahead of the device without racing on a staging buffer). */
+int hgs_select_view(void* stream, const HgsViewTargets* table, int view, HgsViewTargets* slot, float lr, float* lr_dst);
+
+/* hgs_hair_params_forward/backward: hgs_strand_geometry_* plus the appearance activations of the same Gaussians
+ *   (scene/gaussian_model.py:93-99 get_opacity / get_mask = sigmoid) and the 4 extra blended channels of the
+ *   single-pass rasterizer, extra4 = [sigmoid(mask_raw), dir.xyz].  backward: g_extra4 [P,4] carries the gradient of
+ *   the mask channel and of the direction (added to g_dir); `opacity`/`extra4` are the forward outputs;
+ *   accumulate_endpoints != 0: d_endpoints is NOT zeroed first (it already holds the smoothness gradient). */
+int hgs_hair_params_forward(void* stream, int P, const float* endpoints, const long long* endpoint_pairs,
+                            const float* width, float dist_to_scale_factor, const float* opacity_raw,
+                            const float* mask_raw, float* xyz, float* scale, float* quat, float* dir, float* opacity,
+                            float* extra4);
+int hgs_hair_params_backward(void* stream, int P, int E, const float* endpoints, const long long* endpoint_pairs,
+                             const float* width, float dist_to_scale_factor, const float* opacity, const float* extra4,
+                             const float* g_xyz, const float* g_scale, const float* g_quat, const float* g_dir,
+                             const float* g_opacity, const float* g_extra4, int accumulate_endpoints,
+                             float* d_endpoints, float* d_width, float* d_opacity_raw, float* d_mask_raw);
+
+/* hgs_loss_head_forward/backward <-> loss/losses.py:319-355 loss_function on the three rendered images:
+ *   total = (1-l_dssim) L1 + l_dssim (1-SSIM) + l_mask BCEWithLogits(mask_img, float_mask) + l_orientation ORI
+ *           + l_smooth SMOOTH(endpoints),  terms with weight 0 (or a NULL target) skipped.
+ *   forward: 4 launches (SSIM/L1 map, BCE + orientation per pixel, smoothness per segment pair, one-block reduction);
+ *   out[HGS_HEAD_*] device floats.  scratch: hgs_loss_head_scratch_floats() floats, kept for the backward.
+ *   backward: d_image [3,H,W], d_mask_img [H,W], d_omap [3,H,W] fully written; d_endpoints [E,3] zeroed, then the
+ *   smoothness gradient scattered into it; grad_out = device scalar dL/dtotal. */
+typedef struct HgsHeadParams {
+  int H, W;
+  float lambda_dssim, lambda_mask, lambda_orientation, lambda_smooth;
+  float bg[3];                  /* background of the orientation render (loss/losses.py:249: black) */
+  float min_val;                /* HairGaussianModel.min_val */
+  float window[11];             /* SSIM window taps */
+  int n_smooth;                 /* rows of the smoothness index table */
+  float cos_threshold, eps;     /* loss/losses.py:175: threshold 30 deg, eps 1e-6 */
+  int n_endpoints;
+} HgsHeadParams;
+enum { HGS_HEAD_TOTAL = 0, HGS_HEAD_L1, HGS_HEAD_DSSIM, HGS_HEAD_MASK, HGS_HEAD_ORIENTATION, HGS_HEAD_SMOOTH,
+       HGS_HEAD_ORI_COUNT, HGS_HEAD_SMOOTH_COUNT, HGS_HEAD_G_SSIM, HGS_HEAD_G_L1, HGS_HEAD_G_MASK, HGS_HEAD_G_ORI,
+       HGS_HEAD_G_SMOOTH, HGS_HEAD_NOUT = 16 };
+size_t hgs_loss_head_scratch_floats(const HgsHeadParams* p);
+int hgs_loss_head_forward(void* stream, const HgsHeadParams* p, const float* image, const float* mask_img,
+                          const float* omap, const HgsViewTargets* targets, const float* endpoints,
+                          const long long* smooth_pairs, float* scratch, float* out);
+int hgs_loss_head_backward(void* stream, const HgsHeadParams* p, const float* image, const float* mask_img,
+                           const float* omap, const HgsViewTargets* targets, const float* endpoints,
+                           const long long* smooth_pairs, const float* scratch, const float* out,
+                           const float* grad_out, float* d_image, float* d_mask_img, float* d_omap,
+                           float* d_endpoints);
+
+/* hgs_densify_stats <-> scene/hair_gaussian_model.py:1401-1408 / gaussian_model.py:675-682 add_densification_stats +
+ *   train.py:170-171 max_radii2D update, for the Gaussians with radii > 0:
+ *   max_radii2D = max(max_radii2D, radii); xyz_gradient_accum += |dL_dmean2D.xy|; denom += 1.
+ *   dL_dmean2D has `stride` floats per Gaussian (3 as the rasterizer returns it). */
+int hgs_densify_stats(void* stream, int P, const int* radii, const float* dL_dmean2D, int stride, float* max_radii2D,
+                      float* xyz_gradient_accum, float* denom);
+
 /* ---- per-kernel device timing (bench.py roofline): when enabled every kernel launch of the library is bracketed
  * by hipEvents recorded on the launch stream.  hgs_prof_collect() synchronises those events, ADDS elapsed
  * milliseconds / launch counts per kernel id into the caller's arrays (length HGS_K_COUNT) and clears the log.
  * No reference counterpart (the reference only times whole iterations, train.py:81-82,133,156). ---- */
 enum { HGS_K_PREPROCESS_FWD = 0, HGS_K_SCAN, HGS_K_SCATTER, HGS_K_SORT_TILES, HGS_K_BLEND_FWD, HGS_K_BLEND_BWD,
        HGS_K_PREPROCESS_BWD, HGS_K_KNN, HGS_K_SSIM_FWD, HGS_K_SSIM_BWD, HGS_K_STRAND_FWD, HGS_K_STRAND_BWD,
-       HGS_K_ORI_FWD, HGS_K_ORI_BWD, HGS_K_ADAM, HGS_K_SMOOTH, HGS_K_COUNT };
+       HGS_K_ORI_FWD, HGS_K_ORI_BWD, HGS_K_ADAM, HGS_K_SMOOTH, HGS_K_HEAD, HGS_K_MISC, HGS_K_COUNT };
 int hgs_prof_enable(int on);
 int hgs_prof_collect(double* total_ms, long long* launches);
 const char* hgs_prof_kernel_name(int kernel_id);

@@ -45,6 +45,21 @@ def test_workspace_sizes_and_layouts_are_consistent():
     assert L.hgs_backward_scratch_bytes(10, 1000) >= 1000 * 48
 
 
+def test_struct_mirrors_match_the_library():
+    import ctypes as C
+    import hgs_runtime as rt
+    L = rt.lib()
+    assert L.hgs_view_targets_bytes() == C.sizeof(rt.ViewTargets) == 184
+    assert L.hgs_head_params_bytes() == C.sizeof(rt.HeadParams)
+    assert rt.ViewTargets.viewmatrix.offset == 40 and rt.ViewTargets.campos.offset == 168
+    src = open(os.path.join(ROOT, "include", "hgs.h")).read()
+    names = re.search(r"enum \{ HGS_HEAD_TOTAL = 0,(.*?)HGS_HEAD_NOUT = (\d+)", src, re.S)
+    listed = [n.strip() for n in ("HGS_HEAD_TOTAL," + names.group(1)).split(",") if n.strip()]
+    assert [n[len("HGS_HEAD_"):].lower() for n in listed] == [
+        {"orientation": "orientation"}.get(k, k) for k in rt.HEAD_OUT]
+    assert int(names.group(2)) == rt.HEAD_NOUT
+
+
 def test_python_surface_matches_reference_names():
     import inspect
     import diff_gaussian_rasterization as dgr

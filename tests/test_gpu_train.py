@@ -235,8 +235,10 @@ def test_graphed_step_matches_eager_steps():
             bg = torch.zeros(3, device="cuda")
             losses = []
             if mode == "eager":
+                from hgs_runtime.strand_step import FusedStrandStep
+                fused = FusedStrandStep(model, cams, opt, bg)  # the iteration the graph captures, launched eagerly
                 for it, ci in enumerate(order, 1):
-                    loss, _, _ = training_step(model, cams[ci], opt, bg, it, extent=extent)
+                    loss, _, _ = training_step(model, cams[ci], opt, bg, it, extent=extent, fused=fused)
                     losses.append(float(loss))
             else:
                 gs = GraphedStep(model, cams, opt, bg, extent=extent)
@@ -385,3 +387,86 @@ def test_fused_ssim_odd_sizes(hw):
     (s2 + 2 * l2).backward()
     assert abs(float(s) - float(s2)) < 2e-5 and abs(float(l) - float(l2)) < 1e-6
     assert (ga - a.grad).abs().max() <= 2e-4 * a.grad.abs().max()
+
+
+def test_fused_iteration_matches_op_by_op_path():
+    """hgs_runtime.strand_step (view table + fused parameter/loss-head kernels, one autograd node) against the
+    op-by-op path (getters, render_multi, loss_function_single_pass, update_densification_stats): same loss terms,
+    same gradients of every parameter group, same densification statistics."""
+    from arguments import OptimizationParams
+    from hgs_runtime.strand_step import FusedStrandStep
+    from loss.losses import loss_function_single_pass
+    from synthetic import build_workload
+    from utils.general import safe_state
+    safe_state(True)
+    model, cams, _ = build_workload("tiny", device="cuda", with_targets=True)
+    opt = OptimizationParams()
+    model.training_setup(opt)
+    bg = torch.zeros(3, device="cuda")
+    params = [model._endpoints, model._width, model._opacity, model._mask, model._features_dc, model._features_rest]
+    # the synthetic targets are renders of this very model: move the parameters off that point, where the L1 term's
+    # sign(image - gt) is not differentiable (a 1-ulp difference of the image would flip whole gradients)
+    g = torch.Generator(device="cuda").manual_seed(5)
+    with torch.no_grad():
+        model._features_dc.add_(0.2 * torch.randn(model._features_dc.shape, device="cuda", generator=g))
+        model._endpoints.add_(0.003 * torch.randn(model._endpoints.shape, device="cuda", generator=g))
+        model._opacity.add_(0.3 * torch.randn(model._opacity.shape, device="cuda", generator=g))
+        model._mask.add_(0.3 * torch.randn(model._mask.shape, device="cuda", generator=g))
+    fused = FusedStrandStep(model, cams, opt, bg)
+    for ci in (2, 0):
+        cam = cams[ci]
+        # ---- op-by-op
+        for p in params:
+            p.grad = None
+        for t in (model.max_radii2D, model.xyz_gradient_accum, model.denom):
+            t.zero_()
+        loss, terms, pkg = loss_function_single_pass(model, cam, opt, bg)
+        loss.backward()
+        with torch.no_grad():
+            model.update_densification_stats(pkg["viewspace_points"], pkg["radii"], pkg["visibility_filter"])
+        ref = dict(loss=float(loss), terms={k: float(v) for k, v in terms.items()},
+                   grads=[p.grad.clone() for p in params],
+                   stats=[t.clone() for t in (model.max_radii2D, model.xyz_gradient_accum, model.denom)],
+                   image=pkg["render"].detach().clone())
+        # ---- fused
+        for p in params:
+            p.grad = None
+        for t in (model.max_radii2D, model.xyz_gradient_accum, model.denom):
+            t.zero_()
+        model._derived = None
+        fused.views.select(fused.views.index[id(cam)])
+        floss, _ = fused.loss()
+        floss.backward()
+        fused.update_densification_stats()
+        fterms = {k: float(v) for k, v in fused.terms().items()}
+        assert abs(float(floss) - ref["loss"]) <= 2e-5 * abs(ref["loss"]), (float(floss), ref["loss"])
+        for k, v in ref["terms"].items():
+            assert abs(fterms[k] - v) <= 2e-5 * max(abs(v), 1e-3), (k, fterms[k], v)
+        assert (fused.last["planes"][:3] - ref["image"]).abs().max() <= 2e-6
+        for name, p, gref in zip(("endpoints", "width", "opacity", "mask", "f_dc", "f_rest"), params, ref["grads"]):
+            if gref.numel() == 0:
+                continue
+            scale = float(gref.abs().max())
+            assert (p.grad - gref).abs().max() <= 2e-4 * max(scale, 1e-12), (name, float((p.grad - gref).abs().max()), scale)
+        for t, sref in zip((model.max_radii2D, model.xyz_gradient_accum, model.denom), ref["stats"]):
+            assert (t - sref).abs().max() <= 1e-4 * max(float(sref.abs().max()), 1e-12)
+        assert float(model.denom.sum()) > 0
+
+
+def test_view_table_select_switches_targets():
+    from hgs_runtime.strand_step import ViewTable
+    from synthetic import build_workload
+    _, cams, _ = build_workload("tiny", device="cuda", with_targets=True)
+    vt = ViewTable(cams)
+    lr = torch.zeros((), device="cuda")
+    for i in (1, 3):
+        vt.select(i, lr=0.125 * i, lr_dst=lr)
+        torch.cuda.synchronize()
+        assert torch.equal(vt.viewmatrix.reshape(4, 4), cams[i].world_view_transform)
+        assert torch.equal(vt.projmatrix.reshape(4, 4), cams[i].full_proj_transform)
+        assert torch.equal(vt.campos, cams[i].camera_center)
+        assert float(lr) == 0.125 * i
+        ptrs = vt.slot[:40].view(torch.int64).tolist()
+        assert ptrs[0] == cams[i].original_image.data_ptr() and ptrs[2] == cams[i].orientation_field.data_ptr()
+    with pytest.raises(Exception):
+        vt.select(len(cams))

@@ -8,6 +8,9 @@ from synthetic import build_workload
 wl = sys.argv[1] if len(sys.argv) > 1 else "north_star"
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 10
 model, cams, _ = build_workload(wl, device="cuda", with_targets=False, n_views=4)
+if len(sys.argv) > 3 and sys.argv[3] == "culled":   # everything behind the camera: launch + output-write floor of the kernels
+    with torch.no_grad():
+        model._endpoints.data += 1.0e4
 bg = torch.zeros(3, device="cuda")
 H, W = cams[0].image_height, cams[0].image_width
 w3 = torch.randn(3, H, W, device="cuda"); w1 = torch.randn(H, W, device="cuda"); wo = torch.randn(3, H, W, device="cuda")

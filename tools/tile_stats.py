@@ -43,3 +43,15 @@ ty, tx = (H + 15) // 16, (W + 15) // 16
 pad = np.zeros((ty * 16, tx * 16), np.uint32); pad[:H, :W] = n_contrib
 last = pad.reshape(ty, 16, tx, 16).max(axis=(1, 3)).reshape(-1)
 print("sum L", L.sum(), "sum tile-max last contributor", last.sum())
+# exact per-(entry, quadrant) visibility: does any of the quadrant's 64 pixels reach alpha >= 1/255?
+recf = torch.from_numpy(rec.view(np.float32).copy()).cuda()
+tile_of = torch.from_numpy(np.repeat(np.arange(T), L).astype(np.int64)).cuda()
+tx0 = (tile_of % tx) * 16; ty0 = (tile_of // tx) * 16
+ii = torch.arange(16, device="cuda", dtype=torch.float32)
+dx = recf[:, 0, None] - (tx0[:, None] + ii[None, :])          # [R,16]
+dy = recf[:, 1, None] - (ty0[:, None] + ii[None, :])
+A, B, Cc, op = recf[:, 2], recf[:, 3], recf[:, 4], recf[:, 5]
+power = -0.5 * (A[:, None, None] * dx[:, None, :] ** 2 + Cc[:, None, None] * dy[:, :, None] ** 2) - B[:, None, None] * dx[:, None, :] * dy[:, :, None]
+vis = (power <= 0) & (op[:, None, None] * torch.exp(power) >= 1.0 / 255.0)   # [R,16(y),16(x)]
+q = vis.reshape(-1, 2, 8, 2, 8).any(dim=4).any(dim=2)                          # [R, qy, qx]
+print("exact kept fraction", q.float().mean().item(), " pixels passing per kept (wave, entry):", vis.float().sum().item() / max(1.0, q.float().sum().item()))
