@@ -44,6 +44,7 @@ def parse():
     ap.add_argument("--no-kernel-timing", action="store_true", help="disable per-kernel HIP-event timing")
     ap.add_argument("--three-pass", action="store_true",
                     help="three separate raster passes per iteration like the reference instead of the single 7-channel pass")
+    ap.add_argument("--op-by-op", action="store_true", help="the iteration as the reference structures it (getters, render, loss_function as separate autograd ops) instead of the fused strand iteration")
     ap.add_argument("--eager", action="store_true", help="eager dispatch of every kernel instead of replaying the captured HIP graph")
     ap.add_argument("--blocking", action="store_true",
                     help="reference-style forward (host reads num_rendered in every pass) instead of the async capacity mode")
@@ -103,6 +104,7 @@ def main():
     model, cams, extent = build_workload(args.workload, device=dev, seed=0, n_views=args.views)
     opt = OptimizationParams()
     opt.single_pass = not args.three_pass
+    opt.fused_step = not args.op_by_op
     opt.enable_topology = False  # densify/merge intervals (every 100 it) are reported separately, not in the timed loop
     model.training_setup(opt)
     bg = torch.zeros(3, dtype=torch.float32, device=dev)
@@ -114,13 +116,18 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    from train import GraphedStep
+    from train import GraphedStep, fused_step_applicable
     use_graph = not (args.eager or args.blocking)
     it = 0
+    views = fused = None
+    if fused_step_applicable(model, opt):
+        from hgs_runtime.strand_step import FusedStrandStep, ViewTable
+        views = ViewTable(cams)
+        fused = FusedStrandStep(model, views, opt, bg)   # eager launches of the same fused iteration (timing pass, --eager)
     if use_graph:
         # the whole iteration is captured once into a HIP graph and replayed (train.GraphedStep); the W warm-up steps
         # and the K timed steps are real optimizer steps on successive random views, exactly like the eager loop
-        gs = GraphedStep(model, cams, opt, bg, extent=extent, vp=vp)
+        gs = GraphedStep(model, cams, opt, bg, extent=extent, vp=vp, views=views)
         gs.capture(cams, iteration=1)
 
         def one_step():
@@ -131,7 +138,7 @@ def main():
         def one_step():
             nonlocal it
             it += 1
-            training_step(model, sampler.next(), opt, bg, it, extent=extent, vp=vp)
+            training_step(model, sampler.next(), opt, bg, it, extent=extent, vp=vp, fused=fused)
     for _ in range(args.warmup):
         one_step()
     sync_all()
@@ -151,7 +158,7 @@ def main():
         rt.prof_enable(True)
         for _ in range(min(args.steps, 50)):
             it += 1
-            training_step(model, sampler.next(), opt, bg, it, extent=extent, vp=vp)
+            training_step(model, sampler.next(), opt, bg, it, extent=extent, vp=vp, fused=fused)
         sync_all()
         kern = rt.prof_collect()
         rt.prof_enable(False)
@@ -210,6 +217,7 @@ def main():
                    "mean_num_rendered": meanR, "mean_sum_tile_list_len": meanL,
                    "forward_mode": "blocking" if args.blocking else "async-capacity",
                    "dispatch": "hip-graph replay" if use_graph else "eager",
+                   "iteration": "fused strand iteration" if fused is not None else "op-by-op",
                    "raster_passes_per_iter": 1 if getattr(opt, "single_pass", True) else 3},
         "render_ms_per_view": render_ms,
     }
@@ -223,8 +231,17 @@ def main():
         bytes_bwd = (rec_b + part_b) * meanL + (4.0 * ch + 8.0) * W * H + 8.0 * T
         bytes_fwd = rec_b * meanL + (4.0 * ch + 8.0) * W * H + 8.0 * T
         ach = bytes_bwd / (bwd_ms / max(bwd_n, 1) * 1e-3) / 1e9 if bwd_ms > 0 else 0.0
+        # HBM traffic of the same kernel from the committed rocprofv3 --pmc passes (tools/pmc_raster.sh; FETCH_SIZE and
+        # WRITE_SIZE collected in separate runs, corrected as MI355X_MICROARCH.md prescribes: 2 x FETCH_SIZE + WRITE_SIZE,
+        # KB units).  Counters cannot be read from inside this process, so the figure is the profiled one, per launch.
+        traffic = None
+        pmc_path = os.path.join(ROOT, "profiles", "pmc_raster_north_star.json")
+        if args.workload == "north_star" and ch == 7 and os.path.exists(pmc_path):
+            pm = json.load(open(pmc_path)).get("blend_bwd_kernel<7>", {})
+            if "FETCH_SIZE" in pm and "WRITE_SIZE" in pm:
+                traffic = (2.0 * pm["FETCH_SIZE"] + pm["WRITE_SIZE"]) * 1024.0
         result["roofline"] = {"kernel": "blend_bwd_kernel", "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS,
-                              "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                              "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
                               "algorithmic_bytes_per_launch": bytes_bwd, "mean_launch_us": bwd_ms / max(bwd_n, 1) * 1e3,
                               "launches": bwd_n}
         result["roofline_blend_fwd"] = {"achieved": bytes_fwd / (fwd_ms / max(fwd_n, 1) * 1e-3) / 1e9 if fwd_ms else 0.0,

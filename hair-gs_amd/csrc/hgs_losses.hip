@@ -358,20 +358,42 @@ __global__ __launch_bounds__(256) void pix_bwd_kernel(int N, HeadFlags fl, float
 // derivative of the total w.r.t. each term (what the backward kernels scale by).
 struct HeadReduce { int nb_ssim, nb_pix, nb_smooth; float inv_chw, inv_hw; float l_dssim, l_mask, l_ori, l_smooth; int bce, ori; };
 
-__device__ __forceinline__ float strided_sum(const float* __restrict__ a, int n, int stride, int off, float* red) {
-  float v = 0.f;
-  for (int i = threadIdx.x; i < n; i += 256) v += a[(size_t)i * stride + off];
-  return block_sum(v, red);
+#define FIN_THREADS 1024
+__device__ __forceinline__ float block_sum_1024(float v, float* red16) {
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red16[threadIdx.x >> 6] = v;
+  __syncthreads();
+  float s = 0.f;
+#pragma unroll
+  for (int k = 0; k < FIN_THREADS / 64; k++) s += red16[k];
+  return s;
+}
+// per-thread strided accumulation of an interleaved [n][NC] partial array: all loads of a thread are independent, so they
+// are in flight together (the one-column-at-a-time form of this kernel took 26 us of pure load latency)
+template <int NC>
+__device__ __forceinline__ void strided_acc(const float* __restrict__ a, int n, float* acc) {
+#pragma unroll
+  for (int c = 0; c < NC; c++) acc[c] = 0.f;
+#pragma unroll 4
+  for (int i = threadIdx.x; i < n; i += FIN_THREADS) {
+#pragma unroll
+    for (int c = 0; c < NC; c++) acc[c] += a[(size_t)i * NC + c];
+  }
 }
 
-__global__ __launch_bounds__(256) void head_finalize_kernel(HeadReduce h, const float* __restrict__ p_ssim,
-                                                            const float* __restrict__ p_pix, const float* __restrict__ p_smooth,
-                                                            float* __restrict__ out) {
-  __shared__ float red[4];
-  const float ssim_s = strided_sum(p_ssim, h.nb_ssim, 2, 0, red), l1_s = strided_sum(p_ssim, h.nb_ssim, 2, 1, red);
-  const float ori_s = strided_sum(p_pix, h.nb_pix, 3, 0, red), ori_c = strided_sum(p_pix, h.nb_pix, 3, 1, red);
-  const float bce_s = strided_sum(p_pix, h.nb_pix, 3, 2, red);
-  const float sm_s = strided_sum(p_smooth, h.nb_smooth, 2, 0, red), sm_c = strided_sum(p_smooth, h.nb_smooth, 2, 1, red);
+__global__ __launch_bounds__(FIN_THREADS) void head_finalize_kernel(HeadReduce h, const float* __restrict__ p_ssim,
+                                                                    const float* __restrict__ p_pix,
+                                                                    const float* __restrict__ p_smooth, float* __restrict__ out) {
+  __shared__ float red[FIN_THREADS / 64];
+  float a2[2], a3[3], s2[2];
+  strided_acc<2>(p_ssim, h.nb_ssim, a2);
+  strided_acc<3>(p_pix, h.nb_pix, a3);
+  strided_acc<2>(p_smooth, h.nb_smooth, s2);
+  const float ssim_s = block_sum_1024(a2[0], red), l1_s = block_sum_1024(a2[1], red);
+  const float ori_s = block_sum_1024(a3[0], red), ori_c = block_sum_1024(a3[1], red), bce_s = block_sum_1024(a3[2], red);
+  const float sm_s = block_sum_1024(s2[0], red), sm_c = block_sum_1024(s2[1], red);
   if (threadIdx.x != 0) return;
   const float l1 = l1_s * h.inv_chw, dssim = 1.f - ssim_s * h.inv_chw;
   const float w_l1 = fmaxf(0.f, 1.f - h.l_dssim);
@@ -522,7 +544,7 @@ int hgs_loss_head_forward(void* stream, const HgsHeadParams* p, const float* ima
   h.bce = fl.bce; h.ori = fl.ori;
   {
     HgsProfScope _prof(s, HGS_K_HEAD);
-    hipLaunchKernelGGL(head_finalize_kernel, dim3(1), dim3(256), 0, s, h, p_ssim, p_pix, p_smooth, out);
+    hipLaunchKernelGGL(head_finalize_kernel, dim3(1), dim3(FIN_THREADS), 0, s, h, p_ssim, p_pix, p_smooth, out);
   }
   HGS_CHECK_LAUNCH();
   return 0;

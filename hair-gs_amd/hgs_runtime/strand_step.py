@@ -140,6 +140,7 @@ class _StrandIteration(torch.autograd.Function):
                                              planes[4:7].data_ptr(), vt.slot.data_ptr(), rt.ptr(endpoints), rt.ptr(idx),
                                              rt.ptr(scratch), rt.ptr(out)))
         ctx.step, ctx.R, ctx.f_rest_k = step, R, f_rest.shape[1]
+        ctx.set_materialize_grads(False)   # no zero tensor for the (non-differentiable) terms output
         ctx.save_for_backward(endpoints, width, pairs, xyz, scale, quat, opacity, extra4, shs, planes, radii, geom, binning,
                               img, scratch, out)
         step.last = {"planes": planes, "radii": radii, "terms": out}
@@ -156,7 +157,7 @@ class _StrandIteration(torch.autograd.Function):
          out) = ctx.saved_tensors
         dev, P, E = endpoints.device, pairs.shape[0], endpoints.shape[0]
         f32 = dict(dtype=torch.float32, device=dev)
-        go = go.contiguous().to(torch.float32)
+        go = step.one if go is None else go.contiguous().to(torch.float32)
         dplanes = torch.empty_like(planes)
         d_ep = torch.empty((E, 3), **f32)
         stream = rt.current_stream()
@@ -194,6 +195,7 @@ class FusedStrandStep:
         dev = self.views.device
         self.bg7 = torch.cat([bg.to(dev, torch.float32), torch.zeros(4, device=dev)]).contiguous()
         self.empty = torch.empty(0, device=dev)
+        self.one = torch.ones((), dtype=torch.float32, device=dev)   # d loss / d loss, passed to backward(): no fill launch
         self.last = {}
         self.refresh()
 
@@ -210,6 +212,10 @@ class FusedStrandStep:
         """(total loss, terms tensor) of the CURRENT slot view; differentiable w.r.t. the model parameters."""
         g = self.gaussians
         return _StrandIteration.apply(g._endpoints, g._width, g._opacity, g._mask, g._features_dc, g._features_rest, self)
+
+    def backward(self, loss):
+        """loss.backward() without the ones_like() launch."""
+        loss.backward(self.one)
 
     def terms(self):
         t = self.last["terms"]

@@ -122,7 +122,10 @@ def _training_step(gaussians, viewpoint_cam, opt, bg, iteration, extent, vp, ras
     else:
         render_pkg = render(viewpoint_cam, gaussians, bg)
         loss, loss_dict = loss_function(gaussians, render_pkg["render"], viewpoint_cam, opt)
-    loss.backward()
+    if fused is not None:
+        fused.backward(loss)
+    else:
+        loss.backward()
     raster.check_async()  # async mode: the step's single synchronisation (raises -> step repeated); no-op otherwise
     with torch.no_grad():
         if iteration < opt.densify_until_iter:
@@ -233,7 +236,7 @@ class GraphedStep:
     def _forward_backward(self):
         if self.fused is not None:
             loss, _ = self.fused.loss()
-            loss.backward()
+            self.fused.backward(loss)
             self.fused.update_densification_stats()
             return loss.detach()
         if getattr(self.opt, "single_pass", True):
