@@ -97,9 +97,50 @@ __device__ __forceinline__ uint32_t block_sum_256(uint32_t v, uint32_t* lds4) {
   return lds4[0] + lds4[1] + lds4[2] + lds4[3];
 }
 
+// ---- block-private tile table ------------------------------------------------------------------------------------
+// Consecutive Gaussians are consecutive strand segments: the 256 of a block touch only a few dozen distinct tiles, and
+// a global atomic per (Gaussian, tile) serialises hundreds of read-modify-writes on the same L2 line (the two kernels
+// below spent ~30 us each mostly there).  Instances are first counted in an LDS hash table keyed by tile (LDS atomics),
+// then ONE global atomic per distinct tile and block publishes the count / reserves the slots.  Gaussians covering more
+// than TH_MAX_AREA tiles, and inserts that find the table full, fall back to direct global atomics.
+#define TH_LOG 10
+#define TH_SIZE (1 << TH_LOG)
+#define TH_EMPTY 0xFFFFFFFFu
+#define TH_MAX_AREA 16u
+#define TH_PROBES 8
+struct TileHash { uint32_t key[TH_SIZE]; uint32_t cnt[TH_SIZE]; uint32_t base[TH_SIZE]; };
+
+__device__ __forceinline__ void th_init(TileHash& h) {
+  for (int i = threadIdx.x; i < TH_SIZE; i += HGS_BLOCK) { h.key[i] = TH_EMPTY; h.cnt[i] = 0u; }
+}
+__device__ __forceinline__ int th_insert(TileHash& h, uint32_t t) {   // slot of tile t (inserting it), -1: table full
+  uint32_t s = (t * 2654435761u) >> (32 - TH_LOG);
+#pragma unroll 1
+  for (int k = 0; k < TH_PROBES; k++) {
+    const uint32_t prev = atomicCAS(&h.key[s], TH_EMPTY, t);
+    if (prev == TH_EMPTY || prev == t) return (int)s;
+    s = (s + 1) & (TH_SIZE - 1);
+  }
+  return -1;
+}
+__device__ __forceinline__ int th_find(const TileHash& h, uint32_t t) {  // slot of an inserted tile, -1 if it never got in
+  uint32_t s = (t * 2654435761u) >> (32 - TH_LOG);
+#pragma unroll 1
+  for (int k = 0; k < TH_PROBES; k++) {
+    const uint32_t cur = h.key[s];
+    if (cur == t) return (int)s;
+    if (cur == TH_EMPTY) return -1;
+    s = (s + 1) & (TH_SIZE - 1);
+  }
+  return -1;
+}
+
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(HGS_BLOCK) void preprocess_fwd_kernel(HgsFwdArgs a, HgsGeom g, HgsImage im, int* radii) {
   __shared__ uint32_t red[4];
+  __shared__ TileHash th;
+  th_init(th);
+  __syncthreads();
   const int idx = blockIdx.x * HGS_BLOCK + threadIdx.x;
   const int gx = (a.W + HGS_TILE - 1) / HGS_TILE, gy = (a.H + HGS_TILE - 1) / HGS_TILE;
   uint32_t ntiles = 0;
@@ -191,16 +232,23 @@ __global__ __launch_bounds__(HGS_BLOCK) void preprocess_fwd_kernel(HgsFwdArgs a,
       my_radius_i = ri;
       ntiles = area;
       rc.x0 = (uint16_t)x0; rc.y0 = (uint16_t)y0; rc.x1 = (uint16_t)x1; rc.y1 = (uint16_t)y1;
-      // per-tile instance counts: integer atomics, order-independent
+      // per-tile instance counts: integer atomics, order-independent (block-private table first, see TileHash)
       for (int ty = y0; ty < y1; ty++)
-        for (int tx = x0; tx < x1; tx++) atomicAdd(&im.tile_count[ty * gx + tx], 1u);
+        for (int tx = x0; tx < x1; tx++) {
+          const uint32_t t = (uint32_t)(ty * gx + tx);
+          const int sl = area <= TH_MAX_AREA ? th_insert(th, t) : -1;
+          if (sl >= 0) atomicAdd(&th.cnt[sl], 1u);
+          else atomicAdd(&im.tile_count[t], 1u);
+        }
     } while (0);
     radii[idx] = my_radius_i;
     g.tiles_touched[idx] = ntiles;
     g.rect[idx] = rc;
   }
-  const uint32_t bs = block_sum_256(ntiles, red);
+  const uint32_t bs = block_sum_256(ntiles, red);   // (its barriers also order the table updates above)
   if (threadIdx.x == 0) g.block_sums[blockIdx.x] = bs;
+  for (int i = threadIdx.x; i < TH_SIZE; i += HGS_BLOCK)
+    if (th.key[i] != TH_EMPTY) atomicAdd(&im.tile_count[th.key[i]], th.cnt[i]);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -210,6 +258,8 @@ __global__ __launch_bounds__(HGS_BLOCK) void preprocess_fwd_kernel(HgsFwdArgs a,
 __global__ __launch_bounds__(HGS_BLOCK) void scatter_kernel(int P, int gx, uint32_t Rcap, const int* radii, HgsGeom g,
                                                             HgsImage im, HgsBinning b) {
   __shared__ uint32_t wsum[4];
+  __shared__ TileHash th;
+  th_init(th);
   const int idx = blockIdx.x * HGS_BLOCK + threadIdx.x;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const uint32_t n = idx < P ? g.tiles_touched[idx] : 0;
@@ -218,18 +268,38 @@ __global__ __launch_bounds__(HGS_BLOCK) void scatter_kernel(int P, int gx, uint3
   __syncthreads();
   uint32_t base = g.block_sums[blockIdx.x];  // exclusive block prefix
   for (int w = 0; w < wave; w++) base += wsum[w];
-  if (idx >= P) return;
-  const uint32_t off_incl = base + incl;
-  g.point_offsets[idx] = off_incl;
+  HgsRect rc = {0, 0, 0, 0, 0, 0};
+  if (idx < P) {
+    const uint32_t off_incl = base + incl;
+    g.point_offsets[idx] = off_incl;
+    if (n != 0) {
+      rc = g.rect[idx];
+      rc.off = off_incl - n;
+      g.rect[idx] = rc;
+    }
+  }
+  const bool small = n != 0 && n <= TH_MAX_AREA;
+  // pass 1: count this block's instances per tile in LDS
+  if (small)
+    for (int ty = rc.y0; ty < rc.y1; ty++)
+      for (int tx = rc.x0; tx < rc.x1; tx++) {
+        const int sl = th_insert(th, (uint32_t)(ty * gx + tx));
+        if (sl >= 0) atomicAdd(&th.cnt[sl], 1u);
+      }
+  __syncthreads();
+  // one global atomic per distinct tile reserves the block's slots in that tile's segment
+  for (int i = threadIdx.x; i < TH_SIZE; i += HGS_BLOCK)
+    if (th.key[i] != TH_EMPTY) { th.base[i] = atomicAdd(&im.tile_cursor[th.key[i]], th.cnt[i]); th.cnt[i] = 0u; }
+  __syncthreads();
   if (n == 0) return;
-  HgsRect rc = g.rect[idx];
-  rc.off = off_incl - n;
-  g.rect[idx] = rc;
+  // pass 2: place the keys (order inside a tile's segment is irrelevant: the per-tile sort key is unique)
   const uint64_t key = ((uint64_t)__float_as_uint(g.depths[idx]) << 32) | (uint32_t)idx;
   for (int ty = rc.y0; ty < rc.y1; ty++)
     for (int tx = rc.x0; tx < rc.x1; tx++) {
-      const int t = ty * gx + tx;
-      const uint32_t pos = im.ranges[t].x + atomicAdd(&im.tile_cursor[t], 1u);
+      const uint32_t t = (uint32_t)(ty * gx + tx);
+      const int sl = small ? th_find(th, t) : -1;
+      const uint32_t pos = im.ranges[t].x + (sl >= 0 ? th.base[sl] + atomicAdd(&th.cnt[sl], 1u)
+                                                     : atomicAdd(&im.tile_cursor[t], 1u));
       if (pos < Rcap) b.keys[pos] = key;
       else im.status[1] = 1;  // overflow: caller under-sized the binning buffer
     }
