@@ -43,14 +43,61 @@ __device__ __forceinline__ uint32_t block_scan(const uint32_t* in, int n, uint32
   return carry;
 }
 
+// Register-blocked variant for n <= SCAN_THREADS * SCAN_IPT: thread t owns the IPT consecutive values starting at t*IPT,
+// all of its loads are issued before anything is consumed (ONE memory round trip instead of one per 1024-value chunk,
+// which is what the loop above pays and what bounded this single-block kernel), then one block-wide scan of the totals.
+#define SCAN_IPT 16
+struct ScanRegs { uint32_t v[SCAN_IPT]; int ipt; };
+__device__ __forceinline__ void scan_load(const uint32_t* in, int n, ScanRegs& r) {
+  r.ipt = (n + SCAN_THREADS - 1) / SCAN_THREADS;
+  const int i0 = threadIdx.x * r.ipt;
+#pragma unroll
+  for (int k = 0; k < SCAN_IPT; k++) r.v[k] = (k < r.ipt && i0 + k < n) ? in[i0 + k] : 0u;
+}
+template <typename F>
+__device__ __forceinline__ uint32_t scan_regs(ScanRegs& r, int n, uint32_t* wtot, F emit) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  uint32_t mine = 0;
+#pragma unroll
+  for (int k = 0; k < SCAN_IPT; k++) mine += r.v[k];
+  const uint32_t incl = hgs_wave_incl_scan(mine, lane);
+  __syncthreads();
+  if (lane == 63) wtot[wave] = incl;
+  __syncthreads();
+  uint32_t woff = 0, total = 0;
+#pragma unroll
+  for (int w = 0; w < SCAN_THREADS / 64; w++) {
+    const uint32_t t = wtot[w];
+    if (w < wave) woff += t;
+    total += t;
+  }
+  uint32_t run = woff + incl - mine;
+  const int i0 = tid * r.ipt;
+#pragma unroll
+  for (int k = 0; k < SCAN_IPT; k++)
+    if (k < r.ipt && i0 + k < n) { emit(i0 + k, run, r.v[k]); run += r.v[k]; }
+  return total;
+}
+
 __global__ __launch_bounds__(SCAN_THREADS) void scan_kernel(int nblk, int T, HgsGeom g, HgsImage im) {
   __shared__ uint32_t wtot[SCAN_THREADS / 64];
   uint32_t* bs = g.block_sums;
-  block_scan(bs, nblk, wtot, [&](int i, uint32_t excl, uint32_t) { bs[i] = excl; });
   uint2* ranges = im.ranges;
-  const uint32_t R = block_scan(im.tile_count, T, wtot, [&](int i, uint32_t excl, uint32_t v) {
+  auto emit_bs = [&](int i, uint32_t excl, uint32_t) { bs[i] = excl; };
+  auto emit_rg = [&](int i, uint32_t excl, uint32_t v) {
     ranges[i] = v ? make_uint2(excl, excl + v) : make_uint2(0u, 0u);  // empty tiles stay (0,0): memset at :310
-  });
+  };
+  uint32_t R;
+  if (nblk <= SCAN_THREADS * SCAN_IPT && T <= SCAN_THREADS * SCAN_IPT) {
+    ScanRegs rb, rt;
+    scan_load(bs, nblk, rb);
+    scan_load(im.tile_count, T, rt);
+    scan_regs(rb, nblk, wtot, emit_bs);
+    R = scan_regs(rt, T, wtot, emit_rg);
+  } else {
+    block_scan(bs, nblk, wtot, emit_bs);
+    R = block_scan(im.tile_count, T, wtot, emit_rg);
+  }
   if (threadIdx.x == 0) im.status[0] = R;
 }
 

@@ -111,59 +111,138 @@ __device__ __forceinline__ void col_pass(const SsimWin& win, float (*hz)[TILE][H
   }
 }
 
-__global__ __launch_bounds__(256) void ssim_l1_fwd_kernel(int H, int W, SsimWin win, const float* __restrict__ img1,
+// Workgroup -> image block mapping, persistent workgroups.
+//  * Workgroups are dealt round-robin to the 8 XCDs (each with its own L2) and neighbouring image blocks share 10-pixel
+//    halos: with the natural mapping every halo is fetched from HBM by two or three different L2s (measured: 255 MB of
+//    fabric traffic for 125 MB of algorithmic bytes).  XCD x owns the contiguous run of logical blocks
+//    [x*chunk, (x+1)*chunk) -- a band of block rows of one channel -- so halos hit in L2 (measured after: 120 MB).
+//  * Each workgroup walks its XCD's run with stride (workgroups per XCD) and fetches the NEXT block's halo tile into
+//    registers while it filters the current one, so the HBM round trip is paid once per workgroup, not once per block
+//    (3 blocks of 44 KB LDS fit a CU: too few to hide it by occupancy alone).
+struct SsimGrid { int nbx, nby, C, chunk, total; };
+struct SsimBlock { int c, bx0, by0, logical; };
+__device__ __forceinline__ bool ssim_block(const SsimGrid& gd, int j, SsimBlock& o) {
+  o.logical = (blockIdx.x & 7) * gd.chunk + j;
+  if (j >= gd.chunk || o.logical >= gd.total) return false;
+  const int per = gd.nbx * gd.nby;
+  o.c = o.logical / per;
+  const int r = o.logical - o.c * per;
+  const int by = r / gd.nbx;
+  o.by0 = by * LT;
+  o.bx0 = (r - by * gd.nbx) * LT;
+  return true;
+}
+static inline SsimGrid ssim_grid(int C, int H, int W) {
+  SsimGrid gd;
+  gd.nbx = (W + LT - 1) / LT; gd.nby = (H + LT - 1) / LT; gd.C = C;
+  gd.total = gd.nbx * gd.nby * C;
+  gd.chunk = (gd.total + 7) / 8;
+  return gd;
+}
+#define SSIM_WG_PER_XCD 96   // 32 CUs x 3 resident workgroups
+static inline unsigned ssim_grid_size(const SsimGrid& gd) { return 8u * (unsigned)(gd.chunk < SSIM_WG_PER_XCD ? gd.chunk : SSIM_WG_PER_XCD); }
+
+// register staging of one halo tile (fast path, W % 4 == 0): 504 float4 per plane = 2 per thread
+#define ST_F4 (TILE * (TW / 4))
+template <int NP> struct TileStage { float4 v[NP][2]; };
+template <int NP, typename PtrOf>
+__device__ __forceinline__ void stage_load(TileStage<NP>& st, int H, int W, int bx0, int by0, PtrOf plane_ptr) {
+#pragma unroll
+  for (int u = 0; u < 2; u++) {
+    const int i = threadIdx.x + 256 * u;
+    const int r = i / (TW / 4), c4 = (i - r * (TW / 4)) * 4;
+    const int y = by0 + r - HALO, x = bx0 - XOFF + c4;
+    const bool in = i < ST_F4 && (unsigned)y < (unsigned)H && x >= 0 && x < W;
+#pragma unroll
+    for (int p = 0; p < NP; p++) {
+      st.v[p][u] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (in) st.v[p][u] = *(const float4*)(plane_ptr(p) + (size_t)y * W + x);
+    }
+  }
+}
+template <int NP>
+__device__ __forceinline__ void stage_store(const TileStage<NP>& st, float (*t)[TILE][TPW]) {
+#pragma unroll
+  for (int u = 0; u < 2; u++) {
+    const int i = threadIdx.x + 256 * u;
+    if (i < ST_F4) {
+      const int r = i / (TW / 4), c4 = (i - r * (TW / 4)) * 4;
+#pragma unroll
+      for (int p = 0; p < NP; p++) {
+        const float4 v = st.v[p][u];
+        t[p][r][c4] = v.x; t[p][r][c4 + 1] = v.y; t[p][r][c4 + 2] = v.z; t[p][r][c4 + 3] = v.w;
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void ssim_l1_fwd_kernel(int H, int W, SsimGrid gd, SsimWin win, const float* __restrict__ img1,
                                                           const float* __restrict__ img2_, const HgsViewTargets* __restrict__ tgt,
                                                           float* __restrict__ dmap, float* __restrict__ partials) {
   __shared__ float t[2][TILE][TPW];
   __shared__ float hz[5][TILE][HP];
   __shared__ float red[4];
-  const int c = blockIdx.z, bx0 = blockIdx.x * LT, by0 = blockIdx.y * LT;
-  const size_t plane = (size_t)H * W;
+  const size_t plane = (size_t)H * W, cp = (size_t)gd.C * plane;
   const float* img2 = tgt ? tgt->image : img2_;   // per-view target read through the device-resident slot
-  const float* p1 = img1 + c * plane;
-  const float* p2 = img2 + c * plane;
-  load_tiles<2>(t, H, W, bx0, by0, [&](int p) { return p == 0 ? p1 : p2; });
-  __syncthreads();
-  row_pass<5>(win, hz, [&](int r, int x, float* v) {   // x = tile column of the tap: image x = bx0 - HALO + x
-    const float a = t[0][r][x + XOFF - HALO], b = t[1][r][x + XOFF - HALO];
-    v[0] = a; v[1] = b; v[2] = a * a; v[3] = b * b; v[4] = a * b;
-  });
-  __syncthreads();
+  const bool fast = (W & 3) == 0;
+  const int nwg = gridDim.x >> 3;
+  int j = blockIdx.x >> 3;
+  SsimBlock bk, nx;
+  bool have = ssim_block(gd, j, bk);
+  TileStage<2> st;
+  if (fast && have) stage_load<2>(st, H, W, bk.bx0, bk.by0, [&](int p) { return (p == 0 ? img1 : img2) + bk.c * plane; });
   const int lx = threadIdx.x & (LT - 1), y0 = (threadIdx.x >> 5) * 4;
-  float f[5][4];
-  col_pass<5>(win, hz, lx, y0, f);
-  const float C1 = 0.01f * 0.01f, C2 = 0.03f * 0.03f;
-  const size_t cp = (size_t)gridDim.z * plane;
-  const int px = bx0 + lx;
-  float ssim_v = 0.f, l1_v = 0.f;
+  while (have) {
+    if (fast) stage_store<2>(st, t);
+    else load_tiles<2>(t, H, W, bk.bx0, bk.by0, [&](int p) { return (p == 0 ? img1 : img2) + bk.c * plane; });
+    __syncthreads();
+    j += nwg;
+    const bool have_next = ssim_block(gd, j, nx);
+    if (fast && have_next) stage_load<2>(st, H, W, nx.bx0, nx.by0, [&](int p) { return (p == 0 ? img1 : img2) + nx.c * plane; });
+    row_pass<5>(win, hz, [&](int r, int x, float* v) {   // x = tile column of the tap: image x = bx0 - HALO + x
+      const float a = t[0][r][x + XOFF - HALO], b = t[1][r][x + XOFF - HALO];
+      v[0] = a; v[1] = b; v[2] = a * a; v[3] = b * b; v[4] = a * b;
+    });
+    __syncthreads();
+    float f[5][4];
+    col_pass<5>(win, hz, lx, y0, f);
+    const float C1 = 0.01f * 0.01f, C2 = 0.03f * 0.03f;
+    const int px = bk.bx0 + lx;
+    float ssim_v = 0.f, l1_v = 0.f;
 #pragma unroll
-  for (int o = 0; o < 4; o++) {
-    const int py = by0 + y0 + o;
-    if (px < W && py < H) {
-      const float mu1 = f[0][o], mu2 = f[1][o];
-      const float mu1_sq = mu1 * mu1, mu2_sq = mu2 * mu2, mu12 = mu1 * mu2;
-      const float s1 = f[2][o] - mu1_sq, s2 = f[3][o] - mu2_sq, s12 = f[4][o] - mu12;
-      const float A1 = 2.f * mu12 + C1, A2 = 2.f * s12 + C2, B1 = mu1_sq + mu2_sq + C1, B2 = s1 + s2 + C2;
-      const float inv = 1.f / (B1 * B2);
-      const float S = (A1 * A2) * inv;                                 // losses.py:71-73
-      ssim_v += S;
-      l1_v += fabsf(t[0][y0 + o + HALO][lx + XOFF] - t[1][y0 + o + HALO][lx + XOFF]);
-      const size_t oo = c * plane + (size_t)py * W + px;
-      dmap[oo] = 2.f * mu2 * (A2 - A1) * inv - S * (2.f * mu1 / B1 - 2.f * mu1 / B2);   // dS/dmu1 at fixed E11, E12
-      dmap[cp + oo] = -S / B2;                                                           // dS/dE11
-      dmap[2 * cp + oo] = 2.f * A1 * inv;                                                // dS/dE12
+    for (int o = 0; o < 4; o++) {
+      const int py = bk.by0 + y0 + o;
+      if (px < W && py < H) {
+        const float mu1 = f[0][o], mu2 = f[1][o];
+        const float mu1_sq = mu1 * mu1, mu2_sq = mu2 * mu2, mu12 = mu1 * mu2;
+        const float s1 = f[2][o] - mu1_sq, s2 = f[3][o] - mu2_sq, s12 = f[4][o] - mu12;
+        const float A1 = 2.f * mu12 + C1, A2 = 2.f * s12 + C2, B1 = mu1_sq + mu2_sq + C1, B2 = s1 + s2 + C2;
+        // B1 >= C1 > 0; B2 = C2 + (window variances) > 0 up to rounding: hardware reciprocals (1 ulp) instead of four
+        // IEEE division sequences per pixel
+        const float iB1 = __builtin_amdgcn_rcpf(B1), iB2 = __builtin_amdgcn_rcpf(B2);
+        const float inv = iB1 * iB2;
+        const float S = (A1 * A2) * inv;                                 // losses.py:71-73
+        ssim_v += S;
+        l1_v += fabsf(t[0][y0 + o + HALO][lx + XOFF] - t[1][y0 + o + HALO][lx + XOFF]);
+        const size_t oo = bk.c * plane + (size_t)py * W + px;
+        dmap[oo] = 2.f * mu2 * (A2 - A1) * inv - S * (2.f * mu1 * iB1 - 2.f * mu1 * iB2);   // dS/dmu1 at fixed E11, E12
+        dmap[cp + oo] = -S * iB2;                                                           // dS/dE11
+        dmap[2 * cp + oo] = 2.f * A1 * inv;                                                 // dS/dE12
+      }
     }
-  }
-  const float bs = block_sum(ssim_v, red);
-  const float bl = block_sum(l1_v, red);
-  if (threadIdx.x == 0) {
-    const size_t b = ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
-    partials[2 * b] = bs;
-    partials[2 * b + 1] = bl;
+    const float bs = block_sum(ssim_v, red);
+    const float bl = block_sum(l1_v, red);
+    if (threadIdx.x == 0) {
+      partials[2 * (size_t)bk.logical] = bs;
+      partials[2 * (size_t)bk.logical + 1] = bl;
+    }
+    __syncthreads();   // t / hz / red are rewritten by the next block of this workgroup
+    bk = nx;
+    have = have_next;
   }
 }
 
-__global__ __launch_bounds__(256) void ssim_l1_bwd_kernel(int H, int W, SsimWin win, const float* __restrict__ img1,
+__global__ __launch_bounds__(256) void ssim_l1_bwd_kernel(int H, int W, SsimGrid gd, SsimWin win, const float* __restrict__ img1,
                                                           const float* __restrict__ img2_, const HgsViewTargets* __restrict__ tgt,
                                                           const float* __restrict__ dmap,
                                                           const float* __restrict__ g_ssim_mean,
@@ -172,31 +251,63 @@ __global__ __launch_bounds__(256) void ssim_l1_bwd_kernel(int H, int W, SsimWin 
   __shared__ float t[3][TILE][TPW];
   __shared__ float hz[3][TILE][HP];
   const float* img2 = tgt ? tgt->image : img2_;
-  const int c = blockIdx.z, bx0 = blockIdx.x * LT, by0 = blockIdx.y * LT;
-  const size_t plane = (size_t)H * W, cp = (size_t)gridDim.z * plane;
-  load_tiles<3>(t, H, W, bx0, by0, [&](int p) { return dmap + p * cp + c * plane; });
-  __syncthreads();
-  row_pass<3>(win, hz, [&](int r, int x, float* v) {
-    v[0] = t[0][r][x + XOFF - HALO]; v[1] = t[1][r][x + XOFF - HALO]; v[2] = t[2][r][x + XOFF - HALO];
-  });
-  __syncthreads();
-  const int lx = threadIdx.x & (LT - 1), y0 = (threadIdx.x >> 5) * 4;
-  float f[3][4];
-  col_pass<3>(win, hz, lx, y0, f);
-  const int px = bx0 + lx;
-  const float n = 1.f / (float)((size_t)gridDim.z * plane);
+  const size_t plane = (size_t)H * W, cp = (size_t)gd.C * plane;
+  const float n = 1.f / (float)((size_t)gd.C * plane);
   const float up = go ? *go : 1.f;                 // upstream dL/dtotal of the loss head (NULL: 1)
   const float gs = *g_ssim_mean * up * n, gl = *g_l1_mean * up * n;
+  const bool fast = (W & 3) == 0;
+  const int nwg = gridDim.x >> 3;
+  const int lx = threadIdx.x & (LT - 1), y0 = (threadIdx.x >> 5) * 4;
+  int j = blockIdx.x >> 3;
+  SsimBlock bk, nx;
+  bool have = ssim_block(gd, j, bk);
+  TileStage<3> st;
+  float x1[4], x2[4];                              // the block's own pixels of both images, fetched with the tile
+  auto centre = [&](const SsimBlock& q) {
 #pragma unroll
-  for (int o = 0; o < 4; o++) {
-    const int py = by0 + y0 + o;
-    if (px < W && py < H) {
-      const size_t oo = c * plane + (size_t)py * W + px;
-      const float x1 = img1[oo], x2 = img2[oo];
-      const float d = x1 - x2;
-      const float sgn = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
-      dimg1[oo] = gs * (f[0][o] + 2.f * x1 * f[1][o] + x2 * f[2][o]) + gl * sgn;
+    for (int o = 0; o < 4; o++) {
+      const int px = q.bx0 + lx, py = q.by0 + y0 + o;
+      x1[o] = 0.f; x2[o] = 0.f;
+      if (px < W && py < H) { const size_t oo = q.c * plane + (size_t)py * W + px; x1[o] = img1[oo]; x2[o] = img2[oo]; }
     }
+  };
+  if (have) {
+    if (fast) stage_load<3>(st, H, W, bk.bx0, bk.by0, [&](int p) { return dmap + p * cp + bk.c * plane; });
+    centre(bk);
+  }
+  while (have) {
+    if (fast) stage_store<3>(st, t);
+    else load_tiles<3>(t, H, W, bk.bx0, bk.by0, [&](int p) { return dmap + p * cp + bk.c * plane; });
+    float c1[4], c2[4];
+#pragma unroll
+    for (int o = 0; o < 4; o++) { c1[o] = x1[o]; c2[o] = x2[o]; }
+    __syncthreads();
+    j += nwg;
+    const bool have_next = ssim_block(gd, j, nx);
+    if (have_next) {
+      if (fast) stage_load<3>(st, H, W, nx.bx0, nx.by0, [&](int p) { return dmap + p * cp + nx.c * plane; });
+      centre(nx);
+    }
+    row_pass<3>(win, hz, [&](int r, int x, float* v) {
+      v[0] = t[0][r][x + XOFF - HALO]; v[1] = t[1][r][x + XOFF - HALO]; v[2] = t[2][r][x + XOFF - HALO];
+    });
+    __syncthreads();
+    float f[3][4];
+    col_pass<3>(win, hz, lx, y0, f);
+    const int px = bk.bx0 + lx;
+#pragma unroll
+    for (int o = 0; o < 4; o++) {
+      const int py = bk.by0 + y0 + o;
+      if (px < W && py < H) {
+        const size_t oo = bk.c * plane + (size_t)py * W + px;
+        const float d = c1[o] - c2[o];
+        const float sgn = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
+        dimg1[oo] = gs * (f[0][o] + 2.f * c1[o] * f[1][o] + c2[o] * f[2][o]) + gl * sgn;
+      }
+    }
+    __syncthreads();   // t / hz are rewritten by the next block of this workgroup
+    bk = nx;
+    have = have_next;
   }
 }
 
@@ -432,7 +543,7 @@ int hgs_ssim_l1_forward(void* stream, int C, int H, int W, const float* window11
   hipStream_t s = (hipStream_t)stream;
   {
     HgsProfScope _prof(s, HGS_K_SSIM_FWD);
-    hipLaunchKernelGGL(ssim_l1_fwd_kernel, dim3((W + LT - 1) / LT, (H + LT - 1) / LT, C), dim3(256), 0, s, H, W, win, img1,
+    hipLaunchKernelGGL(ssim_l1_fwd_kernel, dim3(ssim_grid_size(ssim_grid(C, H, W))), dim3(256), 0, s, H, W, ssim_grid(C, H, W), win, img1,
                        img2, (const HgsViewTargets*)nullptr, dmaps, partials);
   }
   HGS_CHECK_LAUNCH();
@@ -450,7 +561,7 @@ int hgs_ssim_l1_backward(void* stream, int C, int H, int W, const float* window1
   hipStream_t s = (hipStream_t)stream;
   {
     HgsProfScope _prof(s, HGS_K_SSIM_BWD);
-    hipLaunchKernelGGL(ssim_l1_bwd_kernel, dim3((W + LT - 1) / LT, (H + LT - 1) / LT, C), dim3(256), 0, s, H, W, win, img1,
+    hipLaunchKernelGGL(ssim_l1_bwd_kernel, dim3(ssim_grid_size(ssim_grid(C, H, W))), dim3(256), 0, s, H, W, ssim_grid(C, H, W), win, img1,
                        img2, (const HgsViewTargets*)nullptr, dmaps, g_ssim_mean, g_l1_mean, (const float*)nullptr, dL_dimg1);
   }
   HGS_CHECK_LAUNCH();
@@ -526,7 +637,7 @@ int hgs_loss_head_forward(void* stream, const HgsHeadParams* p, const float* ima
   hipStream_t s = (hipStream_t)stream;
   {
     HgsProfScope _prof(s, HGS_K_SSIM_FWD);
-    hipLaunchKernelGGL(ssim_l1_fwd_kernel, dim3((W + LT - 1) / LT, (H + LT - 1) / LT, 3), dim3(256), 0, s, H, W, win, image,
+    hipLaunchKernelGGL(ssim_l1_fwd_kernel, dim3(ssim_grid_size(ssim_grid(3, H, W))), dim3(256), 0, s, H, W, ssim_grid(3, H, W), win, image,
                        (const float*)nullptr, targets, dmaps, p_ssim);
   }
   HeadFlags fl;
@@ -567,7 +678,7 @@ int hgs_loss_head_backward(void* stream, const HgsHeadParams* p, const float* im
   hipStream_t s = (hipStream_t)stream;
   {
     HgsProfScope _prof(s, HGS_K_SSIM_BWD);
-    hipLaunchKernelGGL(ssim_l1_bwd_kernel, dim3((W + LT - 1) / LT, (H + LT - 1) / LT, 3), dim3(256), 0, s, H, W, win, image,
+    hipLaunchKernelGGL(ssim_l1_bwd_kernel, dim3(ssim_grid_size(ssim_grid(3, H, W))), dim3(256), 0, s, H, W, ssim_grid(3, H, W), win, image,
                        (const float*)nullptr, targets, dmaps, out + HGS_HEAD_G_SSIM, out + HGS_HEAD_G_L1, grad_out, d_image);
   }
   HeadFlags fl;

@@ -29,6 +29,9 @@ VARIANTS = {
     "rotated_cam": dict(P=1500, W=160, H=96, seed=12, sh_degree=2, eye=(1.0, -0.7, 0.55), behind_frac=0.0, fovx_deg=90.0),
     "all_culled": dict(P=300, W=64, H=64, seed=8, behind_frac=1.0),
     "tiny_image": dict(P=200, W=7, H=5, seed=9),
+    # 145 x 121 = 17545 tiles (> 16384: the scan kernel's chunked path) and footprints of hundreds of tiles (the direct
+    # global-atomic path of the counting / scatter kernels)
+    "many_tiles": dict(P=400, W=2320, H=1936, seed=13, sh_degree=1),
 }
 
 
