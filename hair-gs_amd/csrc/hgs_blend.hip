@@ -267,73 +267,85 @@ __global__ __launch_bounds__(HGS_BLOCK) void blend_bwd_kernel(const uint2* __res
     // positions at or past this wavefront's last contributor cannot be valid for any of its pixels
     if ((int)wlast <= lo) m = 0;
     else if ((int)wlast - lo < 64) m &= (1ull << ((int)wlast - lo)) - 1ull;
-    if (m) {
-      int e = 63 - __builtin_clzll(m);
-      Rec<C> r = lds_record<C>(recs[cur], e);
-      while (true) {
-        m &= ~(1ull << e);
-        const int en = m ? 63 - __builtin_clzll(m) : e;
-        const Rec<C> rn = lds_record<C>(recs[cur], en);
-        const int p = lo + e;
-        const float* f = (const float*)&r.q[0];
-        const float4 r0 = r.q[0], r1 = r.q[1];
-        const float dx = r0.x - pxf, dy = r0.y - pyf;
-        const float power = -0.5f * (r0.z * dx * dx + r1.x * dy * dy) - r0.w * dx * dy;
-        const float G = __expf(power);
-        const float alpha = fminf(0.99f, r1.y * G);
-        const bool ok = (uint32_t)p < last && power <= 0.f && alpha >= (1.0f / 255.0f);
-        if (__ballot(ok) != 0) {
-          float v[NV];
+    // one entry: evaluate, update the per-pixel state, reduce the NPART partial sums over the wavefront.  The gradient
+    // arithmetic is branch-free: lanes that do not blend the entry run it with alpha = G = 0, which makes every
+    // partial sum an exact zero (masked vector instructions cost the same as unmasked ones, and this way no register
+    // has to be cleared per entry); only the state recurrences sit under the lane mask.
+    auto process = [&](const Rec<C>& r, int e) {
+      const int p = lo + e;
+      const float* f = (const float*)&r.q[0];
+      const float4 r0 = r.q[0], r1 = r.q[1];
+      const float dx = r0.x - pxf, dy = r0.y - pyf;
+      const float power = -0.5f * (r0.z * dx * dx + r1.x * dy * dy) - r0.w * dx * dy;
+      const float Gx = __expf(power);
+      const float ax = fminf(0.99f, r1.y * Gx);
+      const bool ok = (uint32_t)p < last && power <= 0.f && ax >= (1.0f / 255.0f);
+      if (__ballot(ok) == 0) return;
+      const float G = ok ? Gx : 0.f, alpha = ok ? ax : 0.f;
+      const float inv_one_m_a = __builtin_amdgcn_rcpf(1.f - alpha);               // 1 ulp; alpha <= 0.99; rcp(1) == 1
+      T = T * inv_one_m_a;                                                         // :960
+      if (ok) {
 #pragma unroll
-          for (int k = 0; k < NV; k++) v[k] = 0.f;
-          if (ok) {
-            const float inv_one_m_a = __builtin_amdgcn_rcpf(1.f - alpha);             // 1 ulp; alpha <= 0.99
-            T = T * inv_one_m_a;                                                       // :960
-            const float dchannel_dcolor = alpha * T;
-            float dL_dalpha = 0.f, dL_dalpha_rgb = 0.f;
-#pragma unroll
-            for (int k = 0; k < C; k++) {
-              const float c = f[6 + k];
-              acc[k] = last_alpha * lc[k] + (1.f - last_alpha) * acc[k];               // :972
-              lc[k] = c;
-              const float t = (c - acc[k]) * dpx[k];
-              dL_dalpha += t;
-              if (k < 3) dL_dalpha_rgb += t;
-              v[6 + k] = dchannel_dcolor * dpx[k];                                     // :980
-            }
-            dL_dalpha *= T;
-            last_alpha = alpha;
-            const float bgw = -T_final * inv_one_m_a;
-            dL_dalpha += bgw * bg_dot;                                                 // :991
-            const float dL_dG = r1.y * dL_dalpha;
-            const float gdx = G * dx, gdy = G * dy;
-            const float dG_ddelx = -gdx * r0.z - gdy * r0.w;
-            const float dG_ddely = -gdy * r1.x - gdx * r0.w;
-            v[0] = dL_dG * dG_ddelx * ddelx_dx;                                        // :1002-1003
-            v[1] = dL_dG * dG_ddely * ddely_dy;
-            v[2] = -0.5f * gdx * dx * dL_dG;                                           // :1006-1008
-            v[3] = -0.5f * gdx * dy * dL_dG;
-            v[4] = -0.5f * gdy * dy * dL_dG;
-            v[5] = G * dL_dalpha;                                                      // :1011
-            if (C > 3) {  // screen-space gradient of the RGB channels alone (densification statistics)
-              const float dL_dG_rgb = r1.y * (dL_dalpha_rgb * T + bgw * bg_dot_rgb);
-              v[6 + C] = dL_dG_rgb * dG_ddelx * ddelx_dx;
-              v[7 + C] = dL_dG_rgb * dG_ddely * ddely_dy;
-            }
-          }
-          float x[NREG];
-          wave_reduce<NREG>(v, x);
-          if ((lane & 15) == 0) {
-            const int row = lane >> 4;
-            const int k = ((row & 1) << 1) | (row >> 1);   // rows hold values (0,2,1,3) of each group of four
-            float* dst = &part[wave][e][0];
-#pragma unroll
-            for (int rr = 0; rr < NREG; rr++) dst[4 * rr + k] = x[rr];
-          }
+        for (int k = 0; k < C; k++) {
+          acc[k] = last_alpha * lc[k] + (1.f - last_alpha) * acc[k];               // :972
+          lc[k] = f[6 + k];
         }
+        last_alpha = alpha;
+      }
+      float v[NV];
+      const float dchannel_dcolor = alpha * T;
+      float dL_dalpha = 0.f, dL_dalpha_rgb = 0.f;
+#pragma unroll
+      for (int k = 0; k < C; k++) {
+        const float t = (f[6 + k] - acc[k]) * dpx[k];
+        dL_dalpha += t;
+        if (k < 3) dL_dalpha_rgb += t;
+        v[6 + k] = dchannel_dcolor * dpx[k];                                       // :980
+      }
+      dL_dalpha *= T;
+      const float bgw = -T_final * inv_one_m_a;
+      dL_dalpha += bgw * bg_dot;                                                   // :991
+      const float dL_dG = r1.y * dL_dalpha;
+      const float gdx = G * dx, gdy = G * dy;
+      const float dG_ddelx = -gdx * r0.z - gdy * r0.w;
+      const float dG_ddely = -gdy * r1.x - gdx * r0.w;
+      v[0] = dL_dG * dG_ddelx * ddelx_dx;                                          // :1002-1003
+      v[1] = dL_dG * dG_ddely * ddely_dy;
+      v[2] = -0.5f * gdx * dx * dL_dG;                                             // :1006-1008
+      v[3] = -0.5f * gdx * dy * dL_dG;
+      v[4] = -0.5f * gdy * dy * dL_dG;
+      v[5] = G * dL_dalpha;                                                        // :1011
+      if (C > 3) {  // screen-space gradient of the RGB channels alone (densification statistics)
+        const float dL_dG_rgb = r1.y * (dL_dalpha_rgb * T + bgw * bg_dot_rgb);
+        v[6 + C] = dL_dG_rgb * dG_ddelx * ddelx_dx;
+        v[7 + C] = dL_dG_rgb * dG_ddely * ddely_dy;
+      }
+#pragma unroll
+      for (int k = NPART; k < NV; k++) v[k] = 0.f;
+      float x[NREG];
+      wave_reduce<NREG>(v, x);
+      if ((lane & 15) == 0) {
+        const int row = lane >> 4;
+        const int k = ((row & 1) << 1) | (row >> 1);   // rows hold values (0,2,1,3) of each group of four
+        float* dst = &part[wave][e][0];
+#pragma unroll
+        for (int rr = 0; rr < NREG; rr++) dst[4 * rr + k] = x[rr];
+      }
+    };
+    if (m) {
+      // two record buffers used alternately: the next entry's LDS reads are in flight while this one is evaluated,
+      // and no register copies rotate the pipeline
+      int ea = 63 - __builtin_clzll(m), eb = 0;
+      Rec<C> ra = lds_record<C>(recs[cur], ea), rb = ra;
+      while (true) {
+        m &= ~(1ull << ea);
+        if (m) { eb = 63 - __builtin_clzll(m); rb = lds_record<C>(recs[cur], eb); }
+        process(ra, ea);
         if (m == 0) break;
-        e = en;
-        r = rn;
+        m &= ~(1ull << eb);
+        if (m) { ea = 63 - __builtin_clzll(m); ra = lds_record<C>(recs[cur], ea); }
+        process(rb, eb);
+        if (m == 0) break;
       }
     }
     __syncthreads();
