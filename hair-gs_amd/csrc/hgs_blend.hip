@@ -142,35 +142,40 @@ __global__ __launch_bounds__(HGS_BLOCK) void blend_fwd_kernel(const uint2* __res
     const uint32_t mk = lane < cnt ? __float_as_uint(rf[lane * 4 * REC4 + 7 + C]) : 0u;
     uint64_t m = __ballot(((mk >> wave) & 1u) != 0u);
     if (__ballot(!done) == 0) m = 0;
+    bool wave_done = false;   // every pixel of this wavefront saturated: leave the batch
+    auto process = [&](const Rec<C>& r, int e) {
+      const float4 r0 = r.q[0], r1 = r.q[1];
+      const float dx = r0.x - pxf, dy = r0.y - pyf;
+      const float power = -0.5f * (r0.z * dx * dx + r1.x * dy * dy) - r0.w * dx * dy;  // forward.cu:335
+      const float alpha = fminf(0.99f, r1.y * __expf(power));                           // :343
+      bool ok = !done && power <= 0.f && alpha >= (1.0f / 255.0f);                      // :336, :344
+      if (__ballot(ok) == 0) return;
+      const float test_T = T * (1.f - alpha);
+      const bool sat = ok && test_T < 0.0001f;                                          // :346-351
+      if (sat) { done = true; ok = false; }
+      if (ok) {
+        const float w = alpha * T;
+        const float* f = (const float*)&r.q[0];                                         // features start at float 6
+#pragma unroll
+        for (int k = 0; k < C; k++) acc[k] += f[6 + k] * w;                             // :354-355
+        T = test_T;
+        last = (uint32_t)(b * REC_BATCH + e + 1);                                       // :328, :361
+      }
+      if (__ballot(sat) != 0 && __ballot(!done) == 0) wave_done = true;
+    };
     if (m) {
-      int e = __builtin_ctzll(m);
-      Rec<C> r = lds_record<C>(recs[cur], e);
+      // two record buffers used alternately (LDS reads of the next entry in flight, no register rotation)
+      int ea = __builtin_ctzll(m), eb = 0;
+      Rec<C> ra = lds_record<C>(recs[cur], ea), rb = ra;
       while (true) {
         m &= m - 1;
-        const int en = m ? __builtin_ctzll(m) : e;
-        const Rec<C> rn = lds_record<C>(recs[cur], en);      // one entry ahead: hides the LDS latency
-        const float4 r0 = r.q[0], r1 = r.q[1];
-        const float dx = r0.x - pxf, dy = r0.y - pyf;
-        const float power = -0.5f * (r0.z * dx * dx + r1.x * dy * dy) - r0.w * dx * dy;  // forward.cu:335
-        const float alpha = fminf(0.99f, r1.y * __expf(power));                           // :343
-        bool ok = !done && power <= 0.f && alpha >= (1.0f / 255.0f);                      // :336, :344
-        if (__ballot(ok) != 0) {
-          const float test_T = T * (1.f - alpha);
-          const bool sat = ok && test_T < 0.0001f;                                        // :346-351
-          if (sat) { done = true; ok = false; }
-          if (ok) {
-            const float w = alpha * T;
-            const float* f = (const float*)&r.q[0];                                       // features start at float 6
-#pragma unroll
-            for (int k = 0; k < C; k++) acc[k] += f[6 + k] * w;                           // :354-355
-            T = test_T;
-            last = (uint32_t)(b * REC_BATCH + e + 1);                                     // :328, :361
-          }
-          if (__ballot(sat) != 0 && __ballot(!done) == 0) break;
-        }
-        if (m == 0) break;
-        e = en;
-        r = rn;
+        if (m) { eb = __builtin_ctzll(m); rb = lds_record<C>(recs[cur], eb); }
+        process(ra, ea);
+        if (m == 0 || wave_done) break;
+        m &= m - 1;
+        if (m) { ea = __builtin_ctzll(m); ra = lds_record<C>(recs[cur], ea); }
+        process(rb, eb);
+        if (m == 0 || wave_done) break;
       }
     }
     if (b + 1 < nb) {
