@@ -83,10 +83,18 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # HGS_BENCH_SHARE_GPU=1: every rank on cuda:0 with the gloo backend -- a LOGIC check of the multi-rank path on a
+    # one-GPU box (the numbers it prints are meaningless); the real path is one rank per GPU over RCCL
+    share = os.environ.get("HGS_BENCH_SHARE_GPU") == "1"
+    if share:
+        local_rank = 0
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if share:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
 

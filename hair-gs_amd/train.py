@@ -29,30 +29,48 @@ class ViewParallel:
         self.world = dist.get_world_size() if self.enabled else 1
         self.rank = dist.get_rank() if self.enabled else 0
         self._flat = None
+        self._flat_key = None
+        self._views = []
 
     def params(self, gaussians):
         return [g["params"][0] for g in gaussians.optimizer.param_groups]
 
+    def pack_gradients(self, gaussians):
+        """Gather every parameter's gradient into ONE flat fp32 buffer (a single multi-tensor copy launch) and make the
+        parameters' .grad views of it, so the exchange below is one in-place collective and Adam reads the reduced
+        values with no copy back.  Layout: [endpoints|f_dc|f_rest|opacity|mask|width] (Stage I: xyz|...|rotation)."""
+        ps = [p for p in self.params(gaussians) if p.grad is not None and p.numel() > 0]
+        n = sum(p.numel() for p in ps)
+        key = tuple((p.data_ptr(), p.numel()) for p in ps)
+        if self._flat is None or self._flat_key != key or self._flat.device != ps[0].device:
+            self._flat = torch.zeros(n, dtype=torch.float32, device=ps[0].device)
+            self._flat_key = key
+            self._views, off = [], 0
+            for p in ps:
+                self._views.append(self._flat[off:off + p.numel()].view(p.shape))
+                off += p.numel()
+        srcs = [p.grad if p.grad.is_contiguous() else p.grad.contiguous() for p in ps]
+        if not all(s_.data_ptr() == v.data_ptr() for s_, v in zip(srcs, self._views)):
+            torch._foreach_copy_(self._views, srcs)
+        for p, v in zip(ps, self._views):
+            p.grad = v
+
+    def exchange(self):
+        """Average the packed gradients over the ranks: one all-reduce over xGMI (RCCL) / gloo on CPU."""
+        if self.world == 1 or self._flat is None:
+            return
+        if dist.get_backend() == "nccl":
+            dist.all_reduce(self._flat, op=dist.ReduceOp.AVG)
+        else:
+            dist.all_reduce(self._flat, op=dist.ReduceOp.SUM)
+            self._flat.div_(self.world)
+
     def reduce_gradients(self, gaussians):
-        """One all-reduce(SUM) over [endpoints|f_dc|f_rest|opacity|mask|width] (Stage I: xyz|...|rotation), / world."""
+        """pack + exchange (the eager path; GraphedStep captures the pack and replays around the exchange)."""
         if self.world == 1:
             return
-        ps = [p for p in self.params(gaussians) if p.grad is not None]
-        n = sum(p.grad.numel() for p in ps)
-        if self._flat is None or self._flat.numel() != n or self._flat.device != ps[0].device:
-            self._flat = torch.empty(n, dtype=torch.float32, device=ps[0].device)
-        off = 0
-        for p in ps:
-            k = p.grad.numel()
-            self._flat[off:off + k].copy_(p.grad.reshape(-1))
-            off += k
-        dist.all_reduce(self._flat, op=dist.ReduceOp.SUM)
-        self._flat.div_(self.world)
-        off = 0
-        for p in ps:
-            k = p.grad.numel()
-            p.grad.copy_(self._flat[off:off + k].view_as(p.grad))
-            off += k
+        self.pack_gradients(gaussians)
+        self.exchange()
 
     def reduce_stats(self, gaussians):
         if self.world == 1:
@@ -261,6 +279,8 @@ class GraphedStep:
                 self._set_lr(iteration)
                 self.load_camera(cam)
                 self._forward_backward()
+                if self.vp.world > 1:
+                    self.vp.pack_gradients(g)   # creates the flat exchange buffer outside the capture
                 g.optimizer.zero_grad(set_to_none=True)
                 g._derived = None
                 raster.check_async()
@@ -281,6 +301,7 @@ class GraphedStep:
             ga, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
             with torch.cuda.graph(ga, stream=s):
                 self.loss_buf = self._forward_backward()
+                self.vp.pack_gradients(g)       # .grad become views of the flat exchange buffer
             with torch.cuda.graph(gb, pool=ga.pool(), stream=s):
                 g.optimizer.step()
             self._graphs = (ga, gb)
@@ -295,7 +316,7 @@ class GraphedStep:
         ga, gb = self._graphs
         ga.replay()
         if gb is not None:
-            self.vp.reduce_gradients(self.g)
+            self.vp.exchange()                  # the only eager work between the two graphs: one in-place all-reduce
             gb.replay()
         self.g._derived = None  # cached derived tensors now hold pre-update values
         return self.loss_buf

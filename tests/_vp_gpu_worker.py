@@ -1,0 +1,80 @@
+"""Worker of tests/test_gpu_view_parallel.py: N ranks SHARING one GPU (gloo backend) run the view-parallel GraphedStep;
+every rank must end with bit-identical parameters, and rank 0 checks them against a single-process run that averages
+the same per-view gradients by hand."""
+import os
+import sys
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "hair-gs_amd")]
+import torch
+import torch.distributed as dist
+
+
+def main():
+    dist.init_process_group(backend="gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    torch.cuda.set_device(0)
+    from arguments import OptimizationParams
+    from diff_gaussian_rasterization import _C as raster
+    from synthetic import build_workload
+    from train import GraphedStep, ViewParallel, ViewSampler
+    from utils.general import safe_state
+    safe_state(True)
+    model, cams, extent = build_workload("tiny", device="cuda", with_targets=True)
+    opt = OptimizationParams()
+    opt.enable_topology = False
+    model.training_setup(opt)
+    bg = torch.zeros(3, device="cuda")
+    vp = ViewParallel()
+    assert vp.world == world
+    sampler = ViewSampler(cams, seed=0, rank=vp.rank, world=vp.world)
+    gs = GraphedStep(model, cams, opt, bg, extent=extent, vp=vp)
+    gs.capture(cams)
+    picks = []
+    for it in range(1, 5):
+        cam = sampler.next()
+        picks.append(cams.index(cam))
+        loss = gs.step(cam, it)
+    gs.check()
+    raster.set_async(False)
+    assert torch.isfinite(loss)
+    flat = torch.cat([p.detach().reshape(-1) for p in vp.params(model)]).cpu()
+    gathered = [torch.empty_like(flat) for _ in range(world)]
+    dist.all_gather(gathered, flat)
+    for r in range(1, world):
+        assert torch.equal(gathered[0], gathered[r]), f"rank {r} diverged from rank 0"
+    allpicks = [None] * world
+    dist.all_gather_object(allpicks, picks)
+    if rank == 0:
+        # single-process reference: same views, gradients averaged by hand, same Adam
+        from hgs_runtime.strand_step import FusedStrandStep
+        safe_state(True)
+        ref, rcams, _ = build_workload("tiny", device="cuda", with_targets=True)
+        ref.training_setup(opt)
+        fused = FusedStrandStep(ref, rcams, opt, bg)
+        params = vp.params(ref)
+        for it in range(1, 5):
+            ref.update_learning_rate(it)
+            acc = [torch.zeros_like(p) for p in params]
+            for r in range(world):
+                fused.views.select(allpicks[r][it - 1])
+                l, _ = fused.loss()
+                fused.backward(l)
+                for a, p in zip(acc, params):
+                    if p.grad is not None:
+                        a += p.grad
+                    p.grad = None
+            for a, p in zip(acc, params):
+                p.grad = a / world
+            ref.optimizer.step()
+            ref.optimizer.zero_grad(set_to_none=True)
+        rflat = torch.cat([p.detach().reshape(-1) for p in params]).cpu()
+        d = (rflat - gathered[0]).abs()
+        assert float(d.max()) <= 2e-4 * float(rflat.abs().max()), float(d.max())
+        print("VP_GPU_OK", float(d.max()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
