@@ -220,7 +220,7 @@ static int backward_impl(void* stream, int P, int D, int M, int R, int W, int H,
     if (!dL_dpix_planes[k]) { hgs_set_error("null dL_dpix plane %d", k); return 1; }
   if (!dL_dmeans2D || !dL_dconic || !dL_dopacity || !dL_dcolors || !dL_dmeans3D || !dL_dcov3D || !dL_dscales ||
       !dL_drotations || (shs && !dL_dsh) || (n_extra && !dL_dextra)) { hgs_set_error("null gradient output"); return 1; }
-  const int channels = 3 + n_extra, row = n_extra ? 16 : HGS_INST_GRAD_FLOATS;
+  const int channels = 3 + n_extra;
   HgsGeom g;
   HgsImage im;
   HgsBinning b = {};
@@ -230,8 +230,7 @@ static int backward_impl(void* stream, int P, int D, int M, int R, int W, int H,
   if (R > 0) {
     if (check_aligned(binning_buf, "binning_buf") || check_aligned(scratch, "scratch")) return 1;
     hgs_binning_carve((char*)binning_buf, (size_t)R, b, nullptr, channels);
-    inst_grad = (float*)scratch;
-    if (hgs_zero_async(s, inst_grad, (size_t)R * row * sizeof(float))) return 1;
+    inst_grad = (float*)scratch;   // not cleared here: blend_bwd writes EVERY row (zeros past a tile's last needed entry)
     if (hgs_launch_blend_bwd(s, W, H, R, channels, bg, im, b, dL_dpix_planes, inst_grad)) return 1;
   }
   HgsBwdArgs a;

@@ -215,8 +215,18 @@ __global__ __launch_bounds__(HGS_BLOCK) void blend_bwd_kernel(const uint2* __res
   __shared__ float4 recs[2][REC_BATCH * REC4];
   const int tile = blockIdx.x;
   const uint2 range = ranges[tile];
-  const uint32_t maxc = tile_maxc[tile];
-  if (maxc == 0 || range.y > Rcap) return;  // nothing in this tile contributed to any pixel (rows stay zero)
+  const uint32_t maxc = range.y > Rcap ? 0u : tile_maxc[tile];   // (list beyond an under-sized binning buffer: no gradients)
+  {
+    // Every instance row of the scratch is written by exactly one tile, so the scratch needs no clearing pass: entries
+    // past the last one any pixel needed (positions >= maxc; ~2% of the instances) get explicit zero rows here.
+    const uint32_t end = min(range.y, Rcap), first = range.x + maxc;
+    if (end > first) {
+      float4* z = (float4*)(inst_grad + (size_t)first * ROW);
+      const uint32_t n4 = (end - first) * (ROW / 4);
+      for (uint32_t i = threadIdx.x; i < n4; i += HGS_BLOCK) z[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  }
+  if (maxc == 0) return;  // nothing in this tile contributed to any pixel
   const int tx = tile % gx, ty = tile / gx;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int px = tx * HGS_TILE + (wave & 1) * 8 + (lane & 7);

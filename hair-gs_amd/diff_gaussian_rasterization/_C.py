@@ -127,6 +127,16 @@ def _forward(background, means3D, colors, opacity, scales, rotations, scale_modi
     return R, out_color, radii, geom, binning, img
 
 
+def _scratch(nbytes, dev):
+    """Backward scratch (per-instance partial-gradient rows).  It is deliberately NOT cleared by the library; with
+    HGS_POISON_SCRATCH=1 (tests) it is filled with NaN so that any read of a row nobody wrote shows up."""
+    import os
+    buf = torch.empty((nbytes,), dtype=torch.uint8, device=dev)
+    if os.environ.get("HGS_POISON_SCRATCH") == "1" and nbytes >= 4:
+        buf[:nbytes // 4 * 4].view(torch.float32).fill_(float("nan"))
+    return buf
+
+
 def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rotations, scale_modifier, cov3D_precomp,
                                  viewmatrix, projmatrix, tan_fovx, tan_fovy, dL_dout_color, sh, degree, campos,
                                  geomBuffer, R, binningBuffer, imageBuffer, debug):
@@ -145,7 +155,7 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
     dL_dsh, dL_dscales, dL_drotations = new((P, M, 3), **f32), new((P, 3), **f32), new((P, 4), **f32)
     if P == 0:
         return dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations
-    scratch = torch.empty((L.hgs_backward_scratch_bytes(P, int(R)),), dtype=torch.uint8, device=dev)
+    scratch = _scratch(L.hgs_backward_scratch_bytes(P, int(R)), dev)
     # keep every (possibly freshly made contiguous) input alive in a local until the launch has been enqueued:
     # a temporary released early would hand its block to the next temporary of the same size
     dpix = rt.require_gpu_tensor(dL_dout_color, "dL_dout_color", torch.float32)
@@ -187,7 +197,7 @@ def rasterize_gaussians_multi_backward(background7, means3D, radii, colors, scal
     dL_dextra = new((P, 4), **f32)
     if P == 0:
         return dL_dmeans2D, dL_dcolors, dL_dextra, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations
-    scratch = torch.empty((L.hgs_backward_scratch_bytes_multi(P, int(R)),), dtype=torch.uint8, device=dev)
+    scratch = _scratch(L.hgs_backward_scratch_bytes_multi(P, int(R)), dev)
     planes = [rt.require_gpu_tensor(g, "grad plane", torch.float32) for g in grad_planes]
     plane_ptrs = (C.c_void_p * 7)(*[g.data_ptr() for g in planes])
     bg_, sh_, colors_, scales_, rots_, cov_ = (_f32(background7, "bg"), _f32(sh, "sh"), _f32(colors, "colors_precomp"),
