@@ -298,11 +298,14 @@ class GraphedStep:
                 g.optimizer.step()
             self._graphs = (ga, None)
         else:
+            # a live RCCL communicator has a watchdog thread that polls events: with the default (global) capture
+            # error mode its calls would invalidate the capture; only this thread's unsafe calls must be errors
+            mode = dict(capture_error_mode="thread_local")
             ga, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-            with torch.cuda.graph(ga, stream=s):
+            with torch.cuda.graph(ga, stream=s, **mode):
                 self.loss_buf = self._forward_backward()
                 self.vp.pack_gradients(g)       # .grad become views of the flat exchange buffer
-            with torch.cuda.graph(gb, pool=ga.pool(), stream=s):
+            with torch.cuda.graph(gb, pool=ga.pool(), stream=s, **mode):
                 g.optimizer.step()
             self._graphs = (ga, gb)
         self._pending = list(raster._state["pending"])  # pinned status buffers the captured copies write into
