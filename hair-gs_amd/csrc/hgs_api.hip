@@ -115,7 +115,7 @@ int hgs_forward_preprocess(void* stream, int P, int D, int M, int W, int H, cons
                            float scale_modifier, const float* rotations, const float* cov3D_precomp,
                            const float* viewmatrix, const float* projmatrix, const float* campos, float tan_fovx,
                            float tan_fovy, int prefiltered, void* geom_buf, void* image_buf, int* radii,
-                           int* num_rendered_host) {
+                           int* num_rendered_host, unsigned int* max_rendered) {
   hipStream_t s = (hipStream_t)stream;
   if (P < 0 || W <= 0 || H <= 0) { hgs_set_error("bad sizes P=%d W=%d H=%d", P, W, H); return 1; }
   if (D < 0 || D > 3) { hgs_set_error("sh degree %d unsupported (0..3)", D); return 1; }
@@ -145,7 +145,7 @@ int hgs_forward_preprocess(void* stream, int P, int D, int M, int W, int H, cons
   a.campos = campos; a.scale_modifier = scale_modifier; a.tan_fovx = tan_fovx; a.tan_fovy = tan_fovy;
   a.prefiltered = prefiltered;
   if (hgs_launch_preprocess_fwd(s, a, g, im, radii)) return 1;
-  if (hgs_launch_scan(s, P, T, g, im)) return 1;
+  if (hgs_launch_scan(s, P, T, g, im, max_rendered)) return 1;
   if (num_rendered_host) {
     uint32_t r = 0;
     HGS_CHECK_HIP(hipMemcpyAsync(&r, im.status, sizeof(uint32_t), hipMemcpyDeviceToHost, s));

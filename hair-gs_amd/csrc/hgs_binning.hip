@@ -79,7 +79,8 @@ __device__ __forceinline__ uint32_t scan_regs(ScanRegs& r, int n, uint32_t* wtot
   return total;
 }
 
-__global__ __launch_bounds__(SCAN_THREADS) void scan_kernel(int nblk, int T, HgsGeom g, HgsImage im) {
+__global__ __launch_bounds__(SCAN_THREADS) void scan_kernel(int nblk, int T, HgsGeom g, HgsImage im,
+                                                            unsigned int* __restrict__ max_rendered) {
   __shared__ uint32_t wtot[SCAN_THREADS / 64];
   uint32_t* bs = g.block_sums;
   uint2* ranges = im.ranges;
@@ -98,7 +99,10 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_kernel(int nblk, int T, Hgs
     block_scan(bs, nblk, wtot, emit_bs);
     R = block_scan(im.tile_count, T, wtot, emit_rg);
   }
-  if (threadIdx.x == 0) im.status[0] = R;
+  if (threadIdx.x == 0) {
+    im.status[0] = R;
+    if (max_rendered) atomicMax(max_rendered, R);   // sticky maximum for graph replays (hgs.h)
+  }
 }
 
 struct EmitCtx { const float* feat; const float* extra; int n_extra; uint32_t Rcap; };
@@ -222,11 +226,11 @@ __global__ __launch_bounds__(HGS_BLOCK) void sort_tiles_kernel(int gx, uint32_t 
 
 }  // namespace
 
-int hgs_launch_scan(hipStream_t s, int P, int T, const HgsGeom& g, const HgsImage& im) {
+int hgs_launch_scan(hipStream_t s, int P, int T, const HgsGeom& g, const HgsImage& im, unsigned int* max_rendered) {
   const int nblk = (P + HGS_BLOCK - 1) / HGS_BLOCK;
   {
     HgsProfScope _prof(s, HGS_K_SCAN);
-    hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(SCAN_THREADS), 0, s, nblk, T, g, im);
+    hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(SCAN_THREADS), 0, s, nblk, T, g, im, max_rendered);
   }
   HGS_CHECK_LAUNCH();
   return 0;

@@ -122,7 +122,7 @@ struct HgsFwdArgs {
   int prefiltered;
 };
 int hgs_launch_preprocess_fwd(hipStream_t s, const HgsFwdArgs& a, const HgsGeom& g, const HgsImage& im, int* radii);
-int hgs_launch_scan(hipStream_t s, int P, int T, const HgsGeom& g, const HgsImage& im);
+int hgs_launch_scan(hipStream_t s, int P, int T, const HgsGeom& g, const HgsImage& im, unsigned int* max_rendered);
 int hgs_launch_scatter(hipStream_t s, int P, int W, int H, int Rcap, const int* radii, const HgsGeom& g,
                        const HgsImage& im, const HgsBinning& b);
 int hgs_launch_sort_tiles(hipStream_t s, int W, int H, int Rcap, const float* features, const float* extra, int n_extra,

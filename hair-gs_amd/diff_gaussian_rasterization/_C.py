@@ -16,7 +16,7 @@ import hgs_runtime as rt
 # instead of three).  If a pass needed more than its capacity, check_async() raises HgsCapacityOverflow after growing
 # the capacity: the caller discards the step's gradients and repeats it.  `num_rendered` returned by
 # rasterize_gaussians is then the capacity (it only sizes/carves buffers downstream).
-_state = {"last_R": 0, "async": False, "cap": 0, "slack": 1.5, "pending": [], "pool": []}
+_state = {"last_R": 0, "async": False, "cap": 0, "slack": 1.5, "dirty": False, "cap_used": None, "max_R": {}}
 
 
 class HgsCapacityOverflow(RuntimeError):
@@ -24,26 +24,36 @@ class HgsCapacityOverflow(RuntimeError):
 
 
 def set_async(enabled=True, slack=1.5):
+    """Capacity mode: passes never wait for num_rendered; the library keeps a sticky device-side maximum of it
+    (hgs_forward_preprocess max_rendered) which check_async() reads -- one synchronisation per check, no per-pass copy."""
     _state["async"], _state["slack"] = bool(enabled), float(slack)
-    _state["pending"].clear()
+    _state["dirty"] = False
+    _state["cap_used"] = None
+
+
+def _max_rendered(dev):
+    t = _state["max_R"].get(dev)
+    if t is None:
+        t = torch.zeros(1, dtype=torch.int32, device=dev)
+        _state["max_R"][dev] = t
+    return t
 
 
 def check_async():
-    """Synchronise once, validate every pass issued since the last check; returns the list of true num_rendered."""
-    if not _state["pending"]:
+    """Synchronise once and validate every pass issued since the last check against the capacity it ran with; returns
+    [largest num_rendered seen] ([] if no pass was issued).  Raises HgsCapacityOverflow after raising the capacity."""
+    if not _state.get("dirty"):
         return []
-    torch.cuda.current_stream().synchronize()
-    counts, overflow = [], False
-    for host, cap in _state["pending"]:
-        r, flag = int(host[0]), int(host[1])
-        counts.append(r)
-        overflow |= (flag != 0) or (r > cap)
-        _state["pool"].append(host)  # pinned buffers are recycled: allocating one per pass costs more than the sync
-    _state["pending"].clear()
-    _state["cap"] = max(_state["cap"], int(max(counts) * _state["slack"]) + 4096)
-    if overflow:
-        raise HgsCapacityOverflow(f"a raster pass needed {max(counts)} instances: capacity raised to {_state['cap']}, repeat the step")
-    return counts
+    worst, cap = 0, _state["cap_used"]
+    for t in _state["max_R"].values():
+        worst = max(worst, int(t.item()))   # .item() synchronises the stream the passes ran on
+        t.zero_()
+    _state["dirty"] = False
+    _state["cap_used"] = None
+    _state["cap"] = max(_state["cap"], int(worst * _state["slack"]) + 4096)
+    if cap is not None and worst > cap:
+        raise HgsCapacityOverflow(f"a raster pass needed {worst} instances (capacity {cap}): capacity raised to {_state['cap']}, repeat the step")
+    return [worst]
 
 
 def _f32(t, name):
@@ -101,7 +111,8 @@ def _forward(background, means3D, colors, opacity, scales, rotations, scale_modi
                                           rt.ptr(opacity_), rt.ptr(scales_), float(scale_modifier), rt.ptr(rots_),
                                           rt.ptr(cov_), rt.ptr(view), rt.ptr(proj), rt.ptr(cam), float(tan_fovx),
                                           float(tan_fovy), int(bool(prefiltered)), rt.ptr(geom), rt.ptr(img),
-                                          rt.ptr(radii), None if use_async else C.addressof(n_host)))
+                                          rt.ptr(radii), None if use_async else C.addressof(n_host),
+                                          rt.ptr(_max_rendered(dev)) if use_async else None))
         if use_async:
             R = _state["cap"]
         else:
@@ -117,10 +128,8 @@ def _forward(background, means3D, colors, opacity, scales, rotations, scale_modi
             rt.check(L.hgs_forward_render_multi(stream, P, W, H, R, rt.ptr(bg), rt.ptr(colors_), rt.ptr(extra_),
                                                 rt.ptr(geom), rt.ptr(binning), rt.ptr(img), rt.ptr(out_color)))
         if use_async:
-            off = rt.layout("image", W, H)["status"]
-            host = _state["pool"].pop() if _state["pool"] else torch.empty(2, dtype=torch.int32, pin_memory=True)
-            host.copy_(img[off:off + 8].view(torch.int32), non_blocking=True)
-            _state["pending"].append((host, R))
+            _state["dirty"] = True
+            _state["cap_used"] = R if _state["cap_used"] is None else min(_state["cap_used"], R)
         if debug:
             torch.cuda.synchronize(dev)  # surface asynchronous faults here, like CHECK_CUDA (auxiliary.h:166-173)
     _state["last_R"] = R

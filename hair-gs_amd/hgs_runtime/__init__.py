@@ -24,7 +24,7 @@ SIGNATURES = {
     "hgs_binning_bytes": (sz, [ci]),
     "hgs_backward_scratch_bytes": (sz, [ci, ci]),
     "hgs_forward_preprocess": (ci, [vp, ci, ci, ci, ci, ci, vp, vp, vp, vp, vp, cf, vp, vp, vp, vp, vp, cf, cf, ci,
-                                    vp, vp, vp, vp]),
+                                    vp, vp, vp, vp, vp]),
     "hgs_forward_render": (ci, [vp, ci, ci, ci, ci, vp, vp, vp, vp, vp, vp]),
     "hgs_backward": (ci, [vp, ci, ci, ci, ci, ci, ci, vp, vp, vp, vp, vp, cf, vp, vp, vp, vp, vp, cf, cf, vp, vp, vp,
                           vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),

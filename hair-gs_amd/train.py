@@ -202,7 +202,7 @@ class GraphedStep:
                 setattr(self.slot, f, v.clone())
         raster.set_async(True, slack=slack)
         self._graphs = None
-        self._pending = []
+        self._cap = None
         self._make_capturable()
 
     def _make_capturable(self):
@@ -283,10 +283,12 @@ class GraphedStep:
                     self.vp.pack_gradients(g)   # creates the flat exchange buffer outside the capture
                 g.optimizer.zero_grad(set_to_none=True)
                 g._derived = None
-                raster.check_async()
+                try:
+                    raster.check_async()        # learns the capacity; an overflow here only raises it for the capture
+                except raster.HgsCapacityOverflow:
+                    pass
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
-        raster._state["pending"].clear()
         g.optimizer.zero_grad(set_to_none=True)
         for dst, src in zip((g.max_radii2D, g.xyz_gradient_accum, g.denom), saved_stats):
             dst.copy_(src)
@@ -308,8 +310,13 @@ class GraphedStep:
             with torch.cuda.graph(gb, pool=ga.pool(), stream=s, **mode):
                 g.optimizer.step()
             self._graphs = (ga, gb)
-        self._pending = list(raster._state["pending"])  # pinned status buffers the captured copies write into
-        raster._state["pending"].clear()
+        # every replay raises the library's sticky device-side maximum of num_rendered; check() compares it with the
+        # capacity the captured passes were built for
+        self._cap = raster._state["cap_used"]
+        for t in raster._state["max_R"].values():
+            t.zero_()                       # the capture itself launched nothing
+        raster._state["dirty"] = False
+        raster._state["cap_used"] = None
         g._derived = None
 
     def step(self, cam, iteration):
@@ -325,13 +332,17 @@ class GraphedStep:
         return self.loss_buf
 
     def check(self):
-        """Synchronise and validate the instance counts of the last replay (raises on capacity overflow)."""
-        torch.cuda.current_stream().synchronize()
-        for host, cap in self._pending:
-            if int(host[1]) != 0 or int(host[0]) > cap:
-                raise self.raster.HgsCapacityOverflow(
-                    f"captured step needed {int(host[0])} instances > capacity {cap}: re-capture with a larger slack")
-        return [int(h[0]) for h, _ in self._pending]
+        """Synchronise and validate the instance counts of ALL replays since the last check (raises on capacity
+        overflow); returns [largest num_rendered seen]."""
+        raster = self.raster
+        worst = 0
+        for t in raster._state["max_R"].values():
+            worst = max(worst, int(t.item()))
+            t.zero_()
+        if self._cap is not None and worst > self._cap:
+            raise raster.HgsCapacityOverflow(
+                f"captured step needed {worst} instances > capacity {self._cap}: re-capture with a larger slack")
+        return [worst]
 
 
 def topology_due(gaussians, opt, iteration):

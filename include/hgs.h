@@ -57,14 +57,18 @@ size_t hgs_backward_scratch_bytes(int P, int R);
 /* Forward, part 1: per-Gaussian preprocess (cull, cov3D, EWA cov2D, conic, radius, tile rect, SH->RGB)
  * + per-tile instance counts + scans.  Writes radii[P].  If num_rendered_host != NULL the call blocks
  * until R = num_rendered is known and stores it there (reference: rasterizer_impl.cu:280-281);
- * with NULL nothing blocks and R stays on the device (pass a capacity to hgs_forward_render). */
+ * with NULL nothing blocks and R stays on the device (pass a capacity to hgs_forward_render).
+ * max_rendered (device, may be NULL): raised atomically to R -- a sticky maximum over all calls since the caller last
+ * cleared it, which is what a captured HIP graph needs to validate its capacity after any number of replays without a
+ * per-iteration device-to-host copy. */
 int hgs_forward_preprocess(void* stream, int P, int D, int M, int W, int H,
                            const float* means3D, const float* shs, const float* colors_precomp,
                            const float* opacities, const float* scales, float scale_modifier,
                            const float* rotations, const float* cov3D_precomp,
                            const float* viewmatrix, const float* projmatrix, const float* campos,
                            float tan_fovx, float tan_fovy, int prefiltered,
-                           void* geom_buf, void* image_buf, int* radii, int* num_rendered_host);
+                           void* geom_buf, void* image_buf, int* radii, int* num_rendered_host,
+                           unsigned int* max_rendered);
 
 /* Forward, part 2: instance scatter (tile binning), per-tile depth sort, front-to-back blend.
  * `R_capacity` = number of instances binning_buf was sized for (== num_rendered in the blocking mode).

@@ -194,7 +194,8 @@ def test_async_capacity_mode_matches_blocking_and_recovers_from_overflow():
         with torch.no_grad():
             got = [render(c, model, bg)["render"].clone() for c in cams]   # first call learns the capacity (blocking)
             counts = raster.check_async()
-        assert len(counts) == len(cams) - 1 and all(c > 0 for c in counts)
+        assert len(counts) == 1 and counts[0] > 0          # the sticky device-side maximum over the async passes
+        assert raster.check_async() == []                   # nothing issued since
         for a, b in zip(got, ref):
             assert torch.equal(a, b)
         # force an overflow: shrink the capacity below what the scene needs

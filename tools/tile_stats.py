@@ -55,3 +55,34 @@ power = -0.5 * (A[:, None, None] * dx[:, None, :] ** 2 + Cc[:, None, None] * dy[
 vis = (power <= 0) & (op[:, None, None] * torch.exp(power) >= 1.0 / 255.0)   # [R,16(y),16(x)]
 q = vis.reshape(-1, 2, 8, 2, 8).any(dim=4).any(dim=2)                          # [R, qy, qx]
 print("exact kept fraction", q.float().mean().item(), " pixels passing per kept (wave, entry):", vis.float().sum().item() / max(1.0, q.float().sum().item()))
+# ---- what a 4x4-block (DPP row) work decomposition would do: per (tile, wave=quadrant, batch of 64 entries) the step
+# count is the max over the quadrant's four 4x4 blocks of the entries whose footprint box reaches the block
+tau = torch.log(255.0 * op)
+det = A * Cc - B * B
+hx = torch.sqrt(2 * tau.clamp(min=0) * (Cc / det)) * 1.0005 + 0.01
+hy = torch.sqrt(2 * tau.clamp(min=0) * (A / det)) * 1.0005 + 0.01
+valid = (tau > 0)
+bi = torch.arange(4, device="cuda", dtype=torch.float32)
+bx0 = tx0[:, None].float() + 4 * bi[None, :]            # [R,4] block x origins
+by0 = ty0[:, None].float() + 4 * bi[None, :]
+ox = (recf[:, 0, None] + hx[:, None] >= bx0) & (recf[:, 0, None] - hx[:, None] <= bx0 + 3)   # [R,4]
+oy = (recf[:, 1, None] + hy[:, None] >= by0) & (recf[:, 1, None] - hy[:, None] <= by0 + 3)
+blk = (oy[:, :, None] & ox[:, None, :]) & valid[:, None, None]                                  # [R, by, bx]
+print("4x4 block kept fraction (box test)", blk.float().mean().item())
+visb = vis.reshape(-1, 4, 4, 4, 4).any(dim=4).any(dim=2)                                        # exact, [R, by, bx]
+print("4x4 block kept fraction (exact)", visb.float().mean().item(), "active pixels per kept block-pair",
+      vis.float().sum().item() / max(1.0, visb.float().sum().item()))
+# steps: group by (tile, batch of 64 positions), per quadrant max over its 4 blocks
+pos_in_tile = torch.arange(R, device="cuda") - torch.from_numpy(np.repeat(ranges[:, 0].astype(np.int64), L)).cuda()
+grp = tile_of * 64 + pos_in_tile // 64                     # (tile, batch) id
+ng = int(grp.max().item()) + 1
+cnt = torch.zeros((ng, 4, 4), device="cuda")
+cnt.index_add_(0, grp, blk.float())
+q = cnt.reshape(ng, 2, 2, 2, 2)                            # [g, qy, by, qx, bx]
+steps_new = q.amax(dim=(2, 4)).sum().item()
+pairs_quad = (cnt.reshape(ng, 2, 2, 2, 2).sum(dim=(2, 4)) > 0)
+quad_kept = torch.zeros((ng, 2, 2), device="cuda")
+qm_t = torch.from_numpy(((qm[:, None] >> np.arange(4)[None, :]) & 1).astype(np.float32)).cuda().reshape(-1, 2, 2)
+quad_kept.index_add_(0, grp, qm_t)
+print("quadrant pairs (current steps)", quad_kept.sum().item(), " 4x4-row steps", steps_new, " block pairs", blk.float().sum().item(),
+      " ratio old*87 / new*150 =", quad_kept.sum().item() * 87 / max(1.0, steps_new * 150))
