@@ -124,8 +124,9 @@ int hgs_forward_preprocess(void* stream, int P, int D, int M, int W, int H, cons
   hgs_image_carve((char*)image_buf, (size_t)W, (size_t)H, im, nullptr);
   const int T = ((W + HGS_TILE - 1) / HGS_TILE) * ((H + HGS_TILE - 1) / HGS_TILE);
   if (hgs_zero_async(s, im.tile_count, ((size_t)3 * T + HGS_STATUS_WORDS) * sizeof(uint32_t))) return 1;
-  if (P == 0) {  // reference short-circuits P == 0 (rasterize_points.cu:81)
-    if (hgs_zero_async(s, im.ranges, (size_t)T * sizeof(uint2))) return 1;
+  if (P == 0) {  // reference short-circuits P == 0 (rasterize_points.cu:81); the scan of all-zero counts writes the
+    HgsGeom none = {};  // empty ranges and the tile order the blend kernel (background fill) indexes with
+    if (hgs_launch_scan(s, 0, T, none, im, nullptr)) return 1;
     if (num_rendered_host) { HGS_CHECK_HIP(hipStreamSynchronize(s)); *num_rendered_host = 0; }
     return 0;
   }

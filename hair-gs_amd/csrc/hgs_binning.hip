@@ -16,6 +16,7 @@
 namespace {
 
 #define SCAN_THREADS 1024
+#define ORD_BUCKETS 512    // list-length buckets of the tile order (<= SCAN_THREADS)
 #define SORT_CAP 2048  // keys per LDS chunk (16 KB)
 
 // generic helper: scans `n` uint32 values with one 1024-thread block; calls emit(i, exclusive, value)
@@ -88,6 +89,25 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_kernel(int nblk, int T, Hgs
   auto emit_rg = [&](int i, uint32_t excl, uint32_t v) {
     ranges[i] = v ? make_uint2(excl, excl + v) : make_uint2(0u, 0u);  // empty tiles stay (0,0): memset at :310
   };
+  // ---- + longest-list-first workgroup order for the blend kernels (counting sort by min(length, ORD_BUCKETS-1)).
+  // A tile's list is consumed sequentially, so the blend kernels end when the longest lists end: measured on the
+  // strand workload, the 58-us tiles of the backward were only started 15-30 us into the launch by raster order.
+  __shared__ uint32_t hist[ORD_BUCKETS], obase[ORD_BUCKETS];
+  for (int i = threadIdx.x; i < ORD_BUCKETS; i += SCAN_THREADS) hist[i] = 0u;
+  auto bucket = [](uint32_t c) { return ORD_BUCKETS - 1 - (int)min(c, (uint32_t)(ORD_BUCKETS - 1)); };  // 0 = longest
+  auto bucket_bases = [&]() {   // exclusive scan of hist -> obase, hist cleared for the placement pass
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    __syncthreads();
+    const uint32_t v = tid < ORD_BUCKETS ? hist[tid] : 0u;
+    const uint32_t incl = hgs_wave_incl_scan(v, lane);
+    __syncthreads();
+    if (lane == 63) wtot[wave] = incl;
+    __syncthreads();
+    uint32_t woff = 0;
+    for (int w = 0; w < wave; w++) woff += wtot[w];
+    if (tid < ORD_BUCKETS) { obase[tid] = woff + incl - v; hist[tid] = 0u; }
+    __syncthreads();
+  };
   uint32_t R;
   if (nblk <= SCAN_THREADS * SCAN_IPT && T <= SCAN_THREADS * SCAN_IPT) {
     ScanRegs rb, rt;
@@ -95,9 +115,26 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_kernel(int nblk, int T, Hgs
     scan_load(im.tile_count, T, rt);
     scan_regs(rb, nblk, wtot, emit_bs);
     R = scan_regs(rt, T, wtot, emit_rg);
+    const int i0 = threadIdx.x * rt.ipt;          // the tile counts are still in registers: no second read
+#pragma unroll
+    for (int k = 0; k < SCAN_IPT; k++)
+      if (k < rt.ipt && i0 + k < T) atomicAdd(&hist[bucket(rt.v[k])], 1u);
+    bucket_bases();
+#pragma unroll
+    for (int k = 0; k < SCAN_IPT; k++)
+      if (k < rt.ipt && i0 + k < T) {
+        const int bkt = bucket(rt.v[k]);
+        im.tile_order[obase[bkt] + atomicAdd(&hist[bkt], 1u)] = (uint32_t)(i0 + k);   // order inside a bucket is irrelevant
+      }
   } else {
     block_scan(bs, nblk, wtot, emit_bs);
     R = block_scan(im.tile_count, T, wtot, emit_rg);
+    for (int i = threadIdx.x; i < T; i += SCAN_THREADS) atomicAdd(&hist[bucket(im.tile_count[i])], 1u);
+    bucket_bases();
+    for (int i = threadIdx.x; i < T; i += SCAN_THREADS) {
+      const int bkt = bucket(im.tile_count[i]);
+      im.tile_order[obase[bkt] + atomicAdd(&hist[bkt], 1u)] = (uint32_t)i;
+    }
   }
   if (threadIdx.x == 0) {
     im.status[0] = R;

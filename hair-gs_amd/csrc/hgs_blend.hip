@@ -15,6 +15,19 @@
 //     No float atomics anywhere -> gradients are bitwise reproducible run to run (the reference's are not).
 #include "hgs_common.h"
 
+// development aid: per-workgroup start/end timestamps (hgs_debug_set_wg_trace)
+__device__ unsigned long long* g_wg_trace_fwd = nullptr;
+__device__ unsigned long long* g_wg_trace_bwd = nullptr;
+struct WgTrace {
+  unsigned long long* buf; int tile;
+  __device__ WgTrace(unsigned long long* b, int t) : buf(b), tile(t) {
+    if (buf && threadIdx.x == 0) buf[2 * tile] = __builtin_amdgcn_s_memrealtime();
+  }
+  __device__ ~WgTrace() {
+    if (buf && threadIdx.x == 0) buf[2 * tile + 1] = __builtin_amdgcn_s_memrealtime();
+  }
+};
+
 namespace {
 
 #define BWD_BATCH 64   // entries combined per LDS flush in the backward
@@ -99,11 +112,13 @@ __global__ __launch_bounds__(HGS_BLOCK) void blend_fwd_kernel(const uint2* __res
                                                               float* __restrict__ final_T,
                                                               uint32_t* __restrict__ n_contrib,
                                                               uint32_t* __restrict__ tile_maxc,
+                                                              const uint32_t* __restrict__ tile_order,
                                                               float* __restrict__ out_color) {
   constexpr int REC4 = Chan<C>::REC4;
   __shared__ float4 recs[2][REC_BATCH * REC4];
   __shared__ uint32_t alive[2][4];
-  const int tile = blockIdx.x;
+  const int tile = (int)tile_order[blockIdx.x];   // longest lists first (scan_kernel)
+  WgTrace _trace(g_wg_trace_fwd, tile);
   const int tx = tile % gx, ty = tile / gx;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int px = tx * HGS_TILE + (wave & 1) * 8 + (lane & 7);
@@ -207,13 +222,14 @@ __global__ __launch_bounds__(HGS_BLOCK) void blend_bwd_kernel(const uint2* __res
                                                               const float* __restrict__ final_Ts,
                                                               const uint32_t* __restrict__ n_contrib,
                                                               const uint32_t* __restrict__ tile_maxc,
-                                                              PixGrad<C> dL_dpix,
+                                                              PixGrad<C> dL_dpix, const uint32_t* __restrict__ tile_order,
                                                               float* __restrict__ inst_grad) {
   constexpr int REC4 = Chan<C>::REC4, NPART = Chan<C>::NPART, NREG = Chan<C>::NREG, NV = 4 * NREG, ROW = Chan<C>::ROW;
   static_assert(BWD_BATCH == REC_BATCH, "one record batch per partial-sum flush");
   __shared__ float part[4][BWD_BATCH][NV];
   __shared__ float4 recs[2][REC_BATCH * REC4];
-  const int tile = blockIdx.x;
+  const int tile = (int)tile_order[blockIdx.x];   // longest lists first (scan_kernel)
+  WgTrace _trace(g_wg_trace_bwd, tile);
   const uint2 range = ranges[tile];
   const uint32_t maxc = range.y > Rcap ? 0u : tile_maxc[tile];   // (list beyond an under-sized binning buffer: no gradients)
   {
@@ -378,6 +394,12 @@ __global__ __launch_bounds__(HGS_BLOCK) void blend_bwd_kernel(const uint2* __res
 
 }  // namespace
 
+extern "C" int hgs_debug_set_wg_trace(void* device_buf_fwd, void* device_buf_bwd) {
+  HGS_CHECK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_wg_trace_fwd), &device_buf_fwd, sizeof(void*)));
+  HGS_CHECK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_wg_trace_bwd), &device_buf_bwd, sizeof(void*)));
+  return 0;
+}
+
 int hgs_launch_blend_fwd(hipStream_t s, int W, int H, int Rcap, int channels, const float* bg, const HgsImage& im,
                          const HgsBinning& b, float* out_color) {
   const int gx = (W + HGS_TILE - 1) / HGS_TILE, gy = (H + HGS_TILE - 1) / HGS_TILE;
@@ -385,10 +407,10 @@ int hgs_launch_blend_fwd(hipStream_t s, int W, int H, int Rcap, int channels, co
     HgsProfScope _prof(s, HGS_K_BLEND_FWD);
     if (channels == 3)
       hipLaunchKernelGGL(blend_fwd_kernel<3>, dim3(gx * gy), dim3(HGS_BLOCK), 0, s, im.ranges, b.packed, W, H, gx,
-                         (uint32_t)Rcap, bg, im.final_T, im.n_contrib, im.tile_maxc, out_color);
+                         (uint32_t)Rcap, bg, im.final_T, im.n_contrib, im.tile_maxc, im.tile_order, out_color);
     else
       hipLaunchKernelGGL(blend_fwd_kernel<7>, dim3(gx * gy), dim3(HGS_BLOCK), 0, s, im.ranges, b.packed, W, H, gx,
-                         (uint32_t)Rcap, bg, im.final_T, im.n_contrib, im.tile_maxc, out_color);
+                         (uint32_t)Rcap, bg, im.final_T, im.n_contrib, im.tile_maxc, im.tile_order, out_color);
   }
   HGS_CHECK_LAUNCH();
   return 0;
@@ -403,12 +425,12 @@ int hgs_launch_blend_bwd(hipStream_t s, int W, int H, int Rcap, int channels, co
       PixGrad<3> pg;
       for (int k = 0; k < 3; k++) pg.plane[k] = dL_dpix_planes[k];
       hipLaunchKernelGGL(blend_bwd_kernel<3>, dim3(gx * gy), dim3(HGS_BLOCK), 0, s, im.ranges, b.packed, W, H, gx,
-                         (uint32_t)Rcap, bg, im.final_T, im.n_contrib, im.tile_maxc, pg, inst_grad);
+                         (uint32_t)Rcap, bg, im.final_T, im.n_contrib, im.tile_maxc, pg, im.tile_order, inst_grad);
     } else {
       PixGrad<7> pg;
       for (int k = 0; k < 7; k++) pg.plane[k] = dL_dpix_planes[k];
       hipLaunchKernelGGL(blend_bwd_kernel<7>, dim3(gx * gy), dim3(HGS_BLOCK), 0, s, im.ranges, b.packed, W, H, gx,
-                         (uint32_t)Rcap, bg, im.final_T, im.n_contrib, im.tile_maxc, pg, inst_grad);
+                         (uint32_t)Rcap, bg, im.final_T, im.n_contrib, im.tile_maxc, pg, im.tile_order, inst_grad);
     }
   }
   HGS_CHECK_LAUNCH();

@@ -3,7 +3,7 @@
 // Workspace layout (all sub-arrays 256-B aligned inside caller-owned byte buffers):
 //   geom    (per Gaussian)  depths, clamped, means2D, cov3D, conic_opacity, rgb, tiles_touched,
 //                           point_offsets, rect(+exclusive instance offset), block_sums
-//   image   (per pixel/tile) final_T, n_contrib, ranges, tile_count, tile_cursor, tile_maxc, status
+//   image   (per pixel/tile) final_T, n_contrib, ranges, tile_count, tile_cursor, tile_maxc, status, tile_order
 //   binning (per instance)  keys (depth<<32|id), point_list, packed records, inverse index, sorted keys
 // They play the roles of GeometryState / ImageState / BinningState of the reference
 // (cuda_rasterizer/rasterizer_impl.h:23-71) but the layout is this library's own.
@@ -30,7 +30,7 @@ struct HgsGeom {
 };
 struct HgsImage {
   float* final_T; uint32_t* n_contrib; uint2* ranges; uint32_t* tile_count; uint32_t* tile_cursor;
-  uint32_t* tile_maxc; uint32_t* status;
+  uint32_t* tile_maxc; uint32_t* status; uint32_t* tile_order;
 };
 struct HgsBinning {
   uint64_t* keys; uint32_t* point_list; float4* packed; uint32_t* inv; uint64_t* keys_sorted;
@@ -72,6 +72,8 @@ static inline size_t hgs_image_carve(char* base, size_t W, size_t H, HgsImage& i
   im.tile_maxc = im.tile_cursor + T;        if (offs) offs[HGS_IMG_TILE_MAXC] = (char*)im.tile_maxc - base;
   im.status = im.tile_maxc + T;             if (offs) offs[HGS_IMG_STATUS] = (char*)im.status - base;
   cur += (3 * T + HGS_STATUS_WORDS) * sizeof(uint32_t);
+  // tiles in descending order of list length: the blend kernels' workgroup -> tile map (written by scan_kernel)
+  hgs_carve(cur, im.tile_order, T);         if (offs) offs[HGS_IMG_TILE_ORDER] = (char*)im.tile_order - base;
   return hgs_align_up((size_t)(cur - base)) + HGS_ALIGN;
 }
 static inline size_t hgs_binning_carve(char* base, size_t R, HgsBinning& b, size_t* offs, int channels = 3) {

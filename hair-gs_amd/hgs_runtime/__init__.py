@@ -58,6 +58,7 @@ SIGNATURES = {
     "hgs_loss_head_forward": (ci, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "hgs_loss_head_backward": (ci, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "hgs_densify_stats": (ci, [vp, ci, vp, vp, ci, vp, vp, vp]),
+    "hgs_debug_set_wg_trace": (ci, [vp, vp]),
     "hgs_prof_enable": (ci, [ci]),
     "hgs_prof_collect": (ci, [vp, vp]),
     "hgs_prof_kernel_name": (C.c_char_p, [ci]),
@@ -67,7 +68,7 @@ SIGNATURES = {
 }
 GEOM_FIELDS = ["depths", "clamped", "means2D", "cov3D", "conic_opacity", "rgb", "tiles_touched", "point_offsets", "rect",
                "block_sums"]
-IMG_FIELDS = ["final_T", "n_contrib", "ranges", "tile_count", "tile_cursor", "tile_maxc", "status"]
+IMG_FIELDS = ["final_T", "n_contrib", "ranges", "tile_count", "tile_cursor", "tile_maxc", "status", "tile_order"]
 BIN_FIELDS = ["keys", "point_list", "packed", "inv", "keys_sorted"]
 PACKED_FLOATS = 12
 INST_GRAD_FLOATS = 12

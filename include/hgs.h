@@ -267,12 +267,16 @@ int hgs_prof_enable(int on);
 int hgs_prof_collect(double* total_ms, long long* launches);
 const char* hgs_prof_kernel_name(int kernel_id);
 
+/* Development aid (tools/wg_trace.py): when a buffer of 2*T uint64 is registered, blend_fwd / blend_bwd record the
+ * start and end time (s_memrealtime, 100 MHz) of every tile's workgroup in it; NULL (the default) switches it off. */
+int hgs_debug_set_wg_trace(void* device_buf_fwd, void* device_buf_bwd);
+
 /* ---- introspection used by the parity tests (byte offsets of the sub-arrays of each buffer) ---- */
 enum { HGS_GEOM_DEPTHS = 0, HGS_GEOM_CLAMPED, HGS_GEOM_MEANS2D, HGS_GEOM_COV3D, HGS_GEOM_CONIC_OPACITY,
        HGS_GEOM_RGB, HGS_GEOM_TILES_TOUCHED, HGS_GEOM_POINT_OFFSETS, HGS_GEOM_RECT, HGS_GEOM_BLOCK_SUMS,
        HGS_GEOM_NFIELDS };
 enum { HGS_IMG_FINAL_T = 0, HGS_IMG_N_CONTRIB, HGS_IMG_RANGES, HGS_IMG_TILE_COUNT, HGS_IMG_TILE_CURSOR,
-       HGS_IMG_TILE_MAXC, HGS_IMG_STATUS, HGS_IMG_NFIELDS };
+       HGS_IMG_TILE_MAXC, HGS_IMG_STATUS, HGS_IMG_TILE_ORDER, HGS_IMG_NFIELDS };
 enum { HGS_BIN_KEYS = 0, HGS_BIN_POINT_LIST, HGS_BIN_PACKED, HGS_BIN_INV, HGS_BIN_KEYS_TMP, HGS_BIN_NFIELDS };
 int hgs_geom_layout(int P, size_t* offsets /* [HGS_GEOM_NFIELDS] */);
 int hgs_image_layout(int W, int H, size_t* offsets /* [HGS_IMG_NFIELDS] */);
