@@ -266,16 +266,15 @@ __global__ __launch_bounds__(HGS_BLOCK) void blend_bwd_kernel(const uint2* __res
 #pragma unroll
   for (int d = 32; d >= 1; d >>= 1) wlast = max(wlast, (uint32_t)__shfl_xor((int)wlast, d, 64));
   wlast = __builtin_amdgcn_readfirstlane(wlast);
-  float dpx[C], acc[C], lc[C];
+  float dpx[C], acc[C];
   float bg_dot = 0.f, bg_dot_rgb = 0.f;                                       // backward_distwar.cu:988-990
 #pragma unroll
   for (int k = 0; k < C; k++) {
     dpx[k] = inside ? dL_dpix.plane[k][pix] : 0.f;
-    acc[k] = 0.f; lc[k] = 0.f;
+    acc[k] = 0.f;
     bg_dot += bg[k] * dpx[k];
     if (k < 3) bg_dot_rgb += bg[k] * dpx[k];
   }
-  float last_alpha = 0.f;
   const float ddelx_dx = 0.5f * W, ddely_dy = 0.5f * H;                       // :917-918
 
   for (int i = threadIdx.x; i < 4 * BWD_BATCH * NV; i += HGS_BLOCK) (&part[0][0][0])[i] = 0.f;
@@ -315,14 +314,6 @@ __global__ __launch_bounds__(HGS_BLOCK) void blend_bwd_kernel(const uint2* __res
       const float G = ok ? Gx : 0.f, alpha = ok ? ax : 0.f;
       const float inv_one_m_a = __builtin_amdgcn_rcpf(1.f - alpha);               // 1 ulp; alpha <= 0.99; rcp(1) == 1
       T = T * inv_one_m_a;                                                         // :960
-      if (ok) {
-#pragma unroll
-        for (int k = 0; k < C; k++) {
-          acc[k] = last_alpha * lc[k] + (1.f - last_alpha) * acc[k];               // :972
-          lc[k] = f[6 + k];
-        }
-        last_alpha = alpha;
-      }
       float v[NV];
       const float dchannel_dcolor = alpha * T;
       float dL_dalpha = 0.f, dL_dalpha_rgb = 0.f;
@@ -351,6 +342,12 @@ __global__ __launch_bounds__(HGS_BLOCK) void blend_bwd_kernel(const uint2* __res
         v[6 + C] = dL_dG_rgb * dG_ddelx * ddelx_dx;
         v[7 + C] = dL_dG_rgb * dG_ddely * ddely_dy;
       }
+      // colour accumulated behind the NEXT (nearer) entry: the reference's accum_rec = last_alpha * last_color +
+      // (1 - last_alpha) * accum_rec (:972), evaluated here, right after its operands were used, instead of at the next
+      // contributing entry -- same operands, same order, and no (last_alpha, last_color) state to carry.  With
+      // alpha = 0 (lanes that do not blend this entry) it is the identity.
+#pragma unroll
+      for (int k = 0; k < C; k++) acc[k] = alpha * f[6 + k] + (1.f - alpha) * acc[k];
 #pragma unroll
       for (int k = NPART; k < NV; k++) v[k] = 0.f;
       float x[NREG];
