@@ -89,25 +89,6 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_kernel(int nblk, int T, Hgs
   auto emit_rg = [&](int i, uint32_t excl, uint32_t v) {
     ranges[i] = v ? make_uint2(excl, excl + v) : make_uint2(0u, 0u);  // empty tiles stay (0,0): memset at :310
   };
-  // ---- + longest-list-first workgroup order for the blend kernels (counting sort by min(length, ORD_BUCKETS-1)).
-  // A tile's list is consumed sequentially, so the blend kernels end when the longest lists end: measured on the
-  // strand workload, the 58-us tiles of the backward were only started 15-30 us into the launch by raster order.
-  __shared__ uint32_t hist[ORD_BUCKETS], obase[ORD_BUCKETS];
-  for (int i = threadIdx.x; i < ORD_BUCKETS; i += SCAN_THREADS) hist[i] = 0u;
-  auto bucket = [](uint32_t c) { return ORD_BUCKETS - 1 - (int)min(c, (uint32_t)(ORD_BUCKETS - 1)); };  // 0 = longest
-  auto bucket_bases = [&]() {   // exclusive scan of hist -> obase, hist cleared for the placement pass
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    __syncthreads();
-    const uint32_t v = tid < ORD_BUCKETS ? hist[tid] : 0u;
-    const uint32_t incl = hgs_wave_incl_scan(v, lane);
-    __syncthreads();
-    if (lane == 63) wtot[wave] = incl;
-    __syncthreads();
-    uint32_t woff = 0;
-    for (int w = 0; w < wave; w++) woff += wtot[w];
-    if (tid < ORD_BUCKETS) { obase[tid] = woff + incl - v; hist[tid] = 0u; }
-    __syncthreads();
-  };
   uint32_t R;
   if (nblk <= SCAN_THREADS * SCAN_IPT && T <= SCAN_THREADS * SCAN_IPT) {
     ScanRegs rb, rt;
@@ -115,26 +96,9 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_kernel(int nblk, int T, Hgs
     scan_load(im.tile_count, T, rt);
     scan_regs(rb, nblk, wtot, emit_bs);
     R = scan_regs(rt, T, wtot, emit_rg);
-    const int i0 = threadIdx.x * rt.ipt;          // the tile counts are still in registers: no second read
-#pragma unroll
-    for (int k = 0; k < SCAN_IPT; k++)
-      if (k < rt.ipt && i0 + k < T) atomicAdd(&hist[bucket(rt.v[k])], 1u);
-    bucket_bases();
-#pragma unroll
-    for (int k = 0; k < SCAN_IPT; k++)
-      if (k < rt.ipt && i0 + k < T) {
-        const int bkt = bucket(rt.v[k]);
-        im.tile_order[obase[bkt] + atomicAdd(&hist[bkt], 1u)] = (uint32_t)(i0 + k);   // order inside a bucket is irrelevant
-      }
   } else {
     block_scan(bs, nblk, wtot, emit_bs);
     R = block_scan(im.tile_count, T, wtot, emit_rg);
-    for (int i = threadIdx.x; i < T; i += SCAN_THREADS) atomicAdd(&hist[bucket(im.tile_count[i])], 1u);
-    bucket_bases();
-    for (int i = threadIdx.x; i < T; i += SCAN_THREADS) {
-      const int bkt = bucket(im.tile_count[i]);
-      im.tile_order[obase[bkt] + atomicAdd(&hist[bkt], 1u)] = (uint32_t)i;
-    }
   }
   if (threadIdx.x == 0) {
     im.status[0] = R;
@@ -213,10 +177,52 @@ __device__ __forceinline__ void bitonic_lds(uint64_t* sk, int m) {
   }
 }
 
-__global__ __launch_bounds__(HGS_BLOCK) void sort_tiles_kernel(int gx, uint32_t Rcap, EmitCtx ec, HgsGeom g, HgsImage im,
+// Longest-list-first workgroup order for the blend kernels (counting sort of the tiles by min(length, ORD_BUCKETS-1)),
+// computed by ONE extra workgroup of the sort kernel, i.e. in the shadow of the per-tile sorts.  A tile's list is consumed
+// sequentially, so the blend kernels end when the longest lists end: measured on the strand workload, raster order
+// started the 58-us tiles of the backward 15-30 us into the launch (88 -> 75 us with this order).
+__device__ __forceinline__ void tile_order_block(int T, const HgsImage& im, uint16_t* bk, int bk_cap) {
+  __shared__ uint32_t hist[ORD_BUCKETS], obase[ORD_BUCKETS], wsum[HGS_BLOCK / 64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int i = tid; i < ORD_BUCKETS; i += HGS_BLOCK) hist[i] = 0u;
+  auto bucket_of = [&](int i) {
+    const uint2 r = im.ranges[i];
+    return ORD_BUCKETS - 1 - (int)min(r.y - r.x, (uint32_t)(ORD_BUCKETS - 1));   // bucket 0 = longest lists
+  };
+  // pass 0: the buckets of all tiles into LDS (bk aliases the sort buffer of this otherwise idle workgroup); nothing in
+  // this loop orders its iterations, so the loads of several iterations are in flight together
+  const bool cached = T <= bk_cap;
+  if (cached) {
+#pragma unroll 8
+    for (int i = tid; i < T; i += HGS_BLOCK) bk[i] = (uint16_t)bucket_of(i);
+  }
+  __syncthreads();
+  for (int i = tid; i < T; i += HGS_BLOCK) atomicAdd(&hist[cached ? (int)bk[i] : bucket_of(i)], 1u);
+  __syncthreads();
+  uint32_t carry = 0;
+  for (int base = 0; base < ORD_BUCKETS; base += HGS_BLOCK) {   // exclusive scan of the histogram
+    const uint32_t v = hist[base + tid];
+    const uint32_t incl = hgs_wave_incl_scan(v, lane);
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    uint32_t woff = 0, total = 0;
+    for (int w = 0; w < HGS_BLOCK / 64; w++) { if (w < wave) woff += wsum[w]; total += wsum[w]; }
+    obase[base + tid] = carry + woff + incl - v;
+    hist[base + tid] = 0u;
+    carry += total;
+    __syncthreads();
+  }
+  for (int i = tid; i < T; i += HGS_BLOCK) {
+    const int bkt = cached ? (int)bk[i] : bucket_of(i);
+    im.tile_order[obase[bkt] + atomicAdd(&hist[bkt], 1u)] = (uint32_t)i;   // order inside a bucket is irrelevant
+  }
+}
+
+__global__ __launch_bounds__(HGS_BLOCK) void sort_tiles_kernel(int gx, int T, uint32_t Rcap, EmitCtx ec, HgsGeom g, HgsImage im,
                                                                HgsBinning b) {
   __shared__ uint64_t sk[SORT_CAP];
-  const int tile = blockIdx.x;
+  if (blockIdx.x == 0) { tile_order_block(T, im, (uint16_t*)sk, SORT_CAP * 4); return; }
+  const int tile = blockIdx.x - 1;
   const uint2 range = im.ranges[tile];
   if (range.y <= range.x || range.y > Rcap) return;  // empty, or binning buffer overflow (status[1] already set)
   const uint32_t start = range.x, n = range.y - range.x;
@@ -279,7 +285,7 @@ int hgs_launch_sort_tiles(hipStream_t s, int W, int H, int Rcap, const float* fe
   {
     HgsProfScope _prof(s, HGS_K_SORT_TILES);
     EmitCtx ec = {features, extra, n_extra, (uint32_t)Rcap};
-    hipLaunchKernelGGL(sort_tiles_kernel, dim3(gx * gy), dim3(HGS_BLOCK), 0, s, gx, (uint32_t)Rcap, ec, g, im, b);
+    hipLaunchKernelGGL(sort_tiles_kernel, dim3(gx * gy + 1), dim3(HGS_BLOCK), 0, s, gx, gx * gy, (uint32_t)Rcap, ec, g, im, b);
   }
   HGS_CHECK_LAUNCH();
   return 0;

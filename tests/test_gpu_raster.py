@@ -91,6 +91,24 @@ def test_forward_matches_oracle(name):
     _check_forward(name)
 
 
+@pytest.mark.parametrize("name", ["strands", "dense_long_lists", "many_tiles", "all_culled"])
+def test_tile_order_is_a_permutation_by_descending_list_length(name):
+    """The blend kernels' workgroup -> tile map: every tile exactly once, list lengths (capped at 511) non-increasing."""
+    import hgs_runtime as rt
+    from tests import gpu_util as G
+    s = _scene(name)
+    fw = G.run_forward(s)
+    W, H = s["W"], s["H"]
+    T = ((W + 15) // 16) * ((H + 15) // 16)
+    lay = rt.layout("image", W, H)
+    img = fw["img"].cpu().numpy()
+    order = img[lay["tile_order"]:lay["tile_order"] + 4 * T].view(np.uint32)
+    ranges = img[lay["ranges"]:lay["ranges"] + 8 * T].view(np.uint32).reshape(T, 2)
+    assert sorted(order.tolist()) == list(range(T))
+    L = np.minimum(ranges[:, 1] - ranges[:, 0], 511)[order]
+    assert (np.diff(L.astype(np.int64)) <= 0).all()
+
+
 def _grad_close(name, a, b, rtol=1e-4):
     a = a.astype(np.float64).reshape(b.shape)
     b = b.astype(np.float64)
