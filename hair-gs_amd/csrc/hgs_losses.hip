@@ -139,8 +139,10 @@ static inline SsimGrid ssim_grid(int C, int H, int W) {
   gd.chunk = (gd.total + 7) / 8;
   return gd;
 }
-#define SSIM_WG_PER_XCD 96   // 32 CUs x 3 resident workgroups
-static inline unsigned ssim_grid_size(const SsimGrid& gd) { return 8u * (unsigned)(gd.chunk < SSIM_WG_PER_XCD ? gd.chunk : SSIM_WG_PER_XCD); }
+// persistent workgroups per XCD = 32 CUs x resident workgroups (forward: 38.7 KB LDS, 127 VGPRs -> 4; backward: 41 KB, 163 -> 3)
+#define SSIM_FWD_WG_PER_XCD 128
+#define SSIM_BWD_WG_PER_XCD 96
+static inline unsigned ssim_grid_size(const SsimGrid& gd, int per_xcd) { return 8u * (unsigned)(gd.chunk < per_xcd ? gd.chunk : per_xcd); }
 
 // register staging of one halo tile (fast path, W % 4 == 0): 504 float4 per plane = 2 per thread
 #define ST_F4 (TILE * (TW / 4))
@@ -180,7 +182,7 @@ __global__ __launch_bounds__(256) void ssim_l1_fwd_kernel(int H, int W, SsimGrid
                                                           const float* __restrict__ img2_, const HgsViewTargets* __restrict__ tgt,
                                                           float* __restrict__ dmap, float* __restrict__ partials) {
   __shared__ float t[2][TILE][TPW];
-  __shared__ float hz[5][TILE][HP];
+  __shared__ float hz[4][TILE][HP];   // mu1, mu2, E[x1^2 + x2^2], E[x1 x2]: S only needs the SUM of the two variances
   __shared__ float red[4];
   const size_t plane = (size_t)H * W, cp = (size_t)gd.C * plane;
   const float* img2 = tgt ? tgt->image : img2_;   // per-view target read through the device-resident slot
@@ -199,13 +201,13 @@ __global__ __launch_bounds__(256) void ssim_l1_fwd_kernel(int H, int W, SsimGrid
     j += nwg;
     const bool have_next = ssim_block(gd, j, nx);
     if (fast && have_next) stage_load<2>(st, H, W, nx.bx0, nx.by0, [&](int p) { return (p == 0 ? img1 : img2) + nx.c * plane; });
-    row_pass<5>(win, hz, [&](int r, int x, float* v) {   // x = tile column of the tap: image x = bx0 - HALO + x
+    row_pass<4>(win, hz, [&](int r, int x, float* v) {   // x = tile column of the tap: image x = bx0 - HALO + x
       const float a = t[0][r][x + XOFF - HALO], b = t[1][r][x + XOFF - HALO];
-      v[0] = a; v[1] = b; v[2] = a * a; v[3] = b * b; v[4] = a * b;
+      v[0] = a; v[1] = b; v[2] = a * a + b * b; v[3] = a * b;
     });
     __syncthreads();
-    float f[5][4];
-    col_pass<5>(win, hz, lx, y0, f);
+    float f[4][4];
+    col_pass<4>(win, hz, lx, y0, f);
     const float C1 = 0.01f * 0.01f, C2 = 0.03f * 0.03f;
     const int px = bk.bx0 + lx;
     float ssim_v = 0.f, l1_v = 0.f;
@@ -215,8 +217,8 @@ __global__ __launch_bounds__(256) void ssim_l1_fwd_kernel(int H, int W, SsimGrid
       if (px < W && py < H) {
         const float mu1 = f[0][o], mu2 = f[1][o];
         const float mu1_sq = mu1 * mu1, mu2_sq = mu2 * mu2, mu12 = mu1 * mu2;
-        const float s1 = f[2][o] - mu1_sq, s2 = f[3][o] - mu2_sq, s12 = f[4][o] - mu12;
-        const float A1 = 2.f * mu12 + C1, A2 = 2.f * s12 + C2, B1 = mu1_sq + mu2_sq + C1, B2 = s1 + s2 + C2;
+        const float s_sum = f[2][o] - (mu1_sq + mu2_sq), s12 = f[3][o] - mu12;    // sigma1^2 + sigma2^2, sigma12
+        const float A1 = 2.f * mu12 + C1, A2 = 2.f * s12 + C2, B1 = mu1_sq + mu2_sq + C1, B2 = s_sum + C2;
         // B1 >= C1 > 0; B2 = C2 + (window variances) > 0 up to rounding: hardware reciprocals (1 ulp) instead of four
         // IEEE division sequences per pixel
         const float iB1 = __builtin_amdgcn_rcpf(B1), iB2 = __builtin_amdgcn_rcpf(B2);
@@ -543,7 +545,7 @@ int hgs_ssim_l1_forward(void* stream, int C, int H, int W, const float* window11
   hipStream_t s = (hipStream_t)stream;
   {
     HgsProfScope _prof(s, HGS_K_SSIM_FWD);
-    hipLaunchKernelGGL(ssim_l1_fwd_kernel, dim3(ssim_grid_size(ssim_grid(C, H, W))), dim3(256), 0, s, H, W, ssim_grid(C, H, W), win, img1,
+    hipLaunchKernelGGL(ssim_l1_fwd_kernel, dim3(ssim_grid_size(ssim_grid(C, H, W), SSIM_FWD_WG_PER_XCD)), dim3(256), 0, s, H, W, ssim_grid(C, H, W), win, img1,
                        img2, (const HgsViewTargets*)nullptr, dmaps, partials);
   }
   HGS_CHECK_LAUNCH();
@@ -561,7 +563,7 @@ int hgs_ssim_l1_backward(void* stream, int C, int H, int W, const float* window1
   hipStream_t s = (hipStream_t)stream;
   {
     HgsProfScope _prof(s, HGS_K_SSIM_BWD);
-    hipLaunchKernelGGL(ssim_l1_bwd_kernel, dim3(ssim_grid_size(ssim_grid(C, H, W))), dim3(256), 0, s, H, W, ssim_grid(C, H, W), win, img1,
+    hipLaunchKernelGGL(ssim_l1_bwd_kernel, dim3(ssim_grid_size(ssim_grid(C, H, W), SSIM_BWD_WG_PER_XCD)), dim3(256), 0, s, H, W, ssim_grid(C, H, W), win, img1,
                        img2, (const HgsViewTargets*)nullptr, dmaps, g_ssim_mean, g_l1_mean, (const float*)nullptr, dL_dimg1);
   }
   HGS_CHECK_LAUNCH();
@@ -637,7 +639,7 @@ int hgs_loss_head_forward(void* stream, const HgsHeadParams* p, const float* ima
   hipStream_t s = (hipStream_t)stream;
   {
     HgsProfScope _prof(s, HGS_K_SSIM_FWD);
-    hipLaunchKernelGGL(ssim_l1_fwd_kernel, dim3(ssim_grid_size(ssim_grid(3, H, W))), dim3(256), 0, s, H, W, ssim_grid(3, H, W), win, image,
+    hipLaunchKernelGGL(ssim_l1_fwd_kernel, dim3(ssim_grid_size(ssim_grid(3, H, W), SSIM_FWD_WG_PER_XCD)), dim3(256), 0, s, H, W, ssim_grid(3, H, W), win, image,
                        (const float*)nullptr, targets, dmaps, p_ssim);
   }
   HeadFlags fl;
@@ -678,7 +680,7 @@ int hgs_loss_head_backward(void* stream, const HgsHeadParams* p, const float* im
   hipStream_t s = (hipStream_t)stream;
   {
     HgsProfScope _prof(s, HGS_K_SSIM_BWD);
-    hipLaunchKernelGGL(ssim_l1_bwd_kernel, dim3(ssim_grid_size(ssim_grid(3, H, W))), dim3(256), 0, s, H, W, ssim_grid(3, H, W), win, image,
+    hipLaunchKernelGGL(ssim_l1_bwd_kernel, dim3(ssim_grid_size(ssim_grid(3, H, W), SSIM_BWD_WG_PER_XCD)), dim3(256), 0, s, H, W, ssim_grid(3, H, W), win, image,
                        (const float*)nullptr, targets, dmaps, out + HGS_HEAD_G_SSIM, out + HGS_HEAD_G_L1, grad_out, d_image);
   }
   HeadFlags fl;
