@@ -249,7 +249,10 @@ __global__ __launch_bounds__(256) void ssim_l1_bwd_kernel(int H, int W, SsimGrid
                                                           const float* __restrict__ dmap,
                                                           const float* __restrict__ g_ssim_mean,
                                                           const float* __restrict__ g_l1_mean, const float* __restrict__ go,
-                                                          float* __restrict__ dimg1) {
+                                                          float* __restrict__ dimg1, float* __restrict__ zero_buf,
+                                                          int zero_n) {
+  // (the loss head's endpoint-gradient buffer is cleared here, in passing: saves a launch before the smoothness scatter)
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < zero_n; i += gridDim.x * 256) zero_buf[i] = 0.f;
   __shared__ float t[3][TILE][TPW];
   __shared__ float hz[3][TILE][HP];
   const float* img2 = tgt ? tgt->image : img2_;
@@ -394,16 +397,41 @@ __global__ __launch_bounds__(256) void ori_bwd_kernel(int N, OriParams p, const 
 // one pass over the pixels; targets come from the device-resident HgsViewTargets.
 struct HeadFlags { int bce, ori; };
 
+// gradient of the orientation term w.r.t. the direction image at one masked pixel, `scale` = dL/d(term) / mask count
+__device__ __forceinline__ void ori_pixel_grad(const OriParams& p, float px, float py, float r, float n, float x, float yq,
+                                               float th, float gt, float conf, float scale, float& g0, float& g1, float& g2) {
+  g0 = 0.f; g1 = 0.f; g2 = 0.f;
+  if (!(r > 0.f)) return;
+  const float hp = 1.57079632679489661923f;
+  const float e = th - gt;
+  const float u = fabsf(e) - hp;
+  const float sg = (u > 0.f ? 1.f : (u < 0.f ? -1.f : 0.f)) * (e > 0.f ? 1.f : (e < 0.f ? -1.f : 0.f));
+  const float dth = -sg * conf * scale;                               // dL/dtheta
+  const float den = x * x + yq * yq;
+  const float dx = dth * (yq / den), dy = dth * (-x / den);           // atan2(x, yq)
+  const float inv_n = 1.f / n, inv_n2 = inv_n * inv_n, ir = 1.f / r;  // x = px/n, y = py/n, n = r + eps
+  const float dn = -(dx * px + dy * py) * inv_n2;
+  const float dpx = dx * inv_n + dn * px * ir, dpy = dy * inv_n + dn * py * ir;
+  const float* v = p.view;
+  g0 = dpx * v[0] + dpy * v[1]; g1 = dpx * v[4] + dpy * v[5]; g2 = dpx * v[8] + dpy * v[9];
+}
+
+// d_unit != NULL: the gradient planes for an upstream gradient of 1 are written in the same pass (g_mask = l_mask/HW,
+// g_ori = l_orientation; the orientation term is normalised by tgt->mask_count, known before the pass)
 __global__ __launch_bounds__(256) void pix_fwd_kernel(int N, HeadFlags fl, float bg0, float bg1, float bg2, float min_val,
                                                       const float* __restrict__ mask_img, const float* __restrict__ omap,
-                                                      const HgsViewTargets* __restrict__ tgt, float* __restrict__ partials) {
+                                                      const HgsViewTargets* __restrict__ tgt, float* __restrict__ partials,
+                                                      float g_mask, float g_ori, float* __restrict__ d_unit) {
   __shared__ float red[4];
   const int i = blockIdx.x * 256 + threadIdx.x;
   float s = 0.f, cnt = 0.f, b = 0.f;
   if (i < N) {
+    float gm = 0.f, g0 = 0.f, g1 = 0.f, g2 = 0.f;
     if (fl.bce) {
       const float x = mask_img[i], y = tgt->float_mask[i];
-      b = fmaxf(x, 0.f) - x * y + log1pf(expf(-fabsf(x)));
+      const float en = expf(-fabsf(x));
+      b = fmaxf(x, 0.f) - x * y + log1pf(en);
+      if (d_unit) gm = g_mask * ((x >= 0.f ? 1.f / (1.f + en) : en / (1.f + en)) - y);   // sigmoid(x) - y
     }
     if (fl.ori) {
       OriParams p;
@@ -414,9 +442,14 @@ __global__ __launch_bounds__(256) void pix_fwd_kernel(int N, HeadFlags fl, float
         float px, py, r, n, x, y, yq, th;
         ori_pixel(p, o0, o1, o2, px, py, r, n, x, y, yq, th);
         const float hp = 1.57079632679489661923f;
-        s = (hp - fabsf(fabsf(th - tgt->orientation[i]) - hp)) * tgt->confidence[i];
+        const float gt = tgt->orientation[i], cf = tgt->confidence[i];
+        s = (hp - fabsf(fabsf(th - gt) - hp)) * cf;
         cnt = 1.f;
+        if (d_unit) ori_pixel_grad(p, px, py, r, n, x, yq, th, gt, cf, g_ori / tgt->mask_count, g0, g1, g2);
       }
+    }
+    if (d_unit) {
+      d_unit[i] = gm; d_unit[(size_t)N + i] = g0; d_unit[2 * (size_t)N + i] = g1; d_unit[3 * (size_t)N + i] = g2;
     }
   }
   const float bs = block_sum(s, red);
@@ -448,20 +481,8 @@ __global__ __launch_bounds__(256) void pix_bwd_kernel(int N, HeadFlags fl, float
     if (m) {
       float px, py, r, n, x, y, yq, th;
       ori_pixel(p, o0, o1, o2, px, py, r, n, x, y, yq, th);
-      if (r > 0.f) {
-        const float hp = 1.57079632679489661923f;
-        const float e = th - tgt->orientation[i];
-        const float u = fabsf(e) - hp;
-        const float sg = (u > 0.f ? 1.f : (u < 0.f ? -1.f : 0.f)) * (e > 0.f ? 1.f : (e < 0.f ? -1.f : 0.f));
-        const float dth = -sg * tgt->confidence[i] * (out[HGS_HEAD_G_ORI] * up) / out[HGS_HEAD_ORI_COUNT];
-        const float den = x * x + yq * yq;
-        const float dx = dth * (yq / den), dy = dth * (-x / den);
-        const float inv_n = 1.f / n, inv_n2 = inv_n * inv_n, ir = 1.f / r;
-        const float dn = -(dx * px + dy * py) * inv_n2;
-        const float dpx = dx * inv_n + dn * px * ir, dpy = dy * inv_n + dn * py * ir;
-        const float* v = p.view;
-        g0 = dpx * v[0] + dpy * v[1]; g1 = dpx * v[4] + dpy * v[5]; g2 = dpx * v[8] + dpy * v[9];
-      }
+      ori_pixel_grad(p, px, py, r, n, x, yq, th, tgt->orientation[i], tgt->confidence[i],
+                     (out[HGS_HEAD_G_ORI] * up) / out[HGS_HEAD_ORI_COUNT], g0, g1, g2);
     }
   }
   d_omap[i] = g0; d_omap[(size_t)N + i] = g1; d_omap[2 * (size_t)N + i] = g2;
@@ -564,7 +585,8 @@ int hgs_ssim_l1_backward(void* stream, int C, int H, int W, const float* window1
   {
     HgsProfScope _prof(s, HGS_K_SSIM_BWD);
     hipLaunchKernelGGL(ssim_l1_bwd_kernel, dim3(ssim_grid_size(ssim_grid(C, H, W), SSIM_BWD_WG_PER_XCD)), dim3(256), 0, s, H, W, ssim_grid(C, H, W), win, img1,
-                       img2, (const HgsViewTargets*)nullptr, dmaps, g_ssim_mean, g_l1_mean, (const float*)nullptr, dL_dimg1);
+                       img2, (const HgsViewTargets*)nullptr, dmaps, g_ssim_mean, g_l1_mean, (const float*)nullptr, dL_dimg1,
+                       (float*)nullptr, 0);
   }
   HGS_CHECK_LAUNCH();
   return 0;
@@ -622,7 +644,7 @@ size_t hgs_loss_head_scratch_floats(const HgsHeadParams* p) {
 
 int hgs_loss_head_forward(void* stream, const HgsHeadParams* p, const float* image, const float* mask_img,
                           const float* omap, const HgsViewTargets* targets, const float* endpoints,
-                          const long long* smooth_pairs, float* scratch, float* out) {
+                          const long long* smooth_pairs, float* scratch, float* out, float* d_extra_unit) {
   if (!p || !image || !mask_img || !omap || !targets || !scratch || !out || p->H <= 0 || p->W <= 0) {
     hgs_set_error("hgs_loss_head_forward: bad arguments");
     return 1;
@@ -647,7 +669,8 @@ int hgs_loss_head_forward(void* stream, const HgsHeadParams* p, const float* ima
   {
     HgsProfScope _prof(s, HGS_K_ORI_FWD);
     hipLaunchKernelGGL(pix_fwd_kernel, dim3(nbp), dim3(256), 0, s, N, fl, p->bg[0], p->bg[1], p->bg[2], p->min_val, mask_img,
-                       omap, targets, p_pix);
+                       omap, targets, p_pix, fl.bce ? p->lambda_mask / (float)N : 0.f, fl.ori ? p->lambda_orientation : 0.f,
+                       d_extra_unit);
   }
   if (nbm > 0 && hgs_launch_smooth_fwd(s, p->n_smooth, endpoints, smooth_pairs, p->cos_threshold, p->eps, p_smooth)) return 1;
   HeadReduce h;
@@ -666,9 +689,10 @@ int hgs_loss_head_forward(void* stream, const HgsHeadParams* p, const float* ima
 int hgs_loss_head_backward(void* stream, const HgsHeadParams* p, const float* image, const float* mask_img,
                            const float* omap, const HgsViewTargets* targets, const float* endpoints,
                            const long long* smooth_pairs, const float* scratch, const float* out,
-                           const float* grad_out, float* d_image, float* d_mask_img, float* d_omap,
-                           float* d_endpoints) {
-  if (!p || !image || !mask_img || !omap || !targets || !scratch || !out || !grad_out || !d_image || !d_mask_img || !d_omap) {
+                           const float* grad_out, int skip_pixel_pass, float* d_image, float* d_mask_img,
+                           float* d_omap, float* d_endpoints) {
+  if (!p || !image || !mask_img || !omap || !targets || !scratch || !out || !grad_out || !d_image ||
+      (!skip_pixel_pass && (!d_mask_img || !d_omap))) {
     hgs_set_error("hgs_loss_head_backward: bad arguments");
     return 1;
   }
@@ -681,17 +705,17 @@ int hgs_loss_head_backward(void* stream, const HgsHeadParams* p, const float* im
   {
     HgsProfScope _prof(s, HGS_K_SSIM_BWD);
     hipLaunchKernelGGL(ssim_l1_bwd_kernel, dim3(ssim_grid_size(ssim_grid(3, H, W), SSIM_BWD_WG_PER_XCD)), dim3(256), 0, s, H, W, ssim_grid(3, H, W), win, image,
-                       (const float*)nullptr, targets, dmaps, out + HGS_HEAD_G_SSIM, out + HGS_HEAD_G_L1, grad_out, d_image);
+                       (const float*)nullptr, targets, dmaps, out + HGS_HEAD_G_SSIM, out + HGS_HEAD_G_L1, grad_out, d_image,
+                       d_endpoints, d_endpoints ? p->n_endpoints * 3 : 0);
   }
   HeadFlags fl;
   fl.bce = p->lambda_mask > 0.f; fl.ori = p->lambda_orientation > 0.f;
-  {
+  if (!skip_pixel_pass) {
     HgsProfScope _prof(s, HGS_K_ORI_BWD);
     hipLaunchKernelGGL(pix_bwd_kernel, dim3(nbp), dim3(256), 0, s, N, fl, p->bg[0], p->bg[1], p->bg[2], p->min_val, mask_img,
                        omap, targets, out, grad_out, d_mask_img, d_omap);
   }
-  if (d_endpoints) {
-    if (hgs_zero_async(s, d_endpoints, (size_t)p->n_endpoints * 3 * sizeof(float))) return 1;
+  if (d_endpoints) {   // (cleared by the SSIM kernel above)
     if (nbm > 0 && hgs_launch_smooth_bwd(s, p->n_smooth, endpoints, smooth_pairs, p->cos_threshold, p->eps,
                                          out + HGS_HEAD_G_SMOOTH, out + HGS_HEAD_SMOOTH_COUNT, grad_out, d_endpoints)) return 1;
   }

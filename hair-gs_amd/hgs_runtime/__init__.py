@@ -55,8 +55,8 @@ SIGNATURES = {
     "hgs_hair_params_forward": (ci, [vp, ci, vp, vp, vp, cf, vp, vp, vp, vp, vp, vp, vp, vp]),
     "hgs_hair_params_backward": (ci, [vp, ci, ci, vp, vp, vp, cf, vp, vp, vp, vp, vp, vp, vp, vp, ci, vp, vp, vp, vp]),
     "hgs_loss_head_scratch_floats": (sz, [vp]),
-    "hgs_loss_head_forward": (ci, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
-    "hgs_loss_head_backward": (ci, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
+    "hgs_loss_head_forward": (ci, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
+    "hgs_loss_head_backward": (ci, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, vp, vp, vp, vp]),
     "hgs_densify_stats": (ci, [vp, ci, vp, vp, ci, vp, vp, vp]),
     "hgs_debug_set_wg_trace": (ci, [vp, vp]),
     "hgs_prof_enable": (ci, [ci]),
@@ -81,7 +81,7 @@ class HgsError(RuntimeError):
 class ViewTargets(C.Structure):
     """include/hgs.h HgsViewTargets (184 bytes)."""
     _fields_ = [("image", vp), ("float_mask", vp), ("orientation", vp), ("confidence", vp), ("mask", vp),
-                ("viewmatrix", cf * 16), ("projmatrix", cf * 16), ("campos", cf * 3), ("pad", cf)]
+                ("viewmatrix", cf * 16), ("projmatrix", cf * 16), ("campos", cf * 3), ("mask_count", cf)]
 
 
 class HeadParams(C.Structure):

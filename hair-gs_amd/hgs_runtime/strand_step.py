@@ -60,6 +60,7 @@ class ViewTable:
                 m = m.view(torch.uint8) if m.dtype == torch.bool else m.to(torch.uint8)
                 keep.append(m)
                 r.mask = m.data_ptr()
+                r.mask_count = float(m.sum().item())
             for k, v in enumerate(c.world_view_transform.detach().float().cpu().reshape(-1).tolist()):
                 r.viewmatrix[k] = v
             for k, v in enumerate(c.full_proj_transform.detach().float().cpu().reshape(-1).tolist()):
@@ -135,10 +136,14 @@ class _StrandIteration(torch.autograd.Function):
         hp.n_endpoints = E
         scratch = torch.empty((L.hgs_loss_head_scratch_floats(C.byref(hp)),), **f32)
         out = torch.empty((rt.HEAD_NOUT,), **f32)
+        # gradient planes of the per-pixel terms for an upstream gradient of 1, written by the forward's own pass over
+        # the pixels (possible when the mask count is a per-view constant, i.e. the views carry masks)
+        d_extra = torch.empty((4, vt.H, vt.W), **f32) if (step.one_pass_pixels and vt.has_mask) else None
         with torch.cuda.device(dev):
             rt.check(L.hgs_loss_head_forward(stream, C.byref(hp), planes[0:3].data_ptr(), planes[3].data_ptr(),
                                              planes[4:7].data_ptr(), vt.slot.data_ptr(), rt.ptr(endpoints), rt.ptr(idx),
-                                             rt.ptr(scratch), rt.ptr(out)))
+                                             rt.ptr(scratch), rt.ptr(out), rt.ptr(d_extra)))
+        ctx.d_extra = d_extra
         ctx.step, ctx.R, ctx.f_rest_k = step, R, f_rest.shape[1]
         ctx.set_materialize_grads(False)   # no zero tensor for the (non-differentiable) terms output
         ctx.save_for_backward(endpoints, width, pairs, xyz, scale, quat, opacity, extra4, shs, planes, radii, geom, binning,
@@ -157,21 +162,29 @@ class _StrandIteration(torch.autograd.Function):
          out) = ctx.saved_tensors
         dev, P, E = endpoints.device, pairs.shape[0], endpoints.shape[0]
         f32 = dict(dtype=torch.float32, device=dev)
+        # FusedStrandStep.backward() hands in its own ones tensor: the upstream gradient is then known to be exactly 1 and
+        # the planes the forward wrote are final (the tensor's address, not its value, is what can be checked without a sync)
+        unit = ctx.d_extra is not None and go is not None and go.data_ptr() == step.one.data_ptr()
         go = step.one if go is None else go.contiguous().to(torch.float32)
-        dplanes = torch.empty_like(planes)
         d_ep = torch.empty((E, 3), **f32)
         stream = rt.current_stream()
         hp.n_endpoints = E
+        if unit:
+            d_image, d_extra = torch.empty((3, vt.H, vt.W), **f32), ctx.d_extra
+        else:
+            dplanes = torch.empty_like(planes)
+            d_image, d_extra = dplanes[0:3], dplanes[3:7]
         with torch.cuda.device(dev):
             rt.check(L.hgs_loss_head_backward(stream, C.byref(hp), planes[0:3].data_ptr(), planes[3].data_ptr(),
                                               planes[4:7].data_ptr(), vt.slot.data_ptr(), rt.ptr(endpoints),
                                               rt.ptr(step.smooth_pairs), rt.ptr(scratch), rt.ptr(out), rt.ptr(go),
-                                              dplanes[0:3].data_ptr(), dplanes[3].data_ptr(), dplanes[4:7].data_ptr(),
-                                              rt.ptr(d_ep)))
+                                              1 if unit else 0, d_image.data_ptr(), d_extra[0].data_ptr(),
+                                              d_extra[1:4].data_ptr(), rt.ptr(d_ep)))
+        grad_planes = [d_image[k] for k in range(3)] + [d_extra[k] for k in range(4)]
         empty = step.empty
         (g_means2D, _gc, g_ex, g_opac, g_means3D, _gcov, g_sh, g_scales, g_rot) = raster.rasterize_gaussians_multi_backward(
             step.bg7, xyz, radii, empty, scale, quat, 1.0, empty, vt.viewmatrix, vt.projmatrix, vt.tanfovx, vt.tanfovy,
-            [dplanes[k] for k in range(7)], shs, g.active_sh_degree, vt.campos, geom, ctx.R, binning, img, False)
+            grad_planes, shs, g.active_sh_degree, vt.campos, geom, ctx.R, binning, img, False)
         d_w, d_o, d_m = torch.empty((P, 1), **f32), torch.empty((P, 1), **f32), torch.empty((P, 1), **f32)
         with torch.cuda.device(dev):
             rt.check(L.hgs_hair_params_backward(stream, P, E, rt.ptr(endpoints), rt.ptr(pairs), rt.ptr(width),
@@ -196,6 +209,7 @@ class FusedStrandStep:
         self.bg7 = torch.cat([bg.to(dev, torch.float32), torch.zeros(4, device=dev)]).contiguous()
         self.empty = torch.empty(0, device=dev)
         self.one = torch.ones((), dtype=torch.float32, device=dev)   # d loss / d loss, passed to backward(): no fill launch
+        self.one_pass_pixels = True    # per-pixel loss terms: value and gradient in one pass over the pixels
         self.last = {}
         self.refresh()
 

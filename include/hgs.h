@@ -196,7 +196,8 @@ typedef struct HgsViewTargets {
   float viewmatrix[16];
   float projmatrix[16];
   float campos[3];
-  float pad;
+  float mask_count;             /* number of set pixels of `mask` (0: unknown / no mask); lets the orientation term's
+                                   gradient be formed in the forward pass */
 } HgsViewTargets;
 size_t hgs_view_targets_bytes(void);   /* sizeof(HgsViewTargets), for bindings that mirror the struct */
 size_t hgs_head_params_bytes(void);    /* sizeof(HgsHeadParams) */
@@ -224,8 +225,12 @@ int hgs_hair_params_backward(void* stream, int P, int E, const float* endpoints,
  *           + l_smooth SMOOTH(endpoints),  terms with weight 0 (or a NULL target) skipped.
  *   forward: 4 launches (SSIM/L1 map, BCE + orientation per pixel, smoothness per segment pair, one-block reduction);
  *   out[HGS_HEAD_*] device floats.  scratch: hgs_loss_head_scratch_floats() floats, kept for the backward.
- *   backward: d_image [3,H,W], d_mask_img [H,W], d_omap [3,H,W] fully written; d_endpoints [E,3] zeroed, then the
- *   smoothness gradient scattered into it; grad_out = device scalar dL/dtotal. */
+ *   d_extra_unit ([4,H,W]: mask plane, then the 3 orientation planes; may be NULL): if given, the per-pixel pass also
+ *   writes dL/d(mask_img) and dL/d(omap) FOR grad_out = 1 (requires targets->mask_count > 0 when the orientation term
+ *   is on, since that gradient is normalised by the mask count); a caller whose upstream gradient is exactly 1 then
+ *   passes skip_pixel_pass = 1 to the backward and uses those planes as they are.
+ *   backward: d_image [3,H,W] fully written; d_mask_img [H,W], d_omap [3,H,W] fully written unless skip_pixel_pass;
+ *   d_endpoints [E,3] zeroed, then the smoothness gradient scattered into it; grad_out = device scalar dL/dtotal. */
 typedef struct HgsHeadParams {
   int H, W;
   float lambda_dssim, lambda_mask, lambda_orientation, lambda_smooth;
@@ -242,12 +247,12 @@ enum { HGS_HEAD_TOTAL = 0, HGS_HEAD_L1, HGS_HEAD_DSSIM, HGS_HEAD_MASK, HGS_HEAD_
 size_t hgs_loss_head_scratch_floats(const HgsHeadParams* p);
 int hgs_loss_head_forward(void* stream, const HgsHeadParams* p, const float* image, const float* mask_img,
                           const float* omap, const HgsViewTargets* targets, const float* endpoints,
-                          const long long* smooth_pairs, float* scratch, float* out);
+                          const long long* smooth_pairs, float* scratch, float* out, float* d_extra_unit);
 int hgs_loss_head_backward(void* stream, const HgsHeadParams* p, const float* image, const float* mask_img,
                            const float* omap, const HgsViewTargets* targets, const float* endpoints,
                            const long long* smooth_pairs, const float* scratch, const float* out,
-                           const float* grad_out, float* d_image, float* d_mask_img, float* d_omap,
-                           float* d_endpoints);
+                           const float* grad_out, int skip_pixel_pass, float* d_image, float* d_mask_img,
+                           float* d_omap, float* d_endpoints);
 
 /* hgs_densify_stats <-> scene/hair_gaussian_model.py:1401-1408 / gaussian_model.py:675-682 add_densification_stats +
  *   train.py:170-171 max_radii2D update, for the Gaussians with radii > 0:

@@ -437,7 +437,10 @@ def test_fused_iteration_matches_op_by_op_path():
         model._derived = None
         fused.views.select(fused.views.index[id(cam)])
         floss, _ = fused.loss()
-        floss.backward()
+        if ci == 2:
+            floss.backward()               # generic upstream gradient: the per-pixel terms' backward kernel runs
+        else:
+            fused.backward(floss)          # known unit gradient: the planes written by the forward pass are used
         fused.update_densification_stats()
         fterms = {k: float(v) for k, v in fused.terms().items()}
         assert abs(float(floss) - ref["loss"]) <= 2e-5 * abs(ref["loss"]), (float(floss), ref["loss"])
