@@ -117,6 +117,19 @@ class GaussianModel:
             self.active_sh_degree += 1
 
     # ---- initialisation from a point cloud (reference :163-208) ----
+    # ---- on-disk format (reference :268-412), scene/ply_io.py ----
+    def construct_list_of_attributes(self):
+        from scene.ply_io import gaussian_attributes
+        return gaussian_attributes(self)
+
+    def save_ply(self, path):
+        from scene.ply_io import save_gaussian_ply
+        save_gaussian_ply(self, path)
+
+    def load_ply(self, path):
+        from scene.ply_io import load_gaussian_ply
+        load_gaussian_ply(self, path)
+
     def create_from_pcd(self, pcd: BasicPointCloud):
         dev = self.device
         pts = torch.tensor(np.asarray(pcd.points)).float().to(dev)

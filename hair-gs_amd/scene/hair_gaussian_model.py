@@ -136,6 +136,19 @@ class HairGaussianModel(HairTopologyMixin, GaussianModel):
     def _num_primitives(self):
         return self.endpoint_pairs.shape[0]
 
+    # ---- on-disk format (reference :292-466), scene/ply_io.py ----
+    def construct_list_of_attributes(self):
+        from scene.ply_io import hair_attributes
+        return hair_attributes(self)
+
+    def save_ply(self, path):
+        from scene.ply_io import save_hair_ply
+        save_hair_ply(self, path)
+
+    def load_ply(self, path):
+        from scene.ply_io import load_hair_ply
+        load_hair_ply(self, path)
+
     def create_from_pcd(self, pcd):
         raise NotImplementedError("This method is only intended for Gaussian Model")
 
