@@ -1,0 +1,96 @@
+"""Scene: a COLMAP capture + the model being optimised (reference scene/__init__.py:30-134).
+ * cameras from <source_path>/sparse/0 (+ images / masks / orientations), extent = nerf_normalization radius;
+ * model = Gaussian cloud initialised from the sparse points, or the newest <model_path>/point_cloud/iteration_N/
+   point_cloud.ply (a one-element file is a Gaussian cloud, a five-element file a strand model);
+ * save(iteration) writes that file.  Evaluation ground truth / head reconstructions (npz side files) are not handled."""
+import json
+import os
+import random
+
+import numpy as np
+import torch
+
+from data.dataset_readers import readColmapSceneInfo
+from scene.cameras import Camera
+from scene.gaussian_model import GaussianModel
+from scene.hair_gaussian_model import HairGaussianModel
+from utils.ply import read_ply
+
+
+def search_for_max_iteration(folder):
+    return max(int(name.split("_")[-1]) for name in os.listdir(folder))
+
+
+def camera_from_info(uid, info, resolution=-1, data_device="cuda"):
+    """CameraInfo -> Camera (reference utils/camera.py loadCam): image to [3,H,W] in 0..1, optional alpha as a mask
+    multiplier, integer downscale factors through PIL; resolution -1 / 1 keeps the native size."""
+    img = info.image
+    w, h = img.size
+    scale = 1 if resolution in (-1, 1) else int(resolution)
+    if scale != 1:
+        img = img.resize((round(w / scale), round(h / scale)))
+    arr = torch.from_numpy(np.asarray(img, dtype=np.float32) / 255.0)
+    arr = arr[..., None] if arr.ndim == 2 else arr
+    arr = arr.permute(2, 0, 1)
+    rgb, alpha = arr[:3], (arr[3:4] if arr.shape[0] == 4 else None)
+
+    def plane(a, dtype):
+        if a is None:
+            return None
+        t = torch.from_numpy(np.ascontiguousarray(a))
+        if scale != 1:
+            t = torch.nn.functional.interpolate(t[None, None].float(), size=rgb.shape[1:], mode="nearest")[0, 0]
+        return t.to(dtype)
+    return Camera(colmap_id=info.uid, R=info.R, T=info.T, FoVx=info.FovX, FoVy=info.FovY, image=rgb, gt_alpha_mask=alpha,
+                  image_name=info.image_name, uid=uid, mask=plane(info.mask, torch.bool),
+                  orientation_field=plane(info.orientation_field, torch.float32),
+                  orientation_confidence=plane(info.orientation_confidence, torch.float32), data_device=data_device)
+
+
+def camera_to_json(uid, info):
+    w2c = np.eye(4)
+    w2c[:3, :3], w2c[:3, 3] = info.R.transpose(), info.T
+    c2w = np.linalg.inv(w2c)
+    from utils.graphics import fov2focal
+    return {"id": uid, "img_name": info.image_name, "width": info.width, "height": info.height,
+            "position": c2w[:3, 3].tolist(), "rotation": [r.tolist() for r in c2w[:3, :3]],
+            "fy": fov2focal(info.FovY, info.height), "fx": fov2focal(info.FovX, info.width)}
+
+
+class Scene:
+    def __init__(self, args, shuffle=True, resolution_scales=(1.0,)):
+        self.model_path = args.model_path
+        self.loaded_iter = None
+        info = readColmapSceneInfo(args.source_path, getattr(args, "images", None))
+        os.makedirs(self.model_path, exist_ok=True)
+        pc_dir = os.path.join(self.model_path, "point_cloud")
+        if os.path.isdir(pc_dir) and os.listdir(pc_dir):
+            self.loaded_iter = search_for_max_iteration(pc_dir)
+        else:   # first run: keep the input cloud and the camera list next to the outputs, like the reference
+            with open(info.ply_path, "rb") as src, open(os.path.join(self.model_path, "input.ply"), "wb") as dst:
+                dst.write(src.read())
+            with open(os.path.join(self.model_path, "cameras.json"), "w") as fh:
+                json.dump([camera_to_json(i, c) for i, c in enumerate(info.cameras)], fh)
+        cams = list(info.cameras)
+        if shuffle:
+            random.shuffle(cams)
+        self.cameras_extent = info.nerf_normalization["radius"]
+        dev = getattr(args, "data_device", "cuda")
+        self.cameras = {s: [camera_from_info(i, c, getattr(args, "resolution", -1), dev) for i, c in enumerate(cams)]
+                        for s in resolution_scales}
+        if self.loaded_iter is None:
+            self.gaussians = GaussianModel(args.sh_degree, self.cameras_extent, device=dev)
+            self.gaussians.create_from_pcd(info.point_cloud)
+            self.loaded_iter = 0
+        else:
+            path = os.path.join(pc_dir, f"iteration_{self.loaded_iter}", "point_cloud.ply")
+            cls = GaussianModel if len(read_ply(path)) == 1 else HairGaussianModel
+            self.gaussians = cls(args.sh_degree, self.cameras_extent, device=dev)
+            self.gaussians.load_ply(path)
+        self.gt = None
+
+    def save(self, iteration):
+        self.gaussians.save_ply(os.path.join(self.model_path, "point_cloud", f"iteration_{iteration}", "point_cloud.ply"))
+
+    def getCameras(self, scale=1.0):
+        return self.cameras[scale]

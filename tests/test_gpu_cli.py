@@ -1,0 +1,74 @@
+"""End-to-end plumbing around the hot path on the GPU: COLMAP capture -> Scene -> Stage-I steps ->
+PLY -> render.py; strand model PLY -> Scene resume -> render.py orientation / mask outputs."""
+import os
+import sys
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch
+from PIL import Image as PILImage
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+
+
+def _args(src, model, **kw):
+    return SimpleNamespace(source_path=str(src), model_path=str(model), images="images", sh_degree=0, resolution=-1,
+                           data_device="cuda", eval=False, **kw)
+
+
+def test_scene_train_save_resume_render(tmp_path):
+    from tests.test_dataset_io_cpu import _write_capture
+    from arguments import OptimizationParams
+    from scene import Scene
+    from scene.gaussian_model import GaussianModel
+    from train import training_step
+    import render as render_cli
+    src, model = tmp_path / "capture", tmp_path / "out"
+    _write_capture(src, n_views=3, W=64, H=48)
+    scene = Scene(_args(src, model), shuffle=False)
+    assert isinstance(scene.gaussians, GaussianModel) and scene.loaded_iter == 0
+    assert os.path.exists(model / "input.ply") and os.path.exists(model / "cameras.json")
+    cams = scene.getCameras()
+    assert cams[0].original_image.shape == (3, 48, 64) and cams[0].mask.dtype == torch.bool
+    opt = OptimizationParams()
+    opt.enable_topology = False
+    scene.gaussians.training_setup(opt)
+    bg = torch.zeros(3, device="cuda")
+    for it in range(1, 4):
+        loss, _, _ = training_step(scene.gaussians, cams[it % 3], opt, bg, it, extent=scene.cameras_extent)
+    assert torch.isfinite(loss)
+    scene.save(3)
+    before = scene.gaussians.get_xyz.detach().clone()
+    scene2 = Scene(_args(src, model), shuffle=False)
+    assert scene2.loaded_iter == 3 and torch.equal(scene2.gaussians.get_xyz.detach(), before)
+    render_cli.main(["-s", str(src), "-m", str(model), "--type", "0", "--quiet"])
+    out = model / "render" / "train" / "iteration_3" / "renders" / "rgb"
+    files = sorted(os.listdir(out))
+    assert files == ["00000.png", "00001.png", "00002.png"]
+    assert np.asarray(PILImage.open(out / files[0])).shape == (48, 64, 3)
+    assert sorted(os.listdir(model / "render" / "train" / "iteration_3" / "gt" / "rgb")) == files
+
+
+def test_strand_model_ply_resume_and_render_types(tmp_path):
+    from tests.test_dataset_io_cpu import _write_capture
+    from scene import Scene
+    from scene.hair_gaussian_model import HairGaussianModel
+    import render as render_cli
+    src, model = tmp_path / "capture", tmp_path / "out"
+    _write_capture(src, n_views=2, W=64, H=48)
+    rng = np.random.default_rng(0)
+    pts = np.cumsum(rng.normal(size=(12, 10, 3)) * 0.02, axis=1).astype(np.float32) + rng.normal(size=(12, 1, 3)).astype(np.float32) * 0.2
+    hair = HairGaussianModel.from_strands(pts, sh_degree=0, device="cuda", ref_strand_root=pts[:, 0])
+    os.makedirs(model / "point_cloud" / "iteration_7")
+    hair.save_ply(str(model / "point_cloud" / "iteration_7" / "point_cloud.ply"))
+    scene = Scene(_args(src, model), shuffle=False)
+    assert isinstance(scene.gaussians, HairGaussianModel) and scene.loaded_iter == 7
+    assert torch.allclose(scene.gaussians.get_xyz, hair.get_xyz)
+    for kind in ("2", "3", "4"):
+        render_cli.main(["-s", str(src), "-m", str(model), "--type", kind, "--quiet"])
+    base = model / "render" / "train" / "iteration_7" / "renders"
+    assert sorted(os.listdir(base)) == ["mask_foreground", "mask_other", "orientation_map"]
+    assert np.asarray(PILImage.open(base / "orientation_map" / "00000.png")).shape == (48, 64, 3)
+    assert np.asarray(PILImage.open(base / "mask_foreground" / "00000.png")).shape == (48, 64)
