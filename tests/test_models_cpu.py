@@ -267,3 +267,21 @@ def test_merge_collapsed_segment_fuses_its_endpoints():
     _chain_invariants(m)
     m.compute_strands_info()
     assert sorted(s.shape[0] for s in m.strands_info.list_strands) == [5, 6]
+
+
+def test_merge_driver_rounds_until_nothing_left():
+    """merge.py's loop (reference merge.py:123-190): three collinear strands 1 mm apart end up as one after two rounds."""
+    import merge as merge_cli
+    from scene.hair_gaussian_model import HairGaussianModel
+    x = np.linspace(0, 0.02, 6)
+    strands = [np.stack([x + k * 0.021, np.zeros(6), np.zeros(6)], 1) for k in range(3)]
+    m = HairGaussianModel.from_strands(np.stack(strands).astype(np.float32), device="cpu",
+                                       ref_strand_root=np.array([[0, 0, 0]], np.float32))
+    m.training_setup(OptimizationParams())
+    m.compute_strands_info()
+    log = []
+    rounds = merge_cli.merge_rounds(m, 10, log=log.append)
+    assert 1 <= rounds <= 2 and len(log) == rounds
+    assert len(m.strands_info.list_strands) == 1 and m.strands_info.list_strands[0].shape[0] == 15
+    assert merge_cli.merge_rounds(m, 10, log=log.append) == 0      # nothing left to merge
+    _chain_invariants(m)
