@@ -238,3 +238,55 @@ int hgs_launch_dist2(hipStream_t st, int P, const float* points, float* out, voi
   HGS_CHECK_LAUNCH();
   return 0;
 }
+
+// ---- fixed-radius pair search over strand ends (hgs_radius_pairs) ------------------------------------------------------
+namespace {
+__global__ __launch_bounds__(256) void radius_pairs_kernel(int N, const float* __restrict__ pos, const float* __restrict__ dir,
+                                                           float r2, float min_cos, int bidirectional, int capacity,
+                                                           int* __restrict__ pairs, float* __restrict__ dist,
+                                                           int* __restrict__ count) {
+  __shared__ float sp[256][3], sd[256][3];
+  const int a = blockIdx.x * 256 + threadIdx.x;
+  float ax = 0.f, ay = 0.f, az = 0.f, ux = 0.f, uy = 0.f, uz = 0.f;
+  if (a < N) { ax = pos[3 * a]; ay = pos[3 * a + 1]; az = pos[3 * a + 2]; ux = dir[3 * a]; uy = dir[3 * a + 1]; uz = dir[3 * a + 2]; }
+  // only tiles at or after this block's own: every unordered pair is tested once, by the block of its smaller index
+  for (int t0 = blockIdx.x * 256; t0 < N; t0 += 256) {
+    const int j = t0 + threadIdx.x;
+    __syncthreads();
+    if (j < N) {
+#pragma unroll
+      for (int c = 0; c < 3; c++) { sp[threadIdx.x][c] = pos[3 * j + c]; sd[threadIdx.x][c] = dir[3 * j + c]; }
+    }
+    __syncthreads();
+    const int nb = min(256, N - t0);
+    if (a < N) {
+      for (int k = 0; k < nb; k++) {                       // broadcast LDS reads
+        const int b = t0 + k;
+        if (b <= a) continue;
+        const float dx = sp[k][0] - ax, dy = sp[k][1] - ay, dz = sp[k][2] - az;
+        const float d2 = dx * dx + dy * dy + dz * dz;
+        if (d2 > r2) continue;
+        float dot = -(ux * sd[k][0] + uy * sd[k][1] + uz * sd[k][2]);
+        if (bidirectional) dot = fabsf(dot);
+        if (!(dot >= min_cos)) continue;
+        const int slot = atomicAdd(count, 1);
+        if (slot < capacity) { pairs[2 * slot] = a; pairs[2 * slot + 1] = b; dist[slot] = sqrtf(d2); }
+      }
+    }
+  }
+}
+}  // namespace
+
+extern "C" int hgs_radius_pairs(void* stream, int N, const float* pos, const float* dir, float radius, float min_cos,
+                                int bidirectional, int capacity, int* pairs, float* dist, int* count) {
+  if (N <= 1) return 0;
+  if (!pos || !dir || !count || capacity < 0 || (capacity > 0 && (!pairs || !dist))) { hgs_set_error("hgs_radius_pairs: bad arguments"); return 1; }
+  hipStream_t s = (hipStream_t)stream;
+  {
+    HgsProfScope _prof(s, HGS_K_KNN);
+    hipLaunchKernelGGL(radius_pairs_kernel, dim3((N + 255) / 256), dim3(256), 0, s, N, pos, dir, radius * radius, min_cos,
+                       bidirectional, capacity, pairs, dist, count);
+  }
+  HGS_CHECK_LAUNCH();
+  return 0;
+}

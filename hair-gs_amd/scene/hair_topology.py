@@ -188,17 +188,27 @@ class HairTopologyMixin:
         dirs_t = dirs_t / torch.norm(dirs_t, dim=1, keepdim=True)
         pos, dirs, ends_np = pos_t.cpu().numpy(), dirs_t.cpu().numpy(), ends.cpu().numpy()
         partner = self.strands_info.strand_endpoint_id_to_complementary  # other end of the same strand, per id
-        pairs = cKDTree(pos).query_pairs(r=float(self.merge_dist_th), output_type="ndarray")
-        if pairs.shape[0] == 0:
-            return empty
-        a, b = pairs[:, 0], pairs[:, 1]
-        ok = partner[ends_np[a]] != ends_np[b]
-        dot = -(dirs[a] * dirs[b]).sum(1)                     # directions must be opposite
-        if self.training_args.bidirectional_merge:
-            dot = np.abs(dot)
-        ok &= dot >= dir_th
+        if pos_t.is_cuda:
+            # candidate search on the GPU (hgs_radius_pairs: distance + direction test, brute force over the strand ends)
+            a, b = self._radius_pairs_gpu(pos_t, dirs_t, float(self.merge_dist_th), float(dir_th),
+                                          bool(self.training_args.bidirectional_merge))
+            ok = partner[ends_np[a]] != ends_np[b]
+        else:
+            pairs = cKDTree(pos).query_pairs(r=float(self.merge_dist_th), output_type="ndarray")
+            if pairs.shape[0] == 0:
+                return empty
+            a, b = pairs[:, 0], pairs[:, 1]
+            ok = partner[ends_np[a]] != ends_np[b]
+            dot = -(dirs[a] * dirs[b]).sum(1)                     # directions must be opposite
+            if self.training_args.bidirectional_merge:
+                dot = np.abs(dot)
+            ok &= dot >= dir_th
         a, b = a[ok], b[ok]
+        if a.shape[0] == 0:
+            return empty
         dist = np.linalg.norm(pos[a] - pos[b], axis=1)
+        order = np.lexsort((b, a, dist))          # deterministic whatever order the candidates were found in
+        a, b, dist = a[order], b[order], dist[order]
         if max_num_nn > 0:  # cap candidates per point, nearest first
             order = np.argsort(dist, kind="stable")
             a, b, dist = a[order], b[order], dist[order]
@@ -231,6 +241,27 @@ class HairTopologyMixin:
         if not out:
             return empty
         return torch.as_tensor(np.asarray(out, np.int64), device=self.device)
+
+    @staticmethod
+    def _radius_pairs_gpu(pos, dirs, radius, min_cos, bidirectional):
+        """(a, b) index arrays (a < b) of the strand ends within `radius` whose directions oppose within the angle."""
+        import hgs_runtime as rt
+        pos = rt.require_gpu_tensor(pos, "positions", torch.float32)
+        dirs = rt.require_gpu_tensor(dirs, "directions", torch.float32)
+        n, dev = pos.shape[0], pos.device
+        cap = max(4 * n, 1024)
+        while True:
+            pairs = torch.empty((cap, 2), dtype=torch.int32, device=dev)
+            dist = torch.empty((cap,), dtype=torch.float32, device=dev)
+            count = torch.zeros(1, dtype=torch.int32, device=dev)
+            with torch.cuda.device(dev):
+                rt.check(rt.lib().hgs_radius_pairs(rt.current_stream(), n, rt.ptr(pos), rt.ptr(dirs), float(radius), float(min_cos),
+                                                   int(bidirectional), cap, rt.ptr(pairs), rt.ptr(dist), rt.ptr(count)))
+            found = int(count.item())
+            if found <= cap:
+                p = pairs[:found].cpu().numpy().astype(np.int64)
+                return p[:, 0], p[:, 1]
+            cap = found      # dense cluster of strand ends: run again with room for every pair
 
     def merge_endpoint_pairs(self, endpoint_pair_index):
         """Fuse each pair of strand ends into ONE new endpoint at their midpoint: the two end segments are re-created

@@ -272,6 +272,16 @@ int hgs_prof_enable(int on);
 int hgs_prof_collect(double* total_ms, long long* launches);
 const char* hgs_prof_kernel_name(int kernel_id);
 
+/* hgs_radius_pairs <-> the candidate search of strand merging, scipy cKDTree(pos).query_pairs(r) + the direction test at
+ *   scene/hair_gaussian_model.py:1205-1290: all index pairs a < b of the N strand ends with
+ *   |pos_a - pos_b| <= radius and -(dir_a . dir_b) >= min_cos (|.| instead if bidirectional).  Brute force, one
+ *   256-point tile against all others through LDS: strand ends number in the thousands, where N^2/2 distance tests cost
+ *   tens of microseconds and no tree has to be built or kept consistent with the moving endpoints.
+ *   Appends (a, b) to pairs[capacity][2] and the distance to dist[capacity] in unspecified order; *count (device, must be
+ *   zero on entry) ends as the number of pairs FOUND, which may exceed capacity (the excess is dropped). */
+int hgs_radius_pairs(void* stream, int N, const float* pos, const float* dir, float radius, float min_cos,
+                     int bidirectional, int capacity, int* pairs, float* dist, int* count);
+
 /* Development aid (tools/wg_trace.py): when a buffer of 2*T uint64 is registered, blend_fwd / blend_bwd record the
  * start and end time (s_memrealtime, 100 MHz) of every tile's workgroup in it; NULL (the default) switches it off. */
 int hgs_debug_set_wg_trace(void* device_buf_fwd, void* device_buf_bwd);

@@ -29,3 +29,51 @@ def test_dist2_empty_and_errors():
     assert distCUDA2(torch.empty((0, 3), device="cuda")).shape == (0,)
     with pytest.raises(Exception):
         distCUDA2(torch.zeros((4, 3)))  # CPU tensor: no CPU path
+
+
+def test_radius_pairs_match_kdtree_query_pairs():
+    """hgs_radius_pairs (GPU candidate search of strand merging) against scipy cKDTree.query_pairs + direction test."""
+    import torch
+    from scipy.spatial import cKDTree
+    from scene.hair_topology import HairTopologyMixin
+    rng = np.random.default_rng(5)
+    for n, r in ((1, 0.1), (257, 0.08), (3000, 0.02)):
+        pos = rng.random((n, 3)).astype(np.float32)
+        d = rng.normal(size=(n, 3)).astype(np.float32)
+        d /= np.linalg.norm(d, axis=1, keepdims=True)
+        for bidir in (False, True):
+            a, b = HairTopologyMixin._radius_pairs_gpu(torch.from_numpy(pos).cuda(), torch.from_numpy(d).cuda(), r, 0.3, bidir) \
+                if n > 1 else (np.zeros(0, np.int64), np.zeros(0, np.int64))
+            ref = cKDTree(pos.astype(np.float64)).query_pairs(r=r, output_type="ndarray") if n > 1 else np.zeros((0, 2), np.int64)
+            dot = -(d[ref[:, 0]] * d[ref[:, 1]]).sum(1)
+            dot = np.abs(dot) if bidir else dot
+            ref = ref[dot >= 0.3]
+            got = set(zip(a.tolist(), b.tolist()))
+            want = set(zip(ref[:, 0].tolist(), ref[:, 1].tolist()))
+            # pairs whose distance / cosine sits within rounding of the thresholds may differ (fp32 vs fp64)
+            dist = lambda p: np.linalg.norm(pos[p[0]].astype(np.float64) - pos[p[1]])
+            edge = lambda p: abs(dist(p) - r) < 1e-6 or abs(abs(float(-(d[p[0]] * d[p[1]]).sum())) - 0.3) < 1e-5
+            assert all(edge(p) for p in got ^ want), (n, bidir, len(got ^ want))
+            assert len(got) > 0 or n < 100
+
+
+def test_merge_candidates_gpu_model_equals_cpu_model():
+    import torch
+    from arguments import OptimizationParams
+    from scene.hair_gaussian_model import HairGaussianModel
+    rng = np.random.default_rng(2)
+    x = np.linspace(0, 0.02, 6)
+    strands = []
+    for k in range(40):       # chains of 3 collinear strands 1 mm apart, scattered in space
+        o = rng.random(3) * 0.5
+        strands += [np.stack([x + j * 0.021, np.zeros(6), np.zeros(6)], 1) + o for j in range(3)]
+    pts = np.stack(strands).astype(np.float32)
+    roots = pts[::3, 0]
+    out = {}
+    for dev in ("cpu", "cuda"):
+        m = HairGaussianModel.from_strands(pts, device=dev, ref_strand_root=roots)
+        m.training_setup(OptimizationParams())
+        m.compute_strands_info()
+        out[dev] = m.compute_endpoint_pair_to_merge().cpu().numpy()
+    assert out["cpu"].shape[0] >= 40
+    assert sorted(map(tuple, np.sort(out["cpu"], 1).tolist())) == sorted(map(tuple, np.sort(out["cuda"], 1).tolist()))
