@@ -430,3 +430,43 @@ def training(gaussians, cameras, opt, iterations=None, extent=1.0, seed=0, log_e
             from diff_gaussian_rasterization import _C as raster
             raster.set_async(False)
     return ema
+
+
+def main(argv=None):
+    """Command-line driver (reference train.py:38-131, 256-265 without logger / viewer / evaluation):
+      python train.py -s <colmap scene> -m <model dir> [--iterations N] [--save_frequency K]
+    Resumes from the newest <model dir>/point_cloud/iteration_*/point_cloud.ply (Gaussian cloud = Stage I, strand model =
+    Stage III) or starts Stage I from the sparse COLMAP points; saves every save_frequency iterations and at the end."""
+    import os
+    import sys
+    from argparse import ArgumentParser
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from arguments import GeneralParams, ModelParams, OptimizationParams
+    from scene import Scene
+    from utils.general import safe_state
+    parser = ArgumentParser(description="Training script parameters")
+    mp, op, gp = ModelParams(parser), OptimizationParams(parser), GeneralParams(parser)
+    args = parser.parse_args(argv)
+    safe_state(args.quiet)
+    os.makedirs(args.model_path, exist_ok=True)
+    with open(os.path.join(args.model_path, "cfg_args"), "w") as fh:   # what render.py's get_combined_args reads back
+        fh.write(str(args))
+    scene = Scene(mp.extract(args))
+    opt = op.extract(args)
+    g = scene.gaussians
+    g.training_setup(opt)
+    cams = scene.getCameras()
+    it, total, every = scene.loaded_iter, scene.loaded_iter + opt.iterations, max(1, int(args.save_frequency))
+    while it < total:
+        n = min(every - it % every, total - it)
+        ema = training(g, cams, opt, iterations=n, extent=scene.cameras_extent, start_iteration=it,
+                       log_every=0 if args.quiet else max(1, n // 4))
+        it += n
+        scene.save(it)
+        if not args.quiet:
+            print(f"[it {it}] saved; loss(ema) {float(ema):.6f}")
+    return scene
+
+
+if __name__ == "__main__":
+    main()

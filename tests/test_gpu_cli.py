@@ -72,3 +72,15 @@ def test_strand_model_ply_resume_and_render_types(tmp_path):
     assert sorted(os.listdir(base)) == ["mask_foreground", "mask_other", "orientation_map"]
     assert np.asarray(PILImage.open(base / "orientation_map" / "00000.png")).shape == (48, 64, 3)
     assert np.asarray(PILImage.open(base / "mask_foreground" / "00000.png")).shape == (48, 64)
+
+
+def test_train_cli_stage_one_then_resume(tmp_path):
+    from tests.test_dataset_io_cpu import _write_capture
+    import train as train_cli
+    src, model = tmp_path / "capture", tmp_path / "out"
+    _write_capture(src, n_views=3, W=64, H=48)
+    scene = train_cli.main(["-s", str(src), "-m", str(model), "--iterations", "6", "--save_frequency", "4", "--quiet"])
+    assert sorted(os.listdir(model / "point_cloud")) == ["iteration_4", "iteration_6"]
+    assert os.path.exists(model / "cfg_args")
+    scene2 = train_cli.main(["-s", str(src), "-m", str(model), "--iterations", "2", "--quiet"])
+    assert scene2.loaded_iter == 6 and os.path.isdir(model / "point_cloud" / "iteration_8")
