@@ -109,6 +109,10 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise HgsError(f"{LIB_PATH} not found: run hgs_runtime.build() (hipcc --offload-arch=gfx950). "
                            "There is no CPU fallback.")
+        # torch first: its wheel carries its own libamdhip64; the process must end up with ONE HIP runtime, and it has to
+        # be the one that owns the tensors' memory.  Loading libhgs.so before torch binds it to /opt/rocm's copy, and a
+        # later kernel launch on torch's memory then fails with "no ROCm-capable device is detected".
+        import torch  # noqa: F401
         L = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)
