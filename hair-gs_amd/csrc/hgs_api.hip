@@ -310,6 +310,7 @@ int hgs_dist2(void* stream, int P, const float* points, float* out, void* scratc
 
 size_t hgs_view_targets_bytes(void) { return sizeof(HgsViewTargets); }
 size_t hgs_head_params_bytes(void) { return sizeof(HgsHeadParams); }
+size_t hgs_strand_fusion_bytes(void) { return sizeof(HgsStrandFusion); }
 
 int hgs_select_view(void* stream, const HgsViewTargets* table, int view, HgsViewTargets* slot, float lr, float* lr_dst) {
   if (!table || !slot || view < 0) { hgs_set_error("hgs_select_view: bad arguments"); return 1; }

@@ -644,18 +644,19 @@ size_t hgs_loss_head_scratch_floats(const HgsHeadParams* p) {
 
 int hgs_loss_head_forward(void* stream, const HgsHeadParams* p, const float* image, const float* mask_img,
                           const float* omap, const HgsViewTargets* targets, const float* endpoints,
-                          const long long* smooth_pairs, float* scratch, float* out, float* d_extra_unit) {
+                          const long long* smooth_pairs, float* scratch, float* out, float* d_extra_unit,
+                          const float* smooth_partials_ext) {
   if (!p || !image || !mask_img || !omap || !targets || !scratch || !out || p->H <= 0 || p->W <= 0) {
     hgs_set_error("hgs_loss_head_forward: bad arguments");
     return 1;
   }
   const int H = p->H, W = p->W, N = H * W;
   const int nbs = head_nb_ssim(p), nbp = head_nb_pix(p), nbm = head_nb_smooth(p);
-  if (nbm > 0 && (!endpoints || !smooth_pairs)) { hgs_set_error("hgs_loss_head_forward: smoothness term without endpoints"); return 1; }
+  if (nbm > 0 && !smooth_partials_ext && (!endpoints || !smooth_pairs)) { hgs_set_error("hgs_loss_head_forward: smoothness term without endpoints"); return 1; }
   float* dmaps = scratch;
   float* p_ssim = dmaps + 9 * (size_t)N;
   float* p_pix = p_ssim + 2 * (size_t)nbs;
-  float* p_smooth = p_pix + 3 * (size_t)nbp;
+  const float* p_smooth = smooth_partials_ext ? smooth_partials_ext : p_pix + 3 * (size_t)nbp;
   SsimWin win;
   for (int k = 0; k < 11; k++) win.w[k] = p->window[k];
   hipStream_t s = (hipStream_t)stream;
@@ -672,7 +673,8 @@ int hgs_loss_head_forward(void* stream, const HgsHeadParams* p, const float* ima
                        omap, targets, p_pix, fl.bce ? p->lambda_mask / (float)N : 0.f, fl.ori ? p->lambda_orientation : 0.f,
                        d_extra_unit);
   }
-  if (nbm > 0 && hgs_launch_smooth_fwd(s, p->n_smooth, endpoints, smooth_pairs, p->cos_threshold, p->eps, p_smooth)) return 1;
+  if (nbm > 0 && !smooth_partials_ext &&
+      hgs_launch_smooth_fwd(s, p->n_smooth, endpoints, smooth_pairs, p->cos_threshold, p->eps, p_pix + 3 * (size_t)nbp)) return 1;
   HeadReduce h;
   h.nb_ssim = nbs; h.nb_pix = nbp; h.nb_smooth = nbm;
   h.inv_chw = 1.f / (3.f * (float)N); h.inv_hw = 1.f / (float)N;
@@ -689,8 +691,9 @@ int hgs_loss_head_forward(void* stream, const HgsHeadParams* p, const float* ima
 int hgs_loss_head_backward(void* stream, const HgsHeadParams* p, const float* image, const float* mask_img,
                            const float* omap, const HgsViewTargets* targets, const float* endpoints,
                            const long long* smooth_pairs, const float* scratch, const float* out,
-                           const float* grad_out, int skip_pixel_pass, float* d_image, float* d_mask_img,
+                           const float* grad_out, int skip, float* d_image, float* d_mask_img,
                            float* d_omap, float* d_endpoints) {
+  const int skip_pixel_pass = skip & HGS_HEAD_SKIP_PIXELS;
   if (!p || !image || !mask_img || !omap || !targets || !scratch || !out || !grad_out || !d_image ||
       (!skip_pixel_pass && (!d_mask_img || !d_omap))) {
     hgs_set_error("hgs_loss_head_backward: bad arguments");
@@ -715,7 +718,7 @@ int hgs_loss_head_backward(void* stream, const HgsHeadParams* p, const float* im
     hipLaunchKernelGGL(pix_bwd_kernel, dim3(nbp), dim3(256), 0, s, N, fl, p->bg[0], p->bg[1], p->bg[2], p->min_val, mask_img,
                        omap, targets, out, grad_out, d_mask_img, d_omap);
   }
-  if (d_endpoints) {   // (cleared by the SSIM kernel above)
+  if (d_endpoints && !(skip & HGS_HEAD_SKIP_SMOOTH)) {   // (cleared by the SSIM kernel above)
     if (nbm > 0 && hgs_launch_smooth_bwd(s, p->n_smooth, endpoints, smooth_pairs, p->cos_threshold, p->eps,
                                          out + HGS_HEAD_G_SMOOTH, out + HGS_HEAD_SMOOTH_COUNT, grad_out, d_endpoints)) return 1;
   }

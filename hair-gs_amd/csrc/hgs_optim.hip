@@ -8,6 +8,7 @@
 // (2) replaces the gather / normalise / acos chain and, above all, its index_put backward (sort-based, ~0.25 ms per
 //     iteration) of loss/losses.py:175-221 angle_smoothness_loss.
 #include "hgs_common.h"
+#include "hgs_smooth.h"
 
 namespace {
 
@@ -48,45 +49,11 @@ __global__ void adam_step_kernel(AdamTensors t) {
   if (threadIdx.x < t.n) *t.step[threadIdx.x] += 1.0f;
 }
 
-// ---- smoothness ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ float block_sum256(float v, float* red4) {
-#pragma unroll
-  for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
-  __syncthreads();
-  if ((threadIdx.x & 63) == 0) red4[threadIdx.x >> 6] = v;
-  __syncthreads();
-  return (red4[0] + red4[1]) + (red4[2] + red4[3]);
-}
-
-struct SmoothEval { float d0[3], d1[3], l0, l1, dot, ang; bool sel; };
-__device__ __forceinline__ SmoothEval smooth_eval(const float* __restrict__ ep, const long long* __restrict__ q,
-                                                   float cos_th, float eps) {
-  SmoothEval s;
-  float a[3], b[3];
-#pragma unroll
-  for (int c = 0; c < 3; c++) { a[c] = ep[3 * q[1] + c] - ep[3 * q[0] + c]; b[c] = ep[3 * q[3] + c] - ep[3 * q[2] + c]; }
-  s.l0 = sqrtf(a[0] * a[0] + a[1] * a[1] + a[2] * a[2]);
-  s.l1 = sqrtf(b[0] * b[0] + b[1] * b[1] + b[2] * b[2]);
-#pragma unroll
-  for (int c = 0; c < 3; c++) { s.d0[c] = a[c] / s.l0; s.d1[c] = b[c] / s.l1; }
-  s.dot = s.d0[0] * s.d1[0] + s.d0[1] * s.d1[1] + s.d0[2] * s.d1[2];
-  s.sel = s.dot <= cos_th;                                      // losses.py:211-213
-  const float dc = fminf(fmaxf(s.dot, -1.f + eps), 1.f - eps);  // :216-218
-  s.ang = acosf(dc);
-  return s;
-}
-
+// ---- smoothness (device code in hgs_smooth.h) -------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void smooth_fwd_kernel(int N, const float* __restrict__ ep, const long long* __restrict__ idx,
                                                          float cos_th, float eps, float* __restrict__ partials) {
   __shared__ float red[4];
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  float s = 0.f, c = 0.f;
-  if (i < N) {
-    const SmoothEval e = smooth_eval(ep, idx + 4 * (size_t)i, cos_th, eps);
-    if (e.sel) { s = e.ang * e.ang; c = 1.f; }
-  }
-  const float bs = block_sum256(s, red), bc = block_sum256(c, red);
-  if (threadIdx.x == 0) { partials[2 * blockIdx.x] = bs; partials[2 * blockIdx.x + 1] = bc; }
+  hgs_smooth_fwd_block(blockIdx.x, N, ep, idx, cos_th, eps, partials, red);
 }
 
 __global__ __launch_bounds__(256) void smooth_bwd_kernel(int N, const float* __restrict__ ep, const long long* __restrict__ idx,
@@ -95,24 +62,7 @@ __global__ __launch_bounds__(256) void smooth_bwd_kernel(int N, const float* __r
                                                          float* __restrict__ d_ep) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= N) return;
-  const long long* q = idx + 4 * (size_t)i;
-  const SmoothEval e = smooth_eval(ep, q, cos_th, eps);
-  if (!e.sel) return;
-  if (!(e.dot > -1.f + eps && e.dot < 1.f - eps)) return;      // clamp saturated: zero gradient
-  const float cnt = fmaxf(*count, 1.f);
-  // d(ang^2)/d(dot) = 2 ang * (-1/sqrt(1-dot^2))
-  const float gdot = (*g_loss * (go ? *go : 1.f) / cnt) * 2.f * e.ang * (-1.f / sqrtf(1.f - e.dot * e.dot));
-  float g0[3], g1[3];                                           // gradients w.r.t. the two segment deltas
-#pragma unroll
-  for (int c = 0; c < 3; c++) {
-    g0[c] = gdot * (e.d1[c] - e.d0[c] * e.dot) / e.l0;          // (I - d0 d0^T) d1 / |a|
-    g1[c] = gdot * (e.d0[c] - e.d1[c] * e.dot) / e.l1;
-  }
-#pragma unroll
-  for (int c = 0; c < 3; c++) {
-    atomicAdd(&d_ep[3 * q[0] + c], -g0[c]); atomicAdd(&d_ep[3 * q[1] + c], g0[c]);
-    atomicAdd(&d_ep[3 * q[2] + c], -g1[c]); atomicAdd(&d_ep[3 * q[3] + c], g1[c]);
-  }
+  hgs_smooth_bwd_pair(i, ep, idx, cos_th, eps, *g_loss * (go ? *go : 1.f) / fmaxf(*count, 1.f), d_ep);
 }
 
 }  // namespace

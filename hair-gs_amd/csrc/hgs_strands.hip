@@ -13,6 +13,7 @@
 // Backward scatters into the shared endpoints with fp32 atomics (an endpoint of a strand has <= 2 segments:
 // two-term sums commute, so the result is order-independent for chains).
 #include "hgs_common.h"
+#include "hgs_smooth.h"
 
 namespace {
 
@@ -23,7 +24,13 @@ __global__ __launch_bounds__(256) void strand_fwd_kernel(int P, const float* __r
                                                          float* __restrict__ scale, float* __restrict__ quat,
                                                          float* __restrict__ dir, const float* __restrict__ opacity_raw,
                                                          const float* __restrict__ mask_raw, float* __restrict__ opacity,
-                                                         float* __restrict__ extra4) {
+                                                         float* __restrict__ extra4, HgsStrandFusion fu) {
+  const int nb_seg = (P + 255) / 256;
+  if ((int)blockIdx.x >= nb_seg) {   // extra workgroups: smoothness partial sums over the same endpoints
+    __shared__ float red[4];
+    hgs_smooth_fwd_block((int)blockIdx.x - nb_seg, fu.n_smooth, ep, fu.smooth_pairs, fu.cos_threshold, fu.eps, fu.smooth_partials, red);
+    return;
+  }
   const int k = blockIdx.x * 256 + threadIdx.x;
   if (k >= P) return;
   const long long i0 = pairs[2 * (size_t)k], i1 = pairs[2 * (size_t)k + 1];
@@ -62,9 +69,27 @@ __global__ __launch_bounds__(256) void strand_bwd_kernel(int P, const float* __r
                                                          float* __restrict__ d_ep, float* __restrict__ d_width,
                                                          const float* __restrict__ opacity, const float* __restrict__ extra4,
                                                          const float* __restrict__ g_opacity, const float* __restrict__ g_extra4,
-                                                         float* __restrict__ d_opacity_raw, float* __restrict__ d_mask_raw) {
+                                                         float* __restrict__ d_opacity_raw, float* __restrict__ d_mask_raw,
+                                                         HgsStrandFusion fu) {
+  const int nb_seg = (P + 255) / 256;
+  if ((int)blockIdx.x >= nb_seg) {   // extra workgroups: smoothness gradient scattered into the same d_ep
+    const int i = ((int)blockIdx.x - nb_seg) * 256 + threadIdx.x;
+    if (i < fu.n_smooth)
+      hgs_smooth_bwd_pair(i, ep, fu.smooth_pairs, fu.cos_threshold, fu.eps,
+                          fu.head_out[HGS_HEAD_G_SMOOTH] * fu.grad_out[0] / fmaxf(fu.head_out[HGS_HEAD_SMOOTH_COUNT], 1.f), d_ep);
+    return;
+  }
   const int k = blockIdx.x * 256 + threadIdx.x;
   if (k >= P) return;
+  if (fu.radii) {                    // densification statistics of this Gaussian (hgs_densify_stats)
+    const int r = fu.radii[k];
+    if (r > 0) {
+      fu.max_radii2D[k] = fmaxf(fu.max_radii2D[k], (float)r);
+      const float gx = fu.dmean2D[(size_t)k * fu.dmean2D_stride], gy = fu.dmean2D[(size_t)k * fu.dmean2D_stride + 1];
+      fu.grad_accum[k] += sqrtf(gx * gx + gy * gy);
+      fu.denom[k] += 1.f;
+    }
+  }
   float4 ge = make_float4(0.f, 0.f, 0.f, 0.f);
   if (g_extra4) ge = ((const float4*)g_extra4)[k];
   if (d_opacity_raw) { const float o = opacity[k]; d_opacity_raw[k] = g_opacity[k] * o * (1.f - o); }   // sigmoid'
@@ -120,7 +145,7 @@ int hgs_strand_geometry_forward(void* stream, int P, const float* endpoints, con
     HgsProfScope _prof(s, HGS_K_STRAND_FWD);
     hipLaunchKernelGGL(strand_fwd_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, endpoints, endpoint_pairs, width,
                        dist_to_scale_factor, xyz, scale, quat, dir, (const float*)nullptr, (const float*)nullptr,
-                       (float*)nullptr, (float*)nullptr);
+                       (float*)nullptr, (float*)nullptr, HgsStrandFusion{});
   }
   HGS_CHECK_LAUNCH();
   return 0;
@@ -137,7 +162,8 @@ int hgs_strand_geometry_backward(void* stream, int P, int E, const float* endpoi
     HgsProfScope _prof(s, HGS_K_STRAND_BWD);
     hipLaunchKernelGGL(strand_bwd_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, endpoints, endpoint_pairs, width,
                        dist_to_scale_factor, g_xyz, g_scale, g_quat, g_dir, d_endpoints, d_width, (const float*)nullptr,
-                       (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (float*)nullptr, (float*)nullptr);
+                       (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (float*)nullptr, (float*)nullptr,
+                       HgsStrandFusion{});
   }
   HGS_CHECK_LAUNCH();
   return 0;
@@ -146,8 +172,11 @@ int hgs_strand_geometry_backward(void* stream, int P, int E, const float* endpoi
 int hgs_hair_params_forward(void* stream, int P, const float* endpoints, const long long* endpoint_pairs,
                             const float* width, float dist_to_scale_factor, const float* opacity_raw,
                             const float* mask_raw, float* xyz, float* scale, float* quat, float* dir, float* opacity,
-                            float* extra4) {
+                            float* extra4, const HgsStrandFusion* fusion) {
   if (P == 0) return 0;
+  HgsStrandFusion fu = fusion ? *fusion : HgsStrandFusion{};
+  const bool smooth = fu.smooth_pairs && fu.n_smooth > 0 && fu.smooth_partials;
+  if (!smooth) fu.n_smooth = 0;
   if (!endpoints || !endpoint_pairs || !width || !opacity_raw || !mask_raw || !xyz || !scale || !quat || !opacity || !extra4) {
     hgs_set_error("hgs_hair_params_forward: null argument");
     return 1;
@@ -155,8 +184,9 @@ int hgs_hair_params_forward(void* stream, int P, const float* endpoints, const l
   hipStream_t s = (hipStream_t)stream;
   {
     HgsProfScope _prof(s, HGS_K_STRAND_FWD);
-    hipLaunchKernelGGL(strand_fwd_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, endpoints, endpoint_pairs, width,
-                       dist_to_scale_factor, xyz, scale, quat, dir, opacity_raw, mask_raw, opacity, extra4);
+    hipLaunchKernelGGL(strand_fwd_kernel, dim3((P + 255) / 256 + (fu.n_smooth + 255) / 256), dim3(256), 0, s, P, endpoints,
+                       endpoint_pairs, width, dist_to_scale_factor, xyz, scale, quat, dir, opacity_raw, mask_raw, opacity,
+                       extra4, fu);
   }
   HGS_CHECK_LAUNCH();
   return 0;
@@ -166,7 +196,15 @@ int hgs_hair_params_backward(void* stream, int P, int E, const float* endpoints,
                              const float* width, float dist_to_scale_factor, const float* opacity, const float* extra4,
                              const float* g_xyz, const float* g_scale, const float* g_quat, const float* g_dir,
                              const float* g_opacity, const float* g_extra4, int accumulate_endpoints,
-                             float* d_endpoints, float* d_width, float* d_opacity_raw, float* d_mask_raw) {
+                             float* d_endpoints, float* d_width, float* d_opacity_raw, float* d_mask_raw,
+                             const HgsStrandFusion* fusion) {
+  HgsStrandFusion fu = fusion ? *fusion : HgsStrandFusion{};
+  const bool smooth = fu.smooth_pairs && fu.n_smooth > 0 && fu.head_out && fu.grad_out;
+  if (!smooth) fu.n_smooth = 0;
+  if (fu.radii && (!fu.dmean2D || fu.dmean2D_stride < 2 || !fu.max_radii2D || !fu.grad_accum || !fu.denom)) {
+    hgs_set_error("hgs_hair_params_backward: incomplete statistics group in HgsStrandFusion");
+    return 1;
+  }
   if (!d_endpoints || !d_width || !d_opacity_raw || !d_mask_raw || !opacity || !extra4 || !g_opacity || !g_extra4) {
     hgs_set_error("hgs_hair_params_backward: null argument");
     return 1;
@@ -176,9 +214,9 @@ int hgs_hair_params_backward(void* stream, int P, int E, const float* endpoints,
   if (P == 0) return 0;
   {
     HgsProfScope _prof(s, HGS_K_STRAND_BWD);
-    hipLaunchKernelGGL(strand_bwd_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, endpoints, endpoint_pairs, width,
-                       dist_to_scale_factor, g_xyz, g_scale, g_quat, g_dir, d_endpoints, d_width, opacity, extra4,
-                       g_opacity, g_extra4, d_opacity_raw, d_mask_raw);
+    hipLaunchKernelGGL(strand_bwd_kernel, dim3((P + 255) / 256 + (fu.n_smooth + 255) / 256), dim3(256), 0, s, P, endpoints,
+                       endpoint_pairs, width, dist_to_scale_factor, g_xyz, g_scale, g_quat, g_dir, d_endpoints, d_width,
+                       opacity, extra4, g_opacity, g_extra4, d_opacity_raw, d_mask_raw, fu);
   }
   HGS_CHECK_LAUNCH();
   return 0;

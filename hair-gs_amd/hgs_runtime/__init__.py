@@ -51,11 +51,12 @@ SIGNATURES = {
     "hgs_strand_geometry_backward": (ci, [vp, ci, ci, vp, vp, vp, cf, vp, vp, vp, vp, vp, vp]),
     "hgs_view_targets_bytes": (sz, []),
     "hgs_head_params_bytes": (sz, []),
+    "hgs_strand_fusion_bytes": (sz, []),
     "hgs_select_view": (ci, [vp, vp, ci, vp, cf, vp]),
-    "hgs_hair_params_forward": (ci, [vp, ci, vp, vp, vp, cf, vp, vp, vp, vp, vp, vp, vp, vp]),
-    "hgs_hair_params_backward": (ci, [vp, ci, ci, vp, vp, vp, cf, vp, vp, vp, vp, vp, vp, vp, vp, ci, vp, vp, vp, vp]),
+    "hgs_hair_params_forward": (ci, [vp, ci, vp, vp, vp, cf, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
+    "hgs_hair_params_backward": (ci, [vp, ci, ci, vp, vp, vp, cf, vp, vp, vp, vp, vp, vp, vp, vp, ci, vp, vp, vp, vp, vp]),
     "hgs_loss_head_scratch_floats": (sz, [vp]),
-    "hgs_loss_head_forward": (ci, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
+    "hgs_loss_head_forward": (ci, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "hgs_loss_head_backward": (ci, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, vp, vp, vp, vp]),
     "hgs_densify_stats": (ci, [vp, ci, vp, vp, ci, vp, vp, vp]),
     "hgs_radius_pairs": (ci, [vp, ci, vp, vp, cf, cf, ci, ci, vp, vp, vp]),
@@ -92,6 +93,14 @@ class HeadParams(C.Structure):
                 ("cos_threshold", cf), ("eps", cf), ("n_endpoints", ci)]
 
 
+class StrandFusion(C.Structure):
+    """include/hgs.h HgsStrandFusion."""
+    _fields_ = [("smooth_pairs", vp), ("n_smooth", ci), ("cos_threshold", cf), ("eps", cf), ("smooth_partials", vp),
+                ("head_out", vp), ("grad_out", vp), ("radii", vp), ("dmean2D", vp), ("dmean2D_stride", ci),
+                ("max_radii2D", vp), ("grad_accum", vp), ("denom", vp)]
+
+
+HEAD_SKIP_PIXELS, HEAD_SKIP_SMOOTH = 1, 2
 HEAD_OUT = ["total", "l1", "dssim", "mask", "orientation", "smooth", "ori_count", "smooth_count", "g_ssim", "g_l1", "g_mask",
             "g_ori", "g_smooth"]
 HEAD_NOUT = 16

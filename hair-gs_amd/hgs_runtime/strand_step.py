@@ -122,17 +122,25 @@ class _StrandIteration(torch.autograd.Function):
         opacity, extra4 = torch.empty((P, 1), **f32), torch.empty((P, 4), **f32)
         factor = float(g.dist_to_scale_factor)
         stream = rt.current_stream()
+        idx = step.smooth_pairs
+        hp = step.head
+        # the smoothness term rides in extra workgroups of the parameter kernels (HgsStrandFusion)
+        fu = rt.StrandFusion()
+        smooth_partials = None
+        if idx is not None and hp.lambda_smooth > 0:
+            smooth_partials = torch.empty((2 * ((idx.shape[0] + 255) // 256),), **f32)
+            fu.smooth_pairs, fu.n_smooth = idx.data_ptr(), int(idx.shape[0])
+            fu.cos_threshold, fu.eps = hp.cos_threshold, hp.eps
+            fu.smooth_partials = smooth_partials.data_ptr()
         with torch.cuda.device(dev):
             rt.check(L.hgs_hair_params_forward(stream, P, rt.ptr(endpoints), rt.ptr(pairs), rt.ptr(width), factor,
                                                rt.ptr(opacity_raw), rt.ptr(mask_raw), rt.ptr(xyz), rt.ptr(scale), rt.ptr(quat),
-                                               None, rt.ptr(opacity), rt.ptr(extra4)))
+                                               None, rt.ptr(opacity), rt.ptr(extra4), C.byref(fu)))
         shs = f_dc if f_rest.numel() == 0 else torch.cat((f_dc, f_rest), dim=1)
         empty = step.empty
         R, planes, radii, geom, binning, img = raster.rasterize_gaussians_multi(
             step.bg7, xyz, empty, extra4, opacity, scale, quat, 1.0, empty, vt.viewmatrix, vt.projmatrix, vt.tanfovx,
             vt.tanfovy, vt.H, vt.W, shs, g.active_sh_degree, vt.campos, False, False)
-        idx = step.smooth_pairs
-        hp = step.head
         hp.n_endpoints = E
         scratch = torch.empty((L.hgs_loss_head_scratch_floats(C.byref(hp)),), **f32)
         out = torch.empty((rt.HEAD_NOUT,), **f32)
@@ -142,8 +150,9 @@ class _StrandIteration(torch.autograd.Function):
         with torch.cuda.device(dev):
             rt.check(L.hgs_loss_head_forward(stream, C.byref(hp), planes[0:3].data_ptr(), planes[3].data_ptr(),
                                              planes[4:7].data_ptr(), vt.slot.data_ptr(), rt.ptr(endpoints), rt.ptr(idx),
-                                             rt.ptr(scratch), rt.ptr(out), rt.ptr(d_extra)))
+                                             rt.ptr(scratch), rt.ptr(out), rt.ptr(d_extra), rt.ptr(smooth_partials)))
         ctx.d_extra = d_extra
+        ctx.fused_smooth = smooth_partials is not None
         ctx.step, ctx.R, ctx.f_rest_k = step, R, f_rest.shape[1]
         ctx.set_materialize_grads(False)   # no zero tensor for the (non-differentiable) terms output
         ctx.save_for_backward(endpoints, width, pairs, xyz, scale, quat, opacity, extra4, shs, planes, radii, geom, binning,
@@ -178,7 +187,8 @@ class _StrandIteration(torch.autograd.Function):
             rt.check(L.hgs_loss_head_backward(stream, C.byref(hp), planes[0:3].data_ptr(), planes[3].data_ptr(),
                                               planes[4:7].data_ptr(), vt.slot.data_ptr(), rt.ptr(endpoints),
                                               rt.ptr(step.smooth_pairs), rt.ptr(scratch), rt.ptr(out), rt.ptr(go),
-                                              1 if unit else 0, d_image.data_ptr(), d_extra[0].data_ptr(),
+                                              (rt.HEAD_SKIP_PIXELS if unit else 0) | (rt.HEAD_SKIP_SMOOTH if ctx.fused_smooth else 0),
+                                              d_image.data_ptr(), d_extra[0].data_ptr(),
                                               d_extra[1:4].data_ptr(), rt.ptr(d_ep)))
         grad_planes = [d_image[k] for k in range(3)] + [d_extra[k] for k in range(4)]
         empty = step.empty
@@ -186,11 +196,23 @@ class _StrandIteration(torch.autograd.Function):
             step.bg7, xyz, radii, empty, scale, quat, 1.0, empty, vt.viewmatrix, vt.projmatrix, vt.tanfovx, vt.tanfovy,
             grad_planes, shs, g.active_sh_degree, vt.campos, geom, ctx.R, binning, img, False)
         d_w, d_o, d_m = torch.empty((P, 1), **f32), torch.empty((P, 1), **f32), torch.empty((P, 1), **f32)
+        fu = rt.StrandFusion()
+        if ctx.fused_smooth:      # smoothness gradient: extra workgroups of the same launch, same d_ep
+            idx = step.smooth_pairs
+            fu.smooth_pairs, fu.n_smooth = idx.data_ptr(), int(idx.shape[0])
+            fu.cos_threshold, fu.eps = hp.cos_threshold, hp.eps
+            fu.head_out, fu.grad_out = out.data_ptr(), go.data_ptr()
+        step.last["stats_done"] = False
+        if step.stats_in_backward:   # densification statistics (train.py:170-171) by the same launch
+            fu.radii, fu.dmean2D, fu.dmean2D_stride = radii.data_ptr(), g_means2D.data_ptr(), int(g_means2D.shape[1])
+            fu.max_radii2D, fu.grad_accum, fu.denom = g.max_radii2D.data_ptr(), g.xyz_gradient_accum.data_ptr(), g.denom.data_ptr()
+            step.last["stats_done"] = True
         with torch.cuda.device(dev):
             rt.check(L.hgs_hair_params_backward(stream, P, E, rt.ptr(endpoints), rt.ptr(pairs), rt.ptr(width),
                                                 float(g.dist_to_scale_factor), rt.ptr(opacity), rt.ptr(extra4),
                                                 rt.ptr(g_means3D), rt.ptr(g_scales), rt.ptr(g_rot), None, rt.ptr(g_opac),
-                                                rt.ptr(g_ex), 1, rt.ptr(d_ep), rt.ptr(d_w), rt.ptr(d_o), rt.ptr(d_m)))
+                                                rt.ptr(g_ex), 1, rt.ptr(d_ep), rt.ptr(d_w), rt.ptr(d_o), rt.ptr(d_m),
+                                                C.byref(fu)))
         step.last["dmean2D"] = g_means2D      # RGB-only screen-space gradient: what the densification statistics see
         if ctx.f_rest_k == 0:
             d_dc, d_rest = g_sh, None
@@ -210,6 +232,7 @@ class FusedStrandStep:
         self.empty = torch.empty(0, device=dev)
         self.one = torch.ones((), dtype=torch.float32, device=dev)   # d loss / d loss, passed to backward(): no fill launch
         self.one_pass_pixels = True    # per-pixel loss terms: value and gradient in one pass over the pixels
+        self.stats_in_backward = True  # densification statistics updated by the backward's last launch
         self.last = {}
         self.refresh()
 
@@ -238,6 +261,8 @@ class FusedStrandStep:
     def update_densification_stats(self):
         """add_densification_stats + max_radii2D of the iteration just back-propagated (one launch)."""
         g, last = self.gaussians, self.last
+        if last.get("stats_done"):
+            return                     # already folded into the backward (stats_in_backward)
         gm, radii = last["dmean2D"], last["radii"]
         with torch.cuda.device(gm.device):
             rt.check(rt.lib().hgs_densify_stats(rt.current_stream(), gm.shape[0], rt.ptr(radii), rt.ptr(gm), gm.shape[1],

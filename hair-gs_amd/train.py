@@ -130,6 +130,7 @@ def _training_step(gaussians, viewpoint_cam, opt, bg, iteration, extent, vp, ras
         gaussians.oneupSHdegree()
     if fused is not None:
         fused.views.select(fused.views.index[id(viewpoint_cam)])
+        fused.stats_in_backward = iteration < opt.densify_until_iter
         loss, _ = fused.loss()
         loss_dict = fused.terms()
         render_pkg = {"render": fused.last["planes"][:3], "radii": fused.last["radii"], "viewspace_points": None,

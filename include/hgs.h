@@ -201,6 +201,7 @@ typedef struct HgsViewTargets {
 } HgsViewTargets;
 size_t hgs_view_targets_bytes(void);   /* sizeof(HgsViewTargets), for bindings that mirror the struct */
 size_t hgs_head_params_bytes(void);    /* sizeof(HgsHeadParams) */
+size_t hgs_strand_fusion_bytes(void);  /* sizeof(HgsStrandFusion) */
 /* slot[0] = table[view]; if lr_dst != NULL also *lr_dst = lr (the position learning rate of this iteration, a by-value
  * kernel argument, so the host may run ahead of the device without racing on a staging buffer). */
 int hgs_select_view(void* stream, const HgsViewTargets* table, int view, HgsViewTargets* slot, float lr, float* lr_dst);
@@ -210,15 +211,28 @@ int hgs_select_view(void* stream, const HgsViewTargets* table, int view, HgsView
  *   single-pass rasterizer, extra4 = [sigmoid(mask_raw), dir.xyz].  backward: g_extra4 [P,4] carries the gradient of
  *   the mask channel and of the direction (added to g_dir); `opacity`/`extra4` are the forward outputs;
  *   accumulate_endpoints != 0: d_endpoints is NOT zeroed first (it already holds the smoothness gradient). */
+/* Optional work folded into the two launches (host struct, NULL = none): extra workgroups evaluate the smoothness term
+ * over the same endpoints (forward: partial sums in the layout of hgs_smoothness_forward; backward: its gradient scattered
+ * into d_endpoints, scaled by head_out[HGS_HEAD_G_SMOOTH] * *grad_out / max(head_out[HGS_HEAD_SMOOTH_COUNT], 1)), and the
+ * backward also updates the densification statistics of hgs_densify_stats for its Gaussians.  Any group whose first
+ * pointer is NULL is skipped. */
+typedef struct HgsStrandFusion {
+  const long long* smooth_pairs; int n_smooth; float cos_threshold, eps;
+  float* smooth_partials;                          /* forward out */
+  const float* head_out; const float* grad_out;    /* backward in (device) */
+  const int* radii; const float* dmean2D; int dmean2D_stride;   /* backward in: statistics inputs */
+  float* max_radii2D; float* grad_accum; float* denom;          /* backward in/out */
+} HgsStrandFusion;
 int hgs_hair_params_forward(void* stream, int P, const float* endpoints, const long long* endpoint_pairs,
                             const float* width, float dist_to_scale_factor, const float* opacity_raw,
                             const float* mask_raw, float* xyz, float* scale, float* quat, float* dir, float* opacity,
-                            float* extra4);
+                            float* extra4, const HgsStrandFusion* fusion);
 int hgs_hair_params_backward(void* stream, int P, int E, const float* endpoints, const long long* endpoint_pairs,
                              const float* width, float dist_to_scale_factor, const float* opacity, const float* extra4,
                              const float* g_xyz, const float* g_scale, const float* g_quat, const float* g_dir,
                              const float* g_opacity, const float* g_extra4, int accumulate_endpoints,
-                             float* d_endpoints, float* d_width, float* d_opacity_raw, float* d_mask_raw);
+                             float* d_endpoints, float* d_width, float* d_opacity_raw, float* d_mask_raw,
+                             const HgsStrandFusion* fusion);
 
 /* hgs_loss_head_forward/backward <-> loss/losses.py:319-355 loss_function on the three rendered images:
  *   total = (1-l_dssim) L1 + l_dssim (1-SSIM) + l_mask BCEWithLogits(mask_img, float_mask) + l_orientation ORI
@@ -228,9 +242,13 @@ int hgs_hair_params_backward(void* stream, int P, int E, const float* endpoints,
  *   d_extra_unit ([4,H,W]: mask plane, then the 3 orientation planes; may be NULL): if given, the per-pixel pass also
  *   writes dL/d(mask_img) and dL/d(omap) FOR grad_out = 1 (requires targets->mask_count > 0 when the orientation term
  *   is on, since that gradient is normalised by the mask count); a caller whose upstream gradient is exactly 1 then
- *   passes skip_pixel_pass = 1 to the backward and uses those planes as they are.
- *   backward: d_image [3,H,W] fully written; d_mask_img [H,W], d_omap [3,H,W] fully written unless skip_pixel_pass;
- *   d_endpoints [E,3] zeroed, then the smoothness gradient scattered into it; grad_out = device scalar dL/dtotal. */
+ *   passes HGS_HEAD_SKIP_PIXELS to the backward and uses those planes as they are.
+ *   smooth_partials_ext (may be NULL): smoothness partial sums already computed elsewhere (HgsStrandFusion): the head then
+ *   launches no smoothness kernel of its own and reduces these.
+ *   backward: d_image [3,H,W] fully written; d_mask_img [H,W], d_omap [3,H,W] fully written unless HGS_HEAD_SKIP_PIXELS;
+ *   d_endpoints [E,3] zeroed, then (unless HGS_HEAD_SKIP_SMOOTH) the smoothness gradient scattered into it;
+ *   grad_out = device scalar dL/dtotal. */
+enum { HGS_HEAD_SKIP_PIXELS = 1, HGS_HEAD_SKIP_SMOOTH = 2 };
 typedef struct HgsHeadParams {
   int H, W;
   float lambda_dssim, lambda_mask, lambda_orientation, lambda_smooth;
@@ -247,11 +265,12 @@ enum { HGS_HEAD_TOTAL = 0, HGS_HEAD_L1, HGS_HEAD_DSSIM, HGS_HEAD_MASK, HGS_HEAD_
 size_t hgs_loss_head_scratch_floats(const HgsHeadParams* p);
 int hgs_loss_head_forward(void* stream, const HgsHeadParams* p, const float* image, const float* mask_img,
                           const float* omap, const HgsViewTargets* targets, const float* endpoints,
-                          const long long* smooth_pairs, float* scratch, float* out, float* d_extra_unit);
+                          const long long* smooth_pairs, float* scratch, float* out, float* d_extra_unit,
+                          const float* smooth_partials_ext);
 int hgs_loss_head_backward(void* stream, const HgsHeadParams* p, const float* image, const float* mask_img,
                            const float* omap, const HgsViewTargets* targets, const float* endpoints,
                            const long long* smooth_pairs, const float* scratch, const float* out,
-                           const float* grad_out, int skip_pixel_pass, float* d_image, float* d_mask_img,
+                           const float* grad_out, int skip, float* d_image, float* d_mask_img,
                            float* d_omap, float* d_endpoints);
 
 /* hgs_densify_stats <-> scene/hair_gaussian_model.py:1401-1408 / gaussian_model.py:675-682 add_densification_stats +

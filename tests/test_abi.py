@@ -51,6 +51,7 @@ def test_struct_mirrors_match_the_library():
     L = rt.lib()
     assert L.hgs_view_targets_bytes() == C.sizeof(rt.ViewTargets) == 184
     assert L.hgs_head_params_bytes() == C.sizeof(rt.HeadParams)
+    assert L.hgs_strand_fusion_bytes() == C.sizeof(rt.StrandFusion)
     assert rt.ViewTargets.viewmatrix.offset == 40 and rt.ViewTargets.campos.offset == 168
     src = open(os.path.join(ROOT, "include", "hgs.h")).read()
     names = re.search(r"enum \{ HGS_HEAD_TOTAL = 0,(.*?)HGS_HEAD_NOUT = (\d+)", src, re.S)
