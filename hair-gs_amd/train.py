@@ -332,14 +332,21 @@ class GraphedStep:
         self.g._derived = None  # cached derived tensors now hold pre-update values
         return self.loss_buf
 
-    def check(self):
-        """Synchronise and validate the instance counts of ALL replays since the last check (raises on capacity
-        overflow); returns [largest num_rendered seen]."""
+    def headroom(self):
+        """(largest num_rendered of the replays since the last check, captured capacity): one synchronisation, no
+        exception -- lets a long run re-capture BEFORE a growing model overflows the captured binning capacity."""
         raster = self.raster
         worst = 0
         for t in raster._state["max_R"].values():
             worst = max(worst, int(t.item()))
             t.zero_()
+        return worst, self._cap
+
+    def check(self):
+        """Synchronise and validate the instance counts of ALL replays since the last check (raises on capacity
+        overflow); returns [largest num_rendered seen]."""
+        raster = self.raster
+        worst, _ = self.headroom()
         if self._cap is not None and worst > self._cap:
             raise raster.HgsCapacityOverflow(
                 f"captured step needed {worst} instances > capacity {self._cap}: re-capture with a larger slack")
@@ -414,6 +421,16 @@ def training(gaussians, cameras, opt, iterations=None, extent=1.0, seed=0, log_e
             else:
                 loss, _, _ = training_step(gaussians, sampler.next(), opt, bg, it, extent=extent, vp=vp, fused=fused)
             ema = loss.clone() if ema is None else 0.4 * loss + 0.6 * ema  # on the device: no per-iteration host sync
+            if gs is not None and it % 64 == 0:
+                # the model grows while it trains: re-capture with a larger capacity once 80% of the captured one is used
+                worst, cap = gs.headroom()
+                if cap is not None and worst > 0.8 * cap:
+                    from diff_gaussian_rasterization import _C as raster
+                    if worst > cap and vp.rank == 0:
+                        print(f"[it {it}] binning capacity {cap} exceeded ({worst} instances): some of the last 64 steps "
+                              "dropped instances; re-capturing with a larger capacity")
+                    raster._state["cap"] = max(raster._state["cap"], int(worst * 2.0) + 4096)
+                    gs = None
             if any(d in due for d in ("densify", "reset_opacity", "merge")):
                 if gs is not None:
                     gs.check()
