@@ -254,6 +254,8 @@ def main():
                               "launches": bwd_n}
         result["roofline_blend_fwd"] = {"achieved": bytes_fwd / (fwd_ms / max(fwd_n, 1) * 1e-3) / 1e9 if fwd_ms else 0.0,
                                         "unit": "GB/s", "mean_launch_us": fwd_ms / max(fwd_n, 1) * 1e3}
+        result["kernel_timing"] = {"method": "HIP event pairs on the launch stream, calibrated bracket cost subtracted",
+                                   "bracket_cost_us": rt.lib().hgs_prof_bracket_overhead_ms() * 1e3}
         result["kernel_us_per_launch"] = {k: (v[0] / v[1] * 1e3 if v[1] else 0.0) for k, v in kern.items()}
         result["kernel_ms_per_iter"] = {k: v[0] / kern_steps for k, v in kern.items()}
     if world == 1 and not args.no_cpu_baseline:

@@ -62,6 +62,7 @@ SIGNATURES = {
     "hgs_radius_pairs": (ci, [vp, ci, vp, vp, cf, cf, ci, ci, vp, vp, vp]),
     "hgs_debug_set_wg_trace": (ci, [vp, vp]),
     "hgs_prof_enable": (ci, [ci]),
+    "hgs_prof_bracket_overhead_ms": (C.c_double, []),
     "hgs_prof_collect": (ci, [vp, vp]),
     "hgs_prof_kernel_name": (C.c_char_p, [ci]),
     "hgs_geom_layout": (ci, [ci, vp]),

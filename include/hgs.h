@@ -283,11 +283,13 @@ int hgs_densify_stats(void* stream, int P, const int* radii, const float* dL_dme
 /* ---- per-kernel device timing (bench.py roofline): when enabled every kernel launch of the library is bracketed
  * by hipEvents recorded on the launch stream.  hgs_prof_collect() synchronises those events, ADDS elapsed
  * milliseconds / launch counts per kernel id into the caller's arrays (length HGS_K_COUNT) and clears the log.
+ * Enabling calibrates the fixed cost of an event pair with empty kernels once; every reading has it subtracted.
  * No reference counterpart (the reference only times whole iterations, train.py:81-82,133,156). ---- */
 enum { HGS_K_PREPROCESS_FWD = 0, HGS_K_SCAN, HGS_K_SCATTER, HGS_K_SORT_TILES, HGS_K_BLEND_FWD, HGS_K_BLEND_BWD,
        HGS_K_PREPROCESS_BWD, HGS_K_KNN, HGS_K_SSIM_FWD, HGS_K_SSIM_BWD, HGS_K_STRAND_FWD, HGS_K_STRAND_BWD,
        HGS_K_ORI_FWD, HGS_K_ORI_BWD, HGS_K_ADAM, HGS_K_SMOOTH, HGS_K_HEAD, HGS_K_MISC, HGS_K_COUNT };
 int hgs_prof_enable(int on);
+double hgs_prof_bracket_overhead_ms(void);   /* calibrated cost of one event pair, subtracted from every reading */
 int hgs_prof_collect(double* total_ms, long long* launches);
 const char* hgs_prof_kernel_name(int kernel_id);
 
