@@ -129,9 +129,9 @@ def main():
     it = 0
     views = fused = None
     if fused_step_applicable(model, opt):
-        from hgs_runtime.strand_step import FusedStrandStep, ViewTable
+        from hgs_runtime.strand_step import ViewTable, fused_step_for
         views = ViewTable(cams)
-        fused = FusedStrandStep(model, views, opt, bg)   # eager launches of the same fused iteration (timing pass, --eager)
+        fused = fused_step_for(model, views, opt, bg)   # eager launches of the same fused iteration (timing pass, --eager)
     if use_graph:
         # the whole iteration is captured once into a HIP graph and replayed (train.GraphedStep); the W warm-up steps
         # and the K timed steps are real optimizer steps on successive random views, exactly like the eager loop
@@ -225,7 +225,7 @@ def main():
                    "mean_num_rendered": meanR, "mean_sum_tile_list_len": meanL,
                    "forward_mode": "blocking" if args.blocking else "async-capacity",
                    "dispatch": "hip-graph replay" if use_graph else "eager",
-                   "iteration": "fused strand iteration" if fused is not None else "op-by-op",
+                   "iteration": "fused iteration" if fused is not None else "op-by-op",
                    "raster_passes_per_iter": 1 if getattr(opt, "single_pass", True) else 3},
         "render_ms_per_view": render_ms,
     }

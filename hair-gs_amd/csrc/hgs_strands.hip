@@ -131,6 +131,79 @@ __global__ __launch_bounds__(256) void strand_bwd_kernel(int P, const float* __r
   d_width[k] = gw;
 }
 
+// ---- Stage-I cloud: raw parameters -> rasterizer inputs (scene/gaussian_model.py:118-157) -------------------------------
+__device__ __forceinline__ int argmax3(float a, float b, float c) { return (b > a) ? ((c > b) ? 2 : 1) : ((c > a) ? 2 : 0); }
+// column `ax` of the rotation matrix of the UNIT quaternion (w, x, y, z)
+__device__ __forceinline__ void rot_column(int ax, float w, float x, float y, float z, float& d0, float& d1, float& d2) {
+  if (ax == 0)      { d0 = 1.f - 2.f * (y * y + z * z); d1 = 2.f * (x * y + w * z);       d2 = 2.f * (x * z - w * y); }
+  else if (ax == 1) { d0 = 2.f * (x * y - w * z);       d1 = 1.f - 2.f * (x * x + z * z); d2 = 2.f * (y * z + w * x); }
+  else              { d0 = 2.f * (x * z + w * y);       d1 = 2.f * (y * z - w * x);       d2 = 1.f - 2.f * (x * x + y * y); }
+}
+
+__global__ __launch_bounds__(256) void cloud_fwd_kernel(int P, const float* __restrict__ s_raw, const float* __restrict__ r_raw,
+                                                        const float* __restrict__ o_raw, const float* __restrict__ m_raw,
+                                                        float* __restrict__ scale, float* __restrict__ quat,
+                                                        float* __restrict__ opacity, float* __restrict__ extra4) {
+  const int k = blockIdx.x * 256 + threadIdx.x;
+  if (k >= P) return;
+  const float s0 = expf(s_raw[3 * (size_t)k]), s1 = expf(s_raw[3 * (size_t)k + 1]), s2 = expf(s_raw[3 * (size_t)k + 2]);
+  scale[3 * (size_t)k] = s0; scale[3 * (size_t)k + 1] = s1; scale[3 * (size_t)k + 2] = s2;
+  const float4 r = ((const float4*)r_raw)[k];
+  const float n = sqrtf(r.x * r.x + r.y * r.y + r.z * r.z + r.w * r.w);
+  const float inq = 1.f / fmaxf(n, 1e-12f);                              // F.normalize (get_rotation)
+  ((float4*)quat)[k] = make_float4(r.x * inq, r.y * inq, r.z * inq, r.w * inq);
+  const float ib = 1.f / n;                                              // build_rotation normalises without the clamp
+  float d0, d1, d2;
+  rot_column(argmax3(s0, s1, s2), r.x * ib, r.y * ib, r.z * ib, r.w * ib, d0, d1, d2);
+  opacity[k] = 1.f / (1.f + expf(-o_raw[k]));
+  ((float4*)extra4)[k] = make_float4(1.f / (1.f + expf(-m_raw[k])), d0, d1, d2);
+}
+
+__global__ __launch_bounds__(256) void cloud_bwd_kernel(int P, const float* __restrict__ s_raw, const float* __restrict__ r_raw,
+                                                        const float* __restrict__ opacity, const float* __restrict__ extra4,
+                                                        const float* __restrict__ g_scale, const float* __restrict__ g_quat,
+                                                        const float* __restrict__ g_opacity, const float* __restrict__ g_extra4,
+                                                        float* __restrict__ d_s, float* __restrict__ d_r,
+                                                        float* __restrict__ d_o, float* __restrict__ d_m, HgsStrandFusion fu) {
+  const int k = blockIdx.x * 256 + threadIdx.x;
+  if (k >= P) return;
+  if (fu.radii) {                    // densification statistics of this Gaussian (hgs_densify_stats)
+    const int rr = fu.radii[k];
+    if (rr > 0) {
+      fu.max_radii2D[k] = fmaxf(fu.max_radii2D[k], (float)rr);
+      const float gx = fu.dmean2D[(size_t)k * fu.dmean2D_stride], gy = fu.dmean2D[(size_t)k * fu.dmean2D_stride + 1];
+      fu.grad_accum[k] += sqrtf(gx * gx + gy * gy);
+      fu.denom[k] += 1.f;
+    }
+  }
+  const float s0 = expf(s_raw[3 * (size_t)k]), s1 = expf(s_raw[3 * (size_t)k + 1]), s2 = expf(s_raw[3 * (size_t)k + 2]);
+  d_s[3 * (size_t)k] = g_scale[3 * (size_t)k] * s0;
+  d_s[3 * (size_t)k + 1] = g_scale[3 * (size_t)k + 1] * s1;
+  d_s[3 * (size_t)k + 2] = g_scale[3 * (size_t)k + 2] * s2;
+  const float4 ge = ((const float4*)g_extra4)[k];
+  { const float o = opacity[k]; d_o[k] = g_opacity[k] * o * (1.f - o); }
+  { const float m = extra4[4 * (size_t)k]; d_m[k] = ge.x * m * (1.f - m); }
+  const float4 r = ((const float4*)r_raw)[k];
+  const float n = sqrtf(r.x * r.x + r.y * r.y + r.z * r.z + r.w * r.w);
+  const float in = 1.f / n;
+  const float w = r.x * in, x = r.y * in, y = r.z * in, z = r.w * in;
+  // dL/dq (q = unit quaternion) = the rasterizer's gradient of `quat` + J^T of the direction column
+  const float4 gq = ((const float4*)g_quat)[k];
+  float qw = gq.x, qx = gq.y, qy = gq.z, qz = gq.w;
+  if (!(n > 1e-12f)) { qw = 0.f; qx = 0.f; qy = 0.f; qz = 0.f; }           // clamped branch of F.normalize: q = r / 1e-12
+  const int ax = argmax3(s0, s1, s2);
+  const float a = ge.y, b = ge.z, c = ge.w;                                // dL/d(direction)
+  if (ax == 0) {        // (1-2(y^2+z^2), 2(xy+wz), 2(xz-wy))
+    qw += 2.f * (b * z - c * y); qx += 2.f * (b * y + c * z); qy += 2.f * (-2.f * a * y + b * x - c * w); qz += 2.f * (-2.f * a * z + b * w + c * x);
+  } else if (ax == 1) { // (2(xy-wz), 1-2(x^2+z^2), 2(yz+wx))
+    qw += 2.f * (-a * z + c * x); qx += 2.f * (a * y - 2.f * b * x + c * w); qy += 2.f * (a * x + c * z); qz += 2.f * (-a * w - 2.f * b * z + c * y);
+  } else {              // (2(xz+wy), 2(yz-wx), 1-2(x^2+y^2))
+    qw += 2.f * (a * y - b * x); qx += 2.f * (a * z - b * w - 2.f * c * x); qy += 2.f * (a * w + b * z - 2.f * c * y); qz += 2.f * (a * x + b * y);
+  }
+  const float dot = w * qw + x * qx + y * qy + z * qz;                     // through r -> r / |r|
+  ((float4*)d_r)[k] = make_float4((qw - w * dot) * in, (qx - x * dot) * in, (qy - y * dot) * in, (qz - z * dot) * in);
+}
+
 }  // namespace
 
 extern "C" {
@@ -217,6 +290,49 @@ int hgs_hair_params_backward(void* stream, int P, int E, const float* endpoints,
     hipLaunchKernelGGL(strand_bwd_kernel, dim3((P + 255) / 256 + (fu.n_smooth + 255) / 256), dim3(256), 0, s, P, endpoints,
                        endpoint_pairs, width, dist_to_scale_factor, g_xyz, g_scale, g_quat, g_dir, d_endpoints, d_width,
                        opacity, extra4, g_opacity, g_extra4, d_opacity_raw, d_mask_raw, fu);
+  }
+  HGS_CHECK_LAUNCH();
+  return 0;
+}
+
+int hgs_cloud_params_forward(void* stream, int P, const float* scaling_raw, const float* rotation_raw,
+                             const float* opacity_raw, const float* mask_raw, float* scale, float* quat, float* opacity,
+                             float* extra4) {
+  if (P == 0) return 0;
+  if (!scaling_raw || !rotation_raw || !opacity_raw || !mask_raw || !scale || !quat || !opacity || !extra4) {
+    hgs_set_error("hgs_cloud_params_forward: null argument");
+    return 1;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  {
+    HgsProfScope _prof(s, HGS_K_STRAND_FWD);
+    hipLaunchKernelGGL(cloud_fwd_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, scaling_raw, rotation_raw, opacity_raw,
+                       mask_raw, scale, quat, opacity, extra4);
+  }
+  HGS_CHECK_LAUNCH();
+  return 0;
+}
+
+int hgs_cloud_params_backward(void* stream, int P, const float* scaling_raw, const float* rotation_raw,
+                              const float* opacity, const float* extra4, const float* g_scale, const float* g_quat,
+                              const float* g_opacity, const float* g_extra4, float* d_scaling_raw, float* d_rotation_raw,
+                              float* d_opacity_raw, float* d_mask_raw, const HgsStrandFusion* fusion) {
+  if (P == 0) return 0;
+  if (!scaling_raw || !rotation_raw || !opacity || !extra4 || !g_scale || !g_quat || !g_opacity || !g_extra4 ||
+      !d_scaling_raw || !d_rotation_raw || !d_opacity_raw || !d_mask_raw) {
+    hgs_set_error("hgs_cloud_params_backward: null argument");
+    return 1;
+  }
+  HgsStrandFusion fu = fusion ? *fusion : HgsStrandFusion{};
+  if (fu.radii && (!fu.dmean2D || fu.dmean2D_stride < 2 || !fu.max_radii2D || !fu.grad_accum || !fu.denom)) {
+    hgs_set_error("hgs_cloud_params_backward: incomplete statistics group in HgsStrandFusion");
+    return 1;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  {
+    HgsProfScope _prof(s, HGS_K_STRAND_BWD);
+    hipLaunchKernelGGL(cloud_bwd_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, scaling_raw, rotation_raw, opacity, extra4,
+                       g_scale, g_quat, g_opacity, g_extra4, d_scaling_raw, d_rotation_raw, d_opacity_raw, d_mask_raw, fu);
   }
   HGS_CHECK_LAUNCH();
   return 0;

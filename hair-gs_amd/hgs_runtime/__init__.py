@@ -55,6 +55,8 @@ SIGNATURES = {
     "hgs_select_view": (ci, [vp, vp, ci, vp, cf, vp]),
     "hgs_hair_params_forward": (ci, [vp, ci, vp, vp, vp, cf, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "hgs_hair_params_backward": (ci, [vp, ci, ci, vp, vp, vp, cf, vp, vp, vp, vp, vp, vp, vp, vp, ci, vp, vp, vp, vp, vp]),
+    "hgs_cloud_params_forward": (ci, [vp, ci, vp, vp, vp, vp, vp, vp, vp, vp]),
+    "hgs_cloud_params_backward": (ci, [vp, ci, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "hgs_loss_head_scratch_floats": (sz, [vp]),
     "hgs_loss_head_forward": (ci, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "hgs_loss_head_backward": (ci, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, vp, vp, vp, vp]),

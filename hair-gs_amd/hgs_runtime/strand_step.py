@@ -106,6 +106,70 @@ def head_params(H, W, opt, n_smooth, n_endpoints, min_val, has_float_mask, thres
     return p
 
 
+def _raster_head_forward(step, xyz, scale, quat, opacity, extra4, shs, endpoints, smooth_idx, smooth_partials, n_endpoints):
+    """Single-pass rasterizer forward + loss head on the CURRENT slot view (shared by the strand and the cloud iteration)."""
+    from diff_gaussian_rasterization import _C as raster
+    g, vt, hp, L = step.gaussians, step.views, step.head, rt.lib()
+    dev = xyz.device
+    f32 = dict(dtype=torch.float32, device=dev)
+    empty = step.empty
+    R, planes, radii, geom, binning, img = raster.rasterize_gaussians_multi(
+        step.bg7, xyz, empty, extra4, opacity, scale, quat, 1.0, empty, vt.viewmatrix, vt.projmatrix, vt.tanfovx,
+        vt.tanfovy, vt.H, vt.W, shs, g.active_sh_degree, vt.campos, False, False)
+    hp.n_endpoints = n_endpoints
+    scratch = torch.empty((L.hgs_loss_head_scratch_floats(C.byref(hp)),), **f32)
+    out = torch.empty((rt.HEAD_NOUT,), **f32)
+    # gradient planes of the per-pixel terms for an upstream gradient of 1, written by the forward's own pass over
+    # the pixels (possible when the mask count is a per-view constant, i.e. the views carry masks)
+    d_extra = torch.empty((4, vt.H, vt.W), **f32) if (step.one_pass_pixels and vt.has_mask) else None
+    with torch.cuda.device(dev):
+        rt.check(L.hgs_loss_head_forward(rt.current_stream(), C.byref(hp), planes[0:3].data_ptr(), planes[3].data_ptr(),
+                                         planes[4:7].data_ptr(), vt.slot.data_ptr(), rt.ptr(endpoints), rt.ptr(smooth_idx),
+                                         rt.ptr(scratch), rt.ptr(out), rt.ptr(d_extra), rt.ptr(smooth_partials)))
+    return R, planes, radii, geom, binning, img, scratch, out, d_extra
+
+
+def _head_raster_backward(ctx, step, go, xyz, scale, quat, shs, planes, radii, geom, binning, img, scratch, out, endpoints,
+                          d_ep, n_endpoints):
+    """Loss-head backward + single-pass rasterizer backward; returns (grad_out tensor, rasterizer gradients)."""
+    from diff_gaussian_rasterization import _C as raster
+    g, vt, hp, L = step.gaussians, step.views, step.head, rt.lib()
+    dev = xyz.device
+    f32 = dict(dtype=torch.float32, device=dev)
+    # Fused*Step.backward() hands in its own ones tensor: the upstream gradient is then known to be exactly 1 and
+    # the planes the forward wrote are final (the tensor's address, not its value, is what can be checked without a sync)
+    unit = ctx.d_extra is not None and go is not None and go.data_ptr() == step.one.data_ptr()
+    go = step.one if go is None else go.contiguous().to(torch.float32)
+    hp.n_endpoints = n_endpoints
+    if unit:
+        d_image, d_extra = torch.empty((3, vt.H, vt.W), **f32), ctx.d_extra
+    else:
+        dplanes = torch.empty_like(planes)
+        d_image, d_extra = dplanes[0:3], dplanes[3:7]
+    with torch.cuda.device(dev):
+        rt.check(L.hgs_loss_head_backward(rt.current_stream(), C.byref(hp), planes[0:3].data_ptr(), planes[3].data_ptr(),
+                                          planes[4:7].data_ptr(), vt.slot.data_ptr(), rt.ptr(endpoints),
+                                          rt.ptr(step.smooth_pairs), rt.ptr(scratch), rt.ptr(out), rt.ptr(go),
+                                          (rt.HEAD_SKIP_PIXELS if unit else 0) | (rt.HEAD_SKIP_SMOOTH if ctx.fused_smooth else 0),
+                                          d_image.data_ptr(), d_extra[0].data_ptr(), d_extra[1:4].data_ptr(), rt.ptr(d_ep)))
+    grad_planes = [d_image[k] for k in range(3)] + [d_extra[k] for k in range(4)]
+    empty = step.empty
+    (g_means2D, _gc, g_ex, g_opac, g_means3D, _gcov, g_sh, g_scales, g_rot) = raster.rasterize_gaussians_multi_backward(
+        step.bg7, xyz, radii, empty, scale, quat, 1.0, empty, vt.viewmatrix, vt.projmatrix, vt.tanfovx, vt.tanfovy,
+        grad_planes, shs, g.active_sh_degree, vt.campos, geom, ctx.R, binning, img, False)
+    return go, (g_means2D, g_ex, g_opac, g_means3D, g_sh, g_scales, g_rot)
+
+
+def _stats_group(step, fu, radii, g_means2D):
+    """Densification statistics (train.py:170-171) folded into the backward's parameter launch."""
+    g = step.gaussians
+    step.last["stats_done"] = False
+    if step.stats_in_backward:
+        fu.radii, fu.dmean2D, fu.dmean2D_stride = radii.data_ptr(), g_means2D.data_ptr(), int(g_means2D.shape[1])
+        fu.max_radii2D, fu.grad_accum, fu.denom = g.max_radii2D.data_ptr(), g.xyz_gradient_accum.data_ptr(), g.denom.data_ptr()
+        step.last["stats_done"] = True
+
+
 class _StrandIteration(torch.autograd.Function):
     @staticmethod
     def forward(ctx, endpoints, width, opacity_raw, mask_raw, f_dc, f_rest, step):
@@ -137,20 +201,8 @@ class _StrandIteration(torch.autograd.Function):
                                                rt.ptr(opacity_raw), rt.ptr(mask_raw), rt.ptr(xyz), rt.ptr(scale), rt.ptr(quat),
                                                None, rt.ptr(opacity), rt.ptr(extra4), C.byref(fu)))
         shs = f_dc if f_rest.numel() == 0 else torch.cat((f_dc, f_rest), dim=1)
-        empty = step.empty
-        R, planes, radii, geom, binning, img = raster.rasterize_gaussians_multi(
-            step.bg7, xyz, empty, extra4, opacity, scale, quat, 1.0, empty, vt.viewmatrix, vt.projmatrix, vt.tanfovx,
-            vt.tanfovy, vt.H, vt.W, shs, g.active_sh_degree, vt.campos, False, False)
-        hp.n_endpoints = E
-        scratch = torch.empty((L.hgs_loss_head_scratch_floats(C.byref(hp)),), **f32)
-        out = torch.empty((rt.HEAD_NOUT,), **f32)
-        # gradient planes of the per-pixel terms for an upstream gradient of 1, written by the forward's own pass over
-        # the pixels (possible when the mask count is a per-view constant, i.e. the views carry masks)
-        d_extra = torch.empty((4, vt.H, vt.W), **f32) if (step.one_pass_pixels and vt.has_mask) else None
-        with torch.cuda.device(dev):
-            rt.check(L.hgs_loss_head_forward(stream, C.byref(hp), planes[0:3].data_ptr(), planes[3].data_ptr(),
-                                             planes[4:7].data_ptr(), vt.slot.data_ptr(), rt.ptr(endpoints), rt.ptr(idx),
-                                             rt.ptr(scratch), rt.ptr(out), rt.ptr(d_extra), rt.ptr(smooth_partials)))
+        R, planes, radii, geom, binning, img, scratch, out, d_extra = _raster_head_forward(
+            step, xyz, scale, quat, opacity, extra4, shs, endpoints, idx, smooth_partials, E)
         ctx.d_extra = d_extra
         ctx.fused_smooth = smooth_partials is not None
         ctx.step, ctx.R, ctx.f_rest_k = step, R, f_rest.shape[1]
@@ -171,30 +223,10 @@ class _StrandIteration(torch.autograd.Function):
          out) = ctx.saved_tensors
         dev, P, E = endpoints.device, pairs.shape[0], endpoints.shape[0]
         f32 = dict(dtype=torch.float32, device=dev)
-        # FusedStrandStep.backward() hands in its own ones tensor: the upstream gradient is then known to be exactly 1 and
-        # the planes the forward wrote are final (the tensor's address, not its value, is what can be checked without a sync)
-        unit = ctx.d_extra is not None and go is not None and go.data_ptr() == step.one.data_ptr()
-        go = step.one if go is None else go.contiguous().to(torch.float32)
         d_ep = torch.empty((E, 3), **f32)
+        go, (g_means2D, g_ex, g_opac, g_means3D, g_sh, g_scales, g_rot) = _head_raster_backward(
+            ctx, step, go, xyz, scale, quat, shs, planes, radii, geom, binning, img, scratch, out, endpoints, d_ep, E)
         stream = rt.current_stream()
-        hp.n_endpoints = E
-        if unit:
-            d_image, d_extra = torch.empty((3, vt.H, vt.W), **f32), ctx.d_extra
-        else:
-            dplanes = torch.empty_like(planes)
-            d_image, d_extra = dplanes[0:3], dplanes[3:7]
-        with torch.cuda.device(dev):
-            rt.check(L.hgs_loss_head_backward(stream, C.byref(hp), planes[0:3].data_ptr(), planes[3].data_ptr(),
-                                              planes[4:7].data_ptr(), vt.slot.data_ptr(), rt.ptr(endpoints),
-                                              rt.ptr(step.smooth_pairs), rt.ptr(scratch), rt.ptr(out), rt.ptr(go),
-                                              (rt.HEAD_SKIP_PIXELS if unit else 0) | (rt.HEAD_SKIP_SMOOTH if ctx.fused_smooth else 0),
-                                              d_image.data_ptr(), d_extra[0].data_ptr(),
-                                              d_extra[1:4].data_ptr(), rt.ptr(d_ep)))
-        grad_planes = [d_image[k] for k in range(3)] + [d_extra[k] for k in range(4)]
-        empty = step.empty
-        (g_means2D, _gc, g_ex, g_opac, g_means3D, _gcov, g_sh, g_scales, g_rot) = raster.rasterize_gaussians_multi_backward(
-            step.bg7, xyz, radii, empty, scale, quat, 1.0, empty, vt.viewmatrix, vt.projmatrix, vt.tanfovx, vt.tanfovy,
-            grad_planes, shs, g.active_sh_degree, vt.campos, geom, ctx.R, binning, img, False)
         d_w, d_o, d_m = torch.empty((P, 1), **f32), torch.empty((P, 1), **f32), torch.empty((P, 1), **f32)
         fu = rt.StrandFusion()
         if ctx.fused_smooth:      # smoothness gradient: extra workgroups of the same launch, same d_ep
@@ -202,11 +234,7 @@ class _StrandIteration(torch.autograd.Function):
             fu.smooth_pairs, fu.n_smooth = idx.data_ptr(), int(idx.shape[0])
             fu.cos_threshold, fu.eps = hp.cos_threshold, hp.eps
             fu.head_out, fu.grad_out = out.data_ptr(), go.data_ptr()
-        step.last["stats_done"] = False
-        if step.stats_in_backward:   # densification statistics (train.py:170-171) by the same launch
-            fu.radii, fu.dmean2D, fu.dmean2D_stride = radii.data_ptr(), g_means2D.data_ptr(), int(g_means2D.shape[1])
-            fu.max_radii2D, fu.grad_accum, fu.denom = g.max_radii2D.data_ptr(), g.xyz_gradient_accum.data_ptr(), g.denom.data_ptr()
-            step.last["stats_done"] = True
+        _stats_group(step, fu, radii, g_means2D)
         with torch.cuda.device(dev):
             rt.check(L.hgs_hair_params_backward(stream, P, E, rt.ptr(endpoints), rt.ptr(pairs), rt.ptr(width),
                                                 float(g.dist_to_scale_factor), rt.ptr(opacity), rt.ptr(extra4),
@@ -267,3 +295,83 @@ class FusedStrandStep:
         with torch.cuda.device(gm.device):
             rt.check(rt.lib().hgs_densify_stats(rt.current_stream(), gm.shape[0], rt.ptr(radii), rt.ptr(gm), gm.shape[1],
                                                 rt.ptr(g.max_radii2D), rt.ptr(g.xyz_gradient_accum), rt.ptr(g.denom)))
+
+
+class _CloudIteration(torch.autograd.Function):
+    """The same iteration for the Stage-I Gaussian cloud (scene/gaussian_model.py): raw (scaling, rotation, opacity, mask)
+    -> rasterizer inputs by hgs_cloud_params_*; xyz and the SH features go to the rasterizer as they are."""
+
+    @staticmethod
+    def forward(ctx, xyz, scaling_raw, rotation_raw, opacity_raw, mask_raw, f_dc, f_rest, step):
+        L = rt.lib()
+        xyz = rt.require_gpu_tensor(xyz, "xyz", torch.float32)
+        scaling_raw = rt.require_gpu_tensor(scaling_raw, "scaling", torch.float32)
+        rotation_raw = rt.require_gpu_tensor(rotation_raw, "rotation", torch.float32)
+        opacity_raw = rt.require_gpu_tensor(opacity_raw, "opacity", torch.float32)
+        mask_raw = rt.require_gpu_tensor(mask_raw, "mask", torch.float32)
+        dev, P = xyz.device, xyz.shape[0]
+        f32 = dict(dtype=torch.float32, device=dev)
+        scale, quat = torch.empty((P, 3), **f32), torch.empty((P, 4), **f32)
+        opacity, extra4 = torch.empty((P, 1), **f32), torch.empty((P, 4), **f32)
+        with torch.cuda.device(dev):
+            rt.check(L.hgs_cloud_params_forward(rt.current_stream(), P, rt.ptr(scaling_raw), rt.ptr(rotation_raw),
+                                                rt.ptr(opacity_raw), rt.ptr(mask_raw), rt.ptr(scale), rt.ptr(quat),
+                                                rt.ptr(opacity), rt.ptr(extra4)))
+        shs = f_dc if f_rest.numel() == 0 else torch.cat((f_dc, f_rest), dim=1)
+        R, planes, radii, geom, binning, img, scratch, out, d_extra = _raster_head_forward(
+            step, xyz, scale, quat, opacity, extra4, shs, None, None, None, 0)
+        ctx.d_extra, ctx.fused_smooth = d_extra, True        # (no smoothness term for a cloud: nothing to launch)
+        ctx.step, ctx.R, ctx.f_rest_k = step, R, f_rest.shape[1]
+        ctx.set_materialize_grads(False)
+        ctx.save_for_backward(xyz, scaling_raw, rotation_raw, scale, quat, opacity, extra4, shs, planes, radii, geom, binning,
+                              img, scratch, out)
+        step.last = {"planes": planes, "radii": radii, "terms": out}
+        terms = out.detach()
+        ctx.mark_non_differentiable(terms)
+        return out[0], terms
+
+    @staticmethod
+    def backward(ctx, go, _):
+        step, L = ctx.step, rt.lib()
+        (xyz, scaling_raw, rotation_raw, scale, quat, opacity, extra4, shs, planes, radii, geom, binning, img, scratch,
+         out) = ctx.saved_tensors
+        dev, P = xyz.device, xyz.shape[0]
+        f32 = dict(dtype=torch.float32, device=dev)
+        go, (g_means2D, g_ex, g_opac, g_means3D, g_sh, g_scales, g_rot) = _head_raster_backward(
+            ctx, step, go, xyz, scale, quat, shs, planes, radii, geom, binning, img, scratch, out, None, None, 0)
+        d_s, d_r = torch.empty((P, 3), **f32), torch.empty((P, 4), **f32)
+        d_o, d_m = torch.empty((P, 1), **f32), torch.empty((P, 1), **f32)
+        fu = rt.StrandFusion()
+        _stats_group(step, fu, radii, g_means2D)
+        with torch.cuda.device(dev):
+            rt.check(L.hgs_cloud_params_backward(rt.current_stream(), P, rt.ptr(scaling_raw), rt.ptr(rotation_raw),
+                                                 rt.ptr(opacity), rt.ptr(extra4), rt.ptr(g_scales), rt.ptr(g_rot),
+                                                 rt.ptr(g_opac), rt.ptr(g_ex), rt.ptr(d_s), rt.ptr(d_r), rt.ptr(d_o),
+                                                 rt.ptr(d_m), C.byref(fu)))
+        step.last["dmean2D"] = g_means2D
+        if ctx.f_rest_k == 0:
+            d_dc, d_rest = g_sh, None
+        else:
+            d_dc, d_rest = g_sh[:, :1], g_sh[:, 1:]
+        return g_means3D, d_s, d_r, d_o, d_m, d_dc, d_rest, None
+
+
+class FusedCloudStep(FusedStrandStep):
+    """Host side of the fused iteration for a Stage-I GaussianModel (same views, same loss head, no smoothness term)."""
+
+    def refresh(self):
+        g = self.gaussians
+        self.smooth_pairs = None
+        self.head = head_params(self.views.H, self.views.W, self.opt, 0, 0, getattr(g, "min_val", 1e-7),
+                                self.views.has_float_mask)
+
+    def loss(self):
+        g = self.gaussians
+        return _CloudIteration.apply(g._xyz, g._scaling, g._rotation, g._opacity, g._mask, g._features_dc, g._features_rest, self)
+
+
+def fused_step_for(gaussians, views, opt, bg):
+    """The fused iteration matching the model class (strand model -> FusedStrandStep, Gaussian cloud -> FusedCloudStep)."""
+    from scene.hair_gaussian_model import HairGaussianModel
+    cls = FusedStrandStep if isinstance(gaussians, HairGaussianModel) else FusedCloudStep
+    return cls(gaussians, views, opt, bg)

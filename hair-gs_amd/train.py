@@ -102,11 +102,10 @@ class ViewSampler:
 
 
 def fused_step_applicable(gaussians, opt):
-    """The fused iteration (hgs_runtime.strand_step) covers the Stage-III model with the single-pass rasterizer on the
-    GPU and the reference's default loss terms (no magnet loss)."""
+    """The fused iteration (hgs_runtime.strand_step) covers both models (Stage-I cloud, Stage-III strands) with the
+    single-pass rasterizer on the GPU and the reference's default loss terms (no magnet loss)."""
     return (getattr(opt, "fused_step", True) and getattr(opt, "single_pass", True)
-            and isinstance(gaussians, HairGaussianModel) and gaussians._endpoints.is_cuda
-            and float(getattr(opt, "lambda_magnet", 0.0)) == 0.0)
+            and gaussians.get_xyz.is_cuda and float(getattr(opt, "lambda_magnet", 0.0)) == 0.0)
 
 
 def training_step(gaussians, viewpoint_cam, opt, bg, iteration, extent=1.0, vp=None, stats_local=None, fused=None):
@@ -191,8 +190,8 @@ class GraphedStep:
         self.fused = None
         if fused_step_applicable(gaussians, opt):
             # device-resident view table: a view switch is one tiny launch, not eight tensor copies
-            from hgs_runtime.strand_step import FusedStrandStep, ViewTable
-            self.fused = FusedStrandStep(gaussians, views if views is not None else ViewTable(cameras), opt, bg)
+            from hgs_runtime.strand_step import ViewTable, fused_step_for
+            self.fused = fused_step_for(gaussians, views if views is not None else ViewTable(cameras), opt, bg)
         c0 = cameras[0]
         for c in cameras:  # by-value kernel arguments are frozen into the graph
             assert (c.image_width, c.image_height, c.FoVx, c.FoVy) == (c0.image_width, c0.image_height, c0.FoVx, c0.FoVy)
@@ -401,10 +400,10 @@ def training(gaussians, cameras, opt, iterations=None, extent=1.0, seed=0, log_e
     use_graph = use_graph and dev.type == "cuda"
     views = fused = None
     if dev.type == "cuda" and fused_step_applicable(gaussians, opt):
-        from hgs_runtime.strand_step import FusedStrandStep, ViewTable
+        from hgs_runtime.strand_step import ViewTable, fused_step_for
         views = ViewTable(cameras)             # built once; survives topology changes
         if not use_graph:
-            fused = FusedStrandStep(gaussians, views, opt, bg)
+            fused = fused_step_for(gaussians, views, opt, bg)
     saved_topology = getattr(opt, "enable_topology", True)
     opt.enable_topology = False  # the loop below schedules the operators itself
     try:

@@ -234,6 +234,20 @@ int hgs_hair_params_backward(void* stream, int P, int E, const float* endpoints,
                              float* d_endpoints, float* d_width, float* d_opacity_raw, float* d_mask_raw,
                              const HgsStrandFusion* fusion);
 
+/* hgs_cloud_params_forward/backward: the Stage-I counterpart of hgs_hair_params_* -- the rasterizer-facing getters of the
+ *   Gaussian cloud (scene/gaussian_model.py:118-157) and their autograd in one launch each:
+ *   scale = exp(scaling_raw); quat = rotation_raw / max(|rotation_raw|, 1e-12) (F.normalize); opacity / mask = sigmoid;
+ *   direction = column argmax(scale) of build_rotation(rotation_raw) (get_orientation: the longest axis in world space);
+ *   extra4 = [mask, direction].  backward: g_scale / g_quat / g_opacity / g_extra4 are the rasterizer's gradients;
+ *   `fusion` may carry the densification-statistics group of HgsStrandFusion (its smoothness group is ignored). */
+int hgs_cloud_params_forward(void* stream, int P, const float* scaling_raw, const float* rotation_raw,
+                             const float* opacity_raw, const float* mask_raw, float* scale, float* quat, float* opacity,
+                             float* extra4);
+int hgs_cloud_params_backward(void* stream, int P, const float* scaling_raw, const float* rotation_raw,
+                              const float* opacity, const float* extra4, const float* g_scale, const float* g_quat,
+                              const float* g_opacity, const float* g_extra4, float* d_scaling_raw, float* d_rotation_raw,
+                              float* d_opacity_raw, float* d_mask_raw, const HgsStrandFusion* fusion);
+
 /* hgs_loss_head_forward/backward <-> loss/losses.py:319-355 loss_function on the three rendered images:
  *   total = (1-l_dssim) L1 + l_dssim (1-SSIM) + l_mask BCEWithLogits(mask_img, float_mask) + l_orientation ORI
  *           + l_smooth SMOOTH(endpoints),  terms with weight 0 (or a NULL target) skipped.

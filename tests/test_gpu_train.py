@@ -474,3 +474,70 @@ def test_view_table_select_switches_targets():
         assert ptrs[0] == cams[i].original_image.data_ptr() and ptrs[2] == cams[i].orientation_field.data_ptr()
     with pytest.raises(Exception):
         vt.select(len(cams))
+
+
+def test_fused_cloud_iteration_matches_op_by_op_path():
+    """Stage-I Gaussian cloud: hgs_cloud_params_* + the shared raster / loss head, one autograd node, against the getters
+    (exp / normalize / sigmoid / build_rotation @ one-hot), render_multi, loss_function_single_pass and
+    update_densification_stats: same loss terms, gradients of all 7 parameter groups, statistics."""
+    from arguments import OptimizationParams
+    from hgs_runtime.strand_step import FusedCloudStep, ViewTable
+    from loss.losses import loss_function_single_pass
+    from scene.gaussian_model import GaussianModel
+    from synthetic import build_workload
+    from utils.general import safe_state
+    safe_state(True)
+    _, cams, _ = build_workload("tiny", device="cuda", with_targets=True)       # cameras + targets of the strand scene
+    g = torch.Generator(device="cuda").manual_seed(11)
+    P = 3000
+    m = GaussianModel(sh_degree=1, device="cuda")
+    m._xyz = torch.nn.Parameter((torch.rand(P, 3, device="cuda", generator=g) - 0.5) * 0.25)
+    m._features_dc = torch.nn.Parameter(torch.randn(P, 1, 3, device="cuda", generator=g) * 0.5)
+    m._features_rest = torch.nn.Parameter(torch.randn(P, 3, 3, device="cuda", generator=g) * 0.1)
+    m._scaling = torch.nn.Parameter(torch.log(torch.rand(P, 3, device="cuda", generator=g) * 0.01 + 0.002))
+    m._rotation = torch.nn.Parameter(torch.randn(P, 4, device="cuda", generator=g))       # not unit: normalisation matters
+    m._opacity = torch.nn.Parameter(torch.randn(P, 1, device="cuda", generator=g))
+    m._mask = torch.nn.Parameter(torch.randn(P, 1, device="cuda", generator=g))
+    m.active_sh_degree = 1
+    for name in ("max_radii2D",):
+        setattr(m, name, torch.zeros(P, device="cuda"))
+    m.xyz_gradient_accum, m.denom = torch.zeros(P, 1, device="cuda"), torch.zeros(P, 1, device="cuda")
+    opt = OptimizationParams()
+    bg = torch.zeros(3, device="cuda")
+    params = [m._xyz, m._scaling, m._rotation, m._opacity, m._mask, m._features_dc, m._features_rest]
+    fused = FusedCloudStep(m, ViewTable(cams), opt, bg)
+    for ci, unit in ((1, False), (3, True)):
+        cam = cams[ci]
+        for p in params:
+            p.grad = None
+        for t in (m.max_radii2D, m.xyz_gradient_accum, m.denom):
+            t.zero_()
+        loss, terms, pkg = loss_function_single_pass(m, cam, opt, bg)
+        loss.backward()
+        with torch.no_grad():
+            m.update_densification_stats(pkg["viewspace_points"], pkg["radii"], pkg["visibility_filter"])
+        ref = dict(loss=float(loss), terms={k: float(v) for k, v in terms.items()}, grads=[p.grad.clone() for p in params],
+                   stats=[t.clone() for t in (m.max_radii2D, m.xyz_gradient_accum, m.denom)])
+        for p in params:
+            p.grad = None
+        for t in (m.max_radii2D, m.xyz_gradient_accum, m.denom):
+            t.zero_()
+        fused.views.select(ci)
+        floss, _ = fused.loss()
+        fused.backward(floss) if unit else floss.backward()
+        fused.update_densification_stats()
+        assert abs(float(floss) - ref["loss"]) <= 2e-5 * abs(ref["loss"]), (float(floss), ref["loss"])
+        fterms = {k: float(v) for k, v in fused.terms().items()}
+        for k, v in ref["terms"].items():
+            assert abs(fterms[k] - v) <= 2e-5 * max(abs(v), 1e-3), (k, fterms[k], v)
+        for name, p, gref in zip(("xyz", "scaling", "rotation", "opacity", "mask", "f_dc", "f_rest"), params, ref["grads"]):
+            scale = float(gref.abs().max())
+            # expf / the reciprocal norm differ from torch.exp / F.normalize by an ulp in the rasterizer's INPUTS, which
+            # moves a few alpha >= 1/255 decisions at footprint edges: 1e-3 of the tensor's scale at the worst element,
+            # 1e-5 in the mean
+            d = (p.grad - gref).abs()
+            assert d.max() <= 1e-3 * max(scale, 1e-12), (name, float(d.max()), scale)
+            assert d.mean() <= 1e-5 * max(scale, 1e-12), (name, float(d.mean()), scale)
+        for t, sref in zip((m.max_radii2D, m.xyz_gradient_accum, m.denom), ref["stats"]):
+            assert (t - sref).abs().max() <= 1e-3 * max(float(sref.abs().max()), 1e-12)
+        assert float(m.denom.sum()) > 0
