@@ -541,3 +541,46 @@ def test_fused_cloud_iteration_matches_op_by_op_path():
         for t, sref in zip((m.max_radii2D, m.xyz_gradient_accum, m.denom), ref["stats"]):
             assert (t - sref).abs().max() <= 1e-3 * max(float(sref.abs().max()), 1e-12)
         assert float(m.denom.sum()) > 0
+
+
+def test_fused_iteration_without_view_masks():
+    """Views without masks: no BCE term, the orientation term masks by any(direction != background); the fused head then
+    takes its two-pass route (the mask count depends on the render).  Loss and gradients against the op-by-op path."""
+    from arguments import OptimizationParams
+    from hgs_runtime.strand_step import FusedStrandStep
+    from loss.losses import loss_function_single_pass
+    from synthetic import build_workload
+    from utils.general import safe_state
+    safe_state(True)
+    model, cams, _ = build_workload("tiny", device="cuda", with_targets=True)
+    for c in cams:
+        c.mask = None
+        c.float_mask = None
+    opt = OptimizationParams()
+    model.training_setup(opt)
+    bg = torch.zeros(3, device="cuda")
+    g = torch.Generator(device="cuda").manual_seed(7)
+    with torch.no_grad():
+        model._features_dc.add_(0.2 * torch.randn(model._features_dc.shape, device="cuda", generator=g))
+        model._endpoints.add_(0.003 * torch.randn(model._endpoints.shape, device="cuda", generator=g))
+    params = [model._endpoints, model._width, model._opacity, model._mask, model._features_dc]
+    fused = FusedStrandStep(model, cams, opt, bg)
+    assert not fused.views.has_mask and fused.head.lambda_mask == 0.0
+    cam = cams[1]
+    loss, terms, _ = loss_function_single_pass(model, cam, opt, bg)
+    assert "mask" not in terms
+    loss.backward()
+    ref = [p.grad.clone() for p in params]
+    for p in params:
+        p.grad = None
+    model._derived = None
+    fused.views.select(1)
+    floss, _ = fused.loss()
+    fused.backward(floss)
+    assert abs(float(floss) - float(loss)) <= 2e-5 * abs(float(loss))
+    assert abs(float(fused.terms()["orientation"]) - float(terms["orientation"])) <= 2e-5 * abs(float(terms["orientation"]))
+    for p, gref in zip(params, ref):
+        if gref.abs().max() == 0:
+            assert p.grad.abs().max() == 0
+            continue
+        assert (p.grad - gref).abs().max() <= 3e-4 * float(gref.abs().max())
