@@ -127,7 +127,8 @@ int hgs_dist2(void* stream, int P, const float* points, float* out, void* scratc
  * `window11_host` (the 11 normalised fp32 taps of the Gaussian window, host memory).
  *
  * hgs_ssim_l1_forward/backward <-> loss/losses.py:16-17 (l1_loss) + :43-84 (ssim: five grouped 11x11 conv2d) and
- *   their autograd.  forward writes 3*C*H*W floats of derivative maps + 2 floats per 16x16 block and channel
+ *   their autograd.  forward writes 3*C*H*W floats of derivative maps + 2 floats per 32x32 block and channel
+ *   (hgs_ssim_l1_num_blocks of them)
  *   (partial sums of the SSIM map and of |img1-img2|; the caller sums them and divides by C*H*W).
  *   backward: dL_dimg1 = g_ssim_mean/(CHW) * dSSIM/dimg1 + g_l1_mean/(CHW) * sign(img1-img2), g_* device scalars.
  * hgs_strand_geometry_forward/backward <-> scene/hair_gaussian_model.py:134-201 getters (get_xyz, get_scaling,
@@ -334,7 +335,8 @@ int hgs_binning_layout(int R, size_t* offsets /* [HGS_BIN_NFIELDS] */);
 
 /* status words written by the kernels into image_buf (HGS_IMG_STATUS): [0]=num_rendered, [1]=overflow flag */
 #define HGS_STATUS_WORDS 4
-/* bytes per packed instance record in HGS_BIN_PACKED (12 floats: x,y, conic a,b,c, opacity, r,g,b, id, pad, pad) */
+/* floats per packed instance record in HGS_BIN_PACKED, 3-channel mode: x,y, conic a,b,c, opacity, r,g,b, id, quadrant
+ * mask, pad (the 7-channel mode uses 16: ..., 7 features, id, quadrant mask, pad) */
 #define HGS_PACKED_FLOATS 12
 /* floats per instance in the backward scratch (dmean2D.xy, dconic.xyw, dopacity, dcolor.rgb, pad...) */
 #define HGS_INST_GRAD_FLOATS 12
