@@ -14,6 +14,8 @@ namespace {
 
 #define ADAM_MAX_TENSORS 8
 
+#define ADAM_ELEMS_PER_BLOCK 2048   // 256 threads x 2 float4
+
 struct AdamTensors {
   float* p[ADAM_MAX_TENSORS];
   const float* g[ADAM_MAX_TENSORS];
@@ -21,28 +23,60 @@ struct AdamTensors {
   float* v[ADAM_MAX_TENSORS];
   const float* lr[ADAM_MAX_TENSORS];
   float* step[ADAM_MAX_TENSORS];
-  unsigned long long start[ADAM_MAX_TENSORS + 1];  // prefix of element counts
+  unsigned long long numel[ADAM_MAX_TENSORS];
+  unsigned int blk_start[ADAM_MAX_TENSORS + 1];   // prefix of the tensors' workgroup counts
+  unsigned int vec4;                              // bit k: tensor k's four arrays are 16-byte aligned
   int n;
 };
 
+__device__ __forceinline__ void adam_one(float& p, float g, float& m, float& v, float one_m_b1, float beta2, float step_size,
+                                         float inv_sqrt_bc2, float eps) {
+  m = m + (g - m) * one_m_b1;                                            // lerp, like torch
+  v = beta2 * v + (1.f - beta2) * g * g;
+  p -= step_size * (m / (sqrtf(v) * inv_sqrt_bc2 + eps));
+}
+
+// One tensor per workgroup (uniform index: the bias corrections -- two powf -- and the learning rate are evaluated once
+// per thread, not once per element), 128-bit accesses where the arrays are aligned.
 __global__ __launch_bounds__(256) void adam_kernel(AdamTensors t, float beta1, float beta2, float eps) {
-  const unsigned long long total = t.start[t.n];
-  const unsigned long long stride = (unsigned long long)gridDim.x * 256;
-  for (unsigned long long i = (unsigned long long)blockIdx.x * 256 + threadIdx.x; i < total; i += stride) {
-    int k = 0;
+  int k = 0;
 #pragma unroll
-    for (int j = 1; j < ADAM_MAX_TENSORS; j++) k += (j < t.n && i >= t.start[j]) ? 1 : 0;
-    const unsigned long long e = i - t.start[k];
-    const float step = *t.step[k] + 1.0f;  // the counter itself is advanced by adam_step_kernel afterwards
-    const float g = t.g[k][e];
-    const float m = t.m[k][e] + (g - t.m[k][e]) * (1.f - beta1);        // lerp, like torch
-    const float v = beta2 * t.v[k][e] + (1.f - beta2) * g * g;
-    const float bc1 = 1.f - powf(beta1, step), bc2 = 1.f - powf(beta2, step);
-    const float step_size = *t.lr[k] / bc1;
-    const float denom = sqrtf(v) / sqrtf(bc2) + eps;
-    t.m[k][e] = m;
-    t.v[k][e] = v;
-    t.p[k][e] -= step_size * (m / denom);
+  for (int j = 1; j < ADAM_MAX_TENSORS; j++) k += (j < t.n && blockIdx.x >= t.blk_start[j]) ? 1 : 0;
+  const float step = *t.step[k] + 1.0f;  // the counter itself is advanced by adam_step_kernel afterwards
+  const float bc1 = 1.f - powf(beta1, step), bc2 = 1.f - powf(beta2, step);
+  const float step_size = *t.lr[k] / bc1, inv_sqrt_bc2 = 1.f / sqrtf(bc2), one_m_b1 = 1.f - beta1;
+  const unsigned long long n = t.numel[k];
+  const unsigned long long base = (unsigned long long)(blockIdx.x - t.blk_start[k]) * ADAM_ELEMS_PER_BLOCK;
+  float* __restrict__ P = t.p[k];
+  const float* __restrict__ G = t.g[k];
+  float* __restrict__ M = t.m[k];
+  float* __restrict__ V = t.v[k];
+  if ((t.vec4 >> k) & 1u) {
+#pragma unroll
+    for (int u = 0; u < ADAM_ELEMS_PER_BLOCK / 1024; u++) {
+      const unsigned long long e = base + (unsigned long long)u * 1024 + threadIdx.x * 4;
+      if (e + 3 < n) {
+        float4 p = *(float4*)(P + e), m = *(float4*)(M + e), v = *(float4*)(V + e);
+        const float4 g = *(const float4*)(G + e);
+        adam_one(p.x, g.x, m.x, v.x, one_m_b1, beta2, step_size, inv_sqrt_bc2, eps);
+        adam_one(p.y, g.y, m.y, v.y, one_m_b1, beta2, step_size, inv_sqrt_bc2, eps);
+        adam_one(p.z, g.z, m.z, v.z, one_m_b1, beta2, step_size, inv_sqrt_bc2, eps);
+        adam_one(p.w, g.w, m.w, v.w, one_m_b1, beta2, step_size, inv_sqrt_bc2, eps);
+        *(float4*)(P + e) = p; *(float4*)(M + e) = m; *(float4*)(V + e) = v;
+      } else {
+        for (unsigned long long i = e; i < n && i < e + 4; i++) {
+          float p = P[i], m = M[i], v = V[i];
+          adam_one(p, G[i], m, v, one_m_b1, beta2, step_size, inv_sqrt_bc2, eps);
+          P[i] = p; M[i] = m; V[i] = v;
+        }
+      }
+    }
+  } else {
+    for (unsigned long long i = base + threadIdx.x; i < n && i < base + ADAM_ELEMS_PER_BLOCK; i += 256) {
+      float p = P[i], m = M[i], v = V[i];
+      adam_one(p, G[i], m, v, one_m_b1, beta2, step_size, inv_sqrt_bc2, eps);
+      P[i] = p; M[i] = m; V[i] = v;
+    }
   }
 }
 __global__ void adam_step_kernel(AdamTensors t) {
@@ -91,22 +125,26 @@ int hgs_adam_step(void* stream, int n_tensors, float* const* params, const float
   if (n_tensors > ADAM_MAX_TENSORS) { hgs_set_error("hgs_adam_step: at most %d tensors per call", ADAM_MAX_TENSORS); return 1; }
   AdamTensors t;
   t.n = n_tensors;
-  t.start[0] = 0;
+  t.blk_start[0] = 0;
+  t.vec4 = 0;
   for (int k = 0; k < n_tensors; k++) {
     if (!params[k] || !grads[k] || !exp_avg[k] || !exp_avg_sq[k] || !lr[k] || !step[k] || numel[k] <= 0) {
       hgs_set_error("hgs_adam_step: null pointer or empty tensor %d", k);
       return 1;
     }
     t.p[k] = params[k]; t.g[k] = grads[k]; t.m[k] = exp_avg[k]; t.v[k] = exp_avg_sq[k]; t.lr[k] = lr[k]; t.step[k] = step[k];
-    t.start[k + 1] = t.start[k] + (unsigned long long)numel[k];
+    t.numel[k] = (unsigned long long)numel[k];
+    t.blk_start[k + 1] = t.blk_start[k] + (unsigned int)((t.numel[k] + ADAM_ELEMS_PER_BLOCK - 1) / ADAM_ELEMS_PER_BLOCK);
+    if (!(((size_t)params[k] | (size_t)grads[k] | (size_t)exp_avg[k] | (size_t)exp_avg_sq[k]) & 15)) t.vec4 |= 1u << k;
   }
-  for (int k = n_tensors; k < ADAM_MAX_TENSORS; k++) { t.p[k] = nullptr; t.g[k] = nullptr; t.m[k] = nullptr; t.v[k] = nullptr; t.lr[k] = nullptr; t.step[k] = nullptr; t.start[k + 1] = t.start[n_tensors]; }
+  for (int k = n_tensors; k < ADAM_MAX_TENSORS; k++) {
+    t.p[k] = nullptr; t.g[k] = nullptr; t.m[k] = nullptr; t.v[k] = nullptr; t.lr[k] = nullptr; t.step[k] = nullptr;
+    t.numel[k] = 0; t.blk_start[k + 1] = t.blk_start[n_tensors];
+  }
   hipStream_t s = (hipStream_t)stream;
-  const unsigned long long total = t.start[n_tensors];
-  const unsigned blocks = (unsigned)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
   {
     HgsProfScope _prof(s, HGS_K_ADAM);
-    hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, s, t, beta1, beta2, eps);
+    hipLaunchKernelGGL(adam_kernel, dim3(t.blk_start[n_tensors]), dim3(256), 0, s, t, beta1, beta2, eps);
     hipLaunchKernelGGL(adam_step_kernel, dim3(1), dim3(64), 0, s, t);
   }
   HGS_CHECK_LAUNCH();
