@@ -44,21 +44,30 @@ __device__ __forceinline__ void hgs_smooth_fwd_block(int blk, int N, const float
   if (threadIdx.x == 0) { partials[2 * blk] = bs; partials[2 * blk + 1] = bc; }
 }
 
-// backward of pair i: scatter into d_ep with fp32 atomics; scale = dL/d(term) / max(count, 1)
-__device__ __forceinline__ void hgs_smooth_bwd_pair(int i, const float* __restrict__ ep, const long long* __restrict__ idx,
-                                                    float cos_th, float eps, float scale, float* __restrict__ d_ep) {
+// gradients of pair i w.r.t. its two segment deltas (g0 for delta a = q[1]-q[0], g1 for delta b = q[3]-q[2]); false if the
+// pair contributes nothing (not selected, or clamp saturated).  scale = dL/d(term) / max(count, 1)
+__device__ __forceinline__ bool hgs_smooth_pair_grads(int i, const float* __restrict__ ep, const long long* __restrict__ idx,
+                                                      float cos_th, float eps, float scale, float* g0, float* g1) {
   const long long* q = idx + 4 * (size_t)i;
   const HgsSmoothEval e = hgs_smooth_eval(ep, q, cos_th, eps);
-  if (!e.sel) return;
-  if (!(e.dot > -1.f + eps && e.dot < 1.f - eps)) return;      // clamp saturated: zero gradient
+  if (!e.sel) return false;
+  if (!(e.dot > -1.f + eps && e.dot < 1.f - eps)) return false;  // clamp saturated: zero gradient
   // d(ang^2)/d(dot) = 2 ang * (-1/sqrt(1-dot^2))
   const float gdot = scale * 2.f * e.ang * (-1.f / sqrtf(1.f - e.dot * e.dot));
-  float g0[3], g1[3];                                           // gradients w.r.t. the two segment deltas
 #pragma unroll
   for (int c = 0; c < 3; c++) {
     g0[c] = gdot * (e.d1[c] - e.d0[c] * e.dot) / e.l0;          // (I - d0 d0^T) d1 / |a|
     g1[c] = gdot * (e.d0[c] - e.d1[c] * e.dot) / e.l1;
   }
+  return true;
+}
+
+// backward of pair i: scatter into d_ep with fp32 atomics; scale = dL/d(term) / max(count, 1)
+__device__ __forceinline__ void hgs_smooth_bwd_pair(int i, const float* __restrict__ ep, const long long* __restrict__ idx,
+                                                    float cos_th, float eps, float scale, float* __restrict__ d_ep) {
+  const long long* q = idx + 4 * (size_t)i;
+  float g0[3], g1[3];
+  if (!hgs_smooth_pair_grads(i, ep, idx, cos_th, eps, scale, g0, g1)) return;
 #pragma unroll
   for (int c = 0; c < 3; c++) {
     atomicAdd(&d_ep[3 * q[0] + c], -g0[c]); atomicAdd(&d_ep[3 * q[1] + c], g0[c]);

@@ -62,6 +62,43 @@ __global__ __launch_bounds__(256) void strand_fwd_kernel(int P, const float* __r
   if (extra4) ((float4*)extra4)[k] = make_float4(1.f / (1.f + expf(-mask_raw[k])), ux, uy, uz);  // :97-99 + direction
 }
 
+// Gradient of segment k w.r.t. its two endpoints: endpoint 0 receives h - gD, endpoint 1 receives h + gD
+// (h = half the gradient of the midpoint, gD = gradient w.r.t. delta = e1 - e0 from direction, quaternion and length).
+struct SegGrads { const float* g_xyz; const float* g_scale; const float* g_quat; const float* g_dir; const float* g_extra4; };
+__device__ __forceinline__ void segment_endpoint_grads(int k, const float* __restrict__ ep, const long long* __restrict__ pairs,
+                                                       float f, const SegGrads& sg, float* h, float* gD) {
+  float4 ge = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (sg.g_extra4) ge = ((const float4*)sg.g_extra4)[k];
+  const long long i0 = pairs[2 * (size_t)k], i1 = pairs[2 * (size_t)k + 1];
+  const float dx = ep[3 * i1] - ep[3 * i0], dy = ep[3 * i1 + 1] - ep[3 * i0 + 1], dz = ep[3 * i1 + 2] - ep[3 * i0 + 2];
+  const float L = sqrtf(dx * dx + dy * dy + dz * dz);
+  h[0] = h[1] = h[2] = 0.f;
+  if (sg.g_xyz) { h[0] = 0.5f * sg.g_xyz[3 * (size_t)k]; h[1] = 0.5f * sg.g_xyz[3 * (size_t)k + 1]; h[2] = 0.5f * sg.g_xyz[3 * (size_t)k + 2]; }
+  gD[0] = gD[1] = gD[2] = 0.f;
+  if (L > MINV) {
+    const float il = 1.f / L;
+    const float vx = dx * il, vy = dy * il, vz = dz * il;
+    float gvx = 0.f, gvy = 0.f, gvz = 0.f;  // gradient w.r.t. the unit direction
+    if (sg.g_dir && L >= MINV) { gvx = sg.g_dir[3 * (size_t)k]; gvy = sg.g_dir[3 * (size_t)k + 1]; gvz = sg.g_dir[3 * (size_t)k + 2]; }
+    if (sg.g_extra4 && L >= MINV) { gvx += ge.y; gvy += ge.z; gvz += ge.w; }
+    const float n0 = 1.f + vx;
+    if (sg.g_quat && n0 > MINV) {
+      const float4 gq = ((const float4*)sg.g_quat)[k];
+      const float in = 1.f / sqrtf(n0 * n0 + vz * vz + vy * vy);
+      const float q0 = n0 * in, q2 = -vz * in, q3 = vy * in;
+      const float dot = q0 * gq.x + q2 * gq.z + q3 * gq.w;  // q1 = 0
+      const float gn0 = (gq.x - q0 * dot) * in, gn2 = (gq.z - q2 * dot) * in, gn3 = (gq.w - q3 * dot) * in;
+      gvx += gn0; gvy += gn3; gvz -= gn2;
+    }
+    const float vd = vx * gvx + vy * gvy + vz * gvz;
+    gD[0] = (gvx - vx * vd) * il; gD[1] = (gvy - vy * vd) * il; gD[2] = (gvz - vz * vd) * il;
+    if (sg.g_scale && L / 2.f * f > MINV) {
+      const float gs = sg.g_scale[3 * (size_t)k] * (0.5f * f);
+      gD[0] += gs * vx; gD[1] += gs * vy; gD[2] += gs * vz;
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void strand_bwd_kernel(int P, const float* __restrict__ ep, const long long* __restrict__ pairs,
                                                          const float* __restrict__ width, float f,
                                                          const float* __restrict__ g_xyz, const float* __restrict__ g_scale,
@@ -72,11 +109,44 @@ __global__ __launch_bounds__(256) void strand_bwd_kernel(int P, const float* __r
                                                          float* __restrict__ d_opacity_raw, float* __restrict__ d_mask_raw,
                                                          HgsStrandFusion fu) {
   const int nb_seg = (P + 255) / 256;
-  if ((int)blockIdx.x >= nb_seg) {   // extra workgroups: smoothness gradient scattered into the same d_ep
+  const SegGrads sg = {g_xyz, g_scale, g_quat, g_dir, g_extra4};
+  const float smooth_scale = fu.n_smooth > 0
+      ? fu.head_out[HGS_HEAD_G_SMOOTH] * fu.grad_out[0] / fmaxf(fu.head_out[HGS_HEAD_SMOOTH_COUNT], 1.f) : 0.f;
+  if ((int)blockIdx.x >= nb_seg) {
     const int i = ((int)blockIdx.x - nb_seg) * 256 + threadIdx.x;
-    if (i < fu.n_smooth)
-      hgs_smooth_bwd_pair(i, ep, fu.smooth_pairs, fu.cos_threshold, fu.eps,
-                          fu.head_out[HGS_HEAD_G_SMOOTH] * fu.grad_out[0] / fmaxf(fu.head_out[HGS_HEAD_SMOOTH_COUNT], 1.f), d_ep);
+    if (fu.ep_segments) {
+      // gather mode: one lane per ENDPOINT sums the contributions of its (<= 2) segments and (<= 4) smoothness pair
+      // roles in a fixed order and stores once: no float atomics (each segment / pair is simply evaluated by every
+      // endpoint it touches: ~500 flops per endpoint against 18 L2 atomics per segment)
+      if (i >= fu.n_endpoints) return;
+      float acc[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s = 0; s < 2; s++) {
+        const int code = fu.ep_segments[2 * (size_t)i + s];
+        if (code < 0) continue;
+        float h[3], gD[3];
+        segment_endpoint_grads(code >> 1, ep, pairs, f, sg, h, gD);
+        const float sign = (code & 1) ? 1.f : -1.f;
+#pragma unroll
+        for (int c = 0; c < 3; c++) acc[c] += h[c] + sign * gD[c];
+      }
+      if (fu.ep_pairs && fu.n_smooth > 0) {
+#pragma unroll
+        for (int s = 0; s < 4; s++) {
+          const int code = fu.ep_pairs[4 * (size_t)i + s];
+          if (code < 0) continue;
+          float g0[3], g1[3];
+          if (!hgs_smooth_pair_grads(code >> 2, ep, fu.smooth_pairs, fu.cos_threshold, fu.eps, smooth_scale, g0, g1)) continue;
+          const int role = code & 3;                       // a0: -g0, a1: +g0, b0: -g1, b1: +g1
+          const float sign = (role & 1) ? 1.f : -1.f;
+#pragma unroll
+          for (int c = 0; c < 3; c++) acc[c] += sign * (role < 2 ? g0[c] : g1[c]);
+        }
+      }
+      d_ep[3 * (size_t)i] = acc[0]; d_ep[3 * (size_t)i + 1] = acc[1]; d_ep[3 * (size_t)i + 2] = acc[2];
+    } else if (i < fu.n_smooth) {   // scatter mode: smoothness gradient added into d_ep with atomics
+      hgs_smooth_bwd_pair(i, ep, fu.smooth_pairs, fu.cos_threshold, fu.eps, smooth_scale, d_ep);
+    }
     return;
   }
   const int k = blockIdx.x * 256 + threadIdx.x;
@@ -90,44 +160,17 @@ __global__ __launch_bounds__(256) void strand_bwd_kernel(int P, const float* __r
       fu.denom[k] += 1.f;
     }
   }
-  float4 ge = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (g_extra4) ge = ((const float4*)g_extra4)[k];
   if (d_opacity_raw) { const float o = opacity[k]; d_opacity_raw[k] = g_opacity[k] * o * (1.f - o); }   // sigmoid'
-  if (d_mask_raw) { const float m = extra4[4 * (size_t)k]; d_mask_raw[k] = ge.x * m * (1.f - m); }
-  const long long i0 = pairs[2 * (size_t)k], i1 = pairs[2 * (size_t)k + 1];
-  const float dx = ep[3 * i1] - ep[3 * i0], dy = ep[3 * i1 + 1] - ep[3 * i0 + 1], dz = ep[3 * i1 + 2] - ep[3 * i0 + 2];
-  const float L = sqrtf(dx * dx + dy * dy + dz * dz);
-  float hx = 0.f, hy = 0.f, hz = 0.f;  // gradient w.r.t. the midpoint, split evenly
-  if (g_xyz) { hx = 0.5f * g_xyz[3 * (size_t)k]; hy = 0.5f * g_xyz[3 * (size_t)k + 1]; hz = 0.5f * g_xyz[3 * (size_t)k + 2]; }
-  float gDx = 0.f, gDy = 0.f, gDz = 0.f;  // gradient w.r.t. delta = e1 - e0
+  if (d_mask_raw) { const float m = extra4[4 * (size_t)k]; d_mask_raw[k] = g_extra4[4 * (size_t)k] * m * (1.f - m); }
   float gw = 0.f;
-  if (g_scale) {
-    gw = (g_scale[3 * (size_t)k + 1] + g_scale[3 * (size_t)k + 2]) * expf(width[k]);
+  if (g_scale) gw = (g_scale[3 * (size_t)k + 1] + g_scale[3 * (size_t)k + 2]) * expf(width[k]);
+  if (!fu.ep_segments) {             // scatter mode: this segment's contribution to its two endpoints
+    float h[3], gD[3];
+    segment_endpoint_grads(k, ep, pairs, f, sg, h, gD);
+    const long long i0 = pairs[2 * (size_t)k], i1 = pairs[2 * (size_t)k + 1];
+    atomicAdd(&d_ep[3 * i0], h[0] - gD[0]); atomicAdd(&d_ep[3 * i0 + 1], h[1] - gD[1]); atomicAdd(&d_ep[3 * i0 + 2], h[2] - gD[2]);
+    atomicAdd(&d_ep[3 * i1], h[0] + gD[0]); atomicAdd(&d_ep[3 * i1 + 1], h[1] + gD[1]); atomicAdd(&d_ep[3 * i1 + 2], h[2] + gD[2]);
   }
-  if (L > MINV) {
-    const float il = 1.f / L;
-    const float vx = dx * il, vy = dy * il, vz = dz * il;
-    float gvx = 0.f, gvy = 0.f, gvz = 0.f;  // gradient w.r.t. the unit direction
-    if (g_dir && L >= MINV) { gvx = g_dir[3 * (size_t)k]; gvy = g_dir[3 * (size_t)k + 1]; gvz = g_dir[3 * (size_t)k + 2]; }
-    if (g_extra4 && L >= MINV) { gvx += ge.y; gvy += ge.z; gvz += ge.w; }
-    const float n0 = 1.f + vx;
-    if (g_quat && n0 > MINV) {
-      const float4 gq = ((const float4*)g_quat)[k];
-      const float in = 1.f / sqrtf(n0 * n0 + vz * vz + vy * vy);
-      const float q0 = n0 * in, q2 = -vz * in, q3 = vy * in;
-      const float dot = q0 * gq.x + q2 * gq.z + q3 * gq.w;  // q1 = 0
-      const float gn0 = (gq.x - q0 * dot) * in, gn2 = (gq.z - q2 * dot) * in, gn3 = (gq.w - q3 * dot) * in;
-      gvx += gn0; gvy += gn3; gvz -= gn2;
-    }
-    const float vd = vx * gvx + vy * gvy + vz * gvz;
-    gDx = (gvx - vx * vd) * il; gDy = (gvy - vy * vd) * il; gDz = (gvz - vz * vd) * il;
-    if (g_scale && L / 2.f * f > MINV) {
-      const float gs = g_scale[3 * (size_t)k] * (0.5f * f);
-      gDx += gs * vx; gDy += gs * vy; gDz += gs * vz;
-    }
-  }
-  atomicAdd(&d_ep[3 * i0], hx - gDx); atomicAdd(&d_ep[3 * i0 + 1], hy - gDy); atomicAdd(&d_ep[3 * i0 + 2], hz - gDz);
-  atomicAdd(&d_ep[3 * i1], hx + gDx); atomicAdd(&d_ep[3 * i1 + 1], hy + gDy); atomicAdd(&d_ep[3 * i1 + 2], hz + gDz);
   d_width[k] = gw;
 }
 
@@ -274,6 +317,9 @@ int hgs_hair_params_backward(void* stream, int P, int E, const float* endpoints,
   HgsStrandFusion fu = fusion ? *fusion : HgsStrandFusion{};
   const bool smooth = fu.smooth_pairs && fu.n_smooth > 0 && fu.head_out && fu.grad_out;
   if (!smooth) fu.n_smooth = 0;
+  const bool gather = fu.ep_segments != nullptr;
+  if (gather && fu.n_endpoints != E) { hgs_set_error("hgs_hair_params_backward: HgsStrandFusion.n_endpoints != E"); return 1; }
+  if (!gather) { fu.ep_pairs = nullptr; fu.n_endpoints = 0; }
   if (fu.radii && (!fu.dmean2D || fu.dmean2D_stride < 2 || !fu.max_radii2D || !fu.grad_accum || !fu.denom)) {
     hgs_set_error("hgs_hair_params_backward: incomplete statistics group in HgsStrandFusion");
     return 1;
@@ -283,11 +329,12 @@ int hgs_hair_params_backward(void* stream, int P, int E, const float* endpoints,
     return 1;
   }
   hipStream_t s = (hipStream_t)stream;
-  if (!accumulate_endpoints && hgs_zero_async(s, d_endpoints, (size_t)E * 3 * sizeof(float))) return 1;
-  if (P == 0) return 0;
+  if (!gather && !accumulate_endpoints && hgs_zero_async(s, d_endpoints, (size_t)E * 3 * sizeof(float))) return 1;
+  if (P == 0) return gather ? hgs_zero_async(s, d_endpoints, (size_t)E * 3 * sizeof(float)) : 0;
   {
     HgsProfScope _prof(s, HGS_K_STRAND_BWD);
-    hipLaunchKernelGGL(strand_bwd_kernel, dim3((P + 255) / 256 + (fu.n_smooth + 255) / 256), dim3(256), 0, s, P, endpoints,
+    const int extra = gather ? (E + 255) / 256 : (fu.n_smooth + 255) / 256;
+    hipLaunchKernelGGL(strand_bwd_kernel, dim3((P + 255) / 256 + extra), dim3(256), 0, s, P, endpoints,
                        endpoint_pairs, width, dist_to_scale_factor, g_xyz, g_scale, g_quat, g_dir, d_endpoints, d_width,
                        opacity, extra4, g_opacity, g_extra4, d_opacity_raw, d_mask_raw, fu);
   }

@@ -100,7 +100,8 @@ class StrandFusion(C.Structure):
     """include/hgs.h HgsStrandFusion."""
     _fields_ = [("smooth_pairs", vp), ("n_smooth", ci), ("cos_threshold", cf), ("eps", cf), ("smooth_partials", vp),
                 ("head_out", vp), ("grad_out", vp), ("radii", vp), ("dmean2D", vp), ("dmean2D_stride", ci),
-                ("max_radii2D", vp), ("grad_accum", vp), ("denom", vp)]
+                ("max_radii2D", vp), ("grad_accum", vp), ("denom", vp), ("ep_segments", vp), ("ep_pairs", vp),
+                ("n_endpoints", ci)]
 
 
 HEAD_SKIP_PIXELS, HEAD_SKIP_SMOOTH = 1, 2

@@ -87,6 +87,23 @@ class ViewTable:
         self.current = int(view)
 
 
+def _adjacency(member_ids, roles, n_targets, max_degree):
+    """member_ids: flat int64 [n_items * roles] of target ids (item i, role r at i * roles + r).  Returns the int32 table
+    [n_targets, max_degree] of codes item * roles + role (-1 = empty), or None if some target has more than max_degree."""
+    ids = member_ids.to(torch.int64)
+    if ids.numel() == 0:
+        return torch.full((n_targets, max_degree), -1, dtype=torch.int32, device=ids.device)
+    order = torch.argsort(ids, stable=True)
+    ids_s = ids[order]
+    first = torch.searchsorted(ids_s, ids_s, right=False)
+    slot = torch.arange(ids.numel(), device=ids.device) - first
+    if int(slot.max()) >= max_degree:
+        return None
+    table = torch.full((n_targets, max_degree), -1, dtype=torch.int32, device=ids.device)
+    table[ids_s, slot] = order.to(torch.int32)          # position in the flat array IS item * roles + role
+    return table.contiguous()
+
+
 def head_params(H, W, opt, n_smooth, n_endpoints, min_val, has_float_mask, threshold_deg=30.0, eps=1e-6):
     p = rt.HeadParams()
     p.H, p.W = int(H), int(W)
@@ -224,8 +241,10 @@ class _StrandIteration(torch.autograd.Function):
         dev, P, E = endpoints.device, pairs.shape[0], endpoints.shape[0]
         f32 = dict(dtype=torch.float32, device=dev)
         d_ep = torch.empty((E, 3), **f32)
+        gather = step.ep_segments is not None and step.ep_segments.shape[0] == E   # endpoint adjacency known: no atomics
         go, (g_means2D, g_ex, g_opac, g_means3D, g_sh, g_scales, g_rot) = _head_raster_backward(
-            ctx, step, go, xyz, scale, quat, shs, planes, radii, geom, binning, img, scratch, out, endpoints, d_ep, E)
+            ctx, step, go, xyz, scale, quat, shs, planes, radii, geom, binning, img, scratch, out, endpoints,
+            None if gather else d_ep, E)
         stream = rt.current_stream()
         d_w, d_o, d_m = torch.empty((P, 1), **f32), torch.empty((P, 1), **f32), torch.empty((P, 1), **f32)
         fu = rt.StrandFusion()
@@ -235,6 +254,9 @@ class _StrandIteration(torch.autograd.Function):
             fu.cos_threshold, fu.eps = hp.cos_threshold, hp.eps
             fu.head_out, fu.grad_out = out.data_ptr(), go.data_ptr()
         _stats_group(step, fu, radii, g_means2D)
+        if gather:
+            fu.ep_segments, fu.n_endpoints = step.ep_segments.data_ptr(), E
+            fu.ep_pairs = None if step.ep_pairs is None else step.ep_pairs.data_ptr()
         with torch.cuda.device(dev):
             rt.check(L.hgs_hair_params_backward(stream, P, E, rt.ptr(endpoints), rt.ptr(pairs), rt.ptr(width),
                                                 float(g.dist_to_scale_factor), rt.ptr(opacity), rt.ptr(extra4),
@@ -272,6 +294,15 @@ class FusedStrandStep:
         self.smooth_pairs = rt.require_gpu_tensor(idx, "index_pairs", torch.int64) if n > 0 else None
         self.head = head_params(self.views.H, self.views.W, self.opt, n, g._endpoints.shape[0], g.min_val,
                                 self.views.has_float_mask)
+        # endpoint adjacency for the gather-mode backward (HgsStrandFusion.ep_segments / ep_pairs): an endpoint of a
+        # chain touches <= 2 segments and <= 4 smoothness-pair roles; anything denser keeps the scatter (atomic) mode
+        E = g._endpoints.shape[0]
+        self.ep_segments = _adjacency(g.endpoint_pairs.reshape(-1), 2, E, 2)
+        self.ep_pairs = None
+        if self.ep_segments is not None and self.smooth_pairs is not None:
+            self.ep_pairs = _adjacency(self.smooth_pairs.reshape(-1), 4, E, 4)
+            if self.ep_pairs is None:
+                self.ep_segments = None
 
     def loss(self):
         """(total loss, terms tensor) of the CURRENT slot view; differentiable w.r.t. the model parameters."""

@@ -223,6 +223,11 @@ typedef struct HgsStrandFusion {
   const float* head_out; const float* grad_out;    /* backward in (device) */
   const int* radii; const float* dmean2D; int dmean2D_stride;   /* backward in: statistics inputs */
   float* max_radii2D; float* grad_accum; float* denom;          /* backward in/out */
+  /* backward, gather mode: adjacency of the endpoints.  ep_segments [E][2]: 2 * segment + (0|1 = which end of it), -1 =
+   * none; ep_pairs [E][4]: 4 * smoothness pair + role (0..3 = a0, a1, b0, b1), -1 = none.  When ep_segments is given,
+   * d_endpoints is written with ONE plain store per endpoint (one extra workgroup range recomputes the adjacent segments'
+   * and pairs' contributions): no float atomics, bitwise reproducible, and accumulate_endpoints is ignored. */
+  const int* ep_segments; const int* ep_pairs; int n_endpoints;
 } HgsStrandFusion;
 int hgs_hair_params_forward(void* stream, int P, const float* endpoints, const long long* endpoint_pairs,
                             const float* width, float dist_to_scale_factor, const float* opacity_raw,

@@ -584,3 +584,34 @@ def test_fused_iteration_without_view_masks():
             assert p.grad.abs().max() == 0
             continue
         assert (p.grad - gref).abs().max() <= 3e-4 * float(gref.abs().max())
+
+
+def test_fused_iteration_is_bitwise_reproducible():
+    """No float atomics anywhere in the fused strand iteration (blend backward: fixed-order partial sums; endpoints:
+    gather over the adjacency tables): two evaluations from the same state give bit-identical loss and gradients."""
+    from arguments import OptimizationParams
+    from hgs_runtime.strand_step import FusedStrandStep
+    from synthetic import build_workload
+    from utils.general import safe_state
+    safe_state(True)
+    model, cams, _ = build_workload("tiny", device="cuda", with_targets=True)
+    opt = OptimizationParams()
+    model.training_setup(opt)
+    with torch.no_grad():
+        model._endpoints.add_(0.002 * torch.randn_like(model._endpoints))
+    fused = FusedStrandStep(model, cams, opt, torch.zeros(3, device="cuda"))
+    assert fused.ep_segments is not None and fused.ep_pairs is not None
+    deg = (fused.ep_segments >= 0).sum(dim=1)
+    assert int(deg.min()) >= 1 and int(deg.max()) == 2
+    params = [model._endpoints, model._width, model._opacity, model._mask, model._features_dc]
+    runs = []
+    for _ in range(2):
+        for p in params:
+            p.grad = None
+        fused.views.select(2)
+        loss, _ = fused.loss()
+        fused.backward(loss)
+        runs.append((loss.detach().clone(), [p.grad.clone() for p in params]))
+    assert torch.equal(runs[0][0], runs[1][0])
+    for a, b in zip(runs[0][1], runs[1][1]):
+        assert torch.equal(a, b)
