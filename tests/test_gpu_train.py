@@ -615,3 +615,34 @@ def test_fused_iteration_is_bitwise_reproducible():
     assert torch.equal(runs[0][0], runs[1][0])
     for a, b in zip(runs[0][1], runs[1][1]):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_stage1_training_loop_with_densification(use_graph):
+    """training() on the Stage-I cloud through the fused cloud iteration: densification (clone / split / prune) and the
+    opacity reset change the number of Gaussians; the optimizer state, the statistics and -- in graph mode -- the
+    captured graph follow."""
+    from arguments import OptimizationParams
+    from synthetic import attach_targets, cameras_extent, make_cameras, make_cloud_model
+    from train import training
+    from utils.general import safe_state
+    safe_state(True)
+    cams = make_cameras(4, 200, 120, device="cuda")
+    model = make_cloud_model(3000, device="cuda", spatial_lr_scale=cameras_extent(cams))
+    attach_targets(cams, model)
+    opt = OptimizationParams()
+    opt.densify_from_iter, opt.densification_interval, opt.opacity_reset_interval = 2, 5, 12
+    opt.densify_grad_threshold = 1e-7            # make the tiny scene densify
+    model.training_setup(opt)
+    P0 = model.get_xyz.shape[0]
+    ema = training(model, cams, opt, iterations=16, extent=cameras_extent(cams), use_graph=use_graph)
+    assert torch.isfinite(ema)
+    P1 = model.get_xyz.shape[0]
+    assert P1 != P0
+    for grp in model.optimizer.param_groups:
+        p = grp["params"][0]
+        st = model.optimizer.state[p]
+        assert p.shape[0] == P1
+        if p.numel() and "exp_avg" in st:     # (empty f_rest at SH degree 0 is never stepped)
+            assert st["exp_avg"].shape == p.shape and st["exp_avg_sq"].shape == p.shape
+    assert model.max_radii2D.shape[0] == P1 and model.denom.shape[0] == P1
