@@ -121,6 +121,15 @@ __device__ __forceinline__ void col_pass(const SsimWin& win, float (*hz)[TILE][H
 //    (3 blocks of 44 KB LDS fit a CU: too few to hide it by occupancy alone).
 struct SsimGrid { int nbx, nby, C, chunk, total; };
 struct SsimBlock { int c, bx0, by0, logical; };
+__device__ __forceinline__ void ssim_block_decode(const SsimGrid& gd, int logical, SsimBlock& o) {
+  o.logical = logical;
+  const int per = gd.nbx * gd.nby;
+  o.c = logical / per;
+  const int r = logical - o.c * per;
+  const int by = r / gd.nbx;
+  o.by0 = by * LT;
+  o.bx0 = (r - by * gd.nbx) * LT;
+}
 __device__ __forceinline__ bool ssim_block(const SsimGrid& gd, int j, SsimBlock& o) {
   o.logical = (blockIdx.x & 7) * gd.chunk + j;
   if (j >= gd.chunk || o.logical >= gd.total) return false;
@@ -180,7 +189,12 @@ __device__ __forceinline__ void stage_store(const TileStage<NP>& st, float (*t)[
 
 __global__ __launch_bounds__(256) void ssim_l1_fwd_kernel(int H, int W, SsimGrid gd, SsimWin win, const float* __restrict__ img1,
                                                           const float* __restrict__ img2_, const HgsViewTargets* __restrict__ tgt,
-                                                          float* __restrict__ dmap, float* __restrict__ partials) {
+                                                          float* __restrict__ dmap, float* __restrict__ partials,
+                                                          unsigned char* __restrict__ zero_flags) {
+  // zero_flags (may be NULL): flag per block = "both images are exactly zero on the block's whole halo tile".  Hair
+  // renders and their targets are black outside the hair: such a block's filtered maps are all zero, so the two filter
+  // passes are skipped (the epilogue below then evaluates the same expressions on zeros, bit for bit what the full path
+  // would produce), and the backward skips blocks whose 3x3 neighbourhood is flagged (its result is exactly zero).
   __shared__ float t[2][TILE][TPW];
   __shared__ float hz[4][TILE][HP];   // mu1, mu2, E[x1^2 + x2^2], E[x1 x2]: S only needs the SUM of the two variances
   __shared__ float red[4];
@@ -195,19 +209,38 @@ __global__ __launch_bounds__(256) void ssim_l1_fwd_kernel(int H, int W, SsimGrid
   if (fast && have) stage_load<2>(st, H, W, bk.bx0, bk.by0, [&](int p) { return (p == 0 ? img1 : img2) + bk.c * plane; });
   const int lx = threadIdx.x & (LT - 1), y0 = (threadIdx.x >> 5) * 4;
   while (have) {
-    if (fast) stage_store<2>(st, t);
-    else load_tiles<2>(t, H, W, bk.bx0, bk.by0, [&](int p) { return (p == 0 ? img1 : img2) + bk.c * plane; });
-    __syncthreads();
+    int nz = 1;                                   // does this thread's share of the tile hold a non-zero value?
+    if (fast) {
+      stage_store<2>(st, t);
+      if (zero_flags) {
+        nz = 0;
+#pragma unroll
+        for (int p = 0; p < 2; p++)
+#pragma unroll
+          for (int u = 0; u < 2; u++) nz |= (st.v[p][u].x != 0.f) | (st.v[p][u].y != 0.f) | (st.v[p][u].z != 0.f) | (st.v[p][u].w != 0.f);
+      }
+    } else {
+      load_tiles<2>(t, H, W, bk.bx0, bk.by0, [&](int p) { return (p == 0 ? img1 : img2) + bk.c * plane; });
+    }
+    const int any_nz = __syncthreads_or(nz);      // (also the barrier that publishes the tile)
     j += nwg;
     const bool have_next = ssim_block(gd, j, nx);
     if (fast && have_next) stage_load<2>(st, H, W, nx.bx0, nx.by0, [&](int p) { return (p == 0 ? img1 : img2) + nx.c * plane; });
-    row_pass<4>(win, hz, [&](int r, int x, float* v) {   // x = tile column of the tap: image x = bx0 - HALO + x
-      const float a = t[0][r][x + XOFF - HALO], b = t[1][r][x + XOFF - HALO];
-      v[0] = a; v[1] = b; v[2] = a * a + b * b; v[3] = a * b;
-    });
-    __syncthreads();
     float f[4][4];
-    col_pass<4>(win, hz, lx, y0, f);
+    if (any_nz) {
+      row_pass<4>(win, hz, [&](int r, int x, float* v) {   // x = tile column of the tap: image x = bx0 - HALO + x
+        const float a = t[0][r][x + XOFF - HALO], b = t[1][r][x + XOFF - HALO];
+        v[0] = a; v[1] = b; v[2] = a * a + b * b; v[3] = a * b;
+      });
+      __syncthreads();
+      col_pass<4>(win, hz, lx, y0, f);
+    } else {
+#pragma unroll
+      for (int q = 0; q < 4; q++)
+#pragma unroll
+        for (int o = 0; o < 4; o++) f[q][o] = 0.f;
+    }
+    if (zero_flags && threadIdx.x == 0) zero_flags[bk.logical] = any_nz ? 0 : 1;
     const float C1 = 0.01f * 0.01f, C2 = 0.03f * 0.03f;
     const int px = bk.bx0 + lx;
     float ssim_v = 0.f, l1_v = 0.f;
@@ -250,7 +283,7 @@ __global__ __launch_bounds__(256) void ssim_l1_bwd_kernel(int H, int W, SsimGrid
                                                           const float* __restrict__ g_ssim_mean,
                                                           const float* __restrict__ g_l1_mean, const float* __restrict__ go,
                                                           float* __restrict__ dimg1, float* __restrict__ zero_buf,
-                                                          int zero_n) {
+                                                          int zero_n, const int* __restrict__ lists) {
   // (the loss head's endpoint-gradient buffer is cleared here, in passing: saves a launch before the smoothness scatter)
   for (int i = blockIdx.x * 256 + threadIdx.x; i < zero_n; i += gridDim.x * 256) zero_buf[i] = 0.f;
   __shared__ float t[3][TILE][TPW];
@@ -265,7 +298,39 @@ __global__ __launch_bounds__(256) void ssim_l1_bwd_kernel(int H, int W, SsimGrid
   const int lx = threadIdx.x & (LT - 1), y0 = (threadIdx.x >> 5) * 4;
   int j = blockIdx.x >> 3;
   SsimBlock bk, nx;
-  bool have = ssim_block(gd, j, bk);
+  // `lists` (the loss head's forward built it, head_finalize_kernel): the blocks whose gradient is not identically zero, in
+  // logical order, and the rest.  Each XCD takes an equal contiguous share of the first list (the halo sharing in its L2
+  // is kept, and the work is balanced however the hair sits in the frame); the second list is only zero-filled.
+  const int xcd = blockIdx.x & 7;
+  int lo = 0, hi = 0, id1 = 0;
+  const int* work = nullptr;
+  if (lists) {
+    const int n_work = lists[0], n_skip = lists[1];
+    work = lists + 4;
+    const int* skipped = work + gd.total;
+    lo = (int)(((long long)n_work * xcd) >> 3);
+    hi = (int)(((long long)n_work * (xcd + 1)) >> 3);
+    for (int q = blockIdx.x; q < n_skip; q += gridDim.x) {
+      SsimBlock z;
+      ssim_block_decode(gd, skipped[q], z);
+      const int px = z.bx0 + lx;
+#pragma unroll
+      for (int o = 0; o < 4; o++) {
+        const int py = z.by0 + y0 + o;
+        if (px < W && py < H) dimg1[z.c * plane + (size_t)py * W + px] = 0.f;
+      }
+    }
+  }
+  // next(j): the j-th block of this workgroup; with a list its id was loaded one block ahead (id1)
+  auto fetch_id = [&](int jj) { return (work && lo + jj < hi) ? work[lo + jj] : 0; };
+  auto block_at = [&](int jj, int id, SsimBlock& o) {
+    if (!work) return ssim_block(gd, jj, o);
+    if (lo + jj >= hi) return false;
+    ssim_block_decode(gd, id, o);
+    return true;
+  };
+  bool have = block_at(j, fetch_id(j), bk);
+  id1 = fetch_id(j + nwg);
   TileStage<3> st;
   float x1[4], x2[4];                              // the block's own pixels of both images, fetched with the tile
   auto centre = [&](const SsimBlock& q) {
@@ -288,7 +353,8 @@ __global__ __launch_bounds__(256) void ssim_l1_bwd_kernel(int H, int W, SsimGrid
     for (int o = 0; o < 4; o++) { c1[o] = x1[o]; c2[o] = x2[o]; }
     __syncthreads();
     j += nwg;
-    const bool have_next = ssim_block(gd, j, nx);
+    const bool have_next = block_at(j, id1, nx);
+    id1 = fetch_id(j + nwg);
     if (have_next) {
       if (fast) stage_load<3>(st, H, W, nx.bx0, nx.by0, [&](int p) { return dmap + p * cp + nx.c * plane; });
       centre(nx);
@@ -421,9 +487,27 @@ __device__ __forceinline__ void ori_pixel_grad(const OriParams& p, float px, flo
 __global__ __launch_bounds__(256) void pix_fwd_kernel(int N, HeadFlags fl, float bg0, float bg1, float bg2, float min_val,
                                                       const float* __restrict__ mask_img, const float* __restrict__ omap,
                                                       const HgsViewTargets* __restrict__ tgt, float* __restrict__ partials,
-                                                      float g_mask, float g_ori, float* __restrict__ d_unit) {
+                                                      float g_mask, float g_ori, float* __restrict__ d_unit, SsimGrid gd,
+                                                      const unsigned char* __restrict__ zero_flags,
+                                                      unsigned char* __restrict__ work_flags) {
   __shared__ float red[4];
   const int i = blockIdx.x * 256 + threadIdx.x;
+  // In passing (the SSIM forward before this launch flagged the blocks whose halo tile is exactly zero in both images):
+  // work_flags[b] = 0 when the whole 3x3 neighbourhood of SSIM block b is flagged.  Such a block has a = dS/dmu1 == 0 on
+  // its halo tile and x1 == x2 == 0 on its own pixels, so its gradient is exactly zero and the backward reads nothing for it.
+  if (work_flags && i < gd.total) {
+    const int per = gd.nbx * gd.nby;
+    const int c = i / per, r = i - c * per, by = r / gd.nbx, bx = r - by * gd.nbx;
+    int zero = 1;
+#pragma unroll
+    for (int dy = -1; dy <= 1; dy++)
+#pragma unroll
+      for (int dx = -1; dx <= 1; dx++) {
+        const int xx = min(max(bx + dx, 0), gd.nbx - 1), yy = min(max(by + dy, 0), gd.nby - 1);   // (outside the frame: zero)
+        zero &= zero_flags[c * per + yy * gd.nbx + xx];
+      }
+    work_flags[i] = zero ? 0 : 1;
+  }
   float s = 0.f, cnt = 0.f, b = 0.f;
   if (i < N) {
     float gm = 0.f, g0 = 0.f, g1 = 0.f, g2 = 0.f;
@@ -493,6 +577,7 @@ __global__ __launch_bounds__(256) void pix_bwd_kernel(int N, HeadFlags fl, float
 struct HeadReduce { int nb_ssim, nb_pix, nb_smooth; float inv_chw, inv_hw; float l_dssim, l_mask, l_ori, l_smooth; int bce, ori; };
 
 #define FIN_THREADS 1024
+#define HEAD_MAX_FLAGGED 32768   // SSIM blocks of a frame the backward's block lists are built for (4K RGB: 24480)
 __device__ __forceinline__ float block_sum_1024(float v, float* red16) {
 #pragma unroll
   for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
@@ -519,8 +604,46 @@ __device__ __forceinline__ void strided_acc(const float* __restrict__ a, int n, 
 
 __global__ __launch_bounds__(FIN_THREADS) void head_finalize_kernel(HeadReduce h, const float* __restrict__ p_ssim,
                                                                     const float* __restrict__ p_pix,
-                                                                    const float* __restrict__ p_smooth, float* __restrict__ out) {
+                                                                    const float* __restrict__ p_smooth, float* __restrict__ out,
+                                                                    SsimGrid gd, const unsigned char* __restrict__ work_flags,
+                                                                    int* __restrict__ lists) {
   __shared__ float red[FIN_THREADS / 64];
+  if (lists) {
+    // Block lists of the SSIM backward from pix_fwd_kernel's work flags:
+    // lists = [n_work, n_skip, -, -][ids of the blocks with a non-zero gradient, logical order][the other ids].
+    __shared__ int wsum[FIN_THREADS / 64];
+    const int per_thread = (gd.total + FIN_THREADS - 1) / FIN_THREADS;   // <= 32 (HEAD_MAX_FLAGGED)
+    const int first = threadIdx.x * per_thread;
+    unsigned bits = 0;
+    for (int k = 0; k < per_thread; k++)
+      if (first + k < gd.total && work_flags[first + k]) bits |= 1u << k;
+    const int cnt = __popc(bits);
+    int inc = cnt;                                  // inclusive scan over the wave, then over the 16 wave totals
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const int v = __shfl_up(inc, d, 64);
+      if ((int)(threadIdx.x & 63) >= d) inc += v;
+    }
+    if ((threadIdx.x & 63) == 63) wsum[threadIdx.x >> 6] = inc;
+    __syncthreads();
+    int base = 0, all = 0;
+#pragma unroll
+    for (int k = 0; k < FIN_THREADS / 64; k++) {
+      const int v = wsum[k];
+      if (k < (int)(threadIdx.x >> 6)) base += v;
+      all += v;
+    }
+    int w = base + inc - cnt;                       // work blocks before this thread's first block
+    int* work = lists + 4;
+    int* skipped = work + gd.total;
+    for (int k = 0; k < per_thread; k++) {
+      const int id = first + k;
+      if (id >= gd.total) break;
+      if (bits >> k & 1) work[w++] = id;
+      else skipped[id - w] = id;
+    }
+    if (threadIdx.x == 0) { lists[0] = all; lists[1] = gd.total - all; }
+  }
   float a2[2], a3[3], s2[2];
   strided_acc<2>(p_ssim, h.nb_ssim, a2);
   strided_acc<3>(p_pix, h.nb_pix, a3);
@@ -567,7 +690,7 @@ int hgs_ssim_l1_forward(void* stream, int C, int H, int W, const float* window11
   {
     HgsProfScope _prof(s, HGS_K_SSIM_FWD);
     hipLaunchKernelGGL(ssim_l1_fwd_kernel, dim3(ssim_grid_size(ssim_grid(C, H, W), SSIM_FWD_WG_PER_XCD)), dim3(256), 0, s, H, W, ssim_grid(C, H, W), win, img1,
-                       img2, (const HgsViewTargets*)nullptr, dmaps, partials);
+                       img2, (const HgsViewTargets*)nullptr, dmaps, partials, (unsigned char*)nullptr);
   }
   HGS_CHECK_LAUNCH();
   return 0;
@@ -586,7 +709,7 @@ int hgs_ssim_l1_backward(void* stream, int C, int H, int W, const float* window1
     HgsProfScope _prof(s, HGS_K_SSIM_BWD);
     hipLaunchKernelGGL(ssim_l1_bwd_kernel, dim3(ssim_grid_size(ssim_grid(C, H, W), SSIM_BWD_WG_PER_XCD)), dim3(256), 0, s, H, W, ssim_grid(C, H, W), win, img1,
                        img2, (const HgsViewTargets*)nullptr, dmaps, g_ssim_mean, g_l1_mean, (const float*)nullptr, dL_dimg1,
-                       (float*)nullptr, 0);
+                       (float*)nullptr, 0, (const int*)nullptr);
   }
   HGS_CHECK_LAUNCH();
   return 0;
@@ -637,9 +760,21 @@ int hgs_orientation_loss_backward(void* stream, int H, int W, const float* omap,
 static inline int head_nb_ssim(const HgsHeadParams* p) { return ((p->W + LT - 1) / LT) * ((p->H + LT - 1) / LT) * 3; }
 static inline int head_nb_pix(const HgsHeadParams* p) { return (int)(((size_t)p->H * p->W + 255) / 256); }
 static inline int head_nb_smooth(const HgsHeadParams* p) { return p->lambda_smooth > 0.f ? (p->n_smooth + 255) / 256 : 0; }
-// scratch: [dmaps 9*H*W][ssim partials 2*nb][pix partials 3*nb][smooth partials 2*nb]
-size_t hgs_loss_head_scratch_floats(const HgsHeadParams* p) {
+// scratch: [dmaps 9*H*W][ssim partials 2*nb][pix partials 3*nb][smooth partials 2*nb][all-zero flags, 1 byte per SSIM block][work flags][block lists]
+static inline size_t head_flags_offset(const HgsHeadParams* p) {
   return 9 * (size_t)p->H * p->W + 2 * (size_t)head_nb_ssim(p) + 3 * (size_t)head_nb_pix(p) + 2 * (size_t)head_nb_smooth(p) + 8;
+}
+static inline size_t head_flag_floats(const HgsHeadParams* p) { return ((size_t)head_nb_ssim(p) + 3) / 4 + 4; }
+static inline unsigned char* head_zero_flags(const HgsHeadParams* p, float* scratch) { return (unsigned char*)(scratch + head_flags_offset(p)); }
+static inline unsigned char* head_work_flags(const HgsHeadParams* p, float* scratch) { return (unsigned char*)(scratch + head_flags_offset(p) + head_flag_floats(p)); }
+// [n_work, n_skip, -, -][work ids][skipped ids] after the flags; NULL when the frame has more blocks than the finalize
+// kernel's LDS copy of the flags holds (the backward then walks every block)
+static inline int* head_block_lists(const HgsHeadParams* p, float* scratch) {
+  if (head_nb_ssim(p) > HEAD_MAX_FLAGGED) return nullptr;
+  return (int*)(scratch + head_flags_offset(p) + 2 * head_flag_floats(p));
+}
+size_t hgs_loss_head_scratch_floats(const HgsHeadParams* p) {
+  return head_flags_offset(p) + 2 * head_flag_floats(p) + 4 + 2 * (size_t)head_nb_ssim(p) + 4;
 }
 
 int hgs_loss_head_forward(void* stream, const HgsHeadParams* p, const float* image, const float* mask_img,
@@ -663,7 +798,7 @@ int hgs_loss_head_forward(void* stream, const HgsHeadParams* p, const float* ima
   {
     HgsProfScope _prof(s, HGS_K_SSIM_FWD);
     hipLaunchKernelGGL(ssim_l1_fwd_kernel, dim3(ssim_grid_size(ssim_grid(3, H, W), SSIM_FWD_WG_PER_XCD)), dim3(256), 0, s, H, W, ssim_grid(3, H, W), win, image,
-                       (const float*)nullptr, targets, dmaps, p_ssim);
+                       (const float*)nullptr, targets, dmaps, p_ssim, head_block_lists(p, scratch) ? head_zero_flags(p, scratch) : nullptr);
   }
   HeadFlags fl;
   fl.bce = p->lambda_mask > 0.f; fl.ori = p->lambda_orientation > 0.f;   // a NULL float_mask with lambda_mask > 0 is the caller's error
@@ -671,7 +806,8 @@ int hgs_loss_head_forward(void* stream, const HgsHeadParams* p, const float* ima
     HgsProfScope _prof(s, HGS_K_ORI_FWD);
     hipLaunchKernelGGL(pix_fwd_kernel, dim3(nbp), dim3(256), 0, s, N, fl, p->bg[0], p->bg[1], p->bg[2], p->min_val, mask_img,
                        omap, targets, p_pix, fl.bce ? p->lambda_mask / (float)N : 0.f, fl.ori ? p->lambda_orientation : 0.f,
-                       d_extra_unit);
+                       d_extra_unit, ssim_grid(3, H, W), (const unsigned char*)head_zero_flags(p, scratch),
+                       head_block_lists(p, scratch) ? head_work_flags(p, scratch) : nullptr);
   }
   if (nbm > 0 && !smooth_partials_ext &&
       hgs_launch_smooth_fwd(s, p->n_smooth, endpoints, smooth_pairs, p->cos_threshold, p->eps, p_pix + 3 * (size_t)nbp)) return 1;
@@ -682,7 +818,8 @@ int hgs_loss_head_forward(void* stream, const HgsHeadParams* p, const float* ima
   h.bce = fl.bce; h.ori = fl.ori;
   {
     HgsProfScope _prof(s, HGS_K_HEAD);
-    hipLaunchKernelGGL(head_finalize_kernel, dim3(1), dim3(FIN_THREADS), 0, s, h, p_ssim, p_pix, p_smooth, out);
+    hipLaunchKernelGGL(head_finalize_kernel, dim3(1), dim3(FIN_THREADS), 0, s, h, p_ssim, p_pix, p_smooth, out, ssim_grid(3, H, W),
+                       (const unsigned char*)head_work_flags(p, scratch), head_block_lists(p, scratch));
   }
   HGS_CHECK_LAUNCH();
   return 0;
@@ -709,7 +846,7 @@ int hgs_loss_head_backward(void* stream, const HgsHeadParams* p, const float* im
     HgsProfScope _prof(s, HGS_K_SSIM_BWD);
     hipLaunchKernelGGL(ssim_l1_bwd_kernel, dim3(ssim_grid_size(ssim_grid(3, H, W), SSIM_BWD_WG_PER_XCD)), dim3(256), 0, s, H, W, ssim_grid(3, H, W), win, image,
                        (const float*)nullptr, targets, dmaps, out + HGS_HEAD_G_SSIM, out + HGS_HEAD_G_L1, grad_out, d_image,
-                       d_endpoints, d_endpoints ? p->n_endpoints * 3 : 0);
+                       d_endpoints, d_endpoints ? p->n_endpoints * 3 : 0, head_block_lists(p, (float*)scratch));
   }
   HeadFlags fl;
   fl.bce = p->lambda_mask > 0.f; fl.ori = p->lambda_orientation > 0.f;

@@ -646,3 +646,68 @@ def test_stage1_training_loop_with_densification(use_graph):
         if p.numel() and "exp_avg" in st:     # (empty f_rest at SH degree 0 is never stepped)
             assert st["exp_avg"].shape == p.shape and st["exp_avg_sq"].shape == p.shape
     assert model.max_radii2D.shape[0] == P1 and model.denom.shape[0] == P1
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("hw", [(200, 328), (96, 64), (70, 132)])
+def test_loss_head_skips_all_zero_blocks_exactly(hw):
+    """The loss head's SSIM kernels skip blocks that are exactly zero in render and target (forward: no filter passes;
+    backward: blocks whose 3x3 block neighbourhood is zero are only zero-filled, the rest is split evenly over the XCDs
+    through a compacted list).  The result has to be what the stand-alone hgs_ssim_l1_* kernels (which walk every block)
+    produce, and the block lists have to partition the frame."""
+    import ctypes as C
+    import numpy as np
+    import hgs_runtime as rt
+    from arguments import OptimizationParams
+    from hgs_runtime.fused import ssim_l1
+    from hgs_runtime.strand_step import head_params
+    H, W = hw
+    dev = torch.device("cuda")
+    g = torch.Generator(device="cuda").manual_seed(11)
+    rnd = lambda *s: torch.rand(*s, device=dev, generator=g)
+    image, gt = torch.zeros(3, H, W, device=dev), torch.zeros(3, H, W, device=dev)
+    y0, y1, x0, x1 = H // 3, H // 3 + H // 4, W // 4, W // 4 + W // 5
+    image[:, y0:y1, x0:x1] = rnd(3, y1 - y0, x1 - x0)
+    gt[:, y0 + 2:y1 + 2, x0 - 3:x1 - 3] = rnd(3, y1 - y0, x1 - x0)
+    mask_img, omap = rnd(H, W) * 4 - 2, rnd(3, H, W)
+    fmask, ori, conf = (rnd(H, W) > 0.5).float(), rnd(H, W) * 3.14159, rnd(H, W)
+    m8 = (rnd(H, W) > 0.3).to(torch.uint8)
+    row = rt.ViewTargets()
+    row.image, row.float_mask, row.orientation, row.confidence, row.mask = (t.data_ptr() for t in (gt, fmask, ori, conf, m8))
+    for k, v in enumerate(np.eye(4, dtype=np.float32).reshape(-1)):
+        row.viewmatrix[k] = row.projmatrix[k] = float(v)
+    row.mask_count = float(m8.sum().item())
+    targets = torch.from_numpy(np.frombuffer(bytes(row), dtype=np.uint8).copy()).to(dev)
+    opt = OptimizationParams()
+    hp = head_params(H, W, opt, 0, 0, 1e-6, True)
+    L = rt.lib()
+    scratch = torch.empty(L.hgs_loss_head_scratch_floats(C.byref(hp)), device=dev)
+    out = torch.zeros(rt.HEAD_NOUT, device=dev)
+    d_img, d_mask, d_omap = torch.full((3, H, W), 7.0, device=dev), torch.empty(H, W, device=dev), torch.empty(3, H, W, device=dev)
+    one = torch.ones(1, device=dev)
+    rt.check(L.hgs_loss_head_forward(rt.current_stream(), C.byref(hp), image.data_ptr(), mask_img.data_ptr(), omap.data_ptr(),
+                                     targets.data_ptr(), None, None, scratch.data_ptr(), out.data_ptr(), None, None))
+    rt.check(L.hgs_loss_head_backward(rt.current_stream(), C.byref(hp), image.data_ptr(), mask_img.data_ptr(), omap.data_ptr(),
+                                      targets.data_ptr(), None, None, scratch.data_ptr(), out.data_ptr(), one.data_ptr(), 0,
+                                      d_img.data_ptr(), d_mask.data_ptr(), d_omap.data_ptr(), None))
+    # stand-alone kernels: every block is filtered
+    a = image.clone().requires_grad_(True)
+    s, l1 = ssim_l1(a, gt)
+    ((1.0 - opt.lambda_dssim) * l1 + opt.lambda_dssim * (1.0 - s)).backward()
+    o = dict(zip(rt.HEAD_OUT, out.tolist()))
+    assert abs(o["l1"] - float(l1)) <= 1e-6 * max(float(l1), 1e-6)
+    assert abs(o["dssim"] - float(1.0 - s)) <= 2e-6
+    assert torch.equal(d_img, a.grad)
+    # block lists (white box: [n_work, n_skip, -, -][work ids][skipped ids] close the scratch buffer)
+    nbs = 3 * ((H + 31) // 32) * ((W + 31) // 32)
+    lists = scratch.view(torch.int32)[scratch.numel() - (2 * nbs + 8):].cpu()
+    n_work, n_skip = int(lists[0]), int(lists[1])
+    assert n_work + n_skip == nbs
+    work, skipped = lists[4:4 + n_work], lists[4 + nbs:4 + nbs + n_skip]
+    assert sorted(work.tolist() + skipped.tolist()) == list(range(nbs))
+    assert work.tolist() == sorted(work.tolist())
+    if (H, W) == (200, 328):
+        assert n_skip > 0 and n_work > 0
+    # skipped blocks carry no gradient; every block with gradient is on the work list
+    gb = torch.nn.functional.max_pool2d(torch.nn.functional.pad((a.grad != 0).float(), (0, (-W) % 32, 0, (-H) % 32))[None], 32)[0]
+    assert not gb.reshape(-1)[skipped.long()].any()
