@@ -187,6 +187,17 @@ __device__ __forceinline__ void stage_store(const TileStage<NP>& st, float (*t)[
   }
 }
 
+// The three derivative maps of a pixel whose window is exactly zero in both images (mu = E = 0), evaluated with the very
+// operations of the forward epilogue on run-time values (no constant folding of the hardware reciprocal: bit-identical).
+__device__ __forceinline__ void ssim_zero_maps(float* m) {
+  float C1 = 0.01f * 0.01f, C2 = 0.03f * 0.03f;
+  asm volatile("" : "+v"(C1), "+v"(C2));
+  const float iB1 = __builtin_amdgcn_rcpf(C1), iB2 = __builtin_amdgcn_rcpf(C2);
+  const float inv = iB1 * iB2;
+  const float S = (C1 * C2) * inv;
+  m[0] = 0.f; m[1] = -S * iB2; m[2] = 2.f * C1 * inv;
+}
+
 __global__ __launch_bounds__(256) void ssim_l1_fwd_kernel(int H, int W, SsimGrid gd, SsimWin win, const float* __restrict__ img1,
                                                           const float* __restrict__ img2_, const HgsViewTargets* __restrict__ tgt,
                                                           float* __restrict__ dmap, float* __restrict__ partials,
@@ -259,10 +270,12 @@ __global__ __launch_bounds__(256) void ssim_l1_fwd_kernel(int H, int W, SsimGrid
         const float S = (A1 * A2) * inv;                                 // losses.py:71-73
         ssim_v += S;
         l1_v += fabsf(t[0][y0 + o + HALO][lx + XOFF] - t[1][y0 + o + HALO][lx + XOFF]);
-        const size_t oo = bk.c * plane + (size_t)py * W + px;
-        dmap[oo] = 2.f * mu2 * (A2 - A1) * inv - S * (2.f * mu1 * iB1 - 2.f * mu1 * iB2);   // dS/dmu1 at fixed E11, E12
-        dmap[cp + oo] = -S * iB2;                                                           // dS/dE11
-        dmap[2 * cp + oo] = 2.f * A1 * inv;                                                 // dS/dE12
+        if (any_nz) {   // (a flagged block's maps are the constants ssim_zero_maps(): the backward substitutes them)
+          const size_t oo = bk.c * plane + (size_t)py * W + px;
+          dmap[oo] = 2.f * mu2 * (A2 - A1) * inv - S * (2.f * mu1 * iB1 - 2.f * mu1 * iB2);   // dS/dmu1 at fixed E11, E12
+          dmap[cp + oo] = -S * iB2;                                                           // dS/dE11
+          dmap[2 * cp + oo] = 2.f * A1 * inv;                                                 // dS/dE12
+        }
       }
     }
     const float bs = block_sum(ssim_v, red);
@@ -283,7 +296,8 @@ __global__ __launch_bounds__(256) void ssim_l1_bwd_kernel(int H, int W, SsimGrid
                                                           const float* __restrict__ g_ssim_mean,
                                                           const float* __restrict__ g_l1_mean, const float* __restrict__ go,
                                                           float* __restrict__ dimg1, float* __restrict__ zero_buf,
-                                                          int zero_n, const int* __restrict__ lists) {
+                                                          int zero_n, const int* __restrict__ lists,
+                                                          const unsigned char* __restrict__ zero_flags) {
   // (the loss head's endpoint-gradient buffer is cleared here, in passing: saves a launch before the smoothness scatter)
   for (int i = blockIdx.x * 256 + threadIdx.x; i < zero_n; i += gridDim.x * 256) zero_buf[i] = 0.f;
   __shared__ float t[3][TILE][TPW];
@@ -341,8 +355,29 @@ __global__ __launch_bounds__(256) void ssim_l1_bwd_kernel(int H, int W, SsimGrid
       if (px < W && py < H) { const size_t oo = q.c * plane + (size_t)py * W + px; x1[o] = img1[oo]; x2[o] = img2[oo]; }
     }
   };
+  // the forward wrote no maps for the blocks it flagged all-zero: their constants are put in place of the loads
+  float zm[3];
+  ssim_zero_maps(zm);
+  auto stage = [&](const SsimBlock& q) {
+    if (!zero_flags) { stage_load<3>(st, H, W, q.bx0, q.by0, [&](int p) { return dmap + p * cp + q.c * plane; }); return; }
+    const int per = gd.nbx * gd.nby;
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+      const int i = threadIdx.x + 256 * u;
+      const int r = i / (TW / 4), c4 = (i - r * (TW / 4)) * 4;
+      const int y = q.by0 + r - HALO, x = q.bx0 - XOFF + c4;
+      const bool in = i < ST_F4 && (unsigned)y < (unsigned)H && x >= 0 && x < W;
+      const bool flagged = in && zero_flags[q.c * per + (y / LT) * gd.nbx + x / LT] != 0;
+#pragma unroll
+      for (int p = 0; p < 3; p++) {
+        st.v[p][u] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (flagged) st.v[p][u] = make_float4(zm[p], zm[p], zm[p], zm[p]);
+        else if (in) st.v[p][u] = *(const float4*)(dmap + p * cp + q.c * plane + (size_t)y * W + x);
+      }
+    }
+  };
   if (have) {
-    if (fast) stage_load<3>(st, H, W, bk.bx0, bk.by0, [&](int p) { return dmap + p * cp + bk.c * plane; });
+    if (fast) stage(bk);
     centre(bk);
   }
   while (have) {
@@ -356,7 +391,7 @@ __global__ __launch_bounds__(256) void ssim_l1_bwd_kernel(int H, int W, SsimGrid
     const bool have_next = block_at(j, id1, nx);
     id1 = fetch_id(j + nwg);
     if (have_next) {
-      if (fast) stage_load<3>(st, H, W, nx.bx0, nx.by0, [&](int p) { return dmap + p * cp + nx.c * plane; });
+      if (fast) stage(nx);
       centre(nx);
     }
     row_pass<3>(win, hz, [&](int r, int x, float* v) {
@@ -608,6 +643,10 @@ __global__ __launch_bounds__(FIN_THREADS) void head_finalize_kernel(HeadReduce h
                                                                     SsimGrid gd, const unsigned char* __restrict__ work_flags,
                                                                     int* __restrict__ lists) {
   __shared__ float red[FIN_THREADS / 64];
+  float a2[2], a3[3], s2[2];
+  strided_acc<2>(p_ssim, h.nb_ssim, a2);
+  strided_acc<3>(p_pix, h.nb_pix, a3);
+  strided_acc<2>(p_smooth, h.nb_smooth, s2);
   if (lists) {
     // Block lists of the SSIM backward from pix_fwd_kernel's work flags:
     // lists = [n_work, n_skip, -, -][ids of the blocks with a non-zero gradient, logical order][the other ids].
@@ -615,8 +654,13 @@ __global__ __launch_bounds__(FIN_THREADS) void head_finalize_kernel(HeadReduce h
     const int per_thread = (gd.total + FIN_THREADS - 1) / FIN_THREADS;   // <= 32 (HEAD_MAX_FLAGGED)
     const int first = threadIdx.x * per_thread;
     unsigned bits = 0;
-    for (int k = 0; k < per_thread; k++)
-      if (first + k < gd.total && work_flags[first + k]) bits |= 1u << k;
+    for (int k0 = 0; k0 < per_thread; k0 += 8) {     // (8 independent loads in flight)
+      unsigned char v[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) v[u] = (k0 + u < per_thread && first + k0 + u < gd.total) ? work_flags[first + k0 + u] : 0;
+#pragma unroll
+      for (int u = 0; u < 8; u++) bits |= (unsigned)(v[u] != 0) << (k0 + u);
+    }
     const int cnt = __popc(bits);
     int inc = cnt;                                  // inclusive scan over the wave, then over the 16 wave totals
 #pragma unroll
@@ -644,10 +688,6 @@ __global__ __launch_bounds__(FIN_THREADS) void head_finalize_kernel(HeadReduce h
     }
     if (threadIdx.x == 0) { lists[0] = all; lists[1] = gd.total - all; }
   }
-  float a2[2], a3[3], s2[2];
-  strided_acc<2>(p_ssim, h.nb_ssim, a2);
-  strided_acc<3>(p_pix, h.nb_pix, a3);
-  strided_acc<2>(p_smooth, h.nb_smooth, s2);
   const float ssim_s = block_sum_1024(a2[0], red), l1_s = block_sum_1024(a2[1], red);
   const float ori_s = block_sum_1024(a3[0], red), ori_c = block_sum_1024(a3[1], red), bce_s = block_sum_1024(a3[2], red);
   const float sm_s = block_sum_1024(s2[0], red), sm_c = block_sum_1024(s2[1], red);
@@ -709,7 +749,7 @@ int hgs_ssim_l1_backward(void* stream, int C, int H, int W, const float* window1
     HgsProfScope _prof(s, HGS_K_SSIM_BWD);
     hipLaunchKernelGGL(ssim_l1_bwd_kernel, dim3(ssim_grid_size(ssim_grid(C, H, W), SSIM_BWD_WG_PER_XCD)), dim3(256), 0, s, H, W, ssim_grid(C, H, W), win, img1,
                        img2, (const HgsViewTargets*)nullptr, dmaps, g_ssim_mean, g_l1_mean, (const float*)nullptr, dL_dimg1,
-                       (float*)nullptr, 0, (const int*)nullptr);
+                       (float*)nullptr, 0, (const int*)nullptr, (const unsigned char*)nullptr);
   }
   HGS_CHECK_LAUNCH();
   return 0;
@@ -846,7 +886,8 @@ int hgs_loss_head_backward(void* stream, const HgsHeadParams* p, const float* im
     HgsProfScope _prof(s, HGS_K_SSIM_BWD);
     hipLaunchKernelGGL(ssim_l1_bwd_kernel, dim3(ssim_grid_size(ssim_grid(3, H, W), SSIM_BWD_WG_PER_XCD)), dim3(256), 0, s, H, W, ssim_grid(3, H, W), win, image,
                        (const float*)nullptr, targets, dmaps, out + HGS_HEAD_G_SSIM, out + HGS_HEAD_G_L1, grad_out, d_image,
-                       d_endpoints, d_endpoints ? p->n_endpoints * 3 : 0, head_block_lists(p, (float*)scratch));
+                       d_endpoints, d_endpoints ? p->n_endpoints * 3 : 0, head_block_lists(p, (float*)scratch),
+                       head_block_lists(p, (float*)scratch) ? (const unsigned char*)head_zero_flags(p, (float*)scratch) : nullptr);
   }
   HeadFlags fl;
   fl.bce = p->lambda_mask > 0.f; fl.ori = p->lambda_orientation > 0.f;
