@@ -119,7 +119,7 @@ __device__ __forceinline__ void col_pass(const SsimWin& win, float (*hz)[TILE][H
 //  * Each workgroup walks its XCD's run with stride (workgroups per XCD) and fetches the NEXT block's halo tile into
 //    registers while it filters the current one, so the HBM round trip is paid once per workgroup, not once per block
 //    (3 blocks of 44 KB LDS fit a CU: too few to hide it by occupancy alone).
-struct SsimGrid { int nbx, nby, C, chunk, total; };
+struct SsimGrid { int nbx, nby, C, chunk, total, sub; };
 struct SsimBlock { int c, bx0, by0, logical; };
 __device__ __forceinline__ void ssim_block_decode(const SsimGrid& gd, int logical, SsimBlock& o) {
   o.logical = logical;
@@ -131,7 +131,11 @@ __device__ __forceinline__ void ssim_block_decode(const SsimGrid& gd, int logica
   o.bx0 = (r - by * gd.nbx) * LT;
 }
 __device__ __forceinline__ bool ssim_block(const SsimGrid& gd, int j, SsimBlock& o) {
-  o.logical = (blockIdx.x & 7) * gd.chunk + j;
+  // the logical sequence is cut into SSIM_SUBBANDS contiguous sub-bands dealt round-robin to the XCDs: neighbours still
+  // share an L2, and an XCD's share mixes parts of the frame (all-zero blocks are cheap: a single band per XCD left
+  // the XCDs that own the middle of the frame as stragglers)
+  const int q = j / gd.sub;
+  o.logical = (q * 8 + (int)(blockIdx.x & 7)) * gd.sub + (j - q * gd.sub);
   if (j >= gd.chunk || o.logical >= gd.total) return false;
   const int per = gd.nbx * gd.nby;
   o.c = o.logical / per;
@@ -141,14 +145,17 @@ __device__ __forceinline__ bool ssim_block(const SsimGrid& gd, int j, SsimBlock&
   o.bx0 = (r - by * gd.nbx) * LT;
   return true;
 }
+#define SSIM_SUBBANDS 32
 static inline SsimGrid ssim_grid(int C, int H, int W) {
   SsimGrid gd;
   gd.nbx = (W + LT - 1) / LT; gd.nby = (H + LT - 1) / LT; gd.C = C;
   gd.total = gd.nbx * gd.nby * C;
-  gd.chunk = (gd.total + 7) / 8;
+  gd.sub = (gd.total + SSIM_SUBBANDS - 1) / SSIM_SUBBANDS;
+  gd.chunk = gd.sub * (SSIM_SUBBANDS / 8);
   return gd;
 }
-// persistent workgroups per XCD = 32 CUs x resident workgroups (forward: 38.7 KB LDS, 127 VGPRs -> 4; backward: 41 KB, 163 -> 3)
+// persistent workgroups per XCD = 32 CUs x resident workgroups (forward: 38.7 KB LDS, register allocation held to 128
+// VGPRs by amdgpu_waves_per_eu(4, 4) -> 4; at 131 it drops to 3 and the kernel takes 54 instead of 42 us; backward: 41 KB, 163 -> 3)
 #define SSIM_FWD_WG_PER_XCD 128
 #define SSIM_BWD_WG_PER_XCD 96
 static inline unsigned ssim_grid_size(const SsimGrid& gd, int per_xcd) { return 8u * (unsigned)(gd.chunk < per_xcd ? gd.chunk : per_xcd); }
@@ -198,7 +205,7 @@ __device__ __forceinline__ void ssim_zero_maps(float* m) {
   m[0] = 0.f; m[1] = -S * iB2; m[2] = 2.f * C1 * inv;
 }
 
-__global__ __launch_bounds__(256) void ssim_l1_fwd_kernel(int H, int W, SsimGrid gd, SsimWin win, const float* __restrict__ img1,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void ssim_l1_fwd_kernel(int H, int W, SsimGrid gd, SsimWin win, const float* __restrict__ img1,
                                                           const float* __restrict__ img2_, const HgsViewTargets* __restrict__ tgt,
                                                           float* __restrict__ dmap, float* __restrict__ partials,
                                                           unsigned char* __restrict__ zero_flags) {
