@@ -86,6 +86,13 @@ __global__ __launch_bounds__(256) void densify_stats_kernel(int P, const int* __
   denom[i] += 1.f;
 }
 
+static int g_tile_cull = 1;
+extern "C" int hgs_set_tile_cull(int on) {
+  const int was = g_tile_cull;
+  g_tile_cull = on != 0;
+  return was;
+}
+
 static int check_aligned(const void* p, const char* what) {
   if (!p || ((size_t)p & (HGS_ALIGN - 1))) {
     hgs_set_error("%s must be a non-null %d-byte aligned device pointer", what, HGS_ALIGN);
@@ -145,6 +152,7 @@ int hgs_forward_preprocess(void* stream, int P, int D, int M, int W, int H, cons
   a.rotations = rotations; a.cov3D_precomp = cov3D_precomp; a.viewmatrix = viewmatrix; a.projmatrix = projmatrix;
   a.campos = campos; a.scale_modifier = scale_modifier; a.tan_fovx = tan_fovx; a.tan_fovy = tan_fovy;
   a.prefiltered = prefiltered;
+  a.tile_cull = g_tile_cull;
   if (hgs_launch_preprocess_fwd(s, a, g, im, radii)) return 1;
   if (hgs_launch_scan(s, P, T, g, im, max_rendered)) return 1;
   if (num_rendered_host) {

@@ -122,6 +122,7 @@ struct HgsFwdArgs {
   const float *viewmatrix, *projmatrix, *campos;
   float scale_modifier, tan_fovx, tan_fovy;
   int prefiltered;
+  int tile_cull;       // shrink every tile rectangle to the alpha >= 1/255 ellipse's bounding box (hgs_set_tile_cull)
 };
 int hgs_launch_preprocess_fwd(hipStream_t s, const HgsFwdArgs& a, const HgsGeom& g, const HgsImage& im, int* radii);
 int hgs_launch_scan(hipStream_t s, int P, int T, const HgsGeom& g, const HgsImage& im, unsigned int* max_rendered);

@@ -230,13 +230,39 @@ __global__ __launch_bounds__(HGS_BLOCK) void preprocess_fwd_kernel(HgsFwdArgs a,
       g.means2D[idx] = make_float2(pixx, pixy);
       g.conic_opacity[idx] = conic_o;
       my_radius_i = ri;
-      ntiles = area;
+      if (a.tile_cull) {
+        // The reference's square of 3-sigma radius (forward.cu:229-235) is kept for `radii`, but a pixel blends this
+        // Gaussian only where opacity * exp(power) >= 1/255 (forward.cu:358), i.e. inside the ellipse 0.5 d^T Q d <= tau,
+        // tau = ln(255 opacity), whose bounding box has half extents sqrt(2 tau cov_xx), sqrt(2 tau cov_yy) (cov = Q^-1).
+        // Tiles outside that box (inflated like the quadrant masks of the sort kernel: 0.05% + 0.01 px) hold no pixel
+        // that passes the test: they get no instance.  For thin strand Gaussians that is a quarter of all instances;
+        // images and gradients are bit-identical with and without (tests/test_gpu_raster.py).
+        const float tau = logf(255.f * conic_o.w);
+        const float cdet = conic_o.x * conic_o.z - conic_o.y * conic_o.y;
+        if (!(tau > 0.f)) {
+          x1 = x0; y1 = y0;                 // alpha < 1/255 everywhere
+        } else if (cdet > 0.f) {
+          const float ex = sqrtf(2.f * tau * (conic_o.z / cdet)) * 1.0005f + 0.01f;
+          const float ey = sqrtf(2.f * tau * (conic_o.x / cdet)) * 1.0005f + 0.01f;
+          if (ex < 1e8f && ey < 1e8f) {     // (false for NaN / inf: no shrinking)
+            // tile t holds pixels 16 t .. 16 t + 15 (centres at integers): overlap <=> c + e >= 16 t and c - e <= 16 t + 15
+            const float lox = ceilf((pixx - ex - (float)(HGS_TILE - 1)) * (1.f / HGS_TILE)), hix = floorf((pixx + ex) * (1.f / HGS_TILE));
+            const float loy = ceilf((pixy - ey - (float)(HGS_TILE - 1)) * (1.f / HGS_TILE)), hiy = floorf((pixy + ey) * (1.f / HGS_TILE));
+            x0 = max(x0, (int)fmaxf(lox, 0.f)); x1 = min(x1, (int)fminf(hix, (float)gx) + 1);
+            y0 = max(y0, (int)fmaxf(loy, 0.f)); y1 = min(y1, (int)fminf(hiy, (float)gy) + 1);
+            if (x1 < x0) x1 = x0;
+            if (y1 < y0) y1 = y0;
+          }
+        }
+      }
+      const uint32_t area_kept = (uint32_t)(x1 - x0) * (uint32_t)(y1 - y0);
+      ntiles = area_kept;
       rc.x0 = (uint16_t)x0; rc.y0 = (uint16_t)y0; rc.x1 = (uint16_t)x1; rc.y1 = (uint16_t)y1;
       // per-tile instance counts: integer atomics, order-independent (block-private table first, see TileHash)
       for (int ty = y0; ty < y1; ty++)
         for (int tx = x0; tx < x1; tx++) {
           const uint32_t t = (uint32_t)(ty * gx + tx);
-          const int sl = area <= TH_MAX_AREA ? th_insert(th, t) : -1;
+          const int sl = area_kept <= TH_MAX_AREA ? th_insert(th, t) : -1;
           if (sl >= 0) atomicAdd(&th.cnt[sl], 1u);
           else atomicAdd(&im.tile_count[t], 1u);
         }

@@ -23,6 +23,12 @@ class HgsCapacityOverflow(RuntimeError):
     pass
 
 
+def set_tile_cull(enabled=True):
+    """include/hgs.h hgs_set_tile_cull: drop the (Gaussian, tile) instances no pixel can blend (default on); off gives the
+    reference's tile lists.  Returns the previous setting."""
+    return bool(rt.lib().hgs_set_tile_cull(int(bool(enabled))))
+
+
 def set_async(enabled=True, slack=1.5):
     """Capacity mode: passes never wait for num_rendered; the library keeps a sticky device-side maximum of it
     (hgs_forward_preprocess max_rendered) which check_async() reads -- one synchronisation per check, no per-pass copy."""

@@ -323,6 +323,15 @@ const char* hgs_prof_kernel_name(int kernel_id);
 int hgs_radius_pairs(void* stream, int N, const float* pos, const float* dir, float radius, float min_cos,
                      int bidirectional, int capacity, int* pairs, float* dist, int* count);
 
+/* Tile culling (default on).  The reference gives every Gaussian the tiles of its 3-sigma square (forward.cu:229-235,
+ * auxiliary.h:46-56) although a pixel only blends it where opacity * exp(power) >= 1/255 (forward.cu:358): with culling on,
+ * hgs_forward_preprocess keeps only the tiles that the bounding box of that ellipse reaches, so num_rendered, the tile
+ * lists and n_contrib count fewer entries than the reference's -- the dropped ones are skipped by every pixel there too.
+ * out_color, radii and all gradients are bit-identical either way.  Off reproduces the reference's lists exactly (the
+ * parity tests of the binning stages use it).  Process-wide, takes effect at the next hgs_forward_preprocess; a forward
+ * and its backward may run under different settings (the buffers carry the rectangles).  Returns the previous setting. */
+int hgs_set_tile_cull(int on);
+
 /* Development aid (tools/wg_trace.py): when a buffer of 2*T uint64 is registered, blend_fwd / blend_bwd record the
  * start and end time (s_memrealtime, 100 MHz) of every tile's workgroup in it; NULL (the default) switches it off. */
 int hgs_debug_set_wg_trace(void* device_buf_fwd, void* device_buf_bwd);

@@ -47,11 +47,24 @@ def _scene(name):
 ALL = list(VARIANTS) + ["strands", "strands_precomp"]
 
 
+def _forward(s, cull):
+    """Forward pass with tile culling (include/hgs.h hgs_set_tile_cull) on or off; the library default is restored."""
+    from diff_gaussian_rasterization import _C
+    from tests import gpu_util as G
+    was = _C.set_tile_cull(cull)
+    try:
+        return G.run_forward(s)
+    finally:
+        _C.set_tile_cull(was)
+
+
 def _check_forward(name):
     from tests import gpu_util as G
     s = _scene(name)
     ref = O.forward(s)
-    fw = G.run_forward(s)
+    # culling off: the tile lists are the reference's, every binning stage is compared bit for bit.  The default (on)
+    # drops instances that no pixel blends; test_tile_cull_changes_no_output shows that nothing else changes.
+    fw = _forward(s, cull=False)
     got = G.intermediates(s, fw)
     vis = ref["radii"] > 0
     assert got["status"][1] == 0
@@ -149,6 +162,55 @@ def test_backward_matches_oracle(name):
     inv = ref["radii"] == 0
     for k in ("dL_dmeans3D", "dL_dscales", "dL_drotations", "dL_dopacity", "dL_dcolors"):
         assert (g[k].reshape(len(inv), -1)[inv] == 0).all()
+
+
+@pytest.mark.parametrize("name", ALL)
+def test_tile_cull_changes_no_output(name):
+    """Tile culling on (the default) against off (the reference's tile lists): fewer instances, and bit-identical image,
+    radii, transmittance and gradients -- every dropped (Gaussian, tile) instance is one that no pixel of the tile
+    blends (alpha < 1/255 on all 256 pixels, checked here in float64 from the preprocessed 2D state)."""
+    from tests import gpu_util as G
+    s = _scene(name)
+    fw_on, fw_off = _forward(s, True), _forward(s, False)
+    on, off = G.intermediates(s, fw_on), G.intermediates(s, fw_off)
+    assert on["status"][1] == 0 and off["status"][1] == 0
+    assert on["num_rendered"] <= off["num_rendered"]
+    if name in ("strands", "strands_precomp", "sh0"):
+        assert on["num_rendered"] < off["num_rendered"]
+    np.testing.assert_array_equal(on["radii"], off["radii"])
+    np.testing.assert_array_equal(on["out_color"].view(np.uint32), off["out_color"].view(np.uint32))
+    np.testing.assert_array_equal(on["final_T"].view(np.uint32), off["final_T"].view(np.uint32))
+    if off["num_rendered"] == 0:
+        return
+    assert (on["tiles_touched"] <= off["tiles_touched"]).all()
+    # ---- the kept list of every tile is the reference's list minus dropped entries, in the same order; dropped
+    # entries cannot pass the alpha test anywhere in the tile
+    W, H = s["W"], s["H"]
+    gx = (W + 15) // 16
+    xy, co = off["means2D"].astype(np.float64), off["conic_opacity"].astype(np.float64)
+    py, px = np.mgrid[0:16, 0:16]
+    worst = 0.0
+    for t in range(len(off["ranges"])):
+        a0, a1 = off["ranges"][t]
+        b0, b1 = on["ranges"][t]
+        full, kept = off["point_list"][a0:a1], on["point_list"][b0:b1]
+        keep = np.isin(full, kept)
+        np.testing.assert_array_equal(full[keep], kept)
+        if keep.all():
+            continue
+        ids = full[~keep]
+        dx = xy[ids, 0, None, None] - ((t % gx) * 16 + px)[None]
+        dy = xy[ids, 1, None, None] - ((t // gx) * 16 + py)[None]
+        power = -0.5 * (co[ids, 0, None, None] * dx * dx + co[ids, 2, None, None] * dy * dy) - co[ids, 1, None, None] * dx * dy
+        alpha = np.where(power > 0, 0.0, co[ids, 3, None, None] * np.exp(np.minimum(power, 0)))
+        worst = max(worst, float(alpha.max()))
+    assert worst < 1.0 / 255.0, worst
+    if name == "all_culled":
+        return
+    dpix = np.random.default_rng(77).normal(size=(3, H, W)).astype(np.float32)
+    g_on, g_off = G.run_backward(s, fw_on, dpix), G.run_backward(s, fw_off, dpix)
+    for k in g_on:
+        np.testing.assert_array_equal(g_on[k].view(np.uint32), g_off[k].view(np.uint32), err_msg=k)
 
 
 def test_backward_is_bitwise_reproducible():
