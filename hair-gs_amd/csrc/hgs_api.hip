@@ -125,6 +125,7 @@ int hgs_forward_preprocess(void* stream, int P, int D, int M, int W, int H, cons
                            int* num_rendered_host, unsigned int* max_rendered) {
   hipStream_t s = (hipStream_t)stream;
   if (P < 0 || W <= 0 || H <= 0) { hgs_set_error("bad sizes P=%d W=%d H=%d", P, W, H); return 1; }
+  if ((unsigned)P > HGS_MAX_GAUSSIANS) { hgs_set_error("P=%d: at most 2^28 Gaussians per pass (instance key layout)", P); return 1; }
   if (D < 0 || D > 3) { hgs_set_error("sh degree %d unsupported (0..3)", D); return 1; }
   if (check_aligned(image_buf, "image_buf")) return 1;
   HgsImage im;

@@ -110,40 +110,13 @@ struct EmitCtx { const float* feat; const float* extra; int n_extra; uint32_t Rc
 
 __device__ __forceinline__ void emit_instance(uint64_t key, uint32_t pos, int tx, int ty, const EmitCtx& e,
                                               const HgsGeom& g, const HgsBinning& b) {
-  const uint32_t id = (uint32_t)key;
+  const uint32_t id = (uint32_t)key >> HGS_QMASK_SHIFT;
   b.point_list[pos] = id;
   b.keys_sorted[pos] = key;
   const float2 xy = g.means2D[id];
   const float4 co = g.conic_opacity[id];
   const float f0 = e.feat[3 * (size_t)id], f1 = e.feat[3 * (size_t)id + 1], f2 = e.feat[3 * (size_t)id + 2];
-  // Quadrant mask for the blend kernels' scalar-unit cull.  A pixel can only blend this Gaussian if
-  // opacity * exp(power) >= 1/255, i.e. 0.5 d^T Q d <= tau = ln(255 * opacity) (Q = conic): an ellipse whose
-  // axis-aligned half extents are sqrt(2 tau cov_xx), sqrt(2 tau cov_yy) with cov = Q^-1.  Bit w is set when that box
-  // (inflated by 0.05% + 0.01 px, orders of magnitude above any rounding of the per-pixel test) overlaps the 8x8 pixel
-  // quadrant wavefront w of this tile owns.  The tile lists themselves use the reference's square 3-sigma radius
-  // (forward.cu:229-235), which for thin strand Gaussians covers far more pixels than can ever pass the alpha test.
-  uint32_t qmask = 0xFu;
-  {
-    const float tau = logf(255.f * co.w);
-    const float det = co.x * co.z - co.y * co.y;
-    if (!(tau > 0.f)) {
-      qmask = 0u;                      // alpha < 1/255 everywhere: never blended by any pixel
-    } else if (det > 0.f) {
-      const float hx = sqrtf(2.f * tau * (co.z / det)) * 1.0005f + 0.01f;
-      const float hy = sqrtf(2.f * tau * (co.x / det)) * 1.0005f + 0.01f;
-      if (hx == hx && hy == hy) {      // finite
-        qmask = 0u;
-        const float x0 = (float)(tx * HGS_TILE), y0 = (float)(ty * HGS_TILE);
-#pragma unroll
-        for (int w = 0; w < 4; w++) {
-          const float qx0 = x0 + (float)((w & 1) * 8), qy0 = y0 + (float)((w >> 1) * 8);
-          const bool ox = xy.x + hx >= qx0 && xy.x - hx <= qx0 + 7.f;
-          const bool oy = xy.y + hy >= qy0 && xy.y - hy <= qy0 + 7.f;
-          if (ox && oy) qmask |= 1u << w;
-        }
-      }
-    }
-  }
+  const uint32_t qmask = (uint32_t)key & HGS_QMASK_BITS;   // quadrant mask, computed by the scatter kernel (hgs_quadrant_mask)
   if (e.n_extra == 0) {  // 48-B record: xy, conic, opacity, rgb, id, quadrant mask
     float4* rec = b.packed + (size_t)pos * 3;
     rec[0] = make_float4(xy.x, xy.y, co.x, co.y);

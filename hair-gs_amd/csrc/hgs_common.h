@@ -116,6 +116,63 @@ int hgs_launch_smooth_fwd(hipStream_t s, int N, const float* endpoints, const lo
                           float* partials);
 int hgs_launch_smooth_bwd(hipStream_t s, int N, const float* endpoints, const long long* index_pairs, float cos_th, float eps,
                           const float* g_loss, const float* count, const float* go, float* d_endpoints);
+
+// ---- quadrant masks ---------------------------------------------------------------------------------------------------
+// Instance key = depth_bits << 32 | gaussian_id << 4 | quadrant mask (ordering by depth, then id, as the reference's stable
+// sort by depth: the mask sits below the id).  Bit w of the mask is set when wavefront w's 8x8 pixel quadrant of the tile
+// may hold a pixel that blends the Gaussian; the blend kernels cull on it on the scalar unit.
+#define HGS_QMASK_SHIFT 4
+#define HGS_QMASK_BITS 0xFu
+#define HGS_MAX_GAUSSIANS (1u << 28)
+#if defined(__HIPCC__)
+struct HgsQuadCull { float tau, hx, hy, nx, ny, rn; int mode; };   // mode 0: never blended, 1: test, 2: keep all (degenerate)
+// A pixel can only blend the Gaussian if opacity * exp(power) >= 1/255 (forward.cu:358), i.e. q(d) = 0.5 d^T Q d <= tau =
+// ln(255 opacity) (Q = conic): an ellipse whose extent along a unit direction n is sqrt(2 tau n^T cov n), cov = Q^-1.
+// Two separating axes are tested per quadrant: the image axes (the ellipse's bounding box) and the ellipse's minor axis,
+// which is what culls a thin diagonal strand Gaussian from the quadrants its bounding box covers but it never enters.
+// Extents are inflated by 0.05% + 0.01 px, orders of magnitude above any rounding of the per-pixel test; the minor-axis
+// variance is evaluated for the direction actually used (any unit n gives a valid test) plus its own rounding bound.
+__device__ __forceinline__ HgsQuadCull hgs_quad_cull(const float4 co) {
+  HgsQuadCull c = {0.f, 0.f, 0.f, 1.f, 0.f, 0.f, 2};
+  c.tau = logf(255.f * co.w);
+  const float det = co.x * co.z - co.y * co.y;
+  if (!(c.tau > 0.f)) { c.mode = 0; return c; }
+  if (!(det > 0.f)) return c;
+  const float idet = 1.f / det;
+  const float cxx = co.z * idet, cyy = co.x * idet, cxy = -co.y * idet;
+  c.hx = sqrtf(2.f * c.tau * cxx) * 1.0005f + 0.01f;
+  c.hy = sqrtf(2.f * c.tau * cyy) * 1.0005f + 0.01f;
+  if (!(c.hx == c.hx && c.hy == c.hy)) return c;
+  // minor axis: eigenvector of the smaller eigenvalue, taken from the better conditioned of the two rows
+  const float hd = 0.5f * (cxx - cyy), rad = sqrtf(hd * hd + cxy * cxy);
+  const float lmin = 0.5f * (cxx + cyy) - rad;
+  float vx = cxy, vy = lmin - cxx;                 // (cxx - l) vx + cxy vy = 0
+  if (cxx < cyy) { vx = lmin - cyy; vy = cxy; }    // cxy vx + (cyy - l) vy = 0
+  const float vn = sqrtf(vx * vx + vy * vy);
+  if (vn > 1e-12f * (cxx + cyy)) { c.nx = vx / vn; c.ny = vy / vn; } else { c.nx = 1.f; c.ny = 0.f; }
+  const float t0 = cxx * c.nx * c.nx, t1 = cyy * c.ny * c.ny, t2 = 2.f * cxy * c.nx * c.ny;
+  const float var_n = (t0 + t1 + t2) + 1e-6f * (t0 + t1 + fabsf(t2));
+  c.rn = sqrtf(2.f * c.tau * fmaxf(var_n, 0.f)) * 1.0005f + 0.01f;
+  c.mode = (c.rn == c.rn) ? 1 : 2;
+  return c;
+}
+__device__ __forceinline__ uint32_t hgs_quadrant_mask(const HgsQuadCull& c, const float2 xy, int tx, int ty) {
+  if (c.mode != 1) return c.mode == 0 ? 0u : HGS_QMASK_BITS;
+  uint32_t qmask = 0u;
+  const float x0 = (float)(tx * HGS_TILE), y0 = (float)(ty * HGS_TILE);
+  const float reach = c.rn + 3.5f * (fabsf(c.nx) + fabsf(c.ny));   // the quadrant's 7x7 px rectangle of pixel centres, projected
+#pragma unroll
+  for (int w = 0; w < 4; w++) {
+    const float qx0 = x0 + (float)((w & 1) * 8), qy0 = y0 + (float)((w >> 1) * 8);
+    const bool ox = xy.x + c.hx >= qx0 && xy.x - c.hx <= qx0 + 7.f;
+    const bool oy = xy.y + c.hy >= qy0 && xy.y - c.hy <= qy0 + 7.f;
+    const float along = c.nx * (qx0 + 3.5f - xy.x) + c.ny * (qy0 + 3.5f - xy.y);
+    if (ox && oy && fabsf(along) <= reach) qmask |= 1u << w;
+  }
+  return qmask;
+}
+#endif
+
 struct HgsFwdArgs {
   int P, D, M, W, H;
   const float *means3D, *shs, *colors_precomp, *opacities, *scales, *rotations, *cov3D_precomp;

@@ -319,10 +319,14 @@ __global__ __launch_bounds__(HGS_BLOCK) void scatter_kernel(int P, int gx, uint3
   __syncthreads();
   if (n == 0) return;
   // pass 2: place the keys (order inside a tile's segment is irrelevant: the per-tile sort key is unique)
-  const uint64_t key = ((uint64_t)__float_as_uint(g.depths[idx]) << 32) | (uint32_t)idx;
+  const uint64_t key0 = ((uint64_t)__float_as_uint(g.depths[idx]) << 32) | ((uint32_t)idx << HGS_QMASK_SHIFT);
+  const float2 xy = g.means2D[idx];
+  const float4 co = g.conic_opacity[idx];
+  const HgsQuadCull qc = hgs_quad_cull(co);
   for (int ty = rc.y0; ty < rc.y1; ty++)
     for (int tx = rc.x0; tx < rc.x1; tx++) {
       const uint32_t t = (uint32_t)(ty * gx + tx);
+      const uint64_t key = key0 | hgs_quadrant_mask(qc, xy, tx, ty);
       const int sl = small ? th_find(th, t) : -1;
       const uint32_t pos = im.ranges[t].x + (sl >= 0 ? th.base[sl] + atomicAdd(&th.cnt[sl], 1u)
                                                      : atomicAdd(&im.tile_cursor[t], 1u));

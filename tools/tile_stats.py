@@ -54,6 +54,7 @@ A, B, Cc, op = recf[:, 2], recf[:, 3], recf[:, 4], recf[:, 5]
 power = -0.5 * (A[:, None, None] * dx[:, None, :] ** 2 + Cc[:, None, None] * dy[:, :, None] ** 2) - B[:, None, None] * dx[:, None, :] * dy[:, :, None]
 vis = (power <= 0) & (op[:, None, None] * torch.exp(power) >= 1.0 / 255.0)   # [R,16(y),16(x)]
 q = vis.reshape(-1, 2, 8, 2, 8).any(dim=4).any(dim=2)                          # [R, qy, qx]
+print("instances with at least one passing pixel (exact tile-level keep):", vis.reshape(vis.shape[0], -1).any(dim=1).float().mean().item())
 print("exact kept fraction", q.float().mean().item(), " pixels passing per kept (wave, entry):", vis.float().sum().item() / max(1.0, q.float().sum().item()))
 # ---- what a 4x4-block (DPP row) work decomposition would do: per (tile, wave=quadrant, batch of 64 entries) the step
 # count is the max over the quadrant's four 4x4 blocks of the entries whose footprint box reaches the block
