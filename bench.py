@@ -195,18 +195,26 @@ def main():
         W, H = cams[0].image_width, cams[0].image_height
         T = ((W + 15) // 16) * ((H + 15) // 16)
         lay = rt.layout("image", W, H)
-        Ls, Rs = [], []
-        for c in cams:
-            import math
-            out = C_.rasterize_gaussians(bg, model.get_xyz, torch.empty(0, device=dev), model.get_opacity, model.get_scaling,
-                                         model.get_rotation, 1.0, torch.empty(0, device=dev), c.world_view_transform,
-                                         c.full_proj_transform, math.tan(c.FoVx * 0.5), math.tan(c.FoVy * 0.5), H, W,
-                                         model.get_features, model.active_sh_degree, c.camera_center, False, False)
-            img = out[5]
-            maxc = img[lay["tile_maxc"]:lay["tile_maxc"] + 4 * T].view(torch.int32)
-            Ls.append(int(maxc.sum().item()))
-            Rs.append(out[0])
-        meanL, meanR = sum(Ls) / len(Ls), sum(Rs) / len(Rs)
+        # Two passes per view: with the reference's tile lists (culling off: L_t and num_rendered as SURVEY.md 8d defines
+        # them, the unit the algorithmic bytes are counted in) and with the lists the product runs on (culling on).
+        import math
+        stats = {}
+        for cull in (False, True):
+            was = C_.set_tile_cull(cull)
+            Ls, Rs = [], []
+            for c in cams:
+                out = C_.rasterize_gaussians(bg, model.get_xyz, torch.empty(0, device=dev), model.get_opacity,
+                                             model.get_scaling, model.get_rotation, 1.0, torch.empty(0, device=dev),
+                                             c.world_view_transform, c.full_proj_transform, math.tan(c.FoVx * 0.5),
+                                             math.tan(c.FoVy * 0.5), H, W, model.get_features, model.active_sh_degree,
+                                             c.camera_center, False, False)
+                img = out[5]
+                maxc = img[lay["tile_maxc"]:lay["tile_maxc"] + 4 * T].view(torch.int32)
+                Ls.append(int(maxc.sum().item()))
+                Rs.append(out[0])
+            C_.set_tile_cull(was)
+            stats[cull] = (sum(Ls) / len(Ls), sum(Rs) / len(Rs))
+        (meanL, meanR), (meanL_culled, meanR_culled) = stats[False], stats[True]
 
     if rank != 0:
         if world > 1:
@@ -223,6 +231,7 @@ def main():
                                "RGB+mask+orientation raster fwd+bwd + L1/DSSIM/mask/orientation/smoothness losses + Adam",
                    "gaussians": P, "views": len(cams), "width": W, "height": H, "parallelism": f"view-parallel x{world}",
                    "mean_num_rendered": meanR, "mean_sum_tile_list_len": meanL,
+                   "mean_num_rendered_after_tile_cull": meanR_culled, "mean_sum_tile_list_len_after_tile_cull": meanL_culled,
                    "forward_mode": "blocking" if args.blocking else "async-capacity",
                    "dispatch": "hip-graph replay" if use_graph else "eager",
                    "iteration": "fused iteration" if fused is not None else "op-by-op",
@@ -236,8 +245,11 @@ def main():
         # partial sums is written; per pixel the upstream gradient (4 B x channels) + final_T + n_contrib are read
         ch = 7 if getattr(opt, "single_pass", True) else 3
         rec_b, part_b = (64.0, 60.0) if ch == 7 else (48.0, 36.0)
+        # counted on the reference's tile lists (L_t = entries of the reference's list any pixel of the
+        # tile needed); the product culls instances no pixel blends and moves less (moved_bytes_model below)
         bytes_bwd = (rec_b + part_b) * meanL + (4.0 * ch + 8.0) * W * H + 8.0 * T
         bytes_fwd = rec_b * meanL + (4.0 * ch + 8.0) * W * H + 8.0 * T
+        moved_bwd = (rec_b + part_b) * meanL_culled + (4.0 * ch + 8.0) * W * H + 8.0 * T
         ach = bytes_bwd / (bwd_ms / max(bwd_n, 1) * 1e-3) / 1e9 if bwd_ms > 0 else 0.0
         # HBM traffic of the same kernel from the committed rocprofv3 --pmc passes (tools/pmc_raster.sh; FETCH_SIZE and
         # WRITE_SIZE collected in separate runs, corrected as MI355X_MICROARCH.md prescribes: 2 x FETCH_SIZE + WRITE_SIZE,
@@ -250,7 +262,8 @@ def main():
                 traffic = (2.0 * pm["FETCH_SIZE"] + pm["WRITE_SIZE"]) * 1024.0
         result["roofline"] = {"kernel": "blend_bwd_kernel", "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS,
                               "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
-                              "algorithmic_bytes_per_launch": bytes_bwd, "mean_launch_us": bwd_ms / max(bwd_n, 1) * 1e3,
+                              "algorithmic_bytes_per_launch": bytes_bwd, "moved_bytes_model": moved_bwd,
+                              "mean_launch_us": bwd_ms / max(bwd_n, 1) * 1e3,
                               "launches": bwd_n}
         result["roofline_blend_fwd"] = {"achieved": bytes_fwd / (fwd_ms / max(fwd_n, 1) * 1e-3) / 1e9 if fwd_ms else 0.0,
                                         "unit": "GB/s", "mean_launch_us": fwd_ms / max(fwd_n, 1) * 1e3}
