@@ -42,12 +42,11 @@ template <int CTRL>
 __device__ __forceinline__ float dpp_mov(float v) {
   return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0u, __builtin_bit_cast(unsigned, v), CTRL, 0xf, 0xf, false));
 }
-__device__ __forceinline__ float row_sum16(float v) {   // every lane of a 16-lane row ends with the row's sum
+__device__ __forceinline__ float row_sum16(float v) {   // every lane ends with the sum of its half row (8 lanes)
   v += dpp_mov<0xB1>(v);    // quad_perm [1,0,3,2]
   v += dpp_mov<0x4E>(v);    // quad_perm [2,3,0,1]
   v += dpp_mov<0x124>(v);   // row_ror:4
-  v += dpp_mov<0x128>(v);   // row_ror:8
-  return v;
+  return v;                 // (row_ror:8 remains: row_finish)
 }
 __device__ __forceinline__ float fold32(float a, float b) {  // lanes 0-31: a[l]+a[l+32]; lanes 32-63: b[l-32]+b[l]
   auto r = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, a), __builtin_bit_cast(unsigned, b), false, false);
@@ -76,11 +75,26 @@ template <int C> struct Chan {
 };
 
 // in : v[0 .. 4*NREG) per lane.  out: x[r] rows (0,1,2,3) hold the wave totals of v[4r], v[4r+2], v[4r+1], v[4r+3].
+// Last step of the row sums (x += x rotated by 8 lanes within the row) as explicit v_add_f32_dpp for all registers at once:
+// left to the compiler, this add is sunk into the lane-masked store branch of the callers, where it can no longer be fused
+// with the DPP move (v_mov 0 + v_mov_dpp + v_add per register instead of one instruction).  One s_nop covers the hazard of
+// a DPP operand written by the immediately preceding VALU instruction (two wait states).
+#define HGS_DPP_ROR8 " row_ror:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+__device__ __forceinline__ void row_finish(float (&x)[3]) {
+  asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %0, %0" HGS_DPP_ROR8 "v_add_f32_dpp %1, %1, %1" HGS_DPP_ROR8
+               "v_add_f32_dpp %2, %2, %2" HGS_DPP_ROR8 : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]));
+}
+__device__ __forceinline__ void row_finish(float (&x)[4]) {
+  asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %0, %0" HGS_DPP_ROR8 "v_add_f32_dpp %1, %1, %1" HGS_DPP_ROR8
+               "v_add_f32_dpp %2, %2, %2" HGS_DPP_ROR8 "v_add_f32_dpp %3, %3, %3" HGS_DPP_ROR8
+               : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]));
+}
 template <int NREG>
-__device__ __forceinline__ void wave_reduce(const float* v, float* x) {
+__device__ __forceinline__ void wave_reduce(const float* v, float (&x)[NREG]) {
 #pragma unroll
   for (int r = 0; r < NREG; r++)
     x[r] = row_sum16(fold16(fold32(v[4 * r], v[4 * r + 1]), fold32(v[4 * r + 2], v[4 * r + 3])));
+  row_finish(x);
 }
 
 // ---- record staging ------------------------------------------------------------------------------------------
