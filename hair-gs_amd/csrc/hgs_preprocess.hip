@@ -375,6 +375,20 @@ __global__ __launch_bounds__(HGS_BLOCK) void preprocess_bwd_kernel(HgsBwdArgs a,
         dmx_rgb += r3.y; dmy_rgb += r3.z;
       }
     }
+    // The rows hold sums of moments of u = G dL/dalpha (blend_bwd_kernel): dmx = S(u dx), dmy = S(u dy), dcx = S(u dx dx),
+    // dcy = S(u dx dy), dcw = S(u dy dy), dop = S(u).  backward_distwar.cu:1002-1011 in terms of them (dL_dG = opacity
+    // dL_dalpha, dG_ddelx = -G (a dx + b dy), dG_ddely = -G (c dy + b dx), ddel_dx = 0.5 W, ddel_dy = 0.5 H):
+    {
+      const float4 co = g.conic_opacity[idx];
+      const float sx = 0.5f * a.W * co.w, sy = 0.5f * a.H * co.w;
+      const float mx = dmx, my = dmy, mrx = dmx_rgb, mry = dmy_rgb;
+      dmx = sx * (-co.x * mx - co.y * my);
+      dmy = sy * (-co.z * my - co.y * mx);
+      dmx_rgb = sx * (-co.x * mrx - co.y * mry);
+      dmy_rgb = sy * (-co.z * mry - co.y * mrx);
+      const float h = -0.5f * co.w;
+      dcx *= h; dcy *= h; dcw *= h;
+    }
     // ---- computeCov2DCUDA, backward_distwar.cu:145-275
     const V3 mean = {a.means3D[3 * idx], a.means3D[3 * idx + 1], a.means3D[3 * idx + 2]};
     const float* cov3D = (a.cov3D_precomp ? a.cov3D_precomp : g.cov3D) + 6 * (size_t)idx;
