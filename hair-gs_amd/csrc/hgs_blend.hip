@@ -281,12 +281,13 @@ __global__ __launch_bounds__(HGS_BLOCK) void blend_bwd_kernel(const uint2* __res
 #pragma unroll
   for (int d = 32; d >= 1; d >>= 1) wlast = max(wlast, (uint32_t)__shfl_xor((int)wlast, d, 64));
   wlast = __builtin_amdgcn_readfirstlane(wlast);
-  float dpx[C], acc[C];
+  // The colour accumulated behind an entry (accum_rec, :972) enters only through its dot product with this pixel's
+  // upstream gradient (:979-984): the state carried per pixel is that scalar (and the RGB-only one), not C colours.
+  float dpx[C], acc_dot = 0.f, acc_dot_rgb = 0.f;
   float bg_dot = 0.f, bg_dot_rgb = 0.f;                                       // backward_distwar.cu:988-990
 #pragma unroll
   for (int k = 0; k < C; k++) {
     dpx[k] = inside ? dL_dpix.plane[k][pix] : 0.f;
-    acc[k] = 0.f;
     bg_dot += bg[k] * dpx[k];
     if (k < 3) bg_dot_rgb += bg[k] * dpx[k];
   }
@@ -330,14 +331,16 @@ __global__ __launch_bounds__(HGS_BLOCK) void blend_bwd_kernel(const uint2* __res
       T = T * inv_one_m_a;                                                         // :960
       float v[NV];
       const float dchannel_dcolor = alpha * T;
-      float dL_dalpha = 0.f, dL_dalpha_rgb = 0.f;
+      // sum_k (c_k - accum_rec_k) dL_dpix_k = c . dL_dpix - accum_rec . dL_dpix  (:979-984)
+      float col_dot = 0.f, col_dot_rgb = 0.f;
 #pragma unroll
       for (int k = 0; k < C; k++) {
-        const float t = (f[6 + k] - acc[k]) * dpx[k];
-        dL_dalpha += t;
-        if (k < 3) dL_dalpha_rgb += t;
+        col_dot += f[6 + k] * dpx[k];
+        if (k == 2) col_dot_rgb = col_dot;
         v[6 + k] = dchannel_dcolor * dpx[k];                                       // :980
       }
+      float dL_dalpha = col_dot - acc_dot;
+      const float dL_dalpha_rgb = col_dot_rgb - acc_dot_rgb;
       dL_dalpha *= T;
       const float bgw = -T_final * inv_one_m_a;
       dL_dalpha += bgw * bg_dot;                                                   // :991
@@ -364,8 +367,8 @@ __global__ __launch_bounds__(HGS_BLOCK) void blend_bwd_kernel(const uint2* __res
       // (1 - last_alpha) * accum_rec (:972), evaluated here, right after its operands were used, instead of at the next
       // contributing entry -- same operands, same order, and no (last_alpha, last_color) state to carry.  With
       // alpha = 0 (lanes that do not blend this entry) it is the identity.
-#pragma unroll
-      for (int k = 0; k < C; k++) acc[k] = alpha * f[6 + k] + (1.f - alpha) * acc[k];
+      acc_dot = alpha * col_dot + (1.f - alpha) * acc_dot;
+      acc_dot_rgb = alpha * col_dot_rgb + (1.f - alpha) * acc_dot_rgb;
 #pragma unroll
       for (int k = NPART; k < NV; k++) v[k] = 0.f;
       float x[NREG];
