@@ -231,7 +231,7 @@ __global__ __launch_bounds__(HGS_BLOCK) void blend_fwd_kernel(const uint2* __res
 template <int C> struct PixGrad { const float* plane[C]; };  // dL/d(output channel k) as [H,W] planes (need not be adjacent)
 
 template <int C>
-__global__ __launch_bounds__(HGS_BLOCK) void blend_bwd_kernel(const uint2* __restrict__ ranges,
+__global__ __launch_bounds__(HGS_BLOCK) __attribute__((amdgpu_waves_per_eu(6))) void blend_bwd_kernel(const uint2* __restrict__ ranges,
                                                               const float4* __restrict__ packed, int W, int H, int gx,
                                                               uint32_t Rcap, const float* __restrict__ bg,
                                                               const float* __restrict__ final_Ts,
@@ -335,7 +335,7 @@ __global__ __launch_bounds__(HGS_BLOCK) void blend_bwd_kernel(const uint2* __res
       float col_dot = 0.f, col_dot_rgb = 0.f;
 #pragma unroll
       for (int k = 0; k < C; k++) {
-        col_dot += f[6 + k] * dpx[k];
+        col_dot = __builtin_fmaf(f[6 + k], dpx[k], col_dot);
         if (k == 2) col_dot_rgb = col_dot;
         v[6 + k] = dchannel_dcolor * dpx[k];                                       // :980
       }
