@@ -36,18 +36,7 @@ namespace {
 // ---- wavefront-wide reduction of 9 per-lane values (CDNA4: v_permlane32_swap / v_permlane16_swap + DPP) ----------
 // Transposing butterfly: a swap of the upper half-wave of `a` with the lower half-wave of `b` followed by one add
 // folds TWO values by a factor 2 into ONE register; the same with 16-lane rows folds four values into one register
-// with one value per row; four DPP adds (quad xor 1, quad xor 2, row_ror 4, row_ror 8) finish each row.  28 VALU
-// instructions for 9 values instead of 54 ds_bpermute round trips.
-template <int CTRL>
-__device__ __forceinline__ float dpp_mov(float v) {
-  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0u, __builtin_bit_cast(unsigned, v), CTRL, 0xf, 0xf, false));
-}
-__device__ __forceinline__ float row_sum16(float v) {   // every lane ends with the sum of its half row (8 lanes)
-  v += dpp_mov<0xB1>(v);    // quad_perm [1,0,3,2]
-  v += dpp_mov<0x4E>(v);    // quad_perm [2,3,0,1]
-  v += dpp_mov<0x124>(v);   // row_ror:4
-  return v;                 // (row_ror:8 remains: row_finish)
-}
+// with one value per row; bank-masked DPP adds continue the transposition inside the rows (row_transpose_sum).
 __device__ __forceinline__ float fold32(float a, float b) {  // lanes 0-31: a[l]+a[l+32]; lanes 32-63: b[l-32]+b[l]
   auto r = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, a), __builtin_bit_cast(unsigned, b), false, false);
   unsigned lo = r[0], hi = r[1];
@@ -76,26 +65,41 @@ template <int C> struct Chan {
 };
 
 // in : v[0 .. 4*NREG) per lane.  out: x[r] rows (0,1,2,3) hold the wave totals of v[4r], v[4r+2], v[4r+1], v[4r+3].
-// Last step of the row sums (x += x rotated by 8 lanes within the row) as explicit v_add_f32_dpp for all registers at once:
-// left to the compiler, this add is sunk into the lane-masked store branch of the callers, where it can no longer be fused
-// with the DPP move (v_mov 0 + v_mov_dpp + v_add per register instead of one instruction).  One s_nop covers the hazard of
-// a DPP operand written by the immediately preceding VALU instruction (two wait states).
-#define HGS_DPP_ROR8 " row_ror:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-__device__ __forceinline__ void row_finish(float (&x)[3]) {
-  asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %0, %0" HGS_DPP_ROR8 "v_add_f32_dpp %1, %1, %1" HGS_DPP_ROR8
-               "v_add_f32_dpp %2, %2, %2" HGS_DPP_ROR8 : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]));
+// In-row part of the reduction, transposing as well.  After fold16 each of the NREG registers holds, in every 16-lane row,
+// 16 partial sums of one value.  Bank-masked DPP adds (a bank = 4 lanes; masked-off lanes keep the destination) fold
+// them so that ONE register ends with: row r, quad q  ->  total of value 4 * reg(q) + k(r), reg = (0,2,1,3)[q],
+// k = (0,2,1,3)[r], the same number in all four lanes of the quad:
+//   x0.lanes 0-7  = x0 + x0 rotated by 8      x0.lanes 8-15 = x1 + x1 rotated by 8        (x2 / x3 likewise)
+//   x0.quads 0,2  = x0 + x0 rotated by 12     x0.quads 1,3  = x2 + x2 rotated by 4
+//   + the two quad butterflies
+// 8 DPP adds instead of the 16 of four independent row sums.  (row_ror:n: lane i reads lane i - n of its row.)  s_nop:
+// a DPP operand written by one of the two preceding VALU instructions needs the wait states.
+#define HGS_DPP(ctrl, banks) " " ctrl " row_mask:0xf bank_mask:" banks "\n\t"
+__device__ __forceinline__ float row_transpose_sum(float x0, float x1, float x2, float x3) {
+  asm volatile("s_nop 1\n\t"
+               "v_add_f32_dpp %0, %0, %0" HGS_DPP("row_ror:8", "0x3")
+               "v_add_f32_dpp %1, %1, %1" HGS_DPP("row_ror:8", "0x3")
+               "v_add_f32_dpp %0, %2, %2" HGS_DPP("row_ror:8", "0xc")
+               "v_add_f32_dpp %1, %3, %3" HGS_DPP("row_ror:8", "0xc")
+               "s_nop 1\n\t"
+               "v_add_f32_dpp %0, %0, %0" HGS_DPP("row_ror:12", "0x5")
+               "v_add_f32_dpp %0, %1, %1" HGS_DPP("row_ror:4", "0xa")
+               "s_nop 1\n\t"
+               "v_add_f32_dpp %0, %0, %0" HGS_DPP("quad_perm:[1,0,3,2]", "0xf")
+               "s_nop 1\n\t"
+               "v_add_f32_dpp %0, %0, %0" HGS_DPP("quad_perm:[2,3,0,1]", "0xf")
+               : "+v"(x0), "+v"(x2) : "v"(x1), "v"(x3));
+  return x0;
 }
-__device__ __forceinline__ void row_finish(float (&x)[4]) {
-  asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %0, %0" HGS_DPP_ROR8 "v_add_f32_dpp %1, %1, %1" HGS_DPP_ROR8
-               "v_add_f32_dpp %2, %2, %2" HGS_DPP_ROR8 "v_add_f32_dpp %3, %3, %3" HGS_DPP_ROR8
-               : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]));
-}
+// in : v[0 .. 4*NREG) per lane.  out: lane 16 r + 4 q (+0..3) holds the wave total of v[4 * (0,2,1,3)[q] + (0,2,1,3)[r]]
 template <int NREG>
-__device__ __forceinline__ void wave_reduce(const float* v, float (&x)[NREG]) {
+__device__ __forceinline__ float wave_reduce(const float* v) {
+  float x[4];
 #pragma unroll
-  for (int r = 0; r < NREG; r++)
-    x[r] = row_sum16(fold16(fold32(v[4 * r], v[4 * r + 1]), fold32(v[4 * r + 2], v[4 * r + 3])));
-  row_finish(x);
+  for (int r = 0; r < NREG; r++) x[r] = fold16(fold32(v[4 * r], v[4 * r + 1]), fold32(v[4 * r + 2], v[4 * r + 3]));
+#pragma unroll
+  for (int r = NREG; r < 4; r++) x[r] = 0.f;
+  return row_transpose_sum(x[0], x[1], x[2], x[3]);
 }
 
 // ---- record staging ------------------------------------------------------------------------------------------
@@ -371,14 +375,12 @@ __global__ __launch_bounds__(HGS_BLOCK) __attribute__((amdgpu_waves_per_eu(6))) 
       acc_dot_rgb = alpha * col_dot_rgb + (1.f - alpha) * acc_dot_rgb;
 #pragma unroll
       for (int k = NPART; k < NV; k++) v[k] = 0.f;
-      float x[NREG];
-      wave_reduce<NREG>(v, x);
-      if ((lane & 15) == 0) {
-        const int row = lane >> 4;
-        const int k = ((row & 1) << 1) | (row >> 1);   // rows hold values (0,2,1,3) of each group of four
-        float* dst = &part[wave][e][0];
-#pragma unroll
-        for (int rr = 0; rr < NREG; rr++) dst[4 * rr + k] = x[rr];
+      const float tot = wave_reduce<NREG>(v);
+      if ((lane & 3) == 0) {                            // one lane per quad stores the quad's value
+        const int row = lane >> 4, quad = (lane >> 2) & 3;
+        const int k = ((row & 1) << 1) | (row >> 1);    // rows hold values (0,2,1,3) of each group of four,
+        const int reg = ((quad & 1) << 1) | (quad >> 1);  // quads the groups (0,2,1,3)
+        if (reg < NREG) part[wave][e][4 * reg + k] = tot;
       }
     };
     if (m) {
