@@ -148,11 +148,13 @@ __global__ __launch_bounds__(HGS_BLOCK) void blend_fwd_kernel(const uint2* __res
   if (range.y > Rcap) range = make_uint2(0u, 0u);  // binning buffer under-sized (flagged by the scatter kernel)
   const uint32_t L = range.y - range.x;
   const int nb = (int)((L + REC_BATCH - 1) / REC_BATCH);
-  float T = 1.f, acc[C];
+  // T < 0 marks a pixel that is done (saturated, forward.cu:346-351, or outside the image): its magnitude stays the
+  // transmittance it stopped at.  A separate per-lane flag costs a byte register and ~6 vector instructions per entry to
+  // test, merge and update; the sign costs one compare.
+  float T = inside ? 1.f : -1.f, acc[C];
 #pragma unroll
   for (int k = 0; k < C; k++) acc[k] = 0.f;
   uint32_t last = 0;
-  bool done = !inside;
 
   const float4* src = packed + (size_t)range.x * REC4;
   const uint32_t nf4 = L * REC4;
@@ -175,27 +177,26 @@ __global__ __launch_bounds__(HGS_BLOCK) void blend_fwd_kernel(const uint2* __res
     const float* rf = (const float*)&recs[cur][0];
     const uint32_t mk = lane < cnt ? __float_as_uint(rf[lane * 4 * REC4 + 7 + C]) : 0u;
     uint64_t m = __ballot(((mk >> wave) & 1u) != 0u);
-    if (__ballot(!done) == 0) m = 0;
+    if (__ballot(T > 0.f) == 0) m = 0;
     bool wave_done = false;   // every pixel of this wavefront saturated: leave the batch
     auto process = [&](const Rec<C>& r, int e) {
       const float4 r0 = r.q[0], r1 = r.q[1];
       const float dx = r0.x - pxf, dy = r0.y - pyf;
       const float power = -0.5f * (r0.z * dx * dx + r1.x * dy * dy) - r0.w * dx * dy;  // forward.cu:335
       const float alpha = fminf(0.99f, r1.y * __expf(power));                           // :343
-      bool ok = !done && power <= 0.f && alpha >= (1.0f / 255.0f);                      // :336, :344
+      const bool ok = T > 0.f && power <= 0.f && alpha >= (1.0f / 255.0f);              // :336, :344
       if (__ballot(ok) == 0) return;
       const float test_T = T * (1.f - alpha);
       const bool sat = ok && test_T < 0.0001f;                                          // :346-351
-      if (sat) { done = true; ok = false; }
-      if (ok) {
+      if (ok && !sat) {
         const float w = alpha * T;
         const float* f = (const float*)&r.q[0];                                         // features start at float 6
 #pragma unroll
         for (int k = 0; k < C; k++) acc[k] += f[6 + k] * w;                             // :354-355
-        T = test_T;
         last = (uint32_t)(b * REC_BATCH + e + 1);                                       // :328, :361
       }
-      if (__ballot(sat) != 0 && __ballot(!done) == 0) wave_done = true;
+      if (ok) T = sat ? -T : test_T;
+      if (__ballot(sat) != 0 && __ballot(T > 0.f) == 0) wave_done = true;
     };
     if (m) {
       // two record buffers used alternately (LDS reads of the next entry in flight, no register rotation)
@@ -214,7 +215,7 @@ __global__ __launch_bounds__(HGS_BLOCK) void blend_fwd_kernel(const uint2* __res
     }
     if (b + 1 < nb) {
       if (threadIdx.x < REC_BATCH * REC4) recs[cur ^ 1][threadIdx.x] = stage;
-      const uint32_t wave_alive = __ballot(!done) != 0 ? 1u : 0u;   // all lanes vote: taken outside the lane-0 branch
+      const uint32_t wave_alive = __ballot(T > 0.f) != 0 ? 1u : 0u;   // all lanes vote: taken outside the lane-0 branch
       if (lane == 0) alive[cur ^ 1][wave] = wave_alive;
     }
   }
@@ -224,6 +225,7 @@ __global__ __launch_bounds__(HGS_BLOCK) void blend_fwd_kernel(const uint2* __res
   if (lane == 0 && wmax) atomicMax(&tile_maxc[tile], wmax);
   if (inside) {
     const size_t pix = (size_t)py * W + px, HW = (size_t)H * W;
+    T = fabsf(T);
     final_T[pix] = T;
     n_contrib[pix] = last;
 #pragma unroll
