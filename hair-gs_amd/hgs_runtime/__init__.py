@@ -9,7 +9,7 @@ import os
 import subprocess
 
 _PKG_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-LIB_PATH = os.path.join(_PKG_ROOT, "libhgs.so")
+LIB_PATH = os.environ.get("HGS_LIB") or os.path.join(_PKG_ROOT, "libhgs.so")   # HGS_LIB: another build of the same ABI (A/B runs, tools/)
 CSRC = os.path.join(_PKG_ROOT, "csrc")
 _lib = None
 
