@@ -649,7 +649,6 @@ __global__ __launch_bounds__(FIN_THREADS) void head_finalize_kernel(HeadReduce h
                                                                     const float* __restrict__ p_smooth, float* __restrict__ out,
                                                                     SsimGrid gd, const unsigned char* __restrict__ work_flags,
                                                                     int* __restrict__ lists) {
-  __shared__ float red[FIN_THREADS / 64];
   float a2[2], a3[3], s2[2];
   strided_acc<2>(p_ssim, h.nb_ssim, a2);
   strided_acc<3>(p_pix, h.nb_pix, a3);
@@ -695,9 +694,26 @@ __global__ __launch_bounds__(FIN_THREADS) void head_finalize_kernel(HeadReduce h
     }
     if (threadIdx.x == 0) { lists[0] = all; lists[1] = gd.total - all; }
   }
-  const float ssim_s = block_sum_1024(a2[0], red), l1_s = block_sum_1024(a2[1], red);
-  const float ori_s = block_sum_1024(a3[0], red), ori_c = block_sum_1024(a3[1], red), bce_s = block_sum_1024(a3[2], red);
-  const float sm_s = block_sum_1024(s2[0], red), sm_c = block_sum_1024(s2[1], red);
+  // the seven sums together: one shuffle tree per value, ONE exchange through LDS (two barriers instead of fourteen)
+  float sv[7] = {a2[0], a2[1], a3[0], a3[1], a3[2], s2[0], s2[1]};
+#pragma unroll
+  for (int q = 0; q < 7; q++)
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) sv[q] += __shfl_xor(sv[q], d, 64);
+  __shared__ float red7[7][FIN_THREADS / 64];
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0)
+#pragma unroll
+    for (int q = 0; q < 7; q++) red7[q][threadIdx.x >> 6] = sv[q];
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < 7; q++) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < FIN_THREADS / 64; k++) t += red7[q][k];   // (same order as block_sum_1024)
+    sv[q] = t;
+  }
+  const float ssim_s = sv[0], l1_s = sv[1], ori_s = sv[2], ori_c = sv[3], bce_s = sv[4], sm_s = sv[5], sm_c = sv[6];
   if (threadIdx.x != 0) return;
   const float l1 = l1_s * h.inv_chw, dssim = 1.f - ssim_s * h.inv_chw;
   const float w_l1 = fmaxf(0.f, 1.f - h.l_dssim);
