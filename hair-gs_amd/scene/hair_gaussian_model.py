@@ -21,6 +21,79 @@ from utils.general import get_expon_lr_func, inverse_sigmoid
 from utils.transform import calculate_rotation_from_vectors
 
 
+def walk_chains(pairs, n_ep, id_to_strand, complementary, end_distance):
+    """Order every open polyline of the edge table `pairs` ([n, 2] endpoint ids; every id has degree 1 or 2) from one end
+    to the other, without walking it edge by edge in Python (a model in training holds 10^5-10^6 segments and this runs at
+    every densification / merge): pointer doubling over the 2 n directed arcs.  Arc (u -> v) is followed by the arc that
+    leaves v through v's other edge; after ceil(log2(longest chain)) doublings every arc knows the chain end it runs
+    into and how many edges lie between.  The chain starts at its end with the SMALLER id (what an id-ordered walk over
+    the ends visits first), strands are numbered in the order of their starts, and a strand is reversed when its start is
+    farther from the reference roots than its other end (`end_distance(ids) -> distances`); reference
+    scene/hair_gaussian_model.py:1410-1498.  Fills id_to_strand / complementary in place and returns the object arrays
+    (list_strands [n_seg, 2] (cur, next) ids, list_strands_segments_id [n_seg] rows of `pairs`).  Closed loops have no end
+    and are left out, like in the walk."""
+    n = pairs.shape[0]
+    pairs = np.ascontiguousarray(pairs, dtype=np.int64)
+    flat = pairs.reshape(-1)
+    # incidence table: endpoint id -> its (at most two) rows
+    order = np.argsort(flat, kind="stable")
+    ids_sorted = flat[order]
+    first = np.r_[True, ids_sorted[1:] != ids_sorted[:-1]]
+    inc = -np.ones((n_ep, 2), np.int64)
+    inc[ids_sorted[first], 0] = order[first] // 2
+    inc[ids_sorted[~first], 1] = order[~first] // 2
+    # arcs: 2 r = pairs[r, 0] -> pairs[r, 1], 2 r + 1 the reverse
+    rows = np.repeat(np.arange(n, dtype=np.int64), 2)
+    head = np.stack([pairs[:, 1], pairs[:, 0]], axis=1).reshape(-1)          # node the arc arrives at
+    r0, r1 = inc[head, 0], inc[head, 1]
+    nrow = np.where(r0 != rows, r0, r1)                                        # the other edge at the head (-1: chain end)
+    terminal = nrow < 0
+    nr = np.where(terminal, 0, nrow)
+    succ = np.where(terminal, np.arange(2 * n), 2 * nr + (pairs[nr, 0] != head))
+    dist = np.where(terminal, 0, 1).astype(np.int64)
+    reached = terminal.copy()
+    for _ in range(max(1, int(np.ceil(np.log2(max(n, 2)))) + 1)):
+        if reached.all():
+            break
+        dist = dist + np.where(reached, 0, dist[succ])
+        reached_next = reached | reached[succ]
+        succ = np.where(reached, succ, succ[succ])
+        reached = reached_next
+    end_of = head[succ]                                                       # chain end in the arc's direction
+    ok = reached[0::2] & reached[1::2]                                        # (arcs of closed loops never arrive)
+    e_fwd, e_bwd = end_of[0::2], end_of[1::2]                                 # ends beyond pairs[:,1] / beyond pairs[:,0]
+    start = np.minimum(e_fwd, e_bwd)
+    from_bwd = e_bwd == start                                                 # walking from the start meets pairs[:,0] first
+    pos = np.where(from_bwd, dist[1::2], dist[0::2])                          # edges between the start and this edge
+    cur = np.where(from_bwd, pairs[:, 0], pairs[:, 1])
+    nxt = np.where(from_bwd, pairs[:, 1], pairs[:, 0])
+    other = np.maximum(e_fwd, e_bwd)
+    sel = np.nonzero(ok)[0]
+    if sel.size == 0:
+        e = np.empty(0, dtype=object)
+        return e, e.copy()
+    key = np.lexsort((pos[sel], start[sel]))
+    sel = sel[key]
+    st = start[sel]
+    bounds = np.r_[0, np.nonzero(st[1:] != st[:-1])[0] + 1, st.size]
+    starts, others = st[bounds[:-1]], other[sel][bounds[:-1]]
+    sid = np.repeat(np.arange(starts.size), np.diff(bounds))
+    id_to_strand[cur[sel]] = sid
+    id_to_strand[nxt[sel]] = sid
+    complementary[starts], complementary[others] = others, starts
+    d0, d1 = end_distance(starts), end_distance(others)
+    flip = np.asarray(d0) > np.asarray(d1)                                    # the far end was first: reverse
+    seq = np.stack([cur[sel], nxt[sel]], axis=1)
+    ls, lr = np.empty(starts.size, dtype=object), np.empty(starts.size, dtype=object)
+    for i in range(starts.size):
+        a, b = bounds[i], bounds[i + 1]
+        if flip[i]:
+            ls[i], lr[i] = seq[a:b][::-1, ::-1].copy(), sel[a:b][::-1].copy()
+        else:
+            ls[i], lr[i] = seq[a:b].copy(), sel[a:b].copy()
+    return ls, lr
+
+
 class StrandsInfo(NamedTuple):
     list_strands: np.ndarray              # object array; each [n_seg, 2] endpoint ids, root -> tip
     list_strands_segments_id: np.ndarray  # object array; each [n_seg] rows of endpoint_pairs
@@ -285,46 +358,8 @@ class HairGaussianModel(HairTopologyMixin, GaussianModel):
             self.strands_info = StrandsInfo(e, e.copy(), id_to_strand, complementary)
             self._smooth_pairs = None
             return
-        # incidence table: endpoint id -> up to two rows (order of appearance, like the reference's id_to_row_id)
-        flat = pairs.reshape(-1)
-        order = np.argsort(flat, kind="stable")
-        ids_sorted = flat[order]
-        first = np.r_[True, ids_sorted[1:] != ids_sorted[:-1]]
-        inc = -np.ones((n_ep, 2), np.int64)
-        inc[ids_sorted[first], 0] = order[first] // 2
-        second = ~first
-        inc[ids_sorted[second], 1] = order[second] // 2
-        counts = np.bincount(flat, minlength=n_ep)
-        strand_ends = np.nonzero(counts == 1)[0]
-        visited = np.zeros(n_ep, bool)
-        strands, strands_rows = [], []
-        for start in strand_ends:
-            if visited[start]:
-                continue
-            cur, row = start, inc[start, 0]
-            seq, seq_rows = [], []
-            sid = len(strands)
-            while row != -1:
-                id_to_strand[cur] = sid
-                a, b = pairs[row]
-                nxt = a if a != cur else b
-                seq.append((cur, nxt))
-                seq_rows.append(row)
-                cur = nxt
-                r0, r1 = inc[cur]
-                row = r0 if r0 != row else r1
-            id_to_strand[cur] = sid
-            visited[start] = visited[cur] = True
-            complementary[start], complementary[cur] = cur, start
-            seq, seq_rows = np.asarray(seq, np.int64), np.asarray(seq_rows, np.int64)
-            dist, _ = tree.query(np.stack([endpoints[start], endpoints[cur]]), k=1)
-            if dist[0] > dist[1]:  # the far end was first: reverse direction and order
-                seq, seq_rows = seq[::-1, ::-1].copy(), seq_rows[::-1].copy()
-            strands.append(seq)
-            strands_rows.append(seq_rows)  # row ids index the (foreground-filtered) pair table, like the reference
-        ls, lr = np.empty(len(strands), dtype=object), np.empty(len(strands), dtype=object)
-        for i, (a, b) in enumerate(zip(strands, strands_rows)):
-            ls[i], lr[i] = a, b
+        ls, lr = walk_chains(pairs, n_ep, id_to_strand, complementary,
+                             lambda ends: tree.query(endpoints[ends], k=1)[0])
         self.strands_info = StrandsInfo(ls, lr, id_to_strand, complementary)
         self._smooth_pairs = None
 

@@ -285,3 +285,75 @@ def test_merge_driver_rounds_until_nothing_left():
     assert len(m.strands_info.list_strands) == 1 and m.strands_info.list_strands[0].shape[0] == 15
     assert merge_cli.merge_rounds(m, 10, log=log.append) == 0      # nothing left to merge
     _chain_invariants(m)
+
+
+def _walk_chains_loop(pairs, n_ep, end_distance):
+    """Edge-by-edge walk (the form the reference uses, scene/hair_gaussian_model.py:1410-1498): checker for the
+    vectorised scene.hair_gaussian_model.walk_chains."""
+    id_to_strand = -np.ones(n_ep, np.int32)
+    complementary = -np.ones(n_ep, np.int32)
+    flat = pairs.reshape(-1)
+    order = np.argsort(flat, kind="stable")
+    ids_sorted = flat[order]
+    first = np.r_[True, ids_sorted[1:] != ids_sorted[:-1]]
+    inc = -np.ones((n_ep, 2), np.int64)
+    inc[ids_sorted[first], 0] = order[first] // 2
+    inc[ids_sorted[~first], 1] = order[~first] // 2
+    counts = np.bincount(flat, minlength=n_ep)
+    visited = np.zeros(n_ep, bool)
+    strands, strands_rows = [], []
+    for start in np.nonzero(counts == 1)[0]:
+        if visited[start]:
+            continue
+        cur, row = start, inc[start, 0]
+        seq, seq_rows = [], []
+        sid = len(strands)
+        while row != -1:
+            id_to_strand[cur] = sid
+            a, b = pairs[row]
+            nxt = a if a != cur else b
+            seq.append((cur, nxt))
+            seq_rows.append(row)
+            cur = nxt
+            r0, r1 = inc[cur]
+            row = r0 if r0 != row else r1
+        id_to_strand[cur] = sid
+        visited[start] = visited[cur] = True
+        complementary[start], complementary[cur] = cur, start
+        seq, seq_rows = np.asarray(seq, np.int64), np.asarray(seq_rows, np.int64)
+        d = end_distance(np.array([start, cur]))
+        if d[0] > d[1]:
+            seq, seq_rows = seq[::-1, ::-1].copy(), seq_rows[::-1].copy()
+        strands.append(seq)
+        strands_rows.append(seq_rows)
+    return strands, strands_rows, id_to_strand, complementary
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_walk_chains_matches_edge_by_edge_walk(seed):
+    from scene.hair_gaussian_model import walk_chains
+    rng = np.random.default_rng(seed)
+    n_ep = 700
+    ids = rng.permutation(n_ep)[:620]                     # some endpoint ids stay unused
+    pairs, pos = [], 0
+    while pos + 1 < ids.size:
+        ln = int(rng.integers(1, 40))                     # chains of 1 .. 39 edges
+        chain = ids[pos:pos + ln + 1]
+        pos += ln + 1
+        for a, b in zip(chain[:-1], chain[1:]):
+            pairs.append((a, b) if rng.random() < 0.5 else (b, a))
+    if seed == 2:                                         # a closed loop has no end: left out by both
+        loop = np.arange(n_ep, n_ep + 5)
+        pairs += [(loop[i], loop[(i + 1) % 5]) for i in range(5)]
+        n_ep += 5
+    pairs = np.asarray(pairs, np.int64)[rng.permutation(len(pairs))]
+    dist = rng.random(n_ep)
+    ref = _walk_chains_loop(pairs, n_ep, lambda e: dist[e])
+    i2s, comp = -np.ones(n_ep, np.int32), -np.ones(n_ep, np.int32)
+    ls, lr = walk_chains(pairs, n_ep, i2s, comp, lambda e: dist[e])
+    assert len(ls) == len(ref[0]) > 10
+    for a, b, ra, rb in zip(ls, lr, ref[0], ref[1]):
+        np.testing.assert_array_equal(a, ra)
+        np.testing.assert_array_equal(b, rb)
+    np.testing.assert_array_equal(i2s, ref[2])
+    np.testing.assert_array_equal(comp, ref[3])

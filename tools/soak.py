@@ -1,0 +1,47 @@
+"""Soak run: the full training loop (train.training: graph replay, densification / merging / opacity reset, re-captures,
+capacity headroom checks) on a synthetic strand workload for a few thousand iterations.  Prints the loss trajectory, the
+PSNR of the first views against their targets before and after, the segment count and the wall-clock rate INCLUDING the
+topology operators and re-captures (bench.py times the steady-state iteration only)."""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "hair-gs_amd")]
+import torch
+import hgs_runtime as rt
+from arguments import OptimizationParams
+from gaussian_renderer import render
+from synthetic import build_workload
+from train import training
+from utils.general import safe_state
+
+wl = sys.argv[1] if len(sys.argv) > 1 else "north_star"
+iters = int(sys.argv[2]) if len(sys.argv) > 2 else 3000
+rt.lib()
+safe_state(True)
+model, cams, extent = build_workload(wl, device=torch.device("cuda"), seed=0, n_views=16)
+opt = OptimizationParams()
+model.training_setup(opt)
+bg = torch.zeros(3, device="cuda")
+
+
+def psnr():
+    with torch.no_grad():
+        v = []
+        for c in cams[:4]:
+            img = render(c, model, bg)["render"]
+            v.append(float(-10 * torch.log10(((img - c.original_image.cuda()) ** 2).mean())))
+    return sum(v) / len(v)
+
+
+p0, n0 = psnr(), model.get_xyz.shape[0]
+done, t0 = 0, time.perf_counter()
+while done < iters:
+    n = min(500, iters - done)
+    ema = training(model, cams, opt, iterations=n, extent=extent, start_iteration=done)
+    done += n
+    torch.cuda.synchronize()
+    print(f"[it {done}] loss(ema) {float(ema):.5f}  segments {model.get_xyz.shape[0]}  elapsed {time.perf_counter() - t0:.2f} s", flush=True)
+dt = time.perf_counter() - t0
+p1 = psnr()
+assert all(bool(torch.isfinite(p).all()) for p in (model._endpoints, model._opacity, model._features_dc)), "non-finite parameters"
+print(f"{wl}: {iters} iterations in {dt:.2f} s = {iters / dt:.0f} it/s incl. topology operators and re-captures; "
+      f"PSNR {p0:.2f} -> {p1:.2f} dB; segments {n0} -> {model.get_xyz.shape[0]}")
