@@ -71,7 +71,7 @@ def walk_chains(pairs, n_ep, id_to_strand, complementary, end_distance):
     sel = np.nonzero(ok)[0]
     if sel.size == 0:
         e = np.empty(0, dtype=object)
-        return e, e.copy()
+        return e, e.copy(), (np.zeros(1, np.int64), np.zeros((0, 2), np.int64))
     key = np.lexsort((pos[sel], start[sel]))
     sel = sel[key]
     st = start[sel]
@@ -83,15 +83,20 @@ def walk_chains(pairs, n_ep, id_to_strand, complementary, end_distance):
     complementary[starts], complementary[others] = others, starts
     d0, d1 = end_distance(starts), end_distance(others)
     flip = np.asarray(d0) > np.asarray(d1)                                    # the far end was first: reverse
-    seq = np.stack([cur[sel], nxt[sel]], axis=1)
+    # reversed strands: reverse the order of their edges and swap (cur, next), in bulk; the per-strand arrays are then
+    # views into the two flat arrays (models hold 10^5 strands: no per-strand copies)
+    lens = np.diff(bounds)
+    flip_e = np.repeat(flip, lens)
+    j = np.arange(sel.size)
+    src = np.where(flip_e, np.repeat(bounds[:-1] + bounds[1:] - 1, lens) - j, j)
+    c, x = cur[sel][src], nxt[sel][src]
+    seq = np.stack([np.where(flip_e, x, c), np.where(flip_e, c, x)], axis=1)
+    rows_sorted = sel[src]
     ls, lr = np.empty(starts.size, dtype=object), np.empty(starts.size, dtype=object)
-    for i in range(starts.size):
-        a, b = bounds[i], bounds[i + 1]
-        if flip[i]:
-            ls[i], lr[i] = seq[a:b][::-1, ::-1].copy(), sel[a:b][::-1].copy()
-        else:
-            ls[i], lr[i] = seq[a:b].copy(), sel[a:b].copy()
-    return ls, lr
+    cuts = bounds[1:-1]
+    for i, (a, b) in enumerate(zip(np.split(seq, cuts), np.split(rows_sorted, cuts))):
+        ls[i], lr[i] = a, b
+    return ls, lr, (bounds.astype(np.int64), seq)
 
 
 class StrandsInfo(NamedTuple):
@@ -99,6 +104,7 @@ class StrandsInfo(NamedTuple):
     list_strands_segments_id: np.ndarray  # object array; each [n_seg] rows of endpoint_pairs
     id_to_strand_id: np.ndarray           # endpoint id -> strand id (-1 if none)
     strand_endpoint_id_to_complementary: np.ndarray  # strand end id -> the other end of its strand
+    flat: tuple = None                    # (offsets [S+1], rows [sum n_seg, 2]): list_strands concatenated (its elements are views)
 
 
 class HairGaussianModel(HairTopologyMixin, GaussianModel):
@@ -358,17 +364,19 @@ class HairGaussianModel(HairTopologyMixin, GaussianModel):
             self.strands_info = StrandsInfo(e, e.copy(), id_to_strand, complementary)
             self._smooth_pairs = None
             return
-        ls, lr = walk_chains(pairs, n_ep, id_to_strand, complementary,
-                             lambda ends: tree.query(endpoints[ends], k=1)[0])
-        self.strands_info = StrandsInfo(ls, lr, id_to_strand, complementary)
+        ls, lr, flat = walk_chains(pairs, n_ep, id_to_strand, complementary,
+                                   lambda ends: tree.query(endpoints[ends], k=1)[0])
+        self.strands_info = StrandsInfo(ls, lr, id_to_strand, complementary, flat)
         self._smooth_pairs = None
 
     def smoothness_index_pairs(self):
         """[pairs, 2, 2] endpoint-id tensor of consecutive segments of every strand, cached on the device until the
         topology changes.  (The reference rebuilds it on the CPU through Cython every iteration, losses.py:193-199.)"""
         if self._smooth_pairs is None:
-            from c_utils import filter_strand_list_segments
-            idx = filter_strand_list_segments(self.strands_info.list_strands)
+            from c_utils import filter_strand_list_segments, filter_strand_segments_flat
+            info = self.strands_info
+            idx = (filter_strand_segments_flat(*info.flat) if getattr(info, "flat", None) is not None
+                   else filter_strand_list_segments(info.list_strands))
             self._smooth_pairs = torch.as_tensor(np.asarray(idx), device=self.device, dtype=torch.long)
         return self._smooth_pairs
 
