@@ -28,7 +28,7 @@ def merge_rounds(hair_gs, max_rounds, log=print):
         hair_gs.compute_strands_info()
         rounds = i
         log(f"[merge {i}] merged {pairs.shape[0]} endpoint pairs in {time.time() - t0:.3f} s; "
-            f"{len(hair_gs.strands_info.list_strands)} strands, {hair_gs.get_xyz.shape[0]} segments")
+            f"{hair_gs.strands_info.n_strands} strands, {hair_gs.get_xyz.shape[0]} segments")
     return rounds
 
 

@@ -9,7 +9,6 @@ Gradients flow through all three back to the shared endpoints (scatter-add of pe
 This file holds the rasterizer-facing surface + optimizer plumbing + strand bookkeeping; the topology
 operators (split / clone / merge / grow) live in scene/hair_topology.py.
 """
-from typing import NamedTuple
 
 import numpy as np
 import torch
@@ -29,9 +28,9 @@ def walk_chains(pairs, n_ep, id_to_strand, complementary, end_distance):
     into and how many edges lie between.  The chain starts at its end with the SMALLER id (what an id-ordered walk over
     the ends visits first), strands are numbered in the order of their starts, and a strand is reversed when its start is
     farther from the reference roots than its other end (`end_distance(ids) -> distances`); reference
-    scene/hair_gaussian_model.py:1410-1498.  Fills id_to_strand / complementary in place and returns the object arrays
-    (list_strands [n_seg, 2] (cur, next) ids, list_strands_segments_id [n_seg] rows of `pairs`).  Closed loops have no end
-    and are left out, like in the walk."""
+    scene/hair_gaussian_model.py:1410-1498.  Fills id_to_strand / complementary in place and returns the strands flat:
+    offsets [S+1], rows [sum n_seg, 2] (cur, next) ids, segment rows [sum n_seg] (rows of `pairs`).  Closed loops have no
+    end and are left out, like in the walk."""
     n = pairs.shape[0]
     pairs = np.ascontiguousarray(pairs, dtype=np.int64)
     flat = pairs.reshape(-1)
@@ -70,8 +69,7 @@ def walk_chains(pairs, n_ep, id_to_strand, complementary, end_distance):
     other = np.maximum(e_fwd, e_bwd)
     sel = np.nonzero(ok)[0]
     if sel.size == 0:
-        e = np.empty(0, dtype=object)
-        return e, e.copy(), (np.zeros(1, np.int64), np.zeros((0, 2), np.int64))
+        return np.zeros(1, np.int64), np.zeros((0, 2), np.int64), np.zeros(0, np.int64)
     key = np.lexsort((pos[sel], start[sel]))
     sel = sel[key]
     st = start[sel]
@@ -92,19 +90,46 @@ def walk_chains(pairs, n_ep, id_to_strand, complementary, end_distance):
     c, x = cur[sel][src], nxt[sel][src]
     seq = np.stack([np.where(flip_e, x, c), np.where(flip_e, c, x)], axis=1)
     rows_sorted = sel[src]
-    ls, lr = np.empty(starts.size, dtype=object), np.empty(starts.size, dtype=object)
-    cuts = bounds[1:-1]
-    for i, (a, b) in enumerate(zip(np.split(seq, cuts), np.split(rows_sorted, cuts))):
-        ls[i], lr[i] = a, b
-    return ls, lr, (bounds.astype(np.int64), seq)
+    return bounds.astype(np.int64), seq, rows_sorted
 
 
-class StrandsInfo(NamedTuple):
-    list_strands: np.ndarray              # object array; each [n_seg, 2] endpoint ids, root -> tip
-    list_strands_segments_id: np.ndarray  # object array; each [n_seg] rows of endpoint_pairs
-    id_to_strand_id: np.ndarray           # endpoint id -> strand id (-1 if none)
-    strand_endpoint_id_to_complementary: np.ndarray  # strand end id -> the other end of its strand
-    flat: tuple = None                    # (offsets [S+1], rows [sum n_seg, 2]): list_strands concatenated (its elements are views)
+class StrandsInfo:
+    """Strands of the model (reference scene/hair_gaussian_model.py:1410-1498, same attribute names).  Held flat --
+    `flat` = (offsets [S+1], rows [sum n_seg, 2] (cur, next) endpoint ids, root -> tip, segment rows [sum n_seg]) --;
+    the reference's per-strand object arrays are built on first access, as views into the flat arrays (a model in training
+    holds 10^5 strands and re-derives them at every densification / merge, mostly without looking at single strands)."""
+
+    def __init__(self, offsets, rows, segment_rows, id_to_strand_id, strand_endpoint_id_to_complementary):
+        self.offsets, self.rows, self.segment_rows = offsets, rows, segment_rows
+        self.id_to_strand_id = id_to_strand_id                      # endpoint id -> strand id (-1 if none)
+        self.strand_endpoint_id_to_complementary = strand_endpoint_id_to_complementary  # strand end -> its other end
+        self._lists = None
+
+    @property
+    def flat(self):
+        return self.offsets, self.rows
+
+    @property
+    def n_strands(self):
+        return len(self.offsets) - 1
+
+    def _materialise(self):
+        if self._lists is None:
+            n = self.n_strands
+            ls, lr = np.empty(n, dtype=object), np.empty(n, dtype=object)
+            o = self.offsets
+            for i in range(n):
+                ls[i], lr[i] = self.rows[o[i]:o[i + 1]], self.segment_rows[o[i]:o[i + 1]]
+            self._lists = (ls, lr)
+        return self._lists
+
+    @property
+    def list_strands(self):              # object array; each [n_seg, 2] endpoint ids, root -> tip
+        return self._materialise()[0]
+
+    @property
+    def list_strands_segments_id(self):  # object array; each [n_seg] rows of (foreground-filtered) endpoint_pairs
+        return self._materialise()[1]
 
 
 class HairGaussianModel(HairTopologyMixin, GaussianModel):
@@ -360,23 +385,21 @@ class HairGaussianModel(HairTopologyMixin, GaussianModel):
         id_to_strand = -np.ones(n_ep, np.int32)
         complementary = -np.ones(n_ep, np.int32)
         if pairs.shape[0] == 0:
-            e = np.empty(0, dtype=object)
-            self.strands_info = StrandsInfo(e, e.copy(), id_to_strand, complementary)
+            self.strands_info = StrandsInfo(np.zeros(1, np.int64), np.zeros((0, 2), np.int64), np.zeros(0, np.int64),
+                                            id_to_strand, complementary)
             self._smooth_pairs = None
             return
-        ls, lr, flat = walk_chains(pairs, n_ep, id_to_strand, complementary,
-                                   lambda ends: tree.query(endpoints[ends], k=1)[0])
-        self.strands_info = StrandsInfo(ls, lr, id_to_strand, complementary, flat)
+        offsets, rows, seg_rows = walk_chains(pairs, n_ep, id_to_strand, complementary,
+                                              lambda ends: tree.query(endpoints[ends], k=1)[0])
+        self.strands_info = StrandsInfo(offsets, rows, seg_rows, id_to_strand, complementary)
         self._smooth_pairs = None
 
     def smoothness_index_pairs(self):
         """[pairs, 2, 2] endpoint-id tensor of consecutive segments of every strand, cached on the device until the
         topology changes.  (The reference rebuilds it on the CPU through Cython every iteration, losses.py:193-199.)"""
         if self._smooth_pairs is None:
-            from c_utils import filter_strand_list_segments, filter_strand_segments_flat
-            info = self.strands_info
-            idx = (filter_strand_segments_flat(*info.flat) if getattr(info, "flat", None) is not None
-                   else filter_strand_list_segments(info.list_strands))
+            from c_utils import filter_strand_segments_flat
+            idx = filter_strand_segments_flat(*self.strands_info.flat)
             self._smooth_pairs = torch.as_tensor(np.asarray(idx), device=self.device, dtype=torch.long)
         return self._smooth_pairs
 

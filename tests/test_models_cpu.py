@@ -350,9 +350,9 @@ def test_walk_chains_matches_edge_by_edge_walk(seed):
     dist = rng.random(n_ep)
     ref = _walk_chains_loop(pairs, n_ep, lambda e: dist[e])
     i2s, comp = -np.ones(n_ep, np.int32), -np.ones(n_ep, np.int32)
-    ls, lr, (offsets, rows) = walk_chains(pairs, n_ep, i2s, comp, lambda e: dist[e])
-    np.testing.assert_array_equal(rows, np.concatenate(list(ls)))
-    np.testing.assert_array_equal(np.diff(offsets), [len(a) for a in ls])
+    from scene.hair_gaussian_model import StrandsInfo
+    info = StrandsInfo(*walk_chains(pairs, n_ep, i2s, comp, lambda e: dist[e]), i2s, comp)
+    ls, lr = info.list_strands, info.list_strands_segments_id
     assert len(ls) == len(ref[0]) > 10
     for a, b, ra, rb in zip(ls, lr, ref[0], ref[1]):
         np.testing.assert_array_equal(a, ra)
