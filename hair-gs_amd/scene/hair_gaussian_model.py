@@ -79,8 +79,8 @@ def walk_chains(pairs, n_ep, id_to_strand, complementary, end_distance):
     id_to_strand[cur[sel]] = sid
     id_to_strand[nxt[sel]] = sid
     complementary[starts], complementary[others] = others, starts
-    d0, d1 = end_distance(starts), end_distance(others)
-    flip = np.asarray(d0) > np.asarray(d1)                                    # the far end was first: reverse
+    d = np.asarray(end_distance(np.concatenate([starts, others])))
+    flip = d[:starts.size] > d[starts.size:]                                  # the far end was first: reverse
     # reversed strands: reverse the order of their edges and swap (cur, next), in bulk; the per-strand arrays are then
     # views into the two flat arrays (models hold 10^5 strands: no per-strand copies)
     lens = np.diff(bounds)
@@ -390,7 +390,7 @@ class HairGaussianModel(HairTopologyMixin, GaussianModel):
             self._smooth_pairs = None
             return
         offsets, rows, seg_rows = walk_chains(pairs, n_ep, id_to_strand, complementary,
-                                              lambda ends: tree.query(endpoints[ends], k=1)[0])
+                                              lambda ends: tree.query(endpoints[ends], k=1, workers=-1)[0])
         self.strands_info = StrandsInfo(offsets, rows, seg_rows, id_to_strand, complementary)
         self._smooth_pairs = None
 
