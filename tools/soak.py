@@ -42,6 +42,7 @@ while done < iters:
     print(f"[it {done}] loss(ema) {float(ema):.5f}  segments {model.get_xyz.shape[0]}  elapsed {time.perf_counter() - t0:.2f} s", flush=True)
 dt = time.perf_counter() - t0
 p1 = psnr()
-assert all(bool(torch.isfinite(p).all()) for p in (model._endpoints, model._opacity, model._features_dc)), "non-finite parameters"
+pos = model._endpoints if hasattr(model, "_endpoints") else model._xyz
+assert all(bool(torch.isfinite(p).all()) for p in (pos, model._opacity, model._features_dc)), "non-finite parameters"
 print(f"{wl}: {iters} iterations in {dt:.2f} s = {iters / dt:.0f} it/s incl. topology operators and re-captures; "
       f"PSNR {p0:.2f} -> {p1:.2f} dB; segments {n0} -> {model.get_xyz.shape[0]}")
