@@ -156,11 +156,16 @@ class HairTopologyMixin:
         self.prune_segments(prune)
 
     # ---- merging (reference :1079-1096, :1205-1362, :619-706) ----------------------------------------------------------
-    def merging(self, training_info=None):
-        self.compute_strands_info()
+    def merging(self, training_info=None, strands_info_is_current=False):
+        """strands_info_is_current: the caller ran densification() (which ends with compute_strands_info) right before,
+        with no optimizer step or topology change since -- the reference recomputes regardless (:1079-1096)."""
+        if not strands_info_is_current or self.strands_info is None:
+            self.compute_strands_info()
         pairs = self.compute_endpoint_pair_to_merge()
         if training_info is not None:
             training_info.densification_info["merge"] = int(pairs.shape[0])
+        if pairs.shape[0] == 0:
+            return                      # nothing merged: the strands are what they were
         self.merge_endpoint_pairs(pairs)
         self.compute_strands_info()
 

@@ -378,7 +378,7 @@ def apply_topology(gaussians, opt, iteration, extent, due, vp=None):
         if "reset_opacity" in due:
             gaussians.reset_opacity()
         if "merge" in due:
-            gaussians.merging(training_info=None)
+            gaussians.merging(training_info=None, strands_info_is_current="densify" in due)
 
 
 def training(gaussians, cameras, opt, iterations=None, extent=1.0, seed=0, log_every=0, vp=None, start_iteration=0,
