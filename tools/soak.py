@@ -36,7 +36,13 @@ p0, n0 = psnr(), model.get_xyz.shape[0]
 done, t0 = 0, time.perf_counter()
 while done < iters:
     n = min(500, iters - done)
-    ema = training(model, cams, opt, iterations=n, extent=extent, start_iteration=done)
+    if os.environ.get("SOAK_PROFILE") and done + n >= iters:      # cProfile of the last chunk
+        import cProfile, pstats
+        pr = cProfile.Profile(); pr.enable()
+        ema = training(model, cams, opt, iterations=n, extent=extent, start_iteration=done)
+        pr.disable(); pstats.Stats(pr).sort_stats("cumulative").print_stats(45)
+    else:
+        ema = training(model, cams, opt, iterations=n, extent=extent, start_iteration=done)
     done += n
     torch.cuda.synchronize()
     print(f"[it {done}] loss(ema) {float(ema):.5f}  segments {model.get_xyz.shape[0]}  elapsed {time.perf_counter() - t0:.2f} s", flush=True)
