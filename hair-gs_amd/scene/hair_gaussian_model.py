@@ -93,6 +93,85 @@ def walk_chains(pairs, n_ep, id_to_strand, complementary, end_distance):
     return bounds.astype(np.int64), seq, rows_sorted
 
 
+def walk_chains_torch(pairs, n_ep, end_distance):
+    """walk_chains on torch tensors (the model's device: the doubling steps are gathers over 2n arcs, a few microseconds
+    each on the GPU against milliseconds in numpy).  pairs: [n, 2] int64 tensor; end_distance(ids tensor) -> distances.
+    Returns (offsets, rows, segment rows, id_to_strand int32 [n_ep], complementary int32 [n_ep]) as tensors on the device;
+    same strands, order and orientation as walk_chains."""
+    dev = pairs.device
+    n = pairs.shape[0]
+    i64 = dict(dtype=torch.int64, device=dev)
+    id_to_strand = torch.full((n_ep,), -1, dtype=torch.int32, device=dev)
+    complementary = torch.full((n_ep,), -1, dtype=torch.int32, device=dev)
+    pairs = pairs.to(torch.int64).contiguous()
+    flat = pairs.reshape(-1)
+    order = torch.argsort(flat, stable=True)
+    ids_sorted = flat[order]
+    first = torch.ones(flat.shape[0], dtype=torch.bool, device=dev)
+    first[1:] = ids_sorted[1:] != ids_sorted[:-1]
+    inc = torch.full((n_ep, 2), -1, **i64)
+    inc[ids_sorted[first], 0] = order[first] // 2
+    inc[ids_sorted[~first], 1] = order[~first] // 2
+    rows = torch.arange(n, **i64).repeat_interleave(2)
+    head = torch.stack([pairs[:, 1], pairs[:, 0]], dim=1).reshape(-1)
+    r0, r1 = inc[head, 0], inc[head, 1]
+    nrow = torch.where(r0 != rows, r0, r1)
+    terminal = nrow < 0
+    nr = torch.where(terminal, torch.zeros_like(nrow), nrow)
+    succ = torch.where(terminal, torch.arange(2 * n, **i64), 2 * nr + (pairs[nr, 0] != head).to(torch.int64))
+    dist = (~terminal).to(torch.int64)
+    reached = terminal.clone()
+    for _ in range(max(1, int(np.ceil(np.log2(max(n, 2)))) + 1)):   # fixed count: no host round trip per step
+        dist = dist + torch.where(reached, torch.zeros_like(dist), dist[succ])
+        reached_next = reached | reached[succ]
+        succ = torch.where(reached, succ, succ[succ])
+        reached = reached_next
+    end_of = head[succ]
+    ok = reached[0::2] & reached[1::2]
+    e_fwd, e_bwd = end_of[0::2], end_of[1::2]
+    start = torch.minimum(e_fwd, e_bwd)
+    from_bwd = e_bwd == start
+    pos = torch.where(from_bwd, dist[1::2], dist[0::2])
+    cur = torch.where(from_bwd, pairs[:, 0], pairs[:, 1])
+    nxt = torch.where(from_bwd, pairs[:, 1], pairs[:, 0])
+    other = torch.maximum(e_fwd, e_bwd)
+    sel = torch.nonzero(ok).squeeze(1)
+    if sel.numel() == 0:
+        return (torch.zeros(1, **i64), torch.zeros((0, 2), **i64), torch.zeros(0, **i64), id_to_strand, complementary)
+    key = start[sel] * (int(n) + 1) + pos[sel]                                # (start, position) in one key: unique
+    sel = sel[torch.argsort(key)]
+    st = start[sel]
+    cut = torch.nonzero(st[1:] != st[:-1]).squeeze(1) + 1
+    bounds = torch.cat([torch.zeros(1, **i64), cut, torch.tensor([st.numel()], **i64)])
+    lens = bounds[1:] - bounds[:-1]
+    starts, others = st[bounds[:-1]], other[sel][bounds[:-1]]
+    sid = torch.arange(starts.numel(), device=dev, dtype=torch.int32).repeat_interleave(lens)
+    id_to_strand[cur[sel]] = sid
+    id_to_strand[nxt[sel]] = sid
+    complementary[starts] = others.to(torch.int32)
+    complementary[others] = starts.to(torch.int32)
+    d = end_distance(torch.cat([starts, others]))
+    flip = d[:starts.numel()] > d[starts.numel():]
+    flip_e = flip.repeat_interleave(lens)
+    j = torch.arange(sel.numel(), **i64)
+    src = torch.where(flip_e, (bounds[:-1] + bounds[1:] - 1).repeat_interleave(lens) - j, j)
+    c, x = cur[sel][src], nxt[sel][src]
+    seq = torch.stack([torch.where(flip_e, x, c), torch.where(flip_e, c, x)], dim=1)
+    return bounds, seq, sel[src], id_to_strand, complementary
+
+
+def nearest_distance(points, refs, chunk=65536):
+    """Distance of every point to its nearest reference point, float64, brute force in chunks (what the reference asks a
+    scipy cKDTree for, :1466-1470; a few thousand roots against 10^5 strand ends is milliseconds on the GPU)."""
+    refs = refs.to(torch.float64)
+    out = torch.empty(points.shape[0], dtype=torch.float64, device=points.device)
+    for s in range(0, points.shape[0], chunk):
+        p = points[s:s + chunk].to(torch.float64)
+        d2 = ((p[:, None, :] - refs[None, :, :]) ** 2).sum(-1)
+        out[s:s + chunk] = d2.min(dim=1).values.sqrt()
+    return out
+
+
 class StrandsInfo:
     """Strands of the model (reference scene/hair_gaussian_model.py:1410-1498, same attribute names).  Held flat --
     `flat` = (offsets [S+1], rows [sum n_seg, 2] (cur, next) endpoint ids, root -> tip, segment rows [sum n_seg]) --;
@@ -374,6 +453,20 @@ class HairGaussianModel(HairTopologyMixin, GaussianModel):
         chains (every endpoint id appears once or twice, no cycles)."""
         if self.ref_strand_root is None or np.asarray(self.ref_strand_root).shape[0] == 0:
             raise ValueError("ref_strand_root is not set")
+        if self._endpoints.is_cuda:
+            # on the device; only the results come to the host
+            pairs_t = self.endpoint_pairs
+            if only_foreground:
+                pairs_t = pairs_t[self.compute_foreground_mask()]
+            ep = self._endpoints.detach()
+            roots = torch.as_tensor(np.asarray(self.ref_strand_root), device=ep.device)
+            chunk = max(1024, (1 << 27) // max(1, roots.shape[0]))       # <= 1 GiB of float64 distances at a time
+            offsets, rows, seg_rows, i2s, comp = walk_chains_torch(
+                pairs_t, ep.shape[0], lambda ids: nearest_distance(ep[ids], roots, chunk))
+            self.strands_info = StrandsInfo(offsets.cpu().numpy(), rows.cpu().numpy(), seg_rows.cpu().numpy(),
+                                            i2s.cpu().numpy(), comp.cpu().numpy())
+            self._smooth_pairs = None
+            return
         from scipy.spatial import cKDTree
         tree = cKDTree(np.asarray(self.ref_strand_root))
         endpoints = self._endpoints.detach().cpu().numpy()

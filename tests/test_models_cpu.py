@@ -359,3 +359,25 @@ def test_walk_chains_matches_edge_by_edge_walk(seed):
         np.testing.assert_array_equal(b, rb)
     np.testing.assert_array_equal(i2s, ref[2])
     np.testing.assert_array_equal(comp, ref[3])
+    # the torch form (what a model on the GPU runs), here on CPU tensors
+    import torch
+    from scene.hair_gaussian_model import walk_chains_torch
+    dist_t = torch.from_numpy(dist)
+    o, r, sr, i2s_t, comp_t = walk_chains_torch(torch.from_numpy(pairs), n_ep, lambda e: dist_t[e])
+    info_t = StrandsInfo(o.numpy(), r.numpy(), sr.numpy(), i2s_t.numpy(), comp_t.numpy())
+    for a, b, ra, rb in zip(info_t.list_strands, info_t.list_strands_segments_id, ref[0], ref[1]):
+        np.testing.assert_array_equal(a, ra)
+        np.testing.assert_array_equal(b, rb)
+    np.testing.assert_array_equal(i2s_t.numpy(), ref[2])
+    np.testing.assert_array_equal(comp_t.numpy(), ref[3])
+
+
+def test_nearest_distance_matches_kdtree():
+    import torch
+    from scipy.spatial import cKDTree
+    from scene.hair_gaussian_model import nearest_distance
+    rng = np.random.default_rng(3)
+    pts, refs = rng.normal(size=(5000, 3)).astype(np.float32), rng.normal(size=(300, 3)).astype(np.float32)
+    d = nearest_distance(torch.from_numpy(pts), torch.from_numpy(refs), chunk=1024).numpy()
+    ref = cKDTree(refs.astype(np.float64)).query(pts.astype(np.float64), k=1)[0]
+    np.testing.assert_allclose(d, ref, rtol=1e-14, atol=0)
