@@ -352,7 +352,9 @@ int hgs_binning_layout(int R, size_t* offsets /* [HGS_BIN_NFIELDS] */);
 /* floats per packed instance record in HGS_BIN_PACKED, 3-channel mode: x,y, conic a,b,c, opacity, r,g,b, id, quadrant
  * mask, pad (the 7-channel mode uses 16: ..., 7 features, id, quadrant mask, pad) */
 #define HGS_PACKED_FLOATS 12
-/* floats per instance in the backward scratch (dmean2D.xy, dconic.xyw, dopacity, dcolor.rgb, pad...) */
+/* floats per instance in the backward scratch: sums over the tile's pixels of u dx, u dy, u dx dx, u dx dy, u dy dy, u
+ * (u = G dL/dalpha, d = mean - pixel; the moments from which dmean2D, dconic and dopacity follow per Gaussian), dcolor.rgb,
+ * pad */
 #define HGS_INST_GRAD_FLOATS 12
 
 #ifdef __cplusplus
