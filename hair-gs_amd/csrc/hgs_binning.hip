@@ -8,8 +8,8 @@
 //                      and over the per-block instance sums -> per-Gaussian offsets (replaces DeviceScan :277)
 //   sort_tiles_kernel  one workgroup per tile sorts its segment by the unique 64-bit key
 //                      depth_bits<<32|id in LDS (bitonic), emits point_list in final order, the packed
-//                      per-instance records the blend kernels stream, and the inverse index the
-//                      deterministic backward gather uses.
+//                      per-instance records the blend kernels stream (with the instance's Gaussian-major slot,
+//                      where the backward stores its row for the deterministic per-Gaussian sum).
 // Result: identical point_list/ranges, ~10x less sort traffic than 144 B/instance, no stability needed.
 #include "hgs_common.h"
 
@@ -117,22 +117,23 @@ __device__ __forceinline__ void emit_instance(uint64_t key, uint32_t pos, int tx
   const float4 co = g.conic_opacity[id];
   const float f0 = e.feat[3 * (size_t)id], f1 = e.feat[3 * (size_t)id + 1], f2 = e.feat[3 * (size_t)id + 2];
   const uint32_t qmask = (uint32_t)key & HGS_QMASK_BITS;   // quadrant mask, computed by the scatter kernel (hgs_quadrant_mask)
+  // the instance's slot in Gaussian-major order (offset of the Gaussian + cell of its tile rectangle): the backward stores
+  // this instance's row of partial sums there, so that a Gaussian's rows are contiguous for preprocess_bwd_kernel
+  const HgsRect rc = g.rect[id];
+  const uint32_t slot = rc.off + (uint32_t)(ty - rc.y0) * (uint32_t)(rc.x1 - rc.x0) + (uint32_t)(tx - rc.x0);
   if (e.n_extra == 0) {  // 48-B record: xy, conic, opacity, rgb, id, quadrant mask
     float4* rec = b.packed + (size_t)pos * 3;
     rec[0] = make_float4(xy.x, xy.y, co.x, co.y);
     rec[1] = make_float4(co.z, co.w, f0, f1);
-    rec[2] = make_float4(f2, __uint_as_float(id), __uint_as_float(qmask), 0.f);
+    rec[2] = make_float4(f2, __uint_as_float(id), __uint_as_float(qmask), __uint_as_float(slot));
   } else {               // 64-B record: ... rgb, 4 extra channels, id, quadrant mask
     const float4 ex = ((const float4*)e.extra)[id];
     float4* rec = b.packed + (size_t)pos * 4;
     rec[0] = make_float4(xy.x, xy.y, co.x, co.y);
     rec[1] = make_float4(co.z, co.w, f0, f1);
     rec[2] = make_float4(f2, ex.x, ex.y, ex.z);
-    rec[3] = make_float4(ex.w, __uint_as_float(id), __uint_as_float(qmask), 0.f);
+    rec[3] = make_float4(ex.w, __uint_as_float(id), __uint_as_float(qmask), __uint_as_float(slot));
   }
-  const HgsRect rc = g.rect[id];
-  const uint32_t k = (uint32_t)(ty - rc.y0) * (uint32_t)(rc.x1 - rc.x0) + (uint32_t)(tx - rc.x0);
-  if (rc.off + k < e.Rcap) b.inv[rc.off + k] = pos;
 }
 
 __device__ __forceinline__ void bitonic_lds(uint64_t* sk, int m) {

@@ -258,9 +258,12 @@ __global__ __launch_bounds__(HGS_BLOCK) __attribute__((amdgpu_waves_per_eu(6))) 
     // past the last one any pixel needed (positions >= maxc; ~2% of the instances) get explicit zero rows here.
     const uint32_t end = min(range.y, Rcap), first = range.x + maxc;
     if (end > first) {
-      float4* z = (float4*)(inst_grad + (size_t)first * ROW);
       const uint32_t n4 = (end - first) * (ROW / 4);
-      for (uint32_t i = threadIdx.x; i < n4; i += HGS_BLOCK) z[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (uint32_t i = threadIdx.x; i < n4; i += HGS_BLOCK) {
+        const uint32_t inst = first + i / (ROW / 4);
+        const uint32_t slot = __float_as_uint(((const float*)packed)[(size_t)inst * 4 * REC4 + 8 + C]);
+        if (slot < Rcap) ((float4*)(inst_grad + (size_t)slot * ROW))[i % (ROW / 4)] = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
     }
   }
   if (maxc == 0) return;  // nothing in this tile contributed to any pixel
@@ -406,7 +409,9 @@ __global__ __launch_bounds__(HGS_BLOCK) __attribute__((amdgpu_waves_per_eu(6))) 
     for (int i = threadIdx.x; i < cnt * NPART; i += HGS_BLOCK) {
       const int e = i / NPART, k = i - e * NPART;
       const float s = ((part[0][e][k] + part[1][e][k]) + part[2][e][k]) + part[3][e][k];
-      inst_grad[(size_t)(range.x + lo + e) * ROW + k] = s;
+      // row of the instance's Gaussian-major slot (record pad, sort_tiles_kernel): a Gaussian's rows lie together
+      const uint32_t slot = __float_as_uint(rf[e * 4 * REC4 + 8 + C]);
+      if (slot < Rcap) inst_grad[(size_t)slot * ROW + k] = s;
       part[0][e][k] = 0.f; part[1][e][k] = 0.f; part[2][e][k] = 0.f; part[3][e][k] = 0.f;
     }
     if (lo > 0 && threadIdx.x < REC_BATCH * REC4) recs[cur ^ 1][threadIdx.x] = stage;

@@ -4,7 +4,7 @@
 //   geom    (per Gaussian)  depths, clamped, means2D, cov3D, conic_opacity, rgb, tiles_touched,
 //                           point_offsets, rect(+exclusive instance offset), block_sums
 //   image   (per pixel/tile) final_T, n_contrib, ranges, tile_count, tile_cursor, tile_maxc, status, tile_order
-//   binning (per instance)  keys (depth<<32|id), point_list, packed records, inverse index, sorted keys
+//   binning (per instance)  keys (depth<<32|id<<4|quadrant mask), point_list, packed records, (reserved), sorted keys
 // They play the roles of GeometryState / ImageState / BinningState of the reference
 // (cuda_rasterizer/rasterizer_impl.h:23-71) but the layout is this library's own.
 #pragma once

@@ -363,9 +363,7 @@ __global__ __launch_bounds__(HGS_BLOCK) void preprocess_bwd_kernel(HgsBwdArgs a,
     const int row_floats = a.n_extra ? 16 : HGS_INST_GRAD_FLOATS;
     for (uint32_t k = 0; k < n; k++) {
       if (rc.off + k >= Rcap) break;  // under-sized binning buffer (forward already flagged the overflow)
-      const uint32_t pos = b.inv[rc.off + k];
-      if (pos >= Rcap) continue;
-      const float4* r = (const float4*)(inst_grad + (size_t)pos * row_floats);
+      const float4* r = (const float4*)(inst_grad + (size_t)(rc.off + k) * row_floats);   // rows in Gaussian-major order
       const float4 r0 = r[0], r1 = r[1], r2 = r[2];
       dmx += r0.x; dmy += r0.y; dcx += r0.z; dcy += r0.w;
       dcw += r1.x; dop += r1.y; dcol[0] += r1.z; dcol[1] += r1.w; dcol[2] += r2.x;
