@@ -154,8 +154,12 @@ int hgs_forward_preprocess(void* stream, int P, int D, int M, int W, int H, cons
   a.campos = campos; a.scale_modifier = scale_modifier; a.tan_fovx = tan_fovx; a.tan_fovy = tan_fovy;
   a.prefiltered = prefiltered;
   a.tile_cull = g_tile_cull;
+  // Capacity mode (nobody waits for num_rendered here) with a place to report the count: the scan is left to the
+  // scatter kernel of hgs_forward_render (scatter_kernel, "fused scan").  A blocking caller needs the count NOW.
+  const bool fused_scan = !num_rendered_host && max_rendered && T <= HGS_FUSED_SCAN_MAX_T;
+  a.fused_scan_ptr = fused_scan ? (unsigned long long)(size_t)max_rendered : 0ull;
   if (hgs_launch_preprocess_fwd(s, a, g, im, radii)) return 1;
-  if (hgs_launch_scan(s, P, T, g, im, max_rendered)) return 1;
+  if (!fused_scan && hgs_launch_scan(s, P, T, g, im, max_rendered)) return 1;
   if (num_rendered_host) {
     uint32_t r = 0;
     HGS_CHECK_HIP(hipMemcpyAsync(&r, im.status, sizeof(uint32_t), hipMemcpyDeviceToHost, s));

@@ -180,7 +180,11 @@ struct HgsFwdArgs {
   float scale_modifier, tan_fovx, tan_fovy;
   int prefiltered;
   int tile_cull;       // shrink every tile rectangle to the alpha >= 1/255 ellipse's bounding box (hgs_set_tile_cull)
+  // != 0: no scan launch follows; the scatter kernel scans the tile counts itself (see scatter_kernel) and reports the
+  // instance count through this device pointer (the caller's max_rendered).  Parked in status[2..3] of the image buffer.
+  unsigned long long fused_scan_ptr;
 };
+#define HGS_FUSED_SCAN_MAX_T 11776   // tiles whose offsets fit the scatter kernel's LDS (47.4 KB with padding); 1080p has 8160
 int hgs_launch_preprocess_fwd(hipStream_t s, const HgsFwdArgs& a, const HgsGeom& g, const HgsImage& im, int* radii);
 int hgs_launch_scan(hipStream_t s, int P, int T, const HgsGeom& g, const HgsImage& im, unsigned int* max_rendered);
 int hgs_launch_scatter(hipStream_t s, int P, int W, int H, int Rcap, const int* radii, const HgsGeom& g,

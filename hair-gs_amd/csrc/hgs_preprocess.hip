@@ -271,6 +271,10 @@ __global__ __launch_bounds__(HGS_BLOCK) void preprocess_fwd_kernel(HgsFwdArgs a,
     g.tiles_touched[idx] = ntiles;
     g.rect[idx] = rc;
   }
+  if (blockIdx.x == 0 && threadIdx.x == 0 && a.fused_scan_ptr) {   // (status words were cleared by the launch before this one)
+    im.status[2] = (uint32_t)a.fused_scan_ptr;
+    im.status[3] = (uint32_t)(a.fused_scan_ptr >> 32);
+  }
   const uint32_t bs = block_sum_256(ntiles, red);   // (its barriers also order the table updates above)
   if (threadIdx.x == 0) g.block_sums[blockIdx.x] = bs;
   for (int i = threadIdx.x; i < TH_SIZE; i += HGS_BLOCK)
@@ -281,18 +285,59 @@ __global__ __launch_bounds__(HGS_BLOCK) void preprocess_fwd_kernel(HgsFwdArgs a,
 // scatter: one lane per Gaussian.  Exclusive instance offset = block prefix (scan kernel) + in-block scan;
 // every touched tile gets key = depth_bits<<32 | gaussian_id appended to the tile's segment (order inside the
 // segment is irrelevant: the per-tile sort key is unique).
-__global__ __launch_bounds__(HGS_BLOCK) void scatter_kernel(int P, int gx, uint32_t Rcap, const int* radii, HgsGeom g,
+//
+// Fused scan (capacity mode, status[2..3] != 0): no scan launch ran.  That one-workgroup kernel sat alone on the GPU for
+// 9-11 us between two grid-wide kernels; here EVERY workgroup scans the T tile counts itself (32 loads per thread at
+// 1080p, all L2 hits, offsets kept in LDS) and sums the block sums before it; workgroup 0 also publishes `ranges`, the
+// instance count and its sticky maximum.  Same integers either way.
+__global__ __launch_bounds__(HGS_BLOCK) void scatter_kernel(int P, int gx, int T, uint32_t Rcap, const int* radii, HgsGeom g,
                                                             HgsImage im, HgsBinning b) {
+  extern __shared__ uint32_t tile_off[];   // [T] in the fused-scan mode (dynamic), empty otherwise
   __shared__ uint32_t wsum[4];
   __shared__ TileHash th;
   th_init(th);
   const int idx = blockIdx.x * HGS_BLOCK + threadIdx.x;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const unsigned long long report = ((unsigned long long)im.status[3] << 32) | im.status[2];
+  const bool fused = report != 0ull;
+  uint32_t blk_base = 0;
+  if (fused) {
+    // counts -> LDS with coalesced loads (all in flight together), then every thread scans ITS run of consecutive tiles
+    // out of LDS (rows padded by one word per 32: a stride of `ipt` words would put a wavefront on one bank)
+    const int ipt = (T + HGS_BLOCK - 1) / HGS_BLOCK, i0 = (int)threadIdx.x * ipt;
+    auto at = [](int i) { return i + (i >> 5); };
+    for (int i = threadIdx.x; i < T; i += HGS_BLOCK) tile_off[at(i)] = im.tile_count[i];
+    __syncthreads();
+    uint32_t mine = 0;
+    for (int k = 0; k < ipt; k++)
+      if (i0 + k < T) mine += tile_off[at(i0 + k)];
+    const uint32_t inc = hgs_wave_incl_scan(mine, lane);
+    if (lane == 63) wsum[wave] = inc;
+    __syncthreads();
+    uint32_t run = inc - mine, total = 0;
+    for (int w = 0; w < 4; w++) { if (w < wave) run += wsum[w]; total += wsum[w]; }
+    for (int k = 0; k < ipt; k++)
+      if (i0 + k < T) {
+        const uint32_t v = tile_off[at(i0 + k)];
+        tile_off[at(i0 + k)] = run;
+        if (blockIdx.x == 0) im.ranges[i0 + k] = v ? make_uint2(run, run + v) : make_uint2(0u, 0u);
+        run += v;
+      }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+      im.status[0] = total;
+      atomicMax((unsigned int*)report, total);   // sticky maximum for graph replays (hgs.h)
+    }
+    uint32_t part = 0;
+    for (int j = threadIdx.x; j < (int)blockIdx.x; j += HGS_BLOCK) part += g.block_sums[j];   // raw sums (no scan ran)
+    __syncthreads();                                 // wsum is reused
+    blk_base = block_sum_256(part, wsum);
+    __syncthreads();
+  }
   const uint32_t n = idx < P ? g.tiles_touched[idx] : 0;
   const uint32_t incl = hgs_wave_incl_scan(n, lane);
   if (lane == 63) wsum[wave] = incl;
   __syncthreads();
-  uint32_t base = g.block_sums[blockIdx.x];  // exclusive block prefix
+  uint32_t base = fused ? blk_base : g.block_sums[blockIdx.x];  // exclusive block prefix
   for (int w = 0; w < wave; w++) base += wsum[w];
   HgsRect rc = {0, 0, 0, 0, 0, 0};
   if (idx < P) {
@@ -328,7 +373,7 @@ __global__ __launch_bounds__(HGS_BLOCK) void scatter_kernel(int P, int gx, uint3
       const uint32_t t = (uint32_t)(ty * gx + tx);
       const uint64_t key = key0 | hgs_quadrant_mask(qc, xy, tx, ty);
       const int sl = small ? th_find(th, t) : -1;
-      const uint32_t pos = im.ranges[t].x + (sl >= 0 ? th.base[sl] + atomicAdd(&th.cnt[sl], 1u)
+      const uint32_t pos = (fused ? tile_off[t + (t >> 5)] : im.ranges[t].x) + (sl >= 0 ? th.base[sl] + atomicAdd(&th.cnt[sl], 1u)
                                                      : atomicAdd(&im.tile_cursor[t], 1u));
       if (pos < Rcap) b.keys[pos] = key;
       else im.status[1] = 1;  // overflow: caller under-sized the binning buffer
@@ -601,12 +646,14 @@ int hgs_launch_preprocess_fwd(hipStream_t s, const HgsFwdArgs& a, const HgsGeom&
 }
 int hgs_launch_scatter(hipStream_t s, int P, int W, int H, int Rcap, const int* radii, const HgsGeom& g,
                        const HgsImage& im, const HgsBinning& b) {
-  (void)H;
   const int nblk = (P + HGS_BLOCK - 1) / HGS_BLOCK;
-  const int gx = (W + HGS_TILE - 1) / HGS_TILE;
+  const int gx = (W + HGS_TILE - 1) / HGS_TILE, T = gx * ((H + HGS_TILE - 1) / HGS_TILE);
+  // LDS for the fused scan's tile offsets: whether that mode is on is a device-side fact (status words written by the
+  // preprocess kernel), so the space is provided whenever the mode is possible
+  const size_t lds = T <= HGS_FUSED_SCAN_MAX_T ? (size_t)(T + T / 32 + 1) * sizeof(uint32_t) : 0;
   {
     HgsProfScope _prof(s, HGS_K_SCATTER);
-    hipLaunchKernelGGL(scatter_kernel, dim3(nblk), dim3(HGS_BLOCK), 0, s, P, gx, (uint32_t)Rcap, radii, g, im, b);
+    hipLaunchKernelGGL(scatter_kernel, dim3(nblk), dim3(HGS_BLOCK), lds, s, P, gx, T, (uint32_t)Rcap, radii, g, im, b);
   }
   HGS_CHECK_LAUNCH();
   return 0;

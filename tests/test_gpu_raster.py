@@ -246,3 +246,37 @@ def test_mark_visible():
     got = _C.mark_visible(to_dev(s["means3D"]), to_dev(s["viewmatrix"]), to_dev(s["projmatrix"])).cpu().numpy()
     np.testing.assert_array_equal(got, O.mark_visible(s["means3D"], s["viewmatrix"]))
     assert 0 < got.sum() < len(got)
+
+
+@pytest.mark.parametrize("name", ["sh0", "strands", "dense_long_lists", "tiny_image", "many_tiles"])
+def test_capacity_mode_binning_equals_blocking_mode(name):
+    """Capacity (async) mode: hgs_forward_preprocess launches no scan, the scatter kernel scans the tile counts itself
+    ("fused scan"; many_tiles exceeds its LDS and keeps the scan launch).  Ranges, sorted lists, image and the reported
+    instance count have to be what the blocking mode produces."""
+    import torch
+    from diff_gaussian_rasterization import _C
+    from tests import gpu_util as G
+    s = _scene(name)
+    ref_fw = G.run_forward(s)
+    ref = G.intermediates(s, ref_fw)
+    try:
+        _C._state["cap"] = 0                   # (a capacity learnt on another scene would be kept)
+        _C.set_async(True)
+        G.run_forward(s)                       # the first pass of the mode learns the capacity (it blocks)
+        fw = G.run_forward(s)                  # capacity mode
+        worst = _C.check_async()
+        assert worst == [ref["num_rendered"]]
+        got = G.intermediates(s, fw)           # (the pass returns its CAPACITY: the buffer is carved for that many)
+    finally:
+        _C.set_async(False)
+    n = ref["num_rendered"]
+    assert fw["R"] >= n and got["status"][0] == n and got["status"][1] == 0
+    for k in ("ranges", "tiles_touched", "point_offsets", "n_contrib"):
+        np.testing.assert_array_equal(got[k], ref[k], err_msg=k)
+    for k in ("point_list", "keys_sorted"):
+        np.testing.assert_array_equal(got[k][:n], ref[k], err_msg=k)
+    np.testing.assert_array_equal(got["out_color"].view(np.uint32), ref["out_color"].view(np.uint32))
+    dpix = np.random.default_rng(3).normal(size=(3, s["H"], s["W"])).astype(np.float32)
+    g1, g0 = G.run_backward(s, fw, dpix), G.run_backward(s, ref_fw, dpix)
+    for k in g0:
+        np.testing.assert_array_equal(g1[k].view(np.uint32), g0[k].view(np.uint32), err_msg=k)
