@@ -60,7 +60,9 @@ size_t hgs_backward_scratch_bytes(int P, int R);
  * with NULL nothing blocks and R stays on the device (pass a capacity to hgs_forward_render).
  * max_rendered (device, may be NULL): raised atomically to R -- a sticky maximum over all calls since the caller last
  * cleared it, which is what a captured HIP graph needs to validate its capacity after any number of replays without a
- * per-iteration device-to-host copy. */
+ * per-iteration device-to-host copy.  With num_rendered_host == NULL and max_rendered != NULL the scans are left to the
+ * scatter kernel of hgs_forward_render (no one-workgroup scan launch in between): R and its maximum are then on the
+ * device once THAT call has run on the stream; max_rendered has to stay valid until then. */
 int hgs_forward_preprocess(void* stream, int P, int D, int M, int W, int H,
                            const float* means3D, const float* shs, const float* colors_precomp,
                            const float* opacities, const float* scales, float scale_modifier,
