@@ -5,6 +5,8 @@ sys.path[:0] = [ROOT, os.path.join(ROOT, "hair-gs_amd")]
 import numpy as np
 from oracle import hgs_oracle as O
 from tests import scenes, gpu_util as G
+from diff_gaussian_rasterization import _C
+_C.set_tile_cull(False)   # the reference's lists: n_contrib counts positions in them (gradients are bit-identical either way)
 for name, s in (("strands", scenes.strand_scene(n_strands=60, n_seg=60, W=256, H=144, seed=3)),
                 ("blobs", scenes.random_scene(P=1500, W=160, H=96, seed=1, sh_degree=0))):
     dpix = np.random.default_rng(123).normal(size=(3, s["H"], s["W"])).astype(np.float32)
