@@ -300,13 +300,32 @@ __global__ __launch_bounds__(HGS_BLOCK) void scatter_kernel(int P, int gx, int T
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const unsigned long long report = ((unsigned long long)im.status[3] << 32) | im.status[2];
   const bool fused = report != 0ull;
+  // every global load the prologue needs is issued before anything waits: tile counts (coalesced, up to
+  // HGS_FUSED_SCAN_MAX_T / 256 per thread), the raw block sums before this workgroup, this lane's Gaussian
+  constexpr int MAX_IPT = HGS_FUSED_SCAN_MAX_T / HGS_BLOCK;
+  uint32_t cnt[MAX_IPT], part = 0;
+  if (fused) {
+#pragma unroll
+    for (int k = 0; k < MAX_IPT; k++) {
+      const int i = k * HGS_BLOCK + (int)threadIdx.x;
+      cnt[k] = i < T ? im.tile_count[i] : 0u;
+    }
+    for (int j = threadIdx.x; j < (int)blockIdx.x; j += HGS_BLOCK) part += g.block_sums[j];   // raw sums (no scan ran)
+  }
+  const uint32_t n = idx < P ? g.tiles_touched[idx] : 0;
+  HgsRect rc = {0, 0, 0, 0, 0, 0};
+  if (idx < P) rc = g.rect[idx];
   uint32_t blk_base = 0;
   if (fused) {
-    // counts -> LDS with coalesced loads (all in flight together), then every thread scans ITS run of consecutive tiles
-    // out of LDS (rows padded by one word per 32: a stride of `ipt` words would put a wavefront on one bank)
+    // counts -> LDS, then every thread scans ITS run of consecutive tiles out of LDS (rows padded by one word per 32: a
+    // stride of `ipt` words would put a wavefront on one bank)
     const int ipt = (T + HGS_BLOCK - 1) / HGS_BLOCK, i0 = (int)threadIdx.x * ipt;
     auto at = [](int i) { return i + (i >> 5); };
-    for (int i = threadIdx.x; i < T; i += HGS_BLOCK) tile_off[at(i)] = im.tile_count[i];
+#pragma unroll
+    for (int k = 0; k < MAX_IPT; k++) {
+      const int i = k * HGS_BLOCK + (int)threadIdx.x;
+      if (i < T) tile_off[at(i)] = cnt[k];
+    }
     __syncthreads();
     uint32_t mine = 0;
     for (int k = 0; k < ipt; k++)
@@ -327,28 +346,24 @@ __global__ __launch_bounds__(HGS_BLOCK) void scatter_kernel(int P, int gx, int T
       im.status[0] = total;
       atomicMax((unsigned int*)report, total);   // sticky maximum for graph replays (hgs.h)
     }
-    uint32_t part = 0;
-    for (int j = threadIdx.x; j < (int)blockIdx.x; j += HGS_BLOCK) part += g.block_sums[j];   // raw sums (no scan ran)
     __syncthreads();                                 // wsum is reused
     blk_base = block_sum_256(part, wsum);
     __syncthreads();
   }
-  const uint32_t n = idx < P ? g.tiles_touched[idx] : 0;
   const uint32_t incl = hgs_wave_incl_scan(n, lane);
   if (lane == 63) wsum[wave] = incl;
   __syncthreads();
   uint32_t base = fused ? blk_base : g.block_sums[blockIdx.x];  // exclusive block prefix
   for (int w = 0; w < wave; w++) base += wsum[w];
-  HgsRect rc = {0, 0, 0, 0, 0, 0};
   if (idx < P) {
     const uint32_t off_incl = base + incl;
     g.point_offsets[idx] = off_incl;
     if (n != 0) {
-      rc = g.rect[idx];
       rc.off = off_incl - n;
       g.rect[idx] = rc;
     }
   }
+  if (n == 0) rc = HgsRect{0, 0, 0, 0, 0, 0};
   const bool small = n != 0 && n <= TH_MAX_AREA;
   // pass 1: count this block's instances per tile in LDS
   if (small)
