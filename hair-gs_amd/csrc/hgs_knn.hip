@@ -244,13 +244,17 @@ namespace {
 __global__ __launch_bounds__(256) void radius_pairs_kernel(int N, const float* __restrict__ pos, const float* __restrict__ dir,
                                                            float r2, float min_cos, int bidirectional, int capacity,
                                                            int* __restrict__ pairs, float* __restrict__ dist,
-                                                           int* __restrict__ count) {
+                                                           int* __restrict__ count, float reach_x) {
   __shared__ float sp[256][3], sd[256][3];
   const int a = blockIdx.x * 256 + threadIdx.x;
   float ax = 0.f, ay = 0.f, az = 0.f, ux = 0.f, uy = 0.f, uz = 0.f;
   if (a < N) { ax = pos[3 * a]; ay = pos[3 * a + 1]; az = pos[3 * a + 2]; ux = dir[3 * a]; uy = dir[3 * a + 1]; uz = dir[3 * a + 2]; }
   // only tiles at or after this block's own: every unordered pair is tested once, by the block of its smaller index
+  // reach_x >= 0: the points are sorted by x; a tile that starts farther than the radius beyond this block's last point
+  // (and every tile after it) holds no partner
+  const float block_max_x = reach_x >= 0.f ? pos[3 * min(N - 1, (int)blockIdx.x * 256 + 255)] + reach_x : 0.f;
   for (int t0 = blockIdx.x * 256; t0 < N; t0 += 256) {
+    if (reach_x >= 0.f && pos[3 * t0] > block_max_x) break;
     const int j = t0 + threadIdx.x;
     __syncthreads();
     if (j < N) {
@@ -278,14 +282,14 @@ __global__ __launch_bounds__(256) void radius_pairs_kernel(int N, const float* _
 }  // namespace
 
 extern "C" int hgs_radius_pairs(void* stream, int N, const float* pos, const float* dir, float radius, float min_cos,
-                                int bidirectional, int capacity, int* pairs, float* dist, int* count) {
+                                int bidirectional, int capacity, int* pairs, float* dist, int* count, int sorted_by_x) {
   if (N <= 1) return 0;
   if (!pos || !dir || !count || capacity < 0 || (capacity > 0 && (!pairs || !dist))) { hgs_set_error("hgs_radius_pairs: bad arguments"); return 1; }
   hipStream_t s = (hipStream_t)stream;
   {
     HgsProfScope _prof(s, HGS_K_KNN);
     hipLaunchKernelGGL(radius_pairs_kernel, dim3((N + 255) / 256), dim3(256), 0, s, N, pos, dir, radius * radius, min_cos,
-                       bidirectional, capacity, pairs, dist, count);
+                       bidirectional, capacity, pairs, dist, count, sorted_by_x ? radius : -1.f);
   }
   HGS_CHECK_LAUNCH();
   return 0;

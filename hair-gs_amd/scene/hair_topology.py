@@ -254,6 +254,9 @@ class HairTopologyMixin:
         pos = rt.require_gpu_tensor(pos, "positions", torch.float32)
         dirs = rt.require_gpu_tensor(dirs, "directions", torch.float32)
         n, dev = pos.shape[0], pos.device
+        order = torch.argsort(pos[:, 0])                 # ascending x: lets the search stop a radius beyond each block
+        pos, dirs = pos[order].contiguous(), dirs[order].contiguous()
+        order = order.cpu().numpy()
         cap = max(4 * n, 1024)
         while True:
             pairs = torch.empty((cap, 2), dtype=torch.int32, device=dev)
@@ -261,11 +264,11 @@ class HairTopologyMixin:
             count = torch.zeros(1, dtype=torch.int32, device=dev)
             with torch.cuda.device(dev):
                 rt.check(rt.lib().hgs_radius_pairs(rt.current_stream(), n, rt.ptr(pos), rt.ptr(dirs), float(radius), float(min_cos),
-                                                   int(bidirectional), cap, rt.ptr(pairs), rt.ptr(dist), rt.ptr(count)))
+                                                   int(bidirectional), cap, rt.ptr(pairs), rt.ptr(dist), rt.ptr(count), 1))
             found = int(count.item())
             if found <= cap:
-                p = pairs[:found].cpu().numpy().astype(np.int64)
-                return p[:, 0], p[:, 1]
+                p = order[pairs[:found].cpu().numpy().astype(np.int64)]      # back to the caller's indices, a < b
+                return p.min(axis=1), p.max(axis=1)
             cap = found      # dense cluster of strand ends: run again with room for every pair
 
     def merge_endpoint_pairs(self, endpoint_pair_index):

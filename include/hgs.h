@@ -319,11 +319,14 @@ const char* hgs_prof_kernel_name(int kernel_id);
  *   scene/hair_gaussian_model.py:1205-1290: all index pairs a < b of the N strand ends with
  *   |pos_a - pos_b| <= radius and -(dir_a . dir_b) >= min_cos (|.| instead if bidirectional).  Brute force, one
  *   256-point tile against all others through LDS: strand ends number in the thousands, where N^2/2 distance tests cost
- *   tens of microseconds and no tree has to be built or kept consistent with the moving endpoints.
+ *   tens of microseconds and no tree has to be built or kept consistent with the moving endpoints.  sorted_by_x != 0: the
+ *   caller passes the points in ascending order of x, and a block stops at the first tile that starts more than `radius`
+ *   beyond its own last point (a model late in training has 10^5 strand ends within a few hundred radii of each other:
+ *   52 ms -> 1 ms).
  *   Appends (a, b) to pairs[capacity][2] and the distance to dist[capacity] in unspecified order; *count (device, must be
  *   zero on entry) ends as the number of pairs FOUND, which may exceed capacity (the excess is dropped). */
 int hgs_radius_pairs(void* stream, int N, const float* pos, const float* dir, float radius, float min_cos,
-                     int bidirectional, int capacity, int* pairs, float* dist, int* count);
+                     int bidirectional, int capacity, int* pairs, float* dist, int* count, int sorted_by_x);
 
 /* Tile culling (default on).  The reference gives every Gaussian the tiles of its 3-sigma square (forward.cu:229-235,
  * auxiliary.h:46-56) although a pixel only blends it where opacity * exp(power) >= 1/255 (forward.cu:358): with culling on,
