@@ -67,23 +67,27 @@ __global__ __launch_bounds__(256) void strand_fwd_kernel(int P, const float* __r
 struct SegGrads { const float* g_xyz; const float* g_scale; const float* g_quat; const float* g_dir; const float* g_extra4; };
 __device__ __forceinline__ void segment_endpoint_grads(int k, const float* __restrict__ ep, const long long* __restrict__ pairs,
                                                        float f, const SegGrads& sg, float* h, float* gD) {
-  float4 ge = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (sg.g_extra4) ge = ((const float4*)sg.g_extra4)[k];
+  // every load first and unconditional (the pointer tests are uniform): a lane that evaluates several segments then has
+  // all of them in flight together instead of one dependent chain after the other
   const long long i0 = pairs[2 * (size_t)k], i1 = pairs[2 * (size_t)k + 1];
+  float4 ge = make_float4(0.f, 0.f, 0.f, 0.f), gq = make_float4(0.f, 0.f, 0.f, 0.f);
+  float gx[3] = {0.f, 0.f, 0.f}, gd[3] = {0.f, 0.f, 0.f}, gs0 = 0.f;
+  if (sg.g_extra4) ge = ((const float4*)sg.g_extra4)[k];
+  if (sg.g_quat) gq = ((const float4*)sg.g_quat)[k];
+  if (sg.g_xyz) { gx[0] = sg.g_xyz[3 * (size_t)k]; gx[1] = sg.g_xyz[3 * (size_t)k + 1]; gx[2] = sg.g_xyz[3 * (size_t)k + 2]; }
+  if (sg.g_dir) { gd[0] = sg.g_dir[3 * (size_t)k]; gd[1] = sg.g_dir[3 * (size_t)k + 1]; gd[2] = sg.g_dir[3 * (size_t)k + 2]; }
+  if (sg.g_scale) gs0 = sg.g_scale[3 * (size_t)k];
   const float dx = ep[3 * i1] - ep[3 * i0], dy = ep[3 * i1 + 1] - ep[3 * i0 + 1], dz = ep[3 * i1 + 2] - ep[3 * i0 + 2];
   const float L = sqrtf(dx * dx + dy * dy + dz * dz);
-  h[0] = h[1] = h[2] = 0.f;
-  if (sg.g_xyz) { h[0] = 0.5f * sg.g_xyz[3 * (size_t)k]; h[1] = 0.5f * sg.g_xyz[3 * (size_t)k + 1]; h[2] = 0.5f * sg.g_xyz[3 * (size_t)k + 2]; }
+  h[0] = 0.5f * gx[0]; h[1] = 0.5f * gx[1]; h[2] = 0.5f * gx[2];
   gD[0] = gD[1] = gD[2] = 0.f;
   if (L > MINV) {
     const float il = 1.f / L;
     const float vx = dx * il, vy = dy * il, vz = dz * il;
-    float gvx = 0.f, gvy = 0.f, gvz = 0.f;  // gradient w.r.t. the unit direction
-    if (sg.g_dir && L >= MINV) { gvx = sg.g_dir[3 * (size_t)k]; gvy = sg.g_dir[3 * (size_t)k + 1]; gvz = sg.g_dir[3 * (size_t)k + 2]; }
-    if (sg.g_extra4 && L >= MINV) { gvx += ge.y; gvy += ge.z; gvz += ge.w; }
+    float gvx = gd[0], gvy = gd[1], gvz = gd[2];  // gradient w.r.t. the unit direction (L > MINV implies L >= MINV)
+    if (sg.g_extra4) { gvx += ge.y; gvy += ge.z; gvz += ge.w; }
     const float n0 = 1.f + vx;
     if (sg.g_quat && n0 > MINV) {
-      const float4 gq = ((const float4*)sg.g_quat)[k];
       const float in = 1.f / sqrtf(n0 * n0 + vz * vz + vy * vy);
       const float q0 = n0 * in, q2 = -vz * in, q3 = vy * in;
       const float dot = q0 * gq.x + q2 * gq.z + q3 * gq.w;  // q1 = 0
@@ -93,7 +97,7 @@ __device__ __forceinline__ void segment_endpoint_grads(int k, const float* __res
     const float vd = vx * gvx + vy * gvy + vz * gvz;
     gD[0] = (gvx - vx * vd) * il; gD[1] = (gvy - vy * vd) * il; gD[2] = (gvz - vz * vd) * il;
     if (sg.g_scale && L / 2.f * f > MINV) {
-      const float gs = sg.g_scale[3 * (size_t)k] * (0.5f * f);
+      const float gs = gs0 * (0.5f * f);
       gD[0] += gs * vx; gD[1] += gs * vy; gD[2] += gs * vz;
     }
   }
@@ -119,28 +123,42 @@ __global__ __launch_bounds__(256) void strand_bwd_kernel(int P, const float* __r
       // roles in a fixed order and stores once: no float atomics (each segment / pair is simply evaluated by every
       // endpoint it touches: ~500 flops per endpoint against 18 L2 atomics per segment)
       if (i >= fu.n_endpoints) return;
+      // The (<= 2 + 4) evaluations are independent: absent slots (code < 0) evaluate item 0 and are masked out afterwards,
+      // so that nothing branches between the loads of one evaluation and the next -- the lane's six dependent chains
+      // (code -> index row -> endpoints) overlap instead of running one after the other (14.5 -> 11.6 us for the launch).
       float acc[3] = {0.f, 0.f, 0.f};
+      const int2 cs = *(const int2*)(fu.ep_segments + 2 * (size_t)i);
+      const bool with_smooth = fu.ep_pairs && fu.n_smooth > 0;
+      int4 cp = make_int4(-1, -1, -1, -1);
+      if (with_smooth) cp = *(const int4*)(fu.ep_pairs + 4 * (size_t)i);
+      const int seg_code[2] = {cs.x, cs.y};
+      float sh[2][3], sD[2][3];
+#pragma unroll
+      for (int s = 0; s < 2; s++) segment_endpoint_grads(seg_code[s] >= 0 ? seg_code[s] >> 1 : 0, ep, pairs, f, sg, sh[s], sD[s]);
+      const int pair_code[4] = {cp.x, cp.y, cp.z, cp.w};
+      float pg0[4][3], pg1[4][3];
+      bool pok[4] = {false, false, false, false};
+      if (with_smooth) {
+#pragma unroll
+        for (int s = 0; s < 4; s++)
+          pok[s] = hgs_smooth_pair_grads(pair_code[s] >= 0 ? pair_code[s] >> 2 : 0, ep, fu.smooth_pairs, fu.cos_threshold, fu.eps,
+                                         smooth_scale, pg0[s], pg1[s]) && pair_code[s] >= 0;
+      }
 #pragma unroll
       for (int s = 0; s < 2; s++) {
-        const int code = fu.ep_segments[2 * (size_t)i + s];
-        if (code < 0) continue;
-        float h[3], gD[3];
-        segment_endpoint_grads(code >> 1, ep, pairs, f, sg, h, gD);
-        const float sign = (code & 1) ? 1.f : -1.f;
+        const float sign = (seg_code[s] & 1) ? 1.f : -1.f;
+        if (seg_code[s] >= 0) {
 #pragma unroll
-        for (int c = 0; c < 3; c++) acc[c] += h[c] + sign * gD[c];
+          for (int c = 0; c < 3; c++) acc[c] += sh[s][c] + sign * sD[s][c];
+        }
       }
-      if (fu.ep_pairs && fu.n_smooth > 0) {
 #pragma unroll
-        for (int s = 0; s < 4; s++) {
-          const int code = fu.ep_pairs[4 * (size_t)i + s];
-          if (code < 0) continue;
-          float g0[3], g1[3];
-          if (!hgs_smooth_pair_grads(code >> 2, ep, fu.smooth_pairs, fu.cos_threshold, fu.eps, smooth_scale, g0, g1)) continue;
-          const int role = code & 3;                       // a0: -g0, a1: +g0, b0: -g1, b1: +g1
-          const float sign = (role & 1) ? 1.f : -1.f;
+      for (int s = 0; s < 4; s++) {
+        const int role = pair_code[s] & 3;                       // a0: -g0, a1: +g0, b0: -g1, b1: +g1
+        const float sign = (role & 1) ? 1.f : -1.f;
+        if (pok[s]) {
 #pragma unroll
-          for (int c = 0; c < 3; c++) acc[c] += sign * (role < 2 ? g0[c] : g1[c]);
+          for (int c = 0; c < 3; c++) acc[c] += sign * (role < 2 ? pg0[s][c] : pg1[s][c]);
         }
       }
       d_ep[3 * (size_t)i] = acc[0]; d_ep[3 * (size_t)i + 1] = acc[1]; d_ep[3 * (size_t)i + 2] = acc[2];
