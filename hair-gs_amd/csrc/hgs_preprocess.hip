@@ -415,11 +415,27 @@ __global__ __launch_bounds__(HGS_BLOCK) void preprocess_bwd_kernel(HgsBwdArgs a,
   float dex[4] = {0.f, 0.f, 0.f, 0.f}, dmx_rgb = 0.f, dmy_rgb = 0.f;
   float dmean[3] = {0.f, 0.f, 0.f}, dcov[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   float dscale[3] = {0.f, 0.f, 0.f}, drot[4] = {0.f, 0.f, 0.f, 0.f};
+  // this Gaussian's own data: every load issued here, before the row loop below (whose data-dependent trip count the
+  // compiler will not move loads across): one memory round trip for all of it instead of one per dependent stage
   const bool vis = a.radii[idx] > 0;
+  const HgsRect rc_pre = g.rect[idx];
+  const uint32_t n_pre = g.tiles_touched[idx];
+  const float4 co_pre = g.conic_opacity[idx];
+  const V3 mean_pre = {a.means3D[3 * idx], a.means3D[3 * idx + 1], a.means3D[3 * idx + 2]};
+  const float* cov3D_pre = (a.cov3D_precomp ? a.cov3D_precomp : g.cov3D) + 6 * (size_t)idx;
+  float cov3_pre[6];
+#pragma unroll
+  for (int k = 0; k < 6; k++) cov3_pre[k] = cov3D_pre[k];
+  float4 q_pre = make_float4(1.f, 0.f, 0.f, 0.f);
+  float s_pre[3] = {1.f, 1.f, 1.f};
+  if (a.scales) {
+    q_pre = ((const float4*)a.rotations)[idx];
+    s_pre[0] = a.scales[3 * idx]; s_pre[1] = a.scales[3 * idx + 1]; s_pre[2] = a.scales[3 * idx + 2];
+  }
   if (vis) {
     // ---- deterministic gather of this Gaussian's per-instance partial sums (instance order = tile rect order)
-    const HgsRect rc = g.rect[idx];
-    const uint32_t n = g.tiles_touched[idx];
+    const HgsRect rc = rc_pre;
+    const uint32_t n = n_pre;
     const int row_floats = a.n_extra ? 16 : HGS_INST_GRAD_FLOATS;
     for (uint32_t k = 0; k < n; k++) {
       if (rc.off + k >= Rcap) break;  // under-sized binning buffer (forward already flagged the overflow)
@@ -437,7 +453,7 @@ __global__ __launch_bounds__(HGS_BLOCK) void preprocess_bwd_kernel(HgsBwdArgs a,
     // dcy = S(u dx dy), dcw = S(u dy dy), dop = S(u).  backward_distwar.cu:1002-1011 in terms of them (dL_dG = opacity
     // dL_dalpha, dG_ddelx = -G (a dx + b dy), dG_ddely = -G (c dy + b dx), ddel_dx = 0.5 W, ddel_dy = 0.5 H):
     {
-      const float4 co = g.conic_opacity[idx];
+      const float4 co = co_pre;
       const float sx = 0.5f * a.W * co.w, sy = 0.5f * a.H * co.w;
       const float mx = dmx, my = dmy, mrx = dmx_rgb, mry = dmy_rgb;
       dmx = sx * (-co.x * mx - co.y * my);
@@ -448,11 +464,10 @@ __global__ __launch_bounds__(HGS_BLOCK) void preprocess_bwd_kernel(HgsBwdArgs a,
       dcx *= h; dcy *= h; dcw *= h;
     }
     // ---- computeCov2DCUDA, backward_distwar.cu:145-275
-    const V3 mean = {a.means3D[3 * idx], a.means3D[3 * idx + 1], a.means3D[3 * idx + 2]};
-    const float* cov3D = (a.cov3D_precomp ? a.cov3D_precomp : g.cov3D) + 6 * (size_t)idx;
+    const V3 mean = mean_pre;
     float cov3[6];
 #pragma unroll
-    for (int k = 0; k < 6; k++) cov3[k] = cov3D[k];
+    for (int k = 0; k < 6; k++) cov3[k] = cov3_pre[k];
     const float h_y = a.H / (2.0f * a.tan_fovy), h_x = a.W / (2.0f * a.tan_fovx);
     Cov2D c;
     cov2d(mean, h_x, h_y, a.tan_fovx, a.tan_fovy, cov3, a.viewmatrix, c);
@@ -586,11 +601,10 @@ __global__ __launch_bounds__(HGS_BLOCK) void preprocess_bwd_kernel(HgsBwdArgs a,
     }
     if (a.scales) {
       // computeCov3D (backward), backward_distwar.cu:279-342
-      const float4 q = ((const float4*)a.rotations)[idx];
+      const float4 q = q_pre;
       const float r = q.x, x = q.y, y = q.z, z = q.w;
       const M3 R = quat_R(r, x, y, z);
-      const float s[3] = {a.scale_modifier * a.scales[3 * idx], a.scale_modifier * a.scales[3 * idx + 1],
-                          a.scale_modifier * a.scales[3 * idx + 2]};
+      const float s[3] = {a.scale_modifier * s_pre[0], a.scale_modifier * s_pre[1], a.scale_modifier * s_pre[2]};
       M3 M2;  // 2 * (S * R)
 #pragma unroll
       for (int cc = 0; cc < 3; cc++)
