@@ -63,32 +63,49 @@ __device__ __forceinline__ void load_tiles(float (*t)[TILE][TPW], int H, int W, 
 // Register-blocked separable filter.  Row pass: one work item = 4 consecutive outputs of one tile row (14 LDS reads
 // per input image feed 4 x 11 taps); column pass: one thread = 4 consecutive output rows of one column (14 reads per
 // filtered quantity).  ~29 LDS reads per output pixel instead of ~100 for the one-pixel-per-thread form.
-template <int NQ, typename F>
-__device__ __forceinline__ void row_pass(const SsimWin& win, float (*hz)[TILE][HP], F load) {
-  for (int it = threadIdx.x; it < TILE * (LT / 4); it += 256) {
-    const int r = it / (LT / 4), x0 = (it - r * (LT / 4)) * 4;
-    float acc[NQ][4];
+// One row-pass work item: NO consecutive outputs of tile row r starting at column x0 (NO + 10 LDS reads per input image
+// feed NO x 11 taps).
+template <int NQ, int NO, typename F>
+__device__ __forceinline__ void row_item(const SsimWin& win, float (*hz)[TILE][HP], F load, int r, int x0) {
+  float acc[NQ][NO];
 #pragma unroll
-    for (int q = 0; q < NQ; q++)
+  for (int q = 0; q < NQ; q++)
 #pragma unroll
-      for (int o = 0; o < 4; o++) acc[q][o] = 0.f;
+    for (int o = 0; o < NO; o++) acc[q][o] = 0.f;
 #pragma unroll
-    for (int k = 0; k < 14; k++) {
-      float val[NQ];
-      load(r, x0 + k, val);
+  for (int k = 0; k < NO + 10; k++) {
+    float val[NQ];
+    load(r, x0 + k, val);
 #pragma unroll
-      for (int o = 0; o < 4; o++) {
-        const int tap = k - o;
-        if (tap >= 0 && tap < 11) {
+    for (int o = 0; o < NO; o++) {
+      const int tap = k - o;
+      if (tap >= 0 && tap < 11) {
 #pragma unroll
-          for (int q = 0; q < NQ; q++) acc[q][o] += win.w[tap] * val[q];
-        }
+        for (int q = 0; q < NQ; q++) acc[q][o] += win.w[tap] * val[q];
       }
     }
+  }
 #pragma unroll
-    for (int q = 0; q < NQ; q++)
+  for (int q = 0; q < NQ; q++)
 #pragma unroll
-      for (int o = 0; o < 4; o++) hz[q][r][x0 + o] = acc[q][o];
+    for (int o = 0; o < NO; o++) hz[q][r][x0 + o] = acc[q][o];
+}
+// The tile has TILE x LT / 4 = 336 four-output items for 256 threads.  Dealt item by item, 80 threads did two and the
+// rest waited (the pass took 88 taps x NQ per thread for 57.75 on average); now every thread takes one four-output item and
+// the remaining 80 are halved into 160 two-output items: 66 taps x NQ on the critical path, 26 LDS reads instead of 28.
+template <int NQ, typename F>
+__device__ __forceinline__ void row_pass(const SsimWin& win, float (*hz)[TILE][HP], F load) {
+  constexpr int ITEMS = TILE * (LT / 4);
+  static_assert(ITEMS > 256 && 2 * (ITEMS - 256) <= 256, "row-pass split assumes 256 < items <= 384");
+  {
+    const int it = threadIdx.x;
+    const int r = it / (LT / 4), x0 = (it - r * (LT / 4)) * 4;
+    row_item<NQ, 4>(win, hz, load, r, x0);
+  }
+  if (threadIdx.x < 2 * (ITEMS - 256)) {
+    const int it = 256 + (threadIdx.x >> 1);
+    const int r = it / (LT / 4), x0 = (it - r * (LT / 4)) * 4 + 2 * (threadIdx.x & 1);
+    row_item<NQ, 2>(win, hz, load, r, x0);
   }
 }
 template <int NQ>
