@@ -58,7 +58,7 @@ SIGNATURES = {
     "hgs_cloud_params_forward": (ci, [vp, ci, vp, vp, vp, vp, vp, vp, vp, vp]),
     "hgs_cloud_params_backward": (ci, [vp, ci, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "hgs_loss_head_scratch_floats": (sz, [vp]),
-    "hgs_loss_head_forward": (ci, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
+    "hgs_loss_head_forward": (ci, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "hgs_loss_head_backward": (ci, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, vp, vp, vp, vp]),
     "hgs_densify_stats": (ci, [vp, ci, vp, vp, ci, vp, vp, vp]),
     "hgs_radius_pairs": (ci, [vp, ci, vp, vp, cf, cf, ci, ci, vp, vp, vp, ci]),
@@ -105,7 +105,7 @@ class StrandFusion(C.Structure):
                 ("n_endpoints", ci)]
 
 
-HEAD_SKIP_PIXELS, HEAD_SKIP_SMOOTH = 1, 2
+HEAD_SKIP_PIXELS, HEAD_SKIP_SMOOTH, HEAD_SKIP_SSIM = 1, 2, 4
 HEAD_OUT = ["total", "l1", "dssim", "mask", "orientation", "smooth", "ori_count", "smooth_count", "g_ssim", "g_l1", "g_mask",
             "g_ori", "g_smooth"]
 HEAD_NOUT = 16

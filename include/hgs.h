@@ -267,10 +267,15 @@ int hgs_cloud_params_backward(void* stream, int P, const float* scaling_raw, con
  *   passes HGS_HEAD_SKIP_PIXELS to the backward and uses those planes as they are.
  *   smooth_partials_ext (may be NULL): smoothness partial sums already computed elsewhere (HgsStrandFusion): the head then
  *   launches no smoothness kernel of its own and reduces these.
+ *   d_image_unit ([3,H,W], may be NULL): if given (and W % 4 == 0), ONE kernel computes the SSIM / L1 sums and writes
+ *   dL/d(image) FOR grad_out = 1 here -- the weights of the two terms are constants of HgsHeadParams, so the gradient does
+ *   not wait for the value; no derivative maps go through HBM.  The caller then passes HGS_HEAD_SKIP_SSIM and this buffer
+ *   (scaled by its upstream gradient if that is not 1) as d_image to the backward, which launches no SSIM kernel.
+ *   With W % 4 != 0 the buffer is left untouched and HGS_HEAD_SKIP_SSIM must not be passed.
  *   backward: d_image [3,H,W] fully written; d_mask_img [H,W], d_omap [3,H,W] fully written unless HGS_HEAD_SKIP_PIXELS;
  *   d_endpoints [E,3] zeroed, then (unless HGS_HEAD_SKIP_SMOOTH) the smoothness gradient scattered into it;
  *   grad_out = device scalar dL/dtotal. */
-enum { HGS_HEAD_SKIP_PIXELS = 1, HGS_HEAD_SKIP_SMOOTH = 2 };
+enum { HGS_HEAD_SKIP_PIXELS = 1, HGS_HEAD_SKIP_SMOOTH = 2, HGS_HEAD_SKIP_SSIM = 4 };
 typedef struct HgsHeadParams {
   int H, W;
   float lambda_dssim, lambda_mask, lambda_orientation, lambda_smooth;
@@ -288,7 +293,7 @@ size_t hgs_loss_head_scratch_floats(const HgsHeadParams* p);
 int hgs_loss_head_forward(void* stream, const HgsHeadParams* p, const float* image, const float* mask_img,
                           const float* omap, const HgsViewTargets* targets, const float* endpoints,
                           const long long* smooth_pairs, float* scratch, float* out, float* d_extra_unit,
-                          const float* smooth_partials_ext);
+                          const float* smooth_partials_ext, float* d_image_unit);
 int hgs_loss_head_backward(void* stream, const HgsHeadParams* p, const float* image, const float* mask_img,
                            const float* omap, const HgsViewTargets* targets, const float* endpoints,
                            const long long* smooth_pairs, const float* scratch, const float* out,
