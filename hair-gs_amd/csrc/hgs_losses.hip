@@ -325,7 +325,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 // MEASURED (1080p, north_star): 118 us against 42 + 40 us for the two kernels -- 61 KB of LDS leave two workgroups (two
 // waves per SIMD) per CU, and five barriers per block with that little to switch to cost more than the bytes saved.  Kept
 // behind hgs_loss_head_forward(d_image_unit) (FusedStrandStep.fused_ssim, off) and tested; a version that filters two of
-// the four maps at a time (42 KB, three workgroups) is the next thing to try.
+// the four maps at a time (42 KB, three workgroups) is the next thing to try (512 threads per workgroup instead of 256, for
+// four waves per SIMD with the same LDS, took 146 us).
 //   LDS: t[2][52][57] (images; later m[3][42][45], the maps) | hz[4][52][45] (row-filtered; later hz2[3][42][33])
 // Tile row r <-> image y = by0 - 10 + r, tile column c <-> x = bx0 - 12 + c (16-byte aligned chunks);
 // map row my <-> y = by0 - 5 + my, map column mx <-> x = bx0 - 5 + mx.

@@ -11,6 +11,7 @@ approximated; tests/test_gpu_train.py checks loss, gradients and statistics agai
 Views live in a device-resident table (ViewTable); the iteration reads the current view through a 184-byte slot, so a
 captured HIP graph switches views with one tiny launch (hgs_select_view) and no image copies."""
 import ctypes as C
+import os
 import math
 
 import numpy as np
@@ -290,9 +291,10 @@ class FusedStrandStep:
         self.empty = torch.empty(0, device=dev)
         self.one = torch.ones((), dtype=torch.float32, device=dev)   # d loss / d loss, passed to backward(): no fill launch
         self.one_pass_pixels = True    # per-pixel loss terms: value and gradient in one pass over the pixels
-        # SSIM / L1 value and image gradient in ONE kernel (hgs.h d_image_unit: no derivative maps through HBM).  Off: at
+        # SSIM / L1 value and image gradient in ONE kernel (hgs.h d_image_unit: no derivative maps through HBM).  Off
+        # (HGS_FUSED_SSIM=1 switches it on for measurements): at
         # 1080p it takes 118 us against 42 + 40 for the two-kernel form (61 KB of LDS leave two workgroups per CU)
-        self.fused_ssim = False
+        self.fused_ssim = os.environ.get("HGS_FUSED_SSIM") == "1"
         self.stats_in_backward = True  # densification statistics updated by the backward's last launch
         self.last = {}
         self.refresh()
