@@ -390,17 +390,21 @@ def test_fused_ssim_odd_sizes(hw):
     assert (ga - a.grad).abs().max() <= 2e-4 * a.grad.abs().max()
 
 
-def test_fused_iteration_matches_op_by_op_path():
+@pytest.mark.parametrize("workload", ["tiny", "north_star"])
+def test_fused_iteration_matches_op_by_op_path(workload):
     """hgs_runtime.strand_step (view table + fused parameter/loss-head kernels, one autograd node) against the
     op-by-op path (getters, render_multi, loss_function_single_pass, update_densification_stats): same loss terms,
-    same gradients of every parameter group, same densification statistics."""
+    same gradients of every parameter group, same densification statistics.  north_star: the BASELINE size (100 000
+    strand-Gaussians at 1080p), where the tile culling, the SSIM block lists and the capacity-mode binning all have
+    something to do."""
     from arguments import OptimizationParams
     from hgs_runtime.strand_step import FusedStrandStep
     from loss.losses import loss_function_single_pass
     from synthetic import build_workload
     from utils.general import safe_state
     safe_state(True)
-    model, cams, _ = build_workload("tiny", device="cuda", with_targets=True)
+    model, cams, _ = (build_workload("tiny", device="cuda", with_targets=True) if workload == "tiny"
+                      else build_workload(workload, device="cuda", with_targets=True, n_views=3))
     opt = OptimizationParams()
     model.training_setup(opt)
     bg = torch.zeros(3, device="cuda")
