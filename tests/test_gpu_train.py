@@ -590,15 +590,18 @@ def test_fused_iteration_without_view_masks():
         assert (p.grad - gref).abs().max() <= 3e-4 * float(gref.abs().max())
 
 
-def test_fused_iteration_is_bitwise_reproducible():
+@pytest.mark.parametrize("workload", ["tiny", "north_star"])
+def test_fused_iteration_is_bitwise_reproducible(workload):
     """No float atomics anywhere in the fused strand iteration (blend backward: fixed-order partial sums; endpoints:
-    gather over the adjacency tables): two evaluations from the same state give bit-identical loss and gradients."""
+    gather over the adjacency tables): two evaluations from the same state give bit-identical loss and gradients
+    (north_star: at the BASELINE size, 100 000 strand-Gaussians at 1080p)."""
     from arguments import OptimizationParams
     from hgs_runtime.strand_step import FusedStrandStep
     from synthetic import build_workload
     from utils.general import safe_state
     safe_state(True)
-    model, cams, _ = build_workload("tiny", device="cuda", with_targets=True)
+    model, cams, _ = (build_workload("tiny", device="cuda", with_targets=True) if workload == "tiny"
+                      else build_workload(workload, device="cuda", with_targets=True, n_views=3))
     opt = OptimizationParams()
     model.training_setup(opt)
     with torch.no_grad():
