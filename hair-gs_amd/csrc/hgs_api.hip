@@ -131,7 +131,7 @@ int hgs_forward_preprocess(void* stream, int P, int D, int M, int W, int H, cons
   HgsImage im;
   hgs_image_carve((char*)image_buf, (size_t)W, (size_t)H, im, nullptr);
   const int T = ((W + HGS_TILE - 1) / HGS_TILE) * ((H + HGS_TILE - 1) / HGS_TILE);
-  if (hgs_zero_async(s, im.tile_count, ((size_t)3 * T + HGS_STATUS_WORDS) * sizeof(uint32_t))) return 1;
+  if (hgs_zero_async(s, im.tile_count, hgs_image_zero_words((size_t)T) * sizeof(uint32_t))) return 1;
   if (P == 0) {  // reference short-circuits P == 0 (rasterize_points.cu:81); the scan of all-zero counts writes the
     HgsGeom none = {};  // empty ranges and the tile order the blend kernel (background fill) indexes with
     if (hgs_launch_scan(s, 0, T, none, im, nullptr)) return 1;
@@ -257,7 +257,7 @@ static int backward_impl(void* stream, int P, int D, int M, int R, int W, int H,
   a.dL_dmeans3D = dL_dmeans3D; a.dL_dcov3D = dL_dcov3D; a.dL_dsh = dL_dsh; a.dL_dscales = dL_dscales;
   a.dL_drotations = dL_drotations;
   a.n_extra = n_extra; a.dL_dextra = dL_dextra;
-  return hgs_launch_preprocess_bwd(s, a, g, b, inst_grad, R);
+  return hgs_launch_preprocess_bwd(s, a, g, b, inst_grad, R, im.status);
 }
 
 int hgs_backward(void* stream, int P, int D, int M, int R, int W, int H, const float* bg, const float* means3D,

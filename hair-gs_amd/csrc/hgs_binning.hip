@@ -10,6 +10,12 @@
 //                      depth_bits<<32|id in LDS (bitonic), emits point_list in final order, the packed
 //                      per-instance records the blend kernels stream (with the instance's Gaussian-major slot,
 //                      where the backward stores its row for the deterministic per-Gaussian sum).
+//                      Lists longer than one LDS chunk (HGS_SORT_CAP keys) are sorted by ONE WORKGROUP PER CHUNK
+//                      of the same launch: every chunk is sorted in LDS and published (agent-scope stores + the
+//                      tile's progress mask, hgs_common.h), then each workgroup ranks its own keys against the
+//                      other chunks (keys are unique: final position = sum of lower bounds) and emits them.
+//                      The same launch builds the blend kernels' work list: segments of split lists first, then
+//                      the other tiles by descending list length.
 // Result: identical point_list/ranges, ~10x less sort traffic than 144 B/instance, no stability needed.
 #include "hgs_common.h"
 
@@ -17,7 +23,7 @@ namespace {
 
 #define SCAN_THREADS 1024
 #define ORD_BUCKETS 512    // list-length buckets of the tile order (<= SCAN_THREADS)
-#define SORT_CAP 2048  // keys per LDS chunk (16 KB)
+#define SORT_CAP HGS_SORT_CAP  // keys per LDS chunk (16 KB)
 
 // generic helper: scans `n` uint32 values with one 1024-thread block; calls emit(i, exclusive, value)
 template <typename F>
@@ -88,6 +94,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_kernel(int nblk, int T, Hgs
   auto emit_bs = [&](int i, uint32_t excl, uint32_t) { bs[i] = excl; };
   auto emit_rg = [&](int i, uint32_t excl, uint32_t v) {
     ranges[i] = v ? make_uint2(excl, excl + v) : make_uint2(0u, 0u);  // empty tiles stay (0,0): memset at :310
+    hgs_emit_sort_items((uint32_t)i, v, (uint32_t)T, im);              // long lists: one sort workgroup per chunk
   };
   uint32_t R;
   if (nblk <= SCAN_THREADS * SCAN_IPT && T <= SCAN_THREADS * SCAN_IPT) {
@@ -101,7 +108,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_kernel(int nblk, int T, Hgs
     R = block_scan(im.tile_count, T, wtot, emit_rg);
   }
   if (threadIdx.x == 0) {
-    im.status[0] = R;
+    im.status[HGS_ST_R] = R;
     if (max_rendered) atomicMax(max_rendered, R);   // sticky maximum for graph replays (hgs.h)
   }
 }
@@ -151,27 +158,53 @@ __device__ __forceinline__ void bitonic_lds(uint64_t* sk, int m) {
   }
 }
 
-// Longest-list-first workgroup order for the blend kernels (counting sort of the tiles by min(length, ORD_BUCKETS-1)),
-// computed by ONE extra workgroup of the sort kernel, i.e. in the shadow of the per-tile sorts.  A tile's list is consumed
-// sequentially, so the blend kernels end when the longest lists end: measured on the strand workload, raster order
-// started the 58-us tiles of the backward 15-30 us into the launch (88 -> 75 us with this order).
-__device__ __forceinline__ void tile_order_block(int T, const HgsImage& im, uint16_t* bk, int bk_cap) {
-  __shared__ uint32_t hist[ORD_BUCKETS], obase[ORD_BUCKETS], wsum[HGS_BLOCK / 64];
+// Work list of the blend kernels, computed by ONE extra workgroup of the sort kernel, i.e. in the shadow of the sorts.
+//   * Lists longer than 1.5 segment lengths (hgs_split_of) are SPLIT: one work item per segment in b.seg_work, a tile's
+//     segments consecutive and ascending (the forward waits on predecessors only), the tile flagged in tile_prog.
+//     These items come first: they are the longest pieces of work.
+//   * The other tiles follow in descending order of list length (counting sort by min(length, ORD_BUCKETS-1)) in
+//     im.tile_order.  A list is consumed sequentially, so the blend kernels end when the longest pieces end: measured
+//     on the strand workload, raster order started the 58-us tiles of the backward 15-30 us into the launch.
+__device__ __forceinline__ void work_list_block(int T, uint32_t Rcap, const HgsImage& im, const HgsBinning& b, uint16_t* bk, int bk_cap) {
+  __shared__ uint32_t hist[ORD_BUCKETS], obase[ORD_BUCKETS], wsum[HGS_BLOCK / 64], nsplit_items, nsplit_tiles;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   for (int i = tid; i < ORD_BUCKETS; i += HGS_BLOCK) hist[i] = 0u;
-  auto bucket_of = [&](int i) {
+  if (tid == 0) { nsplit_items = 0u; nsplit_tiles = 0u; }
+  const uint32_t S = hgs_segment_length(im.status[HGS_ST_R]);
+  const uint32_t seg_cap = b.seg_cap;
+  __syncthreads();
+  constexpr int SPLIT_BUCKET = 0xFFFF;
+  // bucket of a tile; split tiles get their work items here (once: pass 0 caches the answer whenever T fits the cache)
+  auto classify = [&](int i) {
     const uint2 r = im.ranges[i];
-    return ORD_BUCKETS - 1 - (int)min(r.y - r.x, (uint32_t)(ORD_BUCKETS - 1));   // bucket 0 = longest lists
+    const uint32_t n = r.y - r.x;
+    const HgsSplit sp = hgs_split_of(n, S);
+    if (sp.nseg > 1 && seg_cap && r.y <= Rcap) {   // (a list beyond the binning capacity is void: status[1])
+      const uint32_t base = atomicAdd(&nsplit_items, sp.nseg);
+      const bool fits = base + sp.nseg <= seg_cap;
+      for (uint32_t k = 0; k < sp.nseg && base + k < seg_cap; k++) b.seg_work[base + k] = fits ? ((uint32_t)i | (k << 24)) : HGS_ITEM_NONE;
+      if (fits) { im.tile_prog[i] = HGS_PART_FLAG; atomicAdd(&nsplit_tiles, 1u); return SPLIT_BUCKET; }
+    }
+    return ORD_BUCKETS - 1 - (int)min(n, (uint32_t)(ORD_BUCKETS - 1));   // bucket 0 = longest lists
   };
-  // pass 0: the buckets of all tiles into LDS (bk aliases the sort buffer of this otherwise idle workgroup); nothing in
-  // this loop orders its iterations, so the loads of several iterations are in flight together
   const bool cached = T <= bk_cap;
   if (cached) {
-#pragma unroll 8
-    for (int i = tid; i < T; i += HGS_BLOCK) bk[i] = (uint16_t)bucket_of(i);
+#pragma unroll 4
+    for (int i = tid; i < T; i += HGS_BLOCK) bk[i] = (uint16_t)classify(i);
+    __syncthreads();
   }
-  __syncthreads();
-  for (int i = tid; i < T; i += HGS_BLOCK) atomicAdd(&hist[cached ? (int)bk[i] : bucket_of(i)], 1u);
+  auto bucket_of = [&](int i) {
+    if (cached) return (int)bk[i];
+    if (im.tile_prog[i] == HGS_PART_FLAG) return SPLIT_BUCKET;
+    const uint2 r = im.ranges[i];
+    return ORD_BUCKETS - 1 - (int)min(r.y - r.x, (uint32_t)(ORD_BUCKETS - 1));
+  };
+  if (!cached) {   // huge frames: classify once (items + flags), buckets are recomputed from the flags afterwards
+    for (int i = tid; i < T; i += HGS_BLOCK) classify(i);
+    __threadfence_block();
+    __syncthreads();
+  }
+  for (int i = tid; i < T; i += HGS_BLOCK) { const int k = bucket_of(i); if (k != SPLIT_BUCKET) atomicAdd(&hist[k], 1u); }
   __syncthreads();
   uint32_t carry = 0;
   for (int base = 0; base < ORD_BUCKETS; base += HGS_BLOCK) {   // exclusive scan of the histogram
@@ -187,16 +220,97 @@ __device__ __forceinline__ void tile_order_block(int T, const HgsImage& im, uint
     __syncthreads();
   }
   for (int i = tid; i < T; i += HGS_BLOCK) {
-    const int bkt = cached ? (int)bk[i] : bucket_of(i);
-    im.tile_order[obase[bkt] + atomicAdd(&hist[bkt], 1u)] = (uint32_t)i;   // order inside a bucket is irrelevant
+    const int bkt = bucket_of(i);
+    if (bkt != SPLIT_BUCKET) im.tile_order[obase[bkt] + atomicAdd(&hist[bkt], 1u)] = (uint32_t)i;   // order inside a bucket is irrelevant
+  }
+  if (tid == 0) {
+    im.status[HGS_ST_SPLIT_ITEMS] = min(nsplit_items, seg_cap);
+    im.status[HGS_ST_SEG_LEN] = S;
+    im.status[HGS_ST_UNSPLIT] = (uint32_t)T - nsplit_tiles;
   }
 }
 
+// ranks of a thread's KPT keys (registers) among the sorted keys staged in sk[0, cn2): lower bounds, searched in lockstep
+// so that the LDS reads of a thread's searches are independent
+template <int KPT>
+__device__ __forceinline__ void add_lower_bounds(const uint64_t* sk, uint32_t cn2, const uint64_t (&key)[KPT], uint32_t (&rank)[KPT]) {
+  uint32_t lo[KPT], hi[KPT];
+#pragma unroll
+  for (int i = 0; i < KPT; i++) { lo[i] = 0u; hi[i] = cn2; }
+  for (uint32_t span = cn2; span > 0; span >>= 1) {      // ceil(log2(cn2)) + 1 halvings bound every search
+#pragma unroll
+    for (int i = 0; i < KPT; i++) {
+      if (lo[i] < hi[i]) {
+        const uint32_t mid = (lo[i] + hi[i]) >> 1;
+        if (sk[mid] < key[i]) lo[i] = mid + 1; else hi[i] = mid;
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < KPT; i++) rank[i] += lo[i];
+}
+
+// grid: [0] work list, [1, T] one workgroup per tile, (T, ...) one workgroup per chunk work item of a long list
 __global__ __launch_bounds__(HGS_BLOCK) void sort_tiles_kernel(int gx, int T, uint32_t Rcap, EmitCtx ec, HgsGeom g, HgsImage im,
                                                                HgsBinning b) {
   __shared__ uint64_t sk[SORT_CAP];
-  if (blockIdx.x == 0) { tile_order_block(T, im, (uint16_t*)sk, SORT_CAP * 4); return; }
+  constexpr int KPT = SORT_CAP / HGS_BLOCK;
+  if (blockIdx.x == 0) { work_list_block(T, Rcap, im, b, (uint16_t*)sk, SORT_CAP * 4); return; }
+  if ((int)blockIdx.x > T) {
+    // ---- one chunk of a long list (work items from the scan: hgs_emit_sort_items)
+    const uint32_t j = blockIdx.x - (uint32_t)T - 1u;
+    if (j >= min(im.status[HGS_ST_SORT_ITEMS], (uint32_t)T)) return;
+    const uint32_t item = im.sort_items[j];
+    if (item == HGS_ITEM_NONE) return;
+    const int tile = (int)HGS_ITEM_TILE(item);
+    const uint32_t c = HGS_ITEM_PART(item);
+    const uint2 range = im.ranges[tile];
+    if (range.y > Rcap) return;                            // binning buffer overflow: the pass is void (status[1])
+    const uint32_t start = range.x, n = range.y - range.x, nchunks = (n + SORT_CAP - 1) / SORT_CAP;
+    const int tx = tile % gx, ty = tile / gx;
+    const uint32_t cbase = start + c * SORT_CAP, cn = min((uint32_t)SORT_CAP, n - c * SORT_CAP);
+    int m = 2;
+    while ((uint32_t)m < cn) m <<= 1;
+    for (int i = threadIdx.x; i < m; i += HGS_BLOCK) sk[i] = (uint32_t)i < cn ? b.keys[cbase + i] : ~0ull;
+    __syncthreads();
+    bitonic_lds(sk, m);
+    // publish the sorted chunk in place (each chunk owns its part of the key array), keep this thread's keys
+    uint64_t key[KPT];
+    uint32_t rank[KPT];
+#pragma unroll
+    for (int i = 0; i < KPT; i++) {
+      const uint32_t e = threadIdx.x + (uint32_t)i * HGS_BLOCK;
+      key[i] = e < cn ? sk[e] : ~0ull;
+      rank[i] = e;
+      if (e < cn) hgs_st_agent((unsigned long long*)&b.keys[cbase + e], (unsigned long long)key[i]);
+    }
+    hgs_drain_stores();
+    __syncthreads();
+    __shared__ int ok;
+    if (threadIdx.x == 0) {
+      hgs_publish_part(&im.tile_sortprog[tile], c);
+      ok = hgs_wait_parts(&im.tile_sortprog[tile], (1ull << nchunks) - 1ull, im.status) ? 1 : 0;
+    }
+    __syncthreads();
+    if (!ok) return;
+    for (uint32_t c2 = 0; c2 < nchunks; c2++) {
+      if (c2 == c) continue;
+      const uint32_t cn2 = min((uint32_t)SORT_CAP, n - c2 * SORT_CAP);
+      __syncthreads();
+      for (uint32_t i = threadIdx.x; i < cn2; i += HGS_BLOCK)
+        sk[i] = hgs_ld_agent((const unsigned long long*)&b.keys[start + c2 * SORT_CAP + i]);
+      __syncthreads();
+      add_lower_bounds<KPT>(sk, cn2, key, rank);
+    }
+#pragma unroll
+    for (int i = 0; i < KPT; i++) {
+      const uint32_t e = threadIdx.x + (uint32_t)i * HGS_BLOCK;
+      if (e < cn) emit_instance(key[i], start + rank[i], tx, ty, ec, g, b);
+    }
+    return;
+  }
   const int tile = blockIdx.x - 1;
+  if (im.tile_sortprog[tile] & HGS_PART_FLAG) return;   // long list: sorted by its chunk workgroups above
   const uint2 range = im.ranges[tile];
   if (range.y <= range.x || range.y > Rcap) return;  // empty, or binning buffer overflow (status[1] already set)
   const uint32_t start = range.x, n = range.y - range.x;
@@ -218,12 +332,8 @@ __global__ __launch_bounds__(HGS_BLOCK) void sort_tiles_kernel(int gx, int T, ui
     __syncthreads();
   }
   if (nchunks > 1) {
-    // long list: chunks are sorted; the final rank of a key = its index in its chunk + the number of smaller keys in
-    // every other chunk (keys are unique).  Per chunk of elements (<= SORT_CAP / HGS_BLOCK keys per thread, in registers)
-    // every OTHER chunk is staged into LDS in turn and searched there: the lower bounds of a thread's keys advance in
-    // lockstep, so their LDS reads are independent.  (Searching the chunks in global memory, as this code first did,
-    // cost ~11 dependent HBM round trips per key and chunk: 135 us on a 3000-entry tile.)
-    constexpr int KPT = SORT_CAP / HGS_BLOCK;
+    // Fallback for lists the chunk work list could not take (more than HGS_MAX_PARTS chunks, or the list was full): the
+    // same rank merge, chunk after chunk in this workgroup.
     __threadfence_block();
     __syncthreads();
     for (uint32_t c = 0; c < nchunks; c++) {
@@ -234,7 +344,7 @@ __global__ __launch_bounds__(HGS_BLOCK) void sort_tiles_kernel(int gx, int T, ui
       for (int i = 0; i < KPT; i++) {
         const uint32_t e = threadIdx.x + (uint32_t)i * HGS_BLOCK;
         key[i] = e < cn ? b.keys[start + c * SORT_CAP + e] : ~0ull;
-        rank[i] = c * 0u + e;
+        rank[i] = e;
       }
       for (uint32_t c2 = 0; c2 < nchunks; c2++) {
         if (c2 == c) continue;
@@ -242,20 +352,7 @@ __global__ __launch_bounds__(HGS_BLOCK) void sort_tiles_kernel(int gx, int T, ui
         __syncthreads();
         for (uint32_t i = threadIdx.x; i < cn2; i += HGS_BLOCK) sk[i] = b.keys[start + c2 * SORT_CAP + i];
         __syncthreads();
-        uint32_t lo[KPT], hi[KPT];
-#pragma unroll
-        for (int i = 0; i < KPT; i++) { lo[i] = 0u; hi[i] = cn2; }
-        for (uint32_t span = cn2; span > 0; span >>= 1) {      // ceil(log2(cn2)) + 1 halvings bound every search
-#pragma unroll
-          for (int i = 0; i < KPT; i++) {
-            if (lo[i] < hi[i]) {
-              const uint32_t mid = (lo[i] + hi[i]) >> 1;
-              if (sk[mid] < key[i]) lo[i] = mid + 1; else hi[i] = mid;
-            }
-          }
-        }
-#pragma unroll
-        for (int i = 0; i < KPT; i++) rank[i] += lo[i];
+        add_lower_bounds<KPT>(sk, cn2, key, rank);
       }
 #pragma unroll
       for (int i = 0; i < KPT; i++) {
@@ -284,7 +381,11 @@ int hgs_launch_sort_tiles(hipStream_t s, int W, int H, int Rcap, const float* fe
   {
     HgsProfScope _prof(s, HGS_K_SORT_TILES);
     EmitCtx ec = {features, extra, n_extra, (uint32_t)Rcap};
-    hipLaunchKernelGGL(sort_tiles_kernel, dim3(gx * gy + 1), dim3(HGS_BLOCK), 0, s, gx, gx * gy, (uint32_t)Rcap, ec, g, im, b);
+    // chunk work items: at most 2 Rcap / HGS_SORT_CAP (every long list has more than HGS_SORT_CAP entries), and at most T
+    const int T = gx * gy;
+    const long long items = 2ll * Rcap / HGS_SORT_CAP + 2;
+    const int extra_wgs = (int)(items < T ? items : T);
+    hipLaunchKernelGGL(sort_tiles_kernel, dim3(T + 1 + extra_wgs), dim3(HGS_BLOCK), 0, s, gx, T, (uint32_t)Rcap, ec, g, im, b);
   }
   HGS_CHECK_LAUNCH();
   return 0;

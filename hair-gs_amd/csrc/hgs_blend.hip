@@ -5,14 +5,32 @@
 // CDNA4 mapping (not the reference's 256-entry shared-memory staging):
 //   * a 16x16 tile = one 256-thread workgroup = 4 wavefronts; wavefront w owns the 8x8 pixel quadrant
 //     (w&1, w>>1): compact footprints make whole-wave rejection of thin strand Gaussians likely;
-//   * the tile's depth-sorted instance records (48 B: xy, conic, opacity, rgb, id -- 64 B with the 4 extra channels of
-//     the single-pass mode; written by sort_tiles_kernel) are wave-uniform data: they are streamed with SCALAR loads (s_load_dwordx4) straight
-//     into SGPRs and used as SGPR operands of the per-pixel VALU math -- no LDS staging, no barriers in the
-//     forward, each wavefront leaves its loop on its own when its 64 pixels are saturated;
-//   * backward: per (wave, entry) the 9 partial sums are reduced across the 64 lanes, the 4 wavefronts'
-//     results are combined through LDS in fixed order and written ONCE per (tile, entry) with plain stores
-//     into an instance-indexed scratch; preprocess_bwd gathers them per Gaussian through the inverse index.
-//     No float atomics anywhere -> gradients are bitwise reproducible run to run (the reference's are not).
+//   * the tile's depth-sorted instance records (48 B: xy, conic, opacity, rgb, id, quadrant mask, Gaussian-major slot --
+//     64 B with the 4 extra channels of the single-pass mode; written by sort_tiles_kernel) are staged through LDS in
+//     batches of 64 with one coalesced float4 load per thread, the next batch in flight during the math; every wavefront
+//     ballots the batch's quadrant masks into a 64-bit set and walks only ITS entries on the scalar unit, reading the
+//     record with wave-uniform ds_read_b128;
+//   * backward: per (wave, entry) the partial sums are reduced across the 64 lanes (permlane swaps + bank-masked DPP),
+//     the 4 wavefronts' results are combined through LDS in fixed order and written ONCE per (tile, entry) with plain
+//     stores into the instance's Gaussian-major row of the scratch; preprocess_bwd sums a Gaussian's contiguous rows.
+//     No float atomics anywhere -> gradients are bitwise reproducible run to run (the reference's are not);
+//   * LONG LISTS ARE SPLIT ACROSS WORKGROUPS (work list of sort_tiles_kernel: segments of 256-1024 entries).  The
+//     reference walks a tile's list with one thread block (forward.cu:295-362); a scene whose Gaussians pile up on a
+//     few hundred tiles (Stage I: 1000-3000 entries per tile) then runs at the speed of one workgroup per tile.
+//     Transmittance is a product, so segments compose:
+//       forward  phase 1: every segment's workgroup multiplies (1 - alpha) over ITS entries per pixel and publishes the
+//                         product (agent-scope stores + the tile's progress mask, hgs_common.h);
+//                phase 2: it reads its predecessors' products -- the transmittance in front of the segment --, walks
+//                         its entries again with the reference's rules (alpha test, T (1 - alpha) < 1e-4 stop) and
+//                         publishes colour, final transmittance and last contributor of the segment; the LAST
+//                         workgroup of the tile to finish (ticket) combines the segments per pixel in list order:
+//                         first stop wins, colours summed back to front (fixed order: reproducible), and leaves the
+//                         SUFFIX sums of the segment colours in place;
+//       backward          needs no communication: a segment starts from the forward's transmittance in front of the NEXT
+//                         segment and from the colour behind it (that suffix sum) -- exactly the state the serial walk
+//                         would carry into it.
+//     The only numerical difference to the serial walk is the association of the transmittance product (one rounding
+//     per segment boundary).
 #include "hgs_common.h"
 
 // development aid: per-workgroup start/end timestamps (hgs_debug_set_wg_trace)
@@ -123,42 +141,55 @@ __device__ __forceinline__ Rec<C> lds_record(const float4* recs, int e) {
   return r;
 }
 
-// ------------------------------------------------------------------------------------------------
-template <int C>
-__global__ __launch_bounds__(HGS_BLOCK) void blend_fwd_kernel(const uint2* __restrict__ ranges,
-                                                              const float4* __restrict__ packed, int W, int H, int gx,
-                                                              uint32_t Rcap, const float* __restrict__ bg,
-                                                              float* __restrict__ final_T,
-                                                              uint32_t* __restrict__ n_contrib,
-                                                              uint32_t* __restrict__ tile_maxc,
-                                                              const uint32_t* __restrict__ tile_order,
-                                                              float* __restrict__ out_color) {
-  constexpr int REC4 = Chan<C>::REC4;
-  __shared__ float4 recs[2][REC_BATCH * REC4];
-  __shared__ uint32_t alive[2][4];
-  const int tile = (int)tile_order[blockIdx.x];   // longest lists first (scan_kernel)
-  WgTrace _trace(g_wg_trace_fwd, tile);
-  const int tx = tile % gx, ty = tile / gx;
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int px = tx * HGS_TILE + (wave & 1) * 8 + (lane & 7);
-  const int py = ty * HGS_TILE + (wave >> 1) * 8 + (lane >> 3);
-  const bool inside = px < W && py < H;
-  const float pxf = (float)px, pyf = (float)py;
-  uint2 range = ranges[tile];
-  if (range.y > Rcap) range = make_uint2(0u, 0u);  // binning buffer under-sized (flagged by the scatter kernel)
-  const uint32_t L = range.y - range.x;
-  const int nb = (int)((L + REC_BATCH - 1) / REC_BATCH);
-  // T < 0 marks a pixel that is done (saturated, forward.cu:346-351, or outside the image): its magnitude stays the
-  // transmittance it stopped at.  A separate per-lane flag costs a byte register and ~6 vector instructions per entry to
-  // test, merge and update; the sign costs one compare.
-  float T = inside ? 1.f : -1.f, acc[C];
-#pragma unroll
-  for (int k = 0; k < C; k++) acc[k] = 0.f;
-  uint32_t last = 0;
+// ---- work items ------------------------------------------------------------------------------------------------
+// blockIdx -> (tile, list segment).  Split lists first (seg_work, a tile's segments consecutive), then the unsplit tiles
+// in descending order of list length (tile_order); both lists come from the sort kernel's work-list workgroup.
+struct BlendItem { int tile; uint32_t seg, nseg, s, e, w; uint2 range; bool split; };
+__device__ __forceinline__ bool blend_item(const HgsImage& im, const HgsBinning& bn, uint32_t Rcap, BlendItem& it) {
+  const uint32_t nsplit = im.status[HGS_ST_SPLIT_ITEMS];
+  it.w = blockIdx.x;
+  it.split = blockIdx.x < nsplit;
+  if (it.split) {
+    const uint32_t item = bn.seg_work[blockIdx.x];
+    if (item == HGS_ITEM_NONE) return false;
+    it.tile = (int)HGS_ITEM_TILE(item);
+    it.seg = HGS_ITEM_PART(item);
+  } else {
+    const uint32_t j = blockIdx.x - nsplit;
+    if (j >= im.status[HGS_ST_UNSPLIT]) return false;
+    it.tile = (int)im.tile_order[j];
+    it.seg = 0u;
+  }
+  it.range = im.ranges[it.tile];
+  if (it.range.y > Rcap) it.range = make_uint2(0u, 0u);   // binning buffer under-sized (flagged by the scatter kernel)
+  const uint32_t n = it.range.y - it.range.x;
+  it.nseg = 1u; it.s = 0u; it.e = n;
+  if (it.split) {
+    const HgsSplit sp = hgs_split_of(n, im.status[HGS_ST_SEG_LEN]);
+    it.nseg = sp.nseg;
+    it.s = it.seg * sp.seglen;
+    it.e = min(n, it.s + sp.seglen);
+  }
+  return true;
+}
 
-  const float4* src = packed + (size_t)range.x * REC4;
+// Front-to-back walk of list positions [s, e) of a tile (src = the tile's first record).
+//   COLOR: the reference's loop (forward.cu:309-362): alpha test, stop rule, colour accumulation, last contributor.
+//          T < 0 marks a pixel that is done (saturated, forward.cu:346-351, or outside the image): its magnitude stays the
+//          transmittance it stopped at.  A separate per-lane flag costs a byte register and ~6 vector instructions per
+//          entry to test, merge and update; the sign costs one compare.
+//   !COLOR: phase 1 of a split list: T only collects the product of (1 - alpha) over the entries that pass the alpha test.
+template <int C, bool COLOR>
+__device__ __forceinline__ void fwd_walk(const float4* __restrict__ src, uint32_t s, uint32_t e,
+                                         float4 (&recs)[2][REC_BATCH * Chan<C>::REC4], uint32_t (&alive)[2][4], float pxf,
+                                         float pyf, int wave, int lane, float& T, float (&acc)[C], uint32_t& last) {
+  constexpr int REC4 = Chan<C>::REC4;
+  const uint32_t L = e - s;
+  const int nb = (int)((L + REC_BATCH - 1) / REC_BATCH);
+  src += (size_t)s * REC4;
   const uint32_t nf4 = L * REC4;
   float4 stage = make_float4(0.f, 0.f, 0.f, 0.f);
+  __syncthreads();   // (the staging buffers may still be read by a previous walk)
   if (nb > 0) {
     if (threadIdx.x < REC_BATCH * REC4 && threadIdx.x < nf4) stage = src[threadIdx.x];
     if (threadIdx.x < REC_BATCH * REC4) recs[0][threadIdx.x] = stage;
@@ -172,14 +203,14 @@ __global__ __launch_bounds__(HGS_BLOCK) void blend_fwd_kernel(const uint2* __res
     }
     __syncthreads();
     // forward.cu:309-311: the tile stops when every pixel is saturated (flags written before the barrier above)
-    if ((alive[cur][0] | alive[cur][1] | alive[cur][2] | alive[cur][3]) == 0u) break;
+    if (COLOR && (alive[cur][0] | alive[cur][1] | alive[cur][2] | alive[cur][3]) == 0u) break;
     const int cnt = min(REC_BATCH, (int)L - b * REC_BATCH);
     const float* rf = (const float*)&recs[cur][0];
     const uint32_t mk = lane < cnt ? __float_as_uint(rf[lane * 4 * REC4 + 7 + C]) : 0u;
     uint64_t m = __ballot(((mk >> wave) & 1u) != 0u);
     if (__ballot(T > 0.f) == 0) m = 0;
     bool wave_done = false;   // every pixel of this wavefront saturated: leave the batch
-    auto process = [&](const Rec<C>& r, int e) {
+    auto process = [&](const Rec<C>& r, int ent) {
       const float4 r0 = r.q[0], r1 = r.q[1];
       const float dx = r0.x - pxf, dy = r0.y - pyf;
       const float power = -0.5f * (r0.z * dx * dx + r1.x * dy * dy) - r0.w * dx * dy;  // forward.cu:335
@@ -187,13 +218,17 @@ __global__ __launch_bounds__(HGS_BLOCK) void blend_fwd_kernel(const uint2* __res
       const bool ok = T > 0.f && power <= 0.f && alpha >= (1.0f / 255.0f);              // :336, :344
       if (__ballot(ok) == 0) return;
       const float test_T = T * (1.f - alpha);
+      if (!COLOR) {
+        if (ok) T = test_T;
+        return;
+      }
       const bool sat = ok && test_T < 0.0001f;                                          // :346-351
       if (ok && !sat) {
         const float w = alpha * T;
         const float* f = (const float*)&r.q[0];                                         // features start at float 6
 #pragma unroll
         for (int k = 0; k < C; k++) acc[k] += f[6 + k] * w;                             // :354-355
-        last = (uint32_t)(b * REC_BATCH + e + 1);                                       // :328, :361
+        last = s + (uint32_t)(b * REC_BATCH + ent + 1);                                 // :328, :361
       }
       if (ok) T = sat ? -T : test_T;
       if (__ballot(sat) != 0 && __ballot(T > 0.f) == 0) wave_done = true;
@@ -219,17 +254,113 @@ __global__ __launch_bounds__(HGS_BLOCK) void blend_fwd_kernel(const uint2* __res
       if (lane == 0) alive[cur ^ 1][wave] = wave_alive;
     }
   }
-  uint32_t wmax = last;
+}
+
+// ------------------------------------------------------------------------------------------------
+template <int C>
+__global__ __launch_bounds__(HGS_BLOCK) void blend_fwd_kernel(HgsImage im, HgsBinning bn, int W, int H, int gx, uint32_t Rcap,
+                                                              const float* __restrict__ bg, float* __restrict__ out_color) {
+  constexpr int REC4 = Chan<C>::REC4;
+  __shared__ float4 recs[2][REC_BATCH * REC4];
+  __shared__ uint32_t alive[2][4];
+  __shared__ uint32_t s_flag;
+  BlendItem it;
+  if (!blend_item(im, bn, Rcap, it)) return;
+  const int tile = it.tile;
+  WgTrace _trace(g_wg_trace_fwd, tile);
+  const int tx = tile % gx, ty = tile / gx;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int px = tx * HGS_TILE + (wave & 1) * 8 + (lane & 7);
+  const int py = ty * HGS_TILE + (wave >> 1) * 8 + (lane >> 3);
+  const bool inside = px < W && py < H;
+  const float pxf = (float)px, pyf = (float)py;
+  const float4* src = bn.packed + (size_t)it.range.x * REC4;
+  float acc[C];
+#pragma unroll
+  for (int k = 0; k < C; k++) acc[k] = 0.f;
+  uint32_t last = 0;
+  const size_t pix = (size_t)py * W + px, HW = (size_t)H * W;
+
+  if (!it.split) {
+    float T = inside ? 1.f : -1.f;
+    fwd_walk<C, true>(src, 0u, it.e, recs, alive, pxf, pyf, wave, lane, T, acc, last);
+    uint32_t wmax = last;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) wmax = max(wmax, (uint32_t)__shfl_xor((int)wmax, d, 64));
+    if (lane == 0 && wmax) atomicMax(&im.tile_maxc[tile], wmax);
+    if (inside) {
+      T = fabsf(T);
+      im.final_T[pix] = T;
+      im.n_contrib[pix] = last;
+#pragma unroll
+      for (int k = 0; k < C; k++) out_color[k * HW + pix] = acc[k] + T * bg[k];         // :372
+    }
+    return;
+  }
+
+  // ---- one segment of a split list (see the file header)
+  const size_t slot = (size_t)it.w * HGS_BLOCK + threadIdx.x;   // this pixel's cell in the per-segment arrays
+  // phase 1: product of (1 - alpha) over this segment
+  float P = inside ? 1.f : -1.f;
+  fwd_walk<C, false>(src, it.s, it.e, recs, alive, pxf, pyf, wave, lane, P, acc, last);
+  hgs_st_agent(&bn.seg_P[slot], P);
+  hgs_drain_stores();
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    hgs_publish_part(&im.tile_prog[tile], it.seg);
+    s_flag = it.seg == 0 || hgs_wait_parts(&im.tile_prog[tile], (1ull << it.seg) - 1ull, im.status) ? 1u : 0u;
+  }
+  __syncthreads();
+  float T = inside ? 1.f : -1.f;
+  if (s_flag) {
+    for (uint32_t m = 0; m < it.seg; m++) T *= hgs_ld_agent(&bn.seg_P[slot - (size_t)(it.seg - m) * HGS_BLOCK]);   // (outside: -1 * -1 ...)
+    if (!inside) T = -1.f;
+  }
+  bn.seg_T[slot] = fabsf(T);     // transmittance in front of this segment: the backward of the PREVIOUS segment starts from it
+  // a pixel below the stop threshold is done: any entry that passes the alpha test would stop it (T (1 - alpha) < T)
+  if (T > 0.f && T < 0.0001f) T = -T;
+  // phase 2: the reference's walk over this segment
+  fwd_walk<C, true>(src, it.s, it.e, recs, alive, pxf, pyf, wave, lane, T, acc, last);
+#pragma unroll
+  for (int k = 0; k < C; k++) hgs_st_agent(&bn.seg_C[((size_t)it.w * C + k) * HGS_BLOCK + threadIdx.x], acc[k]);
+  hgs_st_agent(&bn.seg_Tout[slot], T);
+  hgs_st_agent(&bn.seg_last[slot], last);
+  hgs_drain_stores();
+  __syncthreads();
+  if (threadIdx.x == 0)
+    s_flag = __hip_atomic_fetch_add(&im.tile_done[tile], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == it.nseg - 1u ? 1u : 0u;
+  __syncthreads();
+  if (!s_flag) return;
+  // ---- the tile's last workgroup: combine the segments per pixel, in list order
+  const size_t slot0 = slot - (size_t)it.seg * HGS_BLOCK;
+  const size_t w0 = (size_t)it.w - it.seg;
+  float Tfin = 1.f;
+  uint32_t nc = 0u, lastseg = it.nseg - 1u;
+  for (uint32_t m = 0; m < it.nseg; m++) {
+    const float to = hgs_ld_agent(&bn.seg_Tout[slot0 + (size_t)m * HGS_BLOCK]);
+    nc = max(nc, hgs_ld_agent(&bn.seg_last[slot0 + (size_t)m * HGS_BLOCK]));
+    Tfin = fabsf(to);
+    if (to < 0.f) { lastseg = m; break; }   // stopped here: nothing behind it contributes
+  }
+#pragma unroll
+  for (int k = 0; k < C; k++) acc[k] = 0.f;
+  for (int m = (int)it.nseg - 1; m >= 0; m--) {
+#pragma unroll
+    for (int k = 0; k < C; k++) {
+      float* cell = &bn.seg_C[((w0 + (size_t)m) * C + k) * HGS_BLOCK + threadIdx.x];
+      if ((uint32_t)m <= lastseg) acc[k] += hgs_ld_agent(cell);
+      *cell = acc[k];                        // suffix sum: colour added by segment m and everything behind it
+    }
+  }
+  uint32_t wmax = inside ? nc : 0u;
 #pragma unroll
   for (int d = 32; d >= 1; d >>= 1) wmax = max(wmax, (uint32_t)__shfl_xor((int)wmax, d, 64));
-  if (lane == 0 && wmax) atomicMax(&tile_maxc[tile], wmax);
+  if (lane == 0 && wmax) atomicMax(&im.tile_maxc[tile], wmax);
   if (inside) {
-    const size_t pix = (size_t)py * W + px, HW = (size_t)H * W;
-    T = fabsf(T);
-    final_T[pix] = T;
-    n_contrib[pix] = last;
+    im.final_T[pix] = Tfin;
+    im.n_contrib[pix] = nc;
 #pragma unroll
-    for (int k = 0; k < C; k++) out_color[k * HW + pix] = acc[k] + T * bg[k];           // :372
+    for (int k = 0; k < C; k++) out_color[k * HW + pix] = acc[k] + Tfin * bg[k];
   }
 }
 
@@ -237,26 +368,27 @@ __global__ __launch_bounds__(HGS_BLOCK) void blend_fwd_kernel(const uint2* __res
 template <int C> struct PixGrad { const float* plane[C]; };  // dL/d(output channel k) as [H,W] planes (need not be adjacent)
 
 template <int C>
-__global__ __launch_bounds__(HGS_BLOCK) __attribute__((amdgpu_waves_per_eu(6))) void blend_bwd_kernel(const uint2* __restrict__ ranges,
-                                                              const float4* __restrict__ packed, int W, int H, int gx,
+__global__ __launch_bounds__(HGS_BLOCK) __attribute__((amdgpu_waves_per_eu(6))) void blend_bwd_kernel(HgsImage im, HgsBinning bn, int W, int H, int gx,
                                                               uint32_t Rcap, const float* __restrict__ bg,
-                                                              const float* __restrict__ final_Ts,
-                                                              const uint32_t* __restrict__ n_contrib,
-                                                              const uint32_t* __restrict__ tile_maxc,
-                                                              PixGrad<C> dL_dpix, const uint32_t* __restrict__ tile_order,
-                                                              float* __restrict__ inst_grad) {
+                                                              PixGrad<C> dL_dpix, float* __restrict__ inst_grad) {
   constexpr int REC4 = Chan<C>::REC4, NPART = Chan<C>::NPART, NREG = Chan<C>::NREG, NV = 4 * NREG, ROW = Chan<C>::ROW;
   static_assert(BWD_BATCH == REC_BATCH, "one record batch per partial-sum flush");
   __shared__ float part[4][BWD_BATCH][NV];
   __shared__ float4 recs[2][REC_BATCH * REC4];
-  const int tile = (int)tile_order[blockIdx.x];   // longest lists first (scan_kernel)
+  // a forward that overflowed its binning capacity is void (records and slots of the dropped lists were never written):
+  // nothing is read or written here, preprocess_bwd_kernel returns zero gradients
+  if (im.status[HGS_ST_OVERFLOW]) return;
+  BlendItem it;
+  if (!blend_item(im, bn, Rcap, it)) return;   // same work list as the forward: (tile, list segment)
+  const int tile = it.tile;
   WgTrace _trace(g_wg_trace_bwd, tile);
-  const uint2 range = ranges[tile];
-  const uint32_t maxc = range.y > Rcap ? 0u : tile_maxc[tile];   // (list beyond an under-sized binning buffer: no gradients)
+  const uint2 range = it.range;
+  const float4* __restrict__ packed = bn.packed;
+  const uint32_t maxc = im.tile_maxc[tile];
   {
-    // Every instance row of the scratch is written by exactly one tile, so the scratch needs no clearing pass: entries
-    // past the last one any pixel needed (positions >= maxc; ~2% of the instances) get explicit zero rows here.
-    const uint32_t end = min(range.y, Rcap), first = range.x + maxc;
+    // Every instance row of the scratch is written by exactly one workgroup, so the scratch needs no clearing pass:
+    // entries past the last one any pixel needed (positions >= maxc; ~2% of the instances) get explicit zero rows here.
+    const uint32_t end = range.x + it.e, first = range.x + max(it.s, maxc);
     if (end > first) {
       const uint32_t n4 = (end - first) * (ROW / 4);
       for (uint32_t i = threadIdx.x; i < n4; i += HGS_BLOCK) {
@@ -266,7 +398,8 @@ __global__ __launch_bounds__(HGS_BLOCK) __attribute__((amdgpu_waves_per_eu(6))) 
       }
     }
   }
-  if (maxc == 0) return;  // nothing in this tile contributed to any pixel
+  if (maxc <= it.s) return;  // nothing in this part of the list contributed to any pixel
+  const int seg_lo = (int)it.s, top = (int)min(maxc, it.e);   // list positions [seg_lo, top) are walked, back to front
   const int tx = tile % gx, ty = tile / gx;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int px = tx * HGS_TILE + (wave & 1) * 8 + (lane & 7);
@@ -279,13 +412,13 @@ __global__ __launch_bounds__(HGS_BLOCK) __attribute__((amdgpu_waves_per_eu(6))) 
   const float4* src = packed + (size_t)range.x * REC4;
   float4 stage = make_float4(0.f, 0.f, 0.f, 0.f);
   {
-    const int lo = max(0, (int)maxc - BWD_BATCH), cnt = (int)maxc - lo;
+    const int lo = max(seg_lo, top - BWD_BATCH), cnt = top - lo;
     if (threadIdx.x < cnt * REC4) stage = src[(size_t)lo * REC4 + threadIdx.x];
   }
 
-  const float T_final = inside ? final_Ts[pix] : 0.f;
+  const float T_final = inside ? im.final_T[pix] : 0.f;
   float T = T_final;
-  const uint32_t last = inside ? n_contrib[pix] : 0u;
+  const uint32_t last = inside ? im.n_contrib[pix] : 0u;
   uint32_t wlast = last;                                                       // wave-wide last contributor
 #pragma unroll
   for (int d = 32; d >= 1; d >>= 1) wlast = max(wlast, (uint32_t)__shfl_xor((int)wlast, d, 64));
@@ -300,6 +433,23 @@ __global__ __launch_bounds__(HGS_BLOCK) __attribute__((amdgpu_waves_per_eu(6))) 
     bg_dot += bg[k] * dpx[k];
     if (k < 3) bg_dot_rgb += bg[k] * dpx[k];
   }
+  if (it.split && last > it.e) {
+    // This pixel has contributors behind this segment.  The serial walk would arrive here with T = the transmittance in
+    // front of the next segment and accum_rec = (colour blended behind) / T: both were left by the forward (seg_T of the
+    // next segment; seg_C holds, after the tile's finalisation, the colour of a segment and everything behind it).
+    const size_t nslot = ((size_t)it.w + 1) * HGS_BLOCK + threadIdx.x;
+    const float Tn = bn.seg_T[nslot];
+    float d = 0.f, d_rgb = 0.f;
+#pragma unroll
+    for (int k = 0; k < C; k++) {
+      d = __builtin_fmaf(bn.seg_C[(((size_t)it.w + 1) * C + k) * HGS_BLOCK + threadIdx.x], dpx[k], d);
+      if (k == 2) d_rgb = d;
+    }
+    const float inv = Tn > 0.f ? 1.f / Tn : 0.f;
+    T = Tn;
+    acc_dot = d * inv;
+    acc_dot_rgb = d_rgb * inv;
+  }
 
   for (int i = threadIdx.x; i < 4 * BWD_BATCH * NV; i += HGS_BLOCK) (&part[0][0][0])[i] = 0.f;
   if (threadIdx.x < REC_BATCH * REC4) recs[0][threadIdx.x] = stage;
@@ -308,11 +458,11 @@ __global__ __launch_bounds__(HGS_BLOCK) __attribute__((amdgpu_waves_per_eu(6))) 
   // walk the list back to front in batches of BWD_BATCH positions; position p (0-based) is valid for a pixel
   // iff p < n_contrib (backward_distwar.cu:943-945)
   int cur = 0;
-  for (int hi = (int)maxc; hi > 0; hi -= BWD_BATCH, cur ^= 1) {
-    const int lo = max(0, hi - BWD_BATCH);
+  for (int hi = top; hi > seg_lo; hi -= BWD_BATCH, cur ^= 1) {
+    const int lo = max(seg_lo, hi - BWD_BATCH);
     const int cnt = hi - lo;
-    if (lo > 0) {  // next batch's records: in flight during this batch's math
-      const int nlo = max(0, lo - BWD_BATCH), ncnt = lo - nlo;
+    if (lo > seg_lo) {  // next batch's records: in flight during this batch's math
+      const int nlo = max(seg_lo, lo - BWD_BATCH), ncnt = lo - nlo;
       if (threadIdx.x < ncnt * REC4) stage = src[(size_t)nlo * REC4 + threadIdx.x];
     }
     const float* rf = (const float*)&recs[cur][0];
@@ -414,7 +564,7 @@ __global__ __launch_bounds__(HGS_BLOCK) __attribute__((amdgpu_waves_per_eu(6))) 
       if (slot < Rcap) inst_grad[(size_t)slot * ROW + k] = s;
       part[0][e][k] = 0.f; part[1][e][k] = 0.f; part[2][e][k] = 0.f; part[3][e][k] = 0.f;
     }
-    if (lo > 0 && threadIdx.x < REC_BATCH * REC4) recs[cur ^ 1][threadIdx.x] = stage;
+    if (lo > seg_lo && threadIdx.x < REC_BATCH * REC4) recs[cur ^ 1][threadIdx.x] = stage;
     __syncthreads();
   }
 }
@@ -427,17 +577,20 @@ extern "C" int hgs_debug_set_wg_trace(void* device_buf_fwd, void* device_buf_bwd
   return 0;
 }
 
+// one workgroup per unsplit tile + one per segment of a split list (at most seg_cap of those; idle workgroups leave at once)
+static inline unsigned blend_grid(int T, const HgsBinning& b) { return (unsigned)T + b.seg_cap; }
+
 int hgs_launch_blend_fwd(hipStream_t s, int W, int H, int Rcap, int channels, const float* bg, const HgsImage& im,
                          const HgsBinning& b, float* out_color) {
   const int gx = (W + HGS_TILE - 1) / HGS_TILE, gy = (H + HGS_TILE - 1) / HGS_TILE;
   {
     HgsProfScope _prof(s, HGS_K_BLEND_FWD);
     if (channels == 3)
-      hipLaunchKernelGGL(blend_fwd_kernel<3>, dim3(gx * gy), dim3(HGS_BLOCK), 0, s, im.ranges, b.packed, W, H, gx,
-                         (uint32_t)Rcap, bg, im.final_T, im.n_contrib, im.tile_maxc, im.tile_order, out_color);
+      hipLaunchKernelGGL(blend_fwd_kernel<3>, dim3(blend_grid(gx * gy, b)), dim3(HGS_BLOCK), 0, s, im, b, W, H, gx,
+                         (uint32_t)Rcap, bg, out_color);
     else
-      hipLaunchKernelGGL(blend_fwd_kernel<7>, dim3(gx * gy), dim3(HGS_BLOCK), 0, s, im.ranges, b.packed, W, H, gx,
-                         (uint32_t)Rcap, bg, im.final_T, im.n_contrib, im.tile_maxc, im.tile_order, out_color);
+      hipLaunchKernelGGL(blend_fwd_kernel<7>, dim3(blend_grid(gx * gy, b)), dim3(HGS_BLOCK), 0, s, im, b, W, H, gx,
+                         (uint32_t)Rcap, bg, out_color);
   }
   HGS_CHECK_LAUNCH();
   return 0;
@@ -451,13 +604,13 @@ int hgs_launch_blend_bwd(hipStream_t s, int W, int H, int Rcap, int channels, co
     if (channels == 3) {
       PixGrad<3> pg;
       for (int k = 0; k < 3; k++) pg.plane[k] = dL_dpix_planes[k];
-      hipLaunchKernelGGL(blend_bwd_kernel<3>, dim3(gx * gy), dim3(HGS_BLOCK), 0, s, im.ranges, b.packed, W, H, gx,
-                         (uint32_t)Rcap, bg, im.final_T, im.n_contrib, im.tile_maxc, pg, im.tile_order, inst_grad);
+      hipLaunchKernelGGL(blend_bwd_kernel<3>, dim3(blend_grid(gx * gy, b)), dim3(HGS_BLOCK), 0, s, im, b, W, H, gx,
+                         (uint32_t)Rcap, bg, pg, inst_grad);
     } else {
       PixGrad<7> pg;
       for (int k = 0; k < 7; k++) pg.plane[k] = dL_dpix_planes[k];
-      hipLaunchKernelGGL(blend_bwd_kernel<7>, dim3(gx * gy), dim3(HGS_BLOCK), 0, s, im.ranges, b.packed, W, H, gx,
-                         (uint32_t)Rcap, bg, im.final_T, im.n_contrib, im.tile_maxc, pg, im.tile_order, inst_grad);
+      hipLaunchKernelGGL(blend_bwd_kernel<7>, dim3(blend_grid(gx * gy, b)), dim3(HGS_BLOCK), 0, s, im, b, W, H, gx,
+                         (uint32_t)Rcap, bg, pg, inst_grad);
     }
   }
   HGS_CHECK_LAUNCH();

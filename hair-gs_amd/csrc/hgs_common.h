@@ -3,8 +3,11 @@
 // Workspace layout (all sub-arrays 256-B aligned inside caller-owned byte buffers):
 //   geom    (per Gaussian)  depths, clamped, means2D, cov3D, conic_opacity, rgb, tiles_touched,
 //                           point_offsets, rect(+exclusive instance offset), block_sums
-//   image   (per pixel/tile) final_T, n_contrib, ranges, tile_count, tile_cursor, tile_maxc, status, tile_order
-//   binning (per instance)  keys (depth<<32|id<<4|quadrant mask), point_list, packed records, (reserved), sorted keys
+//   image   (per pixel/tile) final_T, n_contrib, ranges, tile_count, tile_cursor, tile_maxc, tile_done, status, tile_prog,
+//                           tile_sortprog, sort_items, tile_order
+//   binning (per instance)  keys (depth<<32|id<<4|quadrant mask), point_list, packed records, (reserved), sorted keys,
+//                           + per list SEGMENT (long tile lists are split across workgroups, see hgs_blend.hip):
+//                           seg_work, seg_P, seg_T, seg_Tout, seg_last, seg_C
 // They play the roles of GeometryState / ImageState / BinningState of the reference
 // (cuda_rasterizer/rasterizer_impl.h:23-71) but the layout is this library's own.
 #pragma once
@@ -31,10 +34,33 @@ struct HgsGeom {
 struct HgsImage {
   float* final_T; uint32_t* n_contrib; uint2* ranges; uint32_t* tile_count; uint32_t* tile_cursor;
   uint32_t* tile_maxc; uint32_t* status; uint32_t* tile_order;
+  // long tile lists (hgs_binning.hip / hgs_blend.hip): per-tile ticket of finished blend segments, bit masks of published
+  // blend segments / sorted chunks (bit 63: the list is handled by several workgroups), chunk work items of the sort
+  uint32_t* tile_done; unsigned long long* tile_prog; unsigned long long* tile_sortprog; uint32_t* sort_items;
 };
 struct HgsBinning {
   uint64_t* keys; uint32_t* point_list; float4* packed; uint32_t* inv; uint64_t* keys_sorted;
+  // per list segment of a split tile (index = the segment's position in seg_work), 256 pixels each:
+  uint32_t* seg_work;   // work items tile | segment << 24, a tile's segments consecutive
+  float* seg_P;         // transmittance product of the segment's entries (forward, phase 1)
+  float* seg_T;         // transmittance in front of the segment (kept for the backward)
+  float* seg_Tout;      // transmittance after the segment's walk, negative: the pixel stopped in it
+  uint32_t* seg_last;   // last contributing list position + 1 inside the segment (0: none)
+  float* seg_C;         // [C][256] colour added by the segment; after the tile's finalisation: by it and all behind it
+  uint32_t seg_cap;     // segments the arrays hold
 };
+
+// status words of the image buffer (HGS_IMG_STATUS)
+enum { HGS_ST_R = 0, HGS_ST_OVERFLOW = 1, HGS_ST_SCANPTR_LO = 2, HGS_ST_SCANPTR_HI = 3, HGS_ST_SORT_ITEMS = 4,
+       HGS_ST_SPLIT_ITEMS = 5, HGS_ST_TIMEOUT = 6, HGS_ST_SEG_LEN = 7, HGS_ST_UNSPLIT = 8 };
+#define HGS_SORT_CAP 2048        // keys one workgroup sorts in LDS (16 KB)
+#define HGS_MAX_PARTS 63         // chunks / segments of one tile list that cooperate (bits 0..62 of the progress masks)
+#define HGS_PART_FLAG (1ull << 63)
+#define HGS_ITEM_NONE 0xFFFFFFFFu
+#define HGS_ITEM_TILE(it) ((it) & 0xFFFFFFu)
+#define HGS_ITEM_PART(it) ((it) >> 24)
+#define HGS_MAX_TILES (1u << 24)
+static inline uint32_t hgs_seg_capacity(size_t R) { return R ? (uint32_t)(R / 128 + 2) : 0u; }
 
 static inline size_t hgs_align_up(size_t v) { return (v + HGS_ALIGN - 1) & ~(size_t)(HGS_ALIGN - 1); }
 
@@ -60,19 +86,24 @@ static inline size_t hgs_geom_carve(char* base, size_t P, HgsGeom& g, size_t* of
   hgs_carve(cur, g.block_sums, nblk + 1);   if (offs) offs[HGS_GEOM_BLOCK_SUMS] = (char*)g.block_sums - base;
   return hgs_align_up((size_t)(cur - base)) + HGS_ALIGN;
 }
+static inline size_t hgs_image_zero_words(size_t T) { return 4 * T + HGS_STATUS_WORDS + 4 * T; }
 static inline size_t hgs_image_carve(char* base, size_t W, size_t H, HgsImage& im, size_t* offs) {
   char* cur = base;
   size_t N = W * H, T = ((W + HGS_TILE - 1) / HGS_TILE) * ((H + HGS_TILE - 1) / HGS_TILE);
   hgs_carve(cur, im.final_T, N);            if (offs) offs[HGS_IMG_FINAL_T] = (char*)im.final_T - base;
   hgs_carve(cur, im.n_contrib, N);          if (offs) offs[HGS_IMG_N_CONTRIB] = (char*)im.n_contrib - base;
   hgs_carve(cur, im.ranges, T);             if (offs) offs[HGS_IMG_RANGES] = (char*)im.ranges - base;
-  // the next four are zeroed together by one memset in hgs_forward_preprocess
+  // the next seven are zeroed together by one fill in hgs_forward_preprocess (HGS_IMG_ZERO_WORDS)
   hgs_carve(cur, im.tile_count, T);         if (offs) offs[HGS_IMG_TILE_COUNT] = (char*)im.tile_count - base;
   im.tile_cursor = im.tile_count + T;       if (offs) offs[HGS_IMG_TILE_CURSOR] = (char*)im.tile_cursor - base;
   im.tile_maxc = im.tile_cursor + T;        if (offs) offs[HGS_IMG_TILE_MAXC] = (char*)im.tile_maxc - base;
-  im.status = im.tile_maxc + T;             if (offs) offs[HGS_IMG_STATUS] = (char*)im.status - base;
-  cur += (3 * T + HGS_STATUS_WORDS) * sizeof(uint32_t);
-  // tiles in descending order of list length: the blend kernels' workgroup -> tile map (written by scan_kernel)
+  im.tile_done = im.tile_maxc + T;
+  im.status = im.tile_done + T;             if (offs) offs[HGS_IMG_STATUS] = (char*)im.status - base;
+  im.tile_prog = (unsigned long long*)(im.status + HGS_STATUS_WORDS);   // 8-byte aligned: 4 T + 16 words past a 256-B boundary
+  im.tile_sortprog = im.tile_prog + T;
+  cur += hgs_image_zero_words(T) * sizeof(uint32_t);
+  hgs_carve(cur, im.sort_items, T);
+  // unsplit tiles in descending order of list length: the blend kernels' workgroup -> tile map (sort_tiles_kernel)
   hgs_carve(cur, im.tile_order, T);         if (offs) offs[HGS_IMG_TILE_ORDER] = (char*)im.tile_order - base;
   return hgs_align_up((size_t)(cur - base)) + HGS_ALIGN;
 }
@@ -83,6 +114,13 @@ static inline size_t hgs_binning_carve(char* base, size_t R, HgsBinning& b, size
   hgs_carve(cur, b.packed, R * (channels <= 3 ? HGS_PACKED_FLOATS / 4 : 4) + 4);  if (offs) offs[HGS_BIN_PACKED] = (char*)b.packed - base;
   hgs_carve(cur, b.inv, R);                                   if (offs) offs[HGS_BIN_INV] = (char*)b.inv - base;
   hgs_carve(cur, b.keys_sorted, R);                           if (offs) offs[HGS_BIN_KEYS_TMP] = (char*)b.keys_sorted - base;
+  b.seg_cap = hgs_seg_capacity(R);
+  hgs_carve(cur, b.seg_work, b.seg_cap);
+  hgs_carve(cur, b.seg_P, (size_t)b.seg_cap * 256);
+  hgs_carve(cur, b.seg_T, (size_t)b.seg_cap * 256);
+  hgs_carve(cur, b.seg_Tout, (size_t)b.seg_cap * 256);
+  hgs_carve(cur, b.seg_last, (size_t)b.seg_cap * 256);
+  hgs_carve(cur, b.seg_C, (size_t)b.seg_cap * 256 * (channels <= 3 ? 3 : 7));
   return hgs_align_up((size_t)(cur - base)) + HGS_ALIGN;
 }
 
@@ -207,13 +245,60 @@ struct HgsBwdArgs {
   float* dL_dextra;    // [P, n_extra]
 };
 int hgs_launch_preprocess_bwd(hipStream_t s, const HgsBwdArgs& a, const HgsGeom& g, const HgsBinning& b,
-                              const float* inst_grad, int Rcap);
+                              const float* inst_grad, int Rcap, const uint32_t* status);
 int hgs_launch_mark_visible(hipStream_t s, int P, const float* means3D, const float* viewmatrix, uint8_t* present);
 int hgs_launch_dist2(hipStream_t s, int P, const float* points, float* out, void* scratch, size_t scratch_bytes);
 size_t hgs_dist2_scratch(int P);
 
 // ---- device helpers ----------------------------------------------------------------------------
 #ifdef __HIPCC__
+// Agent-scope traffic between workgroups of ONE launch (the eight XCDs have private L2s): relaxed agent-scope atomic
+// loads / stores compile to sc1 accesses that go through to the memory side, no cache-wide write-back or invalidate.
+// A producer stores its data with hgs_st_agent, drains its stores (hgs_drain_stores + barrier) and then sets its bit in
+// the tile's progress mask; a consumer polls the mask (bounded: a timeout raises HGS_ST_TIMEOUT instead of hanging
+// the GPU) and reads with hgs_ld_agent.  Waiting is only ever on workgroups within HGS_MAX_PARTS positions of the
+// waiter in dispatch order, so the workgroups waited for are resident or finished.
+template <typename T> __device__ __forceinline__ void hgs_st_agent(T* p, T v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+template <typename T> __device__ __forceinline__ T hgs_ld_agent(const T* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void hgs_drain_stores() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ void hgs_publish_part(unsigned long long* mask, uint32_t part) {
+  __hip_atomic_fetch_or(mask, 1ull << part, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ bool hgs_wait_parts(const unsigned long long* mask, unsigned long long want, uint32_t* status) {
+  for (int spin = 0; spin < (1 << 21); spin++) {
+    if ((hgs_ld_agent(mask) & want) == want) return true;
+    __builtin_amdgcn_s_sleep(8);
+  }
+  status[HGS_ST_TIMEOUT] = 1u;
+  return false;
+}
+// segment length of the split blend for a pass with R instances: long lists are cut so that the pass has on the order
+// of 2048 segments, within [256, 1024] entries (multiples of the 64-entry staging batch)
+__device__ __forceinline__ uint32_t hgs_segment_length(uint32_t R) {
+  const uint32_t s = ((R / 2048u) + 63u) & ~63u;
+  return s < 256u ? 256u : (s > 1024u ? 1024u : s);
+}
+struct HgsSplit { uint32_t nseg, seglen; };   // nseg == 1: the list is walked by one workgroup
+__device__ __forceinline__ HgsSplit hgs_split_of(uint32_t n, uint32_t S) {
+  if (n <= S + S / 2) return {1u, n};
+  uint32_t seglen = S, nseg = (n + S - 1) / S;
+  if (nseg > HGS_MAX_PARTS) { seglen = (((n + HGS_MAX_PARTS - 1) / HGS_MAX_PARTS) + 63u) & ~63u; nseg = (n + seglen - 1) / seglen; }
+  return {nseg, seglen};
+}
+// chunk work items of a long list for the sort kernel (called where the tile counts are scanned)
+__device__ __forceinline__ void hgs_emit_sort_items(uint32_t tile, uint32_t n, uint32_t T, const HgsImage& im) {
+  if (n <= HGS_SORT_CAP) return;
+  const uint32_t nch = (n + HGS_SORT_CAP - 1) / HGS_SORT_CAP;
+  if (nch > HGS_MAX_PARTS) return;                       // the tile's own workgroup sorts it chunk after chunk
+  const uint32_t base = atomicAdd(&im.status[HGS_ST_SORT_ITEMS], nch);
+  const bool fits = base + nch <= T;
+  for (uint32_t c = 0; c < nch && base + c < T; c++) im.sort_items[base + c] = fits ? (tile | (c << 24)) : HGS_ITEM_NONE;
+  if (fits) im.tile_sortprog[tile] = HGS_PART_FLAG;
+}
 // float -> int with the hardware's saturating semantics made explicit (NaN -> 0).
 __device__ __forceinline__ int hgs_f2i(float v) {
   if (v != v) return 0;

@@ -272,8 +272,8 @@ __global__ __launch_bounds__(HGS_BLOCK) void preprocess_fwd_kernel(HgsFwdArgs a,
     g.rect[idx] = rc;
   }
   if (blockIdx.x == 0 && threadIdx.x == 0 && a.fused_scan_ptr) {   // (status words were cleared by the launch before this one)
-    im.status[2] = (uint32_t)a.fused_scan_ptr;
-    im.status[3] = (uint32_t)(a.fused_scan_ptr >> 32);
+    im.status[HGS_ST_SCANPTR_LO] = (uint32_t)a.fused_scan_ptr;
+    im.status[HGS_ST_SCANPTR_HI] = (uint32_t)(a.fused_scan_ptr >> 32);
   }
   const uint32_t bs = block_sum_256(ntiles, red);   // (its barriers also order the table updates above)
   if (threadIdx.x == 0) g.block_sums[blockIdx.x] = bs;
@@ -298,7 +298,7 @@ __global__ __launch_bounds__(HGS_BLOCK) void scatter_kernel(int P, int gx, int T
   th_init(th);
   const int idx = blockIdx.x * HGS_BLOCK + threadIdx.x;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const unsigned long long report = ((unsigned long long)im.status[3] << 32) | im.status[2];
+  const unsigned long long report = ((unsigned long long)im.status[HGS_ST_SCANPTR_HI] << 32) | im.status[HGS_ST_SCANPTR_LO];
   const bool fused = report != 0ull;
   // every global load the prologue needs is issued before anything waits: tile counts (coalesced, up to
   // HGS_FUSED_SCAN_MAX_T / 256 per thread), the raw block sums before this workgroup, this lane's Gaussian
@@ -339,11 +339,14 @@ __global__ __launch_bounds__(HGS_BLOCK) void scatter_kernel(int P, int gx, int T
       if (i0 + k < T) {
         const uint32_t v = tile_off[at(i0 + k)];
         tile_off[at(i0 + k)] = run;
-        if (blockIdx.x == 0) im.ranges[i0 + k] = v ? make_uint2(run, run + v) : make_uint2(0u, 0u);
+        if (blockIdx.x == 0) {
+          im.ranges[i0 + k] = v ? make_uint2(run, run + v) : make_uint2(0u, 0u);
+          hgs_emit_sort_items((uint32_t)(i0 + k), v, (uint32_t)T, im);   // long lists: one sort workgroup per chunk
+        }
         run += v;
       }
     if (blockIdx.x == 0 && threadIdx.x == 0) {
-      im.status[0] = total;
+      im.status[HGS_ST_R] = total;
       atomicMax((unsigned int*)report, total);   // sticky maximum for graph replays (hgs.h)
     }
     __syncthreads();                                 // wsum is reused
@@ -391,7 +394,7 @@ __global__ __launch_bounds__(HGS_BLOCK) void scatter_kernel(int P, int gx, int T
       const uint32_t pos = (fused ? tile_off[t + (t >> 5)] : im.ranges[t].x) + (sl >= 0 ? th.base[sl] + atomicAdd(&th.cnt[sl], 1u)
                                                      : atomicAdd(&im.tile_cursor[t], 1u));
       if (pos < Rcap) b.keys[pos] = key;
-      else im.status[1] = 1;  // overflow: caller under-sized the binning buffer
+      else im.status[HGS_ST_OVERFLOW] = 1;  // overflow: caller under-sized the binning buffer
     }
 }
 
@@ -407,9 +410,14 @@ __device__ __forceinline__ V3 dnormvdv(V3 v, V3 dv) {  // auxiliary.h:107-117
 }
 
 __global__ __launch_bounds__(HGS_BLOCK) void preprocess_bwd_kernel(HgsBwdArgs a, HgsGeom g, HgsBinning b,
-                                                                   const float* __restrict__ inst_grad, uint32_t Rcap) {
+                                                                   const float* __restrict__ inst_grad, uint32_t Rcap,
+                                                                   const uint32_t* __restrict__ status) {
   const int idx = blockIdx.x * HGS_BLOCK + threadIdx.x;
   if (idx >= a.P) return;
+  // A forward that overflowed its binning capacity (status[1]) dropped instances: their rows of the scratch were never
+  // written.  Such a pass is void; its backward returns EXACTLY ZERO for every gradient (deterministic, finite) and the
+  // caller repeats the step with a larger capacity (include/hgs.h).
+  const bool void_pass = status[HGS_ST_OVERFLOW] != 0u;
   const int M = a.M;
   float dmx = 0.f, dmy = 0.f, dcx = 0.f, dcy = 0.f, dcw = 0.f, dop = 0.f, dcol[3] = {0.f, 0.f, 0.f};
   float dex[4] = {0.f, 0.f, 0.f, 0.f}, dmx_rgb = 0.f, dmy_rgb = 0.f;
@@ -417,7 +425,7 @@ __global__ __launch_bounds__(HGS_BLOCK) void preprocess_bwd_kernel(HgsBwdArgs a,
   float dscale[3] = {0.f, 0.f, 0.f}, drot[4] = {0.f, 0.f, 0.f, 0.f};
   // this Gaussian's own data: every load issued here, before the row loop below (whose data-dependent trip count the
   // compiler will not move loads across): one memory round trip for all of it instead of one per dependent stage
-  const bool vis = a.radii[idx] > 0;
+  const bool vis = a.radii[idx] > 0 && !void_pass;
   const HgsRect rc_pre = g.rect[idx];
   const uint32_t n_pre = g.tiles_touched[idx];
   const float4 co_pre = g.conic_opacity[idx];
@@ -688,11 +696,11 @@ int hgs_launch_scatter(hipStream_t s, int P, int W, int H, int Rcap, const int* 
   return 0;
 }
 int hgs_launch_preprocess_bwd(hipStream_t s, const HgsBwdArgs& a, const HgsGeom& g, const HgsBinning& b,
-                              const float* inst_grad, int Rcap) {
+                              const float* inst_grad, int Rcap, const uint32_t* status) {
   const int nblk = (a.P + HGS_BLOCK - 1) / HGS_BLOCK;
   {
     HgsProfScope _prof(s, HGS_K_PREPROCESS_BWD);
-    hipLaunchKernelGGL(preprocess_bwd_kernel, dim3(nblk), dim3(HGS_BLOCK), 0, s, a, g, b, inst_grad, (uint32_t)Rcap);
+    hipLaunchKernelGGL(preprocess_bwd_kernel, dim3(nblk), dim3(HGS_BLOCK), 0, s, a, g, b, inst_grad, (uint32_t)Rcap, status);
   }
   HGS_CHECK_LAUNCH();
   return 0;

@@ -230,4 +230,8 @@ class FusedAdam(torch.optim.Optimizer):
         with torch.cuda.device(rows[0][0].device):
             rt.check(rt.lib().hgs_adam_step(rt.current_stream(), n, arrs[0], arrs[1], arrs[2], arrs[3], arrs[4], arrs[5],
                                             numel, float(beta1), float(beta2), float(eps)))
+        # the kernel wrote the parameters through raw pointers: tell autograd (and every cache keyed on tensor versions,
+        # e.g. HairGaussianModel._derived) that they changed in place
+        for r in rows:
+            torch.autograd.graph.increment_version(r[0])
         return None

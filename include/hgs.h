@@ -357,8 +357,10 @@ int hgs_geom_layout(int P, size_t* offsets /* [HGS_GEOM_NFIELDS] */);
 int hgs_image_layout(int W, int H, size_t* offsets /* [HGS_IMG_NFIELDS] */);
 int hgs_binning_layout(int R, size_t* offsets /* [HGS_BIN_NFIELDS] */);
 
-/* status words written by the kernels into image_buf (HGS_IMG_STATUS): [0]=num_rendered, [1]=overflow flag */
-#define HGS_STATUS_WORDS 4
+/* status words written by the kernels into image_buf (HGS_IMG_STATUS): [0]=num_rendered, [1]=overflow flag (the pass
+ * dropped instances: its image is incomplete and its backward returns exactly zero gradients), [6]=a cooperative wait
+ * between workgroups timed out (never expected; results of that pass are invalid); the others are internal */
+#define HGS_STATUS_WORDS 16
 /* floats per packed instance record in HGS_BIN_PACKED, 3-channel mode: x,y, conic a,b,c, opacity, r,g,b, id, quadrant
  * mask, pad (the 7-channel mode uses 16: ..., 7 features, id, quadrant mask, pad) */
 #define HGS_PACKED_FLOATS 12

@@ -1,5 +1,7 @@
-"""Builds the one piece of the reference that compiles from its own sources with the image's
-toolchain: c_utils/c_utils.pyx (Cython -> C -> gcc), the CPU helper on the Stage-III loss path.
+"""Builds the pieces of the reference that compile from its own sources with the image's toolchain:
+  * c_utils/c_utils.pyx (Cython -> C -> gcc), the CPU helper on the Stage-III loss path;
+  * the header-only glm the rasterizer vendors (DGR/third_party/glm), through oracle/glm_probe.cpp: a probe of
+    glm's mat3 operator* / transpose, the operand order every bit-exact key of the rasterizer depends on.
 
 Runs ONLY in the authoring container (needs /root/reference).  Output goes to oracle/_ref/
 (git-ignored, travels to the GPU box as a built artefact).  No reference source is copied: the
@@ -42,6 +44,22 @@ def build():
         shutil.rmtree(tmp, ignore_errors=True)
 
 
+GLM_INC = "/root/reference/submodules/diff-gaussian-rasterization/third_party/glm"
+GLM_SO = os.path.join(OUT, "libglm_probe.so")
+
+
+def build_glm_probe():
+    """g++ on oracle/glm_probe.cpp with the reference's vendored glm on the include path (plain g++, no stand-ins)."""
+    if not os.path.exists(os.path.join(GLM_INC, "glm", "glm.hpp")):
+        return None
+    os.makedirs(OUT, exist_ok=True)
+    src = os.path.join(os.path.dirname(os.path.abspath(__file__)), "glm_probe.cpp")
+    if os.path.exists(GLM_SO) and os.path.getmtime(GLM_SO) >= os.path.getmtime(src):
+        return GLM_SO
+    subprocess.check_call(["g++", "-O0", "-ffp-contract=off", "-fPIC", "-shared", "-w", "-I" + GLM_INC, src, "-o", GLM_SO])
+    return GLM_SO
+
+
 def load():
     """Import the built reference module (None if it was never built)."""
     so = glob.glob(os.path.join(OUT, "c_utils*.so"))
@@ -56,3 +74,4 @@ def load():
 
 if __name__ == "__main__":
     print(build())
+    print(build_glm_probe())

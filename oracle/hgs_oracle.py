@@ -130,10 +130,11 @@ def backward(inp, fwd, dL_dpix, f64=False):
     dpix = _arr(dL_dpix, dt, (3, H, W))
     feats = n["colors_precomp"] if n["colors_precomp"] is not None else fwd["rgb"]
     acc = np.zeros((P, 9), np.float64)
+    fragile = np.zeros(P, np.uint8)   # Gaussians with a near-threshold (pixel, entry) decision (raster_oracle.c)
     getattr(L, "hgs_oracle_render_backward" + sfx)(C.c_int(P), C.c_int(W), C.c_int(H), _p(fwd["ranges"]),
                                                    _p(fwd["point_list"]), _p(n["bg"]), _p(fwd["means2D"]),
                                                    _p(fwd["conic_opacity"]), _p(feats), _p(fwd["final_T"]),
-                                                   _p(fwd["n_contrib"]), _p(dpix), _p(acc))
+                                                   _p(fwd["n_contrib"]), _p(dpix), _p(acc), _p(fragile))
     g = {
         "dL_dmeans2D": np.zeros((P, 3), dt), "dL_dconic": np.zeros((P, 4), dt), "dL_dopacity": np.zeros((P, 1), dt),
         "dL_dcolors": np.zeros((P, 3), dt), "dL_dmeans3D": np.zeros((P, 3), dt), "dL_dcov3D": np.zeros((P, 6), dt),
@@ -153,6 +154,7 @@ def backward(inp, fwd, dL_dpix, f64=False):
         cr(n["tanfovy"]), _p(n["campos"]), _p(g["dL_dmeans2D"]), _p(g["dL_dconic"]), _p(g["dL_dmeans3D"]),
         _p(g["dL_dcolors"]), _p(g["dL_dcov3D"]), _p(g["dL_dsh"]), _p(g["dL_dscales"]), _p(g["dL_drotations"]))
     g["acc"] = acc
+    g["fragile"] = fragile.astype(bool)
     return g
 
 

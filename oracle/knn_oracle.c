@@ -4,7 +4,7 @@
  *
  * TEST INFRASTRUCTURE ONLY (see raster_oracle.c header).  "Parity unpinned": the reference
  * ships no test or golden vector for this function and its CUDA source cannot be built here;
- * the independent pin is a brute-force O(P^2) 3-NN (tests/test_oracle_knn.py) -- the box
+ * the independent pin is a brute-force O(P^2) 3-NN (tests/test_oracle_checks.py) -- the box
  * pruning of the reference is exact, so both must agree to the last bit of the fp32 distances.
  *
  * Follows /root/reference/submodules/simple-knn/simple_knn.cu (SK/) line by line:

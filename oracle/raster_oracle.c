@@ -10,8 +10,12 @@
  * vectors for this path.  What IS pinned against the reference itself: SH colour evaluation
  * (utils/sh.py::eval_sh) and the camera matrices (utils/graphics.py), through
  * tests/golden/ref_python_pins.npz (generator: tests/golden/make_ref_python_pins.py).
- * Independent cross-checks: fp64 build of this file + central finite differences, and a
- * pure-torch autograd restatement (tests/torch_restatement.py).
+ * glm's mat3 operator* / transpose operand order (what every bit-exact key depends on) is pinned
+ * against the reference's vendored glm itself: oracle/build_ref.py compiles a small TU against
+ * DGR/third_party/glm into oracle/_ref/, tests/golden/make_glm_pins.py records its outputs and
+ * tests/test_oracle_pins.py asserts mat3_mul / mat3_tr / the computeCov3D and cov2D chains bit for bit.
+ * Independent cross-checks: fp64 build of this file + central finite differences
+ * (tests/test_oracle_checks.py).
  *
  * Each function cites the reference lines it follows.  Paths are relative to
  * /root/reference/submodules/diff-gaussian-rasterization/cuda_rasterizer/ (CR/).
@@ -88,6 +92,35 @@ static mat3 mat3_tr(mat3 A) {
   for (int c = 0; c < 3; c++)
     for (int w = 0; w < 3; w++) r.m[c][w] = A.m[w][c];
   return r;
+}
+
+/* Exports for the glm pin (tests/test_oracle_pins.py): the two helpers above and the two chains the rasterizer builds
+ * from them, on 9 floats in glm memory order (m[col][row]). */
+void SYM(hgs_oracle_mat3_mul)(const real* a, const real* b, real* out) {
+  mat3 A, B;
+  memcpy(A.m, a, sizeof(A.m));
+  memcpy(B.m, b, sizeof(B.m));
+  mat3 r = mat3_mul(A, B);
+  memcpy(out, r.m, sizeof(r.m));
+}
+void SYM(hgs_oracle_mat3_tr)(const real* a, real* out) {
+  mat3 A;
+  memcpy(A.m, a, sizeof(A.m));
+  mat3 r = mat3_tr(A);
+  memcpy(out, r.m, sizeof(r.m));
+}
+void SYM(hgs_oracle_mat3_gram)(const real* m, real* out) { /* Sigma = transpose(M) * M, CR/forward.cu:143 */
+  mat3 M;
+  memcpy(M.m, m, sizeof(M.m));
+  mat3 r = mat3_mul(mat3_tr(M), M);
+  memcpy(out, r.m, sizeof(r.m));
+}
+void SYM(hgs_oracle_mat3_sandwich)(const real* t, const real* v, real* out) { /* CR/forward.cu:108 */
+  mat3 T, V;
+  memcpy(T.m, t, sizeof(T.m));
+  memcpy(V.m, v, sizeof(V.m));
+  mat3 r = mat3_mul(mat3_mul(mat3_tr(T), mat3_tr(V)), T);
+  memcpy(out, r.m, sizeof(r.m));
 }
 
 /* CR/auxiliary.h:58-66 */
@@ -394,7 +427,8 @@ void SYM(hgs_oracle_render)(int W, int H, const uint32_t* ranges, const uint32_t
 void SYM(hgs_oracle_render_backward)(int P, int W, int H, const uint32_t* ranges, const uint32_t* point_list,
                                      const real* bg, const real* means2D, const real* conic_opacity, const real* colors,
                                      const real* final_Ts, const uint32_t* n_contrib, const real* dL_dpixels,
-                                     double* acc /* [P][9], zeroed here */) {
+                                     double* acc /* [P][9], zeroed here */,
+                                     uint8_t* fragile /* [P] or NULL: see below */) {
   const int gx = (W + BLOCK_X - 1) / BLOCK_X, gy = (H + BLOCK_Y - 1) / BLOCK_Y;
   memset(acc, 0, (size_t)P * 9 * sizeof(double));
   const real ddelx_dx = (real)(0.5 * W), ddely_dy = (real)(0.5 * H);
@@ -422,9 +456,18 @@ void SYM(hgs_oracle_render_backward)(int P, int W, int H, const uint32_t* ranges
           real dx = means2D[2 * id] - pixf[0], dy = means2D[2 * id + 1] - pixf[1];
           const real* co = conic_opacity + 4 * (size_t)id;
           real power = (real)-0.5 * (co[0] * dx * dx + co[2] * dy * dy) - co[1] * dx * dy;
-          if (power > 0) continue;
+          if (power > 0) {
+            if (fragile && (double)power < 1e-5) fragile[id] = 1;
+            continue;
+          }
           real G = R_EXP(power);
           real alpha = rmin((real)0.99, co[3] * G);
+          /* Checker aid (not part of the reference): a Gaussian is marked fragile when one of its (pixel, entry)
+           * decisions sits within 1e-4 relative of the alpha >= 1/255 threshold or within 1e-5 of power > 0 -- an
+           * implementation whose exp differs by an ulp may branch the other way there (the CUDA reference against
+           * any CPU code has the same property).  Tests bound the number of such Gaussians and hold every other
+           * one to the tolerance. */
+          if (fragile && (fabs((double)alpha * 255.0 - 1.0) < 1e-4 || fabs((double)power) < 1e-5)) fragile[id] = 1;
           if (alpha < (real)1.0 / (real)255.0) continue;
           T = T / ((real)1.0 - alpha);
           real dchannel_dcolor = alpha * T;
