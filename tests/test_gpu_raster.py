@@ -174,23 +174,38 @@ def test_blend_work_list_covers_every_tile_once(name):
 GRAD_KEYS = ("dL_dmeans2D", "dL_dconic", "dL_dopacity", "dL_dcolors", "dL_dmeans3D", "dL_dcov3D", "dL_dsh", "dL_dscales",
              "dL_drotations")
 # Gradient bar (BASELINE.json north_star: "per-param grads within 1e-4 rel fp32"), enforced on EVERY element:
-#   |got - ref| <= 5e-5 x max|ref tensor|       for every Gaussian the oracle does not mark fragile
+#   |got - ref| <= 1e-4 x max|ref tensor|       for every Gaussian the oracle does not mark fragile (measured: 1e-5 at
+#       north_star, 6e-5 at C4 -- thin strands make `power` a difference of large terms, and the blend kernels contract
+#       it into FMAs like nvcc does for the reference while the oracle rounds every operation)
 #   |got - ref| <= 1e-4 x max(|ref|, 1e-2 x max|ref tensor|)  on all but NOISE_FRAC of the elements (the oracle sums in
 #       double, the GPU in fp32: an element that cancels to ~0 sits at the fp32 noise of its terms, not at 1e-4 of itself)
 # Fragile Gaussians (oracle/raster_oracle.c: a (pixel, entry) decision within 1e-4 of the alpha >= 1/255 threshold or
-# 1e-5 of power > 0, where v_exp_f32 and libm expf may branch differently) are enumerated: their number is bounded and
-# their error too (one pixel's alpha ~ 1/255 contribution).
-GRAD_MAX_OF_SCALE = 5e-5
+# 1e-5 of power > 0, where v_exp_f32 and libm expf may branch differently) are enumerated.  Their number is bounded by
+# what the geometry predicts -- the pixels of a Gaussian whose power lies in a window of width dp cover an area of
+# 2 pi sqrt(det cov2D) dp (uniform in power), so a Gaussian is fragile with probability ~ min(1, 2 pi dp / sqrt(det
+# conic)) per view -- and their error is bounded too (single pixels with alpha ~ 1/255).
+GRAD_MAX_OF_SCALE = 1e-4
 GRAD_NOISE_FRAC = 2e-3
 FRAGILE_MAX_OF_SCALE = 2e-2
 
 
-def _grad_check(g, gref, skip=()):
+def _expected_fragile(fwd_ref):
+    """Expected number of Gaussians with a pixel inside the oracle's threshold windows (see above), from the preprocessed
+    2D state: visible, opacity above 1/255, ring area 2 pi sqrt(det cov2D) x (2e-4 + 1e-5)."""
+    co = fwd_ref["conic_opacity"].astype(np.float64)
+    vis = (fwd_ref["radii"] > 0) & (co[:, 3] > 1.0 / 255.0)
+    det = co[vis, 0] * co[vis, 2] - co[vis, 1] ** 2
+    ring = 2.0 * np.pi / np.sqrt(np.maximum(det, 1e-30)) * 2.1e-4
+    return float(np.minimum(1.0, ring).sum())
+
+
+def _grad_check(g, gref, fwd_ref, skip=()):
     """Asserts the gradient bar above for every tensor; returns {name: (max error / tensor scale, fraction outside the
     element-wise tolerance, fragile Gaussians)} for the log."""
     fragile = gref["fragile"]
     P = fragile.shape[0]
-    assert int(fragile.sum()) <= max(4, P // 500), f"{int(fragile.sum())} of {P} Gaussians near a blend threshold"
+    expected = _expected_fragile(fwd_ref)
+    assert int(fragile.sum()) <= 3.0 * expected + 8, f"{int(fragile.sum())} of {P} Gaussians near a blend threshold, {expected:.1f} expected"
     report = {}
     for k in GRAD_KEYS:
         if k in skip or gref[k].size == 0:
@@ -226,7 +241,7 @@ def test_backward_matches_oracle(name):
     ref_state["final_T"] = got["final_T"].copy()
     gref = O.backward(s, ref_state, dpix)
     g = G.run_backward(s, fw, dpix)
-    _grad_check(g, gref)
+    _grad_check(g, gref, ref)
     # culled Gaussians receive exactly zero everywhere (trap 4)
     inv = ref["radii"] == 0
     for k in ("dL_dmeans3D", "dL_dscales", "dL_drotations", "dL_dopacity", "dL_dcolors"):
@@ -443,5 +458,5 @@ def test_full_size_forward_and_backward_against_oracle(workload):
     dpix = np.random.default_rng(9).normal(size=(3, s["H"], s["W"])).astype(np.float32)
     gref = O.backward(s, ref, dpix)
     g = G.run_backward(s, fw, dpix)
-    report = _grad_check(g, gref, skip=("dL_dcov3D",))
+    report = _grad_check(g, gref, ref, skip=("dL_dcov3D",))
     print(workload, {k: (f"{v[0]:.1e}", f"{v[1]:.1e}", v[2]) for k, v in report.items()})
