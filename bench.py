@@ -1,23 +1,39 @@
 #!/usr/bin/env python3
 """bench.py -- headline benchmark: strand-Gaussian training iterations per second (+ forward render ms/view).
 
-  python bench.py --gpus N --steps K --warmup W [--workload north_star|c2|c3|c4|c5|tiny]
+  python bench.py --gpus N --steps K --warmup W [--workload north_star|c2|c3|c4|c5|tiny] [--scaling weak|strong]
 
 One *train iteration* is the reference's (train.py:133-204): lr update, ONE camera view, render + 2 more raster
 passes inside the losses (mask, orientation), backward through all three, densification statistics, Adam step.
-With N GPUs (one process per GPU, launched by torch.distributed.run) every rank trains a different view of the same
-optimizer step; gradients are all-reduced over RCCL before Adam (hair-gs_amd/train.py).  `value` = whole-job train
-iterations (views) per second = N x optimizer steps / s; per-GPU work is fixed, so scaling is "weak".
+With N GPUs (one process per GPU, launched by torch.distributed.run, backend nccl = RCCL over xGMI) the views of an
+optimizer step are shared between the ranks and the gradients all-reduced before Adam (hair-gs_amd/train.py):
+  --scaling weak   (default) every rank trains ONE view per step: N views per optimizer step, per-GPU work fixed;
+  --scaling strong SURVEY.md 8e's protocol: a FIXED global batch of --global-views V (default 8) views per optimizer
+                   step, rank r renders views r, r+N, ... and sums their gradients inside its captured graph; one GPU
+                   renders all V sequentially.  Total work is fixed, so the N-GPU speed-up is read off `value` directly.
+`value` = whole-job train iterations (views) per second in both modes.
 
 Default workload = BASELINE.json north_star: synthetic 100k strand-Gaussians (1000 strands x 100 segments), 1080p,
 32 views.  Data is synthetic (SURVEY.md 8d generators), parameters random-init: there is no dataset offline.
 
+Timing: W untimed warm-up steps, then the region of EXACTLY K steps (barrier + synchronize on both sides, maximum over
+the ranks) is timed --repeats times back to back; `value` / `ms_per_step` are the MEDIAN region, `repeats` holds
+min / median / max.  A `sustained` leg then replays steps for >= --sustained-seconds (default 2 s) in one region, long
+enough for an SMI sampler to see the GPU busy, and reports its own rate.
+
 The JSON line also carries
-  roofline      blend_bwd_kernel (the dominant kernel): algorithmic bytes (76 B x sum_tiles L_t +
-                20 B x W*H + 8 B x T per launch) / mean launch duration measured with HIP events on the launch
-                stream inside the timed region; peak = 8 TB/s HBM3E.
-  cpu_baseline  the CPU oracle (oracle/, OpenMP C restatement of the reference rasterizer) doing the 3 raster
-                fwd+bwd passes of one iteration on the host cores (rank 0, N=1 only, bounded sample).
+  roofline      blend_bwd_kernel (the dominant kernel): algorithmic bytes (SURVEY.md 8d formula generalised to the
+                7-channel single pass: (64 + 60) B x sum_tiles L_t + 36 B x W*H + 8 B x T per launch) / mean launch
+                duration.  The duration is measured in THIS run with HIP events on the launch stream around every launch
+                of the kernel, in an EAGER continuation of the same steps right after the timed regions (events cannot
+                bracket the nodes of a replayed graph); peak = 8 TB/s HBM3E.  `traffic` is not measurable from inside
+                the process: it is the HBM byte count of the committed rocprofv3 --pmc passes of the same workload
+                (`traffic_source` names the file), per launch.
+  cpu_baseline  the CPU oracle (oracle/, OpenMP C restatement of the reference rasterizer) doing the 3 raster fwd+bwd
+                passes of one iteration on the host cores, plus -- `cpu_only_paths` -- the reference's CPU-only paths
+                timed in the same run on the same cores: c_utils.filter_strand_list_segments (this package's native
+                module, and the reference's own Cython build when oracle/_ref/ holds it) and the strand metrics of
+                eval.py (loss/metrics.py compute_metrics).  Rank 0, N=1 only, bounded samples.
 """
 import argparse
 import json
@@ -40,6 +56,10 @@ def parse():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="north_star")
     ap.add_argument("--views", type=int, default=None, help="override the number of camera views")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
+    ap.add_argument("--global-views", type=int, default=8, help="views per optimizer step of the strong-scaling protocol")
+    ap.add_argument("--repeats", type=int, default=5, help="how many times the K-step region is timed")
+    ap.add_argument("--sustained-seconds", type=float, default=2.0, help="length of the sustained leg (0: skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true", help="disable per-kernel HIP-event timing")
     ap.add_argument("--three-pass", action="store_true",
@@ -74,6 +94,52 @@ def cpu_baseline(model, cam, threads):
         O.backward(s, f, dpix)
     dt = time.perf_counter() - t0
     return dt
+
+
+def cpu_only_paths():
+    """The reference's CPU-only paths on bounded samples: the strand-segment filter of the smoothness
+    loss (c_utils/c_utils.pyx:83-127) and the strand metrics of eval.py (loss/metrics.py:88-173)."""
+    import numpy as np
+    import c_utils
+    from loss.metrics import HairEvalData, compute_metrics
+    from synthetic import strand_polylines
+    out = {}
+    rng = np.random.default_rng(0)
+    S = 2000
+    strands = np.empty(S, object)
+    for j in range(S):
+        strands[j] = rng.integers(0, 10 ** 6, (101, 2)).astype(np.int64)
+
+    def med(f, n=9):
+        ts = []
+        for _ in range(n):
+            t = time.perf_counter()
+            f()
+            ts.append(time.perf_counter() - t)
+        return sorted(ts)[n // 2]
+    out["filter_strand_list_segments_ms"] = med(lambda: c_utils.filter_strand_list_segments(strands)) * 1e3
+    out["filter_strand_list_segments_sample"] = f"{S} strands x 100 segments, 1 core (native CPython extension)"
+    try:
+        from oracle import build_ref
+        ref = build_ref.load()
+        if ref is not None:
+            out["filter_strand_list_segments_reference_cython_ms"] = med(lambda: ref.filter_strand_list_segments(strands)) * 1e3
+    except Exception as e:
+        out["reference_cython_error"] = str(e)
+    n_str = 500
+    sp = strand_polylines(n_str, 100, seed=0)
+    mid = 0.5 * (sp[:, 1:] + sp[:, :-1]).reshape(-1, 3)
+    d = (sp[:, 1:] - sp[:, :-1]).reshape(-1, 3)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    sid = np.repeat(np.arange(n_str), 100)
+    gt = HairEvalData(mid.astype(np.float64), d.astype(np.float64), sid)
+    pred = HairEvalData(mid + rng.normal(size=mid.shape) * 1e-3, d.astype(np.float64), sid)
+    t = time.perf_counter()
+    res, _ = compute_metrics(pred, gt, bidirectional=True)
+    out["compute_metrics_s"] = time.perf_counter() - t
+    out["compute_metrics_sample"] = f"{mid.shape[0]} predicted vs {mid.shape[0]} ground-truth oriented points, 4 threshold pairs"
+    out["compute_metrics_f1"] = [float(x) for x in res["f1(b)"]]
+    return out
 
 
 def main():
@@ -126,6 +192,15 @@ def main():
 
     from train import GraphedStep, fused_step_applicable
     use_graph = not (args.eager or args.blocking)
+    strong = args.scaling == "strong"
+    views_per_rank = 1
+    if strong:
+        if not use_graph:
+            raise SystemExit("--scaling strong needs the captured step (no --eager / --blocking)")
+        if args.global_views % world:
+            raise SystemExit(f"--global-views {args.global_views} does not divide over {world} ranks")
+        views_per_rank = args.global_views // world
+    views_per_step = views_per_rank * world if strong else world      # views of ONE optimizer step, whole job
     it = 0
     views = fused = None
     if fused_step_applicable(model, opt):
@@ -135,46 +210,61 @@ def main():
     if use_graph:
         # the whole iteration is captured once into a HIP graph and replayed (train.GraphedStep); the W warm-up steps
         # and the K timed steps are real optimizer steps on successive random views, exactly like the eager loop
-        gs = GraphedStep(model, cams, opt, bg, extent=extent, vp=vp, views=views)
+        gs = GraphedStep(model, cams, opt, bg, extent=extent, vp=vp, views=views, views_per_step=views_per_rank)
         gs.capture(cams, iteration=1)
 
         def one_step():
             nonlocal it
             it += 1
-            gs.step(sampler.next(), it)
+            gs.step(sampler.next_batch(args.global_views) if views_per_rank > 1 else sampler.next(), it)
     else:
         def one_step():
             nonlocal it
             it += 1
             training_step(model, sampler.next(), opt, bg, it, extent=extent, vp=vp, fused=fused)
+
+    def timed_region(n_steps):
+        """EXACTLY n_steps optimizer steps between two barrier + synchronize pairs; seconds, maximum over the ranks."""
+        sync_all()
+        t0 = time.perf_counter()
+        for _ in range(n_steps):
+            one_step()
+        sync_all()
+        t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+        if world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
     for _ in range(args.warmup):
         one_step()
-    sync_all()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        one_step()
-    sync_all()
-    dt = time.perf_counter() - t0
+    regions = sorted(timed_region(args.steps) for _ in range(max(1, args.repeats)))
+    dt = regions[len(regions) // 2]
+    sustained = None
+    if args.sustained_seconds > 0:
+        n_sus = max(args.steps, int(args.sustained_seconds / (dt / args.steps)) + 1)
+        if world > 1:   # (every rank must run the same number of steps)
+            n = torch.tensor([n_sus], dtype=torch.int64, device=dev)
+            dist.all_reduce(n, op=dist.ReduceOp.MAX)
+            n_sus = int(n.item())
+        t_sus = timed_region(n_sus)
+        sustained = {"steps": n_sus, "seconds": t_sus, "iters_per_sec": views_per_step * n_sus / t_sus}
     if use_graph:
         gs.check()  # instance counts of the captured passes stayed within capacity
-    # per-kernel device time: HIP events cannot bracket individual nodes of a replayed graph, so the same K steps are
-    # continued with eager dispatch and every library launch bracketed by events on its stream (hgs_prof_*)
+    # per-kernel device time: HIP events cannot bracket individual nodes of a replayed graph, so the same steps are
+    # CONTINUED with eager dispatch after the timed regions and every library launch is bracketed by events on its
+    # stream (hgs_prof_*): the figures are per launch, one view per eager step
     kern = {}
     if not args.no_kernel_timing:
         sync_all()
         rt.prof_collect()
         rt.prof_enable(True)
-        for _ in range(min(args.steps, 50)):
+        kern_steps = min(args.steps, 50)
+        for _ in range(kern_steps):
             it += 1
             training_step(model, sampler.next(), opt, bg, it, extent=extent, vp=vp, fused=fused)
         sync_all()
         kern = rt.prof_collect()
         rt.prof_enable(False)
-        kern_steps = min(args.steps, 50)
-    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
-    if world > 1:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    dt = float(tmax.item())
 
     # ---- forward-only render ms/view (SURVEY.md 3b), all views, after 3 warm-ups
     raster.check_async()
@@ -224,12 +314,21 @@ def main():
     T = ((W + 15) // 16) * ((H + 15) // 16)
     P = model.get_xyz.shape[0]
     result = {
-        "metric": "train_iters_per_sec", "value": world * args.steps / dt, "unit": "iters/s", "n_gpus": world,
+        "metric": "train_iters_per_sec", "value": views_per_step * args.steps / dt, "unit": "iters/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt * 1e3 / args.steps, "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"{args.workload}: {P} strand-Gaussians, {len(cams)} views @ {W}x{H}, 1 view/GPU/step, "
+        "scaling": args.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "repeats": {"n": len(regions), "min_iters_per_sec": views_per_step * args.steps / regions[-1],
+                    "median_iters_per_sec": views_per_step * args.steps / dt,
+                    "max_iters_per_sec": views_per_step * args.steps / regions[0]},
+        "sustained": sustained,
+        "sustained_iters_per_sec": None if sustained is None else sustained["iters_per_sec"],
+        "n_ranks_seen": dist.get_world_size() if world > 1 else 1,
+        "collective_backend": (dist.get_backend() + (" (RCCL)" if dist.get_backend() == "nccl" else "")) if world > 1 else None,
+        "config": {"workload": f"{args.workload}: {P} strand-Gaussians, {len(cams)} views @ {W}x{H}, "
+                               f"{views_per_rank} view(s)/GPU/optimizer step ({views_per_step} views/step), "
                                "RGB+mask+orientation raster fwd+bwd + L1/DSSIM/mask/orientation/smoothness losses + Adam",
                    "gaussians": P, "views": len(cams), "width": W, "height": H, "parallelism": f"view-parallel x{world}",
+                   "views_per_optimizer_step": views_per_step,
                    "mean_num_rendered": meanR, "mean_sum_tile_list_len": meanL,
                    "mean_num_rendered_after_tile_cull": meanR_culled, "mean_sum_tile_list_len_after_tile_cull": meanL_culled,
                    "forward_mode": "blocking" if args.blocking else "async-capacity",
@@ -254,14 +353,19 @@ def main():
         # HBM traffic of the same kernel from the committed rocprofv3 --pmc passes (tools/pmc_raster.sh; FETCH_SIZE and
         # WRITE_SIZE collected in separate runs, corrected as MI355X_MICROARCH.md prescribes: 2 x FETCH_SIZE + WRITE_SIZE,
         # KB units).  Counters cannot be read from inside this process, so the figure is the profiled one, per launch.
-        traffic = None
-        pmc_path = os.path.join(ROOT, "profiles", "pmc_raster_north_star.json")
-        if args.workload == "north_star" and ch == 7 and os.path.exists(pmc_path):
-            pm = json.load(open(pmc_path)).get("blend_bwd_kernel<7>", {})
-            if "FETCH_SIZE" in pm and "WRITE_SIZE" in pm:
-                traffic = (2.0 * pm["FETCH_SIZE"] + pm["WRITE_SIZE"]) * 1024.0
+        traffic = traffic_source = None
+        for name in ("r02_pmc_raster_north_star.json", "pmc_raster_north_star.json"):
+            pmc_path = os.path.join(ROOT, "profiles", name)
+            if args.workload == "north_star" and ch == 7 and os.path.exists(pmc_path):
+                pm = json.load(open(pmc_path)).get("blend_bwd_kernel<7>", {})
+                if "FETCH_SIZE" in pm and "WRITE_SIZE" in pm:
+                    traffic = (2.0 * pm["FETCH_SIZE"] + pm["WRITE_SIZE"]) * 1024.0
+                    traffic_source = f"profiles/{name}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of the same workload (profiled, static)"
+                    break
         result["roofline"] = {"kernel": "blend_bwd_kernel", "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS,
                               "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
+                              "traffic_source": traffic_source,
+                              "duration_source": "HIP events around every launch, eager continuation of this run's steps",
                               "algorithmic_bytes_per_launch": bytes_bwd, "moved_bytes_model": moved_bwd,
                               "mean_launch_us": bwd_ms / max(bwd_n, 1) * 1e3,
                               "launches": bwd_n}
@@ -279,6 +383,10 @@ def main():
                                       "sample": "1 view of the same workload: the 3 raster fwd+bwd passes of one "
                                                 "iteration through oracle/ (OpenMP C restatement of the reference "
                                                 "rasterizer); losses and Adam excluded"}
+            try:
+                result["cpu_baseline"]["cpu_only_paths"] = dict(cpu_only_paths(), host_cores=os.cpu_count())
+            except Exception as e:
+                result["cpu_baseline"]["cpu_only_paths"] = {"error": str(e)}
         except Exception as e:  # the baseline must never break the headline number
             result["cpu_baseline"] = {"value": None, "error": str(e)}
     print(json.dumps(result))

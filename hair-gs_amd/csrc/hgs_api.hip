@@ -72,6 +72,22 @@ __global__ void select_view_kernel(const HgsViewTargets* __restrict__ table, int
   if (threadIdx.x == 0 && lr_dst) *lr_dst = lr;
 }
 
+struct HgsViewQueueArgs { int v[HGS_VIEW_QUEUE_MAX]; };
+__global__ void set_view_queue_kernel(int* __restrict__ queue, int n, HgsViewQueueArgs a, float lr, float* __restrict__ lr_slot) {
+  if ((int)threadIdx.x < n) queue[threadIdx.x] = a.v[threadIdx.x];
+  if (threadIdx.x == 0 && lr_slot) *lr_slot = lr;
+}
+__global__ void select_view_queued_kernel(const HgsViewTargets* __restrict__ table, int n_views,
+                                          const int* __restrict__ view_index, HgsViewTargets* __restrict__ slot,
+                                          const float* __restrict__ lr_slot, float* __restrict__ lr_dst) {
+  int view = *view_index;
+  if (view < 0 || view >= n_views) view = 0;
+  const uint32_t* src = (const uint32_t*)(table + view);
+  uint32_t* dst = (uint32_t*)slot;
+  for (int i = threadIdx.x; i < (int)(sizeof(HgsViewTargets) / 4); i += 64) dst[i] = src[i];
+  if (threadIdx.x == 0 && lr_dst && lr_slot) *lr_dst = *lr_slot;
+}
+
 __global__ __launch_bounds__(256) void densify_stats_kernel(int P, const int* __restrict__ radii,
                                                             const float* __restrict__ g, int stride,
                                                             float* __restrict__ max_radii, float* __restrict__ accum,
@@ -125,6 +141,7 @@ int hgs_forward_preprocess(void* stream, int P, int D, int M, int W, int H, cons
                            int* num_rendered_host, unsigned int* max_rendered) {
   hipStream_t s = (hipStream_t)stream;
   if (P < 0 || W <= 0 || H <= 0) { hgs_set_error("bad sizes P=%d W=%d H=%d", P, W, H); return 1; }
+  if ((size_t)((W + HGS_TILE - 1) / HGS_TILE) * ((H + HGS_TILE - 1) / HGS_TILE) > HGS_MAX_TILES) { hgs_set_error("%dx%d: more than 2^24 tiles", W, H); return 1; }
   if ((unsigned)P > HGS_MAX_GAUSSIANS) { hgs_set_error("P=%d: at most 2^28 Gaussians per pass (instance key layout)", P); return 1; }
   if (D < 0 || D > 3) { hgs_set_error("sh degree %d unsupported (0..3)", D); return 1; }
   if (check_aligned(image_buf, "image_buf")) return 1;
@@ -367,6 +384,31 @@ int hgs_select_view(void* stream, const HgsViewTargets* table, int view, HgsView
   {
     HgsProfScope _prof(s, HGS_K_MISC);
     hipLaunchKernelGGL(select_view_kernel, dim3(1), dim3(64), 0, s, table, view, slot, lr, lr_dst);
+  }
+  HGS_CHECK_LAUNCH();
+  return 0;
+}
+
+int hgs_set_view_queue(void* stream, int* queue, int n, const int* views_host, float lr, float* lr_slot) {
+  if (!queue || !views_host || n < 1 || n > HGS_VIEW_QUEUE_MAX) { hgs_set_error("hgs_set_view_queue: bad arguments (1 <= n <= %d)", HGS_VIEW_QUEUE_MAX); return 1; }
+  HgsViewQueueArgs a = {};
+  for (int i = 0; i < n; i++) a.v[i] = views_host[i];
+  hipStream_t s = (hipStream_t)stream;
+  {
+    HgsProfScope _prof(s, HGS_K_MISC);
+    hipLaunchKernelGGL(set_view_queue_kernel, dim3(1), dim3(64), 0, s, queue, n, a, lr, lr_slot);
+  }
+  HGS_CHECK_LAUNCH();
+  return 0;
+}
+
+int hgs_select_view_queued(void* stream, const HgsViewTargets* table, int n_views, const int* view_index,
+                           HgsViewTargets* slot, const float* lr_slot, float* lr_dst) {
+  if (!table || !slot || !view_index || n_views < 1) { hgs_set_error("hgs_select_view_queued: bad arguments"); return 1; }
+  hipStream_t s = (hipStream_t)stream;
+  {
+    HgsProfScope _prof(s, HGS_K_MISC);
+    hipLaunchKernelGGL(select_view_queued_kernel, dim3(1), dim3(64), 0, s, table, n_views, view_index, slot, lr_slot, lr_dst);
   }
   HGS_CHECK_LAUNCH();
   return 0;

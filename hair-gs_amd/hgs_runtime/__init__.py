@@ -53,6 +53,8 @@ SIGNATURES = {
     "hgs_head_params_bytes": (sz, []),
     "hgs_strand_fusion_bytes": (sz, []),
     "hgs_select_view": (ci, [vp, vp, ci, vp, cf, vp]),
+    "hgs_set_view_queue": (ci, [vp, vp, ci, vp, cf, vp]),
+    "hgs_select_view_queued": (ci, [vp, vp, ci, vp, vp, vp, vp]),
     "hgs_hair_params_forward": (ci, [vp, ci, vp, vp, vp, cf, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "hgs_hair_params_backward": (ci, [vp, ci, ci, vp, vp, vp, cf, vp, vp, vp, vp, vp, vp, vp, vp, ci, vp, vp, vp, vp, vp]),
     "hgs_cloud_params_forward": (ci, [vp, ci, vp, vp, vp, vp, vp, vp, vp, vp]),
@@ -106,6 +108,7 @@ class StrandFusion(C.Structure):
 
 
 HEAD_SKIP_PIXELS, HEAD_SKIP_SMOOTH, HEAD_SKIP_SSIM = 1, 2, 4
+VIEW_QUEUE_MAX = 16   # include/hgs.h HGS_VIEW_QUEUE_MAX
 HEAD_OUT = ["total", "l1", "dssim", "mask", "orientation", "smooth", "ori_count", "smooth_count", "g_ssim", "g_l1", "g_mask",
             "g_ori", "g_smooth"]
 HEAD_NOUT = 16

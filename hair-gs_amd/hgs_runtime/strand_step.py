@@ -77,6 +77,9 @@ class ViewTable:
         self.index = {id(c): i for i, c in enumerate(cameras)}
         self.n = len(cameras)
         self.current = -1
+        # several views per captured step (include/hgs.h hgs_set_view_queue / hgs_select_view_queued)
+        self.queue = torch.zeros(rt.VIEW_QUEUE_MAX, dtype=torch.int32, device=self.device)
+        self.queue_lr = torch.zeros((), dtype=torch.float32, device=self.device)
 
     def select(self, view, lr=0.0, lr_dst=None):
         """slot <- table[view] (and *lr_dst <- lr): one launch on the current stream."""
@@ -86,6 +89,26 @@ class ViewTable:
             rt.check(rt.lib().hgs_select_view(rt.current_stream(), self.table.data_ptr(), int(view), self.slot.data_ptr(),
                                               float(lr), None if lr_dst is None else lr_dst.data_ptr()))
         self.current = int(view)
+
+
+    def set_queue(self, views, lr=0.0):
+        """queue[:len(views)] <- views, queue_lr <- lr: one launch, values travel as kernel arguments."""
+        views = [int(v) for v in views]
+        if not 1 <= len(views) <= rt.VIEW_QUEUE_MAX or any(not 0 <= v < self.n for v in views):
+            raise rt.HgsError(f"view queue {views}: 1..{rt.VIEW_QUEUE_MAX} views inside the table (0..{self.n - 1})")
+        arr = (C.c_int * len(views))(*views)
+        with torch.cuda.device(self.device):
+            rt.check(rt.lib().hgs_set_view_queue(rt.current_stream(), self.queue.data_ptr(), len(views), arr, float(lr),
+                                                 self.queue_lr.data_ptr()))
+
+    def select_queued(self, k, lr_dst=None):
+        """slot <- table[queue[k]] (and *lr_dst <- queue_lr), everything read on the device: capturable once, replayable
+        with a different queue."""
+        with torch.cuda.device(self.device):
+            rt.check(rt.lib().hgs_select_view_queued(rt.current_stream(), self.table.data_ptr(), self.n,
+                                                     self.queue[k:].data_ptr(), self.slot.data_ptr(), self.queue_lr.data_ptr(),
+                                                     None if lr_dst is None else lr_dst.data_ptr()))
+        self.current = -1
 
 
 def _adjacency(member_ids, roles, n_targets, max_degree):

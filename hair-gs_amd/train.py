@@ -55,15 +55,17 @@ class ViewParallel:
         for p, v in zip(ps, self._views):
             p.grad = v
 
-    def exchange(self):
-        """Average the packed gradients over the ranks: one all-reduce over xGMI (RCCL) / gloo on CPU."""
+    def exchange(self, average=True):
+        """Average (or, average=False, sum) the packed gradients over the ranks: one all-reduce over xGMI (RCCL) / gloo
+        on CPU."""
         if self.world == 1 or self._flat is None:
             return
-        if dist.get_backend() == "nccl":
+        if average and dist.get_backend() == "nccl":
             dist.all_reduce(self._flat, op=dist.ReduceOp.AVG)
         else:
             dist.all_reduce(self._flat, op=dist.ReduceOp.SUM)
-            self._flat.div_(self.world)
+            if average:
+                self._flat.div_(self.world)
 
     def reduce_gradients(self, gaussians):
         """pack + exchange (the eager path; GraphedStep captures the pack and replays around the exchange)."""
@@ -92,13 +94,22 @@ class ViewSampler:
         self.rng = random.Random(seed)
         self.stack = []
 
+    def _pop(self):
+        if not self.stack:
+            self.stack = list(range(len(self.cameras)))
+        return self.stack.pop(self.rng.randint(0, len(self.stack) - 1))
+
     def next(self):
-        picks = []
-        for _ in range(self.world):
-            if not self.stack:
-                self.stack = list(range(len(self.cameras)))
-            picks.append(self.stack.pop(self.rng.randint(0, len(self.stack) - 1)))
+        picks = [self._pop() for _ in range(self.world)]
         return self.cameras[picks[self.rank]]
+
+    def next_batch(self, total):
+        """A global batch of `total` views for one optimizer step (strong scaling): the same draw on every
+        rank, rank r takes entries r, r + world, ...  (`total` must be a multiple of the world size)."""
+        if total % self.world:
+            raise ValueError(f"global batch of {total} views does not divide over {self.world} ranks")
+        picks = [self._pop() for _ in range(total)]
+        return [self.cameras[i] for i in picks[self.rank::self.world]]
 
 
 def fused_step_applicable(gaussians, opt):
@@ -145,6 +156,7 @@ def _training_step(gaussians, viewpoint_cam, opt, bg, iteration, extent, vp, ras
     else:
         loss.backward()
     raster.check_async()  # async mode: the step's single synchronisation (raises -> step repeated); no-op otherwise
+    densified = False
     with torch.no_grad():
         if iteration < opt.densify_until_iter:
             if fused is not None:
@@ -158,11 +170,12 @@ def _training_step(gaussians, viewpoint_cam, opt, bg, iteration, extent, vp, ras
                     vp.reduce_stats(gaussians)
                 size_threshold = opt.prune_max_radii_2d if iteration > opt.opacity_reset_interval else None
                 gaussians.densification(extent, size_threshold, None)
+                densified = True
             if iteration % opt.opacity_reset_interval == 0:
                 gaussians.reset_opacity()
         if isinstance(gaussians, HairGaussianModel) and getattr(opt, "enable_topology", True):
             if iteration % opt.merge_interval == 0 and hasattr(gaussians, "merging"):
-                gaussians.merging(training_info=None)
+                gaussians.merging(training_info=None, strands_info_is_current=densified)
         if vp is not None:
             vp.reduce_gradients(gaussians)
         gaussians.optimizer.step()
@@ -182,7 +195,10 @@ class GraphedStep:
     CAMERA_FIELDS = ("world_view_transform", "full_proj_transform", "camera_center", "original_image", "mask",
                      "float_mask", "orientation_field", "orientation_confidence")
 
-    def __init__(self, gaussians, cameras, opt, bg, extent=1.0, vp=None, slack=2.0, views=None):
+    def __init__(self, gaussians, cameras, opt, bg, extent=1.0, vp=None, slack=2.0, views=None, views_per_step=1):
+        """views_per_step > 1: every rank renders that many views per optimizer step inside the one captured graph and
+        sums their gradients; with W ranks the step's gradient is the MEAN over the views_per_step x W views of the
+        global batch (strong-scaling protocol: the batch is fixed, the ranks share it)."""
         import copy
         from diff_gaussian_rasterization import _C as raster
         self.g, self.opt, self.bg, self.extent, self.raster = gaussians, opt, bg, extent, raster
@@ -203,6 +219,9 @@ class GraphedStep:
         raster.set_async(True, slack=slack)
         self._graphs = None
         self._cap = None
+        self.views_per_step = int(views_per_step)
+        if self.views_per_step > 1 and self.fused is None:
+            raise ValueError("several views per captured step need the fused iteration (hgs_runtime.strand_step)")
         self._make_capturable()
 
     def _make_capturable(self):
@@ -251,6 +270,25 @@ class GraphedStep:
                 dst.copy_(src, non_blocking=True)
         self.slot.uid = cam.uid
 
+    def _forward_backward_queue(self):
+        """views_per_step views, selected on the device from the view queue; gradients accumulate in .grad (autograd's
+        AccumulateGrad), statistics per view.  Returns the mean loss of the local views."""
+        total = None
+        for k in range(self.views_per_step):
+            self.fused.views.select_queued(k, lr_dst=self._position_lr() if k == 0 else None)
+            loss, _ = self.fused.loss()
+            self.fused.backward(loss)
+            self.fused.update_densification_stats()
+            self.g._derived = None
+            total = loss.detach().clone() if total is None else total + loss.detach()
+        return total / self.views_per_step
+
+    def _scale_gradients(self):
+        """.grad <- .grad / (views of the global batch): one multi-tensor launch (captured in front of Adam)."""
+        grads = [p.grad for p in self.vp.params(self.g) if p.grad is not None]
+        if grads:
+            torch._foreach_mul_(grads, 1.0 / (self.views_per_step * self.vp.world))
+
     def _forward_backward(self):
         if self.fused is not None:
             loss, _ = self.fused.loss()
@@ -293,10 +331,16 @@ class GraphedStep:
         for dst, src in zip((g.max_radii2D, g.xyz_gradient_accum, g.denom), saved_stats):
             dst.copy_(src)
         self.loss_buf = None
+        multi = self.views_per_step > 1
+        if multi:
+            self.fused.views.set_queue([0] * self.views_per_step, lr=self._lr_now)   # (the capture itself launches nothing)
+        fwd_bwd = self._forward_backward_queue if multi else self._forward_backward
         if self.vp.world == 1:
             ga = torch.cuda.CUDAGraph()
             with torch.cuda.graph(ga, stream=s):
-                self.loss_buf = self._forward_backward()
+                self.loss_buf = fwd_bwd()
+                if multi:
+                    self._scale_gradients()
                 g.optimizer.step()
             self._graphs = (ga, None)
         else:
@@ -305,9 +349,11 @@ class GraphedStep:
             mode = dict(capture_error_mode="thread_local")
             ga, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
             with torch.cuda.graph(ga, stream=s, **mode):
-                self.loss_buf = self._forward_backward()
+                self.loss_buf = fwd_bwd()
                 self.vp.pack_gradients(g)       # .grad become views of the flat exchange buffer
             with torch.cuda.graph(gb, pool=ga.pool(), stream=s, **mode):
+                if multi:
+                    self._scale_gradients()     # (the exchange in between SUMS over the ranks)
                 g.optimizer.step()
             self._graphs = (ga, gb)
         # every replay raises the library's sticky device-side maximum of num_rendered; check() compares it with the
@@ -320,13 +366,23 @@ class GraphedStep:
         g._derived = None
 
     def step(self, cam, iteration):
-        """One optimizer step on `cam`; returns the (device) loss of this step."""
+        """One optimizer step on `cam` (views_per_step > 1: on the list of this rank's views of the global batch);
+        returns the (device) loss of this step."""
         self._set_lr(iteration)
-        self.load_camera(cam)
+        if self.views_per_step > 1:
+            cams = list(cam)
+            if len(cams) != self.views_per_step:
+                raise ValueError(f"captured for {self.views_per_step} views per step, got {len(cams)}")
+            v = self.fused.views
+            v.set_queue([v.index[id(c)] for c in cams], lr=self._lr_now)
+        else:
+            self.load_camera(cam)
         ga, gb = self._graphs
         ga.replay()
         if gb is not None:
-            self.vp.exchange()                  # the only eager work between the two graphs: one in-place all-reduce
+            # the only eager work between the two graphs: one in-place all-reduce (mean over the ranks; with several views
+            # per rank a sum, scaled to the mean over the global batch in front of Adam)
+            self.vp.exchange(average=self.views_per_step == 1)
             gb.replay()
         self.g._derived = None  # cached derived tensors now hold pre-update values
         return self.loss_buf
@@ -367,33 +423,18 @@ def topology_due(gaussians, opt, iteration):
     return due
 
 
-def apply_topology(gaussians, opt, iteration, extent, due, vp=None):
-    """Run the due operators on (replicated) state, in the reference's order (train.py:172-200)."""
-    with torch.no_grad():
-        if "densify" in due:
-            if vp is not None:
-                vp.reduce_stats(gaussians)
-            size_threshold = opt.prune_max_radii_2d if iteration > opt.opacity_reset_interval else None
-            gaussians.densification(extent, size_threshold, None)
-        if "reset_opacity" in due:
-            gaussians.reset_opacity()
-        if "merge" in due:
-            gaussians.merging(training_info=None, strands_info_is_current="densify" in due)
-
-
 def training(gaussians, cameras, opt, iterations=None, extent=1.0, seed=0, log_every=0, vp=None, start_iteration=0,
-             use_graph=True):
+             use_graph=True, sampler=None):
     """Training loop (reference train.py:91-254 without logger / viewer / dataset IO, which are outside the
-    accelerated path).  With use_graph the iteration body replays a captured HIP graph (GraphedStep); iterations that
-    change tensor shapes (densification, merging, opacity reset, SH-degree bump) run their operators eagerly after
-    the step's backward+Adam, exactly where the reference runs them relative to the next step, and the graph is
-    re-captured.  Note: the reference applies densify/merge BEFORE optimizer.step() of the same iteration
-    (train.py:172-204); with freshly re-created tensors that step has no gradients for them, so applying the
-    operators after the step changes nothing but the order of two independent updates."""
+    accelerated path).  With use_graph the iteration body replays a captured HIP graph (GraphedStep).  Iterations on which
+    the reference schedules a shape-changing operator (densification, merging, opacity reset, SH-degree bump:
+    train.py:136-200) run EAGERLY through `training_step`, which has the reference's order -- operators between backward
+    and optimizer.step(), so re-created tensors skip that Adam step exactly as in the reference --, and the graph is
+    captured again afterwards.  `sampler`: a ViewSampler to continue (main() trains in chunks between saves)."""
     vp = ViewParallel() if vp is None else vp
     dev = gaussians.get_xyz.device
     bg = torch.zeros(3, dtype=torch.float32, device=dev)
-    sampler = ViewSampler(cameras, seed=seed, rank=vp.rank, world=vp.world)
+    sampler = ViewSampler(cameras, seed=seed, rank=vp.rank, world=vp.world) if sampler is None else sampler
     ema = None
     n = opt.iterations if iterations is None else iterations
     gs = None
@@ -402,51 +443,60 @@ def training(gaussians, cameras, opt, iterations=None, extent=1.0, seed=0, log_e
     if dev.type == "cuda" and fused_step_applicable(gaussians, opt):
         from hgs_runtime.strand_step import ViewTable, fused_step_for
         views = ViewTable(cameras)             # built once; survives topology changes
-        if not use_graph:
-            fused = fused_step_for(gaussians, views, opt, bg)
-    saved_topology = getattr(opt, "enable_topology", True)
-    opt.enable_topology = False  # the loop below schedules the operators itself
+        fused = fused_step_for(gaussians, views, opt, bg)   # eager launches of the same iteration (topology iterations)
+    topology = getattr(opt, "enable_topology", True)
+    void_steps = 0
     try:
         for it in range(start_iteration + 1, start_iteration + n + 1):
-            due = topology_due(gaussians, opt, it) if saved_topology else []
-            if "sh" in due:
-                gaussians.oneupSHdegree()
-                gs = None
-            if use_graph:
+            due = topology_due(gaussians, opt, it) if topology else []
+            if use_graph and not due:
                 if gs is None:
                     gs = GraphedStep(gaussians, cameras, opt, bg, extent=extent, vp=vp, views=views)
                     gs.capture(cameras, iteration=it)
                 loss = gs.step(sampler.next(), it)
             else:
+                if gs is not None:
+                    void_steps += _void_steps(gs)
+                    gs = None                  # shapes change below: capture again at the next iteration
                 loss, _, _ = training_step(gaussians, sampler.next(), opt, bg, it, extent=extent, vp=vp, fused=fused)
+                if fused is not None and due:
+                    fused.refresh()
             ema = loss.clone() if ema is None else 0.4 * loss + 0.6 * ema  # on the device: no per-iteration host sync
             if gs is not None and it % 64 == 0:
-                # the model grows while it trains: re-capture with a larger capacity once 80% of the captured one is used
+                # the model grows while it trains: re-capture with a larger capacity once 80% of the captured one is used.
+                # The decision is taken on the maximum over the ranks (views differ; replicas must re-capture together).
                 worst, cap = gs.headroom()
+                if vp.world > 1:
+                    w = torch.tensor([worst], dtype=torch.int64, device=dev)
+                    dist.all_reduce(w, op=dist.ReduceOp.MAX)
+                    worst = int(w.item())
                 if cap is not None and worst > 0.8 * cap:
                     from diff_gaussian_rasterization import _C as raster
-                    if worst > cap and vp.rank == 0:
-                        print(f"[it {it}] binning capacity {cap} exceeded ({worst} instances): some of the last 64 steps "
-                              "dropped instances; re-capturing with a larger capacity")
+                    if worst > cap:
+                        # passes beyond the capacity were void: exactly zero gradients (include/hgs.h), i.e. those steps
+                        # moved the parameters by Adam's momentum only -- deterministic, finite, reported
+                        void_steps += 1
+                        if vp.rank == 0:
+                            print(f"[it {it}] binning capacity {cap} exceeded ({worst} instances): steps since the last check "
+                                  "that overflowed ran with zero gradients; re-capturing with a larger capacity")
                     raster._state["cap"] = max(raster._state["cap"], int(worst * 2.0) + 4096)
                     gs = None
-            if any(d in due for d in ("densify", "reset_opacity", "merge")):
-                if gs is not None:
-                    gs.check()
-                apply_topology(gaussians, opt, it, extent, due, vp)
-                gs = None  # shapes changed: capture again at the next iteration
-                if fused is not None:
-                    fused.refresh()
             if log_every and it % log_every == 0 and vp.rank == 0:
                 print(f"[it {it}] loss(ema) {float(ema):.6f}  segments {gaussians.get_xyz.shape[0]}")
         if gs is not None:
-            gs.check()
+            void_steps += _void_steps(gs)
     finally:
-        opt.enable_topology = saved_topology
         if use_graph:
             from diff_gaussian_rasterization import _C as raster
             raster.set_async(False)
+    training.last_void_steps = void_steps
     return ema
+
+
+def _void_steps(gs):
+    """1 if a replay since the last check overflowed the captured capacity (its gradients were exactly zero), else 0."""
+    worst, cap = gs.headroom()
+    return int(cap is not None and worst > cap)
 
 
 def main(argv=None):
@@ -464,24 +514,44 @@ def main(argv=None):
     parser = ArgumentParser(description="Training script parameters")
     mp, op, gp = ModelParams(parser), OptimizationParams(parser), GeneralParams(parser)
     args = parser.parse_args(argv)
-    safe_state(args.quiet)
-    os.makedirs(args.model_path, exist_ok=True)
-    with open(os.path.join(args.model_path, "cfg_args"), "w") as fh:   # what render.py's get_combined_args reads back
-        fh.write(str(args))
+    # view-parallel run (python -m torch.distributed.run ... train.py): one process per GPU, initialised before anything
+    # touches the GPU; every rank seeds identically (replicated topology operators draw the same random numbers), rank 0
+    # alone writes to the model directory
+    world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        local = int(os.environ.get("LOCAL_RANK", "0"))
+        if torch.cuda.is_available():
+            torch.cuda.set_device(local)
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend="gloo")
+    safe_state(args.quiet or rank != 0)
+    if rank == 0:
+        os.makedirs(args.model_path, exist_ok=True)
+        with open(os.path.join(args.model_path, "cfg_args"), "w") as fh:   # what render.py's get_combined_args reads back
+            fh.write(str(args))
     scene = Scene(mp.extract(args))
     opt = op.extract(args)
     g = scene.gaussians
     g.training_setup(opt)
     cams = scene.getCameras()
+    vp = ViewParallel()
+    sampler = ViewSampler(cams, seed=0, rank=vp.rank, world=vp.world)   # ONE view order for the whole run
     it, total, every = scene.loaded_iter, scene.loaded_iter + opt.iterations, max(1, int(args.save_frequency))
     while it < total:
         n = min(every - it % every, total - it)
-        ema = training(g, cams, opt, iterations=n, extent=scene.cameras_extent, start_iteration=it,
-                       log_every=0 if args.quiet else max(1, n // 4))
+        ema = training(g, cams, opt, iterations=n, extent=scene.cameras_extent, start_iteration=it, vp=vp, sampler=sampler,
+                       log_every=0 if (args.quiet or rank != 0) else max(1, n // 4))
         it += n
-        scene.save(it)
-        if not args.quiet:
-            print(f"[it {it}] saved; loss(ema) {float(ema):.6f}")
+        if rank == 0:
+            scene.save(it)
+            if not args.quiet:
+                print(f"[it {it}] saved; loss(ema) {float(ema):.6f}")
+        if world > 1:
+            dist.barrier()
+    if world > 1:
+        dist.destroy_process_group()
     return scene
 
 

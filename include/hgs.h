@@ -208,6 +208,18 @@ size_t hgs_strand_fusion_bytes(void);  /* sizeof(HgsStrandFusion) */
 /* slot[0] = table[view]; if lr_dst != NULL also *lr_dst = lr (the position learning rate of this iteration, a by-value
  * kernel argument, so the host may run ahead of the device without racing on a staging buffer). */
 int hgs_select_view(void* stream, const HgsViewTargets* table, int view, HgsViewTargets* slot, float lr, float* lr_dst);
+/* Several views per optimizer step inside ONE captured graph (strong-scaling protocol, SURVEY.md 8e: a fixed global batch
+ * of V views per step, rank r takes views r, r+N, ...).  The graph holds one hgs_select_view_queued launch per local view,
+ * which reads the view index from DEVICE memory; before every replay the host writes the step's indices (and the
+ * position learning rate) with ONE hgs_set_view_queue launch whose values are by-value kernel arguments (n <=
+ * HGS_VIEW_QUEUE_MAX), so the host may run ahead of the device.
+ *   hgs_set_view_queue:     queue[i] = views[i] (i < n), *lr_slot = lr
+ *   hgs_select_view_queued: slot[0] = table[*view_index]; if lr_dst != NULL also *lr_dst = *lr_slot.  An index outside
+ *                           [0, n_views) selects view 0 (a replay with an unwritten queue must not read wild memory). */
+#define HGS_VIEW_QUEUE_MAX 16
+int hgs_set_view_queue(void* stream, int* queue, int n, const int* views_host, float lr, float* lr_slot);
+int hgs_select_view_queued(void* stream, const HgsViewTargets* table, int n_views, const int* view_index,
+                           HgsViewTargets* slot, const float* lr_slot, float* lr_dst);
 
 /* hgs_hair_params_forward/backward: hgs_strand_geometry_* plus the appearance activations of the same Gaussians
  *   (scene/gaussian_model.py:93-99 get_opacity / get_mask = sigmoid) and the 4 extra blended channels of the

@@ -1,6 +1,7 @@
 """Worker of tests/test_gpu_view_parallel.py: N ranks SHARING one GPU (gloo backend) run the view-parallel GraphedStep;
 every rank must end with bit-identical parameters, and rank 0 checks them against a single-process run that averages
-the same per-view gradients by hand."""
+the same per-view gradients by hand.  HGS_VP_MODE=strong: a fixed global batch of HGS_VP_GLOBAL_VIEWS views per optimizer
+step shared by the ranks (several views per rank inside one captured graph, bench.py --scaling strong)."""
 import os
 import sys
 
@@ -11,8 +12,10 @@ import torch.distributed as dist
 
 
 def main():
-    dist.init_process_group(backend="gloo")
-    rank, world = dist.get_rank(), dist.get_world_size()
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        dist.init_process_group(backend="gloo")
+    distributed = dist.is_initialized()
+    rank, world = (dist.get_rank(), dist.get_world_size()) if distributed else (0, 1)
     torch.cuda.set_device(0)
     from arguments import OptimizationParams
     from diff_gaussian_rasterization import _C as raster
@@ -28,23 +31,30 @@ def main():
     vp = ViewParallel()
     assert vp.world == world
     sampler = ViewSampler(cams, seed=0, rank=vp.rank, world=vp.world)
-    gs = GraphedStep(model, cams, opt, bg, extent=extent, vp=vp)
+    strong = os.environ.get("HGS_VP_MODE", "weak") == "strong"
+    V = int(os.environ.get("HGS_VP_GLOBAL_VIEWS", str(world)))
+    per_rank = V // world if strong else 1
+    gs = GraphedStep(model, cams, opt, bg, extent=extent, vp=vp, views_per_step=per_rank)
     gs.capture(cams)
     picks = []
     for it in range(1, 5):
-        cam = sampler.next()
-        picks.append(cams.index(cam))
-        loss = gs.step(cam, it)
+        mine = sampler.next_batch(V) if strong else [sampler.next()]
+        assert len(mine) == per_rank
+        picks.append([cams.index(c) for c in mine])
+        loss = gs.step(mine if per_rank > 1 else mine[0], it)
     gs.check()
     raster.set_async(False)
     assert torch.isfinite(loss)
     flat = torch.cat([p.detach().reshape(-1) for p in vp.params(model)]).cpu()
     gathered = [torch.empty_like(flat) for _ in range(world)]
-    dist.all_gather(gathered, flat)
+    allpicks = [None] * world
+    if distributed:
+        dist.all_gather(gathered, flat)
+        dist.all_gather_object(allpicks, picks)
+    else:
+        gathered, allpicks = [flat], [picks]
     for r in range(1, world):
         assert torch.equal(gathered[0], gathered[r]), f"rank {r} diverged from rank 0"
-    allpicks = [None] * world
-    dist.all_gather_object(allpicks, picks)
     if rank == 0:
         # single-process reference: same views, gradients averaged by hand, same Adam
         from hgs_runtime.strand_step import FusedStrandStep
@@ -57,23 +67,25 @@ def main():
             ref.update_learning_rate(it)
             acc = [torch.zeros_like(p) for p in params]
             for r in range(world):
-                fused.views.select(allpicks[r][it - 1])
-                l, _ = fused.loss()
-                fused.backward(l)
-                for a, p in zip(acc, params):
-                    if p.grad is not None:
-                        a += p.grad
-                    p.grad = None
+                for view in allpicks[r][it - 1]:
+                    fused.views.select(view)
+                    l, _ = fused.loss()
+                    fused.backward(l)
+                    for a, p in zip(acc, params):
+                        if p.grad is not None:
+                            a += p.grad
+                        p.grad = None
             for a, p in zip(acc, params):
-                p.grad = a / world
+                p.grad = a / (world * per_rank)
             ref.optimizer.step()
             ref.optimizer.zero_grad(set_to_none=True)
         rflat = torch.cat([p.detach().reshape(-1) for p in params]).cpu()
         d = (rflat - gathered[0]).abs()
         assert float(d.max()) <= 2e-4 * float(rflat.abs().max()), float(d.max())
         print("VP_GPU_OK", float(d.max()))
-    dist.barrier()
-    dist.destroy_process_group()
+    if distributed:
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -1,6 +1,8 @@
-"""View-parallel training step on the GPU: two ranks share the one GPU of the test box through the gloo backend (RCCL
+"""View-parallel training step on the GPU: the ranks share the one GPU of the test box through the gloo backend (RCCL
 needs one GPU per rank), which exercises everything but the transport: per-rank views, the captured pack of the
-gradients into the flat exchange buffer, the in-place averaging all-reduce between the two graphs, replicated Adam."""
+gradients into the flat exchange buffer, the in-place all-reduce between the two graphs, replicated Adam -- in the weak
+mode (one view per rank and step) and in the strong mode of SURVEY.md 8e (a fixed global batch of views per optimizer
+step shared by the ranks, several views per rank inside one captured graph)."""
 import os
 import subprocess
 import sys
@@ -11,10 +13,32 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
 
 
-def test_two_ranks_stay_replicated_and_match_hand_averaged_gradients():
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29533", os.path.join(ROOT, "tests", "_vp_gpu_worker.py")]
-    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+def _run(nproc, port, mode="weak", global_views=None):
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0", HGS_VP_MODE=mode)
+    if global_views is not None:
+        env["HGS_VP_GLOBAL_VIEWS"] = str(global_views)
+    worker = os.path.join(ROOT, "tests", "_vp_gpu_worker.py")
+    if nproc == 1:
+        env.pop("WORLD_SIZE", None)
+        cmd = [sys.executable, worker]
+    else:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr",
+               "127.0.0.1", "--master-port", str(port), worker]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
     assert "VP_GPU_OK" in out.stdout
+
+
+def test_two_ranks_stay_replicated_and_match_hand_averaged_gradients():
+    _run(2, 29533)
+
+
+def test_four_ranks_stay_replicated_and_match_hand_averaged_gradients():
+    _run(4, 29534)
+
+
+@pytest.mark.parametrize("nproc", [1, 2, 4])
+def test_strong_mode_equals_single_process_gradient_accumulation(nproc):
+    """A global batch of 4 views per optimizer step on 1, 2 and 4 ranks (4, 2, 1 views per rank): the same parameters as
+    one process that accumulates the four views' gradients by hand and takes their mean."""
+    _run(nproc, 29535 + nproc, mode="strong", global_views=4)

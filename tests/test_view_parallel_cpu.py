@@ -70,3 +70,54 @@ def test_two_rank_gradient_and_stats_exchange():
     tot = sum(w * m.get_opacity.sum() for w in (1.0, 2.0)) / 2
     tot.backward()
     assert torch.allclose(a["grad_op"], m._opacity.grad, rtol=1e-6)
+
+
+def _worker_strong(rank, world, port, out):
+    """Strong-scaling protocol on CPU tensors: a global batch of 4 'views' per step, 2 per rank, gradients summed locally,
+    SUM all-reduced, scaled to the mean over the batch (what GraphedStep(views_per_step=2) captures on the GPU)."""
+    for p in (ROOT, os.path.join(ROOT, "hair-gs_amd")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from arguments import OptimizationParams
+    from scene.hair_gaussian_model import HairGaussianModel
+    from synthetic import strand_polylines
+    from train import ViewParallel, ViewSampler
+    m = HairGaussianModel.from_strands(strand_polylines(4, 5, seed=0), device="cpu")
+    m.training_setup(OptimizationParams())
+    vp = ViewParallel()
+    sampler = ViewSampler(list(range(8)), seed=5, rank=rank, world=world)
+    mine = sampler.next_batch(4)
+    assert len(mine) == 2
+    for view in mine:                       # local accumulation over this rank's views (AccumulateGrad)
+        w = float(view + 1)
+        (w * (m.get_xyz ** 2).sum() + w * m.get_opacity.sum()).backward()
+    vp.pack_gradients(m)
+    vp.exchange(average=False)
+    torch._foreach_mul_([p.grad for p in vp.params(m) if p.grad is not None], 1.0 / 4)
+    out[rank] = dict(mine=mine, grad_op=m._opacity.grad.clone(), grad_ep=m._endpoints.grad.clone())
+    dist.destroy_process_group()
+
+
+def test_strong_mode_global_batch_is_partitioned_and_averaged():
+    world, port = 2, _free_port()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker_strong, args=(world, port, out), nprocs=world, join=True)
+    a, b = out[0], out[1]
+    batch = sorted(a["mine"] + b["mine"])
+    assert len(set(batch)) == 4 and not set(a["mine"]) & set(b["mine"])      # one draw, disjoint shares
+    assert torch.equal(a["grad_op"], b["grad_op"]) and torch.equal(a["grad_ep"], b["grad_ep"])
+    for p in (ROOT, os.path.join(ROOT, "hair-gs_amd")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    from scene.hair_gaussian_model import HairGaussianModel
+    from synthetic import strand_polylines
+    from train import ViewSampler
+    assert sorted(ViewSampler(list(range(8)), seed=5).next_batch(4)) == batch   # the 1-rank run draws the same batch
+    m = HairGaussianModel.from_strands(strand_polylines(4, 5, seed=0), device="cpu")
+    tot = sum(float(v + 1) * ((m.get_xyz ** 2).sum() + m.get_opacity.sum()) for v in batch) / 4
+    tot.backward()
+    assert torch.allclose(a["grad_op"], m._opacity.grad, rtol=1e-6)
+    assert torch.allclose(a["grad_ep"], m._endpoints.grad, rtol=1e-5, atol=1e-9)
