@@ -172,6 +172,9 @@ def main():
     from utils.general import safe_state
 
     rt.lib()  # fail loudly if the HIP library is missing
+    if os.environ.get("HGS_SEG_POLICY"):   # measurement aid: "min,max,target" of hgs_set_segment_policy
+        pol = [int(x) for x in os.environ["HGS_SEG_POLICY"].split(",")]
+        rt.check(rt.lib().hgs_set_segment_policy(*pol[:3]))
     from diff_gaussian_rasterization import _C as raster
     raster.set_async(not args.blocking)
     safe_state(True)

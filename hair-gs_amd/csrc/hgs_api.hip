@@ -207,13 +207,11 @@ static int forward_render_impl(void* stream, int P, int W, int H, int R_capacity
       hgs_binning_carve((char*)binning_buf, (size_t)R_capacity, b, nullptr, channels);
     }
     // the scatter also finishes the per-Gaussian instance offsets, so it runs even when nothing is visible
-    if (hgs_launch_scatter(s, P, W, H, R_capacity > 0 ? R_capacity : 0, nullptr, g, im, b)) return 1;
-  }
-  {
-    // always launched: besides the per-tile sorts (no-ops on empty lists) it computes the blend kernels' tile order
     const float* feat = colors_precomp ? colors_precomp : g.rgb;
-    if (hgs_launch_sort_tiles(s, W, H, R_capacity > 0 ? R_capacity : 0, feat, extra, n_extra, g, im, b)) return 1;
+    if (hgs_launch_scatter(s, P, W, H, R_capacity > 0 ? R_capacity : 0, feat, extra, n_extra, g, im, b)) return 1;
   }
+  // always launched: besides the per-tile sorts (no-ops on empty lists) it computes the blend kernels' work list
+  if (hgs_launch_sort_tiles(s, W, H, R_capacity > 0 ? R_capacity : 0, n_extra, g, im, b)) return 1;
   return hgs_launch_blend_fwd(s, W, H, R_capacity > 0 ? R_capacity : 0, channels, bg, im, b, out_color);
 }
 

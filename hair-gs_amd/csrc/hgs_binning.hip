@@ -113,33 +113,31 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_kernel(int nblk, int T, Hgs
   }
 }
 
-struct EmitCtx { const float* feat; const float* extra; int n_extra; uint32_t Rcap; };
-
-__device__ __forceinline__ void emit_instance(uint64_t key, uint32_t pos, int tx, int ty, const EmitCtx& e,
-                                              const HgsGeom& g, const HgsBinning& b) {
+// One instance in its final list position: point_list, the sorted key and the packed record the blend kernels stream.
+// Everything about the Gaussian comes from its 64-byte template (HgsGeom::grec, scatter_kernel): one contiguous gather.
+template <bool EXTRA>   // EXTRA: 64-B records with the 4 extra channels of the single-pass mode, else 48-B records
+__device__ __forceinline__ void emit_instance(uint64_t key, uint32_t pos, int tx, int ty, const HgsGeom& g, const HgsBinning& b) {
   const uint32_t id = (uint32_t)key >> HGS_QMASK_SHIFT;
+  const float4* t = g.grec + 4 * (size_t)id;
+  const float4 t0 = t[0], t1 = t[1], t2 = t[2];
+  const uint4 u3 = ((const uint4*)t)[3];
   b.point_list[pos] = id;
   b.keys_sorted[pos] = key;
-  const float2 xy = g.means2D[id];
-  const float4 co = g.conic_opacity[id];
-  const float f0 = e.feat[3 * (size_t)id], f1 = e.feat[3 * (size_t)id + 1], f2 = e.feat[3 * (size_t)id + 2];
   const uint32_t qmask = (uint32_t)key & HGS_QMASK_BITS;   // quadrant mask, computed by the scatter kernel (hgs_quadrant_mask)
   // the instance's slot in Gaussian-major order (offset of the Gaussian + cell of its tile rectangle): the backward stores
   // this instance's row of partial sums there, so that a Gaussian's rows are contiguous for preprocess_bwd_kernel
-  const HgsRect rc = g.rect[id];
-  const uint32_t slot = rc.off + (uint32_t)(ty - rc.y0) * (uint32_t)(rc.x1 - rc.x0) + (uint32_t)(tx - rc.x0);
-  if (e.n_extra == 0) {  // 48-B record: xy, conic, opacity, rgb, id, quadrant mask
+  const uint32_t slot = u3.y + ((uint32_t)ty - (u3.z >> 16)) * u3.w + ((uint32_t)tx - (u3.z & 0xFFFFu));
+  if (!EXTRA) {  // 48-B record: xy, conic, opacity, rgb, id, quadrant mask, slot
     float4* rec = b.packed + (size_t)pos * 3;
-    rec[0] = make_float4(xy.x, xy.y, co.x, co.y);
-    rec[1] = make_float4(co.z, co.w, f0, f1);
-    rec[2] = make_float4(f2, __uint_as_float(id), __uint_as_float(qmask), __uint_as_float(slot));
-  } else {               // 64-B record: ... rgb, 4 extra channels, id, quadrant mask
-    const float4 ex = ((const float4*)e.extra)[id];
+    rec[0] = t0;
+    rec[1] = t1;
+    ((uint4*)rec)[2] = make_uint4(__float_as_uint(t2.x), id, qmask, slot);
+  } else {               // 64-B record: ... rgb, 4 extra channels, id, quadrant mask, slot
     float4* rec = b.packed + (size_t)pos * 4;
-    rec[0] = make_float4(xy.x, xy.y, co.x, co.y);
-    rec[1] = make_float4(co.z, co.w, f0, f1);
-    rec[2] = make_float4(f2, ex.x, ex.y, ex.z);
-    rec[3] = make_float4(ex.w, __uint_as_float(id), __uint_as_float(qmask), __uint_as_float(slot));
+    rec[0] = t0;
+    rec[1] = t1;
+    rec[2] = t2;
+    ((uint4*)rec)[3] = make_uint4(u3.x, id, qmask, slot);
   }
 }
 
@@ -165,12 +163,12 @@ __device__ __forceinline__ void bitonic_lds(uint64_t* sk, int m) {
 //   * The other tiles follow in descending order of list length (counting sort by min(length, ORD_BUCKETS-1)) in
 //     im.tile_order.  A list is consumed sequentially, so the blend kernels end when the longest pieces end: measured
 //     on the strand workload, raster order started the 58-us tiles of the backward 15-30 us into the launch.
-__device__ __forceinline__ void work_list_block(int T, uint32_t Rcap, const HgsImage& im, const HgsBinning& b, uint16_t* bk, int bk_cap) {
+__device__ __forceinline__ void work_list_block(int T, uint32_t Rcap, HgsSegPolicy pol, const HgsImage& im, const HgsBinning& b, uint16_t* bk, int bk_cap) {
   __shared__ uint32_t hist[ORD_BUCKETS], obase[ORD_BUCKETS], wsum[HGS_BLOCK / 64], nsplit_items, nsplit_tiles;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   for (int i = tid; i < ORD_BUCKETS; i += HGS_BLOCK) hist[i] = 0u;
   if (tid == 0) { nsplit_items = 0u; nsplit_tiles = 0u; }
-  const uint32_t S = hgs_segment_length(im.status[HGS_ST_R]);
+  const uint32_t S = hgs_segment_length(im.status[HGS_ST_R], pol);
   const uint32_t seg_cap = b.seg_cap;
   __syncthreads();
   constexpr int SPLIT_BUCKET = 0xFFFF;
@@ -251,11 +249,12 @@ __device__ __forceinline__ void add_lower_bounds(const uint64_t* sk, uint32_t cn
 }
 
 // grid: [0] work list, [1, T] one workgroup per tile, (T, ...) one workgroup per chunk work item of a long list
-__global__ __launch_bounds__(HGS_BLOCK) void sort_tiles_kernel(int gx, int T, uint32_t Rcap, EmitCtx ec, HgsGeom g, HgsImage im,
+template <bool EXTRA>
+__global__ __launch_bounds__(HGS_BLOCK) void sort_tiles_kernel(int gx, int T, uint32_t Rcap, HgsSegPolicy pol, HgsGeom g, HgsImage im,
                                                                HgsBinning b) {
   __shared__ uint64_t sk[SORT_CAP];
   constexpr int KPT = SORT_CAP / HGS_BLOCK;
-  if (blockIdx.x == 0) { work_list_block(T, Rcap, im, b, (uint16_t*)sk, SORT_CAP * 4); return; }
+  if (blockIdx.x == 0) { work_list_block(T, Rcap, pol, im, b, (uint16_t*)sk, SORT_CAP * 4); return; }
   if ((int)blockIdx.x > T) {
     // ---- one chunk of a long list (work items from the scan: hgs_emit_sort_items)
     const uint32_t j = blockIdx.x - (uint32_t)T - 1u;
@@ -305,7 +304,7 @@ __global__ __launch_bounds__(HGS_BLOCK) void sort_tiles_kernel(int gx, int T, ui
 #pragma unroll
     for (int i = 0; i < KPT; i++) {
       const uint32_t e = threadIdx.x + (uint32_t)i * HGS_BLOCK;
-      if (e < cn) emit_instance(key[i], start + rank[i], tx, ty, ec, g, b);
+      if (e < cn) emit_instance<EXTRA>(key[i], start + rank[i], tx, ty, g, b);
     }
     return;
   }
@@ -325,7 +324,7 @@ __global__ __launch_bounds__(HGS_BLOCK) void sort_tiles_kernel(int gx, int T, ui
     __syncthreads();
     bitonic_lds(sk, m);
     if (nchunks == 1) {
-      for (uint32_t i = threadIdx.x; i < cn; i += HGS_BLOCK) emit_instance(sk[i], cbase + i, tx, ty, ec, g, b);
+      for (uint32_t i = threadIdx.x; i < cn; i += HGS_BLOCK) emit_instance<EXTRA>(sk[i], cbase + i, tx, ty, g, b);
     } else {
       for (uint32_t i = threadIdx.x; i < cn; i += HGS_BLOCK) b.keys[cbase + i] = sk[i];
     }
@@ -357,13 +356,23 @@ __global__ __launch_bounds__(HGS_BLOCK) void sort_tiles_kernel(int gx, int T, ui
 #pragma unroll
       for (int i = 0; i < KPT; i++) {
         const uint32_t e = threadIdx.x + (uint32_t)i * HGS_BLOCK;
-        if (e < cn) emit_instance(key[i], start + rank[i], tx, ty, ec, g, b);
+        if (e < cn) emit_instance<EXTRA>(key[i], start + rank[i], tx, ty, g, b);
       }
     }
   }
 }
 
 }  // namespace
+
+static HgsSegPolicy g_seg_policy = {128u, 1024u, 2048u};
+extern "C" int hgs_set_segment_policy(int min_len, int max_len, int target_segments) {
+  if (min_len < 128 || (min_len & 63) || max_len < min_len || (max_len & 63) || target_segments < 1) {
+    hgs_set_error("hgs_set_segment_policy: lengths must be multiples of 64 with 128 <= min <= max, target >= 1");
+    return 1;
+  }
+  g_seg_policy.min_len = (uint32_t)min_len; g_seg_policy.max_len = (uint32_t)max_len; g_seg_policy.target = (uint32_t)target_segments;
+  return 0;
+}
 
 int hgs_launch_scan(hipStream_t s, int P, int T, const HgsGeom& g, const HgsImage& im, unsigned int* max_rendered) {
   const int nblk = (P + HGS_BLOCK - 1) / HGS_BLOCK;
@@ -375,17 +384,19 @@ int hgs_launch_scan(hipStream_t s, int P, int T, const HgsGeom& g, const HgsImag
   return 0;
 }
 
-int hgs_launch_sort_tiles(hipStream_t s, int W, int H, int Rcap, const float* features, const float* extra, int n_extra,
-                          const HgsGeom& g, const HgsImage& im, const HgsBinning& b) {
+int hgs_launch_sort_tiles(hipStream_t s, int W, int H, int Rcap, int n_extra, const HgsGeom& g, const HgsImage& im,
+                          const HgsBinning& b) {
   const int gx = (W + HGS_TILE - 1) / HGS_TILE, gy = (H + HGS_TILE - 1) / HGS_TILE;
   {
     HgsProfScope _prof(s, HGS_K_SORT_TILES);
-    EmitCtx ec = {features, extra, n_extra, (uint32_t)Rcap};
     // chunk work items: at most 2 Rcap / HGS_SORT_CAP (every long list has more than HGS_SORT_CAP entries), and at most T
     const int T = gx * gy;
     const long long items = 2ll * Rcap / HGS_SORT_CAP + 2;
     const int extra_wgs = (int)(items < T ? items : T);
-    hipLaunchKernelGGL(sort_tiles_kernel, dim3(T + 1 + extra_wgs), dim3(HGS_BLOCK), 0, s, gx, T, (uint32_t)Rcap, ec, g, im, b);
+    if (n_extra)
+      hipLaunchKernelGGL(sort_tiles_kernel<true>, dim3(T + 1 + extra_wgs), dim3(HGS_BLOCK), 0, s, gx, T, (uint32_t)Rcap, g_seg_policy, g, im, b);
+    else
+      hipLaunchKernelGGL(sort_tiles_kernel<false>, dim3(T + 1 + extra_wgs), dim3(HGS_BLOCK), 0, s, gx, T, (uint32_t)Rcap, g_seg_policy, g, im, b);
   }
   HGS_CHECK_LAUNCH();
   return 0;

@@ -440,8 +440,7 @@ __global__ __launch_bounds__(HGS_BLOCK) __attribute__((amdgpu_waves_per_eu(HGS_B
     // This pixel has contributors behind this segment.  The serial walk would arrive here with T = the transmittance in
     // front of the next segment and accum_rec = (colour blended behind) / T: both were left by the forward (seg_T of the
     // next segment; seg_C holds, after the tile's finalisation, the colour of a segment and everything behind it).
-    const size_t nslot = ((size_t)it.w + 1) * HGS_BLOCK + threadIdx.x;
-    const float Tn = bn.seg_T[nslot];
+    const float Tn = bn.seg_T[((size_t)it.w + 1) * HGS_BLOCK + threadIdx.x];
     float d = 0.f, d_rgb = 0.f;
 #pragma unroll
     for (int k = 0; k < C; k++) {

@@ -30,6 +30,10 @@ struct HgsRect {        // 16 B per Gaussian: tile rectangle + exclusive instanc
 struct HgsGeom {
   float* depths; uint8_t* clamped; float2* means2D; float* cov3D; float4* conic_opacity; float* rgb;
   uint32_t* tiles_touched; uint32_t* point_offsets; HgsRect* rect; uint32_t* block_sums;
+  // 64 B per Gaussian, everything an instance record needs, assembled once by the scatter kernel so that the sort kernel's
+  // emission is ONE contiguous gather per instance instead of five scattered ones:
+  //   [x, y, conic a, b | conic c, opacity, f0, f1 | f2, extra0..2 | extra3, offset, x0 | y0 << 16, width of the rectangle]
+  float4* grec;
 };
 struct HgsImage {
   float* final_T; uint32_t* n_contrib; uint2* ranges; uint32_t* tile_count; uint32_t* tile_cursor;
@@ -60,7 +64,7 @@ enum { HGS_ST_R = 0, HGS_ST_OVERFLOW = 1, HGS_ST_SCANPTR_LO = 2, HGS_ST_SCANPTR_
 #define HGS_ITEM_TILE(it) ((it) & 0xFFFFFFu)
 #define HGS_ITEM_PART(it) ((it) >> 24)
 #define HGS_MAX_TILES (1u << 24)
-static inline uint32_t hgs_seg_capacity(size_t R) { return R ? (uint32_t)(R / 128 + 2) : 0u; }
+static inline uint32_t hgs_seg_capacity(size_t R) { return R ? (uint32_t)(R / 64 + 2) : 0u; }      // segments >= 128 entries, < 2 R / 128 of them
 
 static inline size_t hgs_align_up(size_t v) { return (v + HGS_ALIGN - 1) & ~(size_t)(HGS_ALIGN - 1); }
 
@@ -84,6 +88,7 @@ static inline size_t hgs_geom_carve(char* base, size_t P, HgsGeom& g, size_t* of
   hgs_carve(cur, g.point_offsets, P);       if (offs) offs[HGS_GEOM_POINT_OFFSETS] = (char*)g.point_offsets - base;
   hgs_carve(cur, g.rect, P);                if (offs) offs[HGS_GEOM_RECT] = (char*)g.rect - base;
   hgs_carve(cur, g.block_sums, nblk + 1);   if (offs) offs[HGS_GEOM_BLOCK_SUMS] = (char*)g.block_sums - base;
+  hgs_carve(cur, g.grec, 4 * P);
   return hgs_align_up((size_t)(cur - base)) + HGS_ALIGN;
 }
 static inline size_t hgs_image_zero_words(size_t T) { return 4 * T + HGS_STATUS_WORDS + 4 * T; }
@@ -225,10 +230,10 @@ struct HgsFwdArgs {
 #define HGS_FUSED_SCAN_MAX_T 11776   // tiles whose offsets fit the scatter kernel's LDS (47.4 KB with padding); 1080p has 8160
 int hgs_launch_preprocess_fwd(hipStream_t s, const HgsFwdArgs& a, const HgsGeom& g, const HgsImage& im, int* radii);
 int hgs_launch_scan(hipStream_t s, int P, int T, const HgsGeom& g, const HgsImage& im, unsigned int* max_rendered);
-int hgs_launch_scatter(hipStream_t s, int P, int W, int H, int Rcap, const int* radii, const HgsGeom& g,
-                       const HgsImage& im, const HgsBinning& b);
-int hgs_launch_sort_tiles(hipStream_t s, int W, int H, int Rcap, const float* features, const float* extra, int n_extra,
-                          const HgsGeom& g, const HgsImage& im, const HgsBinning& b);
+int hgs_launch_scatter(hipStream_t s, int P, int W, int H, int Rcap, const float* features, const float* extra, int n_extra,
+                       const HgsGeom& g, const HgsImage& im, const HgsBinning& b);
+int hgs_launch_sort_tiles(hipStream_t s, int W, int H, int Rcap, int n_extra, const HgsGeom& g, const HgsImage& im,
+                          const HgsBinning& b);
 int hgs_launch_blend_fwd(hipStream_t s, int W, int H, int Rcap, int channels, const float* bg, const HgsImage& im,
                          const HgsBinning& b, float* out_color);
 int hgs_launch_blend_bwd(hipStream_t s, int W, int H, int Rcap, int channels, const float* bg, const HgsImage& im,
@@ -277,10 +282,11 @@ __device__ __forceinline__ bool hgs_wait_parts(const unsigned long long* mask, u
   return false;
 }
 // segment length of the split blend for a pass with R instances: long lists are cut so that the pass has on the order
-// of 2048 segments, within [256, 1024] entries (multiples of the 64-entry staging batch)
-__device__ __forceinline__ uint32_t hgs_segment_length(uint32_t R) {
-  const uint32_t s = ((R / 2048u) + 63u) & ~63u;
-  return s < 256u ? 256u : (s > 1024u ? 1024u : s);
+// of `target` segments, within [min_len, max_len] entries (multiples of the 64-entry staging batch); hgs_set_segment_policy
+struct HgsSegPolicy { uint32_t min_len, max_len, target; };
+__device__ __forceinline__ uint32_t hgs_segment_length(uint32_t R, const HgsSegPolicy& p) {
+  const uint32_t s = ((R / p.target) + 63u) & ~63u;
+  return s < p.min_len ? p.min_len : (s > p.max_len ? p.max_len : s);
 }
 struct HgsSplit { uint32_t nseg, seglen; };   // nseg == 1: the list is walked by one workgroup
 __device__ __forceinline__ HgsSplit hgs_split_of(uint32_t n, uint32_t S) {

@@ -315,205 +315,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// Fused SSIM/L1 value + image gradient for a KNOWN upstream gradient (the loss head in training: dL/dSSIM-mean and
-// dL/dL1-mean are constants of the loss weights, so the gradient does not have to wait for the value).
-// The two-kernel form stores three derivative maps per pixel and channel (75 MB at 1080p) and reads them back with halos:
-// its forward is bound by that traffic (30 of 42 us remain with both filter passes removed), its backward by reading it.
-// Here one workgroup computes, for a 32x32 output block, the maps on the 42x42 pixels its gradient needs (from a 52x52
-// pixel tile of both images), keeps them in LDS, and filters them again: nothing but the two images is read, nothing but
-// the gradient and two partial sums per block is written.  1.43 x the multiply-adds, a quarter of the bytes.
-// MEASURED (1080p, north_star): 118 us against 42 + 40 us for the two kernels -- 61 KB of LDS leave two workgroups (two
-// waves per SIMD) per CU, and five barriers per block with that little to switch to cost more than the bytes saved.  Kept
-// behind hgs_loss_head_forward(d_image_unit) (FusedStrandStep.fused_ssim, off) and tested; a version that filters two of
-// the four maps at a time (42 KB, three workgroups) is the next thing to try (512 threads per workgroup instead of 256, for
-// four waves per SIMD with the same LDS, took 146 us).
-//   LDS: t[2][52][57] (images; later m[3][42][45], the maps) | hz[4][52][45] (row-filtered; later hz2[3][42][33])
-// Tile row r <-> image y = by0 - 10 + r, tile column c <-> x = bx0 - 12 + c (16-byte aligned chunks);
-// map row my <-> y = by0 - 5 + my, map column mx <-> x = bx0 - 5 + mx.
-#define F_T (LT + 4 * HALO)      // 52 tile rows
-#define F_XOFF 12
-#define F_TW (LT + 2 * F_XOFF)   // 56 staged columns
-#define F_TPW (F_TW + 1)
-#define F_MH (LT + 2 * HALO)     // 42 map rows
-#define F_MW 44                  // map columns computed (42 needed; 4-column items)
-#define F_MPW (F_MW + 1)
-#define F_F4 (F_T * (F_TW / 4))  // 728 float4 per image tile
-#define SSIM_FUSED_WG_PER_XCD 64 // 32 CUs x 2 resident workgroups (61 KB LDS each)
-struct FusedStage { float4 v[2][3]; };
-__device__ __forceinline__ void fused_stage_load(FusedStage& st, int H, int W, int bx0, int by0, const float* p0, const float* p1) {
-#pragma unroll
-  for (int u = 0; u < 3; u++) {
-    const int i = threadIdx.x + 256 * u;
-    const int r = i / (F_TW / 4), c4 = (i - r * (F_TW / 4)) * 4;
-    const int y = by0 + r - 2 * HALO, x = bx0 - F_XOFF + c4;
-    const bool in = i < F_F4 && (unsigned)y < (unsigned)H && x >= 0 && x < W;
-    st.v[0][u] = st.v[1][u] = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (in) { st.v[0][u] = *(const float4*)(p0 + (size_t)y * W + x); st.v[1][u] = *(const float4*)(p1 + (size_t)y * W + x); }
-  }
-}
-__global__ __launch_bounds__(256) void ssim_l1_fused_kernel(int H, int W, SsimGrid gd, SsimWin win, const float* __restrict__ img1,
-                                                            const HgsViewTargets* __restrict__ tgt, float g_ssim, float g_l1,
-                                                            float* __restrict__ dimg1, float* __restrict__ partials) {
-  __shared__ float lds_a[2 * F_T * F_TPW];          // t[2][F_T][F_TPW], then m[3][F_MH][F_MPW]
-  __shared__ float lds_b[4 * F_T * F_MPW];          // hz[4][F_T][F_MPW], then hz2[3][F_MH][HP]
-  __shared__ float red[4];
-  static_assert(3 * F_MH * F_MPW <= 2 * F_T * F_TPW && 3 * F_MH * HP <= 4 * F_T * F_MPW, "aliased buffers");
-  float (*t)[F_T][F_TPW] = (float (*)[F_T][F_TPW])lds_a;
-  float (*m)[F_MH][F_MPW] = (float (*)[F_MH][F_MPW])lds_a;
-  float (*hz)[F_T][F_MPW] = (float (*)[F_T][F_MPW])lds_b;
-  float (*hz2)[F_MH][HP] = (float (*)[F_MH][HP])lds_b;
-  const float* img2 = tgt->image;
-  const size_t plane = (size_t)H * W;
-  const float n = 1.f / (float)((size_t)gd.C * plane);
-  const float gs = g_ssim * n, gl = g_l1 * n;
-  const int nwg = gridDim.x >> 3;
-  const int lx = threadIdx.x & (LT - 1), y0 = (threadIdx.x >> 5) * 4;
-  const float C1 = 0.01f * 0.01f, C2 = 0.03f * 0.03f;
-  int j = blockIdx.x >> 3;
-  SsimBlock bk, nx;
-  bool have = ssim_block(gd, j, bk);
-  FusedStage st;
-  if (have) fused_stage_load(st, H, W, bk.bx0, bk.by0, img1 + bk.c * plane, img2 + bk.c * plane);
-  while (have) {
-    // ---- tile -> LDS; is anything in it non-zero?
-    int nz = 0;
-#pragma unroll
-    for (int u = 0; u < 3; u++) {
-      const int i = threadIdx.x + 256 * u;
-      if (i < F_F4) {
-        const int r = i / (F_TW / 4), c4 = (i - r * (F_TW / 4)) * 4;
-#pragma unroll
-        for (int p = 0; p < 2; p++) {
-          const float4 v = st.v[p][u];
-          t[p][r][c4] = v.x; t[p][r][c4 + 1] = v.y; t[p][r][c4 + 2] = v.z; t[p][r][c4 + 3] = v.w;
-          nz |= (v.x != 0.f) | (v.y != 0.f) | (v.z != 0.f) | (v.w != 0.f);
-        }
-      }
-    }
-    const int any_nz = __syncthreads_or(nz);
-    j += nwg;
-    const bool have_next = ssim_block(gd, j, nx);
-    if (have_next) fused_stage_load(st, H, W, nx.bx0, nx.by0, img1 + nx.c * plane, img2 + nx.c * plane);
-    const int px = bk.bx0 + lx;
-    float ssim_v = 0.f, l1_v = 0.f;
-    float out[4] = {0.f, 0.f, 0.f, 0.f};
-    if (any_nz) {
-      // own pixels of both images (L1 term, final formula): out of the tile while it is still there
-      float x1[4], x2[4];
-#pragma unroll
-      for (int o = 0; o < 4; o++) {
-        x1[o] = t[0][y0 + o + 2 * HALO][lx + F_XOFF]; x2[o] = t[1][y0 + o + 2 * HALO][lx + F_XOFF];
-        if (px < W && bk.by0 + y0 + o < H) l1_v += fabsf(x1[o] - x2[o]);
-      }
-      // ---- pass 1, rows: hz[q][r][mx] = sum_tap w[tap] * v_q(t[.][r][mx + 2 + tap]);  v = (x1, x2, x1^2 + x2^2, x1 x2)
-      for (int it = threadIdx.x; it < F_T * (F_MW / 4); it += 256) {
-        const int r = it / (F_MW / 4), mx0 = (it - r * (F_MW / 4)) * 4;
-        float acc[4][4];
-#pragma unroll
-        for (int q = 0; q < 4; q++)
-#pragma unroll
-          for (int o = 0; o < 4; o++) acc[q][o] = 0.f;
-#pragma unroll
-        for (int k = 0; k < 14; k++) {
-          const float a = t[0][r][mx0 + 2 + k], b = t[1][r][mx0 + 2 + k];
-          const float v[4] = {a, b, a * a + b * b, a * b};
-#pragma unroll
-          for (int o = 0; o < 4; o++) {
-            const int tap = k - o;
-            if (tap >= 0 && tap < 11) {
-#pragma unroll
-              for (int q = 0; q < 4; q++) acc[q][o] += win.w[tap] * v[q];
-            }
-          }
-        }
-#pragma unroll
-        for (int q = 0; q < 4; q++)
-#pragma unroll
-          for (int o = 0; o < 4; o++) hz[q][r][mx0 + o] = acc[q][o];
-      }
-      __syncthreads();
-      // ---- pass 1, columns + the derivative maps of the 42 x 44 pixels (zero outside the image: nothing there has an S)
-      for (int it = threadIdx.x; it < F_MW * ((F_MH + 3) / 4); it += 256) {
-        const int g4 = it / F_MW, mx = it - g4 * F_MW, my0 = g4 * 4;
-        float f[4][4];
-#pragma unroll
-        for (int q = 0; q < 4; q++)
-#pragma unroll
-          for (int o = 0; o < 4; o++) f[q][o] = 0.f;
-#pragma unroll
-        for (int k = 0; k < 14; k++) {
-          if (my0 + k < F_T) {
-#pragma unroll
-            for (int q = 0; q < 4; q++) {
-              const float v = hz[q][my0 + k][mx];
-#pragma unroll
-              for (int o = 0; o < 4; o++) {
-                const int tap = k - o;
-                if (tap >= 0 && tap < 11) f[q][o] += win.w[tap] * v;
-              }
-            }
-          }
-        }
-#pragma unroll
-        for (int o = 0; o < 4; o++) {
-          const int my = my0 + o;
-          if (my >= F_MH) break;
-          const int y = bk.by0 - HALO + my, x = bk.bx0 - HALO + mx;
-          float ma = 0.f, mb = 0.f, mc = 0.f;
-          if ((unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W) {
-            const float mu1 = f[0][o], mu2 = f[1][o];
-            const float mu1_sq = mu1 * mu1, mu2_sq = mu2 * mu2, mu12 = mu1 * mu2;
-            const float s_sum = f[2][o] - (mu1_sq + mu2_sq), s12 = f[3][o] - mu12;
-            const float A1 = 2.f * mu12 + C1, A2 = 2.f * s12 + C2, B1 = mu1_sq + mu2_sq + C1, B2 = s_sum + C2;
-            const float iB1 = __builtin_amdgcn_rcpf(B1), iB2 = __builtin_amdgcn_rcpf(B2);
-            const float inv = iB1 * iB2;
-            const float S = (A1 * A2) * inv;                                 // losses.py:71-73
-            ma = 2.f * mu2 * (A2 - A1) * inv - S * (2.f * mu1 * iB1 - 2.f * mu1 * iB2);   // dS/dmu1 at fixed E11, E12
-            mb = -S * iB2;                                                                 // dS/dE11
-            mc = 2.f * A1 * inv;                                                           // dS/dE12
-            if (my >= HALO && my < HALO + LT && mx >= HALO && mx < HALO + LT) ssim_v += S; // this block's own pixels
-          }
-          m[0][my][mx] = ma; m[1][my][mx] = mb; m[2][my][mx] = mc;        // (m overlays t: its last reader was pass 1)
-        }
-      }
-      __syncthreads();
-      // ---- pass 2, rows: hz2[q][my][ox] = sum_tap w[tap] m[q][my][ox + tap]   (hz2 overlays hz)
-      row_pass<3>(win, (float (*)[TILE][HP])hz2, [&](int r, int x, float* v) {
-        v[0] = m[0][r][x]; v[1] = m[1][r][x]; v[2] = m[2][r][x];
-      });
-      __syncthreads();
-      float f2[3][4];
-      col_pass<3>(win, (float (*)[TILE][HP])hz2, lx, y0, f2);
-#pragma unroll
-      for (int o = 0; o < 4; o++) {
-        const float d = x1[o] - x2[o];
-        const float sgn = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
-        out[o] = gs * (f2[0][o] + 2.f * x1[o] * f2[1][o] + x2[o] * f2[2][o]) + gl * sgn;
-      }
-    } else {
-      // exactly zero tile: S is the same constant on every pixel, the gradient is zero
-      const float inv = __builtin_amdgcn_rcpf(C1) * __builtin_amdgcn_rcpf(C2);
-      const float S0 = (C1 * C2) * inv;
-#pragma unroll
-      for (int o = 0; o < 4; o++)
-        if (px < W && bk.by0 + y0 + o < H) ssim_v += S0;
-    }
-#pragma unroll
-    for (int o = 0; o < 4; o++) {
-      const int py = bk.by0 + y0 + o;
-      if (px < W && py < H) dimg1[bk.c * plane + (size_t)py * W + px] = out[o];
-    }
-    const float bs = block_sum(ssim_v, red);
-    const float bl = block_sum(l1_v, red);
-    if (threadIdx.x == 0) {
-      partials[2 * (size_t)bk.logical] = bs;
-      partials[2 * (size_t)bk.logical + 1] = bl;
-    }
-    __syncthreads();   // the LDS buffers are rewritten by the next block of this workgroup
-    bk = nx;
-    have = have_next;
-  }
-}
 
 __global__ __launch_bounds__(256) void ssim_l1_bwd_kernel(int H, int W, SsimGrid gd, SsimWin win, const float* __restrict__ img1,
                                                           const float* __restrict__ img2_, const HgsViewTargets* __restrict__ tgt,
@@ -1061,7 +862,7 @@ size_t hgs_loss_head_scratch_floats(const HgsHeadParams* p) {
 int hgs_loss_head_forward(void* stream, const HgsHeadParams* p, const float* image, const float* mask_img,
                           const float* omap, const HgsViewTargets* targets, const float* endpoints,
                           const long long* smooth_pairs, float* scratch, float* out, float* d_extra_unit,
-                          const float* smooth_partials_ext, float* d_image_unit) {
+                          const float* smooth_partials_ext) {
   if (!p || !image || !mask_img || !omap || !targets || !scratch || !out || p->H <= 0 || p->W <= 0) {
     hgs_set_error("hgs_loss_head_forward: bad arguments");
     return 1;
@@ -1076,15 +877,8 @@ int hgs_loss_head_forward(void* stream, const HgsHeadParams* p, const float* ima
   SsimWin win;
   for (int k = 0; k < 11; k++) win.w[k] = p->window[k];
   hipStream_t s = (hipStream_t)stream;
-  // d_image_unit: the SSIM/L1 value AND dL/d(image) for grad_out = 1 in one kernel (ssim_l1_fused_kernel); no derivative
-  // maps, block flags or block lists exist then.  (Rows that are not float4-aligned keep the two-kernel form.)
-  const bool fused_ssim = d_image_unit != nullptr && (W & 3) == 0;
-  int* lists = fused_ssim ? nullptr : head_block_lists(p, scratch);
-  if (fused_ssim) {
-    HgsProfScope _prof(s, HGS_K_SSIM_FWD);
-    hipLaunchKernelGGL(ssim_l1_fused_kernel, dim3(ssim_grid_size(ssim_grid(3, H, W), SSIM_FUSED_WG_PER_XCD)), dim3(256), 0, s, H, W,
-                       ssim_grid(3, H, W), win, image, targets, -p->lambda_dssim, fmaxf(0.f, 1.f - p->lambda_dssim), d_image_unit, p_ssim);
-  } else {
+  int* lists = head_block_lists(p, scratch);
+  {
     HgsProfScope _prof(s, HGS_K_SSIM_FWD);
     hipLaunchKernelGGL(ssim_l1_fwd_kernel, dim3(ssim_grid_size(ssim_grid(3, H, W), SSIM_FWD_WG_PER_XCD)), dim3(256), 0, s, H, W, ssim_grid(3, H, W), win, image,
                        (const float*)nullptr, targets, dmaps, p_ssim, lists ? head_zero_flags(p, scratch) : nullptr);
@@ -1131,11 +925,7 @@ int hgs_loss_head_backward(void* stream, const HgsHeadParams* p, const float* im
   SsimWin win;
   for (int k = 0; k < 11; k++) win.w[k] = p->window[k];
   hipStream_t s = (hipStream_t)stream;
-  if (skip & HGS_HEAD_SKIP_SSIM) {
-    // d_image already holds what the forward's fused kernel wrote (times grad_out, the caller's business); only the
-    // endpoint-gradient buffer still has to be cleared for the smoothness scatter
-    if (d_endpoints && hgs_zero_async(s, d_endpoints, (size_t)p->n_endpoints * 3 * sizeof(float))) return 1;
-  } else {
+  {
     HgsProfScope _prof(s, HGS_K_SSIM_BWD);
     hipLaunchKernelGGL(ssim_l1_bwd_kernel, dim3(ssim_grid_size(ssim_grid(3, H, W), SSIM_BWD_WG_PER_XCD)), dim3(256), 0, s, H, W, ssim_grid(3, H, W), win, image,
                        (const float*)nullptr, targets, dmaps, out + HGS_HEAD_G_SSIM, out + HGS_HEAD_G_L1, grad_out, d_image,

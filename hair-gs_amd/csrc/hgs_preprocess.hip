@@ -290,8 +290,9 @@ __global__ __launch_bounds__(HGS_BLOCK) void preprocess_fwd_kernel(HgsFwdArgs a,
 // 9-11 us between two grid-wide kernels; here EVERY workgroup scans the T tile counts itself (32 loads per thread at
 // 1080p, all L2 hits, offsets kept in LDS) and sums the block sums before it; workgroup 0 also publishes `ranges`, the
 // instance count and its sticky maximum.  Same integers either way.
-__global__ __launch_bounds__(HGS_BLOCK) void scatter_kernel(int P, int gx, int T, uint32_t Rcap, const int* radii, HgsGeom g,
-                                                            HgsImage im, HgsBinning b) {
+__global__ __launch_bounds__(HGS_BLOCK) void scatter_kernel(int P, int gx, int T, uint32_t Rcap, const float* __restrict__ feat,
+                                                            const float* __restrict__ extra, HgsGeom g, HgsImage im,
+                                                            HgsBinning b) {
   extern __shared__ uint32_t tile_off[];   // [T] in the fused-scan mode (dynamic), empty otherwise
   __shared__ uint32_t wsum[4];
   __shared__ TileHash th;
@@ -314,7 +315,19 @@ __global__ __launch_bounds__(HGS_BLOCK) void scatter_kernel(int P, int gx, int T
   }
   const uint32_t n = idx < P ? g.tiles_touched[idx] : 0;
   HgsRect rc = {0, 0, 0, 0, 0, 0};
-  if (idx < P) rc = g.rect[idx];
+  // this lane's Gaussian: loaded now, with everything else the prologue needs, used after the scans (for a culled
+  // Gaussian these slots hold whatever the previous pass left: never used, n == 0)
+  float2 xy = make_float2(0.f, 0.f);
+  float4 co = make_float4(0.f, 0.f, 0.f, 0.f), ex = make_float4(0.f, 0.f, 0.f, 0.f);
+  float depth = 0.f, f0 = 0.f, f1 = 0.f, f2 = 0.f;
+  if (idx < P) {
+    rc = g.rect[idx];
+    xy = g.means2D[idx];
+    co = g.conic_opacity[idx];
+    depth = g.depths[idx];
+    f0 = feat[3 * (size_t)idx]; f1 = feat[3 * (size_t)idx + 1]; f2 = feat[3 * (size_t)idx + 2];
+    if (extra) ex = ((const float4*)extra)[idx];
+  }
   uint32_t blk_base = 0;
   if (fused) {
     // counts -> LDS, then every thread scans ITS run of consecutive tiles out of LDS (rows padded by one word per 32: a
@@ -382,9 +395,16 @@ __global__ __launch_bounds__(HGS_BLOCK) void scatter_kernel(int P, int gx, int T
   __syncthreads();
   if (n == 0) return;
   // pass 2: place the keys (order inside a tile's segment is irrelevant: the per-tile sort key is unique)
-  const uint64_t key0 = ((uint64_t)__float_as_uint(g.depths[idx]) << 32) | ((uint32_t)idx << HGS_QMASK_SHIFT);
-  const float2 xy = g.means2D[idx];
-  const float4 co = g.conic_opacity[idx];
+  const uint64_t key0 = ((uint64_t)__float_as_uint(depth) << 32) | ((uint32_t)idx << HGS_QMASK_SHIFT);
+  {
+    // this Gaussian's instance-record template (HgsGeom::grec), read back once per instance by the sort kernel
+    float4* rec = g.grec + 4 * (size_t)idx;
+    rec[0] = make_float4(xy.x, xy.y, co.x, co.y);
+    rec[1] = make_float4(co.z, co.w, f0, f1);
+    rec[2] = make_float4(f2, ex.x, ex.y, ex.z);
+    rec[3] = make_float4(ex.w, __uint_as_float(rc.off), __uint_as_float((uint32_t)rc.x0 | ((uint32_t)rc.y0 << 16)),
+                         __uint_as_float((uint32_t)(rc.x1 - rc.x0)));
+  }
   const HgsQuadCull qc = hgs_quad_cull(co);
   for (int ty = rc.y0; ty < rc.y1; ty++)
     for (int tx = rc.x0; tx < rc.x1; tx++) {
@@ -409,16 +429,20 @@ __device__ __forceinline__ V3 dnormvdv(V3 v, V3 dv) {  // auxiliary.h:107-117
   return r;
 }
 
+// DC_ONLY: the strand / Stage-I default -- SH degree 0 with one stored coefficient (or precomputed colours): the
+// view-dependent SH code is compiled out (136 -> fewer registers for a kernel that lives on its occupancy).
+template <bool DC_ONLY>
 __global__ __launch_bounds__(HGS_BLOCK) void preprocess_bwd_kernel(HgsBwdArgs a, HgsGeom g, HgsBinning b,
                                                                    const float* __restrict__ inst_grad, uint32_t Rcap,
                                                                    const uint32_t* __restrict__ status) {
   const int idx = blockIdx.x * HGS_BLOCK + threadIdx.x;
   if (idx >= a.P) return;
+  const int D = DC_ONLY ? 0 : a.D;
   // A forward that overflowed its binning capacity (status[1]) dropped instances: their rows of the scratch were never
   // written.  Such a pass is void; its backward returns EXACTLY ZERO for every gradient (deterministic, finite) and the
   // caller repeats the step with a larger capacity (include/hgs.h).
   const bool void_pass = status[HGS_ST_OVERFLOW] != 0u;
-  const int M = a.M;
+  const int M = DC_ONLY ? 1 : a.M;
   float dmx = 0.f, dmy = 0.f, dcx = 0.f, dcy = 0.f, dcw = 0.f, dop = 0.f, dcol[3] = {0.f, 0.f, 0.f};
   float dex[4] = {0.f, 0.f, 0.f, 0.f}, dmx_rgb = 0.f, dmy_rgb = 0.f;
   float dmean[3] = {0.f, 0.f, 0.f}, dcov[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -481,46 +505,43 @@ __global__ __launch_bounds__(HGS_BLOCK) void preprocess_bwd_kernel(HgsBwdArgs a,
     cov2d(mean, h_x, h_y, a.tan_fovx, a.tan_fovy, cov3, a.viewmatrix, c);
     const float x_grad_mul = (c.txtz < -c.limx || c.txtz > c.limx) ? 0.f : 1.f;
     const float y_grad_mul = (c.tytz < -c.limy || c.tytz > c.limy) ? 0.f : 1.f;
+    // cov2D = [[A, B], [B, Cc]] = (t0 V t0, t0 V t1; ., t1 V t1) with V = Vrk (symmetric) and t0, t1 the two vectors
+    // T_(0, .), T_(1, .) of the projection T = W J.  Everything below is that bilinear form differentiated:
+    //   dL/dcov2D from dL/dconic (conic = cov2D^-1; the reference's regularised 1 / (det^2 + 1e-7), :206-214)
+    //   dL/dV    = da t0 t0^T + db/2 (t0 t1^T + t1 t0^T) + dc t1 t1^T      (off-diagonal entries count twice, :216-232)
+    //   dL/dt0   = 2 da V t0 + db V t1,   dL/dt1 = 2 dc V t1 + db V t0     (:237-249; V t0 and V t1 evaluated once each)
+    //   dL/dJ    = rows of W against those two vectors                      (:251-255)
     const float A = c.a, B = c.b, Cc = c.c;
     const float denom = A * Cc - B * B;
-    float dL_da = 0, dL_db = 0, dL_dc = 0;
     const float denom2inv = 1.0f / ((denom * denom) + 0.0000001f);
-#define T_(i, j) c.T.m[i][j]
-#define V_(i, j) c.Vrk.m[i][j]
-#define W_(i, j) c.W.m[i][j]
+    const float t0[3] = {c.T.m[0][0], c.T.m[0][1], c.T.m[0][2]}, t1[3] = {c.T.m[1][0], c.T.m[1][1], c.T.m[1][2]};
+    float dL_da = 0.f, dL_db = 0.f, dL_dc = 0.f;
     if (denom2inv != 0) {
       dL_da = denom2inv * (-Cc * Cc * dcx + 2 * B * Cc * dcy + (denom - A * Cc) * dcw);
       dL_dc = denom2inv * (-A * A * dcw + 2 * A * B * dcy + (denom - A * Cc) * dcx);
       dL_db = denom2inv * 2 * (B * Cc * dcx - (denom + 2 * B * B) * dcy + A * B * dcw);
-      dcov[0] = (T_(0, 0) * T_(0, 0) * dL_da + T_(0, 0) * T_(1, 0) * dL_db + T_(1, 0) * T_(1, 0) * dL_dc);
-      dcov[3] = (T_(0, 1) * T_(0, 1) * dL_da + T_(0, 1) * T_(1, 1) * dL_db + T_(1, 1) * T_(1, 1) * dL_dc);
-      dcov[5] = (T_(0, 2) * T_(0, 2) * dL_da + T_(0, 2) * T_(1, 2) * dL_db + T_(1, 2) * T_(1, 2) * dL_dc);
-      dcov[1] = 2 * T_(0, 0) * T_(0, 1) * dL_da + (T_(0, 0) * T_(1, 1) + T_(0, 1) * T_(1, 0)) * dL_db +
-                2 * T_(1, 0) * T_(1, 1) * dL_dc;
-      dcov[2] = 2 * T_(0, 0) * T_(0, 2) * dL_da + (T_(0, 0) * T_(1, 2) + T_(0, 2) * T_(1, 0)) * dL_db +
-                2 * T_(1, 0) * T_(1, 2) * dL_dc;
-      dcov[4] = 2 * T_(0, 2) * T_(0, 1) * dL_da + (T_(0, 1) * T_(1, 2) + T_(0, 2) * T_(1, 1)) * dL_db +
-                2 * T_(1, 1) * T_(1, 2) * dL_dc;
+      constexpr int TRI[6][2] = {{0, 0}, {0, 1}, {0, 2}, {1, 1}, {1, 2}, {2, 2}};   // storage order of the symmetric 3x3
+#pragma unroll
+      for (int k = 0; k < 6; k++) {
+        const int i = TRI[k][0], j = TRI[k][1];
+        const float sym = i == j ? 1.f : 2.f;
+        dcov[k] = sym * t0[i] * t0[j] * dL_da + (i == j ? t0[i] * t1[i] : t0[i] * t1[j] + t0[j] * t1[i]) * dL_db +
+                  sym * t1[i] * t1[j] * dL_dc;
+      }
     }
-    const float dL_dT00 = 2 * (T_(0, 0) * V_(0, 0) + T_(0, 1) * V_(0, 1) + T_(0, 2) * V_(0, 2)) * dL_da +
-                          (T_(1, 0) * V_(0, 0) + T_(1, 1) * V_(0, 1) + T_(1, 2) * V_(0, 2)) * dL_db;
-    const float dL_dT01 = 2 * (T_(0, 0) * V_(1, 0) + T_(0, 1) * V_(1, 1) + T_(0, 2) * V_(1, 2)) * dL_da +
-                          (T_(1, 0) * V_(1, 0) + T_(1, 1) * V_(1, 1) + T_(1, 2) * V_(1, 2)) * dL_db;
-    const float dL_dT02 = 2 * (T_(0, 0) * V_(2, 0) + T_(0, 1) * V_(2, 1) + T_(0, 2) * V_(2, 2)) * dL_da +
-                          (T_(1, 0) * V_(2, 0) + T_(1, 1) * V_(2, 1) + T_(1, 2) * V_(2, 2)) * dL_db;
-    const float dL_dT10 = 2 * (T_(1, 0) * V_(0, 0) + T_(1, 1) * V_(0, 1) + T_(1, 2) * V_(0, 2)) * dL_dc +
-                          (T_(0, 0) * V_(0, 0) + T_(0, 1) * V_(0, 1) + T_(0, 2) * V_(0, 2)) * dL_db;
-    const float dL_dT11 = 2 * (T_(1, 0) * V_(1, 0) + T_(1, 1) * V_(1, 1) + T_(1, 2) * V_(1, 2)) * dL_dc +
-                          (T_(0, 0) * V_(1, 0) + T_(0, 1) * V_(1, 1) + T_(0, 2) * V_(1, 2)) * dL_db;
-    const float dL_dT12 = 2 * (T_(1, 0) * V_(2, 0) + T_(1, 1) * V_(2, 1) + T_(1, 2) * V_(2, 2)) * dL_dc +
-                          (T_(0, 0) * V_(2, 0) + T_(0, 1) * V_(2, 1) + T_(0, 2) * V_(2, 2)) * dL_db;
-    const float dL_dJ00 = W_(0, 0) * dL_dT00 + W_(0, 1) * dL_dT01 + W_(0, 2) * dL_dT02;
-    const float dL_dJ02 = W_(2, 0) * dL_dT00 + W_(2, 1) * dL_dT01 + W_(2, 2) * dL_dT02;
-    const float dL_dJ11 = W_(1, 0) * dL_dT10 + W_(1, 1) * dL_dT11 + W_(1, 2) * dL_dT12;
-    const float dL_dJ12 = W_(2, 0) * dL_dT10 + W_(2, 1) * dL_dT11 + W_(2, 2) * dL_dT12;
-#undef T_
-#undef V_
-#undef W_
+    float Vt0[3], Vt1[3], g0[3], g1[3];
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+      Vt0[j] = t0[0] * c.Vrk.m[j][0] + t0[1] * c.Vrk.m[j][1] + t0[2] * c.Vrk.m[j][2];
+      Vt1[j] = t1[0] * c.Vrk.m[j][0] + t1[1] * c.Vrk.m[j][1] + t1[2] * c.Vrk.m[j][2];
+    }
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+      g0[j] = 2 * Vt0[j] * dL_da + Vt1[j] * dL_db;
+      g1[j] = 2 * Vt1[j] * dL_dc + Vt0[j] * dL_db;
+    }
+    auto w_row = [&](int r, const float (&g)[3]) { return c.W.m[r][0] * g[0] + c.W.m[r][1] * g[1] + c.W.m[r][2] * g[2]; };
+    const float dL_dJ00 = w_row(0, g0), dL_dJ02 = w_row(2, g0), dL_dJ11 = w_row(1, g1), dL_dJ12 = w_row(2, g1);
     const float tz = 1.f / c.t.z, tz2 = tz * tz, tz3 = tz2 * tz;
     const float dL_dtx = x_grad_mul * -h_x * tz2 * dL_dJ02;
     const float dL_dty = y_grad_mul * -h_y * tz2 * dL_dJ12;
@@ -555,7 +576,7 @@ __global__ __launch_bounds__(HGS_BLOCK) void preprocess_bwd_kernel(HgsBwdArgs a,
 #define SHC(k, ch) sh[3 * (k) + (ch)]
 #define DSH(k, coef) { const float cf_ = (coef); dsh[3 * (k)] = cf_ * dRGB[0]; dsh[3 * (k) + 1] = cf_ * dRGB[1]; dsh[3 * (k) + 2] = cf_ * dRGB[2]; }
       DSH(0, kSH_C0);
-      if (a.D > 0) {
+      if (D > 0) {
         DSH(1, -kSH_C1 * y); DSH(2, kSH_C1 * z); DSH(3, -kSH_C1 * x);
 #pragma unroll
         for (int ch = 0; ch < 3; ch++) {
@@ -563,7 +584,7 @@ __global__ __launch_bounds__(HGS_BLOCK) void preprocess_bwd_kernel(HgsBwdArgs a,
           ddy[ch] = -kSH_C1 * SHC(1, ch);
           ddz[ch] = kSH_C1 * SHC(2, ch);
         }
-        if (a.D > 1) {
+        if (D > 1) {
           const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
           DSH(4, kSH_C2[0] * xy); DSH(5, kSH_C2[1] * yz); DSH(6, kSH_C2[2] * (2.f * zz - xx - yy));
           DSH(7, kSH_C2[3] * xz); DSH(8, kSH_C2[4] * (xx - yy));
@@ -575,7 +596,7 @@ __global__ __launch_bounds__(HGS_BLOCK) void preprocess_bwd_kernel(HgsBwdArgs a,
                        kSH_C2[4] * 2.f * -y * SHC(8, ch);
             ddz[ch] += kSH_C2[1] * y * SHC(5, ch) + kSH_C2[2] * 2.f * 2.f * z * SHC(6, ch) + kSH_C2[3] * x * SHC(7, ch);
           }
-          if (a.D > 2) {
+          if (D > 2) {
             DSH(9, kSH_C3[0] * y * (3.f * xx - yy)); DSH(10, kSH_C3[1] * xy * z);
             DSH(11, kSH_C3[2] * y * (4.f * zz - xx - yy)); DSH(12, kSH_C3[3] * z * (2.f * zz - 3.f * xx - 3.f * yy));
             DSH(13, kSH_C3[4] * x * (4.f * zz - xx - yy)); DSH(14, kSH_C3[5] * z * (xx - yy));
@@ -598,7 +619,7 @@ __global__ __launch_bounds__(HGS_BLOCK) void preprocess_bwd_kernel(HgsBwdArgs a,
         }
       }
       // coefficients above the active degree receive zero gradient
-      for (int k = (a.D + 1) * (a.D + 1); k < M; k++) { dsh[3 * k] = 0.f; dsh[3 * k + 1] = 0.f; dsh[3 * k + 2] = 0.f; }
+      for (int k = (D + 1) * (D + 1); k < M; k++) { dsh[3 * k] = 0.f; dsh[3 * k + 1] = 0.f; dsh[3 * k + 2] = 0.f; }
 #undef SHC
 #undef DSH
       const V3 dL_ddir = {ddx[0] * dRGB[0] + ddx[1] * dRGB[1] + ddx[2] * dRGB[2],
@@ -681,8 +702,8 @@ int hgs_launch_preprocess_fwd(hipStream_t s, const HgsFwdArgs& a, const HgsGeom&
   HGS_CHECK_LAUNCH();
   return 0;
 }
-int hgs_launch_scatter(hipStream_t s, int P, int W, int H, int Rcap, const int* radii, const HgsGeom& g,
-                       const HgsImage& im, const HgsBinning& b) {
+int hgs_launch_scatter(hipStream_t s, int P, int W, int H, int Rcap, const float* features, const float* extra, int n_extra,
+                       const HgsGeom& g, const HgsImage& im, const HgsBinning& b) {
   const int nblk = (P + HGS_BLOCK - 1) / HGS_BLOCK;
   const int gx = (W + HGS_TILE - 1) / HGS_TILE, T = gx * ((H + HGS_TILE - 1) / HGS_TILE);
   // LDS for the fused scan's tile offsets: whether that mode is on is a device-side fact (status words written by the
@@ -690,7 +711,7 @@ int hgs_launch_scatter(hipStream_t s, int P, int W, int H, int Rcap, const int* 
   const size_t lds = T <= HGS_FUSED_SCAN_MAX_T ? (size_t)(T + T / 32 + 1) * sizeof(uint32_t) : 0;
   {
     HgsProfScope _prof(s, HGS_K_SCATTER);
-    hipLaunchKernelGGL(scatter_kernel, dim3(nblk), dim3(HGS_BLOCK), lds, s, P, gx, T, (uint32_t)Rcap, radii, g, im, b);
+    hipLaunchKernelGGL(scatter_kernel, dim3(nblk), dim3(HGS_BLOCK), lds, s, P, gx, T, (uint32_t)Rcap, features, n_extra ? extra : nullptr, g, im, b);
   }
   HGS_CHECK_LAUNCH();
   return 0;
@@ -700,7 +721,10 @@ int hgs_launch_preprocess_bwd(hipStream_t s, const HgsBwdArgs& a, const HgsGeom&
   const int nblk = (a.P + HGS_BLOCK - 1) / HGS_BLOCK;
   {
     HgsProfScope _prof(s, HGS_K_PREPROCESS_BWD);
-    hipLaunchKernelGGL(preprocess_bwd_kernel, dim3(nblk), dim3(HGS_BLOCK), 0, s, a, g, b, inst_grad, (uint32_t)Rcap, status);
+    if (!a.shs || (a.D == 0 && a.M == 1))
+      hipLaunchKernelGGL(preprocess_bwd_kernel<true>, dim3(nblk), dim3(HGS_BLOCK), 0, s, a, g, b, inst_grad, (uint32_t)Rcap, status);
+    else
+      hipLaunchKernelGGL(preprocess_bwd_kernel<false>, dim3(nblk), dim3(HGS_BLOCK), 0, s, a, g, b, inst_grad, (uint32_t)Rcap, status);
   }
   HGS_CHECK_LAUNCH();
   return 0;

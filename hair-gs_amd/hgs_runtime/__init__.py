@@ -60,11 +60,12 @@ SIGNATURES = {
     "hgs_cloud_params_forward": (ci, [vp, ci, vp, vp, vp, vp, vp, vp, vp, vp]),
     "hgs_cloud_params_backward": (ci, [vp, ci, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "hgs_loss_head_scratch_floats": (sz, [vp]),
-    "hgs_loss_head_forward": (ci, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
+    "hgs_loss_head_forward": (ci, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "hgs_loss_head_backward": (ci, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, vp, vp, vp, vp]),
     "hgs_densify_stats": (ci, [vp, ci, vp, vp, ci, vp, vp, vp]),
     "hgs_radius_pairs": (ci, [vp, ci, vp, vp, cf, cf, ci, ci, vp, vp, vp, ci]),
     "hgs_set_tile_cull": (ci, [ci]),
+    "hgs_set_segment_policy": (ci, [ci, ci, ci]),
     "hgs_debug_set_wg_trace": (ci, [vp, vp]),
     "hgs_prof_enable": (ci, [ci]),
     "hgs_prof_bracket_overhead_ms": (C.c_double, []),
@@ -107,7 +108,7 @@ class StrandFusion(C.Structure):
                 ("n_endpoints", ci)]
 
 
-HEAD_SKIP_PIXELS, HEAD_SKIP_SMOOTH, HEAD_SKIP_SSIM = 1, 2, 4
+HEAD_SKIP_PIXELS, HEAD_SKIP_SMOOTH = 1, 2
 VIEW_QUEUE_MAX = 16   # include/hgs.h HGS_VIEW_QUEUE_MAX
 HEAD_OUT = ["total", "l1", "dssim", "mask", "orientation", "smooth", "ori_count", "smooth_count", "g_ssim", "g_l1", "g_mask",
             "g_ori", "g_smooth"]

@@ -163,14 +163,11 @@ def _raster_head_forward(step, xyz, scale, quat, opacity, extra4, shs, endpoints
     # gradient planes of the per-pixel terms for an upstream gradient of 1, written by the forward's own pass over
     # the pixels (possible when the mask count is a per-view constant, i.e. the views carry masks)
     d_extra = torch.empty((4, vt.H, vt.W), **f32) if (step.one_pass_pixels and vt.has_mask) else None
-    # dL/d(image) for an upstream gradient of 1, written by the forward's fused SSIM / L1 kernel (hgs.h d_image_unit)
-    d_image = torch.empty((3, vt.H, vt.W), **f32) if (step.fused_ssim and vt.W % 4 == 0) else None
     with torch.cuda.device(dev):
         rt.check(L.hgs_loss_head_forward(rt.current_stream(), C.byref(hp), planes[0:3].data_ptr(), planes[3].data_ptr(),
                                          planes[4:7].data_ptr(), vt.slot.data_ptr(), rt.ptr(endpoints), rt.ptr(smooth_idx),
-                                         rt.ptr(scratch), rt.ptr(out), rt.ptr(d_extra), rt.ptr(smooth_partials),
-                                         rt.ptr(d_image)))
-    return R, planes, radii, geom, binning, img, scratch, out, (d_extra, d_image)
+                                         rt.ptr(scratch), rt.ptr(out), rt.ptr(d_extra), rt.ptr(smooth_partials)))
+    return R, planes, radii, geom, binning, img, scratch, out, d_extra
 
 
 def _head_raster_backward(ctx, step, go, xyz, scale, quat, shs, planes, radii, geom, binning, img, scratch, out, endpoints,
@@ -186,20 +183,16 @@ def _head_raster_backward(ctx, step, go, xyz, scale, quat, shs, planes, radii, g
     unit = ctx.d_extra is not None and unit_go
     go = step.one if go is None else go.contiguous().to(torch.float32)
     hp.n_endpoints = n_endpoints
-    skip_ssim = ctx.d_image_unit is not None
     if unit:
         d_image, d_extra = torch.empty((3, vt.H, vt.W), **f32), ctx.d_extra
     else:
         dplanes = torch.empty_like(planes)
         d_image, d_extra = dplanes[0:3], dplanes[3:7]
-    if skip_ssim:     # the forward already wrote dL/d(image) for grad_out = 1 (linear in grad_out)
-        d_image = ctx.d_image_unit if unit_go else ctx.d_image_unit * go
     with torch.cuda.device(dev):
         rt.check(L.hgs_loss_head_backward(rt.current_stream(), C.byref(hp), planes[0:3].data_ptr(), planes[3].data_ptr(),
                                           planes[4:7].data_ptr(), vt.slot.data_ptr(), rt.ptr(endpoints),
                                           rt.ptr(step.smooth_pairs), rt.ptr(scratch), rt.ptr(out), rt.ptr(go),
-                                          (rt.HEAD_SKIP_PIXELS if unit else 0) | (rt.HEAD_SKIP_SMOOTH if ctx.fused_smooth else 0)
-                                          | (rt.HEAD_SKIP_SSIM if skip_ssim else 0),
+                                          (rt.HEAD_SKIP_PIXELS if unit else 0) | (rt.HEAD_SKIP_SMOOTH if ctx.fused_smooth else 0),
                                           d_image.data_ptr(), d_extra[0].data_ptr(), d_extra[1:4].data_ptr(), rt.ptr(d_ep)))
     grad_planes = [d_image[k] for k in range(3)] + [d_extra[k] for k in range(4)]
     empty = step.empty
@@ -250,9 +243,9 @@ class _StrandIteration(torch.autograd.Function):
                                                rt.ptr(opacity_raw), rt.ptr(mask_raw), rt.ptr(xyz), rt.ptr(scale), rt.ptr(quat),
                                                None, rt.ptr(opacity), rt.ptr(extra4), C.byref(fu)))
         shs = f_dc if f_rest.numel() == 0 else torch.cat((f_dc, f_rest), dim=1)
-        R, planes, radii, geom, binning, img, scratch, out, (d_extra, d_image_unit) = _raster_head_forward(
+        R, planes, radii, geom, binning, img, scratch, out, d_extra = _raster_head_forward(
             step, xyz, scale, quat, opacity, extra4, shs, endpoints, idx, smooth_partials, E)
-        ctx.d_extra, ctx.d_image_unit = d_extra, d_image_unit
+        ctx.d_extra = d_extra
         ctx.fused_smooth = smooth_partials is not None
         ctx.step, ctx.R, ctx.f_rest_k = step, R, f_rest.shape[1]
         ctx.set_materialize_grads(False)   # no zero tensor for the (non-differentiable) terms output
@@ -314,10 +307,6 @@ class FusedStrandStep:
         self.empty = torch.empty(0, device=dev)
         self.one = torch.ones((), dtype=torch.float32, device=dev)   # d loss / d loss, passed to backward(): no fill launch
         self.one_pass_pixels = True    # per-pixel loss terms: value and gradient in one pass over the pixels
-        # SSIM / L1 value and image gradient in ONE kernel (hgs.h d_image_unit: no derivative maps through HBM).  Off
-        # (HGS_FUSED_SSIM=1 switches it on for measurements): at
-        # 1080p it takes 118 us against 42 + 40 for the two-kernel form (61 KB of LDS leave two workgroups per CU)
-        self.fused_ssim = os.environ.get("HGS_FUSED_SSIM") == "1"
         self.stats_in_backward = True  # densification statistics updated by the backward's last launch
         self.last = {}
         self.refresh()
@@ -385,9 +374,9 @@ class _CloudIteration(torch.autograd.Function):
                                                 rt.ptr(opacity_raw), rt.ptr(mask_raw), rt.ptr(scale), rt.ptr(quat),
                                                 rt.ptr(opacity), rt.ptr(extra4)))
         shs = f_dc if f_rest.numel() == 0 else torch.cat((f_dc, f_rest), dim=1)
-        R, planes, radii, geom, binning, img, scratch, out, (d_extra, d_image_unit) = _raster_head_forward(
+        R, planes, radii, geom, binning, img, scratch, out, d_extra = _raster_head_forward(
             step, xyz, scale, quat, opacity, extra4, shs, None, None, None, 0)
-        ctx.d_extra, ctx.d_image_unit, ctx.fused_smooth = d_extra, d_image_unit, True   # (no smoothness term for a cloud: nothing to launch)
+        ctx.d_extra, ctx.fused_smooth = d_extra, True   # (no smoothness term for a cloud: nothing to launch)
         ctx.step, ctx.R, ctx.f_rest_k = step, R, f_rest.shape[1]
         ctx.set_materialize_grads(False)
         ctx.save_for_backward(xyz, scaling_raw, rotation_raw, scale, quat, opacity, extra4, shs, planes, radii, geom, binning,

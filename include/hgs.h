@@ -279,15 +279,10 @@ int hgs_cloud_params_backward(void* stream, int P, const float* scaling_raw, con
  *   passes HGS_HEAD_SKIP_PIXELS to the backward and uses those planes as they are.
  *   smooth_partials_ext (may be NULL): smoothness partial sums already computed elsewhere (HgsStrandFusion): the head then
  *   launches no smoothness kernel of its own and reduces these.
- *   d_image_unit ([3,H,W], may be NULL): if given (and W % 4 == 0), ONE kernel computes the SSIM / L1 sums and writes
- *   dL/d(image) FOR grad_out = 1 here -- the weights of the two terms are constants of HgsHeadParams, so the gradient does
- *   not wait for the value; no derivative maps go through HBM.  The caller then passes HGS_HEAD_SKIP_SSIM and this buffer
- *   (scaled by its upstream gradient if that is not 1) as d_image to the backward, which launches no SSIM kernel.
- *   With W % 4 != 0 the buffer is left untouched and HGS_HEAD_SKIP_SSIM must not be passed.
  *   backward: d_image [3,H,W] fully written; d_mask_img [H,W], d_omap [3,H,W] fully written unless HGS_HEAD_SKIP_PIXELS;
  *   d_endpoints [E,3] zeroed, then (unless HGS_HEAD_SKIP_SMOOTH) the smoothness gradient scattered into it;
  *   grad_out = device scalar dL/dtotal. */
-enum { HGS_HEAD_SKIP_PIXELS = 1, HGS_HEAD_SKIP_SMOOTH = 2, HGS_HEAD_SKIP_SSIM = 4 };
+enum { HGS_HEAD_SKIP_PIXELS = 1, HGS_HEAD_SKIP_SMOOTH = 2 };
 typedef struct HgsHeadParams {
   int H, W;
   float lambda_dssim, lambda_mask, lambda_orientation, lambda_smooth;
@@ -305,7 +300,7 @@ size_t hgs_loss_head_scratch_floats(const HgsHeadParams* p);
 int hgs_loss_head_forward(void* stream, const HgsHeadParams* p, const float* image, const float* mask_img,
                           const float* omap, const HgsViewTargets* targets, const float* endpoints,
                           const long long* smooth_pairs, float* scratch, float* out, float* d_extra_unit,
-                          const float* smooth_partials_ext, float* d_image_unit);
+                          const float* smooth_partials_ext);
 int hgs_loss_head_backward(void* stream, const HgsHeadParams* p, const float* image, const float* mask_img,
                            const float* omap, const HgsViewTargets* targets, const float* endpoints,
                            const long long* smooth_pairs, const float* scratch, const float* out,
@@ -356,6 +351,12 @@ int hgs_set_tile_cull(int on);
 
 /* Development aid (tools/wg_trace.py): when a buffer of 2*T uint64 is registered, blend_fwd / blend_bwd record the
  * start and end time (s_memrealtime, 100 MHz) of every tile's workgroup in it; NULL (the default) switches it off. */
+/* Tuning knob of the segment-parallel blend (csrc/hgs_blend.hip): tile lists longer than 1.5 segment lengths are walked
+ * by one workgroup per segment; the segment length of a pass with R instances is R / target_segments rounded up to a
+ * multiple of 64 and clamped to [min_len, max_len] (multiples of 64, min_len >= 128; default 128, 1024, 2048).  Process-wide, takes
+ * effect at the next forward pass (a captured graph keeps the policy it was captured with).  Results do not depend
+ * on it beyond the association of the per-pixel transmittance product. */
+int hgs_set_segment_policy(int min_len, int max_len, int target_segments);
 int hgs_debug_set_wg_trace(void* device_buf_fwd, void* device_buf_bwd);
 
 /* ---- introspection used by the parity tests (byte offsets of the sub-arrays of each buffer) ---- */

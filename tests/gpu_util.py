@@ -91,5 +91,5 @@ def segment_work(fw):
     R = fw["R"]
     b = rt.layout("binning", R)
     off = (b["keys_sorted"] + 8 * R + 255) // 256 * 256
-    cap = R // 128 + 2
+    cap = R // 64 + 2
     return _view(fw["binning"], off, cap, np.uint32)

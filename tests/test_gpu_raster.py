@@ -65,7 +65,7 @@ def _forward(s, cull):
         _C.set_tile_cull(was)
 
 
-SPLIT_MIN_LEN = 256   # csrc/hgs_blend.hip: tile lists up to this length are never split across workgroups
+SPLIT_MIN_LEN = 192   # csrc/hgs_blend.hip: tile lists up to this length are never split across workgroups
 
 
 def _long_tile_pixels(ranges, W, H):
@@ -147,7 +147,7 @@ def test_blend_work_list_covers_every_tile_once(name):
     img = fw["img"].cpu().numpy()
     st = img[lay["status"]:lay["status"] + 64].view(np.uint32)
     n_split_items, seg_len, n_unsplit = int(st[5]), int(st[7]), int(st[8])
-    assert st[6] == 0 and 256 <= seg_len <= 1024 and seg_len % 64 == 0
+    assert st[6] == 0 and 128 <= seg_len <= 1024 and seg_len % 64 == 0
     order = img[lay["tile_order"]:lay["tile_order"] + 4 * T].view(np.uint32)[:n_unsplit]
     ranges = img[lay["ranges"]:lay["ranges"] + 8 * T].view(np.uint32).reshape(T, 2)
     n = (ranges[:, 1] - ranges[:, 0]).astype(np.int64)

@@ -693,7 +693,7 @@ def test_loss_head_skips_all_zero_blocks_exactly(hw):
     d_img, d_mask, d_omap = torch.full((3, H, W), 7.0, device=dev), torch.empty(H, W, device=dev), torch.empty(3, H, W, device=dev)
     one = torch.ones(1, device=dev)
     rt.check(L.hgs_loss_head_forward(rt.current_stream(), C.byref(hp), image.data_ptr(), mask_img.data_ptr(), omap.data_ptr(),
-                                     targets.data_ptr(), None, None, scratch.data_ptr(), out.data_ptr(), None, None, None))
+                                     targets.data_ptr(), None, None, scratch.data_ptr(), out.data_ptr(), None, None))
     rt.check(L.hgs_loss_head_backward(rt.current_stream(), C.byref(hp), image.data_ptr(), mask_img.data_ptr(), omap.data_ptr(),
                                       targets.data_ptr(), None, None, scratch.data_ptr(), out.data_ptr(), one.data_ptr(), 0,
                                       d_img.data_ptr(), d_mask.data_ptr(), d_omap.data_ptr(), None))
@@ -705,20 +705,6 @@ def test_loss_head_skips_all_zero_blocks_exactly(hw):
     assert abs(o["l1"] - float(l1)) <= 1e-6 * max(float(l1), 1e-6)
     assert abs(o["dssim"] - float(1.0 - s)) <= 2e-6
     assert torch.equal(d_img, a.grad)
-    # ---- the one-kernel form (value + gradient for grad_out = 1, no derivative maps): same numbers
-    if W % 4 == 0:
-        out2 = torch.zeros(rt.HEAD_NOUT, device=dev)
-        d_unit = torch.full((3, H, W), 7.0, device=dev)
-        scratch2 = torch.empty_like(scratch)
-        rt.check(L.hgs_loss_head_forward(rt.current_stream(), C.byref(hp), image.data_ptr(), mask_img.data_ptr(), omap.data_ptr(),
-                                         targets.data_ptr(), None, None, scratch2.data_ptr(), out2.data_ptr(), None, None,
-                                         d_unit.data_ptr()))
-        o2 = dict(zip(rt.HEAD_OUT, out2.tolist()))
-        for k in ("total", "l1", "dssim", "mask", "orientation"):
-            assert abs(o2[k] - o[k]) <= 2e-6 * max(abs(o[k]), 1e-3), (k, o2[k], o[k])
-        scale = float(a.grad.abs().max())
-        assert float((d_unit - a.grad).abs().max()) <= 2e-6 * scale
-        assert torch.equal(d_unit == 0, a.grad == 0) or float((d_unit - a.grad).abs().max()) <= 1e-7 * scale
     # block lists (white box: [n_work, n_skip, -, -][work ids][skipped ids] close the scratch buffer)
     nbs = 3 * ((H + 31) // 32) * ((W + 31) // 32)
     lists = scratch.view(torch.int32)[scratch.numel() - (2 * nbs + 8):].cpu()
