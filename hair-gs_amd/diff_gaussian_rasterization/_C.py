@@ -16,7 +16,7 @@ import hgs_runtime as rt
 # instead of three).  If a pass needed more than its capacity, check_async() raises HgsCapacityOverflow after growing
 # the capacity: the caller discards the step's gradients and repeats it.  `num_rendered` returned by
 # rasterize_gaussians is then the capacity (it only sizes/carves buffers downstream).
-_state = {"last_R": 0, "async": False, "cap": 0, "slack": 1.5, "dirty": False, "cap_used": None, "max_R": {}}
+_state = {"last_R": 0, "async": False, "cap": 0, "slack": 1.5, "dirty": False, "cap_used": None, "max_R": {}, "cull": None}
 
 
 class HgsCapacityOverflow(RuntimeError):
@@ -24,9 +24,17 @@ class HgsCapacityOverflow(RuntimeError):
 
 
 def set_tile_cull(enabled=True):
-    """include/hgs.h hgs_set_tile_cull: drop the (Gaussian, tile) instances no pixel can blend (default on); off gives the
-    reference's tile lists.  Returns the previous setting."""
-    return bool(rt.lib().hgs_set_tile_cull(int(bool(enabled))))
+    """Tile culling (include/hgs.h hgs_set_tile_cull: drop the (Gaussian, tile) instances no pixel can blend; image,
+    radii and every gradient are bit-identical with and without) for ALL entry points of this module: True / False, or
+    None for the per-entry-point defaults:
+      rasterize_gaussians         OFF -- the reference's own function: `num_rendered`, the tile lists in the returned
+                                  buffers and `n_contrib` are the reference's, entry for entry;
+      rasterize_gaussians_culled  (what diff_gaussian_rasterization.GaussianRasterizer, i.e. render(), calls) and
+      rasterize_gaussians_multi   ON -- callers that only see the image, the radii and the gradients.
+    Returns the previous setting."""
+    was = _state["cull"]
+    _state["cull"] = None if enabled is None else bool(enabled)
+    return was
 
 
 def set_async(enabled=True, slack=1.5):
@@ -72,10 +80,21 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
                         viewmatrix, projmatrix, tan_fovx, tan_fovy, image_height, image_width, sh, degree, campos,
                         prefiltered, debug):
     """RasterizeGaussiansCUDA (rasterize_points.cu:35-115).
-    Returns (num_rendered, out_color[3,H,W], radii[P], geomBuffer, binningBuffer, imgBuffer)."""
+    Returns (num_rendered, out_color[3,H,W], radii[P], geomBuffer, binningBuffer, imgBuffer); the tile lists are the
+    reference's (see set_tile_cull)."""
     return _forward(background, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp, viewmatrix,
                     projmatrix, tan_fovx, tan_fovy, image_height, image_width, sh, degree, campos, prefiltered, debug,
-                    None)
+                    None, False)
+
+
+def rasterize_gaussians_culled(background, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp,
+                               viewmatrix, projmatrix, tan_fovx, tan_fovy, image_height, image_width, sh, degree, campos,
+                               prefiltered, debug):
+    """rasterize_gaussians with tile culling on (this module's extension; what GaussianRasterizer / render() call): same
+    image, radii and gradients bit for bit, fewer instances in the buffers."""
+    return _forward(background, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp, viewmatrix,
+                    projmatrix, tan_fovx, tan_fovy, image_height, image_width, sh, degree, campos, prefiltered, debug,
+                    None, True)
 
 
 def rasterize_gaussians_multi(background7, means3D, colors, extra4, opacity, scales, rotations, scale_modifier,
@@ -85,14 +104,16 @@ def rasterize_gaussians_multi(background7, means3D, colors, extra4, opacity, sca
     the same weights.  Returns (num_rendered, out_color[7,H,W], radii, geomBuffer, binningBuffer, imgBuffer)."""
     return _forward(background7, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp, viewmatrix,
                     projmatrix, tan_fovx, tan_fovy, image_height, image_width, sh, degree, campos, prefiltered, debug,
-                    extra4)
+                    extra4, True)
 
 
 def _forward(background, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp, viewmatrix,
-             projmatrix, tan_fovx, tan_fovy, image_height, image_width, sh, degree, campos, prefiltered, debug, extra4):
+             projmatrix, tan_fovx, tan_fovy, image_height, image_width, sh, degree, campos, prefiltered, debug, extra4,
+             cull):
     if means3D.ndim != 2 or means3D.shape[1] != 3:
         raise RuntimeError("means3D must have dimensions (num_points, 3)")  # rasterize_points.cu:57-59
     L = rt.lib()
+    L.hgs_set_tile_cull(int(_state["cull"] if _state["cull"] is not None else bool(cull)))   # host-side switch, read by this pass
     means3D = rt.require_gpu_tensor(means3D, "means3D", torch.float32)
     dev = means3D.device
     P, H, W = means3D.shape[0], int(image_height), int(image_width)

@@ -40,13 +40,13 @@ class _RasterizeGaussians(torch.autograd.Function):
         if rs.debug:  # reference :83-90: snapshot the inputs so a failing call can be replayed
             cpu_args = cpu_deep_copy_tuple(args)
             try:
-                num_rendered, color, radii, geomBuffer, binningBuffer, imgBuffer = _C.rasterize_gaussians(*args)
+                num_rendered, color, radii, geomBuffer, binningBuffer, imgBuffer = _C.rasterize_gaussians_culled(*args)   # (callers of the autograd op see image, radii, gradients: unchanged by culling)
             except Exception:
                 torch.save(cpu_args, "snapshot_fw.dump")
                 print("\nAn error occured in forward. Please forward snapshot_fw.dump for debugging.")
                 raise
         else:
-            num_rendered, color, radii, geomBuffer, binningBuffer, imgBuffer = _C.rasterize_gaussians(*args)
+            num_rendered, color, radii, geomBuffer, binningBuffer, imgBuffer = _C.rasterize_gaussians_culled(*args)   # (callers of the autograd op see image, radii, gradients: unchanged by culling)
         ctx.raster_settings = rs
         ctx.num_rendered = num_rendered
         ctx.save_for_backward(colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geomBuffer,

@@ -55,7 +55,7 @@ ALL = list(VARIANTS) + ["strands", "strands_precomp"]
 
 
 def _forward(s, cull):
-    """Forward pass with tile culling (include/hgs.h hgs_set_tile_cull) on or off; the library default is restored."""
+    """Forward pass with tile culling (include/hgs.h hgs_set_tile_cull) on or off; the module default is restored."""
     from diff_gaussian_rasterization import _C
     from tests import gpu_util as G
     was = _C.set_tile_cull(cull)
@@ -91,9 +91,10 @@ def _check_forward(name):
     from tests import gpu_util as G
     s = _scene(name)
     ref = O.forward(s)
-    # culling off: the tile lists are the reference's, every binning stage is compared bit for bit.  The default (on)
-    # drops instances that no pixel blends; test_tile_cull_changes_no_output shows that nothing else changes.
-    fw = _forward(s, cull=False)
+    # the reference's own entry point with its 19 arguments (no culling): the tile lists are the reference's, every binning
+    # stage is compared bit for bit.  render() and the training step cull instances that no pixel blends;
+    # test_tile_cull_changes_no_output shows that nothing else changes.
+    fw = G.run_forward(s)
     got = G.intermediates(s, fw)
     vis = ref["radii"] > 0
     assert got["status"][1] == 0 and got["status"][6] == 0   # no capacity overflow, no cooperative-wait timeout
@@ -433,7 +434,7 @@ def test_full_size_forward_and_backward_against_oracle(workload):
     from tests import gpu_util as G
     s = _workload_scene(workload)
     ref = O.forward(s)
-    fw = G.run_forward(s)                                    # default: culling on
+    fw = _forward(s, True)                                   # what render() and the training step run: culling on
     img = fw["color"].cpu().numpy()
     err = np.abs(img - ref["out_color"])
     mse = float(np.mean(err.astype(np.float64) ** 2))

@@ -1,7 +1,8 @@
 mkdir -p gpurun_out
-timeout 300 python -m pytest tests/test_gpu_raster.py -m gpu -q -x --tb=short -k "backward or full_size or cull" 2>&1 | tail -8 > gpurun_out/t1.log
-for v in "" _single _p4; do
+for rep in 1 2; do
+for v in "" _nogrec; do
  for w in north_star c2 c4; do
-  HGS_LIB=$PWD/hair-gs_amd/libhgs$v.so timeout 300 python bench.py --workload $w --steps 100 --warmup 10 --no-cpu-baseline 2>&1 | tail -1 > gpurun_out/ab${v}_$w.json
+  HGS_LIB=$PWD/hair-gs_amd/libhgs$v.so timeout 300 python bench.py --workload $w --steps 200 --warmup 10 --repeats 3 --sustained-seconds 0 --no-cpu-baseline 2>/dev/null | tail -1 > gpurun_out/ab2${v}_${w}_$rep.json
  done
+done
 done
