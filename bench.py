@@ -240,17 +240,64 @@ def main():
 
     for _ in range(args.warmup):
         one_step()
-    regions = sorted(timed_region(args.steps) for _ in range(max(1, args.repeats)))
+    # Training changes the workload (the Gaussians grow: +30 % instances per view after 500 steps).  Every timed region,
+    # the kernel-timing pass and the workload statistics therefore start from the SAME state -- the parameters, Adam
+    # moments and step counters as they are after the warm-up -- restored outside the timed regions; the regions time
+    # real optimizer steps of that trajectory.
+    torch.cuda.synchronize()
+    state_tensors = [p.data for g_ in model.optimizer.param_groups for p in g_["params"]]
+    for g_ in model.optimizer.param_groups:
+        for p in g_["params"]:
+            state_tensors += [v for v in model.optimizer.state.get(p, {}).values() if torch.is_tensor(v)]
+    state_tensors += [model.max_radii2D, model.xyz_gradient_accum, model.denom]
+    snapshot = [t.clone() for t in state_tensors]
+    it0 = it
+
+    def restore():
+        nonlocal it
+        with torch.no_grad():
+            for t, s_ in zip(state_tensors, snapshot):
+                t.copy_(s_)
+        model._derived = None
+        it = it0
+        sampler.rng.seed(12345)
+        sampler.stack = []
+        torch.cuda.synchronize()
+
+    regions = []
+    for _ in range(max(1, args.repeats)):
+        restore()
+        regions.append(timed_region(args.steps))
+    regions.sort()
     dt = regions[len(regions) // 2]
     sustained = None
     if args.sustained_seconds > 0:
-        n_sus = max(args.steps, int(args.sustained_seconds / (dt / args.steps)) + 1)
+        # >= sustained_seconds of back-to-back steps in ONE region (for SMI samplers); the state is put back every K steps
+        # (12 small device copies per K steps, inside the region) so that the workload stays the one the headline times
+        chunks = max(1, int(args.sustained_seconds / dt) + 1)
         if world > 1:   # (every rank must run the same number of steps)
-            n = torch.tensor([n_sus], dtype=torch.int64, device=dev)
+            n = torch.tensor([chunks], dtype=torch.int64, device=dev)
             dist.all_reduce(n, op=dist.ReduceOp.MAX)
-            n_sus = int(n.item())
-        t_sus = timed_region(n_sus)
-        sustained = {"steps": n_sus, "seconds": t_sus, "iters_per_sec": views_per_step * n_sus / t_sus}
+            chunks = int(n.item())
+        restore()
+        sync_all()
+        t0 = time.perf_counter()
+        for _ in range(chunks):
+            with torch.no_grad():
+                for t, s_ in zip(state_tensors, snapshot):
+                    t.copy_(s_, non_blocking=True)
+            it = it0
+            for _ in range(args.steps):
+                one_step()
+        sync_all()
+        t_sus = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+        if world > 1:
+            dist.all_reduce(t_sus, op=dist.ReduceOp.MAX)
+        t_sus = float(t_sus.item())
+        n_sus = chunks * args.steps
+        sustained = {"steps": n_sus, "seconds": t_sus, "iters_per_sec": views_per_step * n_sus / t_sus,
+                     "state_restored_every_steps": args.steps}
+    restore()
     if use_graph:
         gs.check()  # instance counts of the captured passes stayed within capacity
     # per-kernel device time: HIP events cannot bracket individual nodes of a replayed graph, so the same steps are

@@ -157,48 +157,54 @@ __device__ __forceinline__ void bitonic_lds(uint64_t* sk, int m) {
 }
 
 // Work list of the blend kernels, computed by ONE extra workgroup of the sort kernel, i.e. in the shadow of the sorts.
-//   * Lists longer than 1.5 segment lengths (hgs_split_of) are SPLIT: one work item per segment in b.seg_work, a tile's
-//     segments consecutive and ascending (the forward waits on predecessors only), the tile flagged in tile_prog.
-//     These items come first: they are the longest pieces of work.
-//   * The other tiles follow in descending order of list length (counting sort by min(length, ORD_BUCKETS-1)) in
-//     im.tile_order.  A list is consumed sequentially, so the blend kernels end when the longest pieces end: measured
-//     on the strand workload, raster order started the 58-us tiles of the backward 15-30 us into the launch.
+// im.tile_order[w] = tile | segment << 24 for workgroup w:
+//   * Lists longer than 1.5 segment lengths (hgs_split_of) are SPLIT: one work item per segment, a tile's segments
+//     consecutive and ascending (the forward waits on predecessors only), the tile flagged in tile_prog.  These items come
+//     first: they are the longest pieces of work (and their position is the index of the segment's state in HgsBinning).
+//   * The other tiles follow in descending order of list length (counting sort by min(length, ORD_BUCKETS-1)).  A list
+//     is consumed sequentially, so the blend kernels end when the longest pieces end: measured on the strand workload,
+//     raster order started the 58-us tiles of the backward 15-30 us into the launch.
 __device__ __forceinline__ void work_list_block(int T, uint32_t Rcap, HgsSegPolicy pol, const HgsImage& im, const HgsBinning& b, uint16_t* bk, int bk_cap) {
   __shared__ uint32_t hist[ORD_BUCKETS], obase[ORD_BUCKETS], wsum[HGS_BLOCK / 64], nsplit_items, nsplit_tiles;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   for (int i = tid; i < ORD_BUCKETS; i += HGS_BLOCK) hist[i] = 0u;
   if (tid == 0) { nsplit_items = 0u; nsplit_tiles = 0u; }
   const uint32_t S = hgs_segment_length(im.status[HGS_ST_R], pol);
-  const uint32_t seg_cap = b.seg_cap;
+  const uint32_t seg_cap = min(b.seg_cap, (uint32_t)HGS_SPLIT_CAPACITY(T));   // (what the work list holds)
   __syncthreads();
   constexpr int SPLIT_BUCKET = 0xFFFF;
-  // bucket of a tile; split tiles get their work items here (once: pass 0 caches the answer whenever T fits the cache)
-  auto classify = [&](int i) {
-    const uint2 r = im.ranges[i];
-    const uint32_t n = r.y - r.x;
+  // bucket of a tile of n entries; split tiles get their work items here (once per tile)
+  auto classify = [&](int i, uint32_t n) {
     const HgsSplit sp = hgs_split_of(n, S);
-    if (sp.nseg > 1 && seg_cap && r.y <= Rcap) {   // (a list beyond the binning capacity is void: status[1])
+    if (sp.nseg > 1 && seg_cap && im.ranges[i].y <= Rcap) {   // (a list beyond the binning capacity is void: status[1])
       const uint32_t base = atomicAdd(&nsplit_items, sp.nseg);
       const bool fits = base + sp.nseg <= seg_cap;
-      for (uint32_t k = 0; k < sp.nseg && base + k < seg_cap; k++) b.seg_work[base + k] = fits ? ((uint32_t)i | (k << 24)) : HGS_ITEM_NONE;
+      for (uint32_t k = 0; k < sp.nseg && base + k < seg_cap; k++) im.tile_order[base + k] = fits ? ((uint32_t)i | (k << 24)) : HGS_ITEM_NONE;
       if (fits) { im.tile_prog[i] = HGS_PART_FLAG; atomicAdd(&nsplit_tiles, 1u); return SPLIT_BUCKET; }
     }
     return ORD_BUCKETS - 1 - (int)min(n, (uint32_t)(ORD_BUCKETS - 1));   // bucket 0 = longest lists
   };
+  auto length_of = [&](int i) { const uint2 r = im.ranges[i]; return r.y - r.x; };
   const bool cached = T <= bk_cap;
   if (cached) {
-#pragma unroll 4
-    for (int i = tid; i < T; i += HGS_BLOCK) bk[i] = (uint16_t)classify(i);
+    // pass 0: the list lengths (clipped to 16 bits) into LDS -- nothing but loads in this loop, so the loads of several
+    // iterations are in flight together (the classification below stores, which would order it behind every load)
+#pragma unroll 8
+    for (int i = tid; i < T; i += HGS_BLOCK) bk[i] = (uint16_t)min(length_of(i), 0xFFFFu);
+    __syncthreads();
+    for (int i = tid; i < T; i += HGS_BLOCK) {
+      const uint32_t n = bk[i] == 0xFFFFu ? length_of(i) : (uint32_t)bk[i];
+      bk[i] = (uint16_t)classify(i, n);
+    }
     __syncthreads();
   }
   auto bucket_of = [&](int i) {
     if (cached) return (int)bk[i];
     if (im.tile_prog[i] == HGS_PART_FLAG) return SPLIT_BUCKET;
-    const uint2 r = im.ranges[i];
-    return ORD_BUCKETS - 1 - (int)min(r.y - r.x, (uint32_t)(ORD_BUCKETS - 1));
+    return ORD_BUCKETS - 1 - (int)min(length_of(i), (uint32_t)(ORD_BUCKETS - 1));
   };
   if (!cached) {   // huge frames: classify once (items + flags), buckets are recomputed from the flags afterwards
-    for (int i = tid; i < T; i += HGS_BLOCK) classify(i);
+    for (int i = tid; i < T; i += HGS_BLOCK) classify(i, length_of(i));
     __threadfence_block();
     __syncthreads();
   }
@@ -217,14 +223,15 @@ __device__ __forceinline__ void work_list_block(int T, uint32_t Rcap, HgsSegPoli
     carry += total;
     __syncthreads();
   }
+  const uint32_t nsplit = min(nsplit_items, seg_cap);   // (final: every tile was classified before the histogram pass)
   for (int i = tid; i < T; i += HGS_BLOCK) {
     const int bkt = bucket_of(i);
-    if (bkt != SPLIT_BUCKET) im.tile_order[obase[bkt] + atomicAdd(&hist[bkt], 1u)] = (uint32_t)i;   // order inside a bucket is irrelevant
+    if (bkt != SPLIT_BUCKET) im.tile_order[nsplit + obase[bkt] + atomicAdd(&hist[bkt], 1u)] = (uint32_t)i;   // order inside a bucket is irrelevant
   }
   if (tid == 0) {
-    im.status[HGS_ST_SPLIT_ITEMS] = min(nsplit_items, seg_cap);
+    im.status[HGS_ST_SPLIT_ITEMS] = nsplit;
     im.status[HGS_ST_SEG_LEN] = S;
-    im.status[HGS_ST_UNSPLIT] = (uint32_t)T - nsplit_tiles;
+    im.status[HGS_ST_WORK_ITEMS] = nsplit + (uint32_t)T - nsplit_tiles;
   }
 }
 
@@ -309,9 +316,11 @@ __global__ __launch_bounds__(HGS_BLOCK) void sort_tiles_kernel(int gx, int T, ui
     return;
   }
   const int tile = blockIdx.x - 1;
-  if (im.tile_sortprog[tile] & HGS_PART_FLAG) return;   // long list: sorted by its chunk workgroups above
   const uint2 range = im.ranges[tile];
-  if (range.y <= range.x || range.y > Rcap) return;  // empty, or binning buffer overflow (status[1] already set)
+  // empty, or binning buffer overflow (status[1] already set), or (more than one chunk: the only lists that can carry the
+  // flag) a long list sorted by its chunk workgroups above
+  if (range.y <= range.x || range.y > Rcap) return;
+  if (range.y - range.x > SORT_CAP && (im.tile_sortprog[tile] & HGS_PART_FLAG)) return;
   const uint32_t start = range.x, n = range.y - range.x;
   const int tx = tile % gx, ty = tile / gx;
   const uint32_t nchunks = (n + SORT_CAP - 1) / SORT_CAP;

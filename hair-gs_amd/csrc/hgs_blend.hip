@@ -48,10 +48,15 @@ struct WgTrace {
 
 namespace {
 
+// Backward: 32 entries staged and combined per LDS flush and one record in registers at a time keep the kernel at 53 VGPRs
+// and 12 KB of LDS, i.e. 8 resident waves per SIMD: measured 2-4 % faster than 64-entry batches with a second record in
+// flight (80 VGPRs, 24.5 KB, 6 waves) on every BASELINE workload.
 #ifndef HGS_BWD_WAVES
-#define HGS_BWD_WAVES 6   // resident waves per SIMD the backward's register allocation aims at (80 VGPRs)
+#define HGS_BWD_WAVES 8
 #endif
-#define BWD_BATCH 64   // entries combined per LDS flush in the backward
+#ifndef BWD_BATCH
+#define BWD_BATCH 32
+#endif
 #define REC_BATCH 64   // instance records staged in LDS per batch (<= one float4 per thread)
 
 // ---- wavefront-wide reduction of 9 per-lane values (CDNA4: v_permlane32_swap / v_permlane16_swap + DPP) ----------
@@ -145,30 +150,24 @@ __device__ __forceinline__ Rec<C> lds_record(const float4* recs, int e) {
 }
 
 // ---- work items ------------------------------------------------------------------------------------------------
-// blockIdx -> (tile, list segment).  Split lists first (seg_work, a tile's segments consecutive), then the unsplit tiles
-// in descending order of list length (tile_order); both lists come from the sort kernel's work-list workgroup.
 struct BlendItem { int tile; uint32_t seg, nseg, s, e, w; uint2 range; bool split; };
-__device__ __forceinline__ bool blend_item(const HgsImage& im, const HgsBinning& bn, uint32_t Rcap, BlendItem& it) {
-  const uint32_t nsplit = im.status[HGS_ST_SPLIT_ITEMS];
+// blockIdx -> (tile, list segment) through the work list of the sort kernel (im.tile_order: segments of split lists
+// first, a tile's segments consecutive, then the other tiles in descending order of list length).  The work item and the
+// counters are independent loads, the tile's range the only dependent one: two memory round trips before the walk starts.
+__device__ __forceinline__ bool blend_item(const HgsImage& im, uint32_t Rcap, BlendItem& it) {
+  const uint4 st = *(const uint4*)(im.status + HGS_ST_SORT_ITEMS);   // [4..7]: -, split items, segment length, work items
+  const uint32_t item = im.tile_order[blockIdx.x];
+  if (blockIdx.x >= st.w || item == HGS_ITEM_NONE) return false;
   it.w = blockIdx.x;
-  it.split = blockIdx.x < nsplit;
-  if (it.split) {
-    const uint32_t item = bn.seg_work[blockIdx.x];
-    if (item == HGS_ITEM_NONE) return false;
-    it.tile = (int)HGS_ITEM_TILE(item);
-    it.seg = HGS_ITEM_PART(item);
-  } else {
-    const uint32_t j = blockIdx.x - nsplit;
-    if (j >= im.status[HGS_ST_UNSPLIT]) return false;
-    it.tile = (int)im.tile_order[j];
-    it.seg = 0u;
-  }
+  it.split = blockIdx.x < st.y;
+  it.tile = (int)HGS_ITEM_TILE(item);
+  it.seg = HGS_ITEM_PART(item);
   it.range = im.ranges[it.tile];
   if (it.range.y > Rcap) it.range = make_uint2(0u, 0u);   // binning buffer under-sized (flagged by the scatter kernel)
   const uint32_t n = it.range.y - it.range.x;
   it.nseg = 1u; it.s = 0u; it.e = n;
   if (it.split) {
-    const HgsSplit sp = hgs_split_of(n, im.status[HGS_ST_SEG_LEN]);
+    const HgsSplit sp = hgs_split_of(n, st.z);
     it.nseg = sp.nseg;
     it.s = it.seg * sp.seglen;
     it.e = min(n, it.s + sp.seglen);
@@ -268,7 +267,7 @@ __global__ __launch_bounds__(HGS_BLOCK) void blend_fwd_kernel(HgsImage im, HgsBi
   __shared__ uint32_t alive[2][4];
   __shared__ uint32_t s_flag;
   BlendItem it;
-  if (!blend_item(im, bn, Rcap, it)) return;
+  if (!blend_item(im, Rcap, it)) return;
   const int tile = it.tile;
   WgTrace _trace(g_wg_trace_fwd, tile);
   const int tx = tile % gx, ty = tile / gx;
@@ -375,14 +374,13 @@ __global__ __launch_bounds__(HGS_BLOCK) __attribute__((amdgpu_waves_per_eu(HGS_B
                                                               uint32_t Rcap, const float* __restrict__ bg,
                                                               PixGrad<C> dL_dpix, float* __restrict__ inst_grad) {
   constexpr int REC4 = Chan<C>::REC4, NPART = Chan<C>::NPART, NREG = Chan<C>::NREG, NV = 4 * NREG, ROW = Chan<C>::ROW;
-  static_assert(BWD_BATCH == REC_BATCH, "one record batch per partial-sum flush");
   __shared__ float part[4][BWD_BATCH][NV];
-  __shared__ float4 recs[2][REC_BATCH * REC4];
+  __shared__ float4 recs[2][BWD_BATCH * REC4];
   // a forward that overflowed its binning capacity is void (records and slots of the dropped lists were never written):
   // nothing is read or written here, preprocess_bwd_kernel returns zero gradients
-  if (im.status[HGS_ST_OVERFLOW]) return;
+  const uint32_t void_pass = im.status[HGS_ST_OVERFLOW];
   BlendItem it;
-  if (!blend_item(im, bn, Rcap, it)) return;   // same work list as the forward: (tile, list segment)
+  if (!blend_item(im, Rcap, it) || void_pass) return;   // same work list as the forward: (tile, list segment)
   const int tile = it.tile;
   WgTrace _trace(g_wg_trace_bwd, tile);
   const uint2 range = it.range;
@@ -454,7 +452,7 @@ __global__ __launch_bounds__(HGS_BLOCK) __attribute__((amdgpu_waves_per_eu(HGS_B
   }
 
   for (int i = threadIdx.x; i < 4 * BWD_BATCH * NV; i += HGS_BLOCK) (&part[0][0][0])[i] = 0.f;
-  if (threadIdx.x < REC_BATCH * REC4) recs[0][threadIdx.x] = stage;
+  if (threadIdx.x < BWD_BATCH * REC4) recs[0][threadIdx.x] = stage;
   __syncthreads();
 
   // walk the list back to front in batches of BWD_BATCH positions; position p (0-based) is valid for a pixel
@@ -540,21 +538,10 @@ __global__ __launch_bounds__(HGS_BLOCK) __attribute__((amdgpu_waves_per_eu(HGS_B
         if (reg < NREG) part[wave][e][4 * reg + k] = tot;
       }
     };
-    if (m) {
-      // two record buffers used alternately: the next entry's LDS reads are in flight while this one is evaluated,
-      // and no register copies rotate the pipeline
-      int ea = 63 - __builtin_clzll(m), eb = 0;
-      Rec<C> ra = lds_record<C>(recs[cur], ea), rb = ra;
-      while (true) {
-        m &= ~(1ull << ea);
-        if (m) { eb = 63 - __builtin_clzll(m); rb = lds_record<C>(recs[cur], eb); }
-        process(ra, ea);
-        if (m == 0) break;
-        m &= ~(1ull << eb);
-        if (m) { ea = 63 - __builtin_clzll(m); ra = lds_record<C>(recs[cur], ea); }
-        process(rb, eb);
-        if (m == 0) break;
-      }
+    while (m) {
+      const int ea = 63 - __builtin_clzll(m);
+      m &= ~(1ull << ea);
+      process(lds_record<C>(recs[cur], ea), ea);
     }
     __syncthreads();
     // combine the 4 wavefronts in fixed order and store one row per (tile, entry)
@@ -566,7 +553,7 @@ __global__ __launch_bounds__(HGS_BLOCK) __attribute__((amdgpu_waves_per_eu(HGS_B
       if (slot < Rcap) inst_grad[(size_t)slot * ROW + k] = s;
       part[0][e][k] = 0.f; part[1][e][k] = 0.f; part[2][e][k] = 0.f; part[3][e][k] = 0.f;
     }
-    if (lo > seg_lo && threadIdx.x < REC_BATCH * REC4) recs[cur ^ 1][threadIdx.x] = stage;
+    if (lo > seg_lo && threadIdx.x < BWD_BATCH * REC4) recs[cur ^ 1][threadIdx.x] = stage;
     __syncthreads();
   }
 }
@@ -579,8 +566,12 @@ extern "C" int hgs_debug_set_wg_trace(void* device_buf_fwd, void* device_buf_bwd
   return 0;
 }
 
-// one workgroup per unsplit tile + one per segment of a split list (at most seg_cap of those; idle workgroups leave at once)
-static inline unsigned blend_grid(int T, const HgsBinning& b) { return (unsigned)T + b.seg_cap; }
+// one workgroup per unsplit tile + one per segment of a split list (at most what the work list and the segment arrays hold;
+// idle workgroups leave at once)
+static inline unsigned blend_grid(int T, const HgsBinning& b) {
+  const unsigned cap = (unsigned)HGS_SPLIT_CAPACITY(T);
+  return (unsigned)T + (b.seg_cap < cap ? b.seg_cap : cap);
+}
 
 int hgs_launch_blend_fwd(hipStream_t s, int W, int H, int Rcap, int channels, const float* bg, const HgsImage& im,
                          const HgsBinning& b, float* out_color) {

@@ -7,7 +7,7 @@
 //                           tile_sortprog, sort_items, tile_order
 //   binning (per instance)  keys (depth<<32|id<<4|quadrant mask), point_list, packed records, (reserved), sorted keys,
 //                           + per list SEGMENT (long tile lists are split across workgroups, see hgs_blend.hip):
-//                           seg_work, seg_P, seg_T, seg_Tout, seg_last, seg_C
+//                           seg_P, seg_T, seg_Tout, seg_last, seg_C
 // They play the roles of GeometryState / ImageState / BinningState of the reference
 // (cuda_rasterizer/rasterizer_impl.h:23-71) but the layout is this library's own.
 #pragma once
@@ -44,8 +44,7 @@ struct HgsImage {
 };
 struct HgsBinning {
   uint64_t* keys; uint32_t* point_list; float4* packed; uint32_t* inv; uint64_t* keys_sorted;
-  // per list segment of a split tile (index = the segment's position in seg_work), 256 pixels each:
-  uint32_t* seg_work;   // work items tile | segment << 24, a tile's segments consecutive
+  // per list segment of a split tile (index = the segment's position in the work list im.tile_order), 256 pixels each:
   float* seg_P;         // transmittance product of the segment's entries (forward, phase 1)
   float* seg_T;         // transmittance in front of the segment (kept for the backward)
   float* seg_Tout;      // transmittance after the segment's walk, negative: the pixel stopped in it
@@ -55,8 +54,9 @@ struct HgsBinning {
 };
 
 // status words of the image buffer (HGS_IMG_STATUS)
+// ([4..7] are read as ONE 16-byte scalar load by every blend workgroup)
 enum { HGS_ST_R = 0, HGS_ST_OVERFLOW = 1, HGS_ST_SCANPTR_LO = 2, HGS_ST_SCANPTR_HI = 3, HGS_ST_SORT_ITEMS = 4,
-       HGS_ST_SPLIT_ITEMS = 5, HGS_ST_TIMEOUT = 6, HGS_ST_SEG_LEN = 7, HGS_ST_UNSPLIT = 8 };
+       HGS_ST_SPLIT_ITEMS = 5, HGS_ST_SEG_LEN = 6, HGS_ST_WORK_ITEMS = 7, HGS_ST_TIMEOUT = 8 };
 #define HGS_SORT_CAP 2048        // keys one workgroup sorts in LDS (16 KB)
 #define HGS_MAX_PARTS 63         // chunks / segments of one tile list that cooperate (bits 0..62 of the progress masks)
 #define HGS_PART_FLAG (1ull << 63)
@@ -91,6 +91,7 @@ static inline size_t hgs_geom_carve(char* base, size_t P, HgsGeom& g, size_t* of
   hgs_carve(cur, g.grec, 4 * P);
   return hgs_align_up((size_t)(cur - base)) + HGS_ALIGN;
 }
+#define HGS_SPLIT_CAPACITY(T) ((size_t)(T) > 1024 ? (size_t)(T) : (size_t)1024)   // segment work items a frame can hold
 static inline size_t hgs_image_zero_words(size_t T) { return 4 * T + HGS_STATUS_WORDS + 4 * T; }
 static inline size_t hgs_image_carve(char* base, size_t W, size_t H, HgsImage& im, size_t* offs) {
   char* cur = base;
@@ -108,8 +109,9 @@ static inline size_t hgs_image_carve(char* base, size_t W, size_t H, HgsImage& i
   im.tile_sortprog = im.tile_prog + T;
   cur += hgs_image_zero_words(T) * sizeof(uint32_t);
   hgs_carve(cur, im.sort_items, T);
-  // unsplit tiles in descending order of list length: the blend kernels' workgroup -> tile map (sort_tiles_kernel)
-  hgs_carve(cur, im.tile_order, T);         if (offs) offs[HGS_IMG_TILE_ORDER] = (char*)im.tile_order - base;
+  // the blend kernels' work list (sort_tiles_kernel): workgroup -> tile | segment << 24; segments of split lists first,
+  // then the other tiles in descending order of list length.  T + HGS_SPLIT_CAPACITY(T) entries.
+  hgs_carve(cur, im.tile_order, T + HGS_SPLIT_CAPACITY(T));  if (offs) offs[HGS_IMG_TILE_ORDER] = (char*)im.tile_order - base;
   return hgs_align_up((size_t)(cur - base)) + HGS_ALIGN;
 }
 static inline size_t hgs_binning_carve(char* base, size_t R, HgsBinning& b, size_t* offs, int channels = 3) {
@@ -120,7 +122,6 @@ static inline size_t hgs_binning_carve(char* base, size_t R, HgsBinning& b, size
   hgs_carve(cur, b.inv, R);                                   if (offs) offs[HGS_BIN_INV] = (char*)b.inv - base;
   hgs_carve(cur, b.keys_sorted, R);                           if (offs) offs[HGS_BIN_KEYS_TMP] = (char*)b.keys_sorted - base;
   b.seg_cap = hgs_seg_capacity(R);
-  hgs_carve(cur, b.seg_work, b.seg_cap);
   hgs_carve(cur, b.seg_P, (size_t)b.seg_cap * 256);
   hgs_carve(cur, b.seg_T, (size_t)b.seg_cap * 256);
   hgs_carve(cur, b.seg_Tout, (size_t)b.seg_cap * 256);

@@ -48,7 +48,7 @@ def intermediates(scene, fw):
     o["final_T"] = _view(ib, im["final_T"], W * H, np.float32).reshape(H, W)
     o["n_contrib"] = _view(ib, im["n_contrib"], W * H, np.uint32).reshape(H, W)
     o["ranges"] = _view(ib, im["ranges"], 2 * T, np.uint32).reshape(T, 2)
-    o["status"] = _view(ib, im["status"], 16, np.uint32)   # csrc/hgs_common.h HGS_ST_*: [0] R, [1] overflow, [4] sort chunk items, [5] blend segment items, [6] wait timeout, [7] segment length, [8] unsplit tiles
+    o["status"] = _view(ib, im["status"], 16, np.uint32)   # csrc/hgs_common.h HGS_ST_*: [0] R, [1] overflow, [4] sort chunk items, [5] blend segment items, [6] segment length, [7] blend work items, [8] wait timeout
     o["tile_maxc"] = _view(ib, im["tile_maxc"], T, np.uint32)
     if R:
         b = rt.layout("binning", R)
@@ -85,11 +85,10 @@ def run_backward(scene, fw, dL_dpix):
     return g
 
 
-def segment_work(fw):
-    """The blend work items of split lists (HgsBinning.seg_work: tile | segment << 24), capacity-many entries.  The array
-    follows the sorted keys in the binning buffer (csrc/hgs_common.h hgs_binning_carve)."""
-    R = fw["R"]
-    b = rt.layout("binning", R)
-    off = (b["keys_sorted"] + 8 * R + 255) // 256 * 256
-    cap = R // 64 + 2
-    return _view(fw["binning"], off, cap, np.uint32)
+
+def blend_work_list(scene, fw):
+    """The blend kernels' work list (HgsImage.tile_order: tile | segment << 24; T + max(T, 1024) entries, sort_tiles_kernel)."""
+    W, H = scene["W"], scene["H"]
+    T = ((W + 15) // 16) * ((H + 15) // 16)
+    lay = rt.layout("image", W, H)
+    return _view(fw["img"], lay["tile_order"], T + max(T, 1024), np.uint32)

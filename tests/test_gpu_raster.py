@@ -97,7 +97,7 @@ def _check_forward(name):
     fw = G.run_forward(s)
     got = G.intermediates(s, fw)
     vis = ref["radii"] > 0
-    assert got["status"][1] == 0 and got["status"][6] == 0   # no capacity overflow, no cooperative-wait timeout
+    assert got["status"][1] == 0 and got["status"][8] == 0   # no capacity overflow, no cooperative-wait timeout
     # ---- bit-exact stages
     np.testing.assert_array_equal(got["radii"], ref["radii"])
     np.testing.assert_array_equal(got["tiles_touched"], ref["tiles_touched"])
@@ -147,14 +147,16 @@ def test_blend_work_list_covers_every_tile_once(name):
     lay = rt.layout("image", W, H)
     img = fw["img"].cpu().numpy()
     st = img[lay["status"]:lay["status"] + 64].view(np.uint32)
-    n_split_items, seg_len, n_unsplit = int(st[5]), int(st[7]), int(st[8])
-    assert st[6] == 0 and 128 <= seg_len <= 1024 and seg_len % 64 == 0
-    order = img[lay["tile_order"]:lay["tile_order"] + 4 * T].view(np.uint32)[:n_unsplit]
+    n_split_items, seg_len, n_work = int(st[5]), int(st[6]), int(st[7])
+    assert st[8] == 0 and 128 <= seg_len <= 1024 and seg_len % 64 == 0
+    work_list = G.blend_work_list(s, fw)
+    order = work_list[n_split_items:n_work]
+    assert (order >> 24 == 0).all()
     ranges = img[lay["ranges"]:lay["ranges"] + 8 * T].view(np.uint32).reshape(T, 2)
     n = (ranges[:, 1] - ranges[:, 0]).astype(np.int64)
     split_tiles = {}
     if n_split_items:
-        work = G.segment_work(fw)[:n_split_items]
+        work = work_list[:n_split_items]
         assert (work != 0xFFFFFFFF).all()
         for pos, item in enumerate(work.tolist()):
             split_tiles.setdefault(item & 0xFFFFFF, []).append((pos, item >> 24))
