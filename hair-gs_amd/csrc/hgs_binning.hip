@@ -156,59 +156,96 @@ __device__ __forceinline__ void bitonic_lds(uint64_t* sk, int m) {
   }
 }
 
-// Work list of the blend kernels, computed by ONE extra workgroup of the sort kernel, i.e. in the shadow of the sorts.
-// im.tile_order[w] = tile | segment << 24 for workgroup w:
+// Work list of the blend kernels, computed by WL_BUILDERS extra workgroups of the sort kernel, i.e. in the shadow of the
+// sorts.  im.tile_order[w] = tile | segment << 24 for workgroup w:
 //   * Lists longer than 1.5 segment lengths (hgs_split_of) are SPLIT: one work item per segment, a tile's segments
 //     consecutive and ascending (the forward waits on predecessors only), the tile flagged in tile_prog.  These items come
 //     first: they are the longest pieces of work (and their position is the index of the segment's state in HgsBinning).
+//     All long lists are split or -- if their segments do not fit the work list / the segment arrays -- none is.
 //   * The other tiles follow in descending order of list length (counting sort by min(length, ORD_BUCKETS-1)).  A list
 //     is consumed sequentially, so the blend kernels end when the longest pieces end: measured on the strand workload,
 //     raster order started the 58-us tiles of the backward 15-30 us into the launch.
+// A builder workgroup runs alone on its SIMDs, so every pass over the T tiles is a chain of latencies (measured at 1080p
+// with one builder: 4 us of loads + 5.5 us per further pass = 21 us, and the sort kernel lasts as long as its slowest
+// workgroup).  Hence: ONE counting pass that every builder runs over all tiles -- load a length, note the bucket in LDS,
+// count it with LDS atomics that return nothing; no global store in the loop, so the loads of several iterations are in
+// flight together; the rare long lists only note their tile in a candidate list --, and a placing pass that each builder
+// runs over ITS share of the tiles only (the tiles of the shares before it were counted separately in the first pass).
+#define WL_BUILDERS 4
 __device__ __forceinline__ void work_list_block(int T, uint32_t Rcap, HgsSegPolicy pol, const HgsImage& im, const HgsBinning& b, uint16_t* bk, int bk_cap) {
-  __shared__ uint32_t hist[ORD_BUCKETS], obase[ORD_BUCKETS], wsum[HGS_BLOCK / 64], nsplit_items, nsplit_tiles;
+  constexpr int SPLIT_BUCKET = 0xFFFF, CANDIDATE = 0xFFFE, MAX_CAND = 512;
+  __shared__ uint32_t hist[ORD_BUCKETS], before[ORD_BUCKETS], wsum[HGS_BLOCK / 64];   // (`before` becomes the buckets' first positions)
+  __shared__ uint32_t cand[MAX_CAND], ncand, nitems, nsplit_base;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  for (int i = tid; i < ORD_BUCKETS; i += HGS_BLOCK) hist[i] = 0u;
-  if (tid == 0) { nsplit_items = 0u; nsplit_tiles = 0u; }
+  if (T > bk_cap && blockIdx.x != 0) return;                          // huge frames: one builder, buckets from memory
+  const bool cached = T <= bk_cap;
+  const int nbuild = cached ? WL_BUILDERS : 1, me = (int)blockIdx.x;
+  const int share = ((T + nbuild - 1) / nbuild + HGS_BLOCK - 1) / HGS_BLOCK * HGS_BLOCK;
+  const int my0 = min(T, me * share), my1 = min(T, my0 + share);     // the tiles this builder places
+  for (int i = tid; i < ORD_BUCKETS; i += HGS_BLOCK) { hist[i] = 0u; before[i] = 0u; }
+  if (tid == 0) { ncand = 0u; nitems = 0u; nsplit_base = 0u; }
   const uint32_t S = hgs_segment_length(im.status[HGS_ST_R], pol);
   const uint32_t seg_cap = min(b.seg_cap, (uint32_t)HGS_SPLIT_CAPACITY(T));   // (what the work list holds)
+  const uint32_t thr = seg_cap ? S + S / 2 : 0xFFFFFFFFu;
   __syncthreads();
-  constexpr int SPLIT_BUCKET = 0xFFFF;
-  // bucket of a tile of n entries; split tiles get their work items here (once per tile)
-  auto classify = [&](int i, uint32_t n) {
-    const HgsSplit sp = hgs_split_of(n, S);
-    if (sp.nseg > 1 && seg_cap && im.ranges[i].y <= Rcap) {   // (a list beyond the binning capacity is void: status[1])
-      const uint32_t base = atomicAdd(&nsplit_items, sp.nseg);
-      const bool fits = base + sp.nseg <= seg_cap;
-      for (uint32_t k = 0; k < sp.nseg && base + k < seg_cap; k++) im.tile_order[base + k] = fits ? ((uint32_t)i | (k << 24)) : HGS_ITEM_NONE;
-      if (fits) { im.tile_prog[i] = HGS_PART_FLAG; atomicAdd(&nsplit_tiles, 1u); return SPLIT_BUCKET; }
-    }
-    return ORD_BUCKETS - 1 - (int)min(n, (uint32_t)(ORD_BUCKETS - 1));   // bucket 0 = longest lists
+  auto length_of = [&](int i) { const uint2 r = im.ranges[i]; return r.y > Rcap ? 0u : r.y - r.x; };   // (beyond the capacity: void)
+  auto bucket_for = [&](uint32_t n) { return ORD_BUCKETS - 1 - (int)min(n, (uint32_t)(ORD_BUCKETS - 1)); };   // 0 = longest
+  auto count = [&](int i, int k) { atomicAdd(&hist[k], 1u); if (i < my0) atomicAdd(&before[k], 1u); };
+  auto bucket_mem = [&](int i) {   // (uncached frames: the bucket again from memory)
+    const uint32_t n = length_of(i);
+    return n > thr && nsplit_base != 0xFFFFFFFFu ? SPLIT_BUCKET : bucket_for(n);
   };
-  auto length_of = [&](int i) { const uint2 r = im.ranges[i]; return r.y - r.x; };
-  const bool cached = T <= bk_cap;
+  // ---- counting pass over ALL tiles
   if (cached) {
-    // pass 0: the list lengths (clipped to 16 bits) into LDS -- nothing but loads in this loop, so the loads of several
-    // iterations are in flight together (the classification below stores, which would order it behind every load)
 #pragma unroll 8
-    for (int i = tid; i < T; i += HGS_BLOCK) bk[i] = (uint16_t)min(length_of(i), 0xFFFFu);
-    __syncthreads();
     for (int i = tid; i < T; i += HGS_BLOCK) {
-      const uint32_t n = bk[i] == 0xFFFFu ? length_of(i) : (uint32_t)bk[i];
-      bk[i] = (uint16_t)classify(i, n);
+      const uint32_t n = length_of(i);
+      const int k = n > thr ? CANDIDATE : bucket_for(n);
+      bk[i] = (uint16_t)k;
+      if (k != CANDIDATE) count(i, k);
+      else { const uint32_t c = atomicAdd(&ncand, 1u); if (c < MAX_CAND) cand[c] = (uint32_t)i; }
     }
-    __syncthreads();
+  } else {
+    for (int i = tid; i < T; i += HGS_BLOCK) {
+      const uint32_t n = length_of(i);
+      if (n > thr) atomicAdd(&ncand, 1u); else count(i, bucket_for(n));
+    }
   }
-  auto bucket_of = [&](int i) {
-    if (cached) return (int)bk[i];
-    if (im.tile_prog[i] == HGS_PART_FLAG) return SPLIT_BUCKET;
-    return ORD_BUCKETS - 1 - (int)min(length_of(i), (uint32_t)(ORD_BUCKETS - 1));
+  __syncthreads();
+  // ---- long lists: how many segments in all?  (every builder computes the same number)
+  const uint32_t nc = ncand;
+  const bool listed = cached && nc <= MAX_CAND;
+  if (listed)
+    for (uint32_t c = tid; c < nc; c += HGS_BLOCK) atomicAdd(&nitems, hgs_split_of(length_of((int)cand[c]), S).nseg);
+  else if (nc)
+    for (int i = tid; i < T; i += HGS_BLOCK) { const uint32_t n = length_of(i); if (n > thr) atomicAdd(&nitems, hgs_split_of(n, S).nseg); }
+  __syncthreads();
+  const bool split_all = nc != 0u && nitems <= seg_cap;
+  const uint32_t nsplit = split_all ? nitems : 0u;
+  if (!split_all && tid == 0) nsplit_base = 0xFFFFFFFFu;              // (bucket_mem: long lists stay whole)
+  __syncthreads();
+  // a long list's tile: its work items (written by builder 0), or its bucket among the others
+  auto place_long = [&](int i) {
+    const uint32_t n = length_of(i);
+    if (split_all) {
+      if (cached) bk[i] = (uint16_t)SPLIT_BUCKET;
+      if (me == 0) {
+        const HgsSplit sp = hgs_split_of(n, S);
+        const uint32_t base = atomicAdd(&nsplit_base, sp.nseg);
+        for (uint32_t k = 0; k < sp.nseg; k++) im.tile_order[base + k] = (uint32_t)i | (k << 24);
+        im.tile_prog[i] = HGS_PART_FLAG;
+      }
+    } else {
+      const int k = bucket_for(n);
+      if (cached) bk[i] = (uint16_t)k;
+      count(i, k);
+    }
   };
-  if (!cached) {   // huge frames: classify once (items + flags), buckets are recomputed from the flags afterwards
-    for (int i = tid; i < T; i += HGS_BLOCK) classify(i, length_of(i));
-    __threadfence_block();
-    __syncthreads();
+  if (listed) {
+    for (uint32_t c = tid; c < nc; c += HGS_BLOCK) place_long((int)cand[c]);
+  } else if (nc) {
+    for (int i = tid; i < T; i += HGS_BLOCK) if (length_of(i) > thr) place_long(i);
   }
-  for (int i = tid; i < T; i += HGS_BLOCK) { const int k = bucket_of(i); if (k != SPLIT_BUCKET) atomicAdd(&hist[k], 1u); }
   __syncthreads();
   uint32_t carry = 0;
   for (int base = 0; base < ORD_BUCKETS; base += HGS_BLOCK) {   // exclusive scan of the histogram
@@ -218,20 +255,22 @@ __device__ __forceinline__ void work_list_block(int T, uint32_t Rcap, HgsSegPoli
     __syncthreads();
     uint32_t woff = 0, total = 0;
     for (int w = 0; w < HGS_BLOCK / 64; w++) { if (w < wave) woff += wsum[w]; total += wsum[w]; }
-    obase[base + tid] = carry + woff + incl - v;
+    before[base + tid] += nsplit + carry + woff + incl - v;   // first position of this builder's tiles in the bucket
     hist[base + tid] = 0u;
     carry += total;
     __syncthreads();
   }
-  const uint32_t nsplit = min(nsplit_items, seg_cap);   // (final: every tile was classified before the histogram pass)
-  for (int i = tid; i < T; i += HGS_BLOCK) {
-    const int bkt = bucket_of(i);
-    if (bkt != SPLIT_BUCKET) im.tile_order[nsplit + obase[bkt] + atomicAdd(&hist[bkt], 1u)] = (uint32_t)i;   // order inside a bucket is irrelevant
+  // ---- placing pass over this builder's share (order inside a bucket is irrelevant; unrolled: the returning LDS atomics
+  // of several iterations are in flight together)
+#pragma unroll 8
+  for (int i = my0 + tid; i < my1; i += HGS_BLOCK) {
+    const int bkt = cached ? (int)bk[i] : bucket_mem(i);
+    if (bkt != SPLIT_BUCKET) im.tile_order[before[bkt] + atomicAdd(&hist[bkt], 1u)] = (uint32_t)i;
   }
-  if (tid == 0) {
+  if (me == 0 && tid == 0) {
     im.status[HGS_ST_SPLIT_ITEMS] = nsplit;
     im.status[HGS_ST_SEG_LEN] = S;
-    im.status[HGS_ST_WORK_ITEMS] = nsplit + (uint32_t)T - nsplit_tiles;
+    im.status[HGS_ST_WORK_ITEMS] = nsplit + (uint32_t)T - (split_all ? nc : 0u);
   }
 }
 
@@ -255,16 +294,16 @@ __device__ __forceinline__ void add_lower_bounds(const uint64_t* sk, uint32_t cn
   for (int i = 0; i < KPT; i++) rank[i] += lo[i];
 }
 
-// grid: [0] work list, [1, T] one workgroup per tile, (T, ...) one workgroup per chunk work item of a long list
+// grid: [0, WL_BUILDERS) work list, then one workgroup per tile, then one per chunk work item of a long list
 template <bool EXTRA>
 __global__ __launch_bounds__(HGS_BLOCK) void sort_tiles_kernel(int gx, int T, uint32_t Rcap, HgsSegPolicy pol, HgsGeom g, HgsImage im,
                                                                HgsBinning b) {
   __shared__ uint64_t sk[SORT_CAP];
   constexpr int KPT = SORT_CAP / HGS_BLOCK;
-  if (blockIdx.x == 0) { work_list_block(T, Rcap, pol, im, b, (uint16_t*)sk, SORT_CAP * 4); return; }
-  if ((int)blockIdx.x > T) {
+  if (blockIdx.x < WL_BUILDERS) { work_list_block(T, Rcap, pol, im, b, (uint16_t*)sk, SORT_CAP * 4); return; }
+  if ((int)blockIdx.x >= T + WL_BUILDERS) {
     // ---- one chunk of a long list (work items from the scan: hgs_emit_sort_items)
-    const uint32_t j = blockIdx.x - (uint32_t)T - 1u;
+    const uint32_t j = blockIdx.x - (uint32_t)T - WL_BUILDERS;
     if (j >= min(im.status[HGS_ST_SORT_ITEMS], (uint32_t)T)) return;
     const uint32_t item = im.sort_items[j];
     if (item == HGS_ITEM_NONE) return;
@@ -315,7 +354,7 @@ __global__ __launch_bounds__(HGS_BLOCK) void sort_tiles_kernel(int gx, int T, ui
     }
     return;
   }
-  const int tile = blockIdx.x - 1;
+  const int tile = blockIdx.x - WL_BUILDERS;
   const uint2 range = im.ranges[tile];
   // empty, or binning buffer overflow (status[1] already set), or (more than one chunk: the only lists that can carry the
   // flag) a long list sorted by its chunk workgroups above
@@ -403,9 +442,9 @@ int hgs_launch_sort_tiles(hipStream_t s, int W, int H, int Rcap, int n_extra, co
     const long long items = 2ll * Rcap / HGS_SORT_CAP + 2;
     const int extra_wgs = (int)(items < T ? items : T);
     if (n_extra)
-      hipLaunchKernelGGL(sort_tiles_kernel<true>, dim3(T + 1 + extra_wgs), dim3(HGS_BLOCK), 0, s, gx, T, (uint32_t)Rcap, g_seg_policy, g, im, b);
+      hipLaunchKernelGGL(sort_tiles_kernel<true>, dim3(T + WL_BUILDERS + extra_wgs), dim3(HGS_BLOCK), 0, s, gx, T, (uint32_t)Rcap, g_seg_policy, g, im, b);
     else
-      hipLaunchKernelGGL(sort_tiles_kernel<false>, dim3(T + 1 + extra_wgs), dim3(HGS_BLOCK), 0, s, gx, T, (uint32_t)Rcap, g_seg_policy, g, im, b);
+      hipLaunchKernelGGL(sort_tiles_kernel<false>, dim3(T + WL_BUILDERS + extra_wgs), dim3(HGS_BLOCK), 0, s, gx, T, (uint32_t)Rcap, g_seg_policy, g, im, b);
   }
   HGS_CHECK_LAUNCH();
   return 0;
