@@ -156,6 +156,26 @@ __device__ __forceinline__ void bitonic_lds(uint64_t* sk, int m) {
   }
 }
 
+// Lists of at most 128 entries (most tiles of a hair frame) are sorted by ONE wavefront: 64 compare-exchange pairs per
+// stage fit its lanes, LDS operations of a wavefront execute in order, so no workgroup barrier separates the stages --
+// and the three other wavefronts of the workgroup leave at once, which frees their slots for the next tiles.
+#define WAVE_SORT_MAX 128
+__device__ __forceinline__ void wave_lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ void bitonic_wave(uint64_t* sk, int m, int lane) {
+  for (int k = 2; k <= m; k <<= 1) {
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      if (lane < (m >> 1)) {
+        const int i = ((lane & ~(j - 1)) << 1) | (lane & (j - 1));
+        const int l = i | j;
+        const bool asc = (i & k) == 0;
+        const uint64_t x = sk[i], y = sk[l];
+        if ((x > y) == asc) { sk[i] = y; sk[l] = x; }
+      }
+      wave_lds_fence();
+    }
+  }
+}
+
 // Work list of the blend kernels, computed by WL_BUILDERS extra workgroups of the sort kernel, i.e. in the shadow of the
 // sorts.  im.tile_order[w] = tile | segment << 24 for workgroup w:
 //   * Lists longer than 1.5 segment lengths (hgs_split_of) are SPLIT: one work item per segment, a tile's segments
@@ -171,7 +191,9 @@ __device__ __forceinline__ void bitonic_lds(uint64_t* sk, int m) {
 // count it with LDS atomics that return nothing; no global store in the loop, so the loads of several iterations are in
 // flight together; the rare long lists only note their tile in a candidate list --, and a placing pass that each builder
 // runs over ITS share of the tiles only (the tiles of the shares before it were counted separately in the first pass).
+#ifndef WL_BUILDERS
 #define WL_BUILDERS 4
+#endif
 __device__ __forceinline__ void work_list_block(int T, uint32_t Rcap, HgsSegPolicy pol, const HgsImage& im, const HgsBinning& b, uint16_t* bk, int bk_cap) {
   constexpr int SPLIT_BUCKET = 0xFFFF, CANDIDATE = 0xFFFE, MAX_CAND = 512;
   __shared__ uint32_t hist[ORD_BUCKETS], before[ORD_BUCKETS], wsum[HGS_BLOCK / 64];   // (`before` becomes the buckets' first positions)
@@ -362,6 +384,17 @@ __global__ __launch_bounds__(HGS_BLOCK) void sort_tiles_kernel(int gx, int T, ui
   if (range.y - range.x > SORT_CAP && (im.tile_sortprog[tile] & HGS_PART_FLAG)) return;
   const uint32_t start = range.x, n = range.y - range.x;
   const int tx = tile % gx, ty = tile / gx;
+  if (n <= WAVE_SORT_MAX) {   // short list: one wavefront, no barriers (see bitonic_wave)
+    if (threadIdx.x >= 64) return;
+    const int lane = threadIdx.x;
+    int m = 2;
+    while ((uint32_t)m < n) m <<= 1;
+    for (int i = lane; i < m; i += 64) sk[i] = (uint32_t)i < n ? b.keys[start + i] : ~0ull;
+    wave_lds_fence();
+    bitonic_wave(sk, m, lane);
+    for (uint32_t i = lane; i < n; i += 64) emit_instance<EXTRA>(sk[i], start + i, tx, ty, g, b);
+    return;
+  }
   const uint32_t nchunks = (n + SORT_CAP - 1) / SORT_CAP;
   for (uint32_t c = 0; c < nchunks; c++) {
     const uint32_t cbase = start + c * SORT_CAP;
