@@ -1,6 +1,12 @@
+#!/bin/bash
+# Same-box comparison of this tree with another checkout of the repository (default: _r1, a worktree of the round-1 head):
+#   tools/cmp_r1.sh [tree] -> gpurun_out/cmp_<tree|cur>_<workload>_<rep>.json   (print: tools/cmp_print.py)
+# Boxes of the pool differ by up to 20 % from call to call; only numbers of ONE gpurun call compare.
+tree=${1:-_r1}
 mkdir -p gpurun_out
 for rep in 1 2; do
-(cd _r1 && timeout 300 python bench.py --no-cpu-baseline 2>/dev/null | tail -1 > ../gpurun_out/cmp_r1_$rep.json)
-timeout 300 python bench.py --no-cpu-baseline --sustained-seconds 0 2>/dev/null | tail -1 > gpurun_out/cmp_cur_$rep.json
-HGS_LIB=$PWD/hair-gs_amd/libhgs_noemit.so timeout 300 python bench.py --no-cpu-baseline --sustained-seconds 0 2>/dev/null | tail -1 > gpurun_out/cmp_noemit_$rep.json
+ for w in ${WORKLOADS:-north_star c2 c3 c4}; do
+  (cd $tree && timeout 400 python bench.py --workload $w --steps 100 --warmup 10 --no-cpu-baseline 2>/dev/null | tail -1 > ../gpurun_out/cmp_${tree}_${w}_$rep.json)
+  timeout 400 python bench.py --workload $w --steps 100 --warmup 10 --repeats 3 --sustained-seconds 0 --no-cpu-baseline 2>/dev/null | tail -1 > gpurun_out/cmp_cur_${w}_$rep.json
+ done
 done

@@ -62,8 +62,8 @@ def knn_throughput():
 
 
 def bench_line(workload, extra=()):
-    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--workload", workload, "--steps", "60", "--warmup", "10",
-           "--no-cpu-baseline", *extra]
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--workload", workload, "--steps", "100", "--warmup", "10",
+           "--repeats", "3", "--sustained-seconds", "0", "--no-cpu-baseline", *extra]
     p = subprocess.run(cmd, capture_output=True, text=True, timeout=1500)
     line = [l for l in p.stdout.strip().split("\n") if l.startswith("{")]
     if not line:
@@ -72,8 +72,14 @@ def bench_line(workload, extra=()):
     k = d.get("kernel_us_per_launch", {})
     return {"iters_per_s": d["value"], "ms_per_step": d["ms_per_step"], "render_ms_per_view": d["render_ms_per_view"],
             "gaussians": d["config"]["gaussians"], "mean_num_rendered": d["config"]["mean_num_rendered"],
-            "iteration": d["config"].get("iteration"), "blend_fwd_us": k.get("blend_fwd_kernel"), "blend_bwd_us": k.get("blend_bwd_kernel"),
-            "sort_tiles_us": k.get("sort_tiles_kernel"), "roofline_frac": d.get("roofline", {}).get("frac")}
+            "mean_num_rendered_after_tile_cull": d["config"].get("mean_num_rendered_after_tile_cull"),
+            "iteration": d["config"].get("iteration"), "scaling": d.get("scaling"), "repeats": d.get("repeats"),
+            "blend_fwd_us": k.get("blend_fwd_kernel"), "blend_bwd_us": k.get("blend_bwd_kernel"),
+            "sort_tiles_us": k.get("sort_tiles_kernel"), "scatter_us": k.get("scatter_kernel"),
+            "preprocess_fwd_us": k.get("preprocess_fwd_kernel"), "preprocess_bwd_us": k.get("preprocess_bwd_kernel"),
+            "ssim_fwd_us": k.get("ssim_l1_fwd_kernel"), "ssim_bwd_us": k.get("ssim_l1_bwd_kernel"),
+            "roofline_frac": d.get("roofline", {}).get("frac"),
+            "algorithmic_bytes_per_launch": d.get("roofline", {}).get("algorithmic_bytes_per_launch")}
 
 
 def main():
@@ -83,6 +89,7 @@ def main():
     out["distCUDA2"] = knn_throughput()
     torch.cuda.empty_cache()
     out["bench"] = {w: bench_line(w) for w in ("north_star", "c2", "c3", "c5", "c4")}
+    out["bench"]["north_star_strong_8_views_per_step"] = bench_line("north_star", ("--scaling", "strong", "--no-kernel-timing"))
     out["bench"]["north_star_op_by_op"] = bench_line("north_star", ("--op-by-op",))
     out["bench"]["north_star_three_pass_eager_blocking"] = bench_line("north_star", ("--op-by-op", "--three-pass", "--blocking"))
     p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "cpu_baselines.py")], capture_output=True, text=True, timeout=1500)
