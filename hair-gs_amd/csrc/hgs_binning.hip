@@ -23,7 +23,7 @@ namespace {
 
 #define SCAN_THREADS 1024
 #define ORD_BUCKETS 512    // list-length buckets of the tile order (<= SCAN_THREADS)
-#define SORT_CAP HGS_SORT_CAP  // keys per LDS chunk (16 KB)
+#define SORT_CAP HGS_SORT_CAP  // keys per chunk
 
 // generic helper: scans `n` uint32 values with one 1024-thread block; calls emit(i, exclusive, value)
 template <typename F>
@@ -320,9 +320,11 @@ __device__ __forceinline__ void add_lower_bounds(const uint64_t* sk, uint32_t cn
 template <bool EXTRA>
 __global__ __launch_bounds__(HGS_BLOCK) void sort_tiles_kernel(int gx, int T, uint32_t Rcap, HgsSegPolicy pol, HgsGeom g, HgsImage im,
                                                                HgsBinning b) {
-  __shared__ uint64_t sk[SORT_CAP];
+  // (at least 16 KB: the work-list builders keep one 16-bit word per tile of a frame of up to 8192 tiles in it)
+  constexpr int SK_WORDS = SORT_CAP > 2048 ? SORT_CAP : 2048;
+  __shared__ uint64_t sk[SK_WORDS];
   constexpr int KPT = SORT_CAP / HGS_BLOCK;
-  if (blockIdx.x < WL_BUILDERS) { work_list_block(T, Rcap, pol, im, b, (uint16_t*)sk, SORT_CAP * 4); return; }
+  if (blockIdx.x < WL_BUILDERS) { work_list_block(T, Rcap, pol, im, b, (uint16_t*)sk, SK_WORDS * 4); return; }
   if ((int)blockIdx.x >= T + WL_BUILDERS) {
     // ---- one chunk of a long list (work items from the scan: hgs_emit_sort_items)
     const uint32_t j = blockIdx.x - (uint32_t)T - WL_BUILDERS;

@@ -57,7 +57,9 @@ struct HgsBinning {
 // ([4..7] are read as ONE 16-byte scalar load by every blend workgroup)
 enum { HGS_ST_R = 0, HGS_ST_OVERFLOW = 1, HGS_ST_SCANPTR_LO = 2, HGS_ST_SCANPTR_HI = 3, HGS_ST_SORT_ITEMS = 4,
        HGS_ST_SPLIT_ITEMS = 5, HGS_ST_SEG_LEN = 6, HGS_ST_WORK_ITEMS = 7, HGS_ST_TIMEOUT = 8 };
-#define HGS_SORT_CAP 2048        // keys one workgroup sorts in LDS (16 KB)
+#ifndef HGS_SORT_CAP
+#define HGS_SORT_CAP 512         // keys of one sort chunk = one workgroup (measured on the Stage-I workload: 2048 -> 65 us, 1024 -> 39 us, 512 -> 29 us for the sort kernel; no effect where lists are short)
+#endif
 #define HGS_MAX_PARTS 63         // chunks / segments of one tile list that cooperate (bits 0..62 of the progress masks)
 #define HGS_PART_FLAG (1ull << 63)
 #define HGS_ITEM_NONE 0xFFFFFFFFu

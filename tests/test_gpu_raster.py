@@ -21,11 +21,11 @@ VARIANTS = {
     "precomp_neg": dict(P=900, W=96, H=64, seed=4, use_colors_precomp=True, neg_colors=True, bg=(1.0, 1.0, 1.0)),
     "cov_precomp": dict(P=900, W=96, H=64, seed=5, use_cov3D_precomp=True, sh_degree=2),
     "dense_long_lists": dict(P=6000, W=64, H=48, seed=6, sh_degree=0, scale_lo=0.03, scale_hi=0.12,
-                             opacity_lo=0.01, opacity_hi=0.08),                              # >2048 entries per tile
+                             opacity_lo=0.01, opacity_hi=0.08),                              # ~3000 entries per tile: 6 sort chunks, 24 blend segments
     # lists of ~1000 entries: split into blend segments, one sort chunk
     "medium_lists": dict(P=2500, W=64, H=48, seed=15, sh_degree=1, scale_lo=0.03, scale_hi=0.1, opacity_lo=0.02,
                          opacity_hi=0.3, bg=(0.2, 0.1, 0.4)),
-    # ONE tile with > 63 x 2048 entries: more chunks / segments than cooperate (serial sort fallback, longer segments),
+    # ONE tile with > 63 x 512 entries: more sort chunks / blend segments than cooperate (serial sort fallback, longer segments),
     # and the stop rule reached deep inside the list
     "one_huge_tile": dict(P=140000, W=16, H=16, seed=14, spread=0.02, scale_lo=0.02, scale_hi=0.05, opacity_lo=0.003,
                           opacity_hi=0.012, behind_frac=0.0),

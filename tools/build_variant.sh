@@ -1,14 +1,17 @@
 #!/bin/bash
-# A/B builds of ONE translation unit: tools/build_variant.sh <name> <unit> [extra hipcc flags...]
-#   -> hair-gs_amd/libhgs_<name>.so = the current objects with csrc/<unit>.hip recompiled with the extra flags
+# A/B builds: tools/build_variant.sh <name> <unit[,unit...]> [extra hipcc flags...]
+#   -> hair-gs_amd/libhgs_<name>.so = the current objects with csrc/<unit>.hip (each listed unit) recompiled with the extra flags
 # (load it with HGS_LIB=... python bench.py ...; boxes differ run to run, variants are only comparable inside one gpurun call)
 set -e
 HERE=$(cd "$(dirname "$0")" && pwd); CS=$HERE/../hair-gs_amd/csrc
-name=$1; unit=$2; shift 2
+name=$1; units=${2//,/ }; shift 2
 make -s -C $CS
-contract=-ffp-contract=fast
-case $unit in hgs_api|hgs_preprocess|hgs_binning|hgs_knn) contract=-ffp-contract=off;; esac
-hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -fno-fast-math -munsafe-fp-atomics -Wall -Wno-unused-function $contract "$@" -c $CS/$unit.hip -o /tmp/variant_$name.o
-objs=$(ls $CS/build/*.o | grep -v "/$unit.o")
-hipcc --offload-arch=gfx950 -shared -fPIC $objs /tmp/variant_$name.o -o $HERE/../hair-gs_amd/libhgs_$name.so
+objs=$(ls $CS/build/*.o)
+for unit in $units; do
+  contract=-ffp-contract=fast
+  case $unit in hgs_api|hgs_preprocess|hgs_binning|hgs_knn) contract=-ffp-contract=off;; esac
+  hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -fno-fast-math -munsafe-fp-atomics -Wall -Wno-unused-function $contract "$@" -c $CS/$unit.hip -o /tmp/variant_${name}_$unit.o
+  objs=$(echo "$objs" | grep -v "/$unit.o")" /tmp/variant_${name}_$unit.o"
+done
+hipcc --offload-arch=gfx950 -shared -fPIC $objs -o $HERE/../hair-gs_amd/libhgs_$name.so
 echo built libhgs_$name.so

@@ -1,7 +1,8 @@
 #!/bin/bash
 # Same-box comparison of this tree with another checkout of the repository (default: _r1, a worktree of the round-1 head):
 #   tools/cmp_r1.sh [tree] -> gpurun_out/cmp_<tree|cur>_<workload>_<rep>.json   (print: tools/cmp_print.py)
-# Boxes of the pool differ by up to 20 % from call to call; only numbers of ONE gpurun call compare.
+# Boxes of the pool differ by a few per cent from call to call (and the workload drifts while it trains): only numbers of ONE
+# gpurun call, taken with the same bench protocol, compare.
 tree=${1:-_r1}
 mkdir -p gpurun_out
 for rep in 1 2; do
