@@ -372,15 +372,16 @@ def test_mark_visible():
     assert 0 < got.sum() < len(got)
 
 
-@pytest.mark.parametrize("name", ["sh0", "strands", "dense_long_lists", "tiny_image", "many_tiles"])
+@pytest.mark.parametrize("name", ["sh0", "strands", "dense_long_lists", "tiny_image", "many_tiles", "c3_full_size"])
 def test_capacity_mode_binning_equals_blocking_mode(name):
     """Capacity (async) mode: hgs_forward_preprocess launches no scan, the scatter kernel scans the tile counts itself
-    ("fused scan"; many_tiles exceeds its LDS and keeps the scan launch).  Ranges, sorted lists, image and the reported
-    instance count have to be what the blocking mode produces."""
+    ("fused scan"; many_tiles exceeds its LDS and c3_full_size -- 200 k Gaussians -- the Gaussian count up to which that
+    pays: both keep the scan launch).  Ranges, sorted lists, image and the reported instance count have to be what the
+    blocking mode produces."""
     import torch
     from diff_gaussian_rasterization import _C
     from tests import gpu_util as G
-    s = _scene(name)
+    s = _workload_scene("c3") if name == "c3_full_size" else _scene(name)
     ref_fw = G.run_forward(s)
     ref = G.intermediates(s, ref_fw)
     try:

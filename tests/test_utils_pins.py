@@ -56,6 +56,36 @@ def test_c_utils_matches_reference_cython(golden):
     assert c_utils.filter_strand_list_segments(np.empty(0, dtype=object)).shape == (0, 2, 2)
 
 
+def test_c_utils_native_module_contract():
+    """The native half (c_utils/_c_utils.c): strided / Fortran-ordered strands, plain lists, the flat form, and the
+    reference's error behaviour (None -> TypeError; a strand of >= 2 rows that is not 2-D int64 -> ValueError, which is what
+    the reference's typed memoryview raises; shorter strands are never looked at)."""
+    import pytest
+    import c_utils
+    assert c_utils._load().__name__ == "c_utils._c_utils"            # the compiled module, not a Python loop
+    rng = np.random.default_rng(3)
+    base = [rng.integers(0, 1000, (n, 2)).astype(np.int64) for n in (5, 0, 1, 7, 2)]
+    want = c_utils.filter_strand_segments_flat_numpy(*c_utils.strands_to_flat(base))
+    assert want.shape == (4 + 0 + 0 + 6 + 1, 2, 2)
+    np.testing.assert_array_equal(c_utils.filter_strand_list_segments(base), want)                       # a plain list
+    views = [np.asfortranarray(a) for a in base]
+    views[3] = np.concatenate([base[3], base[3]], axis=1)[:, ::2][:, :2].copy()[:, :]                    # fresh copy ...
+    wide = np.zeros((7, 6), np.int64)
+    wide[:, ::3] = base[3]
+    views[3] = wide[:, ::3]                                                                               # ... and a strided view
+    np.testing.assert_array_equal(c_utils.filter_strand_list_segments(np.array(views + [None], dtype=object)[:-1]), want)
+    np.testing.assert_array_equal(c_utils.filter_strand_segments_flat(*c_utils.strands_to_flat(base)), want)
+    with pytest.raises(TypeError):
+        c_utils.filter_strand_list_segments(None)
+    with pytest.raises(ValueError):
+        c_utils.filter_strand_list_segments([base[0].astype(np.int32)])
+    with pytest.raises(ValueError):
+        c_utils.filter_strand_list_segments([np.zeros((3, 2, 2), np.int64)])
+    assert c_utils.filter_strand_list_segments([np.zeros((1, 2), np.int32)]).shape == (0, 2, 2)         # too short to matter
+    with pytest.raises(ValueError):
+        c_utils.filter_strand_segments_flat(np.array([0, 5], np.int64), np.zeros((3, 2), np.int64))     # offsets beyond rows
+
+
 def test_argument_defaults_match_reference(golden):
     from argparse import ArgumentParser
     from arguments import GeneralParams, ModelParams, OptimizationParams
