@@ -17,33 +17,47 @@
 //   * LONG LISTS ARE SPLIT ACROSS WORKGROUPS (work list of sort_tiles_kernel: segments of 256-1024 entries).  The
 //     reference walks a tile's list with one thread block (forward.cu:295-362); a scene whose Gaussians pile up on a
 //     few hundred tiles (Stage I: 1000-3000 entries per tile) then runs at the speed of one workgroup per tile.
-//     Transmittance is a product, so segments compose:
-//       forward  phase 1: every segment's workgroup multiplies (1 - alpha) over ITS entries per pixel and publishes the
-//                         product (agent-scope stores + the tile's progress mask, hgs_common.h);
-//                phase 2: it reads its predecessors' products -- the transmittance in front of the segment --, walks
-//                         its entries again with the reference's rules (alpha test, T (1 - alpha) < 1e-4 stop) and
-//                         publishes colour, final transmittance and last contributor of the segment; the LAST
-//                         workgroup of the tile to finish (ticket) combines the segments per pixel in list order:
-//                         first stop wins, colours summed back to front (fixed order: reproducible), and leaves the
-//                         SUFFIX sums of the segment colours in place;
+//     Transmittance is a product and blending is linear in the transmittance in front, so segments compose:
+//       forward  pass A:  every segment's workgroup runs the reference's walk over ITS entries from a transmittance of 1
+//                         (no dependence on the segments in front) and publishes the per-pixel product (agent-scope
+//                         stores + the tile's progress mask, hgs_common.h);
+//                scaling: it reads its predecessors' products -- the true transmittance T_in in front of the segment.
+//                         A pixel the walk would not have stopped on (T_in * product clear of the 1e-4 rule) takes its
+//                         local colours times T_in; a pixel that is done before the segment contributes nothing;
+//                pass B:  only the pixels that stop INSIDE this segment (one segment per pixel; waves without such a
+//                         pixel skip) are walked again from T_in with the reference's rules (alpha test,
+//                         T (1 - alpha) < 1e-4 stop), which fixes their colour, final transmittance and last contributor;
+//                         the LAST workgroup of the tile to finish (ticket) combines the segments per pixel in list
+//                         order: first stop wins, colours summed back to front (fixed order: reproducible), and leaves
+//                         the SUFFIX sums of the segment colours in place;
 //       backward          needs no communication: a segment starts from the forward's transmittance in front of the NEXT
 //                         segment and from the colour behind it (that suffix sum) -- exactly the state the serial walk
 //                         would carry into it.
-//     The only numerical difference to the serial walk is the association of the transmittance product (one rounding
-//     per segment boundary).
+//     Numerical differences to the serial walk: the association of the transmittance product (one rounding per segment
+//     boundary) and, for the segments a pixel passes through, c alpha T_local T_in in place of c alpha T (one rounding
+//     per contribution).  Integer results (last contributor) follow the reference's rules on those products.
 #include "hgs_common.h"
 
 // development aid: per-workgroup start/end timestamps (hgs_debug_set_wg_trace)
 __device__ unsigned long long* g_wg_trace_fwd = nullptr;
 __device__ unsigned long long* g_wg_trace_bwd = nullptr;
-struct WgTrace {
-  unsigned long long* buf; int tile;
-  __device__ WgTrace(unsigned long long* b, int t) : buf(b), tile(t) {
-    if (buf && threadIdx.x == 0) buf[2 * tile] = __builtin_amdgcn_s_memrealtime();
+#ifndef HGS_WG_TRACE
+#define HGS_WG_TRACE 0   // build with -DHGS_WG_TRACE=1 (tools/build_variant.sh trace hgs_blend -DHGS_WG_TRACE=1) to record
+#endif
+struct WgTrace {   // 8 words per workgroup: start, marks 1..5, (tile | seg << 24 | nseg << 32 | list entries << 40), end
+#if HGS_WG_TRACE
+  unsigned long long* buf;
+  __device__ WgTrace(unsigned long long* b) : buf(b ? b + 8 * (size_t)blockIdx.x : nullptr) { mark(0); }
+  __device__ void mark(int k) const { if (buf && threadIdx.x == 0) buf[k] = __builtin_amdgcn_s_memrealtime(); }
+  __device__ void item(int tile, uint32_t seg, uint32_t nseg, uint32_t len) const {
+    if (buf && threadIdx.x == 0) buf[6] = (unsigned long long)tile | (unsigned long long)seg << 24 | (unsigned long long)nseg << 32 | (unsigned long long)len << 40;
   }
-  __device__ ~WgTrace() {
-    if (buf && threadIdx.x == 0) buf[2 * tile + 1] = __builtin_amdgcn_s_memrealtime();
-  }
+  __device__ ~WgTrace() { mark(7); }
+#else
+  __device__ WgTrace(unsigned long long*) {}
+  __device__ void mark(int) const {}
+  __device__ void item(int, uint32_t, uint32_t, uint32_t) const {}
+#endif
 };
 
 namespace {
@@ -176,12 +190,11 @@ __device__ __forceinline__ bool blend_item(const HgsImage& im, uint32_t Rcap, Bl
 }
 
 // Front-to-back walk of list positions [s, e) of a tile (src = the tile's first record).
-//   COLOR: the reference's loop (forward.cu:309-362): alpha test, stop rule, colour accumulation, last contributor.
-//          T < 0 marks a pixel that is done (saturated, forward.cu:346-351, or outside the image): its magnitude stays the
-//          transmittance it stopped at.  A separate per-lane flag costs a byte register and ~6 vector instructions per
-//          entry to test, merge and update; the sign costs one compare.
-//   !COLOR: phase 1 of a split list: T only collects the product of (1 - alpha) over the entries that pass the alpha test.
-template <int C, bool COLOR>
+// The reference's loop (forward.cu:309-362): alpha test, stop rule, colour accumulation, last contributor.
+// T < 0 marks a pixel that is done (saturated, forward.cu:346-351, or outside the image): its magnitude stays the
+// transmittance it stopped at.  A separate per-lane flag costs a byte register and ~6 vector instructions per
+// entry to test, merge and update; the sign costs one compare.
+template <int C>
 __device__ __forceinline__ void fwd_walk(const float4* __restrict__ src, uint32_t s, uint32_t e,
                                          float4 (&recs)[2][REC_BATCH * Chan<C>::REC4], uint32_t (&alive)[2][4], float pxf,
                                          float pyf, int wave, int lane, float& T, float (&acc)[C], uint32_t& last) {
@@ -205,7 +218,7 @@ __device__ __forceinline__ void fwd_walk(const float4* __restrict__ src, uint32_
     }
     __syncthreads();
     // forward.cu:309-311: the tile stops when every pixel is saturated (flags written before the barrier above)
-    if (COLOR && (alive[cur][0] | alive[cur][1] | alive[cur][2] | alive[cur][3]) == 0u) break;
+    if ((alive[cur][0] | alive[cur][1] | alive[cur][2] | alive[cur][3]) == 0u) break;
     const int cnt = min(REC_BATCH, (int)L - b * REC_BATCH);
     const float* rf = (const float*)&recs[cur][0];
     const uint32_t mk = lane < cnt ? __float_as_uint(rf[lane * 4 * REC4 + 7 + C]) : 0u;
@@ -220,10 +233,6 @@ __device__ __forceinline__ void fwd_walk(const float4* __restrict__ src, uint32_
       const bool ok = T > 0.f && power <= 0.f && alpha >= (1.0f / 255.0f);              // :336, :344
       if (__ballot(ok) == 0) return;
       const float test_T = T * (1.f - alpha);
-      if (!COLOR) {
-        if (ok) T = test_T;
-        return;
-      }
       const bool sat = ok && test_T < 0.0001f;                                          // :346-351
       if (ok && !sat) {
         const float w = alpha * T;
@@ -260,7 +269,7 @@ __device__ __forceinline__ void fwd_walk(const float4* __restrict__ src, uint32_
 
 // ------------------------------------------------------------------------------------------------
 template <int C>
-__global__ __launch_bounds__(HGS_BLOCK) void blend_fwd_kernel(HgsImage im, HgsBinning bn, int W, int H, int gx, uint32_t Rcap,
+__global__ __launch_bounds__(HGS_BLOCK) __attribute__((amdgpu_waves_per_eu(8))) void blend_fwd_kernel(HgsImage im, HgsBinning bn, int W, int H, int gx, uint32_t Rcap,
                                                               const float* __restrict__ bg, float* __restrict__ out_color) {
   constexpr int REC4 = Chan<C>::REC4;
   __shared__ float4 recs[2][REC_BATCH * REC4];
@@ -269,7 +278,8 @@ __global__ __launch_bounds__(HGS_BLOCK) void blend_fwd_kernel(HgsImage im, HgsBi
   BlendItem it;
   if (!blend_item(im, Rcap, it)) return;
   const int tile = it.tile;
-  WgTrace _trace(g_wg_trace_fwd, tile);
+  WgTrace _trace(g_wg_trace_fwd);
+  _trace.item(tile, it.seg, it.nseg, it.e - it.s);
   const int tx = tile % gx, ty = tile / gx;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int px = tx * HGS_TILE + (wave & 1) * 8 + (lane & 7);
@@ -285,7 +295,7 @@ __global__ __launch_bounds__(HGS_BLOCK) void blend_fwd_kernel(HgsImage im, HgsBi
 
   if (!it.split) {
     float T = inside ? 1.f : -1.f;
-    fwd_walk<C, true>(src, 0u, it.e, recs, alive, pxf, pyf, wave, lane, T, acc, last);
+    fwd_walk<C>(src, 0u, it.e, recs, alive, pxf, pyf, wave, lane, T, acc, last);
     uint32_t wmax = last;
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) wmax = max(wmax, (uint32_t)__shfl_xor((int)wmax, d, 64));
@@ -302,9 +312,15 @@ __global__ __launch_bounds__(HGS_BLOCK) void blend_fwd_kernel(HgsImage im, HgsBi
 
   // ---- one segment of a split list (see the file header)
   const size_t slot = (size_t)it.w * HGS_BLOCK + threadIdx.x;   // this pixel's cell in the per-segment arrays
-  // phase 1: product of (1 - alpha) over this segment
-  float P = inside ? 1.f : -1.f;
-  fwd_walk<C, false>(src, it.s, it.e, recs, alive, pxf, pyf, wave, lane, P, acc, last);
+  const size_t slot0 = slot - (size_t)it.seg * HGS_BLOCK;       // the same pixel's cell of the tile's first segment
+  // pass A: the reference's walk over this segment with the transmittance in front of it taken as 1 (no dependence on the
+  // segments before it): local product, local colours, last contributing position
+  float T = inside ? 1.f : -1.f;
+  fwd_walk<C>(src, it.s, it.e, recs, alive, pxf, pyf, wave, lane, T, acc, last);
+  // A pixel that stopped on the local product stops in this segment or before it for any transmittance <= 1 in front:
+  // what the later segments read as this segment's product only has to be below the stop threshold.
+  const float P = inside ? fmaxf(T, 0.f) : -1.f;
+  _trace.mark(1);
   hgs_st_agent(&bn.seg_P[slot], P);
   hgs_drain_stores();
   __syncthreads();
@@ -313,46 +329,105 @@ __global__ __launch_bounds__(HGS_BLOCK) void blend_fwd_kernel(HgsImage im, HgsBi
     s_flag = it.seg == 0 || hgs_wait_parts(&im.tile_prog[tile], (1ull << it.seg) - 1ull, im.status) ? 1u : 0u;
   }
   __syncthreads();
-  float T = inside ? 1.f : -1.f;
+  float T_in = inside ? 1.f : -1.f;
   if (s_flag) {
-    for (uint32_t m = 0; m < it.seg; m++) T *= hgs_ld_agent(&bn.seg_P[slot - (size_t)(it.seg - m) * HGS_BLOCK]);   // (outside: -1 * -1 ...)
-    if (!inside) T = -1.f;
-  }
-  bn.seg_T[slot] = fabsf(T);     // transmittance in front of this segment: the backward of the PREVIOUS segment starts from it
-  // a pixel below the stop threshold is done: any entry that passes the alpha test would stop it (T (1 - alpha) < T)
-  if (T > 0.f && T < 0.0001f) T = -T;
-  // phase 2: the reference's walk over this segment
-  fwd_walk<C, true>(src, it.s, it.e, recs, alive, pxf, pyf, wave, lane, T, acc, last);
+    constexpr uint32_t TG = 8;
+    // (several loads in flight at a time: one L2 round trip per predecessor was most of a late segment's wait)
+    for (uint32_t m0 = 0; m0 < it.seg; m0 += TG) {
+      float v[TG];
 #pragma unroll
-  for (int k = 0; k < C; k++) hgs_st_agent(&bn.seg_C[((size_t)it.w * C + k) * HGS_BLOCK + threadIdx.x], acc[k]);
-  hgs_st_agent(&bn.seg_Tout[slot], T);
-  hgs_st_agent(&bn.seg_last[slot], last);
+      for (uint32_t j = 0; j < TG; j++) v[j] = m0 + j < it.seg ? hgs_ld_agent(&bn.seg_P[slot0 + (size_t)(m0 + j) * HGS_BLOCK]) : 1.f;
+#pragma unroll
+      for (uint32_t j = 0; j < TG; j++) T_in *= v[j];                 // list order (a factor of 1 is exact)
+    }
+    if (!inside) T_in = -1.f;
+  }
+  _trace.mark(2);
+  bn.seg_T[slot] = fabsf(T_in);  // transmittance in front of this segment: the backward of the PREVIOUS segment starts from it
+  // Per pixel, with the true transmittance in front now known:
+  //   below the stop threshold  -> done before this segment: any entry that passes the alpha test would stop it;
+  //   no local stop and T_in * P clear of the threshold -> the walk would not have stopped here either: its colours are
+  //                                the local ones times T_in (blending is linear in the transmittance in front);
+  //   otherwise                 -> the pixel stops in this segment (or sits within rounding of the threshold): only
+  //                                these pixels are walked again, from T_in, exactly as the serial walk would.
+  const bool dead = inside && T_in < 0.0001f;
+  const bool through = inside && !dead && T > 0.f && T_in * T >= 0.00010002f;
+  const bool redo = inside && !dead && !through;
+  auto publish = [&]() {   // this pixel's result for the segment (the tile's finalisation and the backward read it)
+#pragma unroll
+    for (int k = 0; k < C; k++) hgs_st_agent(&bn.seg_C[((size_t)it.w * C + k) * HGS_BLOCK + threadIdx.x], acc[k]);
+    hgs_st_agent(&bn.seg_Tout[slot], T);
+    hgs_st_agent(&bn.seg_last[slot], last);
+  };
+  if (through) {
+    T *= T_in;
+#pragma unroll
+    for (int k = 0; k < C; k++) acc[k] *= T_in;
+  } else if (!redo) {      // done before this segment (or outside the image)
+    T = -fmaxf(fabsf(T_in), 1e-30f);
+    last = 0u;
+#pragma unroll
+    for (int k = 0; k < C; k++) acc[k] = 0.f;
+  }
+  if (!redo) publish();
+  if (__syncthreads_or(redo ? 1 : 0)) {   // pass B (the registers of pass A are free again: its results are stored)
+    T = redo ? T_in : -1.f;
+    last = 0u;
+#pragma unroll
+    for (int k = 0; k < C; k++) acc[k] = 0.f;
+    fwd_walk<C>(src, it.s, it.e, recs, alive, pxf, pyf, wave, lane, T, acc, last);
+    if (redo) publish();
+  }
+  _trace.mark(3);
   hgs_drain_stores();
   __syncthreads();
   if (threadIdx.x == 0)
     s_flag = __hip_atomic_fetch_add(&im.tile_done[tile], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == it.nseg - 1u ? 1u : 0u;
   __syncthreads();
+  _trace.mark(4);
   if (!s_flag) return;
   // ---- the tile's last workgroup: combine the segments per pixel, in list order
-  const size_t slot0 = slot - (size_t)it.seg * HGS_BLOCK;
   const size_t w0 = (size_t)it.w - it.seg;
+  // (loads in groups: each group costs one L2 round trip, and a 60-segment tile is finalised by ONE workgroup)
   float Tfin = 1.f;
   uint32_t nc = 0u, lastseg = it.nseg - 1u;
-  for (uint32_t m = 0; m < it.nseg; m++) {
-    const float to = hgs_ld_agent(&bn.seg_Tout[slot0 + (size_t)m * HGS_BLOCK]);
-    nc = max(nc, hgs_ld_agent(&bn.seg_last[slot0 + (size_t)m * HGS_BLOCK]));
-    Tfin = fabsf(to);
-    if (to < 0.f) { lastseg = m; break; }   // stopped here: nothing behind it contributes
+  bool stopped = false;
+  for (uint32_t m0 = 0; m0 < it.nseg; m0 += 8) {
+    float to[8];
+    uint32_t la[8];
+#pragma unroll
+    for (uint32_t j = 0; j < 8; j++) {
+      const bool in = m0 + j < it.nseg;
+      to[j] = in ? hgs_ld_agent(&bn.seg_Tout[slot0 + (size_t)(m0 + j) * HGS_BLOCK]) : 0.f;
+      la[j] = in ? hgs_ld_agent(&bn.seg_last[slot0 + (size_t)(m0 + j) * HGS_BLOCK]) : 0u;
+    }
+#pragma unroll
+    for (uint32_t j = 0; j < 8; j++)
+      if (m0 + j < it.nseg && !stopped) {
+        nc = max(nc, la[j]);
+        Tfin = fabsf(to[j]);
+        if (to[j] < 0.f) { lastseg = m0 + j; stopped = true; }   // stopped here: nothing behind it contributes
+      }
   }
 #pragma unroll
   for (int k = 0; k < C; k++) acc[k] = 0.f;
-  for (int m = (int)it.nseg - 1; m >= 0; m--) {
+  constexpr int FG = C <= 4 ? 8 : 4;                               // segments per group of the colour sums
+  for (int mh = (int)it.nseg - 1; mh >= 0; mh -= FG) {
+    float v[FG][C];
 #pragma unroll
-    for (int k = 0; k < C; k++) {
-      float* cell = &bn.seg_C[((w0 + (size_t)m) * C + k) * HGS_BLOCK + threadIdx.x];
-      if ((uint32_t)m <= lastseg) acc[k] += hgs_ld_agent(cell);
-      *cell = acc[k];                        // suffix sum: colour added by segment m and everything behind it
-    }
+    for (int j = 0; j < FG; j++)
+#pragma unroll
+      for (int k = 0; k < C; k++)
+        v[j][k] = mh - j >= 0 ? hgs_ld_agent(&bn.seg_C[((w0 + (size_t)(mh - j)) * C + k) * HGS_BLOCK + threadIdx.x]) : 0.f;
+#pragma unroll
+    for (int j = 0; j < FG; j++)
+      if (mh - j >= 0) {
+#pragma unroll
+        for (int k = 0; k < C; k++) {
+          if ((uint32_t)(mh - j) <= lastseg) acc[k] += v[j][k];
+          bn.seg_C[((w0 + (size_t)(mh - j)) * C + k) * HGS_BLOCK + threadIdx.x] = acc[k];   // suffix sum: segment m and everything behind it
+        }
+      }
   }
   uint32_t wmax = inside ? nc : 0u;
 #pragma unroll
@@ -382,7 +457,8 @@ __global__ __launch_bounds__(HGS_BLOCK) __attribute__((amdgpu_waves_per_eu(HGS_B
   BlendItem it;
   if (!blend_item(im, Rcap, it) || void_pass) return;   // same work list as the forward: (tile, list segment)
   const int tile = it.tile;
-  WgTrace _trace(g_wg_trace_bwd, tile);
+  WgTrace _trace(g_wg_trace_bwd);
+  _trace.item(tile, it.seg, it.nseg, it.e - it.s);
   const uint2 range = it.range;
   const float4* __restrict__ packed = bn.packed;
   const uint32_t maxc = im.tile_maxc[tile];

@@ -349,8 +349,9 @@ int hgs_radius_pairs(void* stream, int N, const float* pos, const float* dir, fl
  * and its backward may run under different settings (the buffers carry the rectangles).  Returns the previous setting. */
 int hgs_set_tile_cull(int on);
 
-/* Development aid (tools/wg_trace.py): when a buffer of 2*T uint64 is registered, blend_fwd / blend_bwd record the
- * start and end time (s_memrealtime, 100 MHz) of every tile's workgroup in it; NULL (the default) switches it off. */
+/* Development aid (tools/wg_trace.py): when a buffer of 8 uint64 per workgroup of the blend grid (2 T + 1024 is always
+ * enough) is registered, blend_fwd / blend_bwd record per workgroup: start, phase marks 1..5, its work item, end (times
+ * from s_memrealtime, 100 MHz); NULL (the default) switches it off. */
 /* Tuning knob of the segment-parallel blend (csrc/hgs_blend.hip): tile lists longer than 1.5 segment lengths are walked
  * by one workgroup per segment; the segment length of a pass with R instances is R / target_segments rounded up to a
  * multiple of 64 and clamped to [min_len, max_len] (multiples of 64, min_len >= 128; default 128, 1024, 2048).  Process-wide, takes

@@ -1,5 +1,5 @@
 """Workgroup timeline of the blend kernels on a workload (development aid, hgs_debug_set_wg_trace): residency over time,
-per-tile duration against list length."""
+phase durations of the split lists, the latest finishers."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "hair-gs_amd")]
@@ -13,8 +13,9 @@ bg = torch.zeros(3, device="cuda")
 cam = cams[0]
 H, W = cam.image_height, cam.image_width
 T = ((W + 15) // 16) * ((H + 15) // 16)
+G = 2 * T + 1024
 w3 = torch.randn(3, H, W, device="cuda"); w1 = torch.randn(H, W, device="cuda"); wo = torch.randn(3, H, W, device="cuda")
-tf = torch.zeros(2 * T, dtype=torch.int64, device="cuda"); tb = torch.zeros(2 * T, dtype=torch.int64, device="cuda")
+tf = torch.zeros(8 * G, dtype=torch.int64, device="cuda"); tb = torch.zeros(8 * G, dtype=torch.int64, device="cuda")
 def run():
     extra = torch.cat((model.get_mask, model.get_orientation), dim=1)
     pkg = render_multi(cam, model, bg, extra, splits=(1, 3))
@@ -26,19 +27,39 @@ torch.cuda.synchronize()
 rt.check(rt.lib().hgs_debug_set_wg_trace(tf.data_ptr(), tb.data_ptr()))
 run(); torch.cuda.synchronize()
 rt.check(rt.lib().hgs_debug_set_wg_trace(None, None))
-from diff_gaussian_rasterization import _C
 for name, t in (("fwd", tf), ("bwd", tb)):
-    a = t.cpu().numpy().reshape(T, 2).astype(np.float64) * 0.01   # us (100 MHz)
-    ok = a[:, 1] > 0
-    t0, t1 = a[ok, 0].min(), a[ok, 1].max()
-    dur = a[:, 1] - a[:, 0]
-    print(f"{name}: kernel span {t1 - t0:.1f} us, tiles {ok.sum()}, mean WG dur {dur[ok].mean():.2f} us, max {dur[ok].max():.2f}, sum {dur[ok].sum():.0f} us")
-    # residency over time
+    a = t.cpu().numpy().reshape(G, 8)
+    ok = a[:, 7] > 0
+    a = a[ok]
+    item = a[:, 6]
+    tile, seg, nseg, length = item & 0xFFFFFF, (item >> 24) & 0xFF, (item >> 32) & 0xFF, item >> 40
+    us = a.astype(np.float64) * 0.01
+    t0, t1 = us[:, 0].min(), us[:, 7].max()
+    dur = us[:, 7] - us[:, 0]
+    split = nseg > 1
+    print(f"{name}: kernel span {t1 - t0:.1f} us, workgroups {len(a)} ({split.sum()} segments of {len(np.unique(tile[split]))} split tiles), "
+          f"entries {length.sum()} ({length[split].sum()} in split lists), sum of WG time {dur.sum():.0f} us")
     edges = np.linspace(t0, t1, 24)
-    occ = [(((a[ok, 0] <= e) & (a[ok, 1] > e)).sum()) for e in edges]
-    print("   resident WGs over time:", occ)
-    order = np.argsort(a[ok, 0]); first = a[ok, 0][order]
-    print("   WG start times (us from kernel start), every 800th:", np.round(first[::800] - t0, 1).tolist())
-    long = np.argsort(-dur)[:8]
-    print("   longest tiles:", [(int(i), round(float(dur[i]), 1), round(float(a[i, 0] - t0), 1)) for i in long])
-    print("   duration percentiles 10/50/90/99:", np.round(np.percentile(dur[ok], [10, 50, 90, 99]), 2).tolist())
+    print("   resident WGs over time:", [int(((us[:, 0] <= e) & (us[:, 7] > e)).sum()) for e in edges])
+    print("   start times percentiles 50/90/99/100:", np.round(np.percentile(us[:, 0] - t0, [50, 90, 99, 100]), 1).tolist())
+    for label, sel in (("unsplit", ~split), ("split", split)):
+        if sel.any():
+            print(f"   {label}: n {sel.sum()}, len mean {length[sel].mean():.0f} max {length[sel].max()}, dur p50/p90/max "
+                  f"{np.percentile(dur[sel], 50):.1f}/{np.percentile(dur[sel], 90):.1f}/{dur[sel].max():.1f} us, "
+                  f"ns per entry {1e3 * dur[sel].sum() / max(1, length[sel].sum()):.0f}")
+    if name == "fwd" and split.any():
+        s = us[split]
+        ph = np.stack([s[:, 1] - s[:, 0], s[:, 2] - s[:, 1], s[:, 3] - s[:, 2], s[:, 4] - s[:, 3], s[:, 7] - s[:, 4]], 1)
+        print("   split fwd phases (phase1, wait, phase2, publish+ticket, finalize) mean us:", np.round(ph.mean(0), 2).tolist(),
+              " p90:", np.round(np.percentile(ph, 90, axis=0), 2).tolist(), " max:", np.round(ph.max(0), 2).tolist())
+        print("   split fwd absolute times of start / mark1 / mark2 / mark3 / end, percentiles 10/50/90/100:",
+              [np.round(np.percentile(s[:, k] - t0, [10, 50, 90, 100]), 1).tolist() for k in (0, 1, 2, 3, 7)])
+        by_seg = [(int(k), round(float((s[seg[split] == k, 1] - s[seg[split] == k, 0]).mean()), 1), round(float((s[seg[split] == k, 2] - s[seg[split] == k, 1]).mean()), 1),
+                   round(float((s[seg[split] == k, 3] - s[seg[split] == k, 2]).mean()), 1)) for k in range(0, int(seg[split].max()) + 1, 2)]
+        print("   by segment index (seg, passA, wait, passB):", by_seg)
+    if name == "fwd":
+        for i in np.argsort(-us[:, 7])[:6]:
+            print("      late:", int(tile[i]), f"{int(seg[i])}/{int(nseg[i])}", "marks (us from kernel start):", np.round(us[i, [0, 1, 2, 3, 4, 7]] - t0, 1).tolist())
+    late = np.argsort(-us[:, 7])[:8]
+    print("   latest finishers (tile, seg/nseg, len, start, dur):",
+          [(int(tile[i]), f"{int(seg[i])}/{int(nseg[i])}", int(length[i]), round(float(us[i, 0] - t0), 1), round(float(dur[i]), 1)) for i in late])
