@@ -449,7 +449,7 @@ __global__ __launch_bounds__(HGS_BLOCK) void sort_tiles_kernel(int gx, int T, ui
 
 static HgsSegPolicy g_seg_policy = {128u, 1024u, 2048u};
 extern "C" int hgs_set_segment_policy(int min_len, int max_len, int target_segments) {
-  if (min_len < 128 || (min_len & 63) || max_len < min_len || (max_len & 63) || target_segments < 1) {
+  if (min_len < HGS_SEG_MIN_LEN || (min_len & 63) || max_len < min_len || (max_len & 63) || target_segments < 1) {
     hgs_set_error("hgs_set_segment_policy: lengths must be multiples of 64 with 128 <= min <= max, target >= 1");
     return 1;
   }

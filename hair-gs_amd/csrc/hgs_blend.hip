@@ -408,11 +408,18 @@ __global__ __launch_bounds__(HGS_BLOCK) __attribute__((amdgpu_waves_per_eu(8))) 
         Tfin = fabsf(to[j]);
         if (to[j] < 0.f) { lastseg = m0 + j; stopped = true; }   // stopped here: nothing behind it contributes
       }
+    if (__ballot(!stopped) == 0) break;                            // (this wavefront's pixels are all accounted for)
   }
+  // Colours: nothing behind a pixel's stop segment is added, and the backward reads the suffix sum of segment m + 1 only
+  // for a pixel with contributors behind segment m: the sums start at the wavefront's last stop segment.
+  uint32_t wseg = lastseg;
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) wseg = max(wseg, (uint32_t)__shfl_xor((int)wseg, d, 64));
+  wseg = __builtin_amdgcn_readfirstlane(wseg);
 #pragma unroll
   for (int k = 0; k < C; k++) acc[k] = 0.f;
   constexpr int FG = C <= 4 ? 8 : 4;                               // segments per group of the colour sums
-  for (int mh = (int)it.nseg - 1; mh >= 0; mh -= FG) {
+  for (int mh = (int)wseg; mh >= 0; mh -= FG) {
     float v[FG][C];
 #pragma unroll
     for (int j = 0; j < FG; j++)

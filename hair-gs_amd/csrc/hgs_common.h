@@ -66,7 +66,13 @@ enum { HGS_ST_R = 0, HGS_ST_OVERFLOW = 1, HGS_ST_SCANPTR_LO = 2, HGS_ST_SCANPTR_
 #define HGS_ITEM_TILE(it) ((it) & 0xFFFFFFu)
 #define HGS_ITEM_PART(it) ((it) >> 24)
 #define HGS_MAX_TILES (1u << 24)
-static inline uint32_t hgs_seg_capacity(size_t R) { return R ? (uint32_t)(R / 64 + 2) : 0u; }      // segments >= 128 entries, < 2 R / 128 of them
+#ifndef HGS_SEG_MIN_LEN
+#define HGS_SEG_MIN_LEN 128      // shortest segment of a split list (multiple of 64)
+#endif
+#ifndef HGS_SPLIT_PER_TILE
+#define HGS_SPLIT_PER_TILE 1     // segment work items a frame can hold, per tile of the image
+#endif
+static inline uint32_t hgs_seg_capacity(size_t R) { return R ? (uint32_t)(R / (HGS_SEG_MIN_LEN / 2) + 2) : 0u; }   // segments >= MIN_LEN entries of lists > 1.5 MIN_LEN: < 2 R / MIN_LEN of them
 
 static inline size_t hgs_align_up(size_t v) { return (v + HGS_ALIGN - 1) & ~(size_t)(HGS_ALIGN - 1); }
 
@@ -93,7 +99,7 @@ static inline size_t hgs_geom_carve(char* base, size_t P, HgsGeom& g, size_t* of
   hgs_carve(cur, g.grec, 4 * P);
   return hgs_align_up((size_t)(cur - base)) + HGS_ALIGN;
 }
-#define HGS_SPLIT_CAPACITY(T) ((size_t)(T) > 1024 ? (size_t)(T) : (size_t)1024)   // segment work items a frame can hold
+#define HGS_SPLIT_CAPACITY(T) ((size_t)HGS_SPLIT_PER_TILE * ((size_t)(T) > 1024 ? (size_t)(T) : (size_t)1024))   // segment work items a frame can hold
 static inline size_t hgs_image_zero_words(size_t T) { return 4 * T + HGS_STATUS_WORDS + 4 * T; }
 static inline size_t hgs_image_carve(char* base, size_t W, size_t H, HgsImage& im, size_t* offs) {
   char* cur = base;
@@ -274,6 +280,19 @@ template <typename T> __device__ __forceinline__ T hgs_ld_agent(const T* p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 __device__ __forceinline__ void hgs_drain_stores() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+// A pointer read from a struct in memory (HgsViewTargets) has no known address space: the compiler emits FLAT loads for
+// it, which count in lgkmcnt as well as vmcnt -- every LDS wait behind such a load then also waits for the HBM round trip
+// (measured in the SSIM kernels: the row pass behind a prefetch of the target image took 2.2 us instead of 0.7).  These
+// are device-memory pointers by contract (include/hgs.h): say so, and keep the address space up to the load (a cast back to
+// a generic pointer is folded away together with the information).
+#define HGS_GLOBAL __attribute__((address_space(1)))
+template <typename T>
+__device__ __forceinline__ const HGS_GLOBAL T* hgs_global(const T* p) { return (const HGS_GLOBAL T*)p; }
+typedef float hgs_float4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 hgs_load4(const HGS_GLOBAL float* p) {      // 16-byte aligned
+  const hgs_float4_t v = *(const HGS_GLOBAL hgs_float4_t*)p;
+  return make_float4(v.x, v.y, v.z, v.w);
+}
 __device__ __forceinline__ void hgs_publish_part(unsigned long long* mask, uint32_t part) {
   __hip_atomic_fetch_or(mask, 1ull << part, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }

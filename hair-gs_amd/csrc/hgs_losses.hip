@@ -20,6 +20,38 @@ namespace {
 
 struct SsimWin { float w[11]; };
 
+// development aid (tools/ssim_trace.py; build with -DHGS_SSIM_TRACE=1): per workgroup of the SSIM kernels, the time spent
+// in each phase of its blocks -- 16 words per workgroup: [0] blocks, [1] filtered blocks, [2..9] phase sums (10 ns ticks),
+// [10] first tick, [11] last tick
+#ifndef HGS_SSIM_TRACE
+#define HGS_SSIM_TRACE 0
+#endif
+#if HGS_SSIM_TRACE
+__device__ unsigned long long* g_ssim_trace[2] = {nullptr, nullptr};
+struct SsimTrace {
+  unsigned long long* buf; unsigned long long last, acc[8], first; unsigned nb = 0, nf = 0;
+  __device__ SsimTrace(int which) : buf(g_ssim_trace[which] ? g_ssim_trace[which] + 16 * (size_t)blockIdx.x : nullptr) {
+    for (int i = 0; i < 8; i++) acc[i] = 0;
+    first = last = __builtin_amdgcn_s_memrealtime();
+  }
+  __device__ void phase(int k) { const unsigned long long n = __builtin_amdgcn_s_memrealtime(); acc[k] += n - last; last = n; }
+  __device__ void block(bool filtered) { nb++; nf += filtered ? 1u : 0u; }
+  __device__ ~SsimTrace() {
+    if (buf && threadIdx.x == 0) {
+      buf[0] = nb; buf[1] = nf;
+      for (int i = 0; i < 8; i++) buf[2 + i] = acc[i];
+      buf[10] = first; buf[11] = __builtin_amdgcn_s_memrealtime();
+    }
+  }
+};
+#else
+struct SsimTrace {
+  __device__ SsimTrace(int) {}
+  __device__ void phase(int) {}
+  __device__ void block(bool) {}
+};
+#endif
+
 __device__ __forceinline__ float block_sum(float v, float* red4) {
 #pragma unroll
   for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
@@ -27,6 +59,17 @@ __device__ __forceinline__ float block_sum(float v, float* red4) {
   if ((threadIdx.x & 63) == 0) red4[threadIdx.x >> 6] = v;
   __syncthreads();
   return (red4[0] + red4[1]) + (red4[2] + red4[3]);
+}
+// the block's totals of two per-thread values (all threads return them); red: 8 floats that no thread touches again
+// before its next barrier
+__device__ __forceinline__ void block_sum2(float& a, float& b, float* red) {
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) { a += __shfl_xor(a, d, 64); b += __shfl_xor(b, d, 64); }
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6] = a; red[4 + (threadIdx.x >> 6)] = b; }
+  __syncthreads();
+  a = (red[0] + red[1]) + (red[2] + red[3]);
+  b = (red[4] + red[5]) + (red[6] + red[7]);
 }
 
 // Halo tile load.  Fast path (W % 4 == 0): the tile is widened to x in [bx0-8, bx0+LT+8) so that every row is 12
@@ -45,7 +88,7 @@ __device__ __forceinline__ void load_tiles(float (*t)[TILE][TPW], int H, int W, 
 #pragma unroll
       for (int p = 0; p < NP; p++) {
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (in) v = *(const float4*)(plane_ptr(p) + (size_t)y * W + x);
+        if (in) v = hgs_load4(plane_ptr(p) + (size_t)y * W + x);
         t[p][r][c4] = v.x; t[p][r][c4 + 1] = v.y; t[p][r][c4 + 2] = v.z; t[p][r][c4 + 3] = v.w;
       }
     }
@@ -174,7 +217,10 @@ static inline SsimGrid ssim_grid(int C, int H, int W) {
 // persistent workgroups per XCD = 32 CUs x resident workgroups (forward: 38.7 KB LDS, register allocation held to 128
 // VGPRs by amdgpu_waves_per_eu(4, 4) -> 4; at 131 it drops to 3 and the kernel takes 54 instead of 42 us; backward: 41 KB, 163 -> 3)
 #define SSIM_FWD_WG_PER_XCD 128
-#define SSIM_BWD_WG_PER_XCD 96
+#ifndef HGS_SSIM_BWD_WAVES
+#define HGS_SSIM_BWD_WAVES 3
+#endif
+#define SSIM_BWD_WG_PER_XCD (32 * HGS_SSIM_BWD_WAVES)
 static inline unsigned ssim_grid_size(const SsimGrid& gd, int per_xcd) { return 8u * (unsigned)(gd.chunk < per_xcd ? gd.chunk : per_xcd); }
 
 // register staging of one halo tile (fast path, W % 4 == 0): 504 float4 per plane = 2 per thread
@@ -191,7 +237,7 @@ __device__ __forceinline__ void stage_load(TileStage<NP>& st, int H, int W, int 
 #pragma unroll
     for (int p = 0; p < NP; p++) {
       st.v[p][u] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (in) st.v[p][u] = *(const float4*)(plane_ptr(p) + (size_t)y * W + x);
+      if (in) st.v[p][u] = hgs_load4(plane_ptr(p) + (size_t)y * W + x);
     }
   }
 }
@@ -232,18 +278,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
   // would produce), and the backward skips blocks whose 3x3 neighbourhood is flagged (its result is exactly zero).
   __shared__ float t[2][TILE][TPW];
   __shared__ float hz[4][TILE][HP];   // mu1, mu2, E[x1^2 + x2^2], E[x1 x2]: S only needs the SUM of the two variances
-  __shared__ float red[4];
+  __shared__ float red[8];
   const size_t plane = (size_t)H * W, cp = (size_t)gd.C * plane;
-  const float* img2 = tgt ? tgt->image : img2_;   // per-view target read through the device-resident slot
+  const HGS_GLOBAL float* im1 = hgs_global(img1);
+  const HGS_GLOBAL float* im2 = tgt ? hgs_global(tgt->image) : hgs_global(img2_);   // per-view target read through the device-resident slot
   const bool fast = (W & 3) == 0;
   const int nwg = gridDim.x >> 3;
   int j = blockIdx.x >> 3;
   SsimBlock bk, nx;
   bool have = ssim_block(gd, j, bk);
   TileStage<2> st;
-  if (fast && have) stage_load<2>(st, H, W, bk.bx0, bk.by0, [&](int p) { return (p == 0 ? img1 : img2) + bk.c * plane; });
+  if (fast && have) stage_load<2>(st, H, W, bk.bx0, bk.by0, [&](int p) { return (p == 0 ? im1 : im2) + bk.c * plane; });
   const int lx = threadIdx.x & (LT - 1), y0 = (threadIdx.x >> 5) * 4;
+  SsimTrace tr(0);
   while (have) {
+    tr.phase(7);
     int nz = 1;                                   // does this thread's share of the tile hold a non-zero value?
     if (fast) {
       stage_store<2>(st, t);
@@ -255,12 +304,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
           for (int u = 0; u < 2; u++) nz |= (st.v[p][u].x != 0.f) | (st.v[p][u].y != 0.f) | (st.v[p][u].z != 0.f) | (st.v[p][u].w != 0.f);
       }
     } else {
-      load_tiles<2>(t, H, W, bk.bx0, bk.by0, [&](int p) { return (p == 0 ? img1 : img2) + bk.c * plane; });
+      load_tiles<2>(t, H, W, bk.bx0, bk.by0, [&](int p) { return (p == 0 ? im1 : im2) + bk.c * plane; });
     }
     const int any_nz = __syncthreads_or(nz);      // (also the barrier that publishes the tile)
+    tr.phase(0);
+    tr.block(any_nz != 0);
     j += nwg;
     const bool have_next = ssim_block(gd, j, nx);
-    if (fast && have_next) stage_load<2>(st, H, W, nx.bx0, nx.by0, [&](int p) { return (p == 0 ? img1 : img2) + nx.c * plane; });
+    if (fast && have_next) stage_load<2>(st, H, W, nx.bx0, nx.by0, [&](int p) { return (p == 0 ? im1 : im2) + nx.c * plane; });
     float f[4][4];
     if (any_nz) {
       row_pass<4>(win, hz, [&](int r, int x, float* v) {   // x = tile column of the tap: image x = bx0 - HALO + x
@@ -268,7 +319,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         v[0] = a; v[1] = b; v[2] = a * a + b * b; v[3] = a * b;
       });
       __syncthreads();
+      tr.phase(1);
       col_pass<4>(win, hz, lx, y0, f);
+      tr.phase(2);
     } else {
 #pragma unroll
       for (int q = 0; q < 4; q++)
@@ -302,13 +355,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         }
       }
     }
-    const float bs = block_sum(ssim_v, red);
-    const float bl = block_sum(l1_v, red);
+    tr.phase(3);
+    block_sum2(ssim_v, l1_v, red);
     if (threadIdx.x == 0) {
-      partials[2 * (size_t)bk.logical] = bs;
-      partials[2 * (size_t)bk.logical + 1] = bl;
+      partials[2 * (size_t)bk.logical] = ssim_v;
+      partials[2 * (size_t)bk.logical + 1] = l1_v;
     }
-    __syncthreads();   // t / hz / red are rewritten by the next block of this workgroup
+    // (no barrier here: t was last read before block_sum2's barriers, hz before them too, and red is rewritten only after
+    // the two barriers of the next block's tile and row pass, which a thread still reading it has not reached)
+    tr.phase(4);
     bk = nx;
     have = have_next;
   }
@@ -316,7 +371,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 
 // ------------------------------------------------------------------------------------------------------------------
 
-__global__ __launch_bounds__(256) void ssim_l1_bwd_kernel(int H, int W, SsimGrid gd, SsimWin win, const float* __restrict__ img1,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HGS_SSIM_BWD_WAVES, HGS_SSIM_BWD_WAVES))) void ssim_l1_bwd_kernel(int H, int W, SsimGrid gd, SsimWin win, const float* __restrict__ img1,
                                                           const float* __restrict__ img2_, const HgsViewTargets* __restrict__ tgt,
                                                           const float* __restrict__ dmap,
                                                           const float* __restrict__ g_ssim_mean,
@@ -328,7 +383,9 @@ __global__ __launch_bounds__(256) void ssim_l1_bwd_kernel(int H, int W, SsimGrid
   for (int i = blockIdx.x * 256 + threadIdx.x; i < zero_n; i += gridDim.x * 256) zero_buf[i] = 0.f;
   __shared__ float t[3][TILE][TPW];
   __shared__ float hz[3][TILE][HP];
-  const float* img2 = tgt ? tgt->image : img2_;
+  const HGS_GLOBAL float* im1 = hgs_global(img1);
+  const HGS_GLOBAL float* im2 = tgt ? hgs_global(tgt->image) : hgs_global(img2_);
+  const HGS_GLOBAL float* dmg = hgs_global(dmap);
   const size_t plane = (size_t)H * W, cp = (size_t)gd.C * plane;
   const float n = 1.f / (float)((size_t)gd.C * plane);
   const float up = go ? *go : 1.f;                 // upstream dL/dtotal of the loss head (NULL: 1)
@@ -342,7 +399,7 @@ __global__ __launch_bounds__(256) void ssim_l1_bwd_kernel(int H, int W, SsimGrid
   // logical order, and the rest.  Each XCD takes an equal contiguous share of the first list (the halo sharing in its L2
   // is kept, and the work is balanced however the hair sits in the frame); the second list is only zero-filled.
   const int xcd = blockIdx.x & 7;
-  int lo = 0, hi = 0, id1 = 0;
+  int lo = 0, hi = 0;
   const int* work = nullptr;
   if (lists) {
     const int n_work = lists[0], n_skip = lists[1];
@@ -361,31 +418,45 @@ __global__ __launch_bounds__(256) void ssim_l1_bwd_kernel(int H, int W, SsimGrid
       }
     }
   }
-  // next(j): the j-th block of this workgroup; with a list its id was loaded one block ahead (id1)
-  auto fetch_id = [&](int jj) { return (work && lo + jj < hi) ? work[lo + jj] : 0; };
-  auto block_at = [&](int jj, int id, SsimBlock& o) {
+  // The ids of this workgroup's next 64 blocks sit one per lane (one vector load per 64 blocks): an id fetched per block is
+  // wave-uniform, so the compiler moves it to a scalar register at once -- a full memory round trip, and a wait for every
+  // load in flight, in the middle of each block.
+  const int jstep = nwg, j0 = j;
+  int idv = 0, idbase = 0;                        // idv: id of block number idbase + lane of this workgroup
+  auto refill = [&](int k0) {
+    idbase = k0;
+    const int jj = j0 + (k0 + (int)(threadIdx.x & 63)) * jstep;
+    idv = (work && lo + jj < hi) ? work[lo + jj] : 0;
+  };
+  int kblk = 0;                                   // number of the current block of this workgroup
+  auto block_at = [&](int jj, int k, SsimBlock& o) {
     if (!work) return ssim_block(gd, jj, o);
     if (lo + jj >= hi) return false;
-    ssim_block_decode(gd, id, o);
+    if (k - idbase >= 64) refill(k);
+    ssim_block_decode(gd, __builtin_amdgcn_readlane(idv, k - idbase), o);
     return true;
   };
-  bool have = block_at(j, fetch_id(j), bk);
-  id1 = fetch_id(j + nwg);
+  refill(0);
+  bool have = block_at(j, 0, bk);
   TileStage<3> st;
-  float x1[4], x2[4];                              // the block's own pixels of both images, fetched with the tile
+  float x1[4], x2[4];                              // the block's own pixels of both images
   auto centre = [&](const SsimBlock& q) {
 #pragma unroll
     for (int o = 0; o < 4; o++) {
       const int px = q.bx0 + lx, py = q.by0 + y0 + o;
       x1[o] = 0.f; x2[o] = 0.f;
-      if (px < W && py < H) { const size_t oo = q.c * plane + (size_t)py * W + px; x1[o] = img1[oo]; x2[o] = img2[oo]; }
+      if (px < W && py < H) { const size_t oo = q.c * plane + (size_t)py * W + px; x1[o] = im1[oo]; x2[o] = im2[oo]; }
     }
   };
   // the forward wrote no maps for the blocks it flagged all-zero: their constants are put in place of the loads
   float zm[3];
   ssim_zero_maps(zm);
+  // (the flag bytes travel with the tile and are applied when it is written to LDS: a load that waits for its flag put one
+  // memory round trip per block on the critical path; the maps of a flagged block are loaded and discarded)
+  unsigned char fl[2] = {0, 0};
   auto stage = [&](const SsimBlock& q) {
-    if (!zero_flags) { stage_load<3>(st, H, W, q.bx0, q.by0, [&](int p) { return dmap + p * cp + q.c * plane; }); return; }
+    stage_load<3>(st, H, W, q.bx0, q.by0, [&](int p) { return dmg + p * cp + q.c * plane; });
+    if (!zero_flags) return;
     const int per = gd.nbx * gd.nby;
 #pragma unroll
     for (int u = 0; u < 2; u++) {
@@ -393,51 +464,55 @@ __global__ __launch_bounds__(256) void ssim_l1_bwd_kernel(int H, int W, SsimGrid
       const int r = i / (TW / 4), c4 = (i - r * (TW / 4)) * 4;
       const int y = q.by0 + r - HALO, x = q.bx0 - XOFF + c4;
       const bool in = i < ST_F4 && (unsigned)y < (unsigned)H && x >= 0 && x < W;
-      const bool flagged = in && zero_flags[q.c * per + (y / LT) * gd.nbx + x / LT] != 0;
-#pragma unroll
-      for (int p = 0; p < 3; p++) {
-        st.v[p][u] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (flagged) st.v[p][u] = make_float4(zm[p], zm[p], zm[p], zm[p]);
-        else if (in) st.v[p][u] = *(const float4*)(dmap + p * cp + q.c * plane + (size_t)y * W + x);
-      }
+      fl[u] = in ? zero_flags[q.c * per + (y / LT) * gd.nbx + x / LT] : (unsigned char)0;
     }
   };
-  if (have) {
-    if (fast) stage(bk);
-    centre(bk);
-  }
-  while (have) {
-    if (fast) stage_store<3>(st, t);
-    else load_tiles<3>(t, H, W, bk.bx0, bk.by0, [&](int p) { return dmap + p * cp + bk.c * plane; });
-    float c1[4], c2[4];
+  auto apply_flags = [&]() {
 #pragma unroll
-    for (int o = 0; o < 4; o++) { c1[o] = x1[o]; c2[o] = x2[o]; }
+    for (int u = 0; u < 2; u++)
+      if (fl[u]) {
+#pragma unroll
+        for (int p = 0; p < 3; p++) st.v[p][u] = make_float4(zm[p], zm[p], zm[p], zm[p]);
+      }
+  };
+  if (have && fast) stage(bk);
+  SsimTrace tr(1);
+  while (have) {
+    tr.phase(7);
+    tr.block(true);
+    if (fast) { apply_flags(); stage_store<3>(st, t); }
+    else load_tiles<3>(t, H, W, bk.bx0, bk.by0, [&](int p) { return dmg + p * cp + bk.c * plane; });
     __syncthreads();
+    tr.phase(0);
+    // this block's own pixels: needed in the epilogue, two filter passes from here (fetched a block ahead they were
+    // loop-carried registers, and the compiler parked a wait for every load in flight in front of the row pass)
+    centre(bk);
     j += nwg;
-    const bool have_next = block_at(j, id1, nx);
-    id1 = fetch_id(j + nwg);
-    if (have_next) {
-      if (fast) stage(nx);
-      centre(nx);
-    }
+    kblk++;
+    const bool have_next = block_at(j, kblk, nx);
+    if (have_next && fast) stage(nx);
     row_pass<3>(win, hz, [&](int r, int x, float* v) {
       v[0] = t[0][r][x + XOFF - HALO]; v[1] = t[1][r][x + XOFF - HALO]; v[2] = t[2][r][x + XOFF - HALO];
     });
     __syncthreads();
+    tr.phase(1);
     float f[3][4];
     col_pass<3>(win, hz, lx, y0, f);
+    tr.phase(2);
     const int px = bk.bx0 + lx;
 #pragma unroll
     for (int o = 0; o < 4; o++) {
       const int py = bk.by0 + y0 + o;
       if (px < W && py < H) {
         const size_t oo = bk.c * plane + (size_t)py * W + px;
-        const float d = c1[o] - c2[o];
+        const float d = x1[o] - x2[o];
         const float sgn = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
-        dimg1[oo] = gs * (f[0][o] + 2.f * c1[o] * f[1][o] + c2[o] * f[2][o]) + gl * sgn;
+        dimg1[oo] = gs * (f[0][o] + 2.f * x1[o] * f[1][o] + x2[o] * f[2][o]) + gl * sgn;
       }
     }
-    __syncthreads();   // t / hz are rewritten by the next block of this workgroup
+    // (no barrier here: t is read only before the row-pass barrier, and hz is rewritten only after the next block's tile
+    // barrier, which a thread still in this block's column pass has not reached)
+    tr.phase(4);
     bk = nx;
     have = have_next;
   }
@@ -573,7 +648,7 @@ __global__ __launch_bounds__(256) void pix_fwd_kernel(int N, HeadFlags fl, float
   if (i < N) {
     float gm = 0.f, g0 = 0.f, g1 = 0.f, g2 = 0.f;
     if (fl.bce) {
-      const float x = mask_img[i], y = tgt->float_mask[i];
+      const float x = mask_img[i], y = hgs_global(tgt->float_mask)[i];
       const float en = expf(-fabsf(x));
       b = fmaxf(x, 0.f) - x * y + log1pf(en);
       if (d_unit) gm = g_mask * ((x >= 0.f ? 1.f / (1.f + en) : en / (1.f + en)) - y);   // sigmoid(x) - y
@@ -582,12 +657,12 @@ __global__ __launch_bounds__(256) void pix_fwd_kernel(int N, HeadFlags fl, float
       OriParams p;
       p.view = tgt->viewmatrix; p.bg0 = bg0; p.bg1 = bg1; p.bg2 = bg2; p.min_val = min_val; p.has_mask = tgt->mask != nullptr;
       const float o0 = omap[i], o1 = omap[(size_t)N + i], o2 = omap[2 * (size_t)N + i];
-      const bool m = p.has_mask ? tgt->mask[i] != 0 : (o0 != p.bg0 || o1 != p.bg1 || o2 != p.bg2);
+      const bool m = p.has_mask ? hgs_global(tgt->mask)[i] != 0 : (o0 != p.bg0 || o1 != p.bg1 || o2 != p.bg2);
       if (m) {
         float px, py, r, n, x, y, yq, th;
         ori_pixel(p, o0, o1, o2, px, py, r, n, x, y, yq, th);
         const float hp = 1.57079632679489661923f;
-        const float gt = tgt->orientation[i], cf = tgt->confidence[i];
+        const float gt = hgs_global(tgt->orientation)[i], cf = hgs_global(tgt->confidence)[i];
         s = (hp - fabsf(fabsf(th - gt) - hp)) * cf;
         cnt = 1.f;
         if (d_unit) ori_pixel_grad(p, px, py, r, n, x, yq, th, gt, cf, g_ori / tgt->mask_count, g0, g1, g2);
@@ -613,7 +688,7 @@ __global__ __launch_bounds__(256) void pix_bwd_kernel(int N, HeadFlags fl, float
   const float up = *go;
   float gm = 0.f;
   if (fl.bce) {
-    const float x = mask_img[i], y = tgt->float_mask[i];
+    const float x = mask_img[i], y = hgs_global(tgt->float_mask)[i];
     gm = out[HGS_HEAD_G_MASK] * up * (1.f / (1.f + expf(-x)) - y);
   }
   d_mask_img[i] = gm;
@@ -622,11 +697,11 @@ __global__ __launch_bounds__(256) void pix_bwd_kernel(int N, HeadFlags fl, float
     OriParams p;
     p.view = tgt->viewmatrix; p.bg0 = bg0; p.bg1 = bg1; p.bg2 = bg2; p.min_val = min_val; p.has_mask = tgt->mask != nullptr;
     const float o0 = omap[i], o1 = omap[(size_t)N + i], o2 = omap[2 * (size_t)N + i];
-    const bool m = p.has_mask ? tgt->mask[i] != 0 : (o0 != p.bg0 || o1 != p.bg1 || o2 != p.bg2);
+    const bool m = p.has_mask ? hgs_global(tgt->mask)[i] != 0 : (o0 != p.bg0 || o1 != p.bg1 || o2 != p.bg2);
     if (m) {
       float px, py, r, n, x, y, yq, th;
       ori_pixel(p, o0, o1, o2, px, py, r, n, x, y, yq, th);
-      ori_pixel_grad(p, px, py, r, n, x, yq, th, tgt->orientation[i], tgt->confidence[i],
+      ori_pixel_grad(p, px, py, r, n, x, yq, th, hgs_global(tgt->orientation)[i], hgs_global(tgt->confidence)[i],
                      (out[HGS_HEAD_G_ORI] * up) / out[HGS_HEAD_ORI_COUNT], g0, g1, g2);
     }
   }
@@ -751,6 +826,14 @@ __global__ __launch_bounds__(FIN_THREADS) void head_finalize_kernel(HeadReduce h
 }
 
 }  // namespace
+
+#if HGS_SSIM_TRACE
+extern "C" int hgs_debug_set_ssim_trace(void* fwd, void* bwd) {
+  void* p[2] = {fwd, bwd};
+  HGS_CHECK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_ssim_trace), p, sizeof(p)));
+  return 0;
+}
+#endif
 
 extern "C" {
 
