@@ -64,12 +64,22 @@ int hgs_zero_async(hipStream_t s, void* ptr, size_t bytes) {
 }
 
 // ---- small per-iteration bookkeeping kernels --------------------------------------------------------------------
-__global__ void select_view_kernel(const HgsViewTargets* __restrict__ table, int view, HgsViewTargets* __restrict__ slot,
-                                   float lr, float* __restrict__ lr_dst) {
-  const uint32_t* src = (const uint32_t*)(table + view);
-  uint32_t* dst = (uint32_t*)slot;
-  for (int i = threadIdx.x; i < (int)(sizeof(HgsViewTargets) / 4); i += 64) dst[i] = src[i];
-  if (threadIdx.x == 0 && lr_dst) *lr_dst = lr;
+// Iteration prologue: workgroup 0 copies the view's row into the slot (and the learning rate); the others clear
+// zero_words words at zero_ptr (the counters of the image buffer the coming forward pass bins into, include/hgs.h
+// HGS_IMAGE_PREZEROED).  view / lr are by-value arguments: a captured graph is re-pointed at another view by updating this
+// node's parameters (hgs_graph_set_prologue), with no launch in between two replays.
+__global__ __launch_bounds__(256) void select_view_kernel(const HgsViewTargets* __restrict__ table, int view,
+                                                          HgsViewTargets* __restrict__ slot, float lr, float* __restrict__ lr_dst,
+                                                          uint32_t* __restrict__ zero_ptr, unsigned long long zero_words) {
+  if (blockIdx.x == 0) {
+    const uint32_t* src = (const uint32_t*)(table + view);
+    uint32_t* dst = (uint32_t*)slot;
+    for (int i = threadIdx.x; i < (int)(sizeof(HgsViewTargets) / 4); i += 256) dst[i] = src[i];
+    if (threadIdx.x == 0 && lr_dst) *lr_dst = lr;
+    return;
+  }
+  const size_t stride = (size_t)(gridDim.x - 1) * 256;
+  for (size_t i = (size_t)(blockIdx.x - 1) * 256 + threadIdx.x; i < zero_words; i += stride) zero_ptr[i] = 0u;
 }
 
 struct HgsViewQueueArgs { int v[HGS_VIEW_QUEUE_MAX]; };
@@ -130,6 +140,15 @@ size_t hgs_backward_scratch_bytes(int P, int R) {
   return hgs_align_up((size_t)(R > 0 ? R : 0) * HGS_INST_GRAD_FLOATS * sizeof(float)) + HGS_ALIGN;
 }
 int hgs_geom_layout(int P, size_t* offsets) { HgsGeom g; hgs_geom_carve(nullptr, (size_t)P, g, offsets); return 0; }
+int hgs_image_zero_range(int W, int H, size_t* offset, size_t* bytes) {
+  if (W <= 0 || H <= 0 || !offset || !bytes) { hgs_set_error("hgs_image_zero_range: bad arguments"); return 1; }
+  HgsImage im;
+  hgs_image_carve(nullptr, (size_t)W, (size_t)H, im, nullptr);
+  const size_t T = (size_t)((W + HGS_TILE - 1) / HGS_TILE) * ((H + HGS_TILE - 1) / HGS_TILE);
+  *offset = (size_t)((char*)im.tile_count - (char*)nullptr);
+  *bytes = hgs_image_zero_words(T) * sizeof(uint32_t);
+  return 0;
+}
 int hgs_image_layout(int W, int H, size_t* offsets) { HgsImage im; hgs_image_carve(nullptr, (size_t)W, (size_t)H, im, offsets); return 0; }
 int hgs_binning_layout(int R, size_t* offsets) { HgsBinning b; hgs_binning_carve(nullptr, (size_t)R, b, offsets); return 0; }
 
@@ -148,7 +167,8 @@ int hgs_forward_preprocess(void* stream, int P, int D, int M, int W, int H, cons
   HgsImage im;
   hgs_image_carve((char*)image_buf, (size_t)W, (size_t)H, im, nullptr);
   const int T = ((W + HGS_TILE - 1) / HGS_TILE) * ((H + HGS_TILE - 1) / HGS_TILE);
-  if (hgs_zero_async(s, im.tile_count, hgs_image_zero_words((size_t)T) * sizeof(uint32_t))) return 1;
+  if (!(prefiltered & HGS_IMAGE_PREZEROED) &&
+      hgs_zero_async(s, im.tile_count, hgs_image_zero_words((size_t)T) * sizeof(uint32_t))) return 1;
   if (P == 0) {  // reference short-circuits P == 0 (rasterize_points.cu:81); the scan of all-zero counts writes the
     HgsGeom none = {};  // empty ranges and the tile order the blend kernel (background fill) indexes with
     if (hgs_launch_scan(s, 0, T, none, im, nullptr)) return 1;
@@ -169,7 +189,7 @@ int hgs_forward_preprocess(void* stream, int P, int D, int M, int W, int H, cons
   a.means3D = means3D; a.shs = shs; a.colors_precomp = colors_precomp; a.opacities = opacities; a.scales = scales;
   a.rotations = rotations; a.cov3D_precomp = cov3D_precomp; a.viewmatrix = viewmatrix; a.projmatrix = projmatrix;
   a.campos = campos; a.scale_modifier = scale_modifier; a.tan_fovx = tan_fovx; a.tan_fovy = tan_fovy;
-  a.prefiltered = prefiltered;
+  a.prefiltered = prefiltered & 1;
   a.tile_cull = g_tile_cull;
   // Capacity mode (nobody waits for num_rendered here) with a place to report the count: the scan is left to the
   // scatter kernel of hgs_forward_render (scatter_kernel, "fused scan").  A blocking caller needs the count NOW.
@@ -379,14 +399,62 @@ size_t hgs_view_targets_bytes(void) { return sizeof(HgsViewTargets); }
 size_t hgs_head_params_bytes(void) { return sizeof(HgsHeadParams); }
 size_t hgs_strand_fusion_bytes(void) { return sizeof(HgsStrandFusion); }
 
-int hgs_select_view(void* stream, const HgsViewTargets* table, int view, HgsViewTargets* slot, float lr, float* lr_dst) {
-  if (!table || !slot || view < 0) { hgs_set_error("hgs_select_view: bad arguments"); return 1; }
+static inline unsigned prologue_blocks(size_t zero_words) {
+  const size_t b = (zero_words + 1023) / 1024;           // 4 words per thread
+  return 1u + (unsigned)(b < 1024 ? b : 1024);
+}
+int hgs_iteration_prologue(void* stream, const HgsViewTargets* table, int view, HgsViewTargets* slot, float lr, float* lr_dst,
+                           void* zero_ptr, size_t zero_bytes) {
+  if (!table || !slot || view < 0) { hgs_set_error("hgs_iteration_prologue: bad arguments"); return 1; }
+  if (((size_t)zero_ptr & 3) || (zero_bytes & 3) || (zero_bytes && !zero_ptr)) { hgs_set_error("hgs_iteration_prologue: zero range must be 4-byte multiples"); return 1; }
   hipStream_t s = (hipStream_t)stream;
   {
     HgsProfScope _prof(s, HGS_K_MISC);
-    hipLaunchKernelGGL(select_view_kernel, dim3(1), dim3(64), 0, s, table, view, slot, lr, lr_dst);
+    hipLaunchKernelGGL(select_view_kernel, dim3(prologue_blocks(zero_bytes / 4)), dim3(256), 0, s, table, view, slot, lr, lr_dst,
+                       (uint32_t*)zero_ptr, (unsigned long long)(zero_bytes / 4));
   }
   HGS_CHECK_LAUNCH();
+  return 0;
+}
+int hgs_select_view(void* stream, const HgsViewTargets* table, int view, HgsViewTargets* slot, float lr, float* lr_dst) {
+  return hgs_iteration_prologue(stream, table, view, slot, lr, lr_dst, nullptr, 0);
+}
+
+// ---- re-pointing the prologue node of a captured graph ----------------------------------------------------------------
+int hgs_graph_find_prologue(void* graph, void** node_out) {
+  if (!graph || !node_out) { hgs_set_error("hgs_graph_find_prologue: bad arguments"); return 1; }
+  size_t n = 0;
+  HGS_CHECK_HIP(hipGraphGetNodes((hipGraph_t)graph, nullptr, &n));
+  std::vector<hipGraphNode_t> nodes(n);
+  if (n) HGS_CHECK_HIP(hipGraphGetNodes((hipGraph_t)graph, nodes.data(), &n));
+  void* found = nullptr;
+  int count = 0;
+  for (size_t i = 0; i < n; i++) {
+    hipGraphNodeType t;
+    HGS_CHECK_HIP(hipGraphNodeGetType(nodes[i], &t));
+    if (t != hipGraphNodeTypeKernel) continue;
+    hipKernelNodeParams kp;
+    HGS_CHECK_HIP(hipGraphKernelNodeGetParams(nodes[i], &kp));
+    if (kp.func == (void*)select_view_kernel) { if (!found) found = (void*)nodes[i]; count++; }
+  }
+  if (count != 1) { hgs_set_error("hgs_graph_find_prologue: the graph holds %d prologue launches (need exactly 1)", count); return 1; }
+  *node_out = found;
+  return 0;
+}
+int hgs_graph_set_prologue(void* graph_exec, void* node, const HgsViewTargets* table, int view, HgsViewTargets* slot, float lr,
+                           float* lr_dst, void* zero_ptr, size_t zero_bytes) {
+  if (!graph_exec || !node || !table || !slot || view < 0) { hgs_set_error("hgs_graph_set_prologue: bad arguments"); return 1; }
+  uint32_t* zp = (uint32_t*)zero_ptr;
+  unsigned long long zw = zero_bytes / 4;
+  void* args[7] = {&table, &view, &slot, &lr, &lr_dst, &zp, &zw};
+  hipKernelNodeParams kp = {};
+  kp.func = (void*)select_view_kernel;
+  kp.gridDim = dim3(prologue_blocks(zw));
+  kp.blockDim = dim3(256);
+  kp.sharedMemBytes = 0;
+  kp.kernelParams = args;
+  kp.extra = nullptr;
+  HGS_CHECK_HIP(hipGraphExecKernelNodeSetParams((hipGraphExec_t)graph_exec, (hipGraphNode_t)node, &kp));
   return 0;
 }
 

@@ -29,6 +29,8 @@ struct AdamTensors {
   int n;
 };
 
+__device__ unsigned int g_adam_ticket[ADAM_MAX_TENSORS] = {};   // launches of adam_kernel are stream-ordered within a process (one optimizer)
+
 __device__ __forceinline__ void adam_one(float& p, float g, float& m, float& v, float one_m_b1, float beta2, float step_size,
                                          float inv_sqrt_bc2, float eps) {
   m = m + (g - m) * one_m_b1;                                            // lerp, like torch
@@ -42,7 +44,7 @@ __global__ __launch_bounds__(256) void adam_kernel(AdamTensors t, float beta1, f
   int k = 0;
 #pragma unroll
   for (int j = 1; j < ADAM_MAX_TENSORS; j++) k += (j < t.n && blockIdx.x >= t.blk_start[j]) ? 1 : 0;
-  const float step = *t.step[k] + 1.0f;  // the counter itself is advanced by adam_step_kernel afterwards
+  const float step = *t.step[k] + 1.0f;  // (the counters themselves are advanced by the last workgroup to finish, below)
   const float bc1 = 1.f - powf(beta1, step), bc2 = 1.f - powf(beta2, step);
   const float step_size = *t.lr[k] / bc1, inv_sqrt_bc2 = 1.f / sqrtf(bc2), one_m_b1 = 1.f - beta1;
   const unsigned long long n = t.numel[k];
@@ -78,9 +80,14 @@ __global__ __launch_bounds__(256) void adam_kernel(AdamTensors t, float beta1, f
       P[i] = p; M[i] = m; V[i] = v;
     }
   }
-}
-__global__ void adam_step_kernel(AdamTensors t) {
-  if (threadIdx.x < t.n) *t.step[threadIdx.x] += 1.0f;
+  // Step counter of this tensor: every workgroup of the tensor has read it by the time it takes a ticket, so the one that
+  // takes the last ticket may advance it (a second launch only for that cost 4 us per iteration; one ticket per tensor:
+  // a single counter for the whole grid serialised ~1200 atomics on one address, 5 us).  atomicInc wraps the ticket back
+  // to 0: nothing to reset between launches.
+  if (threadIdx.x == 0) {
+    const unsigned nblk = t.blk_start[k + 1] - t.blk_start[k];
+    if (atomicInc(&g_adam_ticket[k], nblk - 1) == nblk - 1) *t.step[k] = step;
+  }
 }
 
 // ---- smoothness (device code in hgs_smooth.h) -------------------------------------------------------------------------
@@ -145,7 +152,6 @@ int hgs_adam_step(void* stream, int n_tensors, float* const* params, const float
   {
     HgsProfScope _prof(s, HGS_K_ADAM);
     hipLaunchKernelGGL(adam_kernel, dim3(t.blk_start[n_tensors]), dim3(256), 0, s, t, beta1, beta2, eps);
-    hipLaunchKernelGGL(adam_step_kernel, dim3(1), dim3(64), 0, s, t);
   }
   HGS_CHECK_LAUNCH();
   return 0;

@@ -16,6 +16,7 @@ import hgs_runtime as rt
 # instead of three).  If a pass needed more than its capacity, check_async() raises HgsCapacityOverflow after growing
 # the capacity: the caller discards the step's gradients and repeats it.  `num_rendered` returned by
 # rasterize_gaussians is then the capacity (it only sizes/carves buffers downstream).
+IMAGE_PREZEROED = 2   # include/hgs.h HGS_IMAGE_PREZEROED (flag in `prefiltered`)
 _state = {"last_R": 0, "async": False, "cap": 0, "slack": 1.5, "dirty": False, "cap_used": None, "max_R": {}, "cull": None}
 
 
@@ -99,17 +100,19 @@ def rasterize_gaussians_culled(background, means3D, colors, opacity, scales, rot
 
 def rasterize_gaussians_multi(background7, means3D, colors, extra4, opacity, scales, rotations, scale_modifier,
                               cov3D_precomp, viewmatrix, projmatrix, tan_fovx, tan_fovy, image_height, image_width, sh,
-                              degree, campos, prefiltered, debug):
+                              degree, campos, prefiltered, debug, image_buffer=None):
     """Single-pass 7-channel forward (hgs_forward_render_multi): RGB + `extra4` [P,4] unclamped channels blended with
-    the same weights.  Returns (num_rendered, out_color[7,H,W], radii, geomBuffer, binningBuffer, imgBuffer)."""
+    the same weights.  Returns (num_rendered, out_color[7,H,W], radii, geomBuffer, binningBuffer, imgBuffer).
+    image_buffer: a uint8 tensor of hgs_image_bytes(W, H) whose counters the caller has cleared on this stream
+    (hgs_iteration_prologue): used as the imgBuffer, and the pass skips its own clearing launch."""
     return _forward(background7, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp, viewmatrix,
                     projmatrix, tan_fovx, tan_fovy, image_height, image_width, sh, degree, campos, prefiltered, debug,
-                    extra4, True)
+                    extra4, True, image_buffer)
 
 
 def _forward(background, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp, viewmatrix,
              projmatrix, tan_fovx, tan_fovy, image_height, image_width, sh, degree, campos, prefiltered, debug, extra4,
-             cull):
+             cull, image_buffer=None):
     if means3D.ndim != 2 or means3D.shape[1] != 3:
         raise RuntimeError("means3D must have dimensions (num_points, 3)")  # rasterize_points.cu:57-59
     L = rt.lib()
@@ -124,7 +127,13 @@ def _forward(background, means3D, colors, opacity, scales, rotations, scale_modi
     radii = torch.empty((P,), dtype=torch.int32, device=dev)
     u8 = dict(dtype=torch.uint8, device=dev)
     geom = torch.empty((L.hgs_geom_bytes(P),), **u8)
-    img = torch.empty((L.hgs_image_bytes(W, H),), **u8)
+    flags = int(bool(prefiltered))
+    if image_buffer is not None:
+        if image_buffer.numel() != L.hgs_image_bytes(W, H) or image_buffer.dtype != torch.uint8 or image_buffer.device != dev:
+            raise RuntimeError("image_buffer: need a uint8 tensor of hgs_image_bytes(W, H) on the inputs' device")
+        img, flags = image_buffer, flags | IMAGE_PREZEROED
+    else:
+        img = torch.empty((L.hgs_image_bytes(W, H),), **u8)
     bg = _f32(background, "bg")
     colors_, opacity_, scales_, rots_, cov_, sh_ = (_f32(colors, "colors_precomp"), _f32(opacity, "opacities"),
                                                      _f32(scales, "scales"), _f32(rotations, "rotations"),
@@ -137,7 +146,7 @@ def _forward(background, means3D, colors, opacity, scales, rotations, scale_modi
         rt.check(L.hgs_forward_preprocess(stream, P, int(degree), M, W, H, rt.ptr(means3D), rt.ptr(sh_), rt.ptr(colors_),
                                           rt.ptr(opacity_), rt.ptr(scales_), float(scale_modifier), rt.ptr(rots_),
                                           rt.ptr(cov_), rt.ptr(view), rt.ptr(proj), rt.ptr(cam), float(tan_fovx),
-                                          float(tan_fovy), int(bool(prefiltered)), rt.ptr(geom), rt.ptr(img),
+                                          float(tan_fovy), flags, rt.ptr(geom), rt.ptr(img),
                                           rt.ptr(radii), None if use_async else C.addressof(n_host),
                                           rt.ptr(_max_rendered(dev)) if use_async else None))
         if use_async:

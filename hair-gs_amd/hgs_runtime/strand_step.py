@@ -80,6 +80,7 @@ class ViewTable:
         # several views per captured step (include/hgs.h hgs_set_view_queue / hgs_select_view_queued)
         self.queue = torch.zeros(rt.VIEW_QUEUE_MAX, dtype=torch.int32, device=self.device)
         self.queue_lr = torch.zeros((), dtype=torch.float32, device=self.device)
+        self._image, self._zero, self._image_ready, self._graph = None, None, False, None
 
     def select(self, view, lr=0.0, lr_dst=None):
         """slot <- table[view] (and *lr_dst <- lr): one launch on the current stream."""
@@ -90,6 +91,51 @@ class ViewTable:
                                               float(lr), None if lr_dst is None else lr_dst.data_ptr()))
         self.current = int(view)
 
+    # ---- iteration prologue: view select + clearing of the image buffer's counters in ONE launch (include/hgs.h) ----
+    def _image_zero_range(self):
+        if self._image is None:
+            L = rt.lib()
+            self._image = torch.empty((L.hgs_image_bytes(self.W, self.H),), dtype=torch.uint8, device=self.device)
+            off, nbytes = C.c_size_t(0), C.c_size_t(0)
+            rt.check(L.hgs_image_zero_range(self.W, self.H, C.addressof(off), C.addressof(nbytes)))
+            self._zero = (self._image.data_ptr() + off.value, nbytes.value)
+        return self._zero
+
+    def prologue(self, view, lr=0.0, lr_dst=None):
+        """select(view, lr, lr_dst) and, in the same launch, the clearing of this table's image buffer for the coming
+        forward pass, which take_image() then hands to the rasterizer (HGS_IMAGE_PREZEROED)."""
+        if not 0 <= int(view) < self.n:
+            raise rt.HgsError(f"view {view} outside the table (0..{self.n - 1})")
+        zp, zb = self._image_zero_range()
+        with torch.cuda.device(self.device):
+            rt.check(rt.lib().hgs_iteration_prologue(rt.current_stream(), self.table.data_ptr(), int(view), self.slot.data_ptr(),
+                                                     float(lr), None if lr_dst is None else lr_dst.data_ptr(), zp, zb))
+        self.current = int(view)
+        self._image_ready = True
+
+    def take_image(self):
+        """The image buffer whose counters the last prologue() cleared (once), else None."""
+        if not self._image_ready:
+            return None
+        self._image_ready = False
+        return self._image
+
+    def graph_bind(self, cuda_graph):
+        """After the capture of a graph that holds exactly one prologue(): find that node (torch.cuda.CUDAGraph built with
+        keep_graph=True and instantiated).  graph_set() then re-points it between replays without any launch."""
+        node = C.c_void_p(0)
+        rt.check(rt.lib().hgs_graph_find_prologue(C.c_void_p(int(cuda_graph.raw_cuda_graph())), C.addressof(node)))
+        self._graph = (cuda_graph, node.value)
+
+    def graph_set(self, view, lr=0.0, lr_dst=None):
+        if not 0 <= int(view) < self.n:
+            raise rt.HgsError(f"view {view} outside the table (0..{self.n - 1})")
+        graph, node = self._graph
+        zp, zb = self._image_zero_range()
+        rt.check(rt.lib().hgs_graph_set_prologue(C.c_void_p(int(graph.raw_cuda_graph_exec())), C.c_void_p(node),
+                                                 self.table.data_ptr(), int(view), self.slot.data_ptr(), float(lr),
+                                                 None if lr_dst is None else lr_dst.data_ptr(), zp, zb))
+        self.current = int(view)
 
     def set_queue(self, views, lr=0.0):
         """queue[:len(views)] <- views, queue_lr <- lr: one launch, values travel as kernel arguments."""
@@ -156,7 +202,7 @@ def _raster_head_forward(step, xyz, scale, quat, opacity, extra4, shs, endpoints
     empty = step.empty
     R, planes, radii, geom, binning, img = raster.rasterize_gaussians_multi(
         step.bg7, xyz, empty, extra4, opacity, scale, quat, 1.0, empty, vt.viewmatrix, vt.projmatrix, vt.tanfovx,
-        vt.tanfovy, vt.H, vt.W, shs, g.active_sh_degree, vt.campos, False, False)
+        vt.tanfovy, vt.H, vt.W, shs, g.active_sh_degree, vt.campos, False, False, image_buffer=vt.take_image())
     hp.n_endpoints = n_endpoints
     scratch = torch.empty((L.hgs_loss_head_scratch_floats(C.byref(hp)),), **f32)
     out = torch.empty((rt.HEAD_NOUT,), **f32)

@@ -139,7 +139,7 @@ def _training_step(gaussians, viewpoint_cam, opt, bg, iteration, extent, vp, ras
     if iteration % 1000 == 0:
         gaussians.oneupSHdegree()
     if fused is not None:
-        fused.views.select(fused.views.index[id(viewpoint_cam)])
+        fused.views.prologue(fused.views.index[id(viewpoint_cam)])
         fused.stats_in_backward = iteration < opt.densify_until_iter
         loss, _ = fused.loss()
         loss_dict = fused.terms()
@@ -218,6 +218,7 @@ class GraphedStep:
                 setattr(self.slot, f, v.clone())
         raster.set_async(True, slack=slack)
         self._graphs = None
+        self._prologue_in_graph = False
         self._cap = None
         self.views_per_step = int(views_per_step)
         if self.views_per_step > 1 and self.fused is None:
@@ -262,7 +263,10 @@ class GraphedStep:
     def load_camera(self, cam):
         if self.fused is not None:
             v = self.fused.views
-            v.select(v.index[id(cam)], lr=self._lr_now, lr_dst=self._position_lr())
+            if self._prologue_in_graph and not torch.cuda.is_current_stream_capturing() and self._graphs is not None:
+                v.graph_set(v.index[id(cam)], lr=self._lr_now, lr_dst=self._position_lr())   # host work only: no launch
+            else:
+                v.prologue(v.index[id(cam)], lr=self._lr_now, lr_dst=self._position_lr())
             return
         for f in self.CAMERA_FIELDS:
             dst, src = getattr(self.slot, f, None), getattr(cam, f, None)
@@ -309,6 +313,7 @@ class GraphedStep:
         """Warm up eagerly on a side stream (allocator, lazy module loads, capacity), then capture."""
         g, raster = self.g, self.raster
         self._make_capturable()
+        self._graphs = None            # (load_camera launches the prologue until the new graph exists)
         saved_stats = (g.max_radii2D.clone(), g.xyz_gradient_accum.clone(), g.denom.clone())  # warm-up must not count
         s = self._stream = torch.cuda.Stream()  # warm-up AND capture run on this stream (AccumulateGrad nodes are per stream)
         s.wait_stream(torch.cuda.current_stream())
@@ -335,9 +340,14 @@ class GraphedStep:
         if multi:
             self.fused.views.set_queue([0] * self.views_per_step, lr=self._lr_now)   # (the capture itself launches nothing)
         fwd_bwd = self._forward_backward_queue if multi else self._forward_backward
+        # one view per step on the fused path: the view select (+ image-buffer clearing) is the graph's first node, and
+        # step() re-points it by updating that node's arguments (no launch between two replays)
+        self._prologue_in_graph = self.fused is not None and not multi
         if self.vp.world == 1:
-            ga = torch.cuda.CUDAGraph()
+            ga = torch.cuda.CUDAGraph(keep_graph=True) if self._prologue_in_graph else torch.cuda.CUDAGraph()
             with torch.cuda.graph(ga, stream=s):
+                if self._prologue_in_graph:
+                    self.load_camera(warmup_cams[0])
                 self.loss_buf = fwd_bwd()
                 if multi:
                     self._scale_gradients()
@@ -347,8 +357,11 @@ class GraphedStep:
             # a live RCCL communicator has a watchdog thread that polls events: with the default (global) capture
             # error mode its calls would invalidate the capture; only this thread's unsafe calls must be errors
             mode = dict(capture_error_mode="thread_local")
-            ga, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+            ga = torch.cuda.CUDAGraph(keep_graph=True) if self._prologue_in_graph else torch.cuda.CUDAGraph()
+            gb = torch.cuda.CUDAGraph()
             with torch.cuda.graph(ga, stream=s, **mode):
+                if self._prologue_in_graph:
+                    self.load_camera(warmup_cams[0])
                 self.loss_buf = fwd_bwd()
                 self.vp.pack_gradients(g)       # .grad become views of the flat exchange buffer
             with torch.cuda.graph(gb, pool=ga.pool(), stream=s, **mode):
@@ -356,6 +369,9 @@ class GraphedStep:
                     self._scale_gradients()     # (the exchange in between SUMS over the ranks)
                 g.optimizer.step()
             self._graphs = (ga, gb)
+        if self._prologue_in_graph:
+            ga.instantiate()
+            self.fused.views.graph_bind(ga)
         # every replay raises the library's sticky device-side maximum of num_rendered; check() compares it with the
         # capacity the captured passes were built for
         self._cap = raster._state["cap_used"]

@@ -62,7 +62,11 @@ size_t hgs_backward_scratch_bytes(int P, int R);
  * cleared it, which is what a captured HIP graph needs to validate its capacity after any number of replays without a
  * per-iteration device-to-host copy.  With num_rendered_host == NULL and max_rendered != NULL the scans are left to the
  * scatter kernel of hgs_forward_render (no one-workgroup scan launch in between): R and its maximum are then on the
- * device once THAT call has run on the stream; max_rendered has to stay valid until then. */
+ * device once THAT call has run on the stream; max_rendered has to stay valid until then.
+ * prefiltered: bit 0 = the reference's flag (accepted, ignored); bit 1 (HGS_IMAGE_PREZEROED) = the caller has already
+ * cleared the counters of image_buf on this stream (hgs_iteration_prologue over hgs_image_zero_range): the call's own
+ * clearing launch is skipped. */
+#define HGS_IMAGE_PREZEROED 2
 int hgs_forward_preprocess(void* stream, int P, int D, int M, int W, int H,
                            const float* means3D, const float* shs, const float* colors_precomp,
                            const float* opacities, const float* scales, float scale_modifier,
@@ -158,7 +162,8 @@ int hgs_orientation_loss_backward(void* stream, int H, int W, const float* omap,
                                   const uint8_t* mask, const float* g_loss, const float* mask_count, float* d_omap);
 /* hgs_adam_step <-> torch.optim.Adam(lr=0, eps=1e-15) as built at scene/gaussian_model.py:250 and
  *   scene/hair_gaussian_model.py:246: all parameter tensors (<= 8) updated by ONE launch.  The six arrays are HOST arrays
- *   of n_tensors DEVICE pointers; lr[k] and step[k] point to fp32 device scalars (step is incremented by the call).
+ *   of n_tensors DEVICE pointers; lr[k] and step[k] point to fp32 device scalars (step is incremented by the call, by
+ *   the launch's last workgroup: calls of one process must be stream-ordered, not concurrent on two streams).
  * hgs_smoothness_forward/backward <-> loss/losses.py:175-221 angle_smoothness_loss: index_pairs is the int64 [N,2,2]
  *   table of consecutive strand segments (endpoint ids); partials: 2 floats per 256 pairs (sum of squared angles of the
  *   pairs bent more than the threshold, their count); loss = sum0 / max(sum1, 1).  backward zeroes d_endpoints [E,3]
@@ -208,6 +213,20 @@ size_t hgs_strand_fusion_bytes(void);  /* sizeof(HgsStrandFusion) */
 /* slot[0] = table[view]; if lr_dst != NULL also *lr_dst = lr (the position learning rate of this iteration, a by-value
  * kernel argument, so the host may run ahead of the device without racing on a staging buffer). */
 int hgs_select_view(void* stream, const HgsViewTargets* table, int view, HgsViewTargets* slot, float lr, float* lr_dst);
+/* Iteration prologue: hgs_select_view and, in the same launch, the clearing of zero_bytes bytes at zero_ptr -- meant for
+ * the counters at the head of the image buffer of the coming hgs_forward_preprocess (range: hgs_image_zero_range; pass
+ * HGS_IMAGE_PREZEROED to that call so that it does not clear them again).  One launch instead of three small ones in
+ * front of every iteration. */
+int hgs_iteration_prologue(void* stream, const HgsViewTargets* table, int view, HgsViewTargets* slot, float lr, float* lr_dst,
+                           void* zero_ptr, size_t zero_bytes);
+int hgs_image_zero_range(int W, int H, size_t* offset, size_t* bytes);   /* of an image_buf of hgs_image_bytes(W, H) */
+/* A captured HIP graph that holds exactly ONE hgs_iteration_prologue / hgs_select_view launch is re-pointed at another
+ * view (and learning rate) without any launch between two replays: hgs_graph_find_prologue(hipGraph_t) returns that
+ * kernel node once after the capture, hgs_graph_set_prologue(hipGraphExec_t, node, ...) rewrites its arguments (host
+ * work only; takes effect at the next launch of the executable graph). */
+int hgs_graph_find_prologue(void* graph, void** node_out);
+int hgs_graph_set_prologue(void* graph_exec, void* node, const HgsViewTargets* table, int view, HgsViewTargets* slot, float lr,
+                           float* lr_dst, void* zero_ptr, size_t zero_bytes);
 /* Several views per optimizer step inside ONE captured graph (strong-scaling protocol, SURVEY.md 8e: a fixed global batch
  * of V views per step, rank r takes views r, r+N, ...).  The graph holds one hgs_select_view_queued launch per local view,
  * which reads the view index from DEVICE memory; before every replay the host writes the step's indices (and the
