@@ -59,6 +59,9 @@ def parse():
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
     ap.add_argument("--global-views", type=int, default=8, help="views per optimizer step of the strong-scaling protocol")
     ap.add_argument("--repeats", type=int, default=5, help="how many times the K-step region is timed")
+    ap.add_argument("--steps-per-graph", type=int, default=8,
+                    help="optimizer steps captured per graph launch (GraphedStep.step_many; 1 GPU, one view per step; the "
+                         "steps that do not fill a launch replay the single-step graph)")
     ap.add_argument("--sustained-seconds", type=float, default=2.0, help="length of the sustained leg (0: skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true", help="disable per-kernel HIP-event timing")
@@ -213,7 +216,9 @@ def main():
     if use_graph:
         # the whole iteration is captured once into a HIP graph and replayed (train.GraphedStep); the W warm-up steps
         # and the K timed steps are real optimizer steps on successive random views, exactly like the eager loop
-        gs = GraphedStep(model, cams, opt, bg, extent=extent, vp=vp, views=views, views_per_step=views_per_rank)
+        spg = args.steps_per_graph if (fused is not None and views_per_rank == 1 and world == 1) else 1
+        gs = GraphedStep(model, cams, opt, bg, extent=extent, vp=vp, views=views, views_per_step=views_per_rank,
+                         steps_per_graph=max(1, spg))
         gs.capture(cams, iteration=1)
 
         def one_step():
@@ -226,20 +231,29 @@ def main():
             it += 1
             training_step(model, sampler.next(), opt, bg, it, extent=extent, vp=vp, fused=fused)
 
+    def run_steps(n_steps):
+        """EXACTLY n_steps optimizer steps: whole launches of the several-steps graph, the rest one step per launch."""
+        nonlocal it
+        K = gs.steps_per_graph if use_graph else 1
+        while K > 1 and n_steps >= K:
+            gs.step_many([sampler.next() for _ in range(K)], it + 1)
+            it += K
+            n_steps -= K
+        for _ in range(n_steps):
+            one_step()
+
     def timed_region(n_steps):
         """EXACTLY n_steps optimizer steps between two barrier + synchronize pairs; seconds, maximum over the ranks."""
         sync_all()
         t0 = time.perf_counter()
-        for _ in range(n_steps):
-            one_step()
+        run_steps(n_steps)
         sync_all()
         t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
         if world > 1:
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
-    for _ in range(args.warmup):
-        one_step()
+    run_steps(args.warmup)
     # Training changes the workload (the Gaussians grow: +30 % instances per view after 500 steps).  Every timed region,
     # the kernel-timing pass and the workload statistics therefore start from the SAME state -- the parameters, Adam
     # moments and step counters as they are after the warm-up -- restored outside the timed regions; the regions time
@@ -287,8 +301,7 @@ def main():
                 for t, s_ in zip(state_tensors, snapshot):
                     t.copy_(s_, non_blocking=True)
             it = it0
-            for _ in range(args.steps):
-                one_step()
+            run_steps(args.steps)
         sync_all()
         t_sus = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
         if world > 1:
@@ -383,6 +396,7 @@ def main():
                    "mean_num_rendered_after_tile_cull": meanR_culled, "mean_sum_tile_list_len_after_tile_cull": meanL_culled,
                    "forward_mode": "blocking" if args.blocking else "async-capacity",
                    "dispatch": "hip-graph replay" if use_graph else "eager",
+                   "optimizer_steps_per_graph_launch": (gs.steps_per_graph if use_graph else None),
                    "iteration": "fused iteration" if fused is not None else "op-by-op",
                    "raster_passes_per_iter": 1 if getattr(opt, "single_pass", True) else 3},
         "render_ms_per_view": render_ms,

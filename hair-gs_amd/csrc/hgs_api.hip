@@ -421,13 +421,12 @@ int hgs_select_view(void* stream, const HgsViewTargets* table, int view, HgsView
 }
 
 // ---- re-pointing the prologue node of a captured graph ----------------------------------------------------------------
-int hgs_graph_find_prologue(void* graph, void** node_out) {
-  if (!graph || !node_out) { hgs_set_error("hgs_graph_find_prologue: bad arguments"); return 1; }
+int hgs_graph_find_prologues(void* graph, int max_nodes, void** nodes_out, float* lr_out, int* n_out) {
+  if (!graph || !nodes_out || !n_out || max_nodes < 1) { hgs_set_error("hgs_graph_find_prologues: bad arguments"); return 1; }
   size_t n = 0;
   HGS_CHECK_HIP(hipGraphGetNodes((hipGraph_t)graph, nullptr, &n));
   std::vector<hipGraphNode_t> nodes(n);
   if (n) HGS_CHECK_HIP(hipGraphGetNodes((hipGraph_t)graph, nodes.data(), &n));
-  void* found = nullptr;
   int count = 0;
   for (size_t i = 0; i < n; i++) {
     hipGraphNodeType t;
@@ -435,10 +434,22 @@ int hgs_graph_find_prologue(void* graph, void** node_out) {
     if (t != hipGraphNodeTypeKernel) continue;
     hipKernelNodeParams kp;
     HGS_CHECK_HIP(hipGraphKernelNodeGetParams(nodes[i], &kp));
-    if (kp.func == (void*)select_view_kernel) { if (!found) found = (void*)nodes[i]; count++; }
+    if (kp.func != (void*)select_view_kernel) continue;
+    if (count < max_nodes) {
+      nodes_out[count] = (void*)nodes[i];
+      if (lr_out) lr_out[count] = kp.kernelParams ? *(const float*)kp.kernelParams[3] : 0.f;   // (argument 3: lr)
+    }
+    count++;
   }
-  if (count != 1) { hgs_set_error("hgs_graph_find_prologue: the graph holds %d prologue launches (need exactly 1)", count); return 1; }
-  *node_out = found;
+  *n_out = count;
+  if (count > max_nodes) { hgs_set_error("hgs_graph_find_prologues: the graph holds %d prologue launches (room for %d)", count, max_nodes); return 1; }
+  return 0;
+}
+int hgs_graph_find_prologue(void* graph, void** node_out) {
+  int n = 0;
+  if (!node_out) { hgs_set_error("hgs_graph_find_prologue: bad arguments"); return 1; }
+  if (hgs_graph_find_prologues(graph, 1, node_out, nullptr, &n)) return 1;
+  if (n != 1) { hgs_set_error("hgs_graph_find_prologue: the graph holds %d prologue launches (need exactly 1)", n); return 1; }
   return 0;
 }
 int hgs_graph_set_prologue(void* graph_exec, void* node, const HgsViewTargets* table, int view, HgsViewTargets* slot, float lr,

@@ -56,6 +56,7 @@ SIGNATURES = {
     "hgs_iteration_prologue": (ci, [vp, vp, ci, vp, cf, vp, vp, sz]),
     "hgs_image_zero_range": (ci, [ci, ci, vp, vp]),
     "hgs_graph_find_prologue": (ci, [vp, vp]),
+    "hgs_graph_find_prologues": (ci, [vp, ci, vp, vp, vp]),
     "hgs_graph_set_prologue": (ci, [vp, vp, vp, ci, vp, cf, vp, vp, sz]),
     "hgs_set_view_queue": (ci, [vp, vp, ci, vp, cf, vp]),
     "hgs_select_view_queued": (ci, [vp, vp, ci, vp, vp, vp, vp]),

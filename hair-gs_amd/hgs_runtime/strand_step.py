@@ -80,7 +80,7 @@ class ViewTable:
         # several views per captured step (include/hgs.h hgs_set_view_queue / hgs_select_view_queued)
         self.queue = torch.zeros(rt.VIEW_QUEUE_MAX, dtype=torch.int32, device=self.device)
         self.queue_lr = torch.zeros((), dtype=torch.float32, device=self.device)
-        self._image, self._zero, self._image_ready, self._graph = None, None, False, None
+        self._image, self._zero, self._image_ready = None, None, False
 
     def select(self, view, lr=0.0, lr_dst=None):
         """slot <- table[view] (and *lr_dst <- lr): one launch on the current stream."""
@@ -120,19 +120,24 @@ class ViewTable:
         self._image_ready = False
         return self._image
 
-    def graph_bind(self, cuda_graph):
-        """After the capture of a graph that holds exactly one prologue(): find that node (torch.cuda.CUDAGraph built with
-        keep_graph=True and instantiated).  graph_set() then re-points it between replays without any launch."""
-        node = C.c_void_p(0)
-        rt.check(rt.lib().hgs_graph_find_prologue(C.c_void_p(int(cuda_graph.raw_cuda_graph())), C.addressof(node)))
-        self._graph = (cuda_graph, node.value)
+    def graph_bind(self, cuda_graph, count=1):
+        """After the capture of a graph that holds `count` prologue() launches, captured with lr = 0, 1, ... count - 1 as
+        tags: find those nodes (torch.cuda.CUDAGraph built with keep_graph=True and instantiated).  Returns the binding
+        graph_set() takes to re-point them between replays without any launch."""
+        nodes, tags, n = (C.c_void_p * count)(), (C.c_float * count)(), C.c_int(0)
+        rt.check(rt.lib().hgs_graph_find_prologues(C.c_void_p(int(cuda_graph.raw_cuda_graph())), count, nodes, tags, C.addressof(n)))
+        order = sorted(range(n.value), key=lambda i: tags[i])
+        if n.value != count or (count > 1 and [int(tags[i]) for i in order] != list(range(count))):
+            raise rt.HgsError(f"graph_bind: expected {count} tagged prologue nodes, found {n.value} with tags {[tags[i] for i in order]}")
+        return (cuda_graph, [nodes[i] for i in order])
 
-    def graph_set(self, view, lr=0.0, lr_dst=None):
+    def graph_set(self, binding, view, lr=0.0, lr_dst=None, k=0):
+        """Re-point the k-th prologue node of a graph_bind() result (host work only; takes effect at the next replay)."""
         if not 0 <= int(view) < self.n:
             raise rt.HgsError(f"view {view} outside the table (0..{self.n - 1})")
-        graph, node = self._graph
+        graph, nodes = binding
         zp, zb = self._image_zero_range()
-        rt.check(rt.lib().hgs_graph_set_prologue(C.c_void_p(int(graph.raw_cuda_graph_exec())), C.c_void_p(node),
+        rt.check(rt.lib().hgs_graph_set_prologue(C.c_void_p(int(graph.raw_cuda_graph_exec())), C.c_void_p(nodes[k]),
                                                  self.table.data_ptr(), int(view), self.slot.data_ptr(), float(lr),
                                                  None if lr_dst is None else lr_dst.data_ptr(), zp, zb))
         self.current = int(view)

@@ -195,7 +195,8 @@ class GraphedStep:
     CAMERA_FIELDS = ("world_view_transform", "full_proj_transform", "camera_center", "original_image", "mask",
                      "float_mask", "orientation_field", "orientation_confidence")
 
-    def __init__(self, gaussians, cameras, opt, bg, extent=1.0, vp=None, slack=2.0, views=None, views_per_step=1):
+    def __init__(self, gaussians, cameras, opt, bg, extent=1.0, vp=None, slack=2.0, views=None, views_per_step=1,
+                 steps_per_graph=1):
         """views_per_step > 1: every rank renders that many views per optimizer step inside the one captured graph and
         sums their gradients; with W ranks the step's gradient is the MEAN over the views_per_step x W views of the
         global batch (strong-scaling protocol: the batch is fixed, the ranks share it)."""
@@ -219,8 +220,12 @@ class GraphedStep:
         raster.set_async(True, slack=slack)
         self._graphs = None
         self._prologue_in_graph = False
+        self._binding = self._many = None
         self._cap = None
         self.views_per_step = int(views_per_step)
+        # steps_per_graph > 1: a second graph holds that many consecutive optimizer steps (step_many): one graph launch costs
+        # ~8 us of idle GPU between two replays whatever the graph holds, so K steps per launch save (1 - 1/K) of that
+        self.steps_per_graph = int(steps_per_graph)
         if self.views_per_step > 1 and self.fused is None:
             raise ValueError("several views per captured step need the fused iteration (hgs_runtime.strand_step)")
         self._make_capturable()
@@ -264,7 +269,7 @@ class GraphedStep:
         if self.fused is not None:
             v = self.fused.views
             if self._prologue_in_graph and not torch.cuda.is_current_stream_capturing() and self._graphs is not None:
-                v.graph_set(v.index[id(cam)], lr=self._lr_now, lr_dst=self._position_lr())   # host work only: no launch
+                v.graph_set(self._binding, v.index[id(cam)], lr=self._lr_now, lr_dst=self._position_lr())   # host work only: no launch
             else:
                 v.prologue(v.index[id(cam)], lr=self._lr_now, lr_dst=self._position_lr())
             return
@@ -371,7 +376,23 @@ class GraphedStep:
             self._graphs = (ga, gb)
         if self._prologue_in_graph:
             ga.instantiate()
-            self.fused.views.graph_bind(ga)
+            self._binding = self.fused.views.graph_bind(ga)
+        self._many = None
+        if self.steps_per_graph > 1:
+            if not self._prologue_in_graph or self.vp.world != 1:
+                raise ValueError("steps_per_graph > 1 needs the fused iteration, one view per step and one rank")
+            K, v = self.steps_per_graph, self.fused.views
+            gk = torch.cuda.CUDAGraph(keep_graph=True)
+            losses = []
+            with torch.cuda.graph(gk, pool=ga.pool(), stream=s):
+                for j in range(K):
+                    g.optimizer.zero_grad(set_to_none=True)   # (host side: this step's backward ASSIGNS its gradients)
+                    g._derived = None
+                    v.prologue(j % v.n, lr=float(j), lr_dst=self._position_lr())   # lr = j: the tag graph_bind sorts by
+                    losses.append(fwd_bwd())
+                    g.optimizer.step()
+            gk.instantiate()
+            self._many = (gk, v.graph_bind(gk, K), losses)
         # every replay raises the library's sticky device-side maximum of num_rendered; check() compares it with the
         # capacity the captured passes were built for
         self._cap = raster._state["cap_used"]
@@ -402,6 +423,21 @@ class GraphedStep:
             gb.replay()
         self.g._derived = None  # cached derived tensors now hold pre-update values
         return self.loss_buf
+
+    def step_many(self, cams, iteration):
+        """steps_per_graph optimizer steps -- iterations `iteration`, `iteration` + 1, ... on the views `cams` -- with ONE
+        graph launch; returns the list of their (device) losses.  Same arithmetic as that many step() calls."""
+        cams = list(cams)
+        if self._many is None or len(cams) != self.steps_per_graph:
+            raise ValueError(f"captured for {self.steps_per_graph} steps per graph, got {len(cams)}")
+        gk, binding, losses = self._many
+        v = self.fused.views
+        for j, cam in enumerate(cams):
+            self._set_lr(iteration + j)
+            v.graph_set(binding, v.index[id(cam)], lr=self._lr_now, lr_dst=self._position_lr(), k=j)
+        gk.replay()
+        self.g._derived = None
+        return losses
 
     def headroom(self):
         """(largest num_rendered of the replays since the last check, captured capacity): one synchronisation, no
@@ -440,13 +476,14 @@ def topology_due(gaussians, opt, iteration):
 
 
 def training(gaussians, cameras, opt, iterations=None, extent=1.0, seed=0, log_every=0, vp=None, start_iteration=0,
-             use_graph=True, sampler=None):
+             use_graph=True, sampler=None, steps_per_graph=8):
     """Training loop (reference train.py:91-254 without logger / viewer / dataset IO, which are outside the
     accelerated path).  With use_graph the iteration body replays a captured HIP graph (GraphedStep).  Iterations on which
     the reference schedules a shape-changing operator (densification, merging, opacity reset, SH-degree bump:
     train.py:136-200) run EAGERLY through `training_step`, which has the reference's order -- operators between backward
     and optimizer.step(), so re-created tensors skip that Adam step exactly as in the reference --, and the graph is
-    captured again afterwards.  `sampler`: a ViewSampler to continue (main() trains in chunks between saves)."""
+    captured again afterwards.  Runs of steps_per_graph plain iterations go out as ONE graph launch (GraphedStep.step_many;
+    single rank, fused iteration).  `sampler`: a ViewSampler to continue (main() trains in chunks between saves)."""
     vp = ViewParallel() if vp is None else vp
     dev = gaussians.get_xyz.device
     bg = torch.zeros(3, dtype=torch.float32, device=dev)
@@ -463,22 +500,31 @@ def training(gaussians, cameras, opt, iterations=None, extent=1.0, seed=0, log_e
     topology = getattr(opt, "enable_topology", True)
     void_steps = 0
     try:
-        for it in range(start_iteration + 1, start_iteration + n + 1):
+        it, last = start_iteration + 1, start_iteration + n
+        while it <= last:
             due = topology_due(gaussians, opt, it) if topology else []
             if use_graph and not due:
                 if gs is None:
-                    gs = GraphedStep(gaussians, cameras, opt, bg, extent=extent, vp=vp, views=views)
+                    many = steps_per_graph if (fused is not None and vp.world == 1) else 1
+                    gs = GraphedStep(gaussians, cameras, opt, bg, extent=extent, vp=vp, views=views, steps_per_graph=many)
                     gs.capture(cameras, iteration=it)
-                loss = gs.step(sampler.next(), it)
+                K = gs.steps_per_graph
+                if K > 1 and it + K - 1 <= last and not (topology and any(topology_due(gaussians, opt, j) for j in range(it + 1, it + K))):
+                    losses = gs.step_many([sampler.next() for _ in range(K)], it)   # K optimizer steps, one graph launch
+                else:
+                    losses = [gs.step(sampler.next(), it)]
             else:
                 if gs is not None:
                     void_steps += _void_steps(gs)
                     gs = None                  # shapes change below: capture again at the next iteration
                 loss, _, _ = training_step(gaussians, sampler.next(), opt, bg, it, extent=extent, vp=vp, fused=fused)
+                losses = [loss]
                 if fused is not None and due:
                     fused.refresh()
-            ema = loss.clone() if ema is None else 0.4 * loss + 0.6 * ema  # on the device: no per-iteration host sync
-            if gs is not None and it % 64 == 0:
+            first, it = it, it + len(losses)
+            for loss in losses:
+                ema = loss.clone() if ema is None else 0.4 * loss + 0.6 * ema  # on the device: no per-iteration host sync
+            if gs is not None and any(j % 64 == 0 for j in range(first, it)):
                 # the model grows while it trains: re-capture with a larger capacity once 80% of the captured one is used.
                 # The decision is taken on the maximum over the ranks (views differ; replicas must re-capture together).
                 worst, cap = gs.headroom()
@@ -493,12 +539,12 @@ def training(gaussians, cameras, opt, iterations=None, extent=1.0, seed=0, log_e
                         # moved the parameters by Adam's momentum only -- deterministic, finite, reported
                         void_steps += 1
                         if vp.rank == 0:
-                            print(f"[it {it}] binning capacity {cap} exceeded ({worst} instances): steps since the last check "
+                            print(f"[it {it - 1}] binning capacity {cap} exceeded ({worst} instances): steps since the last check "
                                   "that overflowed ran with zero gradients; re-capturing with a larger capacity")
                     raster._state["cap"] = max(raster._state["cap"], int(worst * 2.0) + 4096)
                     gs = None
-            if log_every and it % log_every == 0 and vp.rank == 0:
-                print(f"[it {it}] loss(ema) {float(ema):.6f}  segments {gaussians.get_xyz.shape[0]}")
+            if log_every and vp.rank == 0 and any(j % log_every == 0 for j in range(first, it)):
+                print(f"[it {it - 1}] loss(ema) {float(ema):.6f}  segments {gaussians.get_xyz.shape[0]}")
         if gs is not None:
             void_steps += _void_steps(gs)
     finally:

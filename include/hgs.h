@@ -225,6 +225,9 @@ int hgs_image_zero_range(int W, int H, size_t* offset, size_t* bytes);   /* of a
  * kernel node once after the capture, hgs_graph_set_prologue(hipGraphExec_t, node, ...) rewrites its arguments (host
  * work only; takes effect at the next launch of the executable graph). */
 int hgs_graph_find_prologue(void* graph, void** node_out);
+/* several iterations captured in one graph: all its prologue nodes (any order) with the `lr` each was captured with, which
+ * the caller uses as a tag to tell them apart */
+int hgs_graph_find_prologues(void* graph, int max_nodes, void** nodes_out, float* lr_out, int* n_out);
 int hgs_graph_set_prologue(void* graph_exec, void* node, const HgsViewTargets* table, int view, HgsViewTargets* slot, float lr,
                            float* lr_dst, void* zero_ptr, size_t zero_bytes);
 /* Several views per optimizer step inside ONE captured graph (strong-scaling protocol, SURVEY.md 8e: a fixed global batch

@@ -260,6 +260,46 @@ def test_graphed_step_matches_eager_steps():
     assert float(results["graph"][3].sum()) > 0
 
 
+def test_several_steps_per_graph_equal_single_step_replays():
+    """GraphedStep(steps_per_graph=4).step_many == four step() replays, bit for bit (same kernels, same order); the two
+    graphs of one GraphedStep can be mixed (8 steps as 4 + 1 + 1 + ... )."""
+    from arguments import OptimizationParams
+    from diff_gaussian_rasterization import _C as raster
+    from synthetic import build_workload
+    from train import GraphedStep
+    from utils.general import safe_state
+    order = [1, 3, 0, 2, 1, 0, 3, 2, 2, 1]
+    results = {}
+    try:
+        for mode in ("single", "many"):
+            safe_state(True)
+            model, cams, extent = build_workload("tiny", device="cuda", with_targets=True)
+            opt = OptimizationParams()
+            opt.enable_topology = False
+            model.training_setup(opt)
+            bg = torch.zeros(3, device="cuda")
+            gs = GraphedStep(model, cams, opt, bg, extent=extent, steps_per_graph=4 if mode == "many" else 1)
+            gs.capture(cams)
+            losses = []
+            if mode == "single":
+                for it, ci in enumerate(order, 1):
+                    losses.append(gs.step(cams[ci], it).clone())
+            else:
+                losses += [l.clone() for l in gs.step_many([cams[ci] for ci in order[0:4]], 1)]
+                losses.append(gs.step(cams[order[4]], 5).clone())
+                losses.append(gs.step(cams[order[5]], 6).clone())
+                losses += [l.clone() for l in gs.step_many([cams[ci] for ci in order[6:10]], 7)]
+            assert min(gs.check()) > 0
+            raster.set_async(False)
+            results[mode] = (torch.stack(losses), model._endpoints.detach().clone(), model._opacity.detach().clone(),
+                             model._features_dc.detach().clone(), model.denom.clone(), model.xyz_gradient_accum.clone(),
+                             model.max_radii2D.clone())
+    finally:
+        raster.set_async(False)
+    for a, b in zip(results["single"], results["many"]):
+        assert torch.equal(a, b)
+
+
 @pytest.mark.parametrize("use_graph", [False, True])
 def test_training_loop_with_topology_changes(use_graph):
     """training(): densification + merging + opacity reset at their intervals, with graph re-capture after each."""
