@@ -52,11 +52,15 @@ struct WgTrace {   // 8 words per workgroup: start, marks 1..5, (tile | seg << 2
   __device__ void item(int tile, uint32_t seg, uint32_t nseg, uint32_t len) const {
     if (buf && threadIdx.x == 0) buf[6] = (unsigned long long)tile | (unsigned long long)seg << 24 | (unsigned long long)nseg << 32 | (unsigned long long)len << 40;
   }
+  // backward statistics (words 1..3 of the workgroup): (entry, wavefront) pairs evaluated / of those with no blending
+  // lane / sum of blending lanes
+  __device__ void count(int k, unsigned v) const { if (buf && (threadIdx.x & 63) == 0) atomicAdd(&buf[k], (unsigned long long)v); }
   __device__ ~WgTrace() { mark(7); }
 #else
   __device__ WgTrace(unsigned long long*) {}
   __device__ void mark(int) const {}
   __device__ void item(int, uint32_t, uint32_t, uint32_t) const {}
+  __device__ void count(int, unsigned) const {}
 #endif
 };
 
@@ -567,7 +571,9 @@ __global__ __launch_bounds__(HGS_BLOCK) __attribute__((amdgpu_waves_per_eu(HGS_B
       const float Gx = __expf(power);
       const float ax = fminf(0.99f, r1.y * Gx);
       const bool ok = (uint32_t)p < last && power <= 0.f && ax >= (1.0f / 255.0f);
-      if (__ballot(ok) == 0) return;
+      _trace.count(1, 1u);
+      if (__ballot(ok) == 0) { _trace.count(2, 1u); return; }
+      _trace.count(3, (unsigned)__popcll(__ballot(ok)));
       const float G = ok ? Gx : 0.f, alpha = ok ? ax : 0.f;
       const float inv_one_m_a = __builtin_amdgcn_rcpf(1.f - alpha);               // 1 ulp; alpha <= 0.99; rcp(1) == 1
       T = T * inv_one_m_a;                                                         // :960

@@ -260,6 +260,48 @@ def test_graphed_step_matches_eager_steps():
     assert float(results["graph"][3].sum()) > 0
 
 
+def test_iteration_prologue_equals_select_then_forward():
+    """ViewTable.prologue() (view select + clearing of the image buffer in one launch, HGS_IMAGE_PREZEROED) against
+    select() + a forward that clears its own buffer: identical loss, planes, gradients; the buffer is handed over once."""
+    from arguments import OptimizationParams
+    from hgs_runtime.strand_step import FusedStrandStep
+    from synthetic import build_workload
+    from utils.general import safe_state
+    import ctypes
+    import hgs_runtime as rt
+    safe_state(True)
+    model, cams, extent = build_workload("tiny", device="cuda", with_targets=True)
+    opt = OptimizationParams()
+    opt.enable_topology = False
+    model.training_setup(opt)
+    bg = torch.zeros(3, device="cuda")
+    fused = FusedStrandStep(model, cams, opt, bg)
+    params = [model._endpoints, model._width, model._opacity, model._mask, model._features_dc]
+    lr = torch.zeros((), device="cuda")
+    out = {}
+    for mode in ("select", "prologue", "prologue"):      # (twice: the buffer still holds the previous pass's counters)
+        for p in params:
+            p.grad = None
+        model._derived = None
+        if mode == "select":
+            fused.views.select(1, lr=0.5, lr_dst=lr)
+            assert fused.views.take_image() is None
+        else:
+            fused.views.prologue(1, lr=0.25, lr_dst=lr)
+            assert float(lr) == 0.25
+        loss, _ = fused.loss()
+        assert fused.views.take_image() is None          # consumed by the forward
+        fused.backward(loss)
+        cur = [loss.detach().clone(), fused.last["planes"].clone()] + [p.grad.clone() for p in params]
+        if mode in out or "select" in out:
+            for a, b in zip(out["select"], cur):
+                assert torch.equal(a, b)
+        out[mode] = cur
+    off, nbytes = ctypes.c_size_t(0), ctypes.c_size_t(0)
+    rt.check(rt.lib().hgs_image_zero_range(64, 48, ctypes.addressof(off), ctypes.addressof(nbytes)))
+    assert off.value % 4 == 0 and 0 < nbytes.value <= rt.lib().hgs_image_bytes(64, 48) - off.value
+
+
 def test_several_steps_per_graph_equal_single_step_replays():
     """GraphedStep(steps_per_graph=4).step_many == four step() replays, bit for bit (same kernels, same order); the two
     graphs of one GraphedStep can be mixed (8 steps as 4 + 1 + 1 + ... )."""

@@ -60,6 +60,10 @@ for name, t in (("fwd", tf), ("bwd", tb)):
     if name == "fwd":
         for i in np.argsort(-us[:, 7])[:6]:
             print("      late:", int(tile[i]), f"{int(seg[i])}/{int(nseg[i])}", "marks (us from kernel start):", np.round(us[i, [0, 1, 2, 3, 4, 7]] - t0, 1).tolist())
+    if name == "bwd":
+        pairs, empty, lanes = int(a[:, 1].sum()), int(a[:, 2].sum()), int(a[:, 3].sum())
+        print(f"   (entry, wavefront) pairs evaluated {pairs} = {pairs / max(1, length.sum()):.2f} per entry; without any blending lane {empty} "
+              f"({100.0 * empty / max(1, pairs):.0f} %); blending lanes per remaining pair {lanes / max(1, pairs - empty):.1f} of 64")
     late = np.argsort(-us[:, 7])[:8]
     print("   latest finishers (tile, seg/nseg, len, start, dur):",
           [(int(tile[i]), f"{int(seg[i])}/{int(nseg[i])}", int(length[i]), round(float(us[i, 0] - t0), 1), round(float(dur[i]), 1)) for i in late])
