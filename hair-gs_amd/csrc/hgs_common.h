@@ -290,8 +290,7 @@ template <typename T>
 __device__ __forceinline__ const HGS_GLOBAL T* hgs_global(const T* p) { return (const HGS_GLOBAL T*)p; }
 typedef float hgs_float4_t __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ float4 hgs_load4(const HGS_GLOBAL float* p) {      // 16-byte aligned
-  const hgs_float4_t v = *(const HGS_GLOBAL hgs_float4_t*)p;
-  return make_float4(v.x, v.y, v.z, v.w);
+  return __builtin_bit_cast(float4, *(const HGS_GLOBAL hgs_float4_t*)p);   // (no component-wise copy: the load's registers are the result)
 }
 __device__ __forceinline__ void hgs_publish_part(unsigned long long* mask, uint32_t part) {
   __hip_atomic_fetch_or(mask, 1ull << part, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

@@ -225,20 +225,23 @@ static inline unsigned ssim_grid_size(const SsimGrid& gd, int per_xcd) { return 
 
 // register staging of one halo tile (fast path, W % 4 == 0): 504 float4 per plane = 2 per thread
 #define ST_F4 (TILE * (TW / 4))
-template <int NP> struct TileStage { float4 v[NP][2]; };
+// Every chunk is loaded UNCONDITIONALLY from an address clamped into the image, straight into its registers, and zeroed
+// when it is written to LDS if it lay outside: a load under `if (inside)` merged with a zero made the compiler wait for
+// the data where the load was ISSUED (to copy it into the merged registers), i.e. the prefetch was not one.
+template <int NP> struct TileStage { float4 v[NP][2]; unsigned in; };   // in: bit u = chunk u lies inside the image
 template <int NP, typename PtrOf>
 __device__ __forceinline__ void stage_load(TileStage<NP>& st, int H, int W, int bx0, int by0, PtrOf plane_ptr) {
+  st.in = 0u;
 #pragma unroll
   for (int u = 0; u < 2; u++) {
     const int i = threadIdx.x + 256 * u;
     const int r = i / (TW / 4), c4 = (i - r * (TW / 4)) * 4;
     const int y = by0 + r - HALO, x = bx0 - XOFF + c4;
     const bool in = i < ST_F4 && (unsigned)y < (unsigned)H && x >= 0 && x < W;
+    st.in |= in ? 1u << u : 0u;
+    const size_t at = (size_t)min(max(y, 0), H - 1) * W + min(max(x, 0), W - 4);
 #pragma unroll
-    for (int p = 0; p < NP; p++) {
-      st.v[p][u] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (in) st.v[p][u] = hgs_load4(plane_ptr(p) + (size_t)y * W + x);
-    }
+    for (int p = 0; p < NP; p++) st.v[p][u] = hgs_load4(plane_ptr(p) + at);
   }
 }
 template <int NP>
@@ -248,10 +251,11 @@ __device__ __forceinline__ void stage_store(const TileStage<NP>& st, float (*t)[
     const int i = threadIdx.x + 256 * u;
     if (i < ST_F4) {
       const int r = i / (TW / 4), c4 = (i - r * (TW / 4)) * 4;
+      const bool in = (st.in >> u) & 1u;
 #pragma unroll
       for (int p = 0; p < NP; p++) {
         const float4 v = st.v[p][u];
-        t[p][r][c4] = v.x; t[p][r][c4 + 1] = v.y; t[p][r][c4 + 2] = v.z; t[p][r][c4 + 3] = v.w;
+        t[p][r][c4] = in ? v.x : 0.f; t[p][r][c4 + 1] = in ? v.y : 0.f; t[p][r][c4 + 2] = in ? v.z : 0.f; t[p][r][c4 + 3] = in ? v.w : 0.f;
       }
     }
   }
@@ -301,7 +305,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 #pragma unroll
         for (int p = 0; p < 2; p++)
 #pragma unroll
-          for (int u = 0; u < 2; u++) nz |= (st.v[p][u].x != 0.f) | (st.v[p][u].y != 0.f) | (st.v[p][u].z != 0.f) | (st.v[p][u].w != 0.f);
+          for (int u = 0; u < 2; u++)
+            if ((st.in >> u) & 1u) nz |= (st.v[p][u].x != 0.f) | (st.v[p][u].y != 0.f) | (st.v[p][u].z != 0.f) | (st.v[p][u].w != 0.f);
       }
     } else {
       load_tiles<2>(t, H, W, bk.bx0, bk.by0, [&](int p) { return (p == 0 ? im1 : im2) + bk.c * plane; });
@@ -463,14 +468,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HGS_SSIM_BW
       const int i = threadIdx.x + 256 * u;
       const int r = i / (TW / 4), c4 = (i - r * (TW / 4)) * 4;
       const int y = q.by0 + r - HALO, x = q.bx0 - XOFF + c4;
-      const bool in = i < ST_F4 && (unsigned)y < (unsigned)H && x >= 0 && x < W;
-      fl[u] = in ? zero_flags[q.c * per + (y / LT) * gd.nbx + x / LT] : (unsigned char)0;
+      fl[u] = zero_flags[q.c * per + (min(max(y, 0), H - 1) / LT) * gd.nbx + min(max(x, 0), W - 4) / LT];   // (unconditional, like the tile)
     }
   };
   auto apply_flags = [&]() {
 #pragma unroll
     for (int u = 0; u < 2; u++)
-      if (fl[u]) {
+      if (fl[u] && ((st.in >> u) & 1u)) {
 #pragma unroll
         for (int p = 0; p < 3; p++) st.v[p][u] = make_float4(zm[p], zm[p], zm[p], zm[p]);
       }
