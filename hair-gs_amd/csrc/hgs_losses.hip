@@ -650,23 +650,35 @@ __global__ __launch_bounds__(256) void pix_fwd_kernel(int N, HeadFlags fl, float
   }
   float s = 0.f, cnt = 0.f, b = 0.f;
   if (i < N) {
+    // Every input of the pixel is loaded first, unconditionally (the targets of the orientation term also outside the
+    // mask): the kernel is a chain of memory round trips otherwise -- logits, then the mask byte, then, behind the branch
+    // on it, angle and confidence -- at 17 resident waves per CU.
+    const bool has_mask = tgt->mask != nullptr;
+    float xm = 0.f, ym = 0.f, o0 = 0.f, o1 = 0.f, o2 = 0.f, gt = 0.f, cf = 0.f;
+    unsigned char mk = 0;
+    if (fl.bce) { xm = mask_img[i]; ym = hgs_global(tgt->float_mask)[i]; }
+    if (fl.ori) {
+      o0 = omap[i]; o1 = omap[(size_t)N + i]; o2 = omap[2 * (size_t)N + i];
+      // (without a mask the byte is read from the direction image and ignored: a load under `if (has_mask)` merged with 0
+      // is waited for where it is issued)
+      gt = hgs_global(tgt->orientation)[i]; cf = hgs_global(tgt->confidence)[i];
+      mk = (has_mask ? hgs_global(tgt->mask) : (const HGS_GLOBAL unsigned char*)hgs_global(omap))[i];   // (last: its test is first)
+    }
     float gm = 0.f, g0 = 0.f, g1 = 0.f, g2 = 0.f;
     if (fl.bce) {
-      const float x = mask_img[i], y = hgs_global(tgt->float_mask)[i];
+      const float x = xm, y = ym;
       const float en = expf(-fabsf(x));
       b = fmaxf(x, 0.f) - x * y + log1pf(en);
       if (d_unit) gm = g_mask * ((x >= 0.f ? 1.f / (1.f + en) : en / (1.f + en)) - y);   // sigmoid(x) - y
     }
     if (fl.ori) {
       OriParams p;
-      p.view = tgt->viewmatrix; p.bg0 = bg0; p.bg1 = bg1; p.bg2 = bg2; p.min_val = min_val; p.has_mask = tgt->mask != nullptr;
-      const float o0 = omap[i], o1 = omap[(size_t)N + i], o2 = omap[2 * (size_t)N + i];
-      const bool m = p.has_mask ? hgs_global(tgt->mask)[i] != 0 : (o0 != p.bg0 || o1 != p.bg1 || o2 != p.bg2);
+      p.view = tgt->viewmatrix; p.bg0 = bg0; p.bg1 = bg1; p.bg2 = bg2; p.min_val = min_val; p.has_mask = has_mask;
+      const bool m = p.has_mask ? mk != 0 : (o0 != p.bg0 || o1 != p.bg1 || o2 != p.bg2);
       if (m) {
         float px, py, r, n, x, y, yq, th;
         ori_pixel(p, o0, o1, o2, px, py, r, n, x, y, yq, th);
         const float hp = 1.57079632679489661923f;
-        const float gt = hgs_global(tgt->orientation)[i], cf = hgs_global(tgt->confidence)[i];
         s = (hp - fabsf(fabsf(th - gt) - hp)) * cf;
         cnt = 1.f;
         if (d_unit) ori_pixel_grad(p, px, py, r, n, x, yq, th, gt, cf, g_ori / tgt->mask_count, g0, g1, g2);
