@@ -236,7 +236,9 @@ struct HgsFwdArgs {
   // instance count through this device pointer (the caller's max_rendered).  Parked in status[2..3] of the image buffer.
   unsigned long long fused_scan_ptr;
 };
-#define HGS_FUSED_SCAN_MAX_P 150000  // Gaussians up to which the scatter kernel's workgroups scan the tile counts themselves
+#ifndef HGS_FUSED_SCAN_MAX_P
+#define HGS_FUSED_SCAN_MAX_P 150000  // Gaussians up to which the scatter kernel's workgroups scan the tile counts themselves (same box, end of round 2: 3320 against 3267 it/s with the separate scan kernel at 100 k; equal at 200 k)
+#endif
 #define HGS_FUSED_SCAN_MAX_T 11776   // tiles whose offsets fit the scatter kernel's LDS (47.4 KB with padding); 1080p has 8160
 int hgs_launch_preprocess_fwd(hipStream_t s, const HgsFwdArgs& a, const HgsGeom& g, const HgsImage& im, int* radii);
 int hgs_launch_scan(hipStream_t s, int P, int T, const HgsGeom& g, const HgsImage& im, unsigned int* max_rendered);
