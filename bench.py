@@ -18,7 +18,10 @@ Default workload = BASELINE.json north_star: synthetic 100k strand-Gaussians (10
 
 Timing: W untimed warm-up steps, then the region of EXACTLY K steps (barrier + synchronize on both sides, maximum over
 the ranks) is timed --repeats times back to back; `value` / `ms_per_step` are the MEDIAN region, `repeats` holds
-min / median / max.  A `sustained` leg then replays steps for >= --sustained-seconds (default 2 s) in one region, long
+min / median / max.  On one GPU the steps go out --steps-per-graph (default 8) at a time: each is a full optimizer step on
+its own random view, eight of them are captured in one HIP graph and replayed with ONE launch (GraphedStep.step_many: a
+graph launch costs ~8 us of idle GPU whatever it holds; bit-identical to single-step replays); steps that do not fill a
+launch -- and every step with several ranks -- replay the single-step graph.  A `sustained` leg then replays steps for >= --sustained-seconds (default 2 s) in one region, long
 enough for an SMI sampler to see the GPU busy, and reports its own rate.
 
 The JSON line also carries
