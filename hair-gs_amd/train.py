@@ -363,17 +363,15 @@ class GraphedStep:
             # error mode its calls would invalidate the capture; only this thread's unsafe calls must be errors
             mode = dict(capture_error_mode="thread_local")
             ga = torch.cuda.CUDAGraph(keep_graph=True) if self._prologue_in_graph else torch.cuda.CUDAGraph()
-            gb = torch.cuda.CUDAGraph()
             with torch.cuda.graph(ga, stream=s, **mode):
                 if self._prologue_in_graph:
                     self.load_camera(warmup_cams[0])
                 self.loss_buf = fwd_bwd()
                 self.vp.pack_gradients(g)       # .grad become views of the flat exchange buffer
-            with torch.cuda.graph(gb, pool=ga.pool(), stream=s, **mode):
-                if multi:
-                    self._scale_gradients()     # (the exchange in between SUMS over the ranks)
-                g.optimizer.step()
-            self._graphs = (ga, gb)
+            # What follows the all-reduce -- (the gradient scale and) ONE Adam launch -- is issued eagerly by step(): a graph
+            # of one or two kernels costs more GPU-idle time per launch (~8 us) than the launches it saves
+            # (tools/probes/graph_gap.py: 2 kernels, 16.6 us per replay against 10.0 us eager).
+            self._graphs = (ga, "eager-tail")
         if self._prologue_in_graph:
             ga.instantiate()
             self._binding = self.fused.views.graph_bind(ga)
@@ -417,10 +415,12 @@ class GraphedStep:
         ga, gb = self._graphs
         ga.replay()
         if gb is not None:
-            # the only eager work between the two graphs: one in-place all-reduce (mean over the ranks; with several views
-            # per rank a sum, scaled to the mean over the global batch in front of Adam)
+            # eager behind the graph: one in-place all-reduce (mean over the ranks; with several views per rank a sum,
+            # scaled to the mean over the global batch in front of Adam), then Adam
             self.vp.exchange(average=self.views_per_step == 1)
-            gb.replay()
+            if self.views_per_step > 1:
+                self._scale_gradients()
+            self.g.optimizer.step()
         self.g._derived = None  # cached derived tensors now hold pre-update values
         return self.loss_buf
 
