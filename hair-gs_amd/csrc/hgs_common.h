@@ -303,6 +303,11 @@ __device__ __forceinline__ bool hgs_wait_parts(const unsigned long long* mask, u
     __builtin_amdgcn_s_sleep(8);
   }
   status[HGS_ST_TIMEOUT] = 1u;
+  // capacity mode: the caller's sticky instance-count maximum (its pointer is parked in the status words) is raised to
+  // 0xFFFFFFFF, which the host's next validation cannot miss (include/hgs.h HGS_WAIT_TIMED_OUT) -- a frame blended from
+  // unfinished segments must not pass silently through any number of graph replays
+  const unsigned long long report = ((unsigned long long)status[HGS_ST_SCANPTR_HI] << 32) | status[HGS_ST_SCANPTR_LO];
+  if (report) atomicMax((unsigned int*)report, 0xFFFFFFFFu);
   return false;
 }
 // segment length of the split blend for a pass with R instances: long lists are cut so that the pass has on the order

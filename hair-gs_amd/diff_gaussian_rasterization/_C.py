@@ -61,10 +61,12 @@ def check_async():
         return []
     worst, cap = 0, _state["cap_used"]
     for t in _state["max_R"].values():
-        worst = max(worst, int(t.item()))   # .item() synchronises the stream the passes ran on
+        worst = max(worst, int(t.item()) & 0xFFFFFFFF)   # (.item() synchronises the stream the passes ran on; the word is unsigned)
         t.zero_()
     _state["dirty"] = False
     _state["cap_used"] = None
+    if worst == 0xFFFFFFFF:   # include/hgs.h HGS_WAIT_TIMED_OUT
+        raise rt.HgsError("a raster pass gave up an inter-workgroup wait (status word 8): its frame is invalid")
     _state["cap"] = max(_state["cap"], int(worst * _state["slack"]) + 4096)
     if cap is not None and worst > cap:
         raise HgsCapacityOverflow(f"a raster pass needed {worst} instances (capacity {cap}): capacity raised to {_state['cap']}, repeat the step")

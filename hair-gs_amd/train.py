@@ -445,8 +445,10 @@ class GraphedStep:
         raster = self.raster
         worst = 0
         for t in raster._state["max_R"].values():
-            worst = max(worst, int(t.item()))
+            worst = max(worst, int(t.item()) & 0xFFFFFFFF)   # (the word is unsigned)
             t.zero_()
+        if worst == 0xFFFFFFFF:   # include/hgs.h HGS_WAIT_TIMED_OUT
+            raise self.raster.rt.HgsError("a replayed raster pass gave up an inter-workgroup wait: its frame is invalid")
         return worst, self._cap
 
     def check(self):

@@ -67,6 +67,10 @@ size_t hgs_backward_scratch_bytes(int P, int R);
  * cleared the counters of image_buf on this stream (hgs_iteration_prologue over hgs_image_zero_range): the call's own
  * clearing launch is skipped. */
 #define HGS_IMAGE_PREZEROED 2
+/* Value a max_rendered word takes when a workgroup of a pass gave up waiting for another one of the same launch (bounded
+ * spins of the list-parallel sort / blend: never observed; would mean the dispatcher kept a predecessor from running).
+ * The frame of that pass is invalid. */
+#define HGS_WAIT_TIMED_OUT 0xFFFFFFFFu
 int hgs_forward_preprocess(void* stream, int P, int D, int M, int W, int H,
                            const float* means3D, const float* shs, const float* colors_precomp,
                            const float* opacities, const float* scales, float scale_modifier,

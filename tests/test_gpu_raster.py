@@ -316,6 +316,26 @@ def test_backward_is_bitwise_reproducible():
         np.testing.assert_array_equal(g1[k].view(np.uint32), g2[k].view(np.uint32), err_msg=k)
 
 
+def test_wait_timeout_word_is_not_silent():
+    """HGS_WAIT_TIMED_OUT (include/hgs.h): a pass whose workgroups gave up a bounded inter-workgroup wait raises the
+    caller's sticky maximum to 0xFFFFFFFF; the host's next validation turns that into an error, not into a capacity."""
+    import torch
+    import hgs_runtime as rt
+    from diff_gaussian_rasterization import _C as raster
+    raster.set_async(True)
+    try:
+        dev = torch.device("cuda", torch.cuda.current_device())
+        word = raster._max_rendered(dev)
+        word.fill_(-1)                      # int32 -1 == 0xFFFFFFFF, what hgs_wait_parts leaves behind
+        raster._state["dirty"] = True
+        cap_before = raster._state["cap"]
+        with pytest.raises(rt.HgsError, match="inter-workgroup wait"):
+            raster.check_async()
+        assert raster._state["cap"] == cap_before and int(word.item()) == 0
+    finally:
+        raster.set_async(False)
+
+
 def test_capacity_overflow_gives_zero_gradients_not_garbage(monkeypatch):
     """A pass whose binning capacity is too small (capacity mode) drops instances: it is flagged (status[1], the host
     raises HgsCapacityOverflow at its next check) and its backward must return EXACTLY ZERO for every gradient -- never
