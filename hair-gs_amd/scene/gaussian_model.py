@@ -194,6 +194,7 @@ class GaussianModel:
             lr_delay_mult=training_args.position_lr_delay_mult, max_steps=training_args.position_lr_max_steps)
         self.set_pval(training_args.pval)
         self.training_args = training_args
+        self._maybe_sort_spatially()
 
     def update_learning_rate(self, iteration):
         for group in self.optimizer.param_groups:
@@ -242,6 +243,37 @@ class GaussianModel:
         """opacity <- min(opacity, 0.01), Adam moments of the group zeroed (reference :414-419)."""
         new = inverse_sigmoid(torch.min(self.get_opacity, torch.ones_like(self.get_opacity) * 0.01))
         self._rebind(self.replace_tensor_to_optimizer(new, "opacity"))
+
+    def _maybe_sort_spatially(self):
+        """training_args.spatial_sort (default on) for a cloud that lives on the GPU: see sort_spatially."""
+        if getattr(getattr(self, "training_args", None), "spatial_sort", True) and self.get_xyz.is_cuda and self.get_xyz.shape[0] > 1:
+            self.sort_spatially()
+
+    def sort_spatially(self, bits=10):
+        """Re-order the Gaussians (parameters, Adam moments, statistics alike) along a Morton curve through their centres.
+        Not in the reference and invisible to it -- the order of a cloud's Gaussians is arbitrary -- but decisive for the
+        binning kernels: 256 consecutive Gaussians of an unordered cloud touch every occupied tile of the frame, so every
+        workgroup sends one atomic per tile to the same few dozen counter lines (C2: preprocess 34 us, scatter 43 us for
+        50 k Gaussians, 90 % of it waiting); along the curve a workgroup's Gaussians share a handful of tiles.  Returns
+        the permutation applied (new[i] = old[perm[i]])."""
+        xyz = self.get_xyz.detach()
+        lo, hi = xyz.min(dim=0).values, xyz.max(dim=0).values
+        q = ((xyz - lo) / (hi - lo).clamp_min(1e-20) * ((1 << bits) - 1)).to(torch.int64).clamp_(0, (1 << bits) - 1)
+        code = torch.zeros(xyz.shape[0], dtype=torch.int64, device=xyz.device)
+        for b in range(bits):
+            for a in range(3):
+                code |= ((q[:, a] >> b) & 1) << (3 * b + a)
+        perm = torch.argsort(code, stable=True)
+        if self.optimizer is not None:
+            self._rebind(self._prune_optimizer(perm))
+        else:
+            for name, attr in self._PARAM_ATTRS:
+                setattr(self, attr, nn.Parameter(getattr(self, attr).detach()[perm].requires_grad_(True)))
+        for attr in ("xyz_gradient_accum", "denom", "max_radii2D"):
+            t = getattr(self, attr, None)
+            if torch.is_tensor(t) and t.shape[0] == perm.shape[0]:
+                setattr(self, attr, t[perm])
+        return perm
 
     def prune_points(self, mask):
         keep = ~mask
@@ -301,6 +333,7 @@ class GaussianModel:
         info["prune_total"] = int(prune.sum())
         if prune.sum() != self.get_xyz.shape[0]:
             self.prune_points(prune)
+        self._maybe_sort_spatially()       # (clones and splits were appended at the end)
 
     def update_densification_stats(self, viewspace_point_tensor, radii, update_filter):
         """max screen radius + accumulated |dL/dmean2D| (pixel grad x (0.5W, 0.5H)) per visible primitive

@@ -216,6 +216,11 @@ class HairGaussianModel(HairTopologyMixin, GaussianModel):
                     ("opacity", "_opacity"), ("mask", "_mask"), ("width", "_width"))
     _POSITION_GROUP = "endpoints"
 
+    def sort_spatially(self, bits=10):
+        """Strand segments are stored strand by strand: consecutive Gaussians are neighbours already (and the parameters are
+        endpoints, not Gaussians): nothing to do."""
+        return None
+
     def __init__(self, sh_degree: int = 3, spatial_lr_scale: float = 1.0, device: str = "cuda"):
         self.active_sh_degree = 0
         self.max_sh_degree = sh_degree

@@ -99,6 +99,39 @@ def test_stage1_cloud_model_step():
     assert "smooth" not in terms
 
 
+def test_spatially_sorted_cloud_is_the_same_cloud():
+    """Stage-I cloud: training_setup() re-orders a GPU cloud along a Morton curve (GaussianModel.sort_spatially; the
+    binning kernels' atomics then meet on a handful of tile counters per workgroup instead of all of them).  The order of
+    a cloud's Gaussians carries no meaning: the render agrees to rounding (depth ties aside, blending order is the
+    depth order) and the gradients are the unsorted model's, permuted."""
+    from arguments import OptimizationParams
+    from gaussian_renderer import render
+    from synthetic import attach_targets, cameras_extent, make_cameras, make_cloud_model
+    cams = make_cameras(3, 200, 120, device="cuda")
+    bg = torch.zeros(3, device="cuda")
+    out = {}
+    for mode in ("unsorted", "sorted"):
+        torch.manual_seed(0)
+        model = make_cloud_model(3000, device="cuda", spatial_lr_scale=cameras_extent(cams))
+        opt = OptimizationParams()
+        opt.spatial_sort = mode == "sorted"
+        xyz0 = model.get_xyz.detach().clone()
+        model.training_setup(opt)
+        if mode == "sorted":
+            # which old Gaussian sits at each new position (centres are distinct)
+            same = (model.get_xyz.detach()[:, None, :] == xyz0[None, :, :]).all(dim=-1)
+            assert bool((same.sum(dim=1) == 1).all())
+            perm = same.to(torch.int8).argmax(dim=1)
+            assert sorted(perm.tolist()) == list(range(3000))
+            assert not torch.equal(perm, torch.arange(3000, device="cuda"))
+        img = render(cams[1], model, bg)["render"]
+        (img ** 2).sum().backward()
+        out[mode] = (img.detach().clone(), model._xyz.grad.clone(), model._opacity.grad.clone(), model._features_dc.grad.clone())
+    assert (out["sorted"][0] - out["unsorted"][0]).abs().max() <= 2e-6
+    for a, b in zip(out["sorted"][1:], out["unsorted"][1:]):
+        assert (a - b[perm]).abs().max() <= 1e-4 * max(float(b.abs().max()), 1e-12)
+
+
 def test_fused_strand_geometry_matches_torch_formulas():
     """hgs_strand_geometry_* vs the op-by-op getters (which restate the reference's), forward and backward."""
     from synthetic import make_strand_model

@@ -82,6 +82,39 @@ def test_densify_prune_keeps_optimizer_state_consistent():
     assert float(st["exp_avg"].abs().max()) == 0.0
 
 
+def test_sort_spatially_permutes_parameters_moments_and_statistics_alike():
+    """GaussianModel.sort_spatially (Morton order of the centres; what a GPU cloud does in training_setup and after every
+    densification): one permutation for all parameter groups, their Adam moments and the statistics; the cloud as a set is
+    unchanged, neighbours on the curve are neighbours in space, a second sort is the identity."""
+    torch.manual_seed(0)
+    m = _cloud(n=500)
+    opt = OptimizationParams()
+    m.training_setup(opt)                      # (CPU model: no automatic sort)
+    (m._xyz ** 2).sum().backward()
+    ((m._opacity ** 2).sum() + (m._features_dc ** 3).sum() + (m._scaling ** 2).sum() + (m._rotation ** 2).sum()
+     + (m._features_rest ** 2).sum() + (m._mask ** 2).sum()).backward()
+    m.optimizer.step()
+    m.xyz_gradient_accum[:] = torch.arange(500.0)[:, None]
+    m.max_radii2D[:] = torch.arange(500.0)
+    before = {g["name"]: (g["params"][0].detach().clone(), m.optimizer.state[g["params"][0]]["exp_avg"].clone(),
+                          m.optimizer.state[g["params"][0]]["exp_avg_sq"].clone()) for g in m.optimizer.param_groups}
+    perm = m.sort_spatially()
+    assert sorted(perm.tolist()) == list(range(500))
+    for g in m.optimizer.param_groups:
+        p = g["params"][0]
+        old_p, old_m, old_v = before[g["name"]]
+        assert p.requires_grad and torch.equal(p.detach(), old_p[perm])
+        st = m.optimizer.state[p]
+        assert torch.equal(st["exp_avg"], old_m[perm]) and torch.equal(st["exp_avg_sq"], old_v[perm])
+    assert torch.equal(m.xyz_gradient_accum[:, 0], perm.to(torch.float32)) and torch.equal(m.max_radii2D, perm.to(torch.float32))
+    assert m._xyz is m.optimizer.param_groups[0]["params"][0]
+    # locality: the mean distance between consecutive centres drops well below that of the unordered cloud
+    step_sorted = (m._xyz[1:] - m._xyz[:-1]).norm(dim=1).mean()
+    step_before = (before["xyz"][0][1:] - before["xyz"][0][:-1]).norm(dim=1).mean()
+    assert float(step_sorted) < 0.5 * float(step_before)
+    assert m.sort_spatially().tolist() == list(range(500))
+
+
 def _strands(S=6, V=9, seed=0):
     from synthetic import strand_polylines
     from scene.hair_gaussian_model import HairGaussianModel
