@@ -707,8 +707,10 @@ int hgs_launch_scatter(hipStream_t s, int P, int W, int H, int Rcap, const float
   const int nblk = (P + HGS_BLOCK - 1) / HGS_BLOCK;
   const int gx = (W + HGS_TILE - 1) / HGS_TILE, T = gx * ((H + HGS_TILE - 1) / HGS_TILE);
   // LDS for the fused scan's tile offsets: whether that mode is on is a device-side fact (status words written by the
-  // preprocess kernel), so the space is provided whenever the mode is possible
-  const size_t lds = T <= HGS_FUSED_SCAN_MAX_T ? (size_t)(T + T / 32 + 1) * sizeof(uint32_t) : 0;
+  // preprocess kernel), so the space is provided whenever the mode is POSSIBLE (hgs_forward_preprocess: T and P within the
+  // limits) -- and only then: 33 KB at 1080p, three resident workgroups per CU instead of thirteen, for nothing above
+  // HGS_FUSED_SCAN_MAX_P Gaussians, where the kernel is latency-bound (200 k Gaussians: 27 -> 21.7 us, 1 M: 83 -> 78)
+  const size_t lds = (T <= HGS_FUSED_SCAN_MAX_T && P <= HGS_FUSED_SCAN_MAX_P) ? (size_t)(T + T / 32 + 1) * sizeof(uint32_t) : 0;
   {
     HgsProfScope _prof(s, HGS_K_SCATTER);
     hipLaunchKernelGGL(scatter_kernel, dim3(nblk), dim3(HGS_BLOCK), lds, s, P, gx, T, (uint32_t)Rcap, features, n_extra ? extra : nullptr, g, im, b);
