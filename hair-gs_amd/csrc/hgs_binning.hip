@@ -27,12 +27,12 @@ namespace {
 
 // generic helper: scans `n` uint32 values with one 1024-thread block; calls emit(i, exclusive, value)
 template <typename F>
-__device__ __forceinline__ uint32_t block_scan(const uint32_t* in, int n, uint32_t* wtot, F emit) {
+__device__ __forceinline__ uint32_t block_scan(const uint32_t* in, int n, uint32_t* wtot, F emit, uint32_t slot_mask = 0u) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   uint32_t carry = 0;
   for (int base = 0; base < n; base += SCAN_THREADS) {
     const int i = base + tid;
-    const uint32_t v = i < n ? in[i] : 0u;
+    const uint32_t v = i < n ? in[slot_mask ? HGS_TILE_SLOT(i, slot_mask) : (uint32_t)i] : 0u;   // (slot_mask: the scattered tile counters)
     const uint32_t incl = hgs_wave_incl_scan(v, lane);
     if (lane == 63) wtot[wave] = incl;
     __syncthreads();
@@ -55,11 +55,12 @@ __device__ __forceinline__ uint32_t block_scan(const uint32_t* in, int n, uint32
 // which is what the loop above pays and what bounded this single-block kernel), then one block-wide scan of the totals.
 #define SCAN_IPT 16
 struct ScanRegs { uint32_t v[SCAN_IPT]; int ipt; };
-__device__ __forceinline__ void scan_load(const uint32_t* in, int n, ScanRegs& r) {
+__device__ __forceinline__ void scan_load(const uint32_t* in, int n, ScanRegs& r, uint32_t slot_mask = 0u) {
   r.ipt = (n + SCAN_THREADS - 1) / SCAN_THREADS;
   const int i0 = threadIdx.x * r.ipt;
 #pragma unroll
-  for (int k = 0; k < SCAN_IPT; k++) r.v[k] = (k < r.ipt && i0 + k < n) ? in[i0 + k] : 0u;
+  for (int k = 0; k < SCAN_IPT; k++)
+    r.v[k] = (k < r.ipt && i0 + k < n) ? in[slot_mask ? HGS_TILE_SLOT(i0 + k, slot_mask) : (uint32_t)(i0 + k)] : 0u;
 }
 template <typename F>
 __device__ __forceinline__ uint32_t scan_regs(ScanRegs& r, int n, uint32_t* wtot, F emit) {
@@ -100,12 +101,12 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_kernel(int nblk, int T, Hgs
   if (nblk <= SCAN_THREADS * SCAN_IPT && T <= SCAN_THREADS * SCAN_IPT) {
     ScanRegs rb, rt;
     scan_load(bs, nblk, rb);
-    scan_load(im.tile_count, T, rt);
+    scan_load(im.tile_count, T, rt, im.tile_mask);
     scan_regs(rb, nblk, wtot, emit_bs);
     R = scan_regs(rt, T, wtot, emit_rg);
   } else {
     block_scan(bs, nblk, wtot, emit_bs);
-    R = block_scan(im.tile_count, T, wtot, emit_rg);
+    R = block_scan(im.tile_count, T, wtot, emit_rg, im.tile_mask);
   }
   if (threadIdx.x == 0) {
     im.status[HGS_ST_R] = R;

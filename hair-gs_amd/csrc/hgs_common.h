@@ -38,6 +38,7 @@ struct HgsGeom {
 struct HgsImage {
   float* final_T; uint32_t* n_contrib; uint2* ranges; uint32_t* tile_count; uint32_t* tile_cursor;
   uint32_t* tile_maxc; uint32_t* status; uint32_t* tile_order;
+  uint32_t tile_mask;   // slots of tile_count / tile_cursor - 1 (hgs_tile_slot)
   // long tile lists (hgs_binning.hip / hgs_blend.hip): per-tile ticket of finished blend segments, bit masks of published
   // blend segments / sorted chunks (bit 63: the list is handled by several workgroups), chunk work items of the sort
   uint32_t* tile_done; unsigned long long* tile_prog; unsigned long long* tile_sortprog; uint32_t* sort_items;
@@ -100,7 +101,15 @@ static inline size_t hgs_geom_carve(char* base, size_t P, HgsGeom& g, size_t* of
   return hgs_align_up((size_t)(cur - base)) + HGS_ALIGN;
 }
 #define HGS_SPLIT_CAPACITY(T) ((size_t)HGS_SPLIT_PER_TILE * ((size_t)(T) > 1024 ? (size_t)(T) : (size_t)1024))   // segment work items a frame can hold
-static inline size_t hgs_image_zero_words(size_t T) { return 4 * T + HGS_STATUS_WORDS + 4 * T; }
+// The per-tile instance counters (tile_count) and segment cursors (tile_cursor) take one atomic per (workgroup, tile) of the
+// binning kernels.  A hair frame concentrates them: the tiles of the dense region are neighbours, sixteen of them share a
+// 64-byte line, and the memory side serialises the read-modify-writes of a line -- half of preprocess_fwd_kernel's time at
+// every size (11.4 -> 6.3 us at 100 k Gaussians, 68 -> 32 us at 1 M with the publish removed).  Tile t's counter therefore
+// lives in slot (t * odd constant) mod 2^k of a power-of-two table: neighbours land on different lines, the hot tiles
+// spread over all of them.
+static inline size_t hgs_tile_slots(size_t T) { size_t n = 64; while (n < T) n <<= 1; return n; }
+#define HGS_TILE_SLOT(t, mask) ((uint32_t)((uint32_t)(t) * 0x9E3779B1u) & (uint32_t)(mask))
+static inline size_t hgs_image_zero_words(size_t T) { return 2 * hgs_tile_slots(T) + 2 * T + HGS_STATUS_WORDS + 4 * T; }
 static inline size_t hgs_image_carve(char* base, size_t W, size_t H, HgsImage& im, size_t* offs) {
   char* cur = base;
   size_t N = W * H, T = ((W + HGS_TILE - 1) / HGS_TILE) * ((H + HGS_TILE - 1) / HGS_TILE);
@@ -108,9 +117,11 @@ static inline size_t hgs_image_carve(char* base, size_t W, size_t H, HgsImage& i
   hgs_carve(cur, im.n_contrib, N);          if (offs) offs[HGS_IMG_N_CONTRIB] = (char*)im.n_contrib - base;
   hgs_carve(cur, im.ranges, T);             if (offs) offs[HGS_IMG_RANGES] = (char*)im.ranges - base;
   // the next seven are zeroed together by one fill in hgs_forward_preprocess (HGS_IMG_ZERO_WORDS)
-  hgs_carve(cur, im.tile_count, T);         if (offs) offs[HGS_IMG_TILE_COUNT] = (char*)im.tile_count - base;
-  im.tile_cursor = im.tile_count + T;       if (offs) offs[HGS_IMG_TILE_CURSOR] = (char*)im.tile_cursor - base;
-  im.tile_maxc = im.tile_cursor + T;        if (offs) offs[HGS_IMG_TILE_MAXC] = (char*)im.tile_maxc - base;
+  const size_t Tp = hgs_tile_slots(T);
+  im.tile_mask = (uint32_t)(Tp - 1);
+  hgs_carve(cur, im.tile_count, T);         if (offs) offs[HGS_IMG_TILE_COUNT] = (char*)im.tile_count - base;   // (Tp slots: below)
+  im.tile_cursor = im.tile_count + Tp;      if (offs) offs[HGS_IMG_TILE_CURSOR] = (char*)im.tile_cursor - base;
+  im.tile_maxc = im.tile_cursor + Tp;       if (offs) offs[HGS_IMG_TILE_MAXC] = (char*)im.tile_maxc - base;
   im.tile_done = im.tile_maxc + T;
   im.status = im.tile_done + T;             if (offs) offs[HGS_IMG_STATUS] = (char*)im.status - base;
   im.tile_prog = (unsigned long long*)(im.status + HGS_STATUS_WORDS);   // 8-byte aligned: 4 T + 16 words past a 256-B boundary
@@ -239,7 +250,7 @@ struct HgsFwdArgs {
 #ifndef HGS_FUSED_SCAN_MAX_P
 #define HGS_FUSED_SCAN_MAX_P 150000  // Gaussians up to which the scatter kernel's workgroups scan the tile counts themselves (same box, end of round 2: 3320 against 3267 it/s with the separate scan kernel at 100 k; equal at 200 k)
 #endif
-#define HGS_FUSED_SCAN_MAX_T 11776   // tiles whose offsets fit the scatter kernel's LDS (47.4 KB with padding); 1080p has 8160
+#define HGS_FUSED_SCAN_MAX_T 8192    // tiles whose counter slots (a power of two) fit the scatter kernel's LDS (33.8 KB with padding); 1080p has 8160
 int hgs_launch_preprocess_fwd(hipStream_t s, const HgsFwdArgs& a, const HgsGeom& g, const HgsImage& im, int* radii);
 int hgs_launch_scan(hipStream_t s, int P, int T, const HgsGeom& g, const HgsImage& im, unsigned int* max_rendered);
 int hgs_launch_scatter(hipStream_t s, int P, int W, int H, int Rcap, const float* features, const float* extra, int n_extra,

@@ -264,7 +264,7 @@ __global__ __launch_bounds__(HGS_BLOCK) void preprocess_fwd_kernel(HgsFwdArgs a,
           const uint32_t t = (uint32_t)(ty * gx + tx);
           const int sl = area_kept <= TH_MAX_AREA ? th_insert(th, t) : -1;
           if (sl >= 0) atomicAdd(&th.cnt[sl], 1u);
-          else atomicAdd(&im.tile_count[t], 1u);
+          else atomicAdd(&im.tile_count[HGS_TILE_SLOT(t, im.tile_mask)], 1u);
         }
     } while (0);
     radii[idx] = my_radius_i;
@@ -278,7 +278,7 @@ __global__ __launch_bounds__(HGS_BLOCK) void preprocess_fwd_kernel(HgsFwdArgs a,
   const uint32_t bs = block_sum_256(ntiles, red);   // (its barriers also order the table updates above)
   if (threadIdx.x == 0) g.block_sums[blockIdx.x] = bs;
   for (int i = threadIdx.x; i < TH_SIZE; i += HGS_BLOCK)
-    if (th.key[i] != TH_EMPTY) atomicAdd(&im.tile_count[th.key[i]], th.cnt[i]);
+    if (th.key[i] != TH_EMPTY) atomicAdd(&im.tile_count[HGS_TILE_SLOT(th.key[i], im.tile_mask)], th.cnt[i]);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -305,11 +305,12 @@ __global__ __launch_bounds__(HGS_BLOCK) void scatter_kernel(int P, int gx, int T
   // HGS_FUSED_SCAN_MAX_T / 256 per thread), the raw block sums before this workgroup, this lane's Gaussian
   constexpr int MAX_IPT = HGS_FUSED_SCAN_MAX_T / HGS_BLOCK;
   uint32_t cnt[MAX_IPT], part = 0;
+  const int n_slots = (int)im.tile_mask + 1;       // counter slots (a power of two >= T: hgs_tile_slots)
   if (fused) {
 #pragma unroll
     for (int k = 0; k < MAX_IPT; k++) {
       const int i = k * HGS_BLOCK + (int)threadIdx.x;
-      cnt[k] = i < T ? im.tile_count[i] : 0u;
+      cnt[k] = i < n_slots ? im.tile_count[i] : 0u;   // (coalesced, in slot order)
     }
     for (int j = threadIdx.x; j < (int)blockIdx.x; j += HGS_BLOCK) part += g.block_sums[j];   // raw sums (no scan ran)
   }
@@ -330,34 +331,44 @@ __global__ __launch_bounds__(HGS_BLOCK) void scatter_kernel(int P, int gx, int T
   }
   uint32_t blk_base = 0;
   if (fused) {
-    // counts -> LDS, then every thread scans ITS run of consecutive tiles out of LDS (rows padded by one word per 32: a
-    // stride of `ipt` words would put a wavefront on one bank)
+    // counts -> LDS in slot order, then every thread gathers ITS run of consecutive tiles out of LDS into registers, scans
+    // it, and writes the run's offsets back in TILE order (rows padded by one word per 32: a stride of `ipt` words would
+    // put a wavefront on one bank)
     const int ipt = (T + HGS_BLOCK - 1) / HGS_BLOCK, i0 = (int)threadIdx.x * ipt;
     auto at = [](int i) { return i + (i >> 5); };
 #pragma unroll
     for (int k = 0; k < MAX_IPT; k++) {
       const int i = k * HGS_BLOCK + (int)threadIdx.x;
-      if (i < T) tile_off[at(i)] = cnt[k];
+      if (i < n_slots) tile_off[at(i)] = cnt[k];
     }
     __syncthreads();
     uint32_t mine = 0;
-    for (int k = 0; k < ipt; k++)
-      if (i0 + k < T) mine += tile_off[at(i0 + k)];
+#pragma unroll
+    for (int k = 0; k < MAX_IPT; k++) {
+      cnt[k] = (k < ipt && i0 + k < T) ? tile_off[at((int)HGS_TILE_SLOT(i0 + k, im.tile_mask))] : 0u;
+      mine += cnt[k];
+    }
     const uint32_t inc = hgs_wave_incl_scan(mine, lane);
     if (lane == 63) wsum[wave] = inc;
-    __syncthreads();
+    __syncthreads();                                 // (every gather above is done: the table may be overwritten)
     uint32_t run = inc - mine, total = 0;
     for (int w = 0; w < 4; w++) { if (w < wave) run += wsum[w]; total += wsum[w]; }
-    for (int k = 0; k < ipt; k++)
-      if (i0 + k < T) {
-        const uint32_t v = tile_off[at(i0 + k)];
-        tile_off[at(i0 + k)] = run;
-        if (blockIdx.x == 0) {
-          im.ranges[i0 + k] = v ? make_uint2(run, run + v) : make_uint2(0u, 0u);
-          hgs_emit_sort_items((uint32_t)(i0 + k), v, (uint32_t)T, im);   // long lists: one sort workgroup per chunk
+#pragma unroll
+    for (int k = 0; k < MAX_IPT; k++)
+      if (k < ipt && i0 + k < T) { tile_off[at(i0 + k)] = run; run += cnt[k]; }
+    if (blockIdx.x == 0) {
+      // workgroup 0 publishes the ranges and the sort kernel's chunk items: a tile's count is the difference of two
+      // offsets (a rolled loop: unrolled with the counts in registers, this rarely taken code was in every workgroup's way)
+      __syncthreads();
+      for (int k = 0; k < ipt; k++) {
+        const int t = i0 + k;
+        if (t < T) {
+          const uint32_t o = tile_off[at(t)], v = (t + 1 < T ? tile_off[at(t + 1)] : total) - o;
+          im.ranges[t] = v ? make_uint2(o, o + v) : make_uint2(0u, 0u);
+          hgs_emit_sort_items((uint32_t)t, v, (uint32_t)T, im);   // long lists: one sort workgroup per chunk
         }
-        run += v;
       }
+    }
     if (blockIdx.x == 0 && threadIdx.x == 0) {
       im.status[HGS_ST_R] = total;
       atomicMax((unsigned int*)report, total);   // sticky maximum for graph replays (hgs.h)
@@ -391,7 +402,7 @@ __global__ __launch_bounds__(HGS_BLOCK) void scatter_kernel(int P, int gx, int T
   __syncthreads();
   // one global atomic per distinct tile reserves the block's slots in that tile's segment
   for (int i = threadIdx.x; i < TH_SIZE; i += HGS_BLOCK)
-    if (th.key[i] != TH_EMPTY) { th.base[i] = atomicAdd(&im.tile_cursor[th.key[i]], th.cnt[i]); th.cnt[i] = 0u; }
+    if (th.key[i] != TH_EMPTY) { th.base[i] = atomicAdd(&im.tile_cursor[HGS_TILE_SLOT(th.key[i], im.tile_mask)], th.cnt[i]); th.cnt[i] = 0u; }
   __syncthreads();
   if (n == 0) return;
   // pass 2: place the keys (order inside a tile's segment is irrelevant: the per-tile sort key is unique)
@@ -412,7 +423,7 @@ __global__ __launch_bounds__(HGS_BLOCK) void scatter_kernel(int P, int gx, int T
       const uint64_t key = key0 | hgs_quadrant_mask(qc, xy, tx, ty);
       const int sl = small ? th_find(th, t) : -1;
       const uint32_t pos = (fused ? tile_off[t + (t >> 5)] : im.ranges[t].x) + (sl >= 0 ? th.base[sl] + atomicAdd(&th.cnt[sl], 1u)
-                                                     : atomicAdd(&im.tile_cursor[t], 1u));
+                                                     : atomicAdd(&im.tile_cursor[HGS_TILE_SLOT(t, im.tile_mask)], 1u));
       if (pos < Rcap) b.keys[pos] = key;
       else im.status[HGS_ST_OVERFLOW] = 1;  // overflow: caller under-sized the binning buffer
     }
@@ -710,7 +721,8 @@ int hgs_launch_scatter(hipStream_t s, int P, int W, int H, int Rcap, const float
   // preprocess kernel), so the space is provided whenever the mode is POSSIBLE (hgs_forward_preprocess: T and P within the
   // limits) -- and only then: 33 KB at 1080p, three resident workgroups per CU instead of thirteen, for nothing above
   // HGS_FUSED_SCAN_MAX_P Gaussians, where the kernel is latency-bound (200 k Gaussians: 27 -> 21.7 us, 1 M: 83 -> 78)
-  const size_t lds = (T <= HGS_FUSED_SCAN_MAX_T && P <= HGS_FUSED_SCAN_MAX_P) ? (size_t)(T + T / 32 + 1) * sizeof(uint32_t) : 0;
+  const size_t Tp = hgs_tile_slots((size_t)T);
+  const size_t lds = (T <= HGS_FUSED_SCAN_MAX_T && P <= HGS_FUSED_SCAN_MAX_P) ? (Tp + Tp / 32 + 1) * sizeof(uint32_t) : 0;
   {
     HgsProfScope _prof(s, HGS_K_SCATTER);
     hipLaunchKernelGGL(scatter_kernel, dim3(nblk), dim3(HGS_BLOCK), lds, s, P, gx, T, (uint32_t)Rcap, features, n_extra ? extra : nullptr, g, im, b);
