@@ -57,7 +57,7 @@ struct HgsBinning {
 // status words of the image buffer (HGS_IMG_STATUS)
 // ([4..7] are read as ONE 16-byte scalar load by every blend workgroup)
 enum { HGS_ST_R = 0, HGS_ST_OVERFLOW = 1, HGS_ST_SCANPTR_LO = 2, HGS_ST_SCANPTR_HI = 3, HGS_ST_SORT_ITEMS = 4,
-       HGS_ST_SPLIT_ITEMS = 5, HGS_ST_SEG_LEN = 6, HGS_ST_WORK_ITEMS = 7, HGS_ST_TIMEOUT = 8 };
+       HGS_ST_SPLIT_ITEMS = 5, HGS_ST_SEG_LEN = 6, HGS_ST_WORK_ITEMS = 7, HGS_ST_TIMEOUT = 8, HGS_ST_SCAN_DONE = 9 };
 #ifndef HGS_SORT_CAP
 #define HGS_SORT_CAP 512         // keys of one sort chunk = one workgroup (measured on the Stage-I workload: 2048 -> 65 us, 1024 -> 39 us, 512 -> 29 us for the sort kernel; no effect where lists are short)
 #endif
@@ -248,7 +248,7 @@ struct HgsFwdArgs {
   unsigned long long fused_scan_ptr;
 };
 #ifndef HGS_FUSED_SCAN_MAX_P
-#define HGS_FUSED_SCAN_MAX_P 150000  // Gaussians up to which the scatter kernel's workgroups scan the tile counts themselves (same box, end of round 2: 3320 against 3267 it/s with the separate scan kernel at 100 k; equal at 200 k)
+#define HGS_FUSED_SCAN_MAX_P 0x7FFFFFFF   // Gaussians up to which the scatter kernel's scan workgroup replaces the scan kernel: no limit since ONE workgroup scans (with every workgroup scanning for itself the limit was 150 k).  Same box, scan workgroup against scan kernel: +0.6 % at 200 k, +1.0 % at 500 k, +0.2 % at 1 M Gaussians (the scan LDS of every workgroup costs the big launches what the scan kernel cost)
 #endif
 #define HGS_FUSED_SCAN_MAX_T 8192    // tiles whose counter slots (a power of two) fit the scatter kernel's LDS (33.8 KB with padding); 1080p has 8160
 int hgs_launch_preprocess_fwd(hipStream_t s, const HgsFwdArgs& a, const HgsGeom& g, const HgsImage& im, int* radii);

@@ -292,48 +292,30 @@ __global__ __launch_bounds__(HGS_BLOCK) void preprocess_fwd_kernel(HgsFwdArgs a,
 // instance count and its sticky maximum.  Same integers either way.
 __global__ __launch_bounds__(HGS_BLOCK) void scatter_kernel(int P, int gx, int T, uint32_t Rcap, const float* __restrict__ feat,
                                                             const float* __restrict__ extra, HgsGeom g, HgsImage im,
-                                                            HgsBinning b) {
-  extern __shared__ uint32_t tile_off[];   // [T] in the fused-scan mode (dynamic), empty otherwise
+                                                            HgsBinning b, int scan_wg) {
+  extern __shared__ uint32_t tile_off[];   // [slots] for the scan workgroup of the fused-scan mode (dynamic), empty otherwise
   __shared__ uint32_t wsum[4];
   __shared__ TileHash th;
-  th_init(th);
-  const int idx = blockIdx.x * HGS_BLOCK + threadIdx.x;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const unsigned long long report = ((unsigned long long)im.status[HGS_ST_SCANPTR_HI] << 32) | im.status[HGS_ST_SCANPTR_LO];
   const bool fused = report != 0ull;
-  // every global load the prologue needs is issued before anything waits: tile counts (coalesced, up to
-  // HGS_FUSED_SCAN_MAX_T / 256 per thread), the raw block sums before this workgroup, this lane's Gaussian
-  constexpr int MAX_IPT = HGS_FUSED_SCAN_MAX_T / HGS_BLOCK;
-  uint32_t cnt[MAX_IPT], part = 0;
-  const int n_slots = (int)im.tile_mask + 1;       // counter slots (a power of two >= T: hgs_tile_slots)
-  if (fused) {
+  const int bid = (int)blockIdx.x - scan_wg;       // Gaussian block of this workgroup; -1: the scan workgroup
+  if (bid < 0) {
+    // ---- fused scan: ONE extra workgroup (dispatched first) scans the tile counts and publishes `ranges`, the chunk work
+    // items of long lists, the instance count and its sticky maximum, while the others load, count and reserve; they
+    // need the offsets only when they place their keys.  (Round 1 had every workgroup scan all T counts itself: 8 of a
+    // workgroup's 18 us.)
+    if (!fused) return;
+    constexpr int MAX_IPT = HGS_FUSED_SCAN_MAX_T / HGS_BLOCK;
+    uint32_t cnt[MAX_IPT];
+    const int n_slots = (int)im.tile_mask + 1;     // counter slots (a power of two >= T: hgs_tile_slots)
 #pragma unroll
     for (int k = 0; k < MAX_IPT; k++) {
       const int i = k * HGS_BLOCK + (int)threadIdx.x;
-      cnt[k] = i < n_slots ? im.tile_count[i] : 0u;   // (coalesced, in slot order)
-    }
-    for (int j = threadIdx.x; j < (int)blockIdx.x; j += HGS_BLOCK) part += g.block_sums[j];   // raw sums (no scan ran)
-  }
-  const uint32_t n = idx < P ? g.tiles_touched[idx] : 0;
-  HgsRect rc = {0, 0, 0, 0, 0, 0};
-  // this lane's Gaussian: loaded now, with everything else the prologue needs, used after the scans (for a culled
-  // Gaussian these slots hold whatever the previous pass left: never used, n == 0)
-  float2 xy = make_float2(0.f, 0.f);
-  float4 co = make_float4(0.f, 0.f, 0.f, 0.f), ex = make_float4(0.f, 0.f, 0.f, 0.f);
-  float depth = 0.f, f0 = 0.f, f1 = 0.f, f2 = 0.f;
-  if (idx < P) {
-    rc = g.rect[idx];
-    xy = g.means2D[idx];
-    co = g.conic_opacity[idx];
-    depth = g.depths[idx];
-    f0 = feat[3 * (size_t)idx]; f1 = feat[3 * (size_t)idx + 1]; f2 = feat[3 * (size_t)idx + 2];
-    if (extra) ex = ((const float4*)extra)[idx];
-  }
-  uint32_t blk_base = 0;
-  if (fused) {
-    // counts -> LDS in slot order, then every thread gathers ITS run of consecutive tiles out of LDS into registers, scans
-    // it, and writes the run's offsets back in TILE order (rows padded by one word per 32: a stride of `ipt` words would
-    // put a wavefront on one bank)
+      cnt[k] = i < n_slots ? im.tile_count[i] : 0u;   // (coalesced, in slot order: gathered from the scattered slots by
+    }                                                 //  ONE workgroup, 8192 single-line requests, the scan took 25 us)
+    // counts -> LDS in slot order, then every thread gathers ITS run of consecutive tiles out of LDS and scans it (rows
+    // padded by one word per 32: a stride of `ipt` words would put a wavefront on one bank)
     const int ipt = (T + HGS_BLOCK - 1) / HGS_BLOCK, i0 = (int)threadIdx.x * ipt;
     auto at = [](int i) { return i + (i >> 5); };
 #pragma unroll
@@ -355,32 +337,57 @@ __global__ __launch_bounds__(HGS_BLOCK) void scatter_kernel(int P, int gx, int T
     for (int w = 0; w < 4; w++) { if (w < wave) run += wsum[w]; total += wsum[w]; }
 #pragma unroll
     for (int k = 0; k < MAX_IPT; k++)
-      if (k < ipt && i0 + k < T) { tile_off[at(i0 + k)] = run; run += cnt[k]; }
-    if (blockIdx.x == 0) {
-      // workgroup 0 publishes the ranges and the sort kernel's chunk items: a tile's count is the difference of two
-      // offsets (a rolled loop: unrolled with the counts in registers, this rarely taken code was in every workgroup's way)
-      __syncthreads();
-      for (int k = 0; k < ipt; k++) {
-        const int t = i0 + k;
-        if (t < T) {
-          const uint32_t o = tile_off[at(t)], v = (t + 1 < T ? tile_off[at(t + 1)] : total) - o;
-          im.ranges[t] = v ? make_uint2(o, o + v) : make_uint2(0u, 0u);
-          hgs_emit_sort_items((uint32_t)t, v, (uint32_t)T, im);   // long lists: one sort workgroup per chunk
-        }
-      }
+      if (k < ipt && i0 + k < T) { tile_off[at(i0 + k)] = run; run += cnt[k]; }   // offsets, in TILE order
+    __syncthreads();
+    // publish: consecutive lanes take consecutive tiles (512 contiguous bytes per wave instruction; a lane per run of 32
+    // tiles made every lane's store a fabric write of its own); a tile's count is the difference of two offsets.
+    // Agent-scope stores: the other workgroups of this launch read them, from other XCDs too.
+    for (int t = threadIdx.x; t < T; t += HGS_BLOCK) {
+      const uint32_t o = tile_off[at(t)], v = (t + 1 < T ? tile_off[at(t + 1)] : total) - o;
+      hgs_st_agent((unsigned long long*)&im.ranges[t], v ? ((unsigned long long)(o + v) << 32) | o : 0ull);
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
+    hgs_drain_stores();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      hgs_st_agent(&im.status[HGS_ST_SCAN_DONE], 1u);
       im.status[HGS_ST_R] = total;
       atomicMax((unsigned int*)report, total);   // sticky maximum for graph replays (hgs.h)
     }
-    __syncthreads();                                 // wsum is reused
+    for (int t = threadIdx.x; t < T; t += HGS_BLOCK) {   // long lists: one sort workgroup per chunk (read by the NEXT kernel)
+      const uint32_t o = tile_off[at(t)], v = (t + 1 < T ? tile_off[at(t + 1)] : total) - o;
+      hgs_emit_sort_items((uint32_t)t, v, (uint32_t)T, im);
+    }
+    return;
+  }
+  th_init(th);
+  const int idx = bid * HGS_BLOCK + threadIdx.x;
+  uint32_t part = 0;
+  if (fused)
+    for (int j = threadIdx.x; j < bid; j += HGS_BLOCK) part += g.block_sums[j];   // raw sums (no scan kernel ran)
+  const uint32_t n = idx < P ? g.tiles_touched[idx] : 0;
+  HgsRect rc = {0, 0, 0, 0, 0, 0};
+  // this lane's Gaussian: loaded now, with everything else the prologue needs, used after the scans (for a culled
+  // Gaussian these slots hold whatever the previous pass left: never used, n == 0)
+  float2 xy = make_float2(0.f, 0.f);
+  float4 co = make_float4(0.f, 0.f, 0.f, 0.f), ex = make_float4(0.f, 0.f, 0.f, 0.f);
+  float depth = 0.f, f0 = 0.f, f1 = 0.f, f2 = 0.f;
+  if (idx < P) {
+    rc = g.rect[idx];
+    xy = g.means2D[idx];
+    co = g.conic_opacity[idx];
+    depth = g.depths[idx];
+    f0 = feat[3 * (size_t)idx]; f1 = feat[3 * (size_t)idx + 1]; f2 = feat[3 * (size_t)idx + 2];
+    if (extra) ex = ((const float4*)extra)[idx];
+  }
+  uint32_t blk_base = 0;
+  if (fused) {
     blk_base = block_sum_256(part, wsum);
-    __syncthreads();
+    __syncthreads();                                 // wsum is reused
   }
   const uint32_t incl = hgs_wave_incl_scan(n, lane);
   if (lane == 63) wsum[wave] = incl;
   __syncthreads();
-  uint32_t base = fused ? blk_base : g.block_sums[blockIdx.x];  // exclusive block prefix
+  uint32_t base = fused ? blk_base : g.block_sums[bid];  // exclusive block prefix
   for (int w = 0; w < wave; w++) base += wsum[w];
   if (idx < P) {
     const uint32_t off_incl = base + incl;
@@ -403,6 +410,15 @@ __global__ __launch_bounds__(HGS_BLOCK) void scatter_kernel(int P, int gx, int T
   // one global atomic per distinct tile reserves the block's slots in that tile's segment
   for (int i = threadIdx.x; i < TH_SIZE; i += HGS_BLOCK)
     if (th.key[i] != TH_EMPTY) { th.base[i] = atomicAdd(&im.tile_cursor[HGS_TILE_SLOT(th.key[i], im.tile_mask)], th.cnt[i]); th.cnt[i] = 0u; }
+  if (fused) {
+    // the offsets of the scan workgroup are needed from here on (it was dispatched first and has had this workgroup's
+    // loads, counting and reservation to finish; bounded wait: HGS_ST_TIMEOUT / HGS_WAIT_TIMED_OUT instead of a hung GPU)
+    if (threadIdx.x == 0) {
+      int spin = 0;
+      while (hgs_ld_agent(&im.status[HGS_ST_SCAN_DONE]) == 0u && ++spin < (1 << 21)) __builtin_amdgcn_s_sleep(4);
+      if (spin >= (1 << 21)) { im.status[HGS_ST_TIMEOUT] = 1u; atomicMax((unsigned int*)report, 0xFFFFFFFFu); }
+    }
+  }
   __syncthreads();
   if (n == 0) return;
   // pass 2: place the keys (order inside a tile's segment is irrelevant: the per-tile sort key is unique)
@@ -422,7 +438,7 @@ __global__ __launch_bounds__(HGS_BLOCK) void scatter_kernel(int P, int gx, int T
       const uint32_t t = (uint32_t)(ty * gx + tx);
       const uint64_t key = key0 | hgs_quadrant_mask(qc, xy, tx, ty);
       const int sl = small ? th_find(th, t) : -1;
-      const uint32_t pos = (fused ? tile_off[t + (t >> 5)] : im.ranges[t].x) + (sl >= 0 ? th.base[sl] + atomicAdd(&th.cnt[sl], 1u)
+      const uint32_t pos = (fused ? hgs_ld_agent(&im.ranges[t].x) : im.ranges[t].x) + (sl >= 0 ? th.base[sl] + atomicAdd(&th.cnt[sl], 1u)
                                                      : atomicAdd(&im.tile_cursor[HGS_TILE_SLOT(t, im.tile_mask)], 1u));
       if (pos < Rcap) b.keys[pos] = key;
       else im.status[HGS_ST_OVERFLOW] = 1;  // overflow: caller under-sized the binning buffer
@@ -717,15 +733,17 @@ int hgs_launch_scatter(hipStream_t s, int P, int W, int H, int Rcap, const float
                        const HgsGeom& g, const HgsImage& im, const HgsBinning& b) {
   const int nblk = (P + HGS_BLOCK - 1) / HGS_BLOCK;
   const int gx = (W + HGS_TILE - 1) / HGS_TILE, T = gx * ((H + HGS_TILE - 1) / HGS_TILE);
-  // LDS for the fused scan's tile offsets: whether that mode is on is a device-side fact (status words written by the
-  // preprocess kernel), so the space is provided whenever the mode is POSSIBLE (hgs_forward_preprocess: T and P within the
-  // limits) -- and only then: 33 KB at 1080p, three resident workgroups per CU instead of thirteen, for nothing above
-  // HGS_FUSED_SCAN_MAX_P Gaussians, where the kernel is latency-bound (200 k Gaussians: 27 -> 21.7 us, 1 M: 83 -> 78)
+  // Whether the fused-scan mode is on is a device-side fact (status words written by the preprocess kernel), so the scan
+  // workgroup and its LDS table are provided whenever the mode is POSSIBLE (hgs_forward_preprocess: T and P within the
+  // limits).  The table is dynamic LDS, i.e. 33 KB at 1080p for EVERY workgroup of the launch (three resident workgroups
+  // per CU instead of thirteen): for the big launches that costs about what the scan kernel did (1 M Gaussians: scatter
+  // 59 + scan 20 us against 81 us).  The scan workgroup leaves at once when a scan kernel ran (blocking mode).
   const size_t Tp = hgs_tile_slots((size_t)T);
   const size_t lds = (T <= HGS_FUSED_SCAN_MAX_T && P <= HGS_FUSED_SCAN_MAX_P) ? (Tp + Tp / 32 + 1) * sizeof(uint32_t) : 0;
   {
     HgsProfScope _prof(s, HGS_K_SCATTER);
-    hipLaunchKernelGGL(scatter_kernel, dim3(nblk), dim3(HGS_BLOCK), lds, s, P, gx, T, (uint32_t)Rcap, features, n_extra ? extra : nullptr, g, im, b);
+    const int scan_wg = lds ? 1 : 0;
+    hipLaunchKernelGGL(scatter_kernel, dim3(nblk + scan_wg), dim3(HGS_BLOCK), lds, s, P, gx, T, (uint32_t)Rcap, features, n_extra ? extra : nullptr, g, im, b, scan_wg);
   }
   HGS_CHECK_LAUNCH();
   return 0;
