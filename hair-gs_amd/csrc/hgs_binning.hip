@@ -193,7 +193,7 @@ __device__ __forceinline__ void bitonic_wave(uint64_t* sk, int m, int lane) {
 // flight together; the rare long lists only note their tile in a candidate list --, and a placing pass that each builder
 // runs over ITS share of the tiles only (the tiles of the shares before it were counted separately in the first pass).
 #ifndef WL_BUILDERS
-#define WL_BUILDERS 4
+#define WL_BUILDERS 8
 #endif
 __device__ __forceinline__ void work_list_block(int T, uint32_t Rcap, HgsSegPolicy pol, const HgsImage& im, const HgsBinning& b, uint16_t* bk, int bk_cap) {
   constexpr int SPLIT_BUCKET = 0xFFFF, CANDIDATE = 0xFFFE, MAX_CAND = 512;
