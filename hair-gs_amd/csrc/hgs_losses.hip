@@ -729,7 +729,9 @@ __global__ __launch_bounds__(256) void pix_bwd_kernel(int N, HeadFlags fl, float
 struct HeadReduce { int nb_ssim, nb_pix, nb_smooth; float inv_chw, inv_hw; float l_dssim, l_mask, l_ori, l_smooth; int bce, ori; };
 
 #define FIN_THREADS 1024
-#define HEAD_MAX_FLAGGED 32768   // SSIM blocks of a frame the backward's block lists are built for (4K RGB: 24480)
+#ifndef HEAD_MAX_FLAGGED
+#define HEAD_MAX_FLAGGED 32768   // SSIM blocks of a frame the backward's block lists are built for (4K RGB: 24480); without the lists (and the zero-block flags that come with them) the SSIM pair takes 90 instead of 77 us at north_star, the finalize kernel 5.7 instead of 8.4
+#endif
 __device__ __forceinline__ float block_sum_1024(float v, float* red16) {
 #pragma unroll
   for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
