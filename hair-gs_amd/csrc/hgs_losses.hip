@@ -624,30 +624,96 @@ __device__ __forceinline__ void ori_pixel_grad(const OriParams& p, float px, flo
 
 // d_unit != NULL: the gradient planes for an upstream gradient of 1 are written in the same pass (g_mask = l_mask/HW,
 // g_ori = l_orientation; the orientation term is normalised by tgt->mask_count, known before the pass)
+#define HEAD_MAX_FLAGGED 32768   // SSIM blocks of a frame the backward's block lists are built for (4K RGB: 24480); without the lists (and the zero-block flags that come with them) the SSIM pair takes 90 instead of 77 us at north_star
+static_assert(HEAD_MAX_FLAGGED % (32 * 256) == 0, "whole 32-block words per thread of the list builder");
+// Block lists of the SSIM backward, built by ONE workgroup of pix_fwd_kernel (the SSIM forward before that launch flagged
+// the blocks whose halo tile is exactly zero in both images): lists = [n_work, n_skip, -, -][ids of the blocks with a
+// non-zero gradient, logical order][the other ids].  A block has work unless its whole 3x3 neighbourhood is flagged: then
+// a = dS/dmu1 == 0 on its halo tile and x1 == x2 == 0 on its own pixels, its gradient is exactly zero and the backward
+// reads nothing for it.  (Round 2 built the lists in the single-workgroup finalize kernel, on the iteration's critical
+// path: 2.7 us of its 8.4.)
+__device__ __forceinline__ void build_block_lists(const SsimGrid& gd, const unsigned char* __restrict__ zero_flags,
+                                                  int* __restrict__ lists) {
+  __shared__ unsigned zbits[HEAD_MAX_FLAGGED / 32], wbits[HEAD_MAX_FLAGGED / 32];   // zero flags; has-work bits, [word][thread]
+  __shared__ int wsum[4];
+  const int total = gd.total, nwords = (total + 31) >> 5;
+  // bit b of zbits = zero flag of block b: every thread packs runs of 32 flag bytes (eight independent word loads; the
+  // bytes behind the last flag belong to the same scratch buffer and are masked off)
+  const unsigned* zf = (const unsigned*)zero_flags;   // (4-byte aligned: the flags start on a float of the scratch)
+#pragma unroll 1
+  for (int w = threadIdx.x; w < nwords; w += 256) {
+    unsigned v[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) v[u] = zf[8 * w + u];
+    unsigned bits = 0;                                 // flags are bytes 0 / 1: bit 0 of each byte of a word -> 4 adjacent bits
+#pragma unroll
+    for (int u = 0; u < 8; u++) bits |= (((v[u] & 0x01010101u) * 0x00204081u) >> 21 & 0xFu) << (4 * u);
+    const int left = total - 32 * w;
+    if (left < 32) bits &= (1u << left) - 1u;
+    zbits[w] = bits;
+  }
+  __syncthreads();
+  const int per = gd.nbx * gd.nby;
+  const int per_thread = (total + 255) / 256;          // <= HEAD_MAX_FLAGGED / 256
+  const int first = threadIdx.x * per_thread;
+  int cnt = 0;
+  int c = first / per, by = (first - c * per) / gd.nbx, bx = first - c * per - by * gd.nbx;   // block `first`; then stepped
+#pragma unroll 1
+  for (int k = 0; k < per_thread; k++) {
+    if (first + k >= total) break;
+    unsigned zero = 1u;
+#pragma unroll
+    for (int dy = -1; dy <= 1; dy++) {
+      const int row = c * per + min(max(by + dy, 0), gd.nby - 1) * gd.nbx;   // (outside the frame: zero)
+#pragma unroll
+      for (int dx = -1; dx <= 1; dx++) {
+        const int nb = row + min(max(bx + dx, 0), gd.nbx - 1);
+        zero &= zbits[nb >> 5] >> (nb & 31);
+      }
+    }
+    const unsigned has_work = (zero & 1u) ^ 1u;
+    if ((k & 31) == 0) wbits[(k >> 5) * 256 + threadIdx.x] = 0u;
+    wbits[(k >> 5) * 256 + threadIdx.x] |= has_work << (k & 31);     // (this thread's own words)
+    cnt += (int)has_work;
+    if (++bx == gd.nbx) { bx = 0; if (++by == gd.nby) { by = 0; c++; } }
+  }
+  int inc = cnt;                                       // inclusive scan over the wave, then over the 4 wave totals
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int v = __shfl_up(inc, d, 64);
+    if ((int)(threadIdx.x & 63) >= d) inc += v;
+  }
+  if ((threadIdx.x & 63) == 63) wsum[threadIdx.x >> 6] = inc;
+  __syncthreads();
+  int base = 0, all = 0;
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const int v = wsum[k];
+    if (k < (int)(threadIdx.x >> 6)) base += v;
+    all += v;
+  }
+  int w = base + inc - cnt;                            // work blocks before this thread's first block
+  int* work = lists + 4;
+  int* skipped = work + total;
+#pragma unroll 1
+  for (int k = 0; k < per_thread; k++) {
+    const int id = first + k;
+    if (id >= total) break;
+    if (wbits[(k >> 5) * 256 + threadIdx.x] >> (k & 31) & 1u) work[w++] = id;
+    else skipped[id - w] = id;
+  }
+  if (threadIdx.x == 0) { lists[0] = all; lists[1] = total - all; }
+}
+
 __global__ __launch_bounds__(256) void pix_fwd_kernel(int N, HeadFlags fl, float bg0, float bg1, float bg2, float min_val,
                                                       const float* __restrict__ mask_img, const float* __restrict__ omap,
                                                       const HgsViewTargets* __restrict__ tgt, float* __restrict__ partials,
                                                       float g_mask, float g_ori, float* __restrict__ d_unit, SsimGrid gd,
                                                       const unsigned char* __restrict__ zero_flags,
-                                                      unsigned char* __restrict__ work_flags) {
+                                                      int* __restrict__ lists) {
   __shared__ float red[4];
   const int i = blockIdx.x * 256 + threadIdx.x;
-  // In passing (the SSIM forward before this launch flagged the blocks whose halo tile is exactly zero in both images):
-  // work_flags[b] = 0 when the whole 3x3 neighbourhood of SSIM block b is flagged.  Such a block has a = dS/dmu1 == 0 on
-  // its halo tile and x1 == x2 == 0 on its own pixels, so its gradient is exactly zero and the backward reads nothing for it.
-  if (work_flags && i < gd.total) {
-    const int per = gd.nbx * gd.nby;
-    const int c = i / per, r = i - c * per, by = r / gd.nbx, bx = r - by * gd.nbx;
-    int zero = 1;
-#pragma unroll
-    for (int dy = -1; dy <= 1; dy++)
-#pragma unroll
-      for (int dx = -1; dx <= 1; dx++) {
-        const int xx = min(max(bx + dx, 0), gd.nbx - 1), yy = min(max(by + dy, 0), gd.nby - 1);   // (outside the frame: zero)
-        zero &= zero_flags[c * per + yy * gd.nbx + xx];
-      }
-    work_flags[i] = zero ? 0 : 1;
-  }
+  if (lists && blockIdx.x == 0) build_block_lists(gd, zero_flags, lists);   // (first workgroup dispatched: hidden behind the rest)
   float s = 0.f, cnt = 0.f, b = 0.f;
   if (i < N) {
     // Every input of the pixel is loaded first, unconditionally (the targets of the orientation term also outside the
@@ -729,9 +795,6 @@ __global__ __launch_bounds__(256) void pix_bwd_kernel(int N, HeadFlags fl, float
 struct HeadReduce { int nb_ssim, nb_pix, nb_smooth; float inv_chw, inv_hw; float l_dssim, l_mask, l_ori, l_smooth; int bce, ori; };
 
 #define FIN_THREADS 1024
-#ifndef HEAD_MAX_FLAGGED
-#define HEAD_MAX_FLAGGED 32768   // SSIM blocks of a frame the backward's block lists are built for (4K RGB: 24480); without the lists (and the zero-block flags that come with them) the SSIM pair takes 90 instead of 77 us at north_star, the finalize kernel 5.7 instead of 8.4
-#endif
 __device__ __forceinline__ float block_sum_1024(float v, float* red16) {
 #pragma unroll
   for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
@@ -758,54 +821,11 @@ __device__ __forceinline__ void strided_acc(const float* __restrict__ a, int n, 
 
 __global__ __launch_bounds__(FIN_THREADS) void head_finalize_kernel(HeadReduce h, const float* __restrict__ p_ssim,
                                                                     const float* __restrict__ p_pix,
-                                                                    const float* __restrict__ p_smooth, float* __restrict__ out,
-                                                                    SsimGrid gd, const unsigned char* __restrict__ work_flags,
-                                                                    int* __restrict__ lists) {
+                                                                    const float* __restrict__ p_smooth, float* __restrict__ out) {
   float a2[2], a3[3], s2[2];
   strided_acc<2>(p_ssim, h.nb_ssim, a2);
   strided_acc<3>(p_pix, h.nb_pix, a3);
   strided_acc<2>(p_smooth, h.nb_smooth, s2);
-  if (lists) {
-    // Block lists of the SSIM backward from pix_fwd_kernel's work flags:
-    // lists = [n_work, n_skip, -, -][ids of the blocks with a non-zero gradient, logical order][the other ids].
-    __shared__ int wsum[FIN_THREADS / 64];
-    const int per_thread = (gd.total + FIN_THREADS - 1) / FIN_THREADS;   // <= 32 (HEAD_MAX_FLAGGED)
-    const int first = threadIdx.x * per_thread;
-    unsigned bits = 0;
-    for (int k0 = 0; k0 < per_thread; k0 += 8) {     // (8 independent loads in flight)
-      unsigned char v[8];
-#pragma unroll
-      for (int u = 0; u < 8; u++) v[u] = (k0 + u < per_thread && first + k0 + u < gd.total) ? work_flags[first + k0 + u] : 0;
-#pragma unroll
-      for (int u = 0; u < 8; u++) bits |= (unsigned)(v[u] != 0) << (k0 + u);
-    }
-    const int cnt = __popc(bits);
-    int inc = cnt;                                  // inclusive scan over the wave, then over the 16 wave totals
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-      const int v = __shfl_up(inc, d, 64);
-      if ((int)(threadIdx.x & 63) >= d) inc += v;
-    }
-    if ((threadIdx.x & 63) == 63) wsum[threadIdx.x >> 6] = inc;
-    __syncthreads();
-    int base = 0, all = 0;
-#pragma unroll
-    for (int k = 0; k < FIN_THREADS / 64; k++) {
-      const int v = wsum[k];
-      if (k < (int)(threadIdx.x >> 6)) base += v;
-      all += v;
-    }
-    int w = base + inc - cnt;                       // work blocks before this thread's first block
-    int* work = lists + 4;
-    int* skipped = work + gd.total;
-    for (int k = 0; k < per_thread; k++) {
-      const int id = first + k;
-      if (id >= gd.total) break;
-      if (bits >> k & 1) work[w++] = id;
-      else skipped[id - w] = id;
-    }
-    if (threadIdx.x == 0) { lists[0] = all; lists[1] = gd.total - all; }
-  }
   // the seven sums together: one shuffle tree per value, ONE exchange through LDS (two barriers instead of fourteen)
   float sv[7] = {a2[0], a2[1], a3[0], a3[1], a3[2], s2[0], s2[1]};
 #pragma unroll
@@ -943,15 +963,14 @@ int hgs_orientation_loss_backward(void* stream, int H, int W, const float* omap,
 static inline int head_nb_ssim(const HgsHeadParams* p) { return ((p->W + LT - 1) / LT) * ((p->H + LT - 1) / LT) * 3; }
 static inline int head_nb_pix(const HgsHeadParams* p) { return (int)(((size_t)p->H * p->W + 255) / 256); }
 static inline int head_nb_smooth(const HgsHeadParams* p) { return p->lambda_smooth > 0.f ? (p->n_smooth + 255) / 256 : 0; }
-// scratch: [dmaps 9*H*W][ssim partials 2*nb][pix partials 3*nb][smooth partials 2*nb][all-zero flags, 1 byte per SSIM block][work flags][block lists]
+// scratch: [dmaps 9*H*W][ssim partials 2*nb][pix partials 3*nb][smooth partials 2*nb][all-zero flags, 1 byte per SSIM block][as many spare bytes: the list builder reads whole 32-byte runs][block lists]
 static inline size_t head_flags_offset(const HgsHeadParams* p) {
   return 9 * (size_t)p->H * p->W + 2 * (size_t)head_nb_ssim(p) + 3 * (size_t)head_nb_pix(p) + 2 * (size_t)head_nb_smooth(p) + 8;
 }
 static inline size_t head_flag_floats(const HgsHeadParams* p) { return ((size_t)head_nb_ssim(p) + 3) / 4 + 4; }
 static inline unsigned char* head_zero_flags(const HgsHeadParams* p, float* scratch) { return (unsigned char*)(scratch + head_flags_offset(p)); }
-static inline unsigned char* head_work_flags(const HgsHeadParams* p, float* scratch) { return (unsigned char*)(scratch + head_flags_offset(p) + head_flag_floats(p)); }
-// [n_work, n_skip, -, -][work ids][skipped ids] after the flags; NULL when the frame has more blocks than the finalize
-// kernel's LDS copy of the flags holds (the backward then walks every block)
+// [n_work, n_skip, -, -][work ids][skipped ids] after the flags; NULL when the frame has more blocks than the list
+// builder's LDS bitmap holds (the backward then walks every block)
 static inline int* head_block_lists(const HgsHeadParams* p, float* scratch) {
   if (head_nb_ssim(p) > HEAD_MAX_FLAGGED) return nullptr;
   return (int*)(scratch + head_flags_offset(p) + 2 * head_flag_floats(p));
@@ -991,7 +1010,7 @@ int hgs_loss_head_forward(void* stream, const HgsHeadParams* p, const float* ima
     hipLaunchKernelGGL(pix_fwd_kernel, dim3(nbp), dim3(256), 0, s, N, fl, p->bg[0], p->bg[1], p->bg[2], p->min_val, mask_img,
                        omap, targets, p_pix, fl.bce ? p->lambda_mask / (float)N : 0.f, fl.ori ? p->lambda_orientation : 0.f,
                        d_extra_unit, ssim_grid(3, H, W), (const unsigned char*)head_zero_flags(p, scratch),
-                       lists ? head_work_flags(p, scratch) : nullptr);
+                       lists);
   }
   if (nbm > 0 && !smooth_partials_ext &&
       hgs_launch_smooth_fwd(s, p->n_smooth, endpoints, smooth_pairs, p->cos_threshold, p->eps, p_pix + 3 * (size_t)nbp)) return 1;
@@ -1002,8 +1021,7 @@ int hgs_loss_head_forward(void* stream, const HgsHeadParams* p, const float* ima
   h.bce = fl.bce; h.ori = fl.ori;
   {
     HgsProfScope _prof(s, HGS_K_HEAD);
-    hipLaunchKernelGGL(head_finalize_kernel, dim3(1), dim3(FIN_THREADS), 0, s, h, p_ssim, p_pix, p_smooth, out, ssim_grid(3, H, W),
-                       (const unsigned char*)head_work_flags(p, scratch), lists);
+    hipLaunchKernelGGL(head_finalize_kernel, dim3(1), dim3(FIN_THREADS), 0, s, h, p_ssim, p_pix, p_smooth, out);
   }
   HGS_CHECK_LAUNCH();
   return 0;
