@@ -10,6 +10,7 @@
 //   backward: dL/dx1(q) = g_ssim * [conv(a) + 2 x1(q) conv(b) + x2(q) conv(c)] + g_l1 * sign(x1 - x2)
 // (the window is symmetric, so the adjoint of the filter is the filter itself; zero padding on both sides).
 #include "hgs_common.h"
+#include "hgs_head_tail.h"
 
 namespace {
 
@@ -624,6 +625,45 @@ __device__ __forceinline__ void ori_pixel_grad(const OriParams& p, float px, flo
 
 // d_unit != NULL: the gradient planes for an upstream gradient of 1 are written in the same pass (g_mask = l_mask/HW,
 // g_ori = l_orientation; the orientation term is normalised by tgt->mask_count, known before the pass)
+struct HeadReduce { int nb_ssim, nb_pix, nb_smooth; float inv_chw, inv_hw; float l_dssim, l_mask, l_ori, l_smooth; int bce, ori; };
+
+// The head's reduction.  Part 1 -- everything that does not depend on the per-pixel kernel's own partials -- runs in
+// workgroup 0 of pix_fwd_kernel (the SSIM forward and the smoothness forward are earlier launches); the tail (the sums
+// over the per-pixel partials, hgs_head_tail.h) needs a later launch: head_tail_kernel, or a spare workgroup of the
+// parameter backward (HgsHeadParams.defer_tail).  Round 2's single finalize launch cost 8.4 us of the iteration.
+__device__ __forceinline__ void head_part1(const HeadReduce& h, const float* __restrict__ p_ssim,
+                                           const float* __restrict__ p_smooth, float* __restrict__ out) {
+  __shared__ float red4[4][4];
+  float sv[4] = {0.f, 0.f, 0.f, 0.f};              // SSIM sum, L1 sum, smoothness sum, smoothness count
+  // (all loads of a thread are independent: in flight together)
+#pragma unroll 24
+  for (int i = threadIdx.x; i < h.nb_ssim; i += 256) { sv[0] += p_ssim[2 * (size_t)i]; sv[1] += p_ssim[2 * (size_t)i + 1]; }
+#pragma unroll 4
+  for (int i = threadIdx.x; i < h.nb_smooth; i += 256) { sv[2] += p_smooth[2 * (size_t)i]; sv[3] += p_smooth[2 * (size_t)i + 1]; }
+#pragma unroll
+  for (int q = 0; q < 4; q++)
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) sv[q] += __shfl_xor(sv[q], d, 64);
+  if ((threadIdx.x & 63) == 0)
+#pragma unroll
+    for (int q = 0; q < 4; q++) red4[q][threadIdx.x >> 6] = sv[q];
+  __syncthreads();
+  if (threadIdx.x != 0) return;
+#pragma unroll
+  for (int q = 0; q < 4; q++) sv[q] = (red4[q][0] + red4[q][1]) + (red4[q][2] + red4[q][3]);
+  const float ssim_s = sv[0], l1_s = sv[1], sm_s = sv[2], sm_c = sv[3];
+  const float l1 = l1_s * h.inv_chw, dssim = 1.f - ssim_s * h.inv_chw;
+  const float w_l1 = fmaxf(0.f, 1.f - h.l_dssim);
+  out[HGS_HEAD_TOTAL] = out[HGS_HEAD_TOTAL_FWD] = fmaf(h.l_dssim, dssim, w_l1 * l1);      // (the tail adds the other terms)
+  out[HGS_HEAD_L1] = l1; out[HGS_HEAD_DSSIM] = dssim;
+  out[HGS_HEAD_SMOOTH] = h.nb_smooth > 0 ? sm_s / fmaxf(sm_c, 1.f) : 0.f;
+  out[HGS_HEAD_SMOOTH_COUNT] = sm_c;
+  out[HGS_HEAD_G_SSIM] = -h.l_dssim; out[HGS_HEAD_G_L1] = w_l1;
+  out[HGS_HEAD_G_MASK] = h.bce ? h.l_mask * h.inv_hw : 0.f;
+  out[HGS_HEAD_G_ORI] = h.ori ? h.l_ori : 0.f;
+  out[HGS_HEAD_G_SMOOTH] = h.nb_smooth > 0 ? h.l_smooth : 0.f;
+}
+
 #define HEAD_MAX_FLAGGED 32768   // SSIM blocks of a frame the backward's block lists are built for (4K RGB: 24480); without the lists (and the zero-block flags that come with them) the SSIM pair takes 90 instead of 77 us at north_star
 static_assert(HEAD_MAX_FLAGGED % (32 * 256) == 0, "whole 32-block words per thread of the list builder");
 // Block lists of the SSIM backward, built by ONE workgroup of pix_fwd_kernel (the SSIM forward before that launch flagged
@@ -705,15 +745,26 @@ __device__ __forceinline__ void build_block_lists(const SsimGrid& gd, const unsi
   if (threadIdx.x == 0) { lists[0] = all; lists[1] = total - all; }
 }
 
+#define PIX_SIDE_WGS 2
 __global__ __launch_bounds__(256) void pix_fwd_kernel(int N, HeadFlags fl, float bg0, float bg1, float bg2, float min_val,
                                                       const float* __restrict__ mask_img, const float* __restrict__ omap,
                                                       const HgsViewTargets* __restrict__ tgt, float* __restrict__ partials,
                                                       float g_mask, float g_ori, float* __restrict__ d_unit, SsimGrid gd,
                                                       const unsigned char* __restrict__ zero_flags,
-                                                      int* __restrict__ lists) {
+                                                      int* __restrict__ lists, HeadReduce h,
+                                                      const float* __restrict__ p_ssim, const float* __restrict__ p_smooth,
+                                                      float* __restrict__ out) {
   __shared__ float red[4];
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (lists && blockIdx.x == 0) build_block_lists(gd, zero_flags, lists);   // (first workgroup dispatched: hidden behind the rest)
+  // The first two workgroups dispatched do the head's side jobs and nothing else (each is a chain of a few memory round
+  // trips, several us apiece while the rest of the launch saturates HBM: as extra work of a pixel workgroup they made
+  // that workgroup the launch's last, 20.5 -> 24 us; on their own 20.5 -> 22)
+  if (blockIdx.x < PIX_SIDE_WGS) {
+    if (blockIdx.x == 0) { if (lists) build_block_lists(gd, zero_flags, lists); }
+    else head_part1(h, p_ssim, p_smooth, out);
+    return;
+  }
+  const int blk = blockIdx.x - PIX_SIDE_WGS;
+  const int i = blk * 256 + threadIdx.x;
   float s = 0.f, cnt = 0.f, b = 0.f;
   if (i < N) {
     // Every input of the pixel is loaded first, unconditionally (the targets of the orientation term also outside the
@@ -757,7 +808,7 @@ __global__ __launch_bounds__(256) void pix_fwd_kernel(int N, HeadFlags fl, float
   const float bs = block_sum(s, red);
   const float bc = block_sum(cnt, red);
   const float bb = block_sum(b, red);
-  if (threadIdx.x == 0) { partials[3 * blockIdx.x] = bs; partials[3 * blockIdx.x + 1] = bc; partials[3 * blockIdx.x + 2] = bb; }
+  if (threadIdx.x == 0) { partials[3 * blk] = bs; partials[3 * blk + 1] = bc; partials[3 * blk + 2] = bb; }
 }
 
 __global__ __launch_bounds__(256) void pix_bwd_kernel(int N, HeadFlags fl, float bg0, float bg1, float bg2, float min_val,
@@ -792,76 +843,8 @@ __global__ __launch_bounds__(256) void pix_bwd_kernel(int N, HeadFlags fl, float
 
 // One block: fixed-order sums of the three partial arrays (bitwise reproducible), the loss terms, the total, and the
 // derivative of the total w.r.t. each term (what the backward kernels scale by).
-struct HeadReduce { int nb_ssim, nb_pix, nb_smooth; float inv_chw, inv_hw; float l_dssim, l_mask, l_ori, l_smooth; int bce, ori; };
 
-#define FIN_THREADS 1024
-__device__ __forceinline__ float block_sum_1024(float v, float* red16) {
-#pragma unroll
-  for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
-  __syncthreads();
-  if ((threadIdx.x & 63) == 0) red16[threadIdx.x >> 6] = v;
-  __syncthreads();
-  float s = 0.f;
-#pragma unroll
-  for (int k = 0; k < FIN_THREADS / 64; k++) s += red16[k];
-  return s;
-}
-// per-thread strided accumulation of an interleaved [n][NC] partial array: all loads of a thread are independent, so they
-// are in flight together (the one-column-at-a-time form of this kernel took 26 us of pure load latency)
-template <int NC>
-__device__ __forceinline__ void strided_acc(const float* __restrict__ a, int n, float* acc) {
-#pragma unroll
-  for (int c = 0; c < NC; c++) acc[c] = 0.f;
-#pragma unroll 4
-  for (int i = threadIdx.x; i < n; i += FIN_THREADS) {
-#pragma unroll
-    for (int c = 0; c < NC; c++) acc[c] += a[(size_t)i * NC + c];
-  }
-}
-
-__global__ __launch_bounds__(FIN_THREADS) void head_finalize_kernel(HeadReduce h, const float* __restrict__ p_ssim,
-                                                                    const float* __restrict__ p_pix,
-                                                                    const float* __restrict__ p_smooth, float* __restrict__ out) {
-  float a2[2], a3[3], s2[2];
-  strided_acc<2>(p_ssim, h.nb_ssim, a2);
-  strided_acc<3>(p_pix, h.nb_pix, a3);
-  strided_acc<2>(p_smooth, h.nb_smooth, s2);
-  // the seven sums together: one shuffle tree per value, ONE exchange through LDS (two barriers instead of fourteen)
-  float sv[7] = {a2[0], a2[1], a3[0], a3[1], a3[2], s2[0], s2[1]};
-#pragma unroll
-  for (int q = 0; q < 7; q++)
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) sv[q] += __shfl_xor(sv[q], d, 64);
-  __shared__ float red7[7][FIN_THREADS / 64];
-  __syncthreads();
-  if ((threadIdx.x & 63) == 0)
-#pragma unroll
-    for (int q = 0; q < 7; q++) red7[q][threadIdx.x >> 6] = sv[q];
-  __syncthreads();
-#pragma unroll
-  for (int q = 0; q < 7; q++) {
-    float t = 0.f;
-#pragma unroll
-    for (int k = 0; k < FIN_THREADS / 64; k++) t += red7[q][k];   // (same order as block_sum_1024)
-    sv[q] = t;
-  }
-  const float ssim_s = sv[0], l1_s = sv[1], ori_s = sv[2], ori_c = sv[3], bce_s = sv[4], sm_s = sv[5], sm_c = sv[6];
-  if (threadIdx.x != 0) return;
-  const float l1 = l1_s * h.inv_chw, dssim = 1.f - ssim_s * h.inv_chw;
-  const float w_l1 = fmaxf(0.f, 1.f - h.l_dssim);
-  float total = w_l1 * l1 + h.l_dssim * dssim;
-  float mask = 0.f, ori = 0.f, smooth = 0.f;
-  if (h.bce) { mask = bce_s * h.inv_hw; total += h.l_mask * mask; }
-  if (h.ori) { ori = ori_s / ori_c; total += h.l_ori * ori; }                        // empty mask -> NaN, as the reference
-  if (h.nb_smooth > 0) { smooth = sm_s / fmaxf(sm_c, 1.f); total += h.l_smooth * smooth; }
-  out[HGS_HEAD_TOTAL] = total; out[HGS_HEAD_L1] = l1; out[HGS_HEAD_DSSIM] = dssim; out[HGS_HEAD_MASK] = mask;
-  out[HGS_HEAD_ORIENTATION] = ori; out[HGS_HEAD_SMOOTH] = smooth;
-  out[HGS_HEAD_ORI_COUNT] = ori_c; out[HGS_HEAD_SMOOTH_COUNT] = sm_c;
-  out[HGS_HEAD_G_SSIM] = -h.l_dssim; out[HGS_HEAD_G_L1] = w_l1;
-  out[HGS_HEAD_G_MASK] = h.bce ? h.l_mask * h.inv_hw : 0.f;
-  out[HGS_HEAD_G_ORI] = h.ori ? h.l_ori : 0.f;
-  out[HGS_HEAD_G_SMOOTH] = h.nb_smooth > 0 ? h.l_smooth : 0.f;
-}
+__global__ __launch_bounds__(256) void head_tail_kernel(HgsHeadTail t) { hgs_head_tail_block(t); }
 
 }  // namespace
 
@@ -979,6 +962,17 @@ size_t hgs_loss_head_scratch_floats(const HgsHeadParams* p) {
   return head_flags_offset(p) + 2 * head_flag_floats(p) + 4 + 2 * (size_t)head_nb_ssim(p) + 4;
 }
 
+int hgs_loss_head_tail(const HgsHeadParams* p, const float* scratch, float* out, HgsHeadTail* tail) {
+  if (!p || !scratch || !out || !tail) { hgs_set_error("hgs_loss_head_tail: null argument"); return 1; }
+  tail->pix_partials = scratch + 9 * (size_t)p->H * p->W + 2 * (size_t)head_nb_ssim(p);
+  tail->nb_pix = head_nb_pix(p);
+  tail->out = out;
+  tail->inv_hw = 1.f / (float)((size_t)p->H * p->W);
+  tail->l_mask = p->lambda_mask; tail->l_ori = p->lambda_orientation; tail->l_smooth = p->lambda_smooth;
+  tail->bce = p->lambda_mask > 0.f; tail->ori = p->lambda_orientation > 0.f; tail->smooth = head_nb_smooth(p) > 0;
+  return 0;
+}
+
 int hgs_loss_head_forward(void* stream, const HgsHeadParams* p, const float* image, const float* mask_img,
                           const float* omap, const HgsViewTargets* targets, const float* endpoints,
                           const long long* smooth_pairs, float* scratch, float* out, float* d_extra_unit,
@@ -1005,13 +999,6 @@ int hgs_loss_head_forward(void* stream, const HgsHeadParams* p, const float* ima
   }
   HeadFlags fl;
   fl.bce = p->lambda_mask > 0.f; fl.ori = p->lambda_orientation > 0.f;   // a NULL float_mask with lambda_mask > 0 is the caller's error
-  {
-    HgsProfScope _prof(s, HGS_K_ORI_FWD);
-    hipLaunchKernelGGL(pix_fwd_kernel, dim3(nbp), dim3(256), 0, s, N, fl, p->bg[0], p->bg[1], p->bg[2], p->min_val, mask_img,
-                       omap, targets, p_pix, fl.bce ? p->lambda_mask / (float)N : 0.f, fl.ori ? p->lambda_orientation : 0.f,
-                       d_extra_unit, ssim_grid(3, H, W), (const unsigned char*)head_zero_flags(p, scratch),
-                       lists);
-  }
   if (nbm > 0 && !smooth_partials_ext &&
       hgs_launch_smooth_fwd(s, p->n_smooth, endpoints, smooth_pairs, p->cos_threshold, p->eps, p_pix + 3 * (size_t)nbp)) return 1;
   HeadReduce h;
@@ -1020,8 +1007,17 @@ int hgs_loss_head_forward(void* stream, const HgsHeadParams* p, const float* ima
   h.l_dssim = p->lambda_dssim; h.l_mask = p->lambda_mask; h.l_ori = p->lambda_orientation; h.l_smooth = p->lambda_smooth;
   h.bce = fl.bce; h.ori = fl.ori;
   {
+    HgsProfScope _prof(s, HGS_K_ORI_FWD);
+    hipLaunchKernelGGL(pix_fwd_kernel, dim3(nbp + PIX_SIDE_WGS), dim3(256), 0, s, N, fl, p->bg[0], p->bg[1], p->bg[2], p->min_val, mask_img,
+                       omap, targets, p_pix, fl.bce ? p->lambda_mask / (float)N : 0.f, fl.ori ? p->lambda_orientation : 0.f,
+                       d_extra_unit, ssim_grid(3, H, W), (const unsigned char*)head_zero_flags(p, scratch), lists, h,
+                       (const float*)p_ssim, p_smooth, out);
+  }
+  if (!p->defer_tail) {
+    HgsHeadTail t;
+    hgs_loss_head_tail(p, scratch, out, &t);
     HgsProfScope _prof(s, HGS_K_HEAD);
-    hipLaunchKernelGGL(head_finalize_kernel, dim3(1), dim3(FIN_THREADS), 0, s, h, p_ssim, p_pix, p_smooth, out);
+    hipLaunchKernelGGL(head_tail_kernel, dim3(1), dim3(256), 0, s, t);
   }
   HGS_CHECK_LAUNCH();
   return 0;
@@ -1044,6 +1040,12 @@ int hgs_loss_head_backward(void* stream, const HgsHeadParams* p, const float* im
   SsimWin win;
   for (int k = 0; k < 11; k++) win.w[k] = p->window[k];
   hipStream_t s = (hipStream_t)stream;
+  if (p->defer_tail && !skip_pixel_pass) {   // pix_bwd_kernel reads out[HGS_HEAD_ORI_COUNT]: the deferred tail cannot wait
+    HgsHeadTail t;
+    hgs_loss_head_tail(p, scratch, (float*)out, &t);
+    HgsProfScope _prof(s, HGS_K_HEAD);
+    hipLaunchKernelGGL(head_tail_kernel, dim3(1), dim3(256), 0, s, t);
+  }
   {
     HgsProfScope _prof(s, HGS_K_SSIM_BWD);
     hipLaunchKernelGGL(ssim_l1_bwd_kernel, dim3(ssim_grid_size(ssim_grid(3, H, W), SSIM_BWD_WG_PER_XCD)), dim3(256), 0, s, H, W, ssim_grid(3, H, W), win, image,

@@ -14,6 +14,7 @@
 // two-term sums commute, so the result is order-independent for chains).
 #include "hgs_common.h"
 #include "hgs_smooth.h"
+#include "hgs_head_tail.h"
 
 namespace {
 
@@ -112,6 +113,8 @@ __global__ __launch_bounds__(256) void strand_bwd_kernel(int P, const float* __r
                                                          const float* __restrict__ g_opacity, const float* __restrict__ g_extra4,
                                                          float* __restrict__ d_opacity_raw, float* __restrict__ d_mask_raw,
                                                          HgsStrandFusion fu) {
+  // (the loss head's deferred tail, include/hgs.h HgsHeadTail: one spare workgroup behind the launch's own)
+  if (fu.head_tail.out && blockIdx.x == gridDim.x - 1) { hgs_head_tail_block(fu.head_tail); return; }
   const int nb_seg = (P + 255) / 256;
   const SegGrads sg = {g_xyz, g_scale, g_quat, g_dir, g_extra4};
   const float smooth_scale = fu.n_smooth > 0
@@ -226,6 +229,7 @@ __global__ __launch_bounds__(256) void cloud_bwd_kernel(int P, const float* __re
                                                         const float* __restrict__ g_opacity, const float* __restrict__ g_extra4,
                                                         float* __restrict__ d_s, float* __restrict__ d_r,
                                                         float* __restrict__ d_o, float* __restrict__ d_m, HgsStrandFusion fu) {
+  if (fu.head_tail.out && blockIdx.x == gridDim.x - 1) { hgs_head_tail_block(fu.head_tail); return; }   // (as strand_bwd_kernel)
   const int k = blockIdx.x * 256 + threadIdx.x;
   if (k >= P) return;
   if (fu.radii) {                    // densification statistics of this Gaussian (hgs_densify_stats)
@@ -348,11 +352,12 @@ int hgs_hair_params_backward(void* stream, int P, int E, const float* endpoints,
   }
   hipStream_t s = (hipStream_t)stream;
   if (!gather && !accumulate_endpoints && hgs_zero_async(s, d_endpoints, (size_t)E * 3 * sizeof(float))) return 1;
+  if (P == 0 && fu.head_tail.out) { hgs_set_error("hgs_hair_params_backward: a deferred loss-head tail needs a launch (P > 0)"); return 1; }
   if (P == 0) return gather ? hgs_zero_async(s, d_endpoints, (size_t)E * 3 * sizeof(float)) : 0;
   {
     HgsProfScope _prof(s, HGS_K_STRAND_BWD);
     const int extra = gather ? (E + 255) / 256 : (fu.n_smooth + 255) / 256;
-    hipLaunchKernelGGL(strand_bwd_kernel, dim3((P + 255) / 256 + extra), dim3(256), 0, s, P, endpoints,
+    hipLaunchKernelGGL(strand_bwd_kernel, dim3((P + 255) / 256 + extra + (fu.head_tail.out ? 1 : 0)), dim3(256), 0, s, P, endpoints,
                        endpoint_pairs, width, dist_to_scale_factor, g_xyz, g_scale, g_quat, g_dir, d_endpoints, d_width,
                        opacity, extra4, g_opacity, g_extra4, d_opacity_raw, d_mask_raw, fu);
   }
@@ -382,6 +387,7 @@ int hgs_cloud_params_backward(void* stream, int P, const float* scaling_raw, con
                               const float* opacity, const float* extra4, const float* g_scale, const float* g_quat,
                               const float* g_opacity, const float* g_extra4, float* d_scaling_raw, float* d_rotation_raw,
                               float* d_opacity_raw, float* d_mask_raw, const HgsStrandFusion* fusion) {
+  if (P == 0 && fusion && fusion->head_tail.out) { hgs_set_error("hgs_cloud_params_backward: a deferred loss-head tail needs a launch (P > 0)"); return 1; }
   if (P == 0) return 0;
   if (!scaling_raw || !rotation_raw || !opacity || !extra4 || !g_scale || !g_quat || !g_opacity || !g_extra4 ||
       !d_scaling_raw || !d_rotation_raw || !d_opacity_raw || !d_mask_raw) {
@@ -396,7 +402,7 @@ int hgs_cloud_params_backward(void* stream, int P, const float* scaling_raw, con
   hipStream_t s = (hipStream_t)stream;
   {
     HgsProfScope _prof(s, HGS_K_STRAND_BWD);
-    hipLaunchKernelGGL(cloud_bwd_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, scaling_raw, rotation_raw, opacity, extra4,
+    hipLaunchKernelGGL(cloud_bwd_kernel, dim3((P + 255) / 256 + (fu.head_tail.out ? 1 : 0)), dim3(256), 0, s, P, scaling_raw, rotation_raw, opacity, extra4,
                        g_scale, g_quat, g_opacity, g_extra4, d_scaling_raw, d_rotation_raw, d_opacity_raw, d_mask_raw, fu);
   }
   HGS_CHECK_LAUNCH();

@@ -65,6 +65,7 @@ SIGNATURES = {
     "hgs_cloud_params_forward": (ci, [vp, ci, vp, vp, vp, vp, vp, vp, vp, vp]),
     "hgs_cloud_params_backward": (ci, [vp, ci, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "hgs_loss_head_scratch_floats": (sz, [vp]),
+    "hgs_loss_head_tail": (ci, [vp, vp, vp, vp]),
     "hgs_loss_head_forward": (ci, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "hgs_loss_head_backward": (ci, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, vp, vp, vp, vp]),
     "hgs_densify_stats": (ci, [vp, ci, vp, vp, ci, vp, vp, vp]),
@@ -102,7 +103,13 @@ class HeadParams(C.Structure):
     """include/hgs.h HgsHeadParams."""
     _fields_ = [("H", ci), ("W", ci), ("lambda_dssim", cf), ("lambda_mask", cf), ("lambda_orientation", cf),
                 ("lambda_smooth", cf), ("bg", cf * 3), ("min_val", cf), ("window", cf * 11), ("n_smooth", ci),
-                ("cos_threshold", cf), ("eps", cf), ("n_endpoints", ci)]
+                ("cos_threshold", cf), ("eps", cf), ("n_endpoints", ci), ("defer_tail", ci)]
+
+
+class HeadTail(C.Structure):
+    """include/hgs.h HgsHeadTail."""
+    _fields_ = [("pix_partials", vp), ("nb_pix", ci), ("out", vp), ("inv_hw", cf), ("l_mask", cf), ("l_ori", cf),
+                ("l_smooth", cf), ("bce", ci), ("ori", ci), ("smooth", ci)]
 
 
 class StrandFusion(C.Structure):
@@ -110,13 +117,13 @@ class StrandFusion(C.Structure):
     _fields_ = [("smooth_pairs", vp), ("n_smooth", ci), ("cos_threshold", cf), ("eps", cf), ("smooth_partials", vp),
                 ("head_out", vp), ("grad_out", vp), ("radii", vp), ("dmean2D", vp), ("dmean2D_stride", ci),
                 ("max_radii2D", vp), ("grad_accum", vp), ("denom", vp), ("ep_segments", vp), ("ep_pairs", vp),
-                ("n_endpoints", ci)]
+                ("n_endpoints", ci), ("head_tail", HeadTail)]
 
 
 HEAD_SKIP_PIXELS, HEAD_SKIP_SMOOTH = 1, 2
 VIEW_QUEUE_MAX = 16   # include/hgs.h HGS_VIEW_QUEUE_MAX
 HEAD_OUT = ["total", "l1", "dssim", "mask", "orientation", "smooth", "ori_count", "smooth_count", "g_ssim", "g_l1", "g_mask",
-            "g_ori", "g_smooth"]
+            "g_ori", "g_smooth", "total_fwd"]
 HEAD_NOUT = 16
 
 

@@ -214,6 +214,8 @@ def _raster_head_forward(step, xyz, scale, quat, opacity, extra4, shs, endpoints
     # gradient planes of the per-pixel terms for an upstream gradient of 1, written by the forward's own pass over
     # the pixels (possible when the mask count is a per-view constant, i.e. the views carry masks)
     d_extra = torch.empty((4, vt.H, vt.W), **f32) if (step.one_pass_pixels and vt.has_mask) else None
+    # the tail of the head's reduction rides in the backward's parameter launch (include/hgs.h HgsHeadTail)
+    hp.defer_tail = 1 if (step.defer_tail and xyz.shape[0] > 0) else 0
     with torch.cuda.device(dev):
         rt.check(L.hgs_loss_head_forward(rt.current_stream(), C.byref(hp), planes[0:3].data_ptr(), planes[3].data_ptr(),
                                          planes[4:7].data_ptr(), vt.slot.data_ptr(), rt.ptr(endpoints), rt.ptr(smooth_idx),
@@ -234,6 +236,7 @@ def _head_raster_backward(ctx, step, go, xyz, scale, quat, shs, planes, radii, g
     unit = ctx.d_extra is not None and unit_go
     go = step.one if go is None else go.contiguous().to(torch.float32)
     hp.n_endpoints = n_endpoints
+    hp.defer_tail = 1 if ctx.defer_tail else 0
     if unit:
         d_image, d_extra = torch.empty((3, vt.H, vt.W), **f32), ctx.d_extra
     else:
@@ -251,6 +254,12 @@ def _head_raster_backward(ctx, step, go, xyz, scale, quat, shs, planes, radii, g
         step.bg7, xyz, radii, empty, scale, quat, 1.0, empty, vt.viewmatrix, vt.projmatrix, vt.tanfovx, vt.tanfovy,
         grad_planes, shs, g.active_sh_degree, vt.campos, geom, ctx.R, binning, img, False)
     return go, (g_means2D, g_ex, g_opac, g_means3D, g_sh, g_scales, g_rot)
+
+
+def _tail_group(ctx, step, fu, scratch, out):
+    """The loss head's deferred tail, run by a spare workgroup of the backward's parameter launch."""
+    if ctx.defer_tail:
+        rt.check(rt.lib().hgs_loss_head_tail(C.byref(step.head), rt.ptr(scratch), rt.ptr(out), C.byref(fu.head_tail)))
 
 
 def _stats_group(step, fu, radii, g_means2D):
@@ -297,6 +306,7 @@ class _StrandIteration(torch.autograd.Function):
         R, planes, radii, geom, binning, img, scratch, out, d_extra = _raster_head_forward(
             step, xyz, scale, quat, opacity, extra4, shs, endpoints, idx, smooth_partials, E)
         ctx.d_extra = d_extra
+        ctx.defer_tail = bool(step.head.defer_tail)
         ctx.fused_smooth = smooth_partials is not None
         ctx.step, ctx.R, ctx.f_rest_k = step, R, f_rest.shape[1]
         ctx.set_materialize_grads(False)   # no zero tensor for the (non-differentiable) terms output
@@ -330,6 +340,7 @@ class _StrandIteration(torch.autograd.Function):
             fu.cos_threshold, fu.eps = hp.cos_threshold, hp.eps
             fu.head_out, fu.grad_out = out.data_ptr(), go.data_ptr()
         _stats_group(step, fu, radii, g_means2D)
+        _tail_group(ctx, step, fu, scratch, out)
         if gather:
             fu.ep_segments, fu.n_endpoints = step.ep_segments.data_ptr(), E
             fu.ep_pairs = None if step.ep_pairs is None else step.ep_pairs.data_ptr()
@@ -359,6 +370,9 @@ class FusedStrandStep:
         self.one = torch.ones((), dtype=torch.float32, device=dev)   # d loss / d loss, passed to backward(): no fill launch
         self.one_pass_pixels = True    # per-pixel loss terms: value and gradient in one pass over the pixels
         self.stats_in_backward = True  # densification statistics updated by the backward's last launch
+        # True: the loss terms (loss(), terms()) are complete only once backward() has run -- the head's last sums ride in
+        # the backward's parameter launch instead of a launch of their own (GraphedStep, which always runs both, sets it)
+        self.defer_tail = False
         self.last = {}
         self.refresh()
 
@@ -428,6 +442,7 @@ class _CloudIteration(torch.autograd.Function):
         R, planes, radii, geom, binning, img, scratch, out, d_extra = _raster_head_forward(
             step, xyz, scale, quat, opacity, extra4, shs, None, None, None, 0)
         ctx.d_extra, ctx.fused_smooth = d_extra, True   # (no smoothness term for a cloud: nothing to launch)
+        ctx.defer_tail = bool(step.head.defer_tail)
         ctx.step, ctx.R, ctx.f_rest_k = step, R, f_rest.shape[1]
         ctx.set_materialize_grads(False)
         ctx.save_for_backward(xyz, scaling_raw, rotation_raw, scale, quat, opacity, extra4, shs, planes, radii, geom, binning,
@@ -450,6 +465,7 @@ class _CloudIteration(torch.autograd.Function):
         d_o, d_m = torch.empty((P, 1), **f32), torch.empty((P, 1), **f32)
         fu = rt.StrandFusion()
         _stats_group(step, fu, radii, g_means2D)
+        _tail_group(ctx, step, fu, scratch, out)
         with torch.cuda.device(dev):
             rt.check(L.hgs_cloud_params_backward(rt.current_stream(), P, rt.ptr(scaling_raw), rt.ptr(rotation_raw),
                                                  rt.ptr(opacity), rt.ptr(extra4), rt.ptr(g_scales), rt.ptr(g_rot),

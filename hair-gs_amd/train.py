@@ -209,6 +209,8 @@ class GraphedStep:
             # device-resident view table: a view switch is one tiny launch, not eight tensor copies
             from hgs_runtime.strand_step import ViewTable, fused_step_for
             self.fused = fused_step_for(gaussians, views if views is not None else ViewTable(cameras), opt, bg)
+            # forward and backward always run together here: no launch of its own for the loss head's last sums
+            self.fused.defer_tail = bool(getattr(opt, "defer_head_tail", True))
         c0 = cameras[0]
         for c in cameras:  # by-value kernel arguments are frozen into the graph
             assert (c.image_width, c.image_height, c.FoVx, c.FoVy) == (c0.image_width, c0.image_height, c0.FoVx, c0.FoVy)

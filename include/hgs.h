@@ -247,6 +247,22 @@ int hgs_set_view_queue(void* stream, int* queue, int n, const int* views_host, f
 int hgs_select_view_queued(void* stream, const HgsViewTargets* table, int n_views, const int* view_index,
                            HgsViewTargets* slot, const float* lr_slot, float* lr_dst);
 
+/* The tail of the loss head's reduction (hgs_loss_head_forward, below): the sums over the per-pixel kernel's partials
+ *   and what depends on them --
+ *   out[HGS_HEAD_MASK], out[HGS_HEAD_ORIENTATION], out[HGS_HEAD_ORI_COUNT] and the last three terms of out[HGS_HEAD_TOTAL]
+ *   (every other entry of `out`, and total's first two terms, are written by the forward's own kernels).  The forward runs
+ *   it as a one-workgroup launch of its own -- 5.7 us on the iteration's critical path -- unless HgsHeadParams.defer_tail is
+ *   set: then `out` is complete only once a later launch has run the tail in a spare workgroup: hgs_hair_params_backward /
+ *   hgs_cloud_params_backward do when HgsStrandFusion.head_tail is filled in (hgs_loss_head_tail), and
+ *   hgs_loss_head_backward runs it first itself when its per-pixel pass needs out[HGS_HEAD_ORI_COUNT] (no
+ *   HGS_HEAD_SKIP_PIXELS).  Same arithmetic either way: the values do not depend on who runs the tail. */
+typedef struct HgsHeadTail {
+  const float* pix_partials; int nb_pix;   /* [nb_pix][3]: orientation sum, orientation count, mask BCE sum */
+  float* out;                              /* NULL: none */
+  float inv_hw, l_mask, l_ori, l_smooth;
+  int bce, ori, smooth;
+} HgsHeadTail;
+
 /* hgs_hair_params_forward/backward: hgs_strand_geometry_* plus the appearance activations of the same Gaussians
  *   (scene/gaussian_model.py:93-99 get_opacity / get_mask = sigmoid) and the 4 extra blended channels of the
  *   single-pass rasterizer, extra4 = [sigmoid(mask_raw), dir.xyz].  backward: g_extra4 [P,4] carries the gradient of
@@ -268,6 +284,7 @@ typedef struct HgsStrandFusion {
    * d_endpoints is written with ONE plain store per endpoint (one extra workgroup range recomputes the adjacent segments'
    * and pairs' contributions): no float atomics, bitwise reproducible, and accumulate_endpoints is ignored. */
   const int* ep_segments; const int* ep_pairs; int n_endpoints;
+  HgsHeadTail head_tail;   /* backward: out != NULL -> one spare workgroup of the launch runs the loss head's deferred tail */
 } HgsStrandFusion;
 int hgs_hair_params_forward(void* stream, int P, const float* endpoints, const long long* endpoint_pairs,
                             const float* width, float dist_to_scale_factor, const float* opacity_raw,
@@ -318,11 +335,15 @@ typedef struct HgsHeadParams {
   int n_smooth;                 /* rows of the smoothness index table */
   float cos_threshold, eps;     /* loss/losses.py:175: threshold 30 deg, eps 1e-6 */
   int n_endpoints;
+  int defer_tail;               /* != 0: the forward leaves the sums over the per-pixel partials (see HgsHeadTail) to the caller */
 } HgsHeadParams;
 enum { HGS_HEAD_TOTAL = 0, HGS_HEAD_L1, HGS_HEAD_DSSIM, HGS_HEAD_MASK, HGS_HEAD_ORIENTATION, HGS_HEAD_SMOOTH,
        HGS_HEAD_ORI_COUNT, HGS_HEAD_SMOOTH_COUNT, HGS_HEAD_G_SSIM, HGS_HEAD_G_L1, HGS_HEAD_G_MASK, HGS_HEAD_G_ORI,
-       HGS_HEAD_G_SMOOTH, HGS_HEAD_NOUT = 16 };
+       HGS_HEAD_G_SMOOTH, HGS_HEAD_TOTAL_FWD, HGS_HEAD_NOUT = 16 };
+/* (HGS_HEAD_TOTAL_FWD: total's first two terms -- what the tail, HgsHeadTail, starts from) */
 size_t hgs_loss_head_scratch_floats(const HgsHeadParams* p);
+/* fills `tail` for the forward that used (p, scratch, out) */
+int hgs_loss_head_tail(const HgsHeadParams* p, const float* scratch, float* out, HgsHeadTail* tail);
 int hgs_loss_head_forward(void* stream, const HgsHeadParams* p, const float* image, const float* mask_img,
                           const float* omap, const HgsViewTargets* targets, const float* endpoints,
                           const long long* smooth_pairs, float* scratch, float* out, float* d_extra_unit,

@@ -335,6 +335,62 @@ def test_iteration_prologue_equals_select_then_forward():
     assert off.value % 4 == 0 and 0 < nbytes.value <= rt.lib().hgs_image_bytes(64, 48) - off.value
 
 
+def test_deferred_head_tail_gives_the_same_terms_and_gradients():
+    """HgsHeadParams.defer_tail: the head's last sums ride in a spare workgroup of the backward's parameter launch instead
+    of a launch of their own.  Every loss term, the planes and the gradients are bit-identical to the undeferred iteration --
+    strand model and Stage-I cloud, unit and non-unit upstream gradient (the latter runs the tail before its per-pixel
+    pass); before the backward the deferred terms are NOT complete (that is the contract)."""
+    from arguments import OptimizationParams
+    from hgs_runtime.strand_step import fused_step_for
+    from synthetic import attach_targets, build_workload, cameras_extent, make_cameras, make_cloud_model
+    from utils.general import safe_state
+    safe_state(True)
+    for kind in ("strands", "cloud"):
+        if kind == "strands":
+            model, cams, extent = build_workload("tiny", device="cuda", with_targets=True)
+        else:
+            cams = make_cameras(3, 200, 120, device="cuda")
+            model = make_cloud_model(3000, device="cuda", spatial_lr_scale=cameras_extent(cams))
+            attach_targets(cams, model)
+        opt = OptimizationParams()
+        opt.enable_topology = False
+        model.training_setup(opt)
+        bg = torch.zeros(3, device="cuda")
+        fused = fused_step_for(model, cams, opt, bg)
+        params = [g["params"][0] for g in model.optimizer.param_groups if g["params"][0].numel() > 0]
+        for scale in (None, 0.5):
+            ref = None
+            for defer in (False, True, True):
+                for p in params:
+                    p.grad = None
+                model._derived = None
+                fused.defer_tail = defer
+                fused.views.prologue(1)
+                loss, terms = fused.loss()
+                if scale is None:
+                    fused.backward(loss)
+                else:
+                    (loss * scale).backward()
+                torch.cuda.synchronize()
+                cur = [terms[:14].clone(), fused.last["planes"].clone()] + [p.grad.clone() for p in params]   # (14 entries used)
+                assert torch.isfinite(cur[0]).all() and float(cur[0][0]) > 0
+                if ref is None:
+                    ref = cur
+                else:
+                    for a, b in zip(ref, cur):
+                        assert torch.equal(a, b)
+        # the contract: with defer_tail the total is complete only after the backward
+        fused.defer_tail = True
+        model._derived = None
+        fused.views.prologue(0)
+        loss, terms = fused.loss()
+        early = terms.clone()
+        fused.backward(loss)
+        torch.cuda.synchronize()
+        assert float(early[0]) < float(terms[0])       # (the per-pixel terms were still missing from the total)
+        assert torch.equal(early[1:3], terms[1:3])     # L1 and DSSIM are the forward's own
+
+
 def test_several_steps_per_graph_equal_single_step_replays():
     """GraphedStep(steps_per_graph=4).step_many == four step() replays, bit for bit (same kernels, same order); the two
     graphs of one GraphedStep can be mixed (8 steps as 4 + 1 + 1 + ... )."""
