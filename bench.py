@@ -73,6 +73,8 @@ def parse():
     ap.add_argument("--op-by-op", action="store_true", help="the iteration as the reference structures it (getters, render, loss_function as separate autograd ops) instead of the fused strand iteration")
     ap.add_argument("--head-tail-launch", action="store_true",
                     help="A/B: the loss head's last sums as a launch of their own instead of a spare workgroup of the backward's parameter launch")
+    ap.add_argument("--prologue-launch", action="store_true",
+                    help="A/B: the iteration prologue (view select + counter clearing) as a launch of its own instead of a rider of the parameter forward launch")
     ap.add_argument("--eager", action="store_true", help="eager dispatch of every kernel instead of replaying the captured HIP graph")
     ap.add_argument("--blocking", action="store_true",
                     help="reference-style forward (host reads num_rendered in every pass) instead of the async capacity mode")
@@ -191,6 +193,7 @@ def main():
     opt.single_pass = not args.three_pass
     opt.fused_step = not args.op_by_op
     opt.defer_head_tail = not args.head_tail_launch
+    opt.ride_prologue = not args.prologue_launch
     opt.enable_topology = False  # densify/merge intervals (every 100 it) are reported separately, not in the timed loop
     model.training_setup(opt)
     bg = torch.zeros(3, dtype=torch.float32, device=dev)

@@ -4,6 +4,7 @@
 #include <string.h>
 
 #include "hgs_common.h"
+#include "hgs_prologue.h"
 
 static thread_local char g_err[512] = "";
 
@@ -68,19 +69,7 @@ int hgs_zero_async(hipStream_t s, void* ptr, size_t bytes) {
 // zero_words words at zero_ptr (the counters of the image buffer the coming forward pass bins into, include/hgs.h
 // HGS_IMAGE_PREZEROED).  view / lr are by-value arguments: a captured graph is re-pointed at another view by updating this
 // node's parameters (hgs_graph_set_prologue), with no launch in between two replays.
-__global__ __launch_bounds__(256) void select_view_kernel(const HgsViewTargets* __restrict__ table, int view,
-                                                          HgsViewTargets* __restrict__ slot, float lr, float* __restrict__ lr_dst,
-                                                          uint32_t* __restrict__ zero_ptr, unsigned long long zero_words) {
-  if (blockIdx.x == 0) {
-    const uint32_t* src = (const uint32_t*)(table + view);
-    uint32_t* dst = (uint32_t*)slot;
-    for (int i = threadIdx.x; i < (int)(sizeof(HgsViewTargets) / 4); i += 256) dst[i] = src[i];
-    if (threadIdx.x == 0 && lr_dst) *lr_dst = lr;
-    return;
-  }
-  const size_t stride = (size_t)(gridDim.x - 1) * 256;
-  for (size_t i = (size_t)(blockIdx.x - 1) * 256 + threadIdx.x; i < zero_words; i += stride) zero_ptr[i] = 0u;
-}
+__global__ __launch_bounds__(256) void select_view_kernel(HgsPrologue p) { hgs_prologue_block(p, blockIdx.x, gridDim.x); }
 
 struct HgsViewQueueArgs { int v[HGS_VIEW_QUEUE_MAX]; };
 __global__ void set_view_queue_kernel(int* __restrict__ queue, int n, HgsViewQueueArgs a, float lr, float* __restrict__ lr_slot) {
@@ -399,19 +388,15 @@ size_t hgs_view_targets_bytes(void) { return sizeof(HgsViewTargets); }
 size_t hgs_head_params_bytes(void) { return sizeof(HgsHeadParams); }
 size_t hgs_strand_fusion_bytes(void) { return sizeof(HgsStrandFusion); }
 
-static inline unsigned prologue_blocks(size_t zero_words) {
-  const size_t b = (zero_words + 1023) / 1024;           // 4 words per thread
-  return 1u + (unsigned)(b < 1024 ? b : 1024);
-}
 int hgs_iteration_prologue(void* stream, const HgsViewTargets* table, int view, HgsViewTargets* slot, float lr, float* lr_dst,
                            void* zero_ptr, size_t zero_bytes) {
   if (!table || !slot || view < 0) { hgs_set_error("hgs_iteration_prologue: bad arguments"); return 1; }
   if (((size_t)zero_ptr & 3) || (zero_bytes & 3) || (zero_bytes && !zero_ptr)) { hgs_set_error("hgs_iteration_prologue: zero range must be 4-byte multiples"); return 1; }
   hipStream_t s = (hipStream_t)stream;
+  const HgsPrologue p = {table, view, slot, lr, lr_dst, zero_ptr, zero_bytes};
   {
     HgsProfScope _prof(s, HGS_K_MISC);
-    hipLaunchKernelGGL(select_view_kernel, dim3(prologue_blocks(zero_bytes / 4)), dim3(256), 0, s, table, view, slot, lr, lr_dst,
-                       (uint32_t*)zero_ptr, (unsigned long long)(zero_bytes / 4));
+    hipLaunchKernelGGL(select_view_kernel, dim3(hgs_prologue_blocks(zero_bytes / 4)), dim3(256), 0, s, p);
   }
   HGS_CHECK_LAUNCH();
   return 0;
@@ -434,10 +419,14 @@ int hgs_graph_find_prologues(void* graph, int max_nodes, void** nodes_out, float
     if (t != hipGraphNodeTypeKernel) continue;
     hipKernelNodeParams kp;
     HGS_CHECK_HIP(hipGraphKernelNodeGetParams(nodes[i], &kp));
-    if (kp.func != (void*)select_view_kernel) continue;
+    int n_params = 1;                                      // the prologue is the LAST argument of all three kernels
+    if (kp.func != (void*)select_view_kernel && !hgs_strands_prologue_kernel(kp.func, &n_params)) continue;
+    if (!kp.kernelParams) continue;
+    const HgsPrologue* pro = (const HgsPrologue*)kp.kernelParams[n_params - 1];
+    if (!pro->table) continue;                             // (a parameter launch without a rider)
     if (count < max_nodes) {
       nodes_out[count] = (void*)nodes[i];
-      if (lr_out) lr_out[count] = kp.kernelParams ? *(const float*)kp.kernelParams[3] : 0.f;   // (argument 3: lr)
+      if (lr_out) lr_out[count] = pro->lr;
     }
     count++;
   }
@@ -455,14 +444,22 @@ int hgs_graph_find_prologue(void* graph, void** node_out) {
 int hgs_graph_set_prologue(void* graph_exec, void* node, const HgsViewTargets* table, int view, HgsViewTargets* slot, float lr,
                            float* lr_dst, void* zero_ptr, size_t zero_bytes) {
   if (!graph_exec || !node || !table || !slot || view < 0) { hgs_set_error("hgs_graph_set_prologue: bad arguments"); return 1; }
-  uint32_t* zp = (uint32_t*)zero_ptr;
-  unsigned long long zw = zero_bytes / 4;
-  void* args[7] = {&table, &view, &slot, &lr, &lr_dst, &zp, &zw};
-  hipKernelNodeParams kp = {};
-  kp.func = (void*)select_view_kernel;
-  kp.gridDim = dim3(prologue_blocks(zw));
-  kp.blockDim = dim3(256);
-  kp.sharedMemBytes = 0;
+  // the node's own launch (kernel, grid, every other argument) with a new prologue as its last argument
+  hipKernelNodeParams kp;
+  HGS_CHECK_HIP(hipGraphKernelNodeGetParams((hipGraphNode_t)node, &kp));
+  int n_params = 1;
+  if (kp.func != (void*)select_view_kernel && !hgs_strands_prologue_kernel(kp.func, &n_params)) {
+    hgs_set_error("hgs_graph_set_prologue: not a prologue node");
+    return 1;
+  }
+  if (((const HgsPrologue*)kp.kernelParams[n_params - 1])->zero_bytes != zero_bytes) {   // (the grid depends on it)
+    hgs_set_error("hgs_graph_set_prologue: the zero range differs from the captured one");
+    return 1;
+  }
+  HgsPrologue p = {table, view, slot, lr, lr_dst, zero_ptr, zero_bytes};
+  void* args[32];
+  for (int i = 0; i < n_params - 1; i++) args[i] = kp.kernelParams[i];
+  args[n_params - 1] = &p;
   kp.kernelParams = args;
   kp.extra = nullptr;
   HGS_CHECK_HIP(hipGraphExecKernelNodeSetParams((hipGraphExec_t)graph_exec, (hipGraphNode_t)node, &kp));

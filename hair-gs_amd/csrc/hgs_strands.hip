@@ -15,6 +15,7 @@
 #include "hgs_common.h"
 #include "hgs_smooth.h"
 #include "hgs_head_tail.h"
+#include "hgs_prologue.h"
 
 namespace {
 
@@ -25,7 +26,10 @@ __global__ __launch_bounds__(256) void strand_fwd_kernel(int P, const float* __r
                                                          float* __restrict__ scale, float* __restrict__ quat,
                                                          float* __restrict__ dir, const float* __restrict__ opacity_raw,
                                                          const float* __restrict__ mask_raw, float* __restrict__ opacity,
-                                                         float* __restrict__ extra4, HgsStrandFusion fu) {
+                                                         float* __restrict__ extra4, HgsStrandFusion fu, HgsPrologue pro) {
+  // (the iteration prologue as a rider, include/hgs.h HgsPrologue: the launch's last workgroups; `pro` stays the LAST argument)
+  const unsigned npro = pro.table ? hgs_prologue_blocks(pro.zero_bytes / 4) : 0u;
+  if (blockIdx.x >= gridDim.x - npro) { hgs_prologue_block(pro, blockIdx.x - (gridDim.x - npro), npro); return; }
   const int nb_seg = (P + 255) / 256;
   if ((int)blockIdx.x >= nb_seg) {   // extra workgroups: smoothness partial sums over the same endpoints
     __shared__ float red[4];
@@ -207,7 +211,9 @@ __device__ __forceinline__ void rot_column(int ax, float w, float x, float y, fl
 __global__ __launch_bounds__(256) void cloud_fwd_kernel(int P, const float* __restrict__ s_raw, const float* __restrict__ r_raw,
                                                         const float* __restrict__ o_raw, const float* __restrict__ m_raw,
                                                         float* __restrict__ scale, float* __restrict__ quat,
-                                                        float* __restrict__ opacity, float* __restrict__ extra4) {
+                                                        float* __restrict__ opacity, float* __restrict__ extra4, HgsPrologue pro) {
+  const unsigned npro = pro.table ? hgs_prologue_blocks(pro.zero_bytes / 4) : 0u;      // (as strand_fwd_kernel)
+  if (blockIdx.x >= gridDim.x - npro) { hgs_prologue_block(pro, blockIdx.x - (gridDim.x - npro), npro); return; }
   const int k = blockIdx.x * 256 + threadIdx.x;
   if (k >= P) return;
   const float s0 = expf(s_raw[3 * (size_t)k]), s1 = expf(s_raw[3 * (size_t)k + 1]), s2 = expf(s_raw[3 * (size_t)k + 2]);
@@ -271,6 +277,24 @@ __global__ __launch_bounds__(256) void cloud_bwd_kernel(int P, const float* __re
 
 }  // namespace
 
+// ---- the iteration prologue as a rider of the forward launches (include/hgs.h HgsPrologue) ------------------------------
+bool hgs_strands_prologue_kernel(const void* func, int* n_params) {
+  if (func == (const void*)strand_fwd_kernel) { *n_params = 15; return true; }
+  if (func == (const void*)cloud_fwd_kernel) { *n_params = 10; return true; }
+  return false;
+}
+static inline unsigned rider_blocks(const HgsPrologue& p) { return p.table ? hgs_prologue_blocks(p.zero_bytes / 4) : 0u; }
+// validates the rider; with nothing to ride on (P == 0) it is launched on its own
+static int prologue_rider(void* stream, int P, const HgsPrologue& p, const char* who) {
+  if (!p.table) return 0;
+  if (!p.slot || p.view < 0 || ((size_t)p.zero_ptr & 3) || (p.zero_bytes & 3) || (p.zero_bytes && !p.zero_ptr)) {
+    hgs_set_error("%s: bad prologue group", who);
+    return 1;
+  }
+  if (P == 0) return hgs_iteration_prologue(stream, p.table, p.view, p.slot, p.lr, p.lr_dst, p.zero_ptr, p.zero_bytes);
+  return 0;
+}
+
 extern "C" {
 
 int hgs_strand_geometry_forward(void* stream, int P, const float* endpoints, const long long* endpoint_pairs,
@@ -283,7 +307,7 @@ int hgs_strand_geometry_forward(void* stream, int P, const float* endpoints, con
     HgsProfScope _prof(s, HGS_K_STRAND_FWD);
     hipLaunchKernelGGL(strand_fwd_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, endpoints, endpoint_pairs, width,
                        dist_to_scale_factor, xyz, scale, quat, dir, (const float*)nullptr, (const float*)nullptr,
-                       (float*)nullptr, (float*)nullptr, HgsStrandFusion{});
+                       (float*)nullptr, (float*)nullptr, HgsStrandFusion{}, HgsPrologue{});
   }
   HGS_CHECK_LAUNCH();
   return 0;
@@ -311,8 +335,9 @@ int hgs_hair_params_forward(void* stream, int P, const float* endpoints, const l
                             const float* width, float dist_to_scale_factor, const float* opacity_raw,
                             const float* mask_raw, float* xyz, float* scale, float* quat, float* dir, float* opacity,
                             float* extra4, const HgsStrandFusion* fusion) {
-  if (P == 0) return 0;
   HgsStrandFusion fu = fusion ? *fusion : HgsStrandFusion{};
+  if (prologue_rider(stream, P, fu.prologue, "hgs_hair_params_forward")) return 1;
+  if (P == 0) return 0;
   const bool smooth = fu.smooth_pairs && fu.n_smooth > 0 && fu.smooth_partials;
   if (!smooth) fu.n_smooth = 0;
   if (!endpoints || !endpoint_pairs || !width || !opacity_raw || !mask_raw || !xyz || !scale || !quat || !opacity || !extra4) {
@@ -322,9 +347,11 @@ int hgs_hair_params_forward(void* stream, int P, const float* endpoints, const l
   hipStream_t s = (hipStream_t)stream;
   {
     HgsProfScope _prof(s, HGS_K_STRAND_FWD);
-    hipLaunchKernelGGL(strand_fwd_kernel, dim3((P + 255) / 256 + (fu.n_smooth + 255) / 256), dim3(256), 0, s, P, endpoints,
-                       endpoint_pairs, width, dist_to_scale_factor, xyz, scale, quat, dir, opacity_raw, mask_raw, opacity,
-                       extra4, fu);
+    const HgsPrologue pro = fu.prologue;
+    fu.prologue = HgsPrologue{};     // (handed over as the kernel's last argument, where the graph functions find it)
+    hipLaunchKernelGGL(strand_fwd_kernel, dim3((P + 255) / 256 + (fu.n_smooth + 255) / 256 + rider_blocks(pro)), dim3(256), 0, s, P,
+                       endpoints, endpoint_pairs, width, dist_to_scale_factor, xyz, scale, quat, dir, opacity_raw, mask_raw,
+                       opacity, extra4, fu, pro);
   }
   HGS_CHECK_LAUNCH();
   return 0;
@@ -367,7 +394,9 @@ int hgs_hair_params_backward(void* stream, int P, int E, const float* endpoints,
 
 int hgs_cloud_params_forward(void* stream, int P, const float* scaling_raw, const float* rotation_raw,
                              const float* opacity_raw, const float* mask_raw, float* scale, float* quat, float* opacity,
-                             float* extra4) {
+                             float* extra4, const HgsStrandFusion* fusion) {
+  const HgsPrologue pro = fusion ? fusion->prologue : HgsPrologue{};
+  if (prologue_rider(stream, P, pro, "hgs_cloud_params_forward")) return 1;
   if (P == 0) return 0;
   if (!scaling_raw || !rotation_raw || !opacity_raw || !mask_raw || !scale || !quat || !opacity || !extra4) {
     hgs_set_error("hgs_cloud_params_forward: null argument");
@@ -376,8 +405,8 @@ int hgs_cloud_params_forward(void* stream, int P, const float* scaling_raw, cons
   hipStream_t s = (hipStream_t)stream;
   {
     HgsProfScope _prof(s, HGS_K_STRAND_FWD);
-    hipLaunchKernelGGL(cloud_fwd_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, scaling_raw, rotation_raw, opacity_raw,
-                       mask_raw, scale, quat, opacity, extra4);
+    hipLaunchKernelGGL(cloud_fwd_kernel, dim3((P + 255) / 256 + rider_blocks(pro)), dim3(256), 0, s, P, scaling_raw, rotation_raw,
+                       opacity_raw, mask_raw, scale, quat, opacity, extra4, pro);
   }
   HGS_CHECK_LAUNCH();
   return 0;

@@ -62,7 +62,7 @@ SIGNATURES = {
     "hgs_select_view_queued": (ci, [vp, vp, ci, vp, vp, vp, vp]),
     "hgs_hair_params_forward": (ci, [vp, ci, vp, vp, vp, cf, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "hgs_hair_params_backward": (ci, [vp, ci, ci, vp, vp, vp, cf, vp, vp, vp, vp, vp, vp, vp, vp, ci, vp, vp, vp, vp, vp]),
-    "hgs_cloud_params_forward": (ci, [vp, ci, vp, vp, vp, vp, vp, vp, vp, vp]),
+    "hgs_cloud_params_forward": (ci, [vp, ci, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "hgs_cloud_params_backward": (ci, [vp, ci, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "hgs_loss_head_scratch_floats": (sz, [vp]),
     "hgs_loss_head_tail": (ci, [vp, vp, vp, vp]),
@@ -112,12 +112,17 @@ class HeadTail(C.Structure):
                 ("l_smooth", cf), ("bce", ci), ("ori", ci), ("smooth", ci)]
 
 
+class Prologue(C.Structure):
+    """include/hgs.h HgsPrologue."""
+    _fields_ = [("table", vp), ("view", ci), ("slot", vp), ("lr", cf), ("lr_dst", vp), ("zero_ptr", vp), ("zero_bytes", sz)]
+
+
 class StrandFusion(C.Structure):
     """include/hgs.h HgsStrandFusion."""
     _fields_ = [("smooth_pairs", vp), ("n_smooth", ci), ("cos_threshold", cf), ("eps", cf), ("smooth_partials", vp),
                 ("head_out", vp), ("grad_out", vp), ("radii", vp), ("dmean2D", vp), ("dmean2D_stride", ci),
                 ("max_radii2D", vp), ("grad_accum", vp), ("denom", vp), ("ep_segments", vp), ("ep_pairs", vp),
-                ("n_endpoints", ci), ("head_tail", HeadTail)]
+                ("n_endpoints", ci), ("head_tail", HeadTail), ("prologue", Prologue)]
 
 
 HEAD_SKIP_PIXELS, HEAD_SKIP_SMOOTH = 1, 2

@@ -81,6 +81,7 @@ class ViewTable:
         self.queue = torch.zeros(rt.VIEW_QUEUE_MAX, dtype=torch.int32, device=self.device)
         self.queue_lr = torch.zeros((), dtype=torch.float32, device=self.device)
         self._image, self._zero, self._image_ready = None, None, False
+        self._rider = None
 
     def select(self, view, lr=0.0, lr_dst=None):
         """slot <- table[view] (and *lr_dst <- lr): one launch on the current stream."""
@@ -90,6 +91,7 @@ class ViewTable:
             rt.check(rt.lib().hgs_select_view(rt.current_stream(), self.table.data_ptr(), int(view), self.slot.data_ptr(),
                                               float(lr), None if lr_dst is None else lr_dst.data_ptr()))
         self.current = int(view)
+        self._rider = None
 
     # ---- iteration prologue: view select + clearing of the image buffer's counters in ONE launch (include/hgs.h) ----
     def _image_zero_range(self):
@@ -101,17 +103,35 @@ class ViewTable:
             self._zero = (self._image.data_ptr() + off.value, nbytes.value)
         return self._zero
 
-    def prologue(self, view, lr=0.0, lr_dst=None):
+    def prologue(self, view, lr=0.0, lr_dst=None, ride=False):
         """select(view, lr, lr_dst) and, in the same launch, the clearing of this table's image buffer for the coming
-        forward pass, which take_image() then hands to the rasterizer (HGS_IMAGE_PREZEROED)."""
+        forward pass, which take_image() then hands to the rasterizer (HGS_IMAGE_PREZEROED).
+        ride=True: no launch here -- the prologue rides in spare workgroups of the fused iteration's first launch
+        (fill_prologue(); the caller promises that Fused*Step.loss() is the next thing it runs on this table)."""
         if not 0 <= int(view) < self.n:
             raise rt.HgsError(f"view {view} outside the table (0..{self.n - 1})")
         zp, zb = self._image_zero_range()
-        with torch.cuda.device(self.device):
-            rt.check(rt.lib().hgs_iteration_prologue(rt.current_stream(), self.table.data_ptr(), int(view), self.slot.data_ptr(),
-                                                     float(lr), None if lr_dst is None else lr_dst.data_ptr(), zp, zb))
+        if ride:
+            self._rider = (int(view), float(lr), None if lr_dst is None else lr_dst.data_ptr())
+        else:
+            self._rider = None
+            with torch.cuda.device(self.device):
+                rt.check(rt.lib().hgs_iteration_prologue(rt.current_stream(), self.table.data_ptr(), int(view),
+                                                         self.slot.data_ptr(), float(lr),
+                                                         None if lr_dst is None else lr_dst.data_ptr(), zp, zb))
         self.current = int(view)
         self._image_ready = True
+
+    def fill_prologue(self, fu):
+        """Hand a prologue(ride=True) to the StrandFusion of the parameter forward launch (once)."""
+        if self._rider is None:
+            return
+        view, lr, lr_dst = self._rider
+        self._rider = None
+        zp, zb = self._image_zero_range()
+        pro = fu.prologue
+        pro.table, pro.view, pro.slot, pro.lr, pro.lr_dst = self.table.data_ptr(), view, self.slot.data_ptr(), lr, lr_dst
+        pro.zero_ptr, pro.zero_bytes = zp, zb
 
     def take_image(self):
         """The image buffer whose counters the last prologue() cleared (once), else None."""
@@ -298,6 +318,7 @@ class _StrandIteration(torch.autograd.Function):
             fu.smooth_pairs, fu.n_smooth = idx.data_ptr(), int(idx.shape[0])
             fu.cos_threshold, fu.eps = hp.cos_threshold, hp.eps
             fu.smooth_partials = smooth_partials.data_ptr()
+        vt.fill_prologue(fu)
         with torch.cuda.device(dev):
             rt.check(L.hgs_hair_params_forward(stream, P, rt.ptr(endpoints), rt.ptr(pairs), rt.ptr(width), factor,
                                                rt.ptr(opacity_raw), rt.ptr(mask_raw), rt.ptr(xyz), rt.ptr(scale), rt.ptr(quat),
@@ -434,10 +455,12 @@ class _CloudIteration(torch.autograd.Function):
         f32 = dict(dtype=torch.float32, device=dev)
         scale, quat = torch.empty((P, 3), **f32), torch.empty((P, 4), **f32)
         opacity, extra4 = torch.empty((P, 1), **f32), torch.empty((P, 4), **f32)
+        fu = rt.StrandFusion()
+        step.views.fill_prologue(fu)
         with torch.cuda.device(dev):
             rt.check(L.hgs_cloud_params_forward(rt.current_stream(), P, rt.ptr(scaling_raw), rt.ptr(rotation_raw),
                                                 rt.ptr(opacity_raw), rt.ptr(mask_raw), rt.ptr(scale), rt.ptr(quat),
-                                                rt.ptr(opacity), rt.ptr(extra4)))
+                                                rt.ptr(opacity), rt.ptr(extra4), C.byref(fu)))
         shs = f_dc if f_rest.numel() == 0 else torch.cat((f_dc, f_rest), dim=1)
         R, planes, radii, geom, binning, img, scratch, out, d_extra = _raster_head_forward(
             step, xyz, scale, quat, opacity, extra4, shs, None, None, None, 0)

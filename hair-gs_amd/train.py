@@ -139,7 +139,7 @@ def _training_step(gaussians, viewpoint_cam, opt, bg, iteration, extent, vp, ras
     if iteration % 1000 == 0:
         gaussians.oneupSHdegree()
     if fused is not None:
-        fused.views.prologue(fused.views.index[id(viewpoint_cam)])
+        fused.views.prologue(fused.views.index[id(viewpoint_cam)], ride=True)   # (no launch: rides in the forward's first one)
         fused.stats_in_backward = iteration < opt.densify_until_iter
         loss, _ = fused.loss()
         loss_dict = fused.terms()
@@ -211,6 +211,8 @@ class GraphedStep:
             self.fused = fused_step_for(gaussians, views if views is not None else ViewTable(cameras), opt, bg)
             # forward and backward always run together here: no launch of its own for the loss head's last sums
             self.fused.defer_tail = bool(getattr(opt, "defer_head_tail", True))
+        # the iteration prologue rides in the first launch of the fused iteration instead of being one (A/B switch)
+        self._ride = self.fused is not None and bool(getattr(opt, "ride_prologue", True))
         c0 = cameras[0]
         for c in cameras:  # by-value kernel arguments are frozen into the graph
             assert (c.image_width, c.image_height, c.FoVx, c.FoVy) == (c0.image_width, c0.image_height, c0.FoVx, c0.FoVy)
@@ -273,7 +275,7 @@ class GraphedStep:
             if self._prologue_in_graph and not torch.cuda.is_current_stream_capturing() and self._graphs is not None:
                 v.graph_set(self._binding, v.index[id(cam)], lr=self._lr_now, lr_dst=self._position_lr())   # host work only: no launch
             else:
-                v.prologue(v.index[id(cam)], lr=self._lr_now, lr_dst=self._position_lr())
+                v.prologue(v.index[id(cam)], lr=self._lr_now, lr_dst=self._position_lr(), ride=self._ride)
             return
         for f in self.CAMERA_FIELDS:
             dst, src = getattr(self.slot, f, None), getattr(cam, f, None)
@@ -388,7 +390,7 @@ class GraphedStep:
                 for j in range(K):
                     g.optimizer.zero_grad(set_to_none=True)   # (host side: this step's backward ASSIGNS its gradients)
                     g._derived = None
-                    v.prologue(j % v.n, lr=float(j), lr_dst=self._position_lr())   # lr = j: the tag graph_bind sorts by
+                    v.prologue(j % v.n, lr=float(j), lr_dst=self._position_lr(), ride=self._ride)   # lr = j: the tag graph_bind sorts by
                     losses.append(fwd_bwd())
                     g.optimizer.step()
             gk.instantiate()

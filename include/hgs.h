@@ -224,6 +224,14 @@ int hgs_select_view(void* stream, const HgsViewTargets* table, int view, HgsView
 int hgs_iteration_prologue(void* stream, const HgsViewTargets* table, int view, HgsViewTargets* slot, float lr, float* lr_dst,
                            void* zero_ptr, size_t zero_bytes);
 int hgs_image_zero_range(int W, int H, size_t* offset, size_t* bytes);   /* of an image_buf of hgs_image_bytes(W, H) */
+/* The same prologue as a rider of another launch: hgs_hair_params_forward / hgs_cloud_params_forward -- the first launch of
+ * an iteration, which needs neither the view nor the counters -- run it in spare workgroups when HgsStrandFusion.prologue
+ * is filled in (table != NULL): no launch of its own in front of the iteration (4 us of a 290 us iteration).  The graph
+ * functions below find and re-point such a rider exactly like a stand-alone prologue launch. */
+typedef struct HgsPrologue {
+  const HgsViewTargets* table; int view; HgsViewTargets* slot; float lr; float* lr_dst;   /* as hgs_iteration_prologue */
+  void* zero_ptr; size_t zero_bytes;
+} HgsPrologue;
 /* A captured HIP graph that holds exactly ONE hgs_iteration_prologue / hgs_select_view launch is re-pointed at another
  * view (and learning rate) without any launch between two replays: hgs_graph_find_prologue(hipGraph_t) returns that
  * kernel node once after the capture, hgs_graph_set_prologue(hipGraphExec_t, node, ...) rewrites its arguments (host
@@ -285,6 +293,7 @@ typedef struct HgsStrandFusion {
    * and pairs' contributions): no float atomics, bitwise reproducible, and accumulate_endpoints is ignored. */
   const int* ep_segments; const int* ep_pairs; int n_endpoints;
   HgsHeadTail head_tail;   /* backward: out != NULL -> one spare workgroup of the launch runs the loss head's deferred tail */
+  HgsPrologue prologue;    /* forward: table != NULL -> spare workgroups of the launch run the iteration prologue */
 } HgsStrandFusion;
 int hgs_hair_params_forward(void* stream, int P, const float* endpoints, const long long* endpoint_pairs,
                             const float* width, float dist_to_scale_factor, const float* opacity_raw,
@@ -305,7 +314,7 @@ int hgs_hair_params_backward(void* stream, int P, int E, const float* endpoints,
  *   `fusion` may carry the densification-statistics group of HgsStrandFusion (its smoothness group is ignored). */
 int hgs_cloud_params_forward(void* stream, int P, const float* scaling_raw, const float* rotation_raw,
                              const float* opacity_raw, const float* mask_raw, float* scale, float* quat, float* opacity,
-                             float* extra4);
+                             float* extra4, const HgsStrandFusion* fusion /* NULL, or its prologue group */);
 int hgs_cloud_params_backward(void* stream, int P, const float* scaling_raw, const float* rotation_raw,
                               const float* opacity, const float* extra4, const float* g_scale, const float* g_quat,
                               const float* g_opacity, const float* g_extra4, float* d_scaling_raw, float* d_rotation_raw,

@@ -312,17 +312,25 @@ def test_iteration_prologue_equals_select_then_forward():
     params = [model._endpoints, model._width, model._opacity, model._mask, model._features_dc]
     lr = torch.zeros((), device="cuda")
     out = {}
-    for mode in ("select", "prologue", "prologue"):      # (twice: the buffer still holds the previous pass's counters)
+    # (each twice: the buffer still holds the previous pass's counters; "ride": no launch of its own, the prologue rides in
+    # spare workgroups of the iteration's first launch, HgsStrandFusion.prologue)
+    for mode in ("select", "prologue", "prologue", "ride", "ride", "prologue"):
         for p in params:
             p.grad = None
         model._derived = None
         if mode == "select":
             fused.views.select(1, lr=0.5, lr_dst=lr)
             assert fused.views.take_image() is None
-        else:
+        elif mode == "prologue":
             fused.views.prologue(1, lr=0.25, lr_dst=lr)
             assert float(lr) == 0.25
+        else:
+            fused.views.select(0, lr=0.75, lr_dst=lr)    # (the slot holds another view until the rider has run)
+            fused.views.prologue(1, lr=0.125, lr_dst=lr, ride=True)
+            assert float(lr) == 0.75                     # nothing launched yet
         loss, _ = fused.loss()
+        if mode == "ride":
+            assert float(lr) == 0.125
         assert fused.views.take_image() is None          # consumed by the forward
         fused.backward(loss)
         cur = [loss.detach().clone(), fused.last["planes"].clone()] + [p.grad.clone() for p in params]
@@ -365,7 +373,7 @@ def test_deferred_head_tail_gives_the_same_terms_and_gradients():
                     p.grad = None
                 model._derived = None
                 fused.defer_tail = defer
-                fused.views.prologue(1)
+                fused.views.prologue(1, ride=defer)      # (and the prologue as a rider of the parameter forward launch)
                 loss, terms = fused.loss()
                 if scale is None:
                     fused.backward(loss)
