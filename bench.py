@@ -222,6 +222,7 @@ def main():
         from hgs_runtime.strand_step import ViewTable, fused_step_for
         views = ViewTable(cams)
         fused = fused_step_for(model, views, opt, bg)   # eager launches of the same fused iteration (timing pass, --eager)
+        fused.defer_tail = opt.defer_head_tail           # (training_step always runs forward and backward together)
     if use_graph:
         # the whole iteration is captured once into a HIP graph and replayed (train.GraphedStep); the W warm-up steps
         # and the K timed steps are real optimizer steps on successive random views, exactly like the eager loop

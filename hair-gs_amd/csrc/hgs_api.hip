@@ -28,7 +28,7 @@ const char* kKernelNames[HGS_K_COUNT] = {"preprocess_fwd_kernel", "scan_kernel",
                                          "blend_fwd_kernel", "blend_bwd_kernel", "preprocess_bwd_kernel", "dist2_kernels",
                                          "ssim_l1_fwd_kernel", "ssim_l1_bwd_kernel", "strand_fwd_kernel",
                                          "strand_bwd_kernel", "ori_fwd_kernel", "ori_bwd_kernel", "adam_kernel",
-                                         "smooth_kernels", "head_finalize_kernel", "misc_kernels"};
+                                         "smooth_kernels", "head_tail_kernel", "misc_kernels"};
 hipEvent_t prof_event() {
   if (!g_prof_pool.empty()) { hipEvent_t e = g_prof_pool.back(); g_prof_pool.pop_back(); return e; }
   hipEvent_t e = nullptr;

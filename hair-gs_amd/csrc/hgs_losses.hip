@@ -401,7 +401,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HGS_SSIM_BW
   const int lx = threadIdx.x & (LT - 1), y0 = (threadIdx.x >> 5) * 4;
   int j = blockIdx.x >> 3;
   SsimBlock bk, nx;
-  // `lists` (the loss head's forward built it, head_finalize_kernel): the blocks whose gradient is not identically zero, in
+  // `lists` (the loss head's forward built it, build_block_lists): the blocks whose gradient is not identically zero, in
   // logical order, and the rest.  Each XCD takes an equal contiguous share of the first list (the halo sharing in its L2
   // is kept, and the work is balanced however the hair sits in the frame); the second list is only zero-filled.
   const int xcd = blockIdx.x & 7;

@@ -503,6 +503,7 @@ def training(gaussians, cameras, opt, iterations=None, extent=1.0, seed=0, log_e
         from hgs_runtime.strand_step import ViewTable, fused_step_for
         views = ViewTable(cameras)             # built once; survives topology changes
         fused = fused_step_for(gaussians, views, opt, bg)   # eager launches of the same iteration (topology iterations)
+        fused.defer_tail = bool(getattr(opt, "defer_head_tail", True))   # (training_step runs forward and backward together)
     topology = getattr(opt, "enable_topology", True)
     void_steps = 0
     try:
