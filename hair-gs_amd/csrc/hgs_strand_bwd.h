@@ -1,45 +1,18 @@
 // hgs_strand_bwd.h -- device code of the strand parameters' backward (hgs_hair_params_backward): gradients of the
 // rasterizer inputs -> endpoints / width / raw opacity / raw mask (+ smoothness gradient, densification statistics, the
-// loss head's tail).  Shared by strand_bwd_kernel (hgs_strands.hip) and by the rasterizer's preprocess backward, whose
-// launch it can RIDE in (hgs_preprocess.hip, hgs_backward_multi_strands): the strand workgroups are dispatched behind the
-// preprocess workgroups of the same launch, fetch everything that does not depend on them -- adjacency codes, index rows,
-// endpoints, the smoothness pairs, the statistics -- and only then wait for the preprocess workgroups' ticket; what is
-// left behind the wait is one round trip for the gradients, the arithmetic and the stores, instead of a launch of three
-// dependent round trips behind a launch boundary (9 + 13 us as two launches).
-// AG = the ride: the rasterizer gradients were written by other workgroups of the SAME launch (agent-scope stores,
-// drained, then the ticket): they are read with agent-scope loads.
+// loss head's tail).  Kept apart from its kernel (hgs_strands.hip) with the loads that do not depend on the rasterizer's
+// gradients -- adjacency codes, index rows, endpoints, the smoothness pairs -- in front of those that do.
+// (Round 2 ran this code as a RIDER of the rasterizer's preprocess-backward launch -- strand workgroups dispatched behind
+// the preprocess workgroups, prefetching, then waiting for a ticket before reading the gradients through an agent-scope
+// acquire: correct, bit-identical, and slower, DESIGN.md section 6: 800 workgroups polling one word next to the 1200
+// atomics on it cost 50 us, and without any wait the merged launch still took 26 us against 9.8 + 12.4 as two launches,
+// because at the preprocess kernel's 128 registers the 1200 workgroups are not resident together.)
 #pragma once
 #include "hgs_common.h"
 #include "hgs_smooth.h"
 #include "hgs_head_tail.h"
 
 #define HGS_STRAND_MINV 1e-7f
-
-template <bool AG> __device__ __forceinline__ float hgs_ldx(const float* p) {
-  if constexpr (AG) return hgs_ld_agent(p); else return *p;
-}
-template <bool AG> __device__ __forceinline__ float4 hgs_ldx4(const float* p) {
-  if constexpr (AG) return make_float4(hgs_ld_agent(p), hgs_ld_agent(p + 1), hgs_ld_agent(p + 2), hgs_ld_agent(p + 3));
-  else return *(const float4*)p;
-}
-
-// the wait of a riding workgroup: thread 0 polls the ticket (bounded, like hgs_wait_parts), then the workgroup meets
-struct HgsRideWait { const uint32_t* ticket; uint32_t want; uint32_t* status; };
-__device__ __forceinline__ void hgs_ride_wait(const HgsRideWait& w) {
-  if (threadIdx.x == 0) {
-    bool ok = false;
-    for (int spin = 0; spin < (1 << 21); spin++) {
-      if (hgs_ld_agent(w.ticket) >= w.want) { ok = true; break; }
-      __builtin_amdgcn_s_sleep(4);
-    }
-    if (!ok) {
-      w.status[HGS_ST_TIMEOUT] = 1u;
-      const unsigned long long report = ((unsigned long long)w.status[HGS_ST_SCANPTR_HI] << 32) | w.status[HGS_ST_SCANPTR_LO];
-      if (report) atomicMax((unsigned int*)report, 0xFFFFFFFFu);     // include/hgs.h HGS_WAIT_TIMED_OUT
-    }
-  }
-  __syncthreads();
-}
 
 // Gradient of segment k w.r.t. its two endpoints: endpoint 0 receives h - gD, endpoint 1 receives h + gD
 // (h = half the gradient of the midpoint, gD = gradient w.r.t. delta = e1 - e0 from direction, quaternion and length).
@@ -49,17 +22,16 @@ __device__ __forceinline__ HgsSegGeom hgs_segment_geom(int k, const float* __res
   const long long i0 = pairs[2 * (size_t)k], i1 = pairs[2 * (size_t)k + 1];
   return {ep[3 * i1] - ep[3 * i0], ep[3 * i1 + 1] - ep[3 * i0 + 1], ep[3 * i1 + 2] - ep[3 * i0 + 2]};
 }
-template <bool AG>
 __device__ __forceinline__ void hgs_segment_endpoint_grads(int k, const HgsSegGeom& sgm, float f, const HgsSegGrads& sg, float* h, float* gD) {
   // every load first and unconditional (the pointer tests are uniform): a lane that evaluates several segments then has
   // all of them in flight together instead of one dependent chain after the other
   float4 ge = make_float4(0.f, 0.f, 0.f, 0.f), gq = make_float4(0.f, 0.f, 0.f, 0.f);
   float gx[3] = {0.f, 0.f, 0.f}, gd[3] = {0.f, 0.f, 0.f}, gs0 = 0.f;
-  if (sg.g_extra4) ge = hgs_ldx4<AG>(sg.g_extra4 + 4 * (size_t)k);
-  if (sg.g_quat) gq = hgs_ldx4<AG>(sg.g_quat + 4 * (size_t)k);
-  if (sg.g_xyz) { gx[0] = hgs_ldx<AG>(sg.g_xyz + 3 * (size_t)k); gx[1] = hgs_ldx<AG>(sg.g_xyz + 3 * (size_t)k + 1); gx[2] = hgs_ldx<AG>(sg.g_xyz + 3 * (size_t)k + 2); }
-  if (sg.g_dir) { gd[0] = hgs_ldx<AG>(sg.g_dir + 3 * (size_t)k); gd[1] = hgs_ldx<AG>(sg.g_dir + 3 * (size_t)k + 1); gd[2] = hgs_ldx<AG>(sg.g_dir + 3 * (size_t)k + 2); }
-  if (sg.g_scale) gs0 = hgs_ldx<AG>(sg.g_scale + 3 * (size_t)k);
+  if (sg.g_extra4) ge = *(const float4*)(sg.g_extra4 + 4 * (size_t)k);
+  if (sg.g_quat) gq = *(const float4*)(sg.g_quat + 4 * (size_t)k);
+  if (sg.g_xyz) { gx[0] = *(sg.g_xyz + 3 * (size_t)k); gx[1] = *(sg.g_xyz + 3 * (size_t)k + 1); gx[2] = *(sg.g_xyz + 3 * (size_t)k + 2); }
+  if (sg.g_dir) { gd[0] = *(sg.g_dir + 3 * (size_t)k); gd[1] = *(sg.g_dir + 3 * (size_t)k + 1); gd[2] = *(sg.g_dir + 3 * (size_t)k + 2); }
+  if (sg.g_scale) gs0 = *(sg.g_scale + 3 * (size_t)k);
   const float dx = sgm.dx, dy = sgm.dy, dz = sgm.dz;
   const float L = sqrtf(dx * dx + dy * dy + dz * dz);
   h[0] = 0.5f * gx[0]; h[1] = 0.5f * gx[1]; h[2] = 0.5f * gx[2];
@@ -98,8 +70,7 @@ struct HgsStrandBwdArgs {
 
 // Workgroup `blk` of `nblk` (256 threads): [0, ceil(P / 256)) one lane per Gaussian; then, gather mode, one lane per
 // endpoint (scatter mode: per smoothness pair); the last one runs the loss head's deferred tail when that is asked for.
-template <bool AG>
-__device__ __forceinline__ void hgs_strand_bwd_block(const HgsStrandBwdArgs& A, unsigned blk, unsigned nblk, const HgsRideWait& w) {
+__device__ __forceinline__ void hgs_strand_bwd_block(const HgsStrandBwdArgs& A, unsigned blk, unsigned nblk) {
   const HgsStrandFusion& fu = A.fu;
   const int P = A.P;
   const float* __restrict__ ep = A.ep;
@@ -117,9 +88,8 @@ __device__ __forceinline__ void hgs_strand_bwd_block(const HgsStrandBwdArgs& A, 
       // gather mode: one lane per ENDPOINT sums the contributions of its (<= 2) segments and (<= 4) smoothness pair
       // roles in a fixed order and stores once: no float atomics (each segment / pair is simply evaluated by every
       // endpoint it touches: ~500 flops per endpoint against 18 L2 atomics per segment)
-      const bool live = i < fu.n_endpoints;
-      if (!AG && !live) return;
-      const int ic = live ? i : fu.n_endpoints - 1;            // (a riding workgroup meets at the wait: no early exit)
+      if (i >= fu.n_endpoints) return;
+      const int ic = i;
       // The (<= 2 + 4) evaluations are independent: absent slots (code < 0) evaluate item 0 and are masked out afterwards,
       // so that nothing branches between the loads of one evaluation and the next -- the lane's six dependent chains
       // (code -> index row -> endpoints) overlap instead of running one after the other (14.5 -> 11.6 us for the launch).
@@ -141,10 +111,10 @@ __device__ __forceinline__ void hgs_strand_bwd_block(const HgsStrandBwdArgs& A, 
           pok[s] = hgs_smooth_pair_grads(pair_code[s] >= 0 ? pair_code[s] >> 2 : 0, ep, fu.smooth_pairs, fu.cos_threshold, fu.eps,
                                          smooth_scale, pg0[s], pg1[s]) && pair_code[s] >= 0;
       }
-      if constexpr (AG) hgs_ride_wait(w);     // everything above is independent of the rasterizer's gradients
+      // (everything above is independent of the rasterizer's gradients)
       float sh[2][3], sD[2][3];
 #pragma unroll
-      for (int s = 0; s < 2; s++) hgs_segment_endpoint_grads<AG>(seg_code[s] >= 0 ? seg_code[s] >> 1 : 0, geo[s], f, sg, sh[s], sD[s]);
+      for (int s = 0; s < 2; s++) hgs_segment_endpoint_grads(seg_code[s] >= 0 ? seg_code[s] >> 1 : 0, geo[s], f, sg, sh[s], sD[s]);
 #pragma unroll
       for (int s = 0; s < 2; s++) {
         const float sign = (seg_code[s] & 1) ? 1.f : -1.f;
@@ -162,60 +132,34 @@ __device__ __forceinline__ void hgs_strand_bwd_block(const HgsStrandBwdArgs& A, 
           for (int c = 0; c < 3; c++) acc[c] += sign * (role < 2 ? pg0[s][c] : pg1[s][c]);
         }
       }
-      if (live) { A.d_ep[3 * (size_t)i] = acc[0]; A.d_ep[3 * (size_t)i + 1] = acc[1]; A.d_ep[3 * (size_t)i + 2] = acc[2]; }
+      A.d_ep[3 * (size_t)i] = acc[0]; A.d_ep[3 * (size_t)i + 1] = acc[1]; A.d_ep[3 * (size_t)i + 2] = acc[2];
     } else if (i < fu.n_smooth) {   // scatter mode: smoothness gradient added into d_ep with atomics
       hgs_smooth_bwd_pair(i, ep, fu.smooth_pairs, fu.cos_threshold, fu.eps, smooth_scale, A.d_ep);
     }
     return;
   }
   const int k = blk * 256 + threadIdx.x;
-  if constexpr (AG) {
-    // the ride: this Gaussian's own values first, the rasterizer's gradients behind the wait
-    const bool live = k < P;
-    const int kc = live ? k : P - 1;
-    int r = 0;
-    float mr = 0.f, ga = 0.f, dn = 0.f;
-    if (fu.radii) { r = fu.radii[kc]; mr = fu.max_radii2D[kc]; ga = fu.grad_accum[kc]; dn = fu.denom[kc]; }
-    const float o = A.d_opacity_raw ? A.opacity[kc] : 0.f;
-    const float m = A.d_mask_raw ? A.extra4[4 * (size_t)kc] : 0.f;
-    const float ew = A.g_scale ? expf(A.width[kc]) : 0.f;
-    hgs_ride_wait(w);
-    if (!live) return;
-    if (fu.radii && r > 0) {           // densification statistics of this Gaussian (hgs_densify_stats)
-      fu.max_radii2D[k] = fmaxf(mr, (float)r);
-      const float gx = hgs_ld_agent(fu.dmean2D + (size_t)k * fu.dmean2D_stride), gy = hgs_ld_agent(fu.dmean2D + (size_t)k * fu.dmean2D_stride + 1);
-      fu.grad_accum[k] = ga + sqrtf(gx * gx + gy * gy);
-      fu.denom[k] = dn + 1.f;
+  if (k >= P) return;
+  if (fu.radii) {                    // densification statistics of this Gaussian (hgs_densify_stats)
+    const int r = fu.radii[k];
+    if (r > 0) {
+      fu.max_radii2D[k] = fmaxf(fu.max_radii2D[k], (float)r);
+      const float gx = fu.dmean2D[(size_t)k * fu.dmean2D_stride], gy = fu.dmean2D[(size_t)k * fu.dmean2D_stride + 1];
+      fu.grad_accum[k] += sqrtf(gx * gx + gy * gy);
+      fu.denom[k] += 1.f;
     }
-    if (A.d_opacity_raw) A.d_opacity_raw[k] = hgs_ld_agent(A.g_opacity + k) * o * (1.f - o);                     // sigmoid'
-    if (A.d_mask_raw) A.d_mask_raw[k] = hgs_ld_agent(A.g_extra4 + 4 * (size_t)k) * m * (1.f - m);
-    float gw = 0.f;
-    if (A.g_scale) gw = (hgs_ld_agent(A.g_scale + 3 * (size_t)k + 1) + hgs_ld_agent(A.g_scale + 3 * (size_t)k + 2)) * ew;
-    A.d_width[k] = gw;                 // (the ride is gather mode only: no scatter of the segment's endpoint gradients here)
-    return;
-  } else {
-    if (k >= P) return;
-    if (fu.radii) {                    // densification statistics of this Gaussian (hgs_densify_stats)
-      const int r = fu.radii[k];
-      if (r > 0) {
-        fu.max_radii2D[k] = fmaxf(fu.max_radii2D[k], (float)r);
-        const float gx = fu.dmean2D[(size_t)k * fu.dmean2D_stride], gy = fu.dmean2D[(size_t)k * fu.dmean2D_stride + 1];
-        fu.grad_accum[k] += sqrtf(gx * gx + gy * gy);
-        fu.denom[k] += 1.f;
-      }
-    }
-    if (A.d_opacity_raw) { const float o = A.opacity[k]; A.d_opacity_raw[k] = A.g_opacity[k] * o * (1.f - o); }   // sigmoid'
-    if (A.d_mask_raw) { const float m = A.extra4[4 * (size_t)k]; A.d_mask_raw[k] = A.g_extra4[4 * (size_t)k] * m * (1.f - m); }
-    float gw = 0.f;
-    if (A.g_scale) gw = (A.g_scale[3 * (size_t)k + 1] + A.g_scale[3 * (size_t)k + 2]) * expf(A.width[k]);
-    if (!fu.ep_segments) {             // scatter mode: this segment's contribution to its two endpoints
-      float h[3], gD[3];
-      hgs_segment_endpoint_grads<false>(k, hgs_segment_geom(k, ep, pairs), f, sg, h, gD);
-      const long long i0 = pairs[2 * (size_t)k], i1 = pairs[2 * (size_t)k + 1];
-      float* d_ep = A.d_ep;
-      atomicAdd(&d_ep[3 * i0], h[0] - gD[0]); atomicAdd(&d_ep[3 * i0 + 1], h[1] - gD[1]); atomicAdd(&d_ep[3 * i0 + 2], h[2] - gD[2]);
-      atomicAdd(&d_ep[3 * i1], h[0] + gD[0]); atomicAdd(&d_ep[3 * i1 + 1], h[1] + gD[1]); atomicAdd(&d_ep[3 * i1 + 2], h[2] + gD[2]);
-    }
-    A.d_width[k] = gw;
   }
+  if (A.d_opacity_raw) { const float o = A.opacity[k]; A.d_opacity_raw[k] = A.g_opacity[k] * o * (1.f - o); }   // sigmoid'
+  if (A.d_mask_raw) { const float m = A.extra4[4 * (size_t)k]; A.d_mask_raw[k] = A.g_extra4[4 * (size_t)k] * m * (1.f - m); }
+  float gw = 0.f;
+  if (A.g_scale) gw = (A.g_scale[3 * (size_t)k + 1] + A.g_scale[3 * (size_t)k + 2]) * expf(A.width[k]);
+  if (!fu.ep_segments) {             // scatter mode: this segment's contribution to its two endpoints
+    float h[3], gD[3];
+    hgs_segment_endpoint_grads(k, hgs_segment_geom(k, ep, pairs), f, sg, h, gD);
+    const long long i0 = pairs[2 * (size_t)k], i1 = pairs[2 * (size_t)k + 1];
+    float* d_ep = A.d_ep;
+    atomicAdd(&d_ep[3 * i0], h[0] - gD[0]); atomicAdd(&d_ep[3 * i0 + 1], h[1] - gD[1]); atomicAdd(&d_ep[3 * i0 + 2], h[2] - gD[2]);
+    atomicAdd(&d_ep[3 * i1], h[0] + gD[0]); atomicAdd(&d_ep[3 * i1 + 1], h[1] + gD[1]); atomicAdd(&d_ep[3 * i1 + 2], h[2] + gD[2]);
+  }
+  A.d_width[k] = gw;
 }

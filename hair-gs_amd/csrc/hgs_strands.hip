@@ -69,7 +69,7 @@ __global__ __launch_bounds__(256) void strand_fwd_kernel(int P, const float* __r
 }
 
 __global__ __launch_bounds__(256) void strand_bwd_kernel(HgsStrandBwdArgs A) {
-  hgs_strand_bwd_block<false>(A, blockIdx.x, gridDim.x, HgsRideWait{});     // (device code: hgs_strand_bwd.h)
+  hgs_strand_bwd_block(A, blockIdx.x, gridDim.x);     // (device code: hgs_strand_bwd.h)
 }
 
 // ---- Stage-I cloud: raw parameters -> rasterizer inputs (scene/gaussian_model.py:118-157) -------------------------------
