@@ -200,11 +200,16 @@ __device__ __forceinline__ void work_list_block(int T, uint32_t Rcap, HgsSegPoli
   __shared__ uint32_t hist[ORD_BUCKETS], before[ORD_BUCKETS], wsum[HGS_BLOCK / 64];   // (`before` becomes the buckets' first positions)
   __shared__ uint32_t cand[MAX_CAND], ncand, nitems, nsplit_base;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  if (T > bk_cap && blockIdx.x != 0) return;                          // huge frames: one builder, buckets from memory
-  const bool cached = T <= bk_cap;
+  // a builder keeps the buckets of ITS share of the tiles (the only ones it places) in LDS: 1024 entries at 1080p, so the
+  // kernel's LDS stays at the 4 KB of a sort chunk and 16 of its workgroups fit a CU instead of 7 (with all 8192 buckets
+  // in a 16 KB array: the tile workgroups of a hair frame live one wavefront each, LDS was what bounded their number)
+  const int share_w = ((T + WL_BUILDERS - 1) / WL_BUILDERS + HGS_BLOCK - 1) / HGS_BLOCK * HGS_BLOCK;
+  const bool cached = share_w <= bk_cap;
+  if (!cached && blockIdx.x != 0) return;                             // huge frames: one builder, buckets from memory
   const int nbuild = cached ? WL_BUILDERS : 1, me = (int)blockIdx.x;
   const int share = ((T + nbuild - 1) / nbuild + HGS_BLOCK - 1) / HGS_BLOCK * HGS_BLOCK;
   const int my0 = min(T, me * share), my1 = min(T, my0 + share);     // the tiles this builder places
+  auto keep = [&](int i, int k) { if (i >= my0 && i < my1) bk[i - my0] = (uint16_t)k; };
   for (int i = tid; i < ORD_BUCKETS; i += HGS_BLOCK) { hist[i] = 0u; before[i] = 0u; }
   if (tid == 0) { ncand = 0u; nitems = 0u; nsplit_base = 0u; }
   const uint32_t S = hgs_segment_length(im.status[HGS_ST_R], pol);
@@ -224,7 +229,7 @@ __device__ __forceinline__ void work_list_block(int T, uint32_t Rcap, HgsSegPoli
     for (int i = tid; i < T; i += HGS_BLOCK) {
       const uint32_t n = length_of(i);
       const int k = n > thr ? CANDIDATE : bucket_for(n);
-      bk[i] = (uint16_t)k;
+      keep(i, k);
       if (k != CANDIDATE) count(i, k);
       else { const uint32_t c = atomicAdd(&ncand, 1u); if (c < MAX_CAND) cand[c] = (uint32_t)i; }
     }
@@ -251,7 +256,7 @@ __device__ __forceinline__ void work_list_block(int T, uint32_t Rcap, HgsSegPoli
   auto place_long = [&](int i) {
     const uint32_t n = length_of(i);
     if (split_all) {
-      if (cached) bk[i] = (uint16_t)SPLIT_BUCKET;
+      if (cached) keep(i, SPLIT_BUCKET);
       if (me == 0) {
         const HgsSplit sp = hgs_split_of(n, S);
         const uint32_t base = atomicAdd(&nsplit_base, sp.nseg);
@@ -260,7 +265,7 @@ __device__ __forceinline__ void work_list_block(int T, uint32_t Rcap, HgsSegPoli
       }
     } else {
       const int k = bucket_for(n);
-      if (cached) bk[i] = (uint16_t)k;
+      if (cached) keep(i, k);
       count(i, k);
     }
   };
@@ -287,7 +292,7 @@ __device__ __forceinline__ void work_list_block(int T, uint32_t Rcap, HgsSegPoli
   // of several iterations are in flight together)
 #pragma unroll 8
   for (int i = my0 + tid; i < my1; i += HGS_BLOCK) {
-    const int bkt = cached ? (int)bk[i] : bucket_mem(i);
+    const int bkt = cached ? (int)bk[i - my0] : bucket_mem(i);
     if (bkt != SPLIT_BUCKET) im.tile_order[before[bkt] + atomicAdd(&hist[bkt], 1u)] = (uint32_t)i;
   }
   if (me == 0 && tid == 0) {
@@ -321,8 +326,8 @@ __device__ __forceinline__ void add_lower_bounds(const uint64_t* sk, uint32_t cn
 template <bool EXTRA>
 __global__ __launch_bounds__(HGS_BLOCK) void sort_tiles_kernel(int gx, int T, uint32_t Rcap, HgsSegPolicy pol, HgsGeom g, HgsImage im,
                                                                HgsBinning b) {
-  // (at least 16 KB: the work-list builders keep one 16-bit word per tile of a frame of up to 8192 tiles in it)
-  constexpr int SK_WORDS = SORT_CAP > 2048 ? SORT_CAP : 2048;
+  // (one sort chunk; the work-list builders keep one 16-bit word per tile of their share of the frame in it)
+  constexpr int SK_WORDS = SORT_CAP > 256 ? SORT_CAP : 256;
   __shared__ uint64_t sk[SK_WORDS];
   constexpr int KPT = SORT_CAP / HGS_BLOCK;
   if (blockIdx.x < WL_BUILDERS) { work_list_block(T, Rcap, pol, im, b, (uint16_t*)sk, SK_WORDS * 4); return; }
