@@ -22,7 +22,7 @@
 namespace {
 
 #define SCAN_THREADS 1024
-#define ORD_BUCKETS 512    // list-length buckets of the tile order (<= SCAN_THREADS)
+#define ORD_BUCKETS HGS_WL_BUCKETS    // list-length buckets of the tile order (<= SCAN_THREADS)
 #define SORT_CAP HGS_SORT_CAP  // keys per chunk
 
 // generic helper: scans `n` uint32 values with one 1024-thread block; calls emit(i, exclusive, value)
@@ -192,13 +192,134 @@ __device__ __forceinline__ void bitonic_wave(uint64_t* sk, int m, int lane) {
 // count it with LDS atomics that return nothing; no global store in the loop, so the loads of several iterations are in
 // flight together; the rare long lists only note their tile in a candidate list --, and a placing pass that each builder
 // runs over ITS share of the tiles only (the tiles of the shares before it were counted separately in the first pass).
-#ifndef WL_BUILDERS
-#define WL_BUILDERS 8
-#endif
-__device__ __forceinline__ void work_list_block(int T, uint32_t Rcap, HgsSegPolicy pol, const HgsImage& im, const HgsBinning& b, uint16_t* bk, int bk_cap) {
-  constexpr int SPLIT_BUCKET = 0xFFFF, CANDIDATE = 0xFFFE, MAX_CAND = 512;
-  __shared__ uint32_t hist[ORD_BUCKETS], before[ORD_BUCKETS], wsum[HGS_BLOCK / 64];   // (`before` becomes the buckets' first positions)
-  __shared__ uint32_t cand[MAX_CAND], ncand, nitems, nsplit_base;
+#define WL_BUILDERS HGS_WL_BUILDERS
+// LDS of a work-list builder (one set for both forms below: static LDS is what bounds the kernel's workgroups per CU)
+struct WlLds { uint32_t hist[ORD_BUCKETS], before[ORD_BUCKETS], aux[ORD_BUCKETS], wsum[HGS_BLOCK / 64], small[4]; };
+
+// The same list by builders that SHARE the counting (frames whose share of tiles fits the LDS array, i.e. all but 8K): the
+// one pass every builder ran over all T tiles -- 32 dependent-batch loads per thread at 1080p, 6 of the builders' 12 us, and
+// the builders are what the sort kernel waits for (14.2 us with them, 10.9 without, measured) -- becomes a pass over its
+// own eighth; the builders then tell each other their histograms through im.wl_exchange (agent-scope stores, a ticket in
+// the status words, agent-scope loads: eight workgroups polling one word is nothing) and derive the same positions.
+//   wl_exchange: [builder][2][bucket]  counts of the builder's share: lists kept whole | long lists (candidates to split)
+//                [HGS_WL_MAX_CAND]     tiles of the candidates, appended through status[HGS_ST_WL_NCAND]
+__device__ __forceinline__ void work_list_shared(int T, uint32_t Rcap, HgsSegPolicy pol, const HgsImage& im, const HgsBinning& b, uint16_t* bk, WlLds& L) {
+  constexpr int CAND_FLAG = 0x8000;
+  uint32_t* hist = L.hist; uint32_t* before = L.before; uint32_t* hist_c = L.aux; uint32_t* wsum = L.wsum;
+  uint32_t& nsplit_base = L.small[0]; uint32_t& s_ok = L.small[1];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, me = (int)blockIdx.x;
+  const int share = ((T + WL_BUILDERS - 1) / WL_BUILDERS + HGS_BLOCK - 1) / HGS_BLOCK * HGS_BLOCK;
+  const int my0 = min(T, me * share), my1 = min(T, my0 + share);
+  for (int i = tid; i < ORD_BUCKETS; i += HGS_BLOCK) { hist[i] = 0u; hist_c[i] = 0u; }
+  if (tid == 0) nsplit_base = 0u;
+  const uint32_t S = hgs_segment_length(im.status[HGS_ST_R], pol);
+  const uint32_t seg_cap = min(b.seg_cap, (uint32_t)HGS_SPLIT_CAPACITY(T));   // (what the work list holds)
+  const uint32_t thr = seg_cap ? S + S / 2 : 0xFFFFFFFFu;
+  __syncthreads();
+  auto length_of = [&](int i) { const uint2 r = im.ranges[i]; return r.y > Rcap ? 0u : r.y - r.x; };   // (beyond the capacity: void)
+  auto bucket_for = [&](uint32_t n) { return ORD_BUCKETS - 1 - (int)min(n, (uint32_t)(ORD_BUCKETS - 1)); };   // 0 = longest
+  // ---- this builder's share: buckets, counts, candidates
+#pragma unroll 4
+  for (int i = my0 + tid; i < my1; i += HGS_BLOCK) {
+    const uint32_t n = length_of(i);
+    const int k = bucket_for(n);
+    if (n > thr) {
+      bk[i - my0] = (uint16_t)(k | CAND_FLAG);
+      atomicAdd(&hist_c[k], 1u);
+      const uint32_t c = atomicAdd(&im.status[HGS_ST_WL_NCAND], 1u);
+      if (c < HGS_WL_MAX_CAND) hgs_st_agent(&im.wl_exchange[WL_BUILDERS * 2 * ORD_BUCKETS + c], (uint32_t)i);
+      atomicAdd(&im.status[HGS_ST_WL_NSEG], hgs_split_of(n, S).nseg);
+    } else {
+      bk[i - my0] = (uint16_t)k;
+      atomicAdd(&hist[k], 1u);
+    }
+  }
+  __syncthreads();
+  uint32_t* mine = im.wl_exchange + (size_t)me * 2 * ORD_BUCKETS;
+  for (int k = tid; k < ORD_BUCKETS; k += HGS_BLOCK) { hgs_st_agent(&mine[k], hist[k]); hgs_st_agent(&mine[ORD_BUCKETS + k], hist_c[k]); }
+  hgs_drain_stores();
+  __syncthreads();
+  if (tid == 0) {
+    atomicAdd(&im.status[HGS_ST_WL_TICKET], 1u);
+    uint32_t ok = 0u;
+    for (int spin = 0; spin < (1 << 21); spin++) {
+      if (hgs_ld_agent(&im.status[HGS_ST_WL_TICKET]) >= (uint32_t)WL_BUILDERS) { ok = 1u; break; }
+      __builtin_amdgcn_s_sleep(2);
+    }
+    if (!ok) {   // (the builders are the launch's first workgroups: resident together; never observed)
+      im.status[HGS_ST_TIMEOUT] = 1u;
+      const unsigned long long report = ((unsigned long long)im.status[HGS_ST_SCANPTR_HI] << 32) | im.status[HGS_ST_SCANPTR_LO];
+      if (report) atomicMax((unsigned int*)report, 0xFFFFFFFFu);
+    }
+    s_ok = ok;
+  }
+  __syncthreads();
+  if (!s_ok) return;
+  // ---- everybody's counts: totals per bucket, and what lies before this builder's share
+  const uint32_t nc = hgs_ld_agent(&im.status[HGS_ST_WL_NCAND]), nitems = hgs_ld_agent(&im.status[HGS_ST_WL_NSEG]);
+  const bool split_all = nc != 0u && nc <= HGS_WL_MAX_CAND && nitems <= seg_cap;
+  const uint32_t nsplit = split_all ? nitems : 0u;
+  for (int k = tid; k < ORD_BUCKETS; k += HGS_BLOCK) {
+    uint32_t v[WL_BUILDERS], vc[WL_BUILDERS];
+#pragma unroll
+    for (int q = 0; q < WL_BUILDERS; q++) {
+      v[q] = hgs_ld_agent(&im.wl_exchange[(size_t)q * 2 * ORD_BUCKETS + k]);
+      vc[q] = hgs_ld_agent(&im.wl_exchange[(size_t)q * 2 * ORD_BUCKETS + ORD_BUCKETS + k]);
+    }
+    uint32_t tot = 0, bef = 0;
+#pragma unroll
+    for (int q = 0; q < WL_BUILDERS; q++) {
+      const uint32_t x = v[q] + (split_all ? 0u : vc[q]);    // long lists that are not split stay whole, in their bucket
+      tot += x;
+      if (q < me) bef += x;
+    }
+    hist[k] = tot;
+    before[k] = bef;
+  }
+  __syncthreads();
+  // ---- the long lists' segments (builder 0)
+  if (split_all && me == 0) {
+    for (uint32_t c = tid; c < nc; c += HGS_BLOCK) {
+      const int i = (int)hgs_ld_agent(&im.wl_exchange[WL_BUILDERS * 2 * ORD_BUCKETS + c]);
+      const HgsSplit sp = hgs_split_of(length_of(i), S);
+      const uint32_t base = atomicAdd(&nsplit_base, sp.nseg);
+      for (uint32_t k = 0; k < sp.nseg; k++) im.tile_order[base + k] = (uint32_t)i | (k << 24);
+      im.tile_prog[i] = HGS_PART_FLAG;
+    }
+  }
+  uint32_t carry = 0;
+  for (int base = 0; base < ORD_BUCKETS; base += HGS_BLOCK) {   // exclusive scan of the histogram
+    const uint32_t v = hist[base + tid];
+    const uint32_t incl = hgs_wave_incl_scan(v, lane);
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    uint32_t woff = 0, total = 0;
+    for (int w = 0; w < HGS_BLOCK / 64; w++) { if (w < wave) woff += wsum[w]; total += wsum[w]; }
+    before[base + tid] += nsplit + carry + woff + incl - v;   // first position of this builder's tiles in the bucket
+    hist[base + tid] = 0u;
+    carry += total;
+    __syncthreads();
+  }
+  // ---- placing pass over this builder's share (order inside a bucket is irrelevant; unrolled: the returning LDS atomics
+  // of several iterations are in flight together)
+#pragma unroll 4
+  for (int i = my0 + tid; i < my1; i += HGS_BLOCK) {
+    const int code = (int)bk[i - my0];
+    if ((code & CAND_FLAG) && split_all) continue;
+    const int bkt = code & (CAND_FLAG - 1);
+    im.tile_order[before[bkt] + atomicAdd(&hist[bkt], 1u)] = (uint32_t)i;
+  }
+  if (me == 0 && tid == 0) {
+    im.status[HGS_ST_SPLIT_ITEMS] = nsplit;
+    im.status[HGS_ST_SEG_LEN] = S;
+    im.status[HGS_ST_WORK_ITEMS] = nsplit + (uint32_t)T - (split_all ? nc : 0u);
+  }
+}
+
+__device__ __forceinline__ void work_list_block(int T, uint32_t Rcap, HgsSegPolicy pol, const HgsImage& im, const HgsBinning& b, uint16_t* bk, int bk_cap, WlLds& L) {
+  constexpr int SPLIT_BUCKET = 0xFFFF, CANDIDATE = 0xFFFE, MAX_CAND = ORD_BUCKETS;
+  uint32_t* hist = L.hist; uint32_t* before = L.before; uint32_t* wsum = L.wsum;   // (`before` becomes the buckets' first positions)
+  uint32_t* cand = L.aux; uint32_t& ncand = L.small[0]; uint32_t& nitems = L.small[1]; uint32_t& nsplit_base = L.small[2];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   // a builder keeps the buckets of ITS share of the tiles (the only ones it places) in LDS: 1024 entries at 1080p, so the
   // kernel's LDS stays at the 4 KB of a sort chunk and 16 of its workgroups fit a CU instead of 7 (with all 8192 buckets
@@ -330,7 +451,13 @@ __global__ __launch_bounds__(HGS_BLOCK) void sort_tiles_kernel(int gx, int T, ui
   constexpr int SK_WORDS = SORT_CAP > 256 ? SORT_CAP : 256;
   __shared__ uint64_t sk[SK_WORDS];
   constexpr int KPT = SORT_CAP / HGS_BLOCK;
-  if (blockIdx.x < WL_BUILDERS) { work_list_block(T, Rcap, pol, im, b, (uint16_t*)sk, SK_WORDS * 4); return; }
+  if (blockIdx.x < WL_BUILDERS) {
+    const int share_w = ((T + WL_BUILDERS - 1) / WL_BUILDERS + HGS_BLOCK - 1) / HGS_BLOCK * HGS_BLOCK;
+    __shared__ WlLds wl;
+    if (share_w <= SK_WORDS * 4) work_list_shared(T, Rcap, pol, im, b, (uint16_t*)sk, wl);
+    else work_list_block(T, Rcap, pol, im, b, (uint16_t*)sk, SK_WORDS * 4, wl);
+    return;
+  }
   if ((int)blockIdx.x >= T + WL_BUILDERS) {
     // ---- one chunk of a long list (work items from the scan: hgs_emit_sort_items)
     const uint32_t j = blockIdx.x - (uint32_t)T - WL_BUILDERS;

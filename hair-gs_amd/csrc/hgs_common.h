@@ -37,7 +37,7 @@ struct HgsGeom {
 };
 struct HgsImage {
   float* final_T; uint32_t* n_contrib; uint2* ranges; uint32_t* tile_count; uint32_t* tile_cursor;
-  uint32_t* tile_maxc; uint32_t* status; uint32_t* tile_order;
+  uint32_t* tile_maxc; uint32_t* status; uint32_t* tile_order; uint32_t* wl_exchange;
   uint32_t tile_mask;   // slots of tile_count / tile_cursor - 1 (hgs_tile_slot)
   // long tile lists (hgs_binning.hip / hgs_blend.hip): per-tile ticket of finished blend segments, bit masks of published
   // blend segments / sorted chunks (bit 63: the list is handled by several workgroups), chunk work items of the sort
@@ -57,7 +57,12 @@ struct HgsBinning {
 // status words of the image buffer (HGS_IMG_STATUS)
 // ([4..7] are read as ONE 16-byte scalar load by every blend workgroup)
 enum { HGS_ST_R = 0, HGS_ST_OVERFLOW = 1, HGS_ST_SCANPTR_LO = 2, HGS_ST_SCANPTR_HI = 3, HGS_ST_SORT_ITEMS = 4,
-       HGS_ST_SPLIT_ITEMS = 5, HGS_ST_SEG_LEN = 6, HGS_ST_WORK_ITEMS = 7, HGS_ST_TIMEOUT = 8, HGS_ST_SCAN_DONE = 9 };
+       HGS_ST_SPLIT_ITEMS = 5, HGS_ST_SEG_LEN = 6, HGS_ST_WORK_ITEMS = 7, HGS_ST_TIMEOUT = 8, HGS_ST_SCAN_DONE = 9,
+       HGS_ST_WL_TICKET = 10, HGS_ST_WL_NCAND = 11, HGS_ST_WL_NSEG = 12 };   // exchange of the sort kernel's work-list builders
+#define HGS_WL_BUILDERS 8        // work-list builder workgroups of the sort kernel
+#define HGS_WL_BUCKETS 512       // list-length buckets of the blend work list's order
+#define HGS_WL_MAX_CAND 4096     // long lists a frame can have split
+#define HGS_WL_EXCHANGE_WORDS (HGS_WL_BUILDERS * 2 * HGS_WL_BUCKETS + HGS_WL_MAX_CAND)
 #ifndef HGS_SORT_CAP
 #define HGS_SORT_CAP 512         // keys of one sort chunk = one workgroup (measured on the Stage-I workload: 2048 -> 65 us, 1024 -> 39 us, 512 -> 29 us for the sort kernel; no effect where lists are short)
 #endif
@@ -131,6 +136,7 @@ static inline size_t hgs_image_carve(char* base, size_t W, size_t H, HgsImage& i
   // the blend kernels' work list (sort_tiles_kernel): workgroup -> tile | segment << 24; segments of split lists first,
   // then the other tiles in descending order of list length.  T + HGS_SPLIT_CAPACITY(T) entries.
   hgs_carve(cur, im.tile_order, T + HGS_SPLIT_CAPACITY(T));  if (offs) offs[HGS_IMG_TILE_ORDER] = (char*)im.tile_order - base;
+  hgs_carve(cur, im.wl_exchange, HGS_WL_EXCHANGE_WORDS);    // what the work-list builders of the sort kernel tell each other
   return hgs_align_up((size_t)(cur - base)) + HGS_ALIGN;
 }
 static inline size_t hgs_binning_carve(char* base, size_t R, HgsBinning& b, size_t* offs, int channels = 3) {
