@@ -14,7 +14,10 @@ namespace {
 
 #define ADAM_MAX_TENSORS 8
 
-#define ADAM_ELEMS_PER_BLOCK 2048   // 256 threads x 2 float4
+// Elements per workgroup: every workgroup ends with a returning atomic on its tensor's ticket, and those serialise -- measured
+// (same box) 1024 / 2048 / 4096 / 8192 / 16384 elements: 15.1 / 10.3 / 9.6 / 11.7 / 18.5 us at 100 k strand-Gaussians (0.9 M
+// elements: 8192 leaves CUs idle), 109 / 62.6 / 45.2 / 42.7 / 47.2 us at 1 M (9 M elements)
+static inline unsigned adam_elems_per_block(unsigned long long total) { return total > (6ull << 20) ? 8192u : 4096u; }
 
 struct AdamTensors {
   float* p[ADAM_MAX_TENSORS];
@@ -26,6 +29,7 @@ struct AdamTensors {
   unsigned long long numel[ADAM_MAX_TENSORS];
   unsigned int blk_start[ADAM_MAX_TENSORS + 1];   // prefix of the tensors' workgroup counts
   unsigned int vec4;                              // bit k: tensor k's four arrays are 16-byte aligned
+  unsigned int elems;                             // elements per workgroup (multiple of 1024)
   int n;
 };
 
@@ -48,15 +52,18 @@ __global__ __launch_bounds__(256) void adam_kernel(AdamTensors t, float beta1, f
   const float bc1 = 1.f - powf(beta1, step), bc2 = 1.f - powf(beta2, step);
   const float step_size = *t.lr[k] / bc1, inv_sqrt_bc2 = 1.f / sqrtf(bc2), one_m_b1 = 1.f - beta1;
   const unsigned long long n = t.numel[k];
-  const unsigned long long base = (unsigned long long)(blockIdx.x - t.blk_start[k]) * ADAM_ELEMS_PER_BLOCK;
+  const unsigned long long base = (unsigned long long)(blockIdx.x - t.blk_start[k]) * t.elems;
   float* __restrict__ P = t.p[k];
   const float* __restrict__ G = t.g[k];
   float* __restrict__ M = t.m[k];
   float* __restrict__ V = t.v[k];
   if ((t.vec4 >> k) & 1u) {
-#pragma unroll
-    for (int u = 0; u < ADAM_ELEMS_PER_BLOCK / 1024; u++) {
+    // (two float4 of each array in flight per thread and trip; more workgroups of fewer elements cost more than they hide:
+    // every workgroup ends with a returning atomic on its tensor's ticket)
+#pragma unroll 2
+    for (unsigned u = 0; u < t.elems / 1024u; u++) {
       const unsigned long long e = base + (unsigned long long)u * 1024 + threadIdx.x * 4;
+      if (e >= n) break;
       if (e + 3 < n) {
         float4 p = *(float4*)(P + e), m = *(float4*)(M + e), v = *(float4*)(V + e);
         const float4 g = *(const float4*)(G + e);
@@ -74,7 +81,7 @@ __global__ __launch_bounds__(256) void adam_kernel(AdamTensors t, float beta1, f
       }
     }
   } else {
-    for (unsigned long long i = base + threadIdx.x; i < n && i < base + ADAM_ELEMS_PER_BLOCK; i += 256) {
+    for (unsigned long long i = base + threadIdx.x; i < n && i < base + t.elems; i += 256) {
       float p = P[i], m = M[i], v = V[i];
       adam_one(p, G[i], m, v, one_m_b1, beta2, step_size, inv_sqrt_bc2, eps);
       P[i] = p; M[i] = m; V[i] = v;
@@ -134,6 +141,9 @@ int hgs_adam_step(void* stream, int n_tensors, float* const* params, const float
   t.n = n_tensors;
   t.blk_start[0] = 0;
   t.vec4 = 0;
+  unsigned long long total = 0;
+  for (int k = 0; k < n_tensors; k++) total += numel[k] > 0 ? (unsigned long long)numel[k] : 0ull;
+  t.elems = adam_elems_per_block(total);
   for (int k = 0; k < n_tensors; k++) {
     if (!params[k] || !grads[k] || !exp_avg[k] || !exp_avg_sq[k] || !lr[k] || !step[k] || numel[k] <= 0) {
       hgs_set_error("hgs_adam_step: null pointer or empty tensor %d", k);
@@ -141,7 +151,7 @@ int hgs_adam_step(void* stream, int n_tensors, float* const* params, const float
     }
     t.p[k] = params[k]; t.g[k] = grads[k]; t.m[k] = exp_avg[k]; t.v[k] = exp_avg_sq[k]; t.lr[k] = lr[k]; t.step[k] = step[k];
     t.numel[k] = (unsigned long long)numel[k];
-    t.blk_start[k + 1] = t.blk_start[k] + (unsigned int)((t.numel[k] + ADAM_ELEMS_PER_BLOCK - 1) / ADAM_ELEMS_PER_BLOCK);
+    t.blk_start[k + 1] = t.blk_start[k] + (unsigned int)((t.numel[k] + t.elems - 1) / t.elems);
     if (!(((size_t)params[k] | (size_t)grads[k] | (size_t)exp_avg[k] | (size_t)exp_avg_sq[k]) & 15)) t.vec4 |= 1u << k;
   }
   for (int k = n_tensors; k < ADAM_MAX_TENSORS; k++) {
