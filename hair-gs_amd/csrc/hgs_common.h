@@ -59,7 +59,9 @@ struct HgsBinning {
 enum { HGS_ST_R = 0, HGS_ST_OVERFLOW = 1, HGS_ST_SCANPTR_LO = 2, HGS_ST_SCANPTR_HI = 3, HGS_ST_SORT_ITEMS = 4,
        HGS_ST_SPLIT_ITEMS = 5, HGS_ST_SEG_LEN = 6, HGS_ST_WORK_ITEMS = 7, HGS_ST_TIMEOUT = 8, HGS_ST_SCAN_DONE = 9,
        HGS_ST_WL_TICKET = 10, HGS_ST_WL_NCAND = 11, HGS_ST_WL_NSEG = 12 };   // exchange of the sort kernel's work-list builders
+#ifndef HGS_WL_BUILDERS
 #define HGS_WL_BUILDERS 8        // work-list builder workgroups of the sort kernel
+#endif
 #define HGS_WL_BUCKETS 512       // list-length buckets of the blend work list's order
 #define HGS_WL_MAX_CAND 4096     // long lists a frame can have split
 #define HGS_WL_EXCHANGE_WORDS (HGS_WL_BUILDERS * 2 * HGS_WL_BUCKETS + HGS_WL_MAX_CAND)
