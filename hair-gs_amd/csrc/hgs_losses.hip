@@ -206,7 +206,9 @@ __device__ __forceinline__ bool ssim_block(const SsimGrid& gd, int j, SsimBlock&
   o.bx0 = (r - by * gd.nbx) * LT;
   return true;
 }
+#ifndef SSIM_SUBBANDS
 #define SSIM_SUBBANDS 32
+#endif
 static inline SsimGrid ssim_grid(int C, int H, int W) {
   SsimGrid gd;
   gd.nbx = (W + LT - 1) / LT; gd.nby = (H + LT - 1) / LT; gd.C = C;
