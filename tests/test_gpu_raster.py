@@ -39,6 +39,9 @@ VARIANTS = {
     # 145 x 121 = 17545 tiles (> 16384: the scan kernel's chunked path) and footprints of hundreds of tiles (the direct
     # global-atomic path of the counting / scatter kernels)
     "many_tiles": dict(P=400, W=2320, H=1936, seed=13, sh_degree=1),
+    # 160 x 90 = 14400 tiles: the largest share (2048 tiles per builder) the work-list builders still keep in LDS, i.e. the
+    # form that shares the counting; many_tiles is the single-builder form
+    "qhd_tiles": dict(P=400, W=2560, H=1440, seed=14, sh_degree=0),
 }
 
 
@@ -134,7 +137,7 @@ def test_forward_matches_oracle(name):
     _check_forward(name)
 
 
-@pytest.mark.parametrize("name", ["strands", "dense_long_lists", "medium_lists", "many_tiles", "all_culled", "one_huge_tile"])
+@pytest.mark.parametrize("name", ["strands", "dense_long_lists", "medium_lists", "many_tiles", "qhd_tiles", "all_culled", "one_huge_tile"])
 def test_blend_work_list_covers_every_tile_once(name):
     """The blend kernels' work list (sort_tiles_kernel): split lists as consecutive ascending segments that tile the list
     exactly, every other tile exactly once in tile_order with list lengths (capped at 511) non-increasing."""
