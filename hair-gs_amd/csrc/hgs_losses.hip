@@ -537,8 +537,9 @@ __device__ __forceinline__ bool ori_pixel(const OriParams& p, float o0, float o1
   py = o0 * v[1] + o1 * v[5] + o2 * v[9];
   r = sqrtf(px * px + py * py);
   n = r + p.min_val;
-  x = px / n;
-  y = py / n;
+  const float in = __builtin_amdgcn_rcpf(n);    // (hardware reciprocals, 1 ulp, here and in the gradient: the per-pixel kernel is
+  x = px * in;                                  //  bound by its vector instructions -- 357 per wavefront, 63 % of the pipe -- and an
+  y = py * in;                                  //  IEEE division is ten of them)
   yq = y < p.min_val ? y + p.min_val : y;
   theta = atan2f(x, yq);
   if (theta < 0.f) theta += 3.14159265358979323846f;
@@ -616,9 +617,9 @@ __device__ __forceinline__ void ori_pixel_grad(const OriParams& p, float px, flo
   const float u = fabsf(e) - hp;
   const float sg = (u > 0.f ? 1.f : (u < 0.f ? -1.f : 0.f)) * (e > 0.f ? 1.f : (e < 0.f ? -1.f : 0.f));
   const float dth = -sg * conf * scale;                               // dL/dtheta
-  const float den = x * x + yq * yq;
-  const float dx = dth * (yq / den), dy = dth * (-x / den);           // atan2(x, yq)
-  const float inv_n = 1.f / n, inv_n2 = inv_n * inv_n, ir = 1.f / r;  // x = px/n, y = py/n, n = r + eps
+  const float iden = __builtin_amdgcn_rcpf(x * x + yq * yq);
+  const float dx = dth * (yq * iden), dy = dth * (-x * iden);         // atan2(x, yq)
+  const float inv_n = __builtin_amdgcn_rcpf(n), inv_n2 = inv_n * inv_n, ir = __builtin_amdgcn_rcpf(r);  // x = px/n, y = py/n, n = r + eps
   const float dn = -(dx * px + dy * py) * inv_n2;
   const float dpx = dx * inv_n + dn * px * ir, dpy = dy * inv_n + dn * py * ir;
   const float* v = p.view;
@@ -786,9 +787,10 @@ __global__ __launch_bounds__(256) void pix_fwd_kernel(int N, HeadFlags fl, float
     float gm = 0.f, g0 = 0.f, g1 = 0.f, g2 = 0.f;
     if (fl.bce) {
       const float x = xm, y = ym;
-      const float en = expf(-fabsf(x));
-      b = fmaxf(x, 0.f) - x * y + log1pf(en);
-      if (d_unit) gm = g_mask * ((x >= 0.f ? 1.f / (1.f + en) : en / (1.f + en)) - y);   // sigmoid(x) - y
+      // (hardware exp2 / log2: en in (0, 1], so log(1 + en) is within 1e-7 absolute of log1p(en) -- of a term of order 0.1-1)
+      const float en = __expf(-fabsf(x));
+      b = fmaxf(x, 0.f) - x * y + __logf(1.f + en);
+      if (d_unit) { const float r1 = __builtin_amdgcn_rcpf(1.f + en); gm = g_mask * ((x >= 0.f ? r1 : en * r1) - y); }   // sigmoid(x) - y
     }
     if (fl.ori) {
       OriParams p;

@@ -14,6 +14,7 @@ opt = OptimizationParams(); opt.enable_topology = False
 model.training_setup(opt)
 bg = torch.zeros(3, device="cuda")
 fused = fused_step_for(model, ViewTable(cams), opt, bg)
+fused.defer_tail = True   # (as the captured iteration: no launch for the loss head's tail)
 for it in range(1, n + 1):
     training_step(model, cams[it % len(cams)], opt, bg, it, extent=extent, fused=fused)
 torch.cuda.synchronize()
