@@ -35,8 +35,9 @@ The JSON line also carries
   cpu_baseline  the CPU oracle (oracle/, OpenMP C restatement of the reference rasterizer) doing the 3 raster fwd+bwd
                 passes of one iteration on the host cores, plus -- `cpu_only_paths` -- the reference's CPU-only paths
                 timed in the same run on the same cores: c_utils.filter_strand_list_segments (this package's native
-                module, and the reference's own Cython build when oracle/_ref/ holds it) and the strand metrics of
-                eval.py (loss/metrics.py compute_metrics).  Rank 0, N=1 only, bounded samples.
+                module; the reference's own Cython build is timed in the authoring container only, BASELINE.md
+                B2: nothing compiled from the reference travels) and the strand metrics of eval.py
+                (loss/metrics.py compute_metrics).  Rank 0, N=1 only, bounded samples.
 """
 import argparse
 import json
@@ -129,13 +130,6 @@ def cpu_only_paths():
         return sorted(ts)[n // 2]
     out["filter_strand_list_segments_ms"] = med(lambda: c_utils.filter_strand_list_segments(strands)) * 1e3
     out["filter_strand_list_segments_sample"] = f"{S} strands x 100 segments, 1 core (native CPython extension)"
-    try:
-        from oracle import build_ref
-        ref = build_ref.load()
-        if ref is not None:
-            out["filter_strand_list_segments_reference_cython_ms"] = med(lambda: ref.filter_strand_list_segments(strands)) * 1e3
-    except Exception as e:
-        out["reference_cython_error"] = str(e)
     n_str = 500
     sp = strand_polylines(n_str, 100, seed=0)
     mid = 0.5 * (sp[:, 1:] + sp[:, :-1]).reshape(-1, 3)
@@ -282,7 +276,6 @@ def main():
         with torch.no_grad():
             for t, s_ in zip(state_tensors, snapshot):
                 t.copy_(s_)
-        model._derived = None
         it = it0
         sampler.rng.seed(12345)
         sampler.stack = []

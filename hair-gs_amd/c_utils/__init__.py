@@ -31,12 +31,35 @@ def build(force=False):
     return so
 
 
+class _NumpyFallback:
+    """The numpy forms below behind the native module's two names -- only where the extension can neither be found nor
+    built (no gcc): a HOST-side helper of the strand bookkeeping, not part of the GPU path (which has no fallback)."""
+
+    @staticmethod
+    def filter_strand_segments_flat(offsets, rows):
+        return filter_strand_segments_flat_numpy(np.asarray(offsets, np.int64), np.asarray(rows, np.int64).reshape(-1, 2))
+
+    @staticmethod
+    def filter_strand_list_segments(strands_list):
+        return filter_strand_segments_flat_numpy(*strands_to_flat(strands_list))
+
+
 def _load():
+    """The native module; built on first use when the .so is missing or older than its source (it is git-ignored: a fresh
+    checkout of a CPU-only environment has none until something builds it)."""
     global _native
     if _native is None:
+        src = os.path.join(_HERE, "_c_utils.c")
         so = glob.glob(os.path.join(_HERE, "_c_utils*.so"))
-        if not so:
-            raise ImportError(f"{_HERE}/_c_utils*.so not found: run hgs_runtime.build() (or c_utils.build())")
+        if not so or os.path.getmtime(so[0]) < os.path.getmtime(src):
+            try:
+                so = [build()]
+            except (OSError, subprocess.CalledProcessError) as e:
+                if not so:
+                    import warnings
+                    warnings.warn(f"c_utils: native module not built ({e}); using the numpy form")
+                    _native = _NumpyFallback
+                    return _native
         import importlib.util
         spec = importlib.util.spec_from_file_location("c_utils._c_utils", so[0])
         mod = importlib.util.module_from_spec(spec)

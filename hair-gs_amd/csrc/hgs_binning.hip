@@ -461,6 +461,10 @@ __global__ __launch_bounds__(HGS_BLOCK) void sort_tiles_kernel(int gx, int T, ui
   if ((int)blockIdx.x >= T + WL_BUILDERS) {
     // ---- one chunk of a long list (work items from the scan: hgs_emit_sort_items)
     const uint32_t j = blockIdx.x - (uint32_t)T - WL_BUILDERS;
+    // A pass that overflowed the binning capacity is void as a whole (status[1]; its backward returns zeros), and its chunk
+    // items may outnumber the workgroups this launch was sized for (2 Rcap / SORT_CAP): a chunk whose sibling has no
+    // workgroup would spin out its bounded wait -- seconds of GPU time -- and turn a recoverable overflow into a timeout.
+    if (im.status[HGS_ST_R] > Rcap) return;
     if (j >= min(im.status[HGS_ST_SORT_ITEMS], (uint32_t)T)) return;
     const uint32_t item = im.sort_items[j];
     if (item == HGS_ITEM_NONE) return;

@@ -31,9 +31,11 @@ struct AdamTensors {
   unsigned int vec4;                              // bit k: tensor k's four arrays are 16-byte aligned
   unsigned int elems;                             // elements per workgroup (multiple of 1024)
   int n;
+  unsigned int* ticket;                           // [ADAM_MAX_TENSORS] words owned by the optimizer (zero between launches)
 };
 
-__device__ unsigned int g_adam_ticket[ADAM_MAX_TENSORS] = {};   // launches of adam_kernel are stream-ordered within a process (one optimizer)
+// fallback ticket words for callers that pass none (tickets == NULL): launches that share them must be stream-ordered
+__device__ unsigned int g_adam_ticket[ADAM_MAX_TENSORS] = {};
 
 __device__ __forceinline__ void adam_one(float& p, float g, float& m, float& v, float one_m_b1, float beta2, float step_size,
                                          float inv_sqrt_bc2, float eps) {
@@ -87,13 +89,16 @@ __global__ __launch_bounds__(256) void adam_kernel(AdamTensors t, float beta1, f
       P[i] = p; M[i] = m; V[i] = v;
     }
   }
-  // Step counter of this tensor: every workgroup of the tensor has read it by the time it takes a ticket, so the one that
-  // takes the last ticket may advance it (a second launch only for that cost 4 us per iteration; one ticket per tensor:
-  // a single counter for the whole grid serialised ~1200 atomics on one address, 5 us).  atomicInc wraps the ticket back
-  // to 0: nothing to reset between launches.
+  // Step counter of this tensor: the workgroup that takes the tensor's last ticket advances it (a second launch only for
+  // that cost 4 us per iteration; one ticket per tensor: a single counter for the whole grid serialised ~1200 atomics on
+  // one address, 5 us).  The barrier makes "took a ticket" imply "EVERY wavefront of this workgroup has read the counter"
+  // (thread 0 could otherwise run ahead of a sibling wavefront that has not loaded it yet), so the last ticket implies
+  // that every workgroup of the tensor has; the next reader is the next launch.  atomicInc wraps the ticket back to 0:
+  // nothing to reset between launches.
+  __syncthreads();
   if (threadIdx.x == 0) {
     const unsigned nblk = t.blk_start[k + 1] - t.blk_start[k];
-    if (atomicInc(&g_adam_ticket[k], nblk - 1) == nblk - 1) *t.step[k] = step;
+    if (atomicInc(&t.ticket[k], nblk - 1) == nblk - 1) *t.step[k] = step;
   }
 }
 
@@ -134,7 +139,7 @@ extern "C" {
 
 int hgs_adam_step(void* stream, int n_tensors, float* const* params, const float* const* grads, float* const* exp_avg,
                   float* const* exp_avg_sq, const float* const* lr, float* const* step, const long long* numel,
-                  float beta1, float beta2, float eps) {
+                  float beta1, float beta2, float eps, unsigned int* tickets) {
   if (n_tensors <= 0) return 0;
   if (n_tensors > ADAM_MAX_TENSORS) { hgs_set_error("hgs_adam_step: at most %d tensors per call", ADAM_MAX_TENSORS); return 1; }
   AdamTensors t;
@@ -157,6 +162,11 @@ int hgs_adam_step(void* stream, int n_tensors, float* const* params, const float
   for (int k = n_tensors; k < ADAM_MAX_TENSORS; k++) {
     t.p[k] = nullptr; t.g[k] = nullptr; t.m[k] = nullptr; t.v[k] = nullptr; t.lr[k] = nullptr; t.step[k] = nullptr;
     t.numel[k] = 0; t.blk_start[k + 1] = t.blk_start[n_tensors];
+  }
+  t.ticket = tickets;
+  if (!tickets && hipGetSymbolAddress((void**)&t.ticket, HIP_SYMBOL(g_adam_ticket)) != hipSuccess) {
+    hgs_set_error("hgs_adam_step: no ticket words");
+    return 1;
   }
   hipStream_t s = (hipStream_t)stream;
   {

@@ -10,7 +10,7 @@ from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianR
 def render(viewpoint_camera, pc, bg_color, scaling_modifier=1.0, override_color=None, debug=False,
            compute_cov3D_python=False, convert_SHs_python=False):
     """Render the scene.  `bg_color` must live on the GPU."""
-    xyz = pc.get_xyz
+    xyz, scales_d, rotations_d = _geometry(pc)
     # zero tensor whose gradient receives dL/d(screen-space mean) (reference :41-50), read by the densification stats
     screenspace_points = torch.zeros_like(xyz, dtype=xyz.dtype, requires_grad=True, device=xyz.device) + 0
     try:
@@ -30,7 +30,7 @@ def render(viewpoint_camera, pc, bg_color, scaling_modifier=1.0, override_color=
     if compute_cov3D_python:
         cov3D_precomp = pc.get_covariance(scaling_modifier)
     else:
-        scales, rotations = pc.get_scaling, pc.get_rotation
+        scales, rotations = scales_d(), rotations_d()
 
     shs = colors_precomp = None
     if override_color is None:
@@ -53,6 +53,17 @@ def render(viewpoint_camera, pc, bg_color, scaling_modifier=1.0, override_color=
             "radii": radii}
 
 
+def _geometry(pc):
+    """(means, scaling getter, rotation getter) of one parameter state.  A strand model derives all of them from its
+    endpoints with one kernel (HairGaussianModel.derived_gaussians); the model itself keeps no derived state, so the
+    bundle lives exactly as long as this render call (the reference recomputes per getter call,
+    scene/hair_gaussian_model.py:134-172)."""
+    bundle = pc.derived_gaussians() if hasattr(pc, "derived_gaussians") else None
+    if bundle is None:
+        return pc.get_xyz, (lambda: pc.get_scaling), (lambda: pc.get_rotation)
+    return bundle[0], (lambda: bundle[1]), (lambda: bundle[2])
+
+
 _BG7 = {}
 
 
@@ -61,7 +72,7 @@ def render_multi(viewpoint_camera, pc, bg_color, extra4, scaling_modifier=1.0, d
     render(..., override_color=extra) on a black background, which is how the reference's mask and orientation losses
     obtain their images (loss/losses.py:247,312).  Returns render()'s dict + "extra": one tensor per entry of `splits`
     ((4,) -> a single [4,H,W] tensor; (1,3) -> ([H,W], [3,H,W]))."""
-    xyz = pc.get_xyz
+    xyz, scales_d, rotations_d = _geometry(pc)
     screenspace_points = torch.zeros_like(xyz, dtype=xyz.dtype, requires_grad=True, device=xyz.device) + 0
     try:
         screenspace_points.retain_grad()
@@ -79,7 +90,7 @@ def render_multi(viewpoint_camera, pc, bg_color, extra4, scaling_modifier=1.0, d
         campos=viewpoint_camera.camera_center, prefiltered=False, debug=debug)
     out = GaussianRasterizer(raster_settings=raster_settings).forward_multi(
         means3D=xyz, means2D=screenspace_points, opacities=pc.get_opacity, extra4=extra4, shs=pc.get_features,
-        scales=pc.get_scaling, rotations=pc.get_rotation, splits=splits)
+        scales=scales_d(), rotations=rotations_d(), splits=splits)
     rgb, radii, extras = out[0], out[1], out[2:]
     return {"render": rgb, "extra": extras[0] if len(extras) == 1 else extras, "viewspace_points": screenspace_points,
             "visibility_filter": radii > 0, "radii": radii}

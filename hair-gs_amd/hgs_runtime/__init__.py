@@ -43,7 +43,7 @@ SIGNATURES = {
     "hgs_orientation_loss_num_blocks": (ci, [ci, ci]),
     "hgs_orientation_loss_forward": (ci, [vp, ci, ci, vp, vp, vp, cf, vp, vp, vp, vp]),
     "hgs_orientation_loss_backward": (ci, [vp, ci, ci, vp, vp, vp, cf, vp, vp, vp, vp, vp, vp]),
-    "hgs_adam_step": (ci, [vp, ci, vp, vp, vp, vp, vp, vp, vp, cf, cf, cf]),
+    "hgs_adam_step": (ci, [vp, ci, vp, vp, vp, vp, vp, vp, vp, cf, cf, cf, vp]),
     "hgs_smoothness_num_blocks": (ci, [ci]),
     "hgs_smoothness_forward": (ci, [vp, ci, vp, vp, cf, cf, vp]),
     "hgs_smoothness_backward": (ci, [vp, ci, ci, vp, vp, cf, cf, vp, vp, vp]),
@@ -130,6 +130,7 @@ VIEW_QUEUE_MAX = 16   # include/hgs.h HGS_VIEW_QUEUE_MAX
 HEAD_OUT = ["total", "l1", "dssim", "mask", "orientation", "smooth", "ori_count", "smooth_count", "g_ssim", "g_l1", "g_mask",
             "g_ori", "g_smooth", "total_fwd"]
 HEAD_NOUT = 16
+ABI_VERSION = 3   # include/hgs.h HGS_ABI_VERSION: bumped whenever a struct, a signature or a buffer layout changes
 
 
 def build(verbose=False):
@@ -155,8 +156,15 @@ def lib():
             fn = getattr(L, name)
             fn.restype = res
             fn.argtypes = args
-        if L.hgs_abi_version() != 1:
-            raise HgsError("libhgs.so ABI version mismatch")
+        # a stale library called through newer struct layouts corrupts memory: refuse it (version AND struct sizes)
+        if L.hgs_abi_version() != ABI_VERSION:
+            raise HgsError(f"{LIB_PATH}: ABI version {L.hgs_abi_version()}, this binding needs {ABI_VERSION}: "
+                           "rebuild with hgs_runtime.build()")
+        for fn, st in (("hgs_view_targets_bytes", ViewTargets), ("hgs_head_params_bytes", HeadParams),
+                       ("hgs_strand_fusion_bytes", StrandFusion)):
+            if getattr(L, fn)() != C.sizeof(st):
+                raise HgsError(f"{LIB_PATH}: {fn}() = {getattr(L, fn)()} but the binding's struct has {C.sizeof(st)} bytes: "
+                               "rebuild with hgs_runtime.build()")
         _lib = L
     return _lib
 

@@ -22,7 +22,7 @@ def gaussian_window11():
 
 class _StrandGeometry(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, endpoints, width, pairs, factor, owner):
+    def forward(ctx, endpoints, width, pairs, factor):
         endpoints = rt.require_gpu_tensor(endpoints, "endpoints", torch.float32)
         width = rt.require_gpu_tensor(width, "width", torch.float32)
         pairs = rt.require_gpu_tensor(pairs, "endpoint_pairs", torch.int64)
@@ -36,14 +36,12 @@ class _StrandGeometry(torch.autograd.Function):
                                                           rt.ptr(width), float(factor), rt.ptr(xyz), rt.ptr(scale),
                                                           rt.ptr(quat), rt.ptr(direction)))
         ctx.save_for_backward(endpoints, width, pairs)
-        ctx.factor, ctx.owner = float(factor), owner
+        ctx.factor = float(factor)
         return xyz, scale, quat, direction
 
     @staticmethod
     def backward(ctx, g_xyz, g_scale, g_quat, g_dir):
         endpoints, width, pairs = ctx.saved_tensors
-        if ctx.owner is not None:
-            ctx.owner._derived = None  # the graph behind the cached tensors is gone after this call
         P, E, dev = pairs.shape[0], endpoints.shape[0], endpoints.device
         gs = [None if g is None else g.contiguous() for g in (g_xyz, g_scale, g_quat, g_dir)]
         d_ep = torch.empty((E, 3), dtype=torch.float32, device=dev)
@@ -52,12 +50,12 @@ class _StrandGeometry(torch.autograd.Function):
             rt.check(rt.lib().hgs_strand_geometry_backward(rt.current_stream(), P, E, rt.ptr(endpoints), rt.ptr(pairs),
                                                            rt.ptr(width), ctx.factor, rt.ptr(gs[0]), rt.ptr(gs[1]),
                                                            rt.ptr(gs[2]), rt.ptr(gs[3]), rt.ptr(d_ep), rt.ptr(d_w)))
-        return d_ep, d_w, None, None, None
+        return d_ep, d_w, None, None
 
 
-def strand_geometry(endpoints, width, pairs, factor, owner=None):
+def strand_geometry(endpoints, width, pairs, factor):
     """(xyz[P,3], scale[P,3], quat[P,4], direction[P,3]) of every segment, differentiable w.r.t. endpoints/width."""
-    return _StrandGeometry.apply(endpoints, width, pairs, factor, owner)
+    return _StrandGeometry.apply(endpoints, width, pairs, factor)
 
 
 class _SsimL1(torch.autograd.Function):
@@ -183,6 +181,7 @@ class FusedAdam(torch.optim.Optimizer):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
         self._lr_dev = {}
         self._call = None
+        self._tickets = None   # the kernel's per-tensor ticket words: owned by this optimizer (include/hgs.h hgs_adam_step)
 
     def _state_for(self, p):
         st = self.state[p]
@@ -227,11 +226,13 @@ class FusedAdam(torch.optim.Optimizer):
             numel = (C.c_longlong * n)(*[r[0].numel() for r in rows])
             self._call = (key, n, arrs, numel)
         _, n, arrs, numel = self._call
-        with torch.cuda.device(rows[0][0].device):
+        dev = rows[0][0].device
+        if self._tickets is None or self._tickets.device != dev:
+            self._tickets = torch.zeros(8, dtype=torch.int32, device=dev)
+        with torch.cuda.device(dev):
             rt.check(rt.lib().hgs_adam_step(rt.current_stream(), n, arrs[0], arrs[1], arrs[2], arrs[3], arrs[4], arrs[5],
-                                            numel, float(beta1), float(beta2), float(eps)))
-        # the kernel wrote the parameters through raw pointers: tell autograd (and every cache keyed on tensor versions,
-        # e.g. HairGaussianModel._derived) that they changed in place
+                                            numel, float(beta1), float(beta2), float(eps), self._tickets.data_ptr()))
+        # the kernel wrote the parameters through raw pointers: tell autograd that they changed in place
         for r in rows:
             torch.autograd.graph.increment_version(r[0])
         return None

@@ -68,10 +68,13 @@ class GaussianModel:
         self.active_sh_degree = model_args[0]
         for a, v in zip(attrs, model_args[1:1 + len(attrs)]):
             setattr(self, a, v)
-        self.max_radii2D, grad_accum, denom, opt_dict, self.spatial_lr_scale = model_args[1 + len(attrs):]
-        self.training_setup(training_args)
-        self.xyz_gradient_accum, self.denom = grad_accum, denom
+        max_radii2D, grad_accum, denom, opt_dict, self.spatial_lr_scale = model_args[1 + len(attrs):]
+        # The checkpoint's Adam moments and statistics are in the checkpoint's order: set up WITHOUT the spatial sort,
+        # attach them, and only then re-order -- one permutation moves parameters, moments and statistics together.
+        self.training_setup(training_args, sort=False)
+        self.max_radii2D, self.xyz_gradient_accum, self.denom = max_radii2D, grad_accum, denom
         self.optimizer.load_state_dict(opt_dict)
+        self._maybe_sort_spatially()
 
     # ---- rasterizer-facing getters (reference :118-157) ----
     @property
@@ -181,7 +184,8 @@ class GaussianModel:
         self.denom = torch.zeros((n, 1), device=self.device)
         self.max_radii2D = torch.zeros((n,), device=self.device)
 
-    def training_setup(self, training_args):
+    def training_setup(self, training_args, sort=True):
+        """sort=False: keep the storage order (restore(): the checkpoint's optimizer state is attached first)."""
         n = self._num_primitives()
         self.xyz_gradient_accum = torch.zeros((n, 1), device=self.device)
         self.denom = torch.zeros((n, 1), device=self.device)
@@ -194,7 +198,8 @@ class GaussianModel:
             lr_delay_mult=training_args.position_lr_delay_mult, max_steps=training_args.position_lr_max_steps)
         self.set_pval(training_args.pval)
         self.training_args = training_args
-        self._maybe_sort_spatially()
+        if sort:
+            self._maybe_sort_spatially()
 
     def update_learning_rate(self, iteration):
         for group in self.optimizer.param_groups:

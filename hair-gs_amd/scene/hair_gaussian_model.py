@@ -244,9 +244,10 @@ class HairGaussianModel(HairTopologyMixin, GaussianModel):
                                     "_features_dc", "_features_rest", "_opacity", "_mask", "_width")]
 
     # ---- derived Gaussian parameters -------------------------------------------------------
-    # On the GPU the four derived tensors come from ONE fused HIP kernel (hgs_strand_geometry_*), evaluated once per
-    # parameter state and shared by every getter call of the step (3 render passes + orientation colours); the
-    # cache is dropped when the parameters change (tensor version counters) or after its graph was back-propagated.
+    # On the GPU the four derived tensors come from ONE fused HIP kernel (hgs_strand_geometry_*).  Like the reference's
+    # getters (scene/hair_gaussian_model.py:134-201) they are recomputed from the parameters on EVERY call: nothing is
+    # cached on the model, so no write to the parameters -- optimizer step, `.data` mutation, raw-pointer kernel -- can
+    # ever be served stale geometry.  A caller that needs several of them (render()) asks `derived_gaussians()` once.
     # `fused_geometry = False` (or CPU tensors) selects the op-by-op PyTorch formulas below, which restate the
     # reference getters and are what the fused kernel is tested against.
     fused_geometry = True
@@ -255,22 +256,15 @@ class HairGaussianModel(HairTopologyMixin, GaussianModel):
         pairs = self._endpoints[self.endpoint_pairs]
         return pairs, pairs[:, 1] - pairs[:, 0]
 
-    def _derived_key(self):
-        return (id(self._endpoints), self._endpoints._version, id(self._width), self._width._version,
-                id(self.endpoint_pairs), float(self.dist_to_scale_factor), torch.is_grad_enabled())
-
-    def _fused(self):
+    def derived_gaussians(self):
+        """(xyz [P,3], scaling [P,3], rotation [P,4], orientation [P,3]) of the current parameters from one launch of the
+        fused geometry kernel (differentiable w.r.t. endpoints / width), or None where the op-by-op formulas apply."""
         if not (self.fused_geometry and self._endpoints.is_cuda):
             return None
-        key = self._derived_key()
-        cached = getattr(self, "_derived", None)
-        if cached is None or cached[0] != key:
-            from hgs_runtime.fused import strand_geometry
-            out = strand_geometry(self._endpoints, self._width, self.endpoint_pairs, float(self.dist_to_scale_factor),
-                                  owner=self if torch.is_grad_enabled() else None)
-            cached = (key, out)
-            self._derived = cached
-        return cached[1]
+        from hgs_runtime.fused import strand_geometry
+        return strand_geometry(self._endpoints, self._width, self.endpoint_pairs, float(self.dist_to_scale_factor))
+
+    _fused = derived_gaussians
 
     @property
     def get_scaling(self):
@@ -345,7 +339,7 @@ class HairGaussianModel(HairTopologyMixin, GaussianModel):
         return {"endpoints": ta.position_lr_init * self.spatial_lr_scale, "f_dc": ta.feature_lr,
                 "f_rest": ta.feature_lr / 20.0, "opacity": ta.opacity_lr, "mask": ta.mask_lr, "width": ta.scaling_lr}
 
-    def training_setup(self, training_args):
+    def training_setup(self, training_args, sort=True):
         """6 Adam groups + endpoint lr schedule + merge distance/angle schedules + max segment length
         (reference :212-283)."""
         n = self._num_primitives()
@@ -413,7 +407,6 @@ class HairGaussianModel(HairTopologyMixin, GaussianModel):
             "mask": new_masks, "width": new_widths}))
         self._reset_stats()
         self._smooth_pairs = None
-        self._derived = None
 
     def prune_segments(self, segments_prune_mask):
         """Drop segments; endpoints no segment references any more are dropped too and ids are compacted."""
@@ -434,7 +427,6 @@ class HairGaussianModel(HairTopologyMixin, GaussianModel):
         self.denom = self.denom[seg_keep]
         self.max_radii2D = self.max_radii2D[seg_keep]
         self._smooth_pairs = None
-        self._derived = None
 
     # ---- strand bookkeeping ----------------------------------------------------------------------
     def update_strand_root(self, dist_th: float = 1e-2):

@@ -131,6 +131,5 @@ def load_hair_ply(model, path):
     model.max_radii2D = torch.zeros((n,), device=dev)
     model.xyz_gradient_accum = torch.zeros((n, 1), device=dev)
     model.denom = torch.zeros((n, 1), device=dev)
-    model._derived = None
     model._smooth_pairs = None
     model.compute_strands_info()

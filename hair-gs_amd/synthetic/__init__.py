@@ -94,30 +94,58 @@ def make_cloud_model(P, seed=0, device="cuda", spatial_lr_scale=1.0, radius=0.12
     return m
 
 
-@torch.no_grad()
-def attach_targets(cams, model, seed=0, perturb=0.001):
-    """GT image = render of a perturbed copy of the model, GT mask = (alpha > 0), orientation ~ U[0,pi),
-    confidence ~ U[0,1] (SURVEY.md 8d 'Targets for the training step')."""
-    from gaussian_renderer import render
-    dev = model.get_xyz.device
+def perturbed_copy(model, seed=0, perturb=0.001):
+    """A shallow copy of the model whose positions (strand endpoints / cloud centres) are moved by N(0, perturb): the
+    synthetic ground truth.  The model itself is not touched (no `.data` writes on its parameters)."""
+    import copy
     g = torch.Generator(device="cpu").manual_seed(seed)
     pos_attr = "_endpoints" if hasattr(model, "_endpoints") and model._endpoints.numel() else "_xyz"
-    saved = getattr(model, pos_attr).data.clone()
-    getattr(model, pos_attr).data.add_(torch.randn(saved.shape, generator=g).to(dev) * perturb)
+    pos = getattr(model, pos_attr)
+    gt = copy.copy(model)
+    setattr(gt, pos_attr, (pos.detach() + torch.randn(pos.shape, generator=g).to(pos.device) * perturb).requires_grad_(False))
+    return gt, g
+
+
+def orientation_angles(omap, view, min_val):
+    """World-space direction image [3,H,W] -> angle in [0, pi) w.r.t. the image y axis, the map the orientation term
+    compares with the target field (reference loss/losses.py:250-268)."""
+    o = omap.permute(1, 2, 0).reshape(-1, 3)
+    pix = (o @ view[:3, :3])[:, :2]
+    pix = pix / (torch.norm(pix, dim=1, keepdim=True) + min_val)
+    x, y = pix[:, 0], pix[:, 1]
+    y = torch.where(y < min_val, y + min_val, y)
+    theta = torch.atan2(x, y)
+    return torch.where(theta < 0, theta + math.pi, theta).reshape(omap.shape[1], omap.shape[2])
+
+
+@torch.no_grad()
+def attach_targets(cams, model, seed=0, perturb=0.001, consistent=False):
+    """GT image = render of a perturbed copy of the model, GT mask = (alpha > 0), orientation ~ U[0,pi),
+    confidence ~ U[0,1] (SURVEY.md 8d 'Targets for the training step').
+    consistent=True: the orientation field is the projected direction of the GROUND-TRUTH strands (the perturbed copy's
+    blended direction image turned into angles exactly as the loss does) with confidence 1 -- targets a model can
+    converge to, for training-curve PSNR (SURVEY.md 8d 'PSNR')."""
+    from gaussian_renderer import render
+    dev = model.get_xyz.device
+    gt, g = perturbed_copy(model, seed=seed, perturb=perturb)
     bg = torch.zeros(3, device=dev)
     ones = torch.ones((model.get_xyz.shape[0], 3), device=dev)
     for cam in cams:
         H, W = cam.image_height, cam.image_width
-        cam.original_image = render(cam, model, bg)["render"].clamp(0, 1).detach()
-        alpha = render(cam, model, bg, override_color=ones)["render"][0]
+        cam.original_image = render(cam, gt, bg)["render"].clamp(0, 1).detach()
+        alpha = render(cam, gt, bg, override_color=ones)["render"][0]
         cam.mask = alpha > 0
         cam.float_mask = cam.mask.to(torch.float32)
-        cam.orientation_field = (torch.rand((H, W), generator=g) * math.pi).to(dev)
-        cam.orientation_confidence = torch.rand((H, W), generator=g).to(dev)
-    getattr(model, pos_attr).data.copy_(saved)
+        if consistent and hasattr(gt, "get_orientation"):
+            omap = render(cam, gt, bg, override_color=gt.get_orientation)["render"]
+            cam.orientation_field = orientation_angles(omap, cam.world_view_transform, gt.min_val).contiguous()
+            cam.orientation_confidence = torch.ones((H, W), device=dev)
+        else:
+            cam.orientation_field = (torch.rand((H, W), generator=g) * math.pi).to(dev)
+            cam.orientation_confidence = torch.rand((H, W), generator=g).to(dev)
 
 
-def build_workload(name, device="cuda", seed=0, with_targets=True, n_views=None):
+def build_workload(name, device="cuda", seed=0, with_targets=True, n_views=None, consistent=False):
     kind, kw, views, W, H = WORKLOADS[name]
     views = views if n_views is None else n_views
     cams = make_cameras(views, W, H, device=device)
@@ -128,5 +156,5 @@ def build_workload(name, device="cuda", seed=0, with_targets=True, n_views=None)
     else:
         model = make_cloud_model(seed=seed, device=device, spatial_lr_scale=extent, **kw)
     if with_targets:
-        attach_targets(cams, model, seed=seed)
+        attach_targets(cams, model, seed=seed, consistent=consistent)
     return model, cams, extent

@@ -292,7 +292,6 @@ class GraphedStep:
             loss, _ = self.fused.loss()
             self.fused.backward(loss)
             self.fused.update_densification_stats()
-            self.g._derived = None
             total = loss.detach().clone() if total is None else total + loss.detach()
         return total / self.views_per_step
 
@@ -334,7 +333,6 @@ class GraphedStep:
                 if self.vp.world > 1:
                     self.vp.pack_gradients(g)   # creates the flat exchange buffer outside the capture
                 g.optimizer.zero_grad(set_to_none=True)
-                g._derived = None
                 try:
                     raster.check_async()        # learns the capacity; an overflow here only raises it for the capture
                 except raster.HgsCapacityOverflow:
@@ -389,7 +387,6 @@ class GraphedStep:
             with torch.cuda.graph(gk, pool=ga.pool(), stream=s):
                 for j in range(K):
                     g.optimizer.zero_grad(set_to_none=True)   # (host side: this step's backward ASSIGNS its gradients)
-                    g._derived = None
                     v.prologue(j % v.n, lr=float(j), lr_dst=self._position_lr(), ride=self._ride)   # lr = j: the tag graph_bind sorts by
                     losses.append(fwd_bwd())
                     g.optimizer.step()
@@ -402,7 +399,6 @@ class GraphedStep:
             t.zero_()                       # the capture itself launched nothing
         raster._state["dirty"] = False
         raster._state["cap_used"] = None
-        g._derived = None
 
     def step(self, cam, iteration):
         """One optimizer step on `cam` (views_per_step > 1: on the list of this rank's views of the global batch);
@@ -425,7 +421,6 @@ class GraphedStep:
             if self.views_per_step > 1:
                 self._scale_gradients()
             self.g.optimizer.step()
-        self.g._derived = None  # cached derived tensors now hold pre-update values
         return self.loss_buf
 
     def step_many(self, cams, iteration):
@@ -440,7 +435,6 @@ class GraphedStep:
             self._set_lr(iteration + j)
             v.graph_set(binding, v.index[id(cam)], lr=self._lr_now, lr_dst=self._position_lr(), k=j)
         gk.replay()
-        self.g._derived = None
         return losses
 
     def headroom(self):

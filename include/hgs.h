@@ -42,7 +42,9 @@
 extern "C" {
 #endif
 
-#define HGS_ABI_VERSION 1
+/* bumped with every incompatible change of a struct, a signature or a buffer layout (round 1: 1, round 2: 2, round 3: 3);
+ * the Python binding refuses a library whose version or struct sizes differ from its own */
+#define HGS_ABI_VERSION 3
 #define HGS_TILE 16 /* cuda_rasterizer/config.h:16-17 */
 
 int hgs_abi_version(void);
@@ -167,14 +169,16 @@ int hgs_orientation_loss_backward(void* stream, int H, int W, const float* omap,
 /* hgs_adam_step <-> torch.optim.Adam(lr=0, eps=1e-15) as built at scene/gaussian_model.py:250 and
  *   scene/hair_gaussian_model.py:246: all parameter tensors (<= 8) updated by ONE launch.  The six arrays are HOST arrays
  *   of n_tensors DEVICE pointers; lr[k] and step[k] point to fp32 device scalars (step is incremented by the call, by
- *   the launch's last workgroup: calls of one process must be stream-ordered, not concurrent on two streams).
+ *   the workgroup that takes the tensor's last ticket).  tickets: 8 uint32 words in device memory owned by the optimizer,
+ *   zero before its first step (they return to zero at the end of every completed launch; an optimizer whose launch was
+ *   aborted zeroes them again).  NULL: process-wide words -- all such calls must then be stream-ordered.
  * hgs_smoothness_forward/backward <-> loss/losses.py:175-221 angle_smoothness_loss: index_pairs is the int64 [N,2,2]
  *   table of consecutive strand segments (endpoint ids); partials: 2 floats per 256 pairs (sum of squared angles of the
  *   pairs bent more than the threshold, their count); loss = sum0 / max(sum1, 1).  backward zeroes d_endpoints [E,3]
  *   and scatters with fp32 atomics (order-dependent in the last bits). */
 int hgs_adam_step(void* stream, int n_tensors, float* const* params, const float* const* grads, float* const* exp_avg,
                   float* const* exp_avg_sq, const float* const* lr, float* const* step, const long long* numel,
-                  float beta1, float beta2, float eps);
+                  float beta1, float beta2, float eps, unsigned int* tickets);
 int hgs_smoothness_num_blocks(int N);
 int hgs_smoothness_forward(void* stream, int N, const float* endpoints, const long long* index_pairs,
                            float cos_threshold, float eps, float* partials);
@@ -428,7 +432,7 @@ int hgs_image_layout(int W, int H, size_t* offsets /* [HGS_IMG_NFIELDS] */);
 int hgs_binning_layout(int R, size_t* offsets /* [HGS_BIN_NFIELDS] */);
 
 /* status words written by the kernels into image_buf (HGS_IMG_STATUS): [0]=num_rendered, [1]=overflow flag (the pass
- * dropped instances: its image is incomplete and its backward returns exactly zero gradients), [6]=a cooperative wait
+ * dropped instances: its image is incomplete and its backward returns exactly zero gradients), [8]=a cooperative wait
  * between workgroups timed out (never expected; results of that pass are invalid); the others are internal */
 #define HGS_STATUS_WORDS 16
 /* floats per packed instance record in HGS_BIN_PACKED, 3-channel mode: x,y, conic a,b,c, opacity, r,g,b, id, quadrant

@@ -3,9 +3,11 @@
   * the header-only glm the rasterizer vendors (DGR/third_party/glm), through oracle/glm_probe.cpp: a probe of
     glm's mat3 operator* / transpose, the operand order every bit-exact key of the rasterizer depends on.
 
-Runs ONLY in the authoring container (needs /root/reference).  Output goes to oracle/_ref/
-(git-ignored, travels to the GPU box as a built artefact).  No reference source is copied: the
-.pyx is cythonized where it lies, the generated C lands in a temp dir.
+Runs ONLY in the authoring container (needs /root/reference).  Output goes OUTSIDE the repository tree
+($HGS_REF_OUT, default /tmp/hgs_ref): nothing compiled from the reference is ever part of the snapshot that
+travels to the GPU box -- only the numeric fixtures generated with it (tests/golden/*.npz) and the timing
+recorded in BASELINE.md do.  No reference source is copied: the .pyx is cythonized where it lies, the generated
+C lands in a temp dir.
 
 The CUDA rasterizer / simple-knn sources are NOT buildable here (need nvcc, cuda_runtime,
 cooperative_groups, CUB, thrust) and no stand-ins are written for them -- see DESIGN.md.
@@ -19,7 +21,9 @@ import sysconfig
 import tempfile
 
 REF = "/root/reference/c_utils/c_utils.pyx"
-OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_ref")
+OUT = os.environ.get("HGS_REF_OUT", "/tmp/hgs_ref")
+_HERE = os.path.dirname(os.path.abspath(__file__))
+assert not os.path.abspath(OUT).startswith(os.path.dirname(_HERE) + os.sep), "HGS_REF_OUT must lie outside the repository"
 
 
 def build():
@@ -61,7 +65,8 @@ def build_glm_probe():
 
 
 def load():
-    """Import the built reference module (None if it was never built)."""
+    """Import the built reference module (None if it was never built).  Fixture generators and tools/ref_cython_timing.py
+    only: nothing that runs on the GPU box may call this."""
     so = glob.glob(os.path.join(OUT, "c_utils*.so"))
     if not so:
         return None

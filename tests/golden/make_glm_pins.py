@@ -1,5 +1,5 @@
 """Generates tests/golden/glm_pins.npz: random mat3 inputs and what the reference's vendored glm
-(DGR/third_party/glm, through oracle/_ref/libglm_probe.so built by oracle/build_ref.py) returns for
+(DGR/third_party/glm, through libglm_probe.so built by oracle/build_ref.py outside the repository, $HGS_REF_OUT) returns for
 A*B, transpose(A), transpose(M)*M and transpose(T)*transpose(V)*T.  Runs only where /root/reference exists;
 the fixture (inputs + outputs, data only) is committed.  Inputs span magnitudes the rasterizer sees
 (rotation-like entries, scales 1e-4..1, Jacobians of ~1e3) so that rounding differences between

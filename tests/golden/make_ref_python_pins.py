@@ -6,7 +6,7 @@ Reference pieces executed (imported by file path, no stubs, no edits):
   * utils/graphics.py::getWorld2View2, getProjectionMatrix, focal2fov, fov2focal
                                                      -> pins the camera-matrix conventions (tests/scenes.py,
                                                         hair-gs_amd/utils/graphics.py)
-  * c_utils/c_utils.pyx::filter_strand_list_segments (built by oracle/build_ref.py into oracle/_ref/)
+  * c_utils/c_utils.pyx::filter_strand_list_segments (built by oracle/build_ref.py outside the repository, $HGS_REF_OUT)
                                                      -> pins oracle/strand_oracle.c
   * arguments/__init__.py                            -> default hyper-parameters (training-step constants)
 Everything else on the hot path is CUDA and cannot be executed here ("parity unpinned").

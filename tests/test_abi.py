@@ -22,7 +22,10 @@ def test_library_exports_every_declared_symbol():
     assert declared == set(rt.SIGNATURES), declared ^ set(rt.SIGNATURES)
     for name in declared:
         assert hasattr(L, name), name
-    assert L.hgs_abi_version() == 1
+    # the version the header declares, the library reports and the binding demands are one number
+    header = open(os.path.join(ROOT, "include", "hgs.h")).read()
+    declared_version = int(re.search(r"#define\s+HGS_ABI_VERSION\s+(\d+)", header).group(1))
+    assert L.hgs_abi_version() == declared_version == rt.ABI_VERSION
 
 
 def test_workspace_sizes_and_layouts_are_consistent():

@@ -132,6 +132,34 @@ def test_spatially_sorted_cloud_is_the_same_cloud():
         assert (a - b[perm]).abs().max() <= 1e-4 * max(float(b.abs().max()), 1e-12)
 
 
+def test_derived_geometry_is_never_stale():
+    """The getters recompute from the parameters on every call (reference scene/hair_gaussian_model.py:134-172): writes
+    that autograd's version counters do not see -- `.data` mutation, raw-pointer kernels -- are visible at once, with and
+    without grad mode, and a render after such a write shows the moved geometry."""
+    from gaussian_renderer import render
+    from synthetic import build_workload
+    model, cams, _ = build_workload("tiny", device="cuda", with_targets=False)
+    bg = torch.zeros(3, device="cuda")
+
+    def means():
+        return model._endpoints.detach()[model.endpoint_pairs].mean(dim=1)
+    for grad in (False, True):
+        with torch.set_grad_enabled(grad):
+            a = model.get_xyz.detach().clone()
+            img_a = render(cams[1], model, bg)["render"].detach().clone()
+            v = model._endpoints._version
+            model._endpoints.data.add_(0.01)
+            assert model._endpoints._version == v          # the write is invisible to the version counter
+            b = model.get_xyz.detach().clone()
+            img_b = render(cams[1], model, bg)["render"].detach().clone()
+        assert torch.allclose(b, means(), atol=1e-7) and torch.allclose(b - a, torch.full_like(a, 0.01), atol=1e-6)
+        assert not torch.equal(img_a, img_b)
+        w0 = model.get_scaling.detach().clone()
+        model._width.data.add_(0.5)
+        assert torch.allclose(model.get_scaling[:, 1], w0[:, 1] * float(np.exp(0.5)), rtol=1e-5)
+    assert not hasattr(model, "_derived")
+
+
 def test_fused_strand_geometry_matches_torch_formulas():
     """hgs_strand_geometry_* vs the op-by-op getters (which restate the reference's), forward and backward."""
     from synthetic import make_strand_model
@@ -144,7 +172,6 @@ def test_fused_strand_geometry_matches_torch_formulas():
     outs, grads = {}, {}
     for fused in (False, True):
         m.fused_geometry = fused
-        m._derived = None
         m._endpoints.grad = None
         m._width.grad = None
         o = (m.get_xyz, m.get_scaling, m.get_rotation, m.get_orientation)
@@ -200,7 +227,6 @@ def test_fused_losses_match_torch_ops():
     out = {}
     for fused in (False, True):
         Ls.fused_losses = fused
-        model._derived = None
         model._endpoints.grad = None
         v = Ls.orientation_loss_rast(model, cam, opt)
         v.backward()
@@ -317,7 +343,6 @@ def test_iteration_prologue_equals_select_then_forward():
     for mode in ("select", "prologue", "prologue", "ride", "ride", "prologue"):
         for p in params:
             p.grad = None
-        model._derived = None
         if mode == "select":
             fused.views.select(1, lr=0.5, lr_dst=lr)
             assert fused.views.take_image() is None
@@ -371,7 +396,6 @@ def test_deferred_head_tail_gives_the_same_terms_and_gradients():
             for defer in (False, True, True):
                 for p in params:
                     p.grad = None
-                model._derived = None
                 fused.defer_tail = defer
                 fused.views.prologue(1, ride=defer)      # (and the prologue as a rider of the parameter forward launch)
                 loss, terms = fused.loss()
@@ -389,7 +413,6 @@ def test_deferred_head_tail_gives_the_same_terms_and_gradients():
                         assert torch.equal(a, b)
         # the contract: with defer_tail the total is complete only after the backward
         fused.defer_tail = True
-        model._derived = None
         fused.views.prologue(0)
         loss, terms = fused.loss()
         early = terms.clone()
@@ -487,7 +510,6 @@ def test_single_pass_equals_three_passes():
     opt = OptimizationParams()
     res = {}
     for single in (False, True):
-        model._derived = None
         for g in model.optimizer.param_groups if model.optimizer else []:
             pass
         for p in (model._endpoints, model._features_dc, model._opacity, model._mask, model._width):
@@ -617,7 +639,6 @@ def test_fused_iteration_matches_op_by_op_path(workload):
             p.grad = None
         for t in (model.max_radii2D, model.xyz_gradient_accum, model.denom):
             t.zero_()
-        model._derived = None
         fused.views.select(fused.views.index[id(cam)])
         floss, _ = fused.loss()
         if ci == 2:
@@ -756,7 +777,6 @@ def test_fused_iteration_without_view_masks():
     ref = [p.grad.clone() for p in params]
     for p in params:
         p.grad = None
-    model._derived = None
     fused.views.select(1)
     floss, _ = fused.loss()
     fused.backward(floss)

@@ -115,6 +115,43 @@ def test_sort_spatially_permutes_parameters_moments_and_statistics_alike():
     assert m.sort_spatially().tolist() == list(range(500))
 
 
+def test_capture_restore_round_trip_with_spatial_sort(monkeypatch):
+    """restore() after a capture() whose cloud was re-ordered since: Adam moments, statistics and parameters must end up
+    attached to the same Gaussians (training_setup sorts a GPU cloud; here the sort is forced on the CPU model, and the
+    centres move between capture and restore so that the permutation at restore is not the identity)."""
+    from scene.gaussian_model import GaussianModel
+    monkeypatch.setattr(GaussianModel, "_maybe_sort_spatially", lambda self: self.sort_spatially())
+    torch.manual_seed(1)
+    m = _cloud(n=300)
+    opt = OptimizationParams()
+    m.training_setup(opt)
+    for _ in range(3):      # three Adam steps: moments differ per Gaussian, centres move
+        m.update_learning_rate(1)
+        ((m._xyz ** 2).sum() * 50 + (m._opacity ** 2).sum() + (m._features_dc ** 3).sum() + (m._scaling ** 2).sum()
+         + (m._rotation ** 2).sum() + (m._features_rest ** 2).sum() + (m._mask ** 2).sum()).backward()
+        m.optimizer.step()
+        m.optimizer.zero_grad(set_to_none=True)
+    with torch.no_grad():
+        m._xyz.add_(torch.randn(300, 3) * 0.5)      # (the curve order of the moved cloud differs)
+    m.xyz_gradient_accum[:] = torch.arange(300.0)[:, None]
+    m.denom[:] = 2 * torch.arange(300.0)[:, None]
+    m.max_radii2D = 3 * torch.arange(300.0)
+    tag = m._opacity.detach().clone().reshape(-1)    # identifies a Gaussian whatever its position
+    want = {float(tag[i]): (m._xyz[i].detach().clone(), m.optimizer.state[m._xyz]["exp_avg"][i].clone(),
+                            m.optimizer.state[m._scaling]["exp_avg_sq"][i].clone(), float(i)) for i in range(300)}
+    ckpt = m.capture()
+    m2 = GaussianModel(sh_degree=1, spatial_lr_scale=2.0, device="cpu")
+    m2.restore(ckpt, opt)
+    order = [want[float(t)][3] for t in m2._opacity.detach().reshape(-1)]
+    assert order != sorted(order)                    # restore() did re-order the cloud
+    for i in range(300):
+        xyz, m1, v2, k = want[float(m2._opacity[i])]
+        assert torch.equal(m2._xyz[i].detach(), xyz)
+        assert torch.equal(m2.optimizer.state[m2._xyz]["exp_avg"][i], m1)
+        assert torch.equal(m2.optimizer.state[m2._scaling]["exp_avg_sq"][i], v2)
+        assert float(m2.xyz_gradient_accum[i]) == k and float(m2.denom[i]) == 2 * k and float(m2.max_radii2D[i]) == 3 * k
+
+
 def _strands(S=6, V=9, seed=0):
     from synthetic import strand_polylines
     from scene.hair_gaussian_model import HairGaussianModel

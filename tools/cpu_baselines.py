@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """CPU-only paths of the repo timed on the host cores (reported baselines, not targets).
-  B2  c_utils.filter_strand_list_segments      S strands x 100 segments  (+ the reference .pyx when oracle/_ref has it)
+  B2  c_utils.filter_strand_list_segments      S strands x 100 segments  (the reference .pyx: tools/ref_cython_timing.py, container only)
   B3  Stage-II merge plumbing (merge.py)       1k Gaussians -> to_hair_gaussian_model -> strands info -> one
                                                compute_endpoint_pair_to_merge round -> merge_endpoint_pairs
   B4  strand metrics compute_metrics           200k-point prediction vs 200k-point GT, 4 threshold pairs
@@ -28,13 +28,6 @@ def main():
         for j in range(S):
             strands[j] = rng.integers(0, 10**6, size=(100, 2)).astype(np.int64)
         out[f"B2_filter_strand_segments_S{S}_ms"] = med(lambda: c_utils.filter_strand_list_segments(strands), 7) * 1e3
-        try:
-            from oracle import build_ref
-            ref = build_ref.load()
-            if ref is not None:
-                out[f"B2_reference_cython_S{S}_ms"] = med(lambda: ref.filter_strand_list_segments(strands), 7) * 1e3
-        except Exception as e:
-            out["B2_reference_error"] = str(e)
     # ---- B3: merge plumbing on 1k Gaussians (config C1), CPU tensors
     from arguments import OptimizationParams
     from scene.gaussian_model import GaussianModel

@@ -20,7 +20,6 @@ for i in range(n):
     pkg = render_multi(cam, model, bg, extra, splits=(1, 3))
     loss = (pkg["render"] * w3).sum() + (pkg["extra"][0] * w1).sum() + (pkg["extra"][1] * wo).sum()
     loss.backward()
-    model._derived = None
     for p in (model._endpoints, model._features_dc, model._opacity, model._mask, model._width):
         p.grad = None
 torch.cuda.synchronize()

@@ -21,7 +21,6 @@ def run():
     pkg = render_multi(cam, model, bg, extra, splits=(1, 3))
     loss = (pkg["render"] * w3).sum() + (pkg["extra"][0] * w1).sum() + (pkg["extra"][1] * wo).sum()
     loss.backward()
-    model._derived = None
 for _ in range(3): run()
 torch.cuda.synchronize()
 rt.check(rt.lib().hgs_debug_set_wg_trace(tf.data_ptr(), tb.data_ptr()))
