@@ -294,3 +294,56 @@ extern "C" int hgs_radius_pairs(void* stream, int N, const float* pos, const flo
   HGS_CHECK_LAUNCH();
   return 0;
 }
+
+// ---- K = 3 nearest neighbours of every point within its own set (hgs_knn3) -----------------------------------------------
+// What the magnet loss asks pytorch3d for (loss/losses.py:139-144: knn_points(ends, ends, K=3, return_sorted=True)) over
+// the strand ends -- thousands to 10^5 points that move every iteration, so no tree: one query per lane, all points
+// through LDS in 256-point tiles (broadcast reads), the three best kept sorted in registers.  The point itself is a
+// candidate like any other (pytorch3d returns it first, at distance 0); ties are ordered by index.
+namespace {
+__global__ __launch_bounds__(256) void knn3_kernel(int N, const float* __restrict__ pos, int* __restrict__ idx, float* __restrict__ d2out) {
+  __shared__ float sp[256][3];
+  const int a = blockIdx.x * 256 + threadIdx.x;
+  float ax = 0.f, ay = 0.f, az = 0.f;
+  if (a < N) { ax = pos[3 * a]; ay = pos[3 * a + 1]; az = pos[3 * a + 2]; }
+  float b0 = INFINITY, b1 = INFINITY, b2 = INFINITY;
+  int i0 = -1, i1 = -1, i2 = -1;
+  for (int t0 = 0; t0 < N; t0 += 256) {
+    const int j = t0 + threadIdx.x;
+    __syncthreads();
+    if (j < N) {
+#pragma unroll
+      for (int c = 0; c < 3; c++) sp[threadIdx.x][c] = pos[3 * j + c];
+    }
+    __syncthreads();
+    const int nb = min(256, N - t0);
+    for (int k = 0; k < nb; k++) {
+      const float dx = ax - sp[k][0], dy = ay - sp[k][1], dz = az - sp[k][2];
+      const float d = dx * dx + dy * dy + dz * dz;
+      if (d < b2) {                               // (indices ascend along the walk: an equal distance never displaces)
+        if (d < b1) {
+          b2 = b1; i2 = i1;
+          if (d < b0) { b1 = b0; i1 = i0; b0 = d; i0 = t0 + k; }
+          else { b1 = d; i1 = t0 + k; }
+        } else { b2 = d; i2 = t0 + k; }
+      }
+    }
+  }
+  if (a < N) {
+    idx[3 * a] = i0; idx[3 * a + 1] = i1; idx[3 * a + 2] = i2;
+    d2out[3 * a] = b0; d2out[3 * a + 1] = b1; d2out[3 * a + 2] = b2;
+  }
+}
+}  // namespace
+
+extern "C" int hgs_knn3(void* stream, int N, const float* points, int* idx, float* dist2) {
+  if (N <= 0) return 0;
+  if (!points || !idx || !dist2) { hgs_set_error("hgs_knn3: null argument"); return 1; }
+  hipStream_t s = (hipStream_t)stream;
+  {
+    HgsProfScope _prof(s, HGS_K_KNN);
+    hipLaunchKernelGGL(knn3_kernel, dim3((N + 255) / 256), dim3(256), 0, s, N, points, idx, dist2);
+  }
+  HGS_CHECK_LAUNCH();
+  return 0;
+}

@@ -70,6 +70,7 @@ SIGNATURES = {
     "hgs_loss_head_backward": (ci, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, vp, vp, vp, vp]),
     "hgs_densify_stats": (ci, [vp, ci, vp, vp, ci, vp, vp, vp]),
     "hgs_radius_pairs": (ci, [vp, ci, vp, vp, cf, cf, ci, ci, vp, vp, vp, ci]),
+    "hgs_knn3": (ci, [vp, ci, vp, vp, vp]),
     "hgs_set_tile_cull": (ci, [ci]),
     "hgs_set_segment_policy": (ci, [ci, ci, ci]),
     "hgs_debug_set_wg_trace": (ci, [vp, vp]),

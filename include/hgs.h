@@ -400,6 +400,13 @@ const char* hgs_prof_kernel_name(int kernel_id);
 int hgs_radius_pairs(void* stream, int N, const float* pos, const float* dir, float radius, float min_cos,
                      int bidirectional, int capacity, int* pairs, float* dist, int* count, int sorted_by_x);
 
+/* hgs_knn3 <-> pytorch3d.ops.knn_points(p, p, K=3, return_sorted=True) as strand_joints_magnet_loss calls it on the strand
+ *   ends (loss/losses.py:139-144; pytorch3d is a from-source dependency of the reference, README.md:25-30, absent from the tree):
+ *   for every point the indices and squared distances of its 3 nearest points OF THE SAME SET, ascending, the point itself
+ *   included (first, at distance 0); equal distances in ascending index order; fewer than 3 points: index -1, distance
+ *   +inf.  Brute force through LDS tiles: the ends move every iteration and number in the thousands. */
+int hgs_knn3(void* stream, int N, const float* points, int* idx /* [N,3] */, float* dist2 /* [N,3] */);
+
 /* Tile culling (default on).  The reference gives every Gaussian the tiles of its 3-sigma square (forward.cu:229-235,
  * auxiliary.h:46-56) although a pixel only blends it where opacity * exp(power) >= 1/255 (forward.cu:358): with culling on,
  * hgs_forward_preprocess keeps only the tiles that the bounding box of that ellipse reaches, so num_rendered, the tile

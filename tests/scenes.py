@@ -143,3 +143,36 @@ def strand_scene(n_strands=20, n_seg=50, W=160, H=96, seed=0, bg=(0.0, 0.0, 0.0)
     else:
         scene["shs"] = ((rng.uniform(0, 1, (P, 1, 3)) - 0.5) / 0.28209479177387814).astype(np.float32)
     return scene
+
+
+def c1_cloud(device="cpu", n_strands=50, n_seg=20, seed=3):
+    """BASELINE.json config C1: a 1k-Gaussian Stage-I cloud for merge.py -- every Gaussian is one segment of one of
+    n_strands polylines (line-like: main axis = half length x dist_to_scale_factor, 0.1 mm across), stored in shuffled
+    order, so that to_hair_gaussian_model() yields 1000 disconnected segments whose ends coincide with their former
+    neighbours' to rounding.  Returns (GaussianModel, polylines [S, n_seg+1, 3])."""
+    import torch
+    from torch import nn
+    from scene.gaussian_model import GaussianModel
+    from synthetic import strand_polylines
+    from utils.transform import calculate_rotation_from_vectors
+    pts = strand_polylines(n_strands, n_seg, seed=seed)
+    e0, e1 = torch.from_numpy(pts[:, :-1].reshape(-1, 3).copy()), torch.from_numpy(pts[:, 1:].reshape(-1, 3).copy())
+    n = e0.shape[0]
+    perm = torch.from_numpy(np.random.default_rng(seed).permutation(n))
+    e0, e1 = e0[perm], e1[perm]
+    m = GaussianModel(sh_degree=0, device=device)
+    d = e1 - e0
+    half = d.norm(dim=1, keepdim=True) / 2
+    x_hat = torch.zeros_like(d)
+    x_hat[:, 0] = 1.0
+    quat = calculate_rotation_from_vectors(x_hat, d, representation="quat")
+    scale = torch.cat((half * m.dist_to_scale_factor, torch.full((n, 2), 1e-4)), dim=1)
+    g = torch.Generator().manual_seed(seed)
+    to = lambda t: nn.Parameter(t.to(device).contiguous())   # noqa: E731
+    m._xyz = to((e0 + e1) / 2)
+    m._features_dc, m._features_rest = to(torch.rand(n, 1, 3, generator=g)), to(torch.zeros(n, 0, 3))
+    m._scaling, m._rotation = to(torch.log(scale)), to(quat)
+    m._opacity, m._mask = to(torch.full((n, 1), 2.0)), to(torch.full((n, 1), 2.0))
+    m.max_radii2D = torch.zeros(n, device=device)
+    m.ref_strand_root = pts[:, 0].copy()
+    return m, pts

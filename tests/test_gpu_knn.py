@@ -77,3 +77,70 @@ def test_merge_candidates_gpu_model_equals_cpu_model():
         out[dev] = m.compute_endpoint_pair_to_merge().cpu().numpy()
     assert out["cpu"].shape[0] >= 40
     assert sorted(map(tuple, np.sort(out["cpu"], 1).tolist())) == sorted(map(tuple, np.sort(out["cuda"], 1).tolist()))
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 255, 256, 257, 5000])
+def test_knn3_matches_brute_force_exactly(n):
+    """hgs_knn3 (the neighbour search of the magnet loss, pytorch3d knn_points(p, p, K=3) in the reference,
+    loss/losses.py:139-144): indices and squared distances bit for bit against a float32 brute force with the same
+    expression and (distance, index) order; duplicates included."""
+    import torch
+    from loss.losses import knn3_self
+    rng = np.random.default_rng(n)
+    pts = rng.normal(size=(n, 3)).astype(np.float32)
+    if n >= 255:
+        pts[:20] = pts[20:40]                     # exact duplicates: zero distances, index order decides
+    d2g, idg = knn3_self(torch.from_numpy(pts).cuda())
+    d2c, idc = knn3_self(torch.from_numpy(pts))   # chunked distance matrix on the CPU: same expression, stable sort
+    np.testing.assert_array_equal(idg.cpu().numpy(), idc.numpy())
+    np.testing.assert_array_equal(d2g.cpu().numpy().view(np.uint32), d2c.numpy().view(np.uint32))
+    if n >= 3:
+        assert np.all(d2c.numpy()[:, 0] == 0)   # the point itself (or a duplicate with a smaller index) comes first
+
+
+def test_magnet_loss_gpu_model_equals_cpu_model():
+    import torch
+    from loss.losses import strand_joints_magnet_loss
+    from scene.hair_gaussian_model import HairGaussianModel
+    from synthetic import strand_polylines
+    pts = strand_polylines(300, 12, seed=4) * 30.0
+    out = {}
+    for dev in ("cpu", "cuda"):
+        m = HairGaussianModel.from_strands(pts, device=dev)
+        m.compute_strands_info(only_foreground=False)
+        loss = strand_joints_magnet_loss(m)
+        loss.backward()
+        out[dev] = (float(loss), m._endpoints.grad.cpu().numpy())
+    assert abs(out["cpu"][0] - out["cuda"][0]) <= 1e-5 * abs(out["cpu"][0])
+    assert np.abs(out["cpu"][1] - out["cuda"][1]).max() <= 1e-5 * np.abs(out["cpu"][1]).max()
+
+
+def test_training_step_with_magnet_term():
+    """--lambda_magnet 0.1 works on the reference (loss/losses.py:352-354): here it selects the op-by-op single-pass
+    iteration (the fused iteration covers the default terms) and trains."""
+    import torch
+    from arguments import OptimizationParams
+    from synthetic import build_workload
+    from train import fused_step_applicable, training_step
+    model, cams, extent = build_workload("tiny", device="cuda", with_targets=True)
+    opt = OptimizationParams()
+    opt.enable_topology = False
+    opt.lambda_magnet = 0.1
+    model.training_setup(opt)
+    assert not fused_step_applicable(model, opt)
+    bg = torch.zeros(3, device="cuda")
+    for it in range(1, 4):
+        loss, terms, _ = training_step(model, cams[it % len(cams)], opt, bg, it, extent=extent)
+        assert "magnet" in terms and torch.isfinite(loss) and torch.isfinite(terms["magnet"])
+
+
+def test_c1_merge_at_size_gpu_model_equals_cpu_model():
+    """BASELINE.json C1 at its stated size on a GPU model (candidate search: hgs_radius_pairs; strand walk: pointer
+    doubling on the device) against the CPU model (cKDTree; numpy walk): the same strands, vertex for vertex, in the same
+    number of rounds (reference merge.py:114-190)."""
+    from tests.test_models_cpu import _c1_merge
+    h_cpu, r_cpu, s_cpu, _ = _c1_merge("cpu")
+    h_gpu, r_gpu, s_gpu, _ = _c1_merge("cuda")
+    assert r_cpu == r_gpu and h_gpu.strands_info.n_strands == h_cpu.strands_info.n_strands == 50
+    assert np.abs(np.asarray(s_cpu) - np.asarray(s_gpu)).max() <= 2e-5
+    assert h_gpu._endpoints.is_cuda and h_gpu.get_xyz.shape[0] == 1000

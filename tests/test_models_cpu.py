@@ -357,6 +357,47 @@ def test_merge_driver_rounds_until_nothing_left():
     _chain_invariants(m)
 
 
+def _c1_merge(device):
+    """BASELINE.json C1 at its stated size: 1k-Gaussian cloud -> to_hair_gaussian_model -> merge_rounds (reference
+    merge.py:114-190).  Returns (model, rounds, strands as sorted tuples of rounded vertex coordinates)."""
+    import merge as merge_cli
+    from tests.scenes import c1_cloud
+    cloud, pts = c1_cloud(device=device)
+    opt = OptimizationParams()
+    cloud.training_setup(opt)
+    with torch.no_grad():
+        hair = cloud.to_hair_gaussian_model()
+        assert hair.get_xyz.shape[0] == 1000 and hair._endpoints.shape[0] == 2000
+        assert hair.strands_info.n_strands == 1000            # every Gaussian one disconnected segment
+        rounds = merge_cli.merge_rounds(hair, opt.iterations, log=lambda *_: None)
+    ep = hair._endpoints.detach().cpu().numpy()
+    strands = sorted(tuple(map(tuple, np.round(ep[np.r_[s[:, 0], s[-1, 1]]], 5).tolist())) for s in hair.strands_info.list_strands)
+    return hair, rounds, strands, pts
+
+
+def test_c1_merge_at_size_reassembles_the_strands():
+    """C1 (merge.py on 1k synthetic Gaussians, CPU model): the 1000 shuffled line-like Gaussians of 50 polylines x 20
+    segments are merged back into exactly those 50 strands of 20 segments, vertex for vertex, in ~log2(20) rounds; a
+    second call finds nothing left to merge."""
+    import merge as merge_cli
+    hair, rounds, strands, pts = _c1_merge("cpu")
+    _chain_invariants(hair)
+    assert 4 <= rounds <= 8
+    assert hair.strands_info.n_strands == 50 and hair.get_xyz.shape[0] == 1000 and hair._endpoints.shape[0] == 50 * 21
+    assert all(s.shape[0] == 20 for s in hair.strands_info.list_strands)
+    assert merge_cli.merge_rounds(hair, 10, log=lambda *_: None) == 0
+    # the merged strands ARE the generating polylines (root -> tip: the roots are the reference roots)
+    want = sorted(tuple(map(tuple, np.round(p, 5).tolist())) for p in pts)
+    got = np.asarray(strands)
+    assert np.abs(got - np.asarray(want)).max() <= 2e-5
+    # appearance travelled with the segments: the multiset of colours is the cloud's
+    from tests.scenes import c1_cloud
+    cloud, _ = c1_cloud(device="cpu")
+    a = np.sort(hair._features_dc.detach().numpy().reshape(-1, 3), axis=0)
+    b = np.sort(cloud._features_dc.detach().numpy().reshape(-1, 3), axis=0)
+    assert np.array_equal(a, b)
+
+
 def _walk_chains_loop(pairs, n_ep, end_distance):
     """Edge-by-edge walk (the form the reference uses, scene/hair_gaussian_model.py:1410-1498): checker for the
     vectorised scene.hair_gaussian_model.walk_chains."""
@@ -451,3 +492,71 @@ def test_nearest_distance_matches_kdtree():
     d = nearest_distance(torch.from_numpy(pts), torch.from_numpy(refs), chunk=1024).numpy()
     ref = cKDTree(refs.astype(np.float64)).query(pts.astype(np.float64), k=1)[0]
     np.testing.assert_allclose(d, ref, rtol=1e-14, atol=0)
+
+
+def _magnet_by_loops(model):
+    """strand_joints_magnet_loss of the reference (loss/losses.py:106-172) as plain loops over the strand ends, float64
+    distances for the neighbour ORDER only; returns (loss, gradient w.r.t. the endpoints) with knn_points' gradient."""
+    ep = model._endpoints.detach().numpy().astype(np.float32)
+    pairs = model.endpoint_pairs.numpy()
+    ids, counts = np.unique(pairs, return_counts=True)
+    ends = [int(i) for i in ids[counts == 1]]
+    partner = {}
+    for a, b in pairs:
+        partner.setdefault(int(a), int(b))
+        partner.setdefault(int(b), int(a))
+    mapping = np.zeros(ep.shape[0], np.int64)
+    for e in ends:
+        mapping[e] = partner[e]
+    ends = [e for e in ends if np.linalg.norm(ep[e] - ep[partner[e]]) > model.min_val]
+    comp = [partner[e] for e in ends]
+    pts = ep[ends]
+    n = len(ends)
+    grad = np.zeros_like(ep, dtype=np.float64)
+    vals = []
+    for i in range(n):
+        d = pts[i][None, :] - pts
+        d2 = (d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1] + d[:, 2] * d[:, 2]).astype(np.float32)
+        order = np.lexsort((np.arange(n), d2))[:3]
+        j = order[1] if (order[1] != i and order[1] != comp[i]) else order[2]     # (local index vs GLOBAL id: as the reference)
+        nn_dir = ep[j] - ep[mapping[j]]                                             # (local index into the global table: same)
+        if not np.linalg.norm(nn_dir) > model.min_val:
+            continue
+        vals.append((i, j, float(d2[j])))
+    m = len(vals)
+    loss = sum(v * v for _, _, v in vals) / m
+    for i, j, v in vals:
+        g = (2.0 * v / m) * 2.0 * (pts[i] - pts[j]).astype(np.float64)
+        grad[ends[i]] += g
+        grad[ends[j]] -= g
+    return loss, grad
+
+
+def test_magnet_loss_matches_the_reference_statement_by_statement():
+    """loss/losses.py::strand_joints_magnet_loss (reference :106-172) against a loop restatement, value and gradient;
+    one collapsed end segment is excluded like in the reference."""
+    from loss.losses import strand_joints_magnet_loss
+    m, _ = _strands(S=40, V=6, seed=3)
+    with torch.no_grad():
+        m._endpoints[5] = m._endpoints[4]          # end segment of strand 0 collapsed (vertices 4, 5 of 0..5)
+        m._endpoints.mul_(30.0)                    # (distances of order 1: the fourth power stays well inside fp32)
+    m.compute_strands_info(only_foreground=False)
+    loss = strand_joints_magnet_loss(m)
+    loss.backward()
+    ref_loss, ref_grad = _magnet_by_loops(m)
+    assert abs(float(loss) - ref_loss) <= 1e-5 * abs(ref_loss)
+    got = m._endpoints.grad.numpy()
+    assert np.abs(got - ref_grad).max() <= 1e-4 * np.abs(ref_grad).max()
+    # only strand ends receive a gradient, and the collapsed end does not take part
+    ids, counts = np.unique(m.endpoint_pairs.numpy(), return_counts=True)
+    inner = np.setdiff1d(np.arange(got.shape[0]), ids[counts == 1])
+    assert np.all(got[inner] == 0) and np.all(got[5] == 0)
+
+
+def test_loss_function_with_magnet_term_runs_on_cpu_model():
+    from loss.losses import angle_smoothness_loss, strand_joints_magnet_loss
+    m, _ = _strands(S=10, V=8, seed=1)
+    m.compute_strands_info(only_foreground=False)
+    total = angle_smoothness_loss(m) + 0.1 * strand_joints_magnet_loss(m)
+    total.backward()
+    assert torch.isfinite(m._endpoints.grad).all()
