@@ -236,7 +236,7 @@ def main():
         if use_graph:
             # the whole iteration is captured once into a HIP graph and replayed (train.GraphedStep); the W warm-up steps
             # and the K timed steps are real optimizer steps on successive random views, exactly like the eager loop
-            spg = args.steps_per_graph if (fused is not None and views_per_rank == 1 and world == 1) else 1
+            spg = args.steps_per_graph if (fused is not None and views_per_rank == 1 and (world == 1 or vp.graph_collective_ok())) else 1
             gs = GraphedStep(model, cams, opt, bg, extent=extent, vp=vp, views=views, views_per_step=views_per_rank,
                              steps_per_graph=max(1, spg))
             gs.capture(cams, iteration=it_start + 1)
@@ -349,7 +349,8 @@ def main():
             rt.prof_enable(False)
 
         return dict(dt=dt, regions=regions, sustained=sustained, kern=kern, kern_steps=kern_steps if kern else 0,
-                    steps_per_graph=(gs.steps_per_graph if use_graph else None), fused=fused)
+                    steps_per_graph=(gs.steps_per_graph if use_graph else None), fused=fused,
+                    collective_captured=(gs.collective_captured if use_graph else False))
 
     head = measure(0, args.sustained_seconds > 0, not args.no_kernel_timing)
     dt, regions, sustained, kern, kern_steps, fused = (head[k] for k in ("dt", "regions", "sustained", "kern", "kern_steps", "fused"))
@@ -444,7 +445,7 @@ def main():
                                "max_iters_per_sec": args.steps / tr["regions"][0]},
                    "render_ms_per_view": tfs["render_ms"], "mean_num_rendered": tfs["meanR"],
                    "mean_num_rendered_after_tile_cull": tfs["meanR_culled"], "mean_sum_tile_list_len": tfs["meanL"],
-                   "void_steps_while_training": getattr(training, "last_void_steps", None)}
+                   "capacity_rollbacks_while_training": getattr(training, "last_rollbacks", None)}
         if tr["kern"]:
             trained["kernel_us_per_launch"] = {k: (v[0] / v[1] * 1e3 if v[1] else 0.0) for k, v in tr["kern"].items()}
 
@@ -466,6 +467,9 @@ def main():
         "sustained_iters_per_sec": None if sustained is None else sustained["iters_per_sec"],
         "n_ranks_seen": dist.get_world_size() if world > 1 else 1,
         "collective_backend": (dist.get_backend() + (" (RCCL)" if dist.get_backend() == "nccl" else "")) if world > 1 else None,
+        # True: the gradient all-reduce and Adam are nodes of the step's HIP graph (several optimizer steps per launch work
+        # across ranks); False with several ranks: the eager exchange behind the graph (gloo, or the capture probe failed)
+        "collective_in_graph": head["collective_captured"] if world > 1 else None,
         "config": {"workload": f"{args.workload}: {P} strand-Gaussians, {len(cams)} views @ {W}x{H}, "
                                f"{views_per_rank} view(s)/GPU/optimizer step ({views_per_step} views/step), "
                                "RGB+mask+orientation raster fwd+bwd + L1/DSSIM/mask/orientation/smoothness losses + Adam",

@@ -35,6 +35,48 @@ class ViewParallel:
     def params(self, gaussians):
         return [g["params"][0] for g in gaussians.optimizer.param_groups]
 
+    def graph_collective_ok(self, device=None):
+        """May the gradient all-reduce be captured INTO the iteration's HIP graph?  Only with the RCCL backend (a gloo
+        collective synchronises with the host), unless switched off (HGS_GRAPH_COLLECTIVE=0), and only if a probe -- a
+        two-node graph holding one all-reduce of a small buffer, captured and replayed twice on every rank -- gives the
+        right sums here.  Decided once per process, identically on every rank (the probe's verdict is itself reduced)."""
+        if self.world == 1:
+            return False
+        if getattr(self, "_graph_ok", None) is None:
+            import os
+            ok = dist.get_backend() == "nccl" and os.environ.get("HGS_GRAPH_COLLECTIVE", "1") != "0" and torch.cuda.is_available()
+            if ok:
+                dev = torch.device("cuda", torch.cuda.current_device()) if device is None else device
+                try:
+                    buf = torch.full((1024,), float(self.rank + 1), device=dev)
+                    s = torch.cuda.Stream(device=dev)
+                    s.wait_stream(torch.cuda.current_stream(dev))
+                    with torch.cuda.stream(s):
+                        dist.all_reduce(buf)                  # communicator set-up outside the capture
+                    torch.cuda.current_stream(dev).wait_stream(s)
+                    torch.cuda.synchronize(dev)
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g, stream=s, capture_error_mode="thread_local"):
+                        dist.all_reduce(buf)
+                    want = float(self.world * (self.world + 1) // 2)
+                    good = True
+                    for _ in range(2):
+                        buf.fill_(float(self.rank + 1))
+                        g.replay()
+                        torch.cuda.synchronize(dev)
+                        good = good and bool((buf == want).all())
+                    ok = good
+                except Exception as e:       # capture of the collective is not supported here: keep the eager exchange
+                    if self.rank == 0:
+                        print(f"ViewParallel: all-reduce inside a captured graph is not available ({type(e).__name__}: {e}); "
+                              "using the eager exchange")
+                    ok = False
+                verdict = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
+                dist.all_reduce(verdict, op=dist.ReduceOp.MIN)
+                ok = bool(int(verdict.item()))
+            self._graph_ok = ok
+        return self._graph_ok
+
     def pack_gradients(self, gaussians):
         """Gather every parameter's gradient into ONE flat fp32 buffer (a single multi-tensor copy launch) and make the
         parameters' .grad views of it, so the exchange below is one in-place collective and Adam reads the reduced
@@ -171,8 +213,8 @@ def _training_step(gaussians, viewpoint_cam, opt, bg, iteration, extent, vp, ras
                 size_threshold = opt.prune_max_radii_2d if iteration > opt.opacity_reset_interval else None
                 gaussians.densification(extent, size_threshold, None)
                 densified = True
-            if iteration % opt.opacity_reset_interval == 0:
-                gaussians.reset_opacity()
+            if iteration % opt.opacity_reset_interval == 0 and getattr(opt, "enable_topology", True):
+                gaussians.reset_opacity()     # (part of the densification schedule, train.py:188-190: off with the operators)
         if isinstance(gaussians, HairGaussianModel) and getattr(opt, "enable_topology", True):
             if iteration % opt.merge_interval == 0 and hasattr(gaussians, "merging"):
                 gaussians.merging(training_info=None, strands_info_is_current=densified)
@@ -232,6 +274,9 @@ class GraphedStep:
         self.steps_per_graph = int(steps_per_graph)
         if self.views_per_step > 1 and self.fused is None:
             raise ValueError("several views per captured step need the fused iteration (hgs_runtime.strand_step)")
+        # several ranks: capture the gradient all-reduce and Adam into the step's graph when the backend allows (RCCL)
+        self.collective_in_graph = bool(getattr(opt, "collective_in_graph", True))
+        self.collective_captured = False
         self._make_capturable()
 
     def _make_capturable(self):
@@ -350,46 +395,56 @@ class GraphedStep:
         # one view per step on the fused path: the view select (+ image-buffer clearing) is the graph's first node, and
         # step() re-points it by updating that node's arguments (no launch between two replays)
         self._prologue_in_graph = self.fused is not None and not multi
-        if self.vp.world == 1:
-            ga = torch.cuda.CUDAGraph(keep_graph=True) if self._prologue_in_graph else torch.cuda.CUDAGraph()
-            with torch.cuda.graph(ga, stream=s):
-                if self._prologue_in_graph:
-                    self.load_camera(warmup_cams[0])
-                self.loss_buf = fwd_bwd()
-                if multi:
-                    self._scale_gradients()
-                g.optimizer.step()
-            self._graphs = (ga, None)
-        else:
-            # a live RCCL communicator has a watchdog thread that polls events: with the default (global) capture
-            # error mode its calls would invalidate the capture; only this thread's unsafe calls must be errors
-            mode = dict(capture_error_mode="thread_local")
-            ga = torch.cuda.CUDAGraph(keep_graph=True) if self._prologue_in_graph else torch.cuda.CUDAGraph()
-            with torch.cuda.graph(ga, stream=s, **mode):
-                if self._prologue_in_graph:
-                    self.load_camera(warmup_cams[0])
-                self.loss_buf = fwd_bwd()
+        # With several ranks the gradient exchange is part of the step.  RCCL collectives can be captured into the graph
+        # (ViewParallel.graph_collective_ok probes it): the whole step -- prologue, forward/backward, packing, all-reduce,
+        # Adam -- is then ONE graph, and several optimizer steps per launch work across ranks exactly as on one.  Otherwise
+        # (gloo on CPU-side tests, HGS_GRAPH_COLLECTIVE=0) the graph ends with the packing and step() issues the exchange
+        # and Adam eagerly behind it.
+        world = self.vp.world
+        in_graph = world == 1 or (self.collective_in_graph and self.vp.graph_collective_ok())
+        # a live RCCL communicator has a watchdog thread that polls events: with the default (global) capture error mode
+        # its calls would invalidate the capture; only this thread's unsafe calls must be errors
+        mode = dict(capture_error_mode="thread_local") if world > 1 else {}
+
+        def exchange_and_step():
+            if world > 1:
                 self.vp.pack_gradients(g)       # .grad become views of the flat exchange buffer
-            # What follows the all-reduce -- (the gradient scale and) ONE Adam launch -- is issued eagerly by step(): a graph
-            # of one or two kernels costs more GPU-idle time per launch (~8 us) than the launches it saves
-            # (tools/probes/graph_gap.py: 2 kernels, 16.6 us per replay against 10.0 us eager).
-            self._graphs = (ga, "eager-tail")
+                self.vp.exchange(average=not multi)
+            if multi:
+                self._scale_gradients()
+            g.optimizer.step()
+
+        ga = torch.cuda.CUDAGraph(keep_graph=True) if self._prologue_in_graph else torch.cuda.CUDAGraph()
+        with torch.cuda.graph(ga, stream=s, **mode):
+            if self._prologue_in_graph:
+                self.load_camera(warmup_cams[0])
+            self.loss_buf = fwd_bwd()
+            if in_graph:
+                exchange_and_step()
+            else:
+                self.vp.pack_gradients(g)
+        # "eager-tail": what follows the packing -- the all-reduce, (the gradient scale and) ONE Adam launch -- is issued by
+        # step(): a graph of one or two kernels costs more GPU-idle time per launch (~8 us) than the launches it saves
+        # (tools/probes/graph_gap.py: 2 kernels, 16.6 us per replay against 10.0 us eager).
+        self._graphs = (ga, None if in_graph else "eager-tail")
+        self.collective_captured = world > 1 and in_graph
         if self._prologue_in_graph:
             ga.instantiate()
             self._binding = self.fused.views.graph_bind(ga)
         self._many = None
         if self.steps_per_graph > 1:
-            if not self._prologue_in_graph or self.vp.world != 1:
-                raise ValueError("steps_per_graph > 1 needs the fused iteration, one view per step and one rank")
+            if not self._prologue_in_graph or not in_graph:
+                raise ValueError("steps_per_graph > 1 needs the fused iteration, one view per step and a step that is one "
+                                 "graph (one rank, or the all-reduce captured with RCCL)")
             K, v = self.steps_per_graph, self.fused.views
             gk = torch.cuda.CUDAGraph(keep_graph=True)
             losses = []
-            with torch.cuda.graph(gk, pool=ga.pool(), stream=s):
+            with torch.cuda.graph(gk, pool=ga.pool(), stream=s, **mode):
                 for j in range(K):
                     g.optimizer.zero_grad(set_to_none=True)   # (host side: this step's backward ASSIGNS its gradients)
                     v.prologue(j % v.n, lr=float(j), lr_dst=self._position_lr(), ride=self._ride)   # lr = j: the tag graph_bind sorts by
                     losses.append(fwd_bwd())
-                    g.optimizer.step()
+                    exchange_and_step()
             gk.instantiate()
             self._many = (gk, v.graph_bind(gk, K), losses)
         # every replay raises the library's sticky device-side maximum of num_rendered; check() compares it with the
@@ -499,16 +554,41 @@ def training(gaussians, cameras, opt, iterations=None, extent=1.0, seed=0, log_e
         fused = fused_step_for(gaussians, views, opt, bg)   # eager launches of the same iteration (topology iterations)
         fused.defer_tail = bool(getattr(opt, "defer_head_tail", True))   # (training_step runs forward and backward together)
     topology = getattr(opt, "enable_topology", True)
-    void_steps = 0
+    rollbacks = 0
+    ckpt = None             # _Checkpoint of the last state known to be exact (captured-graph mode only)
+
+    def overflowed(gs_):
+        """(worst instance count since the last check over all ranks, captured capacity): one synchronisation."""
+        worst, cap = gs_.headroom()
+        if vp.world > 1:
+            w = torch.tensor([worst], dtype=torch.int64, device=dev)
+            dist.all_reduce(w, op=dist.ReduceOp.MAX)
+            worst = int(w.item())
+        return worst, cap
+
+    def roll_back(worst, cap, it_now):
+        """A replayed pass needed more instances than the graph was captured for: its gradients were zero (include/hgs.h),
+        so the steps since the last check are not what the reference computes (train.py:146-204: every step has its
+        gradient).  Return to the checkpoint, raise the capacity and run those iterations again."""
+        from diff_gaussian_rasterization import _C as raster
+        if vp.rank == 0:
+            print(f"[it {it_now}] binning capacity {cap} exceeded ({worst} instances): iterations {ckpt.it + 1}..{it_now} "
+                  "are run again from the last checkpoint with a larger capacity")
+        raster._state["cap"] = max(raster._state["cap"], int(worst * 2.0) + 4096)
+        return ckpt.restore(gaussians, sampler)
+
     try:
         it, last = start_iteration + 1, start_iteration + n
         while it <= last:
             due = topology_due(gaussians, opt, it) if topology else []
             if use_graph and not due:
                 if gs is None:
-                    many = steps_per_graph if (fused is not None and vp.world == 1) else 1
-                    gs = GraphedStep(gaussians, cameras, opt, bg, extent=extent, vp=vp, views=views, steps_per_graph=many)
+                    many = steps_per_graph if (fused is not None and (vp.world == 1 or (
+                        getattr(opt, "collective_in_graph", True) and vp.graph_collective_ok()))) else 1
+                    gs = GraphedStep(gaussians, cameras, opt, bg, extent=extent, vp=vp, views=views, steps_per_graph=many,
+                                     slack=float(getattr(opt, "capacity_slack", 2.0)))
                     gs.capture(cameras, iteration=it)
+                    ckpt = _Checkpoint(gaussians, sampler, ema, it - 1)    # (eager steps are exact: they repeat on overflow)
                 K = gs.steps_per_graph
                 if K > 1 and it + K - 1 <= last and not (topology and any(topology_due(gaussians, opt, j) for j in range(it + 1, it + K))):
                     losses = gs.step_many([sampler.next() for _ in range(K)], it)   # K optimizer steps, one graph launch
@@ -516,8 +596,13 @@ def training(gaussians, cameras, opt, iterations=None, extent=1.0, seed=0, log_e
                     losses = [gs.step(sampler.next(), it)]
             else:
                 if gs is not None:
-                    void_steps += _void_steps(gs)
+                    # leaving the captured graph: every replay since the last check must have been exact
+                    worst, cap = overflowed(gs)
                     gs = None                  # shapes change below: capture again at the next iteration
+                    if cap is not None and worst > cap:
+                        it, ema = roll_back(worst, cap, it - 1)
+                        rollbacks += 1
+                        continue
                 loss, _, _ = training_step(gaussians, sampler.next(), opt, bg, it, extent=extent, vp=vp, fused=fused)
                 losses = [loss]
                 if fused is not None and due:
@@ -525,41 +610,66 @@ def training(gaussians, cameras, opt, iterations=None, extent=1.0, seed=0, log_e
             first, it = it, it + len(losses)
             for loss in losses:
                 ema = loss.clone() if ema is None else 0.4 * loss + 0.6 * ema  # on the device: no per-iteration host sync
-            if gs is not None and any(j % 64 == 0 for j in range(first, it)):
-                # the model grows while it trains: re-capture with a larger capacity once 80% of the captured one is used.
-                # The decision is taken on the maximum over the ranks (views differ; replicas must re-capture together).
-                worst, cap = gs.headroom()
-                if vp.world > 1:
-                    w = torch.tensor([worst], dtype=torch.int64, device=dev)
-                    dist.all_reduce(w, op=dist.ReduceOp.MAX)
-                    worst = int(w.item())
+            if gs is not None and (it > last or any(j % 64 == 0 for j in range(first, it))):
+                # The model grows while it trains.  Every 64 iterations (and at the end of the run): if a replay overflowed
+                # the captured capacity, roll back to the last checkpoint and run the iterations again; otherwise this
+                # state is exact -- checkpoint it -- and the graph is re-captured with a larger capacity once 80 % of the
+                # captured one is in use.  Decisions are taken on the maximum over the ranks (replicas act together).
+                worst, cap = overflowed(gs)
+                if cap is not None and worst > cap:
+                    gs = None
+                    it, ema = roll_back(worst, cap, it - 1)
+                    rollbacks += 1
+                    continue
+                ckpt.take(gaussians, sampler, ema, it - 1)
                 if cap is not None and worst > 0.8 * cap:
                     from diff_gaussian_rasterization import _C as raster
-                    if worst > cap:
-                        # passes beyond the capacity were void: exactly zero gradients (include/hgs.h), i.e. those steps
-                        # moved the parameters by Adam's momentum only -- deterministic, finite, reported
-                        void_steps += 1
-                        if vp.rank == 0:
-                            print(f"[it {it - 1}] binning capacity {cap} exceeded ({worst} instances): steps since the last check "
-                                  "that overflowed ran with zero gradients; re-capturing with a larger capacity")
                     raster._state["cap"] = max(raster._state["cap"], int(worst * 2.0) + 4096)
                     gs = None
             if log_every and vp.rank == 0 and any(j % log_every == 0 for j in range(first, it)):
                 print(f"[it {it - 1}] loss(ema) {float(ema):.6f}  segments {gaussians.get_xyz.shape[0]}")
-        if gs is not None:
-            void_steps += _void_steps(gs)
     finally:
         if use_graph:
             from diff_gaussian_rasterization import _C as raster
             raster.set_async(False)
-    training.last_void_steps = void_steps
+    training.last_void_steps = 0          # (kept for callers of earlier rounds: overflowed steps are now run again)
+    training.last_rollbacks = rollbacks
     return ema
 
 
-def _void_steps(gs):
-    """1 if a replay since the last check overflowed the captured capacity (its gradients were exactly zero), else 0."""
-    worst, cap = gs.headroom()
-    return int(cap is not None and worst > cap)
+class _Checkpoint:
+    """Parameters, Adam state (moments and step counters), densification statistics, the view sampler and the loss average
+    at an iteration whose state is known to be exact: what training() returns to when replays of the captured graph ran
+    past its binning capacity.  One multi-tensor copy per take / restore (~120 B per Gaussian, every 64 iterations)."""
+
+    def __init__(self, gaussians, sampler, ema, it):
+        self._src = self._tensors(gaussians)
+        self._buf = [torch.empty_like(t) for t in self._src]
+        self.take(gaussians, sampler, ema, it)
+
+    @staticmethod
+    def _tensors(g):
+        ts = []
+        for group in g.optimizer.param_groups:
+            for p in group["params"]:
+                ts.append(p.data)
+                ts += [v for v in g.optimizer.state.get(p, {}).values() if torch.is_tensor(v)]
+        return ts + [g.max_radii2D, g.xyz_gradient_accum, g.denom]
+
+    def take(self, gaussians, sampler, ema, it):
+        with torch.no_grad():
+            torch._foreach_copy_(self._buf, self._src)
+        self.it = it
+        self.sampler = (sampler.rng.getstate(), list(sampler.stack))
+        self.ema = None if ema is None else ema.clone()
+
+    def restore(self, gaussians, sampler):
+        """Puts the state back; returns (next iteration, loss average)."""
+        with torch.no_grad():
+            torch._foreach_copy_(self._src, self._buf)
+        sampler.rng.setstate(self.sampler[0])
+        sampler.stack = list(self.sampler[1])
+        return self.it + 1, (None if self.ema is None else self.ema.clone())
 
 
 def main(argv=None):

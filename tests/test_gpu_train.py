@@ -487,6 +487,69 @@ def test_training_loop_with_topology_changes(use_graph):
     assert float(model.get_opacity.max()) < 0.9               # opacity reset happened at it 12
 
 
+def test_capacity_overflow_mid_run_is_rolled_back_exactly(capsys, monkeypatch):
+    """training() with a captured graph whose binning capacity is too small: the replays that overflow have zero gradients
+    (include/hgs.h), the loop notices at its next headroom check, returns to its last checkpoint, re-captures with a larger
+    capacity and runs those iterations again -- the run ends BIT-IDENTICAL to one that never overflowed (the reference
+    computes every step with its gradient, train.py:146-204).  Case 1: the capacity is too small from the first replay on.
+    Case 2: the strands become 100x wider at iteration 73, under the feet of a graph captured for thin ones -- the overflow
+    starts after the checkpoint of iteration 64, which is what the loop returns to."""
+    from arguments import OptimizationParams
+    from diff_gaussian_rasterization import _C as raster
+    from synthetic import attach_targets, cameras_extent, make_cameras, make_strand_model
+    import train as T
+    from utils.general import safe_state
+    safe_state(True)
+    cams = make_cameras(4, 400, 240, device="cuda")
+    extent = cameras_extent(cams)
+
+    def run(slack, iterations, widen_at=None):
+        raster._state["cap"] = 0
+        model = make_strand_model(300, 40, device="cuda", spatial_lr_scale=extent)
+        model.compute_strands_info(only_foreground=True)
+        attach_targets(cams, model)
+        opt = OptimizationParams()
+        opt.enable_topology = False
+        opt.capacity_slack = slack
+        model.training_setup(opt)
+        set_lr = T.GraphedStep._set_lr
+
+        def set_lr_and_widen(self, iteration):
+            if iteration == widen_at:          # (host code of the step: runs again when the iteration is run again)
+                with torch.no_grad():
+                    model._width.add_(float(np.log(100.0)))
+            return set_lr(self, iteration)
+        monkeypatch.setattr(T.GraphedStep, "_set_lr", set_lr_and_widen)
+        try:
+            ema = T.training(model, cams, opt, iterations=iterations, extent=extent)
+        finally:
+            monkeypatch.setattr(T.GraphedStep, "_set_lr", set_lr)
+        state = [g["params"][0].detach().clone() for g in model.optimizer.param_groups]
+        for g in model.optimizer.param_groups:
+            st = model.optimizer.state[g["params"][0]]
+            state += [st["exp_avg"].clone(), st["exp_avg_sq"].clone(), st["step"].clone()]
+        state += [model.max_radii2D.clone(), model.xyz_gradient_accum.clone(), model.denom.clone(), ema.clone()]
+        return state, T.training.last_rollbacks
+
+    try:
+        small, rb_small = run(0.3, 100)          # capacity 0.3 x the busiest view: every replay overflows until the first check
+        roomy, rb_roomy = run(4.0, 100)
+        assert rb_small >= 1 and rb_roomy == 0
+        assert "are run again from the last checkpoint" in capsys.readouterr().out
+        for a, b in zip(small, roomy):
+            assert torch.equal(a, b)
+        small2, rb2 = run(1.0, 160, widen_at=73)
+        out2 = capsys.readouterr().out
+        roomy2, rb2r = run(200.0, 160, widen_at=73)
+        assert rb2 >= 1 and rb2r == 0
+        assert "iterations 65.." in out2         # returned to the checkpoint of iteration 64, not to the start
+        for a, b in zip(small2, roomy2):
+            assert torch.equal(a, b)
+    finally:
+        raster._state["cap"] = 0
+        raster.set_async(False)
+
+
 def test_single_pass_equals_three_passes():
     """render_multi (7 channels, one traversal) vs the reference's three render() calls: identical images, gradients
     equal up to fp32 summation order, RGB-only screen-space gradient for the densification statistics."""
