@@ -603,8 +603,10 @@ def training(gaussians, cameras, opt, iterations=None, extent=1.0, seed=0, log_e
                         it, ema = roll_back(worst, cap, it - 1)
                         rollbacks += 1
                         continue
-                loss, _, _ = training_step(gaussians, sampler.next(), opt, bg, it, extent=extent, vp=vp, fused=fused)
-                losses = [loss]
+                # only the (detached) loss is kept: the terms and the render package of an op-by-op iteration hold its autograd
+                # graph -- and with it the parameters' AccumulateGrad nodes, created on THIS stream -- alive, which breaks the
+                # next capture on the side stream (stream mismatch; observed as a crash in capture_end)
+                losses = [training_step(gaussians, sampler.next(), opt, bg, it, extent=extent, vp=vp, fused=fused)[0]]
                 if fused is not None and due:
                     fused.refresh()
             first, it = it, it + len(losses)

@@ -487,6 +487,29 @@ def test_training_loop_with_topology_changes(use_graph):
     assert float(model.get_opacity.max()) < 0.9               # opacity reset happened at it 12
 
 
+def test_op_by_op_graph_loop_recaptures_cleanly_after_eager_iterations(recwarn):
+    """training() with the op-by-op iteration (fused_step off) under graph replay: iterations on which a topology operator
+    is due run eagerly on the current stream and the graph is captured again on its side stream afterwards.  Nothing of
+    the eager iteration's autograd graph may survive it (a merge round that merges nothing keeps the parameters, whose
+    AccumulateGrad nodes would then belong to the wrong stream: seen as a crash in capture_end at 100 k segments)."""
+    from arguments import OptimizationParams
+    from synthetic import build_workload
+    from train import training
+    from utils.general import safe_state
+    safe_state(True)
+    model, cams, extent = build_workload("tiny", device="cuda", with_targets=True)
+    opt = OptimizationParams()
+    opt.fused_step = False
+    opt.merge_interval, opt.merge_dist_th_init, opt.merge_dist_th_final = 5, 1e-9, 1e-9     # merge rounds that find nothing
+    model.training_setup(opt)
+    P0 = model.get_xyz.shape[0]
+    for chunk in range(2):
+        ema = training(model, cams, opt, iterations=12, extent=extent, start_iteration=12 * chunk)
+        assert torch.isfinite(ema)
+    assert model.get_xyz.shape[0] == P0
+    assert not [w for w in recwarn.list if "AccumulateGrad" in str(w.message)]
+
+
 def test_capacity_overflow_mid_run_is_rolled_back_exactly(capsys, monkeypatch):
     """training() with a captured graph whose binning capacity is too small: the replays that overflow have zero gradients
     (include/hgs.h), the loop notices at its next headroom check, returns to its last checkpoint, re-captures with a larger
