@@ -322,6 +322,59 @@ def test_hair_densification_split_clone_prune():
     _chain_invariants(m)
 
 
+def test_hair_sort_spatially_restores_strand_order_without_changing_the_model():
+    """HairGaussianModel.sort_spatially: after clones / splits / merges appended their results at the end of the arrays,
+    the storage goes back to strand by strand, root -> tip -- parameters, Adam moments, statistics and id tables by ONE
+    pair of permutations; the model (segments with their attributes, strands as vertex sequences) is unchanged as a set,
+    and a second call finds nothing to move."""
+    from scene.hair_gaussian_model import HairGaussianModel
+    from synthetic import strand_polylines
+    torch.manual_seed(0)
+    m = HairGaussianModel.from_strands(strand_polylines(12, 10, seed=5), device="cpu")
+    opt = OptimizationParams()
+    opt.spatial_sort = False                      # (the operators below must leave their mess behind)
+    m.training_setup(opt)
+    m.compute_strands_info()
+    # a few Adam steps so that moments differ per element, then operators that append / prune
+    for _ in range(2):
+        ((m._endpoints ** 2).sum() * 30 + (m._opacity ** 2).sum() + (m._features_dc ** 3).sum() + (m._width ** 2).sum()
+         + (m._mask ** 2).sum()).backward()
+        m.optimizer.step()
+        m.optimizer.zero_grad(set_to_none=True)
+    m.denom[:] = 1.0
+    m.xyz_gradient_accum[::3] = 1.0               # every third segment is split in two
+    m.densification(extent=1e-3, max_screen_size=None)
+    m.xyz_gradient_accum[:, 0] = torch.arange(m.endpoint_pairs.shape[0], dtype=torch.float32)
+    m.max_radii2D = 2 * torch.arange(m.endpoint_pairs.shape[0], dtype=torch.float32)
+
+    def segment_records(model):
+        ep = model._endpoints.detach()[model.endpoint_pairs]                 # [P, 2, 3]
+        st_w = model.optimizer.state[model._width]
+        st_e = model.optimizer.state[model._endpoints]
+        mom_e = st_e["exp_avg"][model.endpoint_pairs]                        # endpoint moments seen from the segments
+        rec = torch.cat([ep.reshape(-1, 6), model._opacity.detach(), model._width.detach(), model._features_dc.detach().reshape(-1, 3),
+                         st_w["exp_avg"], st_w["exp_avg_sq"], mom_e.reshape(-1, 6), model.xyz_gradient_accum,
+                         model.max_radii2D[:, None]], dim=1).numpy()
+        return rec[np.lexsort(rec.T[::-1])]
+
+    def strands_as_points(model):
+        ep = model._endpoints.detach().numpy()
+        return sorted(tuple(map(tuple, ep[np.r_[s[:, 0], s[-1, 1]]].tolist())) for s in model.strands_info.list_strands)
+    before, strands_before = segment_records(m), strands_as_points(m)
+    rows0 = [np.asarray(r) for r in m.strands_info.list_strands_segments_id]
+    assert any(np.any(np.diff(r) != 1) for r in rows0)                        # storage IS scrambled
+    perms = m.sort_spatially()
+    assert perms is not None and sorted(perms[0].tolist()) == list(range(m.endpoint_pairs.shape[0]))
+    _chain_invariants(m)
+    assert np.array_equal(segment_records(m), before) and strands_as_points(m) == strands_before
+    # strand by strand: the segments of a strand are consecutive rows, its vertices consecutive ids, root first
+    for rows, seq in zip(m.strands_info.list_strands_segments_id, m.strands_info.list_strands):
+        assert np.all(np.diff(rows) == 1) and np.all(np.diff(seq[:, 0]) == 1) and np.all(seq[:, 1] == seq[:, 0] + 1)
+    for g in m.optimizer.param_groups:
+        assert g["params"][0] is getattr(m, dict(m._PARAM_ATTRS)[g["name"]]) and g["params"][0].requires_grad
+    assert m.sort_spatially() is None
+
+
 def test_merge_collapsed_segment_fuses_its_endpoints():
     from scene.hair_gaussian_model import HairGaussianModel
     from synthetic import strand_polylines
