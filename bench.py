@@ -200,6 +200,8 @@ def main():
     opt.fused_step = not args.op_by_op
     opt.defer_head_tail = not args.head_tail_launch
     opt.ride_prologue = not args.prologue_launch
+    if os.environ.get("HGS_SKIP_UNREAD") == "0":   # A/B: the SSIM backward filters every block the 3x3 zero rule does not spare
+        opt.skip_unread_blocks = False
     opt.enable_topology = False  # densify/merge intervals (every 100 it) are reported separately, not in the timed loop
     model.training_setup(opt)
     bg = torch.zeros(3, dtype=torch.float32, device=dev)

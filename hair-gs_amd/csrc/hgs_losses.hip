@@ -667,6 +667,7 @@ __device__ __forceinline__ void head_part1(const HeadReduce& h, const float* __r
   out[HGS_HEAD_G_SMOOTH] = h.nb_smooth > 0 ? h.l_smooth : 0.f;
 }
 
+#define HEAD_MAX_TILES 32768     // tiles of a frame the list builder keeps the use bits of (4K: 32400); more: the hint is ignored
 #define HEAD_MAX_FLAGGED 32768   // SSIM blocks of a frame the backward's block lists are built for (4K RGB: 24480); without the lists (and the zero-block flags that come with them) the SSIM pair takes 90 instead of 77 us at north_star
 static_assert(HEAD_MAX_FLAGGED % (32 * 256) == 0, "whole 32-block words per thread of the list builder");
 // Block lists of the SSIM backward, built by ONE workgroup of pix_fwd_kernel (the SSIM forward before that launch flagged
@@ -675,14 +676,36 @@ static_assert(HEAD_MAX_FLAGGED % (32 * 256) == 0, "whole 32-block words per thre
 // a = dS/dmu1 == 0 on its halo tile and x1 == x2 == 0 on its own pixels, its gradient is exactly zero and the backward
 // reads nothing for it.  (Round 2 built the lists in the single-workgroup finalize kernel, on the iteration's critical
 // path: 2.7 us of its 8.4.)
+//   tile_used (may be NULL; HgsHeadParams.tile_used): the rasterizer's per-tile contributor count.  The blend backward
+//   reads dL/dimage only on tiles where some pixel blended an entry, so a block none of whose 2x2 tiles did is left out
+//   of BOTH lists -- neither filtered nor zero-filled: nobody reads its gradient.  (The 3x3 rule above has to spare a
+//   block next to the hair, whose gradient is not zero; this rule looks at who reads it: 23 % -> 1/3 of the blocks of a
+//   hair frame need no filter pass.)
 __device__ __forceinline__ void build_block_lists(const SsimGrid& gd, const unsigned char* __restrict__ zero_flags,
-                                                  int* __restrict__ lists) {
+                                                  int* __restrict__ lists, const unsigned int* __restrict__ tile_used,
+                                                  int tiles_x, int tiles_y) {
   __shared__ unsigned zbits[HEAD_MAX_FLAGGED / 32], wbits[HEAD_MAX_FLAGGED / 32];   // zero flags; has-work bits, [word][thread]
-  __shared__ int wsum[4];
+  __shared__ unsigned ubits[HEAD_MAX_FLAGGED / 32];                                  // somebody reads the block's gradient
+  __shared__ unsigned tbits[HEAD_MAX_TILES / 32];                                    // tile_used as a bitmap
+  __shared__ int wsum[4], zsum[4];
   const int total = gd.total, nwords = (total + 31) >> 5;
   // bit b of zbits = zero flag of block b: every thread packs runs of 32 flag bytes (eight independent word loads; the
   // bytes behind the last flag belong to the same scratch buffer and are masked off)
   const unsigned* zf = (const unsigned*)zero_flags;   // (4-byte aligned: the flags start on a float of the scratch)
+  // The tile hint becomes a bitmap in LDS.  Its loads -- 16-byte, eight per thread, all of a 1080p frame's 8160 words in
+  // ONE round trip -- are issued in front of the zero-flag loads below and consumed behind them: this workgroup's chain of
+  // memory round trips is what the whole launch waits for while 8100 pixel workgroups saturate HBM (one load per trip: 32
+  // trips, the launch 36 instead of 21 us).
+  const int n_tiles = tiles_x * tiles_y;
+  if (tile_used && (n_tiles > HEAD_MAX_TILES || ((size_t)tile_used & 15))) tile_used = nullptr;
+  const uint4* tu4 = (const uint4*)tile_used;
+  const int n4 = (n_tiles + 3) >> 2;
+  uint4 tv[8];
+  if (tile_used) {
+    for (int i = threadIdx.x; i < HEAD_MAX_TILES / 32; i += 256) tbits[i] = 0u;
+#pragma unroll
+    for (int u = 0; u < 8; u++) tv[u] = tu4[min(u * 256 + (int)threadIdx.x, n4 - 1)];   // (the words behind the last tile belong to the image buffer)
+  }
 #pragma unroll 1
   for (int w = threadIdx.x; w < nwords; w += 256) {
     unsigned v[8];
@@ -695,74 +718,119 @@ __device__ __forceinline__ void build_block_lists(const SsimGrid& gd, const unsi
     if (left < 32) bits &= (1u << left) - 1u;
     zbits[w] = bits;
   }
+  if (tile_used) {
+    __syncthreads();                                   // (tbits cleared)
+    for (int base = 0; base < n4; base += 8 * 256) {
+      if (base) {
+#pragma unroll
+        for (int u = 0; u < 8; u++) tv[u] = tu4[min(base + u * 256 + (int)threadIdx.x, n4 - 1)];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        const int q = base + u * 256 + (int)threadIdx.x, t = 4 * q;      // tiles t .. t + 3: one nibble of a word
+        if (q < n4) {
+          unsigned nib = (tv[u].x != 0u ? 1u : 0u) | (tv[u].y != 0u ? 2u : 0u) | (tv[u].z != 0u ? 4u : 0u) | (tv[u].w != 0u ? 8u : 0u);
+          if (t + 4 > n_tiles) nib &= (1u << (n_tiles - t)) - 1u;
+          if (nib) atomicOr(&tbits[t >> 5], nib << (t & 31));
+        }
+      }
+    }
+  }
   __syncthreads();
   const int per = gd.nbx * gd.nby;
   const int per_thread = (total + 255) / 256;          // <= HEAD_MAX_FLAGGED / 256
   const int first = threadIdx.x * per_thread;
-  int cnt = 0;
+  int cnt = 0, cnt_z = 0;
   int c = first / per, by = (first - c * per) / gd.nbx, bx = first - c * per - by * gd.nbx;   // block `first`; then stepped
-#pragma unroll 1
+  // (predicated and unrolled: the LDS reads of four blocks are in flight together, the result bits gather in registers -- as a
+  // serial chain of 13 dependent LDS reads and two LDS read-modify-writes per block this loop was most of the workgroup's
+  // time, and this workgroup is what the launch waits for)
+  unsigned wacc = 0u, uacc = 0u;
+#pragma unroll 4
   for (int k = 0; k < per_thread; k++) {
-    if (first + k >= total) break;
+    const unsigned valid = first + k < total ? 1u : 0u;
+    unsigned used = 1u;
+    if (tile_used) {                                   // the block's 2 x 2 tiles of 16 x 16 pixels (LT = 2 * HGS_TILE)
+      used = 0u;
+#pragma unroll
+      for (int ty = 0; ty < LT / HGS_TILE; ty++)
+#pragma unroll
+        for (int tx = 0; tx < LT / HGS_TILE; tx++) {
+          const int X = bx * (LT / HGS_TILE) + tx, Y = by * (LT / HGS_TILE) + ty;
+          const int t = min(Y, tiles_y - 1) * tiles_x + min(X, tiles_x - 1);
+          const unsigned bit = (tbits[t >> 5] >> (t & 31)) & 1u;
+          used |= (X < tiles_x && Y < tiles_y) ? bit : 0u;
+        }
+    }
     unsigned zero = 1u;
 #pragma unroll
     for (int dy = -1; dy <= 1; dy++) {
-      const int row = c * per + min(max(by + dy, 0), gd.nby - 1) * gd.nbx;   // (outside the frame: zero)
+      const int row = min(c, gd.C - 1) * per + min(max(by + dy, 0), gd.nby - 1) * gd.nbx;   // (outside the frame: zero)
 #pragma unroll
       for (int dx = -1; dx <= 1; dx++) {
         const int nb = row + min(max(bx + dx, 0), gd.nbx - 1);
         zero &= zbits[nb >> 5] >> (nb & 31);
       }
     }
-    const unsigned has_work = (zero & 1u) ^ 1u;
-    if ((k & 31) == 0) wbits[(k >> 5) * 256 + threadIdx.x] = 0u;
-    wbits[(k >> 5) * 256 + threadIdx.x] |= has_work << (k & 31);     // (this thread's own words)
+    used &= valid;
+    const unsigned has_work = ((zero & 1u) ^ 1u) & used;
+    wacc |= has_work << (k & 31);
+    uacc |= used << (k & 31);
+    if ((k & 31) == 31 || k == per_thread - 1) {       // (this thread's own words)
+      wbits[(k >> 5) * 256 + threadIdx.x] = wacc; ubits[(k >> 5) * 256 + threadIdx.x] = uacc;
+      wacc = 0u; uacc = 0u;
+    }
     cnt += (int)has_work;
+    cnt_z += (int)(used & (has_work ^ 1u));            // read by the blend backward, gradient exactly zero: zero-filled
     if (++bx == gd.nbx) { bx = 0; if (++by == gd.nby) { by = 0; c++; } }
   }
-  int inc = cnt;                                       // inclusive scan over the wave, then over the 4 wave totals
+  int inc = cnt, inc_z = cnt_z;                        // inclusive scans over the wave, then over the 4 wave totals
 #pragma unroll
   for (int d = 1; d < 64; d <<= 1) {
-    const int v = __shfl_up(inc, d, 64);
-    if ((int)(threadIdx.x & 63) >= d) inc += v;
+    const int v = __shfl_up(inc, d, 64), vz = __shfl_up(inc_z, d, 64);
+    if ((int)(threadIdx.x & 63) >= d) { inc += v; inc_z += vz; }
   }
-  if ((threadIdx.x & 63) == 63) wsum[threadIdx.x >> 6] = inc;
+  if ((threadIdx.x & 63) == 63) { wsum[threadIdx.x >> 6] = inc; zsum[threadIdx.x >> 6] = inc_z; }
   __syncthreads();
-  int base = 0, all = 0;
+  int base = 0, all = 0, base_z = 0, all_z = 0;
 #pragma unroll
   for (int k = 0; k < 4; k++) {
-    const int v = wsum[k];
-    if (k < (int)(threadIdx.x >> 6)) base += v;
-    all += v;
+    const int v = wsum[k], vz = zsum[k];
+    if (k < (int)(threadIdx.x >> 6)) { base += v; base_z += vz; }
+    all += v; all_z += vz;
   }
-  int w = base + inc - cnt;                            // work blocks before this thread's first block
+  int w = base + inc - cnt, z = base_z + inc_z - cnt_z;   // work / zero-fill blocks before this thread's first block
   int* work = lists + 4;
   int* skipped = work + total;
+  unsigned ww = 0u, uu = 0u;
 #pragma unroll 1
   for (int k = 0; k < per_thread; k++) {
     const int id = first + k;
     if (id >= total) break;
-    if (wbits[(k >> 5) * 256 + threadIdx.x] >> (k & 31) & 1u) work[w++] = id;
-    else skipped[id - w] = id;
+    if ((k & 31) == 0) { ww = wbits[(k >> 5) * 256 + threadIdx.x]; uu = ubits[(k >> 5) * 256 + threadIdx.x]; }
+    if (ww >> (k & 31) & 1u) work[w++] = id;
+    else if (uu >> (k & 31) & 1u) skipped[z++] = id;
   }
-  if (threadIdx.x == 0) { lists[0] = all; lists[1] = total - all; }
+  if (threadIdx.x == 0) { lists[0] = all; lists[1] = all_z; }
 }
 
 #define PIX_SIDE_WGS 2
-__global__ __launch_bounds__(256) void pix_fwd_kernel(int N, HeadFlags fl, float bg0, float bg1, float bg2, float min_val,
+// (8 waves per SIMD, i.e. at most 64 VGPRs: the pixel workgroups need the occupancy; the two side workgroups fit in)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8))) void pix_fwd_kernel(int N, HeadFlags fl, float bg0, float bg1, float bg2, float min_val,
                                                       const float* __restrict__ mask_img, const float* __restrict__ omap,
                                                       const HgsViewTargets* __restrict__ tgt, float* __restrict__ partials,
                                                       float g_mask, float g_ori, float* __restrict__ d_unit, SsimGrid gd,
                                                       const unsigned char* __restrict__ zero_flags,
                                                       int* __restrict__ lists, HeadReduce h,
                                                       const float* __restrict__ p_ssim, const float* __restrict__ p_smooth,
-                                                      float* __restrict__ out) {
+                                                      float* __restrict__ out, const unsigned int* __restrict__ tile_used,
+                                                      int tiles_x, int tiles_y) {
   __shared__ float red[4];
   // The first two workgroups dispatched do the head's side jobs and nothing else (each is a chain of a few memory round
   // trips, several us apiece while the rest of the launch saturates HBM: as extra work of a pixel workgroup they made
   // that workgroup the launch's last, 20.5 -> 24 us; on their own 20.5 -> 22)
   if (blockIdx.x < PIX_SIDE_WGS) {
-    if (blockIdx.x == 0) { if (lists) build_block_lists(gd, zero_flags, lists); }
+    if (blockIdx.x == 0) { if (lists) build_block_lists(gd, zero_flags, lists, tile_used, tiles_x, tiles_y); }
     else head_part1(h, p_ssim, p_smooth, out);
     return;
   }
@@ -1015,7 +1083,7 @@ int hgs_loss_head_forward(void* stream, const HgsHeadParams* p, const float* ima
     hipLaunchKernelGGL(pix_fwd_kernel, dim3(nbp + PIX_SIDE_WGS), dim3(256), 0, s, N, fl, p->bg[0], p->bg[1], p->bg[2], p->min_val, mask_img,
                        omap, targets, p_pix, fl.bce ? p->lambda_mask / (float)N : 0.f, fl.ori ? p->lambda_orientation : 0.f,
                        d_extra_unit, ssim_grid(3, H, W), (const unsigned char*)head_zero_flags(p, scratch), lists, h,
-                       (const float*)p_ssim, p_smooth, out);
+                       (const float*)p_ssim, p_smooth, out, p->tile_used, p->tiles_x, p->tiles_y);
   }
   if (!p->defer_tail) {
     HgsHeadTail t;

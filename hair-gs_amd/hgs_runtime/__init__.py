@@ -104,7 +104,8 @@ class HeadParams(C.Structure):
     """include/hgs.h HgsHeadParams."""
     _fields_ = [("H", ci), ("W", ci), ("lambda_dssim", cf), ("lambda_mask", cf), ("lambda_orientation", cf),
                 ("lambda_smooth", cf), ("bg", cf * 3), ("min_val", cf), ("window", cf * 11), ("n_smooth", ci),
-                ("cos_threshold", cf), ("eps", cf), ("n_endpoints", ci), ("defer_tail", ci)]
+                ("cos_threshold", cf), ("eps", cf), ("n_endpoints", ci), ("defer_tail", ci), ("tile_used", vp),
+                ("tiles_x", ci), ("tiles_y", ci)]
 
 
 class HeadTail(C.Structure):

@@ -229,6 +229,15 @@ def _raster_head_forward(step, xyz, scale, quat, opacity, extra4, shs, endpoints
         step.bg7, xyz, empty, extra4, opacity, scale, quat, 1.0, empty, vt.viewmatrix, vt.projmatrix, vt.tanfovx,
         vt.tanfovy, vt.H, vt.W, shs, g.active_sh_degree, vt.campos, False, False, image_buffer=vt.take_image())
     hp.n_endpoints = n_endpoints
+    # the blend backward reads dL/dimage only on tiles where a pixel blended an entry (the image buffer's per-tile
+    # contributor count, written by the forward pass above): the SSIM backward leaves the other blocks alone
+    if step.skip_unread_blocks:
+        if step._tile_maxc_offset is None:
+            step._tile_maxc_offset = rt.layout("image", vt.W, vt.H)["tile_maxc"]
+        hp.tile_used = img.data_ptr() + step._tile_maxc_offset
+        hp.tiles_x, hp.tiles_y = (vt.W + 15) // 16, (vt.H + 15) // 16
+    else:
+        hp.tile_used = None
     scratch = torch.empty((L.hgs_loss_head_scratch_floats(C.byref(hp)),), **f32)
     out = torch.empty((rt.HEAD_NOUT,), **f32)
     # gradient planes of the per-pixel terms for an upstream gradient of 1, written by the forward's own pass over
@@ -391,6 +400,9 @@ class FusedStrandStep:
         self.one = torch.ones((), dtype=torch.float32, device=dev)   # d loss / d loss, passed to backward(): no fill launch
         self.one_pass_pixels = True    # per-pixel loss terms: value and gradient in one pass over the pixels
         self.stats_in_backward = True  # densification statistics updated by the backward's last launch
+        # dL/dimage is produced only where the rasterizer backward reads it (include/hgs.h HgsHeadParams.tile_used)
+        self.skip_unread_blocks = bool(getattr(opt, "skip_unread_blocks", True))
+        self._tile_maxc_offset = None
         # True: the loss terms (loss(), terms()) are complete only once backward() has run -- the head's last sums ride in
         # the backward's parameter launch instead of a launch of their own (GraphedStep, which always runs both, sets it)
         self.defer_tail = False

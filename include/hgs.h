@@ -335,7 +335,7 @@ int hgs_cloud_params_backward(void* stream, int P, const float* scaling_raw, con
  *   passes HGS_HEAD_SKIP_PIXELS to the backward and uses those planes as they are.
  *   smooth_partials_ext (may be NULL): smoothness partial sums already computed elsewhere (HgsStrandFusion): the head then
  *   launches no smoothness kernel of its own and reduces these.
- *   backward: d_image [3,H,W] fully written; d_mask_img [H,W], d_omap [3,H,W] fully written unless HGS_HEAD_SKIP_PIXELS;
+ *   backward: d_image [3,H,W] fully written (but see HgsHeadParams.tile_used); d_mask_img [H,W], d_omap [3,H,W] fully written unless HGS_HEAD_SKIP_PIXELS;
  *   d_endpoints [E,3] zeroed, then (unless HGS_HEAD_SKIP_SMOOTH) the smoothness gradient scattered into it;
  *   grad_out = device scalar dL/dtotal. */
 enum { HGS_HEAD_SKIP_PIXELS = 1, HGS_HEAD_SKIP_SMOOTH = 2 };
@@ -349,6 +349,12 @@ typedef struct HgsHeadParams {
   float cos_threshold, eps;     /* loss/losses.py:175: threshold 30 deg, eps 1e-6 */
   int n_endpoints;
   int defer_tail;               /* != 0: the forward leaves the sums over the per-pixel partials (see HgsHeadTail) to the caller */
+  /* Optional hint (NULL: none): tile_used[ty * tiles_x + tx] != 0 <=> the consumer of d_image reads the 16 x 16 tile
+   * (tx, ty).  For the rasterizer backward that is the image buffer's per-tile contributor count (hgs_image_layout,
+   * HGS_IMG_TILE_MAXC) of the forward pass that produced `image`: it touches dL/dpixel only where a pixel blended an entry.
+   * With the hint, hgs_loss_head_backward leaves d_image UNWRITTEN on 32 x 32 blocks none of whose tiles is read (it
+   * neither filters nor zero-fills them). */
+  const unsigned int* tile_used; int tiles_x, tiles_y;
 } HgsHeadParams;
 enum { HGS_HEAD_TOTAL = 0, HGS_HEAD_L1, HGS_HEAD_DSSIM, HGS_HEAD_MASK, HGS_HEAD_ORIENTATION, HGS_HEAD_SMOOTH,
        HGS_HEAD_ORI_COUNT, HGS_HEAD_SMOOTH_COUNT, HGS_HEAD_G_SSIM, HGS_HEAD_G_L1, HGS_HEAD_G_MASK, HGS_HEAD_G_ORI,

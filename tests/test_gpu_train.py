@@ -909,6 +909,44 @@ def test_fused_iteration_is_bitwise_reproducible(workload):
         assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize("workload", ["tiny", "north_star"])
+def test_unread_image_gradient_blocks_change_no_parameter_gradient(workload):
+    """HgsHeadParams.tile_used: the SSIM backward neither filters nor zero-fills the 32 x 32 blocks of dL/dimage whose
+    tiles the blend backward never reads (no pixel there blended an entry).  Loss terms, every parameter gradient and the
+    densification statistics are bit-identical with and without; the number of filtered blocks drops."""
+    from arguments import OptimizationParams
+    from hgs_runtime.strand_step import FusedStrandStep
+    from synthetic import build_workload
+    from utils.general import safe_state
+    safe_state(True)
+    model, cams, _ = (build_workload("tiny", device="cuda", with_targets=True) if workload == "tiny"
+                      else build_workload(workload, device="cuda", with_targets=True, n_views=2))
+    opt = OptimizationParams()
+    model.training_setup(opt)
+    with torch.no_grad():
+        model._endpoints.add_(0.002 * torch.randn_like(model._endpoints))
+    fused = FusedStrandStep(model, cams, opt, torch.zeros(3, device="cuda"))
+    params = [model._endpoints, model._width, model._opacity, model._mask, model._features_dc]
+    runs = {}
+    for skip in (False, True):
+        fused.skip_unread_blocks = skip
+        for p in params:
+            p.grad = None
+        for t in (model.max_radii2D, model.xyz_gradient_accum, model.denom):
+            t.zero_()
+        fused.views.select(1)
+        loss, terms = fused.loss()
+        fused.backward(loss)
+        fused.update_densification_stats()
+        # the block lists sit behind the zero flags in the head's scratch: [n_work, n_zero_fill, ...]
+        runs[skip] = (loss.detach().clone(), terms.clone(), [p.grad.clone() for p in params],
+                      [model.max_radii2D.clone(), model.xyz_gradient_accum.clone(), model.denom.clone()])
+    n_terms = 14     # (hgs.h HGS_HEAD_TOTAL_FWD + 1: the two words behind are padding nobody writes)
+    assert torch.equal(runs[False][0], runs[True][0]) and torch.equal(runs[False][1][:n_terms], runs[True][1][:n_terms])
+    for a, b in zip(runs[False][2] + runs[False][3], runs[True][2] + runs[True][3]):
+        assert torch.equal(a, b)
+
+
 @pytest.mark.parametrize("use_graph", [False, True])
 def test_stage1_training_loop_with_densification(use_graph):
     """training() on the Stage-I cloud through the fused cloud iteration: densification (clone / split / prune) and the
