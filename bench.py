@@ -68,10 +68,11 @@ def parse():
                     help="optimizer steps captured per graph launch (GraphedStep.step_many; 1 GPU, one view per step; the "
                          "steps that do not fill a launch replay the single-step graph)")
     ap.add_argument("--sustained-seconds", type=float, default=2.0, help="length of the sustained leg (0: skip)")
-    ap.add_argument("--trained-iters", type=int, default=1000,
-                    help="second leg (1 GPU): train this many iterations WITH the topology operators (densification, merging, "
-                         "opacity reset), then time the same protocol on that state; reported beside the headline as "
-                         "`trained_state` (0: skip)")
+    ap.add_argument("--trained-iters", type=int, default=0,
+                    help="second leg (1 GPU), e.g. 1000: train this many iterations WITH the topology operators (densification, "
+                         "merging, opacity reset), then time the same protocol on that state; reported beside the headline as "
+                         "`trained_state`.  Off by default so that the rocprofv3 kernel statistics of the default command average "
+                         "ONE state per kernel (profiles/ holds a run with it)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true", help="disable per-kernel HIP-event timing")
     ap.add_argument("--three-pass", action="store_true",

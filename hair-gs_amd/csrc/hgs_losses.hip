@@ -667,6 +667,9 @@ __device__ __forceinline__ void head_part1(const HeadReduce& h, const float* __r
   out[HGS_HEAD_G_SMOOTH] = h.nb_smooth > 0 ? h.l_smooth : 0.f;
 }
 
+#ifndef HGS_PIX_TRACE
+#define HGS_PIX_TRACE 0   // development aid: timestamps of the side workgroups behind the block lists (tools/dev/pix_trace.py)
+#endif
 #define HEAD_MAX_TILES 32768     // tiles of a frame the list builder keeps the use bits of (4K: 32400); more: the hint is ignored
 #define HEAD_MAX_FLAGGED 32768   // SSIM blocks of a frame the backward's block lists are built for (4K RGB: 24480); without the lists (and the zero-block flags that come with them) the SSIM pair takes 90 instead of 77 us at north_star
 static_assert(HEAD_MAX_FLAGGED % (32 * 256) == 0, "whole 32-block words per thread of the list builder");
@@ -681,31 +684,49 @@ static_assert(HEAD_MAX_FLAGGED % (32 * 256) == 0, "whole 32-block words per thre
 //   of BOTH lists -- neither filtered nor zero-filled: nobody reads its gradient.  (The 3x3 rule above has to spare a
 //   block next to the hair, whose gradient is not zero; this rule looks at who reads it: 23 % -> 1/3 of the blocks of a
 //   hair frame need no filter pass.)
+// even bits of a 64-bit value, compressed into its low 32 bits
+__device__ __forceinline__ unsigned even_bits(unsigned long long x) {
+  x &= 0x5555555555555555ull;
+  x = (x | (x >> 1)) & 0x3333333333333333ull;
+  x = (x | (x >> 2)) & 0x0F0F0F0F0F0F0F0Full;
+  x = (x | (x >> 4)) & 0x00FF00FF00FF00FFull;
+  x = (x | (x >> 8)) & 0x0000FFFF0000FFFFull;
+  x = (x | (x >> 16)) & 0x00000000FFFFFFFFull;
+  return (unsigned)x;
+}
+
 __device__ __forceinline__ void build_block_lists(const SsimGrid& gd, const unsigned char* __restrict__ zero_flags,
                                                   int* __restrict__ lists, const unsigned int* __restrict__ tile_used,
                                                   int tiles_x, int tiles_y) {
-  __shared__ unsigned zbits[HEAD_MAX_FLAGGED / 32], wbits[HEAD_MAX_FLAGGED / 32];   // zero flags; has-work bits, [word][thread]
-  __shared__ unsigned ubits[HEAD_MAX_FLAGGED / 32];                                  // somebody reads the block's gradient
-  __shared__ unsigned tbits[HEAD_MAX_TILES / 32];                                    // tile_used as a bitmap
+#if HGS_PIX_TRACE
+#define BL_STAMP(k) do { __syncthreads(); if (threadIdx.x == 0) lists[4 + 2 * gd.total + 7 + (k)] = (int)(unsigned)__builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define BL_STAMP(k) do { } while (0)
+#endif
+  // This workgroup is what the launch waits for (timestamps, tools/dev/pix_trace.py: the 8100 pixel workgroups are through
+  // after 17 us; a builder that gave every thread a run of 24 consecutive blocks -- 13 dependent LDS reads and two LDS
+  // read-modify-writes per block, then one store at a time -- ended at 21-25 us).  Now everything is done on 32-block WORDS:
+  // bitmaps in LDS from loads that are all in flight together; one thread per word forms the 3x3 test from nine funnel
+  // shifts of the zero bitmap (edge masks: a neighbour outside the frame is ignored) and the 2x2-tile test from the tile
+  // bitmap (pairs OR-ed, even bits compressed); counts, one scan, and every thread emits the ids of its own words.
+  constexpr int WPT = HEAD_MAX_FLAGGED / 32 / 256;     // words per thread of the largest frame
+  __shared__ unsigned zbits[HEAD_MAX_FLAGGED / 32];    // zero flags of the blocks (bits behind the last block: 1)
+  __shared__ unsigned tbits[HEAD_MAX_TILES / 32 + 2];  // tile_used as a bitmap
   __shared__ int wsum[4], zsum[4];
   const int total = gd.total, nwords = (total + 31) >> 5;
-  // bit b of zbits = zero flag of block b: every thread packs runs of 32 flag bytes (eight independent word loads; the
-  // bytes behind the last flag belong to the same scratch buffer and are masked off)
   const unsigned* zf = (const unsigned*)zero_flags;   // (4-byte aligned: the flags start on a float of the scratch)
-  // The tile hint becomes a bitmap in LDS.  Its loads -- 16-byte, eight per thread, all of a 1080p frame's 8160 words in
-  // ONE round trip -- are issued in front of the zero-flag loads below and consumed behind them: this workgroup's chain of
-  // memory round trips is what the whole launch waits for while 8100 pixel workgroups saturate HBM (one load per trip: 32
-  // trips, the launch 36 instead of 21 us).
   const int n_tiles = tiles_x * tiles_y;
   if (tile_used && (n_tiles > HEAD_MAX_TILES || ((size_t)tile_used & 15))) tile_used = nullptr;
   const uint4* tu4 = (const uint4*)tile_used;
   const int n4 = (n_tiles + 3) >> 2;
   uint4 tv[8];
   if (tile_used) {
-    for (int i = threadIdx.x; i < HEAD_MAX_TILES / 32; i += 256) tbits[i] = 0u;
+    for (int i = threadIdx.x; i < HEAD_MAX_TILES / 32 + 2; i += 256) tbits[i] = 0u;
 #pragma unroll
     for (int u = 0; u < 8; u++) tv[u] = tu4[min(u * 256 + (int)threadIdx.x, n4 - 1)];   // (the words behind the last tile belong to the image buffer)
   }
+  // bit b of zbits = zero flag of block b: a thread packs runs of 32 flag bytes (eight independent word loads; the bytes
+  // behind the last flag belong to the same scratch buffer and are overwritten with ones: neutral in the tests below)
 #pragma unroll 1
   for (int w = threadIdx.x; w < nwords; w += 256) {
     unsigned v[8];
@@ -715,7 +736,7 @@ __device__ __forceinline__ void build_block_lists(const SsimGrid& gd, const unsi
 #pragma unroll
     for (int u = 0; u < 8; u++) bits |= (((v[u] & 0x01010101u) * 0x00204081u) >> 21 & 0xFu) << (4 * u);
     const int left = total - 32 * w;
-    if (left < 32) bits &= (1u << left) - 1u;
+    if (left < 32) bits |= ~((1u << left) - 1u);
     zbits[w] = bits;
   }
   if (tile_used) {
@@ -737,53 +758,65 @@ __device__ __forceinline__ void build_block_lists(const SsimGrid& gd, const unsi
     }
   }
   __syncthreads();
-  const int per = gd.nbx * gd.nby;
-  const int per_thread = (total + 255) / 256;          // <= HEAD_MAX_FLAGGED / 256
-  const int first = threadIdx.x * per_thread;
+  BL_STAMP(0);
+  const int per = gd.nbx * gd.nby, nbx = gd.nbx;
+  // 32 bits of the zero bitmap from bit `start` on; bits outside [0, total) read as 1
+  auto zfetch = [&](int start) -> unsigned {
+    const int wi = start >> 5, sh = start & 31;        // (arithmetic shift: floor)
+    const unsigned lo = (wi >= 0 && wi < nwords) ? zbits[wi] : 0xFFFFFFFFu;
+    const unsigned hi = (wi + 1 >= 0 && wi + 1 < nwords) ? zbits[wi + 1] : 0xFFFFFFFFu;
+    return sh ? (lo >> sh) | (hi << (32 - sh)) : lo;
+  };
+  // 64 bits of the tile bitmap from bit `start` (>= 0) on (the bitmap is zero behind the last tile)
+  auto tfetch = [&](int start) -> unsigned long long {
+    const int wi = start >> 5, sh = start & 31;
+    const unsigned long long a = tbits[wi], b = tbits[wi + 1], c = tbits[wi + 2];
+    const unsigned long long lo = a | (b << 32);
+    return sh ? (lo >> sh) | (c << (64 - sh)) : lo;
+  };
+  unsigned work_w[WPT], fill_w[WPT];
   int cnt = 0, cnt_z = 0;
-  int c = first / per, by = (first - c * per) / gd.nbx, bx = first - c * per - by * gd.nbx;   // block `first`; then stepped
-  // (predicated and unrolled: the LDS reads of four blocks are in flight together, the result bits gather in registers -- as a
-  // serial chain of 13 dependent LDS reads and two LDS read-modify-writes per block this loop was most of the workgroup's
-  // time, and this workgroup is what the launch waits for)
-  unsigned wacc = 0u, uacc = 0u;
-#pragma unroll 4
-  for (int k = 0; k < per_thread; k++) {
-    const unsigned valid = first + k < total ? 1u : 0u;
-    unsigned used = 1u;
-    if (tile_used) {                                   // the block's 2 x 2 tiles of 16 x 16 pixels (LT = 2 * HGS_TILE)
-      used = 0u;
+  const int wpt = (nwords + 255) >> 8, w_first = threadIdx.x * wpt;
 #pragma unroll
-      for (int ty = 0; ty < LT / HGS_TILE; ty++)
+  for (int q = 0; q < WPT; q++) {
+    work_w[q] = 0u; fill_w[q] = 0u;
+    const int w = w_first + q;
+    if (q >= wpt || w >= nwords) continue;
+    const int b0 = 32 * w;
+    // edge masks of the word's blocks, and its row segments for the tile test
+    unsigned L = 0u, R = 0u, T = 0u, Bm = 0u, used = tile_used ? 0u : 0xFFFFFFFFu;
+    int r = b0 % per, by = r / nbx, bx = r - by * nbx;
+    for (int i = 0; i < 32;) {
+      const int len = min(32 - i, nbx - bx);           // blocks i .. i + len - 1 of the word lie in block row `by`
+      const unsigned seg = (len == 32 ? 0xFFFFFFFFu : ((1u << len) - 1u)) << i;
+      if (bx == 0) L |= 1u << i;
+      if (bx + len == nbx) R |= 1u << (i + len - 1);
+      if (by == 0) T |= seg;
+      if (by == gd.nby - 1) Bm |= seg;
+      if (tile_used) {
 #pragma unroll
-        for (int tx = 0; tx < LT / HGS_TILE; tx++) {
-          const int X = bx * (LT / HGS_TILE) + tx, Y = by * (LT / HGS_TILE) + ty;
-          const int t = min(Y, tiles_y - 1) * tiles_x + min(X, tiles_x - 1);
-          const unsigned bit = (tbits[t >> 5] >> (t & 31)) & 1u;
-          used |= (X < tiles_x && Y < tiles_y) ? bit : 0u;
+        for (int ty = 0; ty < 2; ty++) {               // the blocks' 2 x 2 tiles of 16 x 16 pixels (LT = 2 * HGS_TILE)
+          const int Y = 2 * by + ty;
+          if (Y < tiles_y) {
+            unsigned long long v = tfetch(Y * tiles_x + 2 * bx);
+            const int nt = min(2 * len, tiles_x - 2 * bx);               // tiles of this row that belong to the segment
+            if (nt < 64) v &= (1ull << nt) - 1ull;
+            used |= (even_bits(v | (v >> 1)) & (len == 32 ? 0xFFFFFFFFu : ((1u << len) - 1u))) << i;
+          }
         }
-    }
-    unsigned zero = 1u;
-#pragma unroll
-    for (int dy = -1; dy <= 1; dy++) {
-      const int row = min(c, gd.C - 1) * per + min(max(by + dy, 0), gd.nby - 1) * gd.nbx;   // (outside the frame: zero)
-#pragma unroll
-      for (int dx = -1; dx <= 1; dx++) {
-        const int nb = row + min(max(bx + dx, 0), gd.nbx - 1);
-        zero &= zbits[nb >> 5] >> (nb & 31);
       }
+      i += len; bx = 0;
+      if (++by == gd.nby) by = 0;
     }
-    used &= valid;
-    const unsigned has_work = ((zero & 1u) ^ 1u) & used;
-    wacc |= has_work << (k & 31);
-    uacc |= used << (k & 31);
-    if ((k & 31) == 31 || k == per_thread - 1) {       // (this thread's own words)
-      wbits[(k >> 5) * 256 + threadIdx.x] = wacc; ubits[(k >> 5) * 256 + threadIdx.x] = uacc;
-      wacc = 0u; uacc = 0u;
-    }
-    cnt += (int)has_work;
-    cnt_z += (int)(used & (has_work ^ 1u));            // read by the blend backward, gradient exactly zero: zero-filled
-    if (++bx == gd.nbx) { bx = 0; if (++by == gd.nby) { by = 0; c++; } }
+    auto H = [&](int start) { return zfetch(start) & (zfetch(start - 1) | L) & (zfetch(start + 1) | R); };
+    const unsigned zero = H(b0) & (H(b0 - nbx) | T) & (H(b0 + nbx) | Bm);
+    const int left = total - b0;
+    const unsigned valid = left >= 32 ? 0xFFFFFFFFu : ((1u << left) - 1u);
+    work_w[q] = used & ~zero & valid;
+    fill_w[q] = used & zero & valid;                   // read by the blend backward, gradient exactly zero: zero-filled
+    cnt += __popc(work_w[q]); cnt_z += __popc(fill_w[q]);
   }
+  BL_STAMP(1);
   int inc = cnt, inc_z = cnt_z;                        // inclusive scans over the wave, then over the 4 wave totals
 #pragma unroll
   for (int d = 1; d < 64; d <<= 1) {
@@ -799,17 +832,16 @@ __device__ __forceinline__ void build_block_lists(const SsimGrid& gd, const unsi
     if (k < (int)(threadIdx.x >> 6)) { base += v; base_z += vz; }
     all += v; all_z += vz;
   }
-  int w = base + inc - cnt, z = base_z + inc_z - cnt_z;   // work / zero-fill blocks before this thread's first block
+  int w = base + inc - cnt, z = base_z + inc_z - cnt_z;   // work / zero-fill blocks before this thread's first word
   int* work = lists + 4;
   int* skipped = work + total;
-  unsigned ww = 0u, uu = 0u;
-#pragma unroll 1
-  for (int k = 0; k < per_thread; k++) {
-    const int id = first + k;
-    if (id >= total) break;
-    if ((k & 31) == 0) { ww = wbits[(k >> 5) * 256 + threadIdx.x]; uu = ubits[(k >> 5) * 256 + threadIdx.x]; }
-    if (ww >> (k & 31) & 1u) work[w++] = id;
-    else if (uu >> (k & 31) & 1u) skipped[z++] = id;
+  BL_STAMP(2);
+#pragma unroll
+  for (int q = 0; q < WPT; q++) {
+    unsigned mw = work_w[q], mz = fill_w[q];
+    const int id0 = 32 * (w_first + q);
+    while (mw) { const int bpos = __ffs(mw) - 1; mw &= mw - 1u; work[w++] = id0 + bpos; }       // (ascending ids: logical order)
+    while (mz) { const int bpos = __ffs(mz) - 1; mz &= mz - 1u; skipped[z++] = id0 + bpos; }
   }
   if (threadIdx.x == 0) { lists[0] = all; lists[1] = all_z; }
 }
@@ -830,8 +862,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8))) void p
   // trips, several us apiece while the rest of the launch saturates HBM: as extra work of a pixel workgroup they made
   // that workgroup the launch's last, 20.5 -> 24 us; on their own 20.5 -> 22)
   if (blockIdx.x < PIX_SIDE_WGS) {
+#if HGS_PIX_TRACE
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+#endif
     if (blockIdx.x == 0) { if (lists) build_block_lists(gd, zero_flags, lists, tile_used, tiles_x, tiles_y); }
     else head_part1(h, p_ssim, p_smooth, out);
+#if HGS_PIX_TRACE
+    __syncthreads();
+    if (threadIdx.x == 0 && lists) { lists[4 + 2 * gd.total + 2 * blockIdx.x] = (int)(unsigned)t0; lists[4 + 2 * gd.total + 2 * blockIdx.x + 1] = (int)(unsigned)__builtin_amdgcn_s_memrealtime(); }
+#endif
     return;
   }
   const int blk = blockIdx.x - PIX_SIDE_WGS;
@@ -881,6 +920,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8))) void p
   const float bc = block_sum(cnt, red);
   const float bb = block_sum(b, red);
   if (threadIdx.x == 0) { partials[3 * blk] = bs; partials[3 * blk + 1] = bc; partials[3 * blk + 2] = bb; }
+#if HGS_PIX_TRACE
+  if (threadIdx.x == 0 && lists && (blk == 0 || blk == (int)gridDim.x - PIX_SIDE_WGS - 1 || blk == 4000))
+    lists[4 + 2 * gd.total + 4 + (blk == 0 ? 0 : (blk == 4000 ? 1 : 2))] = (int)(unsigned)__builtin_amdgcn_s_memrealtime();
+#endif
 }
 
 __global__ __launch_bounds__(256) void pix_bwd_kernel(int N, HeadFlags fl, float bg0, float bg1, float bg2, float min_val,
@@ -1031,7 +1074,7 @@ static inline int* head_block_lists(const HgsHeadParams* p, float* scratch) {
   return (int*)(scratch + head_flags_offset(p) + 2 * head_flag_floats(p));
 }
 size_t hgs_loss_head_scratch_floats(const HgsHeadParams* p) {
-  return head_flags_offset(p) + 2 * head_flag_floats(p) + 4 + 2 * (size_t)head_nb_ssim(p) + 4;
+  return head_flags_offset(p) + 2 * head_flag_floats(p) + 4 + 2 * (size_t)head_nb_ssim(p) + 12;   // (+ 8 words of HGS_PIX_TRACE stamps)
 }
 
 int hgs_loss_head_tail(const HgsHeadParams* p, const float* scratch, float* out, HgsHeadTail* tail) {

@@ -1030,7 +1030,7 @@ def test_loss_head_skips_all_zero_blocks_exactly(hw):
     assert torch.equal(d_img, a.grad)
     # block lists (white box: [n_work, n_skip, -, -][work ids][skipped ids] close the scratch buffer)
     nbs = 3 * ((H + 31) // 32) * ((W + 31) // 32)
-    lists = scratch.view(torch.int32)[scratch.numel() - (2 * nbs + 8):].cpu()
+    lists = scratch.view(torch.int32)[scratch.numel() - (2 * nbs + 16):].cpu()     # (4 header words, 2 nbs ids, 12 spare)
     n_work, n_skip = int(lists[0]), int(lists[1])
     assert n_work + n_skip == nbs
     work, skipped = lists[4:4 + n_work], lists[4 + nbs:4 + nbs + n_skip]
@@ -1041,3 +1041,28 @@ def test_loss_head_skips_all_zero_blocks_exactly(hw):
     # skipped blocks carry no gradient; every block with gradient is on the work list
     gb = torch.nn.functional.max_pool2d(torch.nn.functional.pad((a.grad != 0).float(), (0, (-W) % 32, 0, (-H) % 32))[None], 32)[0]
     assert not gb.reshape(-1)[skipped.long()].any()
+    # ---- with the consumer's tile hint (HgsHeadParams.tile_used): blocks none of whose 16 x 16 tiles is read are left alone
+    # (neither filtered nor zero-filled), the others are exactly as before.  Odd tile counts per row / column included
+    # (W, H not multiples of 32: the last block of a row / column has one tile, not two).
+    tx_n, ty_n = (W + 15) // 16, (H + 15) // 16
+    used = (torch.rand(ty_n, tx_n, device=dev, generator=g) > 0.5)
+    used[:, -1] = True                                   # (the odd last column / row matter)
+    used[-1, :] = ~used[-1, :]
+    tile_used = (used.to(torch.int32) * 5).contiguous()
+    hp.tile_used, hp.tiles_x, hp.tiles_y = tile_used.data_ptr(), tx_n, ty_n
+    d2 = torch.full((3, H, W), 7.0, device=dev)
+    out2 = torch.zeros(rt.HEAD_NOUT, device=dev)
+    rt.check(L.hgs_loss_head_forward(rt.current_stream(), C.byref(hp), image.data_ptr(), mask_img.data_ptr(), omap.data_ptr(),
+                                     targets.data_ptr(), None, None, scratch.data_ptr(), out2.data_ptr(), None, None))
+    rt.check(L.hgs_loss_head_backward(rt.current_stream(), C.byref(hp), image.data_ptr(), mask_img.data_ptr(), omap.data_ptr(),
+                                      targets.data_ptr(), None, None, scratch.data_ptr(), out2.data_ptr(), one.data_ptr(), 0,
+                                      d2.data_ptr(), d_mask.data_ptr(), d_omap.data_ptr(), None))
+    assert torch.equal(out2[:14], out[:14])
+    # a block is read iff one of its 2 x 2 tiles is
+    bu = torch.nn.functional.max_pool2d(torch.nn.functional.pad(used.float(), (0, tx_n % 2, 0, ty_n % 2))[None, None], 2)[0, 0] > 0
+    px_used = bu.repeat_interleave(32, dim=0).repeat_interleave(32, dim=1)[:H, :W]
+    assert torch.equal(d2[:, px_used], a.grad[:, px_used])            # read blocks: the full result (zero-filled where it is zero)
+    assert bool((d2[:, ~px_used] == 7.0).all())                        # the others: untouched
+    lists2 = scratch.view(torch.int32)[scratch.numel() - (2 * nbs + 16):].cpu()
+    read_blocks = int(bu.sum()) * 3
+    assert int(lists2[0]) + int(lists2[1]) == read_blocks and int(lists2[0]) <= n_work
