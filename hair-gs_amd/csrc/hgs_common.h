@@ -58,7 +58,11 @@ struct HgsBinning {
 // ([4..7] are read as ONE 16-byte scalar load by every blend workgroup)
 enum { HGS_ST_R = 0, HGS_ST_OVERFLOW = 1, HGS_ST_SCANPTR_LO = 2, HGS_ST_SCANPTR_HI = 3, HGS_ST_SORT_ITEMS = 4,
        HGS_ST_SPLIT_ITEMS = 5, HGS_ST_SEG_LEN = 6, HGS_ST_WORK_ITEMS = 7, HGS_ST_TIMEOUT = 8, HGS_ST_SCAN_DONE = 9,
-       HGS_ST_WL_TICKET = 10, HGS_ST_WL_NCAND = 11, HGS_ST_WL_NSEG = 12 };   // exchange of the sort kernel's work-list builders
+       HGS_ST_WL_TICKET = 10, HGS_ST_WL_NCAND = 11, HGS_ST_WL_NSEG = 12,    // exchange of the sort kernel's work-list builders
+       HGS_ST_SCAN_SHARE = 13 };                                              // [13..15]: instance totals of the fused scan's shares
+#ifndef HGS_SCAN_WGS
+#define HGS_SCAN_WGS 4   // workgroups sharing the fused scan of the scatter kernel (<= 4: three share totals fit the status words)
+#endif
 #ifndef HGS_WL_BUILDERS
 #define HGS_WL_BUILDERS 8        // work-list builder workgroups of the sort kernel
 #endif

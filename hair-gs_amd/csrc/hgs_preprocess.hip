@@ -301,12 +301,18 @@ __global__ __launch_bounds__(HGS_BLOCK) void scatter_kernel(int P, int gx, int T
   const bool fused = report != 0ull;
   const int bid = (int)blockIdx.x - scan_wg;       // Gaussian block of this workgroup; -1: the scan workgroup
   if (bid < 0) {
-    // ---- fused scan: ONE extra workgroup (dispatched first) scans the tile counts and publishes `ranges`, the chunk work
-    // items of long lists, the instance count and its sticky maximum, while the others load, count and reserve; they
+    // ---- fused scan: `scan_wg` extra workgroups (dispatched first) scan the tile counts and publish `ranges`, the chunk
+    // work items of long lists, the instance count and its sticky maximum, while the others load, count and reserve; they
     // need the offsets only when they place their keys.  (Round 1 had every workgroup scan all T counts itself: 8 of a
-    // workgroup's 18 us.)
+    // workgroup's 18 us.  Round 2: one scan workgroup, 8 us until its flag -- the others were through with their own 6.6 us
+    // of loads, counting and reservation by then and waited.  Round 3: the tiles are shared between HGS_SCAN_WGS
+    // workgroups; each still loads the whole counter table -- the slots of its tiles are scattered over it -- but gathers,
+    // scans and, above all, publishes only its share (16 KB of agent-scope stores instead of 64); the totals of the shares
+    // in front travel through three status words.)
     if (!fused) return;
     constexpr int MAX_IPT = HGS_FUSED_SCAN_MAX_T / HGS_BLOCK;
+    const int q = (int)blockIdx.x;                  // this workgroup's share of the tiles: [t_lo, t_hi)
+    const int share = (T + scan_wg - 1) / scan_wg, t_lo = min(T, q * share), t_hi = min(T, t_lo + share);
     uint32_t cnt[MAX_IPT];
     const int n_slots = (int)im.tile_mask + 1;     // counter slots (a power of two >= T: hgs_tile_slots)
 #pragma unroll
@@ -316,7 +322,7 @@ __global__ __launch_bounds__(HGS_BLOCK) void scatter_kernel(int P, int gx, int T
     }                                                 //  ONE workgroup, 8192 single-line requests, the scan took 25 us)
     // counts -> LDS in slot order, then every thread gathers ITS run of consecutive tiles out of LDS and scans it (rows
     // padded by one word per 32: a stride of `ipt` words would put a wavefront on one bank)
-    const int ipt = (T + HGS_BLOCK - 1) / HGS_BLOCK, i0 = (int)threadIdx.x * ipt;
+    const int ipt = (t_hi - t_lo + HGS_BLOCK - 1) / HGS_BLOCK, i0 = t_lo + (int)threadIdx.x * ipt;
     auto at = [](int i) { return i + (i >> 5); };
 #pragma unroll
     for (int k = 0; k < MAX_IPT; k++) {
@@ -327,7 +333,7 @@ __global__ __launch_bounds__(HGS_BLOCK) void scatter_kernel(int P, int gx, int T
     uint32_t mine = 0;
 #pragma unroll
     for (int k = 0; k < MAX_IPT; k++) {
-      cnt[k] = (k < ipt && i0 + k < T) ? tile_off[at((int)HGS_TILE_SLOT(i0 + k, im.tile_mask))] : 0u;
+      cnt[k] = (k < ipt && i0 + k < t_hi) ? tile_off[at((int)HGS_TILE_SLOT(i0 + k, im.tile_mask))] : 0u;
       mine += cnt[k];
     }
     const uint32_t inc = hgs_wave_incl_scan(mine, lane);
@@ -335,26 +341,46 @@ __global__ __launch_bounds__(HGS_BLOCK) void scatter_kernel(int P, int gx, int T
     __syncthreads();                                 // (every gather above is done: the table may be overwritten)
     uint32_t run = inc - mine, total = 0;
     for (int w = 0; w < 4; w++) { if (w < wave) run += wsum[w]; total += wsum[w]; }
+    // the instances of the shares in front of this one (agent-scope words, + 1 so that 0 means "not there yet")
+    __shared__ uint32_t s_front;
+    if (threadIdx.x == 0) {
+      if (q + 1 < scan_wg) hgs_st_agent(&im.status[HGS_ST_SCAN_SHARE + q], total + 1u);
+      uint32_t front = 0;
+      for (int p = 0; p < q; p++) {
+        uint32_t v = 0;
+        int spin = 0;
+        while ((v = hgs_ld_agent(&im.status[HGS_ST_SCAN_SHARE + p])) == 0u && ++spin < (1 << 21)) __builtin_amdgcn_s_sleep(2);
+        if (v == 0u) { im.status[HGS_ST_TIMEOUT] = 1u; atomicMax((unsigned int*)report, 0xFFFFFFFFu); v = 1u; }
+        front += v - 1u;
+      }
+      s_front = front;
+    }
+    __syncthreads();
+    const uint32_t front = s_front;
+    run += front;
 #pragma unroll
     for (int k = 0; k < MAX_IPT; k++)
-      if (k < ipt && i0 + k < T) { tile_off[at(i0 + k)] = run; run += cnt[k]; }   // offsets, in TILE order
+      if (k < ipt && i0 + k < t_hi) { tile_off[at(i0 + k - t_lo)] = run; run += cnt[k]; }   // offsets, in TILE order
     __syncthreads();
+    const uint32_t end_all = front + total;           // offset behind this share's last tile
     // publish: consecutive lanes take consecutive tiles (512 contiguous bytes per wave instruction; a lane per run of 32
     // tiles made every lane's store a fabric write of its own); a tile's count is the difference of two offsets.
     // Agent-scope stores: the other workgroups of this launch read them, from other XCDs too.
-    for (int t = threadIdx.x; t < T; t += HGS_BLOCK) {
-      const uint32_t o = tile_off[at(t)], v = (t + 1 < T ? tile_off[at(t + 1)] : total) - o;
+    for (int t = t_lo + (int)threadIdx.x; t < t_hi; t += HGS_BLOCK) {
+      const uint32_t o = tile_off[at(t - t_lo)], v = (t + 1 < t_hi ? tile_off[at(t + 1 - t_lo)] : end_all) - o;
       hgs_st_agent((unsigned long long*)&im.ranges[t], v ? ((unsigned long long)(o + v) << 32) | o : 0ull);
     }
     hgs_drain_stores();
     __syncthreads();
     if (threadIdx.x == 0) {
-      hgs_st_agent(&im.status[HGS_ST_SCAN_DONE], 1u);
-      im.status[HGS_ST_R] = total;
-      atomicMax((unsigned int*)report, total);   // sticky maximum for graph replays (hgs.h)
+      __hip_atomic_fetch_add(&im.status[HGS_ST_SCAN_DONE], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (q == scan_wg - 1) {
+        im.status[HGS_ST_R] = end_all;
+        atomicMax((unsigned int*)report, end_all);   // sticky maximum for graph replays (hgs.h)
+      }
     }
-    for (int t = threadIdx.x; t < T; t += HGS_BLOCK) {   // long lists: one sort workgroup per chunk (read by the NEXT kernel)
-      const uint32_t o = tile_off[at(t)], v = (t + 1 < T ? tile_off[at(t + 1)] : total) - o;
+    for (int t = t_lo + (int)threadIdx.x; t < t_hi; t += HGS_BLOCK) {   // long lists: one sort workgroup per chunk (read by the NEXT kernel)
+      const uint32_t o = tile_off[at(t - t_lo)], v = (t + 1 < t_hi ? tile_off[at(t + 1 - t_lo)] : end_all) - o;
       hgs_emit_sort_items((uint32_t)t, v, (uint32_t)T, im);
     }
     return;
@@ -415,7 +441,7 @@ __global__ __launch_bounds__(HGS_BLOCK) void scatter_kernel(int P, int gx, int T
     // loads, counting and reservation to finish; bounded wait: HGS_ST_TIMEOUT / HGS_WAIT_TIMED_OUT instead of a hung GPU)
     if (threadIdx.x == 0) {
       int spin = 0;
-      while (hgs_ld_agent(&im.status[HGS_ST_SCAN_DONE]) == 0u && ++spin < (1 << 21)) __builtin_amdgcn_s_sleep(4);
+      while (hgs_ld_agent(&im.status[HGS_ST_SCAN_DONE]) < (uint32_t)scan_wg && ++spin < (1 << 21)) __builtin_amdgcn_s_sleep(4);
       if (spin >= (1 << 21)) { im.status[HGS_ST_TIMEOUT] = 1u; atomicMax((unsigned int*)report, 0xFFFFFFFFu); }
     }
   }
@@ -742,7 +768,7 @@ int hgs_launch_scatter(hipStream_t s, int P, int W, int H, int Rcap, const float
   const size_t lds = (T <= HGS_FUSED_SCAN_MAX_T && P <= HGS_FUSED_SCAN_MAX_P) ? (Tp + Tp / 32 + 1) * sizeof(uint32_t) : 0;
   {
     HgsProfScope _prof(s, HGS_K_SCATTER);
-    const int scan_wg = lds ? 1 : 0;
+    const int scan_wg = lds ? HGS_SCAN_WGS : 0;
     hipLaunchKernelGGL(scatter_kernel, dim3(nblk + scan_wg), dim3(HGS_BLOCK), lds, s, P, gx, T, (uint32_t)Rcap, features, n_extra ? extra : nullptr, g, im, b, scan_wg);
   }
   HGS_CHECK_LAUNCH();
