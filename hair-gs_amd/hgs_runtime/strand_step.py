@@ -271,6 +271,8 @@ def _head_raster_backward(ctx, step, go, xyz, scale, quat, shs, planes, radii, g
     else:
         dplanes = torch.empty_like(planes)
         d_image, d_extra = dplanes[0:3], dplanes[3:7]
+    if step.poison_unwritten:     # test aid: what the loss head leaves unwritten (HgsHeadParams.tile_used) must never be read
+        d_image.fill_(float("nan"))
     with torch.cuda.device(dev):
         rt.check(L.hgs_loss_head_backward(rt.current_stream(), C.byref(hp), planes[0:3].data_ptr(), planes[3].data_ptr(),
                                           planes[4:7].data_ptr(), vt.slot.data_ptr(), rt.ptr(endpoints),
@@ -403,6 +405,7 @@ class FusedStrandStep:
         # dL/dimage is produced only where the rasterizer backward reads it (include/hgs.h HgsHeadParams.tile_used)
         self.skip_unread_blocks = bool(getattr(opt, "skip_unread_blocks", True))
         self._tile_maxc_offset = None
+        self.poison_unwritten = False   # tests: dL/dimage starts as NaN
         # True: the loss terms (loss(), terms()) are complete only once backward() has run -- the head's last sums ride in
         # the backward's parameter launch instead of a launch of their own (GraphedStep, which always runs both, sets it)
         self.defer_tail = False

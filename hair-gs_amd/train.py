@@ -177,6 +177,10 @@ def training_step(gaussians, viewpoint_cam, opt, bg, iteration, extent=1.0, vp=N
 
 
 def _training_step(gaussians, viewpoint_cam, opt, bg, iteration, extent, vp, raster, fused=None):
+    # The reference ends every iteration with zero_grad(set_to_none=True) (train.py:203): an iteration starts without
+    # gradients.  A captured graph leaves its static gradient tensors in `.grad` after a replay -- an eager iteration that
+    # follows (topology iterations of training(), bench.py's kernel-timing pass) would ACCUMULATE onto them.
+    gaussians.optimizer.zero_grad(set_to_none=True)
     gaussians.update_learning_rate(iteration)
     if iteration % 1000 == 0:
         gaussians.oneupSHdegree()

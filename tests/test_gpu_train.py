@@ -319,6 +319,50 @@ def test_graphed_step_matches_eager_steps():
     assert float(results["graph"][3].sum()) > 0
 
 
+def test_eager_step_after_graph_replays_starts_without_gradients():
+    """training() leaves its captured graph for an eager training_step whenever a topology operator is due.  The graph's
+    static gradient tensors stay in `.grad` after a replay; the eager iteration must not accumulate onto them (the
+    reference zeroes the gradients at the end of every iteration, train.py:203): eight replays + one eager step end
+    bit-identical to eight replays + one more replay."""
+    from arguments import OptimizationParams
+    from diff_gaussian_rasterization import _C as raster
+    from hgs_runtime.strand_step import ViewTable, fused_step_for
+    from synthetic import build_workload
+    from train import GraphedStep, training_step
+    from utils.general import safe_state
+    order = [1, 3, 0, 2, 1, 0, 3, 2, 3]
+    res = {}
+    try:
+        for mode in ("replay", "eager_last"):
+            safe_state(True)
+            model, cams, extent = build_workload("tiny", device="cuda", with_targets=True)
+            opt = OptimizationParams()
+            opt.enable_topology = False
+            model.training_setup(opt)
+            bg = torch.zeros(3, device="cuda")
+            views = ViewTable(cams)
+            fused = fused_step_for(model, views, opt, bg)
+            fused.defer_tail = True
+            gs = GraphedStep(model, cams, opt, bg, extent=extent, views=views)
+            gs.capture(cams)
+            for it, ci in enumerate(order[:-1], 1):
+                gs.step(cams[ci], it)
+            if mode == "replay":
+                gs.step(cams[order[-1]], len(order))
+            else:
+                assert model._endpoints.grad is not None          # what the replays left behind
+                training_step(model, cams[order[-1]], opt, bg, len(order), extent=extent, fused=fused)
+            torch.cuda.synchronize()
+            raster.set_async(False)
+            res[mode] = [g["params"][0].detach().clone() for g in model.optimizer.param_groups] + \
+                        [model.optimizer.state[g["params"][0]]["exp_avg"].clone() for g in model.optimizer.param_groups
+                         if g["params"][0].numel()]
+    finally:
+        raster.set_async(False)
+    for a, b in zip(res["replay"], res["eager_last"]):
+        assert torch.equal(a, b)
+
+
 def test_iteration_prologue_equals_select_then_forward():
     """ViewTable.prologue() (view select + clearing of the image buffer in one launch, HGS_IMAGE_PREZEROED) against
     select() + a forward that clears its own buffer: identical loss, planes, gradients; the buffer is handed over once."""
@@ -928,6 +972,7 @@ def test_unread_image_gradient_blocks_change_no_parameter_gradient(workload):
     fused = FusedStrandStep(model, cams, opt, torch.zeros(3, device="cuda"))
     params = [model._endpoints, model._width, model._opacity, model._mask, model._features_dc]
     runs = {}
+    fused.poison_unwritten = True     # dL/dimage starts as NaN: a block left unwritten and read anyway would show
     for skip in (False, True):
         fused.skip_unread_blocks = skip
         for p in params:
@@ -941,6 +986,7 @@ def test_unread_image_gradient_blocks_change_no_parameter_gradient(workload):
         # the block lists sit behind the zero flags in the head's scratch: [n_work, n_zero_fill, ...]
         runs[skip] = (loss.detach().clone(), terms.clone(), [p.grad.clone() for p in params],
                       [model.max_radii2D.clone(), model.xyz_gradient_accum.clone(), model.denom.clone()])
+    assert all(bool(torch.isfinite(g_).all()) for g_ in runs[True][2])
     n_terms = 14     # (hgs.h HGS_HEAD_TOTAL_FWD + 1: the two words behind are padding nobody writes)
     assert torch.equal(runs[False][0], runs[True][0]) and torch.equal(runs[False][1][:n_terms], runs[True][1][:n_terms])
     for a, b in zip(runs[False][2] + runs[False][3], runs[True][2] + runs[True][3]):
