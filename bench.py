@@ -25,6 +25,10 @@ launch -- and every step with several ranks -- replay the single-step graph.  A 
 enough for an SMI sampler to see the GPU busy, and reports its own rate.
 
 The JSON line also carries
+  psnr_vs_oracle_db  PSNR of the HIP render of view 0 against the CPU oracle's image of the same parameters (cpu_baseline leg)
+  trained_state      with --trained-iters N: the same protocol after N iterations of the full loop (densification, merging,
+                opacity reset), beside the headline (off by default: the rocprofv3 statistics of the default command
+                then average one state per kernel; profiles/r03_bench_trained_state.json holds a run with it)
   roofline      blend_bwd_kernel (the dominant kernel): algorithmic bytes (SURVEY.md 8d formula generalised to the
                 7-channel single pass: (64 + 60) B x sum_tiles L_t + 36 B x W*H + 8 B x T per launch) / mean launch
                 duration.  The duration is measured in THIS run with HIP events on the launch stream around every launch
