@@ -455,7 +455,10 @@ __global__ __launch_bounds__(HGS_BLOCK) __attribute__((amdgpu_waves_per_eu(8))) 
 // ------------------------------------------------------------------------------------------------
 template <int C> struct PixGrad { const float* plane[C]; };  // dL/d(output channel k) as [H,W] planes (need not be adjacent)
 
-template <int C>
+// BLACK: the background is black (bg == NULL at the C ABI: what the training step renders on, train.py:94, and what the
+// mask / orientation passes always use, loss/losses.py:228,296): the background terms of dL/dalpha (backward_distwar.cu:
+// 988-991) vanish and their four instructions per (wavefront, entry) pair are compiled out.
+template <int C, bool BLACK>
 __global__ __launch_bounds__(HGS_BLOCK) __attribute__((amdgpu_waves_per_eu(HGS_BWD_WAVES))) void blend_bwd_kernel(HgsImage im, HgsBinning bn, int W, int H, int gx,
                                                               uint32_t Rcap, const float* __restrict__ bg,
                                                               PixGrad<C> dL_dpix, float* __restrict__ inst_grad) {
@@ -518,8 +521,10 @@ __global__ __launch_bounds__(HGS_BLOCK) __attribute__((amdgpu_waves_per_eu(HGS_B
 #pragma unroll
   for (int k = 0; k < C; k++) {
     dpx[k] = inside ? dL_dpix.plane[k][pix] : 0.f;
-    bg_dot += bg[k] * dpx[k];
-    if (k < 3) bg_dot_rgb += bg[k] * dpx[k];
+    if (!BLACK) {
+      bg_dot += bg[k] * dpx[k];
+      if (k < 3) bg_dot_rgb += bg[k] * dpx[k];
+    }
   }
   if (it.split && last > it.e) {
     // This pixel has contributors behind this segment.  The serial walk would arrive here with T = the transmittance in
@@ -590,8 +595,8 @@ __global__ __launch_bounds__(HGS_BLOCK) __attribute__((amdgpu_waves_per_eu(HGS_B
       float dL_dalpha = col_dot - acc_dot;
       const float dL_dalpha_rgb = col_dot_rgb - acc_dot_rgb;
       dL_dalpha *= T;
-      const float bgw = -T_final * inv_one_m_a;
-      dL_dalpha += bgw * bg_dot;                                                   // :991
+      const float bgw = BLACK ? 0.f : -T_final * inv_one_m_a;
+      if (!BLACK) dL_dalpha += bgw * bg_dot;                                       // :991
       // Everything downstream of dL/dalpha is LINEAR in u = G * dL_dalpha with per-Gaussian coefficients (:1002-1011):
       //   dL_dG = opacity * dL_dalpha, dG_ddelx = -G (a dx + b dy), dG_ddely = -G (c dy + b dx)
       //   dmean2D = dL_dG * dG_ddel{x,y} * ddel_d{x,y},  dconic = -0.5 * G * (dx dx, dx dy, dy dy) * dL_dG,  dopacity = u
@@ -607,7 +612,7 @@ __global__ __launch_bounds__(HGS_BLOCK) __attribute__((amdgpu_waves_per_eu(HGS_B
       v[4] = uy * dy;
       v[5] = u;
       if (C > 3) {  // the same moments for the RGB channels alone (densification statistics see only those)
-        const float u_rgb = G * (dL_dalpha_rgb * T + bgw * bg_dot_rgb);
+        const float u_rgb = BLACK ? G * (dL_dalpha_rgb * T) : G * (dL_dalpha_rgb * T + bgw * bg_dot_rgb);
         v[6 + C] = u_rgb * dx;
         v[7 + C] = u_rgb * dy;
       }
@@ -686,13 +691,17 @@ int hgs_launch_blend_bwd(hipStream_t s, int W, int H, int Rcap, int channels, co
     if (channels == 3) {
       PixGrad<3> pg;
       for (int k = 0; k < 3; k++) pg.plane[k] = dL_dpix_planes[k];
-      hipLaunchKernelGGL(blend_bwd_kernel<3>, dim3(blend_grid(gx * gy, b)), dim3(HGS_BLOCK), 0, s, im, b, W, H, gx,
-                         (uint32_t)Rcap, bg, pg, inst_grad);
+      if (bg) hipLaunchKernelGGL((blend_bwd_kernel<3, false>), dim3(blend_grid(gx * gy, b)), dim3(HGS_BLOCK), 0, s, im, b, W, H, gx,
+                                 (uint32_t)Rcap, bg, pg, inst_grad);
+      else hipLaunchKernelGGL((blend_bwd_kernel<3, true>), dim3(blend_grid(gx * gy, b)), dim3(HGS_BLOCK), 0, s, im, b, W, H, gx,
+                              (uint32_t)Rcap, bg, pg, inst_grad);
     } else {
       PixGrad<7> pg;
       for (int k = 0; k < 7; k++) pg.plane[k] = dL_dpix_planes[k];
-      hipLaunchKernelGGL(blend_bwd_kernel<7>, dim3(blend_grid(gx * gy, b)), dim3(HGS_BLOCK), 0, s, im, b, W, H, gx,
-                         (uint32_t)Rcap, bg, pg, inst_grad);
+      if (bg) hipLaunchKernelGGL((blend_bwd_kernel<7, false>), dim3(blend_grid(gx * gy, b)), dim3(HGS_BLOCK), 0, s, im, b, W, H, gx,
+                                 (uint32_t)Rcap, bg, pg, inst_grad);
+      else hipLaunchKernelGGL((blend_bwd_kernel<7, true>), dim3(blend_grid(gx * gy, b)), dim3(HGS_BLOCK), 0, s, im, b, W, H, gx,
+                              (uint32_t)Rcap, bg, pg, inst_grad);
     }
   }
   HGS_CHECK_LAUNCH();

@@ -282,7 +282,7 @@ def _head_raster_backward(ctx, step, go, xyz, scale, quat, shs, planes, radii, g
     grad_planes = [d_image[k] for k in range(3)] + [d_extra[k] for k in range(4)]
     empty = step.empty
     (g_means2D, _gc, g_ex, g_opac, g_means3D, _gcov, g_sh, g_scales, g_rot) = raster.rasterize_gaussians_multi_backward(
-        step.bg7, xyz, radii, empty, scale, quat, 1.0, empty, vt.viewmatrix, vt.projmatrix, vt.tanfovx, vt.tanfovy,
+        step.bg7_backward, xyz, radii, empty, scale, quat, 1.0, empty, vt.viewmatrix, vt.projmatrix, vt.tanfovx, vt.tanfovy,
         grad_planes, shs, g.active_sh_degree, vt.campos, geom, ctx.R, binning, img, False)
     return go, (g_means2D, g_ex, g_opac, g_means3D, g_sh, g_scales, g_rot)
 
@@ -398,6 +398,9 @@ class FusedStrandStep:
         self.views = cameras if isinstance(cameras, ViewTable) else ViewTable(cameras)
         dev = self.views.device
         self.bg7 = torch.cat([bg.to(dev, torch.float32), torch.zeros(4, device=dev)]).contiguous()
+        # a black background (the training default, train.py:94) is handed to the backward as NULL: its terms are compiled
+        # out of the blend backward (include/hgs.h hgs_backward_multi); one read-back here, at construction
+        self.bg7_backward = None if (bool((self.bg7 == 0).all()) and os.environ.get("HGS_BLACK_BG", "1") != "0") else self.bg7
         self.empty = torch.empty(0, device=dev)
         self.one = torch.ones((), dtype=torch.float32, device=dev)   # d loss / d loss, passed to backward(): no fill launch
         self.one_pass_pixels = True    # per-pixel loss terms: value and gradient in one pass over the pixels

@@ -89,7 +89,9 @@ int hgs_forward_render(void* stream, int P, int W, int H, int R_capacity, const 
                        const float* colors_precomp, void* geom_buf, void* binning_buf, void* image_buf,
                        float* out_color);
 
-/* Backward.  All nine gradient outputs are fully written by the call (zeros for culled Gaussians):
+/* Backward.  bg == NULL means a BLACK background (the same gradients as a zero vector; the background terms of the blend
+ * backward are compiled out -- what a training step on a black background, train.py:94, should pass).
+ * All nine gradient outputs are fully written by the call (zeros for culled Gaussians):
  * the caller does not need to zero-fill them (reference zero-allocates, rasterize_points.cu:151-159).
  * dL_dconic is [P,2,2] (element [1,0] is written as 0), dL_dmeans2D is [P,3] (z = 0).
  * `scratch` >= hgs_backward_scratch_bytes(P, R) bytes. */

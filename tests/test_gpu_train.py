@@ -993,6 +993,33 @@ def test_unread_image_gradient_blocks_change_no_parameter_gradient(workload):
         assert torch.equal(a, b)
 
 
+def test_black_background_backward_specialisation_is_exact():
+    """hgs_backward_multi(bg = NULL) -- the blend backward with the background terms compiled out, what the fused iteration
+    passes for a black background -- gives the gradients of bg = (0, ..., 0), bit for bit."""
+    from arguments import OptimizationParams
+    from hgs_runtime.strand_step import FusedStrandStep
+    from synthetic import build_workload
+    model, cams, _ = build_workload("tiny", device="cuda", with_targets=True)
+    opt = OptimizationParams()
+    model.training_setup(opt)
+    fused = FusedStrandStep(model, cams, opt, torch.zeros(3, device="cuda"))
+    assert fused.bg7_backward is None
+    grey = FusedStrandStep(model, cams, opt, torch.full((3,), 0.25, device="cuda"))
+    assert grey.bg7_backward is grey.bg7                     # (only an all-zero background takes the specialisation)
+    params = [model._endpoints, model._width, model._opacity, model._mask, model._features_dc]
+    runs = []
+    for bgb in (None, fused.bg7):
+        fused.bg7_backward = bgb
+        for p in params:
+            p.grad = None
+        fused.views.select(2)
+        loss, _ = fused.loss()
+        fused.backward(loss)
+        runs.append([p.grad.clone() for p in params] + [fused.last["dmean2D"].clone()])
+    for a, b in zip(*runs):
+        assert torch.equal(a, b) and bool(a.abs().sum() > 0)
+
+
 @pytest.mark.parametrize("use_graph", [False, True])
 def test_stage1_training_loop_with_densification(use_graph):
     """training() on the Stage-I cloud through the fused cloud iteration: densification (clone / split / prune) and the
