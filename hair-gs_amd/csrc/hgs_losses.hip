@@ -152,6 +152,63 @@ __device__ __forceinline__ void row_pass(const SsimWin& win, float (*hz)[TILE][H
     row_item<NQ, 2>(win, hz, load, r, x0);
   }
 }
+// The same row pass with its results kept in registers until the caller has passed a barrier (`row_store` then writes them):
+// for kernels whose filtered planes ALIAS the input tile in LDS.
+template <int NQ, int NO, typename F>
+__device__ __forceinline__ void row_item_regs(const SsimWin& win, F load, int r, int x0, float (*acc)[NO]) {
+#pragma unroll
+  for (int q = 0; q < NQ; q++)
+#pragma unroll
+    for (int o = 0; o < NO; o++) acc[q][o] = 0.f;
+#pragma unroll
+  for (int k = 0; k < NO + 10; k++) {
+    float val[NQ];
+    load(r, x0 + k, val);
+#pragma unroll
+    for (int o = 0; o < NO; o++) {
+      const int tap = k - o;
+      if (tap >= 0 && tap < 11) {
+#pragma unroll
+        for (int q = 0; q < NQ; q++) acc[q][o] += win.w[tap] * val[q];
+      }
+    }
+  }
+}
+template <int NQ> struct RowRegs { float a4[NQ][4], a2[NQ][2]; };
+template <int NQ, typename F>
+__device__ __forceinline__ void row_pass_regs(const SsimWin& win, F load, RowRegs<NQ>& rr) {
+  constexpr int ITEMS = TILE * (LT / 4);
+  {
+    const int it = threadIdx.x;
+    const int r = it / (LT / 4), x0 = (it - r * (LT / 4)) * 4;
+    row_item_regs<NQ, 4>(win, load, r, x0, rr.a4);
+  }
+  if (threadIdx.x < 2 * (ITEMS - 256)) {
+    const int it = 256 + (threadIdx.x >> 1);
+    const int r = it / (LT / 4), x0 = (it - r * (LT / 4)) * 4 + 2 * (threadIdx.x & 1);
+    row_item_regs<NQ, 2>(win, load, r, x0, rr.a2);
+  }
+}
+template <int NQ>
+__device__ __forceinline__ void row_store(float (*hz)[TILE][HP], const RowRegs<NQ>& rr) {
+  constexpr int ITEMS = TILE * (LT / 4);
+  {
+    const int it = threadIdx.x;
+    const int r = it / (LT / 4), x0 = (it - r * (LT / 4)) * 4;
+#pragma unroll
+    for (int q = 0; q < NQ; q++)
+#pragma unroll
+      for (int o = 0; o < 4; o++) hz[q][r][x0 + o] = rr.a4[q][o];
+  }
+  if (threadIdx.x < 2 * (ITEMS - 256)) {
+    const int it = 256 + (threadIdx.x >> 1);
+    const int r = it / (LT / 4), x0 = (it - r * (LT / 4)) * 4 + 2 * (threadIdx.x & 1);
+#pragma unroll
+    for (int q = 0; q < NQ; q++)
+#pragma unroll
+      for (int o = 0; o < 2; o++) hz[q][r][x0 + o] = rr.a2[q][o];
+  }
+}
 template <int NQ>
 __device__ __forceinline__ void col_pass(const SsimWin& win, float (*hz)[TILE][HP], int lx, int y0, float (*out)[4]) {
 #pragma unroll
@@ -221,7 +278,7 @@ static inline SsimGrid ssim_grid(int C, int H, int W) {
 // VGPRs by amdgpu_waves_per_eu(4, 4) -> 4; at 131 it drops to 3 and the kernel takes 54 instead of 42 us; backward: 41 KB, 163 -> 3)
 #define SSIM_FWD_WG_PER_XCD 128
 #ifndef HGS_SSIM_BWD_WAVES
-#define HGS_SSIM_BWD_WAVES 3
+#define HGS_SSIM_BWD_WAVES 4
 #endif
 #define SSIM_BWD_WG_PER_XCD (32 * HGS_SSIM_BWD_WAVES)
 static inline unsigned ssim_grid_size(const SsimGrid& gd, int per_xcd) { return 8u * (unsigned)(gd.chunk < per_xcd ? gd.chunk : per_xcd); }
@@ -389,8 +446,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HGS_SSIM_BW
                                                           const unsigned char* __restrict__ zero_flags) {
   // (the loss head's endpoint-gradient buffer is cleared here, in passing: saves a launch before the smoothness scatter)
   for (int i = blockIdx.x * 256 + threadIdx.x; i < zero_n; i += gridDim.x * 256) zero_buf[i] = 0.f;
+#ifndef HGS_SSIM_BWD_ALIAS
+#define HGS_SSIM_BWD_ALIAS 1
+#endif
+#if HGS_SSIM_BWD_ALIAS
+  // The filtered planes live in the SAME LDS as the input tile (24.7 KB instead of 24.7 + 16.6): a fourth workgroup fits a
+  // CU.  The row pass keeps its results in registers until every thread has read the tile (one barrier), and the next tile
+  // is written only when every thread is through with the column pass (one more).
+  __shared__ float smem[3 * TILE * TPW];
+  float (*t)[TILE][TPW] = (float (*)[TILE][TPW])smem;
+  float (*hz)[TILE][HP] = (float (*)[TILE][HP])smem;
+#else
   __shared__ float t[3][TILE][TPW];
   __shared__ float hz[3][TILE][HP];
+#endif
   const HGS_GLOBAL float* im1 = hgs_global(img1);
   const HGS_GLOBAL float* im2 = tgt ? hgs_global(tgt->image) : hgs_global(img2_);
   const HGS_GLOBAL float* dmg = hgs_global(dmap);
@@ -487,6 +556,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HGS_SSIM_BW
   while (have) {
     tr.phase(7);
     tr.block(true);
+#if HGS_SSIM_BWD_ALIAS
+    __syncthreads();                               // (the previous block's column pass has read the aliased planes)
+#endif
     if (fast) { apply_flags(); stage_store<3>(st, t); }
     else load_tiles<3>(t, H, W, bk.bx0, bk.by0, [&](int p) { return dmg + p * cp + bk.c * plane; });
     __syncthreads();
@@ -498,9 +570,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HGS_SSIM_BW
     kblk++;
     const bool have_next = block_at(j, kblk, nx);
     if (have_next && fast) stage(nx);
+#if HGS_SSIM_BWD_ALIAS
+    {
+      RowRegs<3> rr;
+      row_pass_regs<3>(win, [&](int r, int x, float* v) {
+        v[0] = t[0][r][x + XOFF - HALO]; v[1] = t[1][r][x + XOFF - HALO]; v[2] = t[2][r][x + XOFF - HALO];
+      }, rr);
+      __syncthreads();                             // every thread has read the tile: its LDS becomes the filtered planes
+      row_store<3>(hz, rr);
+    }
+#else
     row_pass<3>(win, hz, [&](int r, int x, float* v) {
       v[0] = t[0][r][x + XOFF - HALO]; v[1] = t[1][r][x + XOFF - HALO]; v[2] = t[2][r][x + XOFF - HALO];
     });
+#endif
     __syncthreads();
     tr.phase(1);
     float f[3][4];
