@@ -276,7 +276,17 @@ static inline SsimGrid ssim_grid(int C, int H, int W) {
 }
 // persistent workgroups per XCD = 32 CUs x resident workgroups (forward: 38.7 KB LDS, register allocation held to 128
 // VGPRs by amdgpu_waves_per_eu(4, 4) -> 4; at 131 it drops to 3 and the kernel takes 54 instead of 42 us; backward: 41 KB, 163 -> 3)
-#define SSIM_FWD_WG_PER_XCD 128
+// Round 3: the forward's filtered planes alias its input tile in LDS (22.5 KB instead of 38.9) and, with the SLP vectorizer
+// off, it needs 94 VGPRs: FIVE workgroups per CU instead of four (same box: 37.4 -> 35.5 us at north_star, 38.2 -> 35.4 at
+// C3; aliasing alone, at four, changes nothing; six would need 80 VGPRs).  |x1 - x2| of a thread's own pixels is read before
+// the tile is overwritten.
+#ifndef HGS_SSIM_FWD_WAVES
+#define HGS_SSIM_FWD_WAVES 5
+#endif
+#ifndef HGS_SSIM_FWD_ALIAS
+#define HGS_SSIM_FWD_ALIAS 1
+#endif
+#define SSIM_FWD_WG_PER_XCD (32 * HGS_SSIM_FWD_WAVES)
 #ifndef HGS_SSIM_BWD_WAVES
 #define HGS_SSIM_BWD_WAVES 4
 #endif
@@ -332,7 +342,7 @@ __device__ __forceinline__ void ssim_zero_maps(float* m) {
   m[0] = 0.f; m[1] = -S * iB2; m[2] = 2.f * C1 * inv;
 }
 
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void ssim_l1_fwd_kernel(int H, int W, SsimGrid gd, SsimWin win, const float* __restrict__ img1,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HGS_SSIM_FWD_WAVES, HGS_SSIM_FWD_WAVES))) void ssim_l1_fwd_kernel(int H, int W, SsimGrid gd, SsimWin win, const float* __restrict__ img1,
                                                           const float* __restrict__ img2_, const HgsViewTargets* __restrict__ tgt,
                                                           float* __restrict__ dmap, float* __restrict__ partials,
                                                           unsigned char* __restrict__ zero_flags) {
@@ -340,8 +350,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
   // renders and their targets are black outside the hair: such a block's filtered maps are all zero, so the two filter
   // passes are skipped (the epilogue below then evaluates the same expressions on zeros, bit for bit what the full path
   // would produce), and the backward skips blocks whose 3x3 neighbourhood is flagged (its result is exactly zero).
+#if HGS_SSIM_FWD_ALIAS
+  __shared__ float smem[4 * TILE * HP];   // the tile (2 planes of TILE x TPW) and, behind a barrier, the 4 filtered planes
+  static_assert(4 * TILE * HP >= 2 * TILE * TPW, "filtered planes cover the tile");
+  float (*t)[TILE][TPW] = (float (*)[TILE][TPW])smem;
+  float (*hz)[TILE][HP] = (float (*)[TILE][HP])smem;
+#else
   __shared__ float t[2][TILE][TPW];
   __shared__ float hz[4][TILE][HP];   // mu1, mu2, E[x1^2 + x2^2], E[x1 x2]: S only needs the SUM of the two variances
+#endif
   __shared__ float red[8];
   const size_t plane = (size_t)H * W, cp = (size_t)gd.C * plane;
   const HGS_GLOBAL float* im1 = hgs_global(img1);
@@ -358,6 +375,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
   while (have) {
     tr.phase(7);
     int nz = 1;                                   // does this thread's share of the tile hold a non-zero value?
+#if HGS_SSIM_FWD_ALIAS
+    __syncthreads();                              // (the previous block's column pass / L1 reads are through)
+#endif
     if (fast) {
       stage_store<2>(st, t);
       if (zero_flags) {
@@ -378,11 +398,28 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     const bool have_next = ssim_block(gd, j, nx);
     if (fast && have_next) stage_load<2>(st, H, W, nx.bx0, nx.by0, [&](int p) { return (p == 0 ? im1 : im2) + nx.c * plane; });
     float f[4][4];
+#if HGS_SSIM_FWD_ALIAS
+    float l1c[4];                                 // |x1 - x2| of this thread's pixels: read before the tile is overwritten
+#pragma unroll
+    for (int o = 0; o < 4; o++) l1c[o] = fabsf(t[0][y0 + o + HALO][lx + XOFF] - t[1][y0 + o + HALO][lx + XOFF]);
+#endif
     if (any_nz) {
+#if HGS_SSIM_FWD_ALIAS
+      {
+        RowRegs<4> rr;
+        row_pass_regs<4>(win, [&](int r, int x, float* v) {
+          const float a = t[0][r][x + XOFF - HALO], b = t[1][r][x + XOFF - HALO];
+          v[0] = a; v[1] = b; v[2] = a * a + b * b; v[3] = a * b;
+        }, rr);
+        __syncthreads();
+        row_store<4>(hz, rr);
+      }
+#else
       row_pass<4>(win, hz, [&](int r, int x, float* v) {   // x = tile column of the tap: image x = bx0 - HALO + x
         const float a = t[0][r][x + XOFF - HALO], b = t[1][r][x + XOFF - HALO];
         v[0] = a; v[1] = b; v[2] = a * a + b * b; v[3] = a * b;
       });
+#endif
       __syncthreads();
       tr.phase(1);
       col_pass<4>(win, hz, lx, y0, f);
@@ -411,7 +448,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         const float inv = iB1 * iB2;
         const float S = (A1 * A2) * inv;                                 // losses.py:71-73
         ssim_v += S;
+#if HGS_SSIM_FWD_ALIAS
+        l1_v += l1c[o];
+#else
         l1_v += fabsf(t[0][y0 + o + HALO][lx + XOFF] - t[1][y0 + o + HALO][lx + XOFF]);
+#endif
         if (any_nz) {   // (a flagged block's maps are the constants ssim_zero_maps(): the backward substitutes them)
           const size_t oo = bk.c * plane + (size_t)py * W + px;
           dmap[oo] = 2.f * mu2 * (A2 - A1) * inv - S * (2.f * mu1 * iB1 - 2.f * mu1 * iB2);   // dS/dmu1 at fixed E11, E12
