@@ -762,11 +762,30 @@ __device__ __forceinline__ void head_part1(const HeadReduce& h, const float* __r
                                            const float* __restrict__ p_smooth, float* __restrict__ out) {
   __shared__ float red4[4][4];
   float sv[4] = {0.f, 0.f, 0.f, 0.f};              // SSIM sum, L1 sum, smoothness sum, smoothness count
-  // (all loads of a thread are independent: in flight together)
-#pragma unroll 24
-  for (int i = threadIdx.x; i < h.nb_ssim; i += 256) { sv[0] += p_ssim[2 * (size_t)i]; sv[1] += p_ssim[2 * (size_t)i + 1]; }
-#pragma unroll 4
-  for (int i = threadIdx.x; i < h.nb_smooth; i += 256) { sv[2] += p_smooth[2 * (size_t)i]; sv[3] += p_smooth[2 * (size_t)i + 1]; }
+  // Twelve 8-byte loads per thread in flight per round trip, issued from clamped indices before the first use (a 1080p
+  // frame: 24 per thread, two trips; the smoothness partials: one).  This workgroup runs while 8100 pixel workgroups saturate
+  // HBM -- every dependent round trip costs it several us, and the launch lasts as long as its slowest workgroup.  The order
+  // of the additions per thread is unchanged (bit-identical sums).
+  const float2* ps = (const float2*)p_ssim;
+  const float2* pm = (const float2*)p_smooth;
+  float2 w[4];
+#pragma unroll
+  for (int u = 0; u < 4; u++) {
+    const int i = u * 256 + (int)threadIdx.x;
+    w[u] = h.nb_smooth > 0 ? pm[min(i, h.nb_smooth - 1)] : make_float2(0.f, 0.f);
+  }
+  for (int base = 0; base < h.nb_ssim; base += 12 * 256) {
+    float2 v[12];
+#pragma unroll
+    for (int u = 0; u < 12; u++) v[u] = ps[min(base + u * 256 + (int)threadIdx.x, h.nb_ssim - 1)];
+#pragma unroll
+    for (int u = 0; u < 12; u++)
+      if (base + u * 256 + (int)threadIdx.x < h.nb_ssim) { sv[0] += v[u].x; sv[1] += v[u].y; }
+  }
+#pragma unroll
+  for (int u = 0; u < 4; u++)
+    if (u * 256 + (int)threadIdx.x < h.nb_smooth) { sv[2] += w[u].x; sv[3] += w[u].y; }
+  for (int i = 4 * 256 + (int)threadIdx.x; i < h.nb_smooth; i += 256) { sv[2] += pm[i].x; sv[3] += pm[i].y; }
 #pragma unroll
   for (int q = 0; q < 4; q++)
 #pragma unroll
