@@ -8,7 +8,7 @@ dur = {k: [] for k in keys}
 for f in glob.glob(os.path.join(ROOT, 'gpurun_out/pmc_*/*/*_counter_collection.csv')):
     for r in csv.DictReader(open(f)):
         for k in keys:
-            if k in r['Kernel_Name']:
+            if k in r['Kernel_Name'] or k.replace('>', ',') in r['Kernel_Name']:   # (blend_bwd_kernel<7> also matches <7, true>)
                 agg[k][r['Counter_Name']].append(float(r['Counter_Value']))
                 if r['Counter_Name'] in ('SQ_WAVES', 'FETCH_SIZE'):
                     dur[k].append((int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3)
