@@ -61,7 +61,8 @@ enum { HGS_ST_R = 0, HGS_ST_OVERFLOW = 1, HGS_ST_SCANPTR_LO = 2, HGS_ST_SCANPTR_
        HGS_ST_WL_TICKET = 10, HGS_ST_WL_NCAND = 11, HGS_ST_WL_NSEG = 12,    // exchange of the sort kernel's work-list builders
        HGS_ST_SCAN_SHARE = 13 };                                              // [13..15]: instance totals of the fused scan's shares
 #ifndef HGS_SCAN_WGS
-#define HGS_SCAN_WGS 4   // workgroups sharing the fused scan of the scatter kernel (<= 4: three share totals fit the status words)
+#define HGS_SCAN_WGS 4   // workgroups sharing the fused scan of the scatter kernel (three share totals fit the status words; a share's offsets
+                         // -- HGS_FUSED_SCAN_MAX_T / 4 tiles -- fit the block's 12 KB tile table: hgs_preprocess.hip)
 #endif
 #ifndef HGS_WL_BUILDERS
 #define HGS_WL_BUILDERS 8        // work-list builder workgroups of the sort kernel
@@ -262,7 +263,7 @@ struct HgsFwdArgs {
 #ifndef HGS_FUSED_SCAN_MAX_P
 #define HGS_FUSED_SCAN_MAX_P 0x7FFFFFFF   // Gaussians up to which the scatter kernel's scan workgroup replaces the scan kernel: no limit since ONE workgroup scans (with every workgroup scanning for itself the limit was 150 k).  Same box, scan workgroup against scan kernel: +0.6 % at 200 k, +1.0 % at 500 k, +0.2 % at 1 M Gaussians (the scan LDS of every workgroup costs the big launches what the scan kernel cost)
 #endif
-#define HGS_FUSED_SCAN_MAX_T 8192    // tiles whose counter slots (a power of two) fit the scatter kernel's LDS (33.8 KB with padding); 1080p has 8160
+#define HGS_FUSED_SCAN_MAX_T 8192    // tiles the scatter kernel's scan workgroups take (a share's offsets live in the block's tile table); 1080p has 8160
 int hgs_launch_preprocess_fwd(hipStream_t s, const HgsFwdArgs& a, const HgsGeom& g, const HgsImage& im, int* radii);
 int hgs_launch_scan(hipStream_t s, int P, int T, const HgsGeom& g, const HgsImage& im, unsigned int* max_rendered);
 int hgs_launch_scatter(hipStream_t s, int P, int W, int H, int Rcap, const float* features, const float* extra, int n_extra,

@@ -293,7 +293,6 @@ __global__ __launch_bounds__(HGS_BLOCK) void preprocess_fwd_kernel(HgsFwdArgs a,
 __global__ __launch_bounds__(HGS_BLOCK) void scatter_kernel(int P, int gx, int T, uint32_t Rcap, const float* __restrict__ feat,
                                                             const float* __restrict__ extra, HgsGeom g, HgsImage im,
                                                             HgsBinning b, int scan_wg) {
-  extern __shared__ uint32_t tile_off[];   // [slots] for the scan workgroup of the fused-scan mode (dynamic), empty otherwise
   __shared__ uint32_t wsum[4];
   __shared__ TileHash th;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -306,39 +305,32 @@ __global__ __launch_bounds__(HGS_BLOCK) void scatter_kernel(int P, int gx, int T
     // need the offsets only when they place their keys.  (Round 1 had every workgroup scan all T counts itself: 8 of a
     // workgroup's 18 us.  Round 2: one scan workgroup, 8 us until its flag -- the others were through with their own 6.6 us
     // of loads, counting and reservation by then and waited.  Round 3: the tiles are shared between HGS_SCAN_WGS
-    // workgroups; each still loads the whole counter table -- the slots of its tiles are scattered over it -- but gathers,
-    // scans and, above all, publishes only its share (16 KB of agent-scope stores instead of 64); the totals of the shares
-    // in front travel through three status words.)
+    // workgroups; each gathers, scans and publishes only its share (16 KB of agent-scope stores instead of 64); the totals
+    // of the shares in front travel through three status words.)
     if (!fused) return;
-    constexpr int MAX_IPT = HGS_FUSED_SCAN_MAX_T / HGS_BLOCK;
+    // The counts of this share's tiles are gathered straight from their (scattered) counter slots: 8 independent 4-byte
+    // loads per thread at 1080p, all in flight together.  (Rounds 2-3a staged the WHOLE slot table in LDS first -- 33.8 KB
+    // of dynamic LDS that EVERY workgroup of the launch reserved: three resident workgroups per CU instead of six, which
+    // is what the launches of more than 768 workgroups, i.e. every model beyond 196 k Gaussians, paid for it.)  The offsets
+    // live in the block's tile table, which a scan workgroup does not use otherwise.
+    constexpr int MAX_IPT = (HGS_FUSED_SCAN_MAX_T / HGS_SCAN_WGS + HGS_BLOCK - 1) / HGS_BLOCK + 1;
+    static_assert(sizeof(TileHash) >= (HGS_FUSED_SCAN_MAX_T / HGS_SCAN_WGS + HGS_FUSED_SCAN_MAX_T / HGS_SCAN_WGS / 32 + 2 + HGS_BLOCK) * sizeof(uint32_t),
+                  "a share's offsets fit the tile table");
+    uint32_t* tile_off = (uint32_t*)&th;
     const int q = (int)blockIdx.x;                  // this workgroup's share of the tiles: [t_lo, t_hi)
     const int share = (T + scan_wg - 1) / scan_wg, t_lo = min(T, q * share), t_hi = min(T, t_lo + share);
     uint32_t cnt[MAX_IPT];
-    const int n_slots = (int)im.tile_mask + 1;     // counter slots (a power of two >= T: hgs_tile_slots)
-#pragma unroll
-    for (int k = 0; k < MAX_IPT; k++) {
-      const int i = k * HGS_BLOCK + (int)threadIdx.x;
-      cnt[k] = i < n_slots ? im.tile_count[i] : 0u;   // (coalesced, in slot order: gathered from the scattered slots by
-    }                                                 //  ONE workgroup, 8192 single-line requests, the scan took 25 us)
-    // counts -> LDS in slot order, then every thread gathers ITS run of consecutive tiles out of LDS and scans it (rows
-    // padded by one word per 32: a stride of `ipt` words would put a wavefront on one bank)
     const int ipt = (t_hi - t_lo + HGS_BLOCK - 1) / HGS_BLOCK, i0 = t_lo + (int)threadIdx.x * ipt;
     auto at = [](int i) { return i + (i >> 5); };
-#pragma unroll
-    for (int k = 0; k < MAX_IPT; k++) {
-      const int i = k * HGS_BLOCK + (int)threadIdx.x;
-      if (i < n_slots) tile_off[at(i)] = cnt[k];
-    }
-    __syncthreads();
     uint32_t mine = 0;
 #pragma unroll
-    for (int k = 0; k < MAX_IPT; k++) {
-      cnt[k] = (k < ipt && i0 + k < t_hi) ? tile_off[at((int)HGS_TILE_SLOT(i0 + k, im.tile_mask))] : 0u;
-      mine += cnt[k];
-    }
+    for (int k = 0; k < MAX_IPT; k++)
+      cnt[k] = (k < ipt && i0 + k < t_hi) ? im.tile_count[HGS_TILE_SLOT(i0 + k, im.tile_mask)] : 0u;
+#pragma unroll
+    for (int k = 0; k < MAX_IPT; k++) mine += cnt[k];
     const uint32_t inc = hgs_wave_incl_scan(mine, lane);
     if (lane == 63) wsum[wave] = inc;
-    __syncthreads();                                 // (every gather above is done: the table may be overwritten)
+    __syncthreads();
     uint32_t run = inc - mine, total = 0;
     for (int w = 0; w < 4; w++) { if (w < wave) run += wsum[w]; total += wsum[w]; }
     // the instances of the shares in front of this one (agent-scope words, + 1 so that 0 means "not there yet")
@@ -764,11 +756,11 @@ int hgs_launch_scatter(hipStream_t s, int P, int W, int H, int Rcap, const float
   // limits).  The table is dynamic LDS, i.e. 33 KB at 1080p for EVERY workgroup of the launch (three resident workgroups
   // per CU instead of thirteen): for the big launches that costs about what the scan kernel did (1 M Gaussians: scatter
   // 59 + scan 20 us against 81 us).  The scan workgroup leaves at once when a scan kernel ran (blocking mode).
-  const size_t Tp = hgs_tile_slots((size_t)T);
-  const size_t lds = (T <= HGS_FUSED_SCAN_MAX_T && P <= HGS_FUSED_SCAN_MAX_P) ? (Tp + Tp / 32 + 1) * sizeof(uint32_t) : 0;
+  const size_t lds = 0;   // (no dynamic LDS: see the scan workgroups)
+  const bool can_fuse = T <= HGS_FUSED_SCAN_MAX_T && P <= HGS_FUSED_SCAN_MAX_P;
   {
     HgsProfScope _prof(s, HGS_K_SCATTER);
-    const int scan_wg = lds ? HGS_SCAN_WGS : 0;
+    const int scan_wg = can_fuse ? HGS_SCAN_WGS : 0;
     hipLaunchKernelGGL(scatter_kernel, dim3(nblk + scan_wg), dim3(HGS_BLOCK), lds, s, P, gx, T, (uint32_t)Rcap, features, n_extra ? extra : nullptr, g, im, b, scan_wg);
   }
   HGS_CHECK_LAUNCH();
