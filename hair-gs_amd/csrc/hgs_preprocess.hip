@@ -477,7 +477,11 @@ __device__ __forceinline__ V3 dnormvdv(V3 v, V3 dv) {  // auxiliary.h:107-117
 // DC_ONLY: the strand / Stage-I default -- SH degree 0 with one stored coefficient (or precomputed colours): the
 // view-dependent SH code is compiled out (136 -> fewer registers for a kernel that lives on its occupancy).
 template <bool DC_ONLY>
-__global__ __launch_bounds__(HGS_BLOCK) void preprocess_bwd_kernel(HgsBwdArgs a, HgsGeom g, HgsBinning b,
+// (five waves per SIMD: 87 VGPRs; at six the compiler spills six registers and the kernel takes 11.7 instead of 8.9 us)
+#ifndef HGS_PPB_WAVES
+#define HGS_PPB_WAVES 5
+#endif
+__global__ __launch_bounds__(HGS_BLOCK) __attribute__((amdgpu_waves_per_eu(HGS_PPB_WAVES))) void preprocess_bwd_kernel(HgsBwdArgs a, HgsGeom g, HgsBinning b,
                                                                    const float* __restrict__ inst_grad, uint32_t Rcap,
                                                                    const uint32_t* __restrict__ status) {
   const int idx = blockIdx.x * HGS_BLOCK + threadIdx.x;

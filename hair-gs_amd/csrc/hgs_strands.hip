@@ -68,7 +68,12 @@ __global__ __launch_bounds__(256) void strand_fwd_kernel(int P, const float* __r
   if (extra4) ((float4*)extra4)[k] = make_float4(1.f / (1.f + expf(-mask_raw[k])), ux, uy, uz);  // :97-99 + direction
 }
 
-__global__ __launch_bounds__(256) void strand_bwd_kernel(HgsStrandBwdArgs A) {
+// (six waves per SIMD = 80 VGPRs without spills instead of 85: nothing at 100 k Gaussians, 22.2 -> 19.9 us at 200 k, 69.9 -> 64.8
+// at 1 M, where the launch's ~8000 workgroups run in rounds of resident ones; eight would spill)
+#ifndef HGS_SBW_WAVES
+#define HGS_SBW_WAVES 6
+#endif
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HGS_SBW_WAVES))) void strand_bwd_kernel(HgsStrandBwdArgs A) {
   hgs_strand_bwd_block(A, blockIdx.x, gridDim.x);     // (device code: hgs_strand_bwd.h)
 }
 
