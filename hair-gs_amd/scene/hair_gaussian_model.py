@@ -162,13 +162,13 @@ def walk_chains_torch(pairs, n_ep, end_distance):
 
 def nearest_distance(points, refs, chunk=65536):
     """Distance of every point to its nearest reference point, float64, brute force in chunks (what the reference asks a
-    scipy cKDTree for, :1466-1470; a few thousand roots against 10^5 strand ends is milliseconds on the GPU)."""
+    scipy cKDTree for, :1466-1470; a few thousand roots against 10^5-10^6 strand ends is milliseconds on the GPU).
+    torch.cdist in its difference form (no matrix-multiply expansion: exact to rounding like the tree's distances)."""
     refs = refs.to(torch.float64)
     out = torch.empty(points.shape[0], dtype=torch.float64, device=points.device)
     for s in range(0, points.shape[0], chunk):
         p = points[s:s + chunk].to(torch.float64)
-        d2 = ((p[:, None, :] - refs[None, :, :]) ** 2).sum(-1)
-        out[s:s + chunk] = d2.min(dim=1).values.sqrt()
+        out[s:s + chunk] = torch.cdist(p, refs, compute_mode="donot_use_mm_for_euclid_dist").min(dim=1).values
     return out
 
 
@@ -257,6 +257,7 @@ class HairGaussianModel(HairTopologyMixin, GaussianModel):
         rest_e = np.ones(E, bool)
         rest_e[ep_in] = False
         ep_perm = np.concatenate([ep_in, np.nonzero(rest_e)[0]])
+        self._order_aux = (order, new_off, rows_o)     # (for the strands-info remap of sort_spatially)
         return seg_perm, ep_perm
 
     def sort_spatially(self, bits=10):
@@ -295,12 +296,35 @@ class HairGaussianModel(HairTopologyMixin, GaussianModel):
             if torch.is_tensor(t) and t.shape[0] == sp.shape[0]:
                 setattr(self, attr, t[sp])
         self._smooth_pairs = None
-        self.compute_strands_info()
+        # The strands themselves did not change: their bookkeeping is renumbered instead of walked again (at 4 10^5 segments a
+        # walk + the root distances cost 75 ms, and this runs at every densification and merge).  In the new numbering a
+        # strand's vertices are consecutive ids, root first, and the strands follow each other in storage order -- which is
+        # exactly what a fresh compute_strands_info() derives (chains start at their smaller end id, strands are numbered by
+        # their starts, the orientation was root -> tip already): tests/test_models_cpu.py compares the two.
+        order, new_off, rows_o = self._order_aux
+        info = self.strands_info
+        inv_ep_h = np.empty(ep_perm.size, np.int64)
+        inv_ep_h[ep_perm] = np.arange(ep_perm.size)
+        rows_new = inv_ep_h[rows_o]
+        S = order.size
+        i2s = -np.ones(ep_perm.size, np.int32)
+        sid = np.repeat(np.arange(S, dtype=np.int32), np.diff(new_off))
+        i2s[rows_new[:, 0]] = sid
+        i2s[rows_new[:, 1]] = sid
+        comp = -np.ones(ep_perm.size, np.int32)
+        starts, ends = rows_new[new_off[:-1], 0], rows_new[new_off[1:] - 1, 1]
+        comp[starts], comp[ends] = ends, starts
+        self.strands_info = StrandsInfo(new_off.astype(np.int64), rows_new, np.arange(rows_new.shape[0], dtype=np.int64), i2s, comp)
+        self._order_aux = None
         return seg_perm, ep_perm
 
+    _storage_dirty = False
+
     def _maybe_sort_spatially(self):
-        """training_args.spatial_sort (default on) for a model on the GPU, after an operator changed the topology."""
-        if getattr(getattr(self, "training_args", None), "spatial_sort", True) and self._endpoints.is_cuda:
+        """training_args.spatial_sort (default on) for a model on the GPU, once the operators of an iteration have changed
+        the topology (they set _storage_dirty; the training step calls this behind the last of them: one sort per event)."""
+        dirty, self._storage_dirty = self._storage_dirty, False
+        if dirty and getattr(getattr(self, "training_args", None), "spatial_sort", True) and self._endpoints.is_cuda:
             self.sort_spatially()
 
     def __init__(self, sh_degree: int = 3, spatial_lr_scale: float = 1.0, device: str = "cuda"):

@@ -53,7 +53,8 @@ class HairTopologyMixin:
         self.merge_collapsed_segments(info)
         self.prune_strategy(extent, max_screen_size, info, avoid_connected=True)
         self.compute_strands_info()
-        self._maybe_sort_spatially()      # (what the operators created sits at the end of the arrays: back to strand order)
+        self._storage_dirty = True        # (what the operators created sits at the end of the arrays: sort_spatially, once the
+                                          #  iteration's operators are through -- train._training_step)
 
     def _segment_lengths(self):
         seg = self._endpoints[self.endpoint_pairs]
@@ -169,7 +170,7 @@ class HairTopologyMixin:
             return                      # nothing merged: the strands are what they were
         self.merge_endpoint_pairs(pairs)
         self.compute_strands_info()
-        self._maybe_sort_spatially()
+        self._storage_dirty = True
 
     def growing(self, training_info=None, **_):
         raise NotImplementedError("the reference's growing() cannot run either (cat_segments is called without "

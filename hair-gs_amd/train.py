@@ -222,6 +222,8 @@ def _training_step(gaussians, viewpoint_cam, opt, bg, iteration, extent, vp, ras
         if isinstance(gaussians, HairGaussianModel) and getattr(opt, "enable_topology", True):
             if iteration % opt.merge_interval == 0 and hasattr(gaussians, "merging"):
                 gaussians.merging(training_info=None, strands_info_is_current=densified)
+            if getattr(gaussians, "_storage_dirty", False):
+                gaussians._maybe_sort_spatially()     # back to strand order, once per iteration (scene/hair_gaussian_model.py)
         if vp is not None:
             vp.reduce_gradients(gaussians)
         gaussians.optimizer.step()

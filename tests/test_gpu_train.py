@@ -529,6 +529,16 @@ def test_training_loop_with_topology_changes(use_graph):
         p = g["params"][0]
         assert torch.isfinite(p).all() and p.shape[0] == (model._endpoints.shape[0] if g["name"] == "endpoints" else P1)
     assert float(model.get_opacity.max()) < 0.9               # opacity reset happened at it 12
+    # sort_spatially (what the operators end with; the strands have moved since, so their order along the curve may have
+    # changed) renumbers the strand bookkeeping instead of walking the chains again: the result is what a fresh walk gives,
+    # and a second sort finds nothing to move
+    model.compute_strands_info()          # (a walk on the CURRENT geometry: the root -> tip orientation is decided by it)
+    model.sort_spatially()
+    assert model.sort_spatially() is None
+    kept = model.strands_info
+    model.compute_strands_info()
+    for a in ("offsets", "rows", "segment_rows", "id_to_strand_id", "strand_endpoint_id_to_complementary"):
+        assert np.array_equal(np.asarray(getattr(kept, a)), np.asarray(getattr(model.strands_info, a))), a
 
 
 def test_op_by_op_graph_loop_recaptures_cleanly_after_eager_iterations(recwarn):

@@ -372,6 +372,12 @@ def test_hair_sort_spatially_restores_strand_order_without_changing_the_model():
         assert np.all(np.diff(rows) == 1) and np.all(np.diff(seq[:, 0]) == 1) and np.all(seq[:, 1] == seq[:, 0] + 1)
     for g in m.optimizer.param_groups:
         assert g["params"][0] is getattr(m, dict(m._PARAM_ATTRS)[g["name"]]) and g["params"][0].requires_grad
+    # the sort renumbers the strand bookkeeping instead of walking the chains again: the result IS what a fresh walk gives
+    remapped = m.strands_info
+    m.compute_strands_info()
+    fresh = m.strands_info
+    for a in ("offsets", "rows", "segment_rows", "id_to_strand_id", "strand_endpoint_id_to_complementary"):
+        assert np.array_equal(np.asarray(getattr(remapped, a)), np.asarray(getattr(fresh, a))), a
     assert m.sort_spatially() is None
 
 
