@@ -58,7 +58,8 @@ class ViewParallel:
                     g = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(g, stream=s, capture_error_mode="thread_local"):
                         dist.all_reduce(buf)
-                    want = float(self.world * (self.world + 1) // 2)
+                    n = dist.get_world_size()
+                    want = float(n * (n + 1) // 2)
                     good = True
                     for _ in range(2):
                         buf.fill_(float(self.rank + 1))

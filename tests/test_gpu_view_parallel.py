@@ -42,3 +42,18 @@ def test_strong_mode_equals_single_process_gradient_accumulation(nproc):
     """A global batch of 4 views per optimizer step on 1, 2 and 4 ranks (4, 2, 1 views per rank): the same parameters as
     one process that accumulates the four views' gradients by hand and takes their mean."""
     _run(nproc, 29535 + nproc, mode="strong", global_views=4)
+
+
+def test_step_graph_with_the_exchange_inside():
+    """The RCCL form of the step -- pack, all-reduce and Adam captured INTO the iteration's graph, several optimizer steps
+    per launch across ranks (train.GraphedStep with ViewParallel.graph_collective_ok()) -- as far as one GPU can exercise it:
+    a 1-rank nccl (= RCCL) group, the world size faked to 2 for the code path, the reduction itself over one rank.  Ten
+    optimizer steps (two 4-step launches + two single steps) equal the single-rank run bit for bit.  What one GPU cannot
+    show is the transport: DESIGN.md section 7."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "_rccl_graph_worker.py")], env=env, capture_output=True,
+                         text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+    assert "RCCL_GRAPH_OK" in out.stdout and "collective captured: True steps per graph: 4" in out.stdout
