@@ -225,29 +225,12 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
     return dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations
 
 
-_BLACK = {}
-
-
-def _black_to_none(bg):
-    """An all-zero background is handed to the backward as NULL (include/hgs.h: the black-background specialisation of the
-    blend backward, the same gradients with four instructions fewer per evaluated pair).  Decided once per background tensor
-    (one read-back, cached on its storage and version)."""
-    if bg is None or bg.numel() == 0:
-        return bg
-    key = (bg.data_ptr(), bg._version, bg.numel())
-    hit = _BLACK.get(key)
-    if hit is None:
-        if len(_BLACK) > 64:
-            _BLACK.clear()
-        hit = _BLACK[key] = bool((bg == 0).all())
-    return None if hit else bg
-
-
 def rasterize_gaussians_multi_backward(background7, means3D, radii, colors, scales, rotations, scale_modifier,
                                        cov3D_precomp, viewmatrix, projmatrix, tan_fovx, tan_fovy, grad_planes, sh,
                                        degree, campos, geomBuffer, R, binningBuffer, imageBuffer, debug):
     """Backward of the single-pass mode (hgs_backward_multi).  `grad_planes`: list of 7 contiguous [H,W] tensors (views
-    into larger gradient tensors are fine).  Returns (dL_dmeans2D_rgb, dL_dcolors, dL_dextra4, dL_dopacity,
+    into larger gradient tensors are fine).  `background7=None` declares an all-zero background (include/hgs.h: selects the
+    black-background specialisation of the blend backward; same gradients).  Returns (dL_dmeans2D_rgb, dL_dcolors, dL_dextra4, dL_dopacity,
     dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations)."""
     L = rt.lib()
     means3D = rt.require_gpu_tensor(means3D, "means3D", torch.float32)
@@ -265,7 +248,6 @@ def rasterize_gaussians_multi_backward(background7, means3D, radii, colors, scal
     scratch = _scratch(L.hgs_backward_scratch_bytes_multi(P, int(R)), dev)
     planes = [rt.require_gpu_tensor(g, "grad plane", torch.float32) for g in grad_planes]
     plane_ptrs = (C.c_void_p * 7)(*[g.data_ptr() for g in planes])
-    background7 = _black_to_none(background7)
     bg_, sh_, colors_, scales_, rots_, cov_ = (_f32(background7, "bg"), _f32(sh, "sh"), _f32(colors, "colors_precomp"),
                                                _f32(scales, "scales"), _f32(rotations, "rotations"),
                                                _f32(cov3D_precomp, "cov3D_precomp"))

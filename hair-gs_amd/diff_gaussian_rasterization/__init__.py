@@ -85,12 +85,15 @@ class _RasterizeGaussiansMulti(torch.autograd.Function):
     """Single-pass mode: RGB (from SH or precomputed colours) + 4 extra unclamped channels in one forward/backward.
     `raster_settings.bg` must have 7 entries.  Returns (rgb[3,H,W], extra[4,H,W], radii): two views of one 7-channel
     buffer, so the losses' gradients arrive as separate tensors and are handed to the kernel plane by plane (no
-    zero-filled 7-channel gradient is ever assembled).  means2D's gradient is the RGB channels' screen-space gradient."""
+    zero-filled 7-channel gradient is ever assembled).  means2D's gradient is the RGB channels' screen-space gradient.
+    `black_background=True` is the CALLER's statement that raster_settings.bg is all zero: the backward then runs the
+    black-background specialisation (include/hgs.h hgs_backward_multi, bg == NULL); nothing here inspects the tensor."""
 
     @staticmethod
     def forward(ctx, means3D, means2D, sh, colors_precomp, extra4, opacities, scales, rotations, cov3Ds_precomp,
-                raster_settings, splits):
+                raster_settings, splits, black_background=False):
         rs = raster_settings
+        ctx.black_background = bool(black_background)
         num_rendered, color, radii, geomBuffer, binningBuffer, imgBuffer = _C.rasterize_gaussians_multi(
             rs.bg, means3D, colors_precomp, extra4, opacities, scales, rotations, rs.scale_modifier, cov3Ds_precomp,
             rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy, rs.image_height, rs.image_width, sh, rs.sh_degree,
@@ -121,7 +124,7 @@ class _RasterizeGaussiansMulti(torch.autograd.Function):
             g = torch.zeros((n, H, W), device=dev) if g is None else g.contiguous().reshape(n, H, W)
             planes += [g[k] for k in range(n)]
         (g_means2D, g_colors, g_ex, g_opac, g_means3D, g_cov, g_sh, g_scales, g_rot) = \
-            _C.rasterize_gaussians_multi_backward(rs.bg, means3D, radii, colors_precomp, scales, rotations,
+            _C.rasterize_gaussians_multi_backward(None if ctx.black_background else rs.bg, means3D, radii, colors_precomp, scales, rotations,
                                                   rs.scale_modifier, cov3Ds_precomp, rs.viewmatrix, rs.projmatrix,
                                                   rs.tanfovx, rs.tanfovy, planes, sh, rs.sh_degree, rs.campos,
                                                   geomBuffer, ctx.num_rendered, binningBuffer, imgBuffer, rs.debug)
@@ -129,7 +132,7 @@ class _RasterizeGaussiansMulti(torch.autograd.Function):
         def _m(g, ref):
             return g if ref.numel() != 0 else None
         return (g_means3D, g_means2D, _m(g_sh, sh), _m(g_colors, colors_precomp), g_ex, g_opac, _m(g_scales, scales),
-                _m(g_rot, rotations), _m(g_cov, cov3Ds_precomp), None, None)
+                _m(g_rot, rotations), _m(g_cov, cov3Ds_precomp), None, None, None)
 
 
 def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
@@ -165,7 +168,7 @@ class GaussianRasterizer(nn.Module):
         return rasterize_gaussians(means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, rs)
 
     def forward_multi(self, means3D, means2D, opacities, extra4, shs=None, colors_precomp=None, scales=None,
-                      rotations=None, cov3D_precomp=None, splits=(4,)):
+                      rotations=None, cov3D_precomp=None, splits=(4,), black_background=False):
         """Single-pass mode: returns (rgb[3,H,W], radii, *extras) where the blended `extra4` [P,4] channels are handed
         back in groups of `splits` channels ((4,) -> one [4,H,W] tensor; (1,3) -> [H,W] and [3,H,W])."""
         if (shs is None) == (colors_precomp is None):
@@ -177,4 +180,4 @@ class GaussianRasterizer(nn.Module):
         return _RasterizeGaussiansMulti.apply(
             means3D, means2D, empty if shs is None else shs, empty if colors_precomp is None else colors_precomp, extra4,
             opacities, empty if scales is None else scales, empty if rotations is None else rotations,
-            empty if cov3D_precomp is None else cov3D_precomp, self.raster_settings, tuple(splits))
+            empty if cov3D_precomp is None else cov3D_precomp, self.raster_settings, tuple(splits), black_background)

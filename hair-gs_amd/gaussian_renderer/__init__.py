@@ -64,24 +64,22 @@ def _geometry(pc):
     return bundle[0], (lambda: bundle[1]), (lambda: bundle[2])
 
 
-_BG7 = {}
-
-
-def render_multi(viewpoint_camera, pc, bg_color, extra4, scaling_modifier=1.0, debug=False, splits=(4,)):
+def render_multi(viewpoint_camera, pc, bg_color, extra4, scaling_modifier=1.0, debug=False, splits=(4,),
+                 black_background=False):
     """One traversal for RGB + 4 extra per-Gaussian channels.  Equivalent to render(...) plus
     render(..., override_color=extra) on a black background, which is how the reference's mask and orientation losses
     obtain their images (loss/losses.py:247,312).  Returns render()'s dict + "extra": one tensor per entry of `splits`
-    ((4,) -> a single [4,H,W] tensor; (1,3) -> ([H,W], [3,H,W]))."""
+    ((4,) -> a single [4,H,W] tensor; (1,3) -> ([H,W], [3,H,W])).  `black_background=True`: the caller states that bg_color
+    is all zero (selects the backward's black-background specialisation; bg_color is not inspected)."""
     xyz, scales_d, rotations_d = _geometry(pc)
     screenspace_points = torch.zeros_like(xyz, dtype=xyz.dtype, requires_grad=True, device=xyz.device) + 0
     try:
         screenspace_points.retain_grad()
     except Exception:
         pass
-    key = id(bg_color)
-    if key not in _BG7:  # RGB background + black for the extra channels (the reference's default bg of those passes)
-        _BG7[key] = (bg_color, torch.cat([bg_color.to(torch.float32), torch.zeros(4, device=bg_color.device)]))
-    bg7 = _BG7[key][1]
+    # RGB background + black for the extra channels (the reference's default bg of those passes); built per call, so a
+    # background that changes between calls (random_background) is the one rendered
+    bg7 = torch.nn.functional.pad(bg_color.to(torch.float32), (0, 4))
     raster_settings = GaussianRasterizationSettings(
         image_height=int(viewpoint_camera.image_height), image_width=int(viewpoint_camera.image_width),
         tanfovx=math.tan(viewpoint_camera.FoVx * 0.5), tanfovy=math.tan(viewpoint_camera.FoVy * 0.5), bg=bg7,
@@ -90,7 +88,7 @@ def render_multi(viewpoint_camera, pc, bg_color, extra4, scaling_modifier=1.0, d
         campos=viewpoint_camera.camera_center, prefiltered=False, debug=debug)
     out = GaussianRasterizer(raster_settings=raster_settings).forward_multi(
         means3D=xyz, means2D=screenspace_points, opacities=pc.get_opacity, extra4=extra4, shs=pc.get_features,
-        scales=scales_d(), rotations=rotations_d(), splits=splits)
+        scales=scales_d(), rotations=rotations_d(), splits=splits, black_background=black_background)
     rgb, radii, extras = out[0], out[1], out[2:]
     return {"render": rgb, "extra": extras[0] if len(extras) == 1 else extras, "viewspace_points": screenspace_points,
             "visibility_filter": radii > 0, "radii": radii}

@@ -219,7 +219,7 @@ class FusedAdam(torch.optim.Optimizer):
             return None
         beta1, beta2 = rows[0][6]["betas"]
         eps = rows[0][6]["eps"]
-        key = tuple(t.data_ptr() for r in rows for t in r[:6])
+        key = tuple(t.data_ptr() for r in rows for t in r[:6]) + tuple(r[0].numel() for r in rows)
         if self._call is None or self._call[0] != key:
             n = len(rows)
             arrs = [(C.c_void_p * n)(*[r[j].data_ptr() for r in rows]) for j in range(6)]

@@ -156,16 +156,21 @@ def _black(device):
     key = str(device)
     if key not in _BLACK:
         _BLACK[key] = torch.zeros(3, dtype=torch.float32, device=device)
-        _BG_HOST[id(_BLACK[key])] = [0.0, 0.0, 0.0]
     return _BLACK[key]
 
 
-def _bg_host(bg):
-    """Host copy of a background colour (a per-run constant), read back at most once per tensor."""
-    v = _BG_HOST.get(id(bg))
-    if v is None:
-        v = _BG_HOST[id(bg)] = [float(x) for x in bg.cpu()]
-    return v
+def _bg_host(bg, needed=True):
+    """Host copy of a background colour for the fused orientation kernel, which uses it only when the camera has no mask
+    (mask = any(o != bg), losses.py:277).  Read back once per tensor OBJECT and version: the entry keeps the tensor alive,
+    so the id cannot be handed to another tensor while the entry exists."""
+    if not needed:
+        return [0.0, 0.0, 0.0]
+    hit = _BG_HOST.get(id(bg))
+    if hit is None or hit[0] is not bg or hit[1] != bg._version:
+        if len(_BG_HOST) > 16:
+            _BG_HOST.clear()
+        hit = _BG_HOST[id(bg)] = (bg, bg._version, [float(x) for x in bg.detach().cpu()])
+    return hit[2]
 
 
 def orientation_loss_rast(gaussians, camera, args, bg=None):
@@ -177,7 +182,7 @@ def orientation_loss_rast(gaussians, camera, args, bg=None):
     omap = render(camera, gaussians, bg, override_color=gaussians.get_orientation)["render"]      # [3,H,W]
     if fused_losses and omap.is_cuda:
         from hgs_runtime.fused import orientation_loss
-        bg3 = _bg_host(bg)
+        bg3 = _bg_host(bg, camera.mask is None)
         return orientation_loss(omap, camera.world_view_transform, bg3, gaussians.min_val, camera.orientation_field,
                                 camera.orientation_confidence, camera.mask)
     omap = omap.permute(1, 2, 0)
@@ -205,7 +210,7 @@ def _orientation_term(omap, gaussians, camera, bg):
     """Everything of orientation_loss_rast after the render, on a [3,H,W] direction image."""
     if fused_losses and omap.is_cuda:
         from hgs_runtime.fused import orientation_loss
-        return orientation_loss(omap, camera.world_view_transform, _bg_host(bg), gaussians.min_val,
+        return orientation_loss(omap, camera.world_view_transform, _bg_host(bg, camera.mask is None), gaussians.min_val,
                                 camera.orientation_field, camera.orientation_confidence, camera.mask)
     o = omap.permute(1, 2, 0)
     h, w = o.shape[:2]
@@ -221,13 +226,13 @@ def _orientation_term(omap, gaussians, camera, bg):
     return (diff * m).sum() / m.sum()
 
 
-def loss_function_single_pass(gaussians, viewpoint_cam, args, bg):
+def loss_function_single_pass(gaussians, viewpoint_cam, args, bg, black_background=False):
     """loss_function with ONE rasterizer traversal: RGB, the mask value and the world-space direction are blended
     together (gaussian_renderer.render_multi) instead of three render() calls.  Same terms, same weights; returns
     (loss, terms, render_pkg) where render_pkg is what render() would have returned for the RGB pass."""
     from gaussian_renderer import render_multi
     extra = torch.cat((gaussians.get_mask, gaussians.get_orientation), dim=1)      # [P, 1 + 3]
-    pkg = render_multi(viewpoint_cam, gaussians, bg, extra, splits=(1, 3))
+    pkg = render_multi(viewpoint_cam, gaussians, bg, extra, splits=(1, 3), black_background=black_background)
     image, (mask_img, omap) = pkg["render"], pkg["extra"]
     gt = viewpoint_cam.original_image
     if fused_losses and image.is_cuda:

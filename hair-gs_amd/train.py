@@ -162,22 +162,25 @@ def fused_step_applicable(gaussians, opt):
             and gaussians.get_xyz.is_cuda and float(getattr(opt, "lambda_magnet", 0.0)) == 0.0)
 
 
-def training_step(gaussians, viewpoint_cam, opt, bg, iteration, extent=1.0, vp=None, stats_local=None, fused=None):
+def training_step(gaussians, viewpoint_cam, opt, bg, iteration, extent=1.0, vp=None, stats_local=None, fused=None,
+                  black_background=False):
     """One optimizer step.  Returns (loss tensor (detached, on device), loss_dict, render_pkg).
     In the rasterizer's asynchronous mode (diff_gaussian_rasterization._C.set_async) the three passes never block;
     their instance counts are validated once here, before Adam, and the step is repeated if a pass overflowed.
     `fused`: a hgs_runtime.strand_step.FusedStrandStep whose view table holds `viewpoint_cam` -> the iteration runs as
-    one autograd node over the fused kernels (same loss, gradients and statistics)."""
+    one autograd node over the fused kernels (same loss, gradients and statistics).  `black_background=True`: the caller
+    states that `bg` is all zero (op-by-op single-pass path: the blend backward's black-background specialisation)."""
     from diff_gaussian_rasterization import _C as raster
     for _attempt in range(4):
         try:
-            return _training_step(gaussians, viewpoint_cam, opt, bg, iteration, extent, vp, raster, fused)
+            return _training_step(gaussians, viewpoint_cam, opt, bg, iteration, extent, vp, raster, fused,
+                                  black_background)
         except raster.HgsCapacityOverflow:
             gaussians.optimizer.zero_grad(set_to_none=True)
     raise RuntimeError("rasterizer capacity kept overflowing")
 
 
-def _training_step(gaussians, viewpoint_cam, opt, bg, iteration, extent, vp, raster, fused=None):
+def _training_step(gaussians, viewpoint_cam, opt, bg, iteration, extent, vp, raster, fused=None, black_background=False):
     # The reference ends every iteration with zero_grad(set_to_none=True) (train.py:203): an iteration starts without
     # gradients.  A captured graph leaves its static gradient tensors in `.grad` after a replay -- an eager iteration that
     # follows (topology iterations of training(), bench.py's kernel-timing pass) would ACCUMULATE onto them.
@@ -194,7 +197,7 @@ def _training_step(gaussians, viewpoint_cam, opt, bg, iteration, extent, vp, ras
                       "visibility_filter": None}
     elif getattr(opt, "single_pass", True) and gaussians.get_xyz.is_cuda:
         # RGB + mask + orientation in one rasterizer traversal (same loss, 3x fewer raster passes)
-        loss, loss_dict, render_pkg = loss_function_single_pass(gaussians, viewpoint_cam, opt, bg)
+        loss, loss_dict, render_pkg = loss_function_single_pass(gaussians, viewpoint_cam, opt, bg, black_background)
     else:
         render_pkg = render(viewpoint_cam, gaussians, bg)
         loss, loss_dict = loss_function(gaussians, render_pkg["render"], viewpoint_cam, opt)
@@ -252,6 +255,8 @@ class GraphedStep:
         import copy
         from diff_gaussian_rasterization import _C as raster
         self.g, self.opt, self.bg, self.extent, self.raster = gaussians, opt, bg, extent, raster
+        # the background is a constant of the captured step: looked at once, here, before anything is captured
+        self.black_background = bool((bg == 0).all())
         self.vp = vp if vp is not None else ViewParallel()
         self.fused = None
         if fused_step_applicable(gaussians, opt):
@@ -360,7 +365,7 @@ class GraphedStep:
             self.fused.update_densification_stats()
             return loss.detach()
         if getattr(self.opt, "single_pass", True):
-            loss, _, pkg = loss_function_single_pass(self.g, self.slot, self.opt, self.bg)
+            loss, _, pkg = loss_function_single_pass(self.g, self.slot, self.opt, self.bg, self.black_background)
         else:
             pkg = render(self.slot, self.g, self.bg)
             loss, _ = loss_function(self.g, pkg["render"], self.slot, self.opt)
@@ -613,7 +618,8 @@ def training(gaussians, cameras, opt, iterations=None, extent=1.0, seed=0, log_e
                 # only the (detached) loss is kept: the terms and the render package of an op-by-op iteration hold its autograd
                 # graph -- and with it the parameters' AccumulateGrad nodes, created on THIS stream -- alive, which breaks the
                 # next capture on the side stream (stream mismatch; observed as a crash in capture_end)
-                losses = [training_step(gaussians, sampler.next(), opt, bg, it, extent=extent, vp=vp, fused=fused)[0]]
+                losses = [training_step(gaussians, sampler.next(), opt, bg, it, extent=extent, vp=vp, fused=fused,
+                                        black_background=True)[0]]
                 if fused is not None and due:
                     fused.refresh()
             first, it = it, it + len(losses)

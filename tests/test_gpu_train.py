@@ -1030,6 +1030,41 @@ def test_black_background_backward_specialisation_is_exact():
         assert torch.equal(a, b) and bool(a.abs().sum() > 0)
 
 
+def test_op_by_op_black_background_is_the_callers_statement():
+    """render_multi / loss_function_single_pass: the black-background backward runs only when the CALLER says the
+    background is black (nothing is cached per tensor: a new background tensor that reuses a freed one's address, or one
+    rewritten in place, is the one rendered and differentiated); with a black background both backwards agree bit for bit."""
+    from arguments import OptimizationParams
+    from loss.losses import loss_function_single_pass
+    from synthetic import build_workload
+    model, cams, _ = build_workload("tiny", device="cuda", with_targets=True)
+    opt = OptimizationParams()
+    model.training_setup(opt)
+    params = [model._endpoints, model._width, model._opacity, model._mask, model._features_dc]
+
+    def grads(bg, black):
+        for p in params:
+            p.grad = None
+        loss, _, pkg = loss_function_single_pass(model, cams[1], opt, bg, black_background=black)
+        loss.backward()
+        return float(loss), [p.grad.clone() for p in params], pkg["render"].detach().clone()
+
+    zero = torch.zeros(3, device="cuda")
+    l0, g0, _ = grads(zero, False)
+    l1, g1, _ = grads(zero, True)
+    assert l0 == l1 and all(torch.equal(a, b) for a, b in zip(g0, g1))
+    # a background rewritten in place between two calls (also through .data, which leaves the version counter alone)
+    bg = torch.zeros(3, device="cuda")
+    _, _, img_black = grads(bg, False)
+    bg.data.fill_(0.6)
+    l2, g2, img_grey = grads(bg, False)
+    fresh = torch.full((3,), 0.6, device="cuda")
+    l3, g3, img_fresh = grads(fresh, False)
+    assert torch.equal(img_grey, img_fresh) and not torch.equal(img_grey, img_black)
+    assert l2 == l3 and all(torch.equal(a, b) for a, b in zip(g2, g3))
+    assert not all(torch.equal(a, b) for a, b in zip(g0, g2))
+
+
 @pytest.mark.parametrize("use_graph", [False, True])
 def test_stage1_training_loop_with_densification(use_graph):
     """training() on the Stage-I cloud through the fused cloud iteration: densification (clone / split / prune) and the

@@ -17,7 +17,7 @@ w3 = torch.randn(3, H, W, device="cuda"); w1 = torch.randn(H, W, device="cuda");
 for i in range(n):
     cam = cams[i % len(cams)]
     extra = torch.cat((model.get_mask, model.get_orientation), dim=1)
-    pkg = render_multi(cam, model, bg, extra, splits=(1, 3))
+    pkg = render_multi(cam, model, bg, extra, splits=(1, 3), black_background=True)   # bg is the zeros made above
     loss = (pkg["render"] * w3).sum() + (pkg["extra"][0] * w1).sum() + (pkg["extra"][1] * wo).sum()
     loss.backward()
     for p in (model._endpoints, model._features_dc, model._opacity, model._mask, model._width):

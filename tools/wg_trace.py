@@ -18,7 +18,7 @@ w3 = torch.randn(3, H, W, device="cuda"); w1 = torch.randn(H, W, device="cuda");
 tf = torch.zeros(8 * G, dtype=torch.int64, device="cuda"); tb = torch.zeros(8 * G, dtype=torch.int64, device="cuda")
 def run():
     extra = torch.cat((model.get_mask, model.get_orientation), dim=1)
-    pkg = render_multi(cam, model, bg, extra, splits=(1, 3))
+    pkg = render_multi(cam, model, bg, extra, splits=(1, 3), black_background=True)   # bg is the zeros made above
     loss = (pkg["render"] * w3).sum() + (pkg["extra"][0] * w1).sum() + (pkg["extra"][1] * wo).sum()
     loss.backward()
 for _ in range(3): run()
