@@ -74,6 +74,7 @@ class ViewTable:
         self.slot = torch.zeros(_SLOT_BYTES, dtype=torch.uint8, device=self.device)
         f = self.slot.view(torch.float32)
         self.viewmatrix, self.projmatrix, self.campos = f[_F_VIEW:_F_VIEW + 16], f[_F_PROJ:_F_PROJ + 16], f[_F_CAM:_F_CAM + 3]
+        self._cameras = list(cameras)     # (keeps the ids below unique for the table's lifetime)
         self.index = {id(c): i for i, c in enumerate(cameras)}
         self.n = len(cameras)
         self.current = -1
