@@ -378,6 +378,34 @@ def main():
             render_ms = (time.perf_counter() - t1) * 1e3 / len(cams)
             raster.check_async()
             raster.set_async(False)
+            # the same frames through gaussian_renderer.frames.FrameRenderer: the whole forward of a view as one captured
+            # graph, re-pointed per view (same protocol: 3 warm-ups, all views, one validation at the end)
+            from gaussian_renderer.frames import FrameRenderer
+            KF = 8 if len(cams) % 8 == 0 else 1
+            fr = FrameRenderer(model, cams, bg, frames_per_launch=KF)
+
+            def all_views():
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                if KF > 1:
+                    for i in range(0, len(cams), KF):
+                        fr.render_batch(list(range(i, i + KF)), check=False)
+                else:
+                    for i in range(len(cams)):
+                        fr.render(i, check=False)
+                redo = fr.validate()
+                return (time.perf_counter() - t1) * 1e3 / len(cams), redo
+
+            for i in range(3):
+                fr.render(i % len(cams))
+            render_graph_ms, redo = all_views()
+            if redo:            # a view exceeded the captured capacity: measure again on the recaptured graph
+                fr.render(redo[0])
+                render_graph_ms, redo = all_views()
+                assert redo == []
+            with torch.no_grad():
+                same = bool(torch.equal(fr.render(1 % len(cams))["render"], render(cams[1 % len(cams)], model, bg)["render"]))
+            del fr
             # sum over tiles of L_t (= tile_maxc) per view, for the algorithmic-byte model
             from diff_gaussian_rasterization import _C as C_
             W, H = cams[0].image_width, cams[0].image_height
@@ -404,7 +432,7 @@ def main():
                 stats[cull] = (sum(Ls) / len(Ls), sum(Rs) / len(Rs))
             (meanL, meanR), (meanL_culled, meanR_culled) = stats[False], stats[True]
 
-        return dict(render_ms=render_ms, meanL=meanL, meanR=meanR, meanL_culled=meanL_culled, meanR_culled=meanR_culled)
+        return dict(render_ms=render_ms, render_graph_ms=render_graph_ms, render_graph_equal=same, render_graph_frames=KF, meanL=meanL, meanR=meanR, meanL_culled=meanL_culled, meanR_culled=meanR_culled)
 
     fs = frame_stats()
     render_ms, meanL, meanR, meanL_culled, meanR_culled = (fs[k] for k in ("render_ms", "meanL", "meanR", "meanL_culled", "meanR_culled"))
@@ -450,7 +478,8 @@ def main():
                    "value": args.steps / tr["dt"], "unit": "iters/s", "ms_per_step": tr["dt"] * 1e3 / args.steps,
                    "repeats": {"n": len(tr["regions"]), "min_iters_per_sec": args.steps / tr["regions"][-1],
                                "max_iters_per_sec": args.steps / tr["regions"][0]},
-                   "render_ms_per_view": tfs["render_ms"], "mean_num_rendered": tfs["meanR"],
+                   "render_ms_per_view": tfs["render_ms"], "render_ms_per_view_frame_renderer": tfs["render_graph_ms"],
+                   "mean_num_rendered": tfs["meanR"],
                    "mean_num_rendered_after_tile_cull": tfs["meanR_culled"], "mean_sum_tile_list_len": tfs["meanL"],
                    "capacity_rollbacks_while_training": getattr(training, "last_rollbacks", None)}
         if tr["kern"]:
@@ -489,7 +518,9 @@ def main():
                    "optimizer_steps_per_graph_launch": head["steps_per_graph"],
                    "iteration": "fused iteration" if fused is not None else "op-by-op",
                    "raster_passes_per_iter": 1 if getattr(opt, "single_pass", True) else 3},
-        "render_ms_per_view": render_ms,
+        "render_ms_per_view": render_ms,                       # render(): the drop-in call, eager, ~20 host-side tensor ops per view
+        "render_ms_per_view_frame_renderer": fs["render_graph_ms"],   # gaussian_renderer.frames: the same frames as one graph per view
+        "frame_renderer_equals_render": fs["render_graph_equal"], "frame_renderer_frames_per_launch": fs["render_graph_frames"],
         "trained_state": trained,
     }
     if kern:

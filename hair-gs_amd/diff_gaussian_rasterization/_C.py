@@ -112,9 +112,20 @@ def rasterize_gaussians_multi(background7, means3D, colors, extra4, opacity, sca
                     extra4, True, image_buffer)
 
 
+def rasterize_gaussians_prezeroed(background, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp,
+                                  viewmatrix, projmatrix, tan_fovx, tan_fovy, image_height, image_width, sh, degree, campos,
+                                  image_buffer, max_rendered=None):
+    """rasterize_gaussians_culled on an image buffer whose counters the caller has cleared on this stream (see
+    rasterize_gaussians_multi); max_rendered: an int32[1] device tensor of the caller's that receives the sticky maximum of
+    num_rendered in capacity mode instead of this module's (gaussian_renderer.frames validates its own frames with it)."""
+    return _forward(background, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp, viewmatrix,
+                    projmatrix, tan_fovx, tan_fovy, image_height, image_width, sh, degree, campos, False, False,
+                    None, True, image_buffer, max_rendered)
+
+
 def _forward(background, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp, viewmatrix,
              projmatrix, tan_fovx, tan_fovy, image_height, image_width, sh, degree, campos, prefiltered, debug, extra4,
-             cull, image_buffer=None):
+             cull, image_buffer=None, max_rendered=None):
     if means3D.ndim != 2 or means3D.shape[1] != 3:
         raise RuntimeError("means3D must have dimensions (num_points, 3)")  # rasterize_points.cu:57-59
     L = rt.lib()
@@ -150,7 +161,8 @@ def _forward(background, means3D, colors, opacity, scales, rotations, scale_modi
                                           rt.ptr(cov_), rt.ptr(view), rt.ptr(proj), rt.ptr(cam), float(tan_fovx),
                                           float(tan_fovy), flags, rt.ptr(geom), rt.ptr(img),
                                           rt.ptr(radii), None if use_async else C.addressof(n_host),
-                                          rt.ptr(_max_rendered(dev)) if use_async else None))
+                                          rt.ptr(max_rendered if max_rendered is not None else _max_rendered(dev))
+                                          if use_async else None))
         if use_async:
             R = _state["cap"]
         else:
@@ -165,7 +177,7 @@ def _forward(background, means3D, colors, opacity, scales, rotations, scale_modi
             binning = torch.empty((L.hgs_binning_bytes_multi(R),), **u8)
             rt.check(L.hgs_forward_render_multi(stream, P, W, H, R, rt.ptr(bg), rt.ptr(colors_), rt.ptr(extra_),
                                                 rt.ptr(geom), rt.ptr(binning), rt.ptr(img), rt.ptr(out_color)))
-        if use_async:
+        if use_async and max_rendered is None:
             _state["dirty"] = True
             _state["cap_used"] = R if _state["cap_used"] is None else min(_state["cap_used"], R)
         if debug:

@@ -29,29 +29,39 @@ class ViewTable:
     """HgsViewTargets rows of a list of cameras in device memory + the slot the kernels read.  The cameras' tensors are
     referenced, not copied (they must stay alive and unchanged)."""
 
-    def __init__(self, cameras, device=None):
+    def __init__(self, cameras, device=None, targets=True):
+        """targets=False: the rows carry the camera matrices only (forward-only rendering, gaussian_renderer.frames): the
+        cameras need no ground-truth tensors and the loss head must not be run on such a table."""
         if len(cameras) == 0:
             raise rt.HgsError("ViewTable needs at least one camera")
         c0 = cameras[0]
-        self.device = torch.device(device) if device is not None else c0.original_image.device
+        self.has_targets = bool(targets)
+        if device is not None:
+            self.device = torch.device(device)
+        elif targets:
+            self.device = c0.original_image.device
+        else:
+            self.device = c0.world_view_transform.device
         self.H, self.W = int(c0.image_height), int(c0.image_width)
         self.tanfovx, self.tanfovy = math.tan(c0.FoVx * 0.5), math.tan(c0.FoVy * 0.5)
-        self.has_float_mask = getattr(c0, "float_mask", None) is not None
-        self.has_mask = getattr(c0, "mask", None) is not None
+        self.has_float_mask = targets and getattr(c0, "float_mask", None) is not None
+        self.has_mask = targets and getattr(c0, "mask", None) is not None
         rows = (rt.ViewTargets * len(cameras))()
         self._keep = []
         for i, c in enumerate(cameras):
             if (int(c.image_height), int(c.image_width), c.FoVx, c.FoVy) != (self.H, self.W, c0.FoVx, c0.FoVy):
                 raise rt.HgsError("all views of a ViewTable must share resolution and field of view")
-            if (getattr(c, "float_mask", None) is not None) != self.has_float_mask or \
-                    (getattr(c, "mask", None) is not None) != self.has_mask:
+            if targets and ((getattr(c, "float_mask", None) is not None) != self.has_float_mask or
+                            (getattr(c, "mask", None) is not None) != self.has_mask):
                 raise rt.HgsError("either every view has a mask or none")
             r = rows[i]
-            img = rt.require_gpu_tensor(c.original_image, "original_image", torch.float32)
-            ori = rt.require_gpu_tensor(c.orientation_field, "orientation_field", torch.float32)
-            conf = rt.require_gpu_tensor(c.orientation_confidence, "orientation_confidence", torch.float32)
-            keep = [img, ori, conf]
-            r.image, r.orientation, r.confidence = img.data_ptr(), ori.data_ptr(), conf.data_ptr()
+            keep = []
+            if targets:
+                img = rt.require_gpu_tensor(c.original_image, "original_image", torch.float32)
+                ori = rt.require_gpu_tensor(c.orientation_field, "orientation_field", torch.float32)
+                conf = rt.require_gpu_tensor(c.orientation_confidence, "orientation_confidence", torch.float32)
+                keep = [img, ori, conf]
+                r.image, r.orientation, r.confidence = img.data_ptr(), ori.data_ptr(), conf.data_ptr()
             if self.has_float_mask:
                 fm = rt.require_gpu_tensor(c.float_mask, "float_mask", torch.float32)
                 keep.append(fm)
@@ -133,6 +143,17 @@ class ViewTable:
         pro = fu.prologue
         pro.table, pro.view, pro.slot, pro.lr, pro.lr_dst = self.table.data_ptr(), view, self.slot.data_ptr(), lr, lr_dst
         pro.zero_ptr, pro.zero_bytes = zp, zb
+
+    def flush_prologue(self):
+        """A prologue(ride=True) nobody carried: launch it now (callers whose first launch cannot take a rider)."""
+        if self._rider is None:
+            return
+        view, lr, lr_dst = self._rider
+        self._rider = None
+        zp, zb = self._image_zero_range()
+        with torch.cuda.device(self.device):
+            rt.check(rt.lib().hgs_iteration_prologue(rt.current_stream(), self.table.data_ptr(), view, self.slot.data_ptr(), lr,
+                                                     lr_dst, zp, zb))
 
     def take_image(self):
         """The image buffer whose counters the last prologue() cleared (once), else None."""
@@ -397,6 +418,8 @@ class FusedStrandStep:
     def __init__(self, gaussians, cameras, opt, bg):
         self.gaussians, self.opt = gaussians, opt
         self.views = cameras if isinstance(cameras, ViewTable) else ViewTable(cameras)
+        if not self.views.has_targets:
+            raise rt.HgsError("the training iteration needs a ViewTable built with the views' targets")
         dev = self.views.device
         self.bg7 = torch.cat([bg.to(dev, torch.float32), torch.zeros(4, device=dev)]).contiguous()
         # a black background (the training default, train.py:94) is handed to the backward as NULL: its terms are compiled
