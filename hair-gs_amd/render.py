@@ -53,9 +53,20 @@ def render_set(args, name, iteration, views, gaussians, optimization, kind):
         gaussians.training_setup(optimization)
         gaussians.clean_gaussians()
     th = gaussians.foreground_binarization_th
+    frames = None
+    if kind in (0, 1) and background.is_cuda and len(views) > 1:
+        # the RGB frames of a fixed model: one captured graph re-pointed per view (gaussian_renderer.frames; the image is
+        # render()'s, bit for bit); views of different sizes keep the per-call path
+        import hgs_runtime as rt
+        from gaussian_renderer.frames import FrameRenderer
+        try:
+            frames = FrameRenderer(gaussians, views, background)
+        except rt.HgsError:
+            frames = None
     for idx, view in enumerate(views):
         if kind in (0, 1):
-            rendering, gt = render(view, gaussians, background)["render"], view.original_image[0:3]
+            rendering = frames.render(idx)["render"] if frames is not None else render(view, gaussians, background)["render"]
+            gt = view.original_image[0:3]
         elif kind == 2:
             rendering = render(view, gaussians, background, override_color=(gaussians.get_mask.repeat(1, 3) >= th).float())["render"][0]
             gt = view.float_mask

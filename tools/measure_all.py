@@ -71,6 +71,7 @@ def bench_line(workload, extra=()):
     d = json.loads(line[-1])
     k = d.get("kernel_us_per_launch", {})
     return {"iters_per_s": d["value"], "ms_per_step": d["ms_per_step"], "render_ms_per_view": d["render_ms_per_view"],
+            "render_ms_per_view_frame_renderer": d.get("render_ms_per_view_frame_renderer"),
             "gaussians": d["config"]["gaussians"], "mean_num_rendered": d["config"]["mean_num_rendered"],
             "mean_num_rendered_after_tile_cull": d["config"].get("mean_num_rendered_after_tile_cull"),
             "iteration": d["config"].get("iteration"), "scaling": d.get("scaling"), "repeats": d.get("repeats"),
