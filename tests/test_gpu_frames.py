@@ -149,3 +149,19 @@ def test_kernel_sigmoid_has_torch_sigmoids_bits():
     ref = torch.sigmoid(x)
     assert torch.equal(o.view(torch.int32), ref.view(torch.int32))
     assert torch.equal(e4[:, 0].contiguous().view(torch.int32), ref[:, 0].contiguous().view(torch.int32))
+
+
+def test_frame_renderer_on_an_empty_model():
+    """No Gaussians: the frame is the background (eager path; nothing to capture), as render() gives it."""
+    import torch
+    from gaussian_renderer import render
+    from gaussian_renderer.frames import FrameRenderer
+    model, cams, bg = _setup("cloud")
+    model.prune_points(torch.ones(model.get_xyz.shape[0], dtype=torch.bool, device="cuda"))
+    assert model.get_xyz.shape[0] == 0
+    fr = FrameRenderer(model, cams, bg)
+    out = fr.render(1)
+    with torch.no_grad():
+        ref = render(cams[1], model, bg)["render"]
+    assert torch.equal(out["render"], ref) and fr.captures == 0
+    assert torch.equal(out["render"], bg.view(3, 1, 1).expand_as(ref))
