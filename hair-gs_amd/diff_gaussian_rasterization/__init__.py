@@ -15,6 +15,9 @@ def cpu_deep_copy_tuple(input_tuple):
     return tuple(item.cpu().clone() if isinstance(item, torch.Tensor) else item for item in input_tuple)
 
 
+_EMPTY = torch.Tensor([])   # stands for an absent optional input (never written to)
+
+
 class GaussianRasterizationSettings(NamedTuple):  # reference :157-169
     image_height: int
     image_width: int
@@ -159,7 +162,7 @@ class GaussianRasterizer(nn.Module):
         if ((scales is None or rotations is None) and cov3D_precomp is None) or \
                 ((scales is not None or rotations is not None) and cov3D_precomp is not None):
             raise Exception("Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!")
-        empty = torch.Tensor([])
+        empty = _EMPTY
         shs = empty if shs is None else shs
         colors_precomp = empty if colors_precomp is None else colors_precomp
         scales = empty if scales is None else scales
@@ -176,7 +179,7 @@ class GaussianRasterizer(nn.Module):
         if ((scales is None or rotations is None) and cov3D_precomp is None) or \
                 ((scales is not None or rotations is not None) and cov3D_precomp is not None):
             raise Exception("Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!")
-        empty = torch.Tensor([])
+        empty = _EMPTY
         return _RasterizeGaussiansMulti.apply(
             means3D, means2D, empty if shs is None else shs, empty if colors_precomp is None else colors_precomp, extra4,
             opacities, empty if scales is None else scales, empty if rotations is None else rotations,

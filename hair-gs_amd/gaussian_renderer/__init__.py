@@ -12,11 +12,14 @@ def render(viewpoint_camera, pc, bg_color, scaling_modifier=1.0, override_color=
     """Render the scene.  `bg_color` must live on the GPU."""
     xyz, scales_d, rotations_d = _geometry(pc)
     # zero tensor whose gradient receives dL/d(screen-space mean) (reference :41-50), read by the densification stats
-    screenspace_points = torch.zeros_like(xyz, dtype=xyz.dtype, requires_grad=True, device=xyz.device) + 0
-    try:
-        screenspace_points.retain_grad()
-    except Exception:
-        pass
+    if torch.is_grad_enabled():
+        screenspace_points = torch.zeros_like(xyz, dtype=xyz.dtype, requires_grad=True, device=xyz.device) + 0
+        try:
+            screenspace_points.retain_grad()
+        except Exception:
+            pass
+    else:       # forward-only call: the same zeros, nothing to retain a gradient for
+        screenspace_points = torch.zeros_like(xyz)
     tanfovx = math.tan(viewpoint_camera.FoVx * 0.5)
     tanfovy = math.tan(viewpoint_camera.FoVy * 0.5)
     raster_settings = GaussianRasterizationSettings(
