@@ -141,12 +141,55 @@ int hgs_image_zero_range(int W, int H, size_t* offset, size_t* bytes) {
 int hgs_image_layout(int W, int H, size_t* offsets) { HgsImage im; hgs_image_carve(nullptr, (size_t)W, (size_t)H, im, offsets); return 0; }
 int hgs_binning_layout(int R, size_t* offsets) { HgsBinning b; hgs_binning_carve(nullptr, (size_t)R, b, offsets); return 0; }
 
+static_assert(HGS_FUSED_PREPROCESS_MAX_TILES == HGS_FUSED_SCAN_MAX_T, "include/hgs.h states the scatter kernel's scan limit");
+// the strand parameters of hgs_hair_forward_preprocess (NULL: the Gaussians are given)
+struct HairSrc {
+  const float* endpoints; const long long* pairs; const float* width; float f; const float* opacity_raw; const float* mask_raw;
+  float* xyz; float* scale; float* quat; float* opacity; float* extra4; const HgsStrandFusion* fusion;
+};
+static int forward_preprocess_impl(void* stream, int P, int D, int M, int W, int H, const float* means3D, const float* shs,
+                                   const float* colors_precomp, const float* opacities, const float* scales,
+                                   float scale_modifier, const float* rotations, const float* cov3D_precomp,
+                                   const float* viewmatrix, const float* projmatrix, const float* campos, float tan_fovx,
+                                   float tan_fovy, int prefiltered, void* geom_buf, void* image_buf, int* radii,
+                                   int* num_rendered_host, unsigned int* max_rendered, const HairSrc* hair);
+
 int hgs_forward_preprocess(void* stream, int P, int D, int M, int W, int H, const float* means3D, const float* shs,
                            const float* colors_precomp, const float* opacities, const float* scales,
                            float scale_modifier, const float* rotations, const float* cov3D_precomp,
                            const float* viewmatrix, const float* projmatrix, const float* campos, float tan_fovx,
                            float tan_fovy, int prefiltered, void* geom_buf, void* image_buf, int* radii,
                            int* num_rendered_host, unsigned int* max_rendered) {
+  return forward_preprocess_impl(stream, P, D, M, W, H, means3D, shs, colors_precomp, opacities, scales, scale_modifier,
+                                 rotations, cov3D_precomp, viewmatrix, projmatrix, campos, tan_fovx, tan_fovy, prefiltered,
+                                 geom_buf, image_buf, radii, num_rendered_host, max_rendered, nullptr);
+}
+
+int hgs_hair_forward_preprocess(void* stream, int P, int D, int M, int W, int H, const float* endpoints,
+                                const long long* endpoint_pairs, const float* width, float dist_to_scale_factor,
+                                const float* opacity_raw, const float* mask_raw, const float* shs, float* xyz, float* scale,
+                                float* quat, float* opacity, float* extra4, const float* viewmatrix, const float* projmatrix,
+                                const float* campos, float tan_fovx, float tan_fovy, int flags, void* geom_buf,
+                                void* image_buf, int* radii, unsigned int* max_rendered, const HgsStrandFusion* fusion) {
+  if (P > 0 && (!endpoints || !endpoint_pairs || !width || !opacity_raw || !mask_raw || !xyz || !scale || !quat || !opacity ||
+                !extra4 || ((size_t)quat & 15) || ((size_t)extra4 & 15))) {
+    hgs_set_error("hgs_hair_forward_preprocess: null (or, quat / extra4, not 16-byte aligned) argument");
+    return 1;
+  }
+  if (!max_rendered) { hgs_set_error("hgs_hair_forward_preprocess: capacity mode only (max_rendered must be given)"); return 1; }
+  const HairSrc hair = {endpoints, endpoint_pairs, width, dist_to_scale_factor, opacity_raw, mask_raw, xyz, scale, quat, opacity,
+                        extra4, fusion};
+  return forward_preprocess_impl(stream, P, D, M, W, H, xyz, shs, nullptr, opacity, scale, 1.f, quat, nullptr, viewmatrix,
+                                 projmatrix, campos, tan_fovx, tan_fovy, flags, geom_buf, image_buf, radii, nullptr,
+                                 max_rendered, &hair);
+}
+
+static int forward_preprocess_impl(void* stream, int P, int D, int M, int W, int H, const float* means3D, const float* shs,
+                                   const float* colors_precomp, const float* opacities, const float* scales,
+                                   float scale_modifier, const float* rotations, const float* cov3D_precomp,
+                                   const float* viewmatrix, const float* projmatrix, const float* campos, float tan_fovx,
+                                   float tan_fovy, int prefiltered, void* geom_buf, void* image_buf, int* radii,
+                                   int* num_rendered_host, unsigned int* max_rendered, const HairSrc* hair) {
   hipStream_t s = (hipStream_t)stream;
   if (P < 0 || W <= 0 || H <= 0) { hgs_set_error("bad sizes P=%d W=%d H=%d", P, W, H); return 1; }
   if ((size_t)((W + HGS_TILE - 1) / HGS_TILE) * ((H + HGS_TILE - 1) / HGS_TILE) > HGS_MAX_TILES) { hgs_set_error("%dx%d: more than 2^24 tiles", W, H); return 1; }
@@ -158,6 +201,18 @@ int hgs_forward_preprocess(void* stream, int P, int D, int M, int W, int H, cons
   const int T = ((W + HGS_TILE - 1) / HGS_TILE) * ((H + HGS_TILE - 1) / HGS_TILE);
   if (!(prefiltered & HGS_IMAGE_PREZEROED) &&
       hgs_zero_async(s, im.tile_count, hgs_image_zero_words((size_t)T) * sizeof(uint32_t))) return 1;
+  const HgsPrologue* rider = (hair && hair->fusion && hair->fusion->prologue.table) ? &hair->fusion->prologue : nullptr;
+  if (rider && (!rider->slot || rider->view < 0 || ((size_t)rider->zero_ptr & 3) || (rider->zero_bytes & 3) ||
+                (rider->zero_bytes && !rider->zero_ptr))) {
+    hgs_set_error("hgs_hair_forward_preprocess: bad prologue group");
+    return 1;
+  }
+  if (hair && T > HGS_FUSED_SCAN_MAX_T) {
+    hgs_set_error("hgs_hair_forward_preprocess: %d tiles, at most %d (the tile counters are cleared by the scatter kernel's scan)", T, HGS_FUSED_SCAN_MAX_T);
+    return 1;
+  }
+  if (P == 0 && rider &&     // nothing to ride on: the prologue as a launch of its own
+      hgs_iteration_prologue(stream, rider->table, rider->view, rider->slot, rider->lr, rider->lr_dst, rider->zero_ptr, rider->zero_bytes)) return 1;
   if (P == 0) {  // reference short-circuits P == 0 (rasterize_points.cu:81); the scan of all-zero counts writes the
     HgsGeom none = {};  // empty ranges and the tile order the blend kernel (background fill) indexes with
     if (hgs_launch_scan(s, 0, T, none, im, nullptr)) return 1;
@@ -187,7 +242,13 @@ int hgs_forward_preprocess(void* stream, int P, int D, int M, int W, int H, cons
   // the one-workgroup scan kernel in between.)
   const bool fused_scan = !num_rendered_host && max_rendered && T <= HGS_FUSED_SCAN_MAX_T && P <= HGS_FUSED_SCAN_MAX_P;
   a.fused_scan_ptr = fused_scan ? (unsigned long long)(size_t)max_rendered : 0ull;
-  if (hgs_launch_preprocess_fwd(s, a, g, im, radii)) return 1;
+  if (hair) {
+    if (!fused_scan) { hgs_set_error("hgs_hair_forward_preprocess: the scan must be the scatter kernel's (sizes beyond its limits)"); return 1; }
+    HgsStrandFusion fu = hair->fusion ? *hair->fusion : HgsStrandFusion{};
+    if (!(fu.smooth_pairs && fu.n_smooth > 0 && fu.smooth_partials)) fu.n_smooth = 0;
+    if (hgs_launch_hair_preprocess_fwd(s, a, g, im, radii, hair->endpoints, hair->pairs, hair->width, hair->f, hair->opacity_raw,
+                                       hair->mask_raw, hair->xyz, hair->scale, hair->quat, hair->opacity, hair->extra4, fu)) return 1;
+  } else if (hgs_launch_preprocess_fwd(s, a, g, im, radii)) return 1;
   if (!fused_scan && hgs_launch_scan(s, P, T, g, im, max_rendered)) return 1;
   if (num_rendered_host) {
     uint32_t r = 0;
@@ -420,7 +481,8 @@ int hgs_graph_find_prologues(void* graph, int max_nodes, void** nodes_out, float
     hipKernelNodeParams kp;
     HGS_CHECK_HIP(hipGraphKernelNodeGetParams(nodes[i], &kp));
     int n_params = 1;                                      // the prologue is the LAST argument of all three kernels
-    if (kp.func != (void*)select_view_kernel && !hgs_strands_prologue_kernel(kp.func, &n_params)) continue;
+    if (kp.func != (void*)select_view_kernel && !hgs_strands_prologue_kernel(kp.func, &n_params) &&
+        !hgs_preprocess_prologue_kernel(kp.func, &n_params)) continue;
     if (!kp.kernelParams) continue;
     const HgsPrologue* pro = (const HgsPrologue*)kp.kernelParams[n_params - 1];
     if (!pro->table) continue;                             // (a parameter launch without a rider)
@@ -448,7 +510,8 @@ int hgs_graph_set_prologue(void* graph_exec, void* node, const HgsViewTargets* t
   hipKernelNodeParams kp;
   HGS_CHECK_HIP(hipGraphKernelNodeGetParams((hipGraphNode_t)node, &kp));
   int n_params = 1;
-  if (kp.func != (void*)select_view_kernel && !hgs_strands_prologue_kernel(kp.func, &n_params)) {
+  if (kp.func != (void*)select_view_kernel && !hgs_strands_prologue_kernel(kp.func, &n_params) &&
+      !hgs_preprocess_prologue_kernel(kp.func, &n_params)) {
     hgs_set_error("hgs_graph_set_prologue: not a prologue node");
     return 1;
   }

@@ -265,6 +265,11 @@ struct HgsFwdArgs {
 #endif
 #define HGS_FUSED_SCAN_MAX_T 8192    // tiles the scatter kernel's scan workgroups take (a share's offsets live in the block's tile table); 1080p has 8160
 int hgs_launch_preprocess_fwd(hipStream_t s, const HgsFwdArgs& a, const HgsGeom& g, const HgsImage& im, int* radii);
+// strand parameters -> Gaussians -> preprocess in one launch (hgs_hair_forward_preprocess), riders of `fusion` included
+int hgs_launch_hair_preprocess_fwd(hipStream_t s, const HgsFwdArgs& a, const HgsGeom& g, const HgsImage& im, int* radii,
+                                   const float* endpoints, const long long* pairs, const float* width, float f,
+                                   const float* opacity_raw, const float* mask_raw, float* xyz, float* scale, float* quat,
+                                   float* opacity, float* extra4, const HgsStrandFusion& fusion);
 int hgs_launch_scan(hipStream_t s, int P, int T, const HgsGeom& g, const HgsImage& im, unsigned int* max_rendered);
 int hgs_launch_scatter(hipStream_t s, int P, int W, int H, int Rcap, const float* features, const float* extra, int n_extra,
                        const HgsGeom& g, const HgsImage& im, const HgsBinning& b);

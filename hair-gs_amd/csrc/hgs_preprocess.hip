@@ -11,6 +11,9 @@
 // depth key is evaluated operation by operation in the reference's order (glm column-major products,
 // type_mat3x3.inl:486-520), so keys/rects are bit-identical to the CPU oracle.
 #include "hgs_common.h"
+#include "hgs_smooth.h"
+#include "hgs_prologue.h"
+#include "hgs_strand_fwd.h"
 
 namespace {
 
@@ -136,9 +139,18 @@ __device__ __forceinline__ int th_find(const TileHash& h, uint32_t t) {  // slot
 }
 
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(HGS_BLOCK) void preprocess_fwd_kernel(HgsFwdArgs a, HgsGeom g, HgsImage im, int* radii) {
-  __shared__ uint32_t red[4];
-  __shared__ TileHash th;
+// The strand model's parameters, for the kernel that derives a segment's Gaussian itself (hgs_hair_forward_preprocess): inputs
+// and the arrays the derived Gaussians are written to (the backward and the scatter kernel read them).
+struct HgsStrandSrc {
+  const float* ep; const long long* pairs; const float* width; float f; const float* opacity_raw; const float* mask_raw;
+  float* xyz; float* scale; float* quat; float* opacity; float* extra4;
+};
+
+// STRAND: lane idx derives its Gaussian from the strand parameters (same device function as strand_fwd_kernel: same bits),
+// stores it, and goes on with the values in registers; a.means3D / scales / rotations / opacities are not read.
+template <bool STRAND>
+__device__ __forceinline__ void preprocess_fwd_body(const HgsFwdArgs& a, const HgsGeom& g, const HgsImage& im, int* radii,
+                                                    const HgsStrandSrc& st, uint32_t* red, TileHash& th) {
   th_init(th);
   __syncthreads();
   const int idx = blockIdx.x * HGS_BLOCK + threadIdx.x;
@@ -147,8 +159,21 @@ __global__ __launch_bounds__(HGS_BLOCK) void preprocess_fwd_kernel(HgsFwdArgs a,
   if (idx < a.P) {
     int my_radius_i = 0;
     HgsRect rc = {0, 0, 0, 0, 0, 0};
+    HgsStrandGaussian sgn = {};
+    float opacity_v = 0.f;
+    if (STRAND) {
+      const long long i0 = st.pairs[2 * (size_t)idx], i1 = st.pairs[2 * (size_t)idx + 1];
+      sgn = hgs_strand_gaussian(st.ep[3 * i0], st.ep[3 * i0 + 1], st.ep[3 * i0 + 2], st.ep[3 * i1], st.ep[3 * i1 + 1],
+                                st.ep[3 * i1 + 2], st.width[idx], st.f);
+      opacity_v = hgs_sigmoid(st.opacity_raw[idx]);
+      st.xyz[3 * (size_t)idx] = sgn.mx; st.xyz[3 * (size_t)idx + 1] = sgn.my; st.xyz[3 * (size_t)idx + 2] = sgn.mz;
+      st.scale[3 * (size_t)idx] = sgn.s0; st.scale[3 * (size_t)idx + 1] = sgn.sw; st.scale[3 * (size_t)idx + 2] = sgn.sw;
+      ((float4*)st.quat)[idx] = make_float4(sgn.q0, sgn.q1, sgn.q2, sgn.q3);
+      st.opacity[idx] = opacity_v;
+      ((float4*)st.extra4)[idx] = make_float4(hgs_sigmoid(st.mask_raw[idx]), sgn.ux, sgn.uy, sgn.uz);
+    }
     do {
-      const V3 p = {a.means3D[3 * idx], a.means3D[3 * idx + 1], a.means3D[3 * idx + 2]};
+      const V3 p = STRAND ? V3{sgn.mx, sgn.my, sgn.mz} : V3{a.means3D[3 * idx], a.means3D[3 * idx + 1], a.means3D[3 * idx + 2]};
       const V3 pv = xform4x3(p, a.viewmatrix);
       if (pv.z <= 0.2f) {  // auxiliary.h:154 (the `prefiltered` trap of :156-160 is not reproduced: it aborts the GPU)
         break;
@@ -165,8 +190,9 @@ __global__ __launch_bounds__(HGS_BLOCK) void preprocess_fwd_kernel(HgsFwdArgs a,
         for (int k = 0; k < 6; k++) cov3[k] = a.cov3D_precomp[6 * (size_t)idx + k];
       } else {
         const float mod = a.scale_modifier;
-        const float s0 = mod * a.scales[3 * idx], s1 = mod * a.scales[3 * idx + 1], s2 = mod * a.scales[3 * idx + 2];
-        const float4 q = ((const float4*)a.rotations)[idx];
+        const float s0 = mod * (STRAND ? sgn.s0 : a.scales[3 * idx]), s1 = mod * (STRAND ? sgn.sw : a.scales[3 * idx + 1]),
+                    s2 = mod * (STRAND ? sgn.sw : a.scales[3 * idx + 2]);
+        const float4 q = STRAND ? make_float4(sgn.q0, sgn.q1, sgn.q2, sgn.q3) : ((const float4*)a.rotations)[idx];
         const M3 R = quat_R(q.x, q.y, q.z, q.w);
         M3 Mm;  // M = S * R  (S diagonal: M[c][r] = s_r * R[c][r]; the zero terms of the full product add exact zeros)
 #pragma unroll
@@ -183,7 +209,7 @@ __global__ __launch_bounds__(HGS_BLOCK) void preprocess_fwd_kernel(HgsFwdArgs a,
       const float det = c2.a * c2.c - c2.b * c2.b;
       if (det == 0.0f) break;
       const float det_inv = 1.f / det;
-      const float4 conic_o = {c2.c * det_inv, -c2.b * det_inv, c2.a * det_inv, a.opacities[idx]};
+      const float4 conic_o = {c2.c * det_inv, -c2.b * det_inv, c2.a * det_inv, STRAND ? opacity_v : a.opacities[idx]};
       const float mid = 0.5f * (c2.a + c2.c);
       const float lambda1 = mid + sqrtf(fmaxf(0.1f, mid * mid - det));
       const float lambda2 = mid - sqrtf(fmaxf(0.1f, mid * mid - det));
@@ -281,6 +307,42 @@ __global__ __launch_bounds__(HGS_BLOCK) void preprocess_fwd_kernel(HgsFwdArgs a,
     if (th.key[i] != TH_EMPTY) atomicAdd(&im.tile_count[HGS_TILE_SLOT(th.key[i], im.tile_mask)], th.cnt[i]);
 }
 
+__global__ __launch_bounds__(HGS_BLOCK) void preprocess_fwd_kernel(HgsFwdArgs a, HgsGeom g, HgsImage im, int* radii) {
+  __shared__ uint32_t red[4];
+  __shared__ TileHash th;
+  preprocess_fwd_body<false>(a, g, im, radii, HgsStrandSrc{}, red, th);
+}
+
+// The iteration's FIRST launch for a strand model (hgs_hair_forward_preprocess): strand parameters -> Gaussians -> preprocess in
+// one kernel, with the riders the parameter kernel used to carry (include/hgs.h HgsStrandFusion: smoothness partial sums;
+// HgsPrologue: view select + clearing of the image buffer's counters -- `pro` stays the LAST argument, where the graph functions
+// find it).  Two things differ from the two-launch form because the riders now run BESIDE the preprocess workgroups:
+//   * the view matrices are read from the view TABLE's row (pro.table[pro.view]), not from the slot the rider fills;
+//   * the rider's zero range must not hold the tile counters these workgroups increment (the caller passes the range behind
+//     them: they are left at zero by the scatter kernel's scan workgroups, which clear what they have read), and the two status
+//     words workgroup 0 writes are stepped over.
+__global__ __launch_bounds__(HGS_BLOCK) void hair_preprocess_fwd_kernel(HgsFwdArgs a, HgsGeom g, HgsImage im, int* radii,
+                                                                        HgsStrandSrc st, HgsStrandFusion fu, HgsPrologue pro) {
+  __shared__ uint32_t red[4];
+  __shared__ TileHash th;
+  const unsigned npro = pro.table ? hgs_prologue_blocks(pro.zero_bytes / 4) : 0u;
+  if (blockIdx.x >= gridDim.x - npro) {
+    hgs_prologue_block(pro, blockIdx.x - (gridDim.x - npro), npro, im.status + HGS_ST_SCANPTR_LO);
+    return;
+  }
+  const int nb_seg = (a.P + HGS_BLOCK - 1) / HGS_BLOCK;
+  if ((int)blockIdx.x >= nb_seg) {   // smoothness partial sums over the same endpoints
+    hgs_smooth_fwd_block((int)blockIdx.x - nb_seg, fu.n_smooth, st.ep, fu.smooth_pairs, fu.cos_threshold, fu.eps, fu.smooth_partials,
+                         (float*)red);
+    return;
+  }
+  if (pro.table) {
+    const HgsViewTargets* row = pro.table + pro.view;
+    a.viewmatrix = row->viewmatrix; a.projmatrix = row->projmatrix; a.campos = row->campos;
+  }
+  preprocess_fwd_body<true>(a, g, im, radii, st, red, th);
+}
+
 // ------------------------------------------------------------------------------------------------
 // scatter: one lane per Gaussian.  Exclusive instance offset = block prefix (scan kernel) + in-block scan;
 // every touched tile gets key = depth_bits<<32 | gaussian_id appended to the tile's segment (order inside the
@@ -328,6 +390,11 @@ __global__ __launch_bounds__(HGS_BLOCK) void scatter_kernel(int P, int gx, int T
       cnt[k] = (k < ipt && i0 + k < t_hi) ? im.tile_count[HGS_TILE_SLOT(i0 + k, im.tile_mask)] : 0u;
 #pragma unroll
     for (int k = 0; k < MAX_IPT; k++) mine += cnt[k];
+    // the counters are dead from here on: leave them at zero for the next pass over this image buffer (whose first kernel may
+    // count into them beside the workgroups that clear the rest of the buffer's counters: hair_preprocess_fwd_kernel)
+#pragma unroll
+    for (int k = 0; k < MAX_IPT; k++)
+      if (k < ipt && i0 + k < t_hi && cnt[k]) im.tile_count[HGS_TILE_SLOT(i0 + k, im.tile_mask)] = 0u;
     const uint32_t inc = hgs_wave_incl_scan(mine, lane);
     if (lane == 63) wsum[wave] = inc;
     __syncthreads();
@@ -747,6 +814,27 @@ int hgs_launch_preprocess_fwd(hipStream_t s, const HgsFwdArgs& a, const HgsGeom&
   {
     HgsProfScope _prof(s, HGS_K_PREPROCESS_FWD);
     hipLaunchKernelGGL(preprocess_fwd_kernel, dim3(nblk), dim3(HGS_BLOCK), 0, s, a, g, im, radii);
+  }
+  HGS_CHECK_LAUNCH();
+  return 0;
+}
+bool hgs_preprocess_prologue_kernel(const void* func, int* n_params) {
+  if (func == (const void*)hair_preprocess_fwd_kernel) { *n_params = 7; return true; }
+  return false;
+}
+int hgs_launch_hair_preprocess_fwd(hipStream_t s, const HgsFwdArgs& a, const HgsGeom& g, const HgsImage& im, int* radii,
+                                   const float* endpoints, const long long* pairs, const float* width, float f,
+                                   const float* opacity_raw, const float* mask_raw, float* xyz, float* scale, float* quat,
+                                   float* opacity, float* extra4, const HgsStrandFusion& fusion) {
+  HgsStrandFusion fu = fusion;
+  const HgsPrologue pro = fu.prologue;
+  fu.prologue = HgsPrologue{};      // (handed over as the kernel's last argument)
+  const HgsStrandSrc st = {endpoints, pairs, width, f, opacity_raw, mask_raw, xyz, scale, quat, opacity, extra4};
+  const unsigned nblk = (unsigned)((a.P + HGS_BLOCK - 1) / HGS_BLOCK) + (unsigned)((fu.n_smooth + 255) / 256) +
+                        (pro.table ? hgs_prologue_blocks(pro.zero_bytes / 4) : 0u);
+  {
+    HgsProfScope _prof(s, HGS_K_PREPROCESS_FWD);
+    hipLaunchKernelGGL(hair_preprocess_fwd_kernel, dim3(nblk), dim3(HGS_BLOCK), 0, s, a, g, im, radii, st, fu, pro);
   }
   HGS_CHECK_LAUNCH();
   return 0;

@@ -10,7 +10,8 @@ __host__ __device__ static inline unsigned hgs_prologue_blocks(size_t zero_words
 }
 
 // workgroup `wg` of `nwg` (256 threads each): wg 0 copies the view (and the learning rate), the others clear
-__device__ __forceinline__ void hgs_prologue_block(const HgsPrologue& p, unsigned wg, unsigned nwg) {
+// `keep`: two consecutive words inside the zero range that are NOT cleared (NULL: none)
+__device__ __forceinline__ void hgs_prologue_block(const HgsPrologue& p, unsigned wg, unsigned nwg, const uint32_t* keep = nullptr) {
   if (wg == 0) {
     const uint32_t* src = (const uint32_t*)(p.table + p.view);
     uint32_t* dst = (uint32_t*)p.slot;
@@ -20,8 +21,12 @@ __device__ __forceinline__ void hgs_prologue_block(const HgsPrologue& p, unsigne
   }
   uint32_t* z = (uint32_t*)p.zero_ptr;
   const size_t words = p.zero_bytes / 4, stride = (size_t)(nwg - 1) * 256;
-  for (size_t i = (size_t)(wg - 1) * 256 + threadIdx.x; i < words; i += stride) z[i] = 0u;
+  const uint32_t* keep1 = keep ? keep + 1 : nullptr;
+  for (size_t i = (size_t)(wg - 1) * 256 + threadIdx.x; i < words; i += stride)
+    if (z + i != keep && z + i != keep1) z[i] = 0u;
 }
 
 // hgs_strands.hip: is `func` one of its forward kernels (which take an HgsPrologue as their LAST of *n_params arguments)?
 bool hgs_strands_prologue_kernel(const void* func, int* n_params);
+// hgs_preprocess.hip: the fused parameters + preprocess kernel (same convention)
+bool hgs_preprocess_prologue_kernel(const void* func, int* n_params);

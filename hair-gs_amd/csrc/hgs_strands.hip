@@ -17,6 +17,7 @@
 #include "hgs_head_tail.h"
 #include "hgs_prologue.h"
 #include "hgs_strand_bwd.h"
+#include "hgs_strand_fwd.h"
 
 namespace {
 
@@ -40,32 +41,16 @@ __global__ __launch_bounds__(256) void strand_fwd_kernel(int P, const float* __r
   const int k = blockIdx.x * 256 + threadIdx.x;
   if (k >= P) return;
   const long long i0 = pairs[2 * (size_t)k], i1 = pairs[2 * (size_t)k + 1];
-  const float ax = ep[3 * i0], ay = ep[3 * i0 + 1], az = ep[3 * i0 + 2];
-  const float bx = ep[3 * i1], by = ep[3 * i1 + 1], bz = ep[3 * i1 + 2];
-  xyz[3 * (size_t)k] = (ax + bx) / 2.f; xyz[3 * (size_t)k + 1] = (ay + by) / 2.f; xyz[3 * (size_t)k + 2] = (az + bz) / 2.f;
-  const float dx = bx - ax, dy = by - ay, dz = bz - az;
-  const float L = sqrtf(dx * dx + dy * dy + dz * dz);
-  const float ew = expf(width[k]);
-  scale[3 * (size_t)k] = fmaxf(L / 2.f * f, MINV);
-  scale[3 * (size_t)k + 1] = ew;
-  scale[3 * (size_t)k + 2] = ew;
-  float q0 = 1.f, q1 = 0.f, q2 = 0.f, q3 = 0.f, ux = 1.f, uy = 0.f, uz = 0.f;
-  if (L > MINV) {
-    const float il = 1.f / L;
-    const float vx = dx * il, vy = dy * il, vz = dz * il;
-    const float n0 = 1.f + vx;
-    if (n0 > MINV) {
-      const float in = 1.f / sqrtf(n0 * n0 + vz * vz + vy * vy);
-      q0 = n0 * in; q1 = 0.f; q2 = -vz * in; q3 = vy * in;
-    } else {  // d = -x_hat: half turn about z
-      q0 = 0.f; q3 = 1.f;
-    }
-    if (L >= MINV) { ux = vx; uy = vy; uz = vz; }
-  }
-  ((float4*)quat)[k] = make_float4(q0, q1, q2, q3);
-  if (dir) { dir[3 * (size_t)k] = ux; dir[3 * (size_t)k + 1] = uy; dir[3 * (size_t)k + 2] = uz; }
-  if (opacity) opacity[k] = 1.f / (1.f + expf(-opacity_raw[k]));              // gaussian_model.py:93-95
-  if (extra4) ((float4*)extra4)[k] = make_float4(1.f / (1.f + expf(-mask_raw[k])), ux, uy, uz);  // :97-99 + direction
+  const HgsStrandGaussian sgn = hgs_strand_gaussian(ep[3 * i0], ep[3 * i0 + 1], ep[3 * i0 + 2], ep[3 * i1], ep[3 * i1 + 1],
+                                                    ep[3 * i1 + 2], width[k], f);
+  xyz[3 * (size_t)k] = sgn.mx; xyz[3 * (size_t)k + 1] = sgn.my; xyz[3 * (size_t)k + 2] = sgn.mz;
+  scale[3 * (size_t)k] = sgn.s0;
+  scale[3 * (size_t)k + 1] = sgn.sw;
+  scale[3 * (size_t)k + 2] = sgn.sw;
+  ((float4*)quat)[k] = make_float4(sgn.q0, sgn.q1, sgn.q2, sgn.q3);
+  if (dir) { dir[3 * (size_t)k] = sgn.ux; dir[3 * (size_t)k + 1] = sgn.uy; dir[3 * (size_t)k + 2] = sgn.uz; }
+  if (opacity) opacity[k] = hgs_sigmoid(opacity_raw[k]);                                          // gaussian_model.py:93-95
+  if (extra4) ((float4*)extra4)[k] = make_float4(hgs_sigmoid(mask_raw[k]), sgn.ux, sgn.uy, sgn.uz);  // :97-99 + direction
 }
 
 // (six waves per SIMD = 80 VGPRs without spills instead of 85: nothing at 100 k Gaussians, 22.2 -> 19.9 us at 200 k, 69.9 -> 64.8

@@ -17,7 +17,7 @@ import hgs_runtime as rt
 # the capacity: the caller discards the step's gradients and repeats it.  `num_rendered` returned by
 # rasterize_gaussians is then the capacity (it only sizes/carves buffers downstream).
 IMAGE_PREZEROED = 2   # include/hgs.h HGS_IMAGE_PREZEROED (flag in `prefiltered`)
-_state = {"last_R": 0, "async": False, "cap": 0, "slack": 1.5, "dirty": False, "cap_used": None, "max_R": {}, "cull": None}
+_state = {"last_R": 0, "last_counts_clean": False, "async": False, "cap": 0, "slack": 1.5, "dirty": False, "cap_used": None, "max_R": {}, "cull": None}
 
 
 class HgsCapacityOverflow(RuntimeError):
@@ -102,30 +102,50 @@ def rasterize_gaussians_culled(background, means3D, colors, opacity, scales, rot
 
 def rasterize_gaussians_multi(background7, means3D, colors, extra4, opacity, scales, rotations, scale_modifier,
                               cov3D_precomp, viewmatrix, projmatrix, tan_fovx, tan_fovy, image_height, image_width, sh,
-                              degree, campos, prefiltered, debug, image_buffer=None):
+                              degree, campos, prefiltered, debug, image_buffer=None, hair=None):
     """Single-pass 7-channel forward (hgs_forward_render_multi): RGB + `extra4` [P,4] unclamped channels blended with
     the same weights.  Returns (num_rendered, out_color[7,H,W], radii, geomBuffer, binningBuffer, imgBuffer).
     image_buffer: a uint8 tensor of hgs_image_bytes(W, H) whose counters the caller has cleared on this stream
     (hgs_iteration_prologue): used as the imgBuffer, and the pass skips its own clearing launch."""
     return _forward(background7, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp, viewmatrix,
                     projmatrix, tan_fovx, tan_fovy, image_height, image_width, sh, degree, campos, prefiltered, debug,
-                    extra4, True, image_buffer)
+                    extra4, True, image_buffer, None, hair)
+
+
+class HairSource:
+    """The strand parameters behind means3D / scales / rotations / opacity (/ extra4) of a pass: those five tensors are then
+    OUTPUTS, written by the pass's first launch.  In capacity mode that launch is hgs_hair_forward_preprocess (parameters ->
+    Gaussians -> preprocess in one kernel, `fusion`'s riders beside it); otherwise hgs_hair_params_forward runs in front of
+    the ordinary preprocess launch.  `fusion`: hgs_runtime.StrandFusion (or None); `fill(fused)` is called once the form is
+    known and must put the iteration prologue (if one rides) into `fusion` with the matching zero range."""
+
+    def __init__(self, endpoints, pairs, width, factor, opacity_raw, mask_raw, fusion=None, fill=None):
+        self.endpoints, self.pairs, self.width, self.factor = endpoints, pairs, width, float(factor)
+        self.opacity_raw, self.mask_raw, self.fusion, self.fill = opacity_raw, mask_raw, fusion, fill
+
+
+def will_fuse_hair(W, H):
+    """Would a pass with a HairSource at this size run the one-launch form now?  (capacity mode with a learnt capacity,
+    at most HGS_FUSED_PREPROCESS_MAX_TILES tiles)"""
+    import os
+    return (_state["async"] and _state["cap"] > 0 and os.environ.get("HGS_FUSE_PREPROCESS", "1") != "0"
+            and ((int(W) + 15) // 16) * ((int(H) + 15) // 16) <= rt.FUSED_PREPROCESS_MAX_TILES)
 
 
 def rasterize_gaussians_prezeroed(background, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp,
                                   viewmatrix, projmatrix, tan_fovx, tan_fovy, image_height, image_width, sh, degree, campos,
-                                  image_buffer, max_rendered=None):
+                                  image_buffer, max_rendered=None, hair=None):
     """rasterize_gaussians_culled on an image buffer whose counters the caller has cleared on this stream (see
     rasterize_gaussians_multi); max_rendered: an int32[1] device tensor of the caller's that receives the sticky maximum of
     num_rendered in capacity mode instead of this module's (gaussian_renderer.frames validates its own frames with it)."""
     return _forward(background, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp, viewmatrix,
                     projmatrix, tan_fovx, tan_fovy, image_height, image_width, sh, degree, campos, False, False,
-                    None, True, image_buffer, max_rendered)
+                    None, True, image_buffer, max_rendered, hair)
 
 
 def _forward(background, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp, viewmatrix,
              projmatrix, tan_fovx, tan_fovy, image_height, image_width, sh, degree, campos, prefiltered, debug, extra4,
-             cull, image_buffer=None, max_rendered=None):
+             cull, image_buffer=None, max_rendered=None, hair=None):
     if means3D.ndim != 2 or means3D.shape[1] != 3:
         raise RuntimeError("means3D must have dimensions (num_points, 3)")  # rasterize_points.cu:57-59
     L = rt.lib()
@@ -156,13 +176,39 @@ def _forward(background, means3D, colors, opacity, scales, rotations, scale_modi
     with torch.cuda.device(dev):
         use_async = _state["async"] and _state["cap"] > 0 and P > 0
         n_host = C.c_int(0)
-        rt.check(L.hgs_forward_preprocess(stream, P, int(degree), M, W, H, rt.ptr(means3D), rt.ptr(sh_), rt.ptr(colors_),
-                                          rt.ptr(opacity_), rt.ptr(scales_), float(scale_modifier), rt.ptr(rots_),
-                                          rt.ptr(cov_), rt.ptr(view), rt.ptr(proj), rt.ptr(cam), float(tan_fovx),
-                                          float(tan_fovy), flags, rt.ptr(geom), rt.ptr(img),
-                                          rt.ptr(radii), None if use_async else C.addressof(n_host),
-                                          rt.ptr(max_rendered if max_rendered is not None else _max_rendered(dev))
-                                          if use_async else None))
+        fused_hair = hair is not None and use_async and will_fuse_hair(W, H)
+        if hair is not None:
+            if scale_modifier != 1.0 or colors_ is not None or cov_ is not None or sh_ is None:
+                raise RuntimeError("a HairSource pass renders SH colours at scale_modifier 1")
+            if hair.fill is not None:
+                hair.fill(fused_hair)
+            ep_, pairs_, w_ = _f32(hair.endpoints, "endpoints"), rt.require_gpu_tensor(hair.pairs, "endpoint_pairs", torch.int64), _f32(hair.width, "width")
+            o_raw, m_raw = _f32(hair.opacity_raw, "opacity_raw"), _f32(hair.mask_raw, "mask_raw")
+            fu_ = None if hair.fusion is None else C.byref(hair.fusion)
+            ex_out = extra_ if extra_ is not None else torch.empty((P, 4), dtype=torch.float32, device=dev)
+            if not fused_hair:
+                rt.check(L.hgs_hair_params_forward(stream, P, rt.ptr(ep_), rt.ptr(pairs_), rt.ptr(w_), hair.factor, rt.ptr(o_raw),
+                                                   rt.ptr(m_raw), rt.ptr(means3D), rt.ptr(scales_), rt.ptr(rots_), None,
+                                                   rt.ptr(opacity_), rt.ptr(ex_out), fu_))
+        if fused_hair:
+            rt.check(L.hgs_hair_forward_preprocess(stream, P, int(degree), M, W, H, rt.ptr(ep_), rt.ptr(pairs_), rt.ptr(w_),
+                                                   hair.factor, rt.ptr(o_raw), rt.ptr(m_raw), rt.ptr(sh_), rt.ptr(means3D),
+                                                   rt.ptr(scales_), rt.ptr(rots_), rt.ptr(opacity_), rt.ptr(ex_out),
+                                                   rt.ptr(view), rt.ptr(proj), rt.ptr(cam), float(tan_fovx), float(tan_fovy),
+                                                   flags, rt.ptr(geom), rt.ptr(img), rt.ptr(radii),
+                                                   rt.ptr(max_rendered if max_rendered is not None else _max_rendered(dev)), fu_))
+        else:
+            rt.check(L.hgs_forward_preprocess(stream, P, int(degree), M, W, H, rt.ptr(means3D), rt.ptr(sh_), rt.ptr(colors_),
+                                              rt.ptr(opacity_), rt.ptr(scales_), float(scale_modifier), rt.ptr(rots_),
+                                              rt.ptr(cov_), rt.ptr(view), rt.ptr(proj), rt.ptr(cam), float(tan_fovx),
+                                              float(tan_fovy), flags, rt.ptr(geom), rt.ptr(img),
+                                              rt.ptr(radii), None if use_async else C.addressof(n_host),
+                                              rt.ptr(max_rendered if max_rendered is not None else _max_rendered(dev))
+                                              if use_async else None))
+        # the scan of a capacity-mode pass (scatter kernel) leaves the per-tile instance counters of `img` at zero; a blocking
+        # pass leaves its counts there (hgs_runtime.strand_step.ViewTable.counts_clean follows this)
+        if P > 0:
+            _state["last_counts_clean"] = bool(use_async and ((W + 15) // 16) * ((H + 15) // 16) <= rt.FUSED_PREPROCESS_MAX_TILES)
         if use_async:
             R = _state["cap"]
         else:

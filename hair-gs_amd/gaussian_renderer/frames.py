@@ -64,26 +64,29 @@ class FrameRenderer:
         with torch.no_grad(), torch.cuda.device(dev):
             if self.hair and g.endpoint_pairs.shape[0] > 0:
                 fu = rt.StrandFusion()
-                vt.fill_prologue(fu)
                 pairs = rt.require_gpu_tensor(g.endpoint_pairs, "endpoint_pairs", torch.int64)
                 P = pairs.shape[0]
                 xyz, scale, quat = torch.empty((P, 3), **f32), torch.empty((P, 3), **f32), torch.empty((P, 4), **f32)
                 # the kernel's sigmoid, 1 / (1 + expf(-x)), gives torch.sigmoid's bits (tests/test_gpu_frames.py pins that on
                 # 10^6 values): the opacity comes out of the same launch instead of one of its own
-                opacity, spare4 = torch.empty((P, 1), **f32), torch.empty((P, 4), **f32)
-                rt.check(L.hgs_hair_params_forward(rt.current_stream(), P, rt.ptr(g._endpoints), rt.ptr(pairs), rt.ptr(g._width),
-                                                   float(g.dist_to_scale_factor), rt.ptr(g._opacity), rt.ptr(g._mask),
-                                                   rt.ptr(xyz), rt.ptr(scale), rt.ptr(quat), None, rt.ptr(opacity),
-                                                   rt.ptr(spare4), C.byref(fu)))
+                opacity = torch.empty((P, 1), **f32)
+
+                def fill(fused):     # (see hgs_runtime.strand_step._StrandIteration: same protocol)
+                    if fused and not vt.counts_clean:
+                        vt.flush_prologue()
+                    vt.fill_prologue(fu, behind_counts=fused)
+                hair = raster.HairSource(g._endpoints, pairs, g._width, g.dist_to_scale_factor, g._opacity, g._mask, fu, fill)
             else:
                 vt.flush_prologue()
-                xyz, scale, quat, opacity = g.get_xyz, g.get_scaling, g.get_rotation, g.get_opacity
+                xyz, scale, quat, opacity, hair = g.get_xyz, g.get_scaling, g.get_rotation, g.get_opacity, None
             # (get_features is cat(dc, rest): with no higher-order coefficients the DC tensor itself is that array)
             shs = g._features_dc if g._features_rest.shape[1] == 0 else g.get_features
+            own_image = vt.take_image()
             out = raster.rasterize_gaussians_prezeroed(
                 self.bg, xyz, self.empty, opacity, scale, quat, 1.0, self.empty, vt.viewmatrix, vt.projmatrix,
-                vt.tanfovx, vt.tanfovy, vt.H, vt.W, shs, int(g.active_sh_degree), vt.campos, vt.take_image(),
-                self._max_R)
+                vt.tanfovx, vt.tanfovy, vt.H, vt.W, shs, int(g.active_sh_degree), vt.campos, own_image, self._max_R, hair)
+            if own_image is not None and xyz.shape[0] > 0:
+                vt.counts_clean = raster._state["last_counts_clean"]
         self._last_R = int(out[0])
         return {"render": out[1], "radii": out[2]}
 
@@ -149,6 +152,7 @@ class FrameRenderer:
         if self._graph is None or self._key != self._model_key():
             self._capture()
         vt.graph_set(self._binding, int(view))
+        vt.ensure_counts_clean()
         self._graph.replay()
         self._pending.append(int(view))
 
@@ -184,6 +188,7 @@ class FrameRenderer:
             gk, binding, outs = self._many
             for j, v in enumerate(views):
                 self.views.graph_set(binding, v, k=j)
+            self.views.ensure_counts_clean()
             gk.replay()
             self._pending += views
             if not check or not self.validate():

@@ -63,6 +63,8 @@ SIGNATURES = {
     "hgs_hair_params_forward": (ci, [vp, ci, vp, vp, vp, cf, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "hgs_hair_params_backward": (ci, [vp, ci, ci, vp, vp, vp, cf, vp, vp, vp, vp, vp, vp, vp, vp, ci, vp, vp, vp, vp, vp]),
     "hgs_cloud_params_forward": (ci, [vp, ci, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
+    "hgs_hair_forward_preprocess": (ci, [vp, ci, ci, ci, ci, ci, vp, vp, vp, cf, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp,
+                                         cf, cf, ci, vp, vp, vp, vp, vp]),
     "hgs_cloud_params_backward": (ci, [vp, ci, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "hgs_loss_head_scratch_floats": (sz, [vp]),
     "hgs_loss_head_tail": (ci, [vp, vp, vp, vp]),
@@ -132,7 +134,8 @@ VIEW_QUEUE_MAX = 16   # include/hgs.h HGS_VIEW_QUEUE_MAX
 HEAD_OUT = ["total", "l1", "dssim", "mask", "orientation", "smooth", "ori_count", "smooth_count", "g_ssim", "g_l1", "g_mask",
             "g_ori", "g_smooth", "total_fwd"]
 HEAD_NOUT = 16
-ABI_VERSION = 3   # include/hgs.h HGS_ABI_VERSION: bumped whenever a struct, a signature or a buffer layout changes
+FUSED_PREPROCESS_MAX_TILES = 8192   # include/hgs.h HGS_FUSED_PREPROCESS_MAX_TILES
+ABI_VERSION = 4   # include/hgs.h HGS_ABI_VERSION: bumped whenever a struct, a signature or a buffer layout changes
 
 
 def build(verbose=False):

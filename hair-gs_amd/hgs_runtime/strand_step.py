@@ -93,6 +93,10 @@ class ViewTable:
         self.queue_lr = torch.zeros((), dtype=torch.float32, device=self.device)
         self._image, self._zero, self._image_ready = None, None, False
         self._rider = None
+        # True while the image buffer's per-tile instance counters are known to be zero: what a forward pass in capacity mode
+        # leaves behind (its scan clears them), and what the fused parameters + preprocess launch needs at its start
+        self.counts_clean = False
+        self._fill_behind = False      # zero range of the last fill_prologue(): True = starts behind those counters
 
     def select(self, view, lr=0.0, lr_dst=None):
         """slot <- table[view] (and *lr_dst <- lr): one launch on the current stream."""
@@ -105,14 +109,23 @@ class ViewTable:
         self._rider = None
 
     # ---- iteration prologue: view select + clearing of the image buffer's counters in ONE launch (include/hgs.h) ----
-    def _image_zero_range(self):
+    def _image_zero_range(self, behind_counts=False):
+        """(pointer, bytes) of the counters a prologue clears; behind_counts: without the per-tile instance counters in front."""
         if self._image is None:
             L = rt.lib()
-            self._image = torch.empty((L.hgs_image_bytes(self.W, self.H),), dtype=torch.uint8, device=self.device)
+            self._image = torch.zeros((L.hgs_image_bytes(self.W, self.H),), dtype=torch.uint8, device=self.device)
+            self.counts_clean = True
             off, nbytes = C.c_size_t(0), C.c_size_t(0)
             rt.check(L.hgs_image_zero_range(self.W, self.H, C.addressof(off), C.addressof(nbytes)))
-            self._zero = (self._image.data_ptr() + off.value, nbytes.value)
-        return self._zero
+            lay = rt.layout("image", self.W, self.H)
+            assert lay["tile_count"] == off.value and off.value < lay["tile_cursor"] < off.value + nbytes.value
+            skip = lay["tile_cursor"] - off.value
+            self._zero = ((self._image.data_ptr() + off.value, nbytes.value),
+                          (self._image.data_ptr() + off.value + skip, nbytes.value - skip))
+        return self._zero[1 if behind_counts else 0]
+
+    def fused_preprocess_possible(self):
+        return ((self.W + 15) // 16) * ((self.H + 15) // 16) <= rt.FUSED_PREPROCESS_MAX_TILES
 
     def prologue(self, view, lr=0.0, lr_dst=None, ride=False):
         """select(view, lr, lr_dst) and, in the same launch, the clearing of this table's image buffer for the coming
@@ -130,16 +143,19 @@ class ViewTable:
                 rt.check(rt.lib().hgs_iteration_prologue(rt.current_stream(), self.table.data_ptr(), int(view),
                                                          self.slot.data_ptr(), float(lr),
                                                          None if lr_dst is None else lr_dst.data_ptr(), zp, zb))
+            self.counts_clean = True
         self.current = int(view)
         self._image_ready = True
 
-    def fill_prologue(self, fu):
-        """Hand a prologue(ride=True) to the StrandFusion of the parameter forward launch (once)."""
+    def fill_prologue(self, fu, behind_counts=False):
+        """Hand a prologue(ride=True) to the StrandFusion of the parameter forward launch (once).  behind_counts: the launch
+        is hgs_hair_forward_preprocess, whose rider must leave the per-tile instance counters alone (include/hgs.h)."""
         if self._rider is None:
             return
         view, lr, lr_dst = self._rider
         self._rider = None
-        zp, zb = self._image_zero_range()
+        self._fill_behind = bool(behind_counts)
+        zp, zb = self._image_zero_range(behind_counts)
         pro = fu.prologue
         pro.table, pro.view, pro.slot, pro.lr, pro.lr_dst = self.table.data_ptr(), view, self.slot.data_ptr(), lr, lr_dst
         pro.zero_ptr, pro.zero_bytes = zp, zb
@@ -150,10 +166,22 @@ class ViewTable:
             return
         view, lr, lr_dst = self._rider
         self._rider = None
+        self._fill_behind = False
         zp, zb = self._image_zero_range()
         with torch.cuda.device(self.device):
             rt.check(rt.lib().hgs_iteration_prologue(rt.current_stream(), self.table.data_ptr(), view, self.slot.data_ptr(), lr,
                                                      lr_dst, zp, zb))
+        self.counts_clean = True
+
+    def ensure_counts_clean(self):
+        """Zero the image buffer's per-tile instance counters unless they are known to be zero (one small fill; needed in
+        front of a replayed graph whose first launch counts into them, after a blocking-mode pass used the buffer)."""
+        if self.counts_clean or self._image is None:
+            return
+        (p0, _), (p1, _) = self._image_zero_range(False), self._image_zero_range(True)
+        off = p0 - self._image.data_ptr()
+        self._image[off:off + (p1 - p0)].zero_()
+        self.counts_clean = True
 
     def take_image(self):
         """The image buffer whose counters the last prologue() cleared (once), else None."""
@@ -171,14 +199,14 @@ class ViewTable:
         order = sorted(range(n.value), key=lambda i: tags[i])
         if n.value != count or (count > 1 and [int(tags[i]) for i in order] != list(range(count))):
             raise rt.HgsError(f"graph_bind: expected {count} tagged prologue nodes, found {n.value} with tags {[tags[i] for i in order]}")
-        return (cuda_graph, [nodes[i] for i in order])
+        return (cuda_graph, [nodes[i] for i in order], self._fill_behind)
 
     def graph_set(self, binding, view, lr=0.0, lr_dst=None, k=0):
         """Re-point the k-th prologue node of a graph_bind() result (host work only; takes effect at the next replay)."""
         if not 0 <= int(view) < self.n:
             raise rt.HgsError(f"view {view} outside the table (0..{self.n - 1})")
-        graph, nodes = binding
-        zp, zb = self._image_zero_range()
+        graph, nodes, behind = binding
+        zp, zb = self._image_zero_range(behind)
         rt.check(rt.lib().hgs_graph_set_prologue(C.c_void_p(int(graph.raw_cuda_graph_exec())), C.c_void_p(nodes[k]),
                                                  self.table.data_ptr(), int(view), self.slot.data_ptr(), float(lr),
                                                  None if lr_dst is None else lr_dst.data_ptr(), zp, zb))
@@ -240,16 +268,20 @@ def head_params(H, W, opt, n_smooth, n_endpoints, min_val, has_float_mask, thres
     return p
 
 
-def _raster_head_forward(step, xyz, scale, quat, opacity, extra4, shs, endpoints, smooth_idx, smooth_partials, n_endpoints):
+def _raster_head_forward(step, xyz, scale, quat, opacity, extra4, shs, endpoints, smooth_idx, smooth_partials, n_endpoints,
+                         hair=None):
     """Single-pass rasterizer forward + loss head on the CURRENT slot view (shared by the strand and the cloud iteration)."""
     from diff_gaussian_rasterization import _C as raster
     g, vt, hp, L = step.gaussians, step.views, step.head, rt.lib()
     dev = xyz.device
     f32 = dict(dtype=torch.float32, device=dev)
     empty = step.empty
+    own_image = vt.take_image()
     R, planes, radii, geom, binning, img = raster.rasterize_gaussians_multi(
         step.bg7, xyz, empty, extra4, opacity, scale, quat, 1.0, empty, vt.viewmatrix, vt.projmatrix, vt.tanfovx,
-        vt.tanfovy, vt.H, vt.W, shs, g.active_sh_degree, vt.campos, False, False, image_buffer=vt.take_image())
+        vt.tanfovy, vt.H, vt.W, shs, g.active_sh_degree, vt.campos, False, False, image_buffer=own_image, hair=hair)
+    if own_image is not None and xyz.shape[0] > 0:
+        vt.counts_clean = raster._state["last_counts_clean"]
     hp.n_endpoints = n_endpoints
     # the blend backward reads dL/dimage only on tiles where a pixel blended an entry (the image buffer's per-tile
     # contributor count, written by the forward pass above): the SSIM backward leaves the other blocks alone
@@ -351,14 +383,25 @@ class _StrandIteration(torch.autograd.Function):
             fu.smooth_pairs, fu.n_smooth = idx.data_ptr(), int(idx.shape[0])
             fu.cos_threshold, fu.eps = hp.cos_threshold, hp.eps
             fu.smooth_partials = smooth_partials.data_ptr()
-        vt.fill_prologue(fu)
-        with torch.cuda.device(dev):
-            rt.check(L.hgs_hair_params_forward(stream, P, rt.ptr(endpoints), rt.ptr(pairs), rt.ptr(width), factor,
-                                               rt.ptr(opacity_raw), rt.ptr(mask_raw), rt.ptr(xyz), rt.ptr(scale), rt.ptr(quat),
-                                               None, rt.ptr(opacity), rt.ptr(extra4), C.byref(fu)))
         shs = f_dc if f_rest.numel() == 0 else torch.cat((f_dc, f_rest), dim=1)
+        if step.fuse_preprocess:
+            # parameters -> Gaussians -> preprocess as ONE launch where the pass runs in capacity mode (HairSource); the riders
+            # then run beside the preprocess workgroups, so the prologue must leave the tile counters alone -- which it may
+            # only if they are known to be zero (ViewTable.counts_clean); otherwise it is launched on its own, clearing them
+            def fill(fused):
+                if fused and not vt.counts_clean:
+                    vt.flush_prologue()
+                vt.fill_prologue(fu, behind_counts=fused)
+            hair = raster.HairSource(endpoints, pairs, width, factor, opacity_raw, mask_raw, fu, fill)
+        else:
+            hair = None
+            vt.fill_prologue(fu)
+            with torch.cuda.device(dev):
+                rt.check(L.hgs_hair_params_forward(stream, P, rt.ptr(endpoints), rt.ptr(pairs), rt.ptr(width), factor,
+                                                   rt.ptr(opacity_raw), rt.ptr(mask_raw), rt.ptr(xyz), rt.ptr(scale),
+                                                   rt.ptr(quat), None, rt.ptr(opacity), rt.ptr(extra4), C.byref(fu)))
         R, planes, radii, geom, binning, img, scratch, out, d_extra = _raster_head_forward(
-            step, xyz, scale, quat, opacity, extra4, shs, endpoints, idx, smooth_partials, E)
+            step, xyz, scale, quat, opacity, extra4, shs, endpoints, idx, smooth_partials, E, hair=hair)
         ctx.d_extra = d_extra
         ctx.defer_tail = bool(step.head.defer_tail)
         ctx.fused_smooth = smooth_partials is not None
@@ -433,6 +476,8 @@ class FusedStrandStep:
         self.skip_unread_blocks = bool(getattr(opt, "skip_unread_blocks", True))
         self._tile_maxc_offset = None
         self.poison_unwritten = False   # tests: dL/dimage starts as NaN
+        # strand parameters -> Gaussians -> preprocess as one launch (hgs_hair_forward_preprocess) where the pass allows it
+        self.fuse_preprocess = bool(getattr(opt, "fuse_preprocess", True)) and os.environ.get("HGS_FUSE_PREPROCESS", "1") != "0"
         # True: the loss terms (loss(), terms()) are complete only once backward() has run -- the head's last sums ride in
         # the backward's parameter launch instead of a launch of their own (GraphedStep, which always runs both, sets it)
         self.defer_tail = False

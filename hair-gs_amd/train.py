@@ -480,6 +480,8 @@ class GraphedStep:
         else:
             self.load_camera(cam)
         ga, gb = self._graphs
+        if self.fused is not None:
+            self.fused.views.ensure_counts_clean()     # (a no-op unless a blocking-mode pass used the views' image buffer)
         ga.replay()
         if gb is not None:
             # eager behind the graph: one in-place all-reduce (mean over the ranks; with several views per rank a sum,
@@ -501,6 +503,7 @@ class GraphedStep:
         for j, cam in enumerate(cams):
             self._set_lr(iteration + j)
             v.graph_set(binding, v.index[id(cam)], lr=self._lr_now, lr_dst=self._position_lr(), k=j)
+        v.ensure_counts_clean()
         gk.replay()
         return losses
 

@@ -44,7 +44,7 @@ extern "C" {
 
 /* bumped with every incompatible change of a struct, a signature or a buffer layout (round 1: 1, round 2: 2, round 3: 3);
  * the Python binding refuses a library whose version or struct sizes differ from its own */
-#define HGS_ABI_VERSION 3
+#define HGS_ABI_VERSION 4
 #define HGS_TILE 16 /* cuda_rasterizer/config.h:16-17 */
 
 int hgs_abi_version(void);
@@ -305,6 +305,25 @@ int hgs_hair_params_forward(void* stream, int P, const float* endpoints, const l
                             const float* width, float dist_to_scale_factor, const float* opacity_raw,
                             const float* mask_raw, float* xyz, float* scale, float* quat, float* dir, float* opacity,
                             float* extra4, const HgsStrandFusion* fusion);
+/* hgs_hair_forward_preprocess: hgs_hair_params_forward AND hgs_forward_preprocess of the same strand model as ONE launch
+ *   (the iteration's first: every lane derives its segment's Gaussian -- written to xyz / scale / quat / opacity / extra4 for
+ *   the backward and the render entry points, bit-identical to hgs_hair_params_forward's -- and preprocesses it from
+ *   registers; SH colours only, scale_modifier 1).  Capacity mode only (max_rendered as in hgs_forward_preprocess; no
+ *   blocking count), at most 8192 tiles.  `flags`: HGS_IMAGE_PREZEROED as in hgs_forward_preprocess.  The riders of
+ *   `fusion` (smoothness partial sums, HgsPrologue) run BESIDE the preprocess workgroups, hence two rules:
+ *     - viewmatrix / projmatrix / campos are read from fusion->prologue.table[view] when a prologue rides (the slot is being
+ *       written by that very launch; the three pointers are used only without a prologue);
+ *     - the prologue's zero range must start BEHIND the per-tile instance counters (hgs_image_layout: from
+ *       HGS_IMG_TILE_CURSOR on): those must already be zero when the launch starts, which every pass of
+ *       hgs_forward_render* in capacity mode leaves behind (its scan clears what it has read); after a pass in blocking mode,
+ *       or on a buffer of unknown content, run hgs_iteration_prologue with the full range of hgs_image_zero_range first. */
+#define HGS_FUSED_PREPROCESS_MAX_TILES 8192
+int hgs_hair_forward_preprocess(void* stream, int P, int D, int M, int W, int H, const float* endpoints,
+                                const long long* endpoint_pairs, const float* width, float dist_to_scale_factor,
+                                const float* opacity_raw, const float* mask_raw, const float* shs, float* xyz, float* scale,
+                                float* quat, float* opacity, float* extra4, const float* viewmatrix, const float* projmatrix,
+                                const float* campos, float tan_fovx, float tan_fovy, int flags, void* geom_buf,
+                                void* image_buf, int* radii, unsigned int* max_rendered, const HgsStrandFusion* fusion);
 int hgs_hair_params_backward(void* stream, int P, int E, const float* endpoints, const long long* endpoint_pairs,
                              const float* width, float dist_to_scale_factor, const float* opacity, const float* extra4,
                              const float* g_xyz, const float* g_scale, const float* g_quat, const float* g_dir,

@@ -1184,3 +1184,115 @@ def test_loss_head_skips_all_zero_blocks_exactly(hw):
     lists2 = scratch.view(torch.int32)[scratch.numel() - (2 * nbs + 16):].cpu()
     read_blocks = int(bu.sum()) * 3
     assert int(lists2[0]) + int(lists2[1]) == read_blocks and int(lists2[0]) <= n_work
+
+
+def test_one_launch_parameters_and_preprocess_equals_two_launches():
+    """hgs_hair_forward_preprocess (strand parameters -> Gaussians -> preprocess in ONE kernel, the riders beside it) against
+    hgs_hair_params_forward + hgs_forward_preprocess: derived Gaussians, radii, the geometry buffer, the image and every
+    gradient bit for bit (the smoothness partial sums ride in a kernel of another translation unit: that term to 1e-6)."""
+    from arguments import OptimizationParams
+    from diff_gaussian_rasterization import _C as raster
+    from hgs_runtime.strand_step import FusedStrandStep, ViewTable
+    from synthetic import build_workload
+    model, cams, _ = build_workload("tiny", device="cuda", with_targets=True)
+    opt = OptimizationParams()
+    model.training_setup(opt)
+    params = [model._endpoints, model._width, model._opacity, model._mask, model._features_dc]
+    runs = {}
+    try:
+        raster.set_async(True, slack=2.0)
+        for fuse in (False, True):
+            views = ViewTable(cams)
+            step = FusedStrandStep(model, views, opt, torch.zeros(3, device="cuda"))
+            step.fuse_preprocess = fuse
+            seen = []
+            for it, v in enumerate([0, 2, 1, 3, 2]):
+                for p in params:
+                    p.grad = None
+                views.prologue(v, ride=True)
+                fused_now = fuse and raster.will_fuse_hair(views.W, views.H)
+                loss, terms = step.loss()
+                step.backward(loss)
+                raster.check_async()
+                seen.append((fused_now, views.counts_clean, float(loss.detach()), terms.clone(), step.last["planes"].clone(),
+                             step.last["radii"].clone(), [p.grad.clone() for p in params]))
+            runs[fuse] = seen
+    finally:
+        raster.set_async(False)
+    assert all(s[0] for s in runs[True][1:]) and not any(s[0] for s in runs[False])   # (a first pass may be the blocking one that learns the capacity)
+    assert all(s[1] for s in runs[True][1:])            # capacity-mode passes leave the tile counters at zero
+    for a, b in zip(runs[False], runs[True]):
+        assert torch.equal(a[4], b[4]) and torch.equal(a[5], b[5])
+        assert abs(a[2] - b[2]) <= 1e-6 * abs(a[2])
+        for ga, gb in zip(a[6], b[6]):
+            assert torch.equal(ga, gb) or float((ga - gb).abs().max()) <= 1e-6 * float(ga.abs().max())
+        assert bool(a[6][0].abs().sum() > 0)
+    # without the smoothness term nothing is left that could differ
+    opt2 = OptimizationParams()
+    opt2.lambda_smooth = 0.0
+    out = {}
+    try:
+        raster.set_async(True, slack=2.0)
+        for fuse in (False, True):
+            views = ViewTable(cams)
+            step = FusedStrandStep(model, views, opt2, torch.zeros(3, device="cuda"))
+            step.fuse_preprocess = fuse
+            for v in (1, 3):
+                for p in params:
+                    p.grad = None
+                views.prologue(v, ride=True)
+                loss, terms = step.loss()
+                step.backward(loss)
+            raster.check_async()
+            out[fuse] = [loss.detach().clone(), terms[:14].clone()] + [p.grad.clone() for p in params]
+    finally:
+        raster.set_async(False)
+    for a, b in zip(out[False], out[True]):
+        assert torch.equal(a, b)
+
+
+def test_replays_after_a_blocking_pass_on_the_same_views():
+    """The captured step's first launch counts into the image buffer's tile counters beside the workgroups that clear the other
+    counters, so it needs them at zero -- which capacity-mode passes leave behind and a blocking-mode pass does not.  A blocking
+    pass over the same ViewTable between two replays is noticed (ViewTable.counts_clean) and repaired: same parameters as
+    without it, bit for bit."""
+    from arguments import OptimizationParams
+    from diff_gaussian_rasterization import _C as raster
+    from hgs_runtime.strand_step import ViewTable, fused_step_for
+    from synthetic import build_workload
+    from train import GraphedStep
+    from utils.general import safe_state
+    res = {}
+    try:
+        for disturb in (False, True):
+            safe_state(True)
+            model, cams, extent = build_workload("tiny", device="cuda", with_targets=True)
+            opt = OptimizationParams()
+            opt.enable_topology = False
+            model.training_setup(opt)
+            bg = torch.zeros(3, device="cuda")
+            views = ViewTable(cams)
+            gs = GraphedStep(model, cams, opt, bg, extent=extent, views=views)
+            gs.capture(cams)
+            assert views.counts_clean and gs._binding[2]            # the rider variant was captured
+            for it, ci in enumerate([1, 3, 0], 1):
+                gs.step(cams[ci], it)
+            if disturb:
+                torch.cuda.synchronize()
+                raster._state["async"] = False                      # a blocking pass through the same table and image buffer
+                probe = fused_step_for(model, views, opt, bg)
+                views.prologue(2, ride=True)
+                with torch.no_grad():
+                    probe.loss()
+                raster._state["async"] = True
+                assert not views.counts_clean
+            for it, ci in enumerate([2, 1, 0], 4):
+                gs.step(cams[ci], it)
+            gs.check()
+            assert views.counts_clean
+            res[disturb] = [g["params"][0].detach().clone() for g in model.optimizer.param_groups]
+            raster.set_async(False)
+    finally:
+        raster.set_async(False)
+    for a, b in zip(res[False], res[True]):
+        assert torch.equal(a, b)
