@@ -10,7 +10,7 @@ bash tools/pmc_raster.sh c3 > gpurun_out/r03_pmc_raster_c3.txt 2>&1
 cp gpurun_out/pmc_summary.json gpurun_out/r03_pmc_raster_c3.json
 rm -rf gpurun_out/pmc_*/
 bash tools/pmc_generic.sh pmcit tools/eager_steps.py north_star 12
-python3 tools/pmc_table.py pmcit strand_fwd_kernel preprocess_fwd_kernel scatter_kernel sort_tiles_kernel blend_fwd_kernel ssim_l1_fwd_kernel pix_fwd_kernel ssim_l1_bwd_kernel blend_bwd_kernel preprocess_bwd_kernel strand_bwd_kernel adam_kernel > gpurun_out/r03_pmc_iteration_north_star.txt 2>&1
+python3 tools/pmc_table.py pmcit hair_preprocess_fwd_kernel scatter_kernel sort_tiles_kernel blend_fwd_kernel ssim_l1_fwd_kernel pix_fwd_kernel ssim_l1_bwd_kernel blend_bwd_kernel preprocess_bwd_kernel strand_bwd_kernel adam_kernel > gpurun_out/r03_pmc_iteration_north_star.txt 2>&1
 rm -rf gpurun_out/pmcit_*/
 python3 tools/convergence.py north_star 8 > gpurun_out/r03_convergence.json 2> gpurun_out/r03_convergence.err
 python3 bench.py --trained-iters 1000 > gpurun_out/r03_bench_trained.json 2> gpurun_out/r03_bench_trained.err
