@@ -146,6 +146,7 @@ static_assert(HGS_FUSED_PREPROCESS_MAX_TILES == HGS_FUSED_SCAN_MAX_T, "include/h
 struct HairSrc {
   const float* endpoints; const long long* pairs; const float* width; float f; const float* opacity_raw; const float* mask_raw;
   float* xyz; float* scale; float* quat; float* opacity; float* extra4; const HgsStrandFusion* fusion;
+  const float* scaling_raw; const float* rotation_raw;    // != NULL: a Stage-I cloud (hgs_cloud_forward_preprocess)
 };
 static int forward_preprocess_impl(void* stream, int P, int D, int M, int W, int H, const float* means3D, const float* shs,
                                    const float* colors_precomp, const float* opacities, const float* scales,
@@ -178,10 +179,29 @@ int hgs_hair_forward_preprocess(void* stream, int P, int D, int M, int W, int H,
   }
   if (!max_rendered) { hgs_set_error("hgs_hair_forward_preprocess: capacity mode only (max_rendered must be given)"); return 1; }
   const HairSrc hair = {endpoints, endpoint_pairs, width, dist_to_scale_factor, opacity_raw, mask_raw, xyz, scale, quat, opacity,
-                        extra4, fusion};
+                        extra4, fusion, nullptr, nullptr};
   return forward_preprocess_impl(stream, P, D, M, W, H, xyz, shs, nullptr, opacity, scale, 1.f, quat, nullptr, viewmatrix,
                                  projmatrix, campos, tan_fovx, tan_fovy, flags, geom_buf, image_buf, radii, nullptr,
                                  max_rendered, &hair);
+}
+
+int hgs_cloud_forward_preprocess(void* stream, int P, int D, int M, int W, int H, const float* means3D, const float* scaling_raw,
+                                 const float* rotation_raw, const float* opacity_raw, const float* mask_raw, const float* shs,
+                                 float* scale, float* quat, float* opacity, float* extra4, const float* viewmatrix,
+                                 const float* projmatrix, const float* campos, float tan_fovx, float tan_fovy, int flags,
+                                 void* geom_buf, void* image_buf, int* radii, unsigned int* max_rendered,
+                                 const HgsStrandFusion* fusion) {
+  if (P > 0 && (!means3D || !scaling_raw || !rotation_raw || !opacity_raw || !mask_raw || !scale || !quat || !opacity || !extra4 ||
+                ((size_t)rotation_raw & 15) || ((size_t)quat & 15) || ((size_t)extra4 & 15))) {
+    hgs_set_error("hgs_cloud_forward_preprocess: null (or, rotation_raw / quat / extra4, not 16-byte aligned) argument");
+    return 1;
+  }
+  if (!max_rendered) { hgs_set_error("hgs_cloud_forward_preprocess: capacity mode only (max_rendered must be given)"); return 1; }
+  const HairSrc cloud = {nullptr, nullptr, nullptr, 0.f, opacity_raw, mask_raw, nullptr, scale, quat, opacity, extra4, fusion,
+                         scaling_raw, rotation_raw};
+  return forward_preprocess_impl(stream, P, D, M, W, H, means3D, shs, nullptr, opacity, scale, 1.f, quat, nullptr, viewmatrix,
+                                 projmatrix, campos, tan_fovx, tan_fovy, flags, geom_buf, image_buf, radii, nullptr,
+                                 max_rendered, &cloud);
 }
 
 static int forward_preprocess_impl(void* stream, int P, int D, int M, int W, int H, const float* means3D, const float* shs,
@@ -204,7 +224,7 @@ static int forward_preprocess_impl(void* stream, int P, int D, int M, int W, int
   const HgsPrologue* rider = (hair && hair->fusion && hair->fusion->prologue.table) ? &hair->fusion->prologue : nullptr;
   if (rider && (!rider->slot || rider->view < 0 || ((size_t)rider->zero_ptr & 3) || (rider->zero_bytes & 3) ||
                 (rider->zero_bytes && !rider->zero_ptr))) {
-    hgs_set_error("hgs_hair_forward_preprocess: bad prologue group");
+    hgs_set_error("hgs_hair/cloud_forward_preprocess: bad prologue group");
     return 1;
   }
   if (hair && T > HGS_FUSED_SCAN_MAX_T) {
@@ -246,8 +266,12 @@ static int forward_preprocess_impl(void* stream, int P, int D, int M, int W, int
     if (!fused_scan) { hgs_set_error("hgs_hair_forward_preprocess: the scan must be the scatter kernel's (sizes beyond its limits)"); return 1; }
     HgsStrandFusion fu = hair->fusion ? *hair->fusion : HgsStrandFusion{};
     if (!(fu.smooth_pairs && fu.n_smooth > 0 && fu.smooth_partials)) fu.n_smooth = 0;
-    if (hgs_launch_hair_preprocess_fwd(s, a, g, im, radii, hair->endpoints, hair->pairs, hair->width, hair->f, hair->opacity_raw,
-                                       hair->mask_raw, hair->xyz, hair->scale, hair->quat, hair->opacity, hair->extra4, fu)) return 1;
+    if (hair->scaling_raw) {
+      if (hgs_launch_cloud_preprocess_fwd(s, a, g, im, radii, hair->scaling_raw, hair->rotation_raw, hair->opacity_raw,
+                                          hair->mask_raw, hair->scale, hair->quat, hair->opacity, hair->extra4, fu.prologue)) return 1;
+    } else if (hgs_launch_hair_preprocess_fwd(s, a, g, im, radii, hair->endpoints, hair->pairs, hair->width, hair->f,
+                                              hair->opacity_raw, hair->mask_raw, hair->xyz, hair->scale, hair->quat,
+                                              hair->opacity, hair->extra4, fu)) return 1;
   } else if (hgs_launch_preprocess_fwd(s, a, g, im, radii)) return 1;
   if (!fused_scan && hgs_launch_scan(s, P, T, g, im, max_rendered)) return 1;
   if (num_rendered_host) {

@@ -270,6 +270,10 @@ int hgs_launch_hair_preprocess_fwd(hipStream_t s, const HgsFwdArgs& a, const Hgs
                                    const float* endpoints, const long long* pairs, const float* width, float f,
                                    const float* opacity_raw, const float* mask_raw, float* xyz, float* scale, float* quat,
                                    float* opacity, float* extra4, const HgsStrandFusion& fusion);
+int hgs_launch_cloud_preprocess_fwd(hipStream_t s, const HgsFwdArgs& a, const HgsGeom& g, const HgsImage& im, int* radii,
+                                    const float* scaling_raw, const float* rotation_raw, const float* opacity_raw,
+                                    const float* mask_raw, float* scale, float* quat, float* opacity, float* extra4,
+                                    const HgsPrologue& pro);
 int hgs_launch_scan(hipStream_t s, int P, int T, const HgsGeom& g, const HgsImage& im, unsigned int* max_rendered);
 int hgs_launch_scatter(hipStream_t s, int P, int W, int H, int Rcap, const float* features, const float* extra, int n_extra,
                        const HgsGeom& g, const HgsImage& im, const HgsBinning& b);

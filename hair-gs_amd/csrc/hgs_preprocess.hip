@@ -139,18 +139,24 @@ __device__ __forceinline__ int th_find(const TileHash& h, uint32_t t) {  // slot
 }
 
 // ------------------------------------------------------------------------------------------------
-// The strand model's parameters, for the kernel that derives a segment's Gaussian itself (hgs_hair_forward_preprocess): inputs
-// and the arrays the derived Gaussians are written to (the backward and the scatter kernel read them).
-struct HgsStrandSrc {
-  const float* ep; const long long* pairs; const float* width; float f; const float* opacity_raw; const float* mask_raw;
-  float* xyz; float* scale; float* quat; float* opacity; float* extra4;
+// The model's raw parameters, for the kernels that derive a lane's Gaussian themselves (hgs_hair_forward_preprocess /
+// hgs_cloud_forward_preprocess): inputs, and the arrays the derived Gaussians are written to (the backward and the scatter
+// kernel read them).
+struct HgsParamSrc {
+  const float* ep; const long long* pairs; const float* width; float f;        // strands
+  const float* scaling_raw; const float* rotation_raw;                         // cloud (its means are a.means3D)
+  const float* opacity_raw; const float* mask_raw;
+  float* xyz; float* scale; float* quat; float* opacity; float* extra4;        // (xyz: strands only)
 };
+enum { SRC_GIVEN = 0, SRC_STRAND = 1, SRC_CLOUD = 2 };
 
-// STRAND: lane idx derives its Gaussian from the strand parameters (same device function as strand_fwd_kernel: same bits),
-// stores it, and goes on with the values in registers; a.means3D / scales / rotations / opacities are not read.
-template <bool STRAND>
+// SRC != SRC_GIVEN: lane idx derives its Gaussian from the raw parameters (the device functions of strand_fwd_kernel /
+// cloud_fwd_kernel: the same bits), stores it, and goes on with the values in registers; a.scales / rotations / opacities
+// (and, for strands, a.means3D) are not read.
+template <int SRC>
 __device__ __forceinline__ void preprocess_fwd_body(const HgsFwdArgs& a, const HgsGeom& g, const HgsImage& im, int* radii,
-                                                    const HgsStrandSrc& st, uint32_t* red, TileHash& th) {
+                                                    const HgsParamSrc& st, uint32_t* red, TileHash& th) {
+  constexpr bool STRAND = SRC == SRC_STRAND, DERIVED = SRC != SRC_GIVEN;
   th_init(th);
   __syncthreads();
   const int idx = blockIdx.x * HGS_BLOCK + threadIdx.x;
@@ -160,17 +166,28 @@ __device__ __forceinline__ void preprocess_fwd_body(const HgsFwdArgs& a, const H
     int my_radius_i = 0;
     HgsRect rc = {0, 0, 0, 0, 0, 0};
     HgsStrandGaussian sgn = {};
-    float opacity_v = 0.f;
-    if (STRAND) {
+    float opacity_v = 0.f, sc0 = 0.f, sc1 = 0.f, sc2 = 0.f;
+    float4 qd = make_float4(1.f, 0.f, 0.f, 0.f);
+    if (SRC == SRC_STRAND) {
       const long long i0 = st.pairs[2 * (size_t)idx], i1 = st.pairs[2 * (size_t)idx + 1];
       sgn = hgs_strand_gaussian(st.ep[3 * i0], st.ep[3 * i0 + 1], st.ep[3 * i0 + 2], st.ep[3 * i1], st.ep[3 * i1 + 1],
                                 st.ep[3 * i1 + 2], st.width[idx], st.f);
       opacity_v = hgs_sigmoid(st.opacity_raw[idx]);
+      sc0 = sgn.s0; sc1 = sgn.sw; sc2 = sgn.sw;
+      qd = make_float4(sgn.q0, sgn.q1, sgn.q2, sgn.q3);
       st.xyz[3 * (size_t)idx] = sgn.mx; st.xyz[3 * (size_t)idx + 1] = sgn.my; st.xyz[3 * (size_t)idx + 2] = sgn.mz;
-      st.scale[3 * (size_t)idx] = sgn.s0; st.scale[3 * (size_t)idx + 1] = sgn.sw; st.scale[3 * (size_t)idx + 2] = sgn.sw;
-      ((float4*)st.quat)[idx] = make_float4(sgn.q0, sgn.q1, sgn.q2, sgn.q3);
-      st.opacity[idx] = opacity_v;
       ((float4*)st.extra4)[idx] = make_float4(hgs_sigmoid(st.mask_raw[idx]), sgn.ux, sgn.uy, sgn.uz);
+    } else if (SRC == SRC_CLOUD) {
+      const HgsCloudGaussian c = hgs_cloud_gaussian(st.scaling_raw[3 * (size_t)idx], st.scaling_raw[3 * (size_t)idx + 1],
+                                                    st.scaling_raw[3 * (size_t)idx + 2], ((const float4*)st.rotation_raw)[idx],
+                                                    st.opacity_raw[idx], st.mask_raw[idx]);
+      opacity_v = c.opacity; sc0 = c.s0; sc1 = c.s1; sc2 = c.s2; qd = c.q;
+      ((float4*)st.extra4)[idx] = c.extra;
+    }
+    if (DERIVED) {
+      st.scale[3 * (size_t)idx] = sc0; st.scale[3 * (size_t)idx + 1] = sc1; st.scale[3 * (size_t)idx + 2] = sc2;
+      ((float4*)st.quat)[idx] = qd;
+      st.opacity[idx] = opacity_v;
     }
     do {
       const V3 p = STRAND ? V3{sgn.mx, sgn.my, sgn.mz} : V3{a.means3D[3 * idx], a.means3D[3 * idx + 1], a.means3D[3 * idx + 2]};
@@ -190,9 +207,9 @@ __device__ __forceinline__ void preprocess_fwd_body(const HgsFwdArgs& a, const H
         for (int k = 0; k < 6; k++) cov3[k] = a.cov3D_precomp[6 * (size_t)idx + k];
       } else {
         const float mod = a.scale_modifier;
-        const float s0 = mod * (STRAND ? sgn.s0 : a.scales[3 * idx]), s1 = mod * (STRAND ? sgn.sw : a.scales[3 * idx + 1]),
-                    s2 = mod * (STRAND ? sgn.sw : a.scales[3 * idx + 2]);
-        const float4 q = STRAND ? make_float4(sgn.q0, sgn.q1, sgn.q2, sgn.q3) : ((const float4*)a.rotations)[idx];
+        const float s0 = mod * (DERIVED ? sc0 : a.scales[3 * idx]), s1 = mod * (DERIVED ? sc1 : a.scales[3 * idx + 1]),
+                    s2 = mod * (DERIVED ? sc2 : a.scales[3 * idx + 2]);
+        const float4 q = DERIVED ? qd : ((const float4*)a.rotations)[idx];
         const M3 R = quat_R(q.x, q.y, q.z, q.w);
         M3 Mm;  // M = S * R  (S diagonal: M[c][r] = s_r * R[c][r]; the zero terms of the full product add exact zeros)
 #pragma unroll
@@ -209,7 +226,7 @@ __device__ __forceinline__ void preprocess_fwd_body(const HgsFwdArgs& a, const H
       const float det = c2.a * c2.c - c2.b * c2.b;
       if (det == 0.0f) break;
       const float det_inv = 1.f / det;
-      const float4 conic_o = {c2.c * det_inv, -c2.b * det_inv, c2.a * det_inv, STRAND ? opacity_v : a.opacities[idx]};
+      const float4 conic_o = {c2.c * det_inv, -c2.b * det_inv, c2.a * det_inv, DERIVED ? opacity_v : a.opacities[idx]};
       const float mid = 0.5f * (c2.a + c2.c);
       const float lambda1 = mid + sqrtf(fmaxf(0.1f, mid * mid - det));
       const float lambda2 = mid - sqrtf(fmaxf(0.1f, mid * mid - det));
@@ -310,7 +327,7 @@ __device__ __forceinline__ void preprocess_fwd_body(const HgsFwdArgs& a, const H
 __global__ __launch_bounds__(HGS_BLOCK) void preprocess_fwd_kernel(HgsFwdArgs a, HgsGeom g, HgsImage im, int* radii) {
   __shared__ uint32_t red[4];
   __shared__ TileHash th;
-  preprocess_fwd_body<false>(a, g, im, radii, HgsStrandSrc{}, red, th);
+  preprocess_fwd_body<SRC_GIVEN>(a, g, im, radii, HgsParamSrc{}, red, th);
 }
 
 // The iteration's FIRST launch for a strand model (hgs_hair_forward_preprocess): strand parameters -> Gaussians -> preprocess in
@@ -322,7 +339,7 @@ __global__ __launch_bounds__(HGS_BLOCK) void preprocess_fwd_kernel(HgsFwdArgs a,
 //     them: they are left at zero by the scatter kernel's scan workgroups, which clear what they have read), and the two status
 //     words workgroup 0 writes are stepped over.
 __global__ __launch_bounds__(HGS_BLOCK) void hair_preprocess_fwd_kernel(HgsFwdArgs a, HgsGeom g, HgsImage im, int* radii,
-                                                                        HgsStrandSrc st, HgsStrandFusion fu, HgsPrologue pro) {
+                                                                        HgsParamSrc st, HgsStrandFusion fu, HgsPrologue pro) {
   __shared__ uint32_t red[4];
   __shared__ TileHash th;
   const unsigned npro = pro.table ? hgs_prologue_blocks(pro.zero_bytes / 4) : 0u;
@@ -340,7 +357,24 @@ __global__ __launch_bounds__(HGS_BLOCK) void hair_preprocess_fwd_kernel(HgsFwdAr
     const HgsViewTargets* row = pro.table + pro.view;
     a.viewmatrix = row->viewmatrix; a.projmatrix = row->projmatrix; a.campos = row->campos;
   }
-  preprocess_fwd_body<true>(a, g, im, radii, st, red, th);
+  preprocess_fwd_body<SRC_STRAND>(a, g, im, radii, st, red, th);
+}
+
+// The same for the Stage-I cloud (hgs_cloud_forward_preprocess: cloud_fwd_kernel + preprocess_fwd_kernel; no smoothness term)
+__global__ __launch_bounds__(HGS_BLOCK) void cloud_preprocess_fwd_kernel(HgsFwdArgs a, HgsGeom g, HgsImage im, int* radii,
+                                                                         HgsParamSrc st, HgsPrologue pro) {
+  __shared__ uint32_t red[4];
+  __shared__ TileHash th;
+  const unsigned npro = pro.table ? hgs_prologue_blocks(pro.zero_bytes / 4) : 0u;
+  if (blockIdx.x >= gridDim.x - npro) {
+    hgs_prologue_block(pro, blockIdx.x - (gridDim.x - npro), npro, im.status + HGS_ST_SCANPTR_LO);
+    return;
+  }
+  if (pro.table) {
+    const HgsViewTargets* row = pro.table + pro.view;
+    a.viewmatrix = row->viewmatrix; a.projmatrix = row->projmatrix; a.campos = row->campos;
+  }
+  preprocess_fwd_body<SRC_CLOUD>(a, g, im, radii, st, red, th);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -820,6 +854,7 @@ int hgs_launch_preprocess_fwd(hipStream_t s, const HgsFwdArgs& a, const HgsGeom&
 }
 bool hgs_preprocess_prologue_kernel(const void* func, int* n_params) {
   if (func == (const void*)hair_preprocess_fwd_kernel) { *n_params = 7; return true; }
+  if (func == (const void*)cloud_preprocess_fwd_kernel) { *n_params = 6; return true; }
   return false;
 }
 int hgs_launch_hair_preprocess_fwd(hipStream_t s, const HgsFwdArgs& a, const HgsGeom& g, const HgsImage& im, int* radii,
@@ -829,12 +864,26 @@ int hgs_launch_hair_preprocess_fwd(hipStream_t s, const HgsFwdArgs& a, const Hgs
   HgsStrandFusion fu = fusion;
   const HgsPrologue pro = fu.prologue;
   fu.prologue = HgsPrologue{};      // (handed over as the kernel's last argument)
-  const HgsStrandSrc st = {endpoints, pairs, width, f, opacity_raw, mask_raw, xyz, scale, quat, opacity, extra4};
+  const HgsParamSrc st = {endpoints, pairs, width, f, nullptr, nullptr, opacity_raw, mask_raw, xyz, scale, quat, opacity, extra4};
   const unsigned nblk = (unsigned)((a.P + HGS_BLOCK - 1) / HGS_BLOCK) + (unsigned)((fu.n_smooth + 255) / 256) +
                         (pro.table ? hgs_prologue_blocks(pro.zero_bytes / 4) : 0u);
   {
     HgsProfScope _prof(s, HGS_K_PREPROCESS_FWD);
     hipLaunchKernelGGL(hair_preprocess_fwd_kernel, dim3(nblk), dim3(HGS_BLOCK), 0, s, a, g, im, radii, st, fu, pro);
+  }
+  HGS_CHECK_LAUNCH();
+  return 0;
+}
+int hgs_launch_cloud_preprocess_fwd(hipStream_t s, const HgsFwdArgs& a, const HgsGeom& g, const HgsImage& im, int* radii,
+                                    const float* scaling_raw, const float* rotation_raw, const float* opacity_raw,
+                                    const float* mask_raw, float* scale, float* quat, float* opacity, float* extra4,
+                                    const HgsPrologue& pro) {
+  const HgsParamSrc st = {nullptr, nullptr, nullptr, 0.f, scaling_raw, rotation_raw, opacity_raw, mask_raw, nullptr, scale, quat,
+                          opacity, extra4};
+  const unsigned nblk = (unsigned)((a.P + HGS_BLOCK - 1) / HGS_BLOCK) + (pro.table ? hgs_prologue_blocks(pro.zero_bytes / 4) : 0u);
+  {
+    HgsProfScope _prof(s, HGS_K_PREPROCESS_FWD);
+    hipLaunchKernelGGL(cloud_preprocess_fwd_kernel, dim3(nblk), dim3(HGS_BLOCK), 0, s, a, g, im, radii, st, pro);
   }
   HGS_CHECK_LAUNCH();
   return 0;

@@ -41,3 +41,29 @@ __device__ __forceinline__ HgsStrandGaussian hgs_strand_gaussian(float ax, float
 }
 
 __device__ __forceinline__ float hgs_sigmoid(float x) { return 1.f / (1.f + expf(-x)); }   // gaussian_model.py:93-99
+
+// ---- Stage-I cloud: raw parameters -> rasterizer inputs (scene/gaussian_model.py:118-157); shared by cloud_fwd_kernel and the
+// fused parameters + preprocess kernel, evaluated operation by operation in both (see above) ------------------------------
+__device__ __forceinline__ int hgs_argmax3(float a, float b, float c) { return (b > a) ? ((c > b) ? 2 : 1) : ((c > a) ? 2 : 0); }
+// column `ax` of the rotation matrix of the UNIT quaternion (w, x, y, z)
+__device__ __forceinline__ void hgs_rot_column(int ax, float w, float x, float y, float z, float& d0, float& d1, float& d2) {
+#pragma clang fp contract(off)
+  if (ax == 0)      { d0 = 1.f - 2.f * (y * y + z * z); d1 = 2.f * (x * y + w * z);       d2 = 2.f * (x * z - w * y); }
+  else if (ax == 1) { d0 = 2.f * (x * y - w * z);       d1 = 1.f - 2.f * (x * x + z * z); d2 = 2.f * (y * z + w * x); }
+  else              { d0 = 2.f * (x * z + w * y);       d1 = 2.f * (y * z - w * x);       d2 = 1.f - 2.f * (x * x + y * y); }
+}
+struct HgsCloudGaussian { float s0, s1, s2; float4 q; float opacity; float4 extra; };
+__device__ __forceinline__ HgsCloudGaussian hgs_cloud_gaussian(float sr0, float sr1, float sr2, float4 r, float o_raw, float m_raw) {
+#pragma clang fp contract(off)
+  HgsCloudGaussian o;
+  o.s0 = expf(sr0); o.s1 = expf(sr1); o.s2 = expf(sr2);
+  const float n = sqrtf(r.x * r.x + r.y * r.y + r.z * r.z + r.w * r.w);
+  const float inq = 1.f / fmaxf(n, 1e-12f);                              // F.normalize (get_rotation)
+  o.q = make_float4(r.x * inq, r.y * inq, r.z * inq, r.w * inq);
+  const float ib = 1.f / n;                                              // build_rotation normalises without the clamp
+  float d0, d1, d2;
+  hgs_rot_column(hgs_argmax3(o.s0, o.s1, o.s2), r.x * ib, r.y * ib, r.z * ib, r.w * ib, d0, d1, d2);
+  o.opacity = hgs_sigmoid(o_raw);
+  o.extra = make_float4(hgs_sigmoid(m_raw), d0, d1, d2);
+  return o;
+}

@@ -63,14 +63,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HGS_SBW_WAV
 }
 
 // ---- Stage-I cloud: raw parameters -> rasterizer inputs (scene/gaussian_model.py:118-157) -------------------------------
-__device__ __forceinline__ int argmax3(float a, float b, float c) { return (b > a) ? ((c > b) ? 2 : 1) : ((c > a) ? 2 : 0); }
-// column `ax` of the rotation matrix of the UNIT quaternion (w, x, y, z)
-__device__ __forceinline__ void rot_column(int ax, float w, float x, float y, float z, float& d0, float& d1, float& d2) {
-  if (ax == 0)      { d0 = 1.f - 2.f * (y * y + z * z); d1 = 2.f * (x * y + w * z);       d2 = 2.f * (x * z - w * y); }
-  else if (ax == 1) { d0 = 2.f * (x * y - w * z);       d1 = 1.f - 2.f * (x * x + z * z); d2 = 2.f * (y * z + w * x); }
-  else              { d0 = 2.f * (x * z + w * y);       d1 = 2.f * (y * z - w * x);       d2 = 1.f - 2.f * (x * x + y * y); }
-}
-
 __global__ __launch_bounds__(256) void cloud_fwd_kernel(int P, const float* __restrict__ s_raw, const float* __restrict__ r_raw,
                                                         const float* __restrict__ o_raw, const float* __restrict__ m_raw,
                                                         float* __restrict__ scale, float* __restrict__ quat,
@@ -79,17 +71,12 @@ __global__ __launch_bounds__(256) void cloud_fwd_kernel(int P, const float* __re
   if (blockIdx.x >= gridDim.x - npro) { hgs_prologue_block(pro, blockIdx.x - (gridDim.x - npro), npro); return; }
   const int k = blockIdx.x * 256 + threadIdx.x;
   if (k >= P) return;
-  const float s0 = expf(s_raw[3 * (size_t)k]), s1 = expf(s_raw[3 * (size_t)k + 1]), s2 = expf(s_raw[3 * (size_t)k + 2]);
-  scale[3 * (size_t)k] = s0; scale[3 * (size_t)k + 1] = s1; scale[3 * (size_t)k + 2] = s2;
-  const float4 r = ((const float4*)r_raw)[k];
-  const float n = sqrtf(r.x * r.x + r.y * r.y + r.z * r.z + r.w * r.w);
-  const float inq = 1.f / fmaxf(n, 1e-12f);                              // F.normalize (get_rotation)
-  ((float4*)quat)[k] = make_float4(r.x * inq, r.y * inq, r.z * inq, r.w * inq);
-  const float ib = 1.f / n;                                              // build_rotation normalises without the clamp
-  float d0, d1, d2;
-  rot_column(argmax3(s0, s1, s2), r.x * ib, r.y * ib, r.z * ib, r.w * ib, d0, d1, d2);
-  opacity[k] = 1.f / (1.f + expf(-o_raw[k]));
-  ((float4*)extra4)[k] = make_float4(1.f / (1.f + expf(-m_raw[k])), d0, d1, d2);
+  const HgsCloudGaussian c = hgs_cloud_gaussian(s_raw[3 * (size_t)k], s_raw[3 * (size_t)k + 1], s_raw[3 * (size_t)k + 2],
+                                                ((const float4*)r_raw)[k], o_raw[k], m_raw[k]);
+  scale[3 * (size_t)k] = c.s0; scale[3 * (size_t)k + 1] = c.s1; scale[3 * (size_t)k + 2] = c.s2;
+  ((float4*)quat)[k] = c.q;
+  opacity[k] = c.opacity;
+  ((float4*)extra4)[k] = c.extra;
 }
 
 __global__ __launch_bounds__(256) void cloud_bwd_kernel(int P, const float* __restrict__ s_raw, const float* __restrict__ r_raw,
@@ -125,7 +112,7 @@ __global__ __launch_bounds__(256) void cloud_bwd_kernel(int P, const float* __re
   const float4 gq = ((const float4*)g_quat)[k];
   float qw = gq.x, qx = gq.y, qy = gq.z, qz = gq.w;
   if (!(n > 1e-12f)) { qw = 0.f; qx = 0.f; qy = 0.f; qz = 0.f; }           // clamped branch of F.normalize: q = r / 1e-12
-  const int ax = argmax3(s0, s1, s2);
+  const int ax = hgs_argmax3(s0, s1, s2);
   const float a = ge.y, b = ge.z, c = ge.w;                                // dL/d(direction)
   if (ax == 0) {        // (1-2(y^2+z^2), 2(xy+wz), 2(xz-wy))
     qw += 2.f * (b * z - c * y); qx += 2.f * (b * y + c * z); qy += 2.f * (-2.f * a * y + b * x - c * w); qz += 2.f * (-2.f * a * z + b * w + c * x);

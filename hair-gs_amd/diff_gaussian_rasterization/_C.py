@@ -119,8 +119,21 @@ class HairSource:
     the ordinary preprocess launch.  `fusion`: hgs_runtime.StrandFusion (or None); `fill(fused)` is called once the form is
     known and must put the iteration prologue (if one rides) into `fusion` with the matching zero range."""
 
+    kind = "hair"
+
     def __init__(self, endpoints, pairs, width, factor, opacity_raw, mask_raw, fusion=None, fill=None):
         self.endpoints, self.pairs, self.width, self.factor = endpoints, pairs, width, float(factor)
+        self.opacity_raw, self.mask_raw, self.fusion, self.fill = opacity_raw, mask_raw, fusion, fill
+
+
+class CloudSource:
+    """The Stage-I counterpart of HairSource: the raw scaling / rotation / opacity / mask parameters behind scales / rotations /
+    opacity / extra4 of a pass (means3D is the model's own parameter): hgs_cloud_forward_preprocess in capacity mode,
+    hgs_cloud_params_forward in front of the ordinary preprocess launch otherwise."""
+    kind = "cloud"
+
+    def __init__(self, scaling_raw, rotation_raw, opacity_raw, mask_raw, fusion=None, fill=None):
+        self.scaling_raw, self.rotation_raw = scaling_raw, rotation_raw
         self.opacity_raw, self.mask_raw, self.fusion, self.fill = opacity_raw, mask_raw, fusion, fill
 
 
@@ -182,22 +195,35 @@ def _forward(background, means3D, colors, opacity, scales, rotations, scale_modi
                 raise RuntimeError("a HairSource pass renders SH colours at scale_modifier 1")
             if hair.fill is not None:
                 hair.fill(fused_hair)
-            ep_, pairs_, w_ = _f32(hair.endpoints, "endpoints"), rt.require_gpu_tensor(hair.pairs, "endpoint_pairs", torch.int64), _f32(hair.width, "width")
             o_raw, m_raw = _f32(hair.opacity_raw, "opacity_raw"), _f32(hair.mask_raw, "mask_raw")
             fu_ = None if hair.fusion is None else C.byref(hair.fusion)
             ex_out = extra_ if extra_ is not None else torch.empty((P, 4), dtype=torch.float32, device=dev)
-            if not fused_hair:
-                rt.check(L.hgs_hair_params_forward(stream, P, rt.ptr(ep_), rt.ptr(pairs_), rt.ptr(w_), hair.factor, rt.ptr(o_raw),
-                                                   rt.ptr(m_raw), rt.ptr(means3D), rt.ptr(scales_), rt.ptr(rots_), None,
-                                                   rt.ptr(opacity_), rt.ptr(ex_out), fu_))
-        if fused_hair:
-            rt.check(L.hgs_hair_forward_preprocess(stream, P, int(degree), M, W, H, rt.ptr(ep_), rt.ptr(pairs_), rt.ptr(w_),
-                                                   hair.factor, rt.ptr(o_raw), rt.ptr(m_raw), rt.ptr(sh_), rt.ptr(means3D),
-                                                   rt.ptr(scales_), rt.ptr(rots_), rt.ptr(opacity_), rt.ptr(ex_out),
-                                                   rt.ptr(view), rt.ptr(proj), rt.ptr(cam), float(tan_fovx), float(tan_fovy),
-                                                   flags, rt.ptr(geom), rt.ptr(img), rt.ptr(radii),
-                                                   rt.ptr(max_rendered if max_rendered is not None else _max_rendered(dev)), fu_))
-        else:
+            mr_ = rt.ptr(max_rendered if max_rendered is not None else _max_rendered(dev)) if fused_hair else None
+            if hair.kind == "hair":
+                ep_, w_ = _f32(hair.endpoints, "endpoints"), _f32(hair.width, "width")
+                pairs_ = rt.require_gpu_tensor(hair.pairs, "endpoint_pairs", torch.int64)
+                if fused_hair:
+                    rt.check(L.hgs_hair_forward_preprocess(stream, P, int(degree), M, W, H, rt.ptr(ep_), rt.ptr(pairs_), rt.ptr(w_),
+                                                           hair.factor, rt.ptr(o_raw), rt.ptr(m_raw), rt.ptr(sh_), rt.ptr(means3D),
+                                                           rt.ptr(scales_), rt.ptr(rots_), rt.ptr(opacity_), rt.ptr(ex_out),
+                                                           rt.ptr(view), rt.ptr(proj), rt.ptr(cam), float(tan_fovx),
+                                                           float(tan_fovy), flags, rt.ptr(geom), rt.ptr(img), rt.ptr(radii), mr_, fu_))
+                else:
+                    rt.check(L.hgs_hair_params_forward(stream, P, rt.ptr(ep_), rt.ptr(pairs_), rt.ptr(w_), hair.factor, rt.ptr(o_raw),
+                                                       rt.ptr(m_raw), rt.ptr(means3D), rt.ptr(scales_), rt.ptr(rots_), None,
+                                                       rt.ptr(opacity_), rt.ptr(ex_out), fu_))
+            else:
+                s_raw, r_raw = _f32(hair.scaling_raw, "scaling_raw"), _f32(hair.rotation_raw, "rotation_raw")
+                if fused_hair:
+                    rt.check(L.hgs_cloud_forward_preprocess(stream, P, int(degree), M, W, H, rt.ptr(means3D), rt.ptr(s_raw),
+                                                            rt.ptr(r_raw), rt.ptr(o_raw), rt.ptr(m_raw), rt.ptr(sh_),
+                                                            rt.ptr(scales_), rt.ptr(rots_), rt.ptr(opacity_), rt.ptr(ex_out),
+                                                            rt.ptr(view), rt.ptr(proj), rt.ptr(cam), float(tan_fovx),
+                                                            float(tan_fovy), flags, rt.ptr(geom), rt.ptr(img), rt.ptr(radii), mr_, fu_))
+                else:
+                    rt.check(L.hgs_cloud_params_forward(stream, P, rt.ptr(s_raw), rt.ptr(r_raw), rt.ptr(o_raw), rt.ptr(m_raw),
+                                                        rt.ptr(scales_), rt.ptr(rots_), rt.ptr(opacity_), rt.ptr(ex_out), fu_))
+        if not fused_hair:
             rt.check(L.hgs_forward_preprocess(stream, P, int(degree), M, W, H, rt.ptr(means3D), rt.ptr(sh_), rt.ptr(colors_),
                                               rt.ptr(opacity_), rt.ptr(scales_), float(scale_modifier), rt.ptr(rots_),
                                               rt.ptr(cov_), rt.ptr(view), rt.ptr(proj), rt.ptr(cam), float(tan_fovx),

@@ -63,6 +63,8 @@ SIGNATURES = {
     "hgs_hair_params_forward": (ci, [vp, ci, vp, vp, vp, cf, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "hgs_hair_params_backward": (ci, [vp, ci, ci, vp, vp, vp, cf, vp, vp, vp, vp, vp, vp, vp, vp, ci, vp, vp, vp, vp, vp]),
     "hgs_cloud_params_forward": (ci, [vp, ci, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
+    "hgs_cloud_forward_preprocess": (ci, [vp, ci, ci, ci, ci, ci, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp,
+                                          cf, cf, ci, vp, vp, vp, vp, vp]),
     "hgs_hair_forward_preprocess": (ci, [vp, ci, ci, ci, ci, ci, vp, vp, vp, cf, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp,
                                          cf, cf, ci, vp, vp, vp, vp, vp]),
     "hgs_cloud_params_backward": (ci, [vp, ci, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),

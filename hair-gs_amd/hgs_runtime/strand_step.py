@@ -542,15 +542,25 @@ class _CloudIteration(torch.autograd.Function):
         f32 = dict(dtype=torch.float32, device=dev)
         scale, quat = torch.empty((P, 3), **f32), torch.empty((P, 4), **f32)
         opacity, extra4 = torch.empty((P, 1), **f32), torch.empty((P, 4), **f32)
+        from diff_gaussian_rasterization import _C as raster
         fu = rt.StrandFusion()
-        step.views.fill_prologue(fu)
-        with torch.cuda.device(dev):
-            rt.check(L.hgs_cloud_params_forward(rt.current_stream(), P, rt.ptr(scaling_raw), rt.ptr(rotation_raw),
-                                                rt.ptr(opacity_raw), rt.ptr(mask_raw), rt.ptr(scale), rt.ptr(quat),
-                                                rt.ptr(opacity), rt.ptr(extra4), C.byref(fu)))
+        vt = step.views
+        if step.fuse_preprocess:      # (as _StrandIteration: parameters -> Gaussians -> preprocess as one launch)
+            def fill(fused):
+                if fused and not vt.counts_clean:
+                    vt.flush_prologue()
+                vt.fill_prologue(fu, behind_counts=fused)
+            src = raster.CloudSource(scaling_raw, rotation_raw, opacity_raw, mask_raw, fu, fill)
+        else:
+            src = None
+            vt.fill_prologue(fu)
+            with torch.cuda.device(dev):
+                rt.check(L.hgs_cloud_params_forward(rt.current_stream(), P, rt.ptr(scaling_raw), rt.ptr(rotation_raw),
+                                                    rt.ptr(opacity_raw), rt.ptr(mask_raw), rt.ptr(scale), rt.ptr(quat),
+                                                    rt.ptr(opacity), rt.ptr(extra4), C.byref(fu)))
         shs = f_dc if f_rest.numel() == 0 else torch.cat((f_dc, f_rest), dim=1)
         R, planes, radii, geom, binning, img, scratch, out, d_extra = _raster_head_forward(
-            step, xyz, scale, quat, opacity, extra4, shs, None, None, None, 0)
+            step, xyz, scale, quat, opacity, extra4, shs, None, None, None, 0, hair=src)
         ctx.d_extra, ctx.fused_smooth = d_extra, True   # (no smoothness term for a cloud: nothing to launch)
         ctx.defer_tail = bool(step.head.defer_tail)
         ctx.step, ctx.R, ctx.f_rest_k = step, R, f_rest.shape[1]

@@ -324,6 +324,15 @@ int hgs_hair_forward_preprocess(void* stream, int P, int D, int M, int W, int H,
                                 float* quat, float* opacity, float* extra4, const float* viewmatrix, const float* projmatrix,
                                 const float* campos, float tan_fovx, float tan_fovy, int flags, void* geom_buf,
                                 void* image_buf, int* radii, unsigned int* max_rendered, const HgsStrandFusion* fusion);
+/* The same for the Stage-I cloud: hgs_cloud_params_forward AND hgs_forward_preprocess as one launch (means3D is the model's
+ *   own parameter; scale / quat / opacity / extra4 are written as hgs_cloud_params_forward writes them, bit for bit); only the
+ *   prologue group of `fusion` is used. */
+int hgs_cloud_forward_preprocess(void* stream, int P, int D, int M, int W, int H, const float* means3D, const float* scaling_raw,
+                                 const float* rotation_raw, const float* opacity_raw, const float* mask_raw, const float* shs,
+                                 float* scale, float* quat, float* opacity, float* extra4, const float* viewmatrix,
+                                 const float* projmatrix, const float* campos, float tan_fovx, float tan_fovy, int flags,
+                                 void* geom_buf, void* image_buf, int* radii, unsigned int* max_rendered,
+                                 const HgsStrandFusion* fusion);
 int hgs_hair_params_backward(void* stream, int P, int E, const float* endpoints, const long long* endpoint_pairs,
                              const float* width, float dist_to_scale_factor, const float* opacity, const float* extra4,
                              const float* g_xyz, const float* g_scale, const float* g_quat, const float* g_dir,

@@ -1251,6 +1251,47 @@ def test_one_launch_parameters_and_preprocess_equals_two_launches():
         assert torch.equal(a, b)
 
 
+def test_one_launch_cloud_parameters_and_preprocess_equals_two_launches():
+    """hgs_cloud_forward_preprocess against hgs_cloud_params_forward + hgs_forward_preprocess (Stage-I cloud iteration): loss
+    terms, image, radii and every parameter gradient bit for bit."""
+    from arguments import OptimizationParams
+    from diff_gaussian_rasterization import _C as raster
+    from hgs_runtime.strand_step import FusedCloudStep, ViewTable
+    from synthetic import attach_targets, cameras_extent, make_cameras, make_cloud_model
+    cams = make_cameras(4, 200, 120, device="cuda")
+    model = make_cloud_model(3000, device="cuda", spatial_lr_scale=cameras_extent(cams))
+    attach_targets(cams, model)
+    opt = OptimizationParams()
+    model.training_setup(opt)
+    params = [model._xyz, model._scaling, model._rotation, model._opacity, model._mask, model._features_dc]
+    out = {}
+    try:
+        raster.set_async(True, slack=2.0)
+        for fuse in (False, True):
+            views = ViewTable(cams)
+            step = FusedCloudStep(model, views, opt, torch.zeros(3, device="cuda"))
+            step.fuse_preprocess = fuse
+            seen = []
+            for v in (0, 2, 1, 3):
+                for p in params:
+                    p.grad = None
+                views.prologue(v, ride=True)
+                fused_now = fuse and raster.will_fuse_hair(views.W, views.H)
+                loss, terms = step.loss()
+                step.backward(loss)
+                raster.check_async()
+                seen.append([fused_now, loss.detach().clone(), terms[:14].clone(), step.last["planes"].clone(),
+                             step.last["radii"].clone()] + [p.grad.clone() for p in params])
+            out[fuse] = seen
+    finally:
+        raster.set_async(False)
+    assert all(s[0] for s in out[True][1:]) and not any(s[0] for s in out[False])
+    for a, b in zip(out[False], out[True]):
+        for x, y in zip(a[1:], b[1:]):
+            assert torch.equal(x, y)
+        assert bool(a[5].abs().sum() > 0)
+
+
 def test_replays_after_a_blocking_pass_on_the_same_views():
     """The captured step's first launch counts into the image buffer's tile counters beside the workgroups that clear the other
     counters, so it needs them at zero -- which capacity-mode passes leave behind and a blocking-mode pass does not.  A blocking
