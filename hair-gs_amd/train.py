@@ -83,6 +83,12 @@ class ViewParallel:
         parameters' .grad views of it, so the exchange below is one in-place collective and Adam reads the reduced
         values with no copy back.  Layout: [endpoints|f_dc|f_rest|opacity|mask|width] (Stage I: xyz|...|rotation)."""
         ps = [p for p in self.params(gaussians) if p.grad is not None and p.numel() > 0]
+        # (an iteration whose topology operators re-created every parameter has no gradient left for this Adam step, as in the
+        # reference, where the operators sit between backward and optimizer.step(): nothing to exchange -- on any rank, the
+        # replicas being identical)
+        self._packed = bool(ps)
+        if not ps:
+            return
         n = sum(p.numel() for p in ps)
         key = tuple((p.data_ptr(), p.numel()) for p in ps)
         if self._flat is None or self._flat_key != key or self._flat.device != ps[0].device:
@@ -101,7 +107,7 @@ class ViewParallel:
     def exchange(self, average=True):
         """Average (or, average=False, sum) the packed gradients over the ranks: one all-reduce over xGMI (RCCL) / gloo
         on CPU."""
-        if self.world == 1 or self._flat is None:
+        if self.world == 1 or self._flat is None or not getattr(self, "_packed", True):
             return
         if average and dist.get_backend() == "nccl":
             dist.all_reduce(self._flat, op=dist.ReduceOp.AVG)

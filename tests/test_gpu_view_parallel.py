@@ -57,3 +57,16 @@ def test_step_graph_with_the_exchange_inside():
                          text=True, timeout=600)
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
     assert "RCCL_GRAPH_OK" in out.stdout and "collective captured: True steps per graph: 4" in out.stdout
+
+
+def test_two_ranks_through_the_topology_operators():
+    """training() on two ranks (one view per rank and step, graph replays) THROUGH densification, merging and the opacity reset:
+    every rank ends with the same segments, endpoints, strands, parameters and Adam moments, bit for bit (the
+    operators' statistics are reduced over the ranks, their random draws are seeded alike)."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    worker = os.path.join(ROOT, "tests", "_vp_topology_worker.py")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29541", worker]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+    assert "VP_TOPOLOGY_OK" in out.stdout
