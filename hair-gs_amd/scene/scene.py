@@ -66,7 +66,9 @@ class Scene:
         pc_dir = os.path.join(self.model_path, "point_cloud")
         if os.path.isdir(pc_dir) and os.listdir(pc_dir):
             self.loaded_iter = search_for_max_iteration(pc_dir)
-        else:   # first run: keep the input cloud and the camera list next to the outputs, like the reference
+        elif int(os.environ.get("RANK", "0")) == 0:
+            # first run: keep the input cloud and the camera list next to the outputs, like the reference (view-parallel run:
+            # rank 0 alone writes to the model directory)
             with open(info.ply_path, "rb") as src, open(os.path.join(self.model_path, "input.ply"), "wb") as dst:
                 dst.write(src.read())
             with open(os.path.join(self.model_path, "cameras.json"), "w") as fh:

@@ -718,11 +718,16 @@ def main(argv=None):
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         local = int(os.environ.get("LOCAL_RANK", "0"))
+        # (HGS_DIST_BACKEND=gloo: ranks may share a GPU -- RCCL needs one per rank --, which is how the tests run this path
+        # on a one-GPU box)
+        backend = os.environ.get("HGS_DIST_BACKEND", "nccl" if torch.cuda.is_available() else "gloo")
         if torch.cuda.is_available():
+            local = local % torch.cuda.device_count() if backend == "gloo" else local
             torch.cuda.set_device(local)
+        if backend == "nccl":
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
         else:
-            dist.init_process_group(backend="gloo")
+            dist.init_process_group(backend=backend)
     safe_state(args.quiet or rank != 0)
     if rank == 0:
         os.makedirs(args.model_path, exist_ok=True)

@@ -84,3 +84,28 @@ def test_train_cli_stage_one_then_resume(tmp_path):
     assert os.path.exists(model / "cfg_args")
     scene2 = train_cli.main(["-s", str(src), "-m", str(model), "--iterations", "2", "--quiet"])
     assert scene2.loaded_iter == 6 and os.path.isdir(model / "point_cloud" / "iteration_8")
+
+
+def test_train_cli_on_two_ranks(tmp_path):
+    """train.py under torchrun (2 ranks sharing the GPU through gloo; RCCL needs one GPU per rank): Stage-I training through
+    densification and an opacity reset; rank 0 alone writes the model directory (cfg_args, input.ply, cameras.json, the
+    checkpoints) and both ranks end with the same cloud, bit for bit."""
+    import subprocess
+    from tests.test_dataset_io_cpu import _write_capture
+    src, model = tmp_path / "capture", tmp_path / "out"
+    _write_capture(src, n_views=4, W=64, H=48)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0", HGS_DIST_BACKEND="gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29551", os.path.join(ROOT, "tests", "_train_cli_worker.py"), str(src), str(model)]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+    assert "TRAIN_CLI_RANK_0_OK" in out.stdout and "TRAIN_CLI_RANK_1_OK" in out.stdout
+    assert sorted(os.listdir(model / "point_cloud")) == ["iteration_12", "iteration_24"]
+    for f in ("cfg_args", "input.ply", "cameras.json"):
+        assert os.path.exists(model / f)
+    a, b = torch.load(model / "rank0.pt"), torch.load(model / "rank1.pt")
+    from utils.ply import read_ply
+    n_input = len(read_ply(str(model / "input.ply"))[0][1])
+    assert a["xyz"].shape[0] > 0 and a["xyz"].shape[0] != n_input        # the densification did change the cloud
+    for k in a:
+        assert torch.equal(a[k], b[k]), k
