@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-/* bumped with every incompatible change of a struct, a signature or a buffer layout (round 1: 1, round 2: 2, round 3: 3);
+/* bumped with every incompatible change of a struct, a signature or a buffer layout (round 1: 1, round 2: 2, round 3: 3, then 4 with the one-launch parameters + preprocess entry points);
  * the Python binding refuses a library whose version or struct sizes differ from its own */
 #define HGS_ABI_VERSION 4
 #define HGS_TILE 16 /* cuda_rasterizer/config.h:16-17 */
