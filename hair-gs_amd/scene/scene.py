@@ -2,7 +2,13 @@
  * cameras from <source_path>/sparse/0 (+ images / masks / orientations), extent = nerf_normalization radius;
  * model = Gaussian cloud initialised from the sparse points, or the newest <model_path>/point_cloud/iteration_N/
    point_cloud.ply (a one-element file is a Gaussian cloud, a five-element file a strand model);
- * save(iteration) writes that file.  Evaluation ground truth / head reconstructions (npz side files) are not handled."""
+ * save(iteration) writes that file;
+ * the two npz side files of a capture, when present (reference :103-122): `hair_eval_data.npz` (ground-truth strands for the
+   metrics: points, directions, points_id_to_strand_id, edges -> `scene.gt`) and `head_reconstruction_data.npz` (head_verts,
+   scalp_verts -> `scene.head_reconstruction`; the scalp vertices become the model's `ref_strand_root`, which Stage II / III
+   orient the strands by: merge.py cannot run without them)."""
+from types import SimpleNamespace
+
 import json
 import os
 import random
@@ -89,7 +95,26 @@ class Scene:
             cls = GaussianModel if len(read_ply(path)) == 1 else HairGaussianModel
             self.gaussians = cls(args.sh_degree, self.cameras_extent, device=dev)
             self.gaussians.load_ply(path)
+        # ground truth for the evaluation metrics (reference :103-107; data/eval_data.py:23-37: directions normalised on load)
         self.gt = None
+        gt_path = os.path.join(args.source_path, "hair_eval_data.npz")
+        if os.path.exists(gt_path):
+            from loss.metrics import HairEvalData
+            d = np.load(gt_path)
+            dirs = np.asarray(d["directions"], dtype=np.float64)
+            dirs = dirs / np.linalg.norm(dirs, axis=1, keepdims=True)
+            self.gt = HairEvalData(points=d["points"], directions=dirs, points_id_to_strand_id=d["points_id_to_strand_id"])
+            self.gt_edges = d["edges"] if "edges" in d.files else None
+        # head reconstruction (reference :109-122): the scalp vertices are the reference strand roots
+        self.head_reconstruction = None
+        head_path = os.path.join(args.source_path, "head_reconstruction_data.npz")
+        if os.path.exists(head_path):
+            d = np.load(head_path)
+            self.head_reconstruction = SimpleNamespace(head_verts=d["head_verts"], scalp_verts=d["scalp_verts"])
+            self.gaussians.ref_strand_root = np.asarray(d["scalp_verts"])
+            if isinstance(self.gaussians, HairGaussianModel):
+                self.gaussians.update_strand_root()
+                self.gaussians.compute_strands_info()
 
     def save(self, iteration):
         self.gaussians.save_ply(os.path.join(self.model_path, "point_cloud", f"iteration_{iteration}", "point_cloud.ply"))

@@ -43,6 +43,19 @@ def test_quaternion_conversions():
                        [[np.cos(0.5), -np.sin(0.5), 0], [np.sin(0.5), np.cos(0.5), 0], [0, 0, 1]])
 
 
+def _write_side_files(root, seed=3):
+    """hair_eval_data.npz / head_reconstruction_data.npz as the reference's scripts write them (data/eval_data.py:23-37,
+    data/head_reconstruction_data.py:20-45): ground-truth strand points + directions, head and scalp vertices."""
+    rng = np.random.default_rng(seed)
+    strands = np.cumsum(rng.normal(size=(6, 8, 3)) * 0.05, axis=1) + rng.normal(size=(6, 1, 3)) * 0.5
+    pts = strands[:, :-1].reshape(-1, 3)
+    dirs = (strands[:, 1:] - strands[:, :-1]).reshape(-1, 3) * 3.0                 # (not unit: the loader normalises)
+    sid = np.repeat(np.arange(6), 7)
+    edges = np.stack([np.arange(41), np.arange(1, 42)], 1)
+    np.savez(root / "hair_eval_data.npz", points=pts, directions=dirs, points_id_to_strand_id=sid, edges=edges)
+    np.savez(root / "head_reconstruction_data.npz", head_verts=rng.normal(size=(50, 3)), scalp_verts=rng.normal(size=(30, 3)))
+
+
 def _write_capture(root, n_views=3, W=32, H=24, text=False):
     sparse = root / "sparse" / "0"
     for d in (sparse, root / "images", root / "masks", root / "orientations"):

@@ -109,3 +109,61 @@ def test_train_cli_on_two_ranks(tmp_path):
     assert a["xyz"].shape[0] > 0 and a["xyz"].shape[0] != n_input        # the densification did change the cloud
     for k in a:
         assert torch.equal(a[k], b[k]), k
+
+
+def test_three_stage_pipeline_through_the_clis(tmp_path):
+    """The reference's workflow end to end on a small capture: train.py (Stage I: Gaussian cloud) -> merge.py (Stage II: cloud ->
+    strands, merged until nothing is left) -> train.py again on the strand model (Stage III: fused strand iteration, graph
+    replays, topology operators at short intervals) -> render.py (all output types)."""
+    from tests.test_dataset_io_cpu import _write_capture, _write_side_files
+    import merge as merge_cli
+    import render as render_cli
+    import train as train_cli
+    from scene.gaussian_model import GaussianModel
+    from scene.hair_gaussian_model import HairGaussianModel
+    src, model = tmp_path / "capture", tmp_path / "out"
+    _write_capture(src, n_views=4, W=96, H=64)
+    _write_side_files(src)                 # (scalp vertices: what Stage II / III orient the strands by)
+    s1 = train_cli.main(["-s", str(src), "-m", str(model), "--iterations", "30", "--save_frequency", "30", "--quiet",
+                         "--densify_from_iter", "5", "--densification_interval", "10", "--densify_grad_threshold", "1e-7"])
+    assert isinstance(s1.gaussians, GaussianModel) and os.path.isdir(model / "point_cloud" / "iteration_30")
+    hair = merge_cli.main(["-s", str(src), "-m", str(model), "--iterations", "5"])
+    assert isinstance(hair, HairGaussianModel) and hair.endpoint_pairs.shape[0] > 0   # (built under inference_mode: not a model to train on)
+    saved = sorted(os.listdir(model / "point_cloud"), key=lambda d: int(d.split("_")[1]))
+    assert len(saved) == 2 and int(saved[-1].split("_")[1]) > 30
+    it2 = int(saved[-1].split("_")[1])
+    s3 = train_cli.main(["-s", str(src), "-m", str(model), "--iterations", "24", "--save_frequency", "24", "--quiet",
+                         "--densify_from_iter", "3", "--densification_interval", "6", "--merge_interval", "8",
+                         "--opacity_reset_interval", "12"])
+    assert isinstance(s3.gaussians, HairGaussianModel) and s3.loaded_iter == it2
+    assert os.path.isdir(model / "point_cloud" / f"iteration_{it2 + 24}")
+    for p in (s3.gaussians._endpoints, s3.gaussians._opacity, s3.gaussians._features_dc):
+        assert torch.isfinite(p).all()
+    render_cli.main(["-s", str(src), "-m", str(model), "--quiet"])          # every type (-1)
+    base = model / "render" / "train" / f"iteration_{it2 + 24}" / "renders"
+    assert sorted(os.listdir(base)) == ["mask_foreground", "mask_other", "orientation_map", "rgb", "rgb_foreground"]
+    assert len(os.listdir(base / "rgb")) == 4
+
+
+def test_scene_reads_the_npz_side_files(tmp_path):
+    """Scene (reference scene/__init__.py:103-122): hair_eval_data.npz -> scene.gt with unit directions;
+    head_reconstruction_data.npz -> scene.head_reconstruction, its scalp vertices as the model's ref_strand_root (carried
+    into the strand model by to_hair_gaussian_model, which cannot orient strands without them)."""
+    from tests.test_dataset_io_cpu import _write_capture, _write_side_files
+    from scene import Scene
+    src, model = tmp_path / "capture", tmp_path / "out"
+    _write_capture(src)
+    args = _args(src, model)
+    plain = Scene(args, shuffle=False)
+    assert plain.gt is None and plain.head_reconstruction is None and plain.gaussians.ref_strand_root is None
+    _write_side_files(src)
+    scene = Scene(args, shuffle=False)
+    assert scene.gt.points.shape == (42, 3) and np.allclose(np.linalg.norm(scene.gt.directions, axis=1), 1.0)
+    assert scene.gt.points_id_to_strand_id.shape == (42,) and scene.gt_edges.shape == (41, 2)
+    assert scene.head_reconstruction.scalp_verts.shape == (30, 3) and scene.head_reconstruction.head_verts.shape == (50, 3)
+    assert np.array_equal(scene.gaussians.ref_strand_root, scene.head_reconstruction.scalp_verts)
+    from arguments import OptimizationParams
+    scene.gaussians.training_setup(OptimizationParams())
+    hair = scene.gaussians.to_hair_gaussian_model()
+    assert hair.strands_info.n_strands == hair.get_xyz.shape[0] > 0          # (every segment its own strand before merging)
+    assert np.array_equal(hair.ref_strand_root, scene.head_reconstruction.scalp_verts)
