@@ -570,8 +570,17 @@ def training(gaussians, cameras, opt, iterations=None, extent=1.0, seed=0, log_e
     use_graph = use_graph and dev.type == "cuda"
     views = fused = None
     if dev.type == "cuda" and fused_step_applicable(gaussians, opt):
+        import hgs_runtime as rt
         from hgs_runtime.strand_step import ViewTable, fused_step_for
-        views = ViewTable(cameras)             # built once; survives topology changes
+        try:
+            views = ViewTable(cameras)             # built once; survives topology changes
+        except (rt.HgsError, AttributeError) as e:
+            # a capture the view table cannot hold (views of different sizes, a view without orientation maps, masks on some
+            # views only): the op-by-op iteration takes every camera as it is, eagerly -- slower, same arithmetic
+            if vp.rank == 0:
+                print(f"training(): the fused iteration needs uniform views ({e}); running the op-by-op iteration eagerly")
+            views, use_graph = None, False
+    if views is not None:
         fused = fused_step_for(gaussians, views, opt, bg)   # eager launches of the same iteration (topology iterations)
         fused.defer_tail = bool(getattr(opt, "defer_head_tail", True))   # (training_step runs forward and backward together)
     topology = getattr(opt, "enable_topology", True)

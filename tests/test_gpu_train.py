@@ -1337,3 +1337,25 @@ def test_replays_after_a_blocking_pass_on_the_same_views():
         raster.set_async(False)
     for a, b in zip(res[False], res[True]):
         assert torch.equal(a, b)
+
+
+def test_training_falls_back_when_the_views_are_not_uniform(capsys):
+    """A capture whose views differ in size cannot go into the view table of the fused iteration (nor into a captured graph,
+    whose launches bake the image size in): training() says so and runs the op-by-op iteration eagerly on every camera as it is."""
+    from arguments import OptimizationParams
+    from synthetic import attach_targets, cameras_extent, make_cameras, make_strand_model
+    from train import training
+    from utils.general import safe_state
+    safe_state(True)
+    cams = make_cameras(2, 160, 96, device="cuda") + make_cameras(2, 128, 80, device="cuda")
+    model = make_strand_model(n_strands=40, n_seg=10, seed=1, device="cuda", spatial_lr_scale=cameras_extent(cams))
+    model.compute_strands_info(only_foreground=True)
+    attach_targets(cams[:2], model)
+    attach_targets(cams[2:], model)
+    opt = OptimizationParams()
+    opt.enable_topology = False
+    model.training_setup(opt)
+    before = model._endpoints.detach().clone()
+    ema = training(model, cams, opt, iterations=6, extent=cameras_extent(cams))
+    assert torch.isfinite(ema) and not torch.equal(before, model._endpoints.detach())
+    assert "op-by-op iteration eagerly" in capsys.readouterr().out
