@@ -107,3 +107,13 @@ def compute_eval_data_from_hair_gs(gaussians, only_foreground=True):
             e2s = gaussians.strands_info.id_to_strand_id
             ids = e2s[gaussians.endpoint_pairs[fg][:, 0].cpu().numpy()]
     return HairEvalData(points=pts, directions=dirs, points_id_to_strand_id=ids)
+
+
+def compute_eval_data_from_gs(gaussians):
+    """Oriented points of a Gaussian cloud: foreground means + the direction of the longest axis (reference
+    data/eval_data.py:121-130)."""
+    import torch
+    with torch.no_grad():
+        fg = gaussians.compute_foreground_mask()
+        return HairEvalData(points=gaussians.get_xyz[fg].cpu().numpy(), directions=gaussians.get_orientation[fg].cpu().numpy())
+

@@ -750,12 +750,30 @@ def main(argv=None):
     vp = ViewParallel()
     sampler = ViewSampler(cams, seed=0, rank=vp.rank, world=vp.world)   # ONE view order for the whole run
     it, total, every = scene.loaded_iter, scene.loaded_iter + opt.iterations, max(1, int(args.save_frequency))
+    eval_every = max(1, int(getattr(args, "eval_frequency", 30000)))
+
+    def evaluate(iteration):
+        """The reference's evaluation hook (train.py:229-246): strand metrics against the capture's ground truth, where it
+        has one (hair_eval_data.npz), every eval_frequency iterations and at the end.  CPU code (cKDTree), rank 0 only."""
+        import numpy as np
+        from loss.metrics import compute_eval_data_from_gs, compute_eval_data_from_hair_gs, compute_metrics
+        from scene.hair_gaussian_model import HairGaussianModel
+        pred = compute_eval_data_from_hair_gs(g) if isinstance(g, HairGaussianModel) else compute_eval_data_from_gs(g)
+        scene.eval_metrics, scene.eval_thresholds = compute_metrics(pred=pred, gt=scene.gt, bidirectional=bool(opt.bidirectional_eval))
+        if not args.quiet:
+            print(f"[it {iteration}] " + "  ".join(f"{k} {np.round(np.asarray(v), 3).tolist()}" for k, v in scene.eval_metrics.items())
+                  + f"  at {scene.eval_thresholds}")
+
     while it < total:
         n = min(every - it % every, total - it)
+        if scene.gt is not None:
+            n = min(n, eval_every - it % eval_every)
         ema = training(g, cams, opt, iterations=n, extent=scene.cameras_extent, start_iteration=it, vp=vp, sampler=sampler,
                        log_every=0 if (args.quiet or rank != 0) else max(1, n // 4))
         it += n
-        if rank == 0:
+        if rank == 0 and scene.gt is not None and (it % eval_every == 0 or it == total):
+            evaluate(it)
+        if rank == 0 and (it % every == 0 or it == total):
             scene.save(it)
             if not args.quiet:
                 print(f"[it {it}] saved; loss(ema) {float(ema):.6f}")

@@ -127,6 +127,8 @@ def test_three_stage_pipeline_through_the_clis(tmp_path):
     s1 = train_cli.main(["-s", str(src), "-m", str(model), "--iterations", "30", "--save_frequency", "30", "--quiet",
                          "--densify_from_iter", "5", "--densification_interval", "10", "--densify_grad_threshold", "1e-7"])
     assert isinstance(s1.gaussians, GaussianModel) and os.path.isdir(model / "point_cloud" / "iteration_30")
+    # (hair_eval_data.npz: evaluated at the end; bidirectional_eval is the default: the reference's "(b)" keys)
+    assert set(s1.eval_metrics) >= {"precision(b)", "recall(b)", "f1(b)"} and len(s1.eval_thresholds) == 4
     hair = merge_cli.main(["-s", str(src), "-m", str(model), "--iterations", "5"])
     assert isinstance(hair, HairGaussianModel) and hair.endpoint_pairs.shape[0] > 0   # (built under inference_mode: not a model to train on)
     saved = sorted(os.listdir(model / "point_cloud"), key=lambda d: int(d.split("_")[1]))
@@ -135,7 +137,7 @@ def test_three_stage_pipeline_through_the_clis(tmp_path):
     s3 = train_cli.main(["-s", str(src), "-m", str(model), "--iterations", "24", "--save_frequency", "24", "--quiet",
                          "--densify_from_iter", "3", "--densification_interval", "6", "--merge_interval", "8",
                          "--opacity_reset_interval", "12"])
-    assert isinstance(s3.gaussians, HairGaussianModel) and s3.loaded_iter == it2
+    assert isinstance(s3.gaussians, HairGaussianModel) and s3.loaded_iter == it2 and "f1(b)" in s3.eval_metrics
     assert os.path.isdir(model / "point_cloud" / f"iteration_{it2 + 24}")
     for p in (s3.gaussians._endpoints, s3.gaussians._opacity, s3.gaussians._features_dc):
         assert torch.isfinite(p).all()
