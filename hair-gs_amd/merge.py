@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Stage II: turn the optimised Gaussian cloud of <model_path> into a strand model and merge strand ends until nothing
 is left to merge (reference merge.py).  The newest iteration's point_cloud.ply must be a Gaussian
-cloud; the result is saved as iteration_<it + rounds>.  Visualisation / logging of the reference are not reproduced.
+cloud; the result is saved as iteration_<it + rounds + 1> (the reference's loop index at exit).  Visualisation / logging of the reference are not reproduced.
   python merge.py -s <colmap scene> -m <model dir> [--iterations N]"""
 import os
 import sys
@@ -47,7 +47,9 @@ def main(argv=None):
         hair_gs = gaussians.to_hair_gaussian_model()
         scene.gaussians = hair_gs
         rounds = merge_rounds(hair_gs, opt.iterations)
-        scene.save(scene.loaded_iter + max(rounds, 1))
+        # the reference saves under its loop index at exit (merge.py:114-190: the round that found nothing to merge, or the
+        # last one allowed)
+        scene.save(scene.loaded_iter + min(rounds + 1, max(int(opt.iterations), 1)))
     return hair_gs
 
 
