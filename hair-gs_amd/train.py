@@ -749,7 +749,10 @@ def main(argv=None):
     cams = scene.getCameras()
     vp = ViewParallel()
     sampler = ViewSampler(cams, seed=0, rank=vp.rank, world=vp.world)   # ONE view order for the whole run
-    it, total, every = scene.loaded_iter, scene.loaded_iter + opt.iterations, max(1, int(args.save_frequency))
+    # As in the reference (train.py:91-92, 251-253), `iteration` counts from 1 in EVERY invocation -- the learning-rate
+    # schedule, the SH-degree bumps and the operators' intervals restart with each stage of the workflow -- and only the
+    # name of a saved iteration adds what the model had when it was loaded.
+    base, total, every = scene.loaded_iter, int(opt.iterations), max(1, int(args.save_frequency))
     eval_every = max(1, int(getattr(args, "eval_frequency", 30000)))
 
     def evaluate(iteration):
@@ -764,6 +767,7 @@ def main(argv=None):
             print(f"[it {iteration}] " + "  ".join(f"{k} {np.round(np.asarray(v), 3).tolist()}" for k, v in scene.eval_metrics.items())
                   + f"  at {scene.eval_thresholds}")
 
+    it = 0
     while it < total:
         n = min(every - it % every, total - it)
         if scene.gt is not None:
@@ -772,11 +776,11 @@ def main(argv=None):
                        log_every=0 if (args.quiet or rank != 0) else max(1, n // 4))
         it += n
         if rank == 0 and scene.gt is not None and (it % eval_every == 0 or it == total):
-            evaluate(it)
+            evaluate(base + it)
         if rank == 0 and (it % every == 0 or it == total):
-            scene.save(it)
+            scene.save(base + it)
             if not args.quiet:
-                print(f"[it {it}] saved; loss(ema) {float(ema):.6f}")
+                print(f"[it {base + it}] saved; loss(ema) {float(ema):.6f}")
         if world > 1:
             dist.barrier()
     if world > 1:

@@ -84,6 +84,10 @@ def test_train_cli_stage_one_then_resume(tmp_path):
     assert os.path.exists(model / "cfg_args")
     scene2 = train_cli.main(["-s", str(src), "-m", str(model), "--iterations", "2", "--quiet"])
     assert scene2.loaded_iter == 6 and os.path.isdir(model / "point_cloud" / "iteration_8")
+    # every invocation counts its iterations from 1 (reference train.py:91): the schedules restart, only the saved name adds up
+    g = scene2.gaussians
+    lr = [float(grp["lr"]) for grp in g.optimizer.param_groups if grp["name"] == g._POSITION_GROUP][0]
+    assert abs(lr - g.xyz_scheduler_args(2)) <= 1e-12 + 1e-6 * lr and abs(lr - g.xyz_scheduler_args(8)) > 1e-9 * lr
 
 
 def test_train_cli_on_two_ranks(tmp_path):
