@@ -104,7 +104,7 @@ def main(argv=None):
     safe_state(getattr(args, "quiet", False))
     from scene import Scene
     with torch.no_grad():
-        scene = Scene(args, shuffle=False)
+        scene = Scene(args)     # (shuffled like the reference, render.py:136: the file numbers follow that order)
         kinds = [args.type] if args.type != -1 else [0, 2, 3, 4, 1]   # 1 deletes Gaussians: last
         for kind in kinds:
             if not args.skip_train:
