@@ -49,7 +49,7 @@ def main(argv=None):
         rounds = merge_rounds(hair_gs, opt.iterations)
         # the reference saves under its loop index at exit (merge.py:114-190: the round that found nothing to merge, or the
         # last one allowed)
-        scene.save(scene.loaded_iter + min(rounds + 1, max(int(opt.iterations), 1)))
+        scene.save(min(rounds + 1, max(int(opt.iterations), 1)))
     return hair_gs
 
 

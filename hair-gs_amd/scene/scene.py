@@ -116,7 +116,11 @@ class Scene:
                 self.gaussians.update_strand_root()
                 self.gaussians.compute_strands_info()
 
-    def save(self, iteration):
+    def save(self, iteration=0):
+        """Writes point_cloud/iteration_<loaded_iter + iteration>/point_cloud.ply: `iteration` counts from the loaded state,
+        as in the reference (:124-131)."""
+        if self.loaded_iter:
+            iteration += self.loaded_iter
         self.gaussians.save_ply(os.path.join(self.model_path, "point_cloud", f"iteration_{iteration}", "point_cloud.ply"))
 
     def getCameras(self, scale=1.0):

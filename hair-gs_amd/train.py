@@ -778,7 +778,7 @@ def main(argv=None):
         if rank == 0 and scene.gt is not None and (it % eval_every == 0 or it == total):
             evaluate(base + it)
         if rank == 0 and (it % every == 0 or it == total):
-            scene.save(base + it)
+            scene.save(it)                  # (Scene.save adds the loaded iteration, like the reference's)
             if not args.quiet:
                 print(f"[it {base + it}] saved; loss(ema) {float(ema):.6f}")
         if world > 1:
