@@ -7,7 +7,6 @@
    metrics: points, directions, points_id_to_strand_id, edges -> `scene.gt`) and `head_reconstruction_data.npz` (head_verts,
    scalp_verts -> `scene.head_reconstruction`; the scalp vertices become the model's `ref_strand_root`, which Stage II / III
    orient the strands by: merge.py cannot run without them)."""
-from types import SimpleNamespace
 
 import json
 import os
@@ -99,19 +98,16 @@ class Scene:
         self.gt = None
         gt_path = os.path.join(args.source_path, "hair_eval_data.npz")
         if os.path.exists(gt_path):
-            from loss.metrics import HairEvalData
-            d = np.load(gt_path)
-            dirs = np.asarray(d["directions"], dtype=np.float64)
-            dirs = dirs / np.linalg.norm(dirs, axis=1, keepdims=True)
-            self.gt = HairEvalData(points=d["points"], directions=dirs, points_id_to_strand_id=d["points_id_to_strand_id"])
-            self.gt_edges = d["edges"] if "edges" in d.files else None
+            from data.eval_data import load_hair_eval_data_npz
+            self.gt = load_hair_eval_data_npz(gt_path)
+            self.gt_edges = self.gt.edges
         # head reconstruction (reference :109-122): the scalp vertices are the reference strand roots
         self.head_reconstruction = None
         head_path = os.path.join(args.source_path, "head_reconstruction_data.npz")
         if os.path.exists(head_path):
-            d = np.load(head_path)
-            self.head_reconstruction = SimpleNamespace(head_verts=d["head_verts"], scalp_verts=d["scalp_verts"])
-            self.gaussians.ref_strand_root = np.asarray(d["scalp_verts"])
+            from data.head_reconstruction_data import load_head_reconstruction_data_npz
+            self.head_reconstruction = load_head_reconstruction_data_npz(head_path)
+            self.gaussians.ref_strand_root = np.asarray(self.head_reconstruction.scalp_verts)
             if isinstance(self.gaussians, HairGaussianModel):
                 self.gaussians.update_strand_root()
                 self.gaussians.compute_strands_info()
