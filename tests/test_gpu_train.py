@@ -1359,3 +1359,35 @@ def test_training_falls_back_when_the_views_are_not_uniform(capsys):
     ema = training(model, cams, opt, iterations=6, extent=cameras_extent(cams))
     assert torch.isfinite(ema) and not torch.equal(before, model._endpoints.detach())
     assert "op-by-op iteration eagerly" in capsys.readouterr().out
+
+
+@pytest.mark.parametrize("kind", ["cloud", "hair"])
+def test_render_with_python_side_sh_and_covariance(kind):
+    """render(convert_SHs_python=True, compute_cov3D_python=True) (reference gaussian_renderer/__init__.py:70-108: colours from
+    utils.sh.eval_sh, 3D covariances from the model's get_covariance, both handed to the rasterizer precomputed) gives the image of
+    the default call, and its gradients reach the same parameters."""
+    from gaussian_renderer import render
+    from synthetic import build_workload, cameras_extent, make_cameras, make_cloud_model
+    if kind == "hair":
+        model, cams, _ = build_workload("tiny", device="cuda", with_targets=False)
+    else:
+        cams = make_cameras(3, 200, 120, device="cuda")
+        model = make_cloud_model(2000, device="cuda", spatial_lr_scale=cameras_extent(cams))
+    bg = torch.tensor([0.2, 0.1, 0.3], device="cuda")
+    cam = cams[1]
+    ref = render(cam, model, bg)
+    for flags in (dict(convert_SHs_python=True), dict(compute_cov3D_python=True), dict(convert_SHs_python=True, compute_cov3D_python=True)):
+        out = render(cam, model, bg, **flags)
+        assert torch.equal(out["radii"], ref["radii"]), flags
+        assert float((out["render"] - ref["render"]).detach().abs().max()) <= 2e-5, flags
+    w = torch.randn_like(ref["render"])
+    grads = {}
+    leaf = model._endpoints if kind == "hair" else model._xyz
+    for name, flags in (("default", {}), ("python", dict(convert_SHs_python=True, compute_cov3D_python=True))):
+        for p in (leaf, model._features_dc, model._opacity):
+            p.grad = None
+        (render(cam, model, bg, **flags)["render"] * w).sum().backward()
+        grads[name] = [p.grad.clone() for p in (leaf, model._features_dc, model._opacity)]
+    for a, b in zip(grads["default"], grads["python"]):
+        scale = float(a.abs().max())
+        assert scale > 0 and float((a - b).abs().max()) <= 2e-3 * scale
