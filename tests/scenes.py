@@ -57,7 +57,8 @@ def make_camera(eye, target, W, H, fovx_deg=60.0, up=(0.0, -1.0, 0.0), znear=0.0
 
 def random_scene(P=500, W=96, H=64, seed=0, sh_degree=0, M=None, use_colors_precomp=False, use_cov3D_precomp=False,
                  bg=(0.0, 0.0, 0.0), spread=0.35, scale_lo=0.005, scale_hi=0.05, depth=1.2, behind_frac=0.05,
-                 neg_colors=False, fovx_deg=60.0, opacity_lo=0.05, opacity_hi=0.95, depth_levels=0, eye=None):
+                 neg_colors=False, fovx_deg=60.0, opacity_lo=0.05, opacity_hi=0.95, depth_levels=0, eye=None,
+                 scale_modifier=1.0):
     """Random blob scene in front of one camera.  Some Gaussians sit behind the near plane / off-screen."""
     rng = np.random.default_rng(seed)
     cam = make_camera(eye=(0.1, -0.05, -depth) if eye is None else eye, target=(0, 0, 0), W=W, H=H, fovx_deg=fovx_deg)
@@ -79,8 +80,9 @@ def random_scene(P=500, W=96, H=64, seed=0, sh_degree=0, M=None, use_colors_prec
     shs = (rng.normal(size=(P, M, 3)) * 0.4).astype(np.float32)
     shs[:, 0, :] += 0.8
     scene = dict(cam)
-    scene.update(means3D=xyz, opacities=opac, bg=np.asarray(bg, np.float32), sh_degree=sh_degree, scale_modifier=1.0,
-                 shs=None, colors_precomp=None, scales=None, rotations=None, cov3D_precomp=None)
+    scene.update(means3D=xyz, opacities=opac, bg=np.asarray(bg, np.float32), sh_degree=sh_degree,
+                 scale_modifier=float(scale_modifier), shs=None, colors_precomp=None, scales=None, rotations=None,
+                 cov3D_precomp=None)
     if use_colors_precomp:
         col = rng.uniform(0, 1, (P, 3)).astype(np.float32)
         if neg_colors:

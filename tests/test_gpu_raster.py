@@ -34,6 +34,8 @@ VARIANTS = {
     "depth_ties": dict(P=3000, W=200, H=120, seed=11, depth_levels=6, scale_lo=0.01, scale_hi=0.06),
     # camera far off the +z axis: view rotation of ~120 degrees about y and ~35 degrees of pitch
     "rotated_cam": dict(P=1500, W=160, H=96, seed=12, sh_degree=2, eye=(1.0, -0.7, 0.55), behind_frac=0.0, fovx_deg=90.0),
+    # the viewer's scaling_modifier (render(..., scaling_modifier), CR/forward.cu:118-150 computeCov3D; its backward :600-650)
+    "scale_modifier": dict(P=1200, W=128, H=80, seed=21, sh_degree=1, scale_modifier=0.6),
     "all_culled": dict(P=300, W=64, H=64, seed=8, behind_frac=1.0),
     "tiny_image": dict(P=200, W=7, H=5, seed=9),
     # 145 x 121 = 17545 tiles (> 16384: the scan kernel's chunked path) and footprints of hundreds of tiles (the direct

@@ -1391,3 +1391,27 @@ def test_render_with_python_side_sh_and_covariance(kind):
     for a, b in zip(grads["default"], grads["python"]):
         scale = float(a.abs().max())
         assert scale > 0 and float((a - b).abs().max()) <= 2e-3 * scale
+
+
+def test_debug_mode_snapshots_the_inputs_of_a_failing_call(tmp_path, monkeypatch):
+    """raster_settings.debug (reference diff_gaussian_rasterization/__init__.py:83-101, 127-140): the call synchronises and gives
+    the same image; a failing forward leaves its inputs in snapshot_fw.dump (CPU copies) before the error propagates."""
+    from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
+    from gaussian_renderer import render
+    from synthetic import build_workload
+    model, cams, _ = build_workload("tiny", device="cuda", with_targets=False)
+    bg = torch.zeros(3, device="cuda")
+    with torch.no_grad():
+        assert torch.equal(render(cams[0], model, bg, debug=True)["render"], render(cams[0], model, bg)["render"])
+    monkeypatch.chdir(tmp_path)
+    cam = cams[0]
+    import math
+    rs = GaussianRasterizationSettings(image_height=int(cam.image_height), image_width=int(cam.image_width),
+                                       tanfovx=math.tan(cam.FoVx * 0.5), tanfovy=math.tan(cam.FoVy * 0.5), bg=bg, scale_modifier=1.0,
+                                       viewmatrix=cam.world_view_transform, projmatrix=cam.full_proj_transform, sh_degree=3,
+                                       campos=cam.camera_center, prefiltered=False, debug=True)
+    with torch.no_grad(), pytest.raises(Exception):      # degree 3 asked of a model that stores one coefficient
+        GaussianRasterizer(rs)(means3D=model.get_xyz, means2D=torch.zeros_like(model.get_xyz), opacities=model.get_opacity,
+                               shs=model.get_features, scales=model.get_scaling, rotations=model.get_rotation)
+    dump = torch.load(tmp_path / "snapshot_fw.dump", weights_only=False)
+    assert len(dump) == 19 and not dump[1].is_cuda and dump[1].shape == model.get_xyz.shape
