@@ -26,14 +26,39 @@ def search_for_max_iteration(folder):
     return max(int(name.split("_")[-1]) for name in os.listdir(folder))
 
 
-def camera_from_info(uid, info, resolution=-1, data_device="cuda"):
-    """CameraInfo -> Camera (reference utils/camera.py loadCam): image to [3,H,W] in 0..1, optional alpha as a mask
-    multiplier, integer downscale factors through PIL; resolution -1 / 1 keeps the native size."""
+_WARNED_LARGE = [False]
+
+
+def target_size(orig_w, orig_h, resolution, resolution_scale=1.0):
+    """The reference's image size rule (scene/cameras.py:136-160): --resolution 1 / 2 / 4 / 8 divides both sides (rounded);
+    -1 keeps the size unless the image is wider than 1600 px, which is then scaled to 1600 wide (with a one-time notice);
+    any other value is the target WIDTH.  (True 1080p therefore needs -r 1.)"""
+    if resolution in (1, 2, 4, 8):
+        return round(orig_w / (resolution_scale * resolution)), round(orig_h / (resolution_scale * resolution))
+    if resolution == -1:
+        if orig_w > 1600:
+            if not _WARNED_LARGE[0]:
+                print("[ INFO ] Encountered quite large input images (>1.6K pixels width), rescaling to 1.6K.\n "
+                      "If this is not desired, please explicitly specify '--resolution/-r' as 1")
+                _WARNED_LARGE[0] = True
+            down = orig_w / 1600
+        else:
+            down = 1
+    else:
+        down = orig_w / resolution
+    scale = float(down) * float(resolution_scale)
+    return int(orig_w / scale), int(orig_h / scale)
+
+
+def camera_from_info(uid, info, resolution=-1, data_device="cuda", resolution_scale=1.0):
+    """CameraInfo -> Camera (reference scene/cameras.py _loadCam): image to [3,H,W] in 0..1 at the size of target_size(),
+    optional alpha as a mask multiplier; the mask / orientation planes follow the image's size (nearest neighbour) where they
+    differ -- the reference hands them over as they are."""
     img = info.image
     w, h = img.size
-    scale = 1 if resolution in (-1, 1) else int(resolution)
-    if scale != 1:
-        img = img.resize((round(w / scale), round(h / scale)))
+    tw, th = target_size(w, h, resolution, resolution_scale)
+    if (tw, th) != (w, h):
+        img = img.resize((tw, th))
     arr = torch.from_numpy(np.asarray(img, dtype=np.float32) / 255.0)
     arr = arr[..., None] if arr.ndim == 2 else arr
     arr = arr.permute(2, 0, 1)
@@ -43,7 +68,7 @@ def camera_from_info(uid, info, resolution=-1, data_device="cuda"):
         if a is None:
             return None
         t = torch.from_numpy(np.ascontiguousarray(a))
-        if scale != 1:
+        if tuple(t.shape[-2:]) != tuple(rgb.shape[1:]):
             t = torch.nn.functional.interpolate(t[None, None].float(), size=rgb.shape[1:], mode="nearest")[0, 0]
         return t.to(dtype)
     return Camera(colmap_id=info.uid, R=info.R, T=info.T, FoVx=info.FovX, FoVy=info.FovY, image=rgb, gt_alpha_mask=alpha,
@@ -83,7 +108,7 @@ class Scene:
             random.shuffle(cams)
         self.cameras_extent = info.nerf_normalization["radius"]
         dev = getattr(args, "data_device", "cuda")
-        self.cameras = {s: [camera_from_info(i, c, getattr(args, "resolution", -1), dev) for i, c in enumerate(cams)]
+        self.cameras = {s: [camera_from_info(i, c, getattr(args, "resolution", -1), dev, resolution_scale=s) for i, c in enumerate(cams)]
                         for s in resolution_scales}
         if self.loaded_iter is None:
             self.gaussians = GaussianModel(args.sh_degree, self.cameras_extent, device=dev)

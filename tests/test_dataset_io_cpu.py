@@ -116,3 +116,17 @@ def test_orientation_colour_wheel():
     for px, want in zip(vis[0], ([255, 0, 0], [0, 255, 0], [0, 0, 255], [0, 255, 255])):
         assert np.abs(px.astype(int) - np.array(want)).max() <= 9, (px, want)
     assert orientation_map_to_vis(th, np.ones_like(th)).max() == 0
+
+
+def test_image_size_rule_of_the_reference():
+    """scene/cameras.py:136-160: -r 1 / 2 / 4 / 8 divide; -1 keeps the size up to 1600 px of width and scales wider images to
+    1600; any other value is the target width."""
+    from scene.scene import target_size
+    assert target_size(1920, 1080, -1) == (1600, 900)
+    assert target_size(1920, 1080, 1) == (1920, 1080)
+    assert target_size(1000, 800, -1) == (1000, 800)
+    assert target_size(1920, 1080, 2) == (960, 540)
+    assert target_size(1920, 1080, 800) == (800, 450)
+    assert target_size(1001, 801, 2) == (round(1001 / 2), round(801 / 2))
+    assert target_size(1920, 1080, 1, resolution_scale=2.0) == (960, 540)
+
