@@ -617,7 +617,11 @@ def training(gaussians, cameras, opt, iterations=None, extent=1.0, seed=0, log_e
                         getattr(opt, "collective_in_graph", True) and vp.graph_collective_ok()))) else 1
                     gs = GraphedStep(gaussians, cameras, opt, bg, extent=extent, vp=vp, views=views, steps_per_graph=many,
                                      slack=float(getattr(opt, "capacity_slack", 2.0)))
-                    gs.capture(cameras, iteration=it)
+                    # warm-up on a spread of the views (allocator, lazy loads, a capacity estimate): a view that needs more than
+                    # slack x their largest instance count is caught by the headroom check and rolled back exactly, so the
+                    # capture need not render every camera first (32 eager iterations per re-capture at north_star)
+                    nw = min(len(cameras), int(getattr(opt, "capture_warmup_views", 4)))
+                    gs.capture([cameras[(k * len(cameras)) // nw] for k in range(nw)], iteration=it)
                     ckpt = _Checkpoint(gaussians, sampler, ema, it - 1)    # (eager steps are exact: they repeat on overflow)
                 K = gs.steps_per_graph
                 if K > 1 and it + K - 1 <= last and not (topology and any(topology_due(gaussians, opt, j) for j in range(it + 1, it + K))):
