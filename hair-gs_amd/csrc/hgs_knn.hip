@@ -347,3 +347,43 @@ extern "C" int hgs_knn3(void* stream, int N, const float* points, int* idx, floa
   HGS_CHECK_LAUNCH();
   return 0;
 }
+
+// ---- distance to the nearest of a small set of reference points, in float64 ------------------------------------------------
+// What compute_strands_info asks a scipy cKDTree of the reference strand roots for (scene/hair_gaussian_model.py:1466-1470: the
+// two ends of every strand, to orient it root -> tip): a few thousand roots against 10^5-10^6 strand ends.  One lane per point,
+// the roots staged through LDS in float64; the distance is sqrt(dx^2 + dy^2 + dz^2) evaluated in float64 in that order (what a
+// brute force over the tree's points gives).  torch.cdist's float64 kernel took 8 ms per call for this shape -- a third of the
+// GPU time of a training run with the topology operators.
+#define ND_TILE 1024
+__global__ __launch_bounds__(256) void nearest_dist_f64_kernel(int N, int M, const float* __restrict__ pts, const double* __restrict__ refs,
+                                                               double* __restrict__ out) {
+#pragma clang fp contract(off)
+  __shared__ double r[ND_TILE * 3];
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  const bool live = i < N;
+  const double px = live ? (double)pts[3 * (size_t)i] : 0.0, py = live ? (double)pts[3 * (size_t)i + 1] : 0.0,
+               pz = live ? (double)pts[3 * (size_t)i + 2] : 0.0;
+  double best = __builtin_inf();
+  for (int m0 = 0; m0 < M; m0 += ND_TILE) {
+    const int cnt = min(ND_TILE, M - m0);
+    __syncthreads();
+    for (int k = threadIdx.x; k < cnt * 3; k += 256) r[k] = refs[(size_t)m0 * 3 + k];
+    __syncthreads();
+    for (int k = 0; k < cnt; k++) {
+      const double dx = px - r[3 * k], dy = py - r[3 * k + 1], dz = pz - r[3 * k + 2];
+      const double d2 = dx * dx + dy * dy + dz * dz;
+      best = d2 < best ? d2 : best;
+    }
+  }
+  if (live) out[i] = sqrt(best);
+}
+
+extern "C" int hgs_nearest_distance_f64(void* stream, int N, int M, const float* points, const double* refs, double* out) {
+  if (N < 0 || M < 0) { hgs_set_error("hgs_nearest_distance_f64: bad sizes"); return 1; }
+  if (N == 0) return 0;
+  if (M == 0 || !points || !refs || !out) { hgs_set_error("hgs_nearest_distance_f64: no reference points / null argument"); return 1; }
+  hipLaunchKernelGGL(nearest_dist_f64_kernel, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, N, M, points, refs, out);
+  HGS_CHECK_LAUNCH();
+  return 0;
+}
+

@@ -75,6 +75,7 @@ SIGNATURES = {
     "hgs_densify_stats": (ci, [vp, ci, vp, vp, ci, vp, vp, vp]),
     "hgs_radius_pairs": (ci, [vp, ci, vp, vp, cf, cf, ci, ci, vp, vp, vp, ci]),
     "hgs_knn3": (ci, [vp, ci, vp, vp, vp]),
+    "hgs_nearest_distance_f64": (ci, [vp, ci, ci, vp, vp, vp]),
     "hgs_set_tile_cull": (ci, [ci]),
     "hgs_set_segment_policy": (ci, [ci, ci, ci]),
     "hgs_debug_set_wg_trace": (ci, [vp, vp]),

@@ -165,6 +165,17 @@ def nearest_distance(points, refs, chunk=65536):
     scipy cKDTree for, :1466-1470; a few thousand roots against 10^5-10^6 strand ends is milliseconds on the GPU).
     torch.cdist in its difference form (no matrix-multiply expansion: exact to rounding like the tree's distances)."""
     refs = refs.to(torch.float64)
+    if points.is_cuda and points.dtype == torch.float32 and refs.shape[0] > 0:
+        # hgs_nearest_distance_f64: one lane per point, the references through LDS (torch.cdist's float64 kernel needs 8 ms for
+        # 6 10^5 ends against 10^3 roots: it was a third of the GPU time of a run with the topology operators)
+        import hgs_runtime as rt
+        pts = points.contiguous()
+        refs_c = refs.to(points.device).contiguous()
+        out = torch.empty(pts.shape[0], dtype=torch.float64, device=pts.device)
+        with torch.cuda.device(pts.device):
+            rt.check(rt.lib().hgs_nearest_distance_f64(rt.current_stream(), pts.shape[0], refs_c.shape[0], rt.ptr(pts), rt.ptr(refs_c),
+                                                       rt.ptr(out)))
+        return out
     out = torch.empty(points.shape[0], dtype=torch.float64, device=points.device)
     for s in range(0, points.shape[0], chunk):
         p = points[s:s + chunk].to(torch.float64)

@@ -442,6 +442,10 @@ int hgs_radius_pairs(void* stream, int N, const float* pos, const float* dir, fl
  *   included (first, at distance 0); equal distances in ascending index order; fewer than 3 points: index -1, distance
  *   +inf.  Brute force through LDS tiles: the ends move every iteration and number in the thousands. */
 int hgs_knn3(void* stream, int N, const float* points, int* idx /* [N,3] */, float* dist2 /* [N,3] */);
+/* hgs_nearest_distance_f64 <-> scipy cKDTree(refs).query(points, k=1)[0] as compute_strands_info uses it on the strands' ends
+ *   (scene/hair_gaussian_model.py:1466-1470): out[i] = min_m |points[i] - refs[m]| in float64 (points float32 [N,3], refs
+ *   float64 [M,3], M >= 1). */
+int hgs_nearest_distance_f64(void* stream, int N, int M, const float* points, const double* refs, double* out);
 
 /* Tile culling (default on).  The reference gives every Gaussian the tiles of its 3-sigma square (forward.cu:229-235,
  * auxiliary.h:46-56) although a pixel only blends it where opacity * exp(power) >= 1/255 (forward.cu:358): with culling on,

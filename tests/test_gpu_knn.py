@@ -144,3 +144,26 @@ def test_c1_merge_at_size_gpu_model_equals_cpu_model():
     assert r_cpu == r_gpu and h_gpu.strands_info.n_strands == h_cpu.strands_info.n_strands == 50
     assert np.abs(np.asarray(s_cpu) - np.asarray(s_gpu)).max() <= 2e-5
     assert h_gpu._endpoints.is_cuda and h_gpu.get_xyz.shape[0] == 1000
+
+
+@pytest.mark.parametrize("N,M", [(1, 1), (1000, 7), (70001, 1000), (300, 2500)])
+def test_nearest_distance_f64_matches_the_tree(N, M):
+    """hgs_nearest_distance_f64 (what orients every strand root -> tip, scene/hair_gaussian_model.py:1466-1470) against
+    scipy cKDTree(refs).query(points)[0] and the float64 brute force: the same distances to the last bit of the brute force,
+    1 ulp of the tree's."""
+    import torch
+    from scipy.spatial import cKDTree
+    from scene.hair_gaussian_model import nearest_distance
+    rng = np.random.default_rng(N + M)
+    pts = rng.normal(size=(N, 3)).astype(np.float32)
+    refs = rng.normal(size=(M, 3))
+    if N >= 1000:
+        pts[:50] = refs[:50 % M or 1][0].astype(np.float32)       # points (nearly) on a reference
+    got = nearest_distance(torch.from_numpy(pts).cuda(), torch.from_numpy(refs).cuda()).cpu().numpy()
+    d = pts.astype(np.float64)[:, None, :] - refs[None, :, :] if N * M <= 4_000_000 else None
+    tree = cKDTree(refs).query(pts.astype(np.float64), k=1)[0]
+    assert np.abs(got - tree).max() <= 4e-16 * max(1.0, np.abs(tree).max())
+    if d is not None:
+        brute = np.sqrt((d[..., 0] * d[..., 0] + d[..., 1] * d[..., 1]) + d[..., 2] * d[..., 2]).min(axis=1)
+        np.testing.assert_array_equal(got, brute)
+

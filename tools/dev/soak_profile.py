@@ -19,7 +19,7 @@ pr = cProfile.Profile(); pr.enable()
 training(model, cams, opt, iterations=iters, extent=extent, start_iteration=100)
 torch.cuda.synchronize()
 pr.disable()
-st = pstats.Stats(pr); st.sort_stats("cumulative").print_stats(int(os.environ.get("TOP", "45")))
+st = pstats.Stats(pr); st.strip_dirs(); st.sort_stats(os.environ.get("SORT", "cumulative")).print_stats(int(os.environ.get("TOP", "45")))
 for fn in os.environ.get("CALLEES", "").split(","):
     if fn:
         st.print_callees(fn)
