@@ -70,3 +70,17 @@ def test_two_ranks_through_the_topology_operators():
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
     assert "VP_TOPOLOGY_OK" in out.stdout
+
+
+def test_two_ranks_roll_a_capacity_overflow_back_together():
+    """training() on two ranks with a captured binning capacity that is too small: the headroom check takes the maximum over the
+    ranks, both return to the same checkpoint, re-capture and run the iterations again -- and end like a run that never
+    overflowed, bit for bit, identically on both ranks."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    worker = os.path.join(ROOT, "tests", "_vp_rollback_worker.py")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29543", worker]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+    assert "VP_ROLLBACK_OK" in out.stdout
+
