@@ -282,6 +282,9 @@ class HairGaussianModel(HairTopologyMixin, GaussianModel):
         without one).  Returns (segment permutation, endpoint permutation) as applied, or None if nothing moved."""
         if self.strands_info is None or self.endpoint_pairs.numel() == 0:
             return None
+        if self._endpoints.is_cuda and getattr(self, "_strands_dev", None) is not None \
+                and self._strands_dev[0].numel() == len(self.strands_info.offsets):
+            return self._sort_spatially_device(bits)
         seg_perm, ep_perm = self.storage_order(bits)
         if np.array_equal(seg_perm, np.arange(seg_perm.size)) and np.array_equal(ep_perm, np.arange(ep_perm.size)):
             return None
@@ -289,24 +292,8 @@ class HairGaussianModel(HairTopologyMixin, GaussianModel):
         sp, epp = torch.as_tensor(seg_perm, device=dev), torch.as_tensor(ep_perm, device=dev)
         inv_ep = torch.empty_like(epp)
         inv_ep[epp] = torch.arange(epp.numel(), device=dev)
-        self.endpoint_pairs = inv_ep[self.endpoint_pairs[sp]]
-        if torch.is_tensor(self.strand_root_endpoint_idx) and self.strand_root_endpoint_idx.numel():
-            self.strand_root_endpoint_idx = torch.sort(inv_ep[self.strand_root_endpoint_idx.to(dev)]).values
-        if self.optimizer is not None:
-            out = {}
-            for g in self.optimizer.param_groups:
-                perm = epp if g["name"] == "endpoints" else sp
-                out[g["name"]] = self._swap_param(g, g["params"][0].detach()[perm], lambda m, k=perm: m[k])
-            self._rebind(out)
-        else:
-            for name, attr in self._PARAM_ATTRS:
-                perm = epp if name == "endpoints" else sp
-                setattr(self, attr, nn.Parameter(getattr(self, attr).detach()[perm].requires_grad_(True)))
-        for attr in ("xyz_gradient_accum", "denom", "max_radii2D"):
-            t = getattr(self, attr, None)
-            if torch.is_tensor(t) and t.shape[0] == sp.shape[0]:
-                setattr(self, attr, t[sp])
-        self._smooth_pairs = None
+        self._apply_storage_permutation(sp, epp, inv_ep)
+        self._strands_dev = None
         # The strands themselves did not change: their bookkeeping is renumbered instead of walked again (at 4 10^5 segments a
         # walk + the root distances cost 75 ms, and this runs at every densification and merge).  In the new numbering a
         # strand's vertices are consecutive ids, root first, and the strands follow each other in storage order -- which is
@@ -329,7 +316,89 @@ class HairGaussianModel(HairTopologyMixin, GaussianModel):
         self._order_aux = None
         return seg_perm, ep_perm
 
+    def _sort_spatially_device(self, bits=10):
+        """sort_spatially for a model on the GPU, without leaving it: the same permutations and the same renumbered strand
+        bookkeeping as storage_order() + the host code above (tests/test_gpu_train.py compares them), from the device copies of
+        the strand tables that compute_strands_info keeps.  (The numpy form took 88 ms at 3 10^5 segments -- most of what a
+        densification / merge event cost; this one a few.)"""
+        dev = self._endpoints.device
+        offsets, rows, seg_full = self._strands_dev
+        P, E = int(self.endpoint_pairs.shape[0]), int(self._endpoints.shape[0])
+        S, total = int(offsets.numel()) - 1, int(rows.shape[0])
+        if S == 0 or total == 0:
+            return None
+        i64 = dict(dtype=torch.int64, device=dev)
+        ep = self._endpoints.detach()
+        first = ep[rows[offsets[:-1], 0]]
+        lo, hi = first.min(dim=0).values, first.max(dim=0).values
+        top = (1 << bits) - 1
+        q = ((first - lo) / torch.clamp_min(hi - lo, 1e-20) * top).to(torch.int64).clamp_(0, top)
+        code = torch.zeros(S, **i64)
+        for b in range(bits):
+            for a in range(3):
+                code |= ((q[:, a] >> b) & 1) << (3 * b + a)
+        order = torch.argsort(code, stable=True)
+        lens = (offsets[1:] - offsets[:-1])[order]
+        new_off = torch.zeros(S + 1, **i64)
+        torch.cumsum(lens, dim=0, out=new_off[1:])
+        ar_s, ar_t = torch.arange(S, **i64), torch.arange(total, **i64)
+        sid = torch.repeat_interleave(ar_s, lens, output_size=total)
+        src = torch.repeat_interleave(offsets[:-1][order], lens, output_size=total) + \
+            (ar_t - torch.repeat_interleave(new_off[:-1], lens, output_size=total))
+        rows_o = rows[src]
+        seg_in = seg_full[src]
+        rest = torch.ones(P, dtype=torch.bool, device=dev)
+        rest[seg_in] = False
+        sp = torch.cat([seg_in, torch.nonzero(rest).squeeze(1)])
+        ep_in = torch.empty(total + S, **i64)
+        ep_in[ar_t + sid] = rows_o[:, 0]
+        ep_in[new_off[1:] + ar_s] = rows_o[new_off[1:] - 1, 1]
+        rest_e = torch.ones(E, dtype=torch.bool, device=dev)
+        rest_e[ep_in] = False
+        epp = torch.cat([ep_in, torch.nonzero(rest_e).squeeze(1)])
+        if bool(torch.equal(sp, torch.arange(P, **i64))) and bool(torch.equal(epp, torch.arange(E, **i64))):
+            return None
+        inv_ep = torch.empty_like(epp)
+        inv_ep[epp] = torch.arange(E, **i64)
+        self._apply_storage_permutation(sp, epp, inv_ep)
+        # the strands' bookkeeping, renumbered (see sort_spatially)
+        rows_new = inv_ep[rows_o]
+        i2s = torch.full((E,), -1, dtype=torch.int32, device=dev)
+        sid32 = sid.to(torch.int32)
+        i2s[rows_new[:, 0]] = sid32
+        i2s[rows_new[:, 1]] = sid32
+        comp = torch.full((E,), -1, dtype=torch.int32, device=dev)
+        starts, ends = rows_new[new_off[:-1], 0], rows_new[new_off[1:] - 1, 1]
+        comp[starts], comp[ends] = ends.to(torch.int32), starts.to(torch.int32)
+        self.strands_info = StrandsInfo(new_off.cpu().numpy(), rows_new.cpu().numpy(), np.arange(total, dtype=np.int64),
+                                        i2s.cpu().numpy(), comp.cpu().numpy())
+        self._strands_dev = (new_off, rows_new, ar_t)
+        return sp.cpu().numpy(), epp.cpu().numpy()
+
+    def _apply_storage_permutation(self, sp, epp, inv_ep):
+        """Parameters, Adam moments, statistics and id tables into the order (sp: segments, epp: endpoints); device tensors."""
+        dev = self._endpoints.device
+        self.endpoint_pairs = inv_ep[self.endpoint_pairs[sp]]
+        if torch.is_tensor(self.strand_root_endpoint_idx) and self.strand_root_endpoint_idx.numel():
+            self.strand_root_endpoint_idx = torch.sort(inv_ep[self.strand_root_endpoint_idx.to(dev)]).values
+        if self.optimizer is not None:
+            out = {}
+            for g in self.optimizer.param_groups:
+                perm = epp if g["name"] == "endpoints" else sp
+                out[g["name"]] = self._swap_param(g, g["params"][0].detach()[perm], lambda m, k=perm: m[k])
+            self._rebind(out)
+        else:
+            for name, attr in self._PARAM_ATTRS:
+                perm = epp if name == "endpoints" else sp
+                setattr(self, attr, nn.Parameter(getattr(self, attr).detach()[perm].requires_grad_(True)))
+        for attr in ("xyz_gradient_accum", "denom", "max_radii2D"):
+            t = getattr(self, attr, None)
+            if torch.is_tensor(t) and t.shape[0] == sp.shape[0]:
+                setattr(self, attr, t[sp])
+        self._smooth_pairs = None
+
     _storage_dirty = False
+    _strands_dev = None
 
     def _maybe_sort_spatially(self):
         """training_args.spatial_sort (default on) for a model on the GPU, once the operators of an iteration have changed
@@ -570,17 +639,22 @@ class HairGaussianModel(HairTopologyMixin, GaussianModel):
         if self._endpoints.is_cuda:
             # on the device; only the results come to the host
             pairs_t = self.endpoint_pairs
-            if only_foreground:
-                pairs_t = pairs_t[self.compute_foreground_mask()]
             ep = self._endpoints.detach()
             roots = torch.as_tensor(np.asarray(self.ref_strand_root), device=ep.device)
             chunk = max(1024, (1 << 27) // max(1, roots.shape[0]))       # <= 1 GiB of float64 distances at a time
+            fg_rows = None
+            if only_foreground:
+                fg_rows = torch.nonzero(self.compute_foreground_mask()).squeeze(1)
+                pairs_t = self.endpoint_pairs[fg_rows]
             offsets, rows, seg_rows, i2s, comp = walk_chains_torch(
                 pairs_t, ep.shape[0], lambda ids: nearest_distance(ep[ids], roots, chunk))
             self.strands_info = StrandsInfo(offsets.cpu().numpy(), rows.cpu().numpy(), seg_rows.cpu().numpy(),
                                             i2s.cpu().numpy(), comp.cpu().numpy())
+            # device copies for sort_spatially (offsets, rows, the row of endpoint_pairs behind every strand row)
+            self._strands_dev = (offsets, rows, seg_rows if fg_rows is None else fg_rows[seg_rows])
             self._smooth_pairs = None
             return
+        self._strands_dev = None
         from scipy.spatial import cKDTree
         tree = cKDTree(np.asarray(self.ref_strand_root))
         endpoints = self._endpoints.detach().cpu().numpy()

@@ -1415,3 +1415,45 @@ def test_debug_mode_snapshots_the_inputs_of_a_failing_call(tmp_path, monkeypatch
                                shs=model.get_features, scales=model.get_scaling, rotations=model.get_rotation)
     dump = torch.load(tmp_path / "snapshot_fw.dump", weights_only=False)
     assert len(dump) == 19 and not dump[1].is_cuda and dump[1].shape == model.get_xyz.shape
+
+
+def test_device_storage_sort_equals_the_host_form():
+    """sort_spatially on a GPU model runs on the device (HairGaussianModel._sort_spatially_device); it applies the permutations of
+    storage_order() -- the numpy form, which CPU models keep -- and leaves the same renumbered strand tables, parameters, Adam
+    moments and statistics.  Checked on a model whose storage the topology operators have scrambled."""
+    from arguments import OptimizationParams
+    from synthetic import build_workload
+    from train import training
+    from utils.general import safe_state
+    import copy
+    safe_state(True)
+    model, cams, extent = build_workload("tiny", device="cuda", with_targets=True)
+    opt = OptimizationParams()
+    opt.spatial_sort = False                          # leave the operators' appended segments where they are
+    opt.densify_from_iter, opt.densification_interval, opt.merge_interval, opt.opacity_reset_interval = 3, 6, 8, 12
+    model.training_setup(opt)
+    training(model, cams, opt, iterations=20, extent=extent)
+    model.compute_strands_info()
+    ref = copy.deepcopy(model)
+    assert model._strands_dev is not None
+    dev_perms = model.sort_spatially()                # device form
+    ref._strands_dev = None
+    host_perms = ref.sort_spatially()                 # numpy form (no device tables: storage_order)
+    assert dev_perms is not None and host_perms is not None
+    for a, b in zip(dev_perms, host_perms):
+        assert np.array_equal(a, b)
+    assert torch.equal(model.endpoint_pairs, ref.endpoint_pairs)
+    for ga, gb in zip(model.optimizer.param_groups, ref.optimizer.param_groups):
+        pa, pb = ga["params"][0], gb["params"][0]
+        assert torch.equal(pa, pb)
+        if pa.numel():
+            assert torch.equal(model.optimizer.state[pa]["exp_avg"], ref.optimizer.state[pb]["exp_avg"])
+    for attr in ("xyz_gradient_accum", "denom", "max_radii2D", "strand_root_endpoint_idx"):
+        assert torch.equal(getattr(model, attr), getattr(ref, attr)), attr
+    for a in ("offsets", "rows", "segment_rows", "id_to_strand_id", "strand_endpoint_id_to_complementary"):
+        assert np.array_equal(np.asarray(getattr(model.strands_info, a)), np.asarray(getattr(ref.strands_info, a))), a
+    assert model.sort_spatially() is None             # nothing left to move, and the kept device tables say so too
+    kept = model.strands_info
+    model.compute_strands_info()
+    for a in ("offsets", "rows", "id_to_strand_id", "strand_endpoint_id_to_complementary"):
+        assert np.array_equal(np.asarray(getattr(kept, a)), np.asarray(getattr(model.strands_info, a))), a
