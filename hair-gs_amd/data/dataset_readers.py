@@ -116,7 +116,10 @@ def readColmapSceneInfo(path, images=None, llffhold=8):
             xyz, rgb, _ = read_points3D_binary(os.path.join(sparse, "points3D.bin"))
         else:
             xyz, rgb, _ = read_points3D_text(os.path.join(sparse, "points3D.txt"))
-        storePly(ply_path, xyz, rgb)
+        # (written under a private name and renamed: another rank of a view-parallel run may be looking for the file now)
+        tmp = f"{ply_path}.{os.getpid()}.tmp"
+        storePly(tmp, xyz, rgb)
+        os.replace(tmp, ply_path)
     try:
         pcd = fetchPly(ply_path)
     except Exception:

@@ -767,7 +767,13 @@ def main(argv=None):
         os.makedirs(args.model_path, exist_ok=True)
         with open(os.path.join(args.model_path, "cfg_args"), "w") as fh:   # what render.py's get_combined_args reads back
             fh.write(str(args))
+    # rank 0 prepares the capture first (it converts the sparse points to a PLY once and writes the model directory's
+    # input.ply / cameras.json); the other ranks read what it left
+    if world > 1 and rank != 0:
+        dist.barrier()
     scene = Scene(mp.extract(args))
+    if world > 1 and rank == 0:
+        dist.barrier()
     opt = op.extract(args)
     g = scene.gaussians
     g.training_setup(opt)
