@@ -92,3 +92,13 @@ def blend_work_list(scene, fw):
     T = ((W + 15) // 16) * ((H + 15) // 16)
     lay = rt.layout("image", W, H)
     return _view(fw["img"], lay["tile_order"], T + max(T, 1024), np.uint32)
+
+
+def free_port():
+    """A TCP port nobody listens on right now (rendezvous of the multi-process tests: fixed numbers collide with whatever else
+    runs on the box, or with the previous test's socket)."""
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+

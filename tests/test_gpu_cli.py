@@ -95,12 +95,13 @@ def test_train_cli_on_two_ranks(tmp_path):
     densification and an opacity reset; rank 0 alone writes the model directory (cfg_args, input.ply, cameras.json, the
     checkpoints) and both ranks end with the same cloud, bit for bit."""
     import subprocess
+    from tests.gpu_util import free_port
     from tests.test_dataset_io_cpu import _write_capture
     src, model = tmp_path / "capture", tmp_path / "out"
     _write_capture(src, n_views=4, W=64, H=48)
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0", HGS_DIST_BACKEND="gloo")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29551", os.path.join(ROOT, "tests", "_train_cli_worker.py"), str(src), str(model)]
+           "--master-port", str(free_port()), os.path.join(ROOT, "tests", "_train_cli_worker.py"), str(src), str(model)]
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
     assert "TRAIN_CLI_RANK_0_OK" in out.stdout and "TRAIN_CLI_RANK_1_OK" in out.stdout

@@ -13,7 +13,9 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
 
 
-def _run(nproc, port, mode="weak", global_views=None):
+def _run(nproc, port=None, mode="weak", global_views=None):
+    from tests.gpu_util import free_port
+    port = free_port()
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0", HGS_VP_MODE=mode)
     if global_views is not None:
         env["HGS_VP_GLOBAL_VIEWS"] = str(global_views)
@@ -50,7 +52,8 @@ def test_step_graph_with_the_exchange_inside():
     a 1-rank nccl (= RCCL) group, the world size faked to 2 for the code path, the reduction itself over one rank.  Ten
     optimizer steps (two 4-step launches + two single steps) equal the single-rank run bit for bit.  What one GPU cannot
     show is the transport: DESIGN.md section 7."""
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    from tests.gpu_util import free_port
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free_port()))
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
         env.pop(k, None)
     out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "_rccl_graph_worker.py")], env=env, capture_output=True,
@@ -63,10 +66,11 @@ def test_two_ranks_through_the_topology_operators():
     """training() on two ranks (one view per rank and step, graph replays) THROUGH densification, merging and the opacity reset:
     every rank ends with the same segments, endpoints, strands, parameters and Adam moments, bit for bit (the
     operators' statistics are reduced over the ranks, their random draws are seeded alike)."""
+    from tests.gpu_util import free_port
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     worker = os.path.join(ROOT, "tests", "_vp_topology_worker.py")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29541", worker]
+           "--master-port", str(free_port()), worker]
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
     assert "VP_TOPOLOGY_OK" in out.stdout
@@ -76,10 +80,11 @@ def test_two_ranks_roll_a_capacity_overflow_back_together():
     """training() on two ranks with a captured binning capacity that is too small: the headroom check takes the maximum over the
     ranks, both return to the same checkpoint, re-capture and run the iterations again -- and end like a run that never
     overflowed, bit for bit, identically on both ranks."""
+    from tests.gpu_util import free_port
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     worker = os.path.join(ROOT, "tests", "_vp_rollback_worker.py")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29543", worker]
+           "--master-port", str(free_port()), worker]
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
     assert "VP_ROLLBACK_OK" in out.stdout
