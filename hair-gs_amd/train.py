@@ -636,6 +636,15 @@ def training(gaussians, cameras, opt, iterations=None, extent=1.0, seed=0, log_e
                 if gs is None:
                     many = steps_per_graph if (fused is not None and (vp.world == 1 or (
                         getattr(opt, "collective_in_graph", True) and vp.graph_collective_ok()))) else 1
+                    # A K-step graph saves (1 - 1/K) of the ~8 us a graph launch idles the GPU (~7 us per iteration at K = 8) and
+                    # costs K more captured iterations (~1.3 ms each) per re-capture: it pays for runs of more than ~1500 plain
+                    # iterations.  Between two topology events of the default schedule (100 iterations) it does not: 10 ms per event.
+                    if many > 1:
+                        need, run = int(getattr(opt, "multi_step_graph_min_run", 1500)), 0
+                        while it + run <= last and run < need and not (topology and topology_due(gaussians, opt, it + run)):
+                            run += 1
+                        if run < need:
+                            many = 1
                     gs = GraphedStep(gaussians, cameras, opt, bg, extent=extent, vp=vp, views=views, steps_per_graph=many,
                                      slack=float(getattr(opt, "capacity_slack", 2.0)))
                     # warm-up on a spread of the views (allocator, lazy loads, a capacity estimate): a view that needs more than
