@@ -604,14 +604,23 @@ class HairGaussianModel(HairTopologyMixin, GaussianModel):
         self.endpoint_pairs = remap[self.endpoint_pairs]
         if torch.is_tensor(self.strand_root_endpoint_idx) and self.strand_root_endpoint_idx.numel():
             self.strand_root_endpoint_idx = remap[self.strand_root_endpoint_idx]
+        # (a call that keeps every segment -- the reference's id compaction, twice per round of merge_collapsed_segments -- or
+        # every endpoint leaves those tensors as they are: a masked copy of all rows is the same rows)
+        all_seg, all_ep = bool(seg_keep.all()), bool(ep_keep.all())
         out = {}
         for g in self.optimizer.param_groups:
-            keep = ep_keep if g["name"] == "endpoints" else seg_keep
+            is_ep = g["name"] == "endpoints"
+            if all_ep if is_ep else all_seg:
+                g["params"][0].grad = None      # (a re-created parameter has no gradient: it skips this iteration's Adam step)
+                continue
+            keep = ep_keep if is_ep else seg_keep
             out[g["name"]] = self._swap_param(g, g["params"][0][keep], lambda m, k=keep: m[k])
-        self._rebind(out)
-        self.xyz_gradient_accum = self.xyz_gradient_accum[seg_keep]
-        self.denom = self.denom[seg_keep]
-        self.max_radii2D = self.max_radii2D[seg_keep]
+        if out:
+            self._rebind(out)
+        if not all_seg:
+            self.xyz_gradient_accum = self.xyz_gradient_accum[seg_keep]
+            self.denom = self.denom[seg_keep]
+            self.max_radii2D = self.max_radii2D[seg_keep]
         self._smooth_pairs = None
 
     # ---- strand bookkeeping ----------------------------------------------------------------------
