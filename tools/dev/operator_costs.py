@@ -40,3 +40,19 @@ timed("prune_strategy", lambda: model.prune_strategy(extent, None, {}, avoid_con
 timed("compute_strands_info (after)", lambda: model.compute_strands_info(), n=1)
 timed("sort_spatially", lambda: model.sort_spatially(), n=1)
 timed("merging", lambda: model.merging(), n=1)
+
+# ---- re-capture cost on this model (no topology change in between: the allocator holds blocks of the right sizes)
+from train import GraphedStep
+from hgs_runtime.strand_step import ViewTable
+from diff_gaussian_rasterization import _C as raster
+bg = torch.zeros(3, device="cuda")
+views = ViewTable(cams)
+for rep in range(3):
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    gs = GraphedStep(model, cams, opt, bg, extent=extent, views=views, steps_per_graph=1)
+    t1 = time.perf_counter()
+    gs.capture([cams[0], cams[4], cams[8], cams[12]], iteration=2000)
+    torch.cuda.synchronize(); t2 = time.perf_counter()
+    print(f"GraphedStep() {1e3 * (t1 - t0):6.1f} ms   capture (4 warm-up views + 1 captured iteration) {1e3 * (t2 - t1):6.1f} ms")
+    gs = None
+raster.set_async(False)
