@@ -37,7 +37,6 @@
 //     boundary) and, for the segments a pixel passes through, c alpha T_local T_in in place of c alpha T (one rounding
 //     per contribution).  Integer results (last contributor) follow the reference's rules on those products.
 #include "hgs_common.h"
-#include <stdlib.h>
 
 // development aid: per-workgroup start/end timestamps (hgs_debug_set_wg_trace)
 __device__ unsigned long long* g_wg_trace_fwd = nullptr;
@@ -227,7 +226,7 @@ __device__ __forceinline__ void fwd_walk(const float4* __restrict__ src, uint32_
     const int cnt = min(REC_BATCH, (int)L - b * REC_BATCH);
     const float* rf = (const float*)&recs[cur][0];
     const uint32_t mk = lane < cnt ? __float_as_uint(rf[lane * 4 * REC4 + 7 + C]) : 0u;
-    uint64_t m = __ballot((mk & HGS_BMASK_QUADRANT(wave)) != 0u);
+    uint64_t m = __ballot(((mk >> wave) & 1u) != 0u);
     if (__ballot(T > 0.f) == 0) m = 0;
     bool wave_done = false;   // every pixel of this wavefront saturated: leave the batch
     auto process = [&](const Rec<C>& r, int ent) {
@@ -560,7 +559,7 @@ __global__ __launch_bounds__(HGS_BLOCK) __attribute__((amdgpu_waves_per_eu(HGS_B
     }
     const float* rf = (const float*)&recs[cur][0];
     const uint32_t mk = lane < cnt ? __float_as_uint(rf[lane * 4 * REC4 + 7 + C]) : 0u;
-    uint64_t m = __ballot((mk & HGS_BMASK_QUADRANT(wave)) != 0u);
+    uint64_t m = __ballot(((mk >> wave) & 1u) != 0u);
     // positions at or past this wavefront's last contributor cannot be valid for any of its pixels
     if ((int)wlast <= lo) m = 0;
     else if ((int)wlast - lo < 64) m &= (1ull << ((int)wlast - lo)) - 1ull;
@@ -653,507 +652,7 @@ __global__ __launch_bounds__(HGS_BLOCK) __attribute__((amdgpu_waves_per_eu(HGS_B
   }
 }
 
-// ------------------------------------------------------------------------------------------------
-// Backward over 4x4-pixel BLOCKS (round 4, variant 2): every 16-lane DPP row of a wavefront walks the list of ITS block.
-//
-// blend_bwd_kernel evaluates an entry for the 64 pixels of a quadrant although a thin strand Gaussian blends ~10 of them,
-// and pays a 64-lane reduction per evaluated (wavefront, entry) pair.  Here a wavefront still owns a quadrant, but its four
-// DPP rows are the quadrant's four 4x4 blocks, and each row steps through its own sub-list: the entries whose block bit is
-// set (hgs_block_mask, in the record).  One step = four (entry, block) pairs, a different entry in every row:
-//   * the record is read from LDS with a per-row address, alpha / the recurrences / the moments run once for four pairs;
-//   * the sixteen partial sums are reduced inside each row (bank-masked DPP adds, quad permutes: ~33 instructions for four
-//     pairs instead of 32 for one), leaving value k in lane k of the row, and added to the wavefront's slab of the batch's
-//     accumulators in LDS (ds_add_f32: lanes of a row hit 16 consecutive words; rows that happen to hold the same entry
-//     serialise in lane order); the four slabs are combined in fixed order as in blend_bwd_kernel.
-// A wavefront's steps per batch = the longest of its four sub-lists.  Same arithmetic per (pixel, entry) as
-// blend_bwd_kernel; the sums of a Gaussian are associated differently (block by block).
-__device__ __forceinline__ float row16_reduce(float (&v)[16]) {
-  // in: v[0..15] per lane.  out: lane 4 q + c of every 16-lane row = the row's total of v[4 * (0,2,1,3)[c] + (0,2,1,3)[q]]
-  // (HGS_ROW16_COL).  Transposing butterfly: each level halves the partial sums of every value and packs two registers
-  // into one (bank-masked DPP adds write only the banks named; row_ror:n: lane i reads lane i - n of its row).
-  asm volatile("s_nop 1\n\t"
-               "v_add_f32_dpp %0, %0, %0" HGS_DPP("row_ror:8", "0x3")   "v_add_f32_dpp %2, %2, %2" HGS_DPP("row_ror:8", "0x3")
-               "v_add_f32_dpp %4, %4, %4" HGS_DPP("row_ror:8", "0x3")   "v_add_f32_dpp %6, %6, %6" HGS_DPP("row_ror:8", "0x3")
-               "v_add_f32_dpp %8, %8, %8" HGS_DPP("row_ror:8", "0x3")   "v_add_f32_dpp %10, %10, %10" HGS_DPP("row_ror:8", "0x3")
-               "v_add_f32_dpp %12, %12, %12" HGS_DPP("row_ror:8", "0x3") "v_add_f32_dpp %14, %14, %14" HGS_DPP("row_ror:8", "0x3")
-               "v_add_f32_dpp %0, %1, %1" HGS_DPP("row_ror:8", "0xc")   "v_add_f32_dpp %2, %3, %3" HGS_DPP("row_ror:8", "0xc")
-               "v_add_f32_dpp %4, %5, %5" HGS_DPP("row_ror:8", "0xc")   "v_add_f32_dpp %6, %7, %7" HGS_DPP("row_ror:8", "0xc")
-               "v_add_f32_dpp %8, %9, %9" HGS_DPP("row_ror:8", "0xc")   "v_add_f32_dpp %10, %11, %11" HGS_DPP("row_ror:8", "0xc")
-               "v_add_f32_dpp %12, %13, %13" HGS_DPP("row_ror:8", "0xc") "v_add_f32_dpp %14, %15, %15" HGS_DPP("row_ror:8", "0xc")
-               // 8 registers (even operands): lanes 0-7 of a row hold 8 partials of v[2i], lanes 8-15 of v[2i+1]
-               "v_add_f32_dpp %0, %0, %0" HGS_DPP("row_ror:12", "0x5")  "v_add_f32_dpp %4, %4, %4" HGS_DPP("row_ror:12", "0x5")
-               "v_add_f32_dpp %8, %8, %8" HGS_DPP("row_ror:12", "0x5")  "v_add_f32_dpp %12, %12, %12" HGS_DPP("row_ror:12", "0x5")
-               "v_add_f32_dpp %0, %2, %2" HGS_DPP("row_ror:4", "0xa")   "v_add_f32_dpp %4, %6, %6" HGS_DPP("row_ror:4", "0xa")
-               "v_add_f32_dpp %8, %10, %10" HGS_DPP("row_ror:4", "0xa") "v_add_f32_dpp %12, %14, %14" HGS_DPP("row_ror:4", "0xa")
-               // 4 registers (%0 %4 %8 %12): quad q of a row holds 4 partials of v[4 j + (0,2,1,3)[q]]
-               "v_add_f32_dpp %0, %0, %0" HGS_DPP("quad_perm:[2,3,0,1]", "0xf")  "v_add_f32_dpp %4, %4, %4" HGS_DPP("quad_perm:[2,3,0,1]", "0xf")
-               "v_add_f32_dpp %8, %8, %8" HGS_DPP("quad_perm:[2,3,0,1]", "0xf")  "v_add_f32_dpp %12, %12, %12" HGS_DPP("quad_perm:[2,3,0,1]", "0xf")
-               "s_nop 0\n\t"
-               "v_cndmask_b32 %0, %0, %4, %16\n\t"      // lanes 2,3 of every quad from j = 1 (j = 3)
-               "v_cndmask_b32 %8, %8, %12, %16\n\t"
-               "s_nop 1\n\t"
-               "v_add_f32_dpp %0, %0, %0" HGS_DPP("quad_perm:[1,0,3,2]", "0xf")  "v_add_f32_dpp %8, %8, %8" HGS_DPP("quad_perm:[1,0,3,2]", "0xf")
-               "s_nop 0\n\t"
-               "v_cndmask_b32 %0, %0, %8, %17\n\t"      // lanes 1,3 of every quad from j = 2, 3
-               : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]), "+v"(v[8]),
-                 "+v"(v[9]), "+v"(v[10]), "+v"(v[11]), "+v"(v[12]), "+v"(v[13]), "+v"(v[14]), "+v"(v[15])
-               : "s"(0xCCCCCCCCCCCCCCCCull), "s"(0xAAAAAAAAAAAAAAAAull));
-  return v[0];
-}
-// value index held by lane l of a row after row16_reduce
-#define HGS_ROW16_COL(l) (4 * ((((l) & 1) << 1) | (((l) >> 1) & 1)) + (((((l) >> 2) & 1) << 1) | (((l) >> 3) & 1)))
-
-template <int C, bool BLACK>
-__global__ __launch_bounds__(HGS_BLOCK) __attribute__((amdgpu_waves_per_eu(HGS_BWD_WAVES))) void blend_bwd_rows_kernel(HgsImage im, HgsBinning bn, int W, int H, int gx,
-                                                              uint32_t Rcap, const float* __restrict__ bg,
-                                                              PixGrad<C> dL_dpix, float* __restrict__ inst_grad) {
-  constexpr int REC4 = Chan<C>::REC4, NPART = Chan<C>::NPART, ROW = Chan<C>::ROW;
-  __shared__ float part[4][BWD_BATCH][16];
-  __shared__ float4 recs[2][BWD_BATCH * REC4];
-  const uint32_t void_pass = im.status[HGS_ST_OVERFLOW];
-  BlendItem it;
-  if (!blend_item(im, Rcap, it) || void_pass) return;
-  const int tile = it.tile;
-  WgTrace _trace(g_wg_trace_bwd);
-  _trace.item(tile, it.seg, it.nseg, it.e - it.s);
-  const uint2 range = it.range;
-  const float4* __restrict__ packed = bn.packed;
-  const uint32_t maxc = im.tile_maxc[tile];
-  {
-    const uint32_t end = range.x + it.e, first = range.x + max(it.s, maxc);   // zero rows past the last needed entry (blend_bwd_kernel)
-    if (end > first) {
-      const uint32_t n4 = (end - first) * (ROW / 4);
-      for (uint32_t i = threadIdx.x; i < n4; i += HGS_BLOCK) {
-        const uint32_t inst = first + i / (ROW / 4);
-        const uint32_t slot = __float_as_uint(((const float*)packed)[(size_t)inst * 4 * REC4 + 8 + C]);
-        if (slot < Rcap) ((float4*)(inst_grad + (size_t)slot * ROW))[i % (ROW / 4)] = make_float4(0.f, 0.f, 0.f, 0.f);
-      }
-    }
-  }
-  if (maxc <= it.s) return;
-  const int seg_lo = (int)it.s, top = (int)min(maxc, it.e);
-  const int tx = tile % gx, ty = tile / gx;
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  // lane -> pixel: row r of the wavefront = block (2 (wave & 1) + (r & 1), 2 (wave >> 1) + (r >> 1)) of the tile
-  const int row = lane >> 4;
-  const int bx = 2 * (wave & 1) + (row & 1), by = 2 * (wave >> 1) + (row >> 1);
-  const int lx = 4 * bx + (lane & 3), ly = 4 * by + ((lane >> 2) & 3);     // pixel inside the tile
-  const int px = tx * HGS_TILE + lx, py = ty * HGS_TILE + ly;
-  const bool inside = px < W && py < H;
-  const float pxf = (float)px, pyf = (float)py;
-  const size_t pix = (size_t)py * W + px;
-  const int tf = ((ly >> 3) * 2 + (lx >> 3)) * 64 + (ly & 7) * 8 + (lx & 7);   // the forward's thread of this pixel (segment state)
-
-  const float4* src = packed + (size_t)range.x * REC4;
-  float4 stage = make_float4(0.f, 0.f, 0.f, 0.f);
-  {
-    const int lo = max(seg_lo, top - BWD_BATCH), cnt = top - lo;
-    if (threadIdx.x < cnt * REC4) stage = src[(size_t)lo * REC4 + threadIdx.x];
-  }
-  const float T_final = inside ? im.final_T[pix] : 0.f;
-  float T = T_final;
-  const uint32_t last = inside ? im.n_contrib[pix] : 0u;
-  uint32_t rlast = last;                                                       // the block's last contributor
-#pragma unroll
-  for (int d = 8; d >= 1; d >>= 1) rlast = max(rlast, (uint32_t)__shfl_xor((int)rlast, d, 64));
-  float dpx[C], acc_dot = 0.f, acc_dot_rgb = 0.f;
-  float bg_dot = 0.f, bg_dot_rgb = 0.f;
-#pragma unroll
-  for (int k = 0; k < C; k++) {
-    dpx[k] = inside ? dL_dpix.plane[k][pix] : 0.f;
-    if (!BLACK) {
-      bg_dot += bg[k] * dpx[k];
-      if (k < 3) bg_dot_rgb += bg[k] * dpx[k];
-    }
-  }
-  if (it.split && last > it.e) {
-    const float Tn = bn.seg_T[((size_t)it.w + 1) * HGS_BLOCK + tf];
-    float d = 0.f, d_rgb = 0.f;
-#pragma unroll
-    for (int k = 0; k < C; k++) {
-      d = __builtin_fmaf(bn.seg_C[(((size_t)it.w + 1) * C + k) * HGS_BLOCK + tf], dpx[k], d);
-      if (k == 2) d_rgb = d;
-    }
-    const float inv = Tn > 0.f ? 1.f / Tn : 0.f;
-    T = Tn;
-    acc_dot = d * inv;
-    acc_dot_rgb = d_rgb * inv;
-  }
-  // wave-uniform per row: block bit and last contributor
-  int blk[4];
-  uint32_t rl[4];
-#pragma unroll
-  for (int r = 0; r < 4; r++) {
-    blk[r] = 4 * (2 * (wave >> 1) + (r >> 1)) + 2 * (wave & 1) + (r & 1);
-    rl[r] = (uint32_t)__builtin_amdgcn_readlane((int)rlast, 16 * r);
-  }
-  const int col = HGS_ROW16_COL(lane & 15);
-
-  for (int i = threadIdx.x; i < 4 * BWD_BATCH * 16; i += HGS_BLOCK) (&part[0][0][0])[i] = 0.f;
-  if (threadIdx.x < BWD_BATCH * REC4) recs[0][threadIdx.x] = stage;
-  __syncthreads();
-
-  int cur = 0;
-  for (int hi = top; hi > seg_lo; hi -= BWD_BATCH, cur ^= 1) {
-    const int lo = max(seg_lo, hi - BWD_BATCH);
-    const int cnt = hi - lo;
-    if (lo > seg_lo) {
-      const int nlo = max(seg_lo, lo - BWD_BATCH), ncnt = lo - nlo;
-      if (threadIdx.x < ncnt * REC4) stage = src[(size_t)nlo * REC4 + threadIdx.x];
-    }
-    const float* rf = (const float*)&recs[cur][0];
-    const uint32_t mk = lane < cnt ? __float_as_uint(rf[lane * 4 * REC4 + 7 + C]) : 0u;
-    uint64_t M[4];
-#pragma unroll
-    for (int r = 0; r < 4; r++) {
-      M[r] = __ballot(((mk >> blk[r]) & 1u) != 0u);
-      // positions at or past the block's last contributor cannot be valid for any of its pixels
-      if ((int)rl[r] <= lo) M[r] = 0;
-      else if ((int)rl[r] - lo < 64) M[r] &= (1ull << ((int)rl[r] - lo)) - 1ull;
-    }
-    while (M[0] | M[1] | M[2] | M[3]) {
-      int er[4];
-#pragma unroll
-      for (int r = 0; r < 4; r++) {
-        er[r] = M[r] ? 63 - __builtin_clzll(M[r]) : -1;
-        if (M[r]) M[r] &= ~(1ull << er[r]);
-      }
-      const int e = row == 0 ? er[0] : (row == 1 ? er[1] : (row == 2 ? er[2] : er[3]));
-      const bool valid = e >= 0;
-      const Rec<C> r = lds_record<C>(recs[cur], valid ? e : 0);
-      const int p = lo + e;
-      const float* f = (const float*)&r.q[0];
-      const float4 r0 = r.q[0], r1 = r.q[1];
-      const float dx = r0.x - pxf, dy = r0.y - pyf;
-      const float power = -0.5f * (r0.z * dx * dx + r1.x * dy * dy) - r0.w * dx * dy;
-      const float Gx = __expf(power);
-      const float ax = fminf(0.99f, r1.y * Gx);
-      const bool ok = valid && (uint32_t)p < last && power <= 0.f && ax >= (1.0f / 255.0f);
-      const float G = ok ? Gx : 0.f, alpha = ok ? ax : 0.f;
-      const float inv_one_m_a = __builtin_amdgcn_rcpf(1.f - alpha);
-      T = T * inv_one_m_a;
-      float v[16];
-      const float dchannel_dcolor = alpha * T;
-      float col_dot = 0.f, col_dot_rgb = 0.f;
-#pragma unroll
-      for (int k = 0; k < C; k++) {
-        col_dot = __builtin_fmaf(f[6 + k], dpx[k], col_dot);
-        if (k == 2) col_dot_rgb = col_dot;
-        v[6 + k] = dchannel_dcolor * dpx[k];
-      }
-      float dL_dalpha = col_dot - acc_dot;
-      const float dL_dalpha_rgb = col_dot_rgb - acc_dot_rgb;
-      dL_dalpha *= T;
-      const float bgw = BLACK ? 0.f : -T_final * inv_one_m_a;
-      if (!BLACK) dL_dalpha += bgw * bg_dot;
-      const float u = G * dL_dalpha;
-      const float ux = u * dx, uy = u * dy;
-      v[0] = ux;
-      v[1] = uy;
-      v[2] = ux * dx;
-      v[3] = ux * dy;
-      v[4] = uy * dy;
-      v[5] = u;
-      if (C > 3) {
-        const float u_rgb = BLACK ? G * (dL_dalpha_rgb * T) : G * (dL_dalpha_rgb * T + bgw * bg_dot_rgb);
-        v[6 + C] = u_rgb * dx;
-        v[7 + C] = u_rgb * dy;
-      }
-      acc_dot = alpha * col_dot + (1.f - alpha) * acc_dot;
-      acc_dot_rgb = alpha * col_dot_rgb + (1.f - alpha) * acc_dot_rgb;
-#pragma unroll
-      for (int k = NPART; k < 16; k++) v[k] = 0.f;
-#ifndef ROWS_EXP_NOREDUCE
-      const float tot = row16_reduce(v);
-      if (valid && col < NPART) atomicAdd(&part[wave][e][col], tot);
-#else
-      if (valid && col < NPART) part[wave][e][col] = v[0] + v[1] + v[2] + v[3] + v[4] + v[5] + v[6] + v[7] + v[8] + v[9] + v[10] + v[11] + v[12] + v[13] + v[14];
-#endif
-    }
-    __syncthreads();
-    for (int i = threadIdx.x; i < cnt * NPART; i += HGS_BLOCK) {
-      const int e = i / NPART, k = i - e * NPART;
-      const float s = ((part[0][e][k] + part[1][e][k]) + part[2][e][k]) + part[3][e][k];
-      const uint32_t slot = __float_as_uint(rf[e * 4 * REC4 + 8 + C]);
-      if (slot < Rcap) inst_grad[(size_t)slot * ROW + k] = s;
-      part[0][e][k] = 0.f; part[1][e][k] = 0.f; part[2][e][k] = 0.f; part[3][e][k] = 0.f;
-    }
-    if (lo > seg_lo && threadIdx.x < BWD_BATCH * REC4) recs[cur ^ 1][threadIdx.x] = stage;
-    __syncthreads();
-  }
-}
-
-// ------------------------------------------------------------------------------------------------
-// Backward with the per-entry sums on the MATRIX pipe (round 4; the default, hgs_set_backward_variant).
-//
-// What blend_bwd_kernel spends most of its vector issue on is not the gradient of a (pixel, entry) pair but what follows
-// it: eleven products with per-lane constants (the moments of u = G dL/dalpha, the colour gradients) and a 16-value
-// transposing reduction over the wavefront -- 45 of its ~86 vector instructions per evaluated (wavefront, entry) pair.
-// Both are ONE contraction over the quadrant's 64 pixels:
-//     row(entry)[n] = sum_p  u(entry, p) phi_n(p)  +  w(entry, p) dLdpix_n(p)        (w = alpha T)
-// with phi = (1, x, y, x^2, x y, y^2) in PIXEL coordinates relative to the quadrant's centre (the per-Gaussian shift to
-// d = mean - pixel is linear in these sums and is applied by preprocess_bwd_kernel once per row), i.e. a
-// [entries x pixels] . [pixels x 16] product whose right-hand side is constant for the whole walk of a wavefront.  That is
-// v_mfma_f32_16x16x4_f32's shape (exact f32, a k-ordered fmaf chain: results stay bitwise reproducible):
-//   * the walk (lanes = pixels) only evaluates alpha, the transmittance / accumulated-colour recurrences and the three
-//     per-pixel scalars u, u_rgb (the RGB-only u of the densification statistics) and w, and parks them in LDS:
-//     one row of 64 floats per scalar and evaluated pair, eight pairs per flush;
-//   * a flush reads them back as A operands (lane (k, m): entry m, pixels 4 k .. 4 k + 3 of a 16-pixel group: one
-//     ds_read_b128 per group) and runs 32 MFMAs against the B operands held in registers (16 for phi, 16 for dL/dpixel,
-//     which reach the B layout through LDS once per workgroup): rows 0-7 of the 16 x 16 result are the eight entries'
-//     [S u, S u x, S u y, S u xx, S u xy, S u yy, dcolor 0 .. C-1], rows 8-15 the same entries' RGB-only (S u, S u x, S u y);
-//   * every (entry, quadrant) pair owns a 64-byte row of the scratch (instance slot * 4 + quadrant), stored straight from
-//     the accumulator registers: no combine of the four wavefronts through LDS, no barrier besides the record staging.
-//     Rows of pairs that are skipped (behind the wavefront's or the tile's last contributor) are zero-filled, so that
-//     preprocess_bwd_kernel may add every row whose quadrant bit is set (HgsBinning::inv holds the masks).
-typedef float hgs_v4f __attribute__((ext_vector_type(4)));
-#define MF_S 8                              // evaluated pairs per flush = rows of the MFMA's M dimension that hold u (and u_rgb)
-#define MF_STRIDE 68                        // floats per parked row: 64 pixels + 4 (the b128 operand reads of 16 rows hit different banks)
-#define MF_ROWS (3 * MF_S)                  // u | u_rgb | w
-#define MF_WAVE_FLOATS (MF_ROWS * MF_STRIDE)
-__device__ __forceinline__ void wave_lds_order() { asm volatile("" ::: "memory"); }   // LDS operations of one wavefront execute in order
-
-template <int C, bool BLACK>
-__global__ __launch_bounds__(HGS_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 5))) void blend_bwd_mfma_kernel(HgsImage im, HgsBinning bn, int W, int H, int gx,
-                                                              uint32_t Rcap, const float* __restrict__ bg,
-                                                              PixGrad<C> dL_dpix, float* __restrict__ inst_grad) {
-  constexpr int REC4 = Chan<C>::REC4;
-  __shared__ __attribute__((aligned(16))) float abuf[4][MF_WAVE_FLOATS];
-  __shared__ __attribute__((aligned(16))) int eslot[4][MF_S];
-  __shared__ float4 recs[2][BWD_BATCH * REC4];
-  const uint32_t void_pass = im.status[HGS_ST_OVERFLOW];
-  BlendItem it;
-  if (!blend_item(im, Rcap, it) || void_pass) return;
-  const int tile = it.tile;
-  WgTrace _trace(g_wg_trace_bwd);
-  _trace.item(tile, it.seg, it.nseg, it.e - it.s);
-  const uint2 range = it.range;
-  const float4* __restrict__ packed = bn.packed;
-  const uint32_t maxc = im.tile_maxc[tile];
-  {
-    // entries past the last one any pixel needed: zero rows for their (instance, quadrant) pairs
-    const uint32_t end = range.x + it.e, first = range.x + max(it.s, maxc);
-    if (end > first) {
-      const uint32_t n4 = (end - first) * 4;
-      for (uint32_t i = threadIdx.x; i < n4; i += HGS_BLOCK) {
-        const uint32_t inst = first + (i >> 2), q = i & 3u;
-        const uint2 ms = *(const uint2*)((const uint32_t*)packed + (size_t)inst * 4 * REC4 + 7 + C);   // (quadrant mask, slot)
-        if ((ms.x & HGS_BMASK_QUADRANT(q)) && ms.y < Rcap) {
-          float4* row = (float4*)(inst_grad + ((size_t)ms.y * 4 + q) * 16);
-          row[0] = row[1] = row[2] = row[3] = make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-      }
-    }
-  }
-  if (maxc <= it.s) return;
-  const int seg_lo = (int)it.s, top = (int)min(maxc, it.e);
-  const int tx = tile % gx, ty = tile / gx;
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int px = tx * HGS_TILE + (wave & 1) * 8 + (lane & 7);
-  const int py = ty * HGS_TILE + (wave >> 1) * 8 + (lane >> 3);
-  const bool inside = px < W && py < H;
-  const float pxf = (float)px, pyf = (float)py;
-  const size_t pix = (size_t)py * W + px;
-
-  const float4* src = packed + (size_t)range.x * REC4;
-  float4 stage = make_float4(0.f, 0.f, 0.f, 0.f);
-  {
-    const int lo = max(seg_lo, top - BWD_BATCH), cnt = top - lo;
-    if (threadIdx.x < cnt * REC4) stage = src[(size_t)lo * REC4 + threadIdx.x];
-  }
-
-  const float T_final = inside ? im.final_T[pix] : 0.f;
-  float T = T_final;
-  const uint32_t last = inside ? im.n_contrib[pix] : 0u;
-  uint32_t wlast = last;
-#pragma unroll
-  for (int d = 32; d >= 1; d >>= 1) wlast = max(wlast, (uint32_t)__shfl_xor((int)wlast, d, 64));
-  wlast = __builtin_amdgcn_readfirstlane(wlast);
-  float dpx[C], acc_dot = 0.f, acc_dot_rgb = 0.f;
-  float bg_dot = 0.f, bg_dot_rgb = 0.f;
-#pragma unroll
-  for (int k = 0; k < C; k++) {
-    dpx[k] = inside ? dL_dpix.plane[k][pix] : 0.f;
-    if (!BLACK) {
-      bg_dot += bg[k] * dpx[k];
-      if (k < 3) bg_dot_rgb += bg[k] * dpx[k];
-    }
-  }
-  if (it.split && last > it.e) {   // contributors behind this segment: the state the serial walk would arrive with (see blend_bwd_kernel)
-    const float Tn = bn.seg_T[((size_t)it.w + 1) * HGS_BLOCK + threadIdx.x];
-    float d = 0.f, d_rgb = 0.f;
-#pragma unroll
-    for (int k = 0; k < C; k++) {
-      d = __builtin_fmaf(bn.seg_C[(((size_t)it.w + 1) * C + k) * HGS_BLOCK + threadIdx.x], dpx[k], d);
-      if (k == 2) d_rgb = d;
-    }
-    const float inv = Tn > 0.f ? 1.f / Tn : 0.f;
-    T = Tn;
-    acc_dot = d * inv;
-    acc_dot_rgb = d_rgb * inv;
-  }
-
-  // ---- B operands (constant for the walk).  Lane (kq = lane >> 4, n = lane & 15) of MFMA (t, i) holds column n at pixel
-  // p = 16 t + 4 kq + i of the quadrant, i.e. x = 4 (kq & 1) + i, y = 2 t + (kq >> 1).
-  float* const ab = abuf[wave];
-  int* const es = eslot[wave];
-  const int n = lane & 15, kq = lane >> 4;
-  hgs_v4f Bu[4], Bw[4];
-  {
-#pragma unroll
-    for (int k = 0; k < C; k++) ab[k * 64 + lane] = dpx[k];
-    wave_lds_order();
-    const int ex = (n == 1 || n == 4) ? 1 : (n == 3 ? 2 : 0), ey = (n == 2 || n == 4) ? 1 : (n == 5 ? 2 : 0);
-    float P[4], Q[4];
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-      const float x = (float)(4 * (kq & 1) + i) - 3.5f, y = (float)(2 * i + (kq >> 1)) - 3.5f;
-      P[i] = n > 5 ? 0.f : (ex == 0 ? 1.f : (ex == 1 ? x : x * x));
-      Q[i] = ey == 0 ? 1.f : (ey == 1 ? y : y * y);
-    }
-    const int ch = n - 6;
-    const bool has = ch >= 0 && ch < C;
-#pragma unroll
-    for (int t = 0; t < 4; t++) {
-#pragma unroll
-      for (int i = 0; i < 4; i++) Bu[t][i] = P[i] * Q[t];
-      const hgs_v4f v = *(const hgs_v4f*)&ab[(has ? ch : 0) * 64 + 16 * t + 4 * kq];
-      Bw[t] = has ? v : hgs_v4f{0.f, 0.f, 0.f, 0.f};
-    }
-    wave_lds_order();
-  }
-  // where lane (kq, n) stores register v of the result: row 4 kq + v = parked pair (4 kq + v) & 7; rows 0-7 carry columns
-  // 0 .. 5 + C, rows 8-15 the RGB-only sums in columns 0-2, which go to floats 13-15 of the same scratch row
-  const int lane_col = kq < 2 ? n : 13 + n;
-  const bool lane_ok = kq < 2 ? n < 6 + C : (C > 3 && n < 3);
-  if (lane < MF_S) es[lane] = -1;
-
-  if (threadIdx.x < BWD_BATCH * REC4) recs[0][threadIdx.x] = stage;
-  __syncthreads();
-
-  int s = 0;   // parked pairs of this wavefront
-  auto flush = [&]() {
-    wave_lds_order();
-#ifndef MF_EXP_NOFLUSH
-    hgs_v4f D = {0.f, 0.f, 0.f, 0.f}, D1 = D, D2 = D, D3 = D;
-    const int m = lane & 15;
-#ifndef MF_EXP_NOMFMA
-#pragma unroll
-    for (int t = 0; t < 4; t++) {
-      const hgs_v4f a = *(const hgs_v4f*)&ab[m * MF_STRIDE + 16 * t + 4 * kq];
-      D = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0], Bu[t][0], D, 0, 0, 0);
-      D1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1], Bu[t][1], D1, 0, 0, 0);
-      D2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[2], Bu[t][2], D2, 0, 0, 0);
-      D3 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[3], Bu[t][3], D3, 0, 0, 0);
-    }
-#pragma unroll
-    for (int t = 0; t < 4; t++) {
-      const hgs_v4f a = *(const hgs_v4f*)&ab[(2 * MF_S + (m & 7)) * MF_STRIDE + 16 * t + 4 * kq];
-      D = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0], Bw[t][0], D, 0, 0, 0);
-      D1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1], Bw[t][1], D1, 0, 0, 0);
-      D2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[2], Bw[t][2], D2, 0, 0, 0);
-      D3 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[3], Bw[t][3], D3, 0, 0, 0);
-    }
-    D = (D + D1) + (D2 + D3);
-#endif
-    const int4 rows = *(const int4*)&es[4 * (kq & 1)];
-    const int rw[4] = {rows.x, rows.y, rows.z, rows.w};
-#pragma unroll
-    for (int v = 0; v < 4; v++)
-      if (rw[v] >= 0 && lane_ok) inst_grad[(size_t)rw[v] * 16 + lane_col] = D[v];
-#endif
-    if (lane < MF_S) es[lane] = -1;
-    wave_lds_order();
-    s = 0;
-  };
-
-  int cur = 0;
-  for (int hi = top; hi > seg_lo; hi -= BWD_BATCH, cur ^= 1) {
-    const int lo = max(seg_lo, hi - BWD_BATCH);
-    const int cnt = hi - lo;
-    if (lo > seg_lo) {
-      const int nlo = max(seg_lo, lo - BWD_BATCH), ncnt = lo - nlo;
-      if (threadIdx.x < ncnt * REC4) stage = src[(size_t)nlo * REC4 + threadIdx.x];
-    }
-    const float* rf = (const float*)&recs[cur][0];
-    const uint32_t mk = lane < cnt ? __float_as_uint(rf[lane * 4 * REC4 + 7 + C]) : 0u;
-    const uint64_t m_all = __ballot((mk & HGS_BMASK_QUADRANT(wave)) != 0u);
-    uint64_t m = m_all;
-    if ((int)wlast <= lo) m = 0;
-    else if ((int)wlast - lo < 64) m &= (1ull << ((int)wlast - lo)) - 1ull;
-    if (m_all & ~m) {   // pairs behind this wavefront's last contributor: their rows are zeros
-      if (((m_all & ~m) >> lane) & 1ull) {
-        const uint32_t slot = __float_as_uint(rf[lane * 4 * REC4 + 8 + C]);
-        if (slot < Rcap) {
-          float4* row = (float4*)(inst_grad + ((size_t)slot * 4 + wave) * 16);
-          row[0] = row[1] = row[2] = row[3] = make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-      }
-    }
-    auto process = [&](const Rec<C>& r, int e) {
-      const int p = lo + e;
-      const float* f = (const float*)&r.q[0];
-      const float4 r0 = r.q[0], r1 = r.q[1];
-      const float dx = r0.x - pxf, dy = r0.y - pyf;
-      const float power = -0.5f * (r0.z * dx * dx + r1.x * dy * dy) - r0.w * dx * dy;
-      const float Gx = __expf(power);
-      const float ax = fminf(0.99f, r1.y * Gx);
-      const bool ok = (uint32_t)p < last && power <= 0.f && ax >= (1.0f / 255.0f);
-      const float G = ok ? Gx : 0.f, alpha = ok ? ax : 0.f;
-      const float inv_one_m_a = __builtin_amdgcn_rcpf(1.f - alpha);
-      T = T * inv_one_m_a;                                                         // backward_distwar.cu:960
-      float col_dot = 0.f, col_dot_rgb = 0.f;
-#pragma unroll
-      for (int k = 0; k < C; k++) {
-        col_dot = __builtin_fmaf(f[6 + k], dpx[k], col_dot);                       // :979-984
-        if (k == 2) col_dot_rgb = col_dot;
-      }
-      float dL_dalpha = (col_dot - acc_dot) * T;
-      const float bgw = BLACK ? 0.f : -T_final * inv_one_m_a;
-      if (!BLACK) dL_dalpha += bgw * bg_dot;                                       // :991
-      const float u = G * dL_dalpha;
-      ab[s * MF_STRIDE + lane] = u;
-      if (C > 3) {
-        const float dr = (col_dot_rgb - acc_dot_rgb) * T;
-        ab[(MF_S + s) * MF_STRIDE + lane] = BLACK ? G * dr : G * (dr + bgw * bg_dot_rgb);
-      }
-      ab[(2 * MF_S + s) * MF_STRIDE + lane] = alpha * T;                           // :980 (times dL/dpixel in the flush)
-      acc_dot = alpha * col_dot + (1.f - alpha) * acc_dot;                         // :972
-      acc_dot_rgb = alpha * col_dot_rgb + (1.f - alpha) * acc_dot_rgb;
-      const uint32_t slot = __float_as_uint(f[8 + C]);                             // (wave-uniform: the record is)
-      const int rowid = slot < Rcap ? (int)(slot * 4u + (uint32_t)wave) : -1;
-      if (lane == 0) es[s] = rowid;
-      s++;
-      if (s == MF_S) flush();
-    };
-    while (m) {
-      const int ea = 63 - __builtin_clzll(m);
-      m &= ~(1ull << ea);
-      process(lds_record<C>(recs[cur], ea), ea);
-    }
-    __syncthreads();
-    if (lo > seg_lo && threadIdx.x < BWD_BATCH * REC4) recs[cur ^ 1][threadIdx.x] = stage;
-    __syncthreads();
-  }
-  if (s) flush();
-}
-
 }  // namespace
-
-static int g_bwd_variant = -1;   // -1: not decided (environment HGS_BWD_VARIANT, default 2); 0: wave reduction (round 3); 1: MFMA; 2: block rows
-static int bwd_variant() {
-  if (g_bwd_variant < 0) {
-    const char* e = getenv("HGS_BWD_VARIANT");
-    g_bwd_variant = e && e[0] >= '0' && e[0] <= '2' ? e[0] - '0' : 2;
-  }
-  return g_bwd_variant;
-}
-extern "C" int hgs_set_backward_variant(int v) {
-  const int was = bwd_variant();
-  if (v >= 0 && v <= 2) g_bwd_variant = v;
-  return was;
-}
-int hgs_backward_variant() { return bwd_variant(); }
 
 extern "C" int hgs_debug_set_wg_trace(void* device_buf_fwd, void* device_buf_bwd) {
   HGS_CHECK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_wg_trace_fwd), &device_buf_fwd, sizeof(void*)));
@@ -1187,25 +686,23 @@ int hgs_launch_blend_fwd(hipStream_t s, int W, int H, int Rcap, int channels, co
 int hgs_launch_blend_bwd(hipStream_t s, int W, int H, int Rcap, int channels, const float* bg, const HgsImage& im,
                          const HgsBinning& b, const float* const* dL_dpix_planes, float* inst_grad) {
   const int gx = (W + HGS_TILE - 1) / HGS_TILE, gy = (H + HGS_TILE - 1) / HGS_TILE;
-  const dim3 grid(blend_grid(gx * gy, b)), block(HGS_BLOCK);
-  const bool mfma = bwd_variant() == 1, rows = bwd_variant() == 2;
   {
     HgsProfScope _prof(s, HGS_K_BLEND_BWD);
-#define HGS_BWD_LAUNCH(KERNEL, CH, BLACK) hipLaunchKernelGGL((KERNEL<CH, BLACK>), grid, block, 0, s, im, b, W, H, gx, (uint32_t)Rcap, bg, pg, inst_grad)
     if (channels == 3) {
       PixGrad<3> pg;
       for (int k = 0; k < 3; k++) pg.plane[k] = dL_dpix_planes[k];
-      if (mfma) { if (bg) HGS_BWD_LAUNCH(blend_bwd_mfma_kernel, 3, false); else HGS_BWD_LAUNCH(blend_bwd_mfma_kernel, 3, true); }
-      else if (rows) { if (bg) HGS_BWD_LAUNCH(blend_bwd_rows_kernel, 3, false); else HGS_BWD_LAUNCH(blend_bwd_rows_kernel, 3, true); }
-      else { if (bg) HGS_BWD_LAUNCH(blend_bwd_kernel, 3, false); else HGS_BWD_LAUNCH(blend_bwd_kernel, 3, true); }
+      if (bg) hipLaunchKernelGGL((blend_bwd_kernel<3, false>), dim3(blend_grid(gx * gy, b)), dim3(HGS_BLOCK), 0, s, im, b, W, H, gx,
+                                 (uint32_t)Rcap, bg, pg, inst_grad);
+      else hipLaunchKernelGGL((blend_bwd_kernel<3, true>), dim3(blend_grid(gx * gy, b)), dim3(HGS_BLOCK), 0, s, im, b, W, H, gx,
+                              (uint32_t)Rcap, bg, pg, inst_grad);
     } else {
       PixGrad<7> pg;
       for (int k = 0; k < 7; k++) pg.plane[k] = dL_dpix_planes[k];
-      if (mfma) { if (bg) HGS_BWD_LAUNCH(blend_bwd_mfma_kernel, 7, false); else HGS_BWD_LAUNCH(blend_bwd_mfma_kernel, 7, true); }
-      else if (rows) { if (bg) HGS_BWD_LAUNCH(blend_bwd_rows_kernel, 7, false); else HGS_BWD_LAUNCH(blend_bwd_rows_kernel, 7, true); }
-      else { if (bg) HGS_BWD_LAUNCH(blend_bwd_kernel, 7, false); else HGS_BWD_LAUNCH(blend_bwd_kernel, 7, true); }
+      if (bg) hipLaunchKernelGGL((blend_bwd_kernel<7, false>), dim3(blend_grid(gx * gy, b)), dim3(HGS_BLOCK), 0, s, im, b, W, H, gx,
+                                 (uint32_t)Rcap, bg, pg, inst_grad);
+      else hipLaunchKernelGGL((blend_bwd_kernel<7, true>), dim3(blend_grid(gx * gy, b)), dim3(HGS_BLOCK), 0, s, im, b, W, H, gx,
+                              (uint32_t)Rcap, bg, pg, inst_grad);
     }
-#undef HGS_BWD_LAUNCH
   }
   HGS_CHECK_LAUNCH();
   return 0;

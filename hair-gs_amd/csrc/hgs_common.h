@@ -247,33 +247,6 @@ __device__ __forceinline__ uint32_t hgs_quadrant_mask(const HgsQuadCull& c, cons
   }
   return qmask;
 }
-// Block masks (round 4): bit 4 by + bx of an instance's 16-bit mask is set when the 4x4-pixel block (bx, by) of its tile may
-// hold a pixel that blends the Gaussian -- the same two separating axes as the quadrant masks, per block (pixel centres
-// span 3 x 3 px).  Computed by the sort kernel where it assembles the instance's record (one lane per instance); the blend
-// backward walks every block's own list (one block per 16-lane DPP row), the forward tests the OR of a quadrant's bits.
-#define HGS_BMASK_QUADRANT(w) (0x33u << (8 * ((w) >> 1) + 2 * ((w) & 1)))   // the four blocks of wavefront w's 8x8 quadrant
-__device__ __forceinline__ uint32_t hgs_block_mask(const HgsQuadCull& c, const float2 xy, int tx, int ty) {
-  if (c.mode != 1) return c.mode == 0 ? 0u : 0xFFFFu;
-  uint32_t mask = 0u;
-  const float x0 = (float)(tx * HGS_TILE), y0 = (float)(ty * HGS_TILE);
-  const float reach = c.rn + 1.5f * (fabsf(c.nx) + fabsf(c.ny));
-  uint32_t ox = 0u, oy = 0u;   // per column / row of blocks: does the bounding box reach it?
-#pragma unroll
-  for (int i = 0; i < 4; i++) {
-    const float bx0 = x0 + (float)(4 * i), by0 = y0 + (float)(4 * i);
-    if (xy.x + c.hx >= bx0 && xy.x - c.hx <= bx0 + 3.f) ox |= 1u << i;
-    if (xy.y + c.hy >= by0 && xy.y - c.hy <= by0 + 3.f) oy |= 1u << i;
-  }
-  const float ax0 = c.nx * (x0 + 1.5f - xy.x), ay0 = c.ny * (y0 + 1.5f - xy.y);
-#pragma unroll
-  for (int by = 0; by < 4; by++)
-#pragma unroll
-    for (int bx = 0; bx < 4; bx++) {
-      const float along = (ax0 + c.nx * (float)(4 * bx)) + (ay0 + c.ny * (float)(4 * by));
-      if (((ox >> bx) & 1u) && ((oy >> by) & 1u) && fabsf(along) <= reach) mask |= 1u << (4 * by + bx);
-    }
-  return mask;
-}
 #endif
 
 struct HgsFwdArgs {

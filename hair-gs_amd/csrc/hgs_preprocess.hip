@@ -584,7 +584,7 @@ template <bool DC_ONLY>
 #endif
 __global__ __launch_bounds__(HGS_BLOCK) __attribute__((amdgpu_waves_per_eu(HGS_PPB_WAVES))) void preprocess_bwd_kernel(HgsBwdArgs a, HgsGeom g, HgsBinning b,
                                                                    const float* __restrict__ inst_grad, uint32_t Rcap,
-                                                                   const uint32_t* __restrict__ status, int quad_rows) {
+                                                                   const uint32_t* __restrict__ status) {
   const int idx = blockIdx.x * HGS_BLOCK + threadIdx.x;
   if (idx >= a.P) return;
   const int D = DC_ONLY ? 0 : a.D;
@@ -618,42 +618,6 @@ __global__ __launch_bounds__(HGS_BLOCK) __attribute__((amdgpu_waves_per_eu(HGS_P
     // ---- deterministic gather of this Gaussian's per-instance partial sums (instance order = tile rect order)
     const HgsRect rc = rc_pre;
     const uint32_t n = n_pre;
-    if (quad_rows) {
-      // blend_bwd_mfma_kernel: one 16-float row per (instance, quadrant) pair whose mask bit is set (b.inv, Gaussian-major like the
-      // rows), holding sums in PIXEL coordinates q = pixel - quadrant centre:
-      //   [S u, S u qx, S u qy, S u qx qx, S u qx qy, S u qy qy, dcolor 0 .. C-1, (C = 7:) S u_rgb, S u_rgb qx, S u_rgb qy]
-      // With c = mean - quadrant centre, d = mean - pixel = c - q: the sums of blend_bwd_kernel's rows follow per row.
-      const float2 mean2 = g.means2D[idx];
-      const int rw = (int)rc.x1 - (int)rc.x0;
-      int cx = 0, cy = 0;   // cell of instance k in the tile rectangle
-      for (uint32_t k = 0; k < n; k++) {
-        if (rc.off + k >= Rcap) break;
-        const uint32_t qm = b.inv[rc.off + k] & HGS_QMASK_BITS;
-        const float4* base = (const float4*)(inst_grad + (size_t)(rc.off + k) * 64);
-        const float tcx = (float)(((int)rc.x0 + cx) * HGS_TILE), tcy = (float)(((int)rc.y0 + cy) * HGS_TILE);
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-          if (!((qm >> q) & 1u)) continue;
-          const float4* r = base + 4 * q;
-          const float4 r0 = r[0], r1 = r[1], r2 = r[2], r3 = r[3];
-          const float ccx = mean2.x - (tcx + (float)((q & 1) * 8) + 3.5f), ccy = mean2.y - (tcy + (float)((q >> 1) * 8) + 3.5f);
-          const float S0 = r0.x, Sx = r0.y, Sy = r0.z, Sxx = r0.w, Sxy = r1.x, Syy = r1.y;
-          dmx += ccx * S0 - Sx;
-          dmy += ccy * S0 - Sy;
-          dcx += (ccx * ccx * S0 - 2.f * ccx * Sx) + Sxx;
-          dcy += ((ccx * ccy * S0 - ccx * Sy) - ccy * Sx) + Sxy;
-          dcw += (ccy * ccy * S0 - 2.f * ccy * Sy) + Syy;
-          dop += S0;
-          dcol[0] += r1.z; dcol[1] += r1.w; dcol[2] += r2.x;
-          if (a.n_extra) {
-            dex[0] += r2.y; dex[1] += r2.z; dex[2] += r2.w; dex[3] += r3.x;
-            dmx_rgb += ccx * r3.y - r3.z;
-            dmy_rgb += ccy * r3.y - r3.w;
-          }
-        }
-        if (++cx == rw) { cx = 0; cy++; }
-      }
-    } else {
     const int row_floats = a.n_extra ? 16 : HGS_INST_GRAD_FLOATS;
     for (uint32_t k = 0; k < n; k++) {
       if (rc.off + k >= Rcap) break;  // under-sized binning buffer (forward already flagged the overflow)
@@ -666,7 +630,6 @@ __global__ __launch_bounds__(HGS_BLOCK) __attribute__((amdgpu_waves_per_eu(HGS_P
         dex[0] += r2.y; dex[1] += r2.z; dex[2] += r2.w; dex[3] += r3.x;
         dmx_rgb += r3.y; dmy_rgb += r3.z;
       }
-    }
     }
     // The rows hold sums of moments of u = G dL/dalpha (blend_bwd_kernel): dmx = S(u dx), dmy = S(u dy), dcx = S(u dx dx),
     // dcy = S(u dx dy), dcw = S(u dy dy), dop = S(u).  backward_distwar.cu:1002-1011 in terms of them (dL_dG = opacity
@@ -944,17 +907,15 @@ int hgs_launch_scatter(hipStream_t s, int P, int W, int H, int Rcap, const float
   HGS_CHECK_LAUNCH();
   return 0;
 }
-int hgs_backward_variant();
 int hgs_launch_preprocess_bwd(hipStream_t s, const HgsBwdArgs& a, const HgsGeom& g, const HgsBinning& b,
                               const float* inst_grad, int Rcap, const uint32_t* status) {
-  const int quad_rows = hgs_backward_variant() == 1;
   const int nblk = (a.P + HGS_BLOCK - 1) / HGS_BLOCK;
   {
     HgsProfScope _prof(s, HGS_K_PREPROCESS_BWD);
     if (!a.shs || (a.D == 0 && a.M == 1))
-      hipLaunchKernelGGL(preprocess_bwd_kernel<true>, dim3(nblk), dim3(HGS_BLOCK), 0, s, a, g, b, inst_grad, (uint32_t)Rcap, status, quad_rows);
+      hipLaunchKernelGGL(preprocess_bwd_kernel<true>, dim3(nblk), dim3(HGS_BLOCK), 0, s, a, g, b, inst_grad, (uint32_t)Rcap, status);
     else
-      hipLaunchKernelGGL(preprocess_bwd_kernel<false>, dim3(nblk), dim3(HGS_BLOCK), 0, s, a, g, b, inst_grad, (uint32_t)Rcap, status, quad_rows);
+      hipLaunchKernelGGL(preprocess_bwd_kernel<false>, dim3(nblk), dim3(HGS_BLOCK), 0, s, a, g, b, inst_grad, (uint32_t)Rcap, status);
   }
   HGS_CHECK_LAUNCH();
   return 0;
