@@ -26,16 +26,20 @@ enough for an SMI sampler to see the GPU busy, and reports its own rate.
 
 The JSON line also carries
   psnr_vs_oracle_db  PSNR of the HIP render of view 0 against the CPU oracle's image of the same parameters (cpu_baseline leg)
-  trained_state      with --trained-iters N: the same protocol after N iterations of the full loop (densification, merging,
-                opacity reset), beside the headline (off by default: the rocprofv3 statistics of the default command
-                then average one state per kernel; profiles/r03_bench_trained_state.json holds a run with it)
-  roofline      blend_bwd_kernel (the dominant kernel): algorithmic bytes (SURVEY.md 8d formula generalised to the
-                7-channel single pass: (64 + 60) B x sum_tiles L_t + 36 B x W*H + 8 B x T per launch) / mean launch
-                duration.  The duration is measured in THIS run with HIP events on the launch stream around every launch
-                of the kernel, in an EAGER continuation of the same steps right after the timed regions (events cannot
-                bracket the nodes of a replayed graph); peak = 8 TB/s HBM3E.  `traffic` is not measurable from inside
-                the process: it is the HBM byte count of the committed rocprofv3 --pmc passes of the same workload
-                (`traffic_source` names the file), per launch.
+  trained_state the same protocol after --trained-iters N (default 1000) iterations of the FULL loop (densification, merging,
+                opacity reset, graph re-captures), beside the headline: the headline times the sparsest state of the workload
+                (five steps after initialisation); `trained_state` carries value, segments, sum of tile-list lengths, per-kernel
+                times and its own `roofline`.  (--trained-iters 0 where one state per kernel is wanted: the rocprofv3 scripts)
+  roofline      blend_bwd_kernel (the dominant kernel), see roofline_block(): `frac` on the ALGORITHMIC bytes of SURVEY.md 8d
+                (reference tile lists; 7-channel pass: (64 + 60) B x sum_tiles L_t + 36 B x W*H + 8 B x T per launch) over the
+                mean launch duration -- measured in THIS run with HIP events on the launch stream around every launch of the
+                kernel, in an EAGER continuation of the same steps right after the timed regions (events cannot bracket the
+                nodes of a replayed graph); peak = 8 TB/s HBM3E -- and, beside it, `frac_moved` on the bytes the implementation
+                physically moves (pixel planes of the tiles with a contributor only, culled lists).  `traffic` is not
+                measurable from inside the process: it is the HBM byte count of the committed rocprofv3 --pmc passes of the
+                same workload (`traffic_source` names the file), per launch, with FETCH_SIZE corrected per access shape.
+  roofline_c3   the same block for BASELINE.json config 3 (200k strand-Gaussians), timed by a child process that runs before this
+                one touches the GPU (--no-c3-leg skips it)
   cpu_baseline  the CPU oracle (oracle/, OpenMP C restatement of the reference rasterizer) doing the 3 raster fwd+bwd
                 passes of one iteration on the host cores, plus -- `cpu_only_paths` -- the reference's CPU-only paths
                 timed in the same run on the same cores: c_utils.filter_strand_list_segments (this package's native
@@ -72,11 +76,14 @@ def parse():
                     help="optimizer steps captured per graph launch (GraphedStep.step_many; 1 GPU, one view per step; the "
                          "steps that do not fill a launch replay the single-step graph)")
     ap.add_argument("--sustained-seconds", type=float, default=2.0, help="length of the sustained leg (0: skip)")
-    ap.add_argument("--trained-iters", type=int, default=0,
-                    help="second leg (1 GPU), e.g. 1000: train this many iterations WITH the topology operators (densification, "
-                         "merging, opacity reset), then time the same protocol on that state; reported beside the headline as "
-                         "`trained_state`.  Off by default so that the rocprofv3 kernel statistics of the default command average "
-                         "ONE state per kernel (profiles/ holds a run with it)")
+    ap.add_argument("--trained-iters", type=int, default=1000,
+                    help="second leg (1 GPU): train this many iterations WITH the topology operators (densification, merging, "
+                         "opacity reset), then time the same protocol on that state; reported beside the headline as "
+                         "`trained_state` (0: skip -- what the rocprofv3 scripts pass, so that their kernel statistics average ONE "
+                         "state per kernel)")
+    ap.add_argument("--no-c3-leg", action="store_true",
+                    help="skip `roofline_c3`: BASELINE.json config 3 (200k strand-Gaussians) timed by a child process of this run "
+                         "(rank 0, 1 GPU, north_star workload only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true", help="disable per-kernel HIP-event timing")
     ap.add_argument("--three-pass", action="store_true",
@@ -162,9 +169,88 @@ def cpu_only_paths():
     out["compute_metrics_f1"] = [float(x) for x in res["f1(b)"]]
     return out
 
+def roofline_block(kern, fs, W, H, ch, wl_tag):
+    """`roofline` of the dominant kernel (blend_bwd_kernel) from this run's per-launch HIP-event time `kern` and the list
+    statistics `fs` (frame_stats) of the state that was timed.
+      algorithmic bytes  SURVEY.md 8d, generalised to the C-channel pass, counted on the REFERENCE's tile lists:
+                         (16 C + 16 + 4 NPART) sum_t L_t + (4 C + 8) W H + 8 T      (C = 7: 124 sum L_t + 36 W H + 8 T)
+      moved bytes model  what this implementation physically moves: per-pixel planes only on tiles where a pixel blended an entry
+                         (the backward returns before touching pixel data elsewhere), records and rows of the CULLED lists:
+                         (4 C + 8) 256 #tiles(maxc > 0) + (16 C + 16 + 4 NPART) sum_t L_t(culled) + 8 T
+      traffic            HBM bytes of the committed rocprofv3 --pmc passes of the same workload, per launch.  FETCH_SIZE counts a
+                         64-byte request at 64 bytes and a 128-byte request at 64 bytes too (profiles/r04_fetch_shape_probe.txt,
+                         tools/probes/fetch_shape_probe.hip: ratio 1.000 for the blend's dword-per-lane quadrant reads of planar
+                         images and for 64-byte gathers, 0.500 for 256 contiguous bytes per wave instruction and for 16 B/lane
+                         streams): the per-pixel planes are counted in full, the coalesced record batches at half, so
+                         traffic = FETCH_SIZE + 1/2 record bytes (culled lists) + WRITE_SIZE  (rounds 1-3 doubled all of FETCH_SIZE)."""
+    bwd_ms, bwd_n = kern["blend_bwd_kernel"]
+    fwd_ms, fwd_n = kern["blend_fwd_kernel"]
+    T = ((W + 15) // 16) * ((H + 15) // 16)
+    rec_b, part_b = (64.0, 60.0) if ch == 7 else (48.0, 36.0)
+    pix_b = 4.0 * ch + 8.0
+    bytes_bwd = (rec_b + part_b) * fs["meanL"] + pix_b * W * H + 8.0 * T
+    bytes_fwd = rec_b * fs["meanL"] + pix_b * W * H + 8.0 * T
+    moved_bwd = (rec_b + part_b) * fs["meanL_culled"] + pix_b * 256.0 * fs["tiles_used"] + 8.0 * T
+    dur_s = bwd_ms / max(bwd_n, 1) * 1e-3
+    ach = bytes_bwd / dur_s / 1e9 if bwd_ms > 0 else 0.0
+    moved = moved_bwd / dur_s / 1e9 if bwd_ms > 0 else 0.0
+    traffic = traffic_source = valu_util = lanes_busy = None
+    for name in (f"r04_pmc_raster_{wl_tag}.json", f"r03_pmc_raster_{wl_tag}.json", f"r02_pmc_raster_{wl_tag}.json", f"pmc_raster_{wl_tag}.json"):
+        pmc_path = os.path.join(ROOT, "profiles", name)
+        if ch == 7 and os.path.exists(pmc_path):
+            pm = json.load(open(pmc_path)).get("blend_bwd_kernel<7>", {})
+            if "FETCH_SIZE" in pm and "WRITE_SIZE" in pm:
+                traffic = (pm["FETCH_SIZE"] + pm["WRITE_SIZE"]) * 1024.0 + 0.5 * rec_b * fs["meanL_culled"]
+                traffic_source = (f"profiles/{name}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of the same workload (profiled, static), "
+                                  "FETCH_SIZE corrected per access shape (profiles/r04_fetch_shape_probe.txt)")
+                if pm.get("GRBM_GUI_ACTIVE") and pm.get("SQ_INSTS_VALU"):
+                    # vector-pipe utilisation: every VALU instruction occupies its SIMD for 4 cycles; 1024 SIMDs;
+                    # GRBM_GUI_ACTIVE counts the kernel's cycles on each of the 8 XCDs
+                    valu_util = pm["SQ_INSTS_VALU"] * 4.0 / (pm["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0)
+                if pm.get("SQ_THREAD_CYCLES_VALU") and pm.get("SQ_ACTIVE_INST_VALU"):
+                    lanes_busy = pm["SQ_THREAD_CYCLES_VALU"] / (pm["SQ_ACTIVE_INST_VALU"] * 64.0)
+                break
+    # `bound`: what the counters of the committed --pmc passes say.  The blend backward is bound by vector-instruction
+    # ISSUE (pipe utilisation 0.7 with every lane enabled while ~10 of 64 lanes blend a kept entry), not by HBM: `frac`
+    # stays the fraction of the HBM roofline the contract asks for, `valu_util` is the fraction of the bound that applies.
+    roof = {"kernel": "blend_bwd_kernel", "bound": "valu" if (valu_util or 0.0) >= 0.5 else "hbm",
+            "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+            "peak_achievable": HBM_ACHIEVABLE_GBS, "frac_of_achievable": ach / HBM_ACHIEVABLE_GBS,
+            "moved_bytes_model": moved_bwd, "moved_gbs": moved, "frac_moved": moved / HBM_PEAK_GBS,
+            "tiles_read": fs["tiles_used"], "tiles": T,
+            "valu_util": valu_util, "valu_exec_lane_util": lanes_busy, "traffic": traffic, "traffic_source": traffic_source,
+            "duration_source": "HIP events around every launch, eager continuation of this run's steps",
+            "algorithmic_bytes_per_launch": bytes_bwd, "mean_launch_us": bwd_ms / max(bwd_n, 1) * 1e3, "launches": bwd_n,
+            "sum_tile_list_len": fs["meanL"], "sum_tile_list_len_after_tile_cull": fs["meanL_culled"]}
+    roof_fwd = {"achieved": bytes_fwd / (fwd_ms / max(fwd_n, 1) * 1e-3) / 1e9 if fwd_ms else 0.0,
+                "unit": "GB/s", "mean_launch_us": fwd_ms / max(fwd_n, 1) * 1e3}
+    return roof, roof_fwd
+
+
+def c3_roofline_leg():
+    """BASELINE.json config 3 (200k strand-Gaussians, 32 views @ 1080p: "rocprof HBM GB/s on blend kernel"): the blend kernels'
+    roofline on that workload, timed by a CHILD process (same library, 4 of the views, eager per-kernel HIP events) that runs
+    to completion BEFORE this process touches the GPU (a process that has initialised the GPU must not start another program
+    on this pool)."""
+    import subprocess
+    try:
+        cp = subprocess.run([sys.executable, os.path.abspath(__file__), "--workload", "c3", "--views", "4", "--steps", "40",
+                             "--warmup", "5", "--repeats", "1", "--sustained-seconds", "0", "--trained-iters", "0",
+                             "--no-cpu-baseline", "--no-c3-leg"], capture_output=True, text=True, timeout=300)
+        c3 = json.loads(cp.stdout.strip().splitlines()[-1])
+        return dict(c3["roofline"], workload=c3["config"]["workload"], iters_per_sec=c3["value"],
+                    blend_fwd=c3.get("roofline_blend_fwd"), kernel_us_per_launch=c3.get("kernel_us_per_launch"))
+    except Exception as e:
+        return {"error": str(e)}
+
 
 def main():
     args = parse()
+    c3_leg = None
+    if (int(os.environ.get("WORLD_SIZE", "1")) == 1 and args.workload == "north_star" and not args.no_c3_leg
+            and not args.no_kernel_timing and not args.eager and not args.blocking
+            and "rocprof" not in os.environ.get("LD_PRELOAD", "").lower()):   # (a profiler's preload has initialised the GPU)
+        c3_leg = c3_roofline_leg()
     import torch
     import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -417,7 +503,7 @@ def main():
             stats = {}
             for cull in (False, True):
                 was = C_.set_tile_cull(cull)
-                Ls, Rs = [], []
+                Ls, Rs, Us = [], [], []
                 for c in cams:
                     out = C_.rasterize_gaussians(bg, model.get_xyz, torch.empty(0, device=dev), model.get_opacity,
                                                  model.get_scaling, model.get_rotation, 1.0, torch.empty(0, device=dev),
@@ -427,12 +513,13 @@ def main():
                     img = out[5]
                     maxc = img[lay["tile_maxc"]:lay["tile_maxc"] + 4 * T].view(torch.int32)
                     Ls.append(int(maxc.sum().item()))
+                    Us.append(int((maxc > 0).sum().item()))
                     Rs.append(out[0])
                 C_.set_tile_cull(was)
-                stats[cull] = (sum(Ls) / len(Ls), sum(Rs) / len(Rs))
-            (meanL, meanR), (meanL_culled, meanR_culled) = stats[False], stats[True]
+                stats[cull] = (sum(Ls) / len(Ls), sum(Rs) / len(Rs), sum(Us) / len(Us))
+            (meanL, meanR, _), (meanL_culled, meanR_culled, tiles_used) = stats[False], stats[True]
 
-        return dict(render_ms=render_ms, render_graph_ms=render_graph_ms, render_graph_equal=same, render_graph_frames=KF, meanL=meanL, meanR=meanR, meanL_culled=meanL_culled, meanR_culled=meanR_culled)
+        return dict(render_ms=render_ms, render_graph_ms=render_graph_ms, render_graph_equal=same, render_graph_frames=KF, meanL=meanL, meanR=meanR, meanL_culled=meanL_culled, meanR_culled=meanR_culled, tiles_used=tiles_used)
 
     fs = frame_stats()
     render_ms, meanL, meanR, meanL_culled, meanR_culled = (fs[k] for k in ("render_ms", "meanL", "meanR", "meanL_culled", "meanR_culled"))
@@ -484,6 +571,8 @@ def main():
                    "capacity_rollbacks_while_training": getattr(training, "last_rollbacks", None)}
         if tr["kern"]:
             trained["kernel_us_per_launch"] = {k: (v[0] / v[1] * 1e3 if v[1] else 0.0) for k, v in tr["kern"].items()}
+            trained["roofline"] = roofline_block(tr["kern"], tfs, cams[0].image_width, cams[0].image_height,
+                                                 7 if getattr(opt, "single_pass", True) else 3, args.workload + "_trained")[0]
 
     if rank != 0:
         if world > 1:
@@ -524,57 +613,15 @@ def main():
         "trained_state": trained,
     }
     if kern:
-        bwd_ms, bwd_n = kern["blend_bwd_kernel"]
-        fwd_ms, fwd_n = kern["blend_fwd_kernel"]
-        # algorithmic bytes per launch: per needed tile entry the packed record is read once and one row of
-        # partial sums is written; per pixel the upstream gradient (4 B x channels) + final_T + n_contrib are read
         ch = 7 if getattr(opt, "single_pass", True) else 3
-        rec_b, part_b = (64.0, 60.0) if ch == 7 else (48.0, 36.0)
-        # counted on the reference's tile lists (L_t = entries of the reference's list any pixel of the
-        # tile needed); the product culls instances no pixel blends and moves less (moved_bytes_model below)
-        bytes_bwd = (rec_b + part_b) * meanL + (4.0 * ch + 8.0) * W * H + 8.0 * T
-        bytes_fwd = rec_b * meanL + (4.0 * ch + 8.0) * W * H + 8.0 * T
-        moved_bwd = (rec_b + part_b) * meanL_culled + (4.0 * ch + 8.0) * W * H + 8.0 * T
-        ach = bytes_bwd / (bwd_ms / max(bwd_n, 1) * 1e-3) / 1e9 if bwd_ms > 0 else 0.0
-        # HBM traffic of the same kernel from the committed rocprofv3 --pmc passes (tools/pmc_raster.sh; FETCH_SIZE and
-        # WRITE_SIZE collected in separate runs, corrected as MI355X_MICROARCH.md prescribes: 2 x FETCH_SIZE + WRITE_SIZE,
-        # KB units).  Counters cannot be read from inside this process, so the figure is the profiled one, per launch.
-        traffic = traffic_source = valu_util = lanes_busy = None
-        wl_tag = args.workload
-        for name in (f"r03_pmc_raster_{wl_tag}.json", f"r02_pmc_raster_{wl_tag}.json", f"pmc_raster_{wl_tag}.json"):
-            pmc_path = os.path.join(ROOT, "profiles", name)
-            if ch == 7 and os.path.exists(pmc_path):
-                pm = json.load(open(pmc_path)).get("blend_bwd_kernel<7>", {})
-                if "FETCH_SIZE" in pm and "WRITE_SIZE" in pm:
-                    traffic = (2.0 * pm["FETCH_SIZE"] + pm["WRITE_SIZE"]) * 1024.0
-                    traffic_source = f"profiles/{name}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of the same workload (profiled, static)"
-                    if pm.get("GRBM_GUI_ACTIVE") and pm.get("SQ_INSTS_VALU"):
-                        # vector-pipe utilisation: every VALU instruction occupies its SIMD for 4 cycles; 1024 SIMDs;
-                        # GRBM_GUI_ACTIVE counts the kernel's cycles on each of the 8 XCDs
-                        valu_util = pm["SQ_INSTS_VALU"] * 4.0 / (pm["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0)
-                    if pm.get("SQ_THREAD_CYCLES_VALU") and pm.get("SQ_ACTIVE_INST_VALU"):
-                        lanes_busy = pm["SQ_THREAD_CYCLES_VALU"] / (pm["SQ_ACTIVE_INST_VALU"] * 64.0)
-                    break
-        # `bound`: what the counters of the committed --pmc passes say.  The blend backward is bound by vector-instruction
-        # ISSUE (pipe utilisation 0.7 with every lane enabled while ~10 of 64 lanes blend a kept entry), not by HBM: `frac`
-        # stays the fraction of the HBM roofline the contract asks for, `valu_util` is the fraction of the bound that applies.
-        result["roofline"] = {"kernel": "blend_bwd_kernel", "bound": "valu" if (valu_util or 0.0) >= 0.5 else "hbm",
-                              "achieved": ach, "peak": HBM_PEAK_GBS,
-                              "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "peak_achievable": HBM_ACHIEVABLE_GBS,
-                              "frac_of_achievable": ach / HBM_ACHIEVABLE_GBS, "valu_util": valu_util,
-                              "valu_exec_lane_util": lanes_busy, "traffic": traffic,
-                              "traffic_source": traffic_source,
-                              "duration_source": "HIP events around every launch, eager continuation of this run's steps",
-                              "algorithmic_bytes_per_launch": bytes_bwd, "moved_bytes_model": moved_bwd,
-                              "mean_launch_us": bwd_ms / max(bwd_n, 1) * 1e3,
-                              "launches": bwd_n}
-        result["roofline_blend_fwd"] = {"achieved": bytes_fwd / (fwd_ms / max(fwd_n, 1) * 1e-3) / 1e9 if fwd_ms else 0.0,
-                                        "unit": "GB/s", "mean_launch_us": fwd_ms / max(fwd_n, 1) * 1e3}
+        result["roofline"], result["roofline_blend_fwd"] = roofline_block(kern, fs, W, H, ch, args.workload)
         result["kernel_timing"] = {"method": "HIP event pairs on the launch stream, calibrated bracket cost subtracted",
                                    "bracket_cost_us": rt.lib().hgs_prof_bracket_overhead_ms() * 1e3}
         result["kernel_us_per_launch"] = {k: (v[0] / v[1] * 1e3 if v[1] else 0.0) for k, v in kern.items()}
         result["kernel_ms_per_iter"] = {k: v[0] / kern_steps for k, v in kern.items()}
     result.update(cpu_result)
+    if c3_leg is not None:
+        result["roofline_c3"] = c3_leg
     print(json.dumps(result))
     if world > 1:
         dist.destroy_process_group()

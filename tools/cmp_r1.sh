@@ -8,6 +8,6 @@ mkdir -p gpurun_out
 for rep in 1 2; do
  for w in ${WORKLOADS:-north_star c2 c3 c4}; do
   (cd $tree && timeout 400 python bench.py --workload $w --steps 100 --warmup 10 --no-cpu-baseline 2>/dev/null | tail -1 > ../gpurun_out/cmp_${tree}_${w}_$rep.json)
-  timeout 400 python bench.py --workload $w --steps 100 --warmup 10 --repeats 3 --sustained-seconds 0 --no-cpu-baseline 2>/dev/null | tail -1 > gpurun_out/cmp_cur_${w}_$rep.json
+  timeout 400 python bench.py --workload $w --steps 100 --warmup 10 --repeats 3 --sustained-seconds 0 --no-cpu-baseline --trained-iters 0 --no-c3-leg 2>/dev/null | tail -1 > gpurun_out/cmp_cur_${w}_$rep.json
  done
 done

@@ -63,7 +63,7 @@ def knn_throughput():
 
 def bench_line(workload, extra=()):
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--workload", workload, "--steps", "100", "--warmup", "10",
-           "--repeats", "3", "--sustained-seconds", "0", "--no-cpu-baseline", *extra]
+           "--repeats", "3", "--sustained-seconds", "0", "--no-cpu-baseline", "--trained-iters", "0", "--no-c3-leg", *extra]
     p = subprocess.run(cmd, capture_output=True, text=True, timeout=1500)
     line = [l for l in p.stdout.strip().split("\n") if l.startswith("{")]
     if not line:
