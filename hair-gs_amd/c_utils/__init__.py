@@ -26,8 +26,16 @@ def build(force=False):
     src = os.path.join(_HERE, "_c_utils.c")
     so = os.path.join(_HERE, "_c_utils" + sysconfig.get_config_var("EXT_SUFFIX"))
     if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
-        subprocess.check_call(["gcc", "-O2", "-fPIC", "-shared", "-Wall", "-I" + sysconfig.get_paths()["include"],
-                               "-I" + np.get_include(), src, "-o", so])
+        # built under a private name and renamed into place: the ranks of a torchrun job (or pytest-xdist workers) may all
+        # find the module missing at once, and none of them may import a half-written file
+        tmp = f"{so}.{os.getpid()}.tmp"
+        try:
+            subprocess.check_call(["gcc", "-O2", "-fPIC", "-shared", "-Wall", "-I" + sysconfig.get_paths()["include"],
+                                   "-I" + np.get_include(), src, "-o", tmp])
+            os.replace(tmp, so)
+        finally:
+            if os.path.exists(tmp):
+                os.remove(tmp)
     return so
 
 
@@ -51,7 +59,11 @@ def _load():
     if _native is None:
         src = os.path.join(_HERE, "_c_utils.c")
         so = glob.glob(os.path.join(_HERE, "_c_utils*.so"))
-        if not so or os.path.getmtime(so[0]) < os.path.getmtime(src):
+        try:
+            stale = not so or os.path.getmtime(so[0]) < os.path.getmtime(src)
+        except OSError:          # (the file another process is just replacing)
+            stale = True
+        if stale:
             try:
                 so = [build()]
             except (OSError, subprocess.CalledProcessError) as e:

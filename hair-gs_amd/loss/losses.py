@@ -134,6 +134,10 @@ def strand_joints_magnet_loss(gaussians: HairGaussianModel):
     if n < 3:
         return pts.sum() * 0.0
     _, nn = knn3_self(pts)
+    # (an end whose coordinates are not finite compares closer to nothing: its neighbour slots stay -1, which would index
+    # the LAST end below instead of failing -- such rows, and rows whose neighbour is one, are left out of the mean)
+    found = (nn >= 0).all(dim=1)
+    nn = nn.clamp(min=0)
     sq = ((pts[:, None, :] - pts[nn]) ** 2).sum(dim=-1)                     # [n, 3], differentiable
     self_idx = torch.arange(n, device=ep.device)
     second_ok = (nn[:, 1] != self_idx) & (nn[:, 1] != comp)
@@ -142,8 +146,10 @@ def strand_joints_magnet_loss(gaussians: HairGaussianModel):
     self_mask = torch.norm(self_dir, dim=1, keepdim=True) > gaussians.min_val
     nn_dir = det[nn] - det[mapping[nn]]
     nn_mask = torch.norm(nn_dir, dim=1, keepdim=True) > gaussians.min_val
-    final = (self_mask & nn_mask).reshape(-1)
+    final = (self_mask & nn_mask).reshape(-1) & found & torch.isfinite(sq.detach())
     sq = sq[final]
+    if sq.numel() == 0:
+        return pts.sum() * 0.0
     return torch.mean(sq * sq)
 
 

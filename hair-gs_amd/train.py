@@ -47,6 +47,21 @@ class ViewParallel:
             ok = dist.get_backend() == "nccl" and os.environ.get("HGS_GRAPH_COLLECTIVE", "1") != "0" and torch.cuda.is_available()
             if ok:
                 dev = torch.device("cuda", torch.cuda.current_device()) if device is None else device
+                # Three agreed stages, so that a rank on which a stage fails never leaves the others waiting inside a collective
+                # it will not join: (1) an eager all-reduce on the capture stream (communicator set-up); (2) the capture alone --
+                # nothing is enqueued by it -- then the ranks tell each other whether it succeeded (eager MIN on the default
+                # stream); (3) only if it did everywhere, two replays whose sums are checked, and a last agreement.
+                def agree(flag):
+                    verdict = torch.tensor([1 if flag else 0], dtype=torch.int32, device=dev)
+                    dist.all_reduce(verdict, op=dist.ReduceOp.MIN)
+                    return bool(int(verdict.item()))
+
+                def report(stage, e):
+                    if self.rank == 0 or e is not None:
+                        print(f"ViewParallel[rank {self.rank}]: all-reduce inside a captured graph is not available "
+                              f"({stage}: {type(e).__name__ if e is not None else 'another rank failed'}: {e}); using the eager exchange")
+
+                g = buf = s = None
                 try:
                     buf = torch.full((1024,), float(self.rank + 1), device=dev)
                     s = torch.cuda.Stream(device=dev)
@@ -58,23 +73,28 @@ class ViewParallel:
                     g = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(g, stream=s, capture_error_mode="thread_local"):
                         dist.all_reduce(buf)
+                    err = None
+                except Exception as e:       # capture of the collective is not supported here: keep the eager exchange
+                    err = e
+                ok = agree(err is None)
+                if not ok:
+                    report("capture", err)
+                else:
                     n = dist.get_world_size()
                     want = float(n * (n + 1) // 2)
                     good = True
-                    for _ in range(2):
-                        buf.fill_(float(self.rank + 1))
-                        g.replay()
-                        torch.cuda.synchronize(dev)
-                        good = good and bool((buf == want).all())
-                    ok = good
-                except Exception as e:       # capture of the collective is not supported here: keep the eager exchange
-                    if self.rank == 0:
-                        print(f"ViewParallel: all-reduce inside a captured graph is not available ({type(e).__name__}: {e}); "
-                              "using the eager exchange")
-                    ok = False
-                verdict = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
-                dist.all_reduce(verdict, op=dist.ReduceOp.MIN)
-                ok = bool(int(verdict.item()))
+                    try:
+                        for _ in range(2):
+                            buf.fill_(float(self.rank + 1))
+                            g.replay()
+                            torch.cuda.synchronize(dev)
+                            good = good and bool((buf == want).all())
+                        err = None
+                    except Exception as e:
+                        good, err = False, e
+                    ok = agree(good)
+                    if not ok:
+                        report("replay", err)
             self._graph_ok = ok
         return self._graph_ok
 
@@ -177,6 +197,10 @@ def training_step(gaussians, viewpoint_cam, opt, bg, iteration, extent=1.0, vp=N
     one autograd node over the fused kernels (same loss, gradients and statistics).  `black_background=True`: the caller
     states that `bg` is all zero (op-by-op single-pass path: the blend backward's black-background specialisation)."""
     from diff_gaussian_rasterization import _C as raster
+    # once per ITERATION, not per attempt: a repeated attempt (capacity overflow) must not bump the SH degree again
+    gaussians.update_learning_rate(iteration)
+    if iteration % 1000 == 0:
+        gaussians.oneupSHdegree()
     for _attempt in range(4):
         try:
             return _training_step(gaussians, viewpoint_cam, opt, bg, iteration, extent, vp, raster, fused,
@@ -191,9 +215,6 @@ def _training_step(gaussians, viewpoint_cam, opt, bg, iteration, extent, vp, ras
     # gradients.  A captured graph leaves its static gradient tensors in `.grad` after a replay -- an eager iteration that
     # follows (topology iterations of training(), bench.py's kernel-timing pass) would ACCUMULATE onto them.
     gaussians.optimizer.zero_grad(set_to_none=True)
-    gaussians.update_learning_rate(iteration)
-    if iteration % 1000 == 0:
-        gaussians.oneupSHdegree()
     if fused is not None:
         fused.views.prologue(fused.views.index[id(viewpoint_cam)], ride=True)   # (no launch: rides in the forward's first one)
         fused.stats_in_backward = iteration < opt.densify_until_iter
@@ -776,12 +797,11 @@ def main(argv=None):
         os.makedirs(args.model_path, exist_ok=True)
         with open(os.path.join(args.model_path, "cfg_args"), "w") as fh:   # what render.py's get_combined_args reads back
             fh.write(str(args))
-    # rank 0 prepares the capture first (it converts the sparse points to a PLY once and writes the model directory's
-    # input.ply / cameras.json); the other ranks read what it left
-    if world > 1 and rank != 0:
-        dist.barrier()
+    # Every rank loads the capture at the same time: the one shared file a first run creates -- sparse/0/points3D.ply -- is
+    # written under a private name and renamed into place (data/dataset_readers.py: whoever converts, every reader sees a
+    # complete file), and the model directory's input.ply / cameras.json are rank 0's alone (scene/scene.py).
     scene = Scene(mp.extract(args))
-    if world > 1 and rank == 0:
+    if world > 1:
         dist.barrier()
     opt = op.extract(args)
     g = scene.gaussians

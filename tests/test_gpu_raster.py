@@ -6,6 +6,8 @@ order, no contraction on either side).  The blend uses the hardware exp (v_exp_f
 so a pixel whose alpha lands within an ulp of the 1/255 or T<1e-4 thresholds may take the other branch: such pixels
 are counted and bounded (the reference on NVIDIA hardware has the same property against any CPU restatement).
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -234,6 +236,34 @@ def _grad_check(g, gref, fwd_ref, skip=()):
         if fragile.any():
             assert float(err[fragile].max()) / scale <= FRAGILE_MAX_OF_SCALE, (k, float(err[fragile].max()) / scale)
     return report
+
+
+def _grad_percentiles(g, gref):
+    """Per-element error distribution of every gradient against the oracle (the measured bar):
+    err / max|ref tensor| and the RELATIVE error err / max(|ref|, 1e-3 max|ref tensor|) -- an element that cancels to ~0 has
+    no relative error of its own -- at p50 / p99 / p99.9 / max, over the Gaussians the oracle does not mark fragile and over all."""
+    fragile = gref["fragile"]
+    P = fragile.shape[0]
+    out = {}
+    for k in GRAD_KEYS:
+        if gref[k].size == 0:
+            continue
+        b = gref[k].astype(np.float64).reshape(P, -1)
+        a = g[k].astype(np.float64).reshape(b.shape)
+        scale = float(np.abs(b).max())
+        if scale == 0.0:
+            continue
+        nz = np.abs(b).max(axis=1) > 0            # Gaussians with a gradient at all (culled ones are exact zeros on both sides)
+        row = {}
+        for tag, sel in (("solid", nz & ~fragile), ("all", nz)):
+            if not sel.any():
+                continue
+            err = np.abs(a[sel] - b[sel]).reshape(-1)
+            rel = err / np.maximum(np.abs(b[sel]).reshape(-1), 1e-3 * scale)
+            q = lambda v: [float(x) for x in np.percentile(v, [50, 99, 99.9, 100])]
+            row[tag] = {"of_scale": q(err / scale), "relative": q(rel), "n": int(err.size)}
+        out[k] = row
+    return out
 
 
 @pytest.mark.parametrize("name", [n for n in ALL if n not in ("all_culled",)])
@@ -487,5 +517,14 @@ def test_full_size_forward_and_backward_against_oracle(workload):
     dpix = np.random.default_rng(9).normal(size=(3, s["H"], s["W"])).astype(np.float32)
     gref = O.backward(s, ref, dpix)
     g = G.run_backward(s, fw, dpix)
-    report = _grad_check(g, gref, ref, skip=("dL_dcov3D",))
+    report = _grad_check(g, gref, ref)
     print(workload, {k: (f"{v[0]:.1e}", f"{v[1]:.1e}", v[2]) for k, v in report.items()})
+    # the measured error distribution, every tensor (dL_dcov3D included), for DESIGN.md's table: printed, and written where a
+    # collecting run asks for it (HGS_GRAD_REPORT_DIR)
+    pct = _grad_percentiles(g, gref)
+    print("GRAD_PERCENTILES", workload, {k: {t: ["%.1e" % x for x in v[t]["relative"]] for t in v} for k, v in pct.items()})
+    if os.environ.get("HGS_GRAD_REPORT_DIR"):
+        import json
+        with open(os.path.join(os.environ["HGS_GRAD_REPORT_DIR"], f"grad_parity_{workload}.json"), "w") as fh:
+            json.dump({"workload": workload, "fragile_gaussians": int(gref["fragile"].sum()), "gaussians": int(gref["fragile"].shape[0]),
+                       "percentiles_p50_p99_p99.9_max": pct}, fh, indent=1)

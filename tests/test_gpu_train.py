@@ -272,6 +272,13 @@ def test_async_capacity_mode_matches_blocking_and_recovers_from_overflow():
         before = model._endpoints.detach().clone()
         loss, _, _ = training_step(model, cams[1], opt, bg, 1, extent=extent)
         assert torch.isfinite(loss) and not torch.equal(before, model._endpoints.detach())
+        # the per-ITERATION bookkeeping is not repeated with the step: an overflow on an iteration that bumps the SH degree
+        # (every 1000th, train.py:136-137) bumps it once (round 3 bumped it per attempt and skipped a degree)
+        bumps = []
+        model.oneupSHdegree = lambda: bumps.append(1)
+        raster._state["cap"] = 64
+        training_step(model, cams[2], opt, bg, 1000, extent=extent)
+        assert raster._state["cap"] > 64 and len(bumps) == 1
     finally:
         raster.set_async(False)
 

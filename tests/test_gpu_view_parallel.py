@@ -13,10 +13,11 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
 
 
-def _run(nproc, port=None, mode="weak", global_views=None):
+def _run(nproc, port=None, mode="weak", global_views=None, backend="gloo", steps_per_graph=1):
     from tests.gpu_util import free_port
     port = free_port()
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0", HGS_VP_MODE=mode)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0", HGS_VP_MODE=mode, HGS_VP_BACKEND=backend,
+               HGS_VP_STEPS_PER_GRAPH=str(steps_per_graph))
     if global_views is not None:
         env["HGS_VP_GLOBAL_VIEWS"] = str(global_views)
     worker = os.path.join(ROOT, "tests", "_vp_gpu_worker.py")
@@ -29,6 +30,38 @@ def _run(nproc, port=None, mode="weak", global_views=None):
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
     assert "VP_GPU_OK" in out.stdout
+    if backend == "nccl" and nproc > 1:
+        assert "VP_RCCL_GRAD_OK" in out.stdout
+    return out.stdout
+
+
+def _devices():
+    import torch
+    return torch.cuda.device_count()      # (does not initialise the GPU: the workers are started from a process that never does)
+
+
+# ---- RCCL between DEVICES: these switch themselves on where the box has more than one GPU (the driver's 8-GPU node); on the
+# one-GPU lease they are skipped and the gloo tests below cover everything but the transport.
+@pytest.mark.skipif(_devices() < 2, reason="needs 2 GPUs: one rank per device over RCCL")
+@pytest.mark.parametrize("steps_per_graph", [1, 4])
+def test_rccl_two_devices_weak(steps_per_graph):
+    """One view per rank and step on two devices: replicas bit-identical, parameters equal to a single process that averages
+    the same views' gradients by hand, the all-reduce captured into the step's graph (four optimizer steps per launch in the
+    second case), one averaged exchange within 1e-5 of the hand mean."""
+    _run(2, mode="weak", backend="nccl", steps_per_graph=steps_per_graph)
+
+
+@pytest.mark.skipif(_devices() < 2, reason="needs 2 GPUs: one rank per device over RCCL")
+def test_rccl_two_devices_strong():
+    """SURVEY.md 8e's protocol on two devices: a global batch of 4 views per optimizer step, two per rank inside one captured
+    graph, summed locally, one all-reduce."""
+    _run(2, mode="strong", global_views=4, backend="nccl")
+
+
+@pytest.mark.skipif(_devices() < 8, reason="needs 8 GPUs")
+@pytest.mark.parametrize("mode,global_views", [("weak", None), ("strong", 8)])
+def test_rccl_eight_devices(mode, global_views):
+    _run(8, mode=mode, global_views=global_views, backend="nccl", steps_per_graph=4 if mode == "weak" else 1)
 
 
 def test_two_ranks_stay_replicated_and_match_hand_averaged_gradients():
