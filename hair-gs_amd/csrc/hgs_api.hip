@@ -126,7 +126,7 @@ size_t hgs_image_bytes(int W, int H) { HgsImage im; return hgs_image_carve(nullp
 size_t hgs_binning_bytes(int R) { HgsBinning b; return hgs_binning_carve(nullptr, (size_t)(R > 0 ? R : 0), b, nullptr); }
 size_t hgs_backward_scratch_bytes(int P, int R) {
   (void)P;
-  return hgs_align_up((size_t)(R > 0 ? R : 0) * HGS_SCRATCH_ROWS * HGS_SCRATCH_ROW_FLOATS * sizeof(float)) + HGS_ALIGN;
+  return hgs_align_up((size_t)(R > 0 ? R : 0) * HGS_INST_GRAD_FLOATS * sizeof(float)) + HGS_ALIGN;
 }
 int hgs_geom_layout(int P, size_t* offsets) { HgsGeom g; hgs_geom_carve(nullptr, (size_t)P, g, offsets); return 0; }
 int hgs_image_zero_range(int W, int H, size_t* offset, size_t* bytes) {
@@ -328,7 +328,7 @@ int hgs_forward_render_multi(void* stream, int P, int W, int H, int R_capacity, 
 size_t hgs_binning_bytes_multi(int R) { HgsBinning b; return hgs_binning_carve(nullptr, (size_t)(R > 0 ? R : 0), b, nullptr, 7); }
 size_t hgs_backward_scratch_bytes_multi(int P, int R) {
   (void)P;
-  return hgs_align_up((size_t)(R > 0 ? R : 0) * HGS_SCRATCH_ROWS * HGS_SCRATCH_ROW_FLOATS * sizeof(float)) + HGS_ALIGN;
+  return hgs_align_up((size_t)(R > 0 ? R : 0) * 16 * sizeof(float)) + HGS_ALIGN;
 }
 
 static int backward_impl(void* stream, int P, int D, int M, int R, int W, int H, const float* bg, const float* means3D,

@@ -117,7 +117,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_kernel(int nblk, int T, Hgs
 // One instance in its final list position: point_list, the sorted key and the packed record the blend kernels stream.
 // Everything about the Gaussian comes from its 64-byte template (HgsGeom::grec, scatter_kernel): one contiguous gather.
 template <bool EXTRA>   // EXTRA: 64-B records with the 4 extra channels of the single-pass mode, else 48-B records
-__device__ __forceinline__ void emit_instance(uint64_t key, uint32_t pos, int tx, int ty, uint32_t Rcap, const HgsGeom& g, const HgsBinning& b) {
+__device__ __forceinline__ void emit_instance(uint64_t key, uint32_t pos, int tx, int ty, const HgsGeom& g, const HgsBinning& b) {
   const uint32_t id = (uint32_t)key >> HGS_QMASK_SHIFT;
   const float4* t = g.grec + 4 * (size_t)id;
   const float4 t0 = t[0], t1 = t[1], t2 = t[2];
@@ -128,9 +128,6 @@ __device__ __forceinline__ void emit_instance(uint64_t key, uint32_t pos, int tx
   // the instance's slot in Gaussian-major order (offset of the Gaussian + cell of its tile rectangle): the backward stores
   // this instance's row of partial sums there, so that a Gaussian's rows are contiguous for preprocess_bwd_kernel
   const uint32_t slot = u3.y + ((uint32_t)ty - (u3.z >> 16)) * u3.w + ((uint32_t)tx - (u3.z & 0xFFFFu));
-  // the same mask in Gaussian-major order: how many of the instance's (instance, quadrant) rows of the backward scratch exist
-  // (blend_bwd_tr_kernel writes one per set bit, preprocess_bwd_kernel adds exactly those)
-  if (slot < Rcap) b.inv[slot] = qmask;
   if (!EXTRA) {  // 48-B record: xy, conic, opacity, rgb, id, quadrant mask, slot
     float4* rec = b.packed + (size_t)pos * 3;
     rec[0] = t0;
@@ -514,7 +511,7 @@ __global__ __launch_bounds__(HGS_BLOCK) void sort_tiles_kernel(int gx, int T, ui
 #pragma unroll
     for (int i = 0; i < KPT; i++) {
       const uint32_t e = threadIdx.x + (uint32_t)i * HGS_BLOCK;
-      if (e < cn) emit_instance<EXTRA>(key[i], start + rank[i], tx, ty, Rcap, g, b);
+      if (e < cn) emit_instance<EXTRA>(key[i], start + rank[i], tx, ty, g, b);
     }
     return;
   }
@@ -534,7 +531,7 @@ __global__ __launch_bounds__(HGS_BLOCK) void sort_tiles_kernel(int gx, int T, ui
     for (int i = lane; i < m; i += 64) sk[i] = (uint32_t)i < n ? b.keys[start + i] : ~0ull;
     wave_lds_fence();
     bitonic_wave(sk, m, lane);
-    for (uint32_t i = lane; i < n; i += 64) emit_instance<EXTRA>(sk[i], start + i, tx, ty, Rcap, g, b);
+    for (uint32_t i = lane; i < n; i += 64) emit_instance<EXTRA>(sk[i], start + i, tx, ty, g, b);
     return;
   }
   const uint32_t nchunks = (n + SORT_CAP - 1) / SORT_CAP;
@@ -547,7 +544,7 @@ __global__ __launch_bounds__(HGS_BLOCK) void sort_tiles_kernel(int gx, int T, ui
     __syncthreads();
     bitonic_lds(sk, m);
     if (nchunks == 1) {
-      for (uint32_t i = threadIdx.x; i < cn; i += HGS_BLOCK) emit_instance<EXTRA>(sk[i], cbase + i, tx, ty, Rcap, g, b);
+      for (uint32_t i = threadIdx.x; i < cn; i += HGS_BLOCK) emit_instance<EXTRA>(sk[i], cbase + i, tx, ty, g, b);
     } else {
       for (uint32_t i = threadIdx.x; i < cn; i += HGS_BLOCK) b.keys[cbase + i] = sk[i];
     }
@@ -579,7 +576,7 @@ __global__ __launch_bounds__(HGS_BLOCK) void sort_tiles_kernel(int gx, int T, ui
 #pragma unroll
       for (int i = 0; i < KPT; i++) {
         const uint32_t e = threadIdx.x + (uint32_t)i * HGS_BLOCK;
-        if (e < cn) emit_instance<EXTRA>(key[i], start + rank[i], tx, ty, Rcap, g, b);
+        if (e < cn) emit_instance<EXTRA>(key[i], start + rank[i], tx, ty, g, b);
       }
     }
   }

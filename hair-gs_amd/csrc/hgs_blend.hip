@@ -37,7 +37,6 @@
 //     boundary) and, for the segments a pixel passes through, c alpha T_local T_in in place of c alpha T (one rounding
 //     per contribution).  Integer results (last contributor) follow the reference's rules on those products.
 #include "hgs_common.h"
-#include <stdlib.h>
 
 // development aid: per-workgroup start/end timestamps (hgs_debug_set_wg_trace)
 __device__ unsigned long long* g_wg_trace_fwd = nullptr;
@@ -653,289 +652,7 @@ __global__ __launch_bounds__(HGS_BLOCK) __attribute__((amdgpu_waves_per_eu(HGS_B
   }
 }
 
-// ------------------------------------------------------------------------------------------------
-// Backward with a TRANSPOSED reduction (round 4; hgs_set_backward_variant 1).
-//
-// What blend_bwd_kernel spends 45 of its ~86 vector instructions per evaluated (wavefront, entry) pair on is not the pair's
-// gradient but what follows it: eleven products with the pixel's dx, dy and dL/dpixel and a 16-value transposing reduction
-// over 64 lanes of which ~10 hold something.  Measured with the reduction compiled out, the walk alone -- alpha, the
-// transmittance / accumulated-colour recurrences, three scalars per pixel -- takes 28.7 of the kernel's 48 us.  Here the
-// walk only PARKS those three scalars of a pair in LDS (u = G dL/dalpha, its RGB-only twin of the densification
-// statistics, w = alpha T: one 64-float row each), eight pairs at a time, and a flush turns the lane assignment round:
-//   lane (g = lane >> 3, m = lane & 7) takes the eight pixels of image row g of the quadrant for parked pair m;
-//   it holds the pair's d = mean - pixel for ITS pixels in registers (dx for eight columns, one dy), so the moments
-//   u dx, u dx dx, ... and the colour gradients w dL/dpixel are plain per-lane multiply-adds over eight pixels (dL/dpixel
-//   of the quadrant stays in LDS for the whole walk: the lanes of a pixel row read it as a broadcast);
-//   the 16 sums of a pair are then reduced over its EIGHT lanes -- three levels (row_ror:8, permlane16 swap, permlane32
-//   swap) of the transposing butterfly, 28 instructions for eight pairs instead of 32 for one -- and lane (g, m) ends with
-//   values g and 8 + g of pair m.
-// Every (instance, quadrant) pair owns a 64-byte row of the scratch -- (instance slot) * 4 + rank of the quadrant among the
-// instance's quadrant-mask bits: an instance's rows are adjacent -- written straight from those registers: no combine of the
-// four wavefronts through LDS, so a flush is not tied to the staging batches (a batch-end flush of ~1 parked pair would
-// cost as much as one of eight), and no barrier besides the record staging.  Rows of pairs that are skipped (behind the
-// wavefront's or the tile's last contributor) are zero-filled: preprocess_bwd_kernel adds popcount(mask) rows per instance
-// (HgsBinning::inv holds the masks in Gaussian-major order).  Same products per (pixel, entry) as blend_bwd_kernel, summed
-// in a different (fixed) order: bitwise reproducible, gradients equal to fp32 rounding.
-#define TR_S 8                              // parked pairs per flush
-#define TR_STRIDE 68                        // floats per parked row: 64 pixels + 4
-#define TR_ROWS (3 * TR_S)                  // u | u_rgb | w
-#define TR_DL_FLOATS (7 * 64)               // dL/dpixel of the quadrant, [channel][pixel]
-#define TR_WAVE_FLOATS (TR_ROWS * TR_STRIDE + TR_DL_FLOATS)
-typedef float hgs_v4f __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ void wave_lds_order() { asm volatile("" ::: "memory"); }   // (LDS operations of one wavefront execute in order)
-
-template <int C, bool BLACK>
-__global__ __launch_bounds__(HGS_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 5))) void blend_bwd_tr_kernel(HgsImage im, HgsBinning bn, int W, int H, int gx,
-                                                              uint32_t Rcap, const float* __restrict__ bg,
-                                                              PixGrad<C> dL_dpix, float* __restrict__ inst_grad) {
-  constexpr int REC4 = Chan<C>::REC4;
-  __shared__ __attribute__((aligned(16))) float abuf[4][TR_WAVE_FLOATS];
-  __shared__ __attribute__((aligned(16))) float pinfo[4][TR_S][4];   // per parked pair: scratch row (as int bits), -, mean x, mean y
-  __shared__ float4 recs[2][BWD_BATCH * REC4];
-  const uint32_t void_pass = im.status[HGS_ST_OVERFLOW];
-  BlendItem it;
-  if (!blend_item(im, Rcap, it) || void_pass) return;
-  const int tile = it.tile;
-  WgTrace _trace(g_wg_trace_bwd);
-  _trace.item(tile, it.seg, it.nseg, it.e - it.s);
-  const uint2 range = it.range;
-  const float4* __restrict__ packed = bn.packed;
-  const uint32_t maxc = im.tile_maxc[tile];
-  {
-    // entries past the last one any pixel needed: zero rows for all their (instance, quadrant) pairs
-    const uint32_t end = range.x + it.e, first = range.x + max(it.s, maxc);
-    if (end > first) {
-      const uint32_t n4 = (end - first) * 4;
-      for (uint32_t i = threadIdx.x; i < n4; i += HGS_BLOCK) {
-        const uint32_t inst = first + (i >> 2), j = i & 3u;
-        const uint2 ms = *(const uint2*)((const uint32_t*)packed + (size_t)inst * 4 * REC4 + 7 + C);   // (quadrant mask, slot)
-        if (j < (uint32_t)__popc(ms.x & HGS_QMASK_BITS) && ms.y < Rcap) {
-          float4* row = (float4*)(inst_grad + ((size_t)ms.y * 4 + j) * 16);
-          row[0] = row[1] = row[2] = row[3] = make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-      }
-    }
-  }
-  if (maxc <= it.s) return;
-  const int seg_lo = (int)it.s, top = (int)min(maxc, it.e);
-  const int tx = tile % gx, ty = tile / gx;
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int qx0 = tx * HGS_TILE + (wave & 1) * 8, qy0 = ty * HGS_TILE + (wave >> 1) * 8;
-  const int px = qx0 + (lane & 7), py = qy0 + (lane >> 3);
-  const bool inside = px < W && py < H;
-  const float pxf = (float)px, pyf = (float)py;
-  const size_t pix = (size_t)py * W + px;
-
-  const float4* src = packed + (size_t)range.x * REC4;
-  float4 stage = make_float4(0.f, 0.f, 0.f, 0.f);
-  {
-    const int lo = max(seg_lo, top - BWD_BATCH), cnt = top - lo;
-    if (threadIdx.x < cnt * REC4) stage = src[(size_t)lo * REC4 + threadIdx.x];
-  }
-
-  const float T_final = inside ? im.final_T[pix] : 0.f;
-  float T = T_final;
-  const uint32_t last = inside ? im.n_contrib[pix] : 0u;
-  uint32_t wlast = last;
-#pragma unroll
-  for (int d = 32; d >= 1; d >>= 1) wlast = max(wlast, (uint32_t)__shfl_xor((int)wlast, d, 64));
-  wlast = __builtin_amdgcn_readfirstlane(wlast);
-  float dpx[C], acc_dot = 0.f, acc_dot_rgb = 0.f;
-  float bg_dot = 0.f, bg_dot_rgb = 0.f;
-#pragma unroll
-  for (int k = 0; k < C; k++) {
-    dpx[k] = inside ? dL_dpix.plane[k][pix] : 0.f;
-    if (!BLACK) {
-      bg_dot += bg[k] * dpx[k];
-      if (k < 3) bg_dot_rgb += bg[k] * dpx[k];
-    }
-  }
-  if (it.split && last > it.e) {   // contributors behind this segment: the state the serial walk would arrive with (blend_bwd_kernel)
-    const float Tn = bn.seg_T[((size_t)it.w + 1) * HGS_BLOCK + threadIdx.x];
-    float d = 0.f, d_rgb = 0.f;
-#pragma unroll
-    for (int k = 0; k < C; k++) {
-      d = __builtin_fmaf(bn.seg_C[(((size_t)it.w + 1) * C + k) * HGS_BLOCK + threadIdx.x], dpx[k], d);
-      if (k == 2) d_rgb = d;
-    }
-    const float inv = Tn > 0.f ? 1.f / Tn : 0.f;
-    T = Tn;
-    acc_dot = d * inv;
-    acc_dot_rgb = d_rgb * inv;
-  }
-
-  float* const ab = abuf[wave];
-  float* const dl = ab + TR_ROWS * TR_STRIDE;
-  float (*const pi)[4] = pinfo[wave];
-#pragma unroll
-  for (int k = 0; k < C; k++) dl[k * 64 + lane] = dpx[k];
-  if (lane < TR_S) pi[lane][0] = __int_as_float(-1);
-  wave_lds_order();
-  const int fm = lane & 7, fg = lane >> 3;                     // the flush's lane assignment: parked pair, pixel row
-  const float fy = (float)(qy0 + fg), fx0 = (float)qx0;
-
-  if (threadIdx.x < BWD_BATCH * REC4) recs[0][threadIdx.x] = stage;
-  __syncthreads();
-
-  int s = 0;   // parked pairs of this wavefront
-  auto flush = [&]() {
-    wave_lds_order();
-    const float4 info = *(const float4*)pi[fm];
-    const int rowid = __float_as_int(info.x);
-    const float dy = info.w - fy;
-    float dxs[8];                                              // (the walk's own dx, dy: mean - pixel, one rounding)
-#pragma unroll
-    for (int x = 0; x < 8; x++) dxs[x] = info.z - (fx0 + (float)x);
-    float v[16];
-#pragma unroll
-    for (int k = 0; k < 16; k++) v[k] = 0.f;
-    {
-      const hgs_v4f ua = *(const hgs_v4f*)&ab[fm * TR_STRIDE + 8 * fg], ub = *(const hgs_v4f*)&ab[fm * TR_STRIDE + 8 * fg + 4];
-      const float u[8] = {ua[0], ua[1], ua[2], ua[3], ub[0], ub[1], ub[2], ub[3]};
-      float s0 = 0.f, mx = 0.f, mxx = 0.f;
-#pragma unroll
-      for (int x = 0; x < 8; x++) {
-        const float t = u[x] * dxs[x];
-        s0 += u[x];
-        mx += t;
-        mxx = __builtin_fmaf(t, dxs[x], mxx);
-      }
-      v[0] = mx; v[1] = dy * s0; v[2] = mxx; v[3] = dy * mx; v[4] = dy * dy * s0; v[5] = s0;
-    }
-    if (C > 3) {
-      const hgs_v4f ra = *(const hgs_v4f*)&ab[(TR_S + fm) * TR_STRIDE + 8 * fg], rb = *(const hgs_v4f*)&ab[(TR_S + fm) * TR_STRIDE + 8 * fg + 4];
-      const float r[8] = {ra[0], ra[1], ra[2], ra[3], rb[0], rb[1], rb[2], rb[3]};
-      float r0 = 0.f, rx = 0.f;
-#pragma unroll
-      for (int x = 0; x < 8; x++) { r0 += r[x]; rx = __builtin_fmaf(r[x], dxs[x], rx); }
-      v[6 + C] = rx; v[7 + C] = dy * r0;
-    }
-    {
-      const hgs_v4f wa = *(const hgs_v4f*)&ab[(2 * TR_S + fm) * TR_STRIDE + 8 * fg], wb = *(const hgs_v4f*)&ab[(2 * TR_S + fm) * TR_STRIDE + 8 * fg + 4];
-      const float w[8] = {wa[0], wa[1], wa[2], wa[3], wb[0], wb[1], wb[2], wb[3]};
-#pragma unroll
-      for (int k = 0; k < C; k++) {
-        const hgs_v4f da = *(const hgs_v4f*)&dl[k * 64 + 8 * fg], db = *(const hgs_v4f*)&dl[k * 64 + 8 * fg + 4];
-        float a = 0.f;
-        a = __builtin_fmaf(w[0], da[0], a); a = __builtin_fmaf(w[1], da[1], a); a = __builtin_fmaf(w[2], da[2], a); a = __builtin_fmaf(w[3], da[3], a);
-        a = __builtin_fmaf(w[4], db[0], a); a = __builtin_fmaf(w[5], db[1], a); a = __builtin_fmaf(w[6], db[2], a); a = __builtin_fmaf(w[7], db[3], a);
-        v[6 + k] = a;
-      }
-    }
-    // reduce over the pair's eight lanes (lane bits 3, 4, 5), transposing: level 1 inside the 16-lane rows (bank-masked
-    // row_ror:8: lanes 0-7 of a row keep value 2i, lanes 8-15 value 2i+1), level 2 across row pairs, level 3 across halves
-    asm volatile("s_nop 1\n\t"
-                 "v_add_f32_dpp %0, %0, %0" HGS_DPP("row_ror:8", "0x3")   "v_add_f32_dpp %2, %2, %2" HGS_DPP("row_ror:8", "0x3")
-                 "v_add_f32_dpp %4, %4, %4" HGS_DPP("row_ror:8", "0x3")   "v_add_f32_dpp %6, %6, %6" HGS_DPP("row_ror:8", "0x3")
-                 "v_add_f32_dpp %8, %8, %8" HGS_DPP("row_ror:8", "0x3")   "v_add_f32_dpp %10, %10, %10" HGS_DPP("row_ror:8", "0x3")
-                 "v_add_f32_dpp %12, %12, %12" HGS_DPP("row_ror:8", "0x3") "v_add_f32_dpp %14, %14, %14" HGS_DPP("row_ror:8", "0x3")
-                 "v_add_f32_dpp %0, %1, %1" HGS_DPP("row_ror:8", "0xc")   "v_add_f32_dpp %2, %3, %3" HGS_DPP("row_ror:8", "0xc")
-                 "v_add_f32_dpp %4, %5, %5" HGS_DPP("row_ror:8", "0xc")   "v_add_f32_dpp %6, %7, %7" HGS_DPP("row_ror:8", "0xc")
-                 "v_add_f32_dpp %8, %9, %9" HGS_DPP("row_ror:8", "0xc")   "v_add_f32_dpp %10, %11, %11" HGS_DPP("row_ror:8", "0xc")
-                 "v_add_f32_dpp %12, %13, %13" HGS_DPP("row_ror:8", "0xc") "v_add_f32_dpp %14, %15, %15" HGS_DPP("row_ror:8", "0xc")
-                 : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]), "+v"(v[8]),
-                   "+v"(v[9]), "+v"(v[10]), "+v"(v[11]), "+v"(v[12]), "+v"(v[13]), "+v"(v[14]), "+v"(v[15]));
-    // (row r = lane >> 4 of fold16(a, b) holds a.r0 + a.r1, b.r0 + b.r1, a.r2 + a.r3, b.r2 + b.r3; fold32: the low half a, the high half b)
-    const float z0 = fold32(fold16(v[0], v[2]), fold16(v[4], v[6]));
-    const float z1 = fold32(fold16(v[8], v[10]), fold16(v[12], v[14]));
-    // lane (fg, fm) now holds values fg and 8 + fg of pair fm
-    if (rowid >= 0) {
-      float* row = inst_grad + (size_t)rowid * 16;
-      row[fg] = z0;
-      row[8 + fg] = z1;
-    }
-    if (lane < TR_S) pi[lane][0] = __int_as_float(-1);
-    wave_lds_order();
-    s = 0;
-  };
-
-  int cur = 0;
-  for (int hi = top; hi > seg_lo; hi -= BWD_BATCH, cur ^= 1) {
-    const int lo = max(seg_lo, hi - BWD_BATCH);
-    const int cnt = hi - lo;
-    if (lo > seg_lo) {
-      const int nlo = max(seg_lo, lo - BWD_BATCH), ncnt = lo - nlo;
-      if (threadIdx.x < ncnt * REC4) stage = src[(size_t)nlo * REC4 + threadIdx.x];
-    }
-    const float* rf = (const float*)&recs[cur][0];
-    const uint32_t mk = lane < cnt ? __float_as_uint(rf[lane * 4 * REC4 + 7 + C]) : 0u;
-    const uint64_t m_all = __ballot(((mk >> wave) & 1u) != 0u);
-    uint64_t m = m_all;
-    if ((int)wlast <= lo) m = 0;
-    else if ((int)wlast - lo < 64) m &= (1ull << ((int)wlast - lo)) - 1ull;
-    if (m_all & ~m) {   // pairs behind this wavefront's last contributor: their rows are zeros
-      if (((m_all & ~m) >> lane) & 1ull) {
-        const uint32_t slot = __float_as_uint(rf[lane * 4 * REC4 + 8 + C]);
-        if (slot < Rcap) {
-          float4* row = (float4*)(inst_grad + ((size_t)slot * 4 + __popc(mk & ((1u << wave) - 1u))) * 16);
-          row[0] = row[1] = row[2] = row[3] = make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-      }
-    }
-    auto process = [&](const Rec<C>& r, int e) {
-      const int p = lo + e;
-      const float* f = (const float*)&r.q[0];
-      const float4 r0 = r.q[0], r1 = r.q[1];
-      const float dx = r0.x - pxf, dy = r0.y - pyf;
-      const float power = -0.5f * (r0.z * dx * dx + r1.x * dy * dy) - r0.w * dx * dy;
-      const float Gx = __expf(power);
-      const float ax = fminf(0.99f, r1.y * Gx);
-      const bool ok = (uint32_t)p < last && power <= 0.f && ax >= (1.0f / 255.0f);
-      const float G = ok ? Gx : 0.f, alpha = ok ? ax : 0.f;
-      const float inv_one_m_a = __builtin_amdgcn_rcpf(1.f - alpha);
-      T = T * inv_one_m_a;                                                         // backward_distwar.cu:960
-      float col_dot = 0.f, col_dot_rgb = 0.f;
-#pragma unroll
-      for (int k = 0; k < C; k++) {
-        col_dot = __builtin_fmaf(f[6 + k], dpx[k], col_dot);                       // :979-984
-        if (k == 2) col_dot_rgb = col_dot;
-      }
-      float dL_dalpha = (col_dot - acc_dot) * T;
-      const float bgw = BLACK ? 0.f : -T_final * inv_one_m_a;
-      if (!BLACK) dL_dalpha += bgw * bg_dot;                                       // :991
-      ab[s * TR_STRIDE + lane] = G * dL_dalpha;
-      if (C > 3) {
-        const float dr = (col_dot_rgb - acc_dot_rgb) * T;
-        ab[(TR_S + s) * TR_STRIDE + lane] = BLACK ? G * dr : G * (dr + bgw * bg_dot_rgb);
-      }
-      ab[(2 * TR_S + s) * TR_STRIDE + lane] = alpha * T;                           // :980 (times dL/dpixel in the flush)
-      acc_dot = alpha * col_dot + (1.f - alpha) * acc_dot;                         // :972
-      acc_dot_rgb = alpha * col_dot_rgb + (1.f - alpha) * acc_dot_rgb;
-      // (wave-uniform: the record is) the pair's scratch row and the Gaussian's centre, for the flush
-      const uint32_t slot = __float_as_uint(f[8 + C]), qm = __float_as_uint(f[7 + C]);
-      const int rowid = slot < Rcap ? (int)(slot * 4u + (uint32_t)__popc(qm & ((1u << wave) - 1u))) : -1;
-      if (lane == 0) *(float4*)pi[s] = make_float4(__int_as_float(rowid), 0.f, r0.x, r0.y);
-      s++;
-      if (s == TR_S) flush();
-    };
-    while (m) {
-      const int ea = 63 - __builtin_clzll(m);
-      m &= ~(1ull << ea);
-      process(lds_record<C>(recs[cur], ea), ea);
-    }
-    __syncthreads();
-    if (lo > seg_lo && threadIdx.x < BWD_BATCH * REC4) recs[cur ^ 1][threadIdx.x] = stage;
-    __syncthreads();
-  }
-  if (s) flush();
-}
-
 }  // namespace
-
-static int g_bwd_variant = -1;   // -1: not decided (environment HGS_BWD_VARIANT, default 1); 0: wavefront reduction per pair (rounds 1-3); 1: transposed flush
-static int bwd_variant() {
-  if (g_bwd_variant < 0) {
-    const char* e = getenv("HGS_BWD_VARIANT");
-    g_bwd_variant = e && e[0] == '0' ? 0 : 1;
-  }
-  return g_bwd_variant;
-}
-extern "C" int hgs_set_backward_variant(int v) {
-  const int was = bwd_variant();
-  if (v == 0 || v == 1) g_bwd_variant = v;
-  return was;
-}
-int hgs_backward_variant() { return bwd_variant(); }
 
 extern "C" int hgs_debug_set_wg_trace(void* device_buf_fwd, void* device_buf_bwd) {
   HGS_CHECK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_wg_trace_fwd), &device_buf_fwd, sizeof(void*)));
@@ -969,23 +686,23 @@ int hgs_launch_blend_fwd(hipStream_t s, int W, int H, int Rcap, int channels, co
 int hgs_launch_blend_bwd(hipStream_t s, int W, int H, int Rcap, int channels, const float* bg, const HgsImage& im,
                          const HgsBinning& b, const float* const* dL_dpix_planes, float* inst_grad) {
   const int gx = (W + HGS_TILE - 1) / HGS_TILE, gy = (H + HGS_TILE - 1) / HGS_TILE;
-  const dim3 grid(blend_grid(gx * gy, b)), block(HGS_BLOCK);
-  const bool tr = bwd_variant() == 1;
   {
     HgsProfScope _prof(s, HGS_K_BLEND_BWD);
-#define HGS_BWD_LAUNCH(KERNEL, CH, BLACK) hipLaunchKernelGGL((KERNEL<CH, BLACK>), grid, block, 0, s, im, b, W, H, gx, (uint32_t)Rcap, bg, pg, inst_grad)
     if (channels == 3) {
       PixGrad<3> pg;
       for (int k = 0; k < 3; k++) pg.plane[k] = dL_dpix_planes[k];
-      if (tr) { if (bg) HGS_BWD_LAUNCH(blend_bwd_tr_kernel, 3, false); else HGS_BWD_LAUNCH(blend_bwd_tr_kernel, 3, true); }
-      else { if (bg) HGS_BWD_LAUNCH(blend_bwd_kernel, 3, false); else HGS_BWD_LAUNCH(blend_bwd_kernel, 3, true); }
+      if (bg) hipLaunchKernelGGL((blend_bwd_kernel<3, false>), dim3(blend_grid(gx * gy, b)), dim3(HGS_BLOCK), 0, s, im, b, W, H, gx,
+                                 (uint32_t)Rcap, bg, pg, inst_grad);
+      else hipLaunchKernelGGL((blend_bwd_kernel<3, true>), dim3(blend_grid(gx * gy, b)), dim3(HGS_BLOCK), 0, s, im, b, W, H, gx,
+                              (uint32_t)Rcap, bg, pg, inst_grad);
     } else {
       PixGrad<7> pg;
       for (int k = 0; k < 7; k++) pg.plane[k] = dL_dpix_planes[k];
-      if (tr) { if (bg) HGS_BWD_LAUNCH(blend_bwd_tr_kernel, 7, false); else HGS_BWD_LAUNCH(blend_bwd_tr_kernel, 7, true); }
-      else { if (bg) HGS_BWD_LAUNCH(blend_bwd_kernel, 7, false); else HGS_BWD_LAUNCH(blend_bwd_kernel, 7, true); }
+      if (bg) hipLaunchKernelGGL((blend_bwd_kernel<7, false>), dim3(blend_grid(gx * gy, b)), dim3(HGS_BLOCK), 0, s, im, b, W, H, gx,
+                                 (uint32_t)Rcap, bg, pg, inst_grad);
+      else hipLaunchKernelGGL((blend_bwd_kernel<7, true>), dim3(blend_grid(gx * gy, b)), dim3(HGS_BLOCK), 0, s, im, b, W, H, gx,
+                              (uint32_t)Rcap, bg, pg, inst_grad);
     }
-#undef HGS_BWD_LAUNCH
   }
   HGS_CHECK_LAUNCH();
   return 0;

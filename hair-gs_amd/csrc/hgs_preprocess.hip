@@ -584,7 +584,7 @@ template <bool DC_ONLY>
 #endif
 __global__ __launch_bounds__(HGS_BLOCK) __attribute__((amdgpu_waves_per_eu(HGS_PPB_WAVES))) void preprocess_bwd_kernel(HgsBwdArgs a, HgsGeom g, HgsBinning b,
                                                                    const float* __restrict__ inst_grad, uint32_t Rcap,
-                                                                   const uint32_t* __restrict__ status, int quad_rows) {
+                                                                   const uint32_t* __restrict__ status) {
   const int idx = blockIdx.x * HGS_BLOCK + threadIdx.x;
   if (idx >= a.P) return;
   const int D = DC_ONLY ? 0 : a.D;
@@ -618,38 +618,17 @@ __global__ __launch_bounds__(HGS_BLOCK) __attribute__((amdgpu_waves_per_eu(HGS_P
     // ---- deterministic gather of this Gaussian's per-instance partial sums (instance order = tile rect order)
     const HgsRect rc = rc_pre;
     const uint32_t n = n_pre;
-    auto add_row = [&](const float4& r0, const float4& r1, const float4& r2, const float4& r3) {
+    const int row_floats = a.n_extra ? 16 : HGS_INST_GRAD_FLOATS;
+    for (uint32_t k = 0; k < n; k++) {
+      if (rc.off + k >= Rcap) break;  // under-sized binning buffer (forward already flagged the overflow)
+      const float4* r = (const float4*)(inst_grad + (size_t)(rc.off + k) * row_floats);   // rows in Gaussian-major order
+      const float4 r0 = r[0], r1 = r[1], r2 = r[2];
       dmx += r0.x; dmy += r0.y; dcx += r0.z; dcy += r0.w;
       dcw += r1.x; dop += r1.y; dcol[0] += r1.z; dcol[1] += r1.w; dcol[2] += r2.x;
       if (a.n_extra) {  // row = [.., dcolor 0..6, rgb-only dmean2D.xy]
+        const float4 r3 = r[3];
         dex[0] += r2.y; dex[1] += r2.z; dex[2] += r2.w; dex[3] += r3.x;
         dmx_rgb += r3.y; dmy_rgb += r3.z;
-      }
-    };
-    if (quad_rows) {
-      // blend_bwd_tr_kernel: 16-float rows, one per (instance, quadrant) pair whose bit is set in the instance's quadrant mask
-      // (b.inv, Gaussian-major like the rows), the rows of an instance adjacent: (slot) * 4 + 0 .. popcount(mask) - 1.  The
-      // mask and the first two rows (one 128-byte line; 95 % of the instances of a strand frame have no more) are requested
-      // together -- a row that does not exist is loaded and dropped, not waited for --; rows 2, 3 only where they exist.
-      for (uint32_t k = 0; k < n; k++) {
-        if (rc.off + k >= Rcap) break;
-        const float4* r = (const float4*)(inst_grad + (size_t)(rc.off + k) * 64);
-        const uint32_t cnt = (uint32_t)__popc(b.inv[rc.off + k] & HGS_QMASK_BITS);
-        if (DC_ONLY) {
-          const float4 a0 = r[0], a1 = r[1], a2 = r[2], a3 = r[3], b0 = r[4], b1 = r[5], b2 = r[6], b3 = r[7];
-          if (cnt > 0) add_row(a0, a1, a2, a3);
-          if (cnt > 1) add_row(b0, b1, b2, b3);
-          for (uint32_t j = 2; j < cnt; j++) add_row(r[4 * j], r[4 * j + 1], r[4 * j + 2], r[4 * j + 3]);
-        } else {   // (the view-dependent SH instantiation has no registers to spare for loads it may not need)
-          for (uint32_t j = 0; j < cnt; j++) add_row(r[4 * j], r[4 * j + 1], r[4 * j + 2], r[4 * j + 3]);
-        }
-      }
-    } else {
-      const int row_floats = a.n_extra ? 16 : HGS_INST_GRAD_FLOATS;
-      for (uint32_t k = 0; k < n; k++) {
-        if (rc.off + k >= Rcap) break;  // under-sized binning buffer (forward already flagged the overflow)
-        const float4* r = (const float4*)(inst_grad + (size_t)(rc.off + k) * row_floats);   // rows in Gaussian-major order
-        add_row(r[0], r[1], r[2], a.n_extra ? r[3] : make_float4(0.f, 0.f, 0.f, 0.f));
       }
     }
     // The rows hold sums of moments of u = G dL/dalpha (blend_bwd_kernel): dmx = S(u dx), dmy = S(u dy), dcx = S(u dx dx),
@@ -928,17 +907,15 @@ int hgs_launch_scatter(hipStream_t s, int P, int W, int H, int Rcap, const float
   HGS_CHECK_LAUNCH();
   return 0;
 }
-int hgs_backward_variant();
 int hgs_launch_preprocess_bwd(hipStream_t s, const HgsBwdArgs& a, const HgsGeom& g, const HgsBinning& b,
                               const float* inst_grad, int Rcap, const uint32_t* status) {
-  const int quad_rows = hgs_backward_variant() == 1;
   const int nblk = (a.P + HGS_BLOCK - 1) / HGS_BLOCK;
   {
     HgsProfScope _prof(s, HGS_K_PREPROCESS_BWD);
     if (!a.shs || (a.D == 0 && a.M == 1))
-      hipLaunchKernelGGL(preprocess_bwd_kernel<true>, dim3(nblk), dim3(HGS_BLOCK), 0, s, a, g, b, inst_grad, (uint32_t)Rcap, status, quad_rows);
+      hipLaunchKernelGGL(preprocess_bwd_kernel<true>, dim3(nblk), dim3(HGS_BLOCK), 0, s, a, g, b, inst_grad, (uint32_t)Rcap, status);
     else
-      hipLaunchKernelGGL(preprocess_bwd_kernel<false>, dim3(nblk), dim3(HGS_BLOCK), 0, s, a, g, b, inst_grad, (uint32_t)Rcap, status, quad_rows);
+      hipLaunchKernelGGL(preprocess_bwd_kernel<false>, dim3(nblk), dim3(HGS_BLOCK), 0, s, a, g, b, inst_grad, (uint32_t)Rcap, status);
   }
   HGS_CHECK_LAUNCH();
   return 0;

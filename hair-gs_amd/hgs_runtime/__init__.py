@@ -78,7 +78,6 @@ SIGNATURES = {
     "hgs_nearest_distance_f64": (ci, [vp, ci, ci, vp, vp, vp]),
     "hgs_set_tile_cull": (ci, [ci]),
     "hgs_set_segment_policy": (ci, [ci, ci, ci]),
-    "hgs_set_backward_variant": (ci, [ci]),
     "hgs_debug_set_wg_trace": (ci, [vp, vp]),
     "hgs_prof_enable": (ci, [ci]),
     "hgs_prof_bracket_overhead_ms": (C.c_double, []),

@@ -465,12 +465,6 @@ int hgs_set_tile_cull(int on);
  * effect at the next forward pass (a captured graph keeps the policy it was captured with).  Results do not depend
  * on it beyond the association of the per-pixel transmittance product. */
 int hgs_set_segment_policy(int min_len, int max_len, int target_segments);
-/* Reduction of the blend backward: 1 (default) = the walk parks three scalars per pixel and pair in LDS and a transposed pass
- * (lane = parked pair x pixel row) forms the per-entry sums, one scratch row per (instance, quadrant); 0 = rounds 1-3: a
- * 64-lane permlane / DPP reduction per (wavefront, entry) pair, the four wavefronts combined through LDS, one row per instance.
- * Process-wide (environment HGS_BWD_VARIANT at first use); takes effect at the next hgs_backward*; returns the previous value.
- * Same gradients within fp32 rounding (the sums are associated differently). */
-int hgs_set_backward_variant(int variant);
 int hgs_debug_set_wg_trace(void* device_buf_fwd, void* device_buf_bwd);
 
 /* ---- introspection used by the parity tests (byte offsets of the sub-arrays of each buffer) ---- */
@@ -495,13 +489,6 @@ int hgs_binning_layout(int R, size_t* offsets /* [HGS_BIN_NFIELDS] */);
  * (u = G dL/dalpha, d = mean - pixel; the moments from which dmean2D, dconic and dopacity follow per Gaussian), dcolor.rgb,
  * pad */
 #define HGS_INST_GRAD_FLOATS 12
-/* round 4 (blend_bwd_tr_kernel, the default backward): the scratch holds HGS_SCRATCH_ROWS rows of HGS_SCRATCH_ROW_FLOATS floats
- * per instance slot; the first popcount(quadrant mask) of them are written -- one per 8x8-pixel quadrant of the instance's tile
- * whose bit is set in the instance's mask (HGS_BIN_INV, in Gaussian-major order like the rows), in ascending quadrant order --
- * each with the sums of HGS_INST_GRAD_FLOATS' layout over that quadrant's pixels (+ dcolor 3..6 and the RGB-only u dx, u dy in
- * the 7-channel mode: floats 9-14) */
-#define HGS_SCRATCH_ROWS 4
-#define HGS_SCRATCH_ROW_FLOATS 16
 
 #ifdef __cplusplus
 }
