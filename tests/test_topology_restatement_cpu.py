@@ -1,0 +1,305 @@
+"""The strand topology operators against a scalar restatement of the reference's statements.
+
+scene/hair_topology.py runs clone / split / merge_collapsed / prune (reference scene/hair_gaussian_model.py:788-1077) as
+vectorised tensor code with id remapping, endpoint compaction and optimizer-state surgery.  Nothing of the reference's own
+code for them can execute here (its module imports pytorch3d / plyfile and pins device="cuda"), so this file restates the
+same statements a SECOND time, in the plainest form available -- Python lists and loops over one segment at a time, one
+function per reference statement block, each citing its lines -- and demands that random models come out of the
+vectorised operators IDENTICAL to the restatement: the same endpoint_pairs (ids and order), endpoint positions, per-segment
+attributes, Adam moments and statistics.  Element-wise quantities the selections read (scales, opacity, mask, segment
+lengths) are taken from the model's getters, which have their own tests; what is pinned here is the topology arithmetic.
+"""
+import copy
+
+import numpy as np
+import pytest
+import torch
+
+from arguments import OptimizationParams
+
+
+# ---- the restatement: a model is a dict of python lists ---------------------------------------------------------------------
+SEG_KEYS = ("f_dc", "f_rest", "opacity", "mask", "width")        # per-segment parameter groups
+ALL_KEYS = ("endpoints",) + SEG_KEYS
+
+
+def snapshot(m):
+    """The builder's model -> lists: pairs [[a, b]], per-group rows of (value, exp_avg, exp_avg_sq), statistics."""
+    st = {"pairs": [[int(a), int(b)] for a, b in m.endpoint_pairs.tolist()]}
+    for g in m.optimizer.param_groups:
+        p = g["params"][0]
+        s = m.optimizer.state.get(p, {})
+        ea = s.get("exp_avg", torch.zeros_like(p)).detach()
+        eq = s.get("exp_avg_sq", torch.zeros_like(p)).detach()
+        st[g["name"]] = [(p.detach()[i].clone(), ea[i].clone(), eq[i].clone()) for i in range(p.shape[0])]
+    st["grad_accum"] = [float(x) for x in m.xyz_gradient_accum.reshape(-1).tolist()]
+    st["denom"] = [float(x) for x in m.denom.reshape(-1).tolist()]
+    st["max_radii2D"] = [float(x) for x in m.max_radii2D.reshape(-1).tolist()]
+    return st
+
+
+def r_prune_segments(st, prune):
+    """prune_segments (reference :575-617): drop the flagged segments, then every endpoint no remaining segment references,
+    renumbering the kept endpoints in ascending order of their old ids; optimizer rows follow their parameters."""
+    keep = [i for i, p in enumerate(prune) if not p]
+    st["pairs"] = [st["pairs"][i] for i in keep]
+    used = sorted({e for pr in st["pairs"] for e in pr})
+    new_id = {old: new for new, old in enumerate(used)}
+    st["pairs"] = [[new_id[a], new_id[b]] for a, b in st["pairs"]]
+    st["endpoints"] = [st["endpoints"][e] for e in used]
+    for k in SEG_KEYS:
+        st[k] = [st[k][i] for i in keep]
+    for k in ("grad_accum", "denom", "max_radii2D"):
+        st[k] = [st[k][i] for i in keep]
+
+
+def r_cat_segments(st, new_pairs, new_endpoints, new_rows):
+    """cat_segments (reference :536-573): append endpoints and segments; new rows start with zero Adam moments; the
+    densification statistics are reset for ALL segments (:561-571)."""
+    st["pairs"] += [list(p) for p in new_pairs]
+    st["endpoints"] += [(v.clone(), torch.zeros_like(v), torch.zeros_like(v)) for v in new_endpoints]
+    for k in SEG_KEYS:
+        st[k] += [(v.clone(), torch.zeros_like(v), torch.zeros_like(v)) for v in new_rows[k]]
+    n = len(st["pairs"])
+    st["grad_accum"], st["denom"], st["max_radii2D"] = [0.0] * n, [0.0] * n, [0.0] * n
+
+
+def r_clone(st, grads, max_scale, thr_grad, thr_size):
+    """clone_strategy (reference :915-967)."""
+    sel = [i for i in range(len(st["pairs"])) if grads[i] >= thr_grad and max_scale[i] <= thr_size]
+    nxt = max(max(p) for p in st["pairs"]) + 1
+    new_pairs, new_eps, rows = [], [], {k: [] for k in SEG_KEYS}
+    for j, i in enumerate(sel):
+        a, b = st["pairs"][i]
+        new_eps += [st["endpoints"][a][0], st["endpoints"][b][0]]
+        new_pairs.append([nxt + 2 * j, nxt + 2 * j + 1])
+        for k in SEG_KEYS:
+            rows[k].append(st[k][i][0])
+    r_cat_segments(st, new_pairs, new_eps, rows)
+    return len(sel)
+
+
+def r_split(st, grads, max_scale, seg_len, mask_prob, centre, thr_grad, thr_size, max_len, fg_th):
+    """split_strategy (reference :828-913): grads are padded with zeros for the segments clone appended (:836-838)."""
+    n = len(st["pairs"])
+    g = list(grads) + [0.0] * (n - len(grads))
+    sel = [i for i in range(n) if ((g[i] >= thr_grad and max_scale[i] > thr_size) or seg_len[i] >= max_len) and mask_prob[i] > fg_th]
+    nxt = max(max(p) for p in st["pairs"]) + 1
+    first, second, mids, rows = [], [], [], {k: [] for k in SEG_KEYS}
+    for j, i in enumerate(sel):
+        a, b = st["pairs"][i]
+        first.append([a, nxt + j])
+        second.append([nxt + j, b])
+        mids.append(centre[i])
+    for k in SEG_KEYS:
+        rows[k] = [st[k][i][0] for i in sel] * 2          # .repeat(2, ...): the selected rows, then the selected rows again
+    r_cat_segments(st, first + second, mids, rows)
+    prune = [False] * len(st["pairs"])
+    for i in sel:
+        prune[i] = True
+    r_prune_segments(st, prune)
+    return len(sel)
+
+
+def r_remove_duplicate_rows(rows):
+    """remove_duplicate_endpoint_rows (reference :712-728): a row survives iff BOTH its ids occur there for the first time
+    in row-major order of the flattened list."""
+    seen, first = set(), []
+    for a, b in rows:
+        fa = a not in seen
+        seen.add(a)
+        fb = b not in seen
+        seen.add(b)
+        first.append(fa and fb)
+    return first
+
+
+def r_merge_collapsed(st, seg_len_of, fg_of, min_val):
+    """merge_collapsed_segments (reference :969-1018), one round per loop trip; `seg_len_of` / `fg_of` evaluate the current
+    model (lengths from the endpoint positions, foreground from opacity and mask)."""
+    total = 0
+    while True:
+        n = len(st["pairs"])
+        lens, fg = seg_len_of(st), fg_of(st)
+        cand = [i for i in range(n) if lens[i] < min_val or not fg[i]]
+        count = {}
+        for a, b in st["pairs"]:
+            count[a] = count.get(a, 0) + 1
+            count[b] = count.get(b, 0) + 1
+        cand = [i for i in cand if count[st["pairs"][i][0]] != 1 and count[st["pairs"][i][1]] != 1]   # both ends interior joints
+        keep = r_remove_duplicate_rows([st["pairs"][i] for i in cand])
+        cand = [i for i, k in zip(cand, keep) if k]
+        to_merge = [list(st["pairs"][i]) for i in cand]                    # ids BEFORE the prune below (:1000-1004)
+        prune = [False] * n
+        for i in cand:
+            prune[i] = True
+        r_prune_segments(st, prune)
+        if to_merge:                                                       # ... applied to the ids AFTER it
+            top = max(max(p) for p in st["pairs"]) + 1
+            mapping = list(range(top))
+            for a, b in to_merge:
+                if b < top:
+                    mapping[b] = a
+                else:                                                      # (an index past the table: the reference would raise)
+                    raise IndexError("merge pair beyond the compacted ids")
+            st["pairs"] = [[mapping[a], mapping[b]] for a, b in st["pairs"]]
+        r_prune_segments(st, [False] * len(st["pairs"]))
+        total += len(to_merge)
+        if not to_merge:
+            return total
+
+
+def r_prune(st, seg_len, opacity, max_scale, mask_prob, min_val, op_th, fg_th, extent, max_screen_size, avoid_connected):
+    """prune_strategy (reference :1020-1077)."""
+    n = len(st["pairs"])
+    prune = [seg_len[i] < min_val or opacity[i] < op_th for i in range(n)]
+    if max_screen_size and extent != 0.0:
+        prune = [prune[i] or max_scale[i] > 0.1 * extent for i in range(n)]
+    if avoid_connected and any(prune):
+        count = {}
+        for a, b in st["pairs"]:
+            count[a] = count.get(a, 0) + 1
+            count[b] = count.get(b, 0) + 1
+        for i in range(n):
+            a, b = st["pairs"][i]
+            is_end = count[a] == 1 or count[b] == 1
+            if not (is_end or mask_prob[i] < fg_th):
+                prune[i] = False
+    k = sum(prune)
+    if 0 < k < n:
+        r_prune_segments(st, prune)
+    return k
+
+
+# ---- element-wise inputs of the selections, from a restated model -----------------------------------------------------------
+def _rebuild(m0, st):
+    """A model object carrying the restated state (for the getters: scales, opacity, mask, lengths)."""
+    m = copy.deepcopy(m0)
+    m.endpoint_pairs = torch.tensor(st["pairs"], dtype=torch.long).reshape(-1, 2)
+    vals = {k: torch.stack([r[0] for r in st[k]]) for k in ALL_KEYS}
+    m._endpoints = torch.nn.Parameter(vals["endpoints"])
+    m._features_dc, m._features_rest = torch.nn.Parameter(vals["f_dc"]), torch.nn.Parameter(vals["f_rest"])
+    m._opacity, m._mask, m._width = torch.nn.Parameter(vals["opacity"]), torch.nn.Parameter(vals["mask"]), torch.nn.Parameter(vals["width"])
+    return m
+
+
+def _elementwise(m0, st):
+    m = _rebuild(m0, st)
+    with torch.no_grad():
+        return dict(max_scale=m.get_scaling.max(dim=1).values.tolist(), seg_len=m._segment_lengths().tolist(),
+                    opacity=m.get_opacity.reshape(-1).tolist(), mask_prob=m.get_mask.reshape(-1).tolist(),
+                    centre=[c.clone() for c in m.get_xyz], fg=m.compute_foreground_mask().tolist())
+
+
+def r_densification(m0, st, extent, max_screen_size):
+    """densification (reference :788-817): clone, split, merge_collapsed, prune, on the restated state."""
+    ta = m0.training_args
+    # :802-803: accum / denom with IEEE semantics (x / 0 = inf for x > 0, 0 / 0 = nan), nan -> 0
+    grads = [(a / d) if d != 0 else (float("inf") if a > 0 else float("nan")) for a, d in zip(st["grad_accum"], st["denom"])]
+    grads = [0.0 if g != g else g for g in grads]
+    thr_size = ta.percent_dense * extent
+    ew = _elementwise(m0, st)
+    info = {"clone": r_clone(st, grads, ew["max_scale"], ta.densify_grad_threshold, thr_size)}
+    ew = _elementwise(m0, st)
+    info["split"] = r_split(st, grads, ew["max_scale"], ew["seg_len"], ew["mask_prob"], ew["centre"], ta.densify_grad_threshold,
+                            thr_size, float(m0.max_segment_length), m0.foreground_binarization_th)
+    info["merge_collapsed"] = r_merge_collapsed(st, lambda s: _elementwise(m0, s)["seg_len"], lambda s: _elementwise(m0, s)["fg"], m0.min_val)
+    ew = _elementwise(m0, st)
+    info["prune_total"] = r_prune(st, ew["seg_len"], ew["opacity"], ew["max_scale"], ew["mask_prob"], m0.min_val, m0.opacity_th,
+                                  m0.foreground_binarization_th, extent, max_screen_size, True)
+    return info
+
+
+# ---- random models -----------------------------------------------------------------------------------------------------------
+def _random_model(seed, device="cpu"):
+    from scene.hair_gaussian_model import HairGaussianModel
+    from synthetic import strand_polylines
+    rng = np.random.default_rng(seed)
+    S, V = int(rng.integers(4, 9)), int(rng.integers(5, 10))
+    m = HairGaussianModel.from_strands(strand_polylines(S, V, seed=seed), device=device)
+    opt = OptimizationParams()
+    m.training_setup(opt)
+    P = m.endpoint_pairs.shape[0]
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        # distinct attributes per segment, so that a row attached to the wrong segment shows
+        m._features_dc.add_(torch.randn(m._features_dc.shape, generator=g).to(device) * 0.1)
+        m._width.add_(torch.randn(m._width.shape, generator=g).to(device) * 0.3)
+        m._opacity.copy_(torch.randn((P, 1), generator=g).to(device) * 2.0)
+        low = torch.rand(P, generator=g) < 0.15
+        m._opacity[low.to(device)] = -8.0                                  # transparent: prune / background candidates
+        bg = torch.rand(P, generator=g) < 0.15
+        m._mask[bg.to(device)] = -3.0                                      # background: merge-collapsed / prune candidates
+        # collapse some interior segments: the second endpoint onto the first
+        for i in torch.nonzero(torch.rand(P, generator=g) < 0.12).flatten().tolist():
+            a, b = m.endpoint_pairs[i].tolist()
+            m._endpoints[b] = m._endpoints[a]
+    # Adam moments that tell rows apart, statistics with a spread of gradients
+    for gp in m.optimizer.param_groups:
+        p = gp["params"][0]
+        m.optimizer.state[p] = {"step": torch.tensor(3.0), "exp_avg": torch.randn(p.shape, generator=g).to(device),
+                                "exp_avg_sq": torch.rand(p.shape, generator=g).to(device)}
+    m.denom = torch.randint(0, 3, (P, 1), generator=g).float().to(device)
+    m.xyz_gradient_accum = (torch.rand((P, 1), generator=g) * 6e-4).to(device) * m.denom.clamp(min=1)
+    m.max_radii2D = torch.rand(P, generator=g).to(device) * 30
+    m.compute_strands_info()
+    return m
+
+
+def _assert_same(m, st, what):
+    got = snapshot(m)
+    assert got["pairs"] == st["pairs"], what
+    for k in ALL_KEYS:
+        assert len(got[k]) == len(st[k]), (what, k)
+        for i, (a, b) in enumerate(zip(got[k], st[k])):
+            for j, name in enumerate(("value", "exp_avg", "exp_avg_sq")):
+                assert torch.equal(a[j].cpu(), b[j].cpu()), (what, k, i, name)
+    for k in ("grad_accum", "denom", "max_radii2D"):
+        assert got[k] == st[k], (what, k)
+
+
+@pytest.mark.parametrize("seed", range(12))
+@pytest.mark.parametrize("extent", [1e-3, 0.05, 50.0])    # tiny: every gradient splits; mid: mixed; huge: every gradient clones
+def test_densification_equals_the_scalar_restatement(seed, extent):
+    m = _random_model(seed)
+    st = snapshot(m)
+    m0 = copy.deepcopy(m)
+    info_r = r_densification(m0, st, extent, None)
+
+    class Info:                      # (the operators fill a dict the way the reference fills training_info.densification_info)
+        densification_info = {}
+    info = Info()
+    info.densification_info = {}
+    m.densification(extent, None, info)
+    assert {k: info.densification_info[k] for k in info_r} == info_r
+    _assert_same(m, st, f"densification seed {seed} extent {extent}")
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_each_operator_alone_equals_its_restatement(seed):
+    """clone, split, merge_collapsed and prune one at a time on the same random model (the screen-size branch of prune on)."""
+    extent = 0.02
+    for op in ("clone", "split", "merge_collapsed", "prune"):
+        m = _random_model(100 + seed)
+        st = snapshot(m)
+        m0 = copy.deepcopy(m)
+        ta = m.training_args
+        grads_t = m.xyz_gradient_accum / m.denom
+        grads_t[grads_t.isnan()] = 0.0
+        grads = [float(x) for x in grads_t.reshape(-1).tolist()]
+        ew = _elementwise(m0, st)
+        if op == "clone":
+            r_clone(st, grads, ew["max_scale"], ta.densify_grad_threshold, ta.percent_dense * extent)
+            m.clone_strategy(grads_t, extent, {})
+        elif op == "split":
+            r_split(st, grads, ew["max_scale"], ew["seg_len"], ew["mask_prob"], ew["centre"], ta.densify_grad_threshold,
+                    ta.percent_dense * extent, float(m.max_segment_length), m.foreground_binarization_th)
+            m.split_strategy(grads_t, extent, {})
+        elif op == "merge_collapsed":
+            r_merge_collapsed(st, lambda s: _elementwise(m0, s)["seg_len"], lambda s: _elementwise(m0, s)["fg"], m.min_val)
+            m.merge_collapsed_segments({})
+        else:
+            r_prune(st, ew["seg_len"], ew["opacity"], ew["max_scale"], ew["mask_prob"], m.min_val, m.opacity_th,
+                    m.foreground_binarization_th, extent, 20, True)
+            m.prune_strategy(extent, 20, {}, avoid_connected=True)
+        _assert_same(m, st, f"{op} seed {seed}")
