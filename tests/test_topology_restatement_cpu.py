@@ -303,3 +303,89 @@ def test_each_operator_alone_equals_its_restatement(seed):
                     m.foreground_binarization_th, extent, 20, True)
             m.prune_strategy(extent, 20, {}, avoid_connected=True)
         _assert_same(m, st, f"{op} seed {seed}")
+
+
+# ---- merging: the greedy matching of strand ends (reference :1205-1362) ---------------------------------------------------------
+def r_pairs_to_merge(m):
+    """compute_endpoint_pair_to_merge restated with loops: every strand end of a foreground segment, its direction towards
+    the other endpoint of its segment; candidates = the OTHER ends within merge_dist_th (brute force instead of the kd-tree)
+    that are neither itself nor the other end of its own strand and whose direction opposes its own within merge_angle_th;
+    both directed rows (i, j) and (j, i) as the reference emits them; ascending distance; a row survives
+    remove_duplicate_endpoint_rows iff both ids are new in row-major order, then remove_complementary_rows walks the
+    survivors and drops a row touching an end whose strand's other end was merged before it."""
+    pairs = m.endpoint_pairs.tolist()
+    ep = m._endpoints.detach().double().numpy()
+    count = {}
+    for a, b in pairs:
+        count[a] = count.get(a, 0) + 1
+        count[b] = count.get(b, 0) + 1
+    fg = m.compute_foreground_mask().tolist()
+    fg_ids = {e for (a, b), f in zip(pairs, fg) if f for e in (a, b)}
+    ends = sorted(e for e, c in count.items() if c == 1 and e in fg_ids)
+    other = {}                                    # end -> the other endpoint of ITS segment (the last row holding it: :730-752)
+    for a, b in pairs:
+        other[a], other[b] = b, a
+    partner = m.strands_info.strand_endpoint_id_to_complementary
+    dirs = {}
+    for e in ends:
+        d = ep[other[e]] - ep[e]
+        dirs[e] = d / np.linalg.norm(d)
+    th, cos_th = float(m.merge_dist_th), float(np.cos(np.deg2rad(m.merge_angle_th)))
+    rows = []
+    for i in ends:
+        for j in ends:
+            if j == i or j == int(partner[i]):
+                continue
+            dist = float(np.linalg.norm(ep[i] - ep[j]))
+            if dist > th:
+                continue
+            dot = float(-(dirs[i] @ dirs[j]))
+            if m.training_args.bidirectional_merge:
+                dot = abs(dot)
+            if dot >= cos_th:
+                rows.append((dist, i, j))
+    rows.sort(key=lambda r: r[0])
+    keep = r_remove_duplicate_rows([(i, j) for _, i, j in rows])
+    rows = [(i, j) for (_, i, j), k in zip(rows, keep) if k]
+    disabled, out = set(), []
+    for i, j in rows:
+        if i in disabled or j in disabled:
+            continue
+        disabled.add(int(partner[i]))
+        disabled.add(int(partner[j]))
+        out.append(frozenset((i, j)))
+    return set(out)
+
+
+@pytest.mark.parametrize("seed", range(10))
+@pytest.mark.parametrize("bidirectional", [False, True])
+def test_pairs_to_merge_equal_the_scalar_restatement(seed, bidirectional):
+    """Long curves cut into pieces whose ends sit 0-3 mm apart (the threshold starts at 2 mm) with jittered directions and some
+    background pieces: the vectorised search (kd-tree pairs, lexsort, one greedy loop) selects exactly the restatement's pairs."""
+    from scene.hair_gaussian_model import HairGaussianModel
+    from synthetic import strand_polylines
+    rng = np.random.default_rng(seed)
+    curves = strand_polylines(5, 41, seed=seed)                       # [5, 41, 3], 2.5 mm steps
+    pieces = []
+    for c in curves:
+        for k in range(5):
+            seg = c[8 * k: 8 * k + 9].copy()                          # 9 vertices; neighbours share a vertex ...
+            seg += rng.normal(scale=4e-4, size=(1, 3))                # ... until each piece is shifted by ~0.7 mm
+            seg[-1] += rng.normal(scale=3e-4, size=3)                 # and its ends bent a little
+            seg[0] += rng.normal(scale=3e-4, size=3)
+            pieces.append(seg)
+    order = rng.permutation(len(pieces))
+    pts = np.stack([pieces[i] for i in order]).astype(np.float32)
+    m = HairGaussianModel.from_strands(pts, device="cpu", ref_strand_root=curves[:, 0])
+    opt = OptimizationParams()
+    opt.bidirectional_merge = bidirectional
+    m.training_setup(opt)
+    with torch.no_grad():
+        P = m.endpoint_pairs.shape[0]
+        bg = torch.from_numpy(rng.random(P) < 0.08)
+        m._mask[bg] = -3.0
+    m.compute_strands_info()
+    got = m.compute_endpoint_pair_to_merge()
+    got = {frozenset(int(x) for x in row) for row in got.tolist()}
+    want = r_pairs_to_merge(m)
+    assert got == want and len(want) >= 5
