@@ -138,6 +138,8 @@ __device__ __forceinline__ float row_transpose_sum(float x0, float x1, float x2,
 // in : v[0 .. 4*NREG) per lane.  out: lane 16 r + 4 q (+0..3) holds the wave total of v[4 * (0,2,1,3)[q] + (0,2,1,3)[r]]
 template <int NREG>
 __device__ __forceinline__ float wave_reduce(const float* v) {
+  // (round 4: all half-wave folds first, then the row folds -- 5 instead of 9 hazard s_nop per entry -- measured no faster:
+  // north_star 48.6 against 48.5 us, C4 398 against 391.5; the nested form stays)
   float x[4];
 #pragma unroll
   for (int r = 0; r < NREG; r++) x[r] = fold16(fold32(v[4 * r], v[4 * r + 1]), fold32(v[4 * r + 2], v[4 * r + 3]));
@@ -228,39 +230,47 @@ __device__ __forceinline__ void fwd_walk(const float4* __restrict__ src, uint32_
     const uint32_t mk = lane < cnt ? __float_as_uint(rf[lane * 4 * REC4 + 7 + C]) : 0u;
     uint64_t m = __ballot(((mk >> wave) & 1u) != 0u);
     if (__ballot(T > 0.f) == 0) m = 0;
-    bool wave_done = false;   // every pixel of this wavefront saturated: leave the batch
+    // One entry, branch-free: the counters of round 3 show the scalar unit as busy as the vector pipe in this loop (195 scalar
+    // against 277 vector instructions per wavefront, together 0.95 of the issue slots) -- exec-mask set-up around the
+    // "blends here" lanes, a wave-wide vote per entry for the early return, 64-bit m & (m - 1).  Lanes that do not blend the
+    // entry add w = 0 (same bits: x + 0 * c, finite c), `last` and T are selects, and the only votes left are the rare ones
+    // behind a saturating lane.
     auto process = [&](const Rec<C>& r, int ent) {
       const float4 r0 = r.q[0], r1 = r.q[1];
       const float dx = r0.x - pxf, dy = r0.y - pyf;
       const float power = -0.5f * (r0.z * dx * dx + r1.x * dy * dy) - r0.w * dx * dy;  // forward.cu:335
       const float alpha = fminf(0.99f, r1.y * __expf(power));                           // :343
       const bool ok = T > 0.f && power <= 0.f && alpha >= (1.0f / 255.0f);              // :336, :344
-      if (__ballot(ok) == 0) return;
       const float test_T = T * (1.f - alpha);
       const bool sat = ok && test_T < 0.0001f;                                          // :346-351
-      if (ok && !sat) {
-        const float w = alpha * T;
-        const float* f = (const float*)&r.q[0];                                         // features start at float 6
+      const bool add = ok && !sat;
+      const float w = add ? alpha * T : 0.f;
+      const float* f = (const float*)&r.q[0];                                           // features start at float 6
 #pragma unroll
-        for (int k = 0; k < C; k++) acc[k] += f[6 + k] * w;                             // :354-355
-        last = s + (uint32_t)(b * REC_BATCH + ent + 1);                                 // :328, :361
-      }
-      if (ok) T = sat ? -T : test_T;
-      if (__ballot(sat) != 0 && __ballot(T > 0.f) == 0) wave_done = true;
+      for (int k = 0; k < C; k++) acc[k] = __builtin_fmaf(f[6 + k], w, acc[k]);         // :354-355
+      last = add ? s + (uint32_t)(b * REC_BATCH + ent + 1) : last;                      // :328, :361
+      T = ok ? (sat ? -T : test_T) : T;
     };
     if (m) {
-      // two record buffers used alternately (LDS reads of the next entry in flight, no register rotation)
+      // two record buffers used alternately (LDS reads of the next entry in flight, no register rotation); the read behind the
+      // last entry is issued all the same, from slot 63 of the batch (inside the array, never used): no branch around it.
+      // A wavefront whose pixels are all saturated leaves the batch (forward.cu:309-311 per wavefront): T > 0 nowhere only
+      // ever follows a saturating entry, so the vote on T alone decides, folded into the bit set the loop runs on.
       int ea = __builtin_ctzll(m), eb = 0;
-      Rec<C> ra = lds_record<C>(recs[cur], ea), rb = ra;
+      Rec<C> ra = lds_record<C>(recs[cur], ea), rb;
       while (true) {
-        m &= m - 1;
-        if (m) { eb = __builtin_ctzll(m); rb = lds_record<C>(recs[cur], eb); }
+        m &= ~(1ull << ea);
+        eb = __builtin_ctzll(m | (1ull << 63));
+        rb = lds_record<C>(recs[cur], eb);
         process(ra, ea);
-        if (m == 0 || wave_done) break;
-        m &= m - 1;
-        if (m) { ea = __builtin_ctzll(m); ra = lds_record<C>(recs[cur], ea); }
+        if (__ballot(T > 0.f) == 0ull) m = 0ull;
+        if (m == 0ull) break;
+        m &= ~(1ull << eb);
+        ea = __builtin_ctzll(m | (1ull << 63));
+        ra = lds_record<C>(recs[cur], ea);
         process(rb, eb);
-        if (m == 0 || wave_done) break;
+        if (__ballot(T > 0.f) == 0ull) m = 0ull;
+        if (m == 0ull) break;
       }
     }
     if (b + 1 < nb) {
