@@ -157,30 +157,63 @@ template <int SRC>
 __device__ __forceinline__ void preprocess_fwd_body(const HgsFwdArgs& a, const HgsGeom& g, const HgsImage& im, int* radii,
                                                     const HgsParamSrc& st, uint32_t* red, TileHash& th) {
   constexpr bool STRAND = SRC == SRC_STRAND, DERIVED = SRC != SRC_GIVEN;
+  // Round 4: every load that depends on nothing is issued HERE, in front of the dependent chain.  The kernel is a chain of
+  // memory round trips at ~4 wavefronts per CU (vector pipe 0.16): the ISA of round 3 fetched the view matrix, then the
+  // projection matrix, then opacity / mask, then the SH coefficients each behind a store of the lane's derived Gaussian --
+  // a store the compiler must assume may alias them -- i.e. one more exposed round trip apiece.  The matrices are
+  // wave-uniform and unwritten during the launch (the hair / cloud kernels read the view TABLE's row, not the slot a rider
+  // is filling): loaded at entry they become scalar loads.
+  float Vm[16], Pmat[16], cam[3];
+#pragma unroll
+  for (int k = 0; k < 16; k++) { Vm[k] = a.viewmatrix[k]; Pmat[k] = a.projmatrix[k]; }
+#pragma unroll
+  for (int k = 0; k < 3; k++) cam[k] = a.campos[k];
+  const int idx = blockIdx.x * HGS_BLOCK + threadIdx.x;
+  const bool live = idx < a.P;
+  const size_t li = live ? (size_t)idx : 0;                   // (loads of the lanes past P read Gaussian 0 and are dropped)
+  long long i0 = 0, i1 = 0;
+  float w_raw = 0.f, o_raw = 0.f, m_raw = 0.f, s_raw[3] = {0.f, 0.f, 0.f}, op_in = 0.f, sc_in[3] = {0.f, 0.f, 0.f}, sh_dc[3] = {0.f, 0.f, 0.f};
+  float4 r_raw = make_float4(1.f, 0.f, 0.f, 0.f), q_in = make_float4(1.f, 0.f, 0.f, 0.f);
+  V3 p_in = {0.f, 0.f, 0.f};
+  if (SRC == SRC_STRAND) {
+    i0 = st.pairs[2 * li]; i1 = st.pairs[2 * li + 1];
+    w_raw = st.width[li]; o_raw = st.opacity_raw[li]; m_raw = st.mask_raw[li];
+  } else if (SRC == SRC_CLOUD) {
+    s_raw[0] = st.scaling_raw[3 * li]; s_raw[1] = st.scaling_raw[3 * li + 1]; s_raw[2] = st.scaling_raw[3 * li + 2];
+    r_raw = ((const float4*)st.rotation_raw)[li];
+    o_raw = st.opacity_raw[li]; m_raw = st.mask_raw[li];
+  } else {
+    op_in = a.opacities[li];
+    if (!a.cov3D_precomp) {
+      sc_in[0] = a.scales[3 * li]; sc_in[1] = a.scales[3 * li + 1]; sc_in[2] = a.scales[3 * li + 2];
+      q_in = ((const float4*)a.rotations)[li];
+    }
+  }
+  if (!STRAND) p_in = V3{a.means3D[3 * li], a.means3D[3 * li + 1], a.means3D[3 * li + 2]};
+  if (!a.colors_precomp) {
+    const float* sh = a.shs + li * a.M * 3;
+    sh_dc[0] = sh[0]; sh_dc[1] = sh[1]; sh_dc[2] = sh[2];
+  }
   th_init(th);
   __syncthreads();
-  const int idx = blockIdx.x * HGS_BLOCK + threadIdx.x;
   const int gx = (a.W + HGS_TILE - 1) / HGS_TILE, gy = (a.H + HGS_TILE - 1) / HGS_TILE;
   uint32_t ntiles = 0;
-  if (idx < a.P) {
+  if (live) {
     int my_radius_i = 0;
     HgsRect rc = {0, 0, 0, 0, 0, 0};
     HgsStrandGaussian sgn = {};
     float opacity_v = 0.f, sc0 = 0.f, sc1 = 0.f, sc2 = 0.f;
     float4 qd = make_float4(1.f, 0.f, 0.f, 0.f);
     if (SRC == SRC_STRAND) {
-      const long long i0 = st.pairs[2 * (size_t)idx], i1 = st.pairs[2 * (size_t)idx + 1];
       sgn = hgs_strand_gaussian(st.ep[3 * i0], st.ep[3 * i0 + 1], st.ep[3 * i0 + 2], st.ep[3 * i1], st.ep[3 * i1 + 1],
-                                st.ep[3 * i1 + 2], st.width[idx], st.f);
-      opacity_v = hgs_sigmoid(st.opacity_raw[idx]);
+                                st.ep[3 * i1 + 2], w_raw, st.f);
+      opacity_v = hgs_sigmoid(o_raw);
       sc0 = sgn.s0; sc1 = sgn.sw; sc2 = sgn.sw;
       qd = make_float4(sgn.q0, sgn.q1, sgn.q2, sgn.q3);
       st.xyz[3 * (size_t)idx] = sgn.mx; st.xyz[3 * (size_t)idx + 1] = sgn.my; st.xyz[3 * (size_t)idx + 2] = sgn.mz;
-      ((float4*)st.extra4)[idx] = make_float4(hgs_sigmoid(st.mask_raw[idx]), sgn.ux, sgn.uy, sgn.uz);
+      ((float4*)st.extra4)[idx] = make_float4(hgs_sigmoid(m_raw), sgn.ux, sgn.uy, sgn.uz);
     } else if (SRC == SRC_CLOUD) {
-      const HgsCloudGaussian c = hgs_cloud_gaussian(st.scaling_raw[3 * (size_t)idx], st.scaling_raw[3 * (size_t)idx + 1],
-                                                    st.scaling_raw[3 * (size_t)idx + 2], ((const float4*)st.rotation_raw)[idx],
-                                                    st.opacity_raw[idx], st.mask_raw[idx]);
+      const HgsCloudGaussian c = hgs_cloud_gaussian(s_raw[0], s_raw[1], s_raw[2], r_raw, o_raw, m_raw);
       opacity_v = c.opacity; sc0 = c.s0; sc1 = c.s1; sc2 = c.s2; qd = c.q;
       ((float4*)st.extra4)[idx] = c.extra;
     }
@@ -190,12 +223,12 @@ __device__ __forceinline__ void preprocess_fwd_body(const HgsFwdArgs& a, const H
       st.opacity[idx] = opacity_v;
     }
     do {
-      const V3 p = STRAND ? V3{sgn.mx, sgn.my, sgn.mz} : V3{a.means3D[3 * idx], a.means3D[3 * idx + 1], a.means3D[3 * idx + 2]};
-      const V3 pv = xform4x3(p, a.viewmatrix);
+      const V3 p = STRAND ? V3{sgn.mx, sgn.my, sgn.mz} : p_in;
+      const V3 pv = xform4x3(p, Vm);
       if (pv.z <= 0.2f) {  // auxiliary.h:154 (the `prefiltered` trap of :156-160 is not reproduced: it aborts the GPU)
         break;
       }
-      const float* Pm = a.projmatrix;
+      const float* Pm = Pmat;
       const float hx = Pm[0] * p.x + Pm[4] * p.y + Pm[8] * p.z + Pm[12];
       const float hy = Pm[1] * p.x + Pm[5] * p.y + Pm[9] * p.z + Pm[13];
       const float hw = Pm[3] * p.x + Pm[7] * p.y + Pm[11] * p.z + Pm[15];
@@ -207,9 +240,9 @@ __device__ __forceinline__ void preprocess_fwd_body(const HgsFwdArgs& a, const H
         for (int k = 0; k < 6; k++) cov3[k] = a.cov3D_precomp[6 * (size_t)idx + k];
       } else {
         const float mod = a.scale_modifier;
-        const float s0 = mod * (DERIVED ? sc0 : a.scales[3 * idx]), s1 = mod * (DERIVED ? sc1 : a.scales[3 * idx + 1]),
-                    s2 = mod * (DERIVED ? sc2 : a.scales[3 * idx + 2]);
-        const float4 q = DERIVED ? qd : ((const float4*)a.rotations)[idx];
+        const float s0 = mod * (DERIVED ? sc0 : sc_in[0]), s1 = mod * (DERIVED ? sc1 : sc_in[1]),
+                    s2 = mod * (DERIVED ? sc2 : sc_in[2]);
+        const float4 q = DERIVED ? qd : q_in;
         const M3 R = quat_R(q.x, q.y, q.z, q.w);
         M3 Mm;  // M = S * R  (S diagonal: M[c][r] = s_r * R[c][r]; the zero terms of the full product add exact zeros)
 #pragma unroll
@@ -222,11 +255,11 @@ __device__ __forceinline__ void preprocess_fwd_body(const HgsFwdArgs& a, const H
       }
       const float focal_y = a.H / (2.0f * a.tan_fovy), focal_x = a.W / (2.0f * a.tan_fovx);
       Cov2D c2;
-      cov2d(p, focal_x, focal_y, a.tan_fovx, a.tan_fovy, cov3, a.viewmatrix, c2);
+      cov2d(p, focal_x, focal_y, a.tan_fovx, a.tan_fovy, cov3, Vm, c2);
       const float det = c2.a * c2.c - c2.b * c2.b;
       if (det == 0.0f) break;
       const float det_inv = 1.f / det;
-      const float4 conic_o = {c2.c * det_inv, -c2.b * det_inv, c2.a * det_inv, DERIVED ? opacity_v : a.opacities[idx]};
+      const float4 conic_o = {c2.c * det_inv, -c2.b * det_inv, c2.a * det_inv, DERIVED ? opacity_v : op_in};
       const float mid = 0.5f * (c2.a + c2.c);
       const float lambda1 = mid + sqrtf(fmaxf(0.1f, mid * mid - det));
       const float lambda2 = mid - sqrtf(fmaxf(0.1f, mid * mid - det));
@@ -241,13 +274,13 @@ __device__ __forceinline__ void preprocess_fwd_body(const HgsFwdArgs& a, const H
       if (area == 0) break;
       if (!a.colors_precomp) {
         // computeColorFromSH, forward.cu:20-71
-        V3 d = {p.x - a.campos[0], p.y - a.campos[1], p.z - a.campos[2]};
+        V3 d = {p.x - cam[0], p.y - cam[1], p.z - cam[2]};
         const float len = sqrtf(d.x * d.x + d.y * d.y + d.z * d.z);
         const float x = d.x / len, y = d.y / len, z = d.z / len;
         const float* sh = a.shs + (size_t)idx * a.M * 3;
 #pragma unroll
         for (int ch = 0; ch < 3; ch++) {
-          float res = kSH_C0 * sh[ch];
+          float res = kSH_C0 * sh_dc[ch];
           if (a.D > 0) {
             res = res - kSH_C1 * y * sh[3 + ch] + kSH_C1 * z * sh[6 + ch] - kSH_C1 * x * sh[9 + ch];
             if (a.D > 1) {
