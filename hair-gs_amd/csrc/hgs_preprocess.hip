@@ -647,6 +647,19 @@ __global__ __launch_bounds__(HGS_BLOCK) __attribute__((amdgpu_waves_per_eu(HGS_P
     q_pre = ((const float4*)a.rotations)[idx];
     s_pre[0] = a.scales[3 * idx]; s_pre[1] = a.scales[3 * idx + 1]; s_pre[2] = a.scales[3 * idx + 2];
   }
+  // (round 4) likewise the wave-uniform matrices and the clamp flags: read where they are used -- behind the row loop, behind
+  // the zero-gradient stores of the lanes that are not visible -- they were three more exposed round trips (vector loads: the
+  // compiler cannot prove them unwritten there); at entry they are scalar loads
+  float Vm_pre[16], pj_pre[16], cam_pre[3];
+#pragma unroll
+  for (int k = 0; k < 16; k++) { Vm_pre[k] = a.viewmatrix[k]; pj_pre[k] = a.projmatrix[k]; }
+#pragma unroll
+  for (int k = 0; k < 3; k++) cam_pre[k] = a.campos[k];
+  bool clamped_pre[3] = {false, false, false};
+  if (a.shs) {
+#pragma unroll
+    for (int ch = 0; ch < 3; ch++) clamped_pre[ch] = g.clamped[3 * (size_t)idx + ch] != 0;
+  }
   if (vis) {
     // ---- deterministic gather of this Gaussian's per-instance partial sums (instance order = tile rect order)
     const HgsRect rc = rc_pre;
@@ -685,7 +698,7 @@ __global__ __launch_bounds__(HGS_BLOCK) __attribute__((amdgpu_waves_per_eu(HGS_P
     for (int k = 0; k < 6; k++) cov3[k] = cov3_pre[k];
     const float h_y = a.H / (2.0f * a.tan_fovy), h_x = a.W / (2.0f * a.tan_fovx);
     Cov2D c;
-    cov2d(mean, h_x, h_y, a.tan_fovx, a.tan_fovy, cov3, a.viewmatrix, c);
+    cov2d(mean, h_x, h_y, a.tan_fovx, a.tan_fovy, cov3, Vm_pre, c);
     const float x_grad_mul = (c.txtz < -c.limx || c.txtz > c.limx) ? 0.f : 1.f;
     const float y_grad_mul = (c.tytz < -c.limy || c.tytz > c.limy) ? 0.f : 1.f;
     // cov2D = [[A, B], [B, Cc]] = (t0 V t0, t0 V t1; ., t1 V t1) with V = Vrk (symmetric) and t0, t1 the two vectors
@@ -730,13 +743,13 @@ __global__ __launch_bounds__(HGS_BLOCK) __attribute__((amdgpu_waves_per_eu(HGS_P
     const float dL_dty = y_grad_mul * -h_y * tz2 * dL_dJ12;
     const float dL_dtz = -h_x * tz2 * dL_dJ00 - h_y * tz2 * dL_dJ11 + (2 * h_x * c.t.x) * tz3 * dL_dJ02 +
                          (2 * h_y * c.t.y) * tz3 * dL_dJ12;
-    const float* Vm = a.viewmatrix;
+    const float* Vm = Vm_pre;
     dmean[0] = Vm[0] * dL_dtx + Vm[1] * dL_dty + Vm[2] * dL_dtz;  // transformVec4x3Transpose, auxiliary.h:89-97
     dmean[1] = Vm[4] * dL_dtx + Vm[5] * dL_dty + Vm[6] * dL_dtz;
     dmean[2] = Vm[8] * dL_dtx + Vm[9] * dL_dty + Vm[10] * dL_dtz;
 
     // ---- preprocessCUDA (backward), backward_distwar.cu:347-397
-    const float* pj = a.projmatrix;
+    const float* pj = pj_pre;
     const float m_hw = pj[3] * mean.x + pj[7] * mean.y + pj[11] * mean.z + pj[15];
     const float m_w = 1.0f / (m_hw + 0.0000001f);
     const float mul1 = (pj[0] * mean.x + pj[4] * mean.y + pj[8] * mean.z + pj[12]) * m_w * m_w;
@@ -747,14 +760,14 @@ __global__ __launch_bounds__(HGS_BLOCK) __attribute__((amdgpu_waves_per_eu(HGS_P
 
     if (a.shs) {
       // computeColorFromSH (backward), backward_distwar.cu:21-140
-      const V3 dir_orig = {mean.x - a.campos[0], mean.y - a.campos[1], mean.z - a.campos[2]};
+      const V3 dir_orig = {mean.x - cam_pre[0], mean.y - cam_pre[1], mean.z - cam_pre[2]};
       const float len = sqrtf(dir_orig.x * dir_orig.x + dir_orig.y * dir_orig.y + dir_orig.z * dir_orig.z);
       const float x = dir_orig.x / len, y = dir_orig.y / len, z = dir_orig.z / len;
       const float* sh = a.shs + (size_t)idx * M * 3;
       float* dsh = a.dL_dsh + (size_t)idx * M * 3;
       float dRGB[3];
 #pragma unroll
-      for (int ch = 0; ch < 3; ch++) dRGB[ch] = dcol[ch] * (g.clamped[3 * (size_t)idx + ch] ? 0.f : 1.f);
+      for (int ch = 0; ch < 3; ch++) dRGB[ch] = dcol[ch] * (clamped_pre[ch] ? 0.f : 1.f);
       float ddx[3] = {0, 0, 0}, ddy[3] = {0, 0, 0}, ddz[3] = {0, 0, 0};
 #define SHC(k, ch) sh[3 * (k) + (ch)]
 #define DSH(k, coef) { const float cf_ = (coef); dsh[3 * (k)] = cf_ * dRGB[0]; dsh[3 * (k) + 1] = cf_ * dRGB[1]; dsh[3 * (k) + 2] = cf_ * dRGB[2]; }
