@@ -8,6 +8,12 @@ import numpy as np
 import torch
 
 
+def _info_dict(info):
+    """The strategies take the reference's `training_info` (an object with a `densification_info` dict, utils/logging.py) or
+    the dict itself."""
+    return getattr(info, "densification_info", info)
+
+
 class HairTopologyMixin:
     # ---- index helpers -------------------------------------------------------------------------------------------
     def get_first_occurence_index(self, tensor):
@@ -62,6 +68,7 @@ class HairTopologyMixin:
 
     def clone_strategy(self, grads, scene_extent, info=None):
         """High view-space gradient + small extent -> duplicate the segment as a new, disconnected one (:915-967)."""
+        info = _info_dict(info)
         ta = self.training_args
         sel = (torch.norm(grads, dim=-1) >= ta.densify_grad_threshold) & (
             torch.max(self.get_scaling, dim=1).values <= ta.percent_dense * scene_extent)
@@ -75,6 +82,7 @@ class HairTopologyMixin:
     def split_strategy(self, grads, scene_extent, info=None):
         """High gradient + large extent, or longer than max_segment_length (foreground only) -> cut at the midpoint
         into two connected segments sharing a new endpoint (:828-913)."""
+        info = _info_dict(info)
         ta = self.training_args
         n0 = self.endpoint_pairs.shape[0]
         padded = torch.zeros((n0,), device=self.device)
@@ -98,6 +106,7 @@ class HairTopologyMixin:
     def merge_collapsed_segments(self, info=None):
         """Segments that collapsed to a point or left the foreground, and whose both ends are interior joints, are
         removed by fusing their two endpoints; repeated until nothing merges (:969-1018)."""
+        info = _info_dict(info)
         total = 0
         while True:
             collapsed = self._segment_lengths() < self.min_val
@@ -127,6 +136,7 @@ class HairTopologyMixin:
     def prune_strategy(self, extent, max_screen_size, info=None, avoid_connected=False):
         """Drop collapsed / transparent / oversized segments; with avoid_connected only strand-end or background
         segments may go, so strands are never cut in the middle (:1020-1077)."""
+        info = _info_dict(info)
         info = {} if info is None else info
         prune = self._segment_lengths() < self.min_val
         info["prune_collapsed"] = int(prune.sum())

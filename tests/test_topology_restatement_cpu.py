@@ -389,3 +389,136 @@ def test_pairs_to_merge_equal_the_scalar_restatement(seed, bidirectional):
     got = {frozenset(int(x) for x in row) for row in got.tolist()}
     want = r_pairs_to_merge(m)
     assert got == want and len(want) >= 5
+
+
+# ---- the reference's own operators, executed on CPU (tests/golden/make_ref_topology_pins.py) ------------------------------------
+# The fixture holds, for the same random models as above, what /root/reference's HairGaussianModel (device="cpu") made of them:
+# the third leg -- reference run == scalar restatement == vectorised product.
+import os
+
+_PINS = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_topology_pins.npz")
+_GROUPS = ("endpoints", "f_dc", "f_rest", "opacity", "mask", "width")
+
+
+@pytest.fixture(scope="module")
+def ref_pins():
+    assert os.path.exists(_PINS), "tests/golden/ref_topology_pins.npz is part of the repository"
+    return np.load(_PINS)
+
+
+def _model_for_pin(pins, seed):
+    """This repository's random model of `seed`, checked to BE the state the reference was given."""
+    m = _random_model(seed)
+    k = f"s{seed}_"
+    # training_setup once more, on the FINAL random state (the reference's ran on it too: max_segment_length, :268-283, is
+    # derived there from the foreground endpoints), then the moments and statistics again
+    keep = {g["name"]: dict(m.optimizer.state[g["params"][0]]) for g in m.optimizer.param_groups}
+    stats = (m.xyz_gradient_accum, m.denom, m.max_radii2D)
+    m.training_setup(OptimizationParams())
+    for g in m.optimizer.param_groups:
+        m.optimizer.state[g["params"][0]] = keep[g["name"]]
+    m.xyz_gradient_accum, m.denom, m.max_radii2D = stats
+    m.compute_strands_info()
+    assert np.array_equal(m.endpoint_pairs.numpy(), pins[k + "pairs"])
+    for g in m.optimizer.param_groups:
+        p = g["params"][0]
+        assert np.array_equal(p.detach().numpy(), pins[k + g["name"]]), g["name"]
+        assert np.array_equal(m.optimizer.state[p]["exp_avg"].numpy(), pins[k + g["name"] + "_exp_avg"])
+    assert np.array_equal(m.xyz_gradient_accum.numpy(), pins[k + "grad_accum"]) and np.array_equal(m.denom.numpy(), pins[k + "denom"])
+    # derived by training_setup on both sides from the same endpoints: the reference's own value
+    if (k + "ref_max_segment_length") in pins.files:
+        assert float(m.max_segment_length) == float(pins[k + "ref_max_segment_length"])
+    return m
+
+
+def _assert_equals_pin(m, pins, key, what):
+    assert np.array_equal(m.endpoint_pairs.numpy(), pins[key + "pairs"]), (what, "endpoint_pairs")
+    for g in m.optimizer.param_groups:
+        p = g["params"][0]
+        st = m.optimizer.state.get(p, {})
+        for name, got in ((g["name"], p.detach()), (g["name"] + "_exp_avg", st.get("exp_avg", torch.zeros_like(p))),
+                          (g["name"] + "_exp_avg_sq", st.get("exp_avg_sq", torch.zeros_like(p)))):
+            want = pins[key + name]
+            assert tuple(got.shape) == want.shape, (what, name, tuple(got.shape), want.shape)
+            assert np.array_equal(got.detach().numpy(), want), (what, name)
+    for name, got in (("grad_accum", m.xyz_gradient_accum), ("denom", m.denom), ("max_radii2D", m.max_radii2D)):
+        assert np.array_equal(got.numpy().reshape(-1), pins[key + name].reshape(-1)), (what, name)
+
+
+def _assert_strands_equal_pin(si, pins, key, what):
+    off = pins[key + "strand_offsets"]
+    assert len(si.list_strands) == len(off) - 1, (what, "number of strands")
+    pts, ids = pins[key + "strand_points"], pins[key + "strand_segment_ids"]
+    for s in range(len(off) - 1):
+        assert np.array_equal(np.asarray(si.list_strands[s]).reshape(-1, 2), pts[off[s]:off[s + 1]]), (what, "strand", s)
+        assert np.array_equal(np.asarray(si.list_strands_segments_id[s]).reshape(-1), ids[off[s]:off[s + 1]]), (what, "segment ids", s)
+    assert np.array_equal(np.asarray(si.id_to_strand_id), pins[key + "id_to_strand_id"]), (what, "id_to_strand_id")
+    assert np.array_equal(np.asarray(si.strand_endpoint_id_to_complementary), pins[key + "complementary"]), (what, "complementary")
+
+
+class _PinInfo:
+    def __init__(self):
+        self.densification_info = {}
+
+
+@pytest.mark.parametrize("seed", range(12))
+@pytest.mark.parametrize("xi", range(3))
+def test_densification_equals_the_reference_run(ref_pins, seed, xi):
+    """densification (reference :788-817) as the reference itself executed it, device="cpu": same segments in the same order,
+    same endpoint ids and positions, same attributes, same Adam moments and statistics, same counters, same strands_info."""
+    extent = float(ref_pins["meta_dens_extents"][xi])
+    m = _model_for_pin(ref_pins, seed)
+    info = _PinInfo()
+    m.densification(extent, None, info)
+    key = f"dens_s{seed}_x{xi}_"
+    _assert_equals_pin(m, ref_pins, key, f"densification seed {seed} extent {extent}")
+    names = [str(n) for n in ref_pins["meta_dens_info_names"]]
+    want = {n: int(v) for n, v in zip(names, ref_pins[key + "info"]) if v >= 0}
+    assert {n: info.densification_info[n] for n in want} == want
+    _assert_strands_equal_pin(m.strands_info, ref_pins, key, f"strands_info after densification seed {seed}")
+
+
+@pytest.mark.parametrize("seed", [100 + s for s in range(8)])
+@pytest.mark.parametrize("op", ["clone", "split", "merge_collapsed", "prune"])
+def test_each_operator_alone_equals_the_reference_run(ref_pins, seed, op):
+    extent = 0.02
+    m = _model_for_pin(ref_pins, seed)
+    grads = m.xyz_gradient_accum / m.denom
+    grads[grads.isnan()] = 0.0
+    info = _PinInfo()
+    if op == "clone":
+        m.clone_strategy(grads, extent, info)
+    elif op == "split":
+        m.split_strategy(grads, extent, info)
+    elif op == "merge_collapsed":
+        m.merge_collapsed_segments(info)
+    else:
+        m.prune_strategy(extent, 20, info, avoid_connected=True)
+    key = f"op_{op}_s{seed}_"
+    _assert_equals_pin(m, ref_pins, key, f"{op} seed {seed}")
+    names = [str(n) for n in ref_pins["meta_dens_info_names"]]
+    want = {n: int(v) for n, v in zip(names, ref_pins[key + "info"]) if v >= 0}
+    assert {n: info.densification_info[n] for n in want} == want
+
+
+@pytest.mark.parametrize("seed", [200 + s for s in range(10)])
+def test_merging_equals_the_reference_run(ref_pins, seed):
+    """compute_strands_info (:1410-1496), compute_endpoint_pair_to_merge (:1205-1362), merging (:1079-1096) and reset_opacity
+    (:1364-1371) as the reference executed them."""
+    m = _model_for_pin(ref_pins, seed)
+    key = f"merge_s{seed}_"
+    m.compute_strands_info()
+    _assert_strands_equal_pin(m.strands_info, ref_pins, key + "before_", f"strands_info seed {seed}")
+    assert float(m.merge_dist_th) == float(ref_pins[key + "merge_dist_th"]) and float(m.merge_angle_th) == float(ref_pins[key + "merge_angle_th"])
+    pairs = m.compute_endpoint_pair_to_merge()
+    assert np.array_equal(pairs.numpy().reshape(-1, 2), ref_pins[key + "pairs_to_merge"]), "pairs to merge"
+    info = _PinInfo()
+    m.merging(info)
+    assert info.densification_info["merge"] == int(ref_pins[key + "info_merge"])
+    _assert_equals_pin(m, ref_pins, key + "after_", f"merging seed {seed}")
+    _assert_strands_equal_pin(m.strands_info, ref_pins, key + "after_", f"strands_info after merging seed {seed}")
+    m.reset_opacity()
+    assert np.array_equal(m._opacity.detach().numpy(), ref_pins[key + "reset_opacity"])
+    st = m.optimizer.state[m._opacity]
+    assert np.array_equal(st["exp_avg"].numpy(), ref_pins[key + "reset_opacity_exp_avg"])
+    assert np.array_equal(st["exp_avg_sq"].numpy(), ref_pins[key + "reset_opacity_exp_avg_sq"])
