@@ -705,7 +705,7 @@ __global__ __launch_bounds__(256) void ori_bwd_kernel(int N, OriParams p, const 
   if (m) {
     float px, py, r, n, x, y, yq, th;
     ori_pixel(p, o0, o1, o2, px, py, r, n, x, y, yq, th);
-    if (r > 0.f) {
+    {
       const float hp = 1.57079632679489661923f;
       const float e = th - gt[i];
       const float u = fabsf(e) - hp;
@@ -714,7 +714,9 @@ __global__ __launch_bounds__(256) void ori_bwd_kernel(int N, OriParams p, const 
       const float den = x * x + yq * yq;
       const float dx = dth * (yq / den), dy = dth * (-x / den);           // atan2(x, yq)
       // x = px/n, y = py/n, n = r + eps
-      const float inv_n = 1.f / n, inv_n2 = inv_n * inv_n, ir = 1.f / r;
+      // r = 0 (a masked pixel nothing was blended into): torch's norm has the subgradient 0 there, the direct 1 / n path stays --
+      // the reference's gradient at such a pixel is ~conf / (count eps^2), and so is this one (tests/test_ref_loss_pins.py)
+      const float inv_n = 1.f / n, inv_n2 = inv_n * inv_n, ir = r > 0.f ? 1.f / r : 0.f;
       const float dn = -(dx * px + dy * py) * inv_n2;
       const float dpx = dx * inv_n + dn * px * ir, dpy = dy * inv_n + dn * py * ir;
       const float* v = p.view;
@@ -734,8 +736,6 @@ struct HeadFlags { int bce, ori; };
 // gradient of the orientation term w.r.t. the direction image at one masked pixel, `scale` = dL/d(term) / mask count
 __device__ __forceinline__ void ori_pixel_grad(const OriParams& p, float px, float py, float r, float n, float x, float yq,
                                                float th, float gt, float conf, float scale, float& g0, float& g1, float& g2) {
-  g0 = 0.f; g1 = 0.f; g2 = 0.f;
-  if (!(r > 0.f)) return;
   const float hp = 1.57079632679489661923f;
   const float e = th - gt;
   const float u = fabsf(e) - hp;
@@ -743,7 +743,9 @@ __device__ __forceinline__ void ori_pixel_grad(const OriParams& p, float px, flo
   const float dth = -sg * conf * scale;                               // dL/dtheta
   const float iden = __builtin_amdgcn_rcpf(x * x + yq * yq);
   const float dx = dth * (yq * iden), dy = dth * (-x * iden);         // atan2(x, yq)
-  const float inv_n = __builtin_amdgcn_rcpf(n), inv_n2 = inv_n * inv_n, ir = __builtin_amdgcn_rcpf(r);  // x = px/n, y = py/n, n = r + eps
+  // x = px/n, y = py/n, n = r + eps.  r = 0 (a masked pixel nothing was blended into): torch's norm has the subgradient 0
+  // there and the direct 1 / n path stays -- the reference's gradient at such a pixel is ~conf / (count eps^2), and so is this one
+  const float inv_n = __builtin_amdgcn_rcpf(n), inv_n2 = inv_n * inv_n, ir = r > 0.f ? __builtin_amdgcn_rcpf(r) : 0.f;
   const float dn = -(dx * px + dy * py) * inv_n2;
   const float dpx = dx * inv_n + dn * px * ir, dpy = dy * inv_n + dn * py * ir;
   const float* v = p.view;

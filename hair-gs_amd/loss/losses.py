@@ -72,16 +72,18 @@ def angle_smoothness_loss(gaussians: HairGaussianModel, threshold: float = 30, e
     if fused_losses and gaussians._endpoints.is_cuda:
         from hgs_runtime.fused import smoothness_loss
         return smoothness_loss(gaussians._endpoints, idx, float(cos_th), float(eps))
+    # op-by-op form (CPU tensors, or fused_losses = False: what the fused kernel is tested against): the reference's statements
+    # as they stand, boolean indexing included -- no selected pair is the python number 0 (no gradient), and a pair with a
+    # zero-length segment (0 / 0 direction) is never selected but, like in the reference, turns the gradient of a non-empty
+    # selection into NaN through the normalisation's backward (tests/test_ref_loss_pins.py; the fused kernel skips such pairs)
     pos = gaussians._endpoints[idx]                      # (N, 2, 2, 3)
     d = pos[:, :, 1] - pos[:, :, 0]
     d = d / torch.norm(d, dim=2, keepdim=True)
     dot = torch.sum(d[:, 0] * d[:, 1], dim=1)
-    sel = dot <= cos_th                                  # only bends sharper than the threshold are penalised
-    ang2 = torch.acos(torch.clamp(dot, -1 + eps, 1 - eps)) ** 2
-    # mean over the selected pairs as sum/count (the reference indexes with the boolean mask: same value, but that
-    # form synchronises with the host every iteration); no selected pair -> 0
-    cnt = sel.sum()
-    return torch.where(sel, ang2, torch.zeros_like(ang2)).sum() / torch.clamp(cnt, min=1).to(ang2.dtype)
+    dot = dot[dot <= cos_th]                             # only bends sharper than the threshold are penalised
+    if dot.shape[0] == 0:
+        return 0
+    return torch.mean(torch.acos(torch.clamp(dot, -1 + eps, 1 - eps)) ** 2)
 
 
 def knn3_self(points):

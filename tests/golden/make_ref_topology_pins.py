@@ -17,14 +17,13 @@ Two stages, two processes (both packages are called `scene` / `utils` / `argumen
                        reset_opacity()                                        :1364-1371
 The reference module's import line pulls in third-party packages this image lacks (pytorch3d, plyfile, simple_knn, cv2,
 pyrr, pyvista, pyvistaqt, dreifus, wandb, tensorboard): they are satisfied by EMPTY placeholder modules whose every attribute
-raises when called.  None of the methods run here calls into them (a call would abort the generation); nothing of the
-reference is edited, wrapped or re-implemented.
+raises when called (tests/golden/_ref_harness.py).  None of the methods run here calls into them (a call would abort the
+generation); nothing of the reference is edited, wrapped or re-implemented.
 """
 import argparse
 import os
 import subprocess
 import sys
-import types
 
 import numpy as np
 
@@ -69,35 +68,6 @@ def stage_inputs():
 
 
 # ---- stage 2: the reference's own methods ------------------------------------------------------------------------------------
-class _Absent(types.ModuleType):
-    """Placeholder for a third-party package this image lacks: importable, and every attribute raises when called."""
-    def __getattr__(self, name):
-        if name.startswith("__"):
-            raise AttributeError(name)
-        full = f"{self.__name__}.{name}"
-
-        def absent(*a, **k):
-            raise RuntimeError(f"{full} is absent in this image and must not be reached by the pinned methods")
-        absent.__name__ = name
-        return absent
-
-
-def _placeholders():
-    for name in ("pytorch3d", "pytorch3d.ops", "pytorch3d.transforms", "plyfile", "simple_knn", "simple_knn._C", "cv2", "pyrr",
-                 "pyvista", "pyvistaqt", "dreifus", "dreifus.pyvista", "wandb", "tensorboard",
-                 "torch.utils.tensorboard"):
-        try:
-            __import__(name)
-        except Exception:
-            mod = _Absent(name)
-            mod.__path__ = []
-            sys.modules[name] = mod
-    # `scene/__init__.py` pulls in the dataset readers and the renderer: the package is entered without running it
-    pkg = types.ModuleType("scene")
-    pkg.__path__ = [os.path.join(REF, "scene")]
-    sys.modules["scene"] = pkg
-
-
 class _Info:
     def __init__(self):
         self.densification_info = {}
@@ -149,9 +119,9 @@ def _dump_strands(out, key, si):
 
 
 def stage_reference():
-    assert os.path.isdir(REF), "needs /root/reference"
-    _placeholders()
-    sys.path.insert(0, REF)
+    sys.path.insert(0, HERE)
+    from _ref_harness import enter_reference
+    enter_reference()
     import torch
     from arguments import OptimizationParams
     from scene.hair_gaussian_model import HairGaussianModel
