@@ -1,13 +1,15 @@
-"""The strand topology operators against a scalar restatement of the reference's statements.
+"""The strand topology operators against (1) a scalar restatement of the reference's statements and (2) the reference's own
+code, run on the CPU of the authoring container (the fixture's tests are at the end of this file).
 
 scene/hair_topology.py runs clone / split / merge_collapsed / prune (reference scene/hair_gaussian_model.py:788-1077) as
-vectorised tensor code with id remapping, endpoint compaction and optimizer-state surgery.  Nothing of the reference's own
-code for them can execute here (its module imports pytorch3d / plyfile and pins device="cuda"), so this file restates the
-same statements a SECOND time, in the plainest form available -- Python lists and loops over one segment at a time, one
-function per reference statement block, each citing its lines -- and demands that random models come out of the
-vectorised operators IDENTICAL to the restatement: the same endpoint_pairs (ids and order), endpoint positions, per-segment
-attributes, Adam moments and statistics.  Element-wise quantities the selections read (scales, opacity, mask, segment
-lengths) are taken from the model's getters, which have their own tests; what is pinned here is the topology arithmetic.
+vectorised tensor code with id remapping, endpoint compaction and optimizer-state surgery.  (1) restates the same statements
+a SECOND time, in the plainest form available -- Python lists and loops over one segment at a time, one function per
+reference statement block, each citing its lines -- and demands that random models come out of the vectorised operators
+IDENTICAL to the restatement: the same endpoint_pairs (ids and order), endpoint positions, per-segment attributes, Adam
+moments and statistics.  Element-wise quantities the selections read (scales, opacity, mask, segment lengths) are taken from
+the model's getters, which have their own tests; what is pinned here is the topology arithmetic.  (2) holds what the
+REFERENCE's HairGaussianModel (device="cpu") made of the very same random models (tests/golden/make_ref_topology_pins.py):
+reference run == restatement == product.
 """
 import copy
 
