@@ -1001,7 +1001,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8))) void p
                                                       int* __restrict__ lists, HeadReduce h,
                                                       const float* __restrict__ p_ssim, const float* __restrict__ p_smooth,
                                                       float* __restrict__ out, const unsigned int* __restrict__ tile_used,
-                                                      int tiles_x, int tiles_y) {
+                                                      int tiles_x, int tiles_y, int W, float inv_w) {
   __shared__ float red[4];
   // The first two workgroups dispatched do the head's side jobs and nothing else (each is a chain of a few memory round
   // trips, several us apiece while the rest of the launch saturates HBM: as extra work of a pixel workgroup they made
@@ -1024,10 +1024,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8))) void p
   if (i < N) {
     // Every input of the pixel is loaded first, unconditionally (the targets of the orientation term also outside the
     // mask): the kernel is a chain of memory round trips otherwise -- logits, then the mask byte, then, behind the branch
-    // on it, angle and confidence -- at 17 resident waves per CU.
+    // on it, angle and confidence -- at 17 resident waves per CU.  (Round 4 tried the byte-saving forms again, now that the
+    // launch moves 93 MB at ~5 TB/s: direction, angle and confidence behind a wave-uniform test of the mask byte, or of the
+    // direction image for views without a mask: 19.2-19.4 us instead of 17.8-18.3 at north_star -- a wavefront's lifetime is
+    // still two round trips -- and 5.0-6.5 instead of 7.2 us for the Stage-I cloud, +-1 % of the step either way.  What stayed:
+    // with the consumer's tile hint, HgsHeadParams.tile_used, the four gradient planes are written only on tiles the blend
+    // backward reads: 18.2 -> 17.8 us.)
     const bool has_mask = tgt->mask != nullptr;
     float xm = 0.f, ym = 0.f, o0 = 0.f, o1 = 0.f, o2 = 0.f, gt = 0.f, cf = 0.f;
     unsigned char mk = 0;
+    unsigned used = 1u;
     if (fl.bce) { xm = mask_img[i]; ym = hgs_global(tgt->float_mask)[i]; }
     if (fl.ori) {
       o0 = omap[i]; o1 = omap[(size_t)N + i]; o2 = omap[2 * (size_t)N + i];
@@ -1035,6 +1041,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8))) void p
       // is waited for where it is issued)
       gt = hgs_global(tgt->orientation)[i]; cf = hgs_global(tgt->confidence)[i];
       mk = (has_mask ? hgs_global(tgt->mask) : (const HGS_GLOBAL unsigned char*)hgs_global(omap))[i];   // (last: its test is first)
+    }
+    if (d_unit && tile_used) {
+      // pixel -> tile: y = i / W through the float reciprocal (exact below 2^24 pixels with the correction step; beyond, the
+      // integer division)
+      int y = N < (1 << 24) ? (int)(((float)i + 0.5f) * inv_w) : i / W;
+      int x = i - y * W;
+      if (x < 0) { y--; x += W; } else if (x >= W) { y++; x -= W; }
+      used = tile_used[(y >> 4) * tiles_x + (x >> 4)];
     }
     float gm = 0.f, g0 = 0.f, g1 = 0.f, g2 = 0.f;
     if (fl.bce) {
@@ -1057,7 +1071,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8))) void p
         if (d_unit) ori_pixel_grad(p, px, py, r, n, x, yq, th, gt, cf, g_ori / tgt->mask_count, g0, g1, g2);
       }
     }
-    if (d_unit) {
+    if (d_unit && used) {
       d_unit[i] = gm; d_unit[(size_t)N + i] = g0; d_unit[2 * (size_t)N + i] = g1; d_unit[3 * (size_t)N + i] = g2;
     }
   }
@@ -1271,7 +1285,7 @@ int hgs_loss_head_forward(void* stream, const HgsHeadParams* p, const float* ima
     hipLaunchKernelGGL(pix_fwd_kernel, dim3(nbp + PIX_SIDE_WGS), dim3(256), 0, s, N, fl, p->bg[0], p->bg[1], p->bg[2], p->min_val, mask_img,
                        omap, targets, p_pix, fl.bce ? p->lambda_mask / (float)N : 0.f, fl.ori ? p->lambda_orientation : 0.f,
                        d_extra_unit, ssim_grid(3, H, W), (const unsigned char*)head_zero_flags(p, scratch), lists, h,
-                       (const float*)p_ssim, p_smooth, out, p->tile_used, p->tiles_x, p->tiles_y);
+                       (const float*)p_ssim, p_smooth, out, p->tile_used, p->tiles_x, p->tiles_y, W, 1.f / (float)W);
   }
   if (!p->defer_tail) {
     HgsHeadTail t;

@@ -297,6 +297,8 @@ def _raster_head_forward(step, xyz, scale, quat, opacity, extra4, shs, endpoints
     # gradient planes of the per-pixel terms for an upstream gradient of 1, written by the forward's own pass over
     # the pixels (possible when the mask count is a per-view constant, i.e. the views carry masks)
     d_extra = torch.empty((4, vt.H, vt.W), **f32) if (step.one_pass_pixels and vt.has_mask) else None
+    if step.poison_unwritten and d_extra is not None:     # test aid, like dL/dimage in _head_raster_backward
+        d_extra.fill_(float("nan"))
     # the tail of the head's reduction rides in the backward's parameter launch (include/hgs.h HgsHeadTail)
     hp.defer_tail = 1 if (step.defer_tail and xyz.shape[0] > 0) else 0
     with torch.cuda.device(dev):

@@ -383,7 +383,8 @@ typedef struct HgsHeadParams {
    * (tx, ty).  For the rasterizer backward that is the image buffer's per-tile contributor count (hgs_image_layout,
    * HGS_IMG_TILE_MAXC) of the forward pass that produced `image`: it touches dL/dpixel only where a pixel blended an entry.
    * With the hint, hgs_loss_head_backward leaves d_image UNWRITTEN on 32 x 32 blocks none of whose tiles is read (it
-   * neither filters nor zero-fills them). */
+   * neither filters nor zero-fills them), and hgs_loss_head_forward leaves d_extra_unit UNWRITTEN on the tiles that are
+   * not read. */
   const unsigned int* tile_used; int tiles_x, tiles_y;
 } HgsHeadParams;
 enum { HGS_HEAD_TOTAL = 0, HGS_HEAD_L1, HGS_HEAD_DSSIM, HGS_HEAD_MASK, HGS_HEAD_ORIENTATION, HGS_HEAD_SMOOTH,
