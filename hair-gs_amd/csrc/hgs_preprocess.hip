@@ -107,33 +107,34 @@ __device__ __forceinline__ uint32_t block_sum_256(uint32_t v, uint32_t* lds4) {
 // then ONE global atomic per distinct tile and block publishes the count / reserves the slots.  Gaussians covering more
 // than TH_MAX_AREA tiles, and inserts that find the table full, fall back to direct global atomics.
 #define TH_LOG 10
-#define TH_SIZE (1 << TH_LOG)
 #define TH_EMPTY 0xFFFFFFFFu
 #define TH_MAX_AREA 16u
 #define TH_PROBES 8
-struct TileHash { uint32_t key[TH_SIZE]; uint32_t cnt[TH_SIZE]; uint32_t base[TH_SIZE]; };
+template <int LOG> struct TileHashT { static constexpr int SIZE = 1 << LOG; uint32_t key[SIZE]; uint32_t cnt[SIZE]; uint32_t base[SIZE]; };
+using TileHash = TileHashT<TH_LOG>;
+#define TH_SIZE (1 << TH_LOG)
 
-__device__ __forceinline__ void th_init(TileHash& h) {
-  for (int i = threadIdx.x; i < TH_SIZE; i += HGS_BLOCK) { h.key[i] = TH_EMPTY; h.cnt[i] = 0u; }
+template <int LOG> __device__ __forceinline__ void th_init(TileHashT<LOG>& h) {
+  for (int i = threadIdx.x; i < (1 << LOG); i += HGS_BLOCK) { h.key[i] = TH_EMPTY; h.cnt[i] = 0u; }
 }
-__device__ __forceinline__ int th_insert(TileHash& h, uint32_t t) {   // slot of tile t (inserting it), -1: table full
-  uint32_t s = (t * 2654435761u) >> (32 - TH_LOG);
+template <int LOG> __device__ __forceinline__ int th_insert(TileHashT<LOG>& h, uint32_t t) {   // slot of tile t (inserting it), -1: table full
+  uint32_t s = (t * 2654435761u) >> (32 - LOG);
 #pragma unroll 1
   for (int k = 0; k < TH_PROBES; k++) {
     const uint32_t prev = atomicCAS(&h.key[s], TH_EMPTY, t);
     if (prev == TH_EMPTY || prev == t) return (int)s;
-    s = (s + 1) & (TH_SIZE - 1);
+    s = (s + 1) & ((1 << LOG) - 1);
   }
   return -1;
 }
-__device__ __forceinline__ int th_find(const TileHash& h, uint32_t t) {  // slot of an inserted tile, -1 if it never got in
-  uint32_t s = (t * 2654435761u) >> (32 - TH_LOG);
+template <int LOG> __device__ __forceinline__ int th_find(const TileHashT<LOG>& h, uint32_t t) {  // slot of an inserted tile, -1 if it never got in
+  uint32_t s = (t * 2654435761u) >> (32 - LOG);
 #pragma unroll 1
   for (int k = 0; k < TH_PROBES; k++) {
     const uint32_t cur = h.key[s];
     if (cur == t) return (int)s;
     if (cur == TH_EMPTY) return -1;
-    s = (s + 1) & (TH_SIZE - 1);
+    s = (s + 1) & ((1 << LOG) - 1);
   }
   return -1;
 }
@@ -410,6 +411,25 @@ __global__ __launch_bounds__(HGS_BLOCK) void cloud_preprocess_fwd_kernel(HgsFwdA
   preprocess_fwd_body<SRC_CLOUD>(a, g, im, radii, st, red, th);
 }
 
+// The scatter kernel's LDS: a 512-slot tile table and one record per Gaussian of the block (what an instance needs of its
+// Gaussian), so that instances can be dealt to the threads evenly (see the kernel).
+#define SC_TH_LOG 9
+using ScTable = TileHashT<SC_TH_LOG>;
+struct ScRec { uint32_t x0y0, w, depth; float x, y, hx, hy, nx, ny, rn; int mode; };
+
+// development aid (tools/dev/scatter_trace.py; build with -DHGS_SCATTER_TRACE=1): per workgroup of the scatter kernel the 10 ns
+// ticks at which it entered, had its loads and block prefix, had counted its tiles, had reserved its slots, saw the scan, ended
+#ifndef HGS_SCATTER_TRACE
+#define HGS_SCATTER_TRACE 0
+#endif
+#if HGS_SCATTER_TRACE
+#define SC_TRACE_MAX 8192
+__device__ unsigned long long g_sc_trace[SC_TRACE_MAX][8];
+#define SC_MARK(k) do { if (threadIdx.x == 0 && blockIdx.x < SC_TRACE_MAX) g_sc_trace[blockIdx.x][k] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define SC_MARK(k) do { } while (0)
+#endif
+
 // ------------------------------------------------------------------------------------------------
 // scatter: one lane per Gaussian.  Exclusive instance offset = block prefix (scan kernel) + in-block scan;
 // every touched tile gets key = depth_bits<<32 | gaussian_id appended to the tile's segment (order inside the
@@ -423,11 +443,17 @@ __global__ __launch_bounds__(HGS_BLOCK) void scatter_kernel(int P, int gx, int T
                                                             const float* __restrict__ extra, HgsGeom g, HgsImage im,
                                                             HgsBinning b, int scan_wg) {
   __shared__ uint32_t wsum[4];
-  __shared__ TileHash th;
+  // one LDS block, carved: the tile table (512 slots: a block's instances fall into a few dozen to ~150 distinct tiles), the
+  // per-Gaussian records and the instance prefix of the balanced loops below; a scan workgroup keeps its share's offsets in it
+  __shared__ __align__(16) unsigned char sc_lds[sizeof(ScTable) + HGS_BLOCK * sizeof(ScRec) + (HGS_BLOCK + 4) * sizeof(uint32_t)];
+  ScTable& th = *(ScTable*)sc_lds;
+  ScRec* srec = (ScRec*)(sc_lds + sizeof(ScTable));
+  uint32_t* ioff = (uint32_t*)(sc_lds + sizeof(ScTable) + HGS_BLOCK * sizeof(ScRec));
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const unsigned long long report = ((unsigned long long)im.status[HGS_ST_SCANPTR_HI] << 32) | im.status[HGS_ST_SCANPTR_LO];
   const bool fused = report != 0ull;
   const int bid = (int)blockIdx.x - scan_wg;       // Gaussian block of this workgroup; -1: the scan workgroup
+  SC_MARK(0);
   if (bid < 0) {
     // ---- fused scan: `scan_wg` extra workgroups (dispatched first) scan the tile counts and publish `ranges`, the chunk
     // work items of long lists, the instance count and its sticky maximum, while the others load, count and reserve; they
@@ -443,9 +469,9 @@ __global__ __launch_bounds__(HGS_BLOCK) void scatter_kernel(int P, int gx, int T
     // is what the launches of more than 768 workgroups, i.e. every model beyond 196 k Gaussians, paid for it.)  The offsets
     // live in the block's tile table, which a scan workgroup does not use otherwise.
     constexpr int MAX_IPT = (HGS_FUSED_SCAN_MAX_T / HGS_SCAN_WGS + HGS_BLOCK - 1) / HGS_BLOCK + 1;
-    static_assert(sizeof(TileHash) >= (HGS_FUSED_SCAN_MAX_T / HGS_SCAN_WGS + HGS_FUSED_SCAN_MAX_T / HGS_SCAN_WGS / 32 + 2 + HGS_BLOCK) * sizeof(uint32_t),
-                  "a share's offsets fit the tile table");
-    uint32_t* tile_off = (uint32_t*)&th;
+    static_assert(sizeof(sc_lds) >= (HGS_FUSED_SCAN_MAX_T / HGS_SCAN_WGS + HGS_FUSED_SCAN_MAX_T / HGS_SCAN_WGS / 32 + 2 + HGS_BLOCK) * sizeof(uint32_t),
+                  "a share's offsets fit the block's LDS");
+    uint32_t* tile_off = (uint32_t*)sc_lds;
     const int q = (int)blockIdx.x;                  // this workgroup's share of the tiles: [t_lo, t_hi)
     const int share = (T + scan_wg - 1) / scan_wg, t_lo = min(T, q * share), t_hi = min(T, t_lo + share);
     uint32_t cnt[MAX_IPT];
@@ -509,6 +535,7 @@ __global__ __launch_bounds__(HGS_BLOCK) void scatter_kernel(int P, int gx, int T
       const uint32_t o = tile_off[at(t - t_lo)], v = (t + 1 < t_hi ? tile_off[at(t + 1 - t_lo)] : end_all) - o;
       hgs_emit_sort_items((uint32_t)t, v, (uint32_t)T, im);
     }
+    SC_MARK(5);
     return;
   }
   th_init(th);
@@ -551,17 +578,71 @@ __global__ __launch_bounds__(HGS_BLOCK) void scatter_kernel(int P, int gx, int T
   }
   if (n == 0) rc = HgsRect{0, 0, 0, 0, 0, 0};
   const bool small = n != 0 && n <= TH_MAX_AREA;
-  // pass 1: count this block's instances per tile in LDS
-  if (small)
-    for (int ty = rc.y0; ty < rc.y1; ty++)
-      for (int tx = rc.x0; tx < rc.x1; tx++) {
-        const int sl = th_insert(th, (uint32_t)(ty * gx + tx));
-        if (sl >= 0) atomicAdd(&th.cnt[sl], 1u);
-      }
+  // Round 4: the instances of the block's Gaussians are dealt to the threads EVENLY.  Rounds 1-3 let every lane walk its own
+  // rectangle, so a workgroup took as long as its largest Gaussian: on the state 1000 iterations of training leave (2.9
+  // instances per Gaussian on average, up to 16 per lane) the key placement took 9.5 us per workgroup on average and 20 at
+  // most for 3.9 at initialisation (tools/dev/scatter_trace.py), and the launch 52 us for 15.  Every Gaussian leaves a
+  // record in LDS; thread t takes the instances [t, t + 1) * ceil(total / 256) of the block's concatenated rectangles
+  // (one binary search over the prefix, then a walk) in both passes.  Order inside a tile's segment is irrelevant: the
+  // per-tile sort key is unique.  (Gaussians of more than TH_MAX_AREA tiles stay with their lane: direct global atomics.)
+  const uint32_t ns = small ? n : 0u;
+  const uint32_t incs = hgs_wave_incl_scan(ns, lane);
+  __syncthreads();                                   // wsum is reused
+  if (lane == 63) wsum[wave] = incs;
+  const HgsQuadCull qc = hgs_quad_cull(co);
+  {
+    ScRec r;
+    r.x0y0 = (uint32_t)rc.x0 | ((uint32_t)rc.y0 << 16); r.w = (uint32_t)(rc.x1 - rc.x0); r.depth = __float_as_uint(depth);
+    r.x = xy.x; r.y = xy.y; r.hx = qc.hx; r.hy = qc.hy; r.nx = qc.nx; r.ny = qc.ny; r.rn = qc.rn; r.mode = qc.mode;
+    srec[threadIdx.x] = r;
+  }
   __syncthreads();
+  uint32_t sbase = 0, stotal = 0;
+  for (int w = 0; w < 4; w++) { if (w < wave) sbase += wsum[w]; stotal += wsum[w]; }
+  ioff[threadIdx.x] = sbase + incs - ns;
+  if (threadIdx.x == HGS_BLOCK - 1) ioff[HGS_BLOCK] = stotal;
+  __syncthreads();
+  SC_MARK(1);
+  // this thread's share of the block's instances: [k0, k1), starting inside Gaussian j0 at its l0-th tile
+  const uint32_t per = (stotal + HGS_BLOCK - 1) / HGS_BLOCK;
+  const uint32_t k0 = min(stotal, threadIdx.x * per), k1 = min(stotal, k0 + per);
+  int j0 = 0;
+  if (k0 < k1) {
+    int lo = 0, hi = HGS_BLOCK;                       // largest j with ioff[j] <= k0 (its Gaussian has an instance there)
+    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (ioff[mid] <= k0) lo = mid; else hi = mid; }
+    j0 = lo;
+  }
+  const uint32_t l0 = k0 < k1 ? k0 - ioff[j0] : 0u;
+  auto for_my_instances = [&](auto&& fn) {
+    if (k0 >= k1) return;
+    int j = j0;
+    uint32_t l = l0, nj = ioff[j + 1] - ioff[j];
+    ScRec r = srec[j];
+    int tx = (int)(r.x0y0 & 0xFFFFu) + (int)(l % r.w), ty = (int)(r.x0y0 >> 16) + (int)(l / r.w);
+    for (uint32_t k = k0; k < k1; k++) {
+      while (l >= nj) {                               // next Gaussian with an instance
+        j++; l = 0; nj = ioff[j + 1] - ioff[j];
+        if (nj) { r = srec[j]; tx = (int)(r.x0y0 & 0xFFFFu); ty = (int)(r.x0y0 >> 16); }
+      }
+      fn(j, r, tx, ty);
+      l++;
+      if (++tx == (int)((r.x0y0 & 0xFFFFu) + r.w)) { tx = (int)(r.x0y0 & 0xFFFFu); ty++; }
+    }
+  };
+  // pass 1: count this block's instances per tile in LDS
+  for_my_instances([&](int, const ScRec&, int tx, int ty) {
+    const int sl = th_insert(th, (uint32_t)(ty * gx + tx));
+    if (sl >= 0) atomicAdd(&th.cnt[sl], 1u);
+  });
+  __syncthreads();
+  SC_MARK(2);
   // one global atomic per distinct tile reserves the block's slots in that tile's segment
-  for (int i = threadIdx.x; i < TH_SIZE; i += HGS_BLOCK)
+  for (int i = threadIdx.x; i < ScTable::SIZE; i += HGS_BLOCK)
     if (th.key[i] != TH_EMPTY) { th.base[i] = atomicAdd(&im.tile_cursor[HGS_TILE_SLOT(th.key[i], im.tile_mask)], th.cnt[i]); th.cnt[i] = 0u; }
+#if HGS_SCATTER_TRACE
+  __syncthreads();
+  SC_MARK(3);
+#endif
   if (fused) {
     // the offsets of the scan workgroup are needed from here on (it was dispatched first and has had this workgroup's
     // loads, counting and reservation to finish; bounded wait: HGS_ST_TIMEOUT / HGS_WAIT_TIMED_OUT instead of a hung GPU)
@@ -572,10 +653,8 @@ __global__ __launch_bounds__(HGS_BLOCK) void scatter_kernel(int P, int gx, int T
     }
   }
   __syncthreads();
-  if (n == 0) return;
-  // pass 2: place the keys (order inside a tile's segment is irrelevant: the per-tile sort key is unique)
-  const uint64_t key0 = ((uint64_t)__float_as_uint(depth) << 32) | ((uint32_t)idx << HGS_QMASK_SHIFT);
-  {
+  SC_MARK(4);
+  if (n != 0) {
     // this Gaussian's instance-record template (HgsGeom::grec), read back once per instance by the sort kernel
     float4* rec = g.grec + 4 * (size_t)idx;
     rec[0] = make_float4(xy.x, xy.y, co.x, co.y);
@@ -584,17 +663,31 @@ __global__ __launch_bounds__(HGS_BLOCK) void scatter_kernel(int P, int gx, int T
     rec[3] = make_float4(ex.w, __uint_as_float(rc.off), __uint_as_float((uint32_t)rc.x0 | ((uint32_t)rc.y0 << 16)),
                          __uint_as_float((uint32_t)(rc.x1 - rc.x0)));
   }
-  const HgsQuadCull qc = hgs_quad_cull(co);
-  for (int ty = rc.y0; ty < rc.y1; ty++)
-    for (int tx = rc.x0; tx < rc.x1; tx++) {
-      const uint32_t t = (uint32_t)(ty * gx + tx);
-      const uint64_t key = key0 | hgs_quadrant_mask(qc, xy, tx, ty);
-      const int sl = small ? th_find(th, t) : -1;
-      const uint32_t pos = (fused ? hgs_ld_agent(&im.ranges[t].x) : im.ranges[t].x) + (sl >= 0 ? th.base[sl] + atomicAdd(&th.cnt[sl], 1u)
-                                                     : atomicAdd(&im.tile_cursor[HGS_TILE_SLOT(t, im.tile_mask)], 1u));
-      if (pos < Rcap) b.keys[pos] = key;
-      else im.status[HGS_ST_OVERFLOW] = 1;  // overflow: caller under-sized the binning buffer
-    }
+  // pass 2: place the keys
+  const uint32_t idx0 = (uint32_t)bid * HGS_BLOCK;
+  auto place = [&](uint64_t key0, const HgsQuadCull& q, float2 c, int tx, int ty, bool table) {
+    const uint32_t t = (uint32_t)(ty * gx + tx);
+    const uint64_t key = key0 | hgs_quadrant_mask(q, c, tx, ty);
+    const int sl = table ? th_find(th, t) : -1;
+    const uint32_t pos = (fused ? hgs_ld_agent(&im.ranges[t].x) : im.ranges[t].x) + (sl >= 0 ? th.base[sl] + atomicAdd(&th.cnt[sl], 1u)
+                                                   : atomicAdd(&im.tile_cursor[HGS_TILE_SLOT(t, im.tile_mask)], 1u));
+    if (pos < Rcap) b.keys[pos] = key;
+    else im.status[HGS_ST_OVERFLOW] = 1;  // overflow: caller under-sized the binning buffer
+  };
+  for_my_instances([&](int j, const ScRec& r, int tx, int ty) {
+    HgsQuadCull q;
+    q.tau = 0.f; q.hx = r.hx; q.hy = r.hy; q.nx = r.nx; q.ny = r.ny; q.rn = r.rn; q.mode = r.mode;
+    place(((uint64_t)r.depth << 32) | ((idx0 + (uint32_t)j) << HGS_QMASK_SHIFT), q, make_float2(r.x, r.y), tx, ty, true);
+  });
+  if (n > TH_MAX_AREA) {
+    const uint64_t key0 = ((uint64_t)__float_as_uint(depth) << 32) | ((uint32_t)idx << HGS_QMASK_SHIFT);
+    for (int ty = rc.y0; ty < rc.y1; ty++)
+      for (int tx = rc.x0; tx < rc.x1; tx++) place(key0, qc, xy, tx, ty, false);
+  }
+#if HGS_SCATTER_TRACE
+  __syncthreads();
+  SC_MARK(5);
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -972,3 +1065,11 @@ int hgs_launch_mark_visible(hipStream_t s, int P, const float* means3D, const fl
   HGS_CHECK_LAUNCH();
   return 0;
 }
+
+#if HGS_SCATTER_TRACE
+extern "C" int hgs_debug_scatter_trace(unsigned long long* host_out, int n_wg) {
+  if (n_wg > SC_TRACE_MAX) n_wg = SC_TRACE_MAX;
+  return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_sc_trace), (size_t)n_wg * 8 * sizeof(unsigned long long)) == hipSuccess ? 0 : 1;
+}
+#endif
+
