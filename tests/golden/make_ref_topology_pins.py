@@ -9,8 +9,8 @@ Two stages, two processes (both packages are called `scene` / `utils` / `argumen
   --stage reference  (/root/reference only on sys.path) each state is loaded into the REFERENCE's HairGaussianModel and the
                      reference's own methods are run on it, unedited:
                        densification(extent, max_screen_size, info)           :788-817   (seeds x three extents)
-                       clone_strategy / split_strategy / merge_collapsed_segments / prune_strategy, one at a time
-                                                                              :828-1077
+                       clone_strategy / split_strategy / merge_collapsed_segments / prune_strategy (both modes),
+                       clean_gaussians (both modes), update_densification_stats, one at a time   :828-1077, 1401-1408, 1502-1516
                        compute_strands_info()                                 :1410-1496
                        compute_endpoint_pair_to_merge()                       :1205-1362
                        merging(info)                                          :1079-1096
@@ -152,7 +152,7 @@ def stage_reference():
             n_runs += 1
     for seed in OP_SEEDS:
         extent = 0.02
-        for op in ("clone", "split", "merge_collapsed", "prune"):
+        for op in ("clone", "split", "merge_collapsed", "prune", "prune_free", "clean", "clean_all", "stats"):
             m = _ref_model(inp, seed, torch, HairGaussianModel, opt)
             info = _Info()
             with torch.no_grad():
@@ -164,8 +164,22 @@ def stage_reference():
                     m.split_strategy(grads, extent, info)
                 elif op == "merge_collapsed":
                     m.merge_collapsed_segments(info)
-                else:
+                elif op == "prune":
                     m.prune_strategy(extent, 20, info, avoid_connected=True)
+                elif op == "prune_free":
+                    m.prune_strategy(extent, 20, info, avoid_connected=False)
+                elif op == "clean":
+                    m.clean_gaussians()                                   # :1502-1516 (render.py:56)
+                elif op == "clean_all":
+                    m.clean_gaussians(avoid_connected=False)
+                else:                                                     # update_densification_stats :1401-1408
+                    rng = np.random.default_rng(seed)
+                    Pn = m.endpoint_pairs.shape[0]
+                    vs = torch.zeros((Pn, 3), requires_grad=True)
+                    vs.grad = torch.from_numpy((rng.normal(size=(Pn, 3)) * 1e-3).astype(np.float32))
+                    radii = torch.from_numpy(rng.integers(0, 40, size=Pn).astype(np.float32))
+                    out[f"op_stats_s{seed}_in_vs_grad"], out[f"op_stats_s{seed}_in_radii"] = vs.grad.numpy().copy(), radii.numpy().copy()
+                    m.update_densification_stats(vs, radii, radii > 0)
             key = f"op_{op}_s{seed}_"
             _dump(out, key, m, torch)
             out[key + "info"] = info_arr(info, DENS_INFO)

@@ -481,7 +481,7 @@ def test_densification_equals_the_reference_run(ref_pins, seed, xi):
 
 
 @pytest.mark.parametrize("seed", [100 + s for s in range(8)])
-@pytest.mark.parametrize("op", ["clone", "split", "merge_collapsed", "prune"])
+@pytest.mark.parametrize("op", ["clone", "split", "merge_collapsed", "prune", "prune_free", "clean", "clean_all", "stats"])
 def test_each_operator_alone_equals_the_reference_run(ref_pins, seed, op):
     extent = 0.02
     m = _model_for_pin(ref_pins, seed)
@@ -494,8 +494,19 @@ def test_each_operator_alone_equals_the_reference_run(ref_pins, seed, op):
         m.split_strategy(grads, extent, info)
     elif op == "merge_collapsed":
         m.merge_collapsed_segments(info)
-    else:
+    elif op == "prune":
         m.prune_strategy(extent, 20, info, avoid_connected=True)
+    elif op == "prune_free":
+        m.prune_strategy(extent, 20, info, avoid_connected=False)
+    elif op == "clean":
+        m.clean_gaussians()
+    elif op == "clean_all":
+        m.clean_gaussians(avoid_connected=False)
+    else:
+        vs = torch.zeros((m.endpoint_pairs.shape[0], 3), requires_grad=True)
+        vs.grad = torch.from_numpy(ref_pins[f"op_stats_s{seed}_in_vs_grad"].copy())
+        radii = torch.from_numpy(ref_pins[f"op_stats_s{seed}_in_radii"].copy())
+        m.update_densification_stats(vs, radii, radii > 0)
     key = f"op_{op}_s{seed}_"
     _assert_equals_pin(m, ref_pins, key, f"{op} seed {seed}")
     names = [str(n) for n in ref_pins["meta_dens_info_names"]]
