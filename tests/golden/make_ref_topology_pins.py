@@ -15,6 +15,7 @@ Two stages, two processes (both packages are called `scene` / `utils` / `argumen
                        compute_endpoint_pair_to_merge()                       :1205-1362
                        merging(info)                                          :1079-1096
                        reset_opacity()                                        :1364-1371
+                       the Stage-II merging loop of merge.py:113-177 (candidates -> merge -> strands_info to a fixed point)
 The reference module's import line pulls in third-party packages this image lacks (pytorch3d, plyfile, simple_knn, cv2,
 pyrr, pyvista, pyvistaqt, dreifus, wandb, tensorboard): they are satisfied by EMPTY placeholder modules whose every attribute
 raises when called (tests/golden/_ref_harness.py).  None of the methods run here calls into them (a call would abort the
@@ -36,7 +37,7 @@ TMP_IN = os.path.join(HERE, "_topology_inputs.npz")
 DENS_SEEDS = list(range(12))
 DENS_EXTENTS = [1e-3, 0.05, 50.0]
 OP_SEEDS = [100 + s for s in range(8)]
-MERGE_SEEDS = [200 + s for s in range(10)]
+MERGE_CASES = list(range(12))        # cut-up curves: seed = case // 2, bidirectional_merge = case % 2
 GROUPS = ("endpoints", "f_dc", "f_rest", "opacity", "mask", "width")
 
 
@@ -46,16 +47,18 @@ def stage_inputs():
     import torch
     import test_topology_restatement_cpu as T
     out = {}
-    for seed in sorted(set(DENS_SEEDS + OP_SEEDS + MERGE_SEEDS)):
-        m = T._random_model(seed)
-        k = f"s{seed}_"
+    models = [(f"s{seed}", T._random_model(seed)) for seed in sorted(set(DENS_SEEDS + OP_SEEDS))]
+    models += [(f"c{case}", T._cut_model(case // 2, bool(case % 2))) for case in MERGE_CASES]
+    for tag, m in models:
+        k = f"{tag}_"
         out[k + "pairs"] = m.endpoint_pairs.numpy().astype(np.int64)
         for g in m.optimizer.param_groups:
             p = g["params"][0]
-            st = m.optimizer.state[p]
+            st = m.optimizer.state.get(p, {})
             out[k + g["name"]] = p.detach().numpy()
-            out[k + g["name"] + "_exp_avg"] = st["exp_avg"].numpy()
-            out[k + g["name"] + "_exp_avg_sq"] = st["exp_avg_sq"].numpy()
+            out[k + g["name"] + "_exp_avg"] = st["exp_avg"].numpy() if "exp_avg" in st else np.zeros(tuple(p.shape), np.float32)
+            out[k + g["name"] + "_exp_avg_sq"] = st["exp_avg_sq"].numpy() if "exp_avg_sq" in st else np.zeros(tuple(p.shape), np.float32)
+            out[k + "has_state"] = np.bool_("exp_avg" in st)
         out[k + "grad_accum"] = m.xyz_gradient_accum.numpy()
         out[k + "denom"] = m.denom.numpy()
         out[k + "max_radii2D"] = m.max_radii2D.numpy()
@@ -74,7 +77,7 @@ class _Info:
 
 
 def _ref_model(inp, seed, torch, HairGaussianModel, opt):
-    k = f"s{seed}_"
+    k = f"{seed}_" if isinstance(seed, str) else f"s{seed}_"
     m = HairGaussianModel(sh_degree=3, device="cpu")
     m.active_sh_degree = int(inp[k + "active_sh_degree"])
     m.ref_strand_root = inp[k + "ref_strand_root"]
@@ -86,8 +89,9 @@ def _ref_model(inp, seed, torch, HairGaussianModel, opt):
     m.training_setup(opt)
     for g in m.optimizer.param_groups:
         p = g["params"][0]
-        m.optimizer.state[p] = {"step": torch.tensor(3.0), "exp_avg": torch.from_numpy(inp[k + g["name"] + "_exp_avg"].copy()),
-                                "exp_avg_sq": torch.from_numpy(inp[k + g["name"] + "_exp_avg_sq"].copy())}
+        if bool(inp[k + "has_state"]):
+            m.optimizer.state[p] = {"step": torch.tensor(3.0), "exp_avg": torch.from_numpy(inp[k + g["name"] + "_exp_avg"].copy()),
+                                    "exp_avg_sq": torch.from_numpy(inp[k + g["name"] + "_exp_avg_sq"].copy())}
     m.xyz_gradient_accum = torch.from_numpy(inp[k + "grad_accum"].copy())
     m.denom = torch.from_numpy(inp[k + "denom"].copy())
     m.max_radii2D = torch.from_numpy(inp[k + "max_radii2D"].copy())
@@ -129,7 +133,7 @@ def stage_reference():
     inp = np.load(TMP_IN)
     out = {k: inp[k] for k in inp.files}
     out["meta_dens_seeds"], out["meta_dens_extents"] = np.array(DENS_SEEDS), np.array(DENS_EXTENTS)
-    out["meta_op_seeds"], out["meta_merge_seeds"] = np.array(OP_SEEDS), np.array(MERGE_SEEDS)
+    out["meta_op_seeds"], out["meta_merge_cases"] = np.array(OP_SEEDS), np.array(MERGE_CASES)
     n_runs = 0
 
     def info_arr(info, names):
@@ -184,11 +188,14 @@ def stage_reference():
             _dump(out, key, m, torch)
             out[key + "info"] = info_arr(info, DENS_INFO)
             n_runs += 1
-    for seed in MERGE_SEEDS:
+    for case in MERGE_CASES:
+        seed = f"c{case}"
+        opt.bidirectional_merge = bool(case % 2)
         m = _ref_model(inp, seed, torch, HairGaussianModel, opt)
+        out[f"{seed}_ref_max_segment_length"] = np.float32(float(m.max_segment_length))
         with torch.no_grad():
             m.compute_strands_info()
-            key = f"merge_s{seed}_"
+            key = f"merge_{seed}_"
             _dump_strands(out, key + "before_", m.strands_info)
             pairs = m.compute_endpoint_pair_to_merge()
             out[key + "pairs_to_merge"] = pairs.numpy().astype(np.int64).reshape(-1, 2)
@@ -198,12 +205,27 @@ def stage_reference():
             _dump(out, key + "after_", m, torch)
             _dump_strands(out, key + "after_", m.strands_info)
             out[key + "info_merge"] = np.int64(info.densification_info["merge"])
+            # merge.py:113-177: the Stage-II loop -- candidates, merge, strands_info -- until no candidate is left
+            ml = _ref_model(inp, seed, torch, HairGaussianModel, opt)
+            ml.compute_strands_info()
+            per_round = []
+            for _ in range(50):
+                pr = ml.compute_endpoint_pair_to_merge()
+                per_round.append(int(pr.shape[0]))
+                if pr.shape[0] == 0:
+                    break
+                ml.merge_endpoint_pairs(pr)
+                ml.compute_strands_info()
+            out[key + "loop_pairs_per_round"] = np.array(per_round, dtype=np.int64)
+            _dump(out, key + "loop_", ml, torch)
+            _dump_strands(out, key + "loop_", ml.strands_info)
             m.reset_opacity()
             out[key + "reset_opacity"] = m._opacity.detach().numpy().copy()
-            st = m.optimizer.state[m._opacity]
-            out[key + "reset_opacity_exp_avg"] = st["exp_avg"].numpy().copy()
-            out[key + "reset_opacity_exp_avg_sq"] = st["exp_avg_sq"].numpy().copy()
+            st = m.optimizer.state.get(m._opacity, {})
+            out[key + "reset_opacity_exp_avg"] = st["exp_avg"].numpy().copy() if "exp_avg" in st else np.zeros(tuple(m._opacity.shape), np.float32)
+            out[key + "reset_opacity_exp_avg_sq"] = st["exp_avg_sq"].numpy().copy() if "exp_avg_sq" in st else np.zeros(tuple(m._opacity.shape), np.float32)
         n_runs += 1
+    opt.bidirectional_merge = False
     np.savez_compressed(OUT, **out)
     os.remove(TMP_IN)
     print(f"reference runs: {n_runs}; wrote {OUT} ({os.path.getsize(OUT) / 1024:.0f} KB, {len(out)} arrays)")
