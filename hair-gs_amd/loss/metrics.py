@@ -13,10 +13,12 @@ from scipy.spatial import cKDTree
 
 @dataclass
 class HairEvalData:
-    """Oriented point cloud: points [N,3], unit directions [N,3], optional strand id per point."""
+    """Oriented point cloud: points [N,3], unit directions [N,3], optional strand id per point, optional edges between points
+    (reference data/eval_data.py:16-20)."""
     points: np.ndarray
     directions: np.ndarray
     points_id_to_strand_id: Optional[np.ndarray] = None
+    edges: Optional[np.ndarray] = None
 
 
 def _csr_matches(p1, p2, dist_th, cos_th, bidirectional):
@@ -93,20 +95,29 @@ def compute_metrics(pred, gt, dist_ths=(2e-3, 3e-3, 4e-3, 4e-3), angle_ths=(20, 
     return ({k + suffix: np.array([v[i] for i in range(len(labels)) if i in v]) for k, v in out.items()}, labels)
 
 
-def compute_eval_data_from_hair_gs(gaussians, only_foreground=True):
-    """Oriented points of a strand model: segment midpoints + unit directions + strand ids (the role of the
-    reference's data.compute_eval_data_from_hair_gs, used by train.py:65-70)."""
-    import torch
-    with torch.no_grad():
-        fg = gaussians.compute_foreground_mask() if only_foreground else torch.ones(
-            gaussians.endpoint_pairs.shape[0], dtype=torch.bool, device=gaussians.get_xyz.device)
-        pts = gaussians.get_xyz[fg].cpu().numpy()
-        dirs = gaussians.get_orientation[fg].cpu().numpy()
-        ids = None
-        if gaussians.strands_info is not None:
-            e2s = gaussians.strands_info.id_to_strand_id
-            ids = e2s[gaussians.endpoint_pairs[fg][:, 0].cpu().numpy()]
-    return HairEvalData(points=pts, directions=dirs, points_id_to_strand_id=ids)
+def compute_eval_data_from_hair_gs(hair_gs, compute_edges=False, only_foreground=False):
+    """Oriented points of a strand model as the reference defines them (data/eval_data.py:133-171): one point per segment of
+    `strands_info.list_strands` -- its FIRST joint in strand order, root to tip --, the unit direction towards the next joint,
+    and the joint's strand id.  (`strands_info` computed with only_foreground=True already holds foreground segments only;
+    only_foreground=True here filters again by the current foreground mask, like the reference.)"""
+    endpoints = hair_gs._endpoints.detach().cpu().numpy()
+    segments_id = np.concatenate(list(hair_gs.strands_info.list_strands), axis=0)
+    if only_foreground:
+        mask = hair_gs.compute_foreground_mask().cpu().numpy()
+        line_points = hair_gs.endpoint_pairs.cpu().numpy()[mask].flatten()
+        segments_id = segments_id[np.any(np.isin(segments_id, line_points), axis=1)]
+    segments = endpoints[segments_id]
+    directions = segments[:, 1] - segments[:, 0]
+    directions /= np.linalg.norm(directions, axis=1, keepdims=True)
+    points_id = segments_id[:, 0]
+    edges = None
+    if compute_edges:   # indices into the new point set; single-segment strands have no edge (:160-166)
+        mapping = np.zeros(segments_id.max() + 1, dtype=np.int32)
+        mapping[segments_id[:, 0]] = np.arange(segments_id.shape[0])
+        u, c = np.unique(segments_id, return_counts=True)
+        edges = mapping[segments_id[np.isin(segments_id[:, 1], u[c > 1])]]
+    return HairEvalData(points=endpoints[points_id], directions=directions,
+                        points_id_to_strand_id=np.asarray(hair_gs.strands_info.id_to_strand_id)[points_id], edges=edges)
 
 
 def compute_eval_data_from_gs(gaussians):
