@@ -32,11 +32,13 @@ class Image(BaseImage):
 
 
 def qvec2rotmat(qvec):
-    """Unit quaternion (w, x, y, z) -> rotation matrix."""
-    w, x, y, z = (float(v) for v in qvec)
-    return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y)],
-                     [2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x)],
-                     [2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)]])
+    """Unit quaternion (w, x, y, z) -> rotation matrix, in COLMAP's own operation order (every term doubled before it is
+    added: the camera matrices, and with them every bit-exact key of the rasterizer, start from these nine numbers;
+    tests/test_ref_colmap_pins_cpu.py holds them to the reference's last bit)."""
+    w, x, y, z = qvec[0], qvec[1], qvec[2], qvec[3]
+    return np.array([[1 - 2 * y ** 2 - 2 * z ** 2, 2 * x * y - 2 * w * z, 2 * z * x + 2 * w * y],
+                     [2 * x * y + 2 * w * z, 1 - 2 * x ** 2 - 2 * z ** 2, 2 * y * z - 2 * w * x],
+                     [2 * z * x - 2 * w * y, 2 * y * z + 2 * w * x, 1 - 2 * x ** 2 - 2 * y ** 2]])
 
 
 def rotmat2qvec(R):
