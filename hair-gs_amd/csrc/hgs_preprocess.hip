@@ -577,15 +577,16 @@ __global__ __launch_bounds__(HGS_BLOCK) void scatter_kernel(int P, int gx, int T
     }
   }
   if (n == 0) rc = HgsRect{0, 0, 0, 0, 0, 0};
-  const bool small = n != 0 && n <= TH_MAX_AREA;
   // Round 4: the instances of the block's Gaussians are dealt to the threads EVENLY.  Rounds 1-3 let every lane walk its own
   // rectangle, so a workgroup took as long as its largest Gaussian: on the state 1000 iterations of training leave (2.9
   // instances per Gaussian on average, up to 16 per lane) the key placement took 9.5 us per workgroup on average and 20 at
   // most for 3.9 at initialisation (tools/dev/scatter_trace.py), and the launch 52 us for 15.  Every Gaussian leaves a
   // record in LDS; thread t takes the instances [t, t + 1) * ceil(total / 256) of the block's concatenated rectangles
   // (one binary search over the prefix, then a walk) in both passes.  Order inside a tile's segment is irrelevant: the
-  // per-tile sort key is unique.  (Gaussians of more than TH_MAX_AREA tiles stay with their lane: direct global atomics.)
-  const uint32_t ns = small ? n : 0u;
+  // per-tile sort key is unique.  Large Gaussians are dealt out like the others (a 36-tile Gaussian walked by its own lane,
+  // one returning global atomic per tile, was what the last workgroup of a launch was still doing 19 us after the median
+  // one had finished); an instance whose tile finds the table full takes the direct global atomic.
+  const uint32_t ns = n;
   const uint32_t incs = hgs_wave_incl_scan(ns, lane);
   __syncthreads();                                   // wsum is reused
   if (lane == 63) wsum[wave] = incs;
@@ -665,10 +666,10 @@ __global__ __launch_bounds__(HGS_BLOCK) void scatter_kernel(int P, int gx, int T
   }
   // pass 2: place the keys
   const uint32_t idx0 = (uint32_t)bid * HGS_BLOCK;
-  auto place = [&](uint64_t key0, const HgsQuadCull& q, float2 c, int tx, int ty, bool table) {
+  auto place = [&](uint64_t key0, const HgsQuadCull& q, float2 c, int tx, int ty) {
     const uint32_t t = (uint32_t)(ty * gx + tx);
     const uint64_t key = key0 | hgs_quadrant_mask(q, c, tx, ty);
-    const int sl = table ? th_find(th, t) : -1;
+    const int sl = th_find(th, t);
     const uint32_t pos = (fused ? hgs_ld_agent(&im.ranges[t].x) : im.ranges[t].x) + (sl >= 0 ? th.base[sl] + atomicAdd(&th.cnt[sl], 1u)
                                                    : atomicAdd(&im.tile_cursor[HGS_TILE_SLOT(t, im.tile_mask)], 1u));
     if (pos < Rcap) b.keys[pos] = key;
@@ -677,13 +678,8 @@ __global__ __launch_bounds__(HGS_BLOCK) void scatter_kernel(int P, int gx, int T
   for_my_instances([&](int j, const ScRec& r, int tx, int ty) {
     HgsQuadCull q;
     q.tau = 0.f; q.hx = r.hx; q.hy = r.hy; q.nx = r.nx; q.ny = r.ny; q.rn = r.rn; q.mode = r.mode;
-    place(((uint64_t)r.depth << 32) | ((idx0 + (uint32_t)j) << HGS_QMASK_SHIFT), q, make_float2(r.x, r.y), tx, ty, true);
+    place(((uint64_t)r.depth << 32) | ((idx0 + (uint32_t)j) << HGS_QMASK_SHIFT), q, make_float2(r.x, r.y), tx, ty);
   });
-  if (n > TH_MAX_AREA) {
-    const uint64_t key0 = ((uint64_t)__float_as_uint(depth) << 32) | ((uint32_t)idx << HGS_QMASK_SHIFT);
-    for (int ty = rc.y0; ty < rc.y1; ty++)
-      for (int tx = rc.x0; tx < rc.x1; tx++) place(key0, qc, xy, tx, ty, false);
-  }
 #if HGS_SCATTER_TRACE
   __syncthreads();
   SC_MARK(5);

@@ -30,19 +30,23 @@ L = rt.lib()
 L.hgs_debug_scatter_trace.argtypes = [C.c_void_p, C.c_int]
 P = model.get_xyz.shape[0]
 nwg = (P + 255) // 256 + 4
-acc = []
+acc, ev = [], []
 for i in range(8):
+    rt.prof_collect(); rt.prof_enable(True)
     training_step(model, sampler.next(), opt, bg, n + 1 + i, extent=extent, fused=fused)
     torch.cuda.synchronize()
+    k = rt.prof_collect(); rt.prof_enable(False)
     buf = np.zeros((min(nwg, 8192), 8), dtype=np.uint64)
     assert L.hgs_debug_scatter_trace(buf.ctypes.data, buf.shape[0]) == 0
     if i >= 3:
         acc.append(buf.astype(np.int64))
+        ev.append({a: round(v[0] / v[1] * 1e3, 1) for a, v in k.items() if v[1] and a in ("scatter_kernel", "preprocess_fwd_kernel", "sort_tiles_kernel")})
 _C.set_async(False)
 names = ["loads + block prefix", "count tiles (LDS)", "reserve (global atomics)", "wait for the scan", "place keys"]
 print(f"P {P} workgroups {nwg} (first 4: scan)")
-for t in acc[-2:]:
+for t, e in zip(acc[-3:], ev[-3:]):
     t0 = t[:, 0].min()
+    print("  HIP events around the launches of this step (us):", e, " trace span:", round((t[:, 5].max() - t0) * 0.01, 1))
     g = t[4:]
     us = lambda a: a * 0.01
     print("  scan workgroups: start", us(t[:4, 0] - t0).round(1).tolist(), "end", us(t[:4, 5] - t0).round(1).tolist())
