@@ -754,16 +754,35 @@ __global__ __launch_bounds__(HGS_BLOCK) __attribute__((amdgpu_waves_per_eu(HGS_P
     const HgsRect rc = rc_pre;
     const uint32_t n = n_pre;
     const int row_floats = a.n_extra ? 16 : HGS_INST_GRAD_FLOATS;
-    for (uint32_t k = 0; k < n; k++) {
-      if (rc.off + k >= Rcap) break;  // under-sized binning buffer (forward already flagged the overflow)
-      const float4* r = (const float4*)(inst_grad + (size_t)(rc.off + k) * row_floats);   // rows in Gaussian-major order
-      const float4 r0 = r[0], r1 = r[1], r2 = r[2];
-      dmx += r0.x; dmy += r0.y; dcx += r0.z; dcy += r0.w;
-      dcw += r1.x; dop += r1.y; dcol[0] += r1.z; dcol[1] += r1.w; dcol[2] += r2.x;
-      if (a.n_extra) {  // row = [.., dcolor 0..6, rgb-only dmean2D.xy]
-        const float4 r3 = r[3];
-        dex[0] += r2.y; dex[1] += r2.z; dex[2] += r2.w; dex[3] += r3.x;
-        dmx_rgb += r3.y; dmy_rgb += r3.z;
+    // (under-sized binning buffer: the forward already flagged the overflow; rows beyond the capacity do not exist)
+    const uint32_t nr = rc.off >= Rcap ? 0u : min(n, Rcap - rc.off);
+    const float4* rows = (const float4*)(inst_grad + (size_t)rc.off * row_floats);   // rows in Gaussian-major order
+    const int rq = row_floats / 4;
+    // HGS_PPB_ROWS rows in flight per trip, added in instance order (the sums are the same sums; a lane with 30 instances used to
+    // pay 30 dependent trips through the cache hierarchy, and its workgroup with it)
+#ifndef HGS_PPB_ROWS
+#define HGS_PPB_ROWS 2
+#endif
+    for (uint32_t k = 0; k < nr; k += HGS_PPB_ROWS) {
+      float4 q[HGS_PPB_ROWS][4];
+#pragma unroll
+      for (int u = 0; u < HGS_PPB_ROWS; u++) {
+        const uint32_t ku = min(k + (uint32_t)u, nr - 1u);            // (clamped: loaded again, not added)
+        const float4* r = rows + (size_t)ku * rq;
+        q[u][0] = r[0]; q[u][1] = r[1]; q[u][2] = r[2];
+        q[u][3] = a.n_extra ? r[3] : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+#pragma unroll
+      for (int u = 0; u < HGS_PPB_ROWS; u++) {
+        if (k + (uint32_t)u < nr) {
+          const float4 r0 = q[u][0], r1 = q[u][1], r2 = q[u][2], r3 = q[u][3];
+          dmx += r0.x; dmy += r0.y; dcx += r0.z; dcy += r0.w;
+          dcw += r1.x; dop += r1.y; dcol[0] += r1.z; dcol[1] += r1.w; dcol[2] += r2.x;
+          if (a.n_extra) {  // row = [.., dcolor 0..6, rgb-only dmean2D.xy]
+            dex[0] += r2.y; dex[1] += r2.z; dex[2] += r2.w; dex[3] += r3.x;
+            dmx_rgb += r3.y; dmy_rgb += r3.z;
+          }
+        }
       }
     }
     // The rows hold sums of moments of u = G dL/dalpha (blend_bwd_kernel): dmx = S(u dx), dmy = S(u dy), dcx = S(u dx dx),
