@@ -214,7 +214,7 @@ __device__ __forceinline__ void work_list_shared(int T, uint32_t Rcap, HgsSegPol
   if (tid == 0) nsplit_base = 0u;
   const uint32_t S = hgs_segment_length(im.status[HGS_ST_R], pol);
   const uint32_t seg_cap = min(b.seg_cap, (uint32_t)HGS_SPLIT_CAPACITY(T));   // (what the work list holds)
-  const uint32_t thr = seg_cap ? S + S / 2 : 0xFFFFFFFFu;
+  const uint32_t thr = seg_cap ? S * HGS_SPLIT_QUARTERS / 4u : 0xFFFFFFFFu;
   __syncthreads();
   auto length_of = [&](int i) { const uint2 r = im.ranges[i]; return r.y > Rcap ? 0u : r.y - r.x; };   // (beyond the capacity: void)
   auto bucket_for = [&](uint32_t n) { return ORD_BUCKETS - 1 - (int)min(n, (uint32_t)(ORD_BUCKETS - 1)); };   // 0 = longest
@@ -335,7 +335,7 @@ __device__ __forceinline__ void work_list_block(int T, uint32_t Rcap, HgsSegPoli
   if (tid == 0) { ncand = 0u; nitems = 0u; nsplit_base = 0u; }
   const uint32_t S = hgs_segment_length(im.status[HGS_ST_R], pol);
   const uint32_t seg_cap = min(b.seg_cap, (uint32_t)HGS_SPLIT_CAPACITY(T));   // (what the work list holds)
-  const uint32_t thr = seg_cap ? S + S / 2 : 0xFFFFFFFFu;
+  const uint32_t thr = seg_cap ? S * HGS_SPLIT_QUARTERS / 4u : 0xFFFFFFFFu;
   __syncthreads();
   auto length_of = [&](int i) { const uint2 r = im.ranges[i]; return r.y > Rcap ? 0u : r.y - r.x; };   // (beyond the capacity: void)
   auto bucket_for = [&](uint32_t n) { return ORD_BUCKETS - 1 - (int)min(n, (uint32_t)(ORD_BUCKETS - 1)); };   // 0 = longest

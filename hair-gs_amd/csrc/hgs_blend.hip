@@ -364,8 +364,14 @@ __global__ __launch_bounds__(HGS_BLOCK) __attribute__((amdgpu_waves_per_eu(8))) 
   //                                the local ones times T_in (blending is linear in the transmittance in front);
   //   otherwise                 -> the pixel stops in this segment (or sits within rounding of the threshold): only
   //                                these pixels are walked again, from T_in, exactly as the serial walk would.
-  const bool dead = inside && T_in < 0.0001f;
-  const bool through = inside && !dead && T > 0.f && T_in * T >= 0.00010002f;
+  // (The FIRST segment has nothing in front of it: its pass A started from the true transmittance, 1, and IS the serial walk --
+  //  every pixel's local result is final.  Until round 4 its stopping pixels were walked a second time like any other
+  //  segment's: on the state training leaves, where opaque strands stop most pixels of a dense tile early, that was a second
+  //  full pass over the segment -- 33 us behind a first pass of 43 us in the one split tile of a frame, whose two workgroups
+  //  were alone on the GPU for the last quarter of the launch, tools/wg_trace.py.)
+  const bool first = it.seg == 0;
+  const bool dead = inside && !first && T_in < 0.0001f;
+  const bool through = inside && !dead && (first || (T > 0.f && T_in * T >= 0.00010002f));
   const bool redo = inside && !dead && !through;
   auto publish = [&]() {   // this pixel's result for the segment (the tile's finalisation and the backward read it)
 #pragma unroll

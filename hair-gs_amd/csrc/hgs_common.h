@@ -350,9 +350,12 @@ __device__ __forceinline__ uint32_t hgs_segment_length(uint32_t R, const HgsSegP
   const uint32_t s = ((R / p.target) + 63u) & ~63u;
   return s < p.min_len ? p.min_len : (s > p.max_len ? p.max_len : s);
 }
+#ifndef HGS_SPLIT_QUARTERS
+#define HGS_SPLIT_QUARTERS 6u   // a list is split when it is longer than this many quarters of the segment length
+#endif
 struct HgsSplit { uint32_t nseg, seglen; };   // nseg == 1: the list is walked by one workgroup
 __device__ __forceinline__ HgsSplit hgs_split_of(uint32_t n, uint32_t S) {
-  if (n <= S + S / 2) return {1u, n};
+  if (n <= S * HGS_SPLIT_QUARTERS / 4u) return {1u, n};
   uint32_t seglen = S, nseg = (n + S - 1) / S;
   if (nseg > HGS_MAX_PARTS) { seglen = (((n + HGS_MAX_PARTS - 1) / HGS_MAX_PARTS) + 63u) & ~63u; nseg = (n + seglen - 1) / seglen; }
   return {nseg, seglen};

@@ -8,8 +8,18 @@ import hgs_runtime as rt
 from gaussian_renderer import render_multi
 from synthetic import build_workload
 wl = sys.argv[1] if len(sys.argv) > 1 else "north_star"
-model, cams, _ = build_workload(wl, device="cuda", with_targets=False, n_views=4)
+n_train = int(sys.argv[2]) if len(sys.argv) > 2 else 0   # trace the state this many iterations of the FULL loop leave
+model, cams, extent = build_workload(wl, device="cuda", with_targets=n_train > 0, n_views=8 if n_train else 4)
 bg = torch.zeros(3, device="cuda")
+if n_train:
+    from arguments import OptimizationParams
+    from train import training
+    from utils.general import safe_state
+    safe_state(True)
+    opt = OptimizationParams()
+    model.training_setup(opt)
+    training(model, cams, opt, iterations=n_train, extent=extent, seed=1)
+    print("trained", n_train, "iterations:", model.get_xyz.shape[0], "segments")
 cam = cams[0]
 H, W = cam.image_height, cam.image_width
 T = ((W + 15) // 16) * ((H + 15) // 16)
