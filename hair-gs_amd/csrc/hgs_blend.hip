@@ -324,6 +324,43 @@ __global__ __launch_bounds__(HGS_BLOCK) __attribute__((amdgpu_waves_per_eu(8))) 
     return;
   }
 
+  // ---- a list of TWO segments is walked serially by its first segment's workgroup (round 4).  The two-pass scheme below costs
+  // a segment its pass A, the wait for the products in front, pass B for the pixels that stop inside it and the finalisation:
+  // with two segments that chain is LONGER than the serial walk (C3: 17.6 + 3.9 + 10 + 5 us against ~30 for the tile's 377
+  // entries; trained state: 43 + 2 + 22 + 4 against ~63 for 599), and a frame's one list just over the split threshold was
+  // what its forward launch ended with, alone on the GPU (tools/wg_trace.py).  The BACKWARD still runs the two segments as two
+  // workgroups (its walk costs 3.5 times the forward's and needs no communication): what it reads of the forward is left here
+  // -- the transmittance in front of the second segment and that segment's colour (nothing lies behind it).
+  if (it.nseg == 2u) {
+    if (it.seg == 1u) return;
+    const uint32_t n = it.range.y - it.range.x;
+    float T = inside ? 1.f : -1.f;
+    fwd_walk<C>(src, 0u, it.e, recs, alive, pxf, pyf, wave, lane, T, acc, last);
+    const size_t slot1 = ((size_t)it.w + 1) * HGS_BLOCK + threadIdx.x;
+    bn.seg_T[slot1] = fabsf(T);
+    // (the first segment's colour waits in its own cell of the segment array, which nobody else reads)
+#pragma unroll
+    for (int k = 0; k < C; k++) { bn.seg_C[((size_t)it.w * C + k) * HGS_BLOCK + threadIdx.x] = acc[k]; acc[k] = 0.f; }
+    fwd_walk<C>(src, it.e, n, recs, alive, pxf, pyf, wave, lane, T, acc, last);
+#pragma unroll
+    for (int k = 0; k < C; k++) {
+      bn.seg_C[(((size_t)it.w + 1) * C + k) * HGS_BLOCK + threadIdx.x] = acc[k];
+      acc[k] += bn.seg_C[((size_t)it.w * C + k) * HGS_BLOCK + threadIdx.x];     // colours summed back to front, like the tile finalisation below
+    }
+    uint32_t wmax = last;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) wmax = max(wmax, (uint32_t)__shfl_xor((int)wmax, d, 64));
+    if (lane == 0 && wmax) atomicMax(&im.tile_maxc[tile], wmax);
+    if (inside) {
+      T = fabsf(T);
+      im.final_T[pix] = T;
+      im.n_contrib[pix] = last;
+#pragma unroll
+      for (int k = 0; k < C; k++) out_color[k * HW + pix] = acc[k] + T * bg[k];
+    }
+    return;
+  }
+
   // ---- one segment of a split list (see the file header)
   const size_t slot = (size_t)it.w * HGS_BLOCK + threadIdx.x;   // this pixel's cell in the per-segment arrays
   const size_t slot0 = slot - (size_t)it.seg * HGS_BLOCK;       // the same pixel's cell of the tile's first segment
