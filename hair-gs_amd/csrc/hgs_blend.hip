@@ -30,6 +30,9 @@
 //                         the LAST workgroup of the tile to finish (ticket) combines the segments per pixel in list
 //                         order: first stop wins, colours summed back to front (fixed order: reproducible), and leaves
 //                         the SUFFIX sums of the segment colours in place;
+//                (round 4: the FIRST segment's pass A starts from the true transmittance and is final -- no pass B --, and a
+//                 list of exactly two segments is walked serially by its first segment's workgroup: two links of this
+//                 chain take longer than the walk)
 //       backward          needs no communication: a segment starts from the forward's transmittance in front of the NEXT
 //                         segment and from the colour behind it (that suffix sum) -- exactly the state the serial walk
 //                         would carry into it.

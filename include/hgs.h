@@ -461,7 +461,7 @@ int hgs_set_tile_cull(int on);
  * enough) is registered, blend_fwd / blend_bwd record per workgroup: start, phase marks 1..5, its work item, end (times
  * from s_memrealtime, 100 MHz); NULL (the default) switches it off. */
 /* Tuning knob of the segment-parallel blend (csrc/hgs_blend.hip): tile lists longer than 1.5 segment lengths are walked
- * by one workgroup per segment; the segment length of a pass with R instances is R / target_segments rounded up to a
+ * by one workgroup per segment (the forward walks a list of exactly two segments with one workgroup); the segment length of a pass with R instances is R / target_segments rounded up to a
  * multiple of 64 and clamped to [min_len, max_len] (multiples of 64, min_len >= 128; default 128, 1024, 2048).  Process-wide, takes
  * effect at the next forward pass (a captured graph keeps the policy it was captured with).  Results do not depend
  * on it beyond the association of the per-pixel transmittance product. */
