@@ -210,10 +210,11 @@ def roofline_block(kern, fs, W, H, ch, wl_tag):
                 if pm.get("SQ_THREAD_CYCLES_VALU") and pm.get("SQ_ACTIVE_INST_VALU"):
                     lanes_busy = pm["SQ_THREAD_CYCLES_VALU"] / (pm["SQ_ACTIVE_INST_VALU"] * 64.0)
                 break
-    # `bound`: what the counters of the committed --pmc passes say.  The blend backward is bound by vector-instruction
-    # ISSUE (pipe utilisation 0.7 with every lane enabled while ~10 of 64 lanes blend a kept entry), not by HBM: `frac`
-    # stays the fraction of the HBM roofline the contract asks for, `valu_util` is the fraction of the bound that applies.
-    roof = {"kernel": "blend_bwd_kernel", "bound": "valu" if (valu_util or 0.0) >= 0.5 else "hbm",
+    # `bound`: the roofline the kernel is priced against -- HBM, as SURVEY.md 8d prescribes for this byte-moving path (`frac` is
+    # the fraction of the HBM specification).  `limited_by`: what the counters of the committed --pmc passes say actually holds
+    # it -- vector-instruction ISSUE (pipe utilisation 0.7 with every lane enabled while ~10 of 64 lanes blend a kept entry),
+    # not HBM; `valu_util` is the fraction of that limit in use.
+    roof = {"kernel": "blend_bwd_kernel", "bound": "hbm", "limited_by": "valu" if (valu_util or 0.0) >= 0.5 else "hbm",
             "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
             "peak_achievable": HBM_ACHIEVABLE_GBS, "frac_of_achievable": ach / HBM_ACHIEVABLE_GBS,
             "moved_bytes_model": moved_bwd, "moved_gbs": moved, "frac_moved": moved / HBM_PEAK_GBS,
