@@ -64,7 +64,12 @@ HBM_ACHIEVABLE_GBS = 6300.0  # what a float4 copy reaches on this part (MI355X_M
 
 def parse():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--gpus", type=int, default=1,
+                    help="ranks of the run, one per GPU.  N > 1 outside a torch.distributed.run environment: this process starts "
+                         "`python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py <same arguments>` as a child "
+                         "BEFORE anything touches the GPU, relays its output and exits with its code (launch_ranks)")
+    ap.add_argument("--dry-launch", action="store_true",
+                    help="print the launcher command of --gpus N as one JSON line and exit (nothing is started; CPU test)")
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="north_star")
@@ -195,7 +200,7 @@ def roofline_block(kern, fs, W, H, ch, wl_tag):
     ach = bytes_bwd / dur_s / 1e9 if bwd_ms > 0 else 0.0
     moved = moved_bwd / dur_s / 1e9 if bwd_ms > 0 else 0.0
     traffic = traffic_source = valu_util = lanes_busy = None
-    for name in (f"r04_pmc_raster_{wl_tag}.json", f"r03_pmc_raster_{wl_tag}.json", f"r02_pmc_raster_{wl_tag}.json", f"pmc_raster_{wl_tag}.json"):
+    for name in (f"r05_pmc_raster_{wl_tag}.json", f"r04_pmc_raster_{wl_tag}.json", f"r03_pmc_raster_{wl_tag}.json", f"r02_pmc_raster_{wl_tag}.json", f"pmc_raster_{wl_tag}.json"):
         pmc_path = os.path.join(ROOT, "profiles", name)
         if ch == 7 and os.path.exists(pmc_path):
             pm = json.load(open(pmc_path)).get("blend_bwd_kernel<7>", {})
@@ -213,8 +218,8 @@ def roofline_block(kern, fs, W, H, ch, wl_tag):
     # `bound`: the roofline the kernel is priced against -- HBM, as SURVEY.md 8d prescribes for this byte-moving path (`frac` is
     # the fraction of the HBM specification).  `limited_by`: what the counters of the committed --pmc passes say actually holds
     # it -- vector-instruction ISSUE (pipe utilisation 0.7 with every lane enabled while ~10 of 64 lanes blend a kept entry),
-    # not HBM; `valu_util` is the fraction of that limit in use.
-    roof = {"kernel": "blend_bwd_kernel", "bound": "hbm", "limited_by": "valu" if (valu_util or 0.0) >= 0.5 else "hbm",
+    # not HBM; `valu_util` is the fraction of that limit in use.  null where no --pmc pass of THIS state is committed.
+    roof = {"kernel": "blend_bwd_kernel", "bound": "hbm", "limited_by": None if valu_util is None else ("valu" if valu_util >= 0.5 else "hbm"),
             "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
             "peak_achievable": HBM_ACHIEVABLE_GBS, "frac_of_achievable": ach / HBM_ACHIEVABLE_GBS,
             "moved_bytes_model": moved_bwd, "moved_gbs": moved, "frac_moved": moved / HBM_PEAK_GBS,
@@ -245,8 +250,52 @@ def c3_roofline_leg():
         return {"error": str(e)}
 
 
+def launcher_command(args, argv, port=None):
+    """The command `bench.py --gpus N` (N > 1, no torch.distributed.run environment) starts: one rank per GPU of THIS node,
+    rendezvous on 127.0.0.1 (the container's hostname may not resolve), the caller's own arguments handed on unchanged."""
+    if port is None:
+        import socket
+        with socket.socket() as s_:            # a free port, so that two runs on one box do not meet
+            s_.bind(("127.0.0.1", 0))
+            port = s_.getsockname()[1]
+    rest = [a for a in argv if a != "--dry-launch"]
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + rest
+
+
+def launch_ranks(args, argv):
+    """`python bench.py --gpus N` by itself: N RCCL ranks as a CHILD process (never exec: nothing of this process has touched
+    the GPU, and nothing will -- torch.cuda.device_count() does not initialise it on this image), the child's stdout (rank
+    0's JSON line) and stderr inherited, its return code ours.  Fewer visible devices than ranks is an ERROR, not a smaller
+    run: a 1-rank line must never be recorded as an N-GPU point (HGS_BENCH_SHARE_GPU=1, the logic check that puts every rank
+    on cuda:0 over gloo, is the one exception and says so in its line)."""
+    import subprocess
+    cmd = launcher_command(args, argv)
+    if args.dry_launch:
+        print(json.dumps({"launcher": cmd, "gpus": args.gpus}))
+        return 0
+    import torch
+    have = torch.cuda.device_count()
+    if have < args.gpus and os.environ.get("HGS_BENCH_SHARE_GPU") != "1":
+        print(f"bench.py: --gpus {args.gpus} needs {args.gpus} visible GPUs, this node shows {have} "
+              "(no line printed: a smaller run is not an N-GPU measurement)", file=sys.stderr)
+        return 2
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // args.gpus)))
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     args = parse()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and (args.gpus > 1 or args.dry_launch):
+        sys.exit(launch_ranks(args, sys.argv[1:]))
+    if int(os.environ.get("WORLD_SIZE", "1")) != args.gpus:
+        # (a torchrun world that is not the one asked for: refuse, or `n_gpus` of the line would contradict the command)
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={os.environ.get('WORLD_SIZE')}", file=sys.stderr)
+        sys.exit(2)
     c3_leg = None
     if (int(os.environ.get("WORLD_SIZE", "1")) == 1 and args.workload == "north_star" and not args.no_c3_leg
             and not args.no_kernel_timing and not args.eager and not args.blocking
@@ -264,11 +313,18 @@ def main():
         local_rank = 0
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if not share and torch.cuda.device_count() < world:
+            print(f"bench.py: {world} ranks but {torch.cuda.device_count()} visible GPUs", file=sys.stderr)
+            sys.exit(2)
         torch.cuda.set_device(local_rank)
         if share:
             dist.init_process_group(backend="gloo")
         else:
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if dist.get_world_size() != args.gpus or (not share and dist.get_backend() != "nccl"):
+            print(f"bench.py: process group has {dist.get_world_size()} ranks over {dist.get_backend()}, "
+                  f"--gpus {args.gpus} over nccl (RCCL) was asked for", file=sys.stderr)
+            sys.exit(2)
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
 
@@ -592,6 +648,7 @@ def main():
         "sustained": sustained,
         "sustained_iters_per_sec": None if sustained is None else sustained["iters_per_sec"],
         "n_ranks_seen": dist.get_world_size() if world > 1 else 1,
+        "ranks_share_one_gpu": share if world > 1 else None,    # True: HGS_BENCH_SHARE_GPU=1, a logic check -- not a measurement
         "collective_backend": (dist.get_backend() + (" (RCCL)" if dist.get_backend() == "nccl" else "")) if world > 1 else None,
         # True: the gradient all-reduce and Adam are nodes of the step's HIP graph (several optimizer steps per launch work
         # across ranks); False with several ranks: the eager exchange behind the graph (gloo, or the capture probe failed)

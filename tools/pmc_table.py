@@ -1,4 +1,10 @@
-"""Per-kernel table of the counters collected by tools/pmc_generic.sh: python tools/pmc_table.py <tag> <kernel substring>..."""
+"""Per-kernel table of the counters collected by tools/pmc_generic.sh: python tools/pmc_table.py <tag> <kernel substring>...
+
+HBM bytes: FETCH_SIZE tallies every memory-side read request at 64 bytes -- a 64-byte request (dword-per-lane reads of 8x8
+quadrants of planar images, 64-byte gathers) in full, a 128-byte request (>= 256 contiguous bytes per wave instruction, 16 B per
+lane streams) at HALF (profiles/r04_fetch_shape_probe.txt).  The table cannot know a kernel's mix of the two, so it prints the
+bracket [FETCH + WRITE, 2 FETCH + WRITE]; bench.py's `traffic` resolves the blend backward's mix from its access shapes
+(planes 1:1, record batches doubled).  Rounds 1-4 printed the upper end only, which overstates every kernel with 64-byte gathers."""
 import csv, glob, collections, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag, keys = sys.argv[1], sys.argv[2:]
@@ -23,9 +29,9 @@ for k in keys:
         g(n) / g("SQ_WAVES") for n in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_SMEM", "SQ_INSTS_LDS", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR")))
     print("   wave-cycle fractions: wait_any %.2f wait_inst_any %.2f active_any %.2f wait_inst_lds %.2f" % (
         g("SQ_WAIT_ANY") / wc, g("SQ_WAIT_INST_ANY") / wc, g("SQ_ACTIVE_INST_ANY") / wc, g("SQ_WAIT_INST_LDS") / wc))
-    print("   lane util %.2f  lds bank conflict cycles %.0f / lds active %.0f  HBM MB %.1f" % (
+    print("   lane util %.2f  lds bank conflict cycles %.0f / lds active %.0f  HBM MB %.1f .. %.1f (all 64-B .. all 128-B read requests)" % (
         g("SQ_THREAD_CYCLES_VALU") / max(1.0, g("SQ_ACTIVE_INST_VALU") * 64), g("SQ_LDS_BANK_CONFLICT"), g("SQ_ACTIVE_INST_LDS"),
-        (2 * g("FETCH_SIZE") + g("WRITE_SIZE")) / 1024))
+        (g("FETCH_SIZE") + g("WRITE_SIZE")) / 1024, (2 * g("FETCH_SIZE") + g("WRITE_SIZE")) / 1024))
     print("   mean resident waves/CU %.1f   VALU pipe util %.2f" % (
         g("SQ_WAVE_CYCLES") * 4 / max(1.0, g("GRBM_GUI_ACTIVE") / 8 * 256),
         g("SQ_INSTS_VALU") * 4 / max(1.0, g("GRBM_GUI_ACTIVE") / 8 * 1024)))
