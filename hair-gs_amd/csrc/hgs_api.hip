@@ -338,15 +338,17 @@ static int backward_impl(void* stream, int P, int D, int M, int R, int W, int H,
                          const void* geom_buf, const void* binning_buf, const void* image_buf,
                          const float* const* dL_dpix_planes, void* scratch, int n_extra, float* dL_dextra, float* dL_dmeans2D, float* dL_dconic,
                          float* dL_dopacity, float* dL_dcolors, float* dL_dmeans3D, float* dL_dcov3D, float* dL_dsh,
-                         float* dL_dscales, float* dL_drotations) {
+                         float* dL_dscales, float* dL_drotations, const HgsParamBackward* pb = nullptr) {
   hipStream_t s = (hipStream_t)stream;
   if (P == 0) return 0;  // rasterize_points.cu:161
   if (check_aligned(geom_buf, "geom_buf") || check_aligned(image_buf, "image_buf")) return 1;
-  if (!dL_dpix_planes || !radii || !means3D) { hgs_set_error("null required input"); return 1; }
+  // (viewmatrix / projmatrix / campos are read at kernel entry whatever the colour source: required, include/hgs.h)
+  if (!dL_dpix_planes || !radii || !means3D || !viewmatrix || !projmatrix || !campos) { hgs_set_error("null required input"); return 1; }
   for (int k = 0; k < 3 + n_extra; k++)
     if (!dL_dpix_planes[k]) { hgs_set_error("null dL_dpix plane %d", k); return 1; }
-  if (!dL_dmeans2D || !dL_dconic || !dL_dopacity || !dL_dcolors || !dL_dmeans3D || !dL_dcov3D || !dL_dscales ||
-      !dL_drotations || (shs && !dL_dsh) || (n_extra && !dL_dextra)) { hgs_set_error("null gradient output"); return 1; }
+  if (!pb && (!dL_dmeans2D || !dL_dconic || !dL_dopacity || !dL_dcolors || !dL_dmeans3D || !dL_dcov3D || !dL_dscales ||
+              !dL_drotations || (n_extra && !dL_dextra))) { hgs_set_error("null gradient output"); return 1; }
+  if (shs && !dL_dsh) { hgs_set_error("null gradient output"); return 1; }
   const int channels = 3 + n_extra;
   HgsGeom g;
   HgsImage im;
@@ -369,7 +371,37 @@ static int backward_impl(void* stream, int P, int D, int M, int R, int W, int H,
   a.dL_dmeans3D = dL_dmeans3D; a.dL_dcov3D = dL_dcov3D; a.dL_dsh = dL_dsh; a.dL_dscales = dL_dscales;
   a.dL_drotations = dL_drotations;
   a.n_extra = n_extra; a.dL_dextra = dL_dextra;
-  return hgs_launch_preprocess_bwd(s, a, g, b, inst_grad, R, im.status);
+  return hgs_launch_preprocess_bwd(s, a, g, b, inst_grad, R, im.status, pb);
+}
+
+size_t hgs_param_backward_bytes(void) { return sizeof(HgsParamBackward); }
+int hgs_backward_multi_params(void* stream, int P, int D, int M, int R, int W, int H, const float* bg7, const float* means3D,
+                              const float* shs, const float* scales, const float* rotations, const float* viewmatrix,
+                              const float* projmatrix, const float* campos, float tan_fovx, float tan_fovy, const int* radii,
+                              const void* geom_buf, const void* binning_buf, const void* image_buf,
+                              const float* const* dL_dpix_planes7, void* scratch, float* dL_dsh, const HgsParamBackward* pb) {
+  if (!pb || (pb->kind != HGS_PARAMS_HAIR && pb->kind != HGS_PARAMS_CLOUD)) { hgs_set_error("hgs_backward_multi_params: params->kind must be HGS_PARAMS_HAIR or HGS_PARAMS_CLOUD"); return 1; }
+  if (P == 0 && pb->head_tail.out) { hgs_set_error("hgs_backward_multi_params: a deferred loss-head tail needs a launch (P > 0)"); return 1; }
+  if (P == 0) return 0;
+  if (!shs || !scales || !rotations || !dL_dsh) { hgs_set_error("hgs_backward_multi_params: SH colours and (scales, rotations) are required"); return 1; }
+  if (!pb->extra4 || !pb->d_opacity_raw || !pb->d_mask_raw || ((size_t)pb->extra4 & 15)) { hgs_set_error("hgs_backward_multi_params: null (or, extra4, unaligned) argument in params"); return 1; }
+  if ((pb->max_radii2D || pb->grad_accum || pb->denom) && !(pb->max_radii2D && pb->grad_accum && pb->denom)) {
+    hgs_set_error("hgs_backward_multi_params: incomplete statistics group");
+    return 1;
+  }
+  if (pb->kind == HGS_PARAMS_HAIR) {
+    if (!pb->endpoints || !pb->endpoint_pairs || !pb->seg_contrib || !pb->d_width || ((size_t)pb->seg_contrib & 15)) {
+      hgs_set_error("hgs_backward_multi_params: null (or, seg_contrib, unaligned) hair argument"); return 1;
+    }
+    if (pb->head_tail.out) { hgs_set_error("hgs_backward_multi_params: the strand model's deferred tail rides in hgs_hair_endpoint_gather"); return 1; }
+  } else if (!pb->rotation_raw || !pb->d_means3D || !pb->d_scaling_raw || !pb->d_rotation_raw || ((size_t)pb->rotation_raw & 15) ||
+             ((size_t)pb->d_rotation_raw & 15)) {
+    hgs_set_error("hgs_backward_multi_params: null (or, rotation_raw / d_rotation_raw, unaligned) cloud argument"); return 1;
+  }
+  HgsParamBackward p = *pb;
+  return backward_impl(stream, P, D, M, R, W, H, bg7, means3D, shs, nullptr, scales, 1.f, rotations, nullptr, viewmatrix,
+                       projmatrix, campos, tan_fovx, tan_fovy, radii, geom_buf, binning_buf, image_buf, dL_dpix_planes7, scratch,
+                       4, nullptr, p.dL_dmeans2D_rgb, nullptr, nullptr, nullptr, nullptr, nullptr, dL_dsh, nullptr, nullptr, &p);
 }
 
 int hgs_backward(void* stream, int P, int D, int M, int R, int W, int H, const float* bg, const float* means3D,

@@ -295,7 +295,7 @@ struct HgsBwdArgs {
   float* dL_dextra;    // [P, n_extra]
 };
 int hgs_launch_preprocess_bwd(hipStream_t s, const HgsBwdArgs& a, const HgsGeom& g, const HgsBinning& b,
-                              const float* inst_grad, int Rcap, const uint32_t* status);
+                              const float* inst_grad, int Rcap, const uint32_t* status, const HgsParamBackward* pb = nullptr);
 int hgs_launch_mark_visible(hipStream_t s, int P, const float* means3D, const float* viewmatrix, uint8_t* present);
 int hgs_launch_dist2(hipStream_t s, int P, const float* points, float* out, void* scratch, size_t scratch_bytes);
 size_t hgs_dist2_scratch(int P);

@@ -14,6 +14,7 @@
 #include "hgs_smooth.h"
 #include "hgs_prologue.h"
 #include "hgs_strand_fwd.h"
+#include "hgs_strand_bwd.h"
 
 namespace {
 
@@ -699,16 +700,33 @@ __device__ __forceinline__ V3 dnormvdv(V3 v, V3 dv) {  // auxiliary.h:107-117
 
 // DC_ONLY: the strand / Stage-I default -- SH degree 0 with one stored coefficient (or precomputed colours): the
 // view-dependent SH code is compiled out (136 -> fewer registers for a kernel that lives on its occupancy).
-template <bool DC_ONLY>
+// MODE (round 5, the backward mirror of hair_preprocess_fwd_kernel / cloud_preprocess_fwd_kernel): the lane that has just
+// finished Gaussian k's gradients holds everything the parameters' backward needs of it in registers.
+//   MODE 0  the rasterizer's own outputs (nine gradient tensors, hgs_backward / hgs_backward_multi);
+//   MODE 1  strand model (hgs_backward_multi_params, HGS_PARAMS_HAIR): the segment's geometry backward is applied HERE, once --
+//           two endpoint contributions (h - gD, h + gD; hgs_strand_bwd.h), d_width, d_opacity_raw, d_mask_raw, dL_dsh and the
+//           densification statistics leave the lane instead of 124 bytes of per-Gaussian gradients that strand_bwd_kernel's
+//           segment lane and both of its endpoint lanes would read again; what remains of that kernel is the endpoint gather
+//           (hgs_hair_endpoint_gather: two 16-byte loads per endpoint);
+//   MODE 2  Stage-I cloud (HGS_PARAMS_CLOUD): raw scaling / rotation / opacity / mask gradients and the statistics from the same
+//           lane -- cloud_bwd_kernel's launch is gone; the loss head's deferred tail rides in one spare workgroup here.
+// The parameter arithmetic is the shared device code of hgs_strand_bwd.h, evaluated without contraction in both translation
+// units: the fused backward's results are the two-launch form's bit for bit (tests/test_gpu_train.py).
+template <bool DC_ONLY, int MODE>
 // (five waves per SIMD: 87 VGPRs; at six the compiler spills six registers and the kernel takes 11.7 instead of 8.9 us)
 #ifndef HGS_PPB_WAVES
 #define HGS_PPB_WAVES 5
 #endif
-__global__ __launch_bounds__(HGS_BLOCK) __attribute__((amdgpu_waves_per_eu(HGS_PPB_WAVES))) void preprocess_bwd_kernel(HgsBwdArgs a, HgsGeom g, HgsBinning b,
+// (MODE 1 / 2 with view-dependent SH: 116 VGPRs, four waves per SIMD; the DC-only forms fit five: 88 / 86)
+__global__ __launch_bounds__(HGS_BLOCK) __attribute__((amdgpu_waves_per_eu((MODE == 0 || DC_ONLY) ? HGS_PPB_WAVES : HGS_PPB_WAVES - 1))) void preprocess_bwd_kernel(HgsBwdArgs a, HgsGeom g, HgsBinning b,
                                                                    const float* __restrict__ inst_grad, uint32_t Rcap,
-                                                                   const uint32_t* __restrict__ status) {
+                                                                   const uint32_t* __restrict__ status, HgsParamBackward pb) {
   const int idx = blockIdx.x * HGS_BLOCK + threadIdx.x;
-  if (idx >= a.P) return;
+  if (idx >= a.P) {
+    // (the loss head's deferred tail: the spare workgroup behind the launch's own, all of whose lanes are past P)
+    if (MODE != 0 && pb.head_tail.out && blockIdx.x == gridDim.x - 1) hgs_head_tail_block(pb.head_tail);
+    return;
+  }
   const int D = DC_ONLY ? 0 : a.D;
   // A forward that overflowed its binning capacity (status[1]) dropped instances: their rows of the scratch were never
   // written.  Such a pass is void; its backward returns EXACTLY ZERO for every gradient (deterministic, finite) and the
@@ -739,16 +757,29 @@ __global__ __launch_bounds__(HGS_BLOCK) __attribute__((amdgpu_waves_per_eu(HGS_P
   // (round 4) likewise the wave-uniform matrices and the clamp flags: read where they are used -- behind the row loop, behind
   // the zero-gradient stores of the lanes that are not visible -- they were three more exposed round trips (vector loads: the
   // compiler cannot prove them unwritten there); at entry they are scalar loads
+  // (read through the constant address space: wave-uniform and unwritten during the launch, so always scalar loads into
+  // SGPRs -- with the loss head's tail among the kernel's code the compiler no longer proves that by itself and the 35 values
+  // take VGPRs: 114 instead of 88)
+  typedef const __attribute__((address_space(4))) float* ConstF;
+  const ConstF vm_c = (ConstF)(uintptr_t)a.viewmatrix, pj_c = (ConstF)(uintptr_t)a.projmatrix, cam_c = (ConstF)(uintptr_t)a.campos;
   float Vm_pre[16], pj_pre[16], cam_pre[3];
 #pragma unroll
-  for (int k = 0; k < 16; k++) { Vm_pre[k] = a.viewmatrix[k]; pj_pre[k] = a.projmatrix[k]; }
+  for (int k = 0; k < 16; k++) { Vm_pre[k] = vm_c[k]; pj_pre[k] = pj_c[k]; }
 #pragma unroll
-  for (int k = 0; k < 3; k++) cam_pre[k] = a.campos[k];
+  for (int k = 0; k < 3; k++) cam_pre[k] = cam_c[k];
   bool clamped_pre[3] = {false, false, false};
   if (a.shs) {
 #pragma unroll
     for (int ch = 0; ch < 3; ch++) clamped_pre[ch] = g.clamped[3 * (size_t)idx + ch] != 0;
   }
+  // (MODE 1 / 2: the parameter side's own inputs, none of which depends on the rows below)
+  HgsSegGeom seg_pre = {0.f, 0.f, 0.f};
+  float4 raw_rot_pre = make_float4(1.f, 0.f, 0.f, 0.f);
+  float mask_pre = 0.f;
+  const int radius_pre = a.radii[idx];
+  if (MODE == 1) seg_pre = hgs_segment_geom(idx, pb.endpoints, pb.endpoint_pairs);
+  if (MODE == 2) raw_rot_pre = ((const float4*)pb.rotation_raw)[idx];
+  if (MODE != 0) mask_pre = pb.extra4[4 * (size_t)idx];
   if (vis) {
     // ---- deterministic gather of this Gaussian's per-instance partial sums (instance order = tile rect order)
     const HgsRect rc = rc_pre;
@@ -974,18 +1005,53 @@ __global__ __launch_bounds__(HGS_BLOCK) __attribute__((amdgpu_waves_per_eu(HGS_P
   // every output is written (zeros for culled Gaussians): no separate zero-fill pass
   // returned screen-space gradient: in the single-pass mode the RGB channels' share only (what the reference's
   // densification statistics read from the RGB pass); dL_dmeans3D above used the total
-  a.dL_dmeans2D[3 * idx] = a.n_extra ? dmx_rgb : dmx;
-  a.dL_dmeans2D[3 * idx + 1] = a.n_extra ? dmy_rgb : dmy;
-  a.dL_dmeans2D[3 * idx + 2] = 0.f;
-  if (a.n_extra) ((float4*)a.dL_dextra)[idx] = make_float4(dex[0], dex[1], dex[2], dex[3]);
-  ((float4*)a.dL_dconic)[idx] = make_float4(dcx, dcy, 0.f, dcw);
-  a.dL_dopacity[idx] = dop;
-  a.dL_dcolors[3 * idx] = dcol[0]; a.dL_dcolors[3 * idx + 1] = dcol[1]; a.dL_dcolors[3 * idx + 2] = dcol[2];
-  a.dL_dmeans3D[3 * idx] = dmean[0]; a.dL_dmeans3D[3 * idx + 1] = dmean[1]; a.dL_dmeans3D[3 * idx + 2] = dmean[2];
+  const float gm2x = a.n_extra ? dmx_rgb : dmx, gm2y = a.n_extra ? dmy_rgb : dmy;
+  if (MODE == 0) {
+    a.dL_dmeans2D[3 * idx] = gm2x;
+    a.dL_dmeans2D[3 * idx + 1] = gm2y;
+    a.dL_dmeans2D[3 * idx + 2] = 0.f;
+    if (a.n_extra) ((float4*)a.dL_dextra)[idx] = make_float4(dex[0], dex[1], dex[2], dex[3]);
+    ((float4*)a.dL_dconic)[idx] = make_float4(dcx, dcy, 0.f, dcw);
+    a.dL_dopacity[idx] = dop;
+    a.dL_dcolors[3 * idx] = dcol[0]; a.dL_dcolors[3 * idx + 1] = dcol[1]; a.dL_dcolors[3 * idx + 2] = dcol[2];
+    a.dL_dmeans3D[3 * idx] = dmean[0]; a.dL_dmeans3D[3 * idx + 1] = dmean[1]; a.dL_dmeans3D[3 * idx + 2] = dmean[2];
 #pragma unroll
-  for (int k = 0; k < 6; k++) a.dL_dcov3D[6 * (size_t)idx + k] = dcov[k];
-  a.dL_dscales[3 * idx] = dscale[0]; a.dL_dscales[3 * idx + 1] = dscale[1]; a.dL_dscales[3 * idx + 2] = dscale[2];
-  ((float4*)a.dL_drotations)[idx] = make_float4(drot[0], drot[1], drot[2], drot[3]);
+    for (int k = 0; k < 6; k++) a.dL_dcov3D[6 * (size_t)idx + k] = dcov[k];
+    a.dL_dscales[3 * idx] = dscale[0]; a.dL_dscales[3 * idx + 1] = dscale[1]; a.dL_dscales[3 * idx + 2] = dscale[2];
+    ((float4*)a.dL_drotations)[idx] = make_float4(drot[0], drot[1], drot[2], drot[3]);
+    return;
+  }
+  // ---- MODE 1 / 2: the parameters' backward of this Gaussian, from registers (see the kernel's header)
+  if (a.dL_dmeans2D) { a.dL_dmeans2D[3 * idx] = gm2x; a.dL_dmeans2D[3 * idx + 1] = gm2y; a.dL_dmeans2D[3 * idx + 2] = 0.f; }
+  if (pb.max_radii2D) hgs_densify_stats_lane(idx, radius_pre, gm2x, gm2y, pb.max_radii2D, pb.grad_accum, pb.denom);
+  // (the forward's opacity, conic_opacity.w, exists for visible Gaussians only; an invisible one has dop = 0)
+  const float o_act = vis ? co_pre.w : 0.f;
+  if (MODE == 1) {
+    HgsSegGradVals gv;
+    gv.gx[0] = dmean[0]; gv.gx[1] = dmean[1]; gv.gx[2] = dmean[2];
+    gv.gs0 = dscale[0];
+    gv.gq = make_float4(drot[0], drot[1], drot[2], drot[3]);
+    gv.gd[0] = gv.gd[1] = gv.gd[2] = 0.f;
+    gv.ge = make_float4(dex[0], dex[1], dex[2], dex[3]);
+    gv.has_quat = true; gv.has_extra = true; gv.has_scale = true;
+    float h[3], gD[3];
+    hgs_segment_endpoint_grads_v(seg_pre, pb.dist_to_scale_factor, gv, h, gD);
+    float4* sc = (float4*)pb.seg_contrib + 2 * (size_t)idx;
+    sc[0] = make_float4(h[0] - gD[0], h[1] - gD[1], h[2] - gD[2], 0.f);
+    sc[1] = make_float4(h[0] + gD[0], h[1] + gD[1], h[2] + gD[2], 0.f);
+    pb.d_width[idx] = (dscale[1] + dscale[2]) * s_pre[1];            // scale.y = exp(width): the forward's own value
+    pb.d_opacity_raw[idx] = dop * o_act * (1.f - o_act);             // sigmoid'
+    pb.d_mask_raw[idx] = dex[0] * mask_pre * (1.f - mask_pre);
+  } else {
+    const HgsCloudParamGrads cg = hgs_cloud_param_grads(s_pre[0], s_pre[1], s_pre[2], raw_rot_pre, o_act, mask_pre, dscale,
+                                                        make_float4(drot[0], drot[1], drot[2], drot[3]), dop,
+                                                        make_float4(dex[0], dex[1], dex[2], dex[3]));
+    pb.d_means3D[3 * idx] = dmean[0]; pb.d_means3D[3 * idx + 1] = dmean[1]; pb.d_means3D[3 * idx + 2] = dmean[2];
+    pb.d_scaling_raw[3 * idx] = cg.d_s[0]; pb.d_scaling_raw[3 * idx + 1] = cg.d_s[1]; pb.d_scaling_raw[3 * idx + 2] = cg.d_s[2];
+    ((float4*)pb.d_rotation_raw)[idx] = cg.d_r;
+    pb.d_opacity_raw[idx] = cg.d_o;
+    pb.d_mask_raw[idx] = cg.d_m;
+  }
 }
 
 __global__ __launch_bounds__(HGS_BLOCK) void mark_visible_kernel(int P, const float* means3D, const float* V, uint8_t* present) {
@@ -1062,14 +1128,19 @@ int hgs_launch_scatter(hipStream_t s, int P, int W, int H, int Rcap, const float
   return 0;
 }
 int hgs_launch_preprocess_bwd(hipStream_t s, const HgsBwdArgs& a, const HgsGeom& g, const HgsBinning& b,
-                              const float* inst_grad, int Rcap, const uint32_t* status) {
-  const int nblk = (a.P + HGS_BLOCK - 1) / HGS_BLOCK;
+                              const float* inst_grad, int Rcap, const uint32_t* status, const HgsParamBackward* pb) {
+  const int mode = pb ? pb->kind : 0;
+  const HgsParamBackward p = pb ? *pb : HgsParamBackward{};
+  // (the loss head's deferred tail, MODE 1 / 2: one spare workgroup behind the launch's own)
+  const int nblk = (a.P + HGS_BLOCK - 1) / HGS_BLOCK + ((mode != 0 && p.head_tail.out) ? 1 : 0);
+  const bool dc = !a.shs || (a.D == 0 && a.M == 1);
   {
     HgsProfScope _prof(s, HGS_K_PREPROCESS_BWD);
-    if (!a.shs || (a.D == 0 && a.M == 1))
-      hipLaunchKernelGGL(preprocess_bwd_kernel<true>, dim3(nblk), dim3(HGS_BLOCK), 0, s, a, g, b, inst_grad, (uint32_t)Rcap, status);
-    else
-      hipLaunchKernelGGL(preprocess_bwd_kernel<false>, dim3(nblk), dim3(HGS_BLOCK), 0, s, a, g, b, inst_grad, (uint32_t)Rcap, status);
+#define HGS_PPB_LAUNCH(DC, MODE) hipLaunchKernelGGL((preprocess_bwd_kernel<DC, MODE>), dim3(nblk), dim3(HGS_BLOCK), 0, s, a, g, b, inst_grad, (uint32_t)Rcap, status, p)
+    if (mode == 0) { if (dc) HGS_PPB_LAUNCH(true, 0); else HGS_PPB_LAUNCH(false, 0); }
+    else if (mode == HGS_PARAMS_HAIR) { if (dc) HGS_PPB_LAUNCH(true, 1); else HGS_PPB_LAUNCH(false, 1); }
+    else { if (dc) HGS_PPB_LAUNCH(true, 2); else HGS_PPB_LAUNCH(false, 2); }
+#undef HGS_PPB_LAUNCH
   }
   HGS_CHECK_LAUNCH();
   return 0;

@@ -88,41 +88,18 @@ __global__ __launch_bounds__(256) void cloud_bwd_kernel(int P, const float* __re
   if (fu.head_tail.out && blockIdx.x == gridDim.x - 1) { hgs_head_tail_block(fu.head_tail); return; }   // (as strand_bwd_kernel)
   const int k = blockIdx.x * 256 + threadIdx.x;
   if (k >= P) return;
-  if (fu.radii) {                    // densification statistics of this Gaussian (hgs_densify_stats)
-    const int rr = fu.radii[k];
-    if (rr > 0) {
-      fu.max_radii2D[k] = fmaxf(fu.max_radii2D[k], (float)rr);
-      const float gx = fu.dmean2D[(size_t)k * fu.dmean2D_stride], gy = fu.dmean2D[(size_t)k * fu.dmean2D_stride + 1];
-      fu.grad_accum[k] += sqrtf(gx * gx + gy * gy);
-      fu.denom[k] += 1.f;
-    }
-  }
-  const float s0 = expf(s_raw[3 * (size_t)k]), s1 = expf(s_raw[3 * (size_t)k + 1]), s2 = expf(s_raw[3 * (size_t)k + 2]);
-  d_s[3 * (size_t)k] = g_scale[3 * (size_t)k] * s0;
-  d_s[3 * (size_t)k + 1] = g_scale[3 * (size_t)k + 1] * s1;
-  d_s[3 * (size_t)k + 2] = g_scale[3 * (size_t)k + 2] * s2;
-  const float4 ge = ((const float4*)g_extra4)[k];
-  { const float o = opacity[k]; d_o[k] = g_opacity[k] * o * (1.f - o); }
-  { const float m = extra4[4 * (size_t)k]; d_m[k] = ge.x * m * (1.f - m); }
-  const float4 r = ((const float4*)r_raw)[k];
-  const float n = sqrtf(r.x * r.x + r.y * r.y + r.z * r.z + r.w * r.w);
-  const float in = 1.f / n;
-  const float w = r.x * in, x = r.y * in, y = r.z * in, z = r.w * in;
-  // dL/dq (q = unit quaternion) = the rasterizer's gradient of `quat` + J^T of the direction column
-  const float4 gq = ((const float4*)g_quat)[k];
-  float qw = gq.x, qx = gq.y, qy = gq.z, qz = gq.w;
-  if (!(n > 1e-12f)) { qw = 0.f; qx = 0.f; qy = 0.f; qz = 0.f; }           // clamped branch of F.normalize: q = r / 1e-12
-  const int ax = hgs_argmax3(s0, s1, s2);
-  const float a = ge.y, b = ge.z, c = ge.w;                                // dL/d(direction)
-  if (ax == 0) {        // (1-2(y^2+z^2), 2(xy+wz), 2(xz-wy))
-    qw += 2.f * (b * z - c * y); qx += 2.f * (b * y + c * z); qy += 2.f * (-2.f * a * y + b * x - c * w); qz += 2.f * (-2.f * a * z + b * w + c * x);
-  } else if (ax == 1) { // (2(xy-wz), 1-2(x^2+z^2), 2(yz+wx))
-    qw += 2.f * (-a * z + c * x); qx += 2.f * (a * y - 2.f * b * x + c * w); qy += 2.f * (a * x + c * z); qz += 2.f * (-a * w - 2.f * b * z + c * y);
-  } else {              // (2(xz+wy), 2(yz-wx), 1-2(x^2+y^2))
-    qw += 2.f * (a * y - b * x); qx += 2.f * (a * z - b * w - 2.f * c * x); qy += 2.f * (a * w + b * z - 2.f * c * y); qz += 2.f * (a * x + b * y);
-  }
-  const float dot = w * qw + x * qx + y * qy + z * qz;                     // through r -> r / |r|
-  ((float4*)d_r)[k] = make_float4((qw - w * dot) * in, (qx - x * dot) * in, (qy - y * dot) * in, (qz - z * dot) * in);
+  if (fu.radii)                      // densification statistics of this Gaussian (hgs_densify_stats)
+    hgs_densify_stats_lane(k, fu.radii[k], fu.dmean2D[(size_t)k * fu.dmean2D_stride], fu.dmean2D[(size_t)k * fu.dmean2D_stride + 1],
+                           fu.max_radii2D, fu.grad_accum, fu.denom);
+  // (the arithmetic: hgs_cloud_param_grads, hgs_strand_bwd.h -- shared with the rasterizer backward's cloud lanes)
+  const float gs[3] = {g_scale[3 * (size_t)k], g_scale[3 * (size_t)k + 1], g_scale[3 * (size_t)k + 2]};
+  const HgsCloudParamGrads o = hgs_cloud_param_grads(expf(s_raw[3 * (size_t)k]), expf(s_raw[3 * (size_t)k + 1]), expf(s_raw[3 * (size_t)k + 2]),
+                                                     ((const float4*)r_raw)[k], opacity[k], extra4[4 * (size_t)k], gs,
+                                                     ((const float4*)g_quat)[k], g_opacity[k], ((const float4*)g_extra4)[k]);
+  d_s[3 * (size_t)k] = o.d_s[0]; d_s[3 * (size_t)k + 1] = o.d_s[1]; d_s[3 * (size_t)k + 2] = o.d_s[2];
+  d_o[k] = o.d_o;
+  d_m[k] = o.d_m;
+  ((float4*)d_r)[k] = o.d_r;
 }
 
 }  // namespace
@@ -173,7 +150,7 @@ int hgs_strand_geometry_backward(void* stream, int P, int E, const float* endpoi
   {
     HgsProfScope _prof(s, HGS_K_STRAND_BWD);
     const HgsStrandBwdArgs A = {P, endpoints, endpoint_pairs, width, dist_to_scale_factor, g_xyz, g_scale, g_quat, g_dir,
-                                d_endpoints, d_width, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, HgsStrandFusion{}};
+                                d_endpoints, d_width, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, HgsStrandFusion{}, nullptr};
     hipLaunchKernelGGL(strand_bwd_kernel, dim3((P + 255) / 256), dim3(256), 0, s, A);
   }
   HGS_CHECK_LAUNCH();
@@ -234,8 +211,35 @@ int hgs_hair_params_backward(void* stream, int P, int E, const float* endpoints,
     HgsProfScope _prof(s, HGS_K_STRAND_BWD);
     const int extra = gather ? (E + 255) / 256 : (fu.n_smooth + 255) / 256;
     const HgsStrandBwdArgs A = {P, endpoints, endpoint_pairs, width, dist_to_scale_factor, g_xyz, g_scale, g_quat, g_dir,
-                                d_endpoints, d_width, opacity, extra4, g_opacity, g_extra4, d_opacity_raw, d_mask_raw, fu};
+                                d_endpoints, d_width, opacity, extra4, g_opacity, g_extra4, d_opacity_raw, d_mask_raw, fu, nullptr};
     hipLaunchKernelGGL(strand_bwd_kernel, dim3((P + 255) / 256 + extra + (fu.head_tail.out ? 1 : 0)), dim3(256), 0, s, A);
+  }
+  HGS_CHECK_LAUNCH();
+  return 0;
+}
+
+int hgs_hair_endpoint_gather(void* stream, int E, const float* seg_contrib, const float* endpoints, float* d_endpoints,
+                             const HgsStrandFusion* fusion) {
+  if (!fusion || !fusion->ep_segments) { hgs_set_error("hgs_hair_endpoint_gather: HgsStrandFusion.ep_segments is required (gather mode)"); return 1; }
+  HgsStrandFusion fu = *fusion;
+  const bool smooth = fu.smooth_pairs && fu.n_smooth > 0 && fu.head_out && fu.grad_out && fu.ep_pairs;
+  if (!smooth) { fu.n_smooth = 0; fu.ep_pairs = nullptr; }
+  fu.n_endpoints = E;
+  fu.radii = nullptr;                                       // (the statistics belong to hgs_backward_multi_params)
+  if (E == 0 && !fu.head_tail.out) return 0;
+  if (E > 0 && (!seg_contrib || !endpoints || !d_endpoints || ((size_t)seg_contrib & 15))) {
+    hgs_set_error("hgs_hair_endpoint_gather: null (or, seg_contrib, unaligned) argument");
+    return 1;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  {
+    HgsProfScope _prof(s, HGS_K_STRAND_BWD);
+    // P = 0 per-segment workgroups: the launch is the endpoint lanes (+ the tail's workgroup)
+    static const float4 kNone = {0.f, 0.f, 0.f, 0.f};
+    const HgsStrandBwdArgs A = {0, endpoints, nullptr, nullptr, 0.f, nullptr, nullptr, nullptr, nullptr, d_endpoints, nullptr,
+                                nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, fu,
+                                E > 0 ? (const float4*)seg_contrib : &kNone};
+    hipLaunchKernelGGL(strand_bwd_kernel, dim3((E + 255) / 256 + (fu.head_tail.out ? 1 : 0)), dim3(256), 0, s, A);
   }
   HGS_CHECK_LAUNCH();
   return 0;

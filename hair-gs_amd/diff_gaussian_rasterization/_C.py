@@ -351,6 +351,32 @@ def rasterize_gaussians_multi_backward(background7, means3D, radii, colors, scal
     return dL_dmeans2D, dL_dcolors, dL_dextra, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations
 
 
+def rasterize_gaussians_multi_backward_params(background7, means3D, radii, scales, rotations, viewmatrix, projmatrix, tan_fovx,
+                                              tan_fovy, grad_planes, sh, degree, campos, geomBuffer, R, binningBuffer,
+                                              imageBuffer, params):
+    """hgs_backward_multi_params: the single-pass backward whose per-Gaussian launch also applies the parameters' backward
+    (`params`: a filled hgs_runtime.ParamBackward; its output tensors are the caller's).  Returns dL_dsh [P,M,3]."""
+    L = rt.lib()
+    means3D = rt.require_gpu_tensor(means3D, "means3D", torch.float32)
+    dev, P = means3D.device, means3D.shape[0]
+    H, W = int(grad_planes[0].shape[-2]), int(grad_planes[0].shape[-1])
+    M = sh.shape[1]
+    dL_dsh = (torch.empty if P > 0 else torch.zeros)((P, M, 3), dtype=torch.float32, device=dev)
+    scratch = _scratch(L.hgs_backward_scratch_bytes_multi(P, int(R)), dev)
+    planes = [rt.require_gpu_tensor(g, "grad plane", torch.float32) for g in grad_planes]
+    plane_ptrs = (C.c_void_p * 7)(*[g.data_ptr() for g in planes])
+    bg_, sh_, scales_, rots_ = _f32(background7, "bg"), _f32(sh, "sh"), _f32(scales, "scales"), _f32(rotations, "rotations")
+    view_, proj_, cam_ = _f32(viewmatrix, "viewmatrix"), _f32(projmatrix, "projmatrix"), _f32(campos, "campos")
+    radii_ = rt.require_gpu_tensor(radii, "radii", torch.int32)
+    with torch.cuda.device(dev):
+        rt.check(L.hgs_backward_multi_params(rt.current_stream(), P, int(degree), M, int(R), W, H, rt.ptr(bg_), rt.ptr(means3D),
+                                             rt.ptr(sh_), rt.ptr(scales_), rt.ptr(rots_), rt.ptr(view_), rt.ptr(proj_), rt.ptr(cam_),
+                                             float(tan_fovx), float(tan_fovy), rt.ptr(radii_), rt.ptr(geomBuffer),
+                                             rt.ptr(binningBuffer), rt.ptr(imageBuffer), plane_ptrs, rt.ptr(scratch),
+                                             rt.ptr(dL_dsh), C.byref(params)))
+    return dL_dsh
+
+
 def mark_visible(means3D, viewmatrix, projmatrix):
     """markVisible (rasterize_points.cu:198-217) -> bool[P]."""
     means3D = rt.require_gpu_tensor(means3D, "means3D", torch.float32)

@@ -33,6 +33,10 @@ SIGNATURES = {
     "hgs_forward_render_multi": (ci, [vp, ci, ci, ci, ci, vp, vp, vp, vp, vp, vp, vp]),
     "hgs_backward_multi": (ci, [vp, ci, ci, ci, ci, ci, ci, vp, vp, vp, vp, vp, cf, vp, vp, vp, vp, vp, cf, cf, vp, vp, vp,
                                 vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
+    "hgs_param_backward_bytes": (sz, []),
+    "hgs_backward_multi_params": (ci, [vp, ci, ci, ci, ci, ci, ci, vp, vp, vp, vp, vp, vp, vp, vp, cf, cf, vp, vp, vp, vp, vp, vp,
+                                       vp, vp]),
+    "hgs_hair_endpoint_gather": (ci, [vp, ci, vp, vp, vp, vp]),
     "hgs_mark_visible": (ci, [vp, ci, vp, vp, vp, vp]),
     "hgs_dist2_scratch_bytes": (sz, [ci]),
     "hgs_dist2": (ci, [vp, ci, vp, vp, vp, sz]),
@@ -132,13 +136,22 @@ class StrandFusion(C.Structure):
                 ("n_endpoints", ci), ("head_tail", HeadTail), ("prologue", Prologue)]
 
 
+class ParamBackward(C.Structure):
+    """include/hgs.h HgsParamBackward."""
+    _fields_ = [("kind", ci), ("endpoints", vp), ("endpoint_pairs", vp), ("dist_to_scale_factor", cf), ("seg_contrib", vp),
+                ("d_width", vp), ("rotation_raw", vp), ("d_means3D", vp), ("d_scaling_raw", vp), ("d_rotation_raw", vp),
+                ("extra4", vp), ("d_opacity_raw", vp), ("d_mask_raw", vp), ("dL_dmeans2D_rgb", vp), ("max_radii2D", vp),
+                ("grad_accum", vp), ("denom", vp), ("head_tail", HeadTail)]
+
+
+PARAMS_HAIR, PARAMS_CLOUD = 1, 2
 HEAD_SKIP_PIXELS, HEAD_SKIP_SMOOTH = 1, 2
 VIEW_QUEUE_MAX = 16   # include/hgs.h HGS_VIEW_QUEUE_MAX
 HEAD_OUT = ["total", "l1", "dssim", "mask", "orientation", "smooth", "ori_count", "smooth_count", "g_ssim", "g_l1", "g_mask",
             "g_ori", "g_smooth", "total_fwd"]
 HEAD_NOUT = 16
 FUSED_PREPROCESS_MAX_TILES = 8192   # include/hgs.h HGS_FUSED_PREPROCESS_MAX_TILES
-ABI_VERSION = 4   # include/hgs.h HGS_ABI_VERSION: bumped whenever a struct, a signature or a buffer layout changes
+ABI_VERSION = 5   # include/hgs.h HGS_ABI_VERSION: bumped whenever a struct, a signature or a buffer layout changes
 
 
 def build(verbose=False):
@@ -169,7 +182,7 @@ def lib():
             raise HgsError(f"{LIB_PATH}: ABI version {L.hgs_abi_version()}, this binding needs {ABI_VERSION}: "
                            "rebuild with hgs_runtime.build()")
         for fn, st in (("hgs_view_targets_bytes", ViewTargets), ("hgs_head_params_bytes", HeadParams),
-                       ("hgs_strand_fusion_bytes", StrandFusion)):
+                       ("hgs_strand_fusion_bytes", StrandFusion), ("hgs_param_backward_bytes", ParamBackward)):
             if getattr(L, fn)() != C.sizeof(st):
                 raise HgsError(f"{LIB_PATH}: {fn}() = {getattr(L, fn)()} but the binding's struct has {C.sizeof(st)} bytes: "
                                "rebuild with hgs_runtime.build()")

@@ -309,7 +309,7 @@ def _raster_head_forward(step, xyz, scale, quat, opacity, extra4, shs, endpoints
 
 
 def _head_raster_backward(ctx, step, go, xyz, scale, quat, shs, planes, radii, geom, binning, img, scratch, out, endpoints,
-                          d_ep, n_endpoints):
+                          d_ep, n_endpoints, params=None):
     """Loss-head backward + single-pass rasterizer backward; returns (grad_out tensor, rasterizer gradients)."""
     from diff_gaussian_rasterization import _C as raster
     g, vt, hp, L = step.gaussians, step.views, step.head, rt.lib()
@@ -336,11 +336,29 @@ def _head_raster_backward(ctx, step, go, xyz, scale, quat, shs, planes, radii, g
                                           (rt.HEAD_SKIP_PIXELS if unit else 0) | (rt.HEAD_SKIP_SMOOTH if ctx.fused_smooth else 0),
                                           d_image.data_ptr(), d_extra[0].data_ptr(), d_extra[1:4].data_ptr(), rt.ptr(d_ep)))
     grad_planes = [d_image[k] for k in range(3)] + [d_extra[k] for k in range(4)]
+    if params is not None:
+        # the backward mirror of the one-launch forward (include/hgs.h hgs_backward_multi_params): the rasterizer's per-Gaussian
+        # gradients never leave the lane that computed them
+        g_means2D = torch.empty((xyz.shape[0], 3), **f32)
+        params.dL_dmeans2D_rgb = rt.ptr(g_means2D)
+        g_sh = raster.rasterize_gaussians_multi_backward_params(
+            step.bg7_backward, xyz, radii, scale, quat, vt.viewmatrix, vt.projmatrix, vt.tanfovx, vt.tanfovy, grad_planes, shs,
+            g.active_sh_degree, vt.campos, geom, ctx.R, binning, img, params)
+        return go, (g_means2D, None, None, None, g_sh, None, None)
     empty = step.empty
     (g_means2D, _gc, g_ex, g_opac, g_means3D, _gcov, g_sh, g_scales, g_rot) = raster.rasterize_gaussians_multi_backward(
         step.bg7_backward, xyz, radii, empty, scale, quat, 1.0, empty, vt.viewmatrix, vt.projmatrix, vt.tanfovx, vt.tanfovy,
         grad_planes, shs, g.active_sh_degree, vt.campos, geom, ctx.R, binning, img, False)
     return go, (g_means2D, g_ex, g_opac, g_means3D, g_sh, g_scales, g_rot)
+
+
+def _params_stats(step, pb):
+    """Densification statistics (train.py:170-171) from the lanes of hgs_backward_multi_params."""
+    g = step.gaussians
+    step.last["stats_done"] = False
+    if step.stats_in_backward:
+        pb.max_radii2D, pb.grad_accum, pb.denom = g.max_radii2D.data_ptr(), g.xyz_gradient_accum.data_ptr(), g.denom.data_ptr()
+        step.last["stats_done"] = True
 
 
 def _tail_group(ctx, step, fu, scratch, out):
@@ -427,11 +445,41 @@ class _StrandIteration(torch.autograd.Function):
         f32 = dict(dtype=torch.float32, device=dev)
         d_ep = torch.empty((E, 3), **f32)
         gather = step.ep_segments is not None and step.ep_segments.shape[0] == E   # endpoint adjacency known: no atomics
+        d_w, d_o, d_m = torch.empty((P, 1), **f32), torch.empty((P, 1), **f32), torch.empty((P, 1), **f32)
+        if gather and step.fuse_param_backward and P > 0:
+            # ---- round 5: the segment geometry's backward in the rasterizer backward's own lanes, then the endpoint gather
+            pb = rt.ParamBackward()
+            seg_contrib = torch.empty((P, 2, 4), **f32)
+            pb.kind, pb.endpoints, pb.endpoint_pairs = rt.PARAMS_HAIR, rt.ptr(endpoints), rt.ptr(pairs)
+            pb.dist_to_scale_factor = float(g.dist_to_scale_factor)
+            pb.seg_contrib, pb.d_width, pb.extra4 = rt.ptr(seg_contrib), rt.ptr(d_w), rt.ptr(extra4)
+            pb.d_opacity_raw, pb.d_mask_raw = rt.ptr(d_o), rt.ptr(d_m)
+            _params_stats(step, pb)
+            go, (g_means2D, _, _, _, g_sh, _, _) = _head_raster_backward(
+                ctx, step, go, xyz, scale, quat, shs, planes, radii, geom, binning, img, scratch, out, endpoints, None, E,
+                params=pb)
+            fu = rt.StrandFusion()
+            if ctx.fused_smooth:
+                idx = step.smooth_pairs
+                fu.smooth_pairs, fu.n_smooth = idx.data_ptr(), int(idx.shape[0])
+                fu.cos_threshold, fu.eps = hp.cos_threshold, hp.eps
+                fu.head_out, fu.grad_out = out.data_ptr(), go.data_ptr()
+            _tail_group(ctx, step, fu, scratch, out)
+            fu.ep_segments, fu.n_endpoints = step.ep_segments.data_ptr(), E
+            fu.ep_pairs = None if step.ep_pairs is None else step.ep_pairs.data_ptr()
+            with torch.cuda.device(dev):
+                rt.check(L.hgs_hair_endpoint_gather(rt.current_stream(), E, rt.ptr(seg_contrib), rt.ptr(endpoints), rt.ptr(d_ep),
+                                                    C.byref(fu)))
+            step.last["dmean2D"] = g_means2D
+            if ctx.f_rest_k == 0:
+                d_dc, d_rest = g_sh, None
+            else:
+                d_dc, d_rest = g_sh[:, :1], g_sh[:, 1:]
+            return d_ep, d_w, d_o, d_m, d_dc, d_rest, None
         go, (g_means2D, g_ex, g_opac, g_means3D, g_sh, g_scales, g_rot) = _head_raster_backward(
             ctx, step, go, xyz, scale, quat, shs, planes, radii, geom, binning, img, scratch, out, endpoints,
             None if gather else d_ep, E)
         stream = rt.current_stream()
-        d_w, d_o, d_m = torch.empty((P, 1), **f32), torch.empty((P, 1), **f32), torch.empty((P, 1), **f32)
         fu = rt.StrandFusion()
         if ctx.fused_smooth:      # smoothness gradient: extra workgroups of the same launch, same d_ep
             idx = step.smooth_pairs
@@ -480,6 +528,8 @@ class FusedStrandStep:
         self.poison_unwritten = False   # tests: dL/dimage starts as NaN
         # strand parameters -> Gaussians -> preprocess as one launch (hgs_hair_forward_preprocess) where the pass allows it
         self.fuse_preprocess = bool(getattr(opt, "fuse_preprocess", True)) and os.environ.get("HGS_FUSE_PREPROCESS", "1") != "0"
+        # the backward mirror: parameters' backward in the rasterizer backward's per-Gaussian lanes (hgs_backward_multi_params)
+        self.fuse_param_backward = bool(getattr(opt, "fuse_param_backward", True)) and os.environ.get("HGS_FUSE_PARAM_BACKWARD", "1") != "0"
         # True: the loss terms (loss(), terms()) are complete only once backward() has run -- the head's last sums ride in
         # the backward's parameter launch instead of a launch of their own (GraphedStep, which always runs both, sets it)
         self.defer_tail = False
@@ -581,10 +631,28 @@ class _CloudIteration(torch.autograd.Function):
          out) = ctx.saved_tensors
         dev, P = xyz.device, xyz.shape[0]
         f32 = dict(dtype=torch.float32, device=dev)
-        go, (g_means2D, g_ex, g_opac, g_means3D, g_sh, g_scales, g_rot) = _head_raster_backward(
-            ctx, step, go, xyz, scale, quat, shs, planes, radii, geom, binning, img, scratch, out, None, None, 0)
         d_s, d_r = torch.empty((P, 3), **f32), torch.empty((P, 4), **f32)
         d_o, d_m = torch.empty((P, 1), **f32), torch.empty((P, 1), **f32)
+        if step.fuse_param_backward and P > 0:
+            # ---- round 5: the raw parameters' gradients from the rasterizer backward's own lanes; no second launch
+            pb = rt.ParamBackward()
+            g_means3D = torch.empty((P, 3), **f32)
+            pb.kind, pb.rotation_raw, pb.extra4 = rt.PARAMS_CLOUD, rt.ptr(rotation_raw), rt.ptr(extra4)
+            pb.d_means3D, pb.d_scaling_raw, pb.d_rotation_raw = rt.ptr(g_means3D), rt.ptr(d_s), rt.ptr(d_r)
+            pb.d_opacity_raw, pb.d_mask_raw = rt.ptr(d_o), rt.ptr(d_m)
+            _params_stats(step, pb)
+            if ctx.defer_tail:
+                rt.check(L.hgs_loss_head_tail(C.byref(step.head), rt.ptr(scratch), rt.ptr(out), C.byref(pb.head_tail)))
+            go, (g_means2D, _, _, _, g_sh, _, _) = _head_raster_backward(
+                ctx, step, go, xyz, scale, quat, shs, planes, radii, geom, binning, img, scratch, out, None, None, 0, params=pb)
+            step.last["dmean2D"] = g_means2D
+            if ctx.f_rest_k == 0:
+                d_dc, d_rest = g_sh, None
+            else:
+                d_dc, d_rest = g_sh[:, :1], g_sh[:, 1:]
+            return g_means3D, d_s, d_r, d_o, d_m, d_dc, d_rest, None
+        go, (g_means2D, g_ex, g_opac, g_means3D, g_sh, g_scales, g_rot) = _head_raster_backward(
+            ctx, step, go, xyz, scale, quat, shs, planes, radii, geom, binning, img, scratch, out, None, None, 0)
         fu = rt.StrandFusion()
         _stats_group(step, fu, radii, g_means2D)
         _tail_group(ctx, step, fu, scratch, out)

@@ -42,9 +42,11 @@
 extern "C" {
 #endif
 
-/* bumped with every incompatible change of a struct, a signature or a buffer layout (round 1: 1, round 2: 2, round 3: 3, then 4 with the one-launch parameters + preprocess entry points);
+/* bumped with every incompatible change of a struct, a signature or a buffer layout (round 1: 1, round 2: 2, round 3: 3, then 4 with the one-launch parameters + preprocess entry points;
+ * 5, round 5: hgs_backward_multi_params / hgs_hair_endpoint_gather, and the contract that HgsHeadParams.tile_used also limits
+ * what hgs_loss_head_forward writes of d_extra_unit -- a caller of version 4 that read those planes everywhere must not);
  * the Python binding refuses a library whose version or struct sizes differ from its own */
-#define HGS_ABI_VERSION 4
+#define HGS_ABI_VERSION 5
 #define HGS_TILE 16 /* cuda_rasterizer/config.h:16-17 */
 
 int hgs_abi_version(void);
@@ -94,7 +96,8 @@ int hgs_forward_render(void* stream, int P, int W, int H, int R_capacity, const 
  * All nine gradient outputs are fully written by the call (zeros for culled Gaussians):
  * the caller does not need to zero-fill them (reference zero-allocates, rasterize_points.cu:151-159).
  * dL_dconic is [P,2,2] (element [1,0] is written as 0), dL_dmeans2D is [P,3] (z = 0).
- * `scratch` >= hgs_backward_scratch_bytes(P, R) bytes. */
+ * `scratch` >= hgs_backward_scratch_bytes(P, R) bytes.  viewmatrix, projmatrix and campos are REQUIRED whatever the colour
+ * source (the kernel reads them at entry; NULL is refused). */
 int hgs_backward(void* stream, int P, int D, int M, int R, int W, int H, const float* bg,
                  const float* means3D, const float* shs, const float* colors_precomp,
                  const float* scales, float scale_modifier, const float* rotations,
@@ -340,6 +343,44 @@ int hgs_hair_params_backward(void* stream, int P, int E, const float* endpoints,
                              float* d_endpoints, float* d_width, float* d_opacity_raw, float* d_mask_raw,
                              const HgsStrandFusion* fusion);
 
+/* ---- hgs_backward_multi_params: the BACKWARD mirror of hgs_hair_forward_preprocess / hgs_cloud_forward_preprocess (round 5).
+ *   hgs_backward_multi whose last per-Gaussian launch also applies the backward of the derivation parameters -> Gaussian, in the
+ *   lane that has just finished the Gaussian's gradients (they never travel through memory):
+ *     HGS_PARAMS_HAIR   what hgs_hair_params_backward's per-segment lanes compute -- d_width, d_opacity_raw, d_mask_raw, the
+ *                       densification statistics -- and, in seg_contrib [P][2][4 floats], the gradient of the segment's first and
+ *                       second endpoint (xyz, pad).  hgs_hair_endpoint_gather then sums, per endpoint, its (<= 2) segments'
+ *                       contributions and (<= 4) smoothness-pair roles with one plain store (HgsStrandFusion.ep_segments /
+ *                       ep_pairs are required: gather mode only) and runs the loss head's deferred tail if one is given.
+ *     HGS_PARAMS_CLOUD  everything hgs_cloud_params_backward computes (d_means3D = the rasterizer's dL_dmeans3D); a deferred tail
+ *                       (head_tail.out != NULL) rides in a spare workgroup of the launch.  No second launch.
+ *   Results are those of hgs_backward_multi + hgs_hair_params_backward (gather mode) / hgs_cloud_params_backward bit for bit.
+ *   SH colours, scale_modifier 1 (as the forward entry points).  dL_dsh [P,M,3] is written as hgs_backward_multi writes it.
+ *   `extra4` / `opacity`-like inputs are the FORWARD's outputs of the same pass.  Optional (NULL = skipped): dL_dmeans2D_rgb
+ *   [P,3], the statistics group (max_radii2D / grad_accum / denom, all three or none). ---- */
+enum { HGS_PARAMS_HAIR = 1, HGS_PARAMS_CLOUD = 2 };
+typedef struct HgsParamBackward {
+  int kind;                                                                /* HGS_PARAMS_HAIR | HGS_PARAMS_CLOUD */
+  const float* endpoints; const long long* endpoint_pairs; float dist_to_scale_factor;   /* hair: in */
+  float* seg_contrib; float* d_width;                                                    /* hair: out */
+  const float* rotation_raw;                                                             /* cloud: in [P,4], 16-byte aligned */
+  float* d_means3D; float* d_scaling_raw; float* d_rotation_raw;                         /* cloud: out */
+  const float* extra4;                                                     /* in: the forward's [P,4] (mask channel first) */
+  float* d_opacity_raw; float* d_mask_raw;                                 /* out [P] */
+  float* dL_dmeans2D_rgb;                                                  /* out [P,3], optional */
+  float* max_radii2D; float* grad_accum; float* denom;                     /* in/out [P], optional (hgs_densify_stats) */
+  HgsHeadTail head_tail;                                                   /* cloud: out != NULL -> a spare workgroup runs the tail */
+} HgsParamBackward;
+size_t hgs_param_backward_bytes(void);   /* sizeof(HgsParamBackward) */
+int hgs_backward_multi_params(void* stream, int P, int D, int M, int R, int W, int H, const float* bg7, const float* means3D,
+                              const float* shs, const float* scales, const float* rotations, const float* viewmatrix,
+                              const float* projmatrix, const float* campos, float tan_fovx, float tan_fovy, const int* radii,
+                              const void* geom_buf, const void* binning_buf, const void* image_buf,
+                              const float* const* dL_dpix_planes7, void* scratch, float* dL_dsh, const HgsParamBackward* params);
+/* d_endpoints [E,3] fully written.  fusion: ep_segments (required), ep_pairs + the smoothness group (smooth_pairs, n_smooth,
+ * cos_threshold, eps, head_out, grad_out) and head_tail as for hgs_hair_params_backward; its other groups are ignored. */
+int hgs_hair_endpoint_gather(void* stream, int E, const float* seg_contrib, const float* endpoints, float* d_endpoints,
+                             const HgsStrandFusion* fusion);
+
 /* hgs_cloud_params_forward/backward: the Stage-I counterpart of hgs_hair_params_* -- the rasterizer-facing getters of the
  *   Gaussian cloud (scene/gaussian_model.py:118-157) and their autograd in one launch each:
  *   scale = exp(scaling_raw); quat = rotation_raw / max(|rotation_raw|, 1e-12) (F.normalize); opacity / mask = sigmoid;
@@ -362,7 +403,8 @@ int hgs_cloud_params_backward(void* stream, int P, const float* scaling_raw, con
  *   d_extra_unit ([4,H,W]: mask plane, then the 3 orientation planes; may be NULL): if given, the per-pixel pass also
  *   writes dL/d(mask_img) and dL/d(omap) FOR grad_out = 1 (requires targets->mask_count > 0 when the orientation term
  *   is on, since that gradient is normalised by the mask count); a caller whose upstream gradient is exactly 1 then
- *   passes HGS_HEAD_SKIP_PIXELS to the backward and uses those planes as they are.
+ *   passes HGS_HEAD_SKIP_PIXELS to the backward and uses those planes as they are.  With HgsHeadParams.tile_used given the
+ *   planes are UNWRITTEN on the 16 x 16 tiles that are not read (ABI 5).
  *   smooth_partials_ext (may be NULL): smoothness partial sums already computed elsewhere (HgsStrandFusion): the head then
  *   launches no smoothness kernel of its own and reduces these.
  *   backward: d_image [3,H,W] fully written (but see HgsHeadParams.tile_used); d_mask_img [H,W], d_omap [3,H,W] fully written unless HGS_HEAD_SKIP_PIXELS;

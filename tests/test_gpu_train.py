@@ -1299,6 +1299,89 @@ def test_one_launch_cloud_parameters_and_preprocess_equals_two_launches():
         assert bool(a[5].abs().sum() > 0)
 
 
+def test_fused_parameter_backward_equals_two_launches():
+    """hgs_backward_multi_params + hgs_hair_endpoint_gather (round 5: the segment geometry's backward applied in the rasterizer
+    backward's per-Gaussian lanes, endpoint contributions instead of 124 bytes of per-Gaussian gradients) against
+    hgs_backward_multi + hgs_hair_params_backward: every parameter gradient, the densification statistics, the RGB-only
+    screen-space gradient and the loss terms BIT FOR BIT (the shared parameter arithmetic is evaluated without contraction in
+    both translation units, hgs_strand_bwd.h) -- with the deferred head tail riding in the gather launch and without, with and
+    without the smoothness term."""
+    from arguments import OptimizationParams
+    from hgs_runtime.strand_step import FusedStrandStep, ViewTable
+    from synthetic import build_workload
+    model, cams, _ = build_workload("tiny", device="cuda", with_targets=True)
+    params = [model._endpoints, model._width, model._opacity, model._mask, model._features_dc]
+    stats = lambda: [model.max_radii2D, model.xyz_gradient_accum, model.denom]
+    for lam_smooth, defer in ((None, False), (None, True), (0.0, False)):
+        opt = OptimizationParams()
+        if lam_smooth is not None:
+            opt.lambda_smooth = lam_smooth
+        model.training_setup(opt)
+        runs = {}
+        for fuse in (False, True):
+            for t in stats():
+                t.zero_()
+            views = ViewTable(cams)
+            step = FusedStrandStep(model, views, opt, torch.zeros(3, device="cuda"))
+            step.fuse_param_backward = fuse
+            step.defer_tail = defer
+            assert step.ep_segments is not None
+            seen = []
+            for v in (0, 2, 1, 3):
+                for p in params:
+                    p.grad = None
+                views.prologue(v, ride=True)
+                loss, terms = step.loss()
+                step.backward(loss)
+                assert step.last["stats_done"]
+                seen.append([loss.detach().clone(), terms[:14].clone(), step.last["dmean2D"].clone()] +
+                            [p.grad.clone() for p in params] + [t.clone() for t in stats()])
+            runs[fuse] = seen
+        for a, b in zip(runs[False], runs[True]):
+            for x, y in zip(a, b):
+                assert torch.equal(x, y)
+            assert bool(a[3].abs().sum() > 0) and bool(a[-1].sum() > 0)
+
+
+def test_fused_cloud_parameter_backward_equals_two_launches():
+    """hgs_backward_multi_params(HGS_PARAMS_CLOUD) against hgs_backward_multi + hgs_cloud_params_backward (Stage-I cloud): the
+    launch of the parameters' backward is gone, its results -- gradients of all seven parameter groups, statistics, loss terms
+    (the deferred tail rides in the rasterizer backward's spare workgroup) -- bit for bit."""
+    from arguments import OptimizationParams
+    from hgs_runtime.strand_step import FusedCloudStep, ViewTable
+    from synthetic import attach_targets, cameras_extent, make_cameras, make_cloud_model
+    cams = make_cameras(4, 200, 120, device="cuda")
+    model = make_cloud_model(3000, device="cuda", spatial_lr_scale=cameras_extent(cams))
+    attach_targets(cams, model)
+    opt = OptimizationParams()
+    model.training_setup(opt)
+    params = [model._xyz, model._scaling, model._rotation, model._opacity, model._mask, model._features_dc]
+    stats = lambda: [model.max_radii2D, model.xyz_gradient_accum, model.denom]
+    for defer in (False, True):
+        out = {}
+        for fuse in (False, True):
+            for t in stats():
+                t.zero_()
+            views = ViewTable(cams)
+            step = FusedCloudStep(model, views, opt, torch.zeros(3, device="cuda"))
+            step.fuse_param_backward = fuse
+            step.defer_tail = defer
+            seen = []
+            for v in (0, 2, 1, 3):
+                for p in params:
+                    p.grad = None
+                views.prologue(v, ride=True)
+                loss, terms = step.loss()
+                step.backward(loss)
+                seen.append([loss.detach().clone(), terms[:14].clone(), step.last["dmean2D"].clone()] +
+                            [p.grad.clone() for p in params] + [t.clone() for t in stats()])
+            out[fuse] = seen
+        for a, b in zip(out[False], out[True]):
+            for x, y in zip(a, b):
+                assert torch.equal(x, y)
+            assert bool(a[3].abs().sum() > 0)
+
+
 def test_replays_after_a_blocking_pass_on_the_same_views():
     """The captured step's first launch counts into the image buffer's tile counters beside the workgroups that clear the other
     counters, so it needs them at zero -- which capacity-mode passes leave behind and a blocking-mode pass does not.  A blocking
