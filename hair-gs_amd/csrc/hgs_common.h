@@ -59,10 +59,10 @@ struct HgsBinning {
 enum { HGS_ST_R = 0, HGS_ST_OVERFLOW = 1, HGS_ST_SCANPTR_LO = 2, HGS_ST_SCANPTR_HI = 3, HGS_ST_SORT_ITEMS = 4,
        HGS_ST_SPLIT_ITEMS = 5, HGS_ST_SEG_LEN = 6, HGS_ST_WORK_ITEMS = 7, HGS_ST_TIMEOUT = 8, HGS_ST_SCAN_DONE = 9,
        HGS_ST_WL_TICKET = 10, HGS_ST_WL_NCAND = 11, HGS_ST_WL_NSEG = 12,    // exchange of the sort kernel's work-list builders
-       HGS_ST_SCAN_SHARE = 13 };                                              // [13..15]: instance totals of the fused scan's shares
+       HGS_ST_ALLOC = 13 };                                                   // allocation cursor of the tiles' segments (capacity mode, scatter_kernel)
 #ifndef HGS_SCAN_WGS
-#define HGS_SCAN_WGS 4   // workgroups sharing the fused scan of the scatter kernel (three share totals fit the status words; a share's offsets
-                         // -- HGS_FUSED_SCAN_MAX_T / 4 tiles -- fit the block's 12 KB tile table: hgs_preprocess.hip)
+#define HGS_SCAN_WGS 32  // workgroups of the scatter kernel that allocate the tiles' segments: one tile per thread up to HGS_FUSED_SCAN_MAX_T
+                         // (round 5; rounds 3-4: four workgroups sharing an exclusive scan in tile order)
 #endif
 #ifndef HGS_WL_BUILDERS
 #define HGS_WL_BUILDERS 8        // work-list builder workgroups of the sort kernel

@@ -385,7 +385,7 @@ __global__ __launch_bounds__(HGS_BLOCK) void hair_preprocess_fwd_kernel(HgsFwdAr
   const int nb_seg = (a.P + HGS_BLOCK - 1) / HGS_BLOCK;
   if ((int)blockIdx.x >= nb_seg) {   // smoothness partial sums over the same endpoints
     hgs_smooth_fwd_block((int)blockIdx.x - nb_seg, fu.n_smooth, st.ep, fu.smooth_pairs, fu.cos_threshold, fu.eps, fu.smooth_partials,
-                         (float*)red);
+                         (float*)red, (float4*)fu.smooth_pair_grads);
     return;
   }
   if (pro.table) {
@@ -464,78 +464,44 @@ __global__ __launch_bounds__(HGS_BLOCK) void scatter_kernel(int P, int gx, int T
     // workgroups; each gathers, scans and publishes only its share (16 KB of agent-scope stores instead of 64); the totals
     // of the shares in front travel through three status words.)
     if (!fused) return;
-    // The counts of this share's tiles are gathered straight from their (scattered) counter slots: 8 independent 4-byte
-    // loads per thread at 1080p, all in flight together.  (Rounds 2-3a staged the WHOLE slot table in LDS first -- 33.8 KB
-    // of dynamic LDS that EVERY workgroup of the launch reserved: three resident workgroups per CU instead of six, which
-    // is what the launches of more than 768 workgroups, i.e. every model beyond 196 k Gaussians, paid for it.)  The offsets
-    // live in the block's tile table, which a scan workgroup does not use otherwise.
-    constexpr int MAX_IPT = (HGS_FUSED_SCAN_MAX_T / HGS_SCAN_WGS + HGS_BLOCK - 1) / HGS_BLOCK + 1;
-    static_assert(sizeof(sc_lds) >= (HGS_FUSED_SCAN_MAX_T / HGS_SCAN_WGS + HGS_FUSED_SCAN_MAX_T / HGS_SCAN_WGS / 32 + 2 + HGS_BLOCK) * sizeof(uint32_t),
-                  "a share's offsets fit the block's LDS");
-    uint32_t* tile_off = (uint32_t*)sc_lds;
-    const int q = (int)blockIdx.x;                  // this workgroup's share of the tiles: [t_lo, t_hi)
-    const int share = (T + scan_wg - 1) / scan_wg, t_lo = min(T, q * share), t_hi = min(T, t_lo + share);
-    uint32_t cnt[MAX_IPT];
-    const int ipt = (t_hi - t_lo + HGS_BLOCK - 1) / HGS_BLOCK, i0 = t_lo + (int)threadIdx.x * ipt;
-    auto at = [](int i) { return i + (i >> 5); };
-    uint32_t mine = 0;
-#pragma unroll
-    for (int k = 0; k < MAX_IPT; k++)
-      cnt[k] = (k < ipt && i0 + k < t_hi) ? im.tile_count[HGS_TILE_SLOT(i0 + k, im.tile_mask)] : 0u;
-#pragma unroll
-    for (int k = 0; k < MAX_IPT; k++) mine += cnt[k];
-    // the counters are dead from here on: leave them at zero for the next pass over this image buffer (whose first kernel may
-    // count into them beside the workgroups that clear the rest of the buffer's counters: hair_preprocess_fwd_kernel)
-#pragma unroll
-    for (int k = 0; k < MAX_IPT; k++)
-      if (k < ipt && i0 + k < t_hi && cnt[k]) im.tile_count[HGS_TILE_SLOT(i0 + k, im.tile_mask)] = 0u;
-    const uint32_t inc = hgs_wave_incl_scan(mine, lane);
-    if (lane == 63) wsum[wave] = inc;
-    __syncthreads();
-    uint32_t run = inc - mine, total = 0;
-    for (int w = 0; w < 4; w++) { if (w < wave) run += wsum[w]; total += wsum[w]; }
-    // the instances of the shares in front of this one (agent-scope words, + 1 so that 0 means "not there yet")
-    __shared__ uint32_t s_front;
-    if (threadIdx.x == 0) {
-      if (q + 1 < scan_wg) hgs_st_agent(&im.status[HGS_ST_SCAN_SHARE + q], total + 1u);
-      uint32_t front = 0;
-      for (int p = 0; p < q; p++) {
-        uint32_t v = 0;
-        int spin = 0;
-        while ((v = hgs_ld_agent(&im.status[HGS_ST_SCAN_SHARE + p])) == 0u && ++spin < (1 << 21)) __builtin_amdgcn_s_sleep(2);
-        if (v == 0u) { im.status[HGS_ST_TIMEOUT] = 1u; atomicMax((unsigned int*)report, 0xFFFFFFFFu); v = 1u; }
-        front += v - 1u;
-      }
-      s_front = front;
-    }
-    __syncthreads();
-    const uint32_t front = s_front;
-    run += front;
-#pragma unroll
-    for (int k = 0; k < MAX_IPT; k++)
-      if (k < ipt && i0 + k < t_hi) { tile_off[at(i0 + k - t_lo)] = run; run += cnt[k]; }   // offsets, in TILE order
-    __syncthreads();
-    const uint32_t end_all = front + total;           // offset behind this share's last tile
-    // publish: consecutive lanes take consecutive tiles (512 contiguous bytes per wave instruction; a lane per run of 32
-    // tiles made every lane's store a fabric write of its own); a tile's count is the difference of two offsets.
+    // Round 5: the tiles' segments are ALLOCATED, not scanned.  Rounds 2-4 laid the segments out in tile order: an exclusive
+    // scan of all T counts, shared by four workgroups that each needed the totals of the shares in front of theirs (three status
+    // words, a chain of agent-scope round trips) and kept their offsets in LDS to publish them coalesced -- done ~8.5 us into
+    // the launch, 2 us after the other workgroups had counted and reserved (tools/dev/scatter_trace.py).  Nothing needs the
+    // tile order: a segment only has to be contiguous and its own (the per-tile sort and the blend go through `ranges`).  So:
+    // one tile per thread, an inclusive scan inside the wavefront, ONE returning atomic per wavefront on the pass's
+    // allocation cursor (status word HGS_ST_ALLOC) for the wavefront's 64 tiles, one coalesced store of the ranges -- three
+    // dependent round trips, no workgroup waits for another.  The segments of a frame then sit in the order the wavefronts'
+    // atomics arrived: the binning buffer's layout differs run to run, every tile's list and everything computed from it does
+    // not (tests/test_gpu_raster.py::test_capacity_mode_binning_equals_blocking_mode compares tile by tile; the blocking mode,
+    // scan_kernel, keeps the reference's layout).
+    static_assert(HGS_FUSED_SCAN_MAX_T <= HGS_SCAN_WGS * HGS_BLOCK, "one tile per thread of the scan workgroups");
+    const int t = (int)blockIdx.x * HGS_BLOCK + (int)threadIdx.x;
+    const uint32_t slot = HGS_TILE_SLOT(t, im.tile_mask);
+    const uint32_t cnt = t < T ? im.tile_count[slot] : 0u;
+    // the counter is dead from here on: leave it at zero for the next pass over this image buffer (whose first kernel may
+    // count into it beside the workgroups that clear the rest of the buffer's counters: hair_preprocess_fwd_kernel)
+    if (cnt) im.tile_count[slot] = 0u;
+    const uint32_t inc = hgs_wave_incl_scan(cnt, lane);
+    const uint32_t wave_total = (uint32_t)__shfl((int)inc, 63, 64);
+    uint32_t base = 0u;
+    if (lane == 63 && wave_total)
+      base = __hip_atomic_fetch_add(&im.status[HGS_ST_ALLOC], wave_total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    base = (uint32_t)__shfl((int)base, 63, 64);
+    const uint32_t o = base + inc - cnt;
     // Agent-scope stores: the other workgroups of this launch read them, from other XCDs too.
-    for (int t = t_lo + (int)threadIdx.x; t < t_hi; t += HGS_BLOCK) {
-      const uint32_t o = tile_off[at(t - t_lo)], v = (t + 1 < t_hi ? tile_off[at(t + 1 - t_lo)] : end_all) - o;
-      hgs_st_agent((unsigned long long*)&im.ranges[t], v ? ((unsigned long long)(o + v) << 32) | o : 0ull);
-    }
+    if (t < T) hgs_st_agent((unsigned long long*)&im.ranges[t], cnt ? ((unsigned long long)(o + cnt) << 32) | o : 0ull);
     hgs_drain_stores();
     __syncthreads();
     if (threadIdx.x == 0) {
-      __hip_atomic_fetch_add(&im.status[HGS_ST_SCAN_DONE], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (q == scan_wg - 1) {
+      const uint32_t done = __hip_atomic_fetch_add(&im.status[HGS_ST_SCAN_DONE], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (done == (uint32_t)scan_wg - 1u) {   // the last one: every wavefront's allocation has returned
+        const uint32_t end_all = hgs_ld_agent(&im.status[HGS_ST_ALLOC]);
         im.status[HGS_ST_R] = end_all;
         atomicMax((unsigned int*)report, end_all);   // sticky maximum for graph replays (hgs.h)
       }
     }
-    for (int t = t_lo + (int)threadIdx.x; t < t_hi; t += HGS_BLOCK) {   // long lists: one sort workgroup per chunk (read by the NEXT kernel)
-      const uint32_t o = tile_off[at(t - t_lo)], v = (t + 1 < t_hi ? tile_off[at(t + 1 - t_lo)] : end_all) - o;
-      hgs_emit_sort_items((uint32_t)t, v, (uint32_t)T, im);
-    }
+    if (t < T) hgs_emit_sort_items((uint32_t)t, cnt, (uint32_t)T, im);   // long lists: one sort workgroup per chunk (read by the NEXT kernel)
     SC_MARK(5);
     return;
   }
@@ -1121,7 +1087,7 @@ int hgs_launch_scatter(hipStream_t s, int P, int W, int H, int Rcap, const float
   const bool can_fuse = T <= HGS_FUSED_SCAN_MAX_T && P <= HGS_FUSED_SCAN_MAX_P;
   {
     HgsProfScope _prof(s, HGS_K_SCATTER);
-    const int scan_wg = can_fuse ? HGS_SCAN_WGS : 0;
+    const int scan_wg = can_fuse ? (T + HGS_BLOCK - 1) / HGS_BLOCK : 0;     // one tile per thread (<= HGS_SCAN_WGS workgroups)
     hipLaunchKernelGGL(scatter_kernel, dim3(nblk + scan_wg), dim3(HGS_BLOCK), lds, s, P, gx, T, (uint32_t)Rcap, features, n_extra ? extra : nullptr, g, im, b, scan_wg);
   }
   HGS_CHECK_LAUNCH();

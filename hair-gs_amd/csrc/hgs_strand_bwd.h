@@ -128,7 +128,11 @@ struct HgsStrandBwdArgs {
 
 // Workgroup `blk` of `nblk` (256 threads): [0, ceil(P / 256)) one lane per Gaussian; then, gather mode, one lane per
 // endpoint (scatter mode: per smoothness pair); the last one runs the loss head's deferred tail when that is asked for.
-__device__ __forceinline__ void hgs_strand_bwd_block(const HgsStrandBwdArgs& A, unsigned blk, unsigned nblk) {
+// CONTRIB: compiled for the gather-only launch (A.seg_contrib given): none of the per-segment code, fewer registers, more waves
+template <bool CONTRIB = false>
+__device__ __forceinline__ void hgs_strand_bwd_block(const HgsStrandBwdArgs& A_in, unsigned blk, unsigned nblk) {
+  HgsStrandBwdArgs A = A_in;
+  if (CONTRIB) { A.P = 0; } else { A.seg_contrib = nullptr; }
   const HgsStrandFusion& fu = A.fu;
   const int P = A.P;
   const float* __restrict__ ep = A.ep;
@@ -136,7 +140,7 @@ __device__ __forceinline__ void hgs_strand_bwd_block(const HgsStrandBwdArgs& A, 
   const float f = A.f;
   // (the loss head's deferred tail, include/hgs.h HgsHeadTail: one spare workgroup behind the launch's own)
   if (fu.head_tail.out && blk == nblk - 1) { hgs_head_tail_block(fu.head_tail); return; }
-  const int nb_seg = A.seg_contrib ? 0 : (P + 255) / 256;
+  const int nb_seg = CONTRIB ? 0 : (P + 255) / 256;
   const HgsSegGrads sg = {A.g_xyz, A.g_scale, A.g_quat, A.g_dir, A.g_extra4};
   const float smooth_scale = fu.n_smooth > 0
       ? fu.head_out[HGS_HEAD_G_SMOOTH] * fu.grad_out[0] / fmaxf(fu.head_out[HGS_HEAD_SMOOTH_COUNT], 1.f) : 0.f;
@@ -158,21 +162,36 @@ __device__ __forceinline__ void hgs_strand_bwd_block(const HgsStrandBwdArgs& A, 
       if (with_smooth) cp = *(const int4*)(fu.ep_pairs + 4 * (size_t)ic);
       const int seg_code[2] = {cs.x, cs.y};
       HgsSegGeom geo[2] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
-      if (!A.seg_contrib) {
+      if (!CONTRIB) {
 #pragma unroll
         for (int s = 0; s < 2; s++) geo[s] = hgs_segment_geom(seg_code[s] >= 0 ? seg_code[s] >> 1 : 0, ep, pairs);
       }
       const int pair_code[4] = {cp.x, cp.y, cp.z, cp.w};
       float pg0[4][3], pg1[4][3];
       bool pok[4] = {false, false, false, false};
-      if (with_smooth) {
+      if (CONTRIB && with_smooth && fu.smooth_pair_grads) {
+        // the pairs' unit gradients as the forward's spare workgroups left them (HgsStrandFusion.smooth_pair_grads): the role's
+        // 16 bytes instead of pair -> index row -> four endpoints; times the scale, as hgs_smooth_pair_grads forms it
+        float4 u[4];
+#pragma unroll
+        for (int s = 0; s < 4; s++) {
+          const int code = pair_code[s] >= 0 ? pair_code[s] : 0;
+          u[s] = ((const float4*)fu.smooth_pair_grads)[2 * (size_t)(code >> 2) + ((code & 3) >> 1)];
+        }
+#pragma unroll
+        for (int s = 0; s < 4; s++) {
+          pok[s] = u[s].w != 0.f && pair_code[s] >= 0;
+          pg0[s][0] = pg1[s][0] = smooth_scale * u[s].x; pg0[s][1] = pg1[s][1] = smooth_scale * u[s].y;
+          pg0[s][2] = pg1[s][2] = smooth_scale * u[s].z;
+        }
+      } else if (with_smooth) {
 #pragma unroll
         for (int s = 0; s < 4; s++)
           pok[s] = hgs_smooth_pair_grads(pair_code[s] >= 0 ? pair_code[s] >> 2 : 0, ep, fu.smooth_pairs, fu.cos_threshold, fu.eps,
                                          smooth_scale, pg0[s], pg1[s]) && pair_code[s] >= 0;
       }
       // (everything above is independent of the rasterizer's gradients)
-      if (A.seg_contrib) {   // the segments' contributions as the rasterizer backward left them: the same two terms, same order
+      if (CONTRIB) {   // the segments' contributions as the rasterizer backward left them: the same two terms, same order
         float4 ct[2];
 #pragma unroll
         for (int s = 0; s < 2; s++) ct[s] = A.seg_contrib[seg_code[s] >= 0 ? seg_code[s] : 0];
@@ -207,6 +226,7 @@ __device__ __forceinline__ void hgs_strand_bwd_block(const HgsStrandBwdArgs& A, 
     }
     return;
   }
+  if (CONTRIB) return;
   const int k = blk * 256 + threadIdx.x;
   if (k >= P) return;
   if (fu.radii)                      // densification statistics of this Gaussian (hgs_densify_stats)

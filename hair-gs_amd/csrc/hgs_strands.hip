@@ -35,7 +35,7 @@ __global__ __launch_bounds__(256) void strand_fwd_kernel(int P, const float* __r
   const int nb_seg = (P + 255) / 256;
   if ((int)blockIdx.x >= nb_seg) {   // extra workgroups: smoothness partial sums over the same endpoints
     __shared__ float red[4];
-    hgs_smooth_fwd_block((int)blockIdx.x - nb_seg, fu.n_smooth, ep, fu.smooth_pairs, fu.cos_threshold, fu.eps, fu.smooth_partials, red);
+    hgs_smooth_fwd_block((int)blockIdx.x - nb_seg, fu.n_smooth, ep, fu.smooth_pairs, fu.cos_threshold, fu.eps, fu.smooth_partials, red, (float4*)fu.smooth_pair_grads);
     return;
   }
   const int k = blockIdx.x * 256 + threadIdx.x;
@@ -59,7 +59,11 @@ __global__ __launch_bounds__(256) void strand_fwd_kernel(int P, const float* __r
 #define HGS_SBW_WAVES 6
 #endif
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HGS_SBW_WAVES))) void strand_bwd_kernel(HgsStrandBwdArgs A) {
-  hgs_strand_bwd_block(A, blockIdx.x, gridDim.x);     // (device code: hgs_strand_bwd.h)
+  hgs_strand_bwd_block<false>(A, blockIdx.x, gridDim.x);     // (device code: hgs_strand_bwd.h)
+}
+// the endpoint gather alone (hgs_hair_endpoint_gather): segment contributions and pair gradients are read, not evaluated
+__global__ __launch_bounds__(256) void strand_gather_kernel(HgsStrandBwdArgs A) {
+  hgs_strand_bwd_block<true>(A, blockIdx.x, gridDim.x);
 }
 
 // ---- Stage-I cloud: raw parameters -> rasterizer inputs (scene/gaussian_model.py:118-157) -------------------------------
@@ -224,6 +228,7 @@ int hgs_hair_endpoint_gather(void* stream, int E, const float* seg_contrib, cons
   HgsStrandFusion fu = *fusion;
   const bool smooth = fu.smooth_pairs && fu.n_smooth > 0 && fu.head_out && fu.grad_out && fu.ep_pairs;
   if (!smooth) { fu.n_smooth = 0; fu.ep_pairs = nullptr; }
+  if (fu.smooth_pair_grads && ((size_t)fu.smooth_pair_grads & 15)) { hgs_set_error("hgs_hair_endpoint_gather: smooth_pair_grads must be 16-byte aligned"); return 1; }
   fu.n_endpoints = E;
   fu.radii = nullptr;                                       // (the statistics belong to hgs_backward_multi_params)
   if (E == 0 && !fu.head_tail.out) return 0;
@@ -239,7 +244,7 @@ int hgs_hair_endpoint_gather(void* stream, int E, const float* seg_contrib, cons
     const HgsStrandBwdArgs A = {0, endpoints, nullptr, nullptr, 0.f, nullptr, nullptr, nullptr, nullptr, d_endpoints, nullptr,
                                 nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, fu,
                                 E > 0 ? (const float4*)seg_contrib : &kNone};
-    hipLaunchKernelGGL(strand_bwd_kernel, dim3((E + 255) / 256 + (fu.head_tail.out ? 1 : 0)), dim3(256), 0, s, A);
+    hipLaunchKernelGGL(strand_gather_kernel, dim3((E + 255) / 256 + (fu.head_tail.out ? 1 : 0)), dim3(256), 0, s, A);
   }
   HGS_CHECK_LAUNCH();
   return 0;

@@ -131,7 +131,7 @@ class Prologue(C.Structure):
 class StrandFusion(C.Structure):
     """include/hgs.h HgsStrandFusion."""
     _fields_ = [("smooth_pairs", vp), ("n_smooth", ci), ("cos_threshold", cf), ("eps", cf), ("smooth_partials", vp),
-                ("head_out", vp), ("grad_out", vp), ("radii", vp), ("dmean2D", vp), ("dmean2D_stride", ci),
+                ("smooth_pair_grads", vp), ("head_out", vp), ("grad_out", vp), ("radii", vp), ("dmean2D", vp), ("dmean2D_stride", ci),
                 ("max_radii2D", vp), ("grad_accum", vp), ("denom", vp), ("ep_segments", vp), ("ep_pairs", vp),
                 ("n_endpoints", ci), ("head_tail", HeadTail), ("prologue", Prologue)]
 

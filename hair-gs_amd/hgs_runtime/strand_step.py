@@ -397,12 +397,17 @@ class _StrandIteration(torch.autograd.Function):
         hp = step.head
         # the smoothness term rides in extra workgroups of the parameter kernels (HgsStrandFusion)
         fu = rt.StrandFusion()
-        smooth_partials = None
+        smooth_partials = pair_grads = None
         if idx is not None and hp.lambda_smooth > 0:
             smooth_partials = torch.empty((2 * ((idx.shape[0] + 255) // 256),), **f32)
             fu.smooth_pairs, fu.n_smooth = idx.data_ptr(), int(idx.shape[0])
             fu.cos_threshold, fu.eps = hp.cos_threshold, hp.eps
             fu.smooth_partials = smooth_partials.data_ptr()
+            # the pairs' unit gradients for the backward's endpoint gather (they do not depend on the rasterizer: the forward's
+            # spare workgroups compute them beside the preprocess workgroups, HgsStrandFusion.smooth_pair_grads)
+            if step.fuse_param_backward and step.ep_pairs is not None:
+                pair_grads = torch.empty((idx.shape[0], 2, 4), **f32)
+                fu.smooth_pair_grads = pair_grads.data_ptr()
         shs = f_dc if f_rest.numel() == 0 else torch.cat((f_dc, f_rest), dim=1)
         if step.fuse_preprocess:
             # parameters -> Gaussians -> preprocess as ONE launch where the pass runs in capacity mode (HairSource); the riders
@@ -429,6 +434,7 @@ class _StrandIteration(torch.autograd.Function):
         ctx.set_materialize_grads(False)   # no zero tensor for the (non-differentiable) terms output
         ctx.save_for_backward(endpoints, width, pairs, xyz, scale, quat, opacity, extra4, shs, planes, radii, geom, binning,
                               img, scratch, out)
+        ctx.pair_grads = pair_grads
         step.last = {"planes": planes, "radii": radii, "terms": out}
         terms = out.detach()
         ctx.mark_non_differentiable(terms)
@@ -464,6 +470,8 @@ class _StrandIteration(torch.autograd.Function):
                 fu.smooth_pairs, fu.n_smooth = idx.data_ptr(), int(idx.shape[0])
                 fu.cos_threshold, fu.eps = hp.cos_threshold, hp.eps
                 fu.head_out, fu.grad_out = out.data_ptr(), go.data_ptr()
+                if ctx.pair_grads is not None:
+                    fu.smooth_pair_grads = ctx.pair_grads.data_ptr()
             _tail_group(ctx, step, fu, scratch, out)
             fu.ep_segments, fu.n_endpoints = step.ep_segments.data_ptr(), E
             fu.ep_pairs = None if step.ep_pairs is None else step.ep_pairs.data_ptr()

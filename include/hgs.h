@@ -293,6 +293,9 @@ typedef struct HgsHeadTail {
 typedef struct HgsStrandFusion {
   const long long* smooth_pairs; int n_smooth; float cos_threshold, eps;
   float* smooth_partials;                          /* forward out */
+  float* smooth_pair_grads;                        /* optional, [n_smooth][2][4]: forward out -- the pairs' unit gradients (g0, ok),
+                                                      (g1, ok) -- and hgs_hair_endpoint_gather in: its endpoint lanes then read 16
+                                                      bytes per pair role instead of evaluating the pair again (same bits) */
   const float* head_out; const float* grad_out;    /* backward in (device) */
   const int* radii; const float* dmean2D; int dmean2D_stride;   /* backward in: statistics inputs */
   float* max_radii2D; float* grad_accum; float* denom;          /* backward in/out */

@@ -70,6 +70,26 @@ def intermediates(scene, fw):
     return o
 
 
+def in_tile_order(o, n):
+    """Capacity mode (round 5) ALLOCATES the tiles' segments instead of scanning them in tile order: the binning buffer holds
+    them in the order the allocating wavefronts' atomics arrived.  Returns (ranges, point_list, keys_sorted) of an
+    intermediates() result re-laid in tile order -- what the blocking mode, i.e. the reference's layout, holds -- after checking
+    that the segments partition [0, n) exactly."""
+    r = o["ranges"].astype(np.int64)
+    lens = r[:, 1] - r[:, 0]
+    used = np.flatnonzero(lens > 0)
+    assert np.all(r[lens == 0] == 0), "an empty tile's range is (0, 0)"
+    order = used[np.argsort(r[used, 0], kind="stable")]
+    assert int(lens.sum()) == n
+    if len(order):                                          # back to back, from 0, without overlap
+        assert r[order[0], 0] == 0 and np.array_equal(r[order[1:], 0], r[order[:-1], 1]) and r[order[-1], 1] == n
+    start = np.concatenate([[0], np.cumsum(lens)[:-1]])
+    ranges = np.stack([start, start + lens], 1)
+    ranges[lens == 0] = 0
+    idx = np.concatenate([np.arange(r[t, 0], r[t, 1]) for t in used]) if len(used) else np.zeros(0, np.int64)
+    return ranges.astype(np.uint32), o["point_list"][idx], o["keys_sorted"][idx]
+
+
 def run_backward(scene, fw, dL_dpix):
     a = fw["args"]
     (bg, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D, view, proj, tfx, tfy, H, W, sh, degree,

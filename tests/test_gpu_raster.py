@@ -451,10 +451,16 @@ def test_capacity_mode_binning_equals_blocking_mode(name):
         _C.set_async(False)
     n = ref["num_rendered"]
     assert fw["R"] >= n and got["status"][0] == n and got["status"][1] == 0
-    for k in ("ranges", "tiles_touched", "point_offsets", "n_contrib"):
+    for k in ("tiles_touched", "point_offsets", "n_contrib"):
         np.testing.assert_array_equal(got[k], ref[k], err_msg=k)
-    for k in ("point_list", "keys_sorted"):
-        np.testing.assert_array_equal(got[k][:n], ref[k], err_msg=k)
+    # Where the scatter kernel allocates the tiles' segments itself (round 5: one atomic per wavefront of 64 tiles instead of
+    # a scan in tile order) the segments sit in the order those atomics arrived: compared tile by tile -- every tile's range
+    # length, list and sorted keys are the blocking mode's, the segments partition [0, n).  (many_tiles and every frame of
+    # more than 8192 tiles keep the scan kernel, i.e. the reference's layout, which in_tile_order leaves as it is.)
+    ranges, point_list, keys_sorted = G.in_tile_order(got, n)
+    np.testing.assert_array_equal(ranges, ref["ranges"], err_msg="ranges")
+    np.testing.assert_array_equal(point_list, ref["point_list"], err_msg="point_list")
+    np.testing.assert_array_equal(keys_sorted, ref["keys_sorted"], err_msg="keys_sorted")
     np.testing.assert_array_equal(got["out_color"].view(np.uint32), ref["out_color"].view(np.uint32))
     dpix = np.random.default_rng(3).normal(size=(3, s["H"], s["W"])).astype(np.float32)
     g1, g0 = G.run_backward(s, fw, dpix), G.run_backward(s, ref_fw, dpix)
