@@ -349,6 +349,10 @@ __global__ __launch_bounds__(HGS_BLOCK) __attribute__((amdgpu_waves_per_eu(8))) 
     for (int k = 0; k < C; k++) {
       bn.seg_C[(((size_t)it.w + 1) * C + k) * HGS_BLOCK + threadIdx.x] = acc[k];
       acc[k] += bn.seg_C[((size_t)it.w * C + k) * HGS_BLOCK + threadIdx.x];     // colours summed back to front, like the tile finalisation below
+      // the SUFFIX sum in the first segment's cell, as the general path's finalisation leaves it (the backward reads only the
+      // cell of segment w + 1 today; a later reader of cell w finds what the file header promises).  NOT written for a
+      // two-segment tile: seg_P, seg_Tout, seg_last, tile_prog, tile_done -- the exchange between segment workgroups.
+      bn.seg_C[((size_t)it.w * C + k) * HGS_BLOCK + threadIdx.x] = acc[k];
     }
     uint32_t wmax = last;
 #pragma unroll

@@ -1048,6 +1048,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8))) void p
       int y = N < (1 << 24) ? (int)(((float)i + 0.5f) * inv_w) : i / W;
       int x = i - y * W;
       if (x < 0) { y--; x += W; } else if (x >= W) { y++; x -= W; }
+      static_assert(HGS_TILE == 16, "pixel -> tile by a shift of 4");
       used = tile_used[(y >> 4) * tiles_x + (x >> 4)];
     }
     float gm = 0.f, g0 = 0.f, g1 = 0.f, g2 = 0.f;
@@ -1256,6 +1257,13 @@ int hgs_loss_head_forward(void* stream, const HgsHeadParams* p, const float* ima
     return 1;
   }
   const int H = p->H, W = p->W, N = H * W;
+  // the tile hint indexes the rasterizer's tile grid of THIS frame: any other geometry would read the wrong tile (or out of bounds)
+  // and leave needed planes of d_extra_unit unwritten
+  if (p->tile_used && (p->tiles_x != (W + HGS_TILE - 1) / HGS_TILE || p->tiles_y != (H + HGS_TILE - 1) / HGS_TILE)) {
+    hgs_set_error("hgs_loss_head_forward: tile_used given with tiles_x / tiles_y = %d x %d, the %d x %d frame has %d x %d tiles", p->tiles_x,
+                  p->tiles_y, W, H, (W + HGS_TILE - 1) / HGS_TILE, (H + HGS_TILE - 1) / HGS_TILE);
+    return 1;
+  }
   const int nbs = head_nb_ssim(p), nbp = head_nb_pix(p), nbm = head_nb_smooth(p);
   if (nbm > 0 && !smooth_partials_ext && (!endpoints || !smooth_pairs)) { hgs_set_error("hgs_loss_head_forward: smoothness term without endpoints"); return 1; }
   float* dmaps = scratch;

@@ -80,6 +80,15 @@ def angle_smoothness_loss(gaussians: HairGaussianModel, threshold: float = 30, e
     d = pos[:, :, 1] - pos[:, :, 0]
     d = d / torch.norm(d, dim=2, keepdim=True)
     dot = torch.sum(d[:, 0] * d[:, 1], dim=1)
+    if dot.is_cuda:
+        # fused_losses = False on the GPU (the op-by-op iteration, which may be captured in a graph): the same selection without
+        # boolean indexing -- no host synchronisation, no data-dependent shape, always a tensor (0 when no pair is selected).
+        # Same value and gradient as the statements below wherever those are finite; with a zero-length segment in a strand the
+        # reference's form gives NaN gradients (0 / 0 through the normalisation's backward), and so does this one -- unlike the
+        # fused kernel, which skips such pairs (tests/test_ref_loss_pins.py).
+        sel = dot <= cos_th
+        ang2 = torch.acos(torch.clamp(dot, -1 + eps, 1 - eps)) ** 2
+        return torch.where(sel, ang2, torch.zeros_like(ang2)).sum() / sel.sum().clamp(min=1)
     dot = dot[dot <= cos_th]                             # only bends sharper than the threshold are penalised
     if dot.shape[0] == 0:
         return 0

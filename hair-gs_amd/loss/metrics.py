@@ -101,7 +101,13 @@ def compute_eval_data_from_hair_gs(hair_gs, compute_edges=False, only_foreground
     and the joint's strand id.  (`strands_info` computed with only_foreground=True already holds foreground segments only;
     only_foreground=True here filters again by the current foreground mask, like the reference.)"""
     endpoints = hair_gs._endpoints.detach().cpu().numpy()
-    segments_id = np.concatenate(list(hair_gs.strands_info.list_strands), axis=0)
+    if hair_gs.strands_info is None:          # (the constructor's default: the reference would fail here; train.evaluate() may come first)
+        hair_gs.compute_strands_info(only_foreground=True)
+    strands = list(hair_gs.strands_info.list_strands)
+    if len(strands) == 0:                     # nothing to evaluate: an empty point set instead of np.concatenate's error
+        return HairEvalData(points=np.zeros((0, 3), endpoints.dtype), directions=np.zeros((0, 3), endpoints.dtype),
+                            points_id_to_strand_id=np.zeros((0,), np.int64), edges=np.zeros((0, 2), np.int32) if compute_edges else None)
+    segments_id = np.concatenate(strands, axis=0)
     if only_foreground:
         mask = hair_gs.compute_foreground_mask().cpu().numpy()
         line_points = hair_gs.endpoint_pairs.cpu().numpy()[mask].flatten()

@@ -181,6 +181,51 @@ def test_blend_work_list_covers_every_tile_once(name):
         assert split_tiles
 
 
+def test_two_segment_lists_walked_by_one_workgroup():
+    """Lists of exactly TWO segments (round 4: the forward's first segment workgroup walks both serially, the backward still
+    runs two workgroups on what it left -- the transmittance in front of the second segment, the segments' colours and their
+    suffix sum).  hgs_set_segment_policy pins the segment length so that tiles of `medium_lists` land in (1.5 S, 2 S]: against
+    the unsplit walk of the same lists n_contrib and final_T are bit-identical and the image agrees to the association of one
+    sum per pixel; the backward agrees with the oracle at the usual bar."""
+    import hgs_runtime as rt
+    from tests import gpu_util as G
+    s = _scene("medium_lists")
+    L = rt.lib()
+    try:
+        rt.check(L.hgs_set_segment_policy(1024, 1024, 1))          # lists up to 1536 entries: one workgroup per tile
+        fw0 = G.run_forward(s)
+        got0 = G.intermediates(s, fw0)
+        n = (got0["ranges"][:, 1].astype(np.int64) - got0["ranges"][:, 0])
+        assert n.max() <= 1536
+        S = next(S for S in range(128, 1025, 64) if ((n > S + S // 2) & (n <= 2 * S)).any())
+        two = np.flatnonzero((n > S + S // 2) & (n <= 2 * S))
+        rt.check(L.hgs_set_segment_policy(S, S, 1))
+        fw = G.run_forward(s)
+        got = G.intermediates(s, fw)
+        assert got["status"][6] == S and got["status"][8] == 0
+        items = G.blend_work_list(s, fw)[:int(got["status"][5])]
+        for t in two:
+            assert sorted((items[(items & 0xFFFFFF) == t] >> 24).tolist()) == [0, 1]
+        # on the two-segment tiles the transmittance is carried through both walks: the serial walk's bits (tiles of three and
+        # more segments multiply per-segment products: rounding, like every split list)
+        gx, gy = (s["W"] + 15) // 16, (s["H"] + 15) // 16
+        tmask = np.zeros(gx * gy, bool)
+        tmask[two] = True
+        pm = np.repeat(np.repeat(tmask.reshape(gy, gx), 16, 0), 16, 1)[:s["H"], :s["W"]]
+        assert pm.any()
+        np.testing.assert_array_equal(got["n_contrib"][pm], got0["n_contrib"][pm])
+        np.testing.assert_array_equal(got["final_T"][pm].view(np.uint32), got0["final_T"][pm].view(np.uint32))
+        assert float(np.abs(got["final_T"].astype(np.float64) - got0["final_T"]).max()) <= 2e-6
+        assert float(np.abs(got["out_color"].astype(np.float64) - got0["out_color"]).max()) <= 2e-6
+        ref = O.forward(s)
+        ref_state = dict(ref)
+        ref_state["n_contrib"], ref_state["final_T"] = got["n_contrib"].copy(), got["final_T"].copy()
+        dpix = np.random.default_rng(5).normal(size=(3, s["H"], s["W"])).astype(np.float32)
+        _grad_check(G.run_backward(s, fw, dpix), O.backward(s, ref_state, dpix), ref)
+    finally:
+        rt.check(L.hgs_set_segment_policy(128, 1024, 2048))
+
+
 GRAD_KEYS = ("dL_dmeans2D", "dL_dconic", "dL_dopacity", "dL_dcolors", "dL_dmeans3D", "dL_dcov3D", "dL_dsh", "dL_dscales",
              "dL_drotations")
 # Gradient bar (BASELINE.json north_star: "per-param grads within 1e-4 rel fp32"), enforced on EVERY element:

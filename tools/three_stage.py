@@ -1,0 +1,201 @@
+#!/usr/bin/env python3
+"""The reference's three-stage workflow (README.md:136-153: train.py -> merge.py -> train.py) on ONE synthetic capture at a
+BASELINE.json size, timed and scored per stage (BASELINE config 4 "full 3-stage" in miniature):
+
+  ground truth  S strands x 100 segments (synthetic.strand_polylines), rendered to image / mask / orientation targets for 16
+                views at 800 x 800 (BASELINE config 2's frame) from the ground-truth strand model itself (consistent targets)
+  Stage I       a Gaussian cloud of as many points as the ground truth has segments -- the segments' midpoints + N(0, 2 mm), what
+                a sparse reconstruction hands train.py -- optimised with the reference's Stage-I loop: densify_and_clone /
+                split / prune every 100 iterations from 500, opacity reset every 3000 (train.training, FusedCloudStep)
+  Stage II      to_hair_gaussian_model + merge rounds until nothing is left to merge (merge.merge_rounds)
+  Stage III     the strand model optimised WITH the topology operators (densification, merging, opacity reset)
+
+PSNR (mean over all views against the targets), primitive count and wall time are recorded every 500 iterations; strand
+metrics (loss/metrics.py compute_metrics against the ground-truth strands) at the end of stages II and III.
+In the same run, `densify_inputs`: the ONE input of densification() that no reference run pins -- xyz_gradient_accum / denom as
+accumulated from the RGB-only moments of the fused 7-channel pass -- is accumulated for 100 iterations of Stage III beside the
+three-pass op-by-op form (the reference's structure: RGB render + its own screen-space gradient) evaluated on the SAME
+parameters every iteration, and compared.
+
+  python tools/three_stage.py [strands=500] [iters_stage1=5000] [iters_stage3=5000] > profiles/r05_three_stage.json
+"""
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "hair-gs_amd")]
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+import hgs_runtime as rt  # noqa: E402
+from arguments import OptimizationParams  # noqa: E402
+from gaussian_renderer import render  # noqa: E402
+from synthetic import attach_targets, cameras_extent, make_cameras, make_strand_model, strand_polylines  # noqa: E402
+from train import training  # noqa: E402
+from utils.general import safe_state  # noqa: E402
+
+S = int(sys.argv[1]) if len(sys.argv) > 1 else 500
+N1 = int(sys.argv[2]) if len(sys.argv) > 2 else 5000
+N3 = int(sys.argv[3]) if len(sys.argv) > 3 else 5000
+N_SEG, VIEWS, W, H = 100, 16, 800, 800
+rt.lib()
+safe_state(True)
+dev = torch.device("cuda")
+bg = torch.zeros(3, device=dev)
+log = lambda *a: print(*a, file=sys.stderr, flush=True)
+
+
+def psnr_all(model, cams):
+    with torch.no_grad():
+        v = [float(-10 * torch.log10(((render(c, model, bg)["render"].clamp(0, 1) - c.original_image) ** 2).mean())) for c in cams]
+    return sum(v) / len(v)
+
+
+def strand_metrics(model, gt_pts):
+    """precision / recall / F1 of the model's oriented points against the ground-truth strands (loss/metrics.py)."""
+    from loss.metrics import HairEvalData, compute_eval_data_from_hair_gs, compute_metrics
+    mid = 0.5 * (gt_pts[:, 1:] + gt_pts[:, :-1]).reshape(-1, 3).astype(np.float64)
+    d = (gt_pts[:, 1:] - gt_pts[:, :-1]).reshape(-1, 3).astype(np.float64)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    gt = HairEvalData(mid, d, np.repeat(np.arange(gt_pts.shape[0]), gt_pts.shape[1] - 1))
+    res, labels = compute_metrics(compute_eval_data_from_hair_gs(model), gt, bidirectional=True)
+    return {k: [float(x) for x in v] for k, v in res.items()}, [str(l) for l in labels]
+
+
+def run_stage(model, cams, opt, extent, n_iters, name):
+    traj, done, t_total = [], 0, 0.0
+    traj.append({"iteration": 0, "psnr_db": psnr_all(model, cams), "primitives": int(model.get_xyz.shape[0]), "seconds": 0.0})
+    log(name, traj[-1])
+    while done < n_iters:
+        n = min(500, n_iters - done)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        training(model, cams, opt, iterations=n, extent=extent, start_iteration=done)
+        torch.cuda.synchronize()
+        t_total += time.perf_counter() - t0
+        done += n
+        traj.append({"iteration": done, "psnr_db": psnr_all(model, cams), "primitives": int(model.get_xyz.shape[0]),
+                     "seconds": t_total})
+        log(name, traj[-1])
+    return traj, t_total
+
+
+def densify_inputs_check(model, cams, opt, extent, iters=100):
+    """xyz_gradient_accum / denom / max_radii2D over `iters` iterations: the fused 7-channel iteration (RGB-only moments of the
+    single pass, statistics folded into the backward's lanes) against the three-pass op-by-op form -- render() + loss_function +
+    update_densification_stats, the reference's structure -- evaluated on the same parameters each iteration (only the fused
+    iteration's Adam step is applied)."""
+    import copy
+    from hgs_runtime.strand_step import ViewTable, fused_step_for
+    from loss.losses import loss_function
+    from train import ViewSampler, training_step
+    o = copy.copy(opt)
+    o.enable_topology = False
+    views = ViewTable(cams)
+    fused = fused_step_for(model, views, o, bg)
+    keep = [t.clone() for t in (model.max_radii2D, model.xyz_gradient_accum, model.denom)]
+    acc3 = [torch.zeros_like(t) for t in keep]
+    for t in (model.max_radii2D, model.xyz_gradient_accum, model.denom):
+        t.zero_()
+    sampler = ViewSampler(cams, seed=7)
+    for it in range(1, iters + 1):
+        cam = sampler.next()
+        # three passes on the CURRENT parameters, statistics into acc3, gradients discarded
+        model.optimizer.zero_grad(set_to_none=True)
+        pkg = render(cam, model, bg)
+        loss, _ = loss_function(model, pkg["render"], cam, o)
+        loss.backward()
+        with torch.no_grad():
+            fused_stats = [t.clone() for t in (model.max_radii2D, model.xyz_gradient_accum, model.denom)]
+            for t, a in zip((model.max_radii2D, model.xyz_gradient_accum, model.denom), acc3):
+                t.copy_(a)
+            model.update_densification_stats(pkg["viewspace_points"], pkg["radii"], pkg["visibility_filter"])
+            for t, a, f in zip((model.max_radii2D, model.xyz_gradient_accum, model.denom), acc3, fused_stats):
+                a.copy_(t)
+                t.copy_(f)
+        model.optimizer.zero_grad(set_to_none=True)
+        training_step(model, cam, o, bg, it, extent=extent, fused=fused)          # fused statistics + the Adam step
+    torch.cuda.synchronize()
+    fz = [t.clone() for t in (model.max_radii2D, model.xyz_gradient_accum, model.denom)]
+    for t, k in zip((model.max_radii2D, model.xyz_gradient_accum, model.denom), keep):
+        t.copy_(k)
+    out = {"iterations": iters, "segments": int(fz[0].shape[0])}
+    for name, a, b in zip(("max_radii2D", "xyz_gradient_accum", "denom"), fz, acc3):
+        a, b = a.reshape(-1).double(), b.reshape(-1).double()
+        out[name] = {"max_abs_diff": float((a - b).abs().max()), "max_rel_diff_of_scale": float((a - b).abs().max() / b.abs().max().clamp(min=1e-30)),
+                     "identical": bool(torch.equal(a, b))}
+    vis = acc3[2].reshape(-1) > 0
+    ratio_f = (fz[1].reshape(-1)[vis] / fz[2].reshape(-1)[vis]).double()
+    ratio_3 = (acc3[1].reshape(-1)[vis] / acc3[2].reshape(-1)[vis]).double()
+    out["grads_ratio_max_rel_diff_of_scale"] = float((ratio_f - ratio_3).abs().max() / ratio_3.abs().max())
+    thr = float(opt.densify_grad_threshold)
+    out["selected_by_threshold"] = {"fused": int((ratio_f >= thr).sum()), "three_pass": int((ratio_3 >= thr).sum()),
+                                    "differ": int(((ratio_f >= thr) != (ratio_3 >= thr)).sum())}
+    return out
+
+
+# ---- ground truth and targets
+gt_pts = strand_polylines(S, N_SEG, seed=0)
+cams = make_cameras(VIEWS, W, H, device=dev)
+extent = cameras_extent(cams)
+gt_model = make_strand_model(S, N_SEG, seed=0, device=dev, spatial_lr_scale=extent)
+attach_targets(cams, gt_model, seed=0, perturb=0.0, consistent=True)
+out = {"ground_truth": {"strands": S, "segments": S * N_SEG, "views": VIEWS, "width": W, "height": H},
+       "protocol": __doc__.split("PSNR (mean")[0].strip().splitlines()[0]}
+
+# ---- Stage I
+from scene.gaussian_model import GaussianModel  # noqa: E402
+from utils.graphics import BasicPointCloud  # noqa: E402
+rng = np.random.default_rng(1)
+mid = 0.5 * (gt_pts[:, 1:] + gt_pts[:, :-1]).reshape(-1, 3)
+pts = (mid + rng.normal(size=mid.shape) * 0.002).astype(np.float32)
+with torch.no_grad():
+    from utils.sh import SH2RGB
+    gt_rgb = SH2RGB(gt_model._features_dc.detach()[:, 0]).clamp(0, 1).cpu().numpy()
+cloud = GaussianModel(sh_degree=0, spatial_lr_scale=extent, device=dev)
+cloud.create_from_pcd(BasicPointCloud(points=pts, colors=np.clip(gt_rgb + rng.normal(size=gt_rgb.shape) * 0.1, 0, 1).astype(np.float32),
+                                      normals=np.zeros_like(pts)))
+cloud.ref_strand_root = gt_pts[:, 0].astype(np.float64)
+opt1 = OptimizationParams()
+opt1.iterations = N1
+opt1._finalise()
+cloud.training_setup(opt1)
+traj1, t1 = run_stage(cloud, cams, opt1, extent, N1, "stage I")
+out["stage_I"] = {"iterations": N1, "seconds": t1, "its_per_sec": N1 / t1, "trajectory": traj1}
+
+# ---- Stage II
+from merge import merge_rounds  # noqa: E402
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+hair = cloud.to_hair_gaussian_model()
+n_before = int(hair.strands_info.n_strands)
+rounds = merge_rounds(hair, 100, log=log)
+torch.cuda.synchronize()
+t2 = time.perf_counter() - t0
+m2, labels = strand_metrics(hair, gt_pts)
+out["stage_II"] = {"seconds": t2, "merge_rounds": rounds, "segments": int(hair.get_xyz.shape[0]), "strands_before": n_before,
+                   "strands_after": int(hair.strands_info.n_strands), "psnr_db": psnr_all(hair, cams), "metrics": m2,
+                   "metric_thresholds": labels}
+log("stage II", {k: v for k, v in out["stage_II"].items() if k != "metrics"})
+
+# ---- Stage III
+opt3 = OptimizationParams()
+opt3.iterations = N3
+opt3._finalise()
+hair.training_setup(opt3)
+out["densify_inputs"] = densify_inputs_check(hair, cams, opt3, extent)
+log("densify inputs", out["densify_inputs"])
+hair.training_setup(opt3)          # (the check's 100 Adam steps are part of the model now; fresh optimizer state and schedule)
+traj3, t3 = run_stage(hair, cams, opt3, extent, N3, "stage III")
+m3, _ = strand_metrics(hair, gt_pts)
+out["stage_III"] = {"iterations": N3, "seconds": t3, "its_per_sec": N3 / t3, "trajectory": traj3, "metrics": m3,
+                    "strands": int(hair.strands_info.n_strands) if hair.strands_info is not None else None,
+                    "rollbacks": getattr(training, "last_rollbacks", None)}
+out["summary"] = {"psnr_db": {"stage_I_start": traj1[0]["psnr_db"], "stage_I_end": traj1[-1]["psnr_db"],
+                              "after_merge": out["stage_II"]["psnr_db"], "stage_III_start": traj3[0]["psnr_db"],
+                              "stage_III_best": max(p["psnr_db"] for p in traj3), "stage_III_end": traj3[-1]["psnr_db"]},
+                  "stage_III_ends_better_than_it_starts": traj3[-1]["psnr_db"] > traj3[0]["psnr_db"],
+                  "wall_seconds": {"stage_I": t1, "stage_II": t2, "stage_III": t3}}
+print(json.dumps(out, indent=1))
