@@ -1382,6 +1382,58 @@ def test_fused_cloud_parameter_backward_equals_two_launches():
             assert bool(a[3].abs().sum() > 0)
 
 
+def test_densification_inputs_of_the_fused_pass_equal_the_three_pass_form():
+    """The one input of densification() that no reference run pins: xyz_gradient_accum / denom /
+    max_radii2D as the fused iteration accumulates them -- from the RGB-only moments of the single 7-channel pass, in the lanes of
+    the rasterizer backward (hgs_backward_multi_params) -- against the reference's structure: render() (the RGB pass and ITS
+    screen-space gradient), loss_function with its two more passes, update_densification_stats (scene/hair_gaussian_model.py:
+    1401-1408, train.py:170).  Both forms see the same parameters in every one of 40 training iterations (the fused iteration's
+    Adam step moves them); the accumulated statistics agree to 1e-5 of their scale and select the same segments at the clone /
+    split threshold.  (tools/three_stage.py runs the same check on a 100 k-segment Stage-II model: profiles/r05_three_stage.json.)"""
+    import copy
+    from arguments import OptimizationParams
+    from gaussian_renderer import render
+    from hgs_runtime.strand_step import ViewTable, fused_step_for
+    from loss.losses import loss_function
+    from synthetic import build_workload
+    from train import ViewSampler, training_step
+    model, cams, extent = build_workload("tiny", device="cuda", with_targets=True)
+    opt = OptimizationParams()
+    opt.enable_topology = False
+    model.training_setup(opt)
+    bg = torch.zeros(3, device="cuda")
+    fused = fused_step_for(model, ViewTable(cams), opt, bg)
+    stats = (model.max_radii2D, model.xyz_gradient_accum, model.denom)
+    acc3 = [torch.zeros_like(t) for t in stats]
+    sampler = ViewSampler(cams, seed=7)
+    for it in range(1, 41):
+        cam = sampler.next()
+        model.optimizer.zero_grad(set_to_none=True)
+        pkg = render(cam, model, bg)
+        loss, _ = loss_function(model, pkg["render"], cam, opt)
+        loss.backward()
+        with torch.no_grad():
+            mine = [t.clone() for t in stats]
+            for t, a in zip(stats, acc3):
+                t.copy_(a)
+            model.update_densification_stats(pkg["viewspace_points"], pkg["radii"], pkg["visibility_filter"])
+            for t, a, f in zip(stats, acc3, mine):
+                a.copy_(t)
+                t.copy_(f)
+        model.optimizer.zero_grad(set_to_none=True)
+        training_step(model, cam, opt, bg, it, extent=extent, fused=fused)
+        assert fused.last["stats_done"]
+    for name, a, b in zip(("max_radii2D", "xyz_gradient_accum", "denom"), stats, acc3):
+        assert float(b.abs().max()) > 0
+        assert float((a - b).abs().max()) <= 1e-5 * float(b.abs().max()), name
+    seen = acc3[2].reshape(-1) > 0
+    gf = (stats[1].reshape(-1)[seen] / stats[2].reshape(-1)[seen])
+    g3 = (acc3[1].reshape(-1)[seen] / acc3[2].reshape(-1)[seen])
+    thr = float(opt.densify_grad_threshold)
+    near = (g3 - thr).abs() <= 1e-5 * thr             # (a segment exactly at the threshold may fall either way)
+    assert bool(((gf >= thr) == (g3 >= thr))[~near].all()) and int(seen.sum()) > 100
+
+
 def test_replays_after_a_blocking_pass_on_the_same_views():
     """The captured step's first launch counts into the image buffer's tile counters beside the workgroups that clear the other
     counters, so it needs them at zero -- which capacity-mode passes leave behind and a blocking-mode pass does not.  A blocking

@@ -8,7 +8,10 @@ BASELINE.json size, timed and scored per stage (BASELIN
                 a sparse reconstruction hands train.py -- optimised with the reference's Stage-I loop: densify_and_clone /
                 split / prune every 100 iterations from 500, opacity reset every 3000 (train.training, FusedCloudStep)
   Stage II      to_hair_gaussian_model + merge rounds until nothing is left to merge (merge.merge_rounds)
-  Stage III     the strand model optimised WITH the topology operators (densification, merging, opacity reset)
+  Stage III     the strand model optimised WITH the topology operators (densification, merging, opacity reset) -- and, from the
+                same Stage-II model (the deterministic pipeline run again), WITHOUT them, so that what the operators do to the
+                image error on this capture can be read off: the two trajectories, and for the first events of the run with
+                operators the PSNR right before and right after each densification (`events`)
 
 PSNR (mean over all views against the targets), primitive count and wall time are recorded every 500 iterations; strand
 metrics (loss/metrics.py compute_metrics against the ground-truth strands) at the end of stages II and III.
@@ -19,10 +22,13 @@ parameters every iteration, and compared.
 
   python tools/three_stage.py [strands=500] [iters_stage1=5000] [iters_stage3=5000] > profiles/r05_three_stage.json
 """
+import faulthandler
 import json
 import os
 import sys
 import time
+
+faulthandler.enable()
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "hair-gs_amd")]
@@ -142,60 +148,112 @@ cams = make_cameras(VIEWS, W, H, device=dev)
 extent = cameras_extent(cams)
 gt_model = make_strand_model(S, N_SEG, seed=0, device=dev, spatial_lr_scale=extent)
 attach_targets(cams, gt_model, seed=0, perturb=0.0, consistent=True)
-out = {"ground_truth": {"strands": S, "segments": S * N_SEG, "views": VIEWS, "width": W, "height": H},
-       "protocol": __doc__.split("PSNR (mean")[0].strip().splitlines()[0]}
+out = {"ground_truth": {"strands": S, "segments": S * N_SEG, "views": VIEWS, "width": W, "height": H,
+                        "psnr_db_of_the_ground_truth_model": psnr_all(gt_model, cams)}}
 
-# ---- Stage I
+from merge import merge_rounds  # noqa: E402
 from scene.gaussian_model import GaussianModel  # noqa: E402
 from utils.graphics import BasicPointCloud  # noqa: E402
-rng = np.random.default_rng(1)
-mid = 0.5 * (gt_pts[:, 1:] + gt_pts[:, :-1]).reshape(-1, 3)
-pts = (mid + rng.normal(size=mid.shape) * 0.002).astype(np.float32)
-with torch.no_grad():
-    from utils.sh import SH2RGB
-    gt_rgb = SH2RGB(gt_model._features_dc.detach()[:, 0]).clamp(0, 1).cpu().numpy()
-cloud = GaussianModel(sh_degree=0, spatial_lr_scale=extent, device=dev)
-cloud.create_from_pcd(BasicPointCloud(points=pts, colors=np.clip(gt_rgb + rng.normal(size=gt_rgb.shape) * 0.1, 0, 1).astype(np.float32),
-                                      normals=np.zeros_like(pts)))
-cloud.ref_strand_root = gt_pts[:, 0].astype(np.float64)
-opt1 = OptimizationParams()
-opt1.iterations = N1
-opt1._finalise()
-cloud.training_setup(opt1)
-traj1, t1 = run_stage(cloud, cams, opt1, extent, N1, "stage I")
-out["stage_I"] = {"iterations": N1, "seconds": t1, "its_per_sec": N1 / t1, "trajectory": traj1}
+from utils.sh import SH2RGB  # noqa: E402
 
-# ---- Stage II
-from merge import merge_rounds  # noqa: E402
-torch.cuda.synchronize()
-t0 = time.perf_counter()
-hair = cloud.to_hair_gaussian_model()
-n_before = int(hair.strands_info.n_strands)
-rounds = merge_rounds(hair, 100, log=log)
-torch.cuda.synchronize()
-t2 = time.perf_counter() - t0
-m2, labels = strand_metrics(hair, gt_pts)
-out["stage_II"] = {"seconds": t2, "merge_rounds": rounds, "segments": int(hair.get_xyz.shape[0]), "strands_before": n_before,
-                   "strands_after": int(hair.strands_info.n_strands), "psnr_db": psnr_all(hair, cams), "metrics": m2,
-                   "metric_thresholds": labels}
-log("stage II", {k: v for k, v in out["stage_II"].items() if k != "metrics"})
 
-# ---- Stage III
-opt3 = OptimizationParams()
-opt3.iterations = N3
-opt3._finalise()
+def stages_one_and_two(record):
+    """Stage I + II (deterministic: the second call reproduces the first model bit for bit)."""
+    rng = np.random.default_rng(1)
+    mid = 0.5 * (gt_pts[:, 1:] + gt_pts[:, :-1]).reshape(-1, 3)
+    pts = (mid + rng.normal(size=mid.shape) * 0.002).astype(np.float32)
+    with torch.no_grad():
+        gt_rgb = SH2RGB(gt_model._features_dc.detach()[:, 0]).clamp(0, 1).cpu().numpy()
+    cloud = GaussianModel(sh_degree=0, spatial_lr_scale=extent, device=dev)
+    cloud.create_from_pcd(BasicPointCloud(points=pts, colors=np.clip(gt_rgb + rng.normal(size=gt_rgb.shape) * 0.1, 0, 1).astype(np.float32),
+                                          normals=np.zeros_like(pts)))
+    cloud.ref_strand_root = gt_pts[:, 0].astype(np.float64)
+    opt1 = OptimizationParams()
+    opt1.iterations = N1
+    opt1._finalise()
+    cloud.training_setup(opt1)
+    if record:
+        traj1, t1 = run_stage(cloud, cams, opt1, extent, N1, "stage I")
+        out["stage_I"] = {"iterations": N1, "seconds": t1, "its_per_sec": N1 / t1, "trajectory": traj1}
+    else:
+        training(cloud, cams, opt1, iterations=N1, extent=extent, start_iteration=0)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    hair = cloud.to_hair_gaussian_model()
+    n_before = int(hair.strands_info.n_strands)
+    rounds = merge_rounds(hair, 100, log=log if record else (lambda *a: None))
+    torch.cuda.synchronize()
+    t2 = time.perf_counter() - t0
+    if record:
+        m2, labels = strand_metrics(hair, gt_pts)
+        out["stage_II"] = {"seconds": t2, "merge_rounds": rounds, "segments": int(hair.get_xyz.shape[0]), "strands_before": n_before,
+                           "strands_after": int(hair.strands_info.n_strands), "psnr_db": psnr_all(hair, cams), "metrics": m2,
+                           "metric_thresholds": labels}
+        log("stage II", {k: v for k, v in out["stage_II"].items() if k != "metrics"})
+    return hair
+
+
+def stage_three_options(topology):
+    opt3 = OptimizationParams()
+    opt3.iterations = N3
+    opt3._finalise()
+    opt3.enable_topology = topology
+    return opt3
+
+
+# ---- Stage I, II, then III with the operators
+hair = stages_one_and_two(True)
+opt3 = stage_three_options(True)
 hair.training_setup(opt3)
-out["densify_inputs"] = densify_inputs_check(hair, cams, opt3, extent)
-log("densify inputs", out["densify_inputs"])
-hair.training_setup(opt3)          # (the check's 100 Adam steps are part of the model now; fresh optimizer state and schedule)
+state_digest = float(hair._endpoints.detach().double().sum())
 traj3, t3 = run_stage(hair, cams, opt3, extent, N3, "stage III")
 m3, _ = strand_metrics(hair, gt_pts)
 out["stage_III"] = {"iterations": N3, "seconds": t3, "its_per_sec": N3 / t3, "trajectory": traj3, "metrics": m3,
                     "strands": int(hair.strands_info.n_strands) if hair.strands_info is not None else None,
                     "rollbacks": getattr(training, "last_rollbacks", None)}
-out["summary"] = {"psnr_db": {"stage_I_start": traj1[0]["psnr_db"], "stage_I_end": traj1[-1]["psnr_db"],
+del hair
+torch.cuda.empty_cache()
+
+# ---- the same Stage-II model again: the densification inputs, Stage III WITHOUT the operators, and the first events one by one
+hair = stages_one_and_two(False)
+assert float(hair._endpoints.detach().double().sum()) == state_digest, "the pipeline is not deterministic"
+hair.training_setup(stage_three_options(True))
+out["densify_inputs"] = densify_inputs_check(hair, cams, stage_three_options(True), extent)
+log("densify inputs", out["densify_inputs"])
+del hair
+hair = stages_one_and_two(False)
+opt3n = stage_three_options(False)
+hair.training_setup(opt3n)
+traj3n, t3n = run_stage(hair, cams, opt3n, extent, N3, "stage III without operators")
+m3n, _ = strand_metrics(hair, gt_pts)
+out["stage_III_without_operators"] = {"iterations": N3, "seconds": t3n, "its_per_sec": N3 / t3n, "trajectory": traj3n, "metrics": m3n}
+del hair
+hair = stages_one_and_two(False)
+opt3 = stage_three_options(True)
+hair.training_setup(opt3)
+events, done = [], 0
+first_event = (int(opt3.densify_from_iter) // 100 + 1) * 100
+training(hair, cams, opt3, iterations=first_event - 1, extent=extent, start_iteration=0)
+done = first_event - 1
+for k in range(8):
+    before = {"iteration": done, "psnr_db": psnr_all(hair, cams), "segments": int(hair.get_xyz.shape[0]),
+              "opacity_sum": float(hair.get_opacity.sum())}
+    training(hair, cams, opt3, iterations=1, extent=extent, start_iteration=done)          # the iteration with the operators
+    done += 1
+    after = {"iteration": done, "psnr_db": psnr_all(hair, cams), "segments": int(hair.get_xyz.shape[0]),
+             "opacity_sum": float(hair.get_opacity.sum())}
+    training(hair, cams, opt3, iterations=99, extent=extent, start_iteration=done)
+    done += 99
+    events.append({"before": before, "after": after, "psnr_change_by_the_event_db": after["psnr_db"] - before["psnr_db"],
+                   "psnr_99_iterations_later_db": psnr_all(hair, cams)})
+    log("event", events[-1])
+out["events"] = events
+out["summary"] = {"psnr_db": {"stage_I_start": out["stage_I"]["trajectory"][0]["psnr_db"], "stage_I_end": out["stage_I"]["trajectory"][-1]["psnr_db"],
                               "after_merge": out["stage_II"]["psnr_db"], "stage_III_start": traj3[0]["psnr_db"],
-                              "stage_III_best": max(p["psnr_db"] for p in traj3), "stage_III_end": traj3[-1]["psnr_db"]},
+                              "stage_III_best": max(p["psnr_db"] for p in traj3), "stage_III_end": traj3[-1]["psnr_db"],
+                              "stage_III_without_operators_end": traj3n[-1]["psnr_db"]},
                   "stage_III_ends_better_than_it_starts": traj3[-1]["psnr_db"] > traj3[0]["psnr_db"],
-                  "wall_seconds": {"stage_I": t1, "stage_II": t2, "stage_III": t3}}
+                  "stage_III_without_operators_ends_better_than_it_starts": traj3n[-1]["psnr_db"] > traj3n[0]["psnr_db"],
+                  "mean_psnr_change_by_a_densification_event_db": sum(e["psnr_change_by_the_event_db"] for e in events) / len(events),
+                  "wall_seconds": {"stage_I": out["stage_I"]["seconds"], "stage_II": out["stage_II"]["seconds"], "stage_III": t3}}
 print(json.dumps(out, indent=1))
