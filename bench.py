@@ -491,15 +491,20 @@ def main():
             rt.prof_collect()
             rt.prof_enable(True)
             kern_steps = min(args.steps, 50)
+            # (the same form of the step as the timed graph holds: Adam in the backward's lanes where that is what was captured)
+            inline = fused is not None and use_graph and gs.inline_adam and fused.enable_inline_adam(True)
             for _ in range(kern_steps):
                 it += 1
                 training_step(model, sampler.next(), opt, bg, it, extent=extent, vp=vp, fused=fused)
+            if inline:
+                fused.enable_inline_adam(False)
             sync_all()
             kern = rt.prof_collect()
             rt.prof_enable(False)
 
         return dict(dt=dt, regions=regions, sustained=sustained, kern=kern, kern_steps=kern_steps if kern else 0,
                     steps_per_graph=(gs.steps_per_graph if use_graph else None), fused=fused,
+                    inline_adam=bool(use_graph and gs.inline_adam),
                     collective_captured=(gs.collective_captured if use_graph else False))
 
     head = measure(0, args.sustained_seconds > 0, not args.no_kernel_timing)
@@ -664,6 +669,8 @@ def main():
                    "dispatch": "hip-graph replay" if use_graph else "eager",
                    "optimizer_steps_per_graph_launch": head["steps_per_graph"],
                    "iteration": "fused iteration" if fused is not None else "op-by-op",
+                   # True: no optimizer launch -- the backward's lanes apply Adam to the elements whose gradient they finish
+                   "adam_in_backward_lanes": head["inline_adam"],
                    "raster_passes_per_iter": 1 if getattr(opt, "single_pass", True) else 3},
         "render_ms_per_view": render_ms,                       # render(): the drop-in call, eager, ~20 host-side tensor ops per view
         "render_ms_per_view_frame_renderer": fs["render_graph_ms"],   # gaussian_renderer.frames: the same frames as one graph per view

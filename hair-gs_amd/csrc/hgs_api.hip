@@ -232,7 +232,8 @@ static int forward_preprocess_impl(void* stream, int P, int D, int M, int W, int
     return 1;
   }
   if (P == 0 && rider &&     // nothing to ride on: the prologue as a launch of its own
-      hgs_iteration_prologue(stream, rider->table, rider->view, rider->slot, rider->lr, rider->lr_dst, rider->zero_ptr, rider->zero_bytes)) return 1;
+      hgs_iteration_prologue(stream, rider->table, rider->view, rider->slot, rider->lr, rider->lr_dst, rider->zero_ptr, rider->zero_bytes,
+                             rider->adam_prep)) return 1;
   if (P == 0) {  // reference short-circuits P == 0 (rasterize_points.cu:81); the scan of all-zero counts writes the
     HgsGeom none = {};  // empty ranges and the tile order the blend kernel (background fill) indexes with
     if (hgs_launch_scan(s, 0, T, none, im, nullptr)) return 1;
@@ -375,6 +376,16 @@ static int backward_impl(void* stream, int P, int D, int M, int R, int W, int H,
 }
 
 size_t hgs_param_backward_bytes(void) { return sizeof(HgsParamBackward); }
+size_t hgs_adam_prep_bytes(void) { return sizeof(HgsAdamPrep); }
+size_t hgs_adam_inline_bytes(void) { return sizeof(HgsAdamInline); }
+static int check_adam_inline(const HgsAdamInline& a, int n_slots, const char* who) {
+  for (int k = 0; k < 6; k++) {
+    const HgsAdamSlot& sl = a.slot[k];
+    if (!sl.p) continue;
+    if (k >= n_slots || !sl.m || !sl.v || !sl.coef) { hgs_set_error("%s: incomplete Adam slot %d", who, k); return 1; }
+  }
+  return 0;
+}
 int hgs_backward_multi_params(void* stream, int P, int D, int M, int R, int W, int H, const float* bg7, const float* means3D,
                               const float* shs, const float* scales, const float* rotations, const float* viewmatrix,
                               const float* projmatrix, const float* campos, float tan_fovx, float tan_fovy, const int* radii,
@@ -398,6 +409,7 @@ int hgs_backward_multi_params(void* stream, int P, int D, int M, int R, int W, i
              ((size_t)pb->d_rotation_raw & 15)) {
     hgs_set_error("hgs_backward_multi_params: null (or, rotation_raw / d_rotation_raw, unaligned) cloud argument"); return 1;
   }
+  if (check_adam_inline(pb->adam, pb->kind == HGS_PARAMS_HAIR ? 4 : 6, "hgs_backward_multi_params")) return 1;
   HgsParamBackward p = *pb;
   return backward_impl(stream, P, D, M, R, W, H, bg7, means3D, shs, nullptr, scales, 1.f, rotations, nullptr, viewmatrix,
                        projmatrix, campos, tan_fovx, tan_fovy, radii, geom_buf, binning_buf, image_buf, dL_dpix_planes7, scratch,
@@ -506,11 +518,11 @@ size_t hgs_head_params_bytes(void) { return sizeof(HgsHeadParams); }
 size_t hgs_strand_fusion_bytes(void) { return sizeof(HgsStrandFusion); }
 
 int hgs_iteration_prologue(void* stream, const HgsViewTargets* table, int view, HgsViewTargets* slot, float lr, float* lr_dst,
-                           void* zero_ptr, size_t zero_bytes) {
+                           void* zero_ptr, size_t zero_bytes, const HgsAdamPrep* adam_prep) {
   if (!table || !slot || view < 0) { hgs_set_error("hgs_iteration_prologue: bad arguments"); return 1; }
   if (((size_t)zero_ptr & 3) || (zero_bytes & 3) || (zero_bytes && !zero_ptr)) { hgs_set_error("hgs_iteration_prologue: zero range must be 4-byte multiples"); return 1; }
   hipStream_t s = (hipStream_t)stream;
-  const HgsPrologue p = {table, view, slot, lr, lr_dst, zero_ptr, zero_bytes};
+  const HgsPrologue p = {table, view, slot, lr, lr_dst, zero_ptr, zero_bytes, adam_prep};
   {
     HgsProfScope _prof(s, HGS_K_MISC);
     hipLaunchKernelGGL(select_view_kernel, dim3(hgs_prologue_blocks(zero_bytes / 4)), dim3(256), 0, s, p);
@@ -519,7 +531,7 @@ int hgs_iteration_prologue(void* stream, const HgsViewTargets* table, int view, 
   return 0;
 }
 int hgs_select_view(void* stream, const HgsViewTargets* table, int view, HgsViewTargets* slot, float lr, float* lr_dst) {
-  return hgs_iteration_prologue(stream, table, view, slot, lr, lr_dst, nullptr, 0);
+  return hgs_iteration_prologue(stream, table, view, slot, lr, lr_dst, nullptr, 0, nullptr);
 }
 
 // ---- re-pointing the prologue node of a captured graph ----------------------------------------------------------------
@@ -575,7 +587,8 @@ int hgs_graph_set_prologue(void* graph_exec, void* node, const HgsViewTargets* t
     hgs_set_error("hgs_graph_set_prologue: the zero range differs from the captured one");
     return 1;
   }
-  HgsPrologue p = {table, view, slot, lr, lr_dst, zero_ptr, zero_bytes};
+  HgsPrologue p = {table, view, slot, lr, lr_dst, zero_ptr, zero_bytes,
+                   ((const HgsPrologue*)kp.kernelParams[n_params - 1])->adam_prep};   // (what the node was captured with)
   void* args[32];
   for (int i = 0; i < n_params - 1; i++) args[i] = kp.kernelParams[i];
   args[n_params - 1] = &p;

@@ -9,6 +9,7 @@
 //     iteration) of loss/losses.py:175-221 angle_smoothness_loss.
 #include "hgs_common.h"
 #include "hgs_smooth.h"
+#include "hgs_adam.h"
 
 namespace {
 
@@ -37,12 +38,8 @@ struct AdamTensors {
 // fallback ticket words for callers that pass none (tickets == NULL): launches that share them must be stream-ordered
 __device__ unsigned int g_adam_ticket[ADAM_MAX_TENSORS] = {};
 
-__device__ __forceinline__ void adam_one(float& p, float g, float& m, float& v, float one_m_b1, float beta2, float step_size,
-                                         float inv_sqrt_bc2, float eps) {
-  m = m + (g - m) * one_m_b1;                                            // lerp, like torch
-  v = beta2 * v + (1.f - beta2) * g * g;
-  p -= step_size * (m / (sqrtf(v) * inv_sqrt_bc2 + eps));
-}
+// (the update rule itself: hgs_adam.h -- shared with the backward kernels that apply it in their own lanes)
+#define adam_one hgs_adam_one
 
 // One tensor per workgroup (uniform index: the bias corrections -- two powf -- and the learning rate are evaluated once
 // per thread, not once per element), 128-bit accesses where the arrays are aligned.
@@ -51,8 +48,8 @@ __global__ __launch_bounds__(256) void adam_kernel(AdamTensors t, float beta1, f
 #pragma unroll
   for (int j = 1; j < ADAM_MAX_TENSORS; j++) k += (j < t.n && blockIdx.x >= t.blk_start[j]) ? 1 : 0;
   const float step = *t.step[k] + 1.0f;  // (the counters themselves are advanced by the last workgroup to finish, below)
-  const float bc1 = 1.f - powf(beta1, step), bc2 = 1.f - powf(beta2, step);
-  const float step_size = *t.lr[k] / bc1, inv_sqrt_bc2 = 1.f / sqrtf(bc2), one_m_b1 = 1.f - beta1;
+  const HgsAdamCoef cf = hgs_adam_coef(*t.lr[k], step, beta1, beta2);
+  const float step_size = cf.step_size, inv_sqrt_bc2 = cf.inv_sqrt_bc2, one_m_b1 = 1.f - beta1;
   const unsigned long long n = t.numel[k];
   const unsigned long long base = (unsigned long long)(blockIdx.x - t.blk_start[k]) * t.elems;
   float* __restrict__ P = t.p[k];

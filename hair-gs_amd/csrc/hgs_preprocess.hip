@@ -703,6 +703,7 @@ __global__ __launch_bounds__(HGS_BLOCK) __attribute__((amdgpu_waves_per_eu((MODE
   float dex[4] = {0.f, 0.f, 0.f, 0.f}, dmx_rgb = 0.f, dmy_rgb = 0.f;
   float dmean[3] = {0.f, 0.f, 0.f}, dcov[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   float dscale[3] = {0.f, 0.f, 0.f}, drot[4] = {0.f, 0.f, 0.f, 0.f};
+  float dsh_dc[3] = {0.f, 0.f, 0.f};               // gradient of the SH DC coefficient (MODE 1 / 2: the in-lane Adam update reads it)
   // this Gaussian's own data: every load issued here, before the row loop below (whose data-dependent trip count the
   // compiler will not move loads across): one memory round trip for all of it instead of one per dependent stage
   const bool vis = a.radii[idx] > 0 && !void_pass;
@@ -877,6 +878,8 @@ __global__ __launch_bounds__(HGS_BLOCK) __attribute__((amdgpu_waves_per_eu((MODE
 #define SHC(k, ch) sh[3 * (k) + (ch)]
 #define DSH(k, coef) { const float cf_ = (coef); dsh[3 * (k)] = cf_ * dRGB[0]; dsh[3 * (k) + 1] = cf_ * dRGB[1]; dsh[3 * (k) + 2] = cf_ * dRGB[2]; }
       DSH(0, kSH_C0);
+#pragma unroll
+      for (int ch = 0; ch < 3; ch++) dsh_dc[ch] = kSH_C0 * dRGB[ch];
       if (D > 0) {
         DSH(1, -kSH_C1 * y); DSH(2, kSH_C1 * z); DSH(3, -kSH_C1 * x);
 #pragma unroll
@@ -1005,9 +1008,18 @@ __global__ __launch_bounds__(HGS_BLOCK) __attribute__((amdgpu_waves_per_eu((MODE
     float4* sc = (float4*)pb.seg_contrib + 2 * (size_t)idx;
     sc[0] = make_float4(h[0] - gD[0], h[1] - gD[1], h[2] - gD[2], 0.f);
     sc[1] = make_float4(h[0] + gD[0], h[1] + gD[1], h[2] + gD[2], 0.f);
-    pb.d_width[idx] = (dscale[1] + dscale[2]) * s_pre[1];            // scale.y = exp(width): the forward's own value
-    pb.d_opacity_raw[idx] = dop * o_act * (1.f - o_act);             // sigmoid'
-    pb.d_mask_raw[idx] = dex[0] * mask_pre * (1.f - mask_pre);
+    const float g_w = (dscale[1] + dscale[2]) * s_pre[1];            // scale.y = exp(width): the forward's own value
+    const float g_o = dop * o_act * (1.f - o_act);                   // sigmoid'
+    const float g_m = dex[0] * mask_pre * (1.f - mask_pre);
+    pb.d_width[idx] = g_w;
+    pb.d_opacity_raw[idx] = g_o;
+    pb.d_mask_raw[idx] = g_m;
+    // Adam in the lane (include/hgs.h HgsAdamSlot): every gradient of this Gaussian's own parameters is final here, and nothing
+    // else in the launch reads the raw parameters (the lane itself works on the forward's activations)
+    hgs_adam_lane<1>(pb.adam.slot[0], (size_t)idx, &g_w, pb.adam.beta1, pb.adam.beta2, pb.adam.eps);
+    hgs_adam_lane<1>(pb.adam.slot[1], (size_t)idx, &g_o, pb.adam.beta1, pb.adam.beta2, pb.adam.eps);
+    hgs_adam_lane<1>(pb.adam.slot[2], (size_t)idx, &g_m, pb.adam.beta1, pb.adam.beta2, pb.adam.eps);
+    hgs_adam_lane<3>(pb.adam.slot[3], (size_t)idx, dsh_dc, pb.adam.beta1, pb.adam.beta2, pb.adam.eps);
   } else {
     const HgsCloudParamGrads cg = hgs_cloud_param_grads(s_pre[0], s_pre[1], s_pre[2], raw_rot_pre, o_act, mask_pre, dscale,
                                                         make_float4(drot[0], drot[1], drot[2], drot[3]), dop,
@@ -1017,6 +1029,13 @@ __global__ __launch_bounds__(HGS_BLOCK) __attribute__((amdgpu_waves_per_eu((MODE
     ((float4*)pb.d_rotation_raw)[idx] = cg.d_r;
     pb.d_opacity_raw[idx] = cg.d_o;
     pb.d_mask_raw[idx] = cg.d_m;
+    const float g_r[4] = {cg.d_r.x, cg.d_r.y, cg.d_r.z, cg.d_r.w};
+    hgs_adam_lane<3>(pb.adam.slot[0], (size_t)idx, dmean, pb.adam.beta1, pb.adam.beta2, pb.adam.eps);
+    hgs_adam_lane<3>(pb.adam.slot[1], (size_t)idx, cg.d_s, pb.adam.beta1, pb.adam.beta2, pb.adam.eps);
+    hgs_adam_lane<4>(pb.adam.slot[2], (size_t)idx, g_r, pb.adam.beta1, pb.adam.beta2, pb.adam.eps);
+    hgs_adam_lane<1>(pb.adam.slot[3], (size_t)idx, &cg.d_o, pb.adam.beta1, pb.adam.beta2, pb.adam.eps);
+    hgs_adam_lane<1>(pb.adam.slot[4], (size_t)idx, &cg.d_m, pb.adam.beta1, pb.adam.beta2, pb.adam.eps);
+    hgs_adam_lane<3>(pb.adam.slot[5], (size_t)idx, dsh_dc, pb.adam.beta1, pb.adam.beta2, pb.adam.eps);
   }
 }
 

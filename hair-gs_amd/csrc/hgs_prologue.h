@@ -3,6 +3,7 @@
 // parameter forward kernels that run it in spare workgroups of the iteration's first launch (hgs_strands.hip).
 #pragma once
 #include "hgs_common.h"
+#include "hgs_adam.h"
 
 __host__ __device__ static inline unsigned hgs_prologue_blocks(size_t zero_words) {
   const size_t b = (zero_words + 1023) / 1024;           // 4 words per thread
@@ -17,6 +18,10 @@ __device__ __forceinline__ void hgs_prologue_block(const HgsPrologue& p, unsigne
     uint32_t* dst = (uint32_t*)p.slot;
     for (int i = threadIdx.x; i < (int)(sizeof(HgsViewTargets) / 4); i += 256) dst[i] = src[i];
     if (threadIdx.x == 0 && p.lr_dst) *p.lr_dst = p.lr;
+    if (p.adam_prep) {            // an iteration whose backward updates in its lanes: step counters + coefficients (hgs_adam.h)
+      __syncthreads();            // (the position learning rate written above is one of the values read)
+      hgs_adam_prepare_block(p.adam_prep);
+    }
     return;
   }
   uint32_t* z = (uint32_t*)p.zero_ptr;

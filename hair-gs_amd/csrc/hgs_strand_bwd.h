@@ -12,6 +12,7 @@
 #include "hgs_smooth.h"
 #include "hgs_head_tail.h"
 #include "hgs_strand_fwd.h"
+#include "hgs_adam.h"
 
 #define HGS_STRAND_MINV 1e-7f
 
@@ -124,6 +125,7 @@ struct HgsStrandBwdArgs {
   // of its first endpoint in seg_contrib[2 k] and of its second in seg_contrib[2 k + 1] (h - gD, h + gD; hgs_backward_multi_params)
   // -- and this launch is the endpoint gather alone (gather mode; no per-segment workgroups)
   const float4* seg_contrib;
+  HgsAdamInline adam;   // gather-only launch: slot 0 = the endpoints' Adam state (p != NULL: the lane applies endpoint i's update)
 };
 
 // Workgroup `blk` of `nblk` (256 threads): [0, ceil(P / 256)) one lane per Gaussian; then, gather mode, one lane per
@@ -221,6 +223,9 @@ __device__ __forceinline__ void hgs_strand_bwd_block(const HgsStrandBwdArgs& A_i
         }
       }
       A.d_ep[3 * (size_t)i] = acc[0]; A.d_ep[3 * (size_t)i + 1] = acc[1]; A.d_ep[3 * (size_t)i + 2] = acc[2];
+      // Adam in the lane (include/hgs.h HgsAdamSlot): possible because nothing of this launch reads the endpoints any more --
+      // segment contributions and pair gradients arrive precomputed (round 4 still noted that the neighbouring lanes re-read them)
+      if (CONTRIB) hgs_adam_lane<3>(A.adam.slot[0], (size_t)i, acc, A.adam.beta1, A.adam.beta2, A.adam.eps);
     } else if (i < fu.n_smooth) {   // scatter mode: smoothness gradient added into d_ep with atomics
       hgs_smooth_bwd_pair(i, ep, fu.smooth_pairs, fu.cos_threshold, fu.eps, smooth_scale, A.d_ep);
     }

@@ -122,7 +122,7 @@ static int prologue_rider(void* stream, int P, const HgsPrologue& p, const char*
     hgs_set_error("%s: bad prologue group", who);
     return 1;
   }
-  if (P == 0) return hgs_iteration_prologue(stream, p.table, p.view, p.slot, p.lr, p.lr_dst, p.zero_ptr, p.zero_bytes);
+  if (P == 0) return hgs_iteration_prologue(stream, p.table, p.view, p.slot, p.lr, p.lr_dst, p.zero_ptr, p.zero_bytes, p.adam_prep);
   return 0;
 }
 
@@ -154,7 +154,7 @@ int hgs_strand_geometry_backward(void* stream, int P, int E, const float* endpoi
   {
     HgsProfScope _prof(s, HGS_K_STRAND_BWD);
     const HgsStrandBwdArgs A = {P, endpoints, endpoint_pairs, width, dist_to_scale_factor, g_xyz, g_scale, g_quat, g_dir,
-                                d_endpoints, d_width, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, HgsStrandFusion{}, nullptr};
+                                d_endpoints, d_width, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, HgsStrandFusion{}, nullptr, HgsAdamInline{}};
     hipLaunchKernelGGL(strand_bwd_kernel, dim3((P + 255) / 256), dim3(256), 0, s, A);
   }
   HGS_CHECK_LAUNCH();
@@ -215,7 +215,7 @@ int hgs_hair_params_backward(void* stream, int P, int E, const float* endpoints,
     HgsProfScope _prof(s, HGS_K_STRAND_BWD);
     const int extra = gather ? (E + 255) / 256 : (fu.n_smooth + 255) / 256;
     const HgsStrandBwdArgs A = {P, endpoints, endpoint_pairs, width, dist_to_scale_factor, g_xyz, g_scale, g_quat, g_dir,
-                                d_endpoints, d_width, opacity, extra4, g_opacity, g_extra4, d_opacity_raw, d_mask_raw, fu, nullptr};
+                                d_endpoints, d_width, opacity, extra4, g_opacity, g_extra4, d_opacity_raw, d_mask_raw, fu, nullptr, HgsAdamInline{}};
     hipLaunchKernelGGL(strand_bwd_kernel, dim3((P + 255) / 256 + extra + (fu.head_tail.out ? 1 : 0)), dim3(256), 0, s, A);
   }
   HGS_CHECK_LAUNCH();
@@ -223,7 +223,7 @@ int hgs_hair_params_backward(void* stream, int P, int E, const float* endpoints,
 }
 
 int hgs_hair_endpoint_gather(void* stream, int E, const float* seg_contrib, const float* endpoints, float* d_endpoints,
-                             const HgsStrandFusion* fusion) {
+                             const HgsStrandFusion* fusion, const HgsAdamInline* adam) {
   if (!fusion || !fusion->ep_segments) { hgs_set_error("hgs_hair_endpoint_gather: HgsStrandFusion.ep_segments is required (gather mode)"); return 1; }
   HgsStrandFusion fu = *fusion;
   const bool smooth = fu.smooth_pairs && fu.n_smooth > 0 && fu.head_out && fu.grad_out && fu.ep_pairs;
@@ -243,7 +243,8 @@ int hgs_hair_endpoint_gather(void* stream, int E, const float* seg_contrib, cons
     static const float4 kNone = {0.f, 0.f, 0.f, 0.f};
     const HgsStrandBwdArgs A = {0, endpoints, nullptr, nullptr, 0.f, nullptr, nullptr, nullptr, nullptr, d_endpoints, nullptr,
                                 nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, fu,
-                                E > 0 ? (const float4*)seg_contrib : &kNone};
+                                E > 0 ? (const float4*)seg_contrib : &kNone, adam ? *adam : HgsAdamInline{}};
+    if (A.adam.slot[0].p && (!A.adam.slot[0].m || !A.adam.slot[0].v || !A.adam.slot[0].coef)) { hgs_set_error("hgs_hair_endpoint_gather: incomplete Adam slot"); return 1; }
     hipLaunchKernelGGL(strand_gather_kernel, dim3((E + 255) / 256 + (fu.head_tail.out ? 1 : 0)), dim3(256), 0, s, A);
   }
   HGS_CHECK_LAUNCH();

@@ -36,7 +36,7 @@ SIGNATURES = {
     "hgs_param_backward_bytes": (sz, []),
     "hgs_backward_multi_params": (ci, [vp, ci, ci, ci, ci, ci, ci, vp, vp, vp, vp, vp, vp, vp, vp, cf, cf, vp, vp, vp, vp, vp, vp,
                                        vp, vp]),
-    "hgs_hair_endpoint_gather": (ci, [vp, ci, vp, vp, vp, vp]),
+    "hgs_hair_endpoint_gather": (ci, [vp, ci, vp, vp, vp, vp, vp]),
     "hgs_mark_visible": (ci, [vp, ci, vp, vp, vp, vp]),
     "hgs_dist2_scratch_bytes": (sz, [ci]),
     "hgs_dist2": (ci, [vp, ci, vp, vp, vp, sz]),
@@ -57,7 +57,9 @@ SIGNATURES = {
     "hgs_head_params_bytes": (sz, []),
     "hgs_strand_fusion_bytes": (sz, []),
     "hgs_select_view": (ci, [vp, vp, ci, vp, cf, vp]),
-    "hgs_iteration_prologue": (ci, [vp, vp, ci, vp, cf, vp, vp, sz]),
+    "hgs_iteration_prologue": (ci, [vp, vp, ci, vp, cf, vp, vp, sz, vp]),
+    "hgs_adam_prep_bytes": (sz, []),
+    "hgs_adam_inline_bytes": (sz, []),
     "hgs_image_zero_range": (ci, [ci, ci, vp, vp]),
     "hgs_graph_find_prologue": (ci, [vp, vp]),
     "hgs_graph_find_prologues": (ci, [vp, ci, vp, vp, vp]),
@@ -125,7 +127,26 @@ class HeadTail(C.Structure):
 
 class Prologue(C.Structure):
     """include/hgs.h HgsPrologue."""
-    _fields_ = [("table", vp), ("view", ci), ("slot", vp), ("lr", cf), ("lr_dst", vp), ("zero_ptr", vp), ("zero_bytes", sz)]
+    _fields_ = [("table", vp), ("view", ci), ("slot", vp), ("lr", cf), ("lr_dst", vp), ("zero_ptr", vp), ("zero_bytes", sz),
+                ("adam_prep", vp)]
+
+
+ADAM_MAX_TENSORS = 8
+
+
+class AdamSlot(C.Structure):
+    """include/hgs.h HgsAdamSlot."""
+    _fields_ = [("p", vp), ("m", vp), ("v", vp), ("coef", vp)]
+
+
+class AdamPrep(C.Structure):
+    """include/hgs.h HgsAdamPrep (lives in device memory: built here, uploaded as bytes)."""
+    _fields_ = [("n", ci), ("lr", vp * ADAM_MAX_TENSORS), ("step", vp * ADAM_MAX_TENSORS), ("beta1", cf), ("beta2", cf), ("coef", vp)]
+
+
+class AdamInline(C.Structure):
+    """include/hgs.h HgsAdamInline."""
+    _fields_ = [("slot", AdamSlot * 6), ("beta1", cf), ("beta2", cf), ("eps", cf)]
 
 
 class StrandFusion(C.Structure):
@@ -141,7 +162,7 @@ class ParamBackward(C.Structure):
     _fields_ = [("kind", ci), ("endpoints", vp), ("endpoint_pairs", vp), ("dist_to_scale_factor", cf), ("seg_contrib", vp),
                 ("d_width", vp), ("rotation_raw", vp), ("d_means3D", vp), ("d_scaling_raw", vp), ("d_rotation_raw", vp),
                 ("extra4", vp), ("d_opacity_raw", vp), ("d_mask_raw", vp), ("dL_dmeans2D_rgb", vp), ("max_radii2D", vp),
-                ("grad_accum", vp), ("denom", vp), ("head_tail", HeadTail)]
+                ("grad_accum", vp), ("denom", vp), ("head_tail", HeadTail), ("adam", AdamInline)]
 
 
 PARAMS_HAIR, PARAMS_CLOUD = 1, 2
@@ -182,7 +203,8 @@ def lib():
             raise HgsError(f"{LIB_PATH}: ABI version {L.hgs_abi_version()}, this binding needs {ABI_VERSION}: "
                            "rebuild with hgs_runtime.build()")
         for fn, st in (("hgs_view_targets_bytes", ViewTargets), ("hgs_head_params_bytes", HeadParams),
-                       ("hgs_strand_fusion_bytes", StrandFusion), ("hgs_param_backward_bytes", ParamBackward)):
+                       ("hgs_strand_fusion_bytes", StrandFusion), ("hgs_param_backward_bytes", ParamBackward),
+                       ("hgs_adam_prep_bytes", AdamPrep), ("hgs_adam_inline_bytes", AdamInline)):
             if getattr(L, fn)() != C.sizeof(st):
                 raise HgsError(f"{LIB_PATH}: {fn}() = {getattr(L, fn)()} but the binding's struct has {C.sizeof(st)} bytes: "
                                "rebuild with hgs_runtime.build()")

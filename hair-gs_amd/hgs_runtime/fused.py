@@ -182,6 +182,25 @@ class FusedAdam(torch.optim.Optimizer):
         self._lr_dev = {}
         self._call = None
         self._tickets = None   # the kernel's per-tensor ticket words: owned by this optimizer (include/hgs.h hgs_adam_step)
+        self._plan = None      # _InlinePlan: the in-lane form of the update (include/hgs.h HgsAdamSlot)
+        self._inline_done = False
+
+    def inline_plan(self):
+        """The plan of the in-lane update for the CURRENT parameter tensors (rebuilt when a tensor, a moment, a step counter or
+        a learning-rate tensor has been replaced): device-resident HgsAdamPrep + coefficient table, slots per parameter."""
+        rows = []
+        for gi, group in enumerate(self.param_groups):
+            for p in group["params"]:
+                if p.numel() == 0:
+                    continue
+                if not p.is_cuda:
+                    raise rt.HgsError("FusedAdam runs on the GPU only")
+                st = self._state_for(p)
+                rows.append((p, st["exp_avg"], st["exp_avg_sq"], self._lr_tensor(gi, group, p.device), st["step"], group))
+        key = tuple(t.data_ptr() for r in rows for t in r[:5])
+        if self._plan is None or self._plan.key != key:
+            self._plan = _InlinePlan(self, rows, key)
+        return self._plan
 
     def _state_for(self, p):
         st = self.state[p]
@@ -205,6 +224,15 @@ class FusedAdam(torch.optim.Optimizer):
 
     @torch.no_grad()
     def step(self, closure=None):
+        if self._inline_done:
+            # the backward that just ran applied the update in its own lanes (strand_step, _InlinePlan.applied): nothing to
+            # launch; the parameters changed in place behind autograd's back, like after the launch below
+            self._inline_done = False
+            for group in self.param_groups:
+                for p in group["params"]:
+                    if p.numel():
+                        torch.autograd.graph.increment_version(p)
+            return None
         rows = []
         for gi, group in enumerate(self.param_groups):
             for p in group["params"]:
@@ -236,3 +264,37 @@ class FusedAdam(torch.optim.Optimizer):
         for r in rows:
             torch.autograd.graph.increment_version(r[0])
         return None
+
+
+class _InlinePlan:
+    """FusedAdam.inline_plan(): what the kernels of an iteration with the in-lane update need of the optimizer (include/hgs.h
+    HgsAdamPrep / HgsAdamSlot).  `prep_ptr`: the device-resident HgsAdamPrep the iteration's prologue works on."""
+
+    def __init__(self, optimizer, rows, key):
+        if len(rows) > rt.ADAM_MAX_TENSORS:
+            raise rt.HgsError(f"in-lane Adam: at most {rt.ADAM_MAX_TENSORS} parameter tensors")
+        self.optimizer, self.key = optimizer, key
+        dev = rows[0][0].device
+        beta1, beta2 = rows[0][5]["betas"]
+        self.betas, self.eps = (float(beta1), float(beta2)), float(rows[0][5]["eps"])
+        self.coef = torch.zeros((len(rows), 2), dtype=torch.float32, device=dev)
+        prep = rt.AdamPrep()
+        prep.n = len(rows)
+        for k, r in enumerate(rows):
+            prep.lr[k], prep.step[k] = r[3].data_ptr(), r[4].data_ptr()
+        prep.beta1, prep.beta2, prep.coef = self.betas[0], self.betas[1], self.coef.data_ptr()
+        self._prep = torch.frombuffer(bytearray(bytes(prep)), dtype=torch.uint8).to(dev)
+        self.prep_ptr = self._prep.data_ptr()
+        self._keep = rows
+        self._slot = {id(r[0]): (r[0].data_ptr(), r[1].data_ptr(), r[2].data_ptr(), self.coef[k].data_ptr()) for k, r in enumerate(rows)}
+
+    def fill(self, adam, params):
+        """adam: rt.AdamInline; slot j <- the state of params[j]."""
+        for j, p in enumerate(params):
+            sl = adam.slot[j]
+            sl.p, sl.m, sl.v, sl.coef = self._slot[id(p)]
+        adam.beta1, adam.beta2, adam.eps = self.betas[0], self.betas[1], self.eps
+
+    def applied(self):
+        """The backward's launches that carry the update are enqueued: the optimizer's next step() launches nothing."""
+        self.optimizer._inline_done = True

@@ -97,6 +97,11 @@ class ViewTable:
         # leaves behind (its scan clears them), and what the fused parameters + preprocess launch needs at its start
         self.counts_clean = False
         self._fill_behind = False      # zero range of the last fill_prologue(): True = starts behind those counters
+        # device pointer of an HgsAdamPrep (hgs_runtime.fused.FusedAdam.inline_plan) every prologue issued from here on carries, or
+        # None: an iteration whose backward applies Adam in its own lanes has its step counters advanced and its coefficients
+        # formed by the prologue (include/hgs.h HgsAdamSlot).  Set by whoever runs such iterations (train.GraphedStep around its
+        # captures, FusedStrandStep.enable_inline_adam), None otherwise.
+        self.adam_prep = None
 
     def select(self, view, lr=0.0, lr_dst=None):
         """slot <- table[view] (and *lr_dst <- lr): one launch on the current stream."""
@@ -142,7 +147,7 @@ class ViewTable:
             with torch.cuda.device(self.device):
                 rt.check(rt.lib().hgs_iteration_prologue(rt.current_stream(), self.table.data_ptr(), int(view),
                                                          self.slot.data_ptr(), float(lr),
-                                                         None if lr_dst is None else lr_dst.data_ptr(), zp, zb))
+                                                         None if lr_dst is None else lr_dst.data_ptr(), zp, zb, self.adam_prep))
             self.counts_clean = True
         self.current = int(view)
         self._image_ready = True
@@ -153,24 +158,26 @@ class ViewTable:
         if self._rider is None:
             return
         view, lr, lr_dst = self._rider
+        adam_prep = self.adam_prep            # (as of now: the iteration's forward has just refreshed the optimizer's plan)
         self._rider = None
         self._fill_behind = bool(behind_counts)
         zp, zb = self._image_zero_range(behind_counts)
         pro = fu.prologue
         pro.table, pro.view, pro.slot, pro.lr, pro.lr_dst = self.table.data_ptr(), view, self.slot.data_ptr(), lr, lr_dst
-        pro.zero_ptr, pro.zero_bytes = zp, zb
+        pro.zero_ptr, pro.zero_bytes, pro.adam_prep = zp, zb, adam_prep
 
     def flush_prologue(self):
         """A prologue(ride=True) nobody carried: launch it now (callers whose first launch cannot take a rider)."""
         if self._rider is None:
             return
         view, lr, lr_dst = self._rider
+        adam_prep = self.adam_prep
         self._rider = None
         self._fill_behind = False
         zp, zb = self._image_zero_range()
         with torch.cuda.device(self.device):
             rt.check(rt.lib().hgs_iteration_prologue(rt.current_stream(), self.table.data_ptr(), view, self.slot.data_ptr(), lr,
-                                                     lr_dst, zp, zb))
+                                                     lr_dst, zp, zb, adam_prep))
         self.counts_clean = True
 
     def ensure_counts_clean(self):
@@ -393,6 +400,7 @@ class _StrandIteration(torch.autograd.Function):
         opacity, extra4 = torch.empty((P, 1), **f32), torch.empty((P, 4), **f32)
         factor = float(g.dist_to_scale_factor)
         stream = rt.current_stream()
+        step.refresh_inline_plan()
         idx = step.smooth_pairs
         hp = step.head
         # the smoothness term rides in extra workgroups of the parameter kernels (HgsStrandFusion)
@@ -461,6 +469,12 @@ class _StrandIteration(torch.autograd.Function):
             pb.seg_contrib, pb.d_width, pb.extra4 = rt.ptr(seg_contrib), rt.ptr(d_w), rt.ptr(extra4)
             pb.d_opacity_raw, pb.d_mask_raw = rt.ptr(d_o), rt.ptr(d_m)
             _params_stats(step, pb)
+            plan = step.inline_plan()
+            ep_adam = None
+            if plan is not None:      # Adam in the backward's own lanes (include/hgs.h HgsAdamSlot)
+                plan.fill(pb.adam, (g._width, g._opacity, g._mask, g._features_dc))
+                ep_adam = rt.AdamInline()
+                plan.fill(ep_adam, (g._endpoints,))
             go, (g_means2D, _, _, _, g_sh, _, _) = _head_raster_backward(
                 ctx, step, go, xyz, scale, quat, shs, planes, radii, geom, binning, img, scratch, out, endpoints, None, E,
                 params=pb)
@@ -477,7 +491,9 @@ class _StrandIteration(torch.autograd.Function):
             fu.ep_pairs = None if step.ep_pairs is None else step.ep_pairs.data_ptr()
             with torch.cuda.device(dev):
                 rt.check(L.hgs_hair_endpoint_gather(rt.current_stream(), E, rt.ptr(seg_contrib), rt.ptr(endpoints), rt.ptr(d_ep),
-                                                    C.byref(fu)))
+                                                    C.byref(fu), None if ep_adam is None else C.byref(ep_adam)))
+            if plan is not None:
+                plan.applied()
             step.last["dmean2D"] = g_means2D
             if ctx.f_rest_k == 0:
                 d_dc, d_rest = g_sh, None
@@ -538,11 +554,42 @@ class FusedStrandStep:
         self.fuse_preprocess = bool(getattr(opt, "fuse_preprocess", True)) and os.environ.get("HGS_FUSE_PREPROCESS", "1") != "0"
         # the backward mirror: parameters' backward in the rasterizer backward's per-Gaussian lanes (hgs_backward_multi_params)
         self.fuse_param_backward = bool(getattr(opt, "fuse_param_backward", True)) and os.environ.get("HGS_FUSE_PARAM_BACKWARD", "1") != "0"
+        # Adam in the backward's own lanes (include/hgs.h HgsAdamSlot; enable_inline_adam): the model's FusedAdam or None
+        self.inline_adam = None
         # True: the loss terms (loss(), terms()) are complete only once backward() has run -- the head's last sums ride in
         # the backward's parameter launch instead of a launch of their own (GraphedStep, which always runs both, sets it)
         self.defer_tail = False
         self.last = {}
         self.refresh()
+
+    def inline_adam_possible(self):
+        """Can this iteration's backward apply the Adam update itself?  One rank, the parameters' backward fused into the
+        rasterizer's (hgs_backward_multi_params; a strand model also needs the endpoint adjacency), a FusedAdam that holds
+        exactly the in-lane tensors (higher SH coefficients would need a launch of their own) -- and not switched off."""
+        from hgs_runtime.fused import FusedAdam
+        g = self.gaussians
+        return (self.fuse_param_backward and isinstance(getattr(g, "optimizer", None), FusedAdam)
+                and g._features_rest.numel() == 0 and getattr(self, "ep_segments", True) is not None
+                and bool(getattr(self.opt, "inline_adam", True)) and os.environ.get("HGS_INLINE_ADAM", "1") != "0"
+                and not (torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1))
+
+    def enable_inline_adam(self, on=True):
+        """From the next prologue on (off: until further notice) the iteration applies Adam in its backward's lanes: the views'
+        prologues carry the optimizer's step-counter / coefficient plan, backward() fills the kernels' Adam slots and tells the
+        optimizer, whose step() then has nothing left to launch.  Returns whether it is on."""
+        on = bool(on) and self.inline_adam_possible()
+        self.inline_adam = self.gaussians.optimizer if on else None
+        self.views.adam_prep = self.inline_plan().prep_ptr if on else None
+        return on
+
+    def inline_plan(self):
+        return None if self.inline_adam is None else self.inline_adam.inline_plan()
+
+    def refresh_inline_plan(self):
+        """Start of an iteration's forward, in front of the launch that carries the prologue: the optimizer's plan as of now
+        (learning rates given as Python numbers are refreshed on the device, replaced tensors picked up) into the views."""
+        if self.inline_adam is not None:
+            self.views.adam_prep = self.inline_plan().prep_ptr
 
     def refresh(self):
         """Call after anything that changes the strands' topology (the smoothness index table and sizes)."""
@@ -605,6 +652,7 @@ class _CloudIteration(torch.autograd.Function):
         from diff_gaussian_rasterization import _C as raster
         fu = rt.StrandFusion()
         vt = step.views
+        step.refresh_inline_plan()
         if step.fuse_preprocess:      # (as _StrandIteration: parameters -> Gaussians -> preprocess as one launch)
             def fill(fused):
                 if fused and not vt.counts_clean:
@@ -649,10 +697,16 @@ class _CloudIteration(torch.autograd.Function):
             pb.d_means3D, pb.d_scaling_raw, pb.d_rotation_raw = rt.ptr(g_means3D), rt.ptr(d_s), rt.ptr(d_r)
             pb.d_opacity_raw, pb.d_mask_raw = rt.ptr(d_o), rt.ptr(d_m)
             _params_stats(step, pb)
+            plan = step.inline_plan()
+            if plan is not None:      # Adam in the backward's own lanes (include/hgs.h HgsAdamSlot)
+                gm = step.gaussians
+                plan.fill(pb.adam, (gm._xyz, gm._scaling, gm._rotation, gm._opacity, gm._mask, gm._features_dc))
             if ctx.defer_tail:
                 rt.check(L.hgs_loss_head_tail(C.byref(step.head), rt.ptr(scratch), rt.ptr(out), C.byref(pb.head_tail)))
             go, (g_means2D, _, _, _, g_sh, _, _) = _head_raster_backward(
                 ctx, step, go, xyz, scale, quat, shs, planes, radii, geom, binning, img, scratch, out, None, None, 0, params=pb)
+            if plan is not None:
+                plan.applied()
             step.last["dmean2D"] = g_means2D
             if ctx.f_rest_k == 0:
                 d_dc, d_rest = g_sh, None

@@ -337,6 +337,9 @@ class GraphedStep:
         # several ranks: capture the gradient all-reduce and Adam into the step's graph when the backend allows (RCCL)
         self.collective_in_graph = bool(getattr(opt, "collective_in_graph", True))
         self.collective_captured = False
+        # Adam in the backward's own lanes (hgs_runtime.strand_step.FusedStrandStep.enable_inline_adam): one rank, one view per
+        # step, the fused iteration -- the captured step then holds no optimizer launch
+        self.inline_adam = False
         self._make_capturable()
 
     def _make_capturable(self):
@@ -474,6 +477,8 @@ class GraphedStep:
                 self._scale_gradients()
             g.optimizer.step()
 
+        # (the warm-up above ran with the optimizer untouched; the captured iterations update in the backward's lanes where possible)
+        self.inline_adam = (self.fused is not None and not multi and world == 1 and self.fused.enable_inline_adam(True))
         ga = torch.cuda.CUDAGraph(keep_graph=True) if self._prologue_in_graph else torch.cuda.CUDAGraph()
         with lean_graph_capture(ga, s, **mode):
             if self._prologue_in_graph:
@@ -507,6 +512,8 @@ class GraphedStep:
                     exchange_and_step()
             gk.instantiate()
             self._many = (gk, v.graph_bind(gk, K), losses)
+        if self.fused is not None:
+            self.fused.enable_inline_adam(False)      # (the graphs keep what they captured; eager users of these views do not inherit it)
         # every replay raises the library's sticky device-side maximum of num_rendered; check() compares it with the
         # capacity the captured passes were built for
         self._cap = raster._state["cap_used"]

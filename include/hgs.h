@@ -43,7 +43,7 @@ extern "C" {
 #endif
 
 /* bumped with every incompatible change of a struct, a signature or a buffer layout (round 1: 1, round 2: 2, round 3: 3, then 4 with the one-launch parameters + preprocess entry points;
- * 5, round 5: hgs_backward_multi_params / hgs_hair_endpoint_gather, and the contract that HgsHeadParams.tile_used also limits
+ * 5, round 5: hgs_backward_multi_params / hgs_hair_endpoint_gather, HgsPrologue.adam_prep and the in-lane Adam update, and the contract that HgsHeadParams.tile_used also limits
  * what hgs_loss_head_forward writes of d_extra_unit -- a caller of version 4 that read those planes everywhere must not);
  * the Python binding refuses a library whose version or struct sizes differ from its own */
 #define HGS_ABI_VERSION 5
@@ -223,6 +223,25 @@ typedef struct HgsViewTargets {
 size_t hgs_view_targets_bytes(void);   /* sizeof(HgsViewTargets), for bindings that mirror the struct */
 size_t hgs_head_params_bytes(void);    /* sizeof(HgsHeadParams) */
 size_t hgs_strand_fusion_bytes(void);  /* sizeof(HgsStrandFusion) */
+/* ---- Adam in the backward's own lanes (round 5; one rank).  The lane of the backward that has just finished the gradient of a
+ * parameter element -- hgs_backward_multi_params' per-Gaussian lanes, hgs_hair_endpoint_gather's endpoint lanes -- applies that
+ * element's Adam update at once (HgsAdamSlot: parameter, both moments, the step's two coefficients); an iteration then has no
+ * optimizer launch.  The coefficients lr / (1 - beta1^t), 1 / sqrt(1 - beta2^t) and the advance of the step counters t are the
+ * business of the iteration's PROLOGUE (HgsPrologue.adam_prep: one thread per tensor of a DEVICE-resident HgsAdamPrep), i.e. of
+ * a launch in front of every kernel that reads them.  Same arithmetic as hgs_adam_step, bit for bit (csrc/hgs_adam.h): a run
+ * may mix iterations of either form.  The gradients are written as without it. ---- */
+#define HGS_ADAM_MAX_TENSORS 8
+typedef struct HgsAdamSlot { float* p; float* m; float* v; const float* coef; } HgsAdamSlot;   /* p == NULL: not updated here */
+typedef struct HgsAdamPrep {                     /* lives in DEVICE memory */
+  int n; const float* lr[HGS_ADAM_MAX_TENSORS]; float* step[HGS_ADAM_MAX_TENSORS]; float beta1, beta2;
+  float* coef;                                   /* [n][2] out: step_size, inv_sqrt_bc2 of tensor k (HgsAdamSlot.coef = coef + 2 k) */
+} HgsAdamPrep;
+/* slots by HgsParamBackward.kind -- HGS_PARAMS_HAIR: 0 width, 1 opacity, 2 mask, 3 SH DC ([P,1,3]);  HGS_PARAMS_CLOUD: 0 xyz,
+ * 1 scaling, 2 rotation, 3 opacity, 4 mask, 5 SH DC;  hgs_hair_endpoint_gather: 0 endpoints */
+typedef struct HgsAdamInline { HgsAdamSlot slot[6]; float beta1, beta2, eps; } HgsAdamInline;
+size_t hgs_adam_prep_bytes(void);     /* sizeof(HgsAdamPrep) */
+size_t hgs_adam_inline_bytes(void);   /* sizeof(HgsAdamInline) */
+
 /* slot[0] = table[view]; if lr_dst != NULL also *lr_dst = lr (the position learning rate of this iteration, a by-value
  * kernel argument, so the host may run ahead of the device without racing on a staging buffer). */
 int hgs_select_view(void* stream, const HgsViewTargets* table, int view, HgsViewTargets* slot, float lr, float* lr_dst);
@@ -231,7 +250,7 @@ int hgs_select_view(void* stream, const HgsViewTargets* table, int view, HgsView
  * HGS_IMAGE_PREZEROED to that call so that it does not clear them again).  One launch instead of three small ones in
  * front of every iteration. */
 int hgs_iteration_prologue(void* stream, const HgsViewTargets* table, int view, HgsViewTargets* slot, float lr, float* lr_dst,
-                           void* zero_ptr, size_t zero_bytes);
+                           void* zero_ptr, size_t zero_bytes, const HgsAdamPrep* adam_prep /* NULL: none */);
 int hgs_image_zero_range(int W, int H, size_t* offset, size_t* bytes);   /* of an image_buf of hgs_image_bytes(W, H) */
 /* The same prologue as a rider of another launch: hgs_hair_params_forward / hgs_cloud_params_forward -- the first launch of
  * an iteration, which needs neither the view nor the counters -- run it in spare workgroups when HgsStrandFusion.prologue
@@ -240,6 +259,7 @@ int hgs_image_zero_range(int W, int H, size_t* offset, size_t* bytes);   /* of a
 typedef struct HgsPrologue {
   const HgsViewTargets* table; int view; HgsViewTargets* slot; float lr; float* lr_dst;   /* as hgs_iteration_prologue */
   void* zero_ptr; size_t zero_bytes;
+  const HgsAdamPrep* adam_prep;   /* NULL: none (see HgsAdamSlot) */
 } HgsPrologue;
 /* A captured HIP graph that holds exactly ONE hgs_iteration_prologue / hgs_select_view launch is re-pointed at another
  * view (and learning rate) without any launch between two replays: hgs_graph_find_prologue(hipGraph_t) returns that
@@ -249,6 +269,7 @@ int hgs_graph_find_prologue(void* graph, void** node_out);
 /* several iterations captured in one graph: all its prologue nodes (any order) with the `lr` each was captured with, which
  * the caller uses as a tag to tell them apart */
 int hgs_graph_find_prologues(void* graph, int max_nodes, void** nodes_out, float* lr_out, int* n_out);
+/* (the node's HgsPrologue.adam_prep stays what it was captured with) */
 int hgs_graph_set_prologue(void* graph_exec, void* node, const HgsViewTargets* table, int view, HgsViewTargets* slot, float lr,
                            float* lr_dst, void* zero_ptr, size_t zero_bytes);
 /* Several views per optimizer step inside ONE captured graph (strong-scaling protocol, SURVEY.md 8e: a fixed global batch
@@ -372,6 +393,7 @@ typedef struct HgsParamBackward {
   float* dL_dmeans2D_rgb;                                                  /* out [P,3], optional */
   float* max_radii2D; float* grad_accum; float* denom;                     /* in/out [P], optional (hgs_densify_stats) */
   HgsHeadTail head_tail;                                                   /* cloud: out != NULL -> a spare workgroup runs the tail */
+  HgsAdamInline adam;                                                      /* slots with p != NULL: updated by the lane (see HgsAdamSlot) */
 } HgsParamBackward;
 size_t hgs_param_backward_bytes(void);   /* sizeof(HgsParamBackward) */
 int hgs_backward_multi_params(void* stream, int P, int D, int M, int R, int W, int H, const float* bg7, const float* means3D,
@@ -381,8 +403,9 @@ int hgs_backward_multi_params(void* stream, int P, int D, int M, int R, int W, i
                               const float* const* dL_dpix_planes7, void* scratch, float* dL_dsh, const HgsParamBackward* params);
 /* d_endpoints [E,3] fully written.  fusion: ep_segments (required), ep_pairs + the smoothness group (smooth_pairs, n_smooth,
  * cos_threshold, eps, head_out, grad_out) and head_tail as for hgs_hair_params_backward; its other groups are ignored. */
+/* adam (may be NULL): slot 0 = the endpoints' Adam state; the lane then also applies endpoint i's update (HgsAdamSlot). */
 int hgs_hair_endpoint_gather(void* stream, int E, const float* seg_contrib, const float* endpoints, float* d_endpoints,
-                             const HgsStrandFusion* fusion);
+                             const HgsStrandFusion* fusion, const HgsAdamInline* adam);
 
 /* hgs_cloud_params_forward/backward: the Stage-I counterpart of hgs_hair_params_* -- the rasterizer-facing getters of the
  *   Gaussian cloud (scene/gaussian_model.py:118-157) and their autograd in one launch each:

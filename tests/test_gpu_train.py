@@ -1434,6 +1434,77 @@ def test_densification_inputs_of_the_fused_pass_equal_the_three_pass_form():
     assert bool(((gf >= thr) == (g3 >= thr))[~near].all()) and int(seen.sum()) > 100
 
 
+@pytest.mark.parametrize("kind", ["strands", "cloud"])
+def test_adam_in_the_backward_lanes_equals_the_adam_launch(kind):
+    """Round 5: a single-rank captured iteration holds no optimizer launch -- the lanes of the backward that finish a parameter
+    element's gradient apply its Adam update (include/hgs.h HgsAdamSlot), the prologue advances the step counters and forms
+    the bias-correction coefficients.  Against the same iterations with hgs_adam_step as a launch of its own: parameters, both
+    moments, step counters and statistics bit for bit -- replayed (one and four steps per graph launch) and eager."""
+    from arguments import OptimizationParams
+    from synthetic import attach_targets, build_workload, cameras_extent, make_cameras, make_cloud_model
+    from train import GraphedStep, ViewSampler, training_step
+    from hgs_runtime.strand_step import ViewTable, fused_step_for
+    from diff_gaussian_rasterization import _C as raster
+    bg = torch.zeros(3, device="cuda")
+
+    def fresh():
+        if kind == "strands":
+            model, cams, extent = build_workload("tiny", device="cuda", with_targets=True)
+        else:
+            cams = make_cameras(4, 200, 120, device="cuda")
+            extent = cameras_extent(cams)
+            model = make_cloud_model(3000, device="cuda", spatial_lr_scale=extent)
+            attach_targets(cams, model)
+        opt = OptimizationParams()
+        opt.enable_topology = False
+        model.training_setup(opt)
+        return model, cams, extent, opt
+
+    def state(model):
+        out = []
+        for g_ in model.optimizer.param_groups:
+            for p in g_["params"]:
+                st = model.optimizer.state.get(p, {})
+                out += [p.detach().clone()] + [st[k].clone() for k in ("exp_avg", "exp_avg_sq", "step") if k in st]
+        return out + [model.max_radii2D.clone(), model.xyz_gradient_accum.clone(), model.denom.clone()]
+
+    runs = {}
+    try:
+        for inline in (False, True):
+            model, cams, extent, opt = fresh()
+            opt.inline_adam = inline
+            sampler = ViewSampler(cams, seed=3)
+            gs = GraphedStep(model, cams, opt, bg, extent=extent, steps_per_graph=4)
+            gs.capture(cams, iteration=1)
+            assert gs.inline_adam is inline
+            it = 0
+            for _ in range(3):
+                it += 1
+                gs.step(sampler.next(), it)
+            gs.step_many([sampler.next() for _ in range(4)], it + 1)
+            it += 4
+            gs.check()
+            raster.set_async(False)
+            snap = state(model)
+            # eager continuation (topology iterations of training() run this way -- with the launch; here also in-lane)
+            views = ViewTable(cams)
+            fused = fused_step_for(model, views, opt, bg)
+            assert fused.enable_inline_adam(inline) is inline
+            for _ in range(3):
+                it += 1
+                training_step(model, sampler.next(), opt, bg, it, extent=extent, fused=fused)
+            torch.cuda.synchronize()
+            runs[inline] = (snap, state(model))
+    finally:
+        raster.set_async(False)
+    for a, b in zip(runs[False], runs[True]):
+        assert len(a) == len(b)
+        for x, y in zip(a, b):
+            assert torch.equal(x, y)
+    steps = [t for t in runs[True][1] if t.ndim == 0]
+    assert steps and all(float(t) == 10.0 for t in steps)
+
+
 def test_replays_after_a_blocking_pass_on_the_same_views():
     """The captured step's first launch counts into the image buffer's tile counters beside the workgroups that clear the other
     counters, so it needs them at zero -- which capacity-mode passes leave behind and a blocking-mode pass does not.  A blocking
