@@ -1501,8 +1501,8 @@ def test_adam_in_the_backward_lanes_equals_the_adam_launch(kind):
         assert len(a) == len(b)
         for x, y in zip(a, b):
             assert torch.equal(x, y)
-    steps = [t for t in runs[True][1] if t.ndim == 0]
-    assert steps and all(float(t) == 10.0 for t in steps)
+    steps = sorted(float(t) for t in runs[True][1] if t.ndim == 0)      # (an empty tensor -- no higher SH coefficients -- never steps)
+    assert steps and steps[-1] == 10.0 and set(steps) <= {0.0, 10.0} and steps.count(10.0) >= 5
 
 
 def test_replays_after_a_blocking_pass_on_the_same_views():
