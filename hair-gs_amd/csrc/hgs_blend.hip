@@ -387,6 +387,7 @@ __global__ __launch_bounds__(HGS_BLOCK) __attribute__((amdgpu_waves_per_eu(8))) 
     s_flag = it.seg == 0 || hgs_wait_parts(&im.tile_prog[tile], (1ull << it.seg) - 1ull, im.status) ? 1u : 0u;
   }
   __syncthreads();
+  _trace.mark(5);                 // (the predecessors' products are published)
   float T_in = inside ? 1.f : -1.f;
   if (s_flag) {
     constexpr uint32_t TG = 8;

@@ -331,9 +331,21 @@ __device__ __forceinline__ void hgs_publish_part(unsigned long long* mask, uint3
   __hip_atomic_fetch_or(mask, 1ull << part, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 __device__ __forceinline__ bool hgs_wait_parts(const unsigned long long* mask, unsigned long long want, uint32_t* status) {
+#ifndef HGS_WAIT_BACKOFF
+#define HGS_WAIT_BACKOFF 0     // experiment (round 5): 1 = the pause between two polls doubles up to ~3 us
+#endif
   for (int spin = 0; spin < (1 << 21); spin++) {
     if ((hgs_ld_agent(mask) & want) == want) return true;
+#if HGS_WAIT_BACKOFF
+    // (s_sleep takes an immediate: 64 x N cycles)
+    if (spin < 4) __builtin_amdgcn_s_sleep(8);
+    else if (spin < 8) __builtin_amdgcn_s_sleep(16);
+    else if (spin < 12) __builtin_amdgcn_s_sleep(32);
+    else if (spin < 16) __builtin_amdgcn_s_sleep(64);
+    else __builtin_amdgcn_s_sleep(127);
+#else
     __builtin_amdgcn_s_sleep(8);
+#endif
   }
   status[HGS_ST_TIMEOUT] = 1u;
   // capacity mode: the caller's sticky instance-count maximum (its pointer is parked in the status words) is raised to

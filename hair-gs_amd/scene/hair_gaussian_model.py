@@ -596,31 +596,40 @@ class HairGaussianModel(HairTopologyMixin, GaussianModel):
 
     def prune_segments(self, segments_prune_mask):
         """Drop segments; endpoints no segment references any more are dropped too and ids are compacted."""
+        # Round 5: every row selection below goes through ONE index list per mask (nonzero: the call's two host
+        # synchronisations) and index_select -- the same rows in the same order as boolean-mask indexing, which costs a
+        # nonzero kernel and a synchronisation per tensor: 18 of them per call (parameter, both Adam moments, six groups),
+        # 0.7 ms of a call that the operators make ~8 times per densification event (tools/dev/soak_profile.py).
         seg_keep = ~segments_prune_mask
-        self.endpoint_pairs = self.endpoint_pairs[seg_keep]
+        seg_idx = torch.nonzero(seg_keep).squeeze(1)
+        all_seg = seg_idx.shape[0] == seg_keep.shape[0]
+        if not all_seg:
+            self.endpoint_pairs = self.endpoint_pairs.index_select(0, seg_idx)
         ep_keep = torch.zeros(self._endpoints.shape[0], dtype=torch.bool, device=self.device)
         ep_keep[self.endpoint_pairs.flatten()] = True
-        remap = torch.cumsum(ep_keep.to(torch.long), dim=0) - 1  # old id -> new id for kept endpoints
-        self.endpoint_pairs = remap[self.endpoint_pairs]
-        if torch.is_tensor(self.strand_root_endpoint_idx) and self.strand_root_endpoint_idx.numel():
-            self.strand_root_endpoint_idx = remap[self.strand_root_endpoint_idx]
+        ep_idx = torch.nonzero(ep_keep).squeeze(1)
+        all_ep = ep_idx.shape[0] == ep_keep.shape[0]
+        if not all_ep:
+            remap = torch.cumsum(ep_keep.to(torch.long), dim=0) - 1  # old id -> new id for kept endpoints
+            self.endpoint_pairs = remap[self.endpoint_pairs]
+            if torch.is_tensor(self.strand_root_endpoint_idx) and self.strand_root_endpoint_idx.numel():
+                self.strand_root_endpoint_idx = remap[self.strand_root_endpoint_idx]
         # (a call that keeps every segment -- the reference's id compaction, twice per round of merge_collapsed_segments -- or
         # every endpoint leaves those tensors as they are: a masked copy of all rows is the same rows)
-        all_seg, all_ep = bool(seg_keep.all()), bool(ep_keep.all())
         out = {}
         for g in self.optimizer.param_groups:
             is_ep = g["name"] == "endpoints"
             if all_ep if is_ep else all_seg:
                 g["params"][0].grad = None      # (a re-created parameter has no gradient: it skips this iteration's Adam step)
                 continue
-            keep = ep_keep if is_ep else seg_keep
-            out[g["name"]] = self._swap_param(g, g["params"][0][keep], lambda m, k=keep: m[k])
+            idx = ep_idx if is_ep else seg_idx
+            out[g["name"]] = self._swap_param(g, g["params"][0].detach().index_select(0, idx), lambda m, k=idx: m.index_select(0, k))
         if out:
             self._rebind(out)
         if not all_seg:
-            self.xyz_gradient_accum = self.xyz_gradient_accum[seg_keep]
-            self.denom = self.denom[seg_keep]
-            self.max_radii2D = self.max_radii2D[seg_keep]
+            self.xyz_gradient_accum = self.xyz_gradient_accum.index_select(0, seg_idx)
+            self.denom = self.denom.index_select(0, seg_idx)
+            self.max_radii2D = self.max_radii2D.index_select(0, seg_idx)
         self._smooth_pairs = None
 
     # ---- strand bookkeeping ----------------------------------------------------------------------

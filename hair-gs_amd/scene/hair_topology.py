@@ -72,12 +72,14 @@ class HairTopologyMixin:
         ta = self.training_args
         sel = (torch.norm(grads, dim=-1) >= ta.densify_grad_threshold) & (
             torch.max(self.get_scaling, dim=1).values <= ta.percent_dense * scene_extent)
-        new_ep = self._endpoints[self.endpoint_pairs[sel]].flatten(0, 1).detach()
+        si = torch.nonzero(sel).squeeze(1)      # (one index list for the seven row selections: same rows as [sel], one sync)
+        take = lambda t: t.detach().index_select(0, si)
+        new_ep = self._endpoints.detach()[take(self.endpoint_pairs)].flatten(0, 1)
         ids = torch.arange(new_ep.shape[0], device=self.device) + self.endpoint_pairs.max() + 1
         if info is not None:
-            info["clone"] = int(sel.sum())
-        self.cat_segments(ids.reshape(-1, 2), new_ep, self._features_dc[sel].detach(), self._features_rest[sel].detach(),
-                          self._opacity[sel].detach(), self._mask[sel].detach(), self._width[sel].detach())
+            info["clone"] = int(si.shape[0])
+        self.cat_segments(ids.reshape(-1, 2), new_ep, take(self._features_dc), take(self._features_rest),
+                          take(self._opacity), take(self._mask), take(self._width))
 
     def split_strategy(self, grads, scene_extent, info=None):
         """High gradient + large extent, or longer than max_segment_length (foreground only) -> cut at the midpoint
@@ -91,14 +93,16 @@ class HairTopologyMixin:
             torch.max(self.get_scaling, dim=1).values > ta.percent_dense * scene_extent)
         sel = sel | (self._segment_lengths() >= self.max_segment_length)
         sel = sel & (self.get_mask > self.foreground_binarization_th).squeeze(1)
-        k = int(sel.sum())
-        mid = self.get_xyz[sel].detach()
+        si = torch.nonzero(sel).squeeze(1)      # (one index list for the seven row selections: same rows as [sel], one sync)
+        k = int(si.shape[0])
+        take = lambda t: t.detach().index_select(0, si)
+        mid = take(self.get_xyz)
         ids = torch.arange(k, device=self.device) + 1 + torch.max(self.endpoint_pairs)
-        orig = self.endpoint_pairs[sel]
+        orig = take(self.endpoint_pairs)
         new_pairs = torch.cat([torch.stack([orig[:, 0], ids], 1), torch.stack([ids, orig[:, 1]], 1)], dim=0)
-        self.cat_segments(new_pairs, mid, self._features_dc[sel].detach().repeat(2, 1, 1),
-                          self._features_rest[sel].detach().repeat(2, 1, 1), self._opacity[sel].detach().repeat(2, 1),
-                          self._mask[sel].detach().repeat(2, 1), self._width[sel].detach().repeat(2, 1))
+        self.cat_segments(new_pairs, mid, take(self._features_dc).repeat(2, 1, 1),
+                          take(self._features_rest).repeat(2, 1, 1), take(self._opacity).repeat(2, 1),
+                          take(self._mask).repeat(2, 1), take(self._width).repeat(2, 1))
         if info is not None:
             info["split"] = k
         self.prune_segments(torch.cat((sel, torch.zeros(2 * k, device=self.device, dtype=torch.bool))))

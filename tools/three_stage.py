@@ -159,6 +159,7 @@ from utils.sh import SH2RGB  # noqa: E402
 
 def stages_one_and_two(record):
     """Stage I + II (deterministic: the second call reproduces the first model bit for bit)."""
+    safe_state(True)                      # (torch / numpy / random seeds: densify_and_split samples new centres)
     rng = np.random.default_rng(1)
     mid = 0.5 * (gt_pts[:, 1:] + gt_pts[:, :-1]).reshape(-1, 3)
     pts = (mid + rng.normal(size=mid.shape) * 0.002).astype(np.float32)

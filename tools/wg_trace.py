@@ -66,6 +66,15 @@ for name, t in (("fwd", tf), ("bwd", tb)):
         by_seg = [(int(k), round(float((s[seg[split] == k, 1] - s[seg[split] == k, 0]).mean()), 1), round(float((s[seg[split] == k, 2] - s[seg[split] == k, 1]).mean()), 1),
                    round(float((s[seg[split] == k, 3] - s[seg[split] == k, 2]).mean()), 1)) for k in range(0, int(seg[split].max()) + 1, 2)]
         print("   by segment index (seg, passA, wait, passB):", by_seg)
+        later = seg[split] > 0
+        if later.any() and (s[later, 5] > 0).all():      # mark 5: the predecessors' products are published (flag seen)
+            sl = s[later]
+            print("   segments > 0: pass A end -> flag seen -> T_in known, mean us:", round(float((sl[:, 5] - sl[:, 1]).mean()), 2),
+                  round(float((sl[:, 2] - sl[:, 5]).mean()), 2), " p90:", round(float(np.percentile(sl[:, 5] - sl[:, 1], 90)), 2),
+                  round(float(np.percentile(sl[:, 2] - sl[:, 5], 90)), 2))
+            first = s[seg[split] == 0]
+            print("   segment 0: pass A mean / p90 / max us:", np.round([(first[:, 1] - first[:, 0]).mean(), np.percentile(first[:, 1] - first[:, 0], 90), (first[:, 1] - first[:, 0]).max()], 1).tolist(),
+                  " segments 1..: ", np.round([(sl[:, 1] - sl[:, 0]).mean(), np.percentile(sl[:, 1] - sl[:, 0], 90), (sl[:, 1] - sl[:, 0]).max()], 1).tolist())
     if name == "fwd":
         for i in np.argsort(-us[:, 7])[:6]:
             print("      late:", int(tile[i]), f"{int(seg[i])}/{int(nseg[i])}", "marks (us from kernel start):", np.round(us[i, [0, 1, 2, 3, 4, 7]] - t0, 1).tolist())
