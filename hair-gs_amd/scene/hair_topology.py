@@ -52,8 +52,9 @@ class HairTopologyMixin:
     # ---- densification (reference :788-1077) -------------------------------------------------------------------------
     def densification(self, extent, max_screen_size, training_info=None):
         grads = self.xyz_gradient_accum / self.denom
-        grads[grads.isnan()] = 0.0
-        info = training_info.densification_info if training_info is not None else {}
+        grads = torch.where(grads.isnan(), torch.zeros_like(grads), grads)      # grads[grads.isnan()] = 0.0 without its host sync
+        # (without a training_info nobody reads the operators' counters: None spares them a synchronisation each)
+        info = training_info.densification_info if training_info is not None else None
         self.clone_strategy(grads, extent, info)
         self.split_strategy(grads, extent, info)
         self.merge_collapsed_segments(info)
@@ -123,17 +124,22 @@ class HairTopologyMixin:
             to_merge = cand[both_interior]
             to_merge, keep = self.remove_duplicate_endpoint_rows(to_merge, return_mask=True)
             mask[mask.clone()] = keep
+            if to_merge.shape[0] == 0:
+                # the round that finds nothing (every call ends with one): `mask` is all False by now, so the reference's two
+                # prune_segments calls keep every segment and every endpoint -- all they leave behind is what a call that
+                # re-creates nothing leaves: parameters without a gradient for this iteration's Adam step
+                for g in self.optimizer.param_groups:
+                    g["params"][0].grad = None
+                self._smooth_pairs = None
+                break
             self.prune_segments(mask)
             mapping = torch.arange(int(self.endpoint_pairs.max()) + 1 if self.endpoint_pairs.numel() else 0,
                                    device=self.device)
-            if to_merge.shape[0]:
-                mapping[to_merge[:, 1]] = to_merge[:, 0]
-                self.endpoint_pairs = mapping[self.endpoint_pairs]
+            mapping[to_merge[:, 1]] = to_merge[:, 0]
+            self.endpoint_pairs = mapping[self.endpoint_pairs]
             # compacts the endpoint table (drops the ids that just lost their last reference)
             self.prune_segments(torch.zeros(self.endpoint_pairs.shape[0], dtype=torch.bool, device=self.device))
             total += int(to_merge.shape[0])
-            if to_merge.shape[0] == 0:
-                break
         if info is not None:
             info["merge_collapsed"] = total
 
@@ -141,24 +147,28 @@ class HairTopologyMixin:
         """Drop collapsed / transparent / oversized segments; with avoid_connected only strand-end or background
         segments may go, so strands are never cut in the middle (:1020-1077)."""
         info = _info_dict(info)
-        info = {} if info is None else info
         prune = self._segment_lengths() < self.min_val
-        info["prune_collapsed"] = int(prune.sum())
+        if info is not None:
+            info["prune_collapsed"] = int(prune.sum())
         low = (self.get_opacity < self.opacity_th).squeeze(1)
-        info["prune_low_opacity"] = int(low.sum())
+        if info is not None:
+            info["prune_low_opacity"] = int(low.sum())
         prune = prune | low
         if max_screen_size and extent != 0.0:
             big = self.get_scaling.max(dim=1).values > 0.1 * extent
-            info["prune_big_ws"] = int(big.sum())
+            if info is not None:
+                info["prune_big_ws"] = int(big.sum())
             prune = prune | big
         if avoid_connected and prune.sum() != 0:
             u, c = torch.unique(self.endpoint_pairs, return_counts=True)
             is_end = torch.any(torch.isin(self.endpoint_pairs, u[c == 1]), dim=1)
             allowed = is_end | (self.get_mask < self.foreground_binarization_th).squeeze(1)
-            info["prune_avoided"] = int(prune.sum() - (prune & allowed).sum())
+            if info is not None:
+                info["prune_avoided"] = int(prune.sum() - (prune & allowed).sum())
             prune = prune & allowed
         n = int(prune.sum())
-        info["prune_total"] = n
+        if info is not None:
+            info["prune_total"] = n
         if 0 < n < self._opacity.shape[0]:
             self.prune_segments(prune)
 

@@ -1,4 +1,6 @@
-"""Runs only the single-pass rasterizer forward+backward on the north_star workload (for rocprofv3 --pmc passes)."""
+"""Runs only the single-pass rasterizer forward+backward on a workload (for rocprofv3 --pmc passes):
+  python tools/raster_only.py [workload] [passes] [culled | train=N]
+train=N: on the state N iterations of the FULL loop leave (densification, merging, opacity reset: bench.py's `trained_state`)."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "hair-gs_amd")]
@@ -7,7 +9,18 @@ from gaussian_renderer import render_multi
 from synthetic import build_workload
 wl = sys.argv[1] if len(sys.argv) > 1 else "north_star"
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 10
-model, cams, _ = build_workload(wl, device="cuda", with_targets=False, n_views=4)
+n_train = int(sys.argv[3].split("=")[1]) if len(sys.argv) > 3 and sys.argv[3].startswith("train=") else 0
+model, cams, extent = build_workload(wl, device="cuda", with_targets=n_train > 0, n_views=8 if n_train else 4)
+if n_train:
+    from arguments import OptimizationParams
+    from train import training
+    from utils.general import safe_state
+    safe_state(True)
+    opt = OptimizationParams()
+    model.training_setup(opt)
+    training(model, cams, opt, iterations=n_train, extent=extent, seed=1)
+    torch.cuda.synchronize()
+    print("trained", n_train, "iterations:", model.get_xyz.shape[0], "segments")
 if len(sys.argv) > 3 and sys.argv[3] == "culled":   # everything behind the camera: launch + output-write floor of the kernels
     with torch.no_grad():
         model._endpoints.data += 1.0e4
