@@ -16,6 +16,7 @@ model.training_setup(opt)
 bg = torch.zeros(3, device="cuda")
 fused = fused_step_for(model, ViewTable(cams), opt, bg)
 fused.defer_tail = True   # (as the captured iteration: no launch for the loss head's tail)
+fused.enable_inline_adam(True)   # (as the captured single-rank iteration: Adam in the backward's lanes, no optimizer launch)
 raster.set_async(True)    # capacity mode, as the captured iteration runs: the first launch is hair_preprocess_fwd_kernel
 for it in range(1, n + 1):
     training_step(model, cams[it % len(cams)], opt, bg, it, extent=extent, fused=fused)

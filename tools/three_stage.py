@@ -47,6 +47,7 @@ N1 = int(sys.argv[2]) if len(sys.argv) > 2 else 5000
 N3 = int(sys.argv[3]) if len(sys.argv) > 3 else 5000
 N_SEG, VIEWS, W, H = 100, 16, 800, 800
 rt.lib()
+_real_stdout, sys.stdout = sys.stdout, sys.stderr      # (the model classes print progress lines: stdout is the JSON alone)
 safe_state(True)
 dev = torch.device("cuda")
 bg = torch.zeros(3, device=dev)
@@ -258,4 +259,5 @@ out["summary"] = {"psnr_db": {"stage_I_start": out["stage_I"]["trajectory"][0]["
                   "stage_III_without_operators_ends_better_than_it_starts": traj3n[-1]["psnr_db"] > traj3n[0]["psnr_db"],
                   "mean_psnr_change_by_a_densification_event_db": sum(e["psnr_change_by_the_event_db"] for e in events) / len(events),
                   "wall_seconds": {"stage_I": out["stage_I"]["seconds"], "stage_II": out["stage_II"]["seconds"], "stage_III": t3}}
+sys.stdout = _real_stdout
 print(json.dumps(out, indent=1))
