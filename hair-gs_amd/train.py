@@ -678,7 +678,7 @@ def training(gaussians, cameras, opt, iterations=None, extent=1.0, seed=0, log_e
                     # warm-up on a spread of the views (allocator, lazy loads, a capacity estimate): a view that needs more than
                     # slack x their largest instance count is caught by the headroom check and rolled back exactly, so the
                     # capture need not render every camera first (32 eager iterations per re-capture at north_star)
-                    nw = min(len(cameras), int(getattr(opt, "capture_warmup_views", 4)))
+                    nw = min(len(cameras), int(getattr(opt, "capture_warmup_views", 2)))
                     gs.capture([cameras[(k * len(cameras)) // nw] for k in range(nw)], iteration=it)
                     ckpt = _Checkpoint(gaussians, sampler, ema, it - 1)    # (eager steps are exact: they repeat on overflow)
                 K = gs.steps_per_graph

@@ -33,7 +33,7 @@ def psnr():
 
 
 p0, n0 = psnr(), model.get_xyz.shape[0]
-done, t0 = 0, time.perf_counter()
+done, t0, rollbacks = 0, time.perf_counter(), 0
 while done < iters:
     n = min(500, iters - done)
     if os.environ.get("SOAK_PROFILE") and done + n >= iters:      # cProfile of the last chunk
@@ -44,6 +44,7 @@ while done < iters:
     else:
         ema = training(model, cams, opt, iterations=n, extent=extent, start_iteration=done)
     done += n
+    rollbacks += int(getattr(training, "last_rollbacks", 0) or 0)
     torch.cuda.synchronize()
     print(f"[it {done}] loss(ema) {float(ema):.5f}  segments {model.get_xyz.shape[0]}  elapsed {time.perf_counter() - t0:.2f} s", flush=True)
 dt = time.perf_counter() - t0
@@ -51,4 +52,4 @@ p1 = psnr()
 pos = model._endpoints if hasattr(model, "_endpoints") else model._xyz
 assert all(bool(torch.isfinite(p).all()) for p in (pos, model._opacity, model._features_dc)), "non-finite parameters"
 print(f"{wl}: {iters} iterations in {dt:.2f} s = {iters / dt:.0f} it/s incl. topology operators and re-captures; "
-      f"PSNR {p0:.2f} -> {p1:.2f} dB; segments {n0} -> {model.get_xyz.shape[0]}")
+      f"PSNR {p0:.2f} -> {p1:.2f} dB; segments {n0} -> {model.get_xyz.shape[0]}; capacity rollbacks {rollbacks}")
