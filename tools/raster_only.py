@@ -10,7 +10,9 @@ from synthetic import build_workload
 wl = sys.argv[1] if len(sys.argv) > 1 else "north_star"
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 10
 n_train = int(sys.argv[3].split("=")[1]) if len(sys.argv) > 3 and sys.argv[3].startswith("train=") else 0
-model, cams, extent = build_workload(wl, device="cuda", with_targets=n_train > 0, n_views=8 if n_train else 4)
+# (train=N: the workload's own views and the seeds of bench.py's trained_state leg, so that the state is the one that leg times
+# as closely as a run-to-run different trajectory allows)
+model, cams, extent = build_workload(wl, device="cuda", with_targets=n_train > 0, n_views=None if n_train else 4)
 if n_train:
     from arguments import OptimizationParams
     from train import training
@@ -18,7 +20,7 @@ if n_train:
     safe_state(True)
     opt = OptimizationParams()
     model.training_setup(opt)
-    training(model, cams, opt, iterations=n_train, extent=extent, seed=1)
+    training(model, cams, opt, iterations=n_train, extent=extent, start_iteration=10, seed=1, steps_per_graph=8)
     torch.cuda.synchronize()
     print("trained", n_train, "iterations:", model.get_xyz.shape[0], "segments")
 if len(sys.argv) > 3 and sys.argv[3] == "culled":   # everything behind the camera: launch + output-write floor of the kernels
