@@ -31,7 +31,8 @@ __device__ __forceinline__ void hgs_adam_one(float& p, float g, float& m, float&
 
 // The in-lane update of element(s) [i * N, (i + 1) * N) of the tensor behind `s` with the gradient values g[0..N).
 // (p, m, v of the element are loaded here, behind the gradient arithmetic: one more round trip at the end of the lane, no
-// registers held across it.)
+// registers held across it.  Requested EARLY instead -- with the lane's other independent loads, 18 more live registers in
+// preprocess_bwd_kernel -- the step was slower at every size, same box: north_star 4196 -> 4181 it/s, C3 3102 -> 3061, C4 1006 -> 992.)
 template <int N>
 __device__ __forceinline__ void hgs_adam_lane(const HgsAdamSlot& s, size_t i, const float* g, float beta1, float beta2, float eps) {
   if (!s.p) return;
@@ -43,28 +44,6 @@ __device__ __forceinline__ void hgs_adam_lane(const HgsAdamSlot& s, size_t i, co
   for (int k = 0; k < N; k++) hgs_adam_one(p[k], g[k], m[k], v[k], one_m_b1, beta2, step_size, inv_sqrt_bc2, eps);
 #pragma unroll
   for (int k = 0; k < N; k++) { s.p[i * N + k] = p[k]; s.m[i * N + k] = m[k]; s.v[i * N + k] = v[k]; }
-}
-
-// The same in two halves, for a lane that can ask for the element's state EARLY -- with its other independent loads, in front of
-// the gradient arithmetic -- and so hides the round trip behind it (3 N more live registers).
-template <int N> struct HgsAdamState { float p[N], m[N], v[N]; };
-template <int N>
-__device__ __forceinline__ void hgs_adam_lane_load(const HgsAdamSlot& s, size_t i, HgsAdamState<N>& st) {
-#pragma unroll
-  for (int k = 0; k < N; k++) { st.p[k] = 0.f; st.m[k] = 0.f; st.v[k] = 0.f; }
-  if (!s.p) return;
-#pragma unroll
-  for (int k = 0; k < N; k++) { st.p[k] = s.p[i * N + k]; st.m[k] = s.m[i * N + k]; st.v[k] = s.v[i * N + k]; }
-}
-template <int N>
-__device__ __forceinline__ void hgs_adam_lane_apply(const HgsAdamSlot& s, size_t i, HgsAdamState<N>& st, const float* g, float beta1,
-                                                    float beta2, float eps) {
-  if (!s.p) return;
-  const float step_size = s.coef[0], inv_sqrt_bc2 = s.coef[1], one_m_b1 = 1.f - beta1;
-#pragma unroll
-  for (int k = 0; k < N; k++) hgs_adam_one(st.p[k], g[k], st.m[k], st.v[k], one_m_b1, beta2, step_size, inv_sqrt_bc2, eps);
-#pragma unroll
-  for (int k = 0; k < N; k++) { s.p[i * N + k] = st.p[k]; s.m[i * N + k] = st.m[k]; s.v[i * N + k] = st.v[k]; }
 }
 
 // Start of an iteration whose backward updates in its lanes (rides with the prologue, hgs_prologue.h): thread k advances tensor

@@ -747,17 +747,6 @@ __global__ __launch_bounds__(HGS_BLOCK) __attribute__((amdgpu_waves_per_eu((MODE
   if (MODE == 1) seg_pre = hgs_segment_geom(idx, pb.endpoints, pb.endpoint_pairs);
   if (MODE == 2) raw_rot_pre = ((const float4*)pb.rotation_raw)[idx];
   if (MODE != 0) mask_pre = pb.extra4[4 * (size_t)idx];
-#ifndef HGS_ADAM_EARLY
-#define HGS_ADAM_EARLY 0      // experiment (round 5): 1 = the in-lane Adam's p / m / v are requested here, with the lane's other loads
-#endif
-#if HGS_ADAM_EARLY
-  HgsAdamState<1> ad_w, ad_o, ad_m;
-  HgsAdamState<3> ad_dc;
-  if (MODE == 1) {
-    hgs_adam_lane_load<1>(pb.adam.slot[0], (size_t)idx, ad_w); hgs_adam_lane_load<1>(pb.adam.slot[1], (size_t)idx, ad_o);
-    hgs_adam_lane_load<1>(pb.adam.slot[2], (size_t)idx, ad_m); hgs_adam_lane_load<3>(pb.adam.slot[3], (size_t)idx, ad_dc);
-  }
-#endif
   if (vis) {
     // ---- deterministic gather of this Gaussian's per-instance partial sums (instance order = tile rect order)
     const HgsRect rc = rc_pre;
@@ -1027,17 +1016,10 @@ __global__ __launch_bounds__(HGS_BLOCK) __attribute__((amdgpu_waves_per_eu((MODE
     pb.d_mask_raw[idx] = g_m;
     // Adam in the lane (include/hgs.h HgsAdamSlot): every gradient of this Gaussian's own parameters is final here, and nothing
     // else in the launch reads the raw parameters (the lane itself works on the forward's activations)
-#if HGS_ADAM_EARLY
-    hgs_adam_lane_apply<1>(pb.adam.slot[0], (size_t)idx, ad_w, &g_w, pb.adam.beta1, pb.adam.beta2, pb.adam.eps);
-    hgs_adam_lane_apply<1>(pb.adam.slot[1], (size_t)idx, ad_o, &g_o, pb.adam.beta1, pb.adam.beta2, pb.adam.eps);
-    hgs_adam_lane_apply<1>(pb.adam.slot[2], (size_t)idx, ad_m, &g_m, pb.adam.beta1, pb.adam.beta2, pb.adam.eps);
-    hgs_adam_lane_apply<3>(pb.adam.slot[3], (size_t)idx, ad_dc, dsh_dc, pb.adam.beta1, pb.adam.beta2, pb.adam.eps);
-#else
     hgs_adam_lane<1>(pb.adam.slot[0], (size_t)idx, &g_w, pb.adam.beta1, pb.adam.beta2, pb.adam.eps);
     hgs_adam_lane<1>(pb.adam.slot[1], (size_t)idx, &g_o, pb.adam.beta1, pb.adam.beta2, pb.adam.eps);
     hgs_adam_lane<1>(pb.adam.slot[2], (size_t)idx, &g_m, pb.adam.beta1, pb.adam.beta2, pb.adam.eps);
     hgs_adam_lane<3>(pb.adam.slot[3], (size_t)idx, dsh_dc, pb.adam.beta1, pb.adam.beta2, pb.adam.eps);
-#endif
   } else {
     const HgsCloudParamGrads cg = hgs_cloud_param_grads(s_pre[0], s_pre[1], s_pre[2], raw_rot_pre, o_act, mask_pre, dscale,
                                                         make_float4(drot[0], drot[1], drot[2], drot[3]), dop,

@@ -15,9 +15,7 @@
 #include "hgs_adam.h"
 
 #define HGS_STRAND_MINV 1e-7f
-#ifndef HGS_ADAM_EARLY
-#define HGS_ADAM_EARLY 0      // experiment (round 5): see hgs_preprocess.hip
-#endif
+
 
 // Gradient of segment k w.r.t. its two endpoints: endpoint 0 receives h - gD, endpoint 1 receives h + gD
 // (h = half the gradient of the midpoint, gD = gradient w.r.t. delta = e1 - e0 from direction, quaternion and length).
@@ -161,10 +159,6 @@ __device__ __forceinline__ void hgs_strand_bwd_block(const HgsStrandBwdArgs& A_i
       // so that nothing branches between the loads of one evaluation and the next -- the lane's six dependent chains
       // (code -> index row -> endpoints) overlap instead of running one after the other (14.5 -> 11.6 us for the launch).
       float acc[3] = {0.f, 0.f, 0.f};
-#if HGS_ADAM_EARLY
-      HgsAdamState<3> ad_ep;
-      if (CONTRIB) hgs_adam_lane_load<3>(A.adam.slot[0], (size_t)i, ad_ep);
-#endif
       const int2 cs = *(const int2*)(fu.ep_segments + 2 * (size_t)ic);
       const bool with_smooth = fu.ep_pairs && fu.n_smooth > 0;
       int4 cp = make_int4(-1, -1, -1, -1);
@@ -232,11 +226,7 @@ __device__ __forceinline__ void hgs_strand_bwd_block(const HgsStrandBwdArgs& A_i
       A.d_ep[3 * (size_t)i] = acc[0]; A.d_ep[3 * (size_t)i + 1] = acc[1]; A.d_ep[3 * (size_t)i + 2] = acc[2];
       // Adam in the lane (include/hgs.h HgsAdamSlot): possible because nothing of this launch reads the endpoints any more --
       // segment contributions and pair gradients arrive precomputed (round 4 still noted that the neighbouring lanes re-read them)
-#if HGS_ADAM_EARLY
-      if (CONTRIB) hgs_adam_lane_apply<3>(A.adam.slot[0], (size_t)i, ad_ep, acc, A.adam.beta1, A.adam.beta2, A.adam.eps);
-#else
       if (CONTRIB) hgs_adam_lane<3>(A.adam.slot[0], (size_t)i, acc, A.adam.beta1, A.adam.beta2, A.adam.eps);
-#endif
     } else if (i < fu.n_smooth) {   // scatter mode: smoothness gradient added into d_ep with atomics
       hgs_smooth_bwd_pair(i, ep, fu.smooth_pairs, fu.cos_threshold, fu.eps, smooth_scale, A.d_ep);
     }
