@@ -600,14 +600,21 @@ class FusedStrandStep:
         self.head = head_params(self.views.H, self.views.W, self.opt, n, g._endpoints.shape[0], g.min_val,
                                 self.views.has_float_mask)
         # endpoint adjacency for the gather-mode backward (HgsStrandFusion.ep_segments / ep_pairs): an endpoint of a
-        # chain touches <= 2 segments and <= 4 smoothness-pair roles; anything denser keeps the scatter (atomic) mode
+        # chain touches <= 2 segments and <= 4 smoothness-pair roles; anything denser keeps the scatter (atomic) mode.
+        # Remembered on the model for as long as both index tables are the same tensors (a topology event assigns new ones): the
+        # eager iteration of training() and the GraphedStep captured after it each build a step object per event.
         E = g._endpoints.shape[0]
+        cached = getattr(g, "_adjacency_cache", None)
+        if cached is not None and cached[0] is g.endpoint_pairs and cached[1] is self.smooth_pairs and cached[2] == E:
+            self.ep_segments, self.ep_pairs = cached[3], cached[4]
+            return
         self.ep_segments = _adjacency(g.endpoint_pairs.reshape(-1), 2, E, 2)
         self.ep_pairs = None
         if self.ep_segments is not None and self.smooth_pairs is not None:
             self.ep_pairs = _adjacency(self.smooth_pairs.reshape(-1), 4, E, 4)
             if self.ep_pairs is None:
                 self.ep_segments = None
+        g._adjacency_cache = (g.endpoint_pairs, self.smooth_pairs, E, self.ep_segments, self.ep_pairs)
 
     def loss(self):
         """(total loss, terms tensor) of the CURRENT slot view; differentiable w.r.t. the model parameters."""

@@ -697,9 +697,27 @@ class HairGaussianModel(HairTopologyMixin, GaussianModel):
         """[pairs, 2, 2] endpoint-id tensor of consecutive segments of every strand, cached on the device until the
         topology changes.  (The reference rebuilds it on the CPU through Cython every iteration, losses.py:193-199.)"""
         if self._smooth_pairs is None:
-            from c_utils import filter_strand_segments_flat
-            idx = filter_strand_segments_flat(*self.strands_info.flat)
-            self._smooth_pairs = torch.as_tensor(np.asarray(idx), device=self.device, dtype=torch.long)
+            dev_tables = getattr(self, "_strands_dev", None)
+            if self._endpoints.is_cuda and dev_tables is not None and dev_tables[0].numel() == len(self.strands_info.offsets) \
+                    and dev_tables[1].shape[0] == len(self.strands_info.rows):
+                # on the device, from the strand tables compute_strands_info / sort_spatially left there: every row of a strand
+                # but its last one, with its successor -- c_utils.filter_strand_segments_flat's pairs in its order
+                # (tests/test_gpu_train.py::test_device_smoothness_pairs_equal_the_native_filter) without the 1.1 ms upload of
+                # a 10 MB host table per topology event (round 5: tools/dev/soak_profile.py)
+                off, rows = dev_tables[0], dev_tables[1].reshape(-1, 2)
+                total = rows.shape[0]
+                if total == 0:
+                    self._smooth_pairs = torch.empty((0, 2, 2), dtype=torch.long, device=self.device)
+                else:
+                    keep = torch.ones(total, dtype=torch.bool, device=self.device)
+                    last = off[1:][off[1:] > off[:-1]] - 1
+                    keep[last] = False
+                    first = torch.nonzero(keep).squeeze(1)
+                    self._smooth_pairs = torch.stack((rows.index_select(0, first), rows.index_select(0, first + 1)), dim=1).to(torch.long).contiguous()
+            else:
+                from c_utils import filter_strand_segments_flat
+                idx = filter_strand_segments_flat(*self.strands_info.flat)
+                self._smooth_pairs = torch.as_tensor(np.asarray(idx), device=self.device, dtype=torch.long)
         return self._smooth_pairs
 
     # ---- construction from explicit polylines (synthetic scenes; the reference builds strands through merge.py) --

@@ -1505,6 +1505,36 @@ def test_adam_in_the_backward_lanes_equals_the_adam_launch(kind):
     assert steps and steps[-1] == 10.0 and set(steps) <= {0.0, 10.0} and steps.count(10.0) >= 5
 
 
+def test_device_smoothness_pairs_equal_the_native_filter():
+    """smoothness_index_pairs() of a GPU model builds the table of consecutive strand segments on the device, from the strand
+    tables compute_strands_info / sort_spatially keep there; c_utils.filter_strand_segments_flat (the native restatement of the
+    reference's Cython helper, pinned against its build) on the host tables gives the same pairs in the same order -- on the
+    initial strands, after densification + merging (clones, splits, background segments) and after the storage sort."""
+    from arguments import OptimizationParams
+    from c_utils import filter_strand_segments_flat
+    from synthetic import build_workload
+    from train import training
+    model, cams, extent = build_workload("tiny", device="cuda", with_targets=True)
+    opt = OptimizationParams()
+    opt.densify_from_iter, opt.densification_interval, opt.merge_interval, opt.densify_grad_threshold = 3, 6, 8, 1e-7
+    model.training_setup(opt)
+
+    def check():
+        model._smooth_pairs = None
+        got = model.smoothness_index_pairs()
+        assert got.is_cuda and got.dtype == torch.long
+        want = np.asarray(filter_strand_segments_flat(*model.strands_info.flat)).reshape(-1, 2, 2)
+        assert np.array_equal(got.cpu().numpy(), want) and want.shape[0] > 0
+
+    check()
+    training(model, cams, opt, iterations=26, extent=extent)
+    assert model.get_xyz.shape[0] != 1200          # the operators did change the model
+    model.compute_strands_info()
+    check()
+    model.sort_spatially()
+    check()
+
+
 def test_replays_after_a_blocking_pass_on_the_same_views():
     """The captured step's first launch counts into the image buffer's tile counters beside the workgroups that clear the other
     counters, so it needs them at zero -- which capacity-mode passes leave behind and a blocking-mode pass does not.  A blocking
