@@ -16,15 +16,18 @@ def _info_dict(info):
 
 class HairTopologyMixin:
     # ---- index helpers -------------------------------------------------------------------------------------------
-    def _endpoint_degrees(self):
-        """torch.unique(endpoint_pairs, return_counts=True), remembered for as long as `endpoint_pairs` is the same tensor
-        object (every topology change assigns a new one): the operators of one event ask four times, ~1 ms each at 3 x 10^5
-        segments."""
+    def _endpoint_degree_table(self):
+        """deg[id] = number of segments that reference endpoint id, for every id below max(id) + 1 (0: not referenced) -- what
+        the reference reads off torch.unique(endpoint_pairs, return_counts=True) + torch.isin (`u[c == 1]` are the ids of degree 1,
+        `isin(x, u[c != 1])` is deg[x] != 1 for ids that occur).  One bincount, and a gather per question instead of a sort-based
+        membership test over 6 x 10^5 ids (torch.isin: 0.4 ms a call, four to six calls per topology event); remembered for as
+        long as `endpoint_pairs` is the same tensor object (every topology change assigns a new one)."""
         cached = getattr(self, "_degree_cache", None)
         if cached is None or cached[0] is not self.endpoint_pairs:
-            u, c = torch.unique(self.endpoint_pairs, return_counts=True)
-            cached = self._degree_cache = (self.endpoint_pairs, u, c)
-        return cached[1], cached[2]
+            flat = self.endpoint_pairs.reshape(-1)
+            deg = torch.bincount(flat) if flat.numel() else torch.zeros(0, dtype=torch.long, device=self.device)
+            cached = self._degree_cache = (self.endpoint_pairs, deg)
+        return cached[1]
 
     def get_first_occurence_index(self, tensor):
         """Index of the first occurrence of every unique value (reference :772-784)."""
@@ -36,9 +39,15 @@ class HairTopologyMixin:
     def remove_duplicate_endpoint_rows(self, index_pairs, return_mask=False):
         """Keep the rows whose two ids both occur there for the first time in row-major order (reference :712-728)."""
         flat = index_pairs.flatten()
-        mask = torch.zeros(flat.shape[0], dtype=torch.bool, device=self.device)
         if flat.numel():
-            mask[self.get_first_occurence_index(flat)] = True
+            # position of every id's first occurrence by a scatter-min (order-independent: deterministic), instead of
+            # get_first_occurence_index's unique(dim=0) + flips: mask[i] <=> flat[i] occurs at i for the first time
+            pos = torch.arange(flat.shape[0], dtype=torch.long, device=flat.device)
+            first = torch.full((int(flat.max()) + 1,), flat.shape[0], dtype=torch.long, device=flat.device)
+            first.scatter_reduce_(0, flat, pos, reduce="amin", include_self=True)
+            mask = first[flat] == pos
+        else:
+            mask = torch.zeros(0, dtype=torch.bool, device=self.device)
         mask = mask.reshape(-1, 2)
         mask = mask[:, 0] & mask[:, 1]
         return (index_pairs[mask], mask) if return_mask else index_pairs[mask]
@@ -132,9 +141,7 @@ class HairTopologyMixin:
                     g["params"][0].grad = None
                 self._smooth_pairs = None
                 break
-            u, c = self._endpoint_degrees()
-            interior = u[c != 1]
-            both_interior = torch.all(torch.isin(cand, interior), dim=1)
+            both_interior = torch.all(self._endpoint_degree_table()[cand] != 1, dim=1)     # (isin(cand, u[c != 1]))
             mask[mask.clone()] = both_interior
             to_merge = cand[both_interior]
             to_merge, keep = self.remove_duplicate_endpoint_rows(to_merge, return_mask=True)
@@ -175,8 +182,7 @@ class HairTopologyMixin:
                 info["prune_big_ws"] = int(big.sum())
             prune = prune | big
         if avoid_connected and prune.sum() != 0:
-            u, c = self._endpoint_degrees()
-            is_end = torch.any(torch.isin(self.endpoint_pairs, u[c == 1]), dim=1)
+            is_end = torch.any(self._endpoint_degree_table()[self.endpoint_pairs] == 1, dim=1)   # (isin(pairs, u[c == 1]))
             allowed = is_end | (self.get_mask < self.foreground_binarization_th).squeeze(1)
             if info is not None:
                 info["prune_avoided"] = int(prune.sum() - (prune & allowed).sum())
@@ -191,8 +197,7 @@ class HairTopologyMixin:
         """Remove background / transparent segments (only strand-end ones when avoid_connected) (:1500-1515)."""
         prune = ~self.compute_foreground_mask()
         if avoid_connected:
-            u, c = self._endpoint_degrees()
-            is_end = torch.any(torch.isin(self.endpoint_pairs[prune], u[c == 1]), dim=1)
+            is_end = torch.any(self._endpoint_degree_table()[self.endpoint_pairs[prune]] == 1, dim=1)
             prune[prune.clone()] = is_end
         self.prune_segments(prune)
 
@@ -222,10 +227,11 @@ class HairTopologyMixin:
         sits on a strand whose OTHER end was already merged in this round.  Returns an [N,2] id tensor."""
         from scipy.spatial import cKDTree
         dir_th = np.cos(np.deg2rad(self.merge_angle_th))
-        ids, counts = self._endpoint_degrees()
-        ends = ids[counts == 1]
-        fg_ids = self.endpoint_pairs[self.compute_foreground_mask()].flatten()
-        ends = ends[torch.isin(ends, fg_ids)]
+        deg = self._endpoint_degree_table()
+        ends = torch.nonzero(deg == 1).squeeze(1)            # ascending ids, like unique()'s (ids[counts == 1])
+        is_fg = torch.zeros(deg.shape[0], dtype=torch.bool, device=self.device)
+        is_fg[self.endpoint_pairs[self.compute_foreground_mask()].flatten()] = True
+        ends = ends[is_fg[ends]]                             # (ends[isin(ends, ids of the foreground segments)])
         empty = torch.zeros((0, 2), dtype=torch.long, device=self.device)
         if ends.numel() < 2:
             return empty
