@@ -20,7 +20,8 @@ accumulated from the RGB-only moments of the fused 7-channel pass -- is accumula
 three-pass op-by-op form (the reference's structure: RGB render + its own screen-space gradient) evaluated on the SAME
 parameters every iteration, and compared.
 
-  python tools/three_stage.py [strands=500] [iters_stage1=5000] [iters_stage3=5000] > profiles/r05_three_stage.json
+  python tools/three_stage.py [strands=500] [iters_stage1=5000] [iters_stage3=5000] [views=16] [W=800] [H=800] > profiles/r05_three_stage.json
+  (profiles/r05_three_stage_1080p.json: 2000 5000 5000 32 1920 1080 -- 200 k ground-truth segments, BASELINE config 3's frame and views)
 """
 import faulthandler
 import json
@@ -45,7 +46,10 @@ from utils.general import safe_state  # noqa: E402
 S = int(sys.argv[1]) if len(sys.argv) > 1 else 500
 N1 = int(sys.argv[2]) if len(sys.argv) > 2 else 5000
 N3 = int(sys.argv[3]) if len(sys.argv) > 3 else 5000
-N_SEG, VIEWS, W, H = 100, 16, 800, 800
+N_SEG = 100
+VIEWS = int(sys.argv[4]) if len(sys.argv) > 4 else 16
+W = int(sys.argv[5]) if len(sys.argv) > 5 else 800
+H = int(sys.argv[6]) if len(sys.argv) > 6 else 800
 rt.lib()
 _real_stdout, sys.stdout = sys.stdout, sys.stderr      # (the model classes print progress lines: stdout is the JSON alone)
 safe_state(True)
