@@ -245,6 +245,12 @@ int hgs_hair_endpoint_gather(void* stream, int E, const float* seg_contrib, cons
                                 nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, fu,
                                 E > 0 ? (const float4*)seg_contrib : &kNone, adam ? *adam : HgsAdamInline{}};
     if (A.adam.slot[0].p && (!A.adam.slot[0].m || !A.adam.slot[0].v || !A.adam.slot[0].coef)) { hgs_set_error("hgs_hair_endpoint_gather: incomplete Adam slot"); return 1; }
+    // the in-lane update writes the endpoints: no lane of the launch may read them, i.e. a smoothness term needs its pair
+    // gradients precomputed (HgsStrandFusion.smooth_pair_grads) -- evaluating the pairs here would race with the updates
+    if (A.adam.slot[0].p && fu.n_smooth > 0 && !fu.smooth_pair_grads) {
+      hgs_set_error("hgs_hair_endpoint_gather: the in-lane Adam update with a smoothness term needs HgsStrandFusion.smooth_pair_grads");
+      return 1;
+    }
     hipLaunchKernelGGL(strand_gather_kernel, dim3((E + 255) / 256 + (fu.head_tail.out ? 1 : 0)), dim3(256), 0, s, A);
   }
   HGS_CHECK_LAUNCH();

@@ -403,7 +403,8 @@ int hgs_backward_multi_params(void* stream, int P, int D, int M, int R, int W, i
                               const float* const* dL_dpix_planes7, void* scratch, float* dL_dsh, const HgsParamBackward* params);
 /* d_endpoints [E,3] fully written.  fusion: ep_segments (required), ep_pairs + the smoothness group (smooth_pairs, n_smooth,
  * cos_threshold, eps, head_out, grad_out) and head_tail as for hgs_hair_params_backward; its other groups are ignored. */
-/* adam (may be NULL): slot 0 = the endpoints' Adam state; the lane then also applies endpoint i's update (HgsAdamSlot). */
+/* adam (may be NULL): slot 0 = the endpoints' Adam state; the lane then also applies endpoint i's update (HgsAdamSlot).  With a
+ * smoothness term this requires fusion->smooth_pair_grads (no lane may read an endpoint while others update them: refused otherwise). */
 int hgs_hair_endpoint_gather(void* stream, int E, const float* seg_contrib, const float* endpoints, float* d_endpoints,
                              const HgsStrandFusion* fusion, const HgsAdamInline* adam);
 
