@@ -286,10 +286,9 @@ static int forward_preprocess_impl(void* stream, int P, int D, int M, int W, int
 
 static int forward_render_impl(void* stream, int P, int W, int H, int R_capacity, const float* bg,
                                const float* colors_precomp, const float* extra, int n_extra, void* geom_buf,
-                               void* binning_buf, void* image_buf, float* out_color, const HgsPixelHead* head = nullptr) {
+                               void* binning_buf, void* image_buf, float* out_color) {
   hipStream_t s = (hipStream_t)stream;
   if (check_aligned(image_buf, "image_buf")) return 1;
-  if (head && (!head->targets || !head->partials)) { hgs_set_error("HgsPixelHead: targets / partials are required"); return 1; }
   if (!bg || !out_color) { hgs_set_error("null bg/out_color"); return 1; }
   if (n_extra != 0 && n_extra != 4) { hgs_set_error("n_extra must be 0 or 4 (got %d)", n_extra); return 1; }
   if (n_extra && P > 0 && (!extra || ((size_t)extra & 15))) { hgs_set_error("extra colours must be a 16-byte aligned [P,4] array"); return 1; }
@@ -311,7 +310,7 @@ static int forward_render_impl(void* stream, int P, int W, int H, int R_capacity
   }
   // always launched: besides the per-tile sorts (no-ops on empty lists) it computes the blend kernels' work list
   if (hgs_launch_sort_tiles(s, W, H, R_capacity > 0 ? R_capacity : 0, n_extra, g, im, b)) return 1;
-  return hgs_launch_blend_fwd(s, W, H, R_capacity > 0 ? R_capacity : 0, channels, bg, im, b, out_color, head);
+  return hgs_launch_blend_fwd(s, W, H, R_capacity > 0 ? R_capacity : 0, channels, bg, im, b, out_color);
 }
 
 int hgs_forward_render(void* stream, int P, int W, int H, int R_capacity, const float* bg, const float* colors_precomp,
@@ -325,13 +324,6 @@ int hgs_forward_render_multi(void* stream, int P, int W, int H, int R_capacity, 
                              void* image_buf, float* out_color7) {
   return forward_render_impl(stream, P, W, H, R_capacity, bg7, colors_precomp, extra4, 4, geom_buf, binning_buf,
                              image_buf, out_color7);
-}
-
-int hgs_forward_render_multi_head(void* stream, int P, int W, int H, int R_capacity, const float* bg7,
-                                  const float* colors_precomp, const float* extra4, void* geom_buf, void* binning_buf,
-                                  void* image_buf, float* out_color7, const HgsPixelHead* head) {
-  return forward_render_impl(stream, P, W, H, R_capacity, bg7, colors_precomp, extra4, 4, geom_buf, binning_buf,
-                             image_buf, out_color7, head);
 }
 
 size_t hgs_binning_bytes_multi(int R) { HgsBinning b; return hgs_binning_carve(nullptr, (size_t)(R > 0 ? R : 0), b, nullptr, 7); }

@@ -40,7 +40,6 @@
 //     boundary) and, for the segments a pixel passes through, c alpha T_local T_in in place of c alpha T (one rounding
 //     per contribution).  Integer results (last contributor) follow the reference's rules on those products.
 #include "hgs_common.h"
-#include "hgs_pixel_head.h"
 
 // development aid: per-workgroup start/end timestamps (hgs_debug_set_wg_trace)
 __device__ unsigned long long* g_wg_trace_fwd = nullptr;
@@ -207,14 +206,10 @@ __device__ __forceinline__ bool blend_item(const HgsImage& im, uint32_t Rcap, Bl
 // T < 0 marks a pixel that is done (saturated, forward.cu:346-351, or outside the image): its magnitude stays the
 // transmittance it stopped at.  A separate per-lane flag costs a byte register and ~6 vector instructions per
 // entry to test, merge and update; the sign costs one compare.
-struct NoHook { __device__ __forceinline__ void operator()() const {} };
-// after_first_stage(): called once the first batch's records are on their way into LDS, i.e. behind the wait for the walk's first
-// global load -- loads the caller issued BEFORE the walk have landed by then at no extra wait (the pixel head's targets).
-template <int C, typename Hook = NoHook>
+template <int C>
 __device__ __forceinline__ void fwd_walk(const float4* __restrict__ src, uint32_t s, uint32_t e,
                                          float4 (&recs)[2][REC_BATCH * Chan<C>::REC4], uint32_t (&alive)[2][4], float pxf,
-                                         float pyf, int wave, int lane, float& T, float (&acc)[C], uint32_t& last,
-                                         Hook after_first_stage = Hook()) {
+                                         float pyf, int wave, int lane, float& T, float (&acc)[C], uint32_t& last) {
   constexpr int REC4 = Chan<C>::REC4;
   const uint32_t L = e - s;
   const int nb = (int)((L + REC_BATCH - 1) / REC_BATCH);
@@ -227,7 +222,6 @@ __device__ __forceinline__ void fwd_walk(const float4* __restrict__ src, uint32_
     if (threadIdx.x < REC_BATCH * REC4) recs[0][threadIdx.x] = stage;
     if (threadIdx.x < 4) alive[0][threadIdx.x] = 1u;
   }
-  after_first_stage();
   for (int b = 0; b < nb; b++) {
     const int cur = b & 1;
     if (b + 1 < nb) {
@@ -294,19 +288,13 @@ __device__ __forceinline__ void fwd_walk(const float4* __restrict__ src, uint32_
 }
 
 // ------------------------------------------------------------------------------------------------
-// HEAD (C = 7): the loss head's per-pixel terms in the epilogue (include/hgs.h HgsPixelHead): the workgroup that finishes a tile
-// evaluates the mask BCE and the orientation term on the channels it still holds in registers, writes the gradient planes of the
-// tiles the backward will read and the tile's three partial sums.
-template <int C, bool HEAD>
+template <int C>
 __global__ __launch_bounds__(HGS_BLOCK) __attribute__((amdgpu_waves_per_eu(8))) void blend_fwd_kernel(HgsImage im, HgsBinning bn, int W, int H, int gx, uint32_t Rcap,
-                                                              const float* __restrict__ bg, float* __restrict__ out_color, HgsPixelHead hd) {
-  static_assert(!HEAD || C == 7, "the pixel head reads the four extra channels");
+                                                              const float* __restrict__ bg, float* __restrict__ out_color) {
   constexpr int REC4 = Chan<C>::REC4;
   __shared__ float4 recs[2][REC_BATCH * REC4];
   __shared__ uint32_t alive[2][4];
   __shared__ uint32_t s_flag;
-  __shared__ float hred[16];                        // (HEAD: the tile's partial sums)
-  __shared__ float4 htgt[HEAD ? HGS_BLOCK : 1];     // (HEAD: the pixels' targets, parked while the list is walked)
   BlendItem it;
   if (!blend_item(im, Rcap, it)) return;
   const int tile = it.tile;
@@ -325,85 +313,20 @@ __global__ __launch_bounds__(HGS_BLOCK) __attribute__((amdgpu_waves_per_eu(8))) 
   uint32_t last = 0;
   const size_t pix = (size_t)py * W + px, HW = (size_t)H * W;
 
-  // HEAD: a tile's workgroup lives for a few us, of which a chain of memory round trips at its END (target pointers, targets,
-  // then the arithmetic) would be half (measured: the forward 24 -> 58 us at north_star with the targets loaded in finish(): the
-  // launch holds eight workgroups per CU however long each takes).  The targets are fetched FIRST instead -- issued before the
-  // walk's first record load, parked in LDS (a thread's own cell: no barrier) behind the wait that load needs anyway.  Only the
-  // finisher of a list split over three or more workgroups, unknown in advance, loads them late.
-  const HGS_CONSTANT HgsViewTargets* tgt = hgs_constant(hd.targets);   // (the slot was filled by an earlier launch: scalar loads)
-  bool tgt_mask = false;
-  const bool prefetch = HEAD && (!it.split || (it.nseg == 2u && it.seg == 0u));
-  float4 pre = make_float4(0.f, 0.f, 0.f, 0.f);   // float mask, angle, confidence, mask byte
-  auto load_targets = [&](bool inside, size_t pix) {
-    if constexpr (HEAD) {
-      tgt_mask = tgt->mask != nullptr;
-      if (inside) {
-        if (hd.bce) pre.x = hgs_global(tgt->float_mask)[pix];
-        if (hd.ori) {
-          pre.y = hgs_global(tgt->orientation)[pix]; pre.z = hgs_global(tgt->confidence)[pix];
-          if (tgt_mask) pre.w = __uint_as_float((unsigned)hgs_global(tgt->mask)[pix]);
-        }
-      }
-    }
-  };
-  auto park_targets = [&]() { if constexpr (HEAD) htgt[threadIdx.x] = pre; };
-  if (prefetch) load_targets(inside, pix);
-
-  // Every path that finishes a tile ends in finish() with the pixel's final transmittance, last contributor and colour sums.
-  auto finish = [&](float T, uint32_t nc) {
-    // (the pixel's offset is formed again from an opaque copy of the thread id: shared with the kernel's first lines it is a 64-bit
-    // value the compiler keeps -- or, at the 64-register limit of eight waves per SIMD, spills -- across the whole walk)
-    int tid = threadIdx.x;
-    asm volatile("" : "+v"(tid));
-    const int px = tx * HGS_TILE + ((tid >> 6) & 1) * 8 + (tid & 7), py = ty * HGS_TILE + (tid >> 7) * 8 + ((tid >> 3) & 7);
-    const bool inside = px < W && py < H;
-    const size_t pix = (size_t)py * W + px;
-    uint32_t wmax = inside ? nc : 0u;
+  if (!it.split) {
+    float T = inside ? 1.f : -1.f;
+    fwd_walk<C>(src, 0u, it.e, recs, alive, pxf, pyf, wave, lane, T, acc, last);
+    uint32_t wmax = last;
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) wmax = max(wmax, (uint32_t)__shfl_xor((int)wmax, d, 64));
     if (lane == 0 && wmax) atomicMax(&im.tile_maxc[tile], wmax);
-    float v[C];
-#pragma unroll
-    for (int k = 0; k < C; k++) v[k] = acc[k] + T * bg[k];                              // :372
     if (inside) {
+      T = fabsf(T);
       im.final_T[pix] = T;
-      im.n_contrib[pix] = nc;
+      im.n_contrib[pix] = last;
 #pragma unroll
-      for (int k = 0; k < C; k++)
-        if (!HEAD || k < 3 || hd.keep_extra_planes) out_color[k * HW + pix] = v[k];
+      for (int k = 0; k < C; k++) out_color[k * HW + pix] = acc[k] + T * bg[k];         // :372
     }
-    if constexpr (HEAD) {
-      if (prefetch) pre = htgt[threadIdx.x];
-      else load_targets(inside, pix);
-      HeadFlags fl;
-      fl.bce = hd.bce; fl.ori = hd.ori;
-      OriParams p;
-      p.view = hd.targets->viewmatrix; p.bg0 = hd.bg[0]; p.bg1 = hd.bg[1]; p.bg2 = hd.bg[2]; p.min_val = hd.min_val;
-      p.has_mask = tgt_mask;
-      HgsPixelIn in;
-      in.xm = v[3]; in.o0 = v[4]; in.o1 = v[5]; in.o2 = v[6];
-      in.ym = pre.x; in.gt = pre.y; in.cf = pre.z; in.mk = (unsigned char)__float_as_uint(pre.w);
-      HgsPixelOut po;
-      hgs_pixel_terms(fl, p, in, hd.d_extra_unit != nullptr, hd.g_mask, fl.ori ? hd.g_ori / tgt->mask_count : 0.f, po);
-      float bs = inside ? po.s : 0.f, bc = inside ? po.cnt : 0.f, bb = inside ? po.b : 0.f;
-#pragma unroll
-      for (int d = 32; d >= 1; d >>= 1) { bs += __shfl_xor(bs, d, 64); bc += __shfl_xor(bc, d, 64); bb += __shfl_xor(bb, d, 64); }
-      if (lane == 0) { hred[4 * wave] = bs; hred[4 * wave + 1] = bc; hred[4 * wave + 2] = bb; hred[4 * wave + 3] = __uint_as_float(wmax); }
-      __syncthreads();
-      // the rasterizer backward reads dL/dpixel only on tiles where some pixel blended an entry (tile_maxc != 0)
-      const bool used = (__float_as_uint(hred[3]) | __float_as_uint(hred[7]) | __float_as_uint(hred[11]) | __float_as_uint(hred[15])) != 0u;
-      if (inside && used && hd.d_extra_unit) {
-        hd.d_extra_unit[pix] = po.gm; hd.d_extra_unit[HW + pix] = po.g0; hd.d_extra_unit[2 * HW + pix] = po.g1; hd.d_extra_unit[3 * HW + pix] = po.g2;
-      }
-      if (threadIdx.x < 3)   // fixed order: bitwise reproducible
-        hd.partials[3 * (size_t)tile + threadIdx.x] = (hred[threadIdx.x] + hred[4 + threadIdx.x]) + (hred[8 + threadIdx.x] + hred[12 + threadIdx.x]);
-    }
-  };
-
-  if (!it.split) {
-    float T = inside ? 1.f : -1.f;
-    fwd_walk<C>(src, 0u, it.e, recs, alive, pxf, pyf, wave, lane, T, acc, last, park_targets);
-    finish(fabsf(T), last);
     return;
   }
 
@@ -418,7 +341,7 @@ __global__ __launch_bounds__(HGS_BLOCK) __attribute__((amdgpu_waves_per_eu(8))) 
     if (it.seg == 1u) return;
     const uint32_t n = it.range.y - it.range.x;
     float T = inside ? 1.f : -1.f;
-    fwd_walk<C>(src, 0u, it.e, recs, alive, pxf, pyf, wave, lane, T, acc, last, park_targets);
+    fwd_walk<C>(src, 0u, it.e, recs, alive, pxf, pyf, wave, lane, T, acc, last);
     const size_t slot1 = ((size_t)it.w + 1) * HGS_BLOCK + threadIdx.x;
     bn.seg_T[slot1] = fabsf(T);
     // (the first segment's colour waits in its own cell of the segment array, which nobody else reads)
@@ -434,7 +357,17 @@ __global__ __launch_bounds__(HGS_BLOCK) __attribute__((amdgpu_waves_per_eu(8))) 
       // two-segment tile: seg_P, seg_Tout, seg_last, tile_prog, tile_done -- the exchange between segment workgroups.
       bn.seg_C[((size_t)it.w * C + k) * HGS_BLOCK + threadIdx.x] = acc[k];
     }
-    finish(fabsf(T), last);
+    uint32_t wmax = last;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) wmax = max(wmax, (uint32_t)__shfl_xor((int)wmax, d, 64));
+    if (lane == 0 && wmax) atomicMax(&im.tile_maxc[tile], wmax);
+    if (inside) {
+      T = fabsf(T);
+      im.final_T[pix] = T;
+      im.n_contrib[pix] = last;
+#pragma unroll
+      for (int k = 0; k < C; k++) out_color[k * HW + pix] = acc[k] + T * bg[k];
+    }
     return;
   }
 
@@ -553,7 +486,7 @@ __global__ __launch_bounds__(HGS_BLOCK) __attribute__((amdgpu_waves_per_eu(8))) 
   wseg = __builtin_amdgcn_readfirstlane(wseg);
 #pragma unroll
   for (int k = 0; k < C; k++) acc[k] = 0.f;
-  constexpr int FG = C <= 4 ? 8 : (HEAD ? 3 : 4);                               // segments per group of the colour sums (HEAD: 4 would spill at 64 registers -- and a kernel with ANY scratch pays for it at every dispatch)
+  constexpr int FG = C <= 4 ? 8 : 4;                               // segments per group of the colour sums
   for (int mh = (int)wseg; mh >= 0; mh -= FG) {
     float v[FG][C];
 #pragma unroll
@@ -571,7 +504,16 @@ __global__ __launch_bounds__(HGS_BLOCK) __attribute__((amdgpu_waves_per_eu(8))) 
         }
       }
   }
-  finish(Tfin, nc);
+  uint32_t wmax = inside ? nc : 0u;
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) wmax = max(wmax, (uint32_t)__shfl_xor((int)wmax, d, 64));
+  if (lane == 0 && wmax) atomicMax(&im.tile_maxc[tile], wmax);
+  if (inside) {
+    im.final_T[pix] = Tfin;
+    im.n_contrib[pix] = nc;
+#pragma unroll
+    for (int k = 0; k < C; k++) out_color[k * HW + pix] = acc[k] + Tfin * bg[k];
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -790,22 +732,16 @@ static inline unsigned blend_grid(int T, const HgsBinning& b) {
 }
 
 int hgs_launch_blend_fwd(hipStream_t s, int W, int H, int Rcap, int channels, const float* bg, const HgsImage& im,
-                         const HgsBinning& b, float* out_color, const HgsPixelHead* head) {
+                         const HgsBinning& b, float* out_color) {
   const int gx = (W + HGS_TILE - 1) / HGS_TILE, gy = (H + HGS_TILE - 1) / HGS_TILE;
-  if (head && channels != 7) { hgs_set_error("the pixel head needs the single-pass (7-channel) forward"); return 1; }
   {
     HgsProfScope _prof(s, HGS_K_BLEND_FWD);
-    HgsPixelHead hd = {};
-    if (head) hd = *head;
     if (channels == 3)
-      hipLaunchKernelGGL((blend_fwd_kernel<3, false>), dim3(blend_grid(gx * gy, b)), dim3(HGS_BLOCK), 0, s, im, b, W, H, gx,
-                         (uint32_t)Rcap, bg, out_color, hd);
-    else if (!head)
-      hipLaunchKernelGGL((blend_fwd_kernel<7, false>), dim3(blend_grid(gx * gy, b)), dim3(HGS_BLOCK), 0, s, im, b, W, H, gx,
-                         (uint32_t)Rcap, bg, out_color, hd);
+      hipLaunchKernelGGL(blend_fwd_kernel<3>, dim3(blend_grid(gx * gy, b)), dim3(HGS_BLOCK), 0, s, im, b, W, H, gx,
+                         (uint32_t)Rcap, bg, out_color);
     else
-      hipLaunchKernelGGL((blend_fwd_kernel<7, true>), dim3(blend_grid(gx * gy, b)), dim3(HGS_BLOCK), 0, s, im, b, W, H, gx,
-                         (uint32_t)Rcap, bg, out_color, hd);
+      hipLaunchKernelGGL(blend_fwd_kernel<7>, dim3(blend_grid(gx * gy, b)), dim3(HGS_BLOCK), 0, s, im, b, W, H, gx,
+                         (uint32_t)Rcap, bg, out_color);
   }
   HGS_CHECK_LAUNCH();
   return 0;

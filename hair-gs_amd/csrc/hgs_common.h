@@ -280,7 +280,7 @@ int hgs_launch_scatter(hipStream_t s, int P, int W, int H, int Rcap, const float
 int hgs_launch_sort_tiles(hipStream_t s, int W, int H, int Rcap, int n_extra, const HgsGeom& g, const HgsImage& im,
                           const HgsBinning& b);
 int hgs_launch_blend_fwd(hipStream_t s, int W, int H, int Rcap, int channels, const float* bg, const HgsImage& im,
-                         const HgsBinning& b, float* out_color, const HgsPixelHead* head = nullptr);
+                         const HgsBinning& b, float* out_color);
 int hgs_launch_blend_bwd(hipStream_t s, int W, int H, int Rcap, int channels, const float* bg, const HgsImage& im,
                          const HgsBinning& b, const float* const* dL_dpix_planes, float* inst_grad);
 struct HgsBwdArgs {
@@ -323,12 +323,6 @@ __device__ __forceinline__ void hgs_drain_stores() { asm volatile("s_waitcnt vmc
 #define HGS_GLOBAL __attribute__((address_space(1)))
 template <typename T>
 __device__ __forceinline__ const HGS_GLOBAL T* hgs_global(const T* p) { return (const HGS_GLOBAL T*)p; }
-// Memory that no launch in flight writes and that a whole wavefront reads at one address (a view's target slot, a camera matrix):
-// read through the CONSTANT address space the loads are scalar (s_load into SGPRs, issued early, no VGPRs) -- a generic or global
-// pointer gets vector loads whenever the kernel also stores somewhere the compiler cannot tell apart.
-#define HGS_CONSTANT __attribute__((address_space(4)))
-template <typename T>
-__device__ __forceinline__ const HGS_CONSTANT T* hgs_constant(const T* p) { return (const HGS_CONSTANT T*)(uintptr_t)p; }
 typedef float hgs_float4_t __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ float4 hgs_load4(const HGS_GLOBAL float* p) {      // 16-byte aligned
   return __builtin_bit_cast(float4, *(const HGS_GLOBAL hgs_float4_t*)p);   // (no component-wise copy: the load's registers are the result)

@@ -10,7 +10,6 @@
 //   backward: dL/dx1(q) = g_ssim * [conv(a) + 2 x1(q) conv(b) + x2(q) conv(c)] + g_l1 * sign(x1 - x2)
 // (the window is symmetric, so the adjoint of the filter is the filter itself; zero padding on both sides).
 #include "hgs_common.h"
-#include "hgs_pixel_head.h"
 #include "hgs_head_tail.h"
 
 namespace {
@@ -650,7 +649,26 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HGS_SSIM_BW
   }
 }
 
-// ---- orientation loss (reference loss/losses.py:224-289): OriParams / ori_pixel / ori_pixel_grad live in hgs_pixel_head.h ----
+// ---- orientation loss (reference loss/losses.py:224-289) ---------------------------------------------------------
+// per pixel: world-space direction image -> view space (x,y) -> unit 2-vector -> angle in [0,pi) w.r.t. the image
+// y axis -> bidirectional difference to the GT angle, confidence-weighted, averaged over the mask.
+struct OriParams { const float* view; float bg0, bg1, bg2; float min_val; int has_mask; };
+
+__device__ __forceinline__ bool ori_pixel(const OriParams& p, float o0, float o1, float o2, float& px, float& py, float& r,
+                                          float& n, float& x, float& y, float& yq, float& theta) {
+  const float* v = p.view;                      // world_view_transform, row-major 4x4 (device, wave-uniform)
+  px = o0 * v[0] + o1 * v[4] + o2 * v[8];      // (flat @ world_view[:3,:3])[:, :2]
+  py = o0 * v[1] + o1 * v[5] + o2 * v[9];
+  r = sqrtf(px * px + py * py);
+  n = r + p.min_val;
+  const float in = __builtin_amdgcn_rcpf(n);    // (hardware reciprocals, 1 ulp, here and in the gradient: the per-pixel kernel is
+  x = px * in;                                  //  bound by its vector instructions -- 357 per wavefront, 63 % of the pipe -- and an
+  y = py * in;                                  //  IEEE division is ten of them)
+  yq = y < p.min_val ? y + p.min_val : y;
+  theta = atan2f(x, yq);
+  if (theta < 0.f) theta += 3.14159265358979323846f;
+  return true;
+}
 
 __global__ __launch_bounds__(256) void ori_fwd_kernel(int N, OriParams p, const float* __restrict__ omap,
                                                       const float* __restrict__ gt, const float* __restrict__ conf,
@@ -713,6 +731,27 @@ __global__ __launch_bounds__(256) void ori_bwd_kernel(int N, OriParams p, const 
 // pix kernels: binary cross-entropy with logits of the blended mask channel against the view's float mask
 // (loss/losses.py:240-248, F.binary_cross_entropy_with_logits, mean over H*W) and the orientation term above, in
 // one pass over the pixels; targets come from the device-resident HgsViewTargets.
+struct HeadFlags { int bce, ori; };
+
+// gradient of the orientation term w.r.t. the direction image at one masked pixel, `scale` = dL/d(term) / mask count
+__device__ __forceinline__ void ori_pixel_grad(const OriParams& p, float px, float py, float r, float n, float x, float yq,
+                                               float th, float gt, float conf, float scale, float& g0, float& g1, float& g2) {
+  const float hp = 1.57079632679489661923f;
+  const float e = th - gt;
+  const float u = fabsf(e) - hp;
+  const float sg = (u > 0.f ? 1.f : (u < 0.f ? -1.f : 0.f)) * (e > 0.f ? 1.f : (e < 0.f ? -1.f : 0.f));
+  const float dth = -sg * conf * scale;                               // dL/dtheta
+  const float iden = __builtin_amdgcn_rcpf(x * x + yq * yq);
+  const float dx = dth * (yq * iden), dy = dth * (-x * iden);         // atan2(x, yq)
+  // x = px/n, y = py/n, n = r + eps.  r = 0 (a masked pixel nothing was blended into): torch's norm has the subgradient 0
+  // there and the direct 1 / n path stays -- the reference's gradient at such a pixel is ~conf / (count eps^2), and so is this one
+  const float inv_n = __builtin_amdgcn_rcpf(n), inv_n2 = inv_n * inv_n, ir = r > 0.f ? __builtin_amdgcn_rcpf(r) : 0.f;
+  const float dn = -(dx * px + dy * py) * inv_n2;
+  const float dpx = dx * inv_n + dn * px * ir, dpy = dy * inv_n + dn * py * ir;
+  const float* v = p.view;
+  g0 = dpx * v[0] + dpy * v[1]; g1 = dpx * v[4] + dpy * v[5]; g2 = dpx * v[8] + dpy * v[9];
+}
+
 // d_unit != NULL: the gradient planes for an upstream gradient of 1 are written in the same pass (g_mask = l_mask/HW,
 // g_ori = l_orientation; the orientation term is normalised by tgt->mask_count, known before the pass)
 struct HeadReduce { int nb_ssim, nb_pix, nb_smooth; float inv_chw, inv_hw; float l_dssim, l_mask, l_ori, l_smooth; int bce, ori; };
@@ -1012,14 +1051,27 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8))) void p
       static_assert(HGS_TILE == 16, "pixel -> tile by a shift of 4");
       used = tile_used[(y >> 4) * tiles_x + (x >> 4)];
     }
-    OriParams p;
-    p.view = tgt->viewmatrix; p.bg0 = bg0; p.bg1 = bg1; p.bg2 = bg2; p.min_val = min_val; p.has_mask = has_mask;
-    HgsPixelIn in;
-    in.xm = xm; in.ym = ym; in.o0 = o0; in.o1 = o1; in.o2 = o2; in.gt = gt; in.cf = cf; in.mk = mk;
-    HgsPixelOut po;
-    hgs_pixel_terms(fl, p, in, d_unit != nullptr, g_mask, fl.ori ? g_ori / tgt->mask_count : 0.f, po);
-    s = po.s; cnt = po.cnt; b = po.b;
-    const float gm = po.gm, g0 = po.g0, g1 = po.g1, g2 = po.g2;
+    float gm = 0.f, g0 = 0.f, g1 = 0.f, g2 = 0.f;
+    if (fl.bce) {
+      const float x = xm, y = ym;
+      // (hardware exp2 / log2: en in (0, 1], so log(1 + en) is within 1e-7 absolute of log1p(en) -- of a term of order 0.1-1)
+      const float en = __expf(-fabsf(x));
+      b = fmaxf(x, 0.f) - x * y + __logf(1.f + en);
+      if (d_unit) { const float r1 = __builtin_amdgcn_rcpf(1.f + en); gm = g_mask * ((x >= 0.f ? r1 : en * r1) - y); }   // sigmoid(x) - y
+    }
+    if (fl.ori) {
+      OriParams p;
+      p.view = tgt->viewmatrix; p.bg0 = bg0; p.bg1 = bg1; p.bg2 = bg2; p.min_val = min_val; p.has_mask = has_mask;
+      const bool m = p.has_mask ? mk != 0 : (o0 != p.bg0 || o1 != p.bg1 || o2 != p.bg2);
+      if (m) {
+        float px, py, r, n, x, y, yq, th;
+        ori_pixel(p, o0, o1, o2, px, py, r, n, x, y, yq, th);
+        const float hp = 1.57079632679489661923f;
+        s = (hp - fabsf(fabsf(th - gt) - hp)) * cf;
+        cnt = 1.f;
+        if (d_unit) ori_pixel_grad(p, px, py, r, n, x, yq, th, gt, cf, g_ori / tgt->mask_count, g0, g1, g2);
+      }
+    }
     if (d_unit && used) {
       d_unit[i] = gm; d_unit[(size_t)N + i] = g0; d_unit[2 * (size_t)N + i] = g1; d_unit[3 * (size_t)N + i] = g2;
     }
@@ -1167,12 +1219,7 @@ int hgs_orientation_loss_backward(void* stream, int H, int W, const float* omap,
 
 // ---- loss head ------------------------------------------------------------------------------------------------------
 static inline int head_nb_ssim(const HgsHeadParams* p) { return ((p->W + LT - 1) / LT) * ((p->H + LT - 1) / LT) * 3; }
-static inline int head_nb_tiles(const HgsHeadParams* p) { return ((p->W + HGS_TILE - 1) / HGS_TILE) * ((p->H + HGS_TILE - 1) / HGS_TILE); }
-static inline int head_nb_pixel_blocks(const HgsHeadParams* p) { return (int)(((size_t)p->H * p->W + 255) / 256); }
-// partial triples of the per-pixel terms: room for either producer (runs of 256 pixels: pix_fwd_kernel; 16 x 16 tiles: the blend
-// forward's epilogue, HgsPixelHead), so the scratch layout does not depend on which one ran
-static inline int head_nb_pix(const HgsHeadParams* p) { return head_nb_tiles(p) > head_nb_pixel_blocks(p) ? head_nb_tiles(p) : head_nb_pixel_blocks(p); }
-static inline int head_nb_pix_used(const HgsHeadParams* p) { return p->pixels_in_rasterizer ? head_nb_tiles(p) : head_nb_pixel_blocks(p); }
+static inline int head_nb_pix(const HgsHeadParams* p) { return (int)(((size_t)p->H * p->W + 255) / 256); }
 static inline int head_nb_smooth(const HgsHeadParams* p) { return p->lambda_smooth > 0.f ? (p->n_smooth + 255) / 256 : 0; }
 // scratch: [dmaps 9*H*W][ssim partials 2*nb][pix partials 3*nb][smooth partials 2*nb][all-zero flags, 1 byte per SSIM block][as many spare bytes: the list builder reads whole 32-byte runs][block lists]
 static inline size_t head_flags_offset(const HgsHeadParams* p) {
@@ -1193,7 +1240,7 @@ size_t hgs_loss_head_scratch_floats(const HgsHeadParams* p) {
 int hgs_loss_head_tail(const HgsHeadParams* p, const float* scratch, float* out, HgsHeadTail* tail) {
   if (!p || !scratch || !out || !tail) { hgs_set_error("hgs_loss_head_tail: null argument"); return 1; }
   tail->pix_partials = scratch + 9 * (size_t)p->H * p->W + 2 * (size_t)head_nb_ssim(p);
-  tail->nb_pix = head_nb_pix_used(p);
+  tail->nb_pix = head_nb_pix(p);
   tail->out = out;
   tail->inv_hw = 1.f / (float)((size_t)p->H * p->W);
   tail->l_mask = p->lambda_mask; tail->l_ori = p->lambda_orientation; tail->l_smooth = p->lambda_smooth;
@@ -1205,7 +1252,7 @@ int hgs_loss_head_forward(void* stream, const HgsHeadParams* p, const float* ima
                           const float* omap, const HgsViewTargets* targets, const float* endpoints,
                           const long long* smooth_pairs, float* scratch, float* out, float* d_extra_unit,
                           const float* smooth_partials_ext) {
-  if (!p || !image || !targets || !scratch || !out || p->H <= 0 || p->W <= 0 || (!p->pixels_in_rasterizer && (!mask_img || !omap))) {
+  if (!p || !image || !mask_img || !omap || !targets || !scratch || !out || p->H <= 0 || p->W <= 0) {
     hgs_set_error("hgs_loss_head_forward: bad arguments");
     return 1;
   }
@@ -1237,18 +1284,15 @@ int hgs_loss_head_forward(void* stream, const HgsHeadParams* p, const float* ima
   if (nbm > 0 && !smooth_partials_ext &&
       hgs_launch_smooth_fwd(s, p->n_smooth, endpoints, smooth_pairs, p->cos_threshold, p->eps, p_pix + 3 * (size_t)nbp)) return 1;
   HeadReduce h;
-  h.nb_ssim = nbs; h.nb_pix = head_nb_pix_used(p); h.nb_smooth = nbm;
+  h.nb_ssim = nbs; h.nb_pix = nbp; h.nb_smooth = nbm;
   h.inv_chw = 1.f / (3.f * (float)N); h.inv_hw = 1.f / (float)N;
   h.l_dssim = p->lambda_dssim; h.l_mask = p->lambda_mask; h.l_ori = p->lambda_orientation; h.l_smooth = p->lambda_smooth;
   h.bce = fl.bce; h.ori = fl.ori;
   {
     HgsProfScope _prof(s, HGS_K_ORI_FWD);
-    // (pixels_in_rasterizer: the blend forward's epilogue has written the per-tile partials and the gradient planes; only the two
-    // side workgroups are left of this launch)
-    const int pix_wgs = p->pixels_in_rasterizer ? 0 : head_nb_pixel_blocks(p);
-    hipLaunchKernelGGL(pix_fwd_kernel, dim3(pix_wgs + PIX_SIDE_WGS), dim3(256), 0, s, p->pixels_in_rasterizer ? 0 : N, fl, p->bg[0], p->bg[1], p->bg[2], p->min_val, mask_img,
+    hipLaunchKernelGGL(pix_fwd_kernel, dim3(nbp + PIX_SIDE_WGS), dim3(256), 0, s, N, fl, p->bg[0], p->bg[1], p->bg[2], p->min_val, mask_img,
                        omap, targets, p_pix, fl.bce ? p->lambda_mask / (float)N : 0.f, fl.ori ? p->lambda_orientation : 0.f,
-                       p->pixels_in_rasterizer ? (float*)nullptr : d_extra_unit, ssim_grid(3, H, W), (const unsigned char*)head_zero_flags(p, scratch), lists, h,
+                       d_extra_unit, ssim_grid(3, H, W), (const unsigned char*)head_zero_flags(p, scratch), lists, h,
                        (const float*)p_ssim, p_smooth, out, p->tile_used, p->tiles_x, p->tiles_y, W, 1.f / (float)W);
   }
   if (!p->defer_tail) {
@@ -1261,37 +1305,19 @@ int hgs_loss_head_forward(void* stream, const HgsHeadParams* p, const float* ima
   return 0;
 }
 
-size_t hgs_pixel_head_bytes(void) { return sizeof(HgsPixelHead); }
-
-int hgs_loss_head_pixel_head(const HgsHeadParams* p, float* scratch, const HgsViewTargets* targets, float* d_extra_unit,
-                             int keep_extra_planes, HgsPixelHead* head) {
-  if (!p || !scratch || !targets || !head || p->H <= 0 || p->W <= 0) { hgs_set_error("hgs_loss_head_pixel_head: bad arguments"); return 1; }
-  const size_t N = (size_t)p->H * p->W;
-  head->targets = targets;
-  head->partials = scratch + 9 * N + 2 * (size_t)head_nb_ssim(p);
-  head->d_extra_unit = d_extra_unit;
-  head->bce = p->lambda_mask > 0.f; head->ori = p->lambda_orientation > 0.f;
-  head->g_mask = head->bce ? p->lambda_mask / (float)N : 0.f;
-  head->g_ori = head->ori ? p->lambda_orientation : 0.f;
-  head->bg[0] = p->bg[0]; head->bg[1] = p->bg[1]; head->bg[2] = p->bg[2];
-  head->min_val = p->min_val;
-  head->keep_extra_planes = keep_extra_planes;
-  return 0;
-}
-
 int hgs_loss_head_backward(void* stream, const HgsHeadParams* p, const float* image, const float* mask_img,
                            const float* omap, const HgsViewTargets* targets, const float* endpoints,
                            const long long* smooth_pairs, const float* scratch, const float* out,
                            const float* grad_out, int skip, float* d_image, float* d_mask_img,
                            float* d_omap, float* d_endpoints) {
   const int skip_pixel_pass = skip & HGS_HEAD_SKIP_PIXELS;
-  if (!p || !image || !targets || !scratch || !out || !grad_out || !d_image ||
-      (!skip_pixel_pass && (!d_mask_img || !d_omap || !mask_img || !omap))) {
+  if (!p || !image || !mask_img || !omap || !targets || !scratch || !out || !grad_out || !d_image ||
+      (!skip_pixel_pass && (!d_mask_img || !d_omap))) {
     hgs_set_error("hgs_loss_head_backward: bad arguments");
     return 1;
   }
   const int H = p->H, W = p->W, N = H * W;
-  const int nbm = head_nb_smooth(p);
+  const int nbp = head_nb_pix(p), nbm = head_nb_smooth(p);
   const float* dmaps = scratch;
   SsimWin win;
   for (int k = 0; k < 11; k++) win.w[k] = p->window[k];
@@ -1313,7 +1339,7 @@ int hgs_loss_head_backward(void* stream, const HgsHeadParams* p, const float* im
   fl.bce = p->lambda_mask > 0.f; fl.ori = p->lambda_orientation > 0.f;
   if (!skip_pixel_pass) {
     HgsProfScope _prof(s, HGS_K_ORI_BWD);
-    hipLaunchKernelGGL(pix_bwd_kernel, dim3(head_nb_pixel_blocks(p)), dim3(256), 0, s, N, fl, p->bg[0], p->bg[1], p->bg[2], p->min_val, mask_img,
+    hipLaunchKernelGGL(pix_bwd_kernel, dim3(nbp), dim3(256), 0, s, N, fl, p->bg[0], p->bg[1], p->bg[2], p->min_val, mask_img,
                        omap, targets, out, grad_out, d_mask_img, d_omap);
   }
   if (d_endpoints && !(skip & HGS_HEAD_SKIP_SMOOTH)) {   // (cleared by the SSIM kernel above)

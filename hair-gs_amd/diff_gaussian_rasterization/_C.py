@@ -102,16 +102,14 @@ def rasterize_gaussians_culled(background, means3D, colors, opacity, scales, rot
 
 def rasterize_gaussians_multi(background7, means3D, colors, extra4, opacity, scales, rotations, scale_modifier,
                               cov3D_precomp, viewmatrix, projmatrix, tan_fovx, tan_fovy, image_height, image_width, sh,
-                              degree, campos, prefiltered, debug, image_buffer=None, hair=None, pixel_head=None):
+                              degree, campos, prefiltered, debug, image_buffer=None, hair=None):
     """Single-pass 7-channel forward (hgs_forward_render_multi): RGB + `extra4` [P,4] unclamped channels blended with
     the same weights.  Returns (num_rendered, out_color[7,H,W], radii, geomBuffer, binningBuffer, imgBuffer).
     image_buffer: a uint8 tensor of hgs_image_bytes(W, H) whose counters the caller has cleared on this stream
-    (hgs_iteration_prologue): used as the imgBuffer, and the pass skips its own clearing launch.
-    pixel_head: hgs_runtime.PixelHead (include/hgs.h HgsPixelHead) -- the loss head's per-pixel terms evaluated by the
-    blend kernel's epilogue (hgs_forward_render_multi_head); planes 3..6 of out_color are then written only if it says so."""
+    (hgs_iteration_prologue): used as the imgBuffer, and the pass skips its own clearing launch."""
     return _forward(background7, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp, viewmatrix,
                     projmatrix, tan_fovx, tan_fovy, image_height, image_width, sh, degree, campos, prefiltered, debug,
-                    extra4, True, image_buffer, None, hair, pixel_head)
+                    extra4, True, image_buffer, None, hair)
 
 
 class HairSource:
@@ -160,7 +158,7 @@ def rasterize_gaussians_prezeroed(background, means3D, colors, opacity, scales, 
 
 def _forward(background, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp, viewmatrix,
              projmatrix, tan_fovx, tan_fovy, image_height, image_width, sh, degree, campos, prefiltered, debug, extra4,
-             cull, image_buffer=None, max_rendered=None, hair=None, pixel_head=None):
+             cull, image_buffer=None, max_rendered=None, hair=None):
     if means3D.ndim != 2 or means3D.shape[1] != 3:
         raise RuntimeError("means3D must have dimensions (num_points, 3)")  # rasterize_points.cu:57-59
     L = rt.lib()
@@ -249,13 +247,8 @@ def _forward(background, means3D, colors, opacity, scales, rotations, scale_modi
                                           rt.ptr(img), rt.ptr(out_color)))
         else:
             binning = torch.empty((L.hgs_binning_bytes_multi(R),), **u8)
-            if pixel_head is not None:
-                rt.check(L.hgs_forward_render_multi_head(stream, P, W, H, R, rt.ptr(bg), rt.ptr(colors_), rt.ptr(extra_),
-                                                         rt.ptr(geom), rt.ptr(binning), rt.ptr(img), rt.ptr(out_color),
-                                                         C.byref(pixel_head)))
-            else:
-                rt.check(L.hgs_forward_render_multi(stream, P, W, H, R, rt.ptr(bg), rt.ptr(colors_), rt.ptr(extra_),
-                                                    rt.ptr(geom), rt.ptr(binning), rt.ptr(img), rt.ptr(out_color)))
+            rt.check(L.hgs_forward_render_multi(stream, P, W, H, R, rt.ptr(bg), rt.ptr(colors_), rt.ptr(extra_),
+                                                rt.ptr(geom), rt.ptr(binning), rt.ptr(img), rt.ptr(out_color)))
         if use_async and max_rendered is None:
             _state["dirty"] = True
             _state["cap_used"] = R if _state["cap_used"] is None else min(_state["cap_used"], R)

@@ -31,9 +31,6 @@ SIGNATURES = {
     "hgs_binning_bytes_multi": (sz, [ci]),
     "hgs_backward_scratch_bytes_multi": (sz, [ci, ci]),
     "hgs_forward_render_multi": (ci, [vp, ci, ci, ci, ci, vp, vp, vp, vp, vp, vp, vp]),
-    "hgs_forward_render_multi_head": (ci, [vp, ci, ci, ci, ci, vp, vp, vp, vp, vp, vp, vp, vp]),
-    "hgs_pixel_head_bytes": (sz, []),
-    "hgs_loss_head_pixel_head": (ci, [vp, vp, vp, vp, ci, vp]),
     "hgs_backward_multi": (ci, [vp, ci, ci, ci, ci, ci, ci, vp, vp, vp, vp, vp, cf, vp, vp, vp, vp, vp, cf, cf, vp, vp, vp,
                                 vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "hgs_param_backward_bytes": (sz, []),
@@ -119,13 +116,7 @@ class HeadParams(C.Structure):
     _fields_ = [("H", ci), ("W", ci), ("lambda_dssim", cf), ("lambda_mask", cf), ("lambda_orientation", cf),
                 ("lambda_smooth", cf), ("bg", cf * 3), ("min_val", cf), ("window", cf * 11), ("n_smooth", ci),
                 ("cos_threshold", cf), ("eps", cf), ("n_endpoints", ci), ("defer_tail", ci), ("tile_used", vp),
-                ("tiles_x", ci), ("tiles_y", ci), ("pixels_in_rasterizer", ci)]
-
-
-class PixelHead(C.Structure):
-    """include/hgs.h HgsPixelHead: the loss head's per-pixel terms in the rasterizer forward's epilogue."""
-    _fields_ = [("targets", vp), ("partials", vp), ("d_extra_unit", vp), ("g_mask", cf), ("g_ori", cf), ("bg", cf * 3),
-                ("min_val", cf), ("bce", ci), ("ori", ci), ("keep_extra_planes", ci)]
+                ("tiles_x", ci), ("tiles_y", ci)]
 
 
 class HeadTail(C.Structure):

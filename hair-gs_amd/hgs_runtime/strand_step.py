@@ -283,31 +283,13 @@ def _raster_head_forward(step, xyz, scale, quat, opacity, extra4, shs, endpoints
     dev = xyz.device
     f32 = dict(dtype=torch.float32, device=dev)
     empty = step.empty
-    hp.n_endpoints = n_endpoints
-    # the tail of the head's reduction rides in the backward's parameter launch (include/hgs.h HgsHeadTail)
-    hp.defer_tail = 1 if (step.defer_tail and xyz.shape[0] > 0) else 0
-    # gradient planes of the per-pixel terms for an upstream gradient of 1, written by the forward's own pass over
-    # the pixels (possible when the mask count is a per-view constant, i.e. the views carry masks)
-    d_extra = torch.empty((4, vt.H, vt.W), **f32) if (step.one_pass_pixels and vt.has_mask) else None
-    if step.poison_unwritten and d_extra is not None:     # test aid, like dL/dimage in _head_raster_backward
-        d_extra.fill_(float("nan"))
-    # the per-pixel terms in the blend forward's epilogue (include/hgs.h HgsPixelHead): the head then launches no pass over the
-    # pixels, and the four extra planes are never written (nothing reads them when the gradient planes come with the forward)
-    pixel_head = None
-    hp.pixels_in_rasterizer = 1 if (step.pixels_in_rasterizer and d_extra is not None) else 0
-    scratch = torch.empty((L.hgs_loss_head_scratch_floats(C.byref(hp)),), **f32)
-    out = torch.empty((rt.HEAD_NOUT,), **f32)
-    if hp.pixels_in_rasterizer:
-        pixel_head = rt.PixelHead()
-        rt.check(L.hgs_loss_head_pixel_head(C.byref(hp), rt.ptr(scratch), vt.slot.data_ptr(), rt.ptr(d_extra), 0,
-                                            C.byref(pixel_head)))
     own_image = vt.take_image()
     R, planes, radii, geom, binning, img = raster.rasterize_gaussians_multi(
         step.bg7, xyz, empty, extra4, opacity, scale, quat, 1.0, empty, vt.viewmatrix, vt.projmatrix, vt.tanfovx,
-        vt.tanfovy, vt.H, vt.W, shs, g.active_sh_degree, vt.campos, False, False, image_buffer=own_image, hair=hair,
-        pixel_head=pixel_head)
+        vt.tanfovy, vt.H, vt.W, shs, g.active_sh_degree, vt.campos, False, False, image_buffer=own_image, hair=hair)
     if own_image is not None and xyz.shape[0] > 0:
         vt.counts_clean = raster._state["last_counts_clean"]
+    hp.n_endpoints = n_endpoints
     # the blend backward reads dL/dimage only on tiles where a pixel blended an entry (the image buffer's per-tile
     # contributor count, written by the forward pass above): the SSIM backward leaves the other blocks alone
     if step.skip_unread_blocks:
@@ -317,6 +299,15 @@ def _raster_head_forward(step, xyz, scale, quat, opacity, extra4, shs, endpoints
         hp.tiles_x, hp.tiles_y = (vt.W + 15) // 16, (vt.H + 15) // 16
     else:
         hp.tile_used = None
+    scratch = torch.empty((L.hgs_loss_head_scratch_floats(C.byref(hp)),), **f32)
+    out = torch.empty((rt.HEAD_NOUT,), **f32)
+    # gradient planes of the per-pixel terms for an upstream gradient of 1, written by the forward's own pass over
+    # the pixels (possible when the mask count is a per-view constant, i.e. the views carry masks)
+    d_extra = torch.empty((4, vt.H, vt.W), **f32) if (step.one_pass_pixels and vt.has_mask) else None
+    if step.poison_unwritten and d_extra is not None:     # test aid, like dL/dimage in _head_raster_backward
+        d_extra.fill_(float("nan"))
+    # the tail of the head's reduction rides in the backward's parameter launch (include/hgs.h HgsHeadTail)
+    hp.defer_tail = 1 if (step.defer_tail and xyz.shape[0] > 0) else 0
     with torch.cuda.device(dev):
         rt.check(L.hgs_loss_head_forward(rt.current_stream(), C.byref(hp), planes[0:3].data_ptr(), planes[3].data_ptr(),
                                          planes[4:7].data_ptr(), vt.slot.data_ptr(), rt.ptr(endpoints), rt.ptr(smooth_idx),
@@ -334,16 +325,12 @@ def _head_raster_backward(ctx, step, go, xyz, scale, quat, shs, planes, radii, g
     # Fused*Step.backward() hands in its own ones tensor: the upstream gradient is then known to be exactly 1 and
     # the planes the forward wrote are final (the tensor's address, not its value, is what can be checked without a sync)
     unit_go = go is not None and go.data_ptr() == step.one.data_ptr()
-    # (the epilogue form of the per-pixel terms left no mask / direction planes for a pass over the pixels to read: a general
-    # upstream gradient then scales the planes of the forward -- the terms are linear in it)
-    in_raster = bool(getattr(ctx, "pixels_in_rasterizer", False))
-    unit = ctx.d_extra is not None and (unit_go or in_raster)
+    unit = ctx.d_extra is not None and unit_go
     go = step.one if go is None else go.contiguous().to(torch.float32)
     hp.n_endpoints = n_endpoints
     hp.defer_tail = 1 if ctx.defer_tail else 0
-    hp.pixels_in_rasterizer = 1 if in_raster else 0
     if unit:
-        d_image, d_extra = torch.empty((3, vt.H, vt.W), **f32), (ctx.d_extra if unit_go else ctx.d_extra * go)
+        d_image, d_extra = torch.empty((3, vt.H, vt.W), **f32), ctx.d_extra
     else:
         dplanes = torch.empty_like(planes)
         d_image, d_extra = dplanes[0:3], dplanes[3:7]
@@ -449,7 +436,6 @@ class _StrandIteration(torch.autograd.Function):
         R, planes, radii, geom, binning, img, scratch, out, d_extra = _raster_head_forward(
             step, xyz, scale, quat, opacity, extra4, shs, endpoints, idx, smooth_partials, E, hair=hair)
         ctx.d_extra = d_extra
-        ctx.pixels_in_rasterizer = bool(step.head.pixels_in_rasterizer)
         ctx.defer_tail = bool(step.head.defer_tail)
         ctx.fused_smooth = smooth_partials is not None
         ctx.step, ctx.R, ctx.f_rest_k = step, R, f_rest.shape[1]
@@ -457,8 +443,7 @@ class _StrandIteration(torch.autograd.Function):
         ctx.save_for_backward(endpoints, width, pairs, xyz, scale, quat, opacity, extra4, shs, planes, radii, geom, binning,
                               img, scratch, out)
         ctx.pair_grads = pair_grads
-        # (the epilogue form of the per-pixel terms writes no mask / direction planes: what was rendered is the RGB image)
-        step.last = {"planes": planes[:3] if ctx.pixels_in_rasterizer else planes, "radii": radii, "terms": out}
+        step.last = {"planes": planes, "radii": radii, "terms": out}
         terms = out.detach()
         ctx.mark_non_differentiable(terms)
         return out[0], terms
@@ -560,8 +545,6 @@ class FusedStrandStep:
         self.empty = torch.empty(0, device=dev)
         self.one = torch.ones((), dtype=torch.float32, device=dev)   # d loss / d loss, passed to backward(): no fill launch
         self.one_pass_pixels = True    # per-pixel loss terms: value and gradient in one pass over the pixels
-        # ... and that pass in the blend forward's epilogue (include/hgs.h HgsPixelHead) instead of a launch of its own
-        self.pixels_in_rasterizer = bool(getattr(opt, "pixels_in_rasterizer", True)) and os.environ.get("HGS_PIXELS_IN_RASTERIZER", "1") != "0"
         self.stats_in_backward = True  # densification statistics updated by the backward's last launch
         # dL/dimage is produced only where the rasterizer backward reads it (include/hgs.h HgsHeadParams.tile_used)
         self.skip_unread_blocks = bool(getattr(opt, "skip_unread_blocks", True))
@@ -694,14 +677,12 @@ class _CloudIteration(torch.autograd.Function):
         R, planes, radii, geom, binning, img, scratch, out, d_extra = _raster_head_forward(
             step, xyz, scale, quat, opacity, extra4, shs, None, None, None, 0, hair=src)
         ctx.d_extra, ctx.fused_smooth = d_extra, True   # (no smoothness term for a cloud: nothing to launch)
-        ctx.pixels_in_rasterizer = bool(step.head.pixels_in_rasterizer)
         ctx.defer_tail = bool(step.head.defer_tail)
         ctx.step, ctx.R, ctx.f_rest_k = step, R, f_rest.shape[1]
         ctx.set_materialize_grads(False)
         ctx.save_for_backward(xyz, scaling_raw, rotation_raw, scale, quat, opacity, extra4, shs, planes, radii, geom, binning,
                               img, scratch, out)
-        # (the epilogue form of the per-pixel terms writes no mask / direction planes: what was rendered is the RGB image)
-        step.last = {"planes": planes[:3] if ctx.pixels_in_rasterizer else planes, "radii": radii, "terms": out}
+        step.last = {"planes": planes, "radii": radii, "terms": out}
         terms = out.detach()
         ctx.mark_non_differentiable(terms)
         return out[0], terms

@@ -455,10 +455,6 @@ typedef struct HgsHeadParams {
    * neither filters nor zero-fills them), and hgs_loss_head_forward leaves d_extra_unit UNWRITTEN on the tiles that are
    * not read. */
   const unsigned int* tile_used; int tiles_x, tiles_y;
-  /* != 0: the per-pixel terms of this frame were evaluated by the rasterizer forward's epilogue (HgsPixelHead below, filled by
-   * hgs_loss_head_pixel_head from THESE parameters and THIS scratch): hgs_loss_head_forward launches no pass over the pixels
-   * (mask_img / omap / d_extra_unit are not read and may be NULL) and the reduction sums one partial triple per 16 x 16 tile. */
-  int pixels_in_rasterizer;
 } HgsHeadParams;
 enum { HGS_HEAD_TOTAL = 0, HGS_HEAD_L1, HGS_HEAD_DSSIM, HGS_HEAD_MASK, HGS_HEAD_ORIENTATION, HGS_HEAD_SMOOTH,
        HGS_HEAD_ORI_COUNT, HGS_HEAD_SMOOTH_COUNT, HGS_HEAD_G_SSIM, HGS_HEAD_G_L1, HGS_HEAD_G_MASK, HGS_HEAD_G_ORI,
@@ -476,35 +472,6 @@ int hgs_loss_head_backward(void* stream, const HgsHeadParams* p, const float* im
                            const long long* smooth_pairs, const float* scratch, const float* out,
                            const float* grad_out, int skip, float* d_image, float* d_mask_img,
                            float* d_omap, float* d_endpoints);
-
-/* ---- the head's per-pixel terms in the rasterizer forward's EPILOGUE (round 5).  The pass over the pixels above reads the four
- * extra planes the blend kernel has just written (33 MB at 1080p), the targets, and writes the four gradient planes: 93 MB and
- * a launch for ~40 instructions per pixel.  The workgroup that finishes a tile still holds the pixel's seven channels in
- * registers: with an HgsPixelHead it evaluates the mask BCE and the orientation term there (same device function, same bits:
- * csrc/hgs_pixel_head.h), writes d_extra_unit on the tiles some pixel blended into (the only ones the rasterizer backward reads;
- * UNWRITTEN elsewhere) and one (orientation sum, masked-pixel count, BCE sum) triple per tile, fixed order within the tile:
- * bitwise reproducible.  The loss VALUES differ from the pixel pass's in the order of the float additions (tiles instead of runs
- * of 256 pixels); the gradient planes are bit-identical.
- *   targets              device-resident slot of the view (mask_count > 0 required when d_extra_unit is given and the orientation term is on)
- *   keep_extra_planes    0: planes 3..6 of out_color7 are NOT written (nothing of the fused iteration reads them);
- *                        needed (!= 0) by hgs_loss_head_backward without HGS_HEAD_SKIP_PIXELS. ---- */
-typedef struct HgsPixelHead {
-  const HgsViewTargets* targets;
-  float* partials;                /* [3 * tiles_x * tiles_y], inside the head's scratch */
-  float* d_extra_unit;            /* [4,H,W] or NULL (no gradient planes) */
-  float g_mask, g_ori;            /* lambda_mask / (H W), lambda_orientation (0: term off) */
-  float bg[3]; float min_val;     /* HgsHeadParams.bg / min_val */
-  int bce, ori;                   /* which terms */
-  int keep_extra_planes;
-} HgsPixelHead;
-size_t hgs_pixel_head_bytes(void);   /* sizeof(HgsPixelHead) */
-/* fills `head` for a forward that will call hgs_loss_head_forward(p with pixels_in_rasterizer = 1, ..., scratch, ...) afterwards */
-int hgs_loss_head_pixel_head(const HgsHeadParams* p, float* scratch, const HgsViewTargets* targets, float* d_extra_unit,
-                             int keep_extra_planes, HgsPixelHead* head);
-/* hgs_forward_render_multi with the epilogue (head == NULL: exactly hgs_forward_render_multi) */
-int hgs_forward_render_multi_head(void* stream, int P, int W, int H, int R_capacity, const float* bg7,
-                                  const float* colors_precomp, const float* extra4, void* geom_buf, void* binning_buf,
-                                  void* image_buf, float* out_color7, const HgsPixelHead* head);
 
 /* hgs_densify_stats <-> scene/hair_gaussian_model.py:1401-1408 / gaussian_model.py:675-682 add_densification_stats +
  *   train.py:170-171 max_radii2D update, for the Gaussians with radii > 0:

@@ -1700,67 +1700,3 @@ def test_device_storage_sort_equals_the_host_form():
     model.compute_strands_info()
     for a in ("offsets", "rows", "id_to_strand_id", "strand_endpoint_id_to_complementary"):
         assert np.array_equal(np.asarray(getattr(kept, a)), np.asarray(getattr(model.strands_info, a))), a
-
-
-@pytest.mark.parametrize("kind", ["strands", "cloud"])
-def test_pixel_terms_in_the_blend_epilogue_equal_the_pass_over_the_pixels(kind):
-    """hgs_forward_render_multi_head (round 5: mask BCE + orientation term evaluated by the workgroup that finishes a tile, on
-    the channels still in its registers -- include/hgs.h HgsPixelHead) against the separate pass over the rendered planes
-    (pix_fwd_kernel): the gradient planes are the same device function's results, so every parameter gradient and the
-    densification inputs must agree BIT FOR BIT; the loss terms are sums in another order (tiles instead of runs of 256 pixels)
-    and agree to float rounding.  Also with a general upstream gradient (the forward's unit planes scaled) and with the unread
-    tiles of the gradient planes poisoned."""
-    from arguments import OptimizationParams
-    from hgs_runtime.strand_step import FusedCloudStep, FusedStrandStep, ViewTable
-    from synthetic import build_workload
-    if kind == "strands":
-        model, cams, _ = build_workload("tiny", device="cuda", with_targets=True)
-        params = [model._endpoints, model._width, model._opacity, model._mask, model._features_dc]
-        Step = FusedStrandStep
-    else:
-        from synthetic import attach_targets, cameras_extent, make_cameras, make_cloud_model
-        cams = make_cameras(4, 200, 120, device="cuda")
-        model = make_cloud_model(3000, device="cuda", spatial_lr_scale=cameras_extent(cams))
-        attach_targets(cams, model)
-        params = [model._xyz, model._scaling, model._rotation, model._opacity, model._mask, model._features_dc]
-        Step = FusedCloudStep
-    opt = OptimizationParams()
-    model.training_setup(opt)
-    stats = lambda: [model.max_radii2D, model.xyz_gradient_accum, model.denom]
-    runs = {}
-    for in_raster in (False, True):
-        for t in stats():
-            t.zero_()
-        views = ViewTable(cams)
-        step = Step(model, views, opt, torch.zeros(3, device="cuda"))
-        step.pixels_in_rasterizer = in_raster
-        step.poison_unwritten = True
-        seen = []
-        for v, scale in ((0, None), (2, None), (1, 0.37), (3, None)):
-            for p in params:
-                p.grad = None
-            views.prologue(v, ride=True)
-            loss, terms = step.loss()
-            assert bool(step.head.pixels_in_rasterizer) == in_raster
-            if scale is None:
-                step.backward(loss)
-            else:
-                (loss * scale).backward()
-            torch.cuda.synchronize()
-            assert step.last["planes"].shape[0] == (3 if in_raster else 7)
-            seen.append([terms[:14].clone(), step.last["planes"][:3].clone()] +
-                        [p.grad.clone() if p.grad is not None else torch.zeros(()) for p in params] +
-                        [t.clone() for t in stats()] + [scale])
-        runs[in_raster] = seen
-    for a, b in zip(runs[False], runs[True]):
-        ta, tb = a[0], b[0]
-        assert torch.isfinite(tb).all() and float(tb[0]) > 0
-        assert float((ta - tb).abs().max()) <= 2e-6 * float(ta.abs().max()), (ta, tb)
-        exact = a[-1] is None          # (a scaled upstream gradient multiplies in another order)
-        for x, y in zip(a[1:-1], b[1:-1]):
-            assert torch.isfinite(y).all()
-            if exact:
-                assert torch.equal(x, y)
-            else:
-                assert float((x - y).abs().max()) <= 1e-6 * max(float(x.abs().max()), 1e-12)
-        assert bool(a[3].abs().sum() > 0)
