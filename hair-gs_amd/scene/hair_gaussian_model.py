@@ -93,11 +93,14 @@ def walk_chains(pairs, n_ep, id_to_strand, complementary, end_distance):
     return bounds.astype(np.int64), seq, rows_sorted
 
 
-def walk_chains_torch(pairs, n_ep, end_distance):
+def walk_chains_torch(pairs, n_ep, end_distance, max_len_hint=None):
     """walk_chains on torch tensors (the model's device: the doubling steps are gathers over 2n arcs, a few microseconds
     each on the GPU against milliseconds in numpy).  pairs: [n, 2] int64 tensor; end_distance(ids tensor) -> distances.
     Returns (offsets, rows, segment rows, id_to_strand int32 [n_ep], complementary int32 [n_ep]) as tensors on the device;
-    same strands, order and orientation as walk_chains."""
+    same strands, order and orientation as walk_chains.
+    max_len_hint: the caller's guess of the longest strand (segments).  The pointer doubling needs log2(longest strand) steps, not
+    log2(n): with a guess the loop runs that many (5 launches per step, ~20 steps for 3 10^5 segments against ~10), and if any
+    arc has not reached its end by then -- the guess was short, or the arc lies on a cycle -- the walk is repeated in full."""
     dev = pairs.device
     n = pairs.shape[0]
     i64 = dict(dtype=torch.int64, device=dev)
@@ -121,13 +124,17 @@ def walk_chains_torch(pairs, n_ep, end_distance):
     succ = torch.where(terminal, torch.arange(2 * n, **i64), 2 * nr + (pairs[nr, 0] != head).to(torch.int64))
     dist = (~terminal).to(torch.int64)
     reached = terminal.clone()
-    for _ in range(max(1, int(np.ceil(np.log2(max(n, 2)))) + 1)):   # fixed count: no host round trip per step
+    full_steps = max(1, int(np.ceil(np.log2(max(n, 2)))) + 1)
+    steps = full_steps if max_len_hint is None else min(full_steps, max(1, int(np.ceil(np.log2(max(int(max_len_hint), 2)))) + 1))
+    for _ in range(steps):   # fixed count: no host round trip per step
         dist = dist + torch.where(reached, torch.zeros_like(dist), dist[succ])
         reached_next = reached | reached[succ]
         succ = torch.where(reached, succ, succ[succ])
         reached = reached_next
     end_of = head[succ]
     ok = reached[0::2] & reached[1::2]
+    if steps < full_steps and int(ok.sum()) != n:      # (the read-back below synchronises anyway)
+        return walk_chains_torch(pairs, n_ep, end_distance, None)
     e_fwd, e_bwd = end_of[0::2], end_of[1::2]
     start = torch.minimum(e_fwd, e_bwd)
     from_bwd = e_bwd == start
@@ -333,10 +340,9 @@ class HairGaussianModel(HairTopologyMixin, GaussianModel):
         lo, hi = first.min(dim=0).values, first.max(dim=0).values
         top = (1 << bits) - 1
         q = ((first - lo) / torch.clamp_min(hi - lo, 1e-20) * top).to(torch.int64).clamp_(0, top)
-        code = torch.zeros(S, **i64)
-        for b in range(bits):
-            for a in range(3):
-                code |= ((q[:, a] >> b) & 1) << (3 * b + a)
+        bvec = torch.arange(bits, **i64)
+        # (bit b of axis a -> bit 3 b + a: one broadcast expression instead of 3 x bits x 4 launches)
+        code = ((((q[:, :, None] >> bvec) & 1) << (3 * bvec + torch.arange(3, **i64)[:, None])).sum(dim=(1, 2)))
         order = torch.argsort(code, stable=True)
         lens = (offsets[1:] - offsets[:-1])[order]
         new_off = torch.zeros(S + 1, **i64)
@@ -664,10 +670,16 @@ class HairGaussianModel(HairTopologyMixin, GaussianModel):
             if only_foreground:
                 fg_rows = torch.nonzero(self.compute_foreground_mask()).squeeze(1)
                 pairs_t = self.endpoint_pairs[fg_rows]
+            # (longest strand so far, with room for what one operator can do to it -- a merge joins at most three strands end to
+            # end, a split doubles a segment: walk_chains_torch checks the guess and falls back)
+            prev = getattr(self, "_longest_strand", None)
             offsets, rows, seg_rows, i2s, comp = walk_chains_torch(
-                pairs_t, ep.shape[0], lambda ids: nearest_distance(ep[ids], roots, chunk))
+                pairs_t, ep.shape[0], lambda ids: nearest_distance(ep[ids], roots, chunk),
+                max_len_hint=None if prev is None else max(64, 4 * prev))
             self.strands_info = StrandsInfo(offsets.cpu().numpy(), rows.cpu().numpy(), seg_rows.cpu().numpy(),
                                             i2s.cpu().numpy(), comp.cpu().numpy())
+            off_h = self.strands_info.offsets
+            self._longest_strand = int((off_h[1:] - off_h[:-1]).max()) if len(off_h) > 1 else None
             # device copies for sort_spatially (offsets, rows, the row of endpoint_pairs behind every strand row)
             self._strands_dev = (offsets, rows, seg_rows if fg_rows is None else fg_rows[seg_rows])
             self._smooth_pairs = None

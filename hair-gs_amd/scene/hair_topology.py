@@ -276,20 +276,23 @@ class HairTopologyMixin:
             a, b, dist = a[keep], b[keep], dist[keep]
         order = np.argsort(dist, kind="stable")
         cand = np.stack([ends_np[a[order]], ends_np[b[order]]], 1)
-        seen, blocked, out = set(), set(), []
-        for p, q in cand:
-            # stage 1 (reference remove_duplicate_endpoint_rows): both ids must occur here for the first time in the
-            # distance-sorted candidate list -- ids of rejected rows count as seen too
-            first = p not in seen and q not in seen
-            seen.add(p)
-            seen.add(q)
-            if not first:
-                continue
+        # stage 1 (reference remove_duplicate_endpoint_rows): both ids must occur here for the first time in the
+        # distance-sorted candidate list -- ids of rejected rows count as seen too, so the test does not depend on what was
+        # accepted: a row survives iff it holds the first occurrence of both its ids (one np.unique instead of a Python loop
+        # over every candidate: thousands per merge event, a few hundred survivors)
+        flat = cand.reshape(-1)
+        _, first_at = np.unique(flat, return_index=True)
+        is_first = np.zeros(flat.shape[0], bool)
+        is_first[first_at] = True
+        cand = cand[is_first.reshape(-1, 2).all(axis=1)]
+        blocked, out = set(), []
+        partner_of = partner[cand]                # (other end of the same strand, per surviving id)
+        for (p, q), (pp, pq) in zip(cand.tolist(), partner_of.tolist()):
             # stage 2 (reference remove_complementary_rows): never merge both ends of one strand in the same round
             if p in blocked or q in blocked:
                 continue
-            blocked.add(int(partner[p]))
-            blocked.add(int(partner[q]))
+            blocked.add(pp)
+            blocked.add(pq)
             out.append((p, q))
         if not out:
             return empty
