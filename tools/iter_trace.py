@@ -4,7 +4,10 @@ d = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/prof_f"
 f = glob.glob(d + "/*/*kernel_trace.csv")[0]
 rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
 names = [r["Kernel_Name"] for r in rows]
-idx = [i for i, n in enumerate(names) if "adam_kernel" in n and "adam_step" not in n]
+# an iteration = from the end of one launch of its LAST kernel to the end of the next (round 5: the endpoint gather, which also
+# applies Adam; before: adam_kernel)
+last = sys.argv[3] if len(sys.argv) > 3 else "strand_gather_kernel"
+idx = [i for i, n in enumerate(names) if last in n]
 k = int(sys.argv[2]) if len(sys.argv) > 2 else -60      # which iteration (counted from the end: skip the timing pass)
 a, b = idx[k - 1], idx[k]
 t0 = prev = int(rows[a]["End_Timestamp"])
