@@ -8,7 +8,11 @@ from tests import scenes, gpu_util as G
 from diff_gaussian_rasterization import _C
 _C.set_tile_cull(False)   # the reference's lists: n_contrib counts positions in them (gradients are bit-identical either way)
 for name, s in (("strands", scenes.strand_scene(n_strands=60, n_seg=60, W=256, H=144, seed=3)),
-                ("blobs", scenes.random_scene(P=1500, W=160, H=96, seed=1, sh_degree=0))):
+                ("blobs", scenes.random_scene(P=1500, W=160, H=96, seed=1, sh_degree=0)),
+                # (found by tools/dev/fuzz_parity.py: screen-filling opaque Gaussians with exact depth ties -- 0.4 % of the cov3D
+                # gradient's elements outside the parity test's element-wise bound, its budget is 0.2 %)
+                ("huge_opaque_ties", scenes.random_scene(P=300, W=131, H=176, seed=120006742, sh_degree=1, scale_lo=0.03, scale_hi=0.6,
+                                                         opacity_lo=0.9, opacity_hi=0.99, behind_frac=0.05, fovx_deg=100.0, depth_levels=4))):
     dpix = np.random.default_rng(123).normal(size=(3, s["H"], s["W"])).astype(np.float32)
     f32 = O.forward(s); f64 = O.forward(s, f64=True)
     fw = G.run_forward(s); got = G.intermediates(s, fw)
