@@ -606,33 +606,51 @@ class HairGaussianModel(HairTopologyMixin, GaussianModel):
         # synchronisations) and index_select -- the same rows in the same order as boolean-mask indexing, which costs a
         # nonzero kernel and a synchronisation per tensor: 18 of them per call (parameter, both Adam moments, six groups),
         # 0.7 ms of a call that the operators make ~8 times per densification event (tools/dev/soak_profile.py).
-        seg_keep = ~segments_prune_mask
-        seg_idx = torch.nonzero(seg_keep).squeeze(1)
-        all_seg = seg_idx.shape[0] == seg_keep.shape[0]
-        if not all_seg:
-            self.endpoint_pairs = self.endpoint_pairs.index_select(0, seg_idx)
-        ep_keep = torch.zeros(self._endpoints.shape[0], dtype=torch.bool, device=self.device)
-        ep_keep[self.endpoint_pairs.flatten()] = True
+        pairs, roots, seg_idx, ep_idx = self._prune_plan(self.endpoint_pairs, self.strand_root_endpoint_idx,
+                                                         self._endpoints.shape[0], segments_prune_mask)
+        self.endpoint_pairs, self.strand_root_endpoint_idx = pairs, roots
+        self._apply_row_selection(seg_idx, ep_idx)
+
+    def _prune_plan(self, pairs, roots, n_endpoints, segments_prune_mask, keeps_every_segment=False):
+        """The index side of prune_segments, on values instead of the model: (pairs with the pruned rows gone and the ids
+        compacted, root ids renumbered, index list of the kept segment rows or None if all are kept, index list of the kept
+        endpoints or None).  No parameter is touched: a caller that prunes several times in a row (merge_collapsed_segments: two
+        calls per round, five rounds on a trained model) composes the index lists and re-creates the tensors ONCE."""
+        seg_idx = None
+        if not keeps_every_segment:
+            seg_keep = ~segments_prune_mask
+            seg_idx = torch.nonzero(seg_keep).squeeze(1)
+            if seg_idx.shape[0] == seg_keep.shape[0]:
+                seg_idx = None
+            else:
+                pairs = pairs.index_select(0, seg_idx)
+        ep_keep = torch.zeros(n_endpoints, dtype=torch.bool, device=self.device)
+        ep_keep[pairs.flatten()] = True
         ep_idx = torch.nonzero(ep_keep).squeeze(1)
-        all_ep = ep_idx.shape[0] == ep_keep.shape[0]
-        if not all_ep:
+        if ep_idx.shape[0] == ep_keep.shape[0]:
+            ep_idx = None
+        else:
             remap = torch.cumsum(ep_keep.to(torch.long), dim=0) - 1  # old id -> new id for kept endpoints
-            self.endpoint_pairs = remap[self.endpoint_pairs]
-            if torch.is_tensor(self.strand_root_endpoint_idx) and self.strand_root_endpoint_idx.numel():
-                self.strand_root_endpoint_idx = remap[self.strand_root_endpoint_idx]
+            pairs = remap[pairs]
+            if torch.is_tensor(roots) and roots.numel():
+                roots = remap[roots]
+        return pairs, roots, seg_idx, ep_idx
+
+    def _apply_row_selection(self, seg_idx, ep_idx):
+        """Re-create the per-segment tensors (parameters, Adam moments, statistics) as their rows seg_idx and the endpoints as
+        their rows ep_idx (None: all rows, the tensor stays as it is)."""
         # (a call that keeps every segment -- the reference's id compaction, twice per round of merge_collapsed_segments -- or
         # every endpoint leaves those tensors as they are: a masked copy of all rows is the same rows)
         out = {}
         for g in self.optimizer.param_groups:
-            is_ep = g["name"] == "endpoints"
-            if all_ep if is_ep else all_seg:
+            idx = ep_idx if g["name"] == "endpoints" else seg_idx
+            if idx is None:
                 g["params"][0].grad = None      # (a re-created parameter has no gradient: it skips this iteration's Adam step)
                 continue
-            idx = ep_idx if is_ep else seg_idx
             out[g["name"]] = self._swap_param(g, g["params"][0].detach().index_select(0, idx), lambda m, k=idx: m.index_select(0, k))
         if out:
             self._rebind(out)
-        if not all_seg:
+        if seg_idx is not None:
             self.xyz_gradient_accum = self.xyz_gradient_accum.index_select(0, seg_idx)
             self.denom = self.denom.index_select(0, seg_idx)
             self.max_radii2D = self.max_radii2D.index_select(0, seg_idx)

@@ -130,38 +130,52 @@ class HairTopologyMixin:
     def merge_collapsed_segments(self, info=None):
         """Segments that collapsed to a point or left the foreground, and whose both ends are interior joints, are
         removed by fusing their two endpoints; repeated until nothing merges (:969-1018)."""
+        # The reference prunes twice per round (the merged segments; then, with an all-False mask, the endpoint ids that lost their
+        # last reference), i.e. re-creates every parameter, both Adam moments and the statistics -- ~20 tensors -- ten times on a
+        # trained model (five rounds).  What a round DECIDES depends on the index structures only -- the pairs, which segment rows and
+        # endpoint ids are left, the (unchanged) positions, opacities and masks behind them -- so the rounds run on those
+        # (_prune_plan: the same statements on values), the row selections compose, and the tensors are re-created ONCE at the end:
+        # the same rows in the same order, 3 ms less per densification event (tools/dev/operator_syncs.py).
         info = _info_dict(info)
         total = 0
+        pairs, roots = self.endpoint_pairs, self.strand_root_endpoint_idx
+        ep_all, fg_all = self._endpoints.detach(), self.compute_foreground_mask()
+        seg_sel, ep_sel = None, None          # current segment row / endpoint id -> the model's (None: identity)
+        compose = lambda sel, idx: sel if idx is None else (idx if sel is None else sel.index_select(0, idx))
         while True:
-            collapsed = self._segment_lengths() < self.min_val
-            mask = collapsed | ~self.compute_foreground_mask()
-            cand = self.endpoint_pairs[mask]
+            ep = ep_all if ep_sel is None else ep_all.index_select(0, ep_sel)
+            seg = ep[pairs]
+            collapsed = torch.norm(seg[:, 1] - seg[:, 0], p=2, dim=1) < self.min_val          # (_segment_lengths)
+            mask = collapsed | ~(fg_all if seg_sel is None else fg_all.index_select(0, seg_sel))
+            cand = pairs[mask]
             if cand.shape[0] == 0:        # nothing collapsed, nothing in the background: the round that finds nothing (below)
-                for g in self.optimizer.param_groups:
-                    g["params"][0].grad = None
-                self._smooth_pairs = None
                 break
-            both_interior = torch.all(self._endpoint_degree_table()[cand] != 1, dim=1)     # (isin(cand, u[c != 1]))
+            flat = pairs.reshape(-1)
+            deg = torch.bincount(flat) if flat.numel() else torch.zeros(0, dtype=torch.long, device=self.device)   # (_endpoint_degree_table)
+            both_interior = torch.all(deg[cand] != 1, dim=1)     # (isin(cand, u[c != 1]))
             mask[mask.clone()] = both_interior
             to_merge = cand[both_interior]
             to_merge, keep = self.remove_duplicate_endpoint_rows(to_merge, return_mask=True)
             mask[mask.clone()] = keep
             if to_merge.shape[0] == 0:
                 # the round that finds nothing (every call ends with one): `mask` is all False by now, so the reference's two
-                # prune_segments calls keep every segment and every endpoint -- all they leave behind is what a call that
-                # re-creates nothing leaves: parameters without a gradient for this iteration's Adam step
-                for g in self.optimizer.param_groups:
-                    g["params"][0].grad = None
-                self._smooth_pairs = None
+                # prune_segments calls keep every segment and every endpoint
                 break
-            self.prune_segments(mask)
-            mapping = torch.arange(int(self.endpoint_pairs.max()) + 1 if self.endpoint_pairs.numel() else 0,
-                                   device=self.device)
+            n_ep = ep.shape[0]
+            pairs, roots, seg_idx, ep_idx = self._prune_plan(pairs, roots, n_ep, mask)
+            seg_sel, ep_sel = compose(seg_sel, seg_idx), compose(ep_sel, ep_idx)
+            n_ep = n_ep if ep_idx is None else ep_idx.shape[0]
+            mapping = torch.arange(n_ep, device=self.device)     # (ids are compact after a prune: max + 1 = their number)
             mapping[to_merge[:, 1]] = to_merge[:, 0]
-            self.endpoint_pairs = mapping[self.endpoint_pairs]
+            pairs = mapping[pairs]
             # compacts the endpoint table (drops the ids that just lost their last reference)
-            self.prune_segments(torch.zeros(self.endpoint_pairs.shape[0], dtype=torch.bool, device=self.device))
+            pairs, roots, _, ep_idx = self._prune_plan(pairs, roots, n_ep, None, keeps_every_segment=True)
+            ep_sel = compose(ep_sel, ep_idx)
             total += int(to_merge.shape[0])
+        self.endpoint_pairs, self.strand_root_endpoint_idx = pairs, roots
+        # all the reference's calls leave behind when they re-create nothing is what _apply_row_selection(None, None) leaves:
+        # parameters without a gradient for this iteration's Adam step
+        self._apply_row_selection(seg_sel, ep_sel)
         if info is not None:
             info["merge_collapsed"] = total
 
