@@ -623,6 +623,9 @@ def main():
         tr = measure(args.warmup + args.trained_iters, False, not args.no_kernel_timing)
         tfs = frame_stats()
         trained = {"iterations_trained": args.trained_iters, "training_seconds_incl_topology_and_recaptures": t_train,
+                   # (the WHOLE loop over those iterations -- graph replays, densification / merging / opacity resets, re-captures;
+                   # tools/soak.py runs 3000 of them: profiles/rNN_soak.txt)
+                   "whole_loop_iters_per_sec_incl_topology_and_recaptures": args.trained_iters / max(t_train, 1e-9),
                    "gaussians": int(model.get_xyz.shape[0]),
                    "value": args.steps / tr["dt"], "unit": "iters/s", "ms_per_step": tr["dt"] * 1e3 / args.steps,
                    "repeats": {"n": len(tr["regions"]), "min_iters_per_sec": args.steps / tr["regions"][-1],
