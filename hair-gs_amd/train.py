@@ -188,14 +188,25 @@ def fused_step_applicable(gaussians, opt):
             and gaussians.get_xyz.is_cuda and float(getattr(opt, "lambda_magnet", 0.0)) == 0.0)
 
 
+class _EventInfo:
+    """What the operators take as `training_info` (the reference's utils/logging.py TrainingInfo: an object with a
+    `densification_info` dict they fill with their counts)."""
+
+    def __init__(self):
+        self.densification_info = {}
+
+
 def training_step(gaussians, viewpoint_cam, opt, bg, iteration, extent=1.0, vp=None, stats_local=None, fused=None,
-                  black_background=False):
+                  black_background=False, event_log=None):
     """One optimizer step.  Returns (loss tensor (detached, on device), loss_dict, render_pkg).
     In the rasterizer's asynchronous mode (diff_gaussian_rasterization._C.set_async) the three passes never block;
     their instance counts are validated once here, before Adam, and the step is repeated if a pass overflowed.
     `fused`: a hgs_runtime.strand_step.FusedStrandStep whose view table holds `viewpoint_cam` -> the iteration runs as
     one autograd node over the fused kernels (same loss, gradients and statistics).  `black_background=True`: the caller
-    states that `bg` is all zero (op-by-op single-pass path: the blend backward's black-background specialisation)."""
+    states that `bg` is all zero (op-by-op single-pass path: the blend backward's black-background specialisation).
+    `event_log`: a list that receives one dict per iteration on which a topology operator ran -- the operators' own counts
+    (clone / split / merge_collapsed / prune_* / merge, the reference's TrainingInfo.densification_info) and the primitive
+    count before and after; asking for it costs the operators one host synchronisation per count."""
     from diff_gaussian_rasterization import _C as raster
     # once per ITERATION, not per attempt: a repeated attempt (capacity overflow) must not bump the SH degree again
     gaussians.update_learning_rate(iteration)
@@ -204,13 +215,14 @@ def training_step(gaussians, viewpoint_cam, opt, bg, iteration, extent=1.0, vp=N
     for _attempt in range(4):
         try:
             return _training_step(gaussians, viewpoint_cam, opt, bg, iteration, extent, vp, raster, fused,
-                                  black_background)
+                                  black_background, event_log)
         except raster.HgsCapacityOverflow:
             gaussians.optimizer.zero_grad(set_to_none=True)
     raise RuntimeError("rasterizer capacity kept overflowing")
 
 
-def _training_step(gaussians, viewpoint_cam, opt, bg, iteration, extent, vp, raster, fused=None, black_background=False):
+def _training_step(gaussians, viewpoint_cam, opt, bg, iteration, extent, vp, raster, fused=None, black_background=False,
+                   event_log=None):
     # The reference ends every iteration with zero_grad(set_to_none=True) (train.py:203): an iteration starts without
     # gradients.  A captured graph leaves its static gradient tensors in `.grad` after a replay -- an eager iteration that
     # follows (topology iterations of training(), bench.py's kernel-timing pass) would ACCUMULATE onto them.
@@ -234,6 +246,8 @@ def _training_step(gaussians, viewpoint_cam, opt, bg, iteration, extent, vp, ras
         loss.backward()
     raster.check_async()  # async mode: the step's single synchronisation (raises -> step repeated); no-op otherwise
     densified = False
+    info = _EventInfo() if event_log is not None else None
+    n_before = int(gaussians.get_xyz.shape[0]) if info is not None else 0
     with torch.no_grad():
         if iteration < opt.densify_until_iter:
             if fused is not None:
@@ -246,15 +260,20 @@ def _training_step(gaussians, viewpoint_cam, opt, bg, iteration, extent, vp, ras
                 if vp is not None:
                     vp.reduce_stats(gaussians)
                 size_threshold = opt.prune_max_radii_2d if iteration > opt.opacity_reset_interval else None
-                gaussians.densification(extent, size_threshold, None)
+                gaussians.densification(extent, size_threshold, info)
                 densified = True
             if iteration % opt.opacity_reset_interval == 0 and getattr(opt, "enable_topology", True):
                 gaussians.reset_opacity()     # (part of the densification schedule, train.py:188-190: off with the operators)
+                if info is not None:
+                    info.densification_info["opacity_reset"] = 1
         if isinstance(gaussians, HairGaussianModel) and getattr(opt, "enable_topology", True):
             if iteration % opt.merge_interval == 0 and hasattr(gaussians, "merging"):
-                gaussians.merging(training_info=None, strands_info_is_current=densified)
+                gaussians.merging(training_info=info, strands_info_is_current=densified)
             if getattr(gaussians, "_storage_dirty", False):
                 gaussians._maybe_sort_spatially()     # back to strand order, once per iteration (scene/hair_gaussian_model.py)
+        if info is not None and info.densification_info:
+            event_log.append(dict(iteration=int(iteration), primitives_before=n_before,
+                                  primitives_after=int(gaussians.get_xyz.shape[0]), **info.densification_info))
         if vp is not None:
             vp.reduce_gradients(gaussians)
         gaussians.optimizer.step()
@@ -601,14 +620,15 @@ def topology_due(gaussians, opt, iteration):
 
 
 def training(gaussians, cameras, opt, iterations=None, extent=1.0, seed=0, log_every=0, vp=None, start_iteration=0,
-             use_graph=True, sampler=None, steps_per_graph=8):
+             use_graph=True, sampler=None, steps_per_graph=8, event_log=None):
     """Training loop (reference train.py:91-254 without logger / viewer / dataset IO, which are outside the
     accelerated path).  With use_graph the iteration body replays a captured HIP graph (GraphedStep).  Iterations on which
     the reference schedules a shape-changing operator (densification, merging, opacity reset, SH-degree bump:
     train.py:136-200) run EAGERLY through `training_step`, which has the reference's order -- operators between backward
     and optimizer.step(), so re-created tensors skip that Adam step exactly as in the reference --, and the graph is
     captured again afterwards.  Runs of steps_per_graph plain iterations go out as ONE graph launch (GraphedStep.step_many;
-    single rank, fused iteration).  `sampler`: a ViewSampler to continue (main() trains in chunks between saves)."""
+    single rank, fused iteration).  `sampler`: a ViewSampler to continue (main() trains in chunks between saves).
+    `event_log`: see training_step (per-event operator counts)."""
     vp = ViewParallel() if vp is None else vp
     dev = gaussians.get_xyz.device
     bg = torch.zeros(3, dtype=torch.float32, device=dev)
@@ -699,7 +719,7 @@ def training(gaussians, cameras, opt, iterations=None, extent=1.0, seed=0, log_e
                 # graph -- and with it the parameters' AccumulateGrad nodes, created on THIS stream -- alive, which breaks the
                 # next capture on the side stream (stream mismatch; observed as a crash in capture_end)
                 losses = [training_step(gaussians, sampler.next(), opt, bg, it, extent=extent, vp=vp, fused=fused,
-                                        black_background=True)[0]]
+                                        black_background=True, event_log=event_log)[0]]
                 if fused is not None and due:
                     fused.refresh()
             first, it = it, it + len(losses)

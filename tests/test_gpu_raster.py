@@ -582,3 +582,331 @@ def test_full_size_forward_and_backward_against_oracle(workload):
         with open(os.path.join(os.environ["HGS_GRAD_REPORT_DIR"], f"grad_parity_{workload}.json"), "w") as fh:
             json.dump({"workload": workload, "fragile_gaussians": int(gref["fragile"].sum()), "gaussians": int(gref["fragile"].shape[0]),
                        "percentiles_p50_p99_p99.9_max": pct}, fh, indent=1)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The kernels the training step runs -- blend_fwd_kernel<7>, blend_bwd_kernel<7, BLACK>, preprocess_bwd_kernel<DC_ONLY, 0/1/2>
+# -- against the oracle at every BASELINE size.  The reference renders three times per iteration (SH RGB: train.py:146;
+# colors_precomp = mask x 3: loss/losses.py:246-249; colors_precomp = orientation: :311-312) and autograd sums the three
+# backward passes (CR/backward_distwar.cu:855-1014); the densification statistics read the screen-space gradient of the RGB
+# pass alone (train.py:170).  So the oracle is called three times on the same scene and its gradients are summed.
+BG7_NONZERO = np.array([0.1, 0.2, 0.3, 0.05, 0.2, -0.1, 0.3], np.float32)
+
+
+def _workload_scene7(workload, view=0):
+    """_workload_scene + the four extra per-Gaussian channels of the single pass (mask, world-space direction) and the model."""
+    import torch
+    from synthetic import build_workload
+    model, cams, _ = build_workload(workload, device="cuda", seed=0, with_targets=False, n_views=2)
+    s = _scene_of(model, cams[view])
+    with torch.no_grad():
+        extra = torch.cat((model.get_mask, model.get_orientation), dim=1).contiguous()
+    return s, extra, model, cams[view]
+
+
+def _scene_of(model, cam):
+    import math
+    import torch
+    with torch.no_grad():
+        return dict(means3D=model.get_xyz.cpu().numpy(), opacities=model.get_opacity.cpu().numpy().reshape(-1),
+                    scales=model.get_scaling.cpu().numpy(), rotations=model.get_rotation.cpu().numpy(), cov3D_precomp=None,
+                    viewmatrix=cam.world_view_transform.cpu().numpy(), projmatrix=cam.full_proj_transform.cpu().numpy(),
+                    campos=cam.camera_center.cpu().numpy(), bg=np.zeros(3, np.float32),
+                    tanfovx=float(math.tan(cam.FoVx * 0.5)), tanfovy=float(math.tan(cam.FoVy * 0.5)), W=cam.image_width,
+                    H=cam.image_height, sh_degree=model.active_sh_degree, scale_modifier=1.0,
+                    shs=model.get_features.cpu().numpy(), colors_precomp=None)
+
+
+def _forward7(s, extra, bg7, cull):
+    """hgs_forward_render_multi through the drop-in module; bg7: a [7] array."""
+    import torch
+    from diff_gaussian_rasterization import _C
+    from tests import gpu_util as G
+    d = G.to_dev
+    was = _C.set_tile_cull(cull)
+    try:
+        R, planes, radii, geom, binning, img = _C.rasterize_gaussians_multi(
+            d(bg7), d(s["means3D"]), d(None), extra, d(s["opacities"]).reshape(-1, 1), d(s["scales"]), d(s["rotations"]), 1.0,
+            d(None), d(s["viewmatrix"]), d(s["projmatrix"]), float(s["tanfovx"]), float(s["tanfovy"]), int(s["H"]), int(s["W"]),
+            d(s["shs"]), int(s["sh_degree"]), d(s["campos"]), False, False)
+    finally:
+        _C.set_tile_cull(was)
+    torch.cuda.synchronize()
+    W, H = s["W"], s["H"]
+    T = ((W + 15) // 16) * ((H + 15) // 16)
+    im = rt_layout_image(W, H)
+    return dict(R=R, planes=planes, radii=radii, geom=geom, binning=binning, img=img,
+                final_T=G._view(img, im["final_T"], W * H, np.float32).reshape(H, W),
+                n_contrib=G._view(img, im["n_contrib"], W * H, np.uint32).reshape(H, W),
+                ranges=G._view(img, im["ranges"], 2 * T, np.uint32).reshape(T, 2),
+                status=G._view(img, im["status"], 16, np.uint32))
+
+
+def rt_layout_image(W, H):
+    import hgs_runtime as rt
+    return rt.layout("image", W, H)
+
+
+def _oracle_three_passes(s, extra_np, bg7):
+    """The reference's three render() calls as three oracle forwards on the same scene: (rgb, mask, orientation) results."""
+    s_rgb = dict(s, bg=bg7[0:3])
+    s_mask = dict(s, shs=None, sh_degree=0, colors_precomp=np.repeat(extra_np[:, 0:1], 3, axis=1), bg=np.repeat(bg7[3:4], 3))
+    s_ori = dict(s, shs=None, sh_degree=0, colors_precomp=np.ascontiguousarray(extra_np[:, 1:4]), bg=bg7[4:7])
+    return [(sc, O.forward(sc)) for sc in (s_rgb, s_mask, s_ori)]
+
+
+def _check_image7(planes, refs, npix):
+    """Seven planes against the three oracle images: <= 1e-4 (x max(|ref|, 1)) except on the few pixels a threshold flip moves."""
+    ref7 = np.concatenate([refs[0][1]["out_color"], refs[1][1]["out_color"][0:1], refs[2][1]["out_color"]], axis=0)
+    err = np.abs(planes - ref7)
+    bad = err > 1e-4 * np.maximum(np.abs(ref7), 1.0)
+    nbad = int(bad.any(0).sum())
+    assert nbad <= max(2, npix // 20000), f"{nbad} pixels outside 1e-4"
+    assert float(err.max()) <= 2e-2 and float(np.median(err)) <= 1e-6
+    return float(err[~bad].max()) if (~bad).any() else 0.0
+
+
+def _oracle_backward7(refs, state, dplanes):
+    """Sum of the three oracle backward passes (what autograd accumulates over the reference's three render() calls) on the
+    given per-pixel state (n_contrib / final_T in the reference's list numbering).  Returns the summed gradient dict in the
+    key set of GRAD_KEYS (+ dL_dextra [P,4], the RGB pass's own dL_dmeans2D as dL_dmeans2D_rgb, fragile = union)."""
+    out = None
+    for k, ((sc, fw), dp) in enumerate(zip(refs, (dplanes[0:3], np.stack([dplanes[3], 0 * dplanes[3], 0 * dplanes[3]]), dplanes[4:7]))):
+        st = dict(fw)
+        st["n_contrib"], st["final_T"] = state["n_contrib"].copy(), state["final_T"].copy()
+        g = O.backward(sc, st, np.ascontiguousarray(dp, dtype=np.float32))
+        if k == 0:
+            out = {n: g[n].astype(np.float64) for n in GRAD_KEYS}
+            out["dL_dmeans2D_rgb"] = g["dL_dmeans2D"].astype(np.float64)
+            out["fragile"] = g["fragile"].copy()
+            P = g["fragile"].shape[0]
+            out["dL_dextra"] = np.zeros((P, 4))
+        else:
+            for n in ("dL_dmeans2D", "dL_dconic", "dL_dopacity", "dL_dmeans3D", "dL_dcov3D", "dL_dscales", "dL_drotations"):
+                out[n] = out[n] + g[n]
+            out["fragile"] |= g["fragile"]
+            if k == 1:
+                out["dL_dextra"][:, 0] = g["dL_dcolors"][:, 0]
+            else:
+                out["dL_dextra"][:, 1:4] = g["dL_dcolors"]
+    return out
+
+
+def _backward7(s, extra, fw, bg7, dplanes):
+    import torch
+    from diff_gaussian_rasterization import _C
+    from tests import gpu_util as G
+    d = G.to_dev
+    dp = d(dplanes)
+    out = _C.rasterize_gaussians_multi_backward(
+        None if bg7 is None else d(bg7), d(s["means3D"]), fw["radii"], d(None), d(s["scales"]), d(s["rotations"]), 1.0, d(None),
+        d(s["viewmatrix"]), d(s["projmatrix"]), float(s["tanfovx"]), float(s["tanfovy"]), [dp[k] for k in range(7)], d(s["shs"]),
+        int(s["sh_degree"]), d(s["campos"]), fw["geom"], fw["R"], fw["binning"], fw["img"], False)
+    torch.cuda.synchronize()
+    names = ["dL_dmeans2D_rgb", "dL_dcolors", "dL_dextra", "dL_dopacity", "dL_dmeans3D", "dL_dcov3D", "dL_dsh", "dL_dscales",
+             "dL_drotations"]
+    return {n: t.cpu().numpy() for n, t in zip(names, out)}
+
+
+def _grad_check7(g, gref, fwd_ref, report_name=None):
+    """_grad_check's bar (1e-4 of the tensor's scale on every element of a non-fragile Gaussian, the element-wise bound on all
+    but 0.2 %) for the tensors the 7-channel backward returns: the summed geometry gradients, dL_dcolors / dL_dsh of the RGB
+    pass, dL_dextra of the other two and the RGB-only screen-space gradient."""
+    fragile = gref["fragile"]
+    P = fragile.shape[0]
+    expected = _expected_fragile(fwd_ref)
+    assert int(fragile.sum()) <= 3.0 * expected + 8
+    report = {}
+    for k in ("dL_dmeans2D_rgb", "dL_dcolors", "dL_dextra", "dL_dopacity", "dL_dmeans3D", "dL_dcov3D", "dL_dsh", "dL_dscales",
+              "dL_drotations"):
+        if k not in g or gref[k].size == 0:
+            continue
+        b = gref[k].astype(np.float64).reshape(P, -1)
+        a = g[k].astype(np.float64).reshape(b.shape)
+        scale = float(np.abs(b).max())
+        if scale == 0.0:
+            assert np.abs(a).max() == 0.0, k
+            continue
+        err = np.abs(a - b)
+        solid = err[~fragile]
+        worst = float(solid.max()) / scale
+        frac = float((solid > 1e-4 * np.maximum(np.abs(b[~fragile]), 1e-2 * scale)).mean())
+        report[k] = (worst, frac, int(fragile.sum()))
+        assert worst <= GRAD_MAX_OF_SCALE, (k, report[k])
+        assert frac <= GRAD_NOISE_FRAC, (k, report[k])
+        if fragile.any():
+            assert float(err[fragile].max()) / scale <= FRAGILE_MAX_OF_SCALE, (k, float(err[fragile].max()) / scale)
+    return report
+
+
+@pytest.mark.parametrize("workload", ["north_star", "c2", "c3", "c4", "c5"])
+def test_seven_channel_pass_against_oracle(workload):
+    """hgs_forward_render_multi + hgs_backward_multi (the 7-channel instantiations bench.py times) against three oracle passes
+    at the BASELINE sizes: seven image planes, n_contrib / final_T, every gradient as the sum of the three oracle backwards at
+    _grad_check's bar, the RGB-only dL_dmeans2D (what densification reads) as the RGB pass's alone.  Twice: bg = NULL (the
+    black-background specialisation blend_bwd_kernel<7, true>: the training step's) and a non-zero 7-channel background."""
+    import torch
+    s, extra, _, _ = _workload_scene7(workload)
+    extra_np = extra.cpu().numpy()
+    npix = s["W"] * s["H"]
+    rng = np.random.default_rng(17)
+    dplanes = rng.normal(size=(7, s["H"], s["W"])).astype(np.float32)
+    for tag, bg7 in (("black", np.zeros(7, np.float32)), ("bg7", BG7_NONZERO)):
+        refs = _oracle_three_passes(s, extra_np, bg7)
+        # the reference's three passes share one geometry: same lists, same per-pixel walk
+        for _, r in refs[1:]:
+            np.testing.assert_array_equal(r["n_contrib"], refs[0][1]["n_contrib"])
+            np.testing.assert_array_equal(r["point_list"], refs[0][1]["point_list"])
+        fw = _forward7(s, extra, bg7, True)                       # the training step's form: tile culling on
+        fw_ref_lists = _forward7(s, extra, bg7, False)            # the reference's lists: per-pixel state in its numbering
+        assert fw["status"][1] == 0 and fw["status"][8] == 0 and fw_ref_lists["status"][1] == 0
+        planes = fw["planes"].cpu().numpy()
+        worst_img = _check_image7(planes, refs, npix)
+        _assert_same_image(fw_ref_lists["planes"].cpu().numpy(), planes, fw_ref_lists["ranges"])
+        np.testing.assert_array_equal(fw["radii"].cpu().numpy(), refs[0][1]["radii"])
+        ref0 = refs[0][1]
+        flips = int((fw_ref_lists["n_contrib"] != ref0["n_contrib"]).sum())
+        assert flips <= max(2, npix // 2000), f"n_contrib differs on {flips}/{npix} pixels"
+        same = fw_ref_lists["n_contrib"] == ref0["n_contrib"]
+        # (an entry in the MIDDLE of a pixel's walk whose alpha sits within rounding of 1/255 is blended by one side only: the
+        # last contributor stays, the transmittance moves by that alpha -- counted like the image's threshold flips)
+        dT = np.abs(fw_ref_lists["final_T"] - ref0["final_T"])[same]
+        assert int((dT > 1e-4).sum()) <= max(2, npix // 20000) and float(dT.max(initial=0.0)) <= 5e-3, (int((dT > 1e-4).sum()), float(dT.max()))
+        gref = _oracle_backward7(refs, fw_ref_lists, dplanes)
+        g = _backward7(s, extra, fw, None if tag == "black" else bg7, dplanes)
+        report = _grad_check7(g, gref, ref0)
+        print("SEVEN", workload, tag, f"image {worst_img:.1e}", {k: (f"{v[0]:.1e}", f"{v[1]:.1e}", v[2]) for k, v in report.items()})
+        if os.environ.get("HGS_GRAD_REPORT_DIR"):
+            import json
+            gg = dict(g)
+            gg["dL_dmeans2D"] = None
+            pct = {}
+            fragile = gref["fragile"]
+            for k in report:
+                b = gref[k].astype(np.float64).reshape(fragile.shape[0], -1)
+                a = g[k].astype(np.float64).reshape(b.shape)
+                scale = float(np.abs(b).max())
+                nz = np.abs(b).max(axis=1) > 0
+                row = {}
+                for t2, sel in (("solid", nz & ~fragile), ("all", nz)):
+                    if sel.any():
+                        err = np.abs(a[sel] - b[sel]).reshape(-1)
+                        rel = err / np.maximum(np.abs(b[sel]).reshape(-1), 1e-3 * scale)
+                        q = lambda v: [float(x) for x in np.percentile(v, [50, 99, 99.9, 100])]
+                        row[t2] = {"of_scale": q(err / scale), "relative": q(rel), "n": int(err.size)}
+                pct[k] = row
+            with open(os.path.join(os.environ["HGS_GRAD_REPORT_DIR"], f"grad_parity7_{workload}_{tag}.json"), "w") as fh:
+                json.dump({"workload": workload, "pass": "7-channel, " + tag, "fragile_gaussians": int(fragile.sum()),
+                           "gaussians": int(fragile.shape[0]), "image_max_err_outside_flips": worst_img,
+                           "percentiles_p50_p99_p99.9_max": pct}, fh, indent=1)
+        del fw, fw_ref_lists
+        torch.cuda.empty_cache()
+
+
+def _chain_rule_reference(model, kind, gref):
+    """The parameters' gradients by torch autograd through the model's own getters (the reference's statements,
+    scene/hair_gaussian_model.py:134-201 / scene/gaussian_model.py:81-113) from the ORACLE's Gaussian-space gradients."""
+    import torch
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).cuda()
+    chain = ((model.get_xyz * t(gref["dL_dmeans3D"])).sum() + (model.get_scaling * t(gref["dL_dscales"])).sum() +
+             (model.get_rotation * t(gref["dL_drotations"])).sum() + (model.get_opacity * t(gref["dL_dopacity"])).sum() +
+             (model.get_mask * t(gref["dL_dextra"][:, 0:1])).sum() + (model.get_orientation * t(gref["dL_dextra"][:, 1:4])).sum())
+    if kind == "hair":
+        params = [model._endpoints, model._width, model._opacity, model._mask]
+    else:
+        params = [model._xyz, model._scaling, model._rotation, model._opacity, model._mask]
+    return [x.detach().cpu().numpy() for x in torch.autograd.grad(chain, params)]
+
+
+@pytest.mark.parametrize("workload", ["north_star", "c2"])
+def test_seven_channel_parameter_backward_against_oracle(workload):
+    """hgs_backward_multi_params (the backward the captured iteration runs: preprocess_bwd_kernel<true, 1> for strands + the
+    endpoint gather, <true, 2> for the Stage-I cloud) at BASELINE size against the oracle's three backward passes pushed
+    through the model's getters by torch autograd: every parameter gradient at _grad_check's bar, dL_dsh, the RGB-only
+    screen-space gradient and the densification statistics it feeds (scene/hair_gaussian_model.py:1401-1408, train.py:170)."""
+    import ctypes as C
+    import torch
+    import hgs_runtime as rt
+    from diff_gaussian_rasterization import _C
+    from hgs_runtime.strand_step import _adjacency
+    from tests import gpu_util as G
+    s, extra, model, cam = _workload_scene7(workload)
+    from scene.hair_gaussian_model import HairGaussianModel
+    kind = "hair" if isinstance(model, HairGaussianModel) else "cloud"
+    extra_np = extra.cpu().numpy()
+    bg7 = np.zeros(7, np.float32)
+    refs = _oracle_three_passes(s, extra_np, bg7)
+    fw = _forward7(s, extra, bg7, True)
+    fw_ref_lists = _forward7(s, extra, bg7, False)
+    dplanes = np.random.default_rng(23).normal(size=(7, s["H"], s["W"])).astype(np.float32)
+    gref = _oracle_backward7(refs, fw_ref_lists, dplanes)
+    ref_params = _chain_rule_reference(model, kind, gref)
+    # ---- the product: one launch for the Gaussians' gradients AND the parameters' backward
+    d = G.to_dev
+    P = s["means3D"].shape[0]
+    f32 = dict(dtype=torch.float32, device="cuda")
+    dp = d(dplanes)
+    pb = rt.ParamBackward()
+    g_means2D = torch.empty((P, 3), **f32)
+    d_o, d_m = torch.empty((P, 1), **f32), torch.empty((P, 1), **f32)
+    max_radii, accum, denom = torch.zeros(P, **f32), torch.zeros((P, 1), **f32), torch.zeros((P, 1), **f32)
+    pb.extra4, pb.d_opacity_raw, pb.d_mask_raw, pb.dL_dmeans2D_rgb = rt.ptr(extra), rt.ptr(d_o), rt.ptr(d_m), rt.ptr(g_means2D)
+    pb.max_radii2D, pb.grad_accum, pb.denom = rt.ptr(max_radii), rt.ptr(accum), rt.ptr(denom)
+    xyz, scales, rots = d(s["means3D"]), d(s["scales"]), d(s["rotations"])
+    if kind == "hair":
+        E = model._endpoints.shape[0]
+        pairs = model.endpoint_pairs.contiguous()
+        seg_contrib, d_w, d_ep = torch.empty((P, 2, 4), **f32), torch.empty((P, 1), **f32), torch.empty((E, 3), **f32)
+        pb.kind, pb.endpoints, pb.endpoint_pairs = rt.PARAMS_HAIR, rt.ptr(model._endpoints.detach()), rt.ptr(pairs)
+        pb.dist_to_scale_factor = float(model.dist_to_scale_factor)
+        pb.seg_contrib, pb.d_width = rt.ptr(seg_contrib), rt.ptr(d_w)
+    else:
+        rot_raw = model._rotation.detach().contiguous()
+        g3, d_s, d_r = torch.empty((P, 3), **f32), torch.empty((P, 3), **f32), torch.empty((P, 4), **f32)
+        pb.kind, pb.rotation_raw = rt.PARAMS_CLOUD, rt.ptr(rot_raw)
+        pb.d_means3D, pb.d_scaling_raw, pb.d_rotation_raw = rt.ptr(g3), rt.ptr(d_s), rt.ptr(d_r)
+    g_sh = _C.rasterize_gaussians_multi_backward_params(
+        None, xyz, fw["radii"], scales, rots, d(s["viewmatrix"]), d(s["projmatrix"]), float(s["tanfovx"]), float(s["tanfovy"]),
+        [dp[k] for k in range(7)], d(s["shs"]), int(s["sh_degree"]), d(s["campos"]), fw["geom"], fw["R"], fw["binning"], fw["img"], pb)
+    if kind == "hair":
+        fu = rt.StrandFusion()
+        adj = _adjacency(pairs.reshape(-1), 2, E, 2)
+        assert adj is not None
+        fu.ep_segments, fu.n_endpoints = adj.data_ptr(), E
+        rt.check(rt.lib().hgs_hair_endpoint_gather(rt.current_stream(), E, rt.ptr(seg_contrib), rt.ptr(model._endpoints.detach()),
+                                                   rt.ptr(d_ep), C.byref(fu), None))
+        got_params = [d_ep, d_w, d_o, d_m]
+        names = ["endpoints", "width", "opacity_raw", "mask_raw"]
+        pr = pairs.cpu().numpy()
+        frag_e = np.zeros(E, bool)
+        frag_e[pr[gref["fragile"]].reshape(-1)] = True
+        frag_rows = [frag_e, gref["fragile"], gref["fragile"], gref["fragile"]]
+    else:
+        got_params = [g3, d_s, d_r, d_o, d_m]
+        names = ["xyz", "scaling_raw", "rotation_raw", "opacity_raw", "mask_raw"]
+        frag_rows = [gref["fragile"]] * 5
+    torch.cuda.synchronize()
+    report = {}
+    for name, got, ref, frag in zip(names, got_params, ref_params, frag_rows):
+        a = got.cpu().numpy().astype(np.float64).reshape(ref.shape[0], -1)
+        b = ref.astype(np.float64).reshape(ref.shape[0], -1)
+        scale = float(np.abs(b).max())
+        assert scale > 0, name
+        err = np.abs(a - b)
+        worst = float(err[~frag].max()) / scale
+        frac = float((err[~frag] > 1e-4 * np.maximum(np.abs(b[~frag]), 1e-2 * scale)).mean())
+        report[name] = (worst, frac)
+        assert worst <= GRAD_MAX_OF_SCALE and frac <= GRAD_NOISE_FRAC, (name, report[name])
+        if frag.any():
+            assert float(err[frag].max()) / scale <= FRAGILE_MAX_OF_SCALE, name
+    rasters = {"dL_dsh": g_sh.cpu().numpy(), "dL_dmeans2D_rgb": g_means2D.cpu().numpy()}
+    report.update(_grad_check7(rasters, gref, refs[0][1]))
+    # ---- the densification statistics of this one pass, from the oracle's RGB-only screen-space gradient
+    vis = refs[0][1]["radii"] > 0
+    np.testing.assert_array_equal(denom.cpu().numpy().reshape(-1), vis.astype(np.float32))
+    np.testing.assert_array_equal(max_radii.cpu().numpy(), np.where(vis, refs[0][1]["radii"], 0).astype(np.float32))
+    want = np.where(vis, np.linalg.norm(gref["dL_dmeans2D_rgb"][:, :2], axis=1), 0.0)
+    got_acc = accum.cpu().numpy().reshape(-1).astype(np.float64)
+    solid = ~gref["fragile"]
+    assert float(np.abs(got_acc - want)[solid].max()) <= 1e-4 * float(want.max())
+    print("SEVEN_PARAMS", workload, {k: tuple(f"{x:.1e}" for x in v[:2]) for k, v in report.items()})
