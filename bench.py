@@ -40,6 +40,12 @@ The JSON line also carries
                 same workload (`traffic_source` names the file), per launch, with FETCH_SIZE corrected per access shape.
   roofline_c3   the same block for BASELINE.json config 3 (200k strand-Gaussians), timed by a child process that runs before this
                 one touches the GPU (--no-c3-leg skips it)
+  pipeline_states  the states the three-stage workflow lives in (synthetic.PIPELINE_STATES, built the way tools/three_stage.py
+                builds them): `stage1_1080p` -- the Stage-I cloud of a 200 k-segment capture at BASELINE config 3's frame after 1000
+                iterations of the Stage-I loop -- and `stage3_merged` -- the Stage-II product of the same capture (5000 Stage-I
+                iterations, merge rounds to the fixed point), the model Stage III starts from; each timed by a child process with
+                the headline's protocol (--workload stage1_1080p / stage3_merged runs one directly): value, kernel_us_per_launch,
+                roofline.  --no-pipeline-legs skips them
   cpu_baseline  the CPU oracle (oracle/, OpenMP C restatement of the reference rasterizer) doing the 3 raster fwd+bwd
                 passes of one iteration on the host cores, plus -- `cpu_only_paths` -- the reference's CPU-only paths
                 timed in the same run on the same cores: c_utils.filter_strand_list_segments (this package's native
@@ -89,6 +95,11 @@ def parse():
     ap.add_argument("--no-c3-leg", action="store_true",
                     help="skip `roofline_c3`: BASELINE.json config 3 (200k strand-Gaussians) timed by a child process of this run "
                          "(rank 0, 1 GPU, north_star workload only)")
+    ap.add_argument("--no-pipeline-legs", action="store_true",
+                    help="skip `pipeline_states`: the Stage-I cloud and the merged Stage-III start model of a 200 k-segment capture, "
+                         "each timed by a child process of this run (rank 0, 1 GPU, north_star workload only)")
+    ap.add_argument("--stage1-iters", type=int, default=None,
+                    help="--workload stage1_1080p / stage3_merged: iterations of the Stage-I loop before the state is taken")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true", help="disable per-kernel HIP-event timing")
     ap.add_argument("--three-pass", action="store_true",
@@ -200,7 +211,7 @@ def roofline_block(kern, fs, W, H, ch, wl_tag):
     ach = bytes_bwd / dur_s / 1e9 if bwd_ms > 0 else 0.0
     moved = moved_bwd / dur_s / 1e9 if bwd_ms > 0 else 0.0
     traffic = traffic_source = valu_util = lanes_busy = None
-    for name in (f"r05_pmc_raster_{wl_tag}.json", f"r04_pmc_raster_{wl_tag}.json", f"r03_pmc_raster_{wl_tag}.json", f"r02_pmc_raster_{wl_tag}.json", f"pmc_raster_{wl_tag}.json"):
+    for name in (f"r06_pmc_raster_{wl_tag}.json", f"r05_pmc_raster_{wl_tag}.json", f"r04_pmc_raster_{wl_tag}.json", f"r03_pmc_raster_{wl_tag}.json", f"r02_pmc_raster_{wl_tag}.json", f"pmc_raster_{wl_tag}.json"):
         pmc_path = os.path.join(ROOT, "profiles", name)
         if ch == 7 and os.path.exists(pmc_path):
             pm = json.load(open(pmc_path)).get("blend_bwd_kernel<7>", {})
@@ -246,6 +257,25 @@ def c3_roofline_leg():
         c3 = json.loads(cp.stdout.strip().splitlines()[-1])
         return dict(c3["roofline"], workload=c3["config"]["workload"], iters_per_sec=c3["value"],
                     blend_fwd=c3.get("roofline_blend_fwd"), kernel_us_per_launch=c3.get("kernel_us_per_launch"))
+    except Exception as e:
+        return {"error": str(e)}
+
+
+def pipeline_state_leg(name):
+    """One entry of `pipeline_states`: this script on --workload <name> as a CHILD process that runs to completion before this
+    process touches the GPU (as c3_roofline_leg)."""
+    import subprocess
+    try:
+        cp = subprocess.run([sys.executable, os.path.abspath(__file__), "--workload", name, "--steps", "40", "--warmup", "5",
+                             "--repeats", "3", "--sustained-seconds", "0", "--trained-iters", "0", "--no-cpu-baseline",
+                             "--no-c3-leg", "--no-pipeline-legs"], capture_output=True, text=True, timeout=600)
+        r = json.loads(cp.stdout.strip().splitlines()[-1])
+        return {"value": r["value"], "unit": r["unit"], "ms_per_step": r["ms_per_step"], "workload": r["config"]["workload"],
+                "state": r["config"].get("pipeline_state"), "gaussians": r["config"]["gaussians"],
+                "mean_num_rendered_after_tile_cull": r["config"]["mean_num_rendered_after_tile_cull"],
+                "mean_sum_tile_list_len": r["config"]["mean_sum_tile_list_len"], "render_ms_per_view": r["render_ms_per_view"],
+                "kernel_us_per_launch": r.get("kernel_us_per_launch"), "roofline": r.get("roofline"),
+                "roofline_blend_fwd": r.get("roofline_blend_fwd")}
     except Exception as e:
         return {"error": str(e)}
 
@@ -296,11 +326,14 @@ def main():
         # (a torchrun world that is not the one asked for: refuse, or `n_gpus` of the line would contradict the command)
         print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={os.environ.get('WORLD_SIZE')}", file=sys.stderr)
         sys.exit(2)
-    c3_leg = None
-    if (int(os.environ.get("WORLD_SIZE", "1")) == 1 and args.workload == "north_star" and not args.no_c3_leg
-            and not args.no_kernel_timing and not args.eager and not args.blocking
-            and "rocprof" not in os.environ.get("LD_PRELOAD", "").lower()):   # (a profiler's preload has initialised the GPU)
+    c3_leg = pipeline_legs = None
+    side_legs_ok = (int(os.environ.get("WORLD_SIZE", "1")) == 1 and args.workload == "north_star"
+                    and not args.no_kernel_timing and not args.eager and not args.blocking
+                    and "rocprof" not in os.environ.get("LD_PRELOAD", "").lower())   # (a profiler's preload has initialised the GPU)
+    if side_legs_ok and not args.no_c3_leg:
         c3_leg = c3_roofline_leg()
+    if side_legs_ok and not args.no_pipeline_legs:
+        pipeline_legs = {name: pipeline_state_leg(name) for name in ("stage1_1080p", "stage3_merged")}
     import torch
     import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -331,7 +364,7 @@ def main():
     import hgs_runtime as rt
     from arguments import OptimizationParams
     from gaussian_renderer import render
-    from synthetic import WORKLOADS, build_workload
+    from synthetic import PIPELINE_STATES, WORKLOADS, build_pipeline_state, build_workload
     from train import ViewParallel, ViewSampler, training_step
     from utils.general import safe_state
 
@@ -342,7 +375,17 @@ def main():
     from diff_gaussian_rasterization import _C as raster
     raster.set_async(not args.blocking)
     safe_state(True)
-    model, cams, extent = build_workload(args.workload, device=dev, seed=0, n_views=args.views)
+    pipeline_info = None
+    if args.workload in PIPELINE_STATES:
+        # a state of the three-stage workflow (its own process: the Stage-I loop that leads to it runs here, untimed)
+        if world != 1:
+            raise SystemExit("the pipeline-state workloads are single-GPU legs")
+        args.trained_iters = 0
+        model, cams, extent, pipeline_info = build_pipeline_state(args.workload, device=dev, seed=0, stage1_iters=args.stage1_iters,
+                                                                   n_views=args.views)
+        raster.set_async(not args.blocking)
+    else:
+        model, cams, extent = build_workload(args.workload, device=dev, seed=0, n_views=args.views)
     opt = OptimizationParams()
     opt.single_pass = not args.three_pass
     opt.fused_step = not args.op_by_op
@@ -643,8 +686,9 @@ def main():
         if world > 1:
             dist.destroy_process_group()
         return
-    kind, kw, views, W, H = WORKLOADS[args.workload]
+    W, H = cams[0].image_width, cams[0].image_height
     T = ((W + 15) // 16) * ((H + 15) // 16)
+    kind_name = "strand-Gaussians" if hasattr(model, "endpoint_pairs") else "Gaussians (Stage-I cloud)"
     P = P_head
     result = {
         "metric": "train_iters_per_sec", "value": views_per_step * args.steps / dt, "unit": "iters/s", "n_gpus": world,
@@ -661,10 +705,11 @@ def main():
         # True: the gradient all-reduce and Adam are nodes of the step's HIP graph (several optimizer steps per launch work
         # across ranks); False with several ranks: the eager exchange behind the graph (gloo, or the capture probe failed)
         "collective_in_graph": head["collective_captured"] if world > 1 else None,
-        "config": {"workload": f"{args.workload}: {P} strand-Gaussians, {len(cams)} views @ {W}x{H}, "
+        "config": {"workload": f"{args.workload}: {P} {kind_name}, {len(cams)} views @ {W}x{H}, "
                                f"{views_per_rank} view(s)/GPU/optimizer step ({views_per_step} views/step), "
                                "RGB+mask+orientation raster fwd+bwd + L1/DSSIM/mask/orientation/smoothness losses + Adam",
                    "gaussians": P, "views": len(cams), "width": W, "height": H, "parallelism": f"view-parallel x{world}",
+                   "pipeline_state": pipeline_info,
                    "views_per_optimizer_step": views_per_step,
                    "mean_num_rendered": meanR, "mean_sum_tile_list_len": meanL,
                    "mean_num_rendered_after_tile_cull": meanR_culled, "mean_sum_tile_list_len_after_tile_cull": meanL_culled,
@@ -690,6 +735,8 @@ def main():
     result.update(cpu_result)
     if c3_leg is not None:
         result["roofline_c3"] = c3_leg
+    if pipeline_legs is not None:
+        result["pipeline_states"] = pipeline_legs
     print(json.dumps(result))
     if world > 1:
         dist.destroy_process_group()

@@ -131,10 +131,11 @@ def backward(inp, fwd, dL_dpix, f64=False):
     feats = n["colors_precomp"] if n["colors_precomp"] is not None else fwd["rgb"]
     acc = np.zeros((P, 9), np.float64)
     fragile = np.zeros(P, np.uint8)   # Gaussians with a near-threshold (pixel, entry) decision (raster_oracle.c)
+    touched = np.zeros(P, np.uint8)   # Gaussians blended at a pixel that holds such a decision (its transmittance chain moves)
     getattr(L, "hgs_oracle_render_backward" + sfx)(C.c_int(P), C.c_int(W), C.c_int(H), _p(fwd["ranges"]),
                                                    _p(fwd["point_list"]), _p(n["bg"]), _p(fwd["means2D"]),
                                                    _p(fwd["conic_opacity"]), _p(feats), _p(fwd["final_T"]),
-                                                   _p(fwd["n_contrib"]), _p(dpix), _p(acc), _p(fragile))
+                                                   _p(fwd["n_contrib"]), _p(dpix), _p(acc), _p(fragile), _p(touched))
     g = {
         "dL_dmeans2D": np.zeros((P, 3), dt), "dL_dconic": np.zeros((P, 4), dt), "dL_dopacity": np.zeros((P, 1), dt),
         "dL_dcolors": np.zeros((P, 3), dt), "dL_dmeans3D": np.zeros((P, 3), dt), "dL_dcov3D": np.zeros((P, 6), dt),
@@ -155,6 +156,7 @@ def backward(inp, fwd, dL_dpix, f64=False):
         _p(g["dL_dcolors"]), _p(g["dL_dcov3D"]), _p(g["dL_dsh"]), _p(g["dL_dscales"]), _p(g["dL_drotations"]))
     g["acc"] = acc
     g["fragile"] = fragile.astype(bool)
+    g["touched"] = touched.astype(bool) | g["fragile"]
     return g
 
 

@@ -428,7 +428,8 @@ void SYM(hgs_oracle_render_backward)(int P, int W, int H, const uint32_t* ranges
                                      const real* bg, const real* means2D, const real* conic_opacity, const real* colors,
                                      const real* final_Ts, const uint32_t* n_contrib, const real* dL_dpixels,
                                      double* acc /* [P][9], zeroed here */,
-                                     uint8_t* fragile /* [P] or NULL: see below */) {
+                                     uint8_t* fragile /* [P] or NULL: see below */,
+                                     uint8_t* touched /* [P] or NULL: see below */) {
   const int gx = (W + BLOCK_X - 1) / BLOCK_X, gy = (H + BLOCK_Y - 1) / BLOCK_Y;
   memset(acc, 0, (size_t)P * 9 * sizeof(double));
   const real ddelx_dx = (real)(0.5 * W), ddely_dy = (real)(0.5 * H);
@@ -449,6 +450,7 @@ void SYM(hgs_oracle_render_backward)(int P, int W, int H, const uint32_t* ranges
         real accum_rec[NCH] = {0, 0, 0}, dL_dpixel[NCH], last_color[NCH] = {0, 0, 0};
         for (int ch = 0; ch < NCH; ch++) dL_dpixel[ch] = dL_dpixels[(size_t)ch * H * W + pix_id];
         real last_alpha = 0;
+        int pixel_fragile = 0;
         for (uint32_t k = 0; k < r1 - r0; k++) {
           uint32_t id = point_list[r1 - k - 1];
           contributor--;
@@ -457,7 +459,7 @@ void SYM(hgs_oracle_render_backward)(int P, int W, int H, const uint32_t* ranges
           const real* co = conic_opacity + 4 * (size_t)id;
           real power = (real)-0.5 * (co[0] * dx * dx + co[2] * dy * dy) - co[1] * dx * dy;
           if (power > 0) {
-            if (fragile && (double)power < 1e-5) fragile[id] = 1;
+            if (fragile && (double)power < 1e-5) { fragile[id] = 1; pixel_fragile = 1; }
             continue;
           }
           real G = R_EXP(power);
@@ -467,7 +469,7 @@ void SYM(hgs_oracle_render_backward)(int P, int W, int H, const uint32_t* ranges
            * implementation whose exp differs by an ulp may branch the other way there (the CUDA reference against
            * any CPU code has the same property).  Tests bound the number of such Gaussians and hold every other
            * one to the tolerance. */
-          if (fragile && (fabs((double)alpha * 255.0 - 1.0) < 1e-4 || fabs((double)power) < 1e-5)) fragile[id] = 1;
+          if (fragile && (fabs((double)alpha * 255.0 - 1.0) < 1e-4 || fabs((double)power) < 1e-5)) { fragile[id] = 1; pixel_fragile = 1; }
           if (alpha < (real)1.0 / (real)255.0) continue;
           T = T / ((real)1.0 - alpha);
           real dchannel_dcolor = alpha * T;
@@ -507,6 +509,25 @@ void SYM(hgs_oracle_render_backward)(int P, int W, int H, const uint32_t* ranges
           a[4] += v4;
 #pragma omp atomic
           a[5] += v5;
+        }
+        /* Checker aid, second part: a decision that an implementation takes the other way changes this PIXEL's transmittance
+         * chain by that entry's alpha (~1/255) and the colour behind every nearer entry -- i.e. the terms of EVERY Gaussian the
+         * pixel blends by up to ~0.4 % of what the pixel contributes to them, not only the fragile one's.  Those Gaussians are
+         * enumerated too (`touched`): the pixel's walk is repeated and every blended entry marked. */
+        if (touched && pixel_fragile) {
+          uint32_t c2 = r1 - r0;
+          for (uint32_t k = 0; k < r1 - r0; k++) {
+            uint32_t id = point_list[r1 - k - 1];
+            c2--;
+            if (c2 >= last_contributor) continue;
+            real dx = means2D[2 * id] - pixf[0], dy = means2D[2 * id + 1] - pixf[1];
+            const real* co = conic_opacity + 4 * (size_t)id;
+            real power = (real)-0.5 * (co[0] * dx * dx + co[2] * dy * dy) - co[1] * dx * dy;
+            if (power > 0) continue;
+            real alpha = rmin((real)0.99, co[3] * R_EXP(power));
+            if (alpha < (real)1.0 / (real)255.0) continue;
+            touched[id] = 1;
+          }
         }
       }
   }

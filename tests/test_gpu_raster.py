@@ -679,12 +679,14 @@ def _oracle_backward7(refs, state, dplanes):
             out = {n: g[n].astype(np.float64) for n in GRAD_KEYS}
             out["dL_dmeans2D_rgb"] = g["dL_dmeans2D"].astype(np.float64)
             out["fragile"] = g["fragile"].copy()
+            out["touched"] = g["touched"].copy()
             P = g["fragile"].shape[0]
             out["dL_dextra"] = np.zeros((P, 4))
         else:
             for n in ("dL_dmeans2D", "dL_dconic", "dL_dopacity", "dL_dmeans3D", "dL_dcov3D", "dL_dscales", "dL_drotations"):
                 out[n] = out[n] + g[n]
             out["fragile"] |= g["fragile"]
+            out["touched"] |= g["touched"]
             if k == 1:
                 out["dL_dextra"][:, 0] = g["dL_dcolors"][:, 0]
             else:
@@ -708,14 +710,24 @@ def _backward7(s, extra, fw, bg7, dplanes):
     return {n: t.cpu().numpy() for n, t in zip(names, out)}
 
 
+TOUCHED_MAX_OF_SCALE = 4e-3   # one decision taken the other way moves what its pixel contributes to the Gaussians it blends by <= alpha ~ 1/255
+
+
 def _grad_check7(g, gref, fwd_ref, report_name=None):
-    """_grad_check's bar (1e-4 of the tensor's scale on every element of a non-fragile Gaussian, the element-wise bound on all
-    but 0.2 %) for the tensors the 7-channel backward returns: the summed geometry gradients, dL_dcolors / dL_dsh of the RGB
-    pass, dL_dextra of the other two and the RGB-only screen-space gradient."""
-    fragile = gref["fragile"]
+    """_grad_check's bar for the tensors the 7-channel backward returns (the summed geometry gradients, dL_dcolors / dL_dsh of the
+    RGB pass, dL_dextra of the other two, the RGB-only screen-space gradient), with the exemption enumerated one step further:
+      every element of a Gaussian that shares NO pixel with a near-threshold decision: 1e-4 of the tensor's scale, and the
+          element-wise bound 1e-4 x max(|ref|, 1e-2 scale) on all but 0.2 %;
+      `touched` Gaussians (oracle/raster_oracle.c: blended at a pixel where some entry's alpha lies within 1e-4 of 1/255 -- if the
+          GPU's v_exp_f32 takes that decision the other way, the transmittance in front of / the colour behind every entry of
+          that pixel moves by that alpha): 4e-3 of scale;
+      `fragile` Gaussians (the ones whose own decision it is): 2e-2 of scale.
+    Both sets are bounded in number by what the geometry predicts (_expected_fragile; touched <= fragile x the longest walk)."""
+    fragile, touched = gref["fragile"], gref["touched"]
     P = fragile.shape[0]
     expected = _expected_fragile(fwd_ref)
     assert int(fragile.sum()) <= 3.0 * expected + 8
+    assert int(touched.sum()) <= int(fragile.sum()) * max(1, int(fwd_ref["n_contrib"].max()))
     report = {}
     for k in ("dL_dmeans2D_rgb", "dL_dcolors", "dL_dextra", "dL_dopacity", "dL_dmeans3D", "dL_dcov3D", "dL_dsh", "dL_dscales",
               "dL_drotations"):
@@ -728,14 +740,17 @@ def _grad_check7(g, gref, fwd_ref, report_name=None):
             assert np.abs(a).max() == 0.0, k
             continue
         err = np.abs(a - b)
-        solid = err[~fragile]
+        solid = err[~touched]
         worst = float(solid.max()) / scale
-        frac = float((solid > 1e-4 * np.maximum(np.abs(b[~fragile]), 1e-2 * scale)).mean())
-        report[k] = (worst, frac, int(fragile.sum()))
+        frac = float((solid > 1e-4 * np.maximum(np.abs(b[~touched]), 1e-2 * scale)).mean())
+        near = touched & ~fragile
+        worst_touched = float(err[near].max()) / scale if near.any() else 0.0
+        worst_fragile = float(err[fragile].max()) / scale if fragile.any() else 0.0
+        report[k] = (worst, frac, int(fragile.sum()), int(touched.sum()), worst_touched, worst_fragile)
         assert worst <= GRAD_MAX_OF_SCALE, (k, report[k])
         assert frac <= GRAD_NOISE_FRAC, (k, report[k])
-        if fragile.any():
-            assert float(err[fragile].max()) / scale <= FRAGILE_MAX_OF_SCALE, (k, float(err[fragile].max()) / scale)
+        assert worst_touched <= TOUCHED_MAX_OF_SCALE, (k, report[k])
+        assert worst_fragile <= FRAGILE_MAX_OF_SCALE, (k, report[k])
     return report
 
 
@@ -775,20 +790,20 @@ def test_seven_channel_pass_against_oracle(workload):
         gref = _oracle_backward7(refs, fw_ref_lists, dplanes)
         g = _backward7(s, extra, fw, None if tag == "black" else bg7, dplanes)
         report = _grad_check7(g, gref, ref0)
-        print("SEVEN", workload, tag, f"image {worst_img:.1e}", {k: (f"{v[0]:.1e}", f"{v[1]:.1e}", v[2]) for k, v in report.items()})
+        print("SEVEN", workload, tag, f"image {worst_img:.1e}", {k: (f"{v[0]:.1e}", f"{v[1]:.1e}", v[2], v[3], f"{v[4]:.1e}", f"{v[5]:.1e}") for k, v in report.items()})
         if os.environ.get("HGS_GRAD_REPORT_DIR"):
             import json
             gg = dict(g)
             gg["dL_dmeans2D"] = None
             pct = {}
-            fragile = gref["fragile"]
+            fragile, touched = gref["fragile"], gref["touched"]
             for k in report:
                 b = gref[k].astype(np.float64).reshape(fragile.shape[0], -1)
                 a = g[k].astype(np.float64).reshape(b.shape)
                 scale = float(np.abs(b).max())
                 nz = np.abs(b).max(axis=1) > 0
                 row = {}
-                for t2, sel in (("solid", nz & ~fragile), ("all", nz)):
+                for t2, sel in (("solid", nz & ~touched), ("touched_not_fragile", nz & touched & ~fragile), ("all", nz)):
                     if sel.any():
                         err = np.abs(a[sel] - b[sel]).reshape(-1)
                         rel = err / np.maximum(np.abs(b[sel]).reshape(-1), 1e-3 * scale)
@@ -797,7 +812,7 @@ def test_seven_channel_pass_against_oracle(workload):
                 pct[k] = row
             with open(os.path.join(os.environ["HGS_GRAD_REPORT_DIR"], f"grad_parity7_{workload}_{tag}.json"), "w") as fh:
                 json.dump({"workload": workload, "pass": "7-channel, " + tag, "fragile_gaussians": int(fragile.sum()),
-                           "gaussians": int(fragile.shape[0]), "image_max_err_outside_flips": worst_img,
+                           "touched_gaussians": int(touched.sum()), "gaussians": int(fragile.shape[0]), "image_max_err_outside_flips": worst_img,
                            "percentiles_p50_p99_p99.9_max": pct}, fh, indent=1)
         del fw, fw_ref_lists
         torch.cuda.empty_cache()
@@ -879,12 +894,12 @@ def test_seven_channel_parameter_backward_against_oracle(workload):
         names = ["endpoints", "width", "opacity_raw", "mask_raw"]
         pr = pairs.cpu().numpy()
         frag_e = np.zeros(E, bool)
-        frag_e[pr[gref["fragile"]].reshape(-1)] = True
-        frag_rows = [frag_e, gref["fragile"], gref["fragile"], gref["fragile"]]
+        frag_e[pr[gref["touched"]].reshape(-1)] = True
+        frag_rows = [frag_e, gref["touched"], gref["touched"], gref["touched"]]
     else:
         got_params = [g3, d_s, d_r, d_o, d_m]
         names = ["xyz", "scaling_raw", "rotation_raw", "opacity_raw", "mask_raw"]
-        frag_rows = [gref["fragile"]] * 5
+        frag_rows = [gref["touched"]] * 5
     torch.cuda.synchronize()
     report = {}
     for name, got, ref, frag in zip(names, got_params, ref_params, frag_rows):
@@ -907,6 +922,6 @@ def test_seven_channel_parameter_backward_against_oracle(workload):
     np.testing.assert_array_equal(max_radii.cpu().numpy(), np.where(vis, refs[0][1]["radii"], 0).astype(np.float32))
     want = np.where(vis, np.linalg.norm(gref["dL_dmeans2D_rgb"][:, :2], axis=1), 0.0)
     got_acc = accum.cpu().numpy().reshape(-1).astype(np.float64)
-    solid = ~gref["fragile"]
+    solid = ~gref["touched"]
     assert float(np.abs(got_acc - want)[solid].max()) <= 1e-4 * float(want.max())
     print("SEVEN_PARAMS", workload, {k: tuple(f"{x:.1e}" for x in v[:2]) for k, v in report.items()})

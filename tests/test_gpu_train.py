@@ -1700,3 +1700,73 @@ def test_device_storage_sort_equals_the_host_form():
     model.compute_strands_info()
     for a in ("offsets", "rows", "id_to_strand_id", "strand_endpoint_id_to_complementary"):
         assert np.array_equal(np.asarray(getattr(kept, a)), np.asarray(getattr(model.strands_info, a))), a
+
+
+def test_cloud_densification_selects_the_same_rows_as_the_three_pass_form():
+    """The Stage-I analogue of test_densification_inputs_of_the_fused_pass_equal_the_three_pass_form:
+    through three densification events of a Stage-I run the op-by-op three-pass form -- render() and ITS screen-space gradient,
+    loss_function with its two more passes, update_densification_stats (reference train.py:146-171, scene/gaussian_model.py:
+    675-682) -- accumulates its statistics beside FusedCloudStep's (RGB-only moments of the single 7-channel pass, in the lanes of
+    hgs_backward_multi_params) on the same parameters; in front of every event both select the same rows for densify_and_clone
+    and densify_and_split (scene/gaussian_model.py:298-322; rows within 1e-5 of the threshold may fall either way).  The event
+    itself then runs from the fused statistics and its counts are logged (training_step(event_log=))."""
+    from arguments import OptimizationParams
+    from gaussian_renderer import render
+    from hgs_runtime.strand_step import ViewTable, fused_step_for
+    from loss.losses import loss_function
+    from synthetic import build_capture, stage1_cloud
+    from train import ViewSampler, training_step
+    from utils.general import safe_state
+    safe_state(True)
+    gt_pts, gt_model, cams, extent = build_capture("tiny_capture", device="cuda")
+    model = stage1_cloud(gt_pts, gt_model, extent, device="cuda")
+    opt = OptimizationParams()
+    opt.densify_from_iter = 100
+    model.training_setup(opt)
+    bg = torch.zeros(3, device="cuda")
+    stats = lambda: (model.max_radii2D, model.xyz_gradient_accum, model.denom)
+    sampler = ViewSampler(cams, seed=11)
+    events, selected = [], 0
+    fused = fused_step_for(model, ViewTable(cams), opt, bg)
+    acc3 = [torch.zeros_like(t) for t in stats()]
+    for it in range(1, 401):
+        cam = sampler.next()
+        event = it > opt.densify_from_iter and it % opt.densification_interval == 0
+        if event:       # both forms have seen iterations .. it - 1 (this iteration adds one more view to both before it densifies)
+            with torch.no_grad():
+                thr, dense = float(opt.densify_grad_threshold), float(opt.percent_dense) * extent
+                big = torch.max(model.get_scaling, dim=1).values > dense
+                sel = []
+                for acc, den in ((model.xyz_gradient_accum, model.denom), (acc3[1], acc3[2])):
+                    g = acc / den
+                    g[g.isnan()] = 0.0
+                    hot = torch.norm(g, dim=-1) >= thr
+                    sel.append((hot & ~big, hot & big, g.reshape(-1)))
+                for name, a, b in zip(("max_radii2D", "xyz_gradient_accum", "denom"), stats(), acc3):
+                    assert float((a - b).abs().max()) <= 1e-5 * max(float(b.abs().max()), 1e-30), (it, name)
+                near = (sel[1][2] - thr).abs() <= 1e-5 * thr
+                differ = ((sel[0][0] != sel[1][0]) | (sel[0][1] != sel[1][1])) & ~near
+                assert int(differ.sum()) == 0, (it, int(differ.sum()))
+                selected += int(sel[1][0].sum()) + int(sel[1][1].sum())
+        model.optimizer.zero_grad(set_to_none=True)
+        pkg = render(cam, model, bg)
+        loss, _ = loss_function(model, pkg["render"], cam, opt)
+        loss.backward()
+        with torch.no_grad():
+            mine = [t.clone() for t in stats()]
+            for t, a in zip(stats(), acc3):
+                t.copy_(a)
+            model.update_densification_stats(pkg["viewspace_points"], pkg["radii"], pkg["visibility_filter"])
+            for t, a, f in zip(stats(), acc3, mine):
+                a.copy_(t)
+                t.copy_(f)
+        model.optimizer.zero_grad(set_to_none=True)
+        n_before = model.get_xyz.shape[0]
+        training_step(model, cam, opt, bg, it, extent=extent, fused=fused, event_log=events)
+        if event:
+            assert events and events[-1]["iteration"] == it and events[-1]["primitives_before"] == n_before
+            assert events[-1]["primitives_after"] == model.get_xyz.shape[0]
+            assert {"clone", "split", "prune_low_opacity", "prune_total"} <= set(events[-1])
+            fused = fused_step_for(model, ViewTable(cams), opt, bg)      # (new tensors behind the model)
+            acc3 = [torch.zeros_like(t) for t in stats()]
+    assert [e["iteration"] for e in events] == [200, 300, 400] and selected > 0

@@ -13,4 +13,6 @@ for set in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_LDS SQ_W
   rocprofv3 --pmc $set --kernel-trace --output-format csv -d gpurun_out/pmc_$tag -- python3 tools/raster_only.py $WL 8 $EXTRA > /dev/null 2>&1
 done
 # (with train=N the process also holds the training iterations: only the 8 measured passes -- the last dispatches -- are averaged)
-case "$EXTRA" in train=*) python3 tools/pmc_aggregate.py gpurun_out/pmc_summary.json 8;; *) python3 tools/pmc_aggregate.py gpurun_out/pmc_summary.json;; esac
+LAST="$EXTRA"
+case "$WL" in stage*) LAST=train=stage;; esac     # (a pipeline state: the Stage-I loop that builds it runs in the same process)
+case "$LAST" in train=*) python3 tools/pmc_aggregate.py gpurun_out/pmc_summary.json 8;; *) python3 tools/pmc_aggregate.py gpurun_out/pmc_summary.json;; esac

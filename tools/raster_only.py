@@ -1,18 +1,24 @@
 """Runs only the single-pass rasterizer forward+backward on a workload (for rocprofv3 --pmc passes):
   python tools/raster_only.py [workload] [passes] [culled | train=N]
-train=N: on the state N iterations of the FULL loop leave (densification, merging, opacity reset: bench.py's `trained_state`)."""
+train=N: on the state N iterations of the FULL loop leave (densification, merging, opacity reset: bench.py's `trained_state`).
+workload stage1_1080p / stage3_merged (synthetic.PIPELINE_STATES): the states bench.py's `pipeline_states` legs time (the Stage-I
+loop that leads to them runs in this process first: average the LAST dispatches only, tools/pmc_aggregate.py <out> <passes>)."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "hair-gs_amd")]
 import torch
 from gaussian_renderer import render_multi
-from synthetic import build_workload
+from synthetic import PIPELINE_STATES, build_pipeline_state, build_workload
 wl = sys.argv[1] if len(sys.argv) > 1 else "north_star"
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 10
 n_train = int(sys.argv[3].split("=")[1]) if len(sys.argv) > 3 and sys.argv[3].startswith("train=") else 0
 # (train=N: the workload's own views and the seeds of bench.py's trained_state leg, so that the state is the one that leg times
 # as closely as a run-to-run different trajectory allows)
-model, cams, extent = build_workload(wl, device="cuda", with_targets=n_train > 0, n_views=None if n_train else 4)
+if wl in PIPELINE_STATES:
+    model, cams, extent, info = build_pipeline_state(wl, device="cuda")
+    print(info)
+else:
+    model, cams, extent = build_workload(wl, device="cuda", with_targets=n_train > 0, n_views=None if n_train else 4)
 if n_train:
     from arguments import OptimizationParams
     from train import training
@@ -35,7 +41,11 @@ for i in range(n):
     pkg = render_multi(cam, model, bg, extra, splits=(1, 3), black_background=True)   # bg is the zeros made above
     loss = (pkg["render"] * w3).sum() + (pkg["extra"][0] * w1).sum() + (pkg["extra"][1] * wo).sum()
     loss.backward()
-    for p in (model._endpoints, model._features_dc, model._opacity, model._mask, model._width):
-        p.grad = None
+    for g_ in model.optimizer.param_groups if model.optimizer is not None else []:
+        for p in g_["params"]:
+            p.grad = None
+    for name in ("_endpoints", "_features_dc", "_opacity", "_mask", "_width", "_xyz", "_scaling", "_rotation"):
+        if hasattr(model, name):
+            getattr(model, name).grad = None
 torch.cuda.synchronize()
 print("done")

@@ -20,8 +20,15 @@ accumulated from the RGB-only moments of the fused 7-channel pass -- is accumula
 three-pass op-by-op form (the reference's structure: RGB render + its own screen-space gradient) evaluated on the SAME
 parameters every iteration, and compared.
 
-  python tools/three_stage.py [strands=500] [iters_stage1=5000] [iters_stage3=5000] [views=16] [W=800] [H=800] > profiles/r05_three_stage.json
+Round 6: `events` of every stage = the operators' own counts per event (clone / split / merge_collapsed / prune_* / merge, the
+reference's TrainingInfo.densification_info; train.training(event_log=)), and for three Stage-I events `stage_I_event_checks`:
+the op-by-op three-pass form accumulates its statistics beside the fused iteration over the 100 iterations in front of the event
+and selects the same rows for clone and split.
+
+  python tools/three_stage.py [strands=500] [iters_stage1=5000] [iters_stage3=5000] [views=16] [W=800] [H=800] [curly=0] [lean=0] > profiles/r05_three_stage.json
   (profiles/r05_three_stage_1080p.json: 2000 5000 5000 32 1920 1080 -- 200 k ground-truth segments, BASELINE config 3's frame and views)
+  (profiles/r06_three_stage_c4.json: 10000 5000 5000 48 1920 1080 1 1 -- BASELINE config 4 as written: curly strands, 1 M ground-truth
+   segments, 48 views at 1080p; lean=1 leaves out the Stage-III run without operators and the one-by-one events)
 """
 import faulthandler
 import json
@@ -39,7 +46,7 @@ import torch  # noqa: E402
 import hgs_runtime as rt  # noqa: E402
 from arguments import OptimizationParams  # noqa: E402
 from gaussian_renderer import render  # noqa: E402
-from synthetic import attach_targets, cameras_extent, make_cameras, make_strand_model, strand_polylines  # noqa: E402
+from synthetic import build_capture, stage1_cloud  # noqa: E402
 from train import training  # noqa: E402
 from utils.general import safe_state  # noqa: E402
 
@@ -50,6 +57,8 @@ N_SEG = 100
 VIEWS = int(sys.argv[4]) if len(sys.argv) > 4 else 16
 W = int(sys.argv[5]) if len(sys.argv) > 5 else 800
 H = int(sys.argv[6]) if len(sys.argv) > 6 else 800
+CURLY = bool(int(sys.argv[7])) if len(sys.argv) > 7 else False
+LEAN = bool(int(sys.argv[8])) if len(sys.argv) > 8 else False
 rt.lib()
 _real_stdout, sys.stdout = sys.stdout, sys.stderr      # (the model classes print progress lines: stdout is the JSON alone)
 safe_state(True)
@@ -75,22 +84,90 @@ def strand_metrics(model, gt_pts):
     return {k: [float(x) for x in v] for k, v in res.items()}, [str(l) for l in labels]
 
 
-def run_stage(model, cams, opt, extent, n_iters, name):
+def run_stage(model, cams, opt, extent, n_iters, name, events=None, pause_at=()):
+    """`events`: list for the operators' counts (training(event_log=)); `pause_at`: iterations (multiples of 100, inside the
+    densification schedule) whose densification inputs are checked against the three-pass form: the stage stops 100 iterations in
+    front of each, cloud_event_check() runs those 100 itself."""
     traj, done, t_total = [], 0, 0.0
+    checks = []
     traj.append({"iteration": 0, "psnr_db": psnr_all(model, cams), "primitives": int(model.get_xyz.shape[0]), "seconds": 0.0})
     log(name, traj[-1])
     while done < n_iters:
-        n = min(500, n_iters - done)
+        nxt = (done // 500 + 1) * 500
+        stop = min([nxt, n_iters] + [p - 100 for p in pause_at if p - 100 > done])
+        n = stop - done
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        training(model, cams, opt, iterations=n, extent=extent, start_iteration=done)
+        training(model, cams, opt, iterations=n, extent=extent, start_iteration=done, event_log=events)
         torch.cuda.synchronize()
         t_total += time.perf_counter() - t0
         done += n
-        traj.append({"iteration": done, "psnr_db": psnr_all(model, cams), "primitives": int(model.get_xyz.shape[0]),
-                     "seconds": t_total})
-        log(name, traj[-1])
+        if done + 100 in pause_at:
+            t0 = time.perf_counter()
+            checks.append(cloud_event_check(model, cams, opt, extent, done, events))
+            torch.cuda.synchronize()
+            t_total += time.perf_counter() - t0       # (the check's 100 iterations are iterations of the stage, run eagerly twice over)
+            done += 100
+            log(name, "event check", checks[-1])
+        if done % 500 == 0 or done == n_iters:
+            traj.append({"iteration": done, "psnr_db": psnr_all(model, cams), "primitives": int(model.get_xyz.shape[0]),
+                         "seconds": t_total})
+            log(name, traj[-1])
+    if pause_at:
+        return traj, t_total, checks
     return traj, t_total
+
+
+def cloud_event_check(model, cams, opt, extent, done, events):
+    """Iterations done + 1 .. done + 100 of Stage I, the last of which densifies: every iteration the op-by-op three-pass form
+    (render() + loss_function + update_densification_stats: the reference's structure, train.py:146-171) is evaluated on the SAME
+    parameters beside the fused iteration (whose Adam step alone is applied) and accumulates its own statistics; in front of the
+    event both statistics select rows for clone and split exactly as densify_and_clone / densify_and_split do
+    (scene/gaussian_model.py:298-322): the selections are compared row by row."""
+    from hgs_runtime.strand_step import ViewTable, fused_step_for
+    from loss.losses import loss_function
+    from train import ViewSampler, training_step
+    views = ViewTable(cams)
+    fused = fused_step_for(model, views, opt, bg)
+    stats = lambda: (model.max_radii2D, model.xyz_gradient_accum, model.denom)
+    acc3 = [t.clone() for t in stats()]                # (both forms start from what the stage has accumulated since the last event)
+    sampler = ViewSampler(cams, seed=1000 + done)
+    out = None
+    for it in range(done + 1, done + 101):
+        cam = sampler.next()
+        if it == done + 100:      # the event's inputs: both forms have seen iterations .. it - 1 (this one adds one more view to both)
+            with torch.no_grad():
+                thr, dense = float(opt.densify_grad_threshold), float(opt.percent_dense) * extent
+                big = torch.max(model.get_scaling, dim=1).values > dense
+                sel = {}
+                for tag, (acc, den) in (("fused", (model.xyz_gradient_accum, model.denom)), ("three_pass", (acc3[1], acc3[2]))):
+                    g = acc / den
+                    g[g.isnan()] = 0.0
+                    hot = torch.norm(g, dim=-1) >= thr
+                    sel[tag] = (hot & ~big, hot & big, g.reshape(-1))
+                near = (sel["three_pass"][2] - thr).abs() <= 1e-5 * thr
+                out = {"event_iteration": done + 100, "gaussians": int(model.get_xyz.shape[0]),
+                       "clone_rows": {k: int(v[0].sum()) for k, v in sel.items()}, "split_rows": {k: int(v[1].sum()) for k, v in sel.items()},
+                       "rows_selected_differently": int(((sel["fused"][0] != sel["three_pass"][0]) | (sel["fused"][1] != sel["three_pass"][1])).sum()),
+                       "rows_selected_differently_outside_1e-5_of_the_threshold":
+                           int((((sel["fused"][0] != sel["three_pass"][0]) | (sel["fused"][1] != sel["three_pass"][1])) & ~near).sum()),
+                       "statistics_identical": bool(all(torch.equal(a, b) for a, b in zip(stats(), acc3))),
+                       "statistics_max_rel_diff": max(float((a - b).abs().max() / b.abs().max().clamp(min=1e-30)) for a, b in zip(stats(), acc3))}
+        model.optimizer.zero_grad(set_to_none=True)
+        pkg = render(cam, model, bg)
+        loss, _ = loss_function(model, pkg["render"], cam, opt)
+        loss.backward()
+        with torch.no_grad():
+            mine = [t.clone() for t in stats()]
+            for t, a in zip(stats(), acc3):
+                t.copy_(a)
+            model.update_densification_stats(pkg["viewspace_points"], pkg["radii"], pkg["visibility_filter"])
+            for t, a, f in zip(stats(), acc3, mine):
+                a.copy_(t)
+                t.copy_(f)
+        model.optimizer.zero_grad(set_to_none=True)
+        training_step(model, cam, opt, bg, it, extent=extent, fused=fused, event_log=events)
+    return out
 
 
 def densify_inputs_check(model, cams, opt, extent, iters=100):
@@ -148,39 +225,30 @@ def densify_inputs_check(model, cams, opt, extent, iters=100):
 
 
 # ---- ground truth and targets
-gt_pts = strand_polylines(S, N_SEG, seed=0)
-cams = make_cameras(VIEWS, W, H, device=dev)
-extent = cameras_extent(cams)
-gt_model = make_strand_model(S, N_SEG, seed=0, device=dev, spatial_lr_scale=extent)
-attach_targets(cams, gt_model, seed=0, perturb=0.0, consistent=True)
-out = {"ground_truth": {"strands": S, "segments": S * N_SEG, "views": VIEWS, "width": W, "height": H,
+gt_pts, gt_model, cams, extent = build_capture((S, CURLY, VIEWS, W, H), device=dev, seed=0, n_seg=N_SEG)
+out = {"ground_truth": {"strands": S, "segments": S * N_SEG, "views": VIEWS, "width": W, "height": H, "curly": CURLY,
                         "psnr_db_of_the_ground_truth_model": psnr_all(gt_model, cams)}}
 
 from merge import merge_rounds  # noqa: E402
-from scene.gaussian_model import GaussianModel  # noqa: E402
-from utils.graphics import BasicPointCloud  # noqa: E402
-from utils.sh import SH2RGB  # noqa: E402
 
 
 def stages_one_and_two(record):
     """Stage I + II."""
     safe_state(True)                      # (torch / numpy / random seeds: densify_and_split samples new centres)
-    rng = np.random.default_rng(1)
-    mid = 0.5 * (gt_pts[:, 1:] + gt_pts[:, :-1]).reshape(-1, 3)
-    pts = (mid + rng.normal(size=mid.shape) * 0.002).astype(np.float32)
-    with torch.no_grad():
-        gt_rgb = SH2RGB(gt_model._features_dc.detach()[:, 0]).clamp(0, 1).cpu().numpy()
-    cloud = GaussianModel(sh_degree=0, spatial_lr_scale=extent, device=dev)
-    cloud.create_from_pcd(BasicPointCloud(points=pts, colors=np.clip(gt_rgb + rng.normal(size=gt_rgb.shape) * 0.1, 0, 1).astype(np.float32),
-                                          normals=np.zeros_like(pts)))
-    cloud.ref_strand_root = gt_pts[:, 0].astype(np.float64)
+    cloud = stage1_cloud(gt_pts, gt_model, extent, device=dev)
     opt1 = OptimizationParams()
     opt1.iterations = N1
     opt1._finalise()
     cloud.training_setup(opt1)
     if record:
-        traj1, t1 = run_stage(cloud, cams, opt1, extent, N1, "stage I")
-        out["stage_I"] = {"iterations": N1, "seconds": t1, "its_per_sec": N1 / t1, "trajectory": traj1}
+        ev1 = []
+        # events 6, 10 and 20 of the schedule (densification from iteration 500, every 100: iterations 1100, 1500, 2500)
+        first = (int(opt1.densify_from_iter) // 100 + 1) * 100
+        pause = tuple(p for p in (first + 500, first + 900, first + 1900) if p <= min(N1, int(opt1.densify_until_iter) - 1))
+        traj1, t1, checks = run_stage(cloud, cams, opt1, extent, N1, "stage I", events=ev1, pause_at=pause) if pause else \
+            (run_stage(cloud, cams, opt1, extent, N1, "stage I", events=ev1) + ([],))
+        out["stage_I"] = {"iterations": N1, "seconds": t1, "its_per_sec": N1 / t1, "trajectory": traj1, "events": ev1,
+                          "stage_I_event_checks": checks}
     else:
         training(cloud, cams, opt1, iterations=N1, extent=extent, start_iteration=0)
     torch.cuda.synchronize()
@@ -214,13 +282,23 @@ fresh_copy = lambda: copy.deepcopy(stage2_model)
 hair = fresh_copy()
 opt3 = stage_three_options(True)
 hair.training_setup(opt3)
-traj3, t3 = run_stage(hair, cams, opt3, extent, N3, "stage III")
+ev3 = []
+traj3, t3 = run_stage(hair, cams, opt3, extent, N3, "stage III", events=ev3)
 m3, _ = strand_metrics(hair, gt_pts)
-out["stage_III"] = {"iterations": N3, "seconds": t3, "its_per_sec": N3 / t3, "trajectory": traj3, "metrics": m3,
+out["stage_III"] = {"iterations": N3, "seconds": t3, "its_per_sec": N3 / t3, "trajectory": traj3, "metrics": m3, "events": ev3,
                     "strands": int(hair.strands_info.n_strands) if hair.strands_info is not None else None,
                     "rollbacks": getattr(training, "last_rollbacks", None)}
 del hair
 torch.cuda.empty_cache()
+
+if LEAN:
+    out["summary"] = {"psnr_db": {"stage_I_start": out["stage_I"]["trajectory"][0]["psnr_db"], "stage_I_end": out["stage_I"]["trajectory"][-1]["psnr_db"],
+                                  "after_merge": out["stage_II"]["psnr_db"], "stage_III_start": traj3[0]["psnr_db"],
+                                  "stage_III_best": max(p["psnr_db"] for p in traj3), "stage_III_end": traj3[-1]["psnr_db"]},
+                      "wall_seconds": {"stage_I": out["stage_I"]["seconds"], "stage_II": out["stage_II"]["seconds"], "stage_III": t3}}
+    sys.stdout = _real_stdout
+    print(json.dumps(out, indent=1))
+    sys.exit(0)
 
 # ---- the same Stage-II model again: the densification inputs, Stage III WITHOUT the operators, and the first events one by one
 hair = fresh_copy()
