@@ -328,8 +328,18 @@ int hgs_forward_render_multi(void* stream, int P, int W, int H, int R_capacity, 
 
 size_t hgs_binning_bytes_multi(int R) { HgsBinning b; return hgs_binning_carve(nullptr, (size_t)(R > 0 ? R : 0), b, nullptr, 7); }
 size_t hgs_backward_scratch_bytes_multi(int P, int R) {
-  (void)P;
-  return hgs_align_up((size_t)(R > 0 ? R : 0) * 16 * sizeof(float)) + HGS_ALIGN;
+  // R instance rows of 16 floats, then (256-byte aligned) row_reduce_kernel's per-Gaussian sums and per-run partial sums
+  const size_t p = (size_t)(P > 0 ? P : 0), r = (size_t)(R > 0 ? R : 0);
+  return hgs_align_up(r * 16 * sizeof(float)) + hgs_align_up(hgs_row_reduce_floats(p, r) * sizeof(float)) + HGS_ALIGN;
+}
+// hgs_set_row_reduce: whether the 7-channel backward sums the instance rows per Gaussian with a launch of its own
+// (row_reduce_kernel, balanced by rows): 1 yes, 0 no, -1 (default) where the pass's R is at least HGS_RR_AUTO_RATIO x P
+#define HGS_RR_AUTO_RATIO 8
+static int g_row_reduce_mode = -1;
+extern "C" int hgs_set_row_reduce(int mode) {
+  const int was = g_row_reduce_mode;
+  g_row_reduce_mode = mode > 0 ? 1 : (mode < 0 ? -1 : 0);
+  return was;
 }
 
 static int backward_impl(void* stream, int P, int D, int M, int R, int W, int H, const float* bg, const float* means3D,
@@ -357,11 +367,20 @@ static int backward_impl(void* stream, int P, int D, int M, int R, int W, int H,
   hgs_geom_carve((char*)geom_buf, (size_t)P, g, nullptr);
   hgs_image_carve((char*)image_buf, (size_t)W, (size_t)H, im, nullptr);
   float* inst_grad = nullptr;
+  // many instances per Gaussian (the states the three-stage workflow lives in: a Stage-I cloud at 1080p, the merged strand
+  // model): the per-Gaussian sums of the rows are taken by a launch that is balanced by rows (csrc/hgs_preprocess.hip)
+  const bool reduce_rows = n_extra && R > 0 && (g_row_reduce_mode > 0 || (g_row_reduce_mode < 0 && (long long)R >= (long long)HGS_RR_AUTO_RATIO * P));
   if (R > 0) {
     if (check_aligned(binning_buf, "binning_buf") || check_aligned(scratch, "scratch")) return 1;
     hgs_binning_carve((char*)binning_buf, (size_t)R, b, nullptr, channels);
     inst_grad = (float*)scratch;   // not cleared here: blend_bwd writes EVERY row (zeros past a tile's last needed entry)
-    if (hgs_launch_blend_bwd(s, W, H, R, channels, bg, im, b, dL_dpix_planes, inst_grad)) return 1;
+    if (hgs_launch_blend_bwd(s, W, H, R, channels, bg, im, b, dL_dpix_planes, inst_grad, reduce_rows ? 1 : 0)) return 1;
+  }
+  float *row_sums = nullptr, *row_partials = nullptr;
+  if (reduce_rows) {
+    row_sums = (float*)((char*)scratch + hgs_align_up((size_t)R * 16 * sizeof(float)));
+    row_partials = row_sums + (size_t)P * 16;
+    if (hgs_launch_row_reduce(s, P, R, inst_grad, im.status, row_sums, row_partials)) return 1;
   }
   HgsBwdArgs a;
   a.P = P; a.D = D; a.M = M; a.W = W; a.H = H;
@@ -372,6 +391,7 @@ static int backward_impl(void* stream, int P, int D, int M, int R, int W, int H,
   a.dL_dmeans3D = dL_dmeans3D; a.dL_dcov3D = dL_dcov3D; a.dL_dsh = dL_dsh; a.dL_dscales = dL_dscales;
   a.dL_drotations = dL_drotations;
   a.n_extra = n_extra; a.dL_dextra = dL_dextra;
+  a.row_sums = row_sums; a.row_partials = row_partials;
   return hgs_launch_preprocess_bwd(s, a, g, b, inst_grad, R, im.status, pb);
 }
 

@@ -525,7 +525,7 @@ template <int C> struct PixGrad { const float* plane[C]; };  // dL/d(output chan
 template <int C, bool BLACK>
 __global__ __launch_bounds__(HGS_BLOCK) __attribute__((amdgpu_waves_per_eu(HGS_BWD_WAVES))) void blend_bwd_kernel(HgsImage im, HgsBinning bn, int W, int H, int gx,
                                                               uint32_t Rcap, const float* __restrict__ bg,
-                                                              PixGrad<C> dL_dpix, float* __restrict__ inst_grad) {
+                                                              PixGrad<C> dL_dpix, float* __restrict__ inst_grad, int tag_rows) {
   constexpr int REC4 = Chan<C>::REC4, NPART = Chan<C>::NPART, NREG = Chan<C>::NREG, NV = 4 * NREG, ROW = Chan<C>::ROW;
   __shared__ float part[4][BWD_BATCH][NV];
   __shared__ float4 recs[2][BWD_BATCH * REC4];
@@ -549,7 +549,9 @@ __global__ __launch_bounds__(HGS_BLOCK) __attribute__((amdgpu_waves_per_eu(HGS_B
       for (uint32_t i = threadIdx.x; i < n4; i += HGS_BLOCK) {
         const uint32_t inst = first + i / (ROW / 4);
         const uint32_t slot = __float_as_uint(((const float*)packed)[(size_t)inst * 4 * REC4 + 8 + C]);
-        if (slot < Rcap) ((float4*)(inst_grad + (size_t)slot * ROW))[i % (ROW / 4)] = make_float4(0.f, 0.f, 0.f, 0.f);
+        // (C = 7: the row's last float names its Gaussian -- what row_reduce_kernel finds the segments of the scratch by)
+        const float tag = (C > 3 && tag_rows && i % (ROW / 4) == ROW / 4 - 1) ? ((const float*)packed)[(size_t)inst * 4 * REC4 + 6 + C] : 0.f;
+        if (slot < Rcap) ((float4*)(inst_grad + (size_t)slot * ROW))[i % (ROW / 4)] = make_float4(0.f, 0.f, 0.f, tag);
       }
     }
   }
@@ -711,6 +713,14 @@ __global__ __launch_bounds__(HGS_BLOCK) __attribute__((amdgpu_waves_per_eu(HGS_B
       if (slot < Rcap) inst_grad[(size_t)slot * ROW + k] = s;
       part[0][e][k] = 0.f; part[1][e][k] = 0.f; part[2][e][k] = 0.f; part[3][e][k] = 0.f;
     }
+    // (C = 7, when row_reduce_kernel will sum the rows: the row's sixteenth float names its Gaussian -- the record's own word --,
+    // which is how that kernel finds the segments of the scratch; the sums ignore it)
+    if (C > 3 && tag_rows) {
+      for (int e = threadIdx.x; e < cnt; e += HGS_BLOCK) {
+        const uint32_t slot = __float_as_uint(rf[e * 4 * REC4 + 8 + C]);
+        if (slot < Rcap) inst_grad[(size_t)slot * ROW + ROW - 1] = rf[e * 4 * REC4 + 6 + C];
+      }
+    }
     if (lo > seg_lo && threadIdx.x < BWD_BATCH * REC4) recs[cur ^ 1][threadIdx.x] = stage;
     __syncthreads();
   }
@@ -748,7 +758,7 @@ int hgs_launch_blend_fwd(hipStream_t s, int W, int H, int Rcap, int channels, co
 }
 
 int hgs_launch_blend_bwd(hipStream_t s, int W, int H, int Rcap, int channels, const float* bg, const HgsImage& im,
-                         const HgsBinning& b, const float* const* dL_dpix_planes, float* inst_grad) {
+                         const HgsBinning& b, const float* const* dL_dpix_planes, float* inst_grad, int tag_rows) {
   const int gx = (W + HGS_TILE - 1) / HGS_TILE, gy = (H + HGS_TILE - 1) / HGS_TILE;
   {
     HgsProfScope _prof(s, HGS_K_BLEND_BWD);
@@ -756,16 +766,16 @@ int hgs_launch_blend_bwd(hipStream_t s, int W, int H, int Rcap, int channels, co
       PixGrad<3> pg;
       for (int k = 0; k < 3; k++) pg.plane[k] = dL_dpix_planes[k];
       if (bg) hipLaunchKernelGGL((blend_bwd_kernel<3, false>), dim3(blend_grid(gx * gy, b)), dim3(HGS_BLOCK), 0, s, im, b, W, H, gx,
-                                 (uint32_t)Rcap, bg, pg, inst_grad);
+                                 (uint32_t)Rcap, bg, pg, inst_grad, tag_rows);
       else hipLaunchKernelGGL((blend_bwd_kernel<3, true>), dim3(blend_grid(gx * gy, b)), dim3(HGS_BLOCK), 0, s, im, b, W, H, gx,
-                              (uint32_t)Rcap, bg, pg, inst_grad);
+                              (uint32_t)Rcap, bg, pg, inst_grad, tag_rows);
     } else {
       PixGrad<7> pg;
       for (int k = 0; k < 7; k++) pg.plane[k] = dL_dpix_planes[k];
       if (bg) hipLaunchKernelGGL((blend_bwd_kernel<7, false>), dim3(blend_grid(gx * gy, b)), dim3(HGS_BLOCK), 0, s, im, b, W, H, gx,
-                                 (uint32_t)Rcap, bg, pg, inst_grad);
+                                 (uint32_t)Rcap, bg, pg, inst_grad, tag_rows);
       else hipLaunchKernelGGL((blend_bwd_kernel<7, true>), dim3(blend_grid(gx * gy, b)), dim3(HGS_BLOCK), 0, s, im, b, W, H, gx,
-                              (uint32_t)Rcap, bg, pg, inst_grad);
+                              (uint32_t)Rcap, bg, pg, inst_grad, tag_rows);
     }
   }
   HGS_CHECK_LAUNCH();

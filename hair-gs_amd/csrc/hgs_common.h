@@ -282,7 +282,7 @@ int hgs_launch_sort_tiles(hipStream_t s, int W, int H, int Rcap, int n_extra, co
 int hgs_launch_blend_fwd(hipStream_t s, int W, int H, int Rcap, int channels, const float* bg, const HgsImage& im,
                          const HgsBinning& b, float* out_color);
 int hgs_launch_blend_bwd(hipStream_t s, int W, int H, int Rcap, int channels, const float* bg, const HgsImage& im,
-                         const HgsBinning& b, const float* const* dL_dpix_planes, float* inst_grad);
+                         const HgsBinning& b, const float* const* dL_dpix_planes, float* inst_grad, int tag_rows = 0);
 struct HgsBwdArgs {
   int P, D, M, W, H;
   const float *means3D, *shs, *colors_precomp, *scales, *rotations, *cov3D_precomp;
@@ -293,7 +293,15 @@ struct HgsBwdArgs {
       *dL_drotations;
   int n_extra;         // 0, or 4 in the single-pass mode
   float* dL_dextra;    // [P, n_extra]
+  // row_reduce_kernel's results (hgs_launch_row_reduce ran in front; 7-channel pass only), or null: the kernel sums the rows itself
+  const float* row_sums;       // [P][16]: the summed rows of the Gaussians whose rows lie inside one run of HGS_RR_RPW rows
+  const float* row_partials;   // [runs][2][16]: per run, the sums of the segment that came in (`first`) and of the one left open (`last`)
 };
+#define HGS_RR_RPW 512         // rows per run (one wavefront) of row_reduce_kernel
+// the scratch of the 7-channel backward behind the R instance rows: [P][16] floats + [ceil(R / HGS_RR_RPW)][2][16] floats
+static inline size_t hgs_row_reduce_floats(size_t P, size_t R) { return P * 16 + ((R + HGS_RR_RPW - 1) / HGS_RR_RPW) * 32; }
+int hgs_launch_row_reduce(hipStream_t s, int P, int Rcap, const float* inst_grad, const uint32_t* status, float* row_sums,
+                          float* row_partials);
 int hgs_launch_preprocess_bwd(hipStream_t s, const HgsBwdArgs& a, const HgsGeom& g, const HgsBinning& b,
                               const float* inst_grad, int Rcap, const uint32_t* status, const HgsParamBackward* pb = nullptr);
 int hgs_launch_mark_visible(hipStream_t s, int P, const float* means3D, const float* viewmatrix, uint8_t* present);

@@ -155,6 +155,9 @@ enum { SRC_GIVEN = 0, SRC_STRAND = 1, SRC_CLOUD = 2 };
 // SRC != SRC_GIVEN: lane idx derives its Gaussian from the raw parameters (the device functions of strand_fwd_kernel /
 // cloud_fwd_kernel: the same bits), stores it, and goes on with the values in registers; a.scales / rotations / opacities
 // (and, for strands, a.means3D) are not read.
+#ifndef HGS_PPF_DEAL
+#define HGS_PPF_DEAL 1     // (0: A/B builds without the block-wide counting of large rectangles)
+#endif
 template <int SRC>
 __device__ __forceinline__ void preprocess_fwd_body(const HgsFwdArgs& a, const HgsGeom& g, const HgsImage& im, int* radii,
                                                     const HgsParamSrc& st, uint32_t* red, TileHash& th) {
@@ -200,6 +203,7 @@ __device__ __forceinline__ void preprocess_fwd_body(const HgsFwdArgs& a, const H
   __syncthreads();
   const int gx = (a.W + HGS_TILE - 1) / HGS_TILE, gy = (a.H + HGS_TILE - 1) / HGS_TILE;
   uint32_t ntiles = 0;
+  uint32_t big_area = 0, big_x0y0 = 0, big_w = 0;   // a rectangle of more than TH_MAX_AREA tiles: counted by the whole block
   if (live) {
     int my_radius_i = 0;
     HgsRect rc = {0, 0, 0, 0, 0, 0};
@@ -336,25 +340,84 @@ __device__ __forceinline__ void preprocess_fwd_body(const HgsFwdArgs& a, const H
       const uint32_t area_kept = (uint32_t)(x1 - x0) * (uint32_t)(y1 - y0);
       ntiles = area_kept;
       rc.x0 = (uint16_t)x0; rc.y0 = (uint16_t)y0; rc.x1 = (uint16_t)x1; rc.y1 = (uint16_t)y1;
-      // per-tile instance counts: integer atomics, order-independent (block-private table first, see TileHash)
-      for (int ty = y0; ty < y1; ty++)
-        for (int tx = x0; tx < x1; tx++) {
-          const uint32_t t = (uint32_t)(ty * gx + tx);
-          const int sl = area_kept <= TH_MAX_AREA ? th_insert(th, t) : -1;
-          if (sl >= 0) atomicAdd(&th.cnt[sl], 1u);
-          else atomicAdd(&im.tile_count[HGS_TILE_SLOT(t, im.tile_mask)], 1u);
-        }
+      // per-tile instance counts: integer atomics, order-independent (block-private table first, see TileHash).  A lane walks
+      // its own rectangle only while that is short; larger ones are dealt to the whole block below.
+      if (!HGS_PPF_DEAL || area_kept <= TH_MAX_AREA) {
+        for (int ty = y0; ty < y1; ty++)
+          for (int tx = x0; tx < x1; tx++) {
+            const uint32_t t = (uint32_t)(ty * gx + tx);
+            const int sl = area_kept <= TH_MAX_AREA ? th_insert(th, t) : -1;
+            if (sl >= 0) atomicAdd(&th.cnt[sl], 1u);
+            else atomicAdd(&im.tile_count[HGS_TILE_SLOT(t, im.tile_mask)], 1u);
+          }
+      } else {
+        big_area = area_kept;
+        big_x0y0 = (uint32_t)x0 | ((uint32_t)y0 << 16);
+        big_w = (uint32_t)(x1 - x0);
+      }
     } while (0);
     radii[idx] = my_radius_i;
     g.tiles_touched[idx] = ntiles;
     g.rect[idx] = rc;
   }
+  // ---- (round 6) rectangles of more than TH_MAX_AREA tiles: their instances are counted by ALL threads of the block, evenly.
+  // Rounds 1-5 let the lane walk its own rectangle with one global atomic per tile: a workgroup took as long as its largest
+  // Gaussian, and a Stage-I cloud at 1080p (12 tiles per Gaussian on average, hundreds for some: 2.3 M instances of 195 k
+  // Gaussians) sent every one of those atomics to the same few thousand counters -- 298 us for a kernel that takes 12 at
+  // north_star.  Now (only in blocks that hold such a rectangle: one barrier elsewhere) every lane leaves (origin, width, area) in
+  // LDS, a block scan gives the prefix, thread t takes the instances [t, t + 1) x ceil(total / 256) of the concatenated
+  // rectangles -- one binary search, then a walk -- through the same LDS tile table: one global atomic per distinct tile and
+  // block.  Counts are integers: the same numbers whoever adds them.
+  // (the block-wide "any" rides on the barrier of the block sum: blocks without such a rectangle -- every block of a fresh strand
+  // model -- pay nothing)
+  __shared__ uint32_t d_any[4];
+  {
+    const unsigned long long anyb = __ballot(big_area != 0u);
+    if ((threadIdx.x & 63) == 0) d_any[threadIdx.x >> 6] = anyb != 0ull ? 1u : 0u;
+  }
+  const uint32_t bs = block_sum_256(ntiles, red);   // (its barriers also order the table updates above)
+  if (threadIdx.x == 0) g.block_sums[blockIdx.x] = bs;
+  if (HGS_PPF_DEAL && (d_any[0] | d_any[1] | d_any[2] | d_any[3]) != 0u) {
+    __shared__ uint32_t d_org[HGS_BLOCK], d_w[HGS_BLOCK], d_off[HGS_BLOCK + 1], d_ws[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t inc = hgs_wave_incl_scan(big_area, lane);
+    if (lane == 63) d_ws[wave] = inc;
+    d_org[threadIdx.x] = big_x0y0;
+    d_w[threadIdx.x] = big_w;
+    __syncthreads();
+    uint32_t base = 0, total = 0;
+    for (int w = 0; w < 4; w++) { if (w < wave) base += d_ws[w]; total += d_ws[w]; }
+    d_off[threadIdx.x] = base + inc - big_area;
+    if (threadIdx.x == HGS_BLOCK - 1) d_off[HGS_BLOCK] = total;
+    __syncthreads();
+    const uint32_t per = (total + HGS_BLOCK - 1) / HGS_BLOCK;
+    const uint32_t k0 = min(total, threadIdx.x * per), k1 = min(total, k0 + per);
+    if (k0 < k1) {
+      int lo = 0, hi = HGS_BLOCK;                       // largest j with d_off[j] <= k0
+      while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (d_off[mid] <= k0) lo = mid; else hi = mid; }
+      int j = lo;
+      uint32_t l = k0 - d_off[j], nj = d_off[j + 1] - d_off[j];
+      uint32_t org = d_org[j], w = d_w[j];
+      int tx = (int)(org & 0xFFFFu) + (int)(l % max(w, 1u)), ty = (int)(org >> 16) + (int)(l / max(w, 1u));
+      for (uint32_t k = k0; k < k1; k++) {
+        while (l >= nj) {                               // next Gaussian with a dealt rectangle
+          j++; l = 0; nj = d_off[j + 1] - d_off[j];
+          if (nj) { org = d_org[j]; w = d_w[j]; tx = (int)(org & 0xFFFFu); ty = (int)(org >> 16); }
+        }
+        const uint32_t t = (uint32_t)(ty * gx + tx);
+        const int sl = th_insert(th, t);
+        if (sl >= 0) atomicAdd(&th.cnt[sl], 1u);
+        else atomicAdd(&im.tile_count[HGS_TILE_SLOT(t, im.tile_mask)], 1u);
+        l++;
+        if (++tx == (int)((org & 0xFFFFu) + w)) { tx = (int)(org & 0xFFFFu); ty++; }
+      }
+    }
+    __syncthreads();                                    // (the table is flushed below)
+  }
   if (blockIdx.x == 0 && threadIdx.x == 0 && a.fused_scan_ptr) {   // (status words were cleared by the launch before this one)
     im.status[HGS_ST_SCANPTR_LO] = (uint32_t)a.fused_scan_ptr;
     im.status[HGS_ST_SCANPTR_HI] = (uint32_t)(a.fused_scan_ptr >> 32);
   }
-  const uint32_t bs = block_sum_256(ntiles, red);   // (its barriers also order the table updates above)
-  if (threadIdx.x == 0) g.block_sums[blockIdx.x] = bs;
   for (int i = threadIdx.x; i < TH_SIZE; i += HGS_BLOCK)
     if (th.key[i] != TH_EMPTY) atomicAdd(&im.tile_count[HGS_TILE_SLOT(th.key[i], im.tile_mask)], th.cnt[i]);
 }
@@ -414,7 +477,9 @@ __global__ __launch_bounds__(HGS_BLOCK) void cloud_preprocess_fwd_kernel(HgsFwdA
 
 // The scatter kernel's LDS: a 512-slot tile table and one record per Gaussian of the block (what an instance needs of its
 // Gaussian), so that instances can be dealt to the threads evenly (see the kernel).
+#ifndef SC_TH_LOG
 #define SC_TH_LOG 9
+#endif
 using ScTable = TileHashT<SC_TH_LOG>;
 struct ScRec { uint32_t x0y0, w, depth; float x, y, hx, hy, nx, ny, rn; int mode; };
 
@@ -440,6 +505,19 @@ __device__ unsigned long long g_sc_trace[SC_TRACE_MAX][8];
 // 9-11 us between two grid-wide kernels; here EVERY workgroup scans the T tile counts itself (32 loads per thread at
 // 1080p, all L2 hits, offsets kept in LDS) and sums the block sums before it; workgroup 0 also publishes `ranges`, the
 // instance count and its sticky maximum.  Same integers either way.
+// (round 6) PARTS.  A workgroup places at most HGS_SC_PART instances.  The first HGS_SC_PART instances of a block of 256
+// Gaussians are its own workgroup's; a block with more -- the near, large Gaussians of a Stage-I cloud or of a merged strand
+// model: 2750 instances in the median block, 19000 in the largest (tools/dev/instance_stats.py), and the launch lasted as long as
+// that one (tools/dev/scatter_trace.py: 90 % of the workgroups done after 45 us of 254) -- is finished by HELPER workgroups at
+// the end of the grid, one per further part.  Every workgroup derives the same partition from the per-block instance counts
+// the preprocess kernel left (block_sums): helper h finds its (block, part) by one pass over them.  A helper loads the block's
+// Gaussians like its owner, counts / reserves / places its share through its own tile table; the per-Gaussian duties (offsets,
+// record templates) stay with the owner.  Order inside a tile's segment is irrelevant (the per-tile sort key is unique).
+#ifndef HGS_SC_PART
+#define HGS_SC_PART 4096u
+#endif
+__device__ __forceinline__ uint32_t hgs_sc_parts(uint32_t block_sum) { return block_sum <= HGS_SC_PART ? 1u : (block_sum + HGS_SC_PART - 1u) / HGS_SC_PART; }
+
 __global__ __launch_bounds__(HGS_BLOCK) void scatter_kernel(int P, int gx, int T, uint32_t Rcap, const float* __restrict__ feat,
                                                             const float* __restrict__ extra, HgsGeom g, HgsImage im,
                                                             HgsBinning b, int scan_wg) {
@@ -453,8 +531,46 @@ __global__ __launch_bounds__(HGS_BLOCK) void scatter_kernel(int P, int gx, int T
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const unsigned long long report = ((unsigned long long)im.status[HGS_ST_SCANPTR_HI] << 32) | im.status[HGS_ST_SCANPTR_LO];
   const bool fused = report != 0ull;
-  const int bid = (int)blockIdx.x - scan_wg;       // Gaussian block of this workgroup; -1: the scan workgroup
+  int bid = (int)blockIdx.x - scan_wg;             // Gaussian block of this workgroup; < 0: a scan workgroup
+  const int nblk_g = (P + HGS_BLOCK - 1) / HGS_BLOCK;
+  uint32_t my_part = 0u;                           // which HGS_SC_PART instances of the block this workgroup places
   SC_MARK(0);
+  if (bid >= nblk_g) {
+    // ---- a helper: which (block, part)?  Thread t sums the further parts of a contiguous share of the blocks; a block scan of
+    // the shares finds the thread whose share holds part number h, which walks its share once more.
+    __shared__ uint32_t h_found[2];
+    const uint32_t h = (uint32_t)(bid - nblk_g);
+    const int per_t = (nblk_g + HGS_BLOCK - 1) / HGS_BLOCK;
+    const int j0 = (int)threadIdx.x * per_t, j1 = min(nblk_g, j0 + per_t);
+    // (block_sums holds the blocks' raw instance counts when the scan is fused into this kernel, their exclusive prefix after a
+    // scan_kernel launch: blocking mode)
+    const uint32_t R_all = fused ? 0u : im.status[HGS_ST_R];
+    auto block_count = [&](int j) -> uint32_t {
+      if (fused) return g.block_sums[j];
+      return (j + 1 < nblk_g ? g.block_sums[j + 1] : R_all) - g.block_sums[j];
+    };
+    uint32_t mine = 0u;
+    for (int j = j0; j < j1; j++) mine += hgs_sc_parts(block_count(j)) - 1u;
+    const uint32_t inc = hgs_wave_incl_scan(mine, lane);
+    if (lane == 63) wsum[wave] = inc;
+    if (threadIdx.x == 0) h_found[0] = 0xFFFFFFFFu;
+    __syncthreads();
+    uint32_t base = inc - mine;
+    for (int w = 0; w < wave; w++) base += wsum[w];
+    if (h >= base && h < base + mine) {
+      uint32_t acc = base;
+      for (int j = j0; j < j1; j++) {
+        const uint32_t ex = hgs_sc_parts(block_count(j)) - 1u;
+        if (h < acc + ex) { h_found[0] = (uint32_t)j; h_found[1] = h - acc + 1u; break; }
+        acc += ex;
+      }
+    }
+    __syncthreads();
+    if (h_found[0] == 0xFFFFFFFFu) return;         // more helpers than further parts: nothing to do
+    bid = (int)h_found[0];
+    my_part = h_found[1];
+    __syncthreads();                               // (wsum is reused below)
+  }
   if (bid < 0) {
     // ---- fused scan: `scan_wg` extra workgroups (dispatched first) scan the tile counts and publish `ranges`, the chunk
     // work items of long lists, the instance count and its sticky maximum, while the others load, count and reserve; they
@@ -535,7 +651,7 @@ __global__ __launch_bounds__(HGS_BLOCK) void scatter_kernel(int P, int gx, int T
   __syncthreads();
   uint32_t base = fused ? blk_base : g.block_sums[bid];  // exclusive block prefix
   for (int w = 0; w < wave; w++) base += wsum[w];
-  if (idx < P) {
+  if (idx < P && my_part == 0u) {
     const uint32_t off_incl = base + incl;
     g.point_offsets[idx] = off_incl;
     if (n != 0) {
@@ -571,9 +687,14 @@ __global__ __launch_bounds__(HGS_BLOCK) void scatter_kernel(int P, int gx, int T
   if (threadIdx.x == HGS_BLOCK - 1) ioff[HGS_BLOCK] = stotal;
   __syncthreads();
   SC_MARK(1);
-  // this thread's share of the block's instances: [k0, k1), starting inside Gaussian j0 at its l0-th tile
-  const uint32_t per = (stotal + HGS_BLOCK - 1) / HGS_BLOCK;
-  const uint32_t k0 = min(stotal, threadIdx.x * per), k1 = min(stotal, k0 + per);
+  // this workgroup's part of the block's instances, [p_lo, p_hi), and this thread's share of it, [k0, k1), which starts inside
+  // Gaussian j0 at its l0-th tile
+  // (a launch without helper workgroups -- a pass that cannot hold many instances per Gaussian -- has one part per block)
+  const bool split = (int)gridDim.x > scan_wg + nblk_g && hgs_sc_parts(stotal) > 1u;
+  const uint32_t p_lo = split ? min(stotal, my_part * HGS_SC_PART) : 0u;
+  const uint32_t p_hi = split ? min(stotal, p_lo + HGS_SC_PART) : stotal;
+  const uint32_t per = (p_hi - p_lo + HGS_BLOCK - 1) / HGS_BLOCK;
+  const uint32_t k0 = min(p_hi, p_lo + threadIdx.x * per), k1 = min(p_hi, k0 + per);
   int j0 = 0;
   if (k0 < k1) {
     int lo = 0, hi = HGS_BLOCK;                       // largest j with ioff[j] <= k0 (its Gaussian has an instance there)
@@ -621,8 +742,20 @@ __global__ __launch_bounds__(HGS_BLOCK) void scatter_kernel(int P, int gx, int T
     }
   }
   __syncthreads();
+  // (round 6) a tile's segment start is read ONCE per distinct tile and block -- into the table entry that already holds the
+  // block's reservation inside the segment -- instead of once per instance: the agent-scope load (it bypasses the XCD's L2: the
+  // scan workgroups may sit on another XCD) was the dependent round trip of every key placed; on many-tile states (a Stage-I
+  // cloud at 1080p: 12 instances per Gaussian, 3000 per workgroup) the placement loop was a chain of them
+  // (only where a block places more than a few keys per thread: a pass over the table and a barrier otherwise cost more than
+  // the two or three loads per thread they replace -- north_star: 14.2 -> 15.4 us with it everywhere)
+  const bool cached_start = p_hi - p_lo > 4u * HGS_BLOCK;
+  if (cached_start) {
+    for (int i = threadIdx.x; i < ScTable::SIZE; i += HGS_BLOCK)
+      if (th.key[i] != TH_EMPTY) th.base[i] += fused ? hgs_ld_agent(&im.ranges[th.key[i]].x) : im.ranges[th.key[i]].x;
+    __syncthreads();
+  }
   SC_MARK(4);
-  if (n != 0) {
+  if (n != 0 && my_part == 0u) {
     // this Gaussian's instance-record template (HgsGeom::grec), read back once per instance by the sort kernel
     float4* rec = g.grec + 4 * (size_t)idx;
     rec[0] = make_float4(xy.x, xy.y, co.x, co.y);
@@ -637,8 +770,9 @@ __global__ __launch_bounds__(HGS_BLOCK) void scatter_kernel(int P, int gx, int T
     const uint32_t t = (uint32_t)(ty * gx + tx);
     const uint64_t key = key0 | hgs_quadrant_mask(q, c, tx, ty);
     const int sl = th_find(th, t);
-    const uint32_t pos = (fused ? hgs_ld_agent(&im.ranges[t].x) : im.ranges[t].x) + (sl >= 0 ? th.base[sl] + atomicAdd(&th.cnt[sl], 1u)
-                                                   : atomicAdd(&im.tile_cursor[HGS_TILE_SLOT(t, im.tile_mask)], 1u));
+    const uint32_t start = (sl >= 0 && cached_start) ? 0u : (fused ? hgs_ld_agent(&im.ranges[t].x) : im.ranges[t].x);
+    const uint32_t pos = start + (sl >= 0 ? th.base[sl] + atomicAdd(&th.cnt[sl], 1u)
+                                          : atomicAdd(&im.tile_cursor[HGS_TILE_SLOT(t, im.tile_mask)], 1u));
     if (pos < Rcap) b.keys[pos] = key;
     else im.status[HGS_ST_OVERFLOW] = 1;  // overflow: caller under-sized the binning buffer
   };
@@ -664,6 +798,181 @@ __device__ __forceinline__ V3 dnormvdv(V3 v, V3 dv) {  // auxiliary.h:107-117
   return r;
 }
 
+
+// ---- (round 6) a wavefront's instance rows summed by the WHOLE wavefront --------------------------------------------------
+// The rows of consecutive Gaussians are consecutive in the scratch (a Gaussian's slot range starts at the exclusive prefix of
+// tiles_touched over the Gaussians in front of it: rc.off), so the rows of a wavefront's 64 Gaussians form ONE contiguous run
+// of R_w rows with a segment per Gaussian.  Rounds 1-5 gave every lane its own segment: a wavefront took as long as its longest
+// one.  That is nothing on fresh strands (1.7 rows per Gaussian) and most of the step on the states the three-stage workflow
+// lives in: a Stage-I cloud at 1080p has 12.8 rows per Gaussian but 67 in the mean wavefront's longest lane (p99: 548, max 4240),
+// the merged Stage-III start model 5.8 / 38 (tools/dev/instance_stats.py) -- preprocess_bwd_kernel 725 / 226 us where the
+// north_star step's takes 14.  Here the run is streamed: 16 rows per load (lane = quarter * 16 + row: four lanes share a row of
+// 64 bytes, 1 KB contiguous per instruction, four loads in flight), a segmented inclusive scan over the 16 rows inside each
+// 16-lane DPP row (row_shr 1, 2, 4, 8; the segment heads of a chunk travel through 16 words of LDS), and the last row of every
+// segment in the chunk adds the segment's partial sum to the owner's accumulator in LDS.  The association of a Gaussian's sum
+// then depends on where its rows fall in the 16-row chunks (fixed for a given pass: bitwise reproducible; different from the
+// in-lane loop's, which waves whose longest segment is short keep).
+#ifndef HGS_PPB_LIGHT_MAX
+#define HGS_PPB_LIGHT_MAX 8
+#endif
+__device__ __forceinline__ float hgs_dpp_shr_f(float v, int d) {   // lane i <- lane i - d inside its 16-lane row, 0 where there is none
+  const int x = __float_as_int(v);
+  int r;
+  switch (d) {
+    case 1: r = __builtin_amdgcn_update_dpp(0, x, 0x111, 0xF, 0xF, false); break;
+    case 2: r = __builtin_amdgcn_update_dpp(0, x, 0x112, 0xF, 0xF, false); break;
+    case 4: r = __builtin_amdgcn_update_dpp(0, x, 0x114, 0xF, 0xF, false); break;
+    default: r = __builtin_amdgcn_update_dpp(0, x, 0x118, 0xF, 0xF, false); break;
+  }
+  return __int_as_float(r);
+}
+__device__ __forceinline__ int hgs_dpp_shr_i(int x, int d) {
+  switch (d) {
+    case 1: return __builtin_amdgcn_update_dpp(0, x, 0x111, 0xF, 0xF, false);
+    case 2: return __builtin_amdgcn_update_dpp(0, x, 0x112, 0xF, 0xF, false);
+    case 4: return __builtin_amdgcn_update_dpp(0, x, 0x114, 0xF, 0xF, false);
+    default: return __builtin_amdgcn_update_dpp(0, x, 0x118, 0xF, 0xF, false);
+  }
+}
+// All 64 lanes of the wavefront must be active.  `base`: the run's first row (wave-uniform), rq = float4 per row (3 or 4),
+// nr = this lane's segment length (0: none).  acc: [64][4] float4 of LDS owned by this wavefront, head: 16 words of it.
+// Returns the lane's own 16 sums in out[0..3].
+__device__ __forceinline__ void hgs_stream_rows(const float4* __restrict__ base, int rq, uint32_t nr, int lane, float4 (*acc)[4],
+                                                uint32_t* head, float4 out[4]) {
+  const uint32_t inc = hgs_wave_incl_scan(nr, lane);
+  const uint32_t pre = inc - nr;
+  const uint32_t Rw = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
+  const int g = lane & 15, q = lane >> 4;
+#pragma unroll
+  for (int k = 0; k < 4; k++) acc[lane][k] = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (lane < 16) head[lane] = 0xFFFFFFFFu;
+  const uint32_t nchunks = (Rw + 15u) >> 4;
+  auto ld = [&](uint32_t c) -> float4 {
+    const uint32_t r = c * 16u + (uint32_t)g;
+    return (r < Rw && q < rq) ? base[(size_t)r * rq + q] : make_float4(0.f, 0.f, 0.f, 0.f);
+  };
+  int carry = 0;                                                  // owner + 1 of the row in front of the chunk (wave-uniform)
+  float4 b0 = ld(0), b1 = ld(1), b2 = ld(2), b3 = ld(3);
+  for (uint32_t c = 0; c < nchunks; c++) {
+    float4 v = b0;
+    b0 = b1; b1 = b2; b2 = b3; b3 = ld(c + 4u);
+    const uint32_t r0 = c * 16u;
+    if (nr != 0u && pre - r0 < 16u) head[pre - r0] = (c << 8) | (uint32_t)lane;   // (pre >= r0 and pre < r0 + 16)
+    const uint32_t h = head[g];                                   // (LDS operations of a wavefront execute in order)
+    const bool is_head = (h >> 8) == c;
+    int own = is_head ? (int)(h & 63u) + 1 : 0;
+    int f = is_head ? 1 : 0;
+    const int f0 = f;
+#pragma unroll
+    for (int d = 1; d < 16; d <<= 1) {
+      const float ux = hgs_dpp_shr_f(v.x, d), uy = hgs_dpp_shr_f(v.y, d), uz = hgs_dpp_shr_f(v.z, d), uw = hgs_dpp_shr_f(v.w, d);
+      const int fu = hgs_dpp_shr_i(f, d), ou = hgs_dpp_shr_i(own, d);
+      if (!f) { v.x += ux; v.y += uy; v.z += uz; v.w += uw; }
+      f |= fu;
+      own = max(own, ou);
+    }
+    if (own == 0) own = carry;
+    // the last row of a segment inside this chunk: the next row starts another, or the chunk / the run ends
+    const int next_head = __builtin_amdgcn_update_dpp(1, f0, 0x101, 0xF, 0xF, false);   // row_shl:1 (lane 15 of a row: 1)
+    const uint32_t r = r0 + (uint32_t)g;
+    const bool tail = r < Rw && (next_head != 0 || r + 1u == Rw);
+    if (tail && q < rq && own > 0) {
+      float4 a = acc[own - 1][q];
+      a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+      acc[own - 1][q] = a;
+    }
+    carry = __builtin_amdgcn_readlane(own, 15);
+  }
+#pragma unroll
+  for (int k = 0; k < 4; k++) out[k] = acc[lane][k];
+}
+
+
+// ---- (round 6) row_reduce_kernel: the per-Gaussian sums of the instance rows as a launch of its own, balanced by ROWS ------
+// hgs_stream_rows balances a wavefront's 64 Gaussians, not the wavefronts: on the states the three-stage workflow lives in the
+// rows per wavefront spread from 670 (median) to 6400, the rows per workgroup from 2750 to 19000 (tools/dev/instance_stats.py: a
+// Stage-I cloud at 1080p) and the launch lasts as long as its heaviest workgroup (365 us where the bytes take 40).  This kernel
+// cuts the scratch into runs of HGS_RR_RPW rows, one per wavefront, whatever Gaussians they belong to.  A row names its Gaussian
+// in its sixteenth float (blend_bwd_kernel<7>), so a run needs no offsets: 16 rows per load as in hgs_stream_rows, a segment
+// head wherever the id changes, the segmented scan inside the 16-lane DPP rows, the open segment's sum carried from chunk to
+// chunk in registers.  A segment that ends inside the run is stored once: to gsum[id] when it also began inside it, to the run's
+// `first` partial when it came in from the run in front; the segment still open at the end of the run goes to its `last`
+// partial (a segment that spans a whole run is its `first`).  preprocess_bwd_kernel then reads ONE row per Gaussian -- or, for
+// the few Gaussians whose rows cross a run boundary, last(w0) + first(w0 + 1) + ... + first(w1), in that order: every sum is a
+// fixed sequence of additions for a given pass (bitwise reproducible).
+__global__ __launch_bounds__(HGS_BLOCK) void row_reduce_kernel(const float4* __restrict__ rows, const uint32_t* __restrict__ status,
+                                                               uint32_t Rcap, float4* __restrict__ gsum, float4* __restrict__ partial,
+                                                               uint32_t P) {
+  const int lane = threadIdx.x & 63, g = lane & 15, q = lane >> 4;
+  const uint32_t w = blockIdx.x * (HGS_BLOCK / 64) + (threadIdx.x >> 6);
+  if (status[HGS_ST_OVERFLOW] != 0u) return;                        // a void pass: nothing was written, nothing is read
+  const uint32_t R = min(status[HGS_ST_R], Rcap);
+  const uint32_t r_lo = w * (uint32_t)HGS_RR_RPW;
+  if (r_lo >= R) return;
+  const uint32_t r_hi = min(R, r_lo + (uint32_t)HGS_RR_RPW);
+  const uint32_t* ids = (const uint32_t*)rows;                       // id of row r: word 16 r + 15
+  const uint32_t NONE = 0xFFFFFFFFu;
+  const uint32_t id_before = r_lo > 0u ? ids[(size_t)(r_lo - 1u) * 16 + 15] : NONE;
+  const uint32_t id_after = r_hi < R ? ids[(size_t)r_hi * 16 + 15] : NONE;
+  const uint32_t nchunks = (r_hi - r_lo + 15u) >> 4;
+  auto ld = [&](uint32_t c, uint32_t& id) -> float4 {
+    const uint32_t r = r_lo + c * 16u + (uint32_t)g;
+    if (r < r_hi) { id = ids[(size_t)r * 16 + 15]; return rows[(size_t)r * 4 + q]; }
+    id = NONE;
+    return make_float4(0.f, 0.f, 0.f, 0.f);
+  };
+  uint32_t i0, i1, i2, i3;
+  float4 b0 = ld(0, i0), b1 = ld(1, i1), b2 = ld(2, i2), b3 = ld(3, i3);
+  // the segment that is open in front of the current chunk (wave-uniform): its id, whether it is the one that came in from the
+  // run in front, whether any of its rows lie in this run yet (then `carry` holds their sum: lane g == 0 of every quarter)
+  uint32_t open_id = id_before;
+  bool open_from_before = true, have_carry = false;
+  float4 carry = make_float4(0.f, 0.f, 0.f, 0.f);
+  auto store_segment = [&](uint32_t id, bool from_before, bool to_after, const float4& v) {
+    if (from_before) partial[((size_t)w * 2 + 0) * 4 + q] = v;
+    else if (to_after) partial[((size_t)w * 2 + 1) * 4 + q] = v;
+    else if (id < P) gsum[(size_t)id * 4 + q] = v;
+  };
+  for (uint32_t c = 0; c < nchunks; c++) {
+    float4 v = b0;
+    const uint32_t id = i0;
+    b0 = b1; i0 = i1; b1 = b2; i1 = i2; b2 = b3; i2 = i3; b3 = ld(c + 4u, i3);
+    const uint32_t r = r_lo + c * 16u + (uint32_t)g;
+    const bool valid = r < r_hi;
+    const uint32_t prev = (uint32_t)__builtin_amdgcn_update_dpp((int)open_id, (int)id, 0x111, 0xF, 0xF, false);   // row_shr:1 (g == 0: open_id)
+    const bool is_head = valid && id != prev;
+    if (g == 0) {
+      // the open segment goes on through row 0 (the carry joins it), or it ended with the chunk in front (stored now)
+      if (!is_head) { v.x += carry.x; v.y += carry.y; v.z += carry.z; v.w += carry.w; }
+      else if (have_carry) store_segment(open_id, open_from_before, false, carry);
+    }
+    int f = is_head ? 1 : 0;
+    const int f0 = f;
+#pragma unroll
+    for (int d = 1; d < 16; d <<= 1) {
+      const float ux = hgs_dpp_shr_f(v.x, d), uy = hgs_dpp_shr_f(v.y, d), uz = hgs_dpp_shr_f(v.z, d), uw = hgs_dpp_shr_f(v.w, d);
+      const int fu = hgs_dpp_shr_i(f, d);
+      if (!f) { v.x += ux; v.y += uy; v.z += uz; v.w += uw; }
+      f |= fu;
+    }
+    // rows that end their segment inside the chunk: the next row starts another one, or the run ends here.  (Row 15 of a chunk
+    // that is not the run's last never does: its segment stays open and is settled by the next chunk's row 0.)
+    const int next_head = __builtin_amdgcn_update_dpp(0, f0, 0x101, 0xF, 0xF, false);   // row_shl:1 (g == 15: 0)
+    const bool last_row = valid && r + 1u == r_hi;
+    const bool from_carry = f == 0;                                    // no head at or in front of this row in the chunk
+    if (valid && (next_head != 0 || last_row))
+      store_segment(id, from_carry && open_from_before, last_row && id == id_after, v);
+    // the segment left open behind the chunk is row 15's
+    open_from_before = open_from_before && __builtin_amdgcn_readlane(f, 15) == 0;
+    open_id = (uint32_t)__builtin_amdgcn_readlane((int)id, 15);
+    have_carry = true;
+    carry.x = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v.x), 0x121, 0xF, 0xF, false));   // row_ror:1: lane 15 -> lane 0
+    carry.y = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v.y), 0x121, 0xF, 0xF, false));
+    carry.z = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v.z), 0x121, 0xF, 0xF, false));
+    carry.w = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v.w), 0x121, 0xF, 0xF, false));
+  }
+}
+
 // DC_ONLY: the strand / Stage-I default -- SH degree 0 with one stored coefficient (or precomputed colours): the
 // view-dependent SH code is compiled out (136 -> fewer registers for a kernel that lives on its occupancy).
 // MODE (round 5, the backward mirror of hair_preprocess_fwd_kernel / cloud_preprocess_fwd_kernel): the lane that has just
@@ -687,12 +996,17 @@ template <bool DC_ONLY, int MODE>
 __global__ __launch_bounds__(HGS_BLOCK) __attribute__((amdgpu_waves_per_eu((MODE == 0 || DC_ONLY) ? HGS_PPB_WAVES : HGS_PPB_WAVES - 1))) void preprocess_bwd_kernel(HgsBwdArgs a, HgsGeom g, HgsBinning b,
                                                                    const float* __restrict__ inst_grad, uint32_t Rcap,
                                                                    const uint32_t* __restrict__ status, HgsParamBackward pb) {
-  const int idx = blockIdx.x * HGS_BLOCK + threadIdx.x;
-  if (idx >= a.P) {
+  __shared__ float4 s_acc[HGS_BLOCK / 64][64][4];     // hgs_stream_rows: per wavefront, one accumulator row per lane
+  __shared__ uint32_t s_head[HGS_BLOCK / 64][16];
+  if ((int)(blockIdx.x * HGS_BLOCK) >= a.P) {
     // (the loss head's deferred tail: the spare workgroup behind the launch's own, all of whose lanes are past P)
     if (MODE != 0 && pb.head_tail.out && blockIdx.x == gridDim.x - 1) hgs_head_tail_block(pb.head_tail);
     return;
   }
+  // (lanes past P of the last workgroup stay: the row summation below is a wavefront-wide operation; they read Gaussian P - 1
+  // and leave before anything is stored)
+  const bool live = (int)(blockIdx.x * HGS_BLOCK + threadIdx.x) < a.P;
+  const int idx = live ? (int)(blockIdx.x * HGS_BLOCK + threadIdx.x) : a.P - 1;
   const int D = DC_ONLY ? 0 : a.D;
   // A forward that overflowed its binning capacity (status[1]) dropped instances: their rows of the scratch were never
   // written.  Such a pass is void; its backward returns EXACTLY ZERO for every gradient (deterministic, finite) and the
@@ -706,7 +1020,7 @@ __global__ __launch_bounds__(HGS_BLOCK) __attribute__((amdgpu_waves_per_eu((MODE
   float dsh_dc[3] = {0.f, 0.f, 0.f};               // gradient of the SH DC coefficient (MODE 1 / 2: the in-lane Adam update reads it)
   // this Gaussian's own data: every load issued here, before the row loop below (whose data-dependent trip count the
   // compiler will not move loads across): one memory round trip for all of it instead of one per dependent stage
-  const bool vis = a.radii[idx] > 0 && !void_pass;
+  const bool vis = live && a.radii[idx] > 0 && !void_pass;
   const HgsRect rc_pre = g.rect[idx];
   const uint32_t n_pre = g.tiles_touched[idx];
   const float4 co_pre = g.conic_opacity[idx];
@@ -747,15 +1061,57 @@ __global__ __launch_bounds__(HGS_BLOCK) __attribute__((amdgpu_waves_per_eu((MODE
   if (MODE == 1) seg_pre = hgs_segment_geom(idx, pb.endpoints, pb.endpoint_pairs);
   if (MODE == 2) raw_rot_pre = ((const float4*)pb.rotation_raw)[idx];
   if (MODE != 0) mask_pre = pb.extra4[4 * (size_t)idx];
-  if (vis) {
+  {
     // ---- deterministic gather of this Gaussian's per-instance partial sums (instance order = tile rect order)
     const HgsRect rc = rc_pre;
     const uint32_t n = n_pre;
     const int row_floats = a.n_extra ? 16 : HGS_INST_GRAD_FLOATS;
     // (under-sized binning buffer: the forward already flagged the overflow; rows beyond the capacity do not exist)
-    const uint32_t nr = rc.off >= Rcap ? 0u : min(n, Rcap - rc.off);
+    const uint32_t nr = (!vis || rc.off >= Rcap) ? 0u : min(n, Rcap - rc.off);
     const float4* rows = (const float4*)(inst_grad + (size_t)rc.off * row_floats);   // rows in Gaussian-major order
     const int rq = row_floats / 4;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const unsigned long long heavy = __ballot(nr > (uint32_t)HGS_PPB_LIGHT_MAX);
+    const unsigned long long some = __ballot(nr != 0u);
+    if (a.row_sums) {
+      // row_reduce_kernel ran in front of this launch: one row per Gaussian -- or the partial sums of the runs its rows cross
+      if (nr != 0u) {
+        const uint32_t w0 = rc.off / (uint32_t)HGS_RR_RPW, w1 = (rc.off + nr - 1u) / (uint32_t)HGS_RR_RPW;
+        float4 o4[4];
+        if (w0 == w1) {
+          const float4* r = (const float4*)a.row_sums + 4 * (size_t)idx;
+          o4[0] = r[0]; o4[1] = r[1]; o4[2] = r[2]; o4[3] = r[3];
+        } else {
+          const float4* pr = (const float4*)a.row_partials;
+          const float4* r = pr + ((size_t)w0 * 2 + 1) * 4;                   // what run w0 left open
+          o4[0] = r[0]; o4[1] = r[1]; o4[2] = r[2]; o4[3] = r[3];
+          for (uint32_t w = w0 + 1u; w <= w1; w++) {                         // what came into the runs behind it, in order
+            const float4* t = pr + ((size_t)w * 2 + 0) * 4;
+#pragma unroll
+            for (int k = 0; k < 4; k++) { const float4 x = t[k]; o4[k].x += x.x; o4[k].y += x.y; o4[k].z += x.z; o4[k].w += x.w; }
+          }
+        }
+        dmx = o4[0].x; dmy = o4[0].y; dcx = o4[0].z; dcy = o4[0].w;
+        dcw = o4[1].x; dop = o4[1].y; dcol[0] = o4[1].z; dcol[1] = o4[1].w; dcol[2] = o4[2].x;
+        dex[0] = o4[2].y; dex[1] = o4[2].z; dex[2] = o4[2].w; dex[3] = o4[3].x;
+        dmx_rgb = o4[3].y; dmy_rgb = o4[3].z;
+      }
+    } else if (heavy != 0ull) {
+      // a wavefront with a long segment: its whole run of rows is streamed (hgs_stream_rows)
+      const int first = (int)__builtin_ctzll(some);
+      const unsigned long long bp = (unsigned long long)(uintptr_t)rows;
+      const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)bp, first);
+      const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(bp >> 32), first);
+      const float4* base = (const float4*)(uintptr_t)(((unsigned long long)hi << 32) | lo);
+      float4 o4[4];
+      hgs_stream_rows(base, rq, nr, lane, s_acc[wave], s_head[wave], o4);
+      dmx = o4[0].x; dmy = o4[0].y; dcx = o4[0].z; dcy = o4[0].w;
+      dcw = o4[1].x; dop = o4[1].y; dcol[0] = o4[1].z; dcol[1] = o4[1].w; dcol[2] = o4[2].x;
+      if (a.n_extra) {
+        dex[0] = o4[2].y; dex[1] = o4[2].z; dex[2] = o4[2].w; dex[3] = o4[3].x;
+        dmx_rgb = o4[3].y; dmy_rgb = o4[3].z;
+      }
+    } else {
     // HGS_PPB_ROWS rows in flight per trip, added in instance order (the sums are the same sums; a lane with 30 instances used to
     // pay 30 dependent trips through the cache hierarchy, and its workgroup with it)
 #ifndef HGS_PPB_ROWS
@@ -783,6 +1139,9 @@ __global__ __launch_bounds__(HGS_BLOCK) __attribute__((amdgpu_waves_per_eu((MODE
         }
       }
     }
+    }
+  }
+  if (vis) {
     // The rows hold sums of moments of u = G dL/dalpha (blend_bwd_kernel): dmx = S(u dx), dmy = S(u dy), dcx = S(u dx dx),
     // dcy = S(u dx dy), dcw = S(u dy dy), dop = S(u).  backward_distwar.cu:1002-1011 in terms of them (dL_dG = opacity
     // dL_dalpha, dG_ddelx = -G (a dx + b dy), dG_ddely = -G (c dy + b dx), ddel_dx = 0.5 W, ddel_dy = 0.5 H):
@@ -971,6 +1330,7 @@ __global__ __launch_bounds__(HGS_BLOCK) __attribute__((amdgpu_waves_per_eu((MODE
     float* dsh = a.dL_dsh + (size_t)idx * M * 3;
     for (int k = 0; k < 3 * M; k++) dsh[k] = 0.f;
   }
+  if (!live) return;
   // every output is written (zeros for culled Gaussians): no separate zero-fill pass
   // returned screen-space gradient: in the single-pass mode the RGB channels' share only (what the reference's
   // densification statistics read from the RGB pass); dL_dmeans3D above used the total
@@ -1107,7 +1467,23 @@ int hgs_launch_scatter(hipStream_t s, int P, int W, int H, int Rcap, const float
   {
     HgsProfScope _prof(s, HGS_K_SCATTER);
     const int scan_wg = can_fuse ? (T + HGS_BLOCK - 1) / HGS_BLOCK : 0;     // one tile per thread (<= HGS_SCAN_WGS workgroups)
-    hipLaunchKernelGGL(scatter_kernel, dim3(nblk + scan_wg), dim3(HGS_BLOCK), lds, s, P, gx, T, (uint32_t)Rcap, features, n_extra ? extra : nullptr, g, im, b, scan_wg);
+    // helper workgroups for the further parts of blocks with more than HGS_SC_PART instances (see the kernel): at most one per
+    // HGS_SC_PART instances of the capacity; none where the pass cannot hold such a block's worth per block on average
+    const long long cap = Rcap > 0 ? Rcap : 0;
+    const int helpers = cap >= 8ll * P ? (int)((cap + HGS_SC_PART - 1) / HGS_SC_PART) : 0;
+    hipLaunchKernelGGL(scatter_kernel, dim3(nblk + scan_wg + helpers), dim3(HGS_BLOCK), lds, s, P, gx, T, (uint32_t)Rcap, features, n_extra ? extra : nullptr, g, im, b, scan_wg);
+  }
+  HGS_CHECK_LAUNCH();
+  return 0;
+}
+int hgs_launch_row_reduce(hipStream_t s, int P, int Rcap, const float* inst_grad, const uint32_t* status, float* row_sums,
+                          float* row_partials) {
+  const unsigned runs = ((unsigned)Rcap + HGS_RR_RPW - 1) / HGS_RR_RPW;
+  const unsigned nblk = (runs + HGS_BLOCK / 64 - 1) / (HGS_BLOCK / 64);
+  {
+    HgsProfScope _prof(s, HGS_K_MISC);
+    hipLaunchKernelGGL(row_reduce_kernel, dim3(nblk), dim3(HGS_BLOCK), 0, s, (const float4*)inst_grad, status, (uint32_t)Rcap,
+                       (float4*)row_sums, (float4*)row_partials, (uint32_t)P);
   }
   HGS_CHECK_LAUNCH();
   return 0;

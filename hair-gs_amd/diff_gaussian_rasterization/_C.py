@@ -24,6 +24,19 @@ class HgsCapacityOverflow(RuntimeError):
     pass
 
 
+def bucket_capacity(n):
+    """A binning capacity of at least `n` instances with four significant bits (m x 2^e, 8 <= m < 16: at most 12.5 % above n).
+    The workspaces carved for a capacity are the largest allocations of a pass (~330 B per instance); a model that grows by a few
+    per cent per topology event would otherwise ask for a slightly larger block at every re-capture, which no cached block can
+    serve -- the caching allocator then holds one retired block per event (tools/dev/recapture_memory.py).  In buckets, successive
+    captures ask for the same sizes and take the blocks the dropped graph has freed."""
+    n = int(n)
+    if n <= 16:
+        return max(n, 0)
+    e = n.bit_length() - 4
+    return ((n + (1 << e) - 1) >> e) << e
+
+
 def set_tile_cull(enabled=True):
     """Tile culling (include/hgs.h hgs_set_tile_cull: drop the (Gaussian, tile) instances no pixel can blend; image,
     radii and every gradient are bit-identical with and without) for ALL entry points of this module: True / False, or
@@ -36,6 +49,24 @@ def set_tile_cull(enabled=True):
     was = _state["cull"]
     _state["cull"] = None if enabled is None else bool(enabled)
     return was
+
+
+def set_row_reduce(mode):
+    """How the single-pass backward sums the instance rows per Gaussian (include/hgs.h hgs_set_row_reduce): True / False, or
+    None = decide per call -- from the exact instance count of a blocking-mode pass (R >= 4 P), from the library's capacity rule
+    otherwise.  train.GraphedStep.capture() sets it from the instance counts its warm-up passes measured, so that the form
+    follows the MODEL (and with it every replay and every eager iteration until the next capture), not the capacity a run
+    happens to hold: a run that rolls back and raises its capacity keeps the arithmetic of one that never overflowed."""
+    was = _state.get("row_reduce")
+    _state["row_reduce"] = None if mode is None else bool(mode)
+    return was
+
+
+def _apply_row_reduce(L, P, R):
+    mode = _state.get("row_reduce")
+    if mode is None:
+        mode = (1 if R >= 4 * P else 0) if not _state["async"] else -1
+    L.hgs_set_row_reduce(int(mode))
 
 
 def set_async(enabled=True, slack=1.5):
@@ -65,9 +96,10 @@ def check_async():
         t.zero_()
     _state["dirty"] = False
     _state["cap_used"] = None
+    _state["last_exact_R"] = worst        # (an instance COUNT, not a capacity: what set_row_reduce's callers decide by)
     if worst == 0xFFFFFFFF:   # include/hgs.h HGS_WAIT_TIMED_OUT
         raise rt.HgsError("a raster pass gave up an inter-workgroup wait (status word 8): its frame is invalid")
-    _state["cap"] = max(_state["cap"], int(worst * _state["slack"]) + 4096)
+    _state["cap"] = max(_state["cap"], bucket_capacity(int(worst * _state["slack"]) + 4096))
     if cap is not None and worst > cap:
         raise HgsCapacityOverflow(f"a raster pass needed {worst} instances (capacity {cap}): capacity raised to {_state['cap']}, repeat the step")
     return [worst]
@@ -239,8 +271,9 @@ def _forward(background, means3D, colors, opacity, scales, rotations, scale_modi
             R = _state["cap"]
         else:
             R = int(n_host.value)
+            _state["last_exact_R"] = R
             if _state["async"]:  # first call: learn the scale of the scene with one blocking read
-                _state["cap"] = max(_state["cap"], int(R * _state["slack"]) + 4096)
+                _state["cap"] = max(_state["cap"], bucket_capacity(int(R * _state["slack"]) + 4096))
         if extra_ is None:
             binning = torch.empty((L.hgs_binning_bytes(R),), **u8)
             rt.check(L.hgs_forward_render(stream, P, W, H, R, rt.ptr(bg), rt.ptr(colors_), rt.ptr(geom), rt.ptr(binning),
@@ -337,6 +370,7 @@ def rasterize_gaussians_multi_backward(background7, means3D, radii, colors, scal
                                                _f32(cov3D_precomp, "cov3D_precomp"))
     view_, proj_, cam_ = _f32(viewmatrix, "viewmatrix"), _f32(projmatrix, "projmatrix"), _f32(campos, "campos")
     radii_ = rt.require_gpu_tensor(radii, "radii", torch.int32)
+    _apply_row_reduce(L, P, int(R))
     with torch.cuda.device(dev):
         rt.check(L.hgs_backward_multi(rt.current_stream(), P, int(degree), M, int(R), W, H, rt.ptr(bg_), rt.ptr(means3D),
                                       rt.ptr(sh_), rt.ptr(colors_), rt.ptr(scales_), float(scale_modifier), rt.ptr(rots_),
@@ -368,6 +402,7 @@ def rasterize_gaussians_multi_backward_params(background7, means3D, radii, scale
     bg_, sh_, scales_, rots_ = _f32(background7, "bg"), _f32(sh, "sh"), _f32(scales, "scales"), _f32(rotations, "rotations")
     view_, proj_, cam_ = _f32(viewmatrix, "viewmatrix"), _f32(projmatrix, "projmatrix"), _f32(campos, "campos")
     radii_ = rt.require_gpu_tensor(radii, "radii", torch.int32)
+    _apply_row_reduce(L, P, int(R))
     with torch.cuda.device(dev):
         rt.check(L.hgs_backward_multi_params(rt.current_stream(), P, int(degree), M, int(R), W, H, rt.ptr(bg_), rt.ptr(means3D),
                                              rt.ptr(sh_), rt.ptr(scales_), rt.ptr(rots_), rt.ptr(view_), rt.ptr(proj_), rt.ptr(cam_),

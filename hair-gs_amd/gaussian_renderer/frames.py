@@ -112,7 +112,7 @@ class FrameRenderer:
                 for v in sorted({(k * vt.n) // 16 for k in range(16)}):
                     vt.prologue(v, ride=True)
                     self._frame()
-                    st["cap"] = max(st["cap"], int(self._read_max() * self.slack) + 4096)
+                    st["cap"] = max(st["cap"], raster.bucket_capacity(int(self._read_max() * self.slack) + 4096))
                 ga = torch.cuda.CUDAGraph(keep_graph=True)
                 with torch.cuda.graph(ga, stream=s):
                     vt.prologue(0, ride=True)
@@ -167,7 +167,7 @@ class FrameRenderer:
             return []
         worst = self._read_max()
         if worst > self._cap:
-            raster._state["cap"] = max(raster._state["cap"], int(worst * self.slack) + 4096)
+            raster._state["cap"] = max(raster._state["cap"], raster.bucket_capacity(int(worst * self.slack) + 4096))
             self._graph = None
             return pending
         return []

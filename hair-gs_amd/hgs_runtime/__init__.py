@@ -84,6 +84,7 @@ SIGNATURES = {
     "hgs_nearest_distance_f64": (ci, [vp, ci, ci, vp, vp, vp]),
     "hgs_set_tile_cull": (ci, [ci]),
     "hgs_set_segment_policy": (ci, [ci, ci, ci]),
+    "hgs_set_row_reduce": (ci, [ci]),
     "hgs_debug_set_wg_trace": (ci, [vp, vp]),
     "hgs_prof_enable": (ci, [ci]),
     "hgs_prof_bracket_overhead_ms": (C.c_double, []),
@@ -172,7 +173,7 @@ HEAD_OUT = ["total", "l1", "dssim", "mask", "orientation", "smooth", "ori_count"
             "g_ori", "g_smooth", "total_fwd"]
 HEAD_NOUT = 16
 FUSED_PREPROCESS_MAX_TILES = 8192   # include/hgs.h HGS_FUSED_PREPROCESS_MAX_TILES
-ABI_VERSION = 5   # include/hgs.h HGS_ABI_VERSION: bumped whenever a struct, a signature or a buffer layout changes
+ABI_VERSION = 6   # include/hgs.h HGS_ABI_VERSION: bumped whenever a struct, a signature or a buffer layout changes
 
 
 def build(verbose=False):

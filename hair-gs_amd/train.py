@@ -302,6 +302,53 @@ def lean_graph_capture(graph, stream, pool=None, **mode):
             graph.capture_end()
 
 
+_GRAPH_POOLS = {}
+
+
+def graph_pool(device):
+    """ONE allocator pool for every graph this process captures on `device` (torch.cuda.graph_pool_handle).  A graph
+    captured into a pool of its own keeps that pool's blocks RESERVED after the graph is dropped -- a private pool's free blocks
+    serve no other pool, and nothing returns them to the driver short of empty_cache() -- so a run that re-captures after every
+    topology event (100 iterations) reserved another 1-2 GB per event: 24 GB after 1500 iterations at north_star with 1.9 GB
+    allocated, and BASELINE config 4's three stages (1 M Gaussians, ~100 re-captures) ran out of the GPU's 288 GB (round 6,
+    tools/dev/recapture_memory.py).  With one shared pool the next capture takes the blocks the dropped graph has freed.  Graphs
+    that share a pool must not be alive and in use at once unless they share no temporaries in time: GraphedStep's single-step
+    and K-step graphs already share one (they are replayed one after the other on one stream and exchange nothing through
+    capture-time temporaries), and a re-capture happens only after the previous GraphedStep has been dropped."""
+    key = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
+    if key not in _GRAPH_POOLS:
+        # A torch.cuda.MemPool OBJECT, kept for the life of the process: the allocator counts it as a user of the pool, so the
+        # pool outlives the graphs captured into it (a bare graph_pool_handle() id is retired with its last graph: the next
+        # capture_begin on it fails the allocator's use_count assertion)
+        with torch.cuda.device(key):
+            _GRAPH_POOLS[key] = torch.cuda.MemPool()
+    return _GRAPH_POOLS[key].id
+
+
+def release_graph_pool(device):
+    """Drop the shared pool of `device` and hand every cached block back to the driver.  The MemPool object's destructor frees the
+    pool's cached blocks (once the last graph captured into it is gone); empty_cache() does the same for the ordinary pools.
+    GraphedStep.capture() calls this when the binning capacity has moved to another bucket since the previous capture: the
+    workspaces carved for the old capacity (the largest allocations of a pass) fit no request any more, and three classes of
+    them linger -- eager topology iterations on the default stream, warm-up passes on the capture stream, the graph's private
+    pool (tools/dev/recapture_memory.py: 3 x the sum of all retired bucket sizes, 10 GB after 1500 iterations at north_star)."""
+    key = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
+    _GRAPH_POOLS.pop(key, None)
+    torch.cuda.empty_cache()
+
+
+_LAST_CAPTURE_CAP = {}
+_CAPTURE_STREAMS = {}
+
+
+def capture_stream(device):
+    """The side stream every GraphedStep of this process warms up and captures on (one per device)."""
+    key = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
+    if key not in _CAPTURE_STREAMS:
+        _CAPTURE_STREAMS[key] = torch.cuda.Stream(device=key)
+    return _CAPTURE_STREAMS[key]
+
+
 class GraphedStep:
     """The whole training iteration (3 raster fwd+bwd, losses, statistics, Adam) captured ONCE into a HIP graph and
     replayed per step: ~100 kernel launches cost one graph launch on the host, so the step runs at GPU speed instead
@@ -450,8 +497,14 @@ class GraphedStep:
         self._make_capturable()
         self._graphs = None            # (load_camera launches the prologue until the new graph exists)
         saved_stats = (g.max_radii2D.clone(), g.xyz_gradient_accum.clone(), g.denom.clone())  # warm-up must not count
-        s = self._stream = torch.cuda.Stream()  # warm-up AND capture run on this stream (AccumulateGrad nodes are per stream)
+        # warm-up AND capture run on one side stream (AccumulateGrad nodes are per stream) -- the SAME one for every capture of the
+        # process: the caching allocator keeps freed blocks per stream, so a new stream per re-capture left the previous
+        # capture's warm-up buffers (binning, scratch: 1-2 GB at 250 k segments) cached where nothing would ever ask for them
+        # again (tools/dev/recapture_memory.py: reserved memory grew by that much per topology event)
+        dev_key = g.get_xyz.device.index
+        s = self._stream = capture_stream(g.get_xyz.device)
         s.wait_stream(torch.cuda.current_stream())
+        warm_R = 0
         with torch.cuda.stream(s):
             for cam in warmup_cams:  # every view once: the capacity must cover the busiest camera
                 self._set_lr(iteration)
@@ -464,9 +517,18 @@ class GraphedStep:
                     raster.check_async()        # learns the capacity; an overflow here only raises it for the capture
                 except raster.HgsCapacityOverflow:
                     pass
+                warm_R = max(warm_R, int(raster._state.get("last_exact_R", 0)) & 0x7FFFFFFF)
+        # how the single-pass backward sums its instance rows (include/hgs.h hgs_set_row_reduce) follows the MODEL: the instance
+        # counts the warm-up has just measured, not the capacity -- for this capture, its replays and the eager iterations until
+        # the next capture (every rank sees the same model and the same warm-up views)
+        raster.set_row_reduce(warm_R >= 4 * int(g.get_xyz.shape[0]))
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
         g.optimizer.zero_grad(set_to_none=True)
+        if _LAST_CAPTURE_CAP.get(dev_key) not in (None, raster._state["cap"]):
+            # the capacity (as the warm-up has just settled it) is in another bucket than the previous capture's: nothing the
+            # allocator has cached for the old one fits any more
+            release_graph_pool(g.get_xyz.device)
         for dst, src in zip((g.max_radii2D, g.xyz_gradient_accum, g.denom), saved_stats):
             dst.copy_(src)
         self.loss_buf = None
@@ -499,7 +561,8 @@ class GraphedStep:
         # (the warm-up above ran with the optimizer untouched; the captured iterations update in the backward's lanes where possible)
         self.inline_adam = (self.fused is not None and not multi and world == 1 and self.fused.enable_inline_adam(True))
         ga = torch.cuda.CUDAGraph(keep_graph=True) if self._prologue_in_graph else torch.cuda.CUDAGraph()
-        with lean_graph_capture(ga, s, **mode):
+        pool = graph_pool(g.get_xyz.device)
+        with lean_graph_capture(ga, s, pool=pool, **mode):
             if self._prologue_in_graph:
                 self.load_camera(warmup_cams[0])
             self.loss_buf = fwd_bwd()
@@ -523,7 +586,7 @@ class GraphedStep:
             K, v = self.steps_per_graph, self.fused.views
             gk = torch.cuda.CUDAGraph(keep_graph=True)
             losses = []
-            with lean_graph_capture(gk, s, pool=ga.pool(), **mode):
+            with lean_graph_capture(gk, s, pool=pool, **mode):
                 for j in range(K):
                     g.optimizer.zero_grad(set_to_none=True)   # (host side: this step's backward ASSIGNS its gradients)
                     v.prologue(j % v.n, lr=float(j), lr_dst=self._position_lr(), ride=self._ride)   # lr = j: the tag graph_bind sorts by
@@ -536,6 +599,7 @@ class GraphedStep:
         # every replay raises the library's sticky device-side maximum of num_rendered; check() compares it with the
         # capacity the captured passes were built for
         self._cap = raster._state["cap_used"]
+        _LAST_CAPTURE_CAP[dev_key] = raster._state["cap"]
         for t in raster._state["max_R"].values():
             t.zero_()                       # the capture itself launched nothing
         raster._state["dirty"] = False
@@ -673,7 +737,7 @@ def training(gaussians, cameras, opt, iterations=None, extent=1.0, seed=0, log_e
         if vp.rank == 0:
             print(f"[it {it_now}] binning capacity {cap} exceeded ({worst} instances): iterations {ckpt.it + 1}..{it_now} "
                   "are run again from the last checkpoint with a larger capacity")
-        raster._state["cap"] = max(raster._state["cap"], int(worst * 2.0) + 4096)
+        raster._state["cap"] = max(raster._state["cap"], raster.bucket_capacity(int(worst * 2.0) + 4096))
         return ckpt.restore(gaussians, sampler)
 
     try:
@@ -739,7 +803,7 @@ def training(gaussians, cameras, opt, iterations=None, extent=1.0, seed=0, log_e
                 ckpt.take(gaussians, sampler, ema, it - 1)
                 if cap is not None and worst > 0.8 * cap:
                     from diff_gaussian_rasterization import _C as raster
-                    raster._state["cap"] = max(raster._state["cap"], int(worst * 2.0) + 4096)
+                    raster._state["cap"] = max(raster._state["cap"], raster.bucket_capacity(int(worst * 2.0) + 4096))
                     gs = None
             if log_every and vp.rank == 0 and any(j % log_every == 0 for j in range(first, it)):
                 print(f"[it {it - 1}] loss(ema) {float(ema):.6f}  segments {gaussians.get_xyz.shape[0]}")
@@ -747,6 +811,7 @@ def training(gaussians, cameras, opt, iterations=None, extent=1.0, seed=0, log_e
         if use_graph:
             from diff_gaussian_rasterization import _C as raster
             raster.set_async(False)
+            raster.set_row_reduce(None)       # (what the captures of this run chose: back to the per-call default)
     training.last_void_steps = 0          # (kept for callers of earlier rounds: overflowed steps are now run again)
     training.last_rollbacks = rollbacks
     return ema

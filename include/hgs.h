@@ -46,7 +46,7 @@ extern "C" {
  * 5, round 5: hgs_backward_multi_params / hgs_hair_endpoint_gather, HgsPrologue.adam_prep and the in-lane Adam update, and the contract that HgsHeadParams.tile_used also limits
  * what hgs_loss_head_forward writes of d_extra_unit -- a caller of version 4 that read those planes everywhere must not);
  * the Python binding refuses a library whose version or struct sizes differ from its own */
-#define HGS_ABI_VERSION 5
+#define HGS_ABI_VERSION 6
 #define HGS_TILE 16 /* cuda_rasterizer/config.h:16-17 */
 
 int hgs_abi_version(void);
@@ -535,6 +535,16 @@ int hgs_set_tile_cull(int on);
  * effect at the next forward pass (a captured graph keeps the policy it was captured with).  Results do not depend
  * on it beyond the association of the per-pixel transmittance product. */
 int hgs_set_segment_policy(int min_len, int max_len, int target_segments);
+/* The 7-channel backward (hgs_backward_multi / hgs_backward_multi_params) takes the per-Gaussian sums of the instance rows either
+ * inside its per-Gaussian launch -- whose wavefronts wait for their longest Gaussian -- or with a launch of their own that is
+ * balanced by ROWS (csrc/hgs_preprocess.hip row_reduce_kernel: runs of 512 rows per wavefront, whatever Gaussians they belong
+ * to): what a pass with many instances per Gaussian wants (a Stage-I cloud at 1080p, the merged strand model: 4 - 12 x faster).
+ * mode 1: always the launch; 0: never; -1 (default): where R >= 8 P.  R is the caller's argument -- in capacity mode a CAPACITY,
+ * not a count --, so a caller that wants the choice to follow the model rather than its capacity sets 0 / 1 itself (the Python
+ * layer does: from the instance counts of the warm-up passes of a capture, diff_gaussian_rasterization._C.set_row_reduce).
+ * Process-wide, read by the next backward (a captured graph keeps what it was captured with).  The same terms either way,
+ * associated differently (rounding); every form is a fixed sequence of additions for a given pass.  Returns the previous mode. */
+int hgs_set_row_reduce(int mode);
 int hgs_debug_set_wg_trace(void* device_buf_fwd, void* device_buf_bwd);
 
 /* ---- introspection used by the parity tests (byte offsets of the sub-arrays of each buffer) ---- */

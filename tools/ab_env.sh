@@ -4,7 +4,7 @@
 VAR=$1; WLS=${2:-north_star}; REPS=${3:-2}
 mkdir -p gpurun_out
 for rep in $(seq 1 $REPS); do for w in $WLS; do for v in 0 1; do
-  env $VAR=$v timeout 400 python bench.py --workload $w --steps 200 --warmup 10 --repeats 3 --sustained-seconds 0 --no-cpu-baseline --trained-iters 0 --no-c3-leg 2>/dev/null | tail -1 > gpurun_out/abenv_${VAR}_${v}_${w}_$rep.json
+  env $VAR=$v timeout 400 python bench.py --workload $w --steps 200 --warmup 10 --repeats 3 --sustained-seconds 0 --no-cpu-baseline --trained-iters 0 --no-c3-leg --no-pipeline-legs 2>/dev/null | tail -1 > gpurun_out/abenv_${VAR}_${v}_${w}_$rep.json
 done; done; done
 python3 - "$VAR" <<'PY'
 import glob, json, sys, os

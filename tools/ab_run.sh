@@ -9,7 +9,7 @@ for v in $1; do
  [ "$lib" = "default" ] && sfx="" || sfx="_$lib"
  tag=${v//[@,]/_}
  for w in $2; do
-  HGS_SEG_POLICY=$pol HGS_LIB=$PWD/hair-gs_amd/libhgs$sfx.so timeout 300 python bench.py --workload $w --steps 200 --warmup 10 --repeats 3 --sustained-seconds 0 --no-cpu-baseline --trained-iters 0 --no-c3-leg 2>/dev/null | tail -1 > gpurun_out/ab_${tag}_${w}_$rep.json
+  HGS_SEG_POLICY=$pol HGS_LIB=$PWD/hair-gs_amd/libhgs$sfx.so timeout 300 python bench.py --workload $w --steps 200 --warmup 10 --repeats 3 --sustained-seconds 0 --no-cpu-baseline --trained-iters 0 --no-c3-leg --no-pipeline-legs 2>/dev/null | tail -1 > gpurun_out/ab_${tag}_${w}_$rep.json
  done
 done
 done

@@ -7,16 +7,21 @@ sys.path[:0] = [ROOT, os.path.join(ROOT, "hair-gs_amd")]
 import numpy as np, torch
 import hgs_runtime as rt
 from arguments import OptimizationParams
-from synthetic import build_workload
+from synthetic import PIPELINE_STATES, build_pipeline_state, build_workload
 from train import training, training_step, ViewSampler
 from diff_gaussian_rasterization import _C
 from utils.general import safe_state
 safe_state(True)
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
 wl = sys.argv[2] if len(sys.argv) > 2 else "north_star"
-model, cams, extent = build_workload(wl, device=torch.device("cuda"), seed=0, n_views=8)
-opt = OptimizationParams()
-model.training_setup(opt)
+if wl in PIPELINE_STATES:      # (a state of the three-stage workflow: `iterations` is ignored, the state's own Stage-I loop runs)
+    model, cams, extent, _info = build_pipeline_state(wl, device="cuda", n_views=8)
+    n = 0
+    opt = OptimizationParams()
+else:
+    model, cams, extent = build_workload(wl, device=torch.device("cuda"), seed=0, n_views=8)
+    opt = OptimizationParams()
+    model.training_setup(opt)
 bg = torch.zeros(3, device="cuda")
 if n:
     training(model, cams, opt, iterations=n, extent=extent, seed=1)
