@@ -232,6 +232,8 @@ def roofline_block(kern, fs, W, H, ch, wl_tag):
     # not HBM; `valu_util` is the fraction of that limit in use.  null where no --pmc pass of THIS state is committed.
     roof = {"kernel": "blend_bwd_kernel", "bound": "hbm", "limited_by": None if valu_util is None else ("valu" if valu_util >= 0.5 else "hbm"),
             "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+            # the fraction of the resource that actually binds this kernel (vector-instruction issue: `limited_by`), beside `frac`
+            "valu_frac": valu_util,
             "peak_achievable": HBM_ACHIEVABLE_GBS, "frac_of_achievable": ach / HBM_ACHIEVABLE_GBS,
             "moved_bytes_model": moved_bwd, "moved_gbs": moved, "frac_moved": moved / HBM_PEAK_GBS,
             "tiles_read": fs["tiles_used"], "tiles": T,
@@ -293,9 +295,33 @@ def launcher_command(args, argv, port=None):
             "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + rest
 
 
+def visible_gpus():
+    """GPUs this process would see, counted WITHOUT a HIP call (the launcher must not initialise the runtime: it only starts the
+    ranks): the KFD topology's nodes with SIMDs, cut down by HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES.  None: unknown (no
+    topology to read although the driver is there) -- the ranks themselves refuse a world larger than their device count."""
+    import glob
+    n = 0
+    if not os.path.isdir("/sys/class/kfd"):
+        return 0                                         # no KFD driver: no GPU
+    nodes = glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties")
+    if not nodes:
+        return None
+    for f in nodes:
+        try:
+            props = dict(line.split()[:2] for line in open(f) if len(line.split()) >= 2)
+            n += int(props.get("simd_count", "0")) > 0
+        except OSError:
+            return None
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            n = min(n, len([x for x in v.split(",") if x.strip() != ""]))
+    return n
+
+
 def launch_ranks(args, argv):
-    """`python bench.py --gpus N` by itself: N RCCL ranks as a CHILD process (never exec: nothing of this process has touched
-    the GPU, and nothing will -- torch.cuda.device_count() does not initialise it on this image), the child's stdout (rank
+    """`python bench.py --gpus N` by itself: N RCCL ranks as a CHILD process (never exec; this process makes no HIP call at all:
+    the devices are counted from the KFD topology, visible_gpus), the child's stdout (rank
     0's JSON line) and stderr inherited, its return code ours.  Fewer visible devices than ranks is an ERROR, not a smaller
     run: a 1-rank line must never be recorded as an N-GPU point (HGS_BENCH_SHARE_GPU=1, the logic check that puts every rank
     on cuda:0 over gloo, is the one exception and says so in its line)."""
@@ -304,9 +330,8 @@ def launch_ranks(args, argv):
     if args.dry_launch:
         print(json.dumps({"launcher": cmd, "gpus": args.gpus}))
         return 0
-    import torch
-    have = torch.cuda.device_count()
-    if have < args.gpus and os.environ.get("HGS_BENCH_SHARE_GPU") != "1":
+    have = visible_gpus()
+    if have is not None and have < args.gpus and os.environ.get("HGS_BENCH_SHARE_GPU") != "1":
         print(f"bench.py: --gpus {args.gpus} needs {args.gpus} visible GPUs, this node shows {have} "
               "(no line printed: a smaller run is not an N-GPU measurement)", file=sys.stderr)
         return 2

@@ -68,6 +68,11 @@ class OptimizationParams(ParamGroup):
         ("growth_averaging_points", 3, False), ("percent_dense", 0.01, False), ("opacity_reset_interval", 3000, False),
         ("densify_from_iter", 500, False), ("densify_until_iter", 27000.0, False), ("densification_interval", 100, False),
         ("prune_max_radii_2d", 1000, False), ("densify_grad_threshold", 0.0002, False),
+        # ---- this package's own (not in the reference): the captured training loop (train.training / GraphedStep)
+        # views a (re-)capture warms up on: its binning capacity is capacity_slack x their largest instance count; a view that
+        # needs more is caught by the headroom check and the iterations since the last checkpoint are run again (exact, only time
+        # is lost): raise it for captures whose views differ much in coverage
+        ("capture_warmup_views", 2, False), ("capacity_slack", 2.0, False),
     )
 
     def _finalise(self):

@@ -5,20 +5,24 @@
 //   * no host round trips: min/max stay on the device (the reference does two blocking D2H copies);
 //   * the stable (code, index) sort is a sort by the unique 64-bit key code<<32|index -> plain bitonic network
 //     (LDS for strides < 4096, global otherwise); called once per run, P <= a few million;
-//   * points are gathered once into Morton order; the search runs one lane per point with WAVE-level box
-//     pruning: a box is visited if any lane of the wavefront needs it, and then its points are wave-uniform
-//     -> scalar loads.  Visiting extra boxes cannot change the 3 smallest distances, so the result is exactly
-//     the reference's (it is the exact 3-NN; only traversal differs).
+//   * points are gathered once into Morton order; the search (round 6) runs one lane per point over a GRID OF MORTON CELLS:
+//     the points that share the top 3 L bits of their code are one contiguous run of the sorted array and fill one cube, so a
+//     table of 8^L cells (first / last position, the cell's exact bounding box: one pass of integer atomics) is an octree level
+//     whose boxes do not overlap.  A lane walks its own cell first, then the cells of the cube range its radius -- min(reject,
+//     third-best so far) -- reaches, each behind the reference's box test on the cell's own box.  Rounds 1-5 tested boxes of
+//     1024 Morton-CONSECUTIVE points: such a run straddles the curve's jumps, its bounding box holds most of the scene, every
+//     point lies inside most boxes and the pruning pruned nothing (3.8 ms for 50 k points, 96 % of the call in the search).
+//     The three smallest distances of a point do not depend on the traversal, so the result is exactly the reference's (the
+//     exact 3-NN in its arithmetic).
 #include <float.h>
 
 #include "hgs_common.h"
 
 namespace {
 
-#define BOX_SIZE 1024
 #define KNN_LDS_KEYS 4096
 
-struct KnnScratch { float* minmax; uint64_t* keys; float4* sorted; float* boxes; };
+struct KnnScratch { float* minmax; uint64_t* keys; float4* sorted; uint32_t* cells; };   // cells: 8 words per cell
 
 __device__ __forceinline__ uint32_t prep_morton(uint32_t x) {
   x = (x | (x << 16)) & 0x030000FF;
@@ -33,14 +37,15 @@ __device__ __forceinline__ uint32_t f2u_sat(float v) {
   return (uint32_t)v;
 }
 
-// one block: component-wise min/max with init (0,0,0) (simple_knn.cu:192)
+// component-wise min/max with init (0,0,0) (simple_knn.cu:192): MM_BLOCKS partial results, folded by whoever reads them
+#define MM_BLOCKS 64
 __global__ __launch_bounds__(1024) void minmax_kernel(int P, const float* __restrict__ pts, float* __restrict__ mm) {
   __shared__ float red[16][6];
   float mn[3] = {0.f, 0.f, 0.f}, mx[3] = {0.f, 0.f, 0.f};
-  for (int i = threadIdx.x; i < P; i += 1024)
+  for (size_t i = (size_t)blockIdx.x * 1024 + threadIdx.x; i < (size_t)P; i += (size_t)MM_BLOCKS * 1024)
 #pragma unroll
     for (int k = 0; k < 3; k++) {
-      const float v = pts[3 * (size_t)i + k];
+      const float v = pts[3 * i + k];
       mn[k] = fminf(mn[k], v);
       mx[k] = fmaxf(mx[k], v);
     }
@@ -58,16 +63,23 @@ __global__ __launch_bounds__(1024) void minmax_kernel(int P, const float* __rest
   if (threadIdx.x < 6) {
     float v = red[0][threadIdx.x];
     for (int w = 1; w < 16; w++) v = threadIdx.x < 3 ? fminf(v, red[w][threadIdx.x]) : fmaxf(v, red[w][threadIdx.x]);
-    mm[threadIdx.x] = v;
+    mm[8 * (size_t)blockIdx.x + threadIdx.x] = v;
   }
 }
 
 __global__ __launch_bounds__(256) void morton_kernel(int P, int Npad, const float* __restrict__ pts,
                                                      const float* __restrict__ mm, uint64_t* __restrict__ keys) {
+  __shared__ float smm[6];
+  if (threadIdx.x < 6) {                      // min / max are exact: the order of folding the partial results does not matter
+    float v = mm[threadIdx.x];
+    for (int b = 1; b < MM_BLOCKS; b++) v = threadIdx.x < 3 ? fminf(v, mm[8 * b + threadIdx.x]) : fmaxf(v, mm[8 * b + threadIdx.x]);
+    smm[threadIdx.x] = v;
+  }
+  __syncthreads();
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= Npad) return;
   if (i >= P) { keys[i] = ~0ull; return; }
-  const float mnx = mm[0], mny = mm[1], mnz = mm[2], mxx = mm[3], mxy = mm[4], mxz = mm[5];
+  const float mnx = smm[0], mny = smm[1], mnz = smm[2], mxx = smm[3], mxy = smm[4], mxz = smm[5];
   const float x = pts[3 * (size_t)i], y = pts[3 * (size_t)i + 1], z = pts[3 * (size_t)i + 2];
   const uint32_t cx = prep_morton(f2u_sat(((x - mnx) / (mxx - mnx)) * 1023));
   const uint32_t cy = prep_morton(f2u_sat(((y - mny) / (mxy - mny)) * 1023));
@@ -117,33 +129,6 @@ __global__ __launch_bounds__(256) void gather_kernel(int P, const float* __restr
   sorted[i] = make_float4(pts[3 * (size_t)id], pts[3 * (size_t)id + 1], pts[3 * (size_t)id + 2], __uint_as_float(id));
 }
 
-// one 1024-thread block per box (simple_knn.cu:79-118): AABB of 1024 Morton-consecutive points
-__global__ __launch_bounds__(BOX_SIZE) void box_minmax_kernel(int P, const float4* __restrict__ sorted, float* __restrict__ boxes) {
-  __shared__ float red[16][6];
-  const int i = blockIdx.x * BOX_SIZE + threadIdx.x;
-  float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
-  if (i < P) {
-    const float4 p = sorted[i];
-    mn[0] = mx[0] = p.x; mn[1] = mx[1] = p.y; mn[2] = mx[2] = p.z;
-  }
-#pragma unroll
-  for (int k = 0; k < 3; k++)
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) {
-      mn[k] = fminf(mn[k], __shfl_xor(mn[k], d, 64));
-      mx[k] = fmaxf(mx[k], __shfl_xor(mx[k], d, 64));
-    }
-  const int wave = threadIdx.x >> 6;
-  if ((threadIdx.x & 63) == 0)
-    for (int k = 0; k < 3; k++) { red[wave][k] = mn[k]; red[wave][3 + k] = mx[k]; }
-  __syncthreads();
-  if (threadIdx.x < 6) {
-    float v = red[0][threadIdx.x];
-    for (int w = 1; w < 16; w++) v = threadIdx.x < 3 ? fminf(v, red[w][threadIdx.x]) : fmaxf(v, red[w][threadIdx.x]);
-    boxes[8 * (size_t)blockIdx.x + threadIdx.x] = v;
-  }
-}
-
 __device__ __forceinline__ void kbest3(float px, float py, float pz, float qx, float qy, float qz, float* knn) {
   const float dx = qx - px, dy = qy - py, dz = qz - pz;
   float dist = dx * dx + dy * dy + dz * dz;  // simple_knn.cu:135-136 (no contraction: built with -ffp-contract=off)
@@ -156,13 +141,58 @@ __device__ __forceinline__ void kbest3(float px, float py, float pz, float qx, f
   }
 }
 
-__global__ __launch_bounds__(256) void mean_dist_kernel(int P, const float4* __restrict__ sorted,
-                                                        const float* __restrict__ boxes, float* __restrict__ out) {
+// squared distance of a point to a box, exactly as distBoxPoint (simple_knn.cu:120-130)
+__device__ __forceinline__ float box_point_dist2(const float* bx, float x, float y, float z) {
+  float d0 = 0.f, d1 = 0.f, d2 = 0.f;
+  if (x < bx[0] || x > bx[3]) d0 = fminf(fabsf(x - bx[0]), fabsf(x - bx[3]));
+  if (y < bx[1] || y > bx[4]) d1 = fminf(fabsf(y - bx[1]), fabsf(y - bx[4]));
+  if (z < bx[2] || z > bx[5]) d2 = fminf(fabsf(z - bx[2]), fabsf(z - bx[5]));
+  return d0 * d0 + d1 * d1 + d2 * d2;
+}
+
+// ---- the cell table: per cell of level L (code >> (30 - 3 L)) [first, end) in the sorted array and the points' bounding box.
+// Floats are kept as order-preserving integers so that min / max are integer atomics (exact, order-independent).
+__device__ __forceinline__ int fkey(float v) { const int b = __float_as_int(v); return b >= 0 ? b : b ^ 0x7FFFFFFF; }   // monotone: a < b <=> fkey(a) < fkey(b)
+__device__ __forceinline__ float funkey(int k) { return __int_as_float(k >= 0 ? k : k ^ 0x7FFFFFFF); }
+
+__global__ __launch_bounds__(256) void cells_clear_kernel(uint32_t n_cells, uint32_t* __restrict__ cells) {
+  const uint32_t c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= n_cells) return;
+  uint4* t = (uint4*)(cells + 8 * (size_t)c);
+  t[0] = make_uint4(0u, 0u, (uint32_t)0x7FFFFFFF, (uint32_t)0x7FFFFFFF);              // first, end, min x, min y
+  t[1] = make_uint4((uint32_t)0x7FFFFFFF, 0x80000000u, 0x80000000u, 0x80000000u);     // min z, max x, max y, max z
+}
+__global__ __launch_bounds__(256) void cells_mark_kernel(int P, int shift, const uint64_t* __restrict__ keys,
+                                                         const float4* __restrict__ sorted, uint32_t* __restrict__ cells) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= P) return;
+  const uint32_t c = (uint32_t)(keys[i] >> 32) >> shift;
+  const bool first = i == 0 || ((uint32_t)(keys[i - 1] >> 32) >> shift) != c;
+  const bool last = i == P - 1 || ((uint32_t)(keys[i + 1] >> 32) >> shift) != c;
+  uint32_t* t = cells + 8 * (size_t)c;
+  if (first) t[0] = (uint32_t)i;
+  if (last) t[1] = (uint32_t)i + 1u;
+  const float4 p = sorted[i];
+  atomicMin((int*)&t[2], fkey(p.x)); atomicMin((int*)&t[3], fkey(p.y)); atomicMin((int*)&t[4], fkey(p.z));
+  atomicMax((int*)&t[5], fkey(p.x)); atomicMax((int*)&t[6], fkey(p.y)); atomicMax((int*)&t[7], fkey(p.z));
+}
+
+// One lane per point of the sorted array.  `mm`: the MM_BLOCKS partial min / max (the Morton kernel's quantisation).
+__global__ __launch_bounds__(256) void mean_dist_kernel(int P, int L, const float4* __restrict__ sorted,
+                                                        const uint64_t* __restrict__ keys, const uint32_t* __restrict__ cells,
+                                                        const float* __restrict__ mm, float* __restrict__ out) {
+  __shared__ float smm[6];
+  if (threadIdx.x < 6) {
+    float v = mm[threadIdx.x];
+    for (int b = 1; b < MM_BLOCKS; b++) v = threadIdx.x < 3 ? fminf(v, mm[8 * b + threadIdx.x]) : fmaxf(v, mm[8 * b + threadIdx.x]);
+    smm[threadIdx.x] = v;
+  }
+  __syncthreads();
   const int idx = blockIdx.x * 256 + threadIdx.x;
-  const bool active = idx < P;
-  const float4 me = sorted[active ? idx : P - 1];
+  if (idx >= P) return;
+  const float4 me = sorted[idx];
   float best[3] = {FLT_MAX, FLT_MAX, FLT_MAX};
-  if (active) {
+  {
     const int lo = max(0, idx - 3), hi = min(P - 1, idx + 3);
     for (int i = lo; i <= hi; i++) {
       if (i == idx) continue;
@@ -170,33 +200,60 @@ __global__ __launch_bounds__(256) void mean_dist_kernel(int P, const float4* __r
       kbest3(me.x, me.y, me.z, q.x, q.y, q.z, best);
     }
   }
-  const float reject = best[2];
+  const float reject = best[2];               // simple_knn.cu:163-165: a box farther than this holds none of the three nearest
   best[0] = best[1] = best[2] = FLT_MAX;
-  const int nb = (P + BOX_SIZE - 1) / BOX_SIZE;
-  for (int b = 0; b < nb; b++) {
-    const float* bx = boxes + 8 * (size_t)b;
-    float d0 = 0.f, d1 = 0.f, d2 = 0.f;  // distBoxPoint, simple_knn.cu:120-130
-    if (me.x < bx[0] || me.x > bx[3]) d0 = fminf(fabsf(me.x - bx[0]), fabsf(me.x - bx[3]));
-    if (me.y < bx[1] || me.y > bx[4]) d1 = fminf(fabsf(me.y - bx[1]), fabsf(me.y - bx[4]));
-    if (me.z < bx[2] || me.z > bx[5]) d2 = fminf(fabsf(me.z - bx[2]), fabsf(me.z - bx[5]));
-    const float dist = d0 * d0 + d1 * d1 + d2 * d2;
-    const bool need = active && !(dist > reject || dist > best[2]);
-    if (__ballot(need) == 0) continue;  // wave-uniform
-    const int i0 = b * BOX_SIZE, i1 = min(P, (b + 1) * BOX_SIZE);
-    for (int i = i0; i < i1; i++) {
-      const float4 q = sorted[i];  // wave-uniform address -> scalar load
-      if (i != idx) kbest3(me.x, me.y, me.z, q.x, q.y, q.z, best);
+  const int shift = 30 - 3 * L;
+  auto walk_cell = [&](uint32_t c) {
+    const uint4 h0 = *(const uint4*)(cells + 8 * (size_t)c), h1 = *(const uint4*)(cells + 8 * (size_t)c + 4);
+    if (h0.x == h0.y) return;                                           // empty
+    const float bx[6] = {funkey((int)h0.z), funkey((int)h0.w), funkey((int)h1.x), funkey((int)h1.y), funkey((int)h1.z), funkey((int)h1.w)};
+    const float dist = box_point_dist2(bx, me.x, me.y, me.z);
+    if (dist > reject || dist > best[2]) return;                        // simple_knn.cu:173-175
+    for (uint32_t i = h0.x; i < h0.y; i++) {
+      const float4 q = sorted[i];
+      if ((int)i != idx) kbest3(me.x, me.y, me.z, q.x, q.y, q.z, best);
     }
+  };
+  // the own cell first: after it the third-best distance is (nearly always) the true one
+  const uint32_t own = (uint32_t)(keys[idx] >> 32) >> shift;
+  walk_cell(own);
+  // the cube of cells the radius reaches.  The quantisation q(x) of the Morton kernel is monotone in x, so every point within
+  // r of this one along an axis has its cell coordinate between q(x - r) and q(x + r).
+  const float r2 = fminf(reject, best[2]);
+  const float r = sqrtf(r2) * 1.000001f;
+  const int cshift = 10 - L;
+  int lo[3], hi[3];
+  const float pc[3] = {me.x, me.y, me.z};
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    const float mn = smm[k], mx = smm[3 + k];
+    lo[k] = (int)(min(f2u_sat(((pc[k] - r - mn) / (mx - mn)) * 1023), 1023u) >> cshift);
+    hi[k] = (int)(min(f2u_sat(((pc[k] + r - mn) / (mx - mn)) * 1023), 1023u) >> cshift);
+    if (!(r < FLT_MAX)) { lo[k] = 0; hi[k] = (1 << L) - 1; }            // (fewer than four points: no radius yet)
   }
-  if (active) out[__float_as_uint(me.w)] = (best[0] + best[1] + best[2]) / 3.0f;
+  for (int cz = lo[2]; cz <= hi[2]; cz++)
+    for (int cy = lo[1]; cy <= hi[1]; cy++)
+      for (int cx = lo[0]; cx <= hi[0]; cx++) {
+        const uint32_t c = (prep_morton((uint32_t)cx << cshift) | (prep_morton((uint32_t)cy << cshift) << 1) |
+                            (prep_morton((uint32_t)cz << cshift) << 2)) >> shift;
+        if (c != own) walk_cell(c);
+      }
+  out[__float_as_uint(me.w)] = (best[0] + best[1] + best[2]) / 3.0f;
+}
+
+// level of the cell grid: about 16 points per cell of a uniform cloud (clustered data fills fewer, fuller cells)
+static int knn_level(size_t P) {
+  int L = 1;
+  while (L < 7 && ((size_t)1 << (3 * (L + 1))) * 16 <= P) L++;
+  return L;
 }
 
 size_t knn_carve(char* base, size_t P, size_t Npad, KnnScratch& s) {
   char* cur = base;
-  hgs_carve(cur, s.minmax, 8);
+  hgs_carve(cur, s.minmax, 8 * MM_BLOCKS);
   hgs_carve(cur, s.keys, Npad);
   hgs_carve(cur, s.sorted, P + 1);
-  hgs_carve(cur, s.boxes, 8 * ((P + BOX_SIZE - 1) / BOX_SIZE + 1));
+  hgs_carve(cur, s.cells, 8 * ((size_t)1 << (3 * knn_level(P))));
   return hgs_align_up((size_t)(cur - base)) + HGS_ALIGN;
 }
 size_t pad_pow2(size_t P) {
@@ -221,7 +278,7 @@ int hgs_launch_dist2(hipStream_t st, int P, const float* points, float* out, voi
     return 1;
   }
   HgsProfScope _prof(st, HGS_K_KNN);
-  hipLaunchKernelGGL(minmax_kernel, dim3(1), dim3(1024), 0, st, P, points, s.minmax);
+  hipLaunchKernelGGL(minmax_kernel, dim3(MM_BLOCKS), dim3(1024), 0, st, P, points, s.minmax);
   hipLaunchKernelGGL(morton_kernel, dim3((unsigned)((Npad + 255) / 256)), dim3(256), 0, st, P, (int)Npad, points, s.minmax, s.keys);
   const unsigned nchunks = (unsigned)(Npad / KNN_LDS_KEYS);
   hipLaunchKernelGGL(bitonic_lds_kernel, dim3(nchunks), dim3(1024), 0, st, s.keys, 0, 0, true);
@@ -231,10 +288,12 @@ int hgs_launch_dist2(hipStream_t st, int P, const float* points, float* out, voi
       hipLaunchKernelGGL(bitonic_global_kernel, dim3((unsigned)((Npad / 2 + 255) / 256)), dim3(256), 0, st, s.keys, Npad / 2, (int)k, (int)j);
     hipLaunchKernelGGL(bitonic_lds_kernel, dim3(nchunks), dim3(1024), 0, st, s.keys, (int)k, (int)j, false);
   }
-  const unsigned nb = (unsigned)((P + BOX_SIZE - 1) / BOX_SIZE);
+  const int L = knn_level((size_t)P);
+  const unsigned n_cells = 1u << (3 * L);
   hipLaunchKernelGGL(gather_kernel, dim3((P + 255) / 256), dim3(256), 0, st, P, points, s.keys, s.sorted);
-  hipLaunchKernelGGL(box_minmax_kernel, dim3(nb), dim3(BOX_SIZE), 0, st, P, s.sorted, s.boxes);
-  hipLaunchKernelGGL(mean_dist_kernel, dim3((P + 255) / 256), dim3(256), 0, st, P, s.sorted, s.boxes, out);
+  hipLaunchKernelGGL(cells_clear_kernel, dim3((n_cells + 255) / 256), dim3(256), 0, st, n_cells, s.cells);
+  hipLaunchKernelGGL(cells_mark_kernel, dim3((P + 255) / 256), dim3(256), 0, st, P, 30 - 3 * L, s.keys, s.sorted, s.cells);
+  hipLaunchKernelGGL(mean_dist_kernel, dim3((P + 255) / 256), dim3(256), 0, st, P, L, s.sorted, s.keys, s.cells, s.minmax, out);
   HGS_CHECK_LAUNCH();
   return 0;
 }

@@ -6,10 +6,53 @@ import torch
 
 from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
 
+_ZEROS = {}      # (P, device) -> zeros [P, 3]: "viewspace_points" of forward-only calls
+_EMPTY = {}      # device -> 0-element tensor (an absent optional input of the native module)
+
+
+def _tanfov(cam):
+    """(tan(FoVx / 2), tan(FoVy / 2)) of a camera, remembered on it for as long as its field of view is what it was."""
+    c = getattr(cam, "_hgs_tanfov", None)
+    if c is None or c[0] != cam.FoVx or c[1] != cam.FoVy:
+        c = (cam.FoVx, cam.FoVy, math.tan(cam.FoVx * 0.5), math.tan(cam.FoVy * 0.5))
+        try:
+            cam._hgs_tanfov = c
+        except AttributeError:
+            pass
+    return c[2], c[3]
+
+
+def _render_forward_only(viewpoint_camera, pc, bg_color, scaling_modifier):
+    """render() with gradients off and the default options -- a frame of an evaluation / viewer loop (reference render.py:60-82,
+    utils/visualization.py:43): the same native call with the same arguments, without the objects that only autograd needs (the
+    zero tensor that would receive dL/dmean2D is one shared tensor of zeros, no autograd.Function, no nn.Module per frame).
+    Host time per frame was 0.115 ms for 0.067 ms of kernels (tools/dev/render_host_profile.py)."""
+    from diff_gaussian_rasterization import _C
+    xyz, scales_d, rotations_d = _geometry(pc)
+    dev = xyz.device
+    key = (xyz.shape[0], dev)
+    zeros = _ZEROS.get(key)
+    if zeros is None:
+        if len(_ZEROS) > 8:
+            _ZEROS.clear()
+        zeros = _ZEROS[key] = torch.zeros_like(xyz)
+    empty = _EMPTY.get(dev)
+    if empty is None:
+        empty = _EMPTY[dev] = torch.empty(0, device=dev)
+    tanfovx, tanfovy = _tanfov(viewpoint_camera)
+    _, color, radii, _, _, _ = _C.rasterize_gaussians_culled(
+        bg_color, xyz, empty, pc.get_opacity, scales_d(), rotations_d(), scaling_modifier, empty,
+        viewpoint_camera.world_view_transform, viewpoint_camera.full_proj_transform, tanfovx, tanfovy,
+        int(viewpoint_camera.image_height), int(viewpoint_camera.image_width), pc.get_features, pc.active_sh_degree,
+        viewpoint_camera.camera_center, False, False)
+    return {"render": color, "viewspace_points": zeros, "visibility_filter": radii > 0, "radii": radii}
+
 
 def render(viewpoint_camera, pc, bg_color, scaling_modifier=1.0, override_color=None, debug=False,
            compute_cov3D_python=False, convert_SHs_python=False):
     """Render the scene.  `bg_color` must live on the GPU."""
+    if not (torch.is_grad_enabled() or debug or compute_cov3D_python or convert_SHs_python or override_color is not None):
+        return _render_forward_only(viewpoint_camera, pc, bg_color, scaling_modifier)
     xyz, scales_d, rotations_d = _geometry(pc)
     # zero tensor whose gradient receives dL/d(screen-space mean) (reference :41-50), read by the densification stats
     if torch.is_grad_enabled():
@@ -20,8 +63,7 @@ def render(viewpoint_camera, pc, bg_color, scaling_modifier=1.0, override_color=
             pass
     else:       # forward-only call: the same zeros, nothing to retain a gradient for
         screenspace_points = torch.zeros_like(xyz)
-    tanfovx = math.tan(viewpoint_camera.FoVx * 0.5)
-    tanfovy = math.tan(viewpoint_camera.FoVy * 0.5)
+    tanfovx, tanfovy = _tanfov(viewpoint_camera)
     raster_settings = GaussianRasterizationSettings(
         image_height=int(viewpoint_camera.image_height), image_width=int(viewpoint_camera.image_width),
         tanfovx=tanfovx, tanfovy=tanfovy, bg=bg_color, scale_modifier=scaling_modifier,

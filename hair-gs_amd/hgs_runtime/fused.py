@@ -20,24 +20,32 @@ def gaussian_window11():
     return _WINDOW
 
 
+def _strand_geometry_launch(endpoints, width, pairs, factor):
+    endpoints = rt.require_gpu_tensor(endpoints, "endpoints", torch.float32)
+    width = rt.require_gpu_tensor(width, "width", torch.float32)
+    pairs = rt.require_gpu_tensor(pairs, "endpoint_pairs", torch.int64)
+    P, dev = pairs.shape[0], endpoints.device
+    # one allocation for the four outputs (13 floats per segment; every view 16-byte aligned)
+    buf = torch.empty((13 * P + 12,), dtype=torch.float32, device=dev)
+    o = [0, (3 * P + 3) // 4 * 4]
+    o.append(o[1] + (3 * P + 3) // 4 * 4)
+    o.append(o[2] + 4 * P)
+    xyz, scale = buf[o[0]:o[0] + 3 * P].view(P, 3), buf[o[1]:o[1] + 3 * P].view(P, 3)
+    quat, direction = buf[o[2]:o[2] + 4 * P].view(P, 4), buf[o[3]:o[3] + 3 * P].view(P, 3)
+    with torch.cuda.device(dev):
+        rt.check(rt.lib().hgs_strand_geometry_forward(rt.current_stream(), P, rt.ptr(endpoints), rt.ptr(pairs),
+                                                      rt.ptr(width), float(factor), rt.ptr(xyz), rt.ptr(scale),
+                                                      rt.ptr(quat), rt.ptr(direction)))
+    return endpoints, width, pairs, (xyz, scale, quat, direction)
+
+
 class _StrandGeometry(torch.autograd.Function):
     @staticmethod
     def forward(ctx, endpoints, width, pairs, factor):
-        endpoints = rt.require_gpu_tensor(endpoints, "endpoints", torch.float32)
-        width = rt.require_gpu_tensor(width, "width", torch.float32)
-        pairs = rt.require_gpu_tensor(pairs, "endpoint_pairs", torch.int64)
-        P, dev = pairs.shape[0], endpoints.device
-        xyz = torch.empty((P, 3), dtype=torch.float32, device=dev)
-        scale = torch.empty((P, 3), dtype=torch.float32, device=dev)
-        quat = torch.empty((P, 4), dtype=torch.float32, device=dev)
-        direction = torch.empty((P, 3), dtype=torch.float32, device=dev)
-        with torch.cuda.device(dev):
-            rt.check(rt.lib().hgs_strand_geometry_forward(rt.current_stream(), P, rt.ptr(endpoints), rt.ptr(pairs),
-                                                          rt.ptr(width), float(factor), rt.ptr(xyz), rt.ptr(scale),
-                                                          rt.ptr(quat), rt.ptr(direction)))
+        endpoints, width, pairs, out = _strand_geometry_launch(endpoints, width, pairs, factor)
         ctx.save_for_backward(endpoints, width, pairs)
         ctx.factor = float(factor)
-        return xyz, scale, quat, direction
+        return out
 
     @staticmethod
     def backward(ctx, g_xyz, g_scale, g_quat, g_dir):
@@ -55,6 +63,8 @@ class _StrandGeometry(torch.autograd.Function):
 
 def strand_geometry(endpoints, width, pairs, factor):
     """(xyz[P,3], scale[P,3], quat[P,4], direction[P,3]) of every segment, differentiable w.r.t. endpoints/width."""
+    if not torch.is_grad_enabled():          # forward-only (render loops): the launch without an autograd node around it
+        return _strand_geometry_launch(endpoints, width, pairs, factor)[3]
     return _StrandGeometry.apply(endpoints, width, pairs, factor)
 
 
@@ -199,8 +209,18 @@ class FusedAdam(torch.optim.Optimizer):
                 rows.append((p, st["exp_avg"], st["exp_avg_sq"], self._lr_tensor(gi, group, p.device), st["step"], group))
         key = tuple(t.data_ptr() for r in rows for t in r[:5])
         if self._plan is None or self._plan.key != key:
+            if torch.cuda.is_current_stream_capturing():
+                # a new plan allocates and uploads from pageable memory: not capturable -- and a graph captured with the OLD plan
+                # would go on writing its (freed) tables.  Whoever captures builds the plan first (train.GraphedStep does).
+                raise rt.HgsError("FusedAdam.inline_plan(): a parameter / moment / learning-rate tensor was replaced during a "
+                                  "graph capture; build the plan (enable_inline_adam) before capturing")
             self._plan = _InlinePlan(self, rows, key)
         return self._plan
+
+    def zero_grad(self, set_to_none=True):
+        # an in-lane update that no step() consumed (a backward without an optimizer step) must not swallow a later step()
+        self._inline_done = False
+        return super().zero_grad(set_to_none=set_to_none)
 
     def _state_for(self, p):
         st = self.state[p]

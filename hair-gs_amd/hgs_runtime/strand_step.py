@@ -401,6 +401,15 @@ class _StrandIteration(torch.autograd.Function):
         factor = float(g.dist_to_scale_factor)
         stream = rt.current_stream()
         step.refresh_inline_plan()
+        # ONE decision for the whole iteration: when the prologue carries the optimizer's plan (it advances the step counters on
+        # the device), the backward MUST apply the update in its lanes -- or Adam's launch would advance them a second time
+        ctx.use_inline = step.inline_plan() is not None
+        if ctx.use_inline:
+            step.inline_adam._inline_done = False
+            if not (step.fuse_param_backward and P > 0 and step.ep_segments is not None and step.ep_segments.shape[0] == E):
+                raise rt.HgsError("in-lane Adam is enabled but this iteration's backward cannot apply it (no segments, the fused "
+                                  "parameter backward off, or an endpoint adjacency that predates a topology change: call "
+                                  "refresh()); disable it with enable_inline_adam(False)")
         idx = step.smooth_pairs
         hp = step.head
         # the smoothness term rides in extra workgroups of the parameter kernels (HgsStrandFusion)
@@ -469,7 +478,7 @@ class _StrandIteration(torch.autograd.Function):
             pb.seg_contrib, pb.d_width, pb.extra4 = rt.ptr(seg_contrib), rt.ptr(d_w), rt.ptr(extra4)
             pb.d_opacity_raw, pb.d_mask_raw = rt.ptr(d_o), rt.ptr(d_m)
             _params_stats(step, pb)
-            plan = step.inline_plan()
+            plan = step.inline_plan() if ctx.use_inline else None
             ep_adam = None
             if plan is not None:      # Adam in the backward's own lanes (include/hgs.h HgsAdamSlot)
                 plan.fill(pb.adam, (g._width, g._opacity, g._mask, g._features_dc))
@@ -500,6 +509,8 @@ class _StrandIteration(torch.autograd.Function):
             else:
                 d_dc, d_rest = g_sh[:, :1], g_sh[:, 1:]
             return d_ep, d_w, d_o, d_m, d_dc, d_rest, None
+        if ctx.use_inline:
+            raise rt.HgsError("the forward's prologue advanced Adam's step counters for an in-lane update this backward cannot apply")
         go, (g_means2D, g_ex, g_opac, g_means3D, g_sh, g_scales, g_rot) = _head_raster_backward(
             ctx, step, go, xyz, scale, quat, shs, planes, radii, geom, binning, img, scratch, out, endpoints,
             None if gather else d_ep, E)
@@ -660,6 +671,12 @@ class _CloudIteration(torch.autograd.Function):
         fu = rt.StrandFusion()
         vt = step.views
         step.refresh_inline_plan()
+        ctx.use_inline = step.inline_plan() is not None      # (one decision per iteration: see _StrandIteration.forward)
+        if ctx.use_inline:
+            step.inline_adam._inline_done = False
+            if not (step.fuse_param_backward and P > 0):
+                raise rt.HgsError("in-lane Adam is enabled but this iteration's backward cannot apply it (no Gaussians, or the "
+                                  "fused parameter backward off); disable it with enable_inline_adam(False)")
         if step.fuse_preprocess:      # (as _StrandIteration: parameters -> Gaussians -> preprocess as one launch)
             def fill(fused):
                 if fused and not vt.counts_clean:
@@ -704,7 +721,7 @@ class _CloudIteration(torch.autograd.Function):
             pb.d_means3D, pb.d_scaling_raw, pb.d_rotation_raw = rt.ptr(g_means3D), rt.ptr(d_s), rt.ptr(d_r)
             pb.d_opacity_raw, pb.d_mask_raw = rt.ptr(d_o), rt.ptr(d_m)
             _params_stats(step, pb)
-            plan = step.inline_plan()
+            plan = step.inline_plan() if ctx.use_inline else None
             if plan is not None:      # Adam in the backward's own lanes (include/hgs.h HgsAdamSlot)
                 gm = step.gaussians
                 plan.fill(pb.adam, (gm._xyz, gm._scaling, gm._rotation, gm._opacity, gm._mask, gm._features_dc))
@@ -720,6 +737,8 @@ class _CloudIteration(torch.autograd.Function):
             else:
                 d_dc, d_rest = g_sh[:, :1], g_sh[:, 1:]
             return g_means3D, d_s, d_r, d_o, d_m, d_dc, d_rest, None
+        if ctx.use_inline:
+            raise rt.HgsError("the forward's prologue advanced Adam's step counters for an in-lane update this backward cannot apply")
         go, (g_means2D, g_ex, g_opac, g_means3D, g_sh, g_scales, g_rot) = _head_raster_backward(
             ctx, step, go, xyz, scale, quat, shs, planes, radii, geom, binning, img, scratch, out, None, None, 0)
         fu = rt.StrandFusion()

@@ -405,6 +405,21 @@ class HairGaussianModel(HairTopologyMixin, GaussianModel):
 
     _storage_dirty = False
     _strands_dev = None
+    _strands_info = None
+
+    @property
+    def strands_info(self):
+        return self._strands_info
+
+    @strands_info.setter
+    def strands_info(self, value):
+        # the device copies of the strand tables (`_strands_dev`) and the smoothness pair table built from them describe the
+        # strands_info they were made WITH: whoever assigns a new one starts without them (compute_strands_info and
+        # sort_spatially put their device tables back right after the assignment) -- a table of equal size from an older
+        # topology can then never be taken for the current one
+        self._strands_info = value
+        self._strands_dev = None
+        self._smooth_pairs = None
 
     def _maybe_sort_spatially(self):
         """training_args.spatial_sort (default on) for a model on the GPU, once the operators of an iteration have changed

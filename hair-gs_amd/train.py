@@ -527,8 +527,12 @@ class GraphedStep:
         g.optimizer.zero_grad(set_to_none=True)
         if _LAST_CAPTURE_CAP.get(dev_key) not in (None, raster._state["cap"]):
             # the capacity (as the warm-up has just settled it) is in another bucket than the previous capture's: nothing the
-            # allocator has cached for the old one fits any more
-            release_graph_pool(g.get_xyz.device)
+            # allocator has cached for the old one fits any more.  Handing it back costs the next passes their hipMallocs
+            # (tens of ms per event: tools/soak.py 2.4 -> 3.1 s when done at every bucket change), so it waits until the
+            # cache holds a quarter of the device's memory -- never on a 100 k - 500 k-segment run, every few events at 1 M
+            free_b, total_b = torch.cuda.mem_get_info(g.get_xyz.device)
+            if torch.cuda.memory_reserved(g.get_xyz.device) > float(getattr(self.opt, "release_cache_fraction", 0.25)) * total_b:
+                release_graph_pool(g.get_xyz.device)
         for dst, src in zip((g.max_radii2D, g.xyz_gradient_accum, g.denom), saved_stats):
             dst.copy_(src)
         self.loss_buf = None
@@ -560,6 +564,9 @@ class GraphedStep:
 
         # (the warm-up above ran with the optimizer untouched; the captured iterations update in the backward's lanes where possible)
         self.inline_adam = (self.fused is not None and not multi and world == 1 and self.fused.enable_inline_adam(True))
+        # (the graphs bake the plan's device tables into their nodes: they stay alive as long as the graphs do, whatever the
+        # optimizer does with its own reference)
+        self._plan_keep = self.fused.inline_plan() if self.inline_adam else None
         ga = torch.cuda.CUDAGraph(keep_graph=True) if self._prologue_in_graph else torch.cuda.CUDAGraph()
         pool = graph_pool(g.get_xyz.device)
         with lean_graph_capture(ga, s, pool=pool, **mode):

@@ -4,7 +4,7 @@ last_n: average only the LAST n dispatches of every kernel (rows ordered by disp
 process also holds the N training iterations in front of the passes that are to be measured."""
 import csv, glob, collections, json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-keys = ['blend_fwd_kernel<7>', 'blend_bwd_kernel<7>', 'sort_tiles_kernel', 'preprocess_fwd_kernel', 'scatter_kernel',
+keys = ['blend_fwd_kernel<7>', 'blend_bwd_kernel<7>', 'sort_tiles_kernel', 'preprocess_fwd_kernel', 'scatter_kernel', 'row_reduce_kernel',
         'preprocess_bwd_kernel']
 agg = {k: collections.defaultdict(list) for k in keys}
 dur = {k: [] for k in keys}

@@ -34,21 +34,36 @@ def psnr():
 
 p0, n0 = psnr(), model.get_xyz.shape[0]
 done, t0, rollbacks = 0, time.perf_counter(), 0
+# PSNR is sampled 100 iterations in front of every opacity reset and 500 behind it -- never ON the reset iteration, where every
+# opacity has just been clamped to 0.01 (reference train.py:188-190) and the number says nothing (round 5's log: 19.13 -> 16.92 dB
+# "at it. 3000"); sampling is outside the timed chunks
+reset = int(opt.opacity_reset_interval)
+samples, t_psnr, events = {}, 0.0, []
 while done < iters:
-    n = min(500, iters - done)
+    marks = [m for m in (k * reset - 100 for k in range(1, iters // reset + 2)) if done < m < iters] + \
+            [m for m in (k * reset + 500 for k in range(1, iters // reset + 2)) if done < m < iters]
+    n = min([500 - done % 500, iters - done] + [m - done for m in marks])
     if os.environ.get("SOAK_PROFILE") and done + n >= iters:      # cProfile of the last chunk
         import cProfile, pstats
         pr = cProfile.Profile(); pr.enable()
         ema = training(model, cams, opt, iterations=n, extent=extent, start_iteration=done)
         pr.disable(); pstats.Stats(pr).sort_stats("cumulative").print_stats(45)
     else:
-        ema = training(model, cams, opt, iterations=n, extent=extent, start_iteration=done)
+        ema = training(model, cams, opt, iterations=n, extent=extent, start_iteration=done, event_log=events if os.environ.get("SOAK_EVENTS") else None)
     done += n
     rollbacks += int(getattr(training, "last_rollbacks", 0) or 0)
     torch.cuda.synchronize()
-    print(f"[it {done}] loss(ema) {float(ema):.5f}  segments {model.get_xyz.shape[0]}  elapsed {time.perf_counter() - t0:.2f} s", flush=True)
-dt = time.perf_counter() - t0
+    if done % 500 == 0 or done == iters:
+        print(f"[it {done}] loss(ema) {float(ema):.5f}  segments {model.get_xyz.shape[0]}  elapsed {time.perf_counter() - t0 - t_psnr:.2f} s", flush=True)
+    if done in marks:
+        tp = time.perf_counter()
+        samples[done] = psnr()
+        t_psnr += time.perf_counter() - tp
+        print(f"[it {done}] PSNR {samples[done]:.2f} dB ({'100 iterations in front of' if (done + 100) % reset == 0 else '500 iterations behind'} an opacity reset)", flush=True)
+dt = time.perf_counter() - t0 - t_psnr
 p1 = psnr()
+for e in events:
+    print("event", e)
 pos = model._endpoints if hasattr(model, "_endpoints") else model._xyz
 assert all(bool(torch.isfinite(p).all()) for p in (pos, model._opacity, model._features_dc)), "non-finite parameters"
 print(f"{wl}: {iters} iterations in {dt:.2f} s = {iters / dt:.0f} it/s incl. topology operators and re-captures; "

@@ -6,10 +6,14 @@ sys.path[:0] = [ROOT, os.path.join(ROOT, "hair-gs_amd")]
 import numpy as np, torch
 import hgs_runtime as rt
 from gaussian_renderer import render_multi
-from synthetic import build_workload
+from synthetic import PIPELINE_STATES, build_pipeline_state, build_workload
 wl = sys.argv[1] if len(sys.argv) > 1 else "north_star"
 n_train = int(sys.argv[2]) if len(sys.argv) > 2 else 0   # trace the state this many iterations of the FULL loop leave
-model, cams, extent = build_workload(wl, device="cuda", with_targets=n_train > 0, n_views=8 if n_train else 4)
+if wl in PIPELINE_STATES:     # a state of the three-stage workflow (its own Stage-I loop runs here; `n_train` is ignored)
+    model, cams, extent, _info = build_pipeline_state(wl, device="cuda", n_views=8)
+    n_train = 0
+else:
+    model, cams, extent = build_workload(wl, device="cuda", with_targets=n_train > 0, n_views=8 if n_train else 4)
 bg = torch.zeros(3, device="cuda")
 if n_train:
     from arguments import OptimizationParams
