@@ -28,6 +28,9 @@ def _render_forward_only(viewpoint_camera, pc, bg_color, scaling_modifier):
     zero tensor that would receive dL/dmean2D is one shared tensor of zeros, no autograd.Function, no nn.Module per frame).
     Host time per frame was 0.115 ms for 0.067 ms of kernels (tools/dev/render_host_profile.py)."""
     from diff_gaussian_rasterization import _C
+    if getattr(pc, "fused_geometry", False) and hasattr(pc, "endpoint_pairs") and pc._endpoints.is_cuda \
+            and pc.endpoint_pairs.shape[0] > 0 and scaling_modifier == 1.0:
+        return _render_strands_forward_only(viewpoint_camera, pc, bg_color, _C)
     xyz, scales_d, rotations_d = _geometry(pc)
     dev = xyz.device
     key = (xyz.shape[0], dev)
@@ -45,6 +48,38 @@ def _render_forward_only(viewpoint_camera, pc, bg_color, scaling_modifier):
         viewpoint_camera.world_view_transform, viewpoint_camera.full_proj_transform, tanfovx, tanfovy,
         int(viewpoint_camera.image_height), int(viewpoint_camera.image_width), pc.get_features, pc.active_sh_degree,
         viewpoint_camera.camera_center, False, False)
+    return {"render": color, "viewspace_points": zeros, "visibility_filter": radii > 0, "radii": radii}
+
+
+def _render_strands_forward_only(viewpoint_camera, pc, bg_color, _C):
+    """The forward-only frame of a strand model: the segments' Gaussians (geometry, sigmoid of the opacity) are derived by the
+    rasterizer's own first launch from the strand parameters (diff_gaussian_rasterization._C.HairSource: the launch
+    gaussian_renderer.frames and the training iteration use -- the same bits as derived_gaussians() + get_opacity,
+    tests/test_gpu_frames.py) instead of by three launches in front of it."""
+    dev = pc._endpoints.device
+    P = pc.endpoint_pairs.shape[0]
+    f32 = dict(dtype=torch.float32, device=dev)
+    buf = torch.empty((11 * P + 8,), **f32)            # xyz | scale | quat | opacity, each 16-byte aligned
+    a = (3 * P + 3) // 4 * 4
+    xyz, scale = buf[0:3 * P].view(P, 3), buf[a:a + 3 * P].view(P, 3)
+    quat, opacity = buf[2 * a:2 * a + 4 * P].view(P, 4), buf[2 * a + 4 * P:2 * a + 5 * P].view(P, 1)
+    key = (P, dev)
+    zeros = _ZEROS.get(key)
+    if zeros is None:
+        if len(_ZEROS) > 8:
+            _ZEROS.clear()
+        zeros = _ZEROS[key] = torch.zeros((P, 3), **f32)
+    empty = _EMPTY.get(dev)
+    if empty is None:
+        empty = _EMPTY[dev] = torch.empty(0, device=dev)
+    tanfovx, tanfovy = _tanfov(viewpoint_camera)
+    hair = _C.HairSource(pc._endpoints, pc.endpoint_pairs, pc._width, pc.dist_to_scale_factor, pc._opacity, pc._mask)
+    # (get_features is cat(dc, rest): with no higher-order coefficients the DC tensor itself is that array)
+    shs = pc._features_dc if pc._features_rest.shape[1] == 0 else pc.get_features
+    _, color, radii, _, _, _ = _C.rasterize_gaussians_prezeroed(
+        bg_color, xyz, empty, opacity, scale, quat, 1.0, empty, viewpoint_camera.world_view_transform,
+        viewpoint_camera.full_proj_transform, tanfovx, tanfovy, int(viewpoint_camera.image_height),
+        int(viewpoint_camera.image_width), shs, pc.active_sh_degree, viewpoint_camera.camera_center, None, None, hair)
     return {"render": color, "viewspace_points": zeros, "visibility_filter": radii > 0, "radii": radii}
 
 
