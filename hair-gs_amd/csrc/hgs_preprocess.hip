@@ -812,8 +812,12 @@ __device__ __forceinline__ V3 dnormvdv(V3 v, V3 dv) {  // auxiliary.h:107-117
 // segment in the chunk adds the segment's partial sum to the owner's accumulator in LDS.  The association of a Gaussian's sum
 // then depends on where its rows fall in the 16-row chunks (fixed for a given pass: bitwise reproducible; different from the
 // in-lane loop's, which waves whose longest segment is short keep).
+// (a wavefront streams its run when its longest segment exceeds this many rows.  Same box, 8 / 16 / 32 / 64 / never: C2 -- five
+// evenly spread instances per Gaussian -- 23.4 / 15.8 / 15.7 / 15.8 / 15.8 us, i.e. streaming a wavefront whose lanes are busy
+// alike costs 50 % more than their loops; stage3_merged without row_reduce_kernel 85 / 93 / 84 / 87 / 220; stage1_1080p 366 /
+// 380 / 311 / 370 / 727)
 #ifndef HGS_PPB_LIGHT_MAX
-#define HGS_PPB_LIGHT_MAX 8
+#define HGS_PPB_LIGHT_MAX 32
 #endif
 __device__ __forceinline__ float hgs_dpp_shr_f(float v, int d) {   // lane i <- lane i - d inside its 16-lane row, 0 where there is none
   const int x = __float_as_int(v);

@@ -63,6 +63,11 @@ def set_row_reduce(mode):
 
 
 def _apply_row_reduce(L, P, R):
+    import os
+    env = os.environ.get("HGS_ROW_REDUCE")          # A/B aid: 0 / 1 pins the form for the whole process
+    if env in ("0", "1"):
+        L.hgs_set_row_reduce(int(env))
+        return
     mode = _state.get("row_reduce")
     if mode is None:
         mode = (1 if R >= 4 * P else 0) if not _state["async"] else -1

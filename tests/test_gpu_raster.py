@@ -378,13 +378,13 @@ def test_tile_cull_changes_no_output(name):
     g_on, g_off = G.run_backward(s, fw_on, dpix), G.run_backward(s, fw_off, dpix)
     if not _long_tile_pixels(off["ranges"], W, H).any():
         # Bit for bit -- except where the per-Gaussian sum of the instance rows is taken by the whole wavefront (round 6,
-        # hgs_stream_rows: wavefronts of 64 consecutive Gaussians one of which has more than HGS_PPB_LIGHT_MAX = 8 instances):
+        # hgs_stream_rows: wavefronts of 64 consecutive Gaussians one of which has more than HGS_PPB_LIGHT_MAX = 32 instances):
         # there a Gaussian's rows are added 16 at a time as they fall into the run's chunks, and dropping instances moves them
         # (the same terms, associated differently: rounding).
         P = len(on["tiles_touched"])
         pad = (-P) % 64
         wave_max = lambda n: np.repeat(np.concatenate([n, np.zeros(pad, n.dtype)]).reshape(-1, 64).max(1), 64)[:P]
-        streamed = (wave_max(on["tiles_touched"]) > 8) | (wave_max(off["tiles_touched"]) > 8)
+        streamed = (wave_max(on["tiles_touched"]) > 32) | (wave_max(off["tiles_touched"]) > 32)
         for k in g_on:
             if g_off[k].size == 0:
                 assert g_on[k].size == 0
