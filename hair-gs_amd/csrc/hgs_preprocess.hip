@@ -158,6 +158,21 @@ enum { SRC_GIVEN = 0, SRC_STRAND = 1, SRC_CLOUD = 2 };
 #ifndef HGS_PPF_DEAL
 #define HGS_PPF_DEAL 1     // (0: A/B builds without the block-wide counting of large rectangles)
 #endif
+// development aid (tools/dev/ppf_trace.py; build with -DHGS_PPF_TRACE=1): per workgroup of the preprocess kernel the 10 ns ticks
+// at which it entered, had its rectangles (and its lanes' own counting), had the block sum, had dealt its large rectangles, ended
+#ifndef HGS_PPF_TRACE
+#define HGS_PPF_TRACE 0
+#endif
+#ifndef HGS_PPF_DIRECT
+#define HGS_PPF_DIRECT 2048u   // dealt instances of a block beyond which they are counted with global atomics, not through the LDS table
+#endif
+#if HGS_PPF_TRACE
+#define PPF_TRACE_MAX 8192
+__device__ unsigned long long g_ppf_trace[PPF_TRACE_MAX][8];
+#define PPF_MARK(k) do { if (threadIdx.x == 0 && blockIdx.x < PPF_TRACE_MAX) g_ppf_trace[blockIdx.x][k] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define PPF_MARK(k) do { } while (0)
+#endif
 template <int SRC>
 __device__ __forceinline__ void preprocess_fwd_body(const HgsFwdArgs& a, const HgsGeom& g, const HgsImage& im, int* radii,
                                                     const HgsParamSrc& st, uint32_t* red, TileHash& th) {
@@ -173,6 +188,7 @@ __device__ __forceinline__ void preprocess_fwd_body(const HgsFwdArgs& a, const H
   for (int k = 0; k < 16; k++) { Vm[k] = a.viewmatrix[k]; Pmat[k] = a.projmatrix[k]; }
 #pragma unroll
   for (int k = 0; k < 3; k++) cam[k] = a.campos[k];
+  PPF_MARK(0);
   const int idx = blockIdx.x * HGS_BLOCK + threadIdx.x;
   const bool live = idx < a.P;
   const size_t li = live ? (size_t)idx : 0;                   // (loads of the lanes past P read Gaussian 0 and are dropped)
@@ -371,12 +387,17 @@ __device__ __forceinline__ void preprocess_fwd_body(const HgsFwdArgs& a, const H
   // (the block-wide "any" rides on the barrier of the block sum: blocks without such a rectangle -- every block of a fresh strand
   // model -- pay nothing)
   __shared__ uint32_t d_any[4];
+#if HGS_PPF_TRACE
+  __syncthreads();
+  PPF_MARK(1);
+#endif
   {
     const unsigned long long anyb = __ballot(big_area != 0u);
     if ((threadIdx.x & 63) == 0) d_any[threadIdx.x >> 6] = anyb != 0ull ? 1u : 0u;
   }
   const uint32_t bs = block_sum_256(ntiles, red);   // (its barriers also order the table updates above)
   if (threadIdx.x == 0) g.block_sums[blockIdx.x] = bs;
+  PPF_MARK(2);
   if (HGS_PPF_DEAL && (d_any[0] | d_any[1] | d_any[2] | d_any[3]) != 0u) {
     __shared__ uint32_t d_org[HGS_BLOCK], d_w[HGS_BLOCK], d_off[HGS_BLOCK + 1], d_ws[4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -405,7 +426,10 @@ __device__ __forceinline__ void preprocess_fwd_body(const HgsFwdArgs& a, const H
           if (nj) { org = d_org[j]; w = d_w[j]; tx = (int)(org & 0xFFFFu); ty = (int)(org >> 16); }
         }
         const uint32_t t = (uint32_t)(ty * gx + tx);
-        const int sl = th_insert(th, t);
+        // (a block with more dealt instances than the table has room for distinct tiles goes to the counters directly: its
+        // instances are runs of consecutive tiles, nearly all distinct, and a full table costs every insert its eight probes --
+        // tools/dev/ppf_trace.py: 55 us for the 14 000 instances of a Stage-I frame's heaviest block, ~1 us per instance and thread)
+        const int sl = total > HGS_PPF_DIRECT ? -1 : th_insert(th, t);
         if (sl >= 0) atomicAdd(&th.cnt[sl], 1u);
         else atomicAdd(&im.tile_count[HGS_TILE_SLOT(t, im.tile_mask)], 1u);
         l++;
@@ -418,8 +442,14 @@ __device__ __forceinline__ void preprocess_fwd_body(const HgsFwdArgs& a, const H
     im.status[HGS_ST_SCANPTR_LO] = (uint32_t)a.fused_scan_ptr;
     im.status[HGS_ST_SCANPTR_HI] = (uint32_t)(a.fused_scan_ptr >> 32);
   }
+  PPF_MARK(3);
   for (int i = threadIdx.x; i < TH_SIZE; i += HGS_BLOCK)
     if (th.key[i] != TH_EMPTY) atomicAdd(&im.tile_count[HGS_TILE_SLOT(th.key[i], im.tile_mask)], th.cnt[i]);
+#if HGS_PPF_TRACE
+  __syncthreads();
+  PPF_MARK(4);
+  if (threadIdx.x == 0 && blockIdx.x < PPF_TRACE_MAX) g_ppf_trace[blockIdx.x][5] = bs;
+#endif
 }
 
 __global__ __launch_bounds__(HGS_BLOCK) void preprocess_fwd_kernel(HgsFwdArgs a, HgsGeom g, HgsImage im, int* radii) {
@@ -1517,6 +1547,12 @@ int hgs_launch_mark_visible(hipStream_t s, int P, const float* means3D, const fl
   return 0;
 }
 
+#if HGS_PPF_TRACE
+extern "C" int hgs_debug_ppf_trace(unsigned long long* host_out, int n_wg) {
+  if (n_wg > PPF_TRACE_MAX) n_wg = PPF_TRACE_MAX;
+  return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_ppf_trace), (size_t)n_wg * 8 * sizeof(unsigned long long)) == hipSuccess ? 0 : 1;
+}
+#endif
 #if HGS_SCATTER_TRACE
 extern "C" int hgs_debug_scatter_trace(unsigned long long* host_out, int n_wg) {
   if (n_wg > SC_TRACE_MAX) n_wg = SC_TRACE_MAX;

@@ -70,3 +70,33 @@ def test_in_tile_order_relays_an_allocated_layout():
     import pytest
     with pytest.raises(AssertionError):                              # overlapping segments are not a partition
         in_tile_order(dict(ranges=np.array([[0, 3], [2, 5]], np.uint32), point_list=point_list[:5], keys_sorted=keys[:5]), 5)
+
+
+def test_bucket_capacity_keeps_four_significant_bits():
+    """diff_gaussian_rasterization._C.bucket_capacity (round 6): >= n, at most 12.5 % above it, monotone, idempotent -- successive
+    captures of a slowly growing model then ask the allocator for the same workspace sizes."""
+    from diff_gaussian_rasterization._C import bucket_capacity as b
+    prev = 0
+    for n in list(range(0, 70)) + [100, 4095, 4096, 4097, 173000, 1 << 20, (1 << 20) + 1, 2437617, (1 << 31) - 5]:
+        c = b(n)
+        assert c >= n and c <= n + max(n // 8, 1) and b(c) == c and c >= prev
+        assert n <= 16 or bin(c).rstrip("0").count("1") <= 4 and len(bin(c).rstrip("0")) - 2 <= 4
+        prev = c
+    assert len({b(n) for n in range(100000, 112000)}) <= 2
+
+
+def test_training_event_log_and_visible_gpus_need_no_gpu():
+    """train._EventInfo is what the operators take as `training_info`; bench.visible_gpus() counts devices without a HIP call."""
+    import importlib.util
+    import os
+    from train import _EventInfo
+    info = _EventInfo()
+    info.densification_info["clone"] = 3
+    assert info.densification_info == {"clone": 3}
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(os.path.dirname(os.path.dirname(__file__)), "bench.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    n = m.visible_gpus()
+    assert n is None or n >= 0
+    if not os.path.isdir("/sys/class/kfd"):
+        assert n == 0
