@@ -256,6 +256,7 @@ static int forward_preprocess_impl(void* stream, int P, int D, int M, int W, int
   a.campos = campos; a.scale_modifier = scale_modifier; a.tan_fovx = tan_fovx; a.tan_fovy = tan_fovy;
   a.prefiltered = prefiltered & 1;
   a.tile_cull = g_tile_cull;
+  a.row_runs = (prefiltered & HGS_COUNT_ROW_RUNS) ? 1 : 0;
   // Capacity mode (nobody waits for num_rendered here) with a place to report the count: the scan is left to the
   // scatter kernel of hgs_forward_render (scatter_kernel, "fused scan").  A blocking caller needs the count NOW.
   // (Every workgroup of the scatter kernel repeats the scan: worth the saved launch only while there are few of them --
@@ -274,7 +275,7 @@ static int forward_preprocess_impl(void* stream, int P, int D, int M, int W, int
                                               hair->opacity_raw, hair->mask_raw, hair->xyz, hair->scale, hair->quat,
                                               hair->opacity, hair->extra4, fu)) return 1;
   } else if (hgs_launch_preprocess_fwd(s, a, g, im, radii)) return 1;
-  if (!fused_scan && hgs_launch_scan(s, P, T, g, im, max_rendered)) return 1;
+  if (!fused_scan && hgs_launch_scan(s, P, T, g, im, max_rendered, a.row_runs)) return 1;
   if (num_rendered_host) {
     uint32_t r = 0;
     HGS_CHECK_HIP(hipMemcpyAsync(&r, im.status, sizeof(uint32_t), hipMemcpyDeviceToHost, s));

@@ -87,9 +87,52 @@ __device__ __forceinline__ uint32_t scan_regs(ScanRegs& r, int n, uint32_t* wtot
   return total;
 }
 
+// (round 6) HGS_COUNT_ROW_RUNS, blocking mode / frames beyond the scatter kernel's scan: the +1 / -1 marks the preprocess launch
+// left per tile row of its large rectangles become counts -- the running sum over the tiles in row-major order is the number of
+// such rectangles covering each tile -- which are added to the scattered counter table; the marks are left at zero for the next
+// pass.  (In capacity mode the scan workgroups of scatter_kernel do this for their own tiles.)
+#define TD_IPT 8
+__device__ __forceinline__ void fold_tile_delta(int T, const HgsImage& im, int* wsum, int* carry_s) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int carry = 0;
+  for (int base = 0; base < T; base += SCAN_THREADS * TD_IPT) {
+    const int t0 = base + (int)threadIdx.x * TD_IPT;
+    int v[TD_IPT], mine = 0;
+    if (t0 + TD_IPT <= T + 1) {      // (the array holds T + 1 entries, an even number of words behind a 256-byte boundary)
+      const int4 a0 = *(const int4*)(im.tile_delta + t0), a1 = *(const int4*)(im.tile_delta + t0 + 4);
+      v[0] = a0.x; v[1] = a0.y; v[2] = a0.z; v[3] = a0.w; v[4] = a1.x; v[5] = a1.y; v[6] = a1.z; v[7] = a1.w;
+    } else {
+#pragma unroll
+      for (int i = 0; i < TD_IPT; i++) v[i] = t0 + i <= T ? im.tile_delta[t0 + i] : 0;
+    }
+#pragma unroll
+    for (int i = 0; i < TD_IPT; i++) mine += v[i];
+    const int incl = (int)hgs_wave_incl_scan((uint32_t)mine, lane);     // (two's complement: sums of signed marks)
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    int run = carry + incl - mine;
+    for (int w = 0; w < wave; w++) run += wsum[w];
+    if (threadIdx.x == SCAN_THREADS - 1) *carry_s = run + mine;
+#pragma unroll
+    for (int i = 0; i < TD_IPT; i++) {
+      run += v[i];
+      if (t0 + i < T && run != 0) atomicAdd(&im.tile_count[HGS_TILE_SLOT((uint32_t)(t0 + i), im.tile_mask)], (uint32_t)run);
+      if (v[i] != 0) im.tile_delta[t0 + i] = 0;
+    }
+    __syncthreads();
+    carry = *carry_s;
+  }
+  __threadfence();      // the scan below reads the counters through other threads
+  __syncthreads();
+}
+
 __global__ __launch_bounds__(SCAN_THREADS) void scan_kernel(int nblk, int T, HgsGeom g, HgsImage im,
-                                                            unsigned int* __restrict__ max_rendered) {
+                                                            unsigned int* __restrict__ max_rendered, int row_runs) {
   __shared__ uint32_t wtot[SCAN_THREADS / 64];
+  if (row_runs) {
+    __shared__ int td_carry;
+    fold_tile_delta(T, im, (int*)wtot, &td_carry);
+  }
   uint32_t* bs = g.block_sums;
   uint2* ranges = im.ranges;
   auto emit_bs = [&](int i, uint32_t excl, uint32_t) { bs[i] = excl; };
@@ -248,7 +291,7 @@ __device__ __forceinline__ void work_list_shared(int T, uint32_t Rcap, HgsSegPol
     }
     if (!ok) {   // (the builders are the launch's first workgroups: resident together; never observed)
       im.status[HGS_ST_TIMEOUT] = 1u;
-      const unsigned long long report = ((unsigned long long)im.status[HGS_ST_SCANPTR_HI] << 32) | im.status[HGS_ST_SCANPTR_LO];
+      const unsigned long long report = (((unsigned long long)im.status[HGS_ST_SCANPTR_HI] << 32) | im.status[HGS_ST_SCANPTR_LO]) & ~1ull;
       if (report) atomicMax((unsigned int*)report, 0xFFFFFFFFu);
     }
     s_ok = ok;
@@ -594,11 +637,11 @@ extern "C" int hgs_set_segment_policy(int min_len, int max_len, int target_segme
   return 0;
 }
 
-int hgs_launch_scan(hipStream_t s, int P, int T, const HgsGeom& g, const HgsImage& im, unsigned int* max_rendered) {
+int hgs_launch_scan(hipStream_t s, int P, int T, const HgsGeom& g, const HgsImage& im, unsigned int* max_rendered, int row_runs) {
   const int nblk = (P + HGS_BLOCK - 1) / HGS_BLOCK;
   {
     HgsProfScope _prof(s, HGS_K_SCAN);
-    hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(SCAN_THREADS), 0, s, nblk, T, g, im, max_rendered);
+    hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(SCAN_THREADS), 0, s, nblk, T, g, im, max_rendered, row_runs);
   }
   HGS_CHECK_LAUNCH();
   return 0;

@@ -37,6 +37,9 @@ struct HgsGeom {
 };
 struct HgsImage {
   float* final_T; uint32_t* n_contrib; uint2* ranges; uint32_t* tile_count; uint32_t* tile_cursor;
+  // row runs of large tile rectangles (HGS_COUNT_ROW_RUNS passes): +1 at (row, x0), -1 at (row, x1) of the tiles in row-major
+  // order, T + 1 entries; the pass's scan adds the running sum to the tiles' counts and leaves the array at zero
+  int32_t* tile_delta;
   uint32_t* tile_maxc; uint32_t* status; uint32_t* tile_order; uint32_t* wl_exchange;
   uint32_t tile_mask;   // slots of tile_count / tile_cursor - 1 (hgs_tile_slot)
   // long tile lists (hgs_binning.hip / hgs_blend.hip): per-tile ticket of finished blend segments, bit masks of published
@@ -121,7 +124,8 @@ static inline size_t hgs_geom_carve(char* base, size_t P, HgsGeom& g, size_t* of
 // spread over all of them.
 static inline size_t hgs_tile_slots(size_t T) { size_t n = 64; while (n < T) n <<= 1; return n; }
 #define HGS_TILE_SLOT(t, mask) ((uint32_t)((uint32_t)(t) * 0x9E3779B1u) & (uint32_t)(mask))
-static inline size_t hgs_image_zero_words(size_t T) { return 2 * hgs_tile_slots(T) + 2 * T + HGS_STATUS_WORDS + 4 * T; }
+static inline size_t hgs_tile_delta_words(size_t T) { return (T + 2) & ~(size_t)1; }   // T + 1 entries, even (tile_prog stays 8-byte aligned)
+static inline size_t hgs_image_zero_words(size_t T) { return 2 * hgs_tile_slots(T) + hgs_tile_delta_words(T) + 2 * T + HGS_STATUS_WORDS + 4 * T; }
 static inline size_t hgs_image_carve(char* base, size_t W, size_t H, HgsImage& im, size_t* offs) {
   char* cur = base;
   size_t N = W * H, T = ((W + HGS_TILE - 1) / HGS_TILE) * ((H + HGS_TILE - 1) / HGS_TILE);
@@ -132,11 +136,14 @@ static inline size_t hgs_image_carve(char* base, size_t W, size_t H, HgsImage& i
   const size_t Tp = hgs_tile_slots(T);
   im.tile_mask = (uint32_t)(Tp - 1);
   hgs_carve(cur, im.tile_count, T);         if (offs) offs[HGS_IMG_TILE_COUNT] = (char*)im.tile_count - base;   // (Tp slots: below)
-  im.tile_cursor = im.tile_count + Tp;      if (offs) offs[HGS_IMG_TILE_CURSOR] = (char*)im.tile_cursor - base;
+  // (tile_delta sits between the counters and the cursors: like tile_count it is left at zero by its last reader, not by the
+  // prologue rider, whose range starts at tile_cursor -- the rider runs beside the workgroups that add to both)
+  im.tile_delta = (int32_t*)(im.tile_count + Tp);
+  im.tile_cursor = im.tile_count + Tp + hgs_tile_delta_words(T);  if (offs) offs[HGS_IMG_TILE_CURSOR] = (char*)im.tile_cursor - base;
   im.tile_maxc = im.tile_cursor + Tp;       if (offs) offs[HGS_IMG_TILE_MAXC] = (char*)im.tile_maxc - base;
   im.tile_done = im.tile_maxc + T;
   im.status = im.tile_done + T;             if (offs) offs[HGS_IMG_STATUS] = (char*)im.status - base;
-  im.tile_prog = (unsigned long long*)(im.status + HGS_STATUS_WORDS);   // 8-byte aligned: 4 T + 16 words past a 256-B boundary
+  im.tile_prog = (unsigned long long*)(im.status + HGS_STATUS_WORDS);   // 8-byte aligned: an even number of words past a 256-B boundary
   im.tile_sortprog = im.tile_prog + T;
   cur += hgs_image_zero_words(T) * sizeof(uint32_t);
   hgs_carve(cur, im.sort_items, T);
@@ -256,6 +263,8 @@ struct HgsFwdArgs {
   float scale_modifier, tan_fovx, tan_fovy;
   int prefiltered;
   int tile_cull;       // shrink every tile rectangle to the alpha >= 1/255 ellipse's bounding box (hgs_set_tile_cull)
+  int row_runs;        // HGS_COUNT_ROW_RUNS: large rectangles leave two marks per tile row in im.tile_delta; the pass's scan (scan_kernel, or
+                       // the scan workgroups of scatter_kernel, told through bit 0 of the parked pointer) adds their running sum
   // != 0: no scan launch follows; the scatter kernel scans the tile counts itself (see scatter_kernel) and reports the
   // instance count through this device pointer (the caller's max_rendered).  Parked in status[2..3] of the image buffer.
   unsigned long long fused_scan_ptr;
@@ -274,7 +283,7 @@ int hgs_launch_cloud_preprocess_fwd(hipStream_t s, const HgsFwdArgs& a, const Hg
                                     const float* scaling_raw, const float* rotation_raw, const float* opacity_raw,
                                     const float* mask_raw, float* scale, float* quat, float* opacity, float* extra4,
                                     const HgsPrologue& pro);
-int hgs_launch_scan(hipStream_t s, int P, int T, const HgsGeom& g, const HgsImage& im, unsigned int* max_rendered);
+int hgs_launch_scan(hipStream_t s, int P, int T, const HgsGeom& g, const HgsImage& im, unsigned int* max_rendered, int row_runs = 0);
 int hgs_launch_scatter(hipStream_t s, int P, int W, int H, int Rcap, const float* features, const float* extra, int n_extra,
                        const HgsGeom& g, const HgsImage& im, const HgsBinning& b);
 int hgs_launch_sort_tiles(hipStream_t s, int W, int H, int Rcap, int n_extra, const HgsGeom& g, const HgsImage& im,
@@ -359,7 +368,7 @@ __device__ __forceinline__ bool hgs_wait_parts(const unsigned long long* mask, u
   // capacity mode: the caller's sticky instance-count maximum (its pointer is parked in the status words) is raised to
   // 0xFFFFFFFF, which the host's next validation cannot miss (include/hgs.h HGS_WAIT_TIMED_OUT) -- a frame blended from
   // unfinished segments must not pass silently through any number of graph replays
-  const unsigned long long report = ((unsigned long long)status[HGS_ST_SCANPTR_HI] << 32) | status[HGS_ST_SCANPTR_LO];
+  const unsigned long long report = (((unsigned long long)status[HGS_ST_SCANPTR_HI] << 32) | status[HGS_ST_SCANPTR_LO]) & ~1ull;   // (bit 0: HGS_COUNT_ROW_RUNS)
   if (report) atomicMax((unsigned int*)report, 0xFFFFFFFFu);
   return false;
 }

@@ -367,7 +367,7 @@ __device__ __forceinline__ void preprocess_fwd_body(const HgsFwdArgs& a, const H
             else atomicAdd(&im.tile_count[HGS_TILE_SLOT(t, im.tile_mask)], 1u);
           }
       } else {
-        big_area = area_kept;
+        big_area = a.row_runs ? (uint32_t)(y1 - y0) : area_kept;   // units dealt below: tile rows / tiles
         big_x0y0 = (uint32_t)x0 | ((uint32_t)y0 << 16);
         big_w = (uint32_t)(x1 - x0);
       }
@@ -419,27 +419,47 @@ __device__ __forceinline__ void preprocess_fwd_body(const HgsFwdArgs& a, const H
       int j = lo;
       uint32_t l = k0 - d_off[j], nj = d_off[j + 1] - d_off[j];
       uint32_t org = d_org[j], w = d_w[j];
-      int tx = (int)(org & 0xFFFFu) + (int)(l % max(w, 1u)), ty = (int)(org >> 16) + (int)(l / max(w, 1u));
-      for (uint32_t k = k0; k < k1; k++) {
-        while (l >= nj) {                               // next Gaussian with a dealt rectangle
-          j++; l = 0; nj = d_off[j + 1] - d_off[j];
-          if (nj) { org = d_org[j]; w = d_w[j]; tx = (int)(org & 0xFFFFu); ty = (int)(org >> 16); }
+      if (a.row_runs) {
+        // (HGS_COUNT_ROW_RUNS) the unit is a tile ROW of a rectangle: +1 where its run of tiles starts, -1 behind its end, in the
+        // row-major array im.tile_delta -- a run that ends at the frame's right edge closes on the next row's first entry, which is
+        // where the running sum of tile_delta_kernel (ONE sum over all tiles, not one per row) has to drop.  Two atomics for a
+        // row of any width against one per tile: a Stage-I cloud's large Gaussians are 10-30 tiles wide (tools/dev/ppf_trace.py:
+        // the heaviest block of such a frame deals 14 000 tiles, ~1400 rows).  Rows of one or two tiles go to the counters directly.
+        for (uint32_t k = k0; k < k1; k++) {
+          while (l >= nj) { j++; l = 0; nj = d_off[j + 1] - d_off[j]; if (nj) { org = d_org[j]; w = d_w[j]; } }
+          const uint32_t t = ((org >> 16) + l) * (uint32_t)gx + (org & 0xFFFFu);
+          if (w <= 2u) {
+            atomicAdd(&im.tile_count[HGS_TILE_SLOT(t, im.tile_mask)], 1u);
+            if (w == 2u) atomicAdd(&im.tile_count[HGS_TILE_SLOT(t + 1u, im.tile_mask)], 1u);
+          } else {
+            atomicAdd(&im.tile_delta[t], 1);
+            atomicAdd(&im.tile_delta[t + w], -1);
+          }
+          l++;
         }
-        const uint32_t t = (uint32_t)(ty * gx + tx);
-        // (a block with more dealt instances than the table has room for distinct tiles goes to the counters directly: its
-        // instances are runs of consecutive tiles, nearly all distinct, and a full table costs every insert its eight probes --
-        // tools/dev/ppf_trace.py: 55 us for the 14 000 instances of a Stage-I frame's heaviest block, ~1 us per instance and thread)
-        const int sl = total > HGS_PPF_DIRECT ? -1 : th_insert(th, t);
-        if (sl >= 0) atomicAdd(&th.cnt[sl], 1u);
-        else atomicAdd(&im.tile_count[HGS_TILE_SLOT(t, im.tile_mask)], 1u);
-        l++;
-        if (++tx == (int)((org & 0xFFFFu) + w)) { tx = (int)(org & 0xFFFFu); ty++; }
+      } else {
+        int tx = (int)(org & 0xFFFFu) + (int)(l % max(w, 1u)), ty = (int)(org >> 16) + (int)(l / max(w, 1u));
+        for (uint32_t k = k0; k < k1; k++) {
+          while (l >= nj) {                               // next Gaussian with a dealt rectangle
+            j++; l = 0; nj = d_off[j + 1] - d_off[j];
+            if (nj) { org = d_org[j]; w = d_w[j]; tx = (int)(org & 0xFFFFu); ty = (int)(org >> 16); }
+          }
+          const uint32_t t = (uint32_t)(ty * gx + tx);
+          // (a block with more dealt instances than the table has room for distinct tiles goes to the counters directly: its
+          // instances are runs of consecutive tiles, nearly all distinct, and a full table costs every insert its eight probes --
+          // tools/dev/ppf_trace.py: 55 us for the 14 000 instances of a Stage-I frame's heaviest block, ~1 us per instance and thread)
+          const int sl = total > HGS_PPF_DIRECT ? -1 : th_insert(th, t);
+          if (sl >= 0) atomicAdd(&th.cnt[sl], 1u);
+          else atomicAdd(&im.tile_count[HGS_TILE_SLOT(t, im.tile_mask)], 1u);
+          l++;
+          if (++tx == (int)((org & 0xFFFFu) + w)) { tx = (int)(org & 0xFFFFu); ty++; }
+        }
       }
     }
     __syncthreads();                                    // (the table is flushed below)
   }
   if (blockIdx.x == 0 && threadIdx.x == 0 && a.fused_scan_ptr) {   // (status words were cleared by the launch before this one)
-    im.status[HGS_ST_SCANPTR_LO] = (uint32_t)a.fused_scan_ptr;
+    im.status[HGS_ST_SCANPTR_LO] = (uint32_t)a.fused_scan_ptr | (a.row_runs ? 1u : 0u);   // (a 4-byte aligned pointer: bit 0 tells the scan workgroups of the scatter kernel about the row-run marks)
     im.status[HGS_ST_SCANPTR_HI] = (uint32_t)(a.fused_scan_ptr >> 32);
   }
   PPF_MARK(3);
@@ -559,8 +579,9 @@ __global__ __launch_bounds__(HGS_BLOCK) void scatter_kernel(int P, int gx, int T
   ScRec* srec = (ScRec*)(sc_lds + sizeof(ScTable));
   uint32_t* ioff = (uint32_t*)(sc_lds + sizeof(ScTable) + HGS_BLOCK * sizeof(ScRec));
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const unsigned long long report = ((unsigned long long)im.status[HGS_ST_SCANPTR_HI] << 32) | im.status[HGS_ST_SCANPTR_LO];
-  const bool fused = report != 0ull;
+  const unsigned long long parked = ((unsigned long long)im.status[HGS_ST_SCANPTR_HI] << 32) | im.status[HGS_ST_SCANPTR_LO];
+  const unsigned long long report = parked & ~1ull;
+  const bool fused = report != 0ull, row_runs = (parked & 1ull) != 0ull;
   int bid = (int)blockIdx.x - scan_wg;             // Gaussian block of this workgroup; < 0: a scan workgroup
   const int nblk_g = (P + HGS_BLOCK - 1) / HGS_BLOCK;
   uint32_t my_part = 0u;                           // which HGS_SC_PART instances of the block this workgroup places
@@ -624,10 +645,25 @@ __global__ __launch_bounds__(HGS_BLOCK) void scatter_kernel(int P, int gx, int T
     static_assert(HGS_FUSED_SCAN_MAX_T <= HGS_SCAN_WGS * HGS_BLOCK, "one tile per thread of the scan workgroups");
     const int t = (int)blockIdx.x * HGS_BLOCK + (int)threadIdx.x;
     const uint32_t slot = HGS_TILE_SLOT(t, im.tile_mask);
-    const uint32_t cnt = t < T ? im.tile_count[slot] : 0u;
+    uint32_t cnt = t < T ? im.tile_count[slot] : 0u;
     // the counter is dead from here on: leave it at zero for the next pass over this image buffer (whose first kernel may
     // count into it beside the workgroups that clear the rest of the buffer's counters: hair_preprocess_fwd_kernel)
     if (cnt) im.tile_count[slot] = 0u;
+    if (row_runs) {
+      // (round 6, HGS_COUNT_ROW_RUNS) the preprocess launch counted its large rectangles as +1 / -1 marks per tile row: a tile's
+      // count is its counter plus the running sum of the marks up to it, in row-major tile order.  Every scan workgroup sums the
+      // marks in front of its tiles itself (at most 8160 coalesced words out of the L2) -- no workgroup waits for another.
+      __shared__ int rr_s[8];
+      int front = 0;
+      for (int i = (int)threadIdx.x; i < (int)blockIdx.x * HGS_BLOCK; i += HGS_BLOCK) front += im.tile_delta[i];
+      const int d = t < T ? im.tile_delta[t] : 0;
+      const int d_inc = (int)hgs_wave_incl_scan((uint32_t)d, lane), f_inc = (int)hgs_wave_incl_scan((uint32_t)front, lane);
+      if (lane == 63) { rr_s[wave] = d_inc; rr_s[4 + wave] = f_inc; }
+      __syncthreads();
+      int run = d_inc + rr_s[4] + rr_s[5] + rr_s[6] + rr_s[7];
+      for (int w = 0; w < wave; w++) run += rr_s[w];
+      if (t < T) cnt += (uint32_t)run;
+    }
     const uint32_t inc = hgs_wave_incl_scan(cnt, lane);
     const uint32_t wave_total = (uint32_t)__shfl((int)inc, 63, 64);
     uint32_t base = 0u;
@@ -639,6 +675,7 @@ __global__ __launch_bounds__(HGS_BLOCK) void scatter_kernel(int P, int gx, int T
     if (t < T) hgs_st_agent((unsigned long long*)&im.ranges[t], cnt ? ((unsigned long long)(o + cnt) << 32) | o : 0ull);
     hgs_drain_stores();
     __syncthreads();
+    __shared__ uint32_t last_s;
     if (threadIdx.x == 0) {
       const uint32_t done = __hip_atomic_fetch_add(&im.status[HGS_ST_SCAN_DONE], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (done == (uint32_t)scan_wg - 1u) {   // the last one: every wavefront's allocation has returned
@@ -646,6 +683,12 @@ __global__ __launch_bounds__(HGS_BLOCK) void scatter_kernel(int P, int gx, int T
         im.status[HGS_ST_R] = end_all;
         atomicMax((unsigned int*)report, end_all);   // sticky maximum for graph replays (hgs.h)
       }
+      last_s = done == (uint32_t)scan_wg - 1u ? 1u : 0u;
+    }
+    if (row_runs) {   // the last scan workgroup (all of them have read their marks) leaves the marks at zero for the next pass
+      __syncthreads();
+      if (last_s)
+        for (int i = (int)threadIdx.x; i <= T; i += HGS_BLOCK) im.tile_delta[i] = 0;
     }
     if (t < T) hgs_emit_sort_items((uint32_t)t, cnt, (uint32_t)T, im);   // long lists: one sort workgroup per chunk (read by the NEXT kernel)
     SC_MARK(5);

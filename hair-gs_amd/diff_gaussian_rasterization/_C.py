@@ -17,6 +17,7 @@ import hgs_runtime as rt
 # the capacity: the caller discards the step's gradients and repeats it.  `num_rendered` returned by
 # rasterize_gaussians is then the capacity (it only sizes/carves buffers downstream).
 IMAGE_PREZEROED = 2   # include/hgs.h HGS_IMAGE_PREZEROED (flag in `prefiltered`)
+COUNT_ROW_RUNS = 4    # include/hgs.h HGS_COUNT_ROW_RUNS
 _state = {"last_R": 0, "last_counts_clean": False, "async": False, "cap": 0, "slack": 1.5, "dirty": False, "cap_used": None, "max_R": {}, "cull": None}
 
 
@@ -72,6 +73,26 @@ def _apply_row_reduce(L, P, R):
     if mode is None:
         mode = (1 if R >= 4 * P else 0) if not _state["async"] else -1
     L.hgs_set_row_reduce(int(mode))
+
+
+def set_row_runs(mode):
+    """How the preprocess launch counts tile rectangles of more than 16 tiles (include/hgs.h HGS_COUNT_ROW_RUNS): True = by tile
+    rows plus a one-workgroup launch, False = tile by tile, None = decide per pass from the instances per Gaussian seen so far
+    (capacity mode: the capacity; blocking mode: the previous pass's exact count) -- the counts are the same integers either way."""
+    was = _state.get("row_runs")
+    _state["row_runs"] = None if mode is None else bool(mode)
+    return was
+
+
+def _row_runs_flag(P, use_async):
+    import os
+    env = os.environ.get("HGS_ROW_RUNS")            # A/B aid: 0 / 1 pins the form for the whole process
+    mode = _state.get("row_runs")
+    if env in ("0", "1"):
+        mode = env == "1"
+    if mode is None:
+        mode = (_state["cap"] if use_async else _state.get("last_exact_R", 0)) >= 8 * P
+    return COUNT_ROW_RUNS if (mode and P > 0) else 0
 
 
 def set_async(enabled=True, slack=1.5):
@@ -225,6 +246,7 @@ def _forward(background, means3D, colors, opacity, scales, rotations, scale_modi
     stream = rt.current_stream()
     with torch.cuda.device(dev):
         use_async = _state["async"] and _state["cap"] > 0 and P > 0
+        flags |= _row_runs_flag(P, use_async)
         n_host = C.c_int(0)
         fused_hair = hair is not None and use_async and will_fuse_hair(W, H)
         if hair is not None:

@@ -69,8 +69,12 @@ size_t hgs_backward_scratch_bytes(int P, int R);
  * device once THAT call has run on the stream; max_rendered has to stay valid until then.
  * prefiltered: bit 0 = the reference's flag (accepted, ignored); bit 1 (HGS_IMAGE_PREZEROED) = the caller has already
  * cleared the counters of image_buf on this stream (hgs_iteration_prologue over hgs_image_zero_range): the call's own
- * clearing launch is skipped. */
+ * clearing launch is skipped; bit 2 (HGS_COUNT_ROW_RUNS) = count the tile rectangles of more than 16 tiles by their tile
+ * ROWS (two marks per row, which the pass's scan turns into counts) instead of tile by tile: the same counts; pays
+ * where Gaussians cover many tiles each (a Stage-I cloud at 1080p, a merged strand
+ * model: callers set it from the instances per Gaussian they have seen -- diff_gaussian_rasterization/_C.py). */
 #define HGS_IMAGE_PREZEROED 2
+#define HGS_COUNT_ROW_RUNS 4
 /* Value a max_rendered word takes when a workgroup of a pass gave up waiting for another one of the same launch (bounded
  * spins of the list-parallel sort / blend: never observed; would mean the dispatcher kept a predecessor from running).
  * The frame of that pass is invalid. */

@@ -43,7 +43,8 @@ def test_workspace_sizes_and_layouts_are_consistent():
         slots = 64
         while slots < T:
             slots *= 2                       # tile_count / tile_cursor: a power-of-two table of scattered slots
-        assert lay["tile_cursor"] - lay["tile_count"] == 4 * slots and lay["status"] + 16 <= n
+        # (between them: the T + 1 row-run marks of HGS_COUNT_ROW_RUNS passes, an even number of words)
+        assert lay["tile_cursor"] - lay["tile_count"] == 4 * (slots + ((T + 2) & ~1)) and lay["status"] + 16 <= n
     for R in (0, 1, 1000, 441042):
         n = L.hgs_binning_bytes(R)
         lay = rt.layout("binning", R)

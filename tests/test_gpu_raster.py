@@ -993,3 +993,50 @@ def test_row_reduce_kernel_equals_the_in_kernel_row_sums(name):
         scale = float(np.abs(g_in[k]).max())
         assert float(np.abs(g_rr[k].astype(np.float64) - g_in[k]).max()) <= 2e-5 * max(scale, 1e-30), k
     assert any(float(np.abs(v).max()) > 0 for v in g_in.values() if v.size)
+
+
+@pytest.mark.parametrize("name", ALL + ["c2_full_size"])
+def test_row_run_counting_changes_nothing(name):
+    """HGS_COUNT_ROW_RUNS (include/hgs.h: tile rectangles of more than 16 tiles counted by their tile rows -- two marks per row,
+    summed up by tile_delta_kernel -- instead of tile by tile): every buffer of the pass is what the tile-by-tile form gives, bit
+    for bit, in the blocking mode and in the capacity mode, and the marks are left at zero (passes on a caller-cleared image
+    buffer, which rely on that: tests/test_gpu_train.py::test_row_run_counting_in_the_fused_iterations).  c2_full_size: BASELINE config 2, a Stage-I cloud whose Gaussians cover ~40 tiles each;
+    many_tiles: 17 545 tiles, three rounds of the summing workgroup; rectangles that end at the frame's right edge close on the
+    next row's first entry (one running sum over all tiles)."""
+    from diff_gaussian_rasterization import _C
+    from tests import gpu_util as G
+    s = _workload_scene("c2") if name == "c2_full_size" else _scene(name)
+    was = _C.set_row_runs(False)
+    try:
+        ref_fw = G.run_forward(s)
+        ref = G.intermediates(s, ref_fw)
+        _C.set_row_runs(True)
+        fw = G.run_forward(s)
+        got = G.intermediates(s, fw)
+        for k in ("radii", "tiles_touched", "point_offsets", "ranges", "point_list", "keys_sorted", "n_contrib"):
+            np.testing.assert_array_equal(got[k], ref[k], err_msg=k)
+        assert got["num_rendered"] == ref["num_rendered"] and got["status"][1] == 0
+        np.testing.assert_array_equal(got["out_color"].view(np.uint32), ref["out_color"].view(np.uint32))
+        lay = G.rt.layout("image", s["W"], s["H"])
+        n_marks = (((s["W"] + 15) // 16) * ((s["H"] + 15) // 16) + 2) & ~1
+        marks = G._view(fw["img"], lay["tile_cursor"] - 4 * n_marks, n_marks, np.int32)
+        assert not marks.any()
+        if ref["num_rendered"] == 0:
+            return
+        try:
+            _C._state["cap"] = 0
+            _C.set_async(True)
+            G.run_forward(s)
+            for _ in range(2):
+                fw2 = G.run_forward(s)
+                assert _C.check_async() == [ref["num_rendered"]]
+                got2 = G.intermediates(s, fw2)
+                ranges, point_list, keys_sorted = G.in_tile_order(got2, ref["num_rendered"])
+                np.testing.assert_array_equal(ranges, ref["ranges"], err_msg="ranges")
+                np.testing.assert_array_equal(point_list, ref["point_list"], err_msg="point_list")
+                np.testing.assert_array_equal(keys_sorted, ref["keys_sorted"], err_msg="keys_sorted")
+                np.testing.assert_array_equal(got2["out_color"].view(np.uint32), ref["out_color"].view(np.uint32))
+        finally:
+            _C.set_async(False)
+    finally:
+        _C.set_row_runs(was)

@@ -1770,3 +1770,62 @@ def test_cloud_densification_selects_the_same_rows_as_the_three_pass_form():
             fused = fused_step_for(model, ViewTable(cams), opt, bg)      # (new tensors behind the model)
             acc3 = [torch.zeros_like(t) for t in stats()]
     assert [e["iteration"] for e in events] == [200, 300, 400] and selected > 0
+
+
+@pytest.mark.parametrize("kind", ["cloud", "strands"])
+def test_row_run_counting_in_the_fused_iterations(kind):
+    """HGS_COUNT_ROW_RUNS in the captured form of the iteration: the one-launch parameters -> preprocess kernels with the prologue
+    riding beside them, on the view table's image buffer whose counters only the kernels themselves keep at zero (the row-run
+    marks lie between the tile counters and the range the rider clears: tile_delta_kernel has to leave them at zero).  Six
+    iterations over changing views, row runs on against off: loss terms, image planes, radii and every parameter gradient bit
+    for bit.  cloud: 3000 Stage-I Gaussians with their scales raised to radii of 50 pixels; strands: the tiny strand model with the extent of its Gaussians
+    along the segment raised to ~15 pixels (rectangles of more than 16 tiles)."""
+    from arguments import OptimizationParams
+    from diff_gaussian_rasterization import _C as raster
+    from hgs_runtime.strand_step import FusedCloudStep, FusedStrandStep, ViewTable
+    from synthetic import attach_targets, build_workload, cameras_extent, make_cameras, make_cloud_model
+    if kind == "cloud":
+        cams = make_cameras(4, 200, 120, device="cuda")
+        model = make_cloud_model(3000, device="cuda", spatial_lr_scale=cameras_extent(cams))
+        with torch.no_grad():
+            model._scaling.add_(1.3)
+        attach_targets(cams, model)
+    else:
+        model, cams, _ = build_workload("tiny", device="cuda", with_targets=True)
+    opt = OptimizationParams()
+    model.training_setup(opt)
+    if kind == "strands":
+        with torch.no_grad():      # sigma along the segment: 0.06 world units = 15 pixels at these cameras (training_setup sets the factor)
+            model.dist_to_scale_factor = float(model.dist_to_scale_factor) * 0.06 / float(model.get_scaling[:, 0].mean())
+    params = ([model._xyz, model._scaling, model._rotation, model._opacity, model._mask, model._features_dc] if kind == "cloud"
+              else [model._endpoints, model._width, model._opacity, model._mask, model._features_dc])
+    out = {}
+    was = raster.set_row_runs(False)
+    try:
+        raster._state["cap"] = 0
+        raster.set_async(True, slack=2.0)
+        for rows in (False, True):
+            raster.set_row_runs(rows)
+            views = ViewTable(cams)
+            step = (FusedCloudStep if kind == "cloud" else FusedStrandStep)(model, views, opt, torch.zeros(3, device="cuda"))
+            seen = []
+            for v in (0, 2, 1, 3, 0, 2):
+                for p in params:
+                    p.grad = None
+                views.prologue(v, ride=True)
+                fused_now = raster.will_fuse_hair(views.W, views.H)
+                loss, terms = step.loss()
+                step.backward(loss)
+                raster.check_async()
+                seen.append([fused_now, views.counts_clean, loss.detach().clone(), terms[:14].clone(), step.last["planes"].clone(),
+                             step.last["radii"].clone()] + [p.grad.clone() for p in params])
+            out[rows] = seen
+    finally:
+        raster.set_async(False)
+        raster.set_row_runs(was)
+    assert all(s[0] and s[1] for s in out[True][1:])        # the one-launch form ran, the tile counters were left at zero
+    for a, b in zip(out[False], out[True]):
+        for x, y in zip(a[2:], b[2:]):
+            assert torch.equal(x, y)
+        assert bool(a[6].abs().sum() > 0)
+    assert int(out[True][-1][5].max()) > 40                 # radii: rectangles of more than 16 tiles exist

@@ -34,6 +34,9 @@ def psnr():
 
 p0, n0 = psnr(), model.get_xyz.shape[0]
 done, t0, rollbacks = 0, time.perf_counter(), 0
+if os.environ.get("SOAK_PROFILE") == "all":      # cProfile of the whole run
+    import cProfile, pstats
+    pr_all = cProfile.Profile(); pr_all.enable()
 # PSNR is sampled 100 iterations in front of every opacity reset and 500 behind it -- never ON the reset iteration, where every
 # opacity has just been clamped to 0.01 (reference train.py:188-190) and the number says nothing (round 5's log: 19.13 -> 16.92 dB
 # "at it. 3000"); sampling is outside the timed chunks
@@ -43,7 +46,7 @@ while done < iters:
     marks = [m for m in (k * reset - 100 for k in range(1, iters // reset + 2)) if done < m < iters] + \
             [m for m in (k * reset + 500 for k in range(1, iters // reset + 2)) if done < m < iters]
     n = min([500 - done % 500, iters - done] + [m - done for m in marks])
-    if os.environ.get("SOAK_PROFILE") and done + n >= iters:      # cProfile of the last chunk
+    if os.environ.get("SOAK_PROFILE") not in (None, "", "all") and done + n >= iters:      # cProfile of the last chunk
         import cProfile, pstats
         pr = cProfile.Profile(); pr.enable()
         ema = training(model, cams, opt, iterations=n, extent=extent, start_iteration=done)
@@ -61,6 +64,8 @@ while done < iters:
         t_psnr += time.perf_counter() - tp
         print(f"[it {done}] PSNR {samples[done]:.2f} dB ({'100 iterations in front of' if (done + 100) % reset == 0 else '500 iterations behind'} an opacity reset)", flush=True)
 dt = time.perf_counter() - t0 - t_psnr
+if os.environ.get("SOAK_PROFILE") == "all":
+    pr_all.disable(); pstats.Stats(pr_all).sort_stats("cumulative").print_stats(70)
 p1 = psnr()
 for e in events:
     print("event", e)
