@@ -446,3 +446,105 @@ extern "C" int hgs_nearest_distance_f64(void* stream, int N, int M, const float*
   return 0;
 }
 
+// ---- strand walk (hgs_strand_walk_ends / hgs_strand_walk_fill) -------------------------------------------------------------------
+// compute_strands_info (reference scene/hair_gaussian_model.py:1410-1498) orders every open polyline of the segment table from one
+// end to the other.  The torch form (walk_chains_torch) doubles pointers over the 2 n arcs: ~10 rounds of gathers over every arc,
+// ~120 launches, 2.7 ms on a 4 10^5-segment model, twice per topology event.  A strand is a CHAIN: here one lane per strand END
+// walks it -- one 16-byte load per step from a node table (for every endpoint its at most two (row, neighbour) entries) -- first
+// to find the other end and the length, then (one lane per strand, once the host side has numbered the strands and decided their
+// direction) to write the ordered rows.  Chains of ~100 segments: ~100 dependent L2 hits, tens of microseconds, all strands in
+// parallel.  Closed loops have no end and are never entered, like in the reference's walk.
+struct WalkNode { int row0, nb0, row1, nb1; };      // (-1: no entry)
+
+__global__ __launch_bounds__(256) void walk_nodes_kernel(int n, int n_ep, const long long* __restrict__ pairs, int* __restrict__ deg,
+                                                         WalkNode* __restrict__ nodes, int* __restrict__ flags) {
+  const int r = blockIdx.x * 256 + threadIdx.x;
+  if (r >= n) return;
+  const long long a = pairs[2 * (size_t)r], b = pairs[2 * (size_t)r + 1];
+  if (a < 0 || b < 0 || a >= n_ep || b >= n_ep) { flags[0] = 1; return; }
+#pragma unroll
+  for (int s = 0; s < 2; s++) {
+    const int id = (int)(s ? b : a), nb = (int)(s ? a : b);
+    const int slot = atomicAdd(&deg[id], 1);
+    if (slot == 0) { nodes[id].row0 = r; nodes[id].nb0 = nb; }
+    else if (slot == 1) { nodes[id].row1 = r; nodes[id].nb1 = nb; }
+    else flags[0] = 1;                                   // an endpoint of degree > 2: not a set of chains
+  }
+}
+
+// other[e] = the end the chain that starts at end e runs into, len[e] = its segments; -1 / 0 for ids that are no chain end
+__global__ __launch_bounds__(256) void walk_ends_kernel(int n, int n_ep, const int* __restrict__ deg, const WalkNode* __restrict__ nodes,
+                                                        int* __restrict__ other, int* __restrict__ len, int* __restrict__ flags) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= n_ep) return;
+  int o = -1, L = 0;
+  if (deg[e] == 1) {
+    const int4 first = *(const int4*)&nodes[e];
+    int row = first.x, v = first.y;                      // arrived at v through `row`
+    L = 1;
+    while (L <= n) {
+      const int4 nd = *(const int4*)&nodes[v];
+      const bool use1 = nd.x == row;                     // leave through the entry that is not the row we came by
+      const int nrow = use1 ? nd.z : nd.x, nnb = use1 ? nd.w : nd.y;
+      if (nrow < 0) break;                               // v has no other row: the chain's other end
+      row = nrow; v = nnb; L++;
+    }
+    if (L > n) { flags[0] = 1; L = 0; } else o = v;
+  }
+  other[e] = o; len[e] = L;
+}
+
+__global__ __launch_bounds__(64) void walk_fill_kernel(int S, const long long* __restrict__ starts, const long long* __restrict__ offsets,
+                                                       const unsigned char* __restrict__ flip, const WalkNode* __restrict__ nodes,
+                                                       long long* __restrict__ rows, long long* __restrict__ seg_rows,
+                                                       int* __restrict__ id_to_strand) {
+  const int s = blockIdx.x * 64 + threadIdx.x;
+  if (s >= S) return;
+  const long long o0 = offsets[s], o1 = offsets[s + 1];
+  const bool rev = flip[s] != 0;
+  int cur = (int)starts[s];
+  const int4 first = *(const int4*)&nodes[cur];
+  int row = first.x, v = first.y;
+  id_to_strand[cur] = s;
+  for (long long k = o0; k < o1; k++) {
+    const long long at = rev ? o1 - 1 - (k - o0) : k;
+    rows[2 * at] = rev ? v : cur;
+    rows[2 * at + 1] = rev ? cur : v;
+    seg_rows[at] = row;
+    id_to_strand[v] = s;
+    const int4 nd = *(const int4*)&nodes[v];
+    const bool use1 = nd.x == row;
+    cur = v;
+    row = use1 ? nd.z : nd.x;
+    v = use1 ? nd.w : nd.y;
+  }
+}
+
+extern "C" int hgs_strand_walk_ends(void* stream, int n, int n_ep, const long long* pairs, int* deg, void* nodes, int* other, int* len,
+                                    int* flags) {
+  if (n < 0 || n_ep < 0) { hgs_set_error("hgs_strand_walk_ends: bad sizes"); return 1; }
+  if (n_ep == 0) return 0;
+  if ((n > 0 && !pairs) || !deg || !nodes || !other || !len || !flags || ((size_t)nodes & 15)) {
+    hgs_set_error("hgs_strand_walk_ends: null argument (or nodes not 16-byte aligned)"); return 1;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  HGS_CHECK_HIP(hipMemsetAsync(deg, 0, sizeof(int) * (size_t)n_ep, s));
+  HGS_CHECK_HIP(hipMemsetAsync(nodes, 0xFF, sizeof(WalkNode) * (size_t)n_ep, s));
+  HGS_CHECK_HIP(hipMemsetAsync(flags, 0, sizeof(int), s));
+  if (n > 0) hipLaunchKernelGGL(walk_nodes_kernel, dim3((n + 255) / 256), dim3(256), 0, s, n, n_ep, pairs, deg, (WalkNode*)nodes, flags);
+  hipLaunchKernelGGL(walk_ends_kernel, dim3((n_ep + 255) / 256), dim3(256), 0, s, n, n_ep, deg, (const WalkNode*)nodes, other, len, flags);
+  HGS_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int hgs_strand_walk_fill(void* stream, int S, const long long* starts, const long long* offsets, const unsigned char* flip,
+                                    const void* nodes, long long* rows, long long* seg_rows, int* id_to_strand) {
+  if (S < 0) { hgs_set_error("hgs_strand_walk_fill: bad size"); return 1; }
+  if (S == 0) return 0;
+  if (!starts || !offsets || !flip || !nodes || !rows || !seg_rows || !id_to_strand) { hgs_set_error("hgs_strand_walk_fill: null argument"); return 1; }
+  hipLaunchKernelGGL(walk_fill_kernel, dim3((S + 63) / 64), dim3(64), 0, (hipStream_t)stream, S, starts, offsets, flip, (const WalkNode*)nodes,
+                     rows, seg_rows, id_to_strand);
+  HGS_CHECK_LAUNCH();
+  return 0;
+}
+

@@ -82,6 +82,8 @@ SIGNATURES = {
     "hgs_radius_pairs": (ci, [vp, ci, vp, vp, cf, cf, ci, ci, vp, vp, vp, ci]),
     "hgs_knn3": (ci, [vp, ci, vp, vp, vp]),
     "hgs_nearest_distance_f64": (ci, [vp, ci, ci, vp, vp, vp]),
+    "hgs_strand_walk_ends": (ci, [vp, ci, ci, vp, vp, vp, vp, vp, vp]),
+    "hgs_strand_walk_fill": (ci, [vp, ci, vp, vp, vp, vp, vp, vp, vp]),
     "hgs_set_tile_cull": (ci, [ci]),
     "hgs_set_segment_policy": (ci, [ci, ci, ci]),
     "hgs_set_row_reduce": (ci, [ci]),

@@ -10,6 +10,8 @@ This file holds the rasterizer-facing surface + optimizer plumbing + strand book
 operators (split / clone / merge / grow) live in scene/hair_topology.py.
 """
 
+import os
+
 import numpy as np
 import torch
 from torch import nn
@@ -165,6 +167,42 @@ def walk_chains_torch(pairs, n_ep, end_distance, max_len_hint=None):
     c, x = cur[sel][src], nxt[sel][src]
     seq = torch.stack([torch.where(flip_e, x, c), torch.where(flip_e, c, x)], dim=1)
     return bounds, seq, sel[src], id_to_strand, complementary
+
+
+def walk_chains_device(pairs, n_ep, end_distance):
+    """walk_chains for a segment table on the GPU, by the library's strand walk (include/hgs.h hgs_strand_walk_ends / _fill: one
+    lane per strand end follows its chain through a node table -- two launches and a handful of index operations instead of the
+    ~120 launches of walk_chains_torch's pointer doubling; 2.7 -> 1 ms on a 4 10^5-segment model, twice per topology event).
+    Same returns as walk_chains_torch (same strands, numbering, order and orientation: tests/test_gpu_train.py compares all three
+    forms); None if the table is not a set of chains (an endpoint of degree > 2), for the caller to fall back."""
+    import hgs_runtime as rt
+    dev, n = pairs.device, int(pairs.shape[0])
+    pairs = rt.require_gpu_tensor(pairs, "endpoint pairs", torch.int64)
+    i32, i64 = dict(dtype=torch.int32, device=dev), dict(dtype=torch.int64, device=dev)
+    deg, nodes = torch.empty(n_ep, **i32), torch.empty((n_ep, 4), **i32)
+    other, length, flags = torch.empty(n_ep, **i32), torch.empty(n_ep, **i32), torch.empty(1, **i32)
+    id_to_strand = torch.full((n_ep,), -1, **i32)
+    L = rt.lib()
+    with torch.cuda.device(dev):
+        rt.check(L.hgs_strand_walk_ends(rt.current_stream(), n, int(n_ep), rt.ptr(pairs), rt.ptr(deg), rt.ptr(nodes), rt.ptr(other),
+                                        rt.ptr(length), rt.ptr(flags)))
+        # a strand is stored from its end with the SMALLER id, strands in ascending order of that id (walk_chains)
+        starts = torch.nonzero(other > torch.arange(n_ep, **i32)).squeeze(1)
+        if int(flags.item()) != 0:
+            return None
+        S = int(starts.numel())
+        if S == 0:
+            return torch.zeros(1, **i64), torch.zeros((0, 2), **i64), torch.zeros(0, **i64), id_to_strand, other
+        others = other[starts].to(torch.int64)
+        offsets = torch.zeros(S + 1, **i64)
+        torch.cumsum(length[starts], dim=0, out=offsets[1:])
+        d = end_distance(torch.cat([starts, others]))
+        flip = (d[:S] > d[S:]).to(torch.uint8)          # the far end was first: stored from the other one
+        rows, seg_rows = torch.empty((n, 2), **i64), torch.empty(n, **i64)
+        rt.check(L.hgs_strand_walk_fill(rt.current_stream(), S, rt.ptr(starts), rt.ptr(offsets), rt.ptr(flip), rt.ptr(nodes),
+                                        rt.ptr(rows), rt.ptr(seg_rows), rt.ptr(id_to_strand)))
+        total = int(offsets[-1].item())                 # (segments on closed loops are on no strand)
+    return offsets, rows[:total], seg_rows[:total], id_to_strand, other
 
 
 def nearest_distance(points, refs, chunk=65536):
@@ -706,9 +744,11 @@ class HairGaussianModel(HairTopologyMixin, GaussianModel):
             # (longest strand so far, with room for what one operator can do to it -- a merge joins at most three strands end to
             # end, a split doubles a segment: walk_chains_torch checks the guess and falls back)
             prev = getattr(self, "_longest_strand", None)
-            offsets, rows, seg_rows, i2s, comp = walk_chains_torch(
-                pairs_t, ep.shape[0], lambda ids: nearest_distance(ep[ids], roots, chunk),
-                max_len_hint=None if prev is None else max(64, 4 * prev))
+            end_distance = lambda ids: nearest_distance(ep[ids], roots, chunk)
+            walked = walk_chains_device(pairs_t, ep.shape[0], end_distance) if os.environ.get("HGS_STRAND_WALK", "device") == "device" else None
+            if walked is None:      # (a table that is not a set of chains, or the torch form asked for: HGS_STRAND_WALK=torch)
+                walked = walk_chains_torch(pairs_t, ep.shape[0], end_distance, max_len_hint=None if prev is None else max(64, 4 * prev))
+            offsets, rows, seg_rows, i2s, comp = walked
             self.strands_info = StrandsInfo(offsets.cpu().numpy(), rows.cpu().numpy(), seg_rows.cpu().numpy(),
                                             i2s.cpu().numpy(), comp.cpu().numpy())
             off_h = self.strands_info.offsets

@@ -520,6 +520,20 @@ int hgs_knn3(void* stream, int N, const float* points, int* idx /* [N,3] */, flo
  *   (scene/hair_gaussian_model.py:1466-1470): out[i] = min_m |points[i] - refs[m]| in float64 (points float32 [N,3], refs
  *   float64 [M,3], M >= 1). */
 int hgs_nearest_distance_f64(void* stream, int N, int M, const float* points, const double* refs, double* out);
+/* hgs_strand_walk_ends / hgs_strand_walk_fill <-> the walk over every open polyline of the segment table in compute_strands_info
+ *   (scene/hair_gaussian_model.py:1410-1498; its per-strand Python loop :1432-1464).  pairs[n][2]: endpoint ids of the segments
+ *   (every id of degree 1 or 2, ids < n_ep).
+ *   _ends: builds the node table (nodes: n_ep x 16 bytes of scratch, 16-byte aligned; deg[n_ep]: degrees) and walks from every
+ *   chain end: other[e] = the end its chain runs into (-1 for ids that are no chain end -- which makes `other` the reference's
+ *   strand_endpoint_id_to_complementary), len[e] = the chain's segment count.  flags[0] != 0 afterwards: the table is not a set of
+ *   chains (an id out of range or of degree > 2); the outputs are then undefined.
+ *   _fill: for the S strands the caller has numbered (starts[s] = the end the strand is stored FROM, offsets[S+1] = prefix of their
+ *   lengths, flip[s] != 0 = store it in the opposite direction), writes rows[total][2] = (current, next) endpoint id of every
+ *   segment in strand order, seg_rows[total] = its row of `pairs`, id_to_strand[id] = s for every endpoint on a strand (the caller
+ *   pre-fills -1).  Closed loops have no end and appear nowhere, like in the reference's walk. */
+int hgs_strand_walk_ends(void* stream, int n, int n_ep, const long long* pairs, int* deg, void* nodes, int* other, int* len, int* flags);
+int hgs_strand_walk_fill(void* stream, int S, const long long* starts, const long long* offsets, const unsigned char* flip,
+                         const void* nodes, long long* rows, long long* seg_rows, int* id_to_strand);
 
 /* Tile culling (default on).  The reference gives every Gaussian the tiles of its 3-sigma square (forward.cu:229-235,
  * auxiliary.h:46-56) although a pixel only blends it where opacity * exp(power) >= 1/255 (forward.cu:358): with culling on,

@@ -1829,3 +1829,51 @@ def test_row_run_counting_in_the_fused_iterations(kind):
             assert torch.equal(x, y)
         assert bool(a[6].abs().sum() > 0)
     assert int(out[True][-1][5].max()) > 40                 # radii: rectangles of more than 16 tiles exist
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_device_strand_walk_equals_the_host_walk(seed):
+    """hgs_strand_walk_ends / hgs_strand_walk_fill (scene.hair_gaussian_model.walk_chains_device) against walk_chains (numpy: the
+    restatement the CPU tests pin to 112 runs of the reference) and walk_chains_torch: the same strands in the same order and
+    orientation, the same id -> strand and end -> other-end tables.  Random sets of chains of 1 .. 300 segments with shuffled
+    endpoint ids, shuffled rows and randomly reversed rows, closed loops (left out by every form), unused ids; then a table with an
+    endpoint of degree 3, which the device form refuses (None: compute_strands_info falls back)."""
+    from scene.hair_gaussian_model import walk_chains, walk_chains_device, walk_chains_torch
+    rng = np.random.default_rng(seed)
+    lens = np.concatenate([rng.integers(1, 300, size=400), np.ones(50, np.int64), rng.integers(2, 12, size=30)])
+    n_chain = 450                                            # the last 30 are closed loops
+    pairs, nid = [], 0
+    for c, L in enumerate(lens):
+        ids = np.arange(nid, nid + L + (1 if c < n_chain else 0))
+        nid = ids[-1] + 1
+        seq = np.stack([ids[:-1], ids[1:]], 1) if c < n_chain else np.stack([ids, np.roll(ids, -1)], 1)
+        pairs.append(seq)
+    pairs = np.concatenate(pairs)
+    n_ep = nid + 17                                          # (ids nobody uses)
+    relabel = rng.permutation(n_ep)
+    pairs = relabel[pairs]
+    swap = rng.random(pairs.shape[0]) < 0.5
+    pairs[swap] = pairs[swap][:, ::-1]
+    pairs = pairs[rng.permutation(pairs.shape[0])].astype(np.int64)
+    pos = rng.normal(size=(n_ep, 3))
+    roots = rng.normal(size=(64, 3))
+
+    def end_distance_np(ids):
+        return np.sqrt(((pos[ids][:, None, :] - roots[None]) ** 2).sum(-1)).min(1)
+
+    i2s_h, comp_h = -np.ones(n_ep, np.int32), -np.ones(n_ep, np.int32)
+    off_h, rows_h, seg_h = walk_chains(pairs, n_ep, i2s_h, comp_h, end_distance_np)
+    pt = torch.as_tensor(pairs, device="cuda")
+    pos_t, roots_t = torch.as_tensor(pos, device="cuda"), torch.as_tensor(roots, device="cuda")
+    end_distance_t = lambda ids: torch.cdist(pos_t[ids], roots_t).min(dim=1).values
+    for form in (walk_chains_device, walk_chains_torch):
+        off, rows, seg, i2s, comp = form(pt, n_ep, end_distance_t)
+        np.testing.assert_array_equal(off.cpu().numpy(), off_h, err_msg=form.__name__)
+        np.testing.assert_array_equal(rows.cpu().numpy(), rows_h, err_msg=form.__name__)
+        np.testing.assert_array_equal(seg.cpu().numpy(), seg_h, err_msg=form.__name__)
+        np.testing.assert_array_equal(i2s.cpu().numpy(), i2s_h, err_msg=form.__name__)
+        np.testing.assert_array_equal(comp.cpu().numpy(), comp_h, err_msg=form.__name__)
+    assert off_h.shape[0] - 1 == n_chain and int(off_h[-1]) == int(lens[:n_chain].sum())
+    bad = np.concatenate([pairs, np.array([[pairs[0, 0], n_ep - 1], [pairs[0, 0], n_ep - 2]], np.int64)])
+    assert walk_chains_device(torch.as_tensor(bad, device="cuda"), n_ep, end_distance_t) is None
+    assert walk_chains_device(torch.zeros((0, 2), dtype=torch.int64, device="cuda"), n_ep, end_distance_t)[0].tolist() == [0]
