@@ -6,13 +6,19 @@ sys.path[:0] = [ROOT, os.path.join(ROOT, "hair-gs_amd")]
 import torch
 import train
 from arguments import OptimizationParams
-from synthetic import build_workload
+from synthetic import build_workload, build_pipeline_state, PIPELINE_STATES
 from utils.general import safe_state
 names = set((sys.argv[3] if len(sys.argv) > 3 else "split_strategy,compute_endpoint_pair_to_merge,merge_collapsed_segments,_sort_spatially_device,compute_strands_info,walk_chains_torch").split(","))
 iters = int(sys.argv[2]) if len(sys.argv) > 2 else 1500
 safe_state(True)
-model, cams, extent = build_workload(sys.argv[1] if len(sys.argv) > 1 else "north_star", device="cuda", seed=0, n_views=16)
+wl = sys.argv[1] if len(sys.argv) > 1 else "north_star"
 opt = OptimizationParams()
+if wl in PIPELINE_STATES:
+    model, cams, extent, _ = build_pipeline_state(wl, device="cuda", seed=0)
+    opt.iterations = 5000
+    opt._finalise()
+else:
+    model, cams, extent = build_workload(wl, device="cuda", seed=0, n_views=16)
 model.training_setup(opt)
 acc, hits = collections.Counter(), collections.Counter()
 state = {}

@@ -7,12 +7,19 @@ sys.path[:0] = [ROOT, os.path.join(ROOT, "hair-gs_amd")]
 import torch
 import train
 from arguments import OptimizationParams
-from synthetic import build_workload
+from synthetic import build_workload, build_pipeline_state, PIPELINE_STATES
 from utils.general import safe_state
 wl = sys.argv[1] if len(sys.argv) > 1 else "north_star"
 iters = int(sys.argv[2]) if len(sys.argv) > 2 else 3000
 def fresh():
     safe_state(True)
+    if wl in PIPELINE_STATES:       # (stage3_merged: the model Stage III starts from; the operators of a 5000-iteration Stage III)
+        model, cams, extent, _ = build_pipeline_state(wl, device="cuda", seed=0)
+        opt = OptimizationParams()
+        opt.iterations = 5000
+        opt._finalise()
+        model.training_setup(opt)
+        return model, cams, extent, opt
     model, cams, extent = build_workload(wl, device="cuda", seed=0, n_views=16)
     opt = OptimizationParams()
     model.training_setup(opt)
