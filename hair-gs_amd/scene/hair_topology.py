@@ -299,18 +299,37 @@ class HairTopologyMixin:
         is_first = np.zeros(flat.shape[0], bool)
         is_first[first_at] = True
         cand = cand[is_first.reshape(-1, 2).all(axis=1)]
-        blocked, out = set(), []
+        # stage 2 (reference remove_complementary_rows): never merge both ends of one strand in the same round.  The reference walks
+        # the rows in order with a set of blocked ids -- the strand partners of the ids of every row it has kept -- and skips a row that
+        # holds a blocked id.  Id p is blocked exactly when the row that holds partner(p) came earlier and was kept (partner is an
+        # involution on strand ends; after stage 1 an id sits in at most one row): every row depends on at most two EARLIER rows,
+        # and the walk is resolved in a few vectorised rounds -- a row is kept once all the earlier rows it depends on are skipped,
+        # skipped once one of them is kept.  (The loop over thousands of Python lists also fed the cyclic garbage collector: a
+        # Stage-III event's 10^4 temporaries were promoted to its oldest generation, and five full collections of ~100 ms each hit
+        # every 2000 iterations: tools/dev/gc_pauses.py.)
+        m = cand.shape[0]
         partner_of = partner[cand]                # (other end of the same strand, per surviving id)
-        for (p, q), (pp, pq) in zip(cand.tolist(), partner_of.tolist()):
-            # stage 2 (reference remove_complementary_rows): never merge both ends of one strand in the same round
-            if p in blocked or q in blocked:
-                continue
-            blocked.add(pp)
-            blocked.add(pq)
-            out.append((p, q))
-        if not out:
+        row_of = np.full(partner.shape[0], -1, np.int64)
+        rows = np.arange(m, dtype=np.int64)
+        row_of[cand[:, 0]] = rows
+        row_of[cand[:, 1]] = rows
+        dep = np.where(partner_of >= 0, row_of[np.maximum(partner_of, 0)], -1)
+        has = (dep >= 0) & (dep < rows[:, None])  # only rows in front of this one can have blocked it
+        dep = np.where(has, dep, 0)
+        state = np.zeros(m, np.int8)              # 0 undecided, 1 kept, 2 skipped
+        while True:
+            und = state == 0
+            if not und.any():
+                break
+            st = np.where(has, state[dep], 2)
+            blocked = (st == 1).any(axis=1)
+            free = (st == 2).all(axis=1)
+            state[und & blocked] = 2
+            state[und & ~blocked & free] = 1
+        out = cand[state == 1]
+        if out.shape[0] == 0:
             return empty
-        return torch.as_tensor(np.asarray(out, np.int64), device=self.device)
+        return torch.as_tensor(np.ascontiguousarray(out, dtype=np.int64), device=self.device)
 
     @staticmethod
     def _radius_pairs_gpu(pos, dirs, radius, min_cos, bidirectional):

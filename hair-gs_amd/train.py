@@ -10,6 +10,8 @@ averaged, densification statistics are reduced the same way (SUM / MAX), then ev
 Adam update, so parameters stay replicated bit for bit.  Topology operators run on identical replicated state with
 identical seeds.
 """
+import gc
+import os
 import random
 
 import torch
@@ -18,6 +20,15 @@ import torch.distributed as dist
 from gaussian_renderer import render
 from loss.losses import loss_function, loss_function_single_pass
 from scene.hair_gaussian_model import HairGaussianModel
+
+# The cyclic garbage collector's oldest generation holds ~2.8 10^5 objects once torch and this package are imported, and a full
+# collection walks all of them: ~100 ms, during which the GPU idles.  The topology operators of a strand model late in training
+# (thousands of merge candidates per event) allocate enough containers to trigger one every few events -- 510 ms of a 2.9 s run of
+# 2000 Stage-III iterations (tools/dev/gc_pauses.py).  What is alive NOW is the imported libraries, not a model: it moves to the
+# permanent generation, which collections skip (gc.freeze: what CPython documents for exactly this); everything created from here
+# on -- models, graphs, the operators' temporaries -- is collected as before.  HGS_GC_FREEZE=0 leaves the collector alone.
+if os.environ.get("HGS_GC_FREEZE", "1") != "0":
+    gc.freeze()
 
 
 class ViewParallel:
