@@ -417,6 +417,7 @@ class HairGaussianModel(HairTopologyMixin, GaussianModel):
         self.strands_info = StrandsInfo(new_off.cpu().numpy(), rows_new.cpu().numpy(), np.arange(total, dtype=np.int64),
                                         i2s.cpu().numpy(), comp.cpu().numpy())
         self._strands_dev = (new_off, rows_new, ar_t)
+        self._comp_dev = comp
         return sp.cpu().numpy(), epp.cpu().numpy()
 
     def _apply_storage_permutation(self, sp, epp, inv_ep):
@@ -443,6 +444,7 @@ class HairGaussianModel(HairTopologyMixin, GaussianModel):
 
     _storage_dirty = False
     _strands_dev = None
+    _comp_dev = None        # strand end -> the other end of its strand, on the device (int32 [E], -1 elsewhere): with _strands_dev
     _strands_info = None
 
     @property
@@ -457,6 +459,7 @@ class HairGaussianModel(HairTopologyMixin, GaussianModel):
         # topology can then never be taken for the current one
         self._strands_info = value
         self._strands_dev = None
+        self._comp_dev = None
         self._smooth_pairs = None
 
     def _maybe_sort_spatially(self):
@@ -755,6 +758,7 @@ class HairGaussianModel(HairTopologyMixin, GaussianModel):
             self._longest_strand = int((off_h[1:] - off_h[:-1]).max()) if len(off_h) > 1 else None
             # device copies for sort_spatially (offsets, rows, the row of endpoint_pairs behind every strand row)
             self._strands_dev = (offsets, rows, seg_rows if fg_rows is None else fg_rows[seg_rows])
+            self._comp_dev = comp
             self._smooth_pairs = None
             return
         self._strands_dev = None

@@ -4,6 +4,8 @@ clone / split / merge-collapsed / prune, :1079-1096 merging, :1205-1362 compute_
 clean_gaussians).  Mixed into HairGaussianModel.  They run every `densification_interval` / `merge_interval` = 100
 iterations on replicated state; the greedy selections are sequential by nature and stay on the host (the reference
 loops over CUDA tensors element by element, :1246-1253), the candidate search is one vectorised kd-tree query."""
+import os
+
 import numpy as np
 import torch
 
@@ -253,52 +255,61 @@ class HairTopologyMixin:
         pos_t = self._endpoints[ends].detach()
         dirs_t = self._endpoints[comp].detach() - pos_t
         dirs_t = dirs_t / torch.norm(dirs_t, dim=1, keepdim=True)
-        pos, dirs, ends_np = pos_t.cpu().numpy(), dirs_t.cpu().numpy(), ends.cpu().numpy()
         partner = self.strands_info.strand_endpoint_id_to_complementary  # other end of the same strand, per id
-        if pos_t.is_cuda:
-            # candidate search on the GPU (hgs_radius_pairs: distance + direction test, brute force over the strand ends)
-            a, b = self._radius_pairs_gpu(pos_t, dirs_t, float(self.merge_dist_th), float(dir_th),
-                                          bool(self.training_args.bidirectional_merge))
-            ok = partner[ends_np[a]] != ends_np[b]
-        else:
-            pairs = cKDTree(pos).query_pairs(r=float(self.merge_dist_th), output_type="ndarray")
-            if pairs.shape[0] == 0:
+        comp_dev = getattr(self, "_comp_dev", None)
+        if pos_t.is_cuda and max_num_nn <= 0 and comp_dev is not None and comp_dev.shape[0] == self._endpoints.shape[0] \
+                and os.environ.get("HGS_MERGE_SEARCH", "device") == "device":       # (HGS_MERGE_SEARCH=host: the form below, for A/B)
+            # everything up to stage 1 on the device: late in Stage III a frame has 5 10^5 strand ends and 3 10^5 candidate pairs,
+            # and the host form below -- norm, lexsort, unique over all of them -- took 95 of an event's 125 ms
+            cand = self._merge_candidates_device(pos_t, dirs_t, ends, comp_dev, float(dir_th))
+            if cand.shape[0] == 0:
                 return empty
-            a, b = pairs[:, 0], pairs[:, 1]
-            ok = partner[ends_np[a]] != ends_np[b]
-            dot = -(dirs[a] * dirs[b]).sum(1)                     # directions must be opposite
-            if self.training_args.bidirectional_merge:
-                dot = np.abs(dot)
-            ok &= dot >= dir_th
-        a, b = a[ok], b[ok]
-        if a.shape[0] == 0:
-            return empty
-        dist = np.linalg.norm(pos[a] - pos[b], axis=1)
-        order = np.lexsort((b, a, dist))          # deterministic whatever order the candidates were found in
-        a, b, dist = a[order], b[order], dist[order]
-        if max_num_nn > 0:  # cap candidates per point, nearest first
-            order = np.argsort(dist, kind="stable")
+        else:
+            pos, dirs, ends_np = pos_t.cpu().numpy(), dirs_t.cpu().numpy(), ends.cpu().numpy()
+            if pos_t.is_cuda:
+                # candidate search on the GPU (hgs_radius_pairs: distance + direction test, brute force over the strand ends)
+                a, b = self._radius_pairs_gpu(pos_t, dirs_t, float(self.merge_dist_th), float(dir_th),
+                                              bool(self.training_args.bidirectional_merge))
+                ok = partner[ends_np[a]] != ends_np[b]
+            else:
+                pairs = cKDTree(pos).query_pairs(r=float(self.merge_dist_th), output_type="ndarray")
+                if pairs.shape[0] == 0:
+                    return empty
+                a, b = pairs[:, 0], pairs[:, 1]
+                ok = partner[ends_np[a]] != ends_np[b]
+                dot = -(dirs[a] * dirs[b]).sum(1)                     # directions must be opposite
+                if self.training_args.bidirectional_merge:
+                    dot = np.abs(dot)
+                ok &= dot >= dir_th
+            a, b = a[ok], b[ok]
+            if a.shape[0] == 0:
+                return empty
+            dist = np.linalg.norm(pos[a] - pos[b], axis=1)
+            order = np.lexsort((b, a, dist))          # deterministic whatever order the candidates were found in
             a, b, dist = a[order], b[order], dist[order]
-            seen = {}
-            keep = np.ones(len(a), bool)
-            for i, (x, y) in enumerate(zip(a, b)):
-                if seen.get(x, 0) >= max_num_nn or seen.get(y, 0) >= max_num_nn:
-                    keep[i] = False
-                else:
-                    seen[x] = seen.get(x, 0) + 1
-                    seen[y] = seen.get(y, 0) + 1
-            a, b, dist = a[keep], b[keep], dist[keep]
-        order = np.argsort(dist, kind="stable")
-        cand = np.stack([ends_np[a[order]], ends_np[b[order]]], 1)
-        # stage 1 (reference remove_duplicate_endpoint_rows): both ids must occur here for the first time in the
-        # distance-sorted candidate list -- ids of rejected rows count as seen too, so the test does not depend on what was
-        # accepted: a row survives iff it holds the first occurrence of both its ids (one np.unique instead of a Python loop
-        # over every candidate: thousands per merge event, a few hundred survivors)
-        flat = cand.reshape(-1)
-        _, first_at = np.unique(flat, return_index=True)
-        is_first = np.zeros(flat.shape[0], bool)
-        is_first[first_at] = True
-        cand = cand[is_first.reshape(-1, 2).all(axis=1)]
+            if max_num_nn > 0:  # cap candidates per point, nearest first
+                order = np.argsort(dist, kind="stable")
+                a, b, dist = a[order], b[order], dist[order]
+                seen = {}
+                keep = np.ones(len(a), bool)
+                for i, (x, y) in enumerate(zip(a, b)):
+                    if seen.get(x, 0) >= max_num_nn or seen.get(y, 0) >= max_num_nn:
+                        keep[i] = False
+                    else:
+                        seen[x] = seen.get(x, 0) + 1
+                        seen[y] = seen.get(y, 0) + 1
+                a, b, dist = a[keep], b[keep], dist[keep]
+            order = np.argsort(dist, kind="stable")
+            cand = np.stack([ends_np[a[order]], ends_np[b[order]]], 1)
+            # stage 1 (reference remove_duplicate_endpoint_rows): both ids must occur here for the first time in the
+            # distance-sorted candidate list -- ids of rejected rows count as seen too, so the test does not depend on what was
+            # accepted: a row survives iff it holds the first occurrence of both its ids (one np.unique instead of a Python loop
+            # over every candidate: thousands per merge event, a few hundred survivors)
+            flat = cand.reshape(-1)
+            _, first_at = np.unique(flat, return_index=True)
+            is_first = np.zeros(flat.shape[0], bool)
+            is_first[first_at] = True
+            cand = cand[is_first.reshape(-1, 2).all(axis=1)]
         # stage 2 (reference remove_complementary_rows): never merge both ends of one strand in the same round.  The reference walks
         # the rows in order with a set of blocked ids -- the strand partners of the ids of every row it has kept -- and skips a row that
         # holds a blocked id.  Id p is blocked exactly when the row that holds partner(p) came earlier and was kept (partner is an
@@ -330,6 +341,54 @@ class HairTopologyMixin:
         if out.shape[0] == 0:
             return empty
         return torch.as_tensor(np.ascontiguousarray(out, dtype=np.int64), device=self.device)
+
+    def _merge_candidates_device(self, pos, dirs, ends, comp_dev, dir_th):
+        """The candidate rows of compute_endpoint_pair_to_merge after its stage 1, [K, 2] endpoint ids on the host, from device
+        operations only: hgs_radius_pairs, the same-strand filter (comp_dev: strand end -> other end), the distances with numpy's
+        expression and association (sqrt((dx dx + dy dy) + dz dz) in float32: the same bits as np.linalg.norm over three
+        components), the order (distance, a, b) by two sorts (a sort on the unique key a n + b, then a stable one on the distance
+        = np.lexsort((b, a, dist))), and the first-occurrence rule by a scatter-min of the row positions (order-independent, like
+        remove_duplicate_endpoint_rows).  tests/test_gpu_knn.py compares the merged pairs with the CPU model's."""
+        import hgs_runtime as rt
+        n, dev = pos.shape[0], pos.device
+        pos = rt.require_gpu_tensor(pos, "positions", torch.float32)
+        dirs = rt.require_gpu_tensor(dirs, "directions", torch.float32)
+        order = torch.argsort(pos[:, 0])
+        ps, ds = pos[order].contiguous(), dirs[order].contiguous()
+        cap = max(4 * n, 1024)
+        while True:
+            pairs = torch.empty((cap, 2), dtype=torch.int32, device=dev)
+            dist_k = torch.empty((cap,), dtype=torch.float32, device=dev)
+            count = torch.zeros(1, dtype=torch.int32, device=dev)
+            with torch.cuda.device(dev):
+                rt.check(rt.lib().hgs_radius_pairs(rt.current_stream(), n, rt.ptr(ps), rt.ptr(ds), float(self.merge_dist_th), float(dir_th),
+                                                   int(bool(self.training_args.bidirectional_merge)), cap, rt.ptr(pairs), rt.ptr(dist_k),
+                                                   rt.ptr(count), 1))
+            found = int(count.item())
+            if found <= cap:
+                break
+            cap = found
+        empty = np.zeros((0, 2), np.int64)
+        if found == 0:
+            return empty
+        ia, ib = order[pairs[:found, 0].long()], order[pairs[:found, 1].long()]      # back to the caller's indices
+        a, b = torch.minimum(ia, ib), torch.maximum(ia, ib)
+        ea, eb = ends[a], ends[b]
+        ok = comp_dev[ea].long() != eb                   # not the two ends of one strand
+        a, b, ea, eb = a[ok], b[ok], ea[ok], eb[ok]
+        if a.numel() == 0:
+            return empty
+        d = pos[a] - pos[b]
+        dist = torch.sqrt((d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1]) + d[:, 2] * d[:, 2])
+        o1 = torch.argsort(a * n + b)
+        o = o1[torch.argsort(dist[o1], stable=True)]
+        cand = torch.stack([ea[o], eb[o]], dim=1)
+        flat = cand.reshape(-1)
+        at = torch.arange(flat.shape[0], dtype=torch.long, device=dev)
+        first = torch.full((int(self._endpoints.shape[0]),), flat.shape[0], dtype=torch.long, device=dev)
+        first.scatter_reduce_(0, flat, at, reduce="amin", include_self=True)
+        keep = (first[flat] == at).reshape(-1, 2).all(dim=1)
+        return cand[keep].cpu().numpy()
 
     @staticmethod
     def _radius_pairs_gpu(pos, dirs, radius, min_cos, bidirectional):
