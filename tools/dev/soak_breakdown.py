@@ -14,7 +14,7 @@ iters = int(sys.argv[2]) if len(sys.argv) > 2 else 3000
 def fresh():
     safe_state(True)
     if wl in PIPELINE_STATES:       # (stage3_merged: the model Stage III starts from; the operators of a 5000-iteration Stage III)
-        model, cams, extent, _ = build_pipeline_state(wl, device="cuda", seed=0)
+        model, cams, extent, _ = build_pipeline_state(wl, device="cuda", seed=0, stage1_iters=int(os.environ["STAGE1_ITERS"]) if "STAGE1_ITERS" in os.environ else None)
         opt = OptimizationParams()
         opt.iterations = 5000
         opt._finalise()
@@ -52,7 +52,8 @@ wrap(train.GraphedStep, "__init__", "GraphedStep()")
 M = type(model)
 for n in ("densification", "merging", "clone_strategy", "split_strategy", "merge_collapsed_segments", "prune_strategy", "compute_strands_info",
           "compute_endpoint_pair_to_merge", "merge_endpoint_pairs", "sort_spatially", "prune_segments", "cat_segments", "reset_opacity",
-          "get_complementary_endpoint_idx", "smoothness_index_pairs", "get_endpoint_pairs_row_indices", "_maybe_sort_spatially"):
+          "get_complementary_endpoint_idx", "smoothness_index_pairs", "get_endpoint_pairs_row_indices", "_maybe_sort_spatially",
+          "densify_and_split", "densify_and_clone", "prune_points", "densification_postfix"):       # (the last four: a Stage-I cloud)
     if hasattr(M, n):
         wrap(M, n)
 t0 = time.perf_counter()
