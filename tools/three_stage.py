@@ -88,7 +88,7 @@ def run_stage(model, cams, opt, extent, n_iters, name, events=None, pause_at=())
     """`events`: list for the operators' counts (training(event_log=)); `pause_at`: iterations (multiples of 100, inside the
     densification schedule) whose densification inputs are checked against the three-pass form: the stage stops 100 iterations in
     front of each, cloud_event_check() runs those 100 itself."""
-    traj, done, t_total = [], 0, 0.0
+    traj, done, t_total, t_checks = [], 0, 0.0, 0.0
     checks = []
     traj.append({"iteration": 0, "psnr_db": psnr_all(model, cams), "primitives": int(model.get_xyz.shape[0]), "seconds": 0.0})
     log(name, traj[-1])
@@ -107,6 +107,7 @@ def run_stage(model, cams, opt, extent, n_iters, name, events=None, pause_at=())
             checks.append(cloud_event_check(model, cams, opt, extent, done, events))
             torch.cuda.synchronize()
             t_total += time.perf_counter() - t0       # (the check's 100 iterations are iterations of the stage, run eagerly twice over)
+            t_checks += time.perf_counter() - t0
             done += 100
             log(name, "event check", checks[-1])
         if done % 500 == 0 or done == n_iters:
@@ -114,7 +115,7 @@ def run_stage(model, cams, opt, extent, n_iters, name, events=None, pause_at=())
                          "seconds": t_total})
             log(name, traj[-1])
     if pause_at:
-        return traj, t_total, checks
+        return traj, t_total, checks, t_checks
     return traj, t_total
 
 
@@ -245,10 +246,12 @@ def stages_one_and_two(record):
         # events 6, 10 and 20 of the schedule (densification from iteration 500, every 100: iterations 1100, 1500, 2500)
         first = (int(opt1.densify_from_iter) // 100 + 1) * 100
         pause = tuple(p for p in (first + 500, first + 900, first + 1900) if p <= min(N1, int(opt1.densify_until_iter) - 1))
-        traj1, t1, checks = run_stage(cloud, cams, opt1, extent, N1, "stage I", events=ev1, pause_at=pause) if pause else \
-            (run_stage(cloud, cams, opt1, extent, N1, "stage I", events=ev1) + ([],))
-        out["stage_I"] = {"iterations": N1, "seconds": t1, "its_per_sec": N1 / t1, "trajectory": traj1, "events": ev1,
-                          "stage_I_event_checks": checks}
+        traj1, t1, checks, tc = run_stage(cloud, cams, opt1, extent, N1, "stage I", events=ev1, pause_at=pause) if pause else \
+            (run_stage(cloud, cams, opt1, extent, N1, "stage I", events=ev1) + ([], 0.0))
+        # (an event check runs its 100 iterations eagerly, twice over, in the three-pass form: seconds of the tool, not of the loop)
+        out["stage_I"] = {"iterations": N1, "seconds": t1, "its_per_sec": N1 / t1, "seconds_in_event_checks": tc,
+                          "its_per_sec_outside_the_checks": (N1 - 100 * len(checks)) / max(t1 - tc, 1e-9), "trajectory": traj1,
+                          "events": ev1, "stage_I_event_checks": checks}
     else:
         training(cloud, cams, opt1, iterations=N1, extent=extent, start_iteration=0)
     torch.cuda.synchronize()
