@@ -208,7 +208,10 @@ def stage1_cloud(gt_pts, gt_model, extent, device="cuda", seed=1, jitter=0.002, 
 #                  reference's Stage-I loop (densification from 500, every 100)
 #   stage3_merged  the Stage-II product of the same capture: Stage I for `stage1_iters` iterations, to_hair_gaussian_model, merge
 #                  rounds to the fixed point (merge.merge_rounds) -- the model Stage III starts from
-PIPELINE_STATES = {"stage1_1080p": ("c3_capture", "cloud"), "stage3_merged": ("c3_capture", "merged")}
+PIPELINE_STATES = {"stage1_1080p": ("c3_capture", "cloud"), "stage3_merged": ("c3_capture", "merged"),
+                   # BASELINE config 4's Stage I (10^6 Gaussians from jittered midpoints of curly strands): bench.py --workload stage1_c4
+                   # --stage1-iters 0 times its first iterations; not a leg of the default bench line
+                   "stage1_c4": ("c4_capture", "cloud")}
 
 
 def build_pipeline_state(name, device="cuda", seed=0, stage1_iters=None, n_views=None, log=None):
