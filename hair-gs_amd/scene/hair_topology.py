@@ -2,8 +2,10 @@
 scene/hair_gaussian_model.py:619-706 merge_endpoint_pairs, :712-784 index helpers, :788-1077 densification =
 clone / split / merge-collapsed / prune, :1079-1096 merging, :1205-1362 compute_endpoint_pair_to_merge, :1500-1515
 clean_gaussians).  Mixed into HairGaussianModel.  They run every `densification_interval` / `merge_interval` = 100
-iterations on replicated state; the greedy selections are sequential by nature and stay on the host (the reference
-loops over CUDA tensors element by element, :1246-1253), the candidate search is one vectorised kd-tree query."""
+iterations on replicated state.  The reference loops over CUDA tensors element by element (:1246-1253); here the candidate
+search is one query (kd-tree on the CPU, hgs_radius_pairs on the GPU, where the candidates also stay on the device up to the
+first-occurrence rule) and the greedy selections, sequential in the reference, are resolved in vectorised rounds that keep its
+order (compute_endpoint_pair_to_merge)."""
 import os
 
 import numpy as np
