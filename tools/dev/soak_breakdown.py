@@ -43,6 +43,8 @@ def wrap(owner, name, label=None):
             return orig(*a, **k)
         finally:
             torch.cuda.synchronize(); acc[label] += time.perf_counter() - t0; cnt[label] += 1
+            if label == os.environ.get("EACH"):      # every call of one function, in ms
+                print(f"   {label} call {cnt[label]}: {1e3 * (time.perf_counter() - t0):.2f} ms", flush=True)
     setattr(owner, name, w)
 
 
