@@ -320,6 +320,16 @@ class HairTopologyMixin:
         # skipped once one of them is kept.  (The loop over thousands of Python lists also fed the cyclic garbage collector: a
         # Stage-III event's 10^4 temporaries were promoted to its oldest generation, and five full collections of ~100 ms each hit
         # every 2000 iterations: tools/dev/gc_pauses.py.)
+        out = cand[self._keep_rows_whose_strand_partners_are_free(cand, partner)]
+        if out.shape[0] == 0:
+            return empty
+        return torch.as_tensor(np.ascontiguousarray(out, dtype=np.int64), device=self.device)
+
+    @staticmethod
+    def _keep_rows_whose_strand_partners_are_free(cand, partner):
+        """Boolean mask over the rows of `cand` ([m, 2] ids, every id in at most one row): the rows the reference's in-order walk
+        keeps (remove_complementary_rows: skip a row that holds the strand partner of an id of a row kept before).
+        tests/test_host_helpers_cpu.py compares it with that walk on random tables."""
         m = cand.shape[0]
         partner_of = partner[cand]                # (other end of the same strand, per surviving id)
         row_of = np.full(partner.shape[0], -1, np.int64)
@@ -330,19 +340,21 @@ class HairTopologyMixin:
         has = (dep >= 0) & (dep < rows[:, None])  # only rows in front of this one can have blocked it
         dep = np.where(has, dep, 0)
         state = np.zeros(m, np.int8)              # 0 undecided, 1 kept, 2 skipped
-        while True:
+        for _ in range(64):
             und = state == 0
             if not und.any():
-                break
+                return state == 1
             st = np.where(has, state[dep], 2)
             blocked = (st == 1).any(axis=1)
             free = (st == 2).all(axis=1)
             state[und & blocked] = 2
             state[und & ~blocked & free] = 1
-        out = cand[state == 1]
-        if out.shape[0] == 0:
-            return empty
-        return torch.as_tensor(np.ascontiguousarray(out, dtype=np.int64), device=self.device)
+        # a dependency chain longer than the rounds above (rows that follow each other end to end IN the table's order: a round
+        # settles one link of it): the rest by the walk itself, over the undecided rows only
+        for r in np.nonzero(state == 0)[0].tolist():
+            d0, d1 = (int(dep[r, 0]) if has[r, 0] else -1), (int(dep[r, 1]) if has[r, 1] else -1)
+            state[r] = 2 if (d0 >= 0 and state[d0] == 1) or (d1 >= 0 and state[d1] == 1) else 1
+        return state == 1
 
     def _merge_candidates_device(self, pos, dirs, ends, comp_dev, dir_th):
         """The candidate rows of compute_endpoint_pair_to_merge after its stage 1, [K, 2] endpoint ids on the host, from device

@@ -100,3 +100,36 @@ def test_training_event_log_and_visible_gpus_need_no_gpu():
     assert n is None or n >= 0
     if not os.path.isdir("/sys/class/kfd"):
         assert n == 0
+
+
+def test_greedy_partner_filter_equals_the_in_order_walk():
+    """HairTopologyMixin._keep_rows_whose_strand_partners_are_free (stage 2 of compute_endpoint_pair_to_merge resolved in vectorised
+    rounds) against the reference's walk (scene/hair_gaussian_model.py:1331-1362: a set of blocked ids, rows in order) on random
+    tables: strands of two ends each, candidate rows pairing ends of different strands, every id in at most one row, long
+    dependency chains included (row k pairs the far end of strand k with the near end of strand k + 1)."""
+    from scene.hair_topology import HairTopologyMixin
+    rng = np.random.default_rng(5)
+    for trial in range(200):
+        n_strands = int(rng.integers(2, 400))
+        n_ids = 2 * n_strands + int(rng.integers(0, 5))
+        ids = rng.permutation(n_ids)[:2 * n_strands]
+        partner = -np.ones(n_ids, np.int32)
+        partner[ids[0::2]], partner[ids[1::2]] = ids[1::2], ids[0::2]
+        if trial % 3 == 0:      # a chain: every row depends on the one in front of it
+            cand = np.stack([ids[1:-1:2], ids[2::2]], 1)
+        else:
+            free = rng.permutation(ids)
+            k = int(rng.integers(1, n_strands + 1))
+            cand = free[:2 * k].reshape(k, 2)
+            cand = cand[partner[cand[:, 0]] != cand[:, 1]]          # (the two ends of one strand are never a candidate row)
+        if trial % 2:
+            cand = cand[rng.permutation(cand.shape[0])]
+        cand = cand.astype(np.int64)
+        blocked, keep = set(), []
+        for (p, q) in cand.tolist():
+            if p in blocked or q in blocked:
+                keep.append(False)
+                continue
+            blocked.add(int(partner[p])); blocked.add(int(partner[q])); keep.append(True)
+        got = HairTopologyMixin._keep_rows_whose_strand_partners_are_free(cand, partner)
+        np.testing.assert_array_equal(got, np.asarray(keep, bool), err_msg=f"trial {trial}")
