@@ -285,6 +285,15 @@ static int forward_preprocess_impl(void* stream, int P, int D, int M, int W, int
   return 0;
 }
 
+// How the blend kernels get their records (hgs_common.h, HgsBinning::lazy): 1 always from the templates, 0 always packed by the sort
+// kernel, -1 (default) by the pass's entries per tile.
+static int g_lazy_mode = -1;
+extern "C" int hgs_set_lazy_records(int mode) {
+  const int was = g_lazy_mode;
+  g_lazy_mode = mode > 0 ? 1 : (mode < 0 ? -1 : 0);
+  return was;
+}
+
 static int forward_render_impl(void* stream, int P, int W, int H, int R_capacity, const float* bg,
                                const float* colors_precomp, const float* extra, int n_extra, void* geom_buf,
                                void* binning_buf, void* image_buf, float* out_color) {
@@ -304,6 +313,9 @@ static int forward_render_impl(void* stream, int P, int W, int H, int R_capacity
     if (R_capacity > 0) {
       if (check_aligned(binning_buf, "binning_buf")) return 1;
       hgs_binning_carve((char*)binning_buf, (size_t)R_capacity, b, nullptr, channels);
+      b.grec = g.grec;
+      const long long tiles = (long long)((W + HGS_TILE - 1) / HGS_TILE) * ((H + HGS_TILE - 1) / HGS_TILE);
+      b.lazy = g_lazy_mode >= 0 ? g_lazy_mode : ((long long)R_capacity >= (long long)HGS_LAZY_MIN_MEAN_LIST * tiles ? 1 : 0);
     }
     // the scatter also finishes the per-Gaussian instance offsets, so it runs even when nothing is visible
     const float* feat = colors_precomp ? colors_precomp : g.rgb;
@@ -374,6 +386,7 @@ static int backward_impl(void* stream, int P, int D, int M, int R, int W, int H,
   if (R > 0) {
     if (check_aligned(binning_buf, "binning_buf") || check_aligned(scratch, "scratch")) return 1;
     hgs_binning_carve((char*)binning_buf, (size_t)R, b, nullptr, channels);
+    b.grec = g.grec;
     inst_grad = (float*)scratch;   // not cleared here: blend_bwd writes EVERY row (zeros past a tile's last needed entry)
     if (hgs_launch_blend_bwd(s, W, H, R, channels, bg, im, b, dL_dpix_planes, inst_grad, reduce_rows ? 1 : 0)) return 1;
   }

@@ -160,13 +160,15 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_kernel(int nblk, int T, Hgs
 // One instance in its final list position: point_list, the sorted key and the packed record the blend kernels stream.
 // Everything about the Gaussian comes from its 64-byte template (HgsGeom::grec, scatter_kernel): one contiguous gather.
 template <bool EXTRA>   // EXTRA: 64-B records with the 4 extra channels of the single-pass mode, else 48-B records
-__device__ __forceinline__ void emit_instance(uint64_t key, uint32_t pos, int tx, int ty, const HgsGeom& g, const HgsBinning& b) {
+__device__ __forceinline__ void emit_instance(uint64_t key, uint32_t pos, uint32_t start, int tx, int ty, const HgsGeom& g, const HgsBinning& b) {
   const uint32_t id = (uint32_t)key >> HGS_QMASK_SHIFT;
+  b.point_list[pos] = id;
+  b.keys_sorted[pos] = key;
+  (void)start;
+  if (b.lazy) return;                // the blend kernels build the record themselves (stage_quarter, hgs_blend.hip)
   const float4* t = g.grec + 4 * (size_t)id;
   const float4 t0 = t[0], t1 = t[1], t2 = t[2];
   const uint4 u3 = ((const uint4*)t)[3];
-  b.point_list[pos] = id;
-  b.keys_sorted[pos] = key;
   const uint32_t qmask = (uint32_t)key & HGS_QMASK_BITS;   // quadrant mask, computed by the scatter kernel (hgs_quadrant_mask)
   // the instance's slot in Gaussian-major order (offset of the Gaussian + cell of its tile rectangle): the backward stores
   // this instance's row of partial sums there, so that a Gaussian's rows are contiguous for preprocess_bwd_kernel
@@ -495,6 +497,7 @@ __global__ __launch_bounds__(HGS_BLOCK) void sort_tiles_kernel(int gx, int T, ui
   __shared__ uint64_t sk[SK_WORDS];
   constexpr int KPT = SORT_CAP / HGS_BLOCK;
   if (blockIdx.x < WL_BUILDERS) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) im.status[HGS_ST_LAZY] = b.lazy ? 1u : 0u;   // (for the blend kernels of this pass, backward included)
     const int share_w = ((T + WL_BUILDERS - 1) / WL_BUILDERS + HGS_BLOCK - 1) / HGS_BLOCK * HGS_BLOCK;
     __shared__ WlLds wl;
     if (share_w <= SK_WORDS * 4) work_list_shared(T, Rcap, pol, im, b, (uint16_t*)sk, wl);
@@ -554,7 +557,7 @@ __global__ __launch_bounds__(HGS_BLOCK) void sort_tiles_kernel(int gx, int T, ui
 #pragma unroll
     for (int i = 0; i < KPT; i++) {
       const uint32_t e = threadIdx.x + (uint32_t)i * HGS_BLOCK;
-      if (e < cn) emit_instance<EXTRA>(key[i], start + rank[i], tx, ty, g, b);
+      if (e < cn) emit_instance<EXTRA>(key[i], start + rank[i], start, tx, ty, g, b);
     }
     return;
   }
@@ -574,7 +577,7 @@ __global__ __launch_bounds__(HGS_BLOCK) void sort_tiles_kernel(int gx, int T, ui
     for (int i = lane; i < m; i += 64) sk[i] = (uint32_t)i < n ? b.keys[start + i] : ~0ull;
     wave_lds_fence();
     bitonic_wave(sk, m, lane);
-    for (uint32_t i = lane; i < n; i += 64) emit_instance<EXTRA>(sk[i], start + i, tx, ty, g, b);
+    for (uint32_t i = lane; i < n; i += 64) emit_instance<EXTRA>(sk[i], start + i, start, tx, ty, g, b);
     return;
   }
   const uint32_t nchunks = (n + SORT_CAP - 1) / SORT_CAP;
@@ -587,7 +590,7 @@ __global__ __launch_bounds__(HGS_BLOCK) void sort_tiles_kernel(int gx, int T, ui
     __syncthreads();
     bitonic_lds(sk, m);
     if (nchunks == 1) {
-      for (uint32_t i = threadIdx.x; i < cn; i += HGS_BLOCK) emit_instance<EXTRA>(sk[i], cbase + i, tx, ty, g, b);
+      for (uint32_t i = threadIdx.x; i < cn; i += HGS_BLOCK) emit_instance<EXTRA>(sk[i], cbase + i, start, tx, ty, g, b);
     } else {
       for (uint32_t i = threadIdx.x; i < cn; i += HGS_BLOCK) b.keys[cbase + i] = sk[i];
     }
@@ -619,7 +622,7 @@ __global__ __launch_bounds__(HGS_BLOCK) void sort_tiles_kernel(int gx, int T, ui
 #pragma unroll
       for (int i = 0; i < KPT; i++) {
         const uint32_t e = threadIdx.x + (uint32_t)i * HGS_BLOCK;
-        if (e < cn) emit_instance<EXTRA>(key[i], start + rank[i], tx, ty, g, b);
+        if (e < cn) emit_instance<EXTRA>(key[i], start + rank[i], start, tx, ty, g, b);
       }
     }
   }

@@ -172,8 +172,36 @@ __device__ __forceinline__ Rec<C> lds_record(const float4* recs, int e) {
   return r;
 }
 
+// Quarter q of the record of list position `pos` (a lazy pass, hgs_common.h: from the sorted key and the Gaussian's template; what
+// emit_instance of the sort kernel wrote otherwise).  The record's last quarter carries the instance's own words: Gaussian id,
+// quadrant mask (the key's low bits), gradient-row slot (the Gaussian's first row + the cell of its tile rectangle).
+template <int C>
+__device__ __forceinline__ float4 stage_quarter(const HgsBinning& bn, bool lazy, uint32_t pos, int q, int tx, int ty) {
+  constexpr int REC4 = Chan<C>::REC4;
+  if (!lazy) return bn.packed[(size_t)pos * REC4 + q];
+  const uint64_t key = bn.keys_sorted[pos];
+  const uint32_t id = (uint32_t)key >> HGS_QMASK_SHIFT;
+  const float4* t = bn.grec + 4 * (size_t)id;
+  if (q < REC4 - 1) return t[q];
+  const uint4 u3 = ((const uint4*)t)[3];
+  const uint32_t slot = u3.y + ((uint32_t)ty - (u3.z >> 16)) * u3.w + ((uint32_t)tx - (u3.z & 0xFFFFu));
+  const uint32_t w0 = C <= 3 ? __float_as_uint(t[2].x) : u3.x;
+  return make_float4(__uint_as_float(w0), __uint_as_float(id), __uint_as_float((uint32_t)key & HGS_QMASK_BITS), __uint_as_float(slot));
+}
+// (id, slot) of list position `pos` without the rest of the record (the backward's zero rows)
+template <int C>
+__device__ __forceinline__ uint2 stage_id_slot(const HgsBinning& bn, bool lazy, uint32_t pos, int tx, int ty) {
+  if (!lazy) {
+    const float* r = (const float*)(bn.packed + (size_t)pos * Chan<C>::REC4);
+    return make_uint2(__float_as_uint(r[6 + C]), __float_as_uint(r[8 + C]));
+  }
+  const uint32_t id = (uint32_t)bn.keys_sorted[pos] >> HGS_QMASK_SHIFT;
+  const uint4 u3 = ((const uint4*)(bn.grec + 4 * (size_t)id))[3];
+  return make_uint2(id, u3.y + ((uint32_t)ty - (u3.z >> 16)) * u3.w + ((uint32_t)tx - (u3.z & 0xFFFFu)));
+}
+
 // ---- work items ------------------------------------------------------------------------------------------------
-struct BlendItem { int tile; uint32_t seg, nseg, s, e, w; uint2 range; bool split; };
+struct BlendItem { int tile; uint32_t seg, nseg, s, e, w; uint2 range; bool split, lazy; };
 // blockIdx -> (tile, list segment) through the work list of the sort kernel (im.tile_order: segments of split lists
 // first, a tile's segments consecutive, then the other tiles in descending order of list length).  The work item and the
 // counters are independent loads, the tile's range the only dependent one: two memory round trips before the walk starts.
@@ -182,11 +210,14 @@ __device__ __forceinline__ bool blend_item(const HgsImage& im, uint32_t Rcap, Bl
   const uint32_t item = im.tile_order[blockIdx.x];
   if (blockIdx.x >= st.w || item == HGS_ITEM_NONE) return false;
   it.w = blockIdx.x;
+  it.lazy = im.status[HGS_ST_LAZY] != 0u;
   it.split = blockIdx.x < st.y;
   it.tile = (int)HGS_ITEM_TILE(item);
   it.seg = HGS_ITEM_PART(item);
   it.range = im.ranges[it.tile];
-  if (it.range.y > Rcap) it.range = make_uint2(0u, 0u);   // binning buffer under-sized (flagged by the scatter kernel)
+  // binning buffer under-sized (flagged by the scatter kernel): the pass is void -- lists were dropped, sorted keys of the others may
+  // never have been written, and a record is built THROUGH its key (a stray id would be a stray address): every list reads as empty
+  if (it.range.y > Rcap || im.status[HGS_ST_OVERFLOW] != 0u) it.range = make_uint2(0u, 0u);
   const uint32_t n = it.range.y - it.range.x;
   it.nseg = 1u; it.s = 0u; it.e = n;
   if (it.split) {
@@ -207,18 +238,20 @@ __device__ __forceinline__ bool blend_item(const HgsImage& im, uint32_t Rcap, Bl
 // transmittance it stopped at.  A separate per-lane flag costs a byte register and ~6 vector instructions per
 // entry to test, merge and update; the sign costs one compare.
 template <int C>
-__device__ __forceinline__ void fwd_walk(const float4* __restrict__ src, uint32_t s, uint32_t e,
+__device__ __forceinline__ void fwd_walk(const HgsBinning& bn, bool lazy, uint32_t first, int tx, int ty, uint32_t s, uint32_t e,
                                          float4 (&recs)[2][REC_BATCH * Chan<C>::REC4], uint32_t (&alive)[2][4], float pxf,
                                          float pyf, int wave, int lane, float& T, float (&acc)[C], uint32_t& last) {
   constexpr int REC4 = Chan<C>::REC4;
   const uint32_t L = e - s;
   const int nb = (int)((L + REC_BATCH - 1) / REC_BATCH);
-  src += (size_t)s * REC4;
+  const uint32_t base = first + s;                       // list position of the walk's first entry
+  const uint32_t sq = threadIdx.x / REC4;                // this thread stages quarter sr of entry sq of every batch
+  const int sr = (int)(threadIdx.x - sq * REC4);
   const uint32_t nf4 = L * REC4;
   float4 stage = make_float4(0.f, 0.f, 0.f, 0.f);
   __syncthreads();   // (the staging buffers may still be read by a previous walk)
   if (nb > 0) {
-    if (threadIdx.x < REC_BATCH * REC4 && threadIdx.x < nf4) stage = src[threadIdx.x];
+    if (threadIdx.x < REC_BATCH * REC4 && threadIdx.x < nf4) stage = stage_quarter<C>(bn, lazy, base + sq, sr, tx, ty);
     if (threadIdx.x < REC_BATCH * REC4) recs[0][threadIdx.x] = stage;
     if (threadIdx.x < 4) alive[0][threadIdx.x] = 1u;
   }
@@ -226,7 +259,7 @@ __device__ __forceinline__ void fwd_walk(const float4* __restrict__ src, uint32_
     const int cur = b & 1;
     if (b + 1 < nb) {
       const uint32_t i = (uint32_t)(b + 1) * (REC_BATCH * REC4) + threadIdx.x;
-      if (threadIdx.x < REC_BATCH * REC4 && i < nf4) stage = src[i];
+      if (threadIdx.x < REC_BATCH * REC4 && i < nf4) stage = stage_quarter<C>(bn, lazy, base + (uint32_t)(b + 1) * REC_BATCH + sq, sr, tx, ty);
     }
     __syncthreads();
     // forward.cu:309-311: the tile stops when every pixel is saturated (flags written before the barrier above)
@@ -306,7 +339,7 @@ __global__ __launch_bounds__(HGS_BLOCK) __attribute__((amdgpu_waves_per_eu(8))) 
   const int py = ty * HGS_TILE + (wave >> 1) * 8 + (lane >> 3);
   const bool inside = px < W && py < H;
   const float pxf = (float)px, pyf = (float)py;
-  const float4* src = bn.packed + (size_t)it.range.x * REC4;
+  const uint32_t list0 = it.range.x;                    // the tile's first list position
   float acc[C];
 #pragma unroll
   for (int k = 0; k < C; k++) acc[k] = 0.f;
@@ -315,7 +348,7 @@ __global__ __launch_bounds__(HGS_BLOCK) __attribute__((amdgpu_waves_per_eu(8))) 
 
   if (!it.split) {
     float T = inside ? 1.f : -1.f;
-    fwd_walk<C>(src, 0u, it.e, recs, alive, pxf, pyf, wave, lane, T, acc, last);
+    fwd_walk<C>(bn, it.lazy, list0, tx, ty, 0u, it.e, recs, alive, pxf, pyf, wave, lane, T, acc, last);
     uint32_t wmax = last;
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) wmax = max(wmax, (uint32_t)__shfl_xor((int)wmax, d, 64));
@@ -341,13 +374,13 @@ __global__ __launch_bounds__(HGS_BLOCK) __attribute__((amdgpu_waves_per_eu(8))) 
     if (it.seg == 1u) return;
     const uint32_t n = it.range.y - it.range.x;
     float T = inside ? 1.f : -1.f;
-    fwd_walk<C>(src, 0u, it.e, recs, alive, pxf, pyf, wave, lane, T, acc, last);
+    fwd_walk<C>(bn, it.lazy, list0, tx, ty, 0u, it.e, recs, alive, pxf, pyf, wave, lane, T, acc, last);
     const size_t slot1 = ((size_t)it.w + 1) * HGS_BLOCK + threadIdx.x;
     bn.seg_T[slot1] = fabsf(T);
     // (the first segment's colour waits in its own cell of the segment array, which nobody else reads)
 #pragma unroll
     for (int k = 0; k < C; k++) { bn.seg_C[((size_t)it.w * C + k) * HGS_BLOCK + threadIdx.x] = acc[k]; acc[k] = 0.f; }
-    fwd_walk<C>(src, it.e, n, recs, alive, pxf, pyf, wave, lane, T, acc, last);
+    fwd_walk<C>(bn, it.lazy, list0, tx, ty, it.e, n, recs, alive, pxf, pyf, wave, lane, T, acc, last);
 #pragma unroll
     for (int k = 0; k < C; k++) {
       bn.seg_C[(((size_t)it.w + 1) * C + k) * HGS_BLOCK + threadIdx.x] = acc[k];
@@ -377,7 +410,7 @@ __global__ __launch_bounds__(HGS_BLOCK) __attribute__((amdgpu_waves_per_eu(8))) 
   // pass A: the reference's walk over this segment with the transmittance in front of it taken as 1 (no dependence on the
   // segments before it): local product, local colours, last contributing position
   float T = inside ? 1.f : -1.f;
-  fwd_walk<C>(src, it.s, it.e, recs, alive, pxf, pyf, wave, lane, T, acc, last);
+  fwd_walk<C>(bn, it.lazy, list0, tx, ty, it.s, it.e, recs, alive, pxf, pyf, wave, lane, T, acc, last);
   // A pixel that stopped on the local product stops in this segment or before it for any transmittance <= 1 in front:
   // what the later segments read as this segment's product only has to be below the stop threshold.
   const float P = inside ? fmaxf(T, 0.f) : -1.f;
@@ -443,7 +476,7 @@ __global__ __launch_bounds__(HGS_BLOCK) __attribute__((amdgpu_waves_per_eu(8))) 
     last = 0u;
 #pragma unroll
     for (int k = 0; k < C; k++) acc[k] = 0.f;
-    fwd_walk<C>(src, it.s, it.e, recs, alive, pxf, pyf, wave, lane, T, acc, last);
+    fwd_walk<C>(bn, it.lazy, list0, tx, ty, it.s, it.e, recs, alive, pxf, pyf, wave, lane, T, acc, last);
     if (redo) publish();
   }
   _trace.mark(3);
@@ -538,8 +571,8 @@ __global__ __launch_bounds__(HGS_BLOCK) __attribute__((amdgpu_waves_per_eu(HGS_B
   WgTrace _trace(g_wg_trace_bwd);
   _trace.item(tile, it.seg, it.nseg, it.e - it.s);
   const uint2 range = it.range;
-  const float4* __restrict__ packed = bn.packed;
   const uint32_t maxc = im.tile_maxc[tile];
+  const int tx = tile % gx, ty = tile / gx;
   {
     // Every instance row of the scratch is written by exactly one workgroup, so the scratch needs no clearing pass:
     // entries past the last one any pixel needed (positions >= maxc; ~2% of the instances) get explicit zero rows here.
@@ -548,16 +581,16 @@ __global__ __launch_bounds__(HGS_BLOCK) __attribute__((amdgpu_waves_per_eu(HGS_B
       const uint32_t n4 = (end - first) * (ROW / 4);
       for (uint32_t i = threadIdx.x; i < n4; i += HGS_BLOCK) {
         const uint32_t inst = first + i / (ROW / 4);
-        const uint32_t slot = __float_as_uint(((const float*)packed)[(size_t)inst * 4 * REC4 + 8 + C]);
+        const uint2 is = stage_id_slot<C>(bn, it.lazy, inst, tx, ty);
+        const uint32_t slot = is.y;
         // (C = 7: the row's last float names its Gaussian -- what row_reduce_kernel finds the segments of the scratch by)
-        const float tag = (C > 3 && tag_rows && i % (ROW / 4) == ROW / 4 - 1) ? ((const float*)packed)[(size_t)inst * 4 * REC4 + 6 + C] : 0.f;
+        const float tag = (C > 3 && tag_rows && i % (ROW / 4) == ROW / 4 - 1) ? __uint_as_float(is.x) : 0.f;
         if (slot < Rcap) ((float4*)(inst_grad + (size_t)slot * ROW))[i % (ROW / 4)] = make_float4(0.f, 0.f, 0.f, tag);
       }
     }
   }
   if (maxc <= it.s) return;  // nothing in this part of the list contributed to any pixel
   const int seg_lo = (int)it.s, top = (int)min(maxc, it.e);   // list positions [seg_lo, top) are walked, back to front
-  const int tx = tile % gx, ty = tile / gx;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int px = tx * HGS_TILE + (wave & 1) * 8 + (lane & 7);
   const int py = ty * HGS_TILE + (wave >> 1) * 8 + (lane >> 3);
@@ -566,11 +599,12 @@ __global__ __launch_bounds__(HGS_BLOCK) __attribute__((amdgpu_waves_per_eu(HGS_B
   const size_t pix = (size_t)py * W + px;
 
   // first batch (the END of the list: the walk is back to front) is in flight while the per-pixel state is set up
-  const float4* src = packed + (size_t)range.x * REC4;
+  const uint32_t sq = threadIdx.x / REC4;                // this thread stages quarter sr of entry sq of every batch
+  const int sr = (int)(threadIdx.x - sq * REC4);
   float4 stage = make_float4(0.f, 0.f, 0.f, 0.f);
   {
     const int lo = max(seg_lo, top - BWD_BATCH), cnt = top - lo;
-    if (threadIdx.x < cnt * REC4) stage = src[(size_t)lo * REC4 + threadIdx.x];
+    if (threadIdx.x < cnt * REC4) stage = stage_quarter<C>(bn, it.lazy, range.x + (uint32_t)lo + sq, sr, tx, ty);
   }
 
   const float T_final = inside ? im.final_T[pix] : 0.f;
@@ -621,7 +655,7 @@ __global__ __launch_bounds__(HGS_BLOCK) __attribute__((amdgpu_waves_per_eu(HGS_B
     const int cnt = hi - lo;
     if (lo > seg_lo) {  // next batch's records: in flight during this batch's math
       const int nlo = max(seg_lo, lo - BWD_BATCH), ncnt = lo - nlo;
-      if (threadIdx.x < ncnt * REC4) stage = src[(size_t)nlo * REC4 + threadIdx.x];
+      if (threadIdx.x < ncnt * REC4) stage = stage_quarter<C>(bn, it.lazy, range.x + (uint32_t)nlo + sq, sr, tx, ty);
     }
     const float* rf = (const float*)&recs[cur][0];
     const uint32_t mk = lane < cnt ? __float_as_uint(rf[lane * 4 * REC4 + 7 + C]) : 0u;

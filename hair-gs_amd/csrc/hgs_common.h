@@ -55,14 +55,32 @@ struct HgsBinning {
   uint32_t* seg_last;   // last contributing list position + 1 inside the segment (0: none)
   float* seg_C;         // [C][256] colour added by the segment; after the tile's finalisation: by it and all behind it
   uint32_t seg_cap;     // segments the arrays hold
+  // Lazy records (round 6).  lazy != 0: the sort kernel orders keys only, and the blend kernels stage an entry's record from its
+  // Gaussian's 64-byte template (grec = HgsGeom::grec of the pass) and the sorted key -- quadrant mask = the key's low bits,
+  // gradient-row slot = a function of the template's rectangle and the tile.  lazy == 0: the sort kernel gathers the template and
+  // writes a 48- / 64-byte record per instance into `packed`, which the blend kernels stream.  Both set by the host side next to
+  // every hgs_binning_carve of a launch; the pass's choice is parked in status word HGS_ST_LAZY for its backward.
+  const float4* grec;
+  int lazy;
 };
+// Which passes are lazy (hgs_set_lazy_records(-1), the default): those whose capacity (or exact instance count) is at least this
+// many entries per tile.  Two thirds of a dense Stage-I frame's records were written and never read (they lie behind their tile's
+// last contributor), and a long list hides the template gather behind the previous batch's arithmetic: config 4 +2.0 %,
+// stage1_1080p +1.9 %, stage3_merged +1.3 %, config 5 +0.9 %, config 3 even.  A fresh strand model's tiles hold ~20 entries and
+// their blend workgroups live for a few microseconds: the gather is one more dependent round trip in them (north_star, everything
+// lazy: sort 12.0 -> 9.7 us, blend forward 24.4 -> 26.8, backward 48.2 -> 49.3: -0.7 %), so they keep the packed records.
+// (Also measured: records packed for every list's first 64 entries only -- slower than either form at north_star.)
+#ifndef HGS_LAZY_MIN_MEAN_LIST
+#define HGS_LAZY_MIN_MEAN_LIST 64
+#endif
 
 // status words of the image buffer (HGS_IMG_STATUS)
 // ([4..7] are read as ONE 16-byte scalar load by every blend workgroup)
 enum { HGS_ST_R = 0, HGS_ST_OVERFLOW = 1, HGS_ST_SCANPTR_LO = 2, HGS_ST_SCANPTR_HI = 3, HGS_ST_SORT_ITEMS = 4,
        HGS_ST_SPLIT_ITEMS = 5, HGS_ST_SEG_LEN = 6, HGS_ST_WORK_ITEMS = 7, HGS_ST_TIMEOUT = 8, HGS_ST_SCAN_DONE = 9,
        HGS_ST_WL_TICKET = 10, HGS_ST_WL_NCAND = 11, HGS_ST_WL_NSEG = 12,    // exchange of the sort kernel's work-list builders
-       HGS_ST_ALLOC = 13 };                                                   // allocation cursor of the tiles' segments (capacity mode, scatter_kernel)
+       HGS_ST_ALLOC = 13,                                                     // allocation cursor of the tiles' segments (capacity mode, scatter_kernel)
+       HGS_ST_LAZY = 14 };                                                    // != 0: this pass's records are built by the blend kernels (HgsBinning::lazy; written by the sort kernel)
 #ifndef HGS_SCAN_WGS
 #define HGS_SCAN_WGS 32  // workgroups of the scatter kernel that allocate the tiles' segments: one tile per thread up to HGS_FUSED_SCAN_MAX_T
                          // (round 5; rounds 3-4: four workgroups sharing an exclusive scan in tile order)

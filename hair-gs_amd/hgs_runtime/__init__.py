@@ -87,6 +87,7 @@ SIGNATURES = {
     "hgs_set_tile_cull": (ci, [ci]),
     "hgs_set_segment_policy": (ci, [ci, ci, ci]),
     "hgs_set_row_reduce": (ci, [ci]),
+    "hgs_set_lazy_records": (ci, [ci]),
     "hgs_debug_set_wg_trace": (ci, [vp, vp]),
     "hgs_prof_enable": (ci, [ci]),
     "hgs_prof_bracket_overhead_ms": (C.c_double, []),

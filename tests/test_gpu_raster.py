@@ -442,7 +442,10 @@ def test_capacity_overflow_gives_zero_gradients_not_garbage(monkeypatch):
     from diff_gaussian_rasterization import _C
     from tests import gpu_util as G
     monkeypatch.setenv("HGS_POISON_SCRATCH", "1")
-    for name in ("strands", "dense_long_lists"):
+    # (both forms of the blend kernels' records: a lazy pass builds a record THROUGH its sorted key -- the keys of a void pass may
+    # never have been written, so its lists must read as empty; round 6's first build followed a stray id out of the buffer)
+    for name, lazy in (("strands", -1), ("dense_long_lists", -1), ("strands", 1), ("dense_long_lists", 1), ("dense_long_lists", 0)):
+        G.rt.lib().hgs_set_lazy_records(lazy)
         s = _scene(name)
         full = G.run_forward(s)
         dpix = np.random.default_rng(4).normal(size=(3, s["H"], s["W"])).astype(np.float32)
@@ -463,6 +466,7 @@ def test_capacity_overflow_gives_zero_gradients_not_garbage(monkeypatch):
         # and the same scene right after, with enough capacity, is unaffected
         g2 = G.run_backward(s, full, dpix)
         assert any((v != 0).any() for v in g2.values())
+    G.rt.lib().hgs_set_lazy_records(-1)
 
 
 def test_empty_inputs():
@@ -1040,3 +1044,47 @@ def test_row_run_counting_changes_nothing(name):
             _C.set_async(False)
     finally:
         _C.set_row_runs(was)
+
+
+@pytest.mark.parametrize("name", ["strands", "dense_long_lists", "medium_lists", "many_tiles", "one_huge_tile", "sh3_bg", "tiny_image",
+                                  "strands_precomp", "c2_full_size", "c3_full_size"])
+def test_lazy_records_change_nothing(name):
+    """hgs_set_lazy_records (include/hgs.h): the blend kernels building an entry's record from its Gaussian's template through the
+    sorted key, against streaming the records the sort kernel packs -- image, contributor counts, final transmittance and every
+    gradient of the 3-channel pass bit for bit, in the blocking and (the 7-channel pass too: tests/test_gpu_train.py) the capacity
+    mode; split lists (dense_long_lists, one_huge_tile, C2 at size), 17 545 tiles, precomputed colours."""
+    from diff_gaussian_rasterization import _C
+    from tests import gpu_util as G
+    L = G.rt.lib()
+    s = _workload_scene(name[:2]) if name.endswith("_full_size") else _scene(name)
+    dpix = np.random.default_rng(11).normal(size=(3, s["H"], s["W"])).astype(np.float32)
+    runs = {}
+    try:
+        for lazy in (0, 1):
+            L.hgs_set_lazy_records(lazy)
+            fw = G.run_forward(s)
+            got = G.intermediates(s, fw)
+            assert got["status"][14] == lazy and got["status"][1] == 0
+            runs[lazy] = (got, G.run_backward(s, fw, dpix))
+        for k in ("out_color", "final_T"):
+            np.testing.assert_array_equal(runs[0][0][k].view(np.uint32), runs[1][0][k].view(np.uint32), err_msg=k)
+        for k in ("n_contrib", "ranges", "point_list", "keys_sorted", "tile_maxc"):
+            np.testing.assert_array_equal(runs[0][0][k], runs[1][0][k], err_msg=k)
+        for k in runs[0][1]:
+            np.testing.assert_array_equal(runs[0][1][k].view(np.uint32), runs[1][1][k].view(np.uint32), err_msg=k)
+        if runs[0][0]["num_rendered"] == 0:
+            return
+        _C._state["cap"] = 0
+        _C.set_async(True)
+        G.run_forward(s)
+        for lazy in (0, 1):
+            L.hgs_set_lazy_records(lazy)
+            fw = G.run_forward(s)
+            assert _C.check_async() == [runs[0][0]["num_rendered"]]
+            np.testing.assert_array_equal(fw["color"].cpu().numpy().view(np.uint32), runs[0][0]["out_color"].view(np.uint32))
+            g = G.run_backward(s, fw, dpix)
+            for k in g:
+                np.testing.assert_array_equal(g[k].view(np.uint32), runs[0][1][k].view(np.uint32), err_msg=k)
+    finally:
+        _C.set_async(False)
+        L.hgs_set_lazy_records(-1)

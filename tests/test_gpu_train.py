@@ -1877,3 +1877,53 @@ def test_device_strand_walk_equals_the_host_walk(seed):
     bad = np.concatenate([pairs, np.array([[pairs[0, 0], n_ep - 1], [pairs[0, 0], n_ep - 2]], np.int64)])
     assert walk_chains_device(torch.as_tensor(bad, device="cuda"), n_ep, end_distance_t) is None
     assert walk_chains_device(torch.zeros((0, 2), dtype=torch.int64, device="cuda"), n_ep, end_distance_t)[0].tolist() == [0]
+
+
+@pytest.mark.parametrize("kind", ["cloud", "strands"])
+def test_lazy_records_in_the_fused_iterations(kind):
+    """hgs_set_lazy_records in the single-pass 7-channel iteration (capacity mode, the one-launch parameter + preprocess kernels, the
+    row sums by row_reduce_kernel for the cloud): records built by the blend kernels against records packed by the sort kernel --
+    loss terms, image planes, radii and every parameter gradient bit for bit over six iterations."""
+    import hgs_runtime as rt
+    from arguments import OptimizationParams
+    from diff_gaussian_rasterization import _C as raster
+    from hgs_runtime.strand_step import FusedCloudStep, FusedStrandStep, ViewTable
+    from synthetic import attach_targets, build_workload, cameras_extent, make_cameras, make_cloud_model
+    if kind == "cloud":
+        cams = make_cameras(4, 200, 120, device="cuda")
+        model = make_cloud_model(3000, device="cuda", spatial_lr_scale=cameras_extent(cams))
+        with torch.no_grad():
+            model._scaling.add_(1.3)
+        attach_targets(cams, model)
+    else:
+        model, cams, _ = build_workload("tiny", device="cuda", with_targets=True)
+    opt = OptimizationParams()
+    model.training_setup(opt)
+    params = ([model._xyz, model._scaling, model._rotation, model._opacity, model._mask, model._features_dc] if kind == "cloud"
+              else [model._endpoints, model._width, model._opacity, model._mask, model._features_dc])
+    out = {}
+    try:
+        raster._state["cap"] = 0
+        raster.set_async(True, slack=2.0)
+        for lazy in (0, 1):
+            rt.lib().hgs_set_lazy_records(lazy)
+            views = ViewTable(cams)
+            step = (FusedCloudStep if kind == "cloud" else FusedStrandStep)(model, views, opt, torch.zeros(3, device="cuda"))
+            seen = []
+            for v in (0, 2, 1, 3, 0, 2):
+                for p in params:
+                    p.grad = None
+                views.prologue(v, ride=True)
+                loss, terms = step.loss()
+                step.backward(loss)
+                raster.check_async()
+                seen.append([loss.detach().clone(), terms[:14].clone(), step.last["planes"].clone(), step.last["radii"].clone()]
+                            + [p.grad.clone() for p in params])
+            out[lazy] = seen
+    finally:
+        raster.set_async(False)
+        rt.lib().hgs_set_lazy_records(-1)
+    for a, b in zip(out[0], out[1]):
+        for x, y in zip(a, b):
+            assert torch.equal(x, y)
+        assert bool(a[4].abs().sum() > 0)
