@@ -212,6 +212,8 @@ def lib():
             if getattr(L, fn)() != C.sizeof(st):
                 raise HgsError(f"{LIB_PATH}: {fn}() = {getattr(L, fn)()} but the binding's struct has {C.sizeof(st)} bytes: "
                                "rebuild with hgs_runtime.build()")
+        if os.environ.get("HGS_LAZY_RECORDS") in ("0", "1"):      # A/B aid: pins include/hgs.h hgs_set_lazy_records for the process
+            L.hgs_set_lazy_records(int(os.environ["HGS_LAZY_RECORDS"]))
         _lib = L
     return _lib
 

@@ -566,7 +566,7 @@ int hgs_set_row_reduce(int mode);
 /* How the blend kernels of the following forward passes (and their backwards) get the per-entry records: 0 = the sort kernel writes a
  * 48- / 64-byte record per instance which they stream (rounds 1-5), 1 = the sort kernel orders keys only and they build an entry's
  * record from its Gaussian's template through the sorted key (nothing is written for the entries behind a tile's last contributor:
- * two thirds of a dense Stage-I frame's), -1 (default) = 1 for passes with at least 64 entries per tile by capacity / exact count.
+ * two thirds of a dense Stage-I frame's), -1 (default) = 1 for passes with at least 128 entries per tile by capacity / exact count.
  * Images and gradients are the same bits either way.  Process-wide; returns the previous setting. */
 int hgs_set_lazy_records(int mode);
 int hgs_debug_set_wg_trace(void* device_buf_fwd, void* device_buf_bwd);
