@@ -65,8 +65,8 @@ struct HgsBinning {
 };
 // Which passes are lazy (hgs_set_lazy_records(-1), the default): those whose capacity (or exact instance count) is at least this
 // many entries per tile (at 64 the whole loop of tools/soak.py, whose model passes through 50-200, was 1 % slower than packed; at
-// 128 the strand workloads below config 5's size stay packed).  Two thirds of a dense Stage-I frame's records were written and never read (they lie behind their tile's
-// last contributor), and a long list hides the template gather behind the previous batch's arithmetic: config 4 +2.0 %,
+// 128 the strand workloads below config 5's size stay packed).  Two thirds of a dense Stage-I frame's records were written and
+// never read (they lie behind their tile's last contributor), and a long list hides the template gather behind the previous batch's arithmetic: config 4 +2.0 %,
 // stage1_1080p +1.9 %, stage3_merged +1.3 %, config 5 +0.9 %, config 3 even.  A fresh strand model's tiles hold ~20 entries and
 // their blend workgroups live for a few microseconds: the gather is one more dependent round trip in them (north_star, everything
 // lazy: sort 12.0 -> 9.7 us, blend forward 24.4 -> 26.8, backward 48.2 -> 49.3: -0.7 %), so they keep the packed records.
